@@ -1,0 +1,106 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  PARITY UNPINNED.
+// C entry points (ctypes) over the CPU restatement.
+#include "orb_extractor_oracle.h"
+
+using namespace oracle;
+
+extern "C" {
+
+void* oo_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+    return new OrbExtractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+}
+void oo_orb_destroy(void* h) { delete (OrbExtractor*)h; }
+void oo_orb_set_blur_sse2(void* h, int on) { ((OrbExtractor*)h)->blur_sse2_rounding = on != 0; }
+
+int oo_orb_extract(void* h, const uint8_t* img, int w, int hgt, int stride, KeyPoint* kps, uint8_t* desc,
+                   int cap, int* n_out) {
+    OrbExtractor* e = (OrbExtractor*)h;
+    std::vector<KeyPoint> k;
+    std::vector<uint8_t> d;
+    int rc = e->extract(img, w, hgt, stride, k, d);
+    if (rc) { *n_out = 0; return rc; }
+    *n_out = (int)k.size();
+    if ((int)k.size() > cap) return -2;
+    if (!k.empty()) {
+        memcpy(kps, k.data(), k.size() * sizeof(KeyPoint));
+        memcpy(desc, d.data(), d.size());
+    }
+    return 0;
+}
+
+void oo_orb_tables(void* h, float* scale, float* inv, float* sigma2, float* invsigma2, int* nfeat, int* umax) {
+    OrbExtractor* e = (OrbExtractor*)h;
+    for (int i = 0; i < e->nlevels; i++) {
+        scale[i] = e->mvScaleFactor[i];
+        inv[i] = e->mvInvScaleFactor[i];
+        sigma2[i] = e->mvLevelSigma2[i];
+        invsigma2[i] = e->mvInvLevelSigma2[i];
+        nfeat[i] = e->mnFeaturesPerLevel[i];
+    }
+    for (int i = 0; i < 16; i++) umax[i] = e->umax[i];
+}
+
+int oo_orb_level_size(void* h, int level, int* w, int* hgt) {
+    OrbExtractor* e = (OrbExtractor*)h;
+    *w = e->mvImagePyramid[level].w;
+    *hgt = e->mvImagePyramid[level].h;
+    return 0;
+}
+int oo_orb_get_level(void* h, int level, uint8_t* out) {
+    const Image& im = ((OrbExtractor*)h)->mvImagePyramid[level];
+    memcpy(out, im.d.data(), im.d.size());
+    return 0;
+}
+int oo_orb_get_blurred(void* h, int level, uint8_t* out) {
+    const Image& im = ((OrbExtractor*)h)->blurred[level];
+    if (im.d.empty()) return -1;
+    memcpy(out, im.d.data(), im.d.size());
+    return 0;
+}
+int oo_orb_num_candidates(void* h, int level) { return (int)((OrbExtractor*)h)->candidates[level].size(); }
+int oo_orb_get_candidates(void* h, int level, KeyPoint* out) {
+    auto& v = ((OrbExtractor*)h)->candidates[level];
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+int oo_orb_num_level_keys(void* h, int level) { return (int)((OrbExtractor*)h)->levelKeys[level].size(); }
+int oo_orb_get_level_keys(void* h, int level, KeyPoint* out) {
+    auto& v = ((OrbExtractor*)h)->levelKeys[level];
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+// run only the quad-tree on caller-supplied candidates
+int oo_distribute_octree(void* h, const KeyPoint* cand, int n, int minX, int maxX, int minY, int maxY, int N,
+                         KeyPoint* out, int cap) {
+    std::vector<KeyPoint> v(cand, cand + n);
+    auto r = ((OrbExtractor*)h)->DistributeOctTree(v, minX, maxX, minY, maxY, N);
+    if ((int)r.size() > cap) return -2;
+    if (!r.empty()) memcpy(out, r.data(), r.size() * sizeof(KeyPoint));
+    return (int)r.size();
+}
+
+// primitives
+int oo_fast_9_16(const uint8_t* roi, int stride, int cols, int rows, int threshold, int nms, KeyPoint* out, int cap) {
+    std::vector<KeyPoint> v;
+    fast_9_16(roi, stride, cols, rows, threshold, nms != 0, v);
+    if ((int)v.size() > cap) return -2;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * sizeof(KeyPoint));
+    return (int)v.size();
+}
+int oo_fast_corner_score(const uint8_t* p, int stride, int threshold) { return fast_corner_score(p, stride, threshold); }
+void oo_resize_linear_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+    Image s(sw, sh), d(dw, dh);
+    memcpy(s.d.data(), src, s.d.size());
+    resize_linear_u8(s, d);
+    memcpy(dst, d.d.data(), d.d.size());
+}
+void oo_gaussian_blur(const uint8_t* src, int w, int h, uint8_t* dst, int sse2) {
+    Image s(w, h), d;
+    memcpy(s.d.data(), src, s.d.size());
+    gaussian_blur_7x7_s2(s, d, sse2 != 0);
+    memcpy(dst, d.d.data(), d.d.size());
+}
+float oo_fast_atan2(float y, float x) { return fastAtan2(y, x); }
+const int8_t* oo_brief_pattern() { return brief_pattern(); }
+
+}  // extern "C"

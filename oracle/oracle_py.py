@@ -1,0 +1,149 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/_build/liboslam_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboslam_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.oo_orb_create.restype = C.c_void_p
+        _lib.oo_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        _lib.oo_orb_destroy.argtypes = [C.c_void_p]
+        _lib.oo_fast_atan2.restype = C.c_float
+        _lib.oo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _lib.oo_brief_pattern.restype = C.POINTER(C.c_int8)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrbExtractor:
+    """Oracle mirror of ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:45-110)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = C.c_void_p(self.L.oo_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.oo_orb_destroy(self.h)
+            self.h = None
+
+    def set_blur_sse2(self, on):
+        self.L.oo_orb_set_blur_sse2(self.h, int(on))
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.oo_orb_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, nfeatures_per_level=nf, umax=um)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape
+        cap = self.nfeatures * 4 + 1024
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        rc = self.L.oo_orb_extract(self.h, _p(img), w, h, w, _p(kps), _p(desc), cap, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("oracle extract rc=%d" % rc)
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        self.L.oo_orb_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        self.L.oo_orb_get_level(self.h, level, _p(out))
+        return out
+
+    def blurred(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        rc = self.L.oo_orb_get_blurred(self.h, level, _p(out))
+        return out if rc == 0 else None
+
+    def candidates(self, level):
+        n = self.L.oo_orb_num_candidates(self.h, level)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.oo_orb_get_candidates(self.h, level, _p(out))
+        return out[:n]
+
+    def level_keys(self, level):
+        n = self.L.oo_orb_num_level_keys(self.h, level)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.oo_orb_get_level_keys(self.h, level, _p(out))
+        return out[:n]
+
+    def distribute_octree(self, cand, minX, maxX, minY, maxY, N):
+        cand = np.ascontiguousarray(cand, dtype=KP_DTYPE)
+        out = np.zeros(len(cand) + 16, KP_DTYPE)
+        n = self.L.oo_distribute_octree(self.h, _p(cand), len(cand), minX, maxX, minY, maxY, N, _p(out), len(out))
+        assert n >= 0
+        return out[:n]
+
+
+def fast_9_16(roi, threshold, nms=True):
+    roi = np.ascontiguousarray(roi, dtype=np.uint8)
+    rows, cols = roi.shape
+    out = np.zeros(rows * cols + 1, KP_DTYPE)
+    n = lib().oo_fast_9_16(_p(roi), cols, cols, rows, threshold, int(nms), _p(out), len(out))
+    assert n >= 0
+    return out[:n]
+
+
+def resize_linear_u8(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().oo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], _p(dst), dw, dh)
+    return dst
+
+
+def gaussian_blur(src, sse2=True):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    lib().oo_gaussian_blur(_p(src), src.shape[1], src.shape[0], _p(dst), int(sse2))
+    return dst
+
+
+def fast_atan2(y, x):
+    return float(lib().oo_fast_atan2(float(y), float(x)))
+
+
+def brief_pattern():
+    p = lib().oo_brief_pattern()
+    return np.ctypeslib.as_array(p, shape=(1024,)).copy()
