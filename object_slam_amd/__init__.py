@@ -1,0 +1,7 @@
+"""MI355X-native (gfx950) front-end + local-BA hot path of yangliu9527/Object_SLAM.
+
+Thin Python view of the C ABI in include/oslam_hip.h (the product is the HIP library;
+Python is harness).  Class and method names mirror the reference's C++ API.
+"""
+from ._lib import KP_DTYPE, OslamError  # noqa: F401
+from .extractor import ORBextractor  # noqa: F401

@@ -1,0 +1,501 @@
+// Host side of the gfx950 ORB extractor: table construction (reference arithmetic of
+// src/ORBextractor.cc:410-470 and the OpenCV-3.2 resize / Gaussian coefficient rules), HBM arena
+// layout, kernel launches and the C ABI of include/oslam_hip.h.
+#include "orb_kernels.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+namespace oslam {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int cv_round(float v) { return (int)lrintf(v); }     // cvRound: half-to-even
+static inline int cv_round(double v) { return (int)lrint(v); }
+static inline short sat_short(float v) {
+    int i = cv_round(v);
+    return (short)std::min(std::max(i, -32768), 32767);
+}
+
+}  // namespace oslam
+
+using namespace oslam;
+
+struct oslam_orb {
+    int device = 0;
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
+    double scaleFactor = 0;
+    int width = 0, height = 0, max_batch = 0;
+    int blur_sse2 = 1;
+    OrbParams P;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> quota;
+
+    // device
+    OrbParams* dP = nullptr;
+    int2* d_rtab = nullptr;
+    uint8_t* d_root_of_x = nullptr;
+    short* d_root_x = nullptr;
+    uint8_t* d_stage = nullptr;   // [B][H][pitch0] staging for host images
+    int stage_pitch = 0;
+    uint8_t* d_pyr = nullptr;
+    long long pyr_stride = 0;
+    uint8_t* d_blur = nullptr;
+    long long blur_stride = 0;
+    int* d_cell_count = nullptr;
+    uint32_t* d_cand = nullptr;
+    uint32_t* d_ent_g = nullptr;
+    uint16_t* d_knode_g = nullptr;
+    uint32_t* d_sel = nullptr;
+    int* d_sel_count = nullptr;
+    oslam_keypoint_t* d_out_kp = nullptr;
+    uint8_t* d_out_desc = nullptr;
+    int* d_out_count = nullptr;
+    int* d_status = nullptr;
+    size_t oct_lds = 0;
+
+    // last batch
+    OrbCtx ctx;
+    int last_batch = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+static void build_resize_tab(int ssize, int dsize, bool is_x, std::vector<int2>& tab) {
+    // OpenCV 3.2 resize(): INTER_LINEAR coefficient tables (imgwarp.cpp)
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (is_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        const float c0 = 1.f - f, c1 = f;
+        const int a0 = (unsigned short)sat_short(c0 * 2048), a1 = (unsigned short)sat_short(c1 * 2048);
+        tab.push_back(make_int2(s, a0 | (a1 << 16)));
+    }
+}
+
+extern "C" {
+
+const char* oslam_last_error(void) { return g_err; }
+
+int oslam_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void oslam_orb_destroy(oslam_orb_t* h) {
+    if (!h) return;
+    void* ptrs[] = {h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
+                    h->d_cell_count, h->d_cand, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
+                    h->d_out_count, h->d_status};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int nlevels, int iniTh, int minTh,
+                     int width, int height, int max_batch, int device) {
+    if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
+    *out = nullptr;
+    if (nfeatures <= 0 || nlevels < 1 || nlevels > OSLAM_MAX_LEVELS || !(scaleFactor_ > 1.0f) || width <= 0 ||
+        height <= 0 || max_batch < 1 || iniTh < 1 || minTh < 1 || iniTh > 255 || minTh > 255) {
+        set_error("oslam_orb_create: invalid argument");
+        return OSLAM_E_INVALID;
+    }
+    int ndev = oslam_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible: the gfx950 extractor has no CPU fallback"); return OSLAM_E_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(device));
+
+    oslam_orb* h = new oslam_orb();
+    h->device = device; h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = iniTh; h->minTh = minTh;
+    h->scaleFactor = scaleFactor_;   // float -> double member, reference include/ORBextractor.h:96
+    h->width = width; h->height = height; h->max_batch = max_batch;
+    const double scaleFactor = h->scaleFactor;
+
+    // scale tables, reference src/ORBextractor.cc:415-432
+    h->scale.resize(nlevels); h->sigma2.resize(nlevels); h->invScale.resize(nlevels); h->invSigma2.resize(nlevels);
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < nlevels; i++) {
+        h->invScale[i] = 1.0f / h->scale[i];
+        h->invSigma2[i] = 1.0f / h->sigma2[i];
+    }
+    // per-level quotas, :436-446
+    h->quota.resize(nlevels);
+    {
+        float factor = (float)(1.0f / scaleFactor);
+        float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int l = 0; l < nlevels - 1; l++) {
+            h->quota[l] = cv_round(nDesired);
+            sum += h->quota[l];
+            nDesired *= factor;
+        }
+        h->quota[nlevels - 1] = std::max(nfeatures - sum, 0);
+    }
+
+    OrbParams& P = h->P;
+    memset(&P, 0, sizeof(P));
+    P.nlevels = nlevels; P.iniTh = iniTh; P.minTh = minTh;
+    // umax, :454-469
+    {
+        int v, v0, vmax = (int)std::floor(kHalfPatch * sqrt(2.f) / 2 + 1);
+        int vmin = (int)std::ceil(kHalfPatch * sqrt(2.f) / 2);
+        const double hp2 = kHalfPatch * kHalfPatch;
+        for (v = 0; v <= vmax; ++v) P.umax[v] = cv_round(sqrt(hp2 - v * v));
+        for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+            while (P.umax[v0] == P.umax[v0 + 1]) ++v0;
+            P.umax[v] = v0;
+            ++v0;
+        }
+    }
+    // Gaussian 7 taps sigma 2 -> 8-bit fixed point (OpenCV 3.2 getGaussianKernel + convertTo(CV_32S, 256))
+    {
+        float cf[7];
+        double sum = 0;
+        for (int i = 0; i < 7; i++) {
+            double x = i - 3.0;
+            cf[i] = (float)std::exp(-0.5 / 4.0 * x * x);
+            sum += cf[i];
+        }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) {
+            cf[i] = (float)(cf[i] * sum);
+            P.gk[i] = cv_round(cf[i] * 256.f);
+        }
+    }
+
+    std::vector<int2> rtab;
+    std::vector<uint8_t> root_of_x((size_t)nlevels * 4096, 0);
+    std::vector<short> root_x;
+    long long pyr_off = 0, blur_off = 0;
+    int cell_base = 0, cand_base = 0, sel_base = 0, node_cap = 0;
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& g = P.lv[l];
+        const float sc = h->invScale[l];
+        g.w = cv_round((float)width * sc);     // :1112
+        g.h = cv_round((float)height * sc);
+        g.pitch = (int)align_up(g.w, 64);
+        g.scale = h->scale[l];
+        g.kp_size = (float)(int)(kPatchSize * h->scale[l]);   // :837
+        g.region_w = g.w - 2 * kRegionBorder;
+        g.region_h = g.h - 2 * kRegionBorder;
+        if (g.region_w < 30 || g.region_h < 30 || g.w >= 4096 || g.h >= 4096) {
+            set_error("level %d is %dx%d: the FAST cell grid needs 62 <= dim < 4096 (reference divides by width/30)", l, g.w, g.h);
+            delete h;
+            return OSLAM_E_INVALID;
+        }
+        const float W = 30;
+        const float fw = (float)g.region_w, fh = (float)g.region_h;
+        g.nCols = (int)(fw / W);
+        g.nRows = (int)(fh / W);
+        g.wCell = (int)std::ceil(fw / g.nCols);
+        g.hCell = (int)std::ceil(fh / g.nRows);
+        if (g.wCell > kMaxCell || g.hCell > kMaxCell) { set_error("cell too large"); delete h; return OSLAM_E_INVALID; }
+        g.cell_base = cell_base;
+        g.cell_cap = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+        g.cand_base = cand_base;
+        cell_base += g.nCols * g.nRows;
+        cand_base += g.nCols * g.nRows * g.cell_cap;
+        if (g.nCols * g.nRows > kCandCap / 2) { set_error("too many FAST cells at level %d", l); delete h; return OSLAM_E_INVALID; }
+        g.quota = h->quota[l];
+        // quad-tree roots, :543-563
+        g.nIni = (int)std::round((float)g.region_w / g.region_h);
+        if (g.nIni < 1 || g.nIni > kMaxRoots) {
+            set_error("level %d aspect %dx%d gives %d quad-tree roots (supported 1..%d)", l, g.region_w, g.region_h, g.nIni, kMaxRoots);
+            delete h;
+            return OSLAM_E_INVALID;
+        }
+        const float hX = (float)g.region_w / g.nIni;
+        g.root_off = (int)root_x.size();
+        for (int i = 0; i <= g.nIni; i++) root_x.push_back((short)(int)(hX * (float)i));
+        for (int x = 0; x < g.region_w && x < 4096; x++) {
+            int r = (int)((float)x / hX);   // vpIniNodes[kp.pt.x/hX], :569
+            root_of_x[(size_t)l * 4096 + x] = (uint8_t)std::min(r, g.nIni - 1);
+        }
+        g.sel_cap = std::max(g.quota + 3, 4 * g.nIni) + 1;
+        g.sel_base = sel_base;
+        sel_base += g.sel_cap;
+        node_cap = std::max(node_cap, g.sel_cap);
+        g.img_off = blur_off;   // same offsets used in both arenas (level 0 slot unused in the pyramid arena)
+        blur_off += (long long)g.pitch * g.h;
+        if (l > 0) {
+            g.xtab_off = (int)rtab.size();
+            build_resize_tab(P.lv[l - 1].w, g.w, true, rtab);
+            g.ytab_off = (int)rtab.size();
+            build_resize_tab(P.lv[l - 1].h, g.h, false, rtab);
+        }
+    }
+    (void)pyr_off;
+    P.total_cells = cell_base;
+    P.cand_per_image = cand_base;
+    P.sel_per_image = sel_base;
+    P.out_cap = sel_base;
+    P.node_cap = node_cap + 8;
+    h->pyr_stride = blur_off;
+    h->blur_stride = blur_off;
+    {
+        const size_t NC = P.node_cap;
+        h->oct_lds = (size_t)kCandCap * 6 + (4 * NC + 4 * NC + NC * 3 + 2 * (NC + 1) + NC * 5 + 32) * 4 + 8 * NC * 2 + 64;
+        if (h->oct_lds > 160 * 1024 - 512) {
+            set_error("nfeatures=%d needs %zu B of LDS for the quad-tree kernel (limit 160 KiB)", nfeatures, h->oct_lds);
+            delete h;
+            return OSLAM_E_INVALID;
+        }
+    }
+
+    const size_t B = max_batch;
+#define ALLOC(ptr, bytes)                                                         \
+    do {                                                                          \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                       \
+        if (e_ != hipSuccess) {                                                   \
+            set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+            oslam_orb_destroy(h);                                                 \
+            return OSLAM_E_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+    ALLOC(h->dP, sizeof(OrbParams));
+    ALLOC(h->d_rtab, std::max<size_t>(rtab.size(), 1) * sizeof(int2));
+    ALLOC(h->d_root_of_x, root_of_x.size());
+    ALLOC(h->d_root_x, root_x.size() * sizeof(short));
+    h->stage_pitch = (int)align_up(width, 64);
+    ALLOC(h->d_stage, B * (size_t)h->stage_pitch * height);
+    ALLOC(h->d_pyr, B * (size_t)h->pyr_stride);
+    ALLOC(h->d_blur, B * (size_t)h->blur_stride);
+    ALLOC(h->d_cell_count, B * (size_t)P.total_cells * sizeof(int));
+    ALLOC(h->d_cand, B * (size_t)P.cand_per_image * sizeof(uint32_t));
+    ALLOC(h->d_ent_g, B * (size_t)P.cand_per_image * sizeof(uint32_t));
+    ALLOC(h->d_knode_g, B * (size_t)P.cand_per_image * sizeof(uint16_t));
+    ALLOC(h->d_sel, B * (size_t)P.sel_per_image * sizeof(uint32_t));
+    ALLOC(h->d_sel_count, B * (size_t)nlevels * sizeof(int));
+    ALLOC(h->d_out_kp, B * (size_t)P.out_cap * sizeof(oslam_keypoint_t));
+    ALLOC(h->d_out_desc, B * (size_t)P.out_cap * 32);
+    ALLOC(h->d_out_count, B * sizeof(int));
+    ALLOC(h->d_status, sizeof(int));
+#undef ALLOC
+    OSLAM_HIP_CHECK(hipMemcpy(h->dP, &P, sizeof(P), hipMemcpyHostToDevice));
+    if (!rtab.empty()) OSLAM_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(int2), hipMemcpyHostToDevice));
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_root_of_x, root_of_x.data(), root_of_x.size(), hipMemcpyHostToDevice));
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_root_x, root_x.data(), root_x.size() * sizeof(short), hipMemcpyHostToDevice));
+    OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
+    OSLAM_HIP_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    *out = h;
+    return OSLAM_OK;
+}
+
+int oslam_orb_get_scale_tables(const oslam_orb_t* h, float* sf, float* isf, float* s2, float* is2, int* nf) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    for (int i = 0; i < h->nlevels; i++) {
+        if (sf) sf[i] = h->scale[i];
+        if (isf) isf[i] = h->invScale[i];
+        if (s2) s2[i] = h->sigma2[i];
+        if (is2) is2[i] = h->invSigma2[i];
+        if (nf) nf[i] = h->quota[i];
+    }
+    return OSLAM_OK;
+}
+
+int oslam_orb_max_keypoints(const oslam_orb_t* h) { return h ? h->P.out_cap : OSLAM_E_INVALID; }
+
+int oslam_orb_set_blur_rounding(oslam_orb_t* h, int sse2) {
+    if (!h) return OSLAM_E_INVALID;
+    h->blur_sse2 = sse2 != 0;
+    return OSLAM_OK;
+}
+
+static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stride, size_t image_stride, hipStream_t st) {
+    const OrbParams& P = h->P;
+    OrbCtx c;
+    c.P = h->dP;
+    c.img0 = d_gray; c.img0_pitch = stride; c.img0_stride = (long long)image_stride;
+    c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
+    c.blur = h->d_blur; c.blur_stride = h->blur_stride;
+    c.rtab = h->d_rtab; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
+    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
+    c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status;
+    h->ctx = c; h->last_batch = batch; h->last_stream = st;
+
+    for (int l = 1; l < P.nlevels; l++) {
+        const LevelGeom& g = P.lv[l];
+        dim3 grid(div_up(g.w, 256), div_up(g.h, 4), batch);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
+    }
+    hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
+    for (int l = 0; l < P.nlevels; l++) {
+        const LevelGeom& g = P.lv[l];
+        dim3 grid(div_up(g.w, kBlurTW), div_up(g.h, kBlurTH), batch);
+        hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, c, l, h->blur_sse2);
+    }
+    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
+    hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4), batch), dim3(256), 0, st, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_orb_extract_batch_device(oslam_orb_t* h, const uint8_t* d_gray, int batch, int stride, size_t image_stride,
+                                   void* stream) {
+    if (!h || !d_gray) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (batch < 1 || batch > h->max_batch) { set_error("batch %d outside [1,%d]", batch, h->max_batch); return OSLAM_E_INVALID; }
+    if (stride < h->width || (batch > 1 && image_stride < (size_t)stride * h->height)) { set_error("bad strides"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    return launch_batch(h, d_gray, batch, stride, image_stride, (hipStream_t)stream);
+}
+
+int oslam_orb_results_device(const oslam_orb_t* h, const oslam_keypoint_t** kp, const uint8_t** desc, const int32_t** counts,
+                             const int32_t** status) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    if (kp) *kp = h->d_out_kp;
+    if (desc) *desc = h->d_out_desc;
+    if (counts) *counts = h->d_out_count;
+    if (status) *status = h->d_status;
+    return OSLAM_OK;
+}
+
+static int check_status(oslam_orb* h) {
+    int st = 0;
+    OSLAM_HIP_CHECK(hipMemcpy(&st, h->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
+        set_error("extractor arena overflow, status bits 0x%x (1 cell, 2 candidates per level, 4/8 quad-tree nodes, 16 outputs)", st);
+        return OSLAM_E_CAPACITY;
+    }
+    return OSLAM_OK;
+}
+
+int oslam_orb_fetch(oslam_orb_t* h, int b, oslam_keypoint_t* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!h || !n_out) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (b < 0 || b >= h->last_batch) { set_error("image %d not in the last batch (%d)", b, h->last_batch); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    int rc = check_status(h);
+    if (rc) return rc;
+    int n = 0;
+    OSLAM_HIP_CHECK(hipMemcpy(&n, h->d_out_count + b, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) { set_error("caller capacity %d < %d keypoints", cap, n); return OSLAM_E_CAPACITY; }
+    if (n > 0) {
+        if (!kps || !desc) { set_error("NULL output"); return OSLAM_E_INVALID; }
+        OSLAM_HIP_CHECK(hipMemcpy(kps, h->d_out_kp + (size_t)b * h->P.out_cap, (size_t)n * sizeof(oslam_keypoint_t), hipMemcpyDeviceToHost));
+        OSLAM_HIP_CHECK(hipMemcpy(desc, h->d_out_desc + (size_t)b * h->P.out_cap * 32, (size_t)n * 32, hipMemcpyDeviceToHost));
+    }
+    return OSLAM_OK;
+}
+
+int oslam_orb_extract(oslam_orb_t* h, const uint8_t* gray, int width, int height, int stride, oslam_keypoint_t* kps,
+                      uint8_t* desc, int cap, int* n_out) {
+    if (!h || !n_out) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    *n_out = 0;
+    if (!gray || width == 0 || height == 0) return OSLAM_OK;   // reference: empty image -> silent return, :1046
+    if (width != h->width || height != h->height || stride < width) {
+        set_error("image %dx%d (stride %d) does not match the handle geometry %dx%d", width, height, stride, h->width, h->height);
+        return OSLAM_E_INVALID;
+    }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipMemcpy2D(h->d_stage, h->stage_pitch, gray, stride, width, height, hipMemcpyHostToDevice));
+    int rc = launch_batch(h, h->d_stage, 1, h->stage_pitch, (size_t)h->stage_pitch * height, nullptr);
+    if (rc) return rc;
+    return oslam_orb_fetch(h, 0, kps, desc, cap, n_out);
+}
+
+int oslam_orb_level_size(const oslam_orb_t* h, int level, int* w, int* hh) {
+    if (!h || level < 0 || level >= h->nlevels) { set_error("bad level"); return OSLAM_E_INVALID; }
+    if (w) *w = h->P.lv[level].w;
+    if (hh) *hh = h->P.lv[level].h;
+    return OSLAM_OK;
+}
+
+int oslam_orb_pyramid_level_device(const oslam_orb_t* h, int b, int level, const uint8_t** d_ptr, int* pitch) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->last_batch) { set_error("bad level/image"); return OSLAM_E_INVALID; }
+    if (level == 0) {
+        *d_ptr = h->ctx.img0 + (long long)b * h->ctx.img0_stride;
+        *pitch = h->ctx.img0_pitch;
+    } else {
+        *d_ptr = h->d_pyr + (long long)b * h->pyr_stride + h->P.lv[level].img_off;
+        *pitch = h->P.lv[level].pitch;
+    }
+    return OSLAM_OK;
+}
+
+int oslam_orb_get_pyramid_level(oslam_orb_t* h, int b, int level, uint8_t* out) {
+    const uint8_t* p; int pitch;
+    int rc = oslam_orb_pyramid_level_device(h, b, level, &p, &pitch);
+    if (rc) return rc;
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    const LevelGeom& g = h->P.lv[level];
+    OSLAM_HIP_CHECK(hipMemcpy2D(out, g.w, p, pitch, g.w, g.h, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+int oslam_orb_debug_get_blurred(oslam_orb_t* h, int b, int level, uint8_t* out) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->last_batch) { set_error("bad level/image"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    const LevelGeom& g = h->P.lv[level];
+    OSLAM_HIP_CHECK(hipMemcpy2D(out, g.w, h->d_blur + (long long)b * h->blur_stride + g.img_off, g.pitch, g.w, g.h, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+int oslam_orb_debug_get_candidates(oslam_orb_t* h, int b, int level, int32_t* out, int cap, int* n_out) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->last_batch || !n_out) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    const LevelGeom& g = h->P.lv[level];
+    const int ncells = g.nCols * g.nRows;
+    std::vector<int> cnt(ncells);
+    std::vector<uint32_t> ent((size_t)ncells * g.cell_cap);
+    OSLAM_HIP_CHECK(hipMemcpy(cnt.data(), h->d_cell_count + (size_t)b * h->P.total_cells + g.cell_base, ncells * sizeof(int), hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(ent.data(), h->d_cand + (size_t)b * h->P.cand_per_image + g.cand_base, ent.size() * 4, hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int ce = 0; ce < ncells; ce++)
+        for (int i = 0; i < cnt[ce]; i++, n++)
+            if (n < cap) {
+                uint32_t e = ent[(size_t)ce * g.cell_cap + i];
+                out[3 * n] = ent_x(e); out[3 * n + 1] = ent_y(e); out[3 * n + 2] = ent_s(e);
+            }
+    *n_out = n;
+    if (n > cap) { set_error("capacity"); return OSLAM_E_CAPACITY; }
+    return OSLAM_OK;
+}
+
+int oslam_orb_debug_get_level_keys(oslam_orb_t* h, int b, int level, int32_t* out, int cap, int* n_out) {
+    if (!h || level < 0 || level >= h->nlevels || b < 0 || b >= h->last_batch || !n_out) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+    const LevelGeom& g = h->P.lv[level];
+    int n = 0;
+    OSLAM_HIP_CHECK(hipMemcpy(&n, h->d_sel_count + (size_t)b * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) { set_error("capacity"); return OSLAM_E_CAPACITY; }
+    std::vector<uint32_t> ent(std::max(n, 1));
+    OSLAM_HIP_CHECK(hipMemcpy(ent.data(), h->d_sel + (size_t)b * h->P.sel_per_image + g.sel_base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) { out[3 * i] = ent_x(ent[i]); out[3 * i + 1] = ent_y(ent[i]); out[3 * i + 2] = ent_s(ent[i]); }
+    return OSLAM_OK;
+}
+
+int64_t oslam_orb_algorithmic_bytes(const oslam_orb_t* h, int n_kp) {
+    // W*H + (P-p_last)+(P-p0) + P + 2P + 749 N + 512 N + 60 N
+    if (!h) return 0;
+    int64_t Ptot = 0;
+    for (int l = 0; l < h->nlevels; l++) Ptot += (int64_t)h->P.lv[l].w * h->P.lv[l].h;
+    const int64_t p0 = (int64_t)h->P.lv[0].w * h->P.lv[0].h;
+    const int64_t pl = (int64_t)h->P.lv[h->nlevels - 1].w * h->P.lv[h->nlevels - 1].h;
+    return p0 + (Ptot - pl) + (Ptot - p0) + Ptot + 2 * Ptot + (int64_t)(749 + 512 + 60) * n_kp;
+}
+
+}  // extern "C"

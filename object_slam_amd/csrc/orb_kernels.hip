@@ -1,0 +1,734 @@
+// gfx950 kernels of the ORB extractor (pyramid, FAST+NMS+cell threshold, quad-tree distribution,
+// Gaussian blur, orientation + steered BRIEF).  Compiled with -ffp-contract=off: float
+// expressions that the reference evaluates on the CPU must round identically here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/oslam_hip.h"
+#include "orb_types.h"
+
+namespace oslam {
+
+struct OrbCtx {
+    const OrbParams* P;       // device
+    const uint8_t* img0;      // level-0 images (caller's buffer or staging)
+    int img0_pitch;
+    long long img0_stride;    // bytes between images
+    uint8_t* pyr;             // [B][pyr_stride]   levels 1..n-1
+    long long pyr_stride;
+    uint8_t* blur;            // [B][blur_stride]  levels 0..n-1
+    long long blur_stride;
+    const int2* rtab;         // resize tables: (src index, a0 | a1 << 16)
+    const uint8_t* root_of_x; // per level: region x -> root index
+    const short* root_x;      // per level: nIni+1 root boundaries
+    int* cell_count;          // [B][total_cells]
+    uint32_t* cand;           // [B][cand_per_image]
+    uint32_t* ent_g;          // [B][cand_per_image] quad-tree spill (levels with > kCandCap candidates)
+    uint16_t* knode_g;        // [B][cand_per_image]
+    uint32_t* sel;            // [B][sel_per_image]
+    int* sel_count;           // [B][nlevels]
+    oslam_keypoint_t* out_kp; // [B][out_cap]
+    uint8_t* out_desc;        // [B][out_cap][32]
+    int* out_count;           // [B]
+    int* status;              // [1]
+};
+
+__device__ __forceinline__ const uint8_t* level_image(const OrbCtx& c, const OrbParams* P, int b, int l,
+                                                      int& pitch) {
+    if (l == 0) {
+        pitch = c.img0_pitch;
+        return c.img0 + (long long)b * c.img0_stride;
+    }
+    pitch = P->lv[l].pitch;
+    return c.pyr + (long long)b * c.pyr_stride + P->lv[l].img_off;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: pyramid level l from level l-1 (cv::resize INTER_LINEAR u8 fixed point, 11-bit taps).
+// Replaces reference src/ORBextractor.cc:1107-1132.  4 dst pixels per thread.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(OrbCtx c, int level) {
+    const OrbParams* P = c.P;
+    const LevelGeom& g = P->lv[level];
+    const LevelGeom& gs = P->lv[level - 1];
+    const int b = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= g.h || x4 >= g.w) return;
+    int spitch;
+    const uint8_t* src = level_image(c, P, b, level - 1, spitch);
+    uint8_t* dst = c.pyr + (long long)b * c.pyr_stride + g.img_off;
+    const int2 ty = c.rtab[g.ytab_off + y];
+    const int sy0 = min(max(ty.x, 0), gs.h - 1), sy1 = min(max(ty.x + 1, 0), gs.h - 1);
+    const int b0 = (short)(ty.y & 0xFFFF), b1 = (short)(ty.y >> 16);
+    const uint8_t* S0 = src + (long long)sy0 * spitch;
+    const uint8_t* S1 = src + (long long)sy1 * spitch;
+    uint32_t outw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = min(x4 + i, g.w - 1);
+        const int2 tx = c.rtab[g.xtab_off + x];
+        const int sx = tx.x, sx1 = min(sx + 1, gs.w - 1);
+        const int a0 = (short)(tx.y & 0xFFFF), a1 = (short)(tx.y >> 16);
+        const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+        const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        outw |= (uint32_t)v << (8 * i);
+    }
+    // pitch is a multiple of 64 so the 4-byte store is aligned and stays inside the row's padding
+    *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: 7x7 Gaussian (sigma 2) u8 fixed point, BORDER_REFLECT_101 about the image edge.
+// Replaces reference src/ORBextractor.cc:1085-1086.  Tile 64x16 outputs per workgroup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (p < 0) p = -p;
+    if (p >= len) p = 2 * (len - 1) - p;
+    return p;
+}
+
+constexpr int kBlurTW = 64, kBlurTH = 16;
+
+__global__ __launch_bounds__(256) void k_blur(OrbCtx c, int level, int sse2_rounding) {
+    const OrbParams* P = c.P;
+    const LevelGeom& g = P->lv[level];
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * kBlurTW, ty0 = blockIdx.y * kBlurTH;
+    int spitch;
+    const uint8_t* src = level_image(c, P, b, level, spitch);
+    uint8_t* dst = c.blur + (long long)b * c.blur_stride + g.img_off;
+
+    __shared__ uint8_t tile[kBlurTH + 6][kBlurTW + 8];   // 22 x 72
+    __shared__ uint16_t rowp[kBlurTH + 6][kBlurTW];      // horizontal pass (<= 255*257 fits u16)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
+        const int ry = i / (kBlurTW + 6), rx = i - ry * (kBlurTW + 6);
+        const int sx = reflect101(min(tx0 + rx - 3, g.w + 2), g.w);
+        const int sy = reflect101(min(ty0 + ry - 3, g.h + 2), g.h);
+        tile[ry][rx] = src[(long long)sy * spitch + sx];
+    }
+    __syncthreads();
+    int k0 = P->gk[0], k1 = P->gk[1], k2 = P->gk[2], k3 = P->gk[3];
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int ry = i >> 6, rx = i & 63;
+        const uint8_t* t = &tile[ry][rx];
+        int s = k0 * (t[0] + t[6]) + k1 * (t[1] + t[5]) + k2 * (t[2] + t[4]) + k3 * t[3];
+        rowp[ry][rx] = (uint16_t)s;
+    }
+    __syncthreads();
+    for (int i = tid; i < kBlurTH * kBlurTW; i += 256) {
+        const int oy = i >> 6, ox = i & 63;
+        const int x = tx0 + ox, y = ty0 + oy;
+        if (x >= g.w || y >= g.h) continue;
+        int s = k0 * ((int)rowp[oy][ox] + rowp[oy + 6][ox]) + k1 * ((int)rowp[oy + 1][ox] + rowp[oy + 5][ox]) +
+                k2 * ((int)rowp[oy + 2][ox] + rowp[oy + 4][ox]) + k3 * (int)rowp[oy + 3][ox];
+        int v;
+        if (sse2_rounding && x < (g.w & ~3)) {
+            // OpenCV 3.2 SymmColumnVec_32s8u: exact fp32 sum, cvtps2dq (half-to-even)
+            int q = s >> 16, r = s & 0xFFFF;
+            if (r > 0x8000) q++;
+            else if (r == 0x8000) q += (q & 1);
+            v = q;
+        } else {
+            v = (s + (1 << 15)) >> 16;
+        }
+        dst[(long long)y * g.pitch + x] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3: per-cell FAST-9/16 score, 3x3 NMS inside the cell, ini/min threshold fallback and
+// ordered compaction.  One workgroup per (image, level, cell).
+// Replaces the per-cell cv::FAST calls of reference src/ORBextractor.cc:789-829.
+// score = max over the 16 arcs of 9 of min |v - p| (signed), minus 1: threshold independent,
+// so "corner at t" <=> score >= t and one score map serves iniThFAST and minThFAST.
+// ------------------------------------------------------------------------------------------
+template <int TP>
+__device__ __forceinline__ int fast_score(const uint8_t* t) {
+    // Bresenham circle r=3, OpenCV order
+    constexpr int off[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,        -TP + 3, -2 * TP + 2, -3 * TP + 1,
+                             -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3, -3,       TP - 3,  2 * TP - 2,  3 * TP - 1};
+    const int v = t[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - (int)t[off[k]];
+    int lo2[16], hi2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo2[k] = min(d[k], d[(k + 1) & 15]);
+        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    }
+    int lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+    }
+    int A = -256, Bm = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        A = max(A, lo9);
+        Bm = min(Bm, hi9);
+    }
+    const int s = max(A, -Bm) - 1;
+    return max(s, 0);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
+    const OrbParams* P = c.P;
+    const int b = blockIdx.y;
+    int cell = blockIdx.x;
+    int level = 0;
+    for (int l = 1; l < P->nlevels; l++)
+        if (cell >= P->lv[l].cell_base) level = l;
+    const LevelGeom& g = P->lv[level];
+    cell -= g.cell_base;
+    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
+    int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
+
+    // cell ROI in level coords (reference :789-806)
+    const int minBX = kRegionBorder, minBY = kRegionBorder;
+    const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
+    const int iniY = minBY + ci * g.hCell, iniX = minBX + cj * g.wCell;
+    int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
+    const bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);
+    if (maxY > maxBY) maxY = maxBY;
+    if (maxX > maxBX) maxX = maxBX;
+    const int cw = maxX - iniX - 6, ch = maxY - iniY - 6;   // interior (pixels FAST can report)
+    if (skip || cw <= 0 || ch <= 0) {
+        if (threadIdx.x == 0) *count_out = 0;
+        return;
+    }
+
+    __shared__ uint8_t tile[(kMaxCell + 6) * kTilePitch];
+    __shared__ uint8_t sc[kMaxCell * kMaxCell];
+    __shared__ int wave_tot[4];
+    __shared__ int any_ini;
+    const int tid = threadIdx.x;
+    if (tid == 0) any_ini = 0;
+
+    int pitch;
+    const uint8_t* img = level_image(c, P, b, level, pitch);
+    const int rw = cw + 6, rh = ch + 6;
+    for (int i = tid; i < rw * rh; i += 256) {
+        const int ry = i / rw, rx = i - ry * rw;
+        tile[ry * kTilePitch + rx] = img[(long long)(iniY + ry) * pitch + iniX + rx];
+    }
+    __syncthreads();
+
+    // scores: 32 x 8 thread layout
+    const int lx = tid & 31, ly = tid >> 5;
+    for (int y = ly; y < ch; y += 8)
+        for (int x = lx; x < cw; x += 32)
+            sc[y * kMaxCell + x] = (uint8_t)fast_score<kTilePitch>(&tile[(y + 3) * kTilePitch + x + 3]);
+    __syncthreads();
+
+    // NMS inside the cell: strictly greater than the 8 neighbours, outside-of-cell counts 0
+    const int minTh = P->minTh, iniTh = P->iniTh;
+    uint32_t keepmask = 0;   // bit i: pixel of iteration i survives NMS with score >= minTh
+    int hit_ini = 0;
+    {
+        int it = 0;
+        for (int y = ly; y < ch; y += 8)
+            for (int x = lx; x < cw; x += 32, it++) {
+                const int s = sc[y * kMaxCell + x];
+                bool keep = s >= minTh;
+                if (keep) {
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int xx = x + dx, yy = y + dy;
+                            const int n = (xx >= 0 && xx < cw && yy >= 0 && yy < ch) ? sc[yy * kMaxCell + xx] : 0;
+                            keep = keep && (s > n);
+                        }
+                }
+                if (keep) {
+                    keepmask |= 1u << it;
+                    if (s >= iniTh) hit_ini = 1;
+                }
+            }
+    }
+    __syncthreads();   // all NMS reads of sc done
+    {
+        int it = 0;
+        for (int y = ly; y < ch; y += 8)
+            for (int x = lx; x < cw; x += 32, it++)
+                if (!((keepmask >> it) & 1)) sc[y * kMaxCell + x] = 0;
+    }
+    if (hit_ini) any_ini = 1;   // benign race: all writers store 1
+    __syncthreads();
+    const int th = any_ini ? iniTh : minTh;
+
+    // ordered compaction, row-major over the cell interior (reference pushes FAST output in
+    // row-major order, :820-825)
+    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
+    const int npx = cw * ch;
+    const int lane = tid & 63, wv = tid >> 6;
+    int running = 0;
+    for (int base = 0; base < npx; base += 256) {
+        const int p = base + tid;
+        int s = 0, x = 0, y = 0;
+        if (p < npx) {
+            y = p / cw;
+            x = p - y * cw;
+            s = sc[y * kMaxCell + x];
+        }
+        const bool flag = s >= th;   // s == 0 for suppressed pixels, th >= 1
+        const unsigned long long m = __ballot(flag);
+        const int pre = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wv] = __popcll(m);
+        __syncthreads();
+        int wbase = running;
+        for (int i = 0; i < wv; i++) wbase += wave_tot[i];
+        if (flag) {
+            const int slot = wbase + pre;
+            if (slot < g.cell_cap) out[slot] = pack_xys(cj * g.wCell + x + 3, ci * g.hCell + y + 3, s);
+        }
+        running += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (running > g.cell_cap) { atomicOr(c.status, 1); running = g.cell_cap; }
+        *count_out = running;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: quad-tree distribution (reference DistributeOctTree, src/ORBextractor.cc:539-763), one
+// workgroup per (image, level).  The std::list algorithm is restated over arrays kept in list
+// order: each pass is described by the set of "processed" nodes and their processing order;
+// children of processed nodes go to the front in reverse processing order (push_front), all
+// other nodes keep their relative order behind them.  Keypoints carry the list position of
+// their node; the per-node survivor is the first maximum response in candidate order.
+// Tie-break of the (size, pointer) sort (:684) is normalised to node creation order.
+// ------------------------------------------------------------------------------------------
+constexpr int kOctThreads = 512;
+
+// exclusive scan of a[0..n) in place; returns the total.  All threads must call.
+__device__ int block_exclusive_scan(int* a, int n, int* scratch /* >= 16 ints */) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n + kOctThreads - 1) / kOctThreads;
+    const int beg = min(tid * per, n), end = min(beg + per, n);
+    int local = 0;
+    for (int i = beg; i < end; i++) local += a[i];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) scratch[wv] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+    for (int i = 0; i < kOctThreads / 64; i++) {
+        if (i < wv) wbase += scratch[i];
+        total += scratch[i];
+    }
+    int run = wbase + incl - local;
+    for (int i = beg; i < end; i++) {
+        const int v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+struct NodeTab {
+    short* x0; short* x1; short* y0; short* y1;
+    int* cnt;
+    int* seq;
+};
+
+__device__ __forceinline__ int child_of(int kx, int ky, int x0, int x1, int y0, int y1) {
+    const int halfX = (x1 - x0 + 1) >> 1;   // ceil((x1-x0)/2), :483
+    const int halfY = (y1 - y0 + 1) >> 1;
+    const int cx = kx < x0 + halfX ? 0 : 1;
+    const int cy = ky < y0 + halfY ? 0 : 1;
+    return cx + 2 * cy;   // n1=0 (UL), n2=1 (UR), n3=2 (BL), n4=3 (BR)
+}
+
+constexpr int kIdxBits = 20;   // candidate index bits in the survivor key (score << 20 | ~index)
+
+template <typename EntT, typename NodeT>
+__device__ __forceinline__ void octree_body(const OrbCtx& c, EntT ent, NodeT knode, int* ibase, const int* cellofs,
+                                            const int n) {
+    const OrbParams* P = c.P;
+    const int level = blockIdx.x, b = blockIdx.y;
+    const LevelGeom& g = P->lv[level];
+    const int tid = threadIdx.x;
+    const int NC = P->node_cap;
+    const int N = g.quota;
+    int* childcnt = ibase;            ibase += 4 * NC;     // [4*NC]
+    int* childpos = ibase;            ibase += 4 * NC;     // [4*NC] new list position of child
+    int* staypos = ibase;             ibase += NC;         // new list position of an unprocessed node
+    int* prank = ibase;               ibase += NC;         // processing rank or -1
+    int* byrank = ibase;              ibase += NC;         // rank -> node
+    int* scanA = ibase;               ibase += NC + 1;
+    int* scanB = ibase;               ibase += NC + 1;
+    int* cntA = ibase;                ibase += NC;
+    int* cntB = ibase;                ibase += NC;
+    int* seqA = ibase;                ibase += NC;
+    int* seqB = ibase;                ibase += NC;
+    int* best = ibase;                ibase += NC;
+    int* scratch = ibase;             ibase += 32;
+    short* sbase = (short*)ibase;
+    short* bx0A = sbase; sbase += NC; short* bx1A = sbase; sbase += NC;
+    short* by0A = sbase; sbase += NC; short* by1A = sbase; sbase += NC;
+    short* bx0B = sbase; sbase += NC; short* bx1B = sbase; sbase += NC;
+    short* by0B = sbase; sbase += NC; short* by1B = sbase; sbase += NC;
+    NodeTab cur = {bx0A, bx1A, by0A, by1A, cntA, seqA};
+    NodeTab nxt = {bx0B, bx1B, by0B, by1B, cntB, seqB};
+    __shared__ int sh_flag, sh_J;
+
+    uint32_t* sel = c.sel + (long long)b * P->sel_per_image + g.sel_base;
+    int* sel_count = c.sel_count + (long long)b * P->nlevels + level;
+
+    // ---- gather the level's candidates in reference order: cells row-major, pixels row-major ----
+    const int ncells = g.nCols * g.nRows;
+    const int* cell_count = c.cell_count + (long long)b * P->total_cells + g.cell_base;
+    const uint32_t* cand = c.cand + (long long)b * P->cand_per_image + g.cand_base;
+    for (int ce = tid >> 4; ce < ncells; ce += kOctThreads / 16) {
+        const int cnt = cell_count[ce], o = cellofs[ce];
+        for (int i = tid & 15; i < cnt; i += 16) ent[o + i] = cand[(long long)ce * g.cell_cap + i];
+    }
+    __syncthreads();
+
+    // ---- roots (:543-585) ----
+    const int nIni = g.nIni;
+    const short* rootx = c.root_x + g.root_off;                        // nIni+1 boundaries
+    const uint8_t* root_of_x = c.root_of_x + (long long)level * 4096;  // region x -> root, (int)(x/hX) :569
+    for (int i = tid; i < nIni; i += kOctThreads) childcnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kOctThreads) {
+        const int r = root_of_x[ent_x(ent[i])];
+        knode[i] = (uint16_t)r;
+        atomicAdd(&childcnt[r], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < nIni; i += kOctThreads) scanA[i] = childcnt[i] > 0 ? 1 : 0;
+    __syncthreads();
+    int S = block_exclusive_scan(scanA, nIni, scratch);
+    for (int i = tid; i < nIni; i += kOctThreads) {
+        if (childcnt[i] > 0) {
+            const int p = scanA[i];
+            cur.x0[p] = rootx[i]; cur.x1[p] = rootx[i + 1];
+            cur.y0[p] = 0; cur.y1[p] = (short)g.region_h;
+            cur.cnt[p] = childcnt[i]; cur.seq[p] = i;
+            staypos[i] = p;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kOctThreads) knode[i] = (uint16_t)staypos[knode[i]];
+    __syncthreads();
+
+    // ---- passes ----
+    bool careful = false;
+    for (int iter = 0; iter < 64; iter++) {
+        // child occupancy of every divisible node
+        for (int i = tid; i < 4 * S; i += kOctThreads) childcnt[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kOctThreads) {
+            const int p = knode[i];
+            if (cur.cnt[p] > 1) {
+                const uint32_t e = ent[i];
+                const int ch = child_of(ent_x(e), ent_y(e), cur.x0[p], cur.x1[p], cur.y0[p], cur.y1[p]);
+                atomicAdd(&childcnt[4 * p + ch], 1);
+            }
+        }
+        __syncthreads();
+
+        // processing order
+        int M;   // number of processed nodes
+        if (!careful) {
+            for (int p = tid; p < S; p += kOctThreads) scanA[p] = cur.cnt[p] > 1 ? 1 : 0;
+            __syncthreads();
+            M = block_exclusive_scan(scanA, S, scratch);
+            for (int p = tid; p < S; p += kOctThreads) {
+                if (cur.cnt[p] > 1) { prank[p] = scanA[p]; byrank[scanA[p]] = p; }
+                else prank[p] = -1;
+            }
+            __syncthreads();
+        } else {
+            // sort divisible nodes by (size, creation seq) descending (:684-686)
+            for (int p = tid; p < S; p += kOctThreads) {
+                int r = -1;
+                const int cp = cur.cnt[p];
+                if (cp > 1) {
+                    const int sp = cur.seq[p];
+                    r = 0;
+                    for (int q = 0; q < S; q++) {
+                        const int cq = cur.cnt[q];
+                        if (cq > 1 && (cq > cp || (cq == cp && cur.seq[q] > sp))) r++;
+                    }
+                    byrank[r] = p;
+                }
+                prank[p] = r;
+            }
+            if (tid == 0) sh_J = 0x7fffffff;
+            for (int p = tid; p < S; p += kOctThreads) scanA[p] = cur.cnt[p] > 1 ? 1 : 0;
+            __syncthreads();
+            const int V = block_exclusive_scan(scanA, S, scratch);
+            // list growth per processed node, in rank order; stop at the first size >= N (:729-730)
+            for (int j = tid; j < V; j += kOctThreads) {
+                const int p = byrank[j];
+                const int k = (childcnt[4 * p] > 0) + (childcnt[4 * p + 1] > 0) + (childcnt[4 * p + 2] > 0) +
+                              (childcnt[4 * p + 3] > 0);
+                scanB[j] = k - 1;
+            }
+            __syncthreads();
+            block_exclusive_scan(scanB, V, scratch);
+            for (int j = tid; j < V; j += kOctThreads) {
+                const int p = byrank[j];
+                const int k = (childcnt[4 * p] > 0) + (childcnt[4 * p + 1] > 0) + (childcnt[4 * p + 2] > 0) +
+                              (childcnt[4 * p + 3] > 0);
+                if (S + scanB[j] + k - 1 >= N) atomicMin(&sh_J, j);
+            }
+            __syncthreads();
+            M = min(V, sh_J == 0x7fffffff ? V : sh_J + 1);
+            for (int p = tid; p < S; p += kOctThreads)
+                if (prank[p] >= M) prank[p] = -1;
+            __syncthreads();
+        }
+
+        // children of processed nodes: positions at the front, reverse processing order
+        for (int j = tid; j < M; j += kOctThreads) {
+            const int p = byrank[j];
+            scanA[j] = (childcnt[4 * p] > 0) + (childcnt[4 * p + 1] > 0) + (childcnt[4 * p + 2] > 0) +
+                       (childcnt[4 * p + 3] > 0);
+        }
+        __syncthreads();
+        const int Ktot = block_exclusive_scan(scanA, M, scratch);   // scanA[j] = children before rank j
+        for (int p = tid; p < S; p += kOctThreads) scanB[p] = prank[p] < 0 ? 1 : 0;
+        __syncthreads();
+        const int R = block_exclusive_scan(scanB, S, scratch);      // scanB[p] = unprocessed before p
+        const int newS = Ktot + R;
+        if (newS > NC) {   // cannot happen for quota+3 sized tables; fail loudly
+            if (tid == 0) { atomicOr(c.status, 4); *sel_count = 0; }
+            return;
+        }
+        if (tid == 0) sh_flag = 0;
+        __syncthreads();
+        int nexp_local = 0;
+        for (int p = tid; p < S; p += kOctThreads) {
+            const int j = prank[p];
+            if (j < 0) {
+                const int pos = Ktot + scanB[p];
+                staypos[p] = pos;
+                nxt.x0[pos] = cur.x0[p]; nxt.x1[pos] = cur.x1[p];
+                nxt.y0[pos] = cur.y0[p]; nxt.y1[pos] = cur.y1[p];
+                nxt.cnt[pos] = cur.cnt[p]; nxt.seq[pos] = cur.seq[p];
+            } else {
+                const int k = (childcnt[4 * p] > 0) + (childcnt[4 * p + 1] > 0) + (childcnt[4 * p + 2] > 0) +
+                              (childcnt[4 * p + 3] > 0);
+                const int basepos = Ktot - scanA[j] - k;   // children of later-processed nodes come first
+                const int x0 = cur.x0[p], x1 = cur.x1[p], y0 = cur.y0[p], y1 = cur.y1[p];
+                const int hx = x0 + ((x1 - x0 + 1) >> 1), hy = y0 + ((y1 - y0 + 1) >> 1);
+                int after = 0;   // non-empty children with a larger index (pushed later => in front)
+                for (int ch = 3; ch >= 0; ch--) {
+                    const int cc = childcnt[4 * p + ch];
+                    if (cc > 0) {
+                        const int pos = basepos + after;
+                        after++;
+                        childpos[4 * p + ch] = pos;
+                        nxt.x0[pos] = (ch & 1) ? hx : x0; nxt.x1[pos] = (ch & 1) ? x1 : hx;
+                        nxt.y0[pos] = (ch & 2) ? hy : y0; nxt.y1[pos] = (ch & 2) ? y1 : hy;
+                        nxt.cnt[pos] = cc;
+                        nxt.seq[pos] = j * 4 + ch;
+                        if (cc > 1) nexp_local++;
+                    }
+                }
+            }
+        }
+        if (nexp_local) atomicAdd(&sh_flag, nexp_local);
+        __syncthreads();
+        for (int i = tid; i < n; i += kOctThreads) {
+            const int p = knode[i];
+            if (prank[p] < 0) knode[i] = (uint16_t)staypos[p];
+            else {
+                const uint32_t e = ent[i];
+                const int ch = child_of(ent_x(e), ent_y(e), cur.x0[p], cur.x1[p], cur.y0[p], cur.y1[p]);
+                knode[i] = (uint16_t)childpos[4 * p + ch];
+            }
+        }
+        __syncthreads();
+        const int nToExpand = sh_flag;
+        { NodeTab t = cur; cur = nxt; nxt = t; }
+        const int prevS = S;
+        S = newS;
+        if (S >= N || S == prevS) break;                      // :669-672, :733-734
+        if (!careful && (S + nToExpand * 3) > N) careful = true;   // :673
+    }
+
+    // ---- survivor per node: first maximum response in candidate order (:744-760) ----
+    for (int p = tid; p < S; p += kOctThreads) best[p] = -1;
+    __syncthreads();
+    for (int i = tid; i < n; i += kOctThreads)
+        atomicMax(&best[knode[i]], (ent_s(ent[i]) << kIdxBits) | ((1 << kIdxBits) - 1 - i));
+    __syncthreads();
+    if (S > g.sel_cap) {
+        if (tid == 0) { atomicOr(c.status, 8); *sel_count = 0; }
+        return;
+    }
+    for (int p = tid; p < S; p += kOctThreads) {
+        const int i = (1 << kIdxBits) - 1 - (best[p] & ((1 << kIdxBits) - 1));
+        const uint32_t e = ent[i];
+        sel[p] = pack_xys(ent_x(e) + kRegionBorder, ent_y(e) + kRegionBorder, ent_s(e));   // level coords, :839-840
+    }
+    if (tid == 0) *sel_count = S;
+}
+
+__global__ __launch_bounds__(kOctThreads) void k_octree(OrbCtx c) {
+    const OrbParams* P = c.P;
+    const int level = blockIdx.x, b = blockIdx.y;
+    const LevelGeom& g = P->lv[level];
+    const int tid = threadIdx.x;
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* ent = (uint32_t*)smem;                       // [kCandCap]
+    uint16_t* knode = (uint16_t*)(ent + kCandCap);         // [kCandCap]
+    int* ibase = (int*)(knode + kCandCap);
+    int* scratch = ibase;                                  // wave totals of the scan below (area is re-initialised by the body)
+    int* sel_count = c.sel_count + (long long)b * P->nlevels + level;
+
+    // prefix of the per-cell counts, kept in the LDS node-id area: the gather reads it while
+    // writing only `ent`; the body first writes node ids after the gather's barrier
+    const int ncells = g.nCols * g.nRows;
+    const int* cell_count = c.cell_count + (long long)b * P->total_cells + g.cell_base;
+    int* cellofs = (int*)knode;   // ncells <= kCandCap/2 ints, checked at create time
+    for (int i = tid; i < ncells; i += kOctThreads) cellofs[i] = cell_count[i];
+    __syncthreads();
+    const int n = block_exclusive_scan(cellofs, ncells, scratch);
+    if (n == 0) {
+        if (tid == 0) *sel_count = 0;
+        return;
+    }
+    if (n >= (1 << kIdxBits)) {
+        if (tid == 0) { atomicOr(c.status, 2); *sel_count = 0; }
+        return;
+    }
+    if (n <= kCandCap) {
+        octree_body(c, ent, knode, ibase, cellofs, n);
+    } else {
+        // spill variant: candidate list and node ids in HBM (L2-resident), same algorithm
+        uint32_t* ent_g = c.ent_g + (long long)b * P->cand_per_image + g.cand_base;
+        uint16_t* knode_g = c.knode_g + (long long)b * P->cand_per_image + g.cand_base;
+        octree_body(c, ent_g, knode_g, ibase, cellofs, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5+K7: intensity-centroid orientation on the level image and steered BRIEF on the blurred
+// level; one wavefront per keypoint.  Replaces reference src/ORBextractor.cc:77-147,472-479,
+// 1090-1104 (IC_Angle, computeOrbDescriptor, the level concat and the pt *= scale).
+// ------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    // cv::fastAtan2 (OpenCV 3.2 atanImpl<float>), fp32 without contraction
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, cc, c2;
+    if (ax >= ay) {
+        cc = __fdiv_rn(ay, ax + eps);
+        c2 = cc * cc;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cc;
+    } else {
+        cc = __fdiv_rn(ax, ay + eps);
+        c2 = cc * cc;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * cc;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c) {
+    const OrbParams* P = c.P;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);   // index in the concatenated output
+    const int* sel_count = c.sel_count + (long long)b * P->nlevels;
+    int level = -1, idx = slot, total = 0;
+    for (int l = 0; l < P->nlevels; l++) {
+        const int cnt = sel_count[l];
+        if (level < 0 && idx < cnt) level = l;
+        if (level < 0) idx -= cnt;
+        total += cnt;
+    }
+    if (slot == 0 && lane == 0) {
+        c.out_count[b] = total;
+        if (total > P->out_cap) atomicOr(c.status, 16);
+    }
+    if (level < 0 || slot >= P->out_cap) return;
+    const LevelGeom& g = P->lv[level];
+    const uint32_t e = c.sel[(long long)b * P->sel_per_image + g.sel_base + idx];
+    const int kx = ent_x(e), ky = ent_y(e), score = ent_s(e);
+
+    // IC_Angle: integer moments over the r=15 circular patch (749 px)
+    int pitch;
+    const uint8_t* img = level_image(c, P, b, level, pitch);
+    const uint8_t* center = img + (long long)ky * pitch + kx;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= P->umax[av]) {
+            const int val = center[v * pitch + u];
+            m10 += u * val;
+            m01 += v * val;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d, 64);
+        m01 += __shfl_xor(m01, d, 64);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // steered BRIEF on the blurred level: 4 tests per lane
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float ang = angle * factorPI;
+    const float a = (float)cos((double)ang), bb = (float)sin((double)ang);
+    const uint8_t* bimg = c.blur + (long long)b * c.blur_stride + g.img_off;
+    const uint8_t* bc = bimg + (long long)ky * g.pitch + kx;
+    int nib = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int8_t* pt = &c_pattern[(lane * 4 + t) * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
+        const int r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
+        const int t0 = bc[r0 * g.pitch + c0], t1 = bc[r1 * g.pitch + c1];
+        nib |= (t0 < t1) << t;
+    }
+    const int other = __shfl_xor(nib, 1, 64);
+    const long long o = (long long)b * P->out_cap + slot;
+    if ((lane & 1) == 0) c.out_desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (lane == 0) {
+        oslam_keypoint_t kp;
+        const float fx = (float)kx, fy = (float)ky;
+        kp.x = level ? fx * g.scale : fx;
+        kp.y = level ? fy * g.scale : fy;
+        kp.size = g.kp_size;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = level;
+        kp.class_id = -1;
+        c.out_kp[o] = kp;
+    }
+}
+
+}  // namespace oslam

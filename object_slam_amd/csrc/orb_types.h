@@ -1,0 +1,54 @@
+// Device/host shared geometry of the ORB extractor (product code).
+#pragma once
+#include <stdint.h>
+
+namespace oslam {
+
+constexpr int kEdgeThreshold = 19;   // reference src/ORBextractor.cc:74
+constexpr int kHalfPatch = 15;       // :73
+constexpr int kPatchSize = 31;       // :72
+constexpr int kRegionBorder = 16;    // EDGE_THRESHOLD-3, :773
+constexpr int kMaxCell = 64;         // max FAST cell interior edge handled by one workgroup
+constexpr int kTilePitch = 72;       // LDS tile pitch (>= kMaxCell + 6)
+constexpr int kCandCap = 16384;      // FAST candidates per (image, level) the quad-tree kernel holds in LDS
+constexpr int kMaxRoots = 64;        // nIni upper bound
+
+// candidate / survivor entry: x (12 bit) | y (12 bit) << 12 | score (8 bit) << 24
+__host__ __device__ inline uint32_t pack_xys(int x, int y, int s) {
+    return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)s << 24);
+}
+__host__ __device__ inline int ent_x(uint32_t e) { return e & 0xFFF; }
+__host__ __device__ inline int ent_y(uint32_t e) { return (e >> 12) & 0xFFF; }
+__host__ __device__ inline int ent_s(uint32_t e) { return e >> 24; }
+
+struct LevelGeom {
+    int w, h, pitch;          // level image (level 0: the caller's image / pitch is passed separately)
+    int region_w, region_h;   // [16, w-16) x [16, h-16): reference :773-782
+    int nCols, nRows, wCell, hCell;  // :784-787
+    int cell_base;            // first cell of this level in the per-image cell arrays
+    int cell_cap;             // candidate slots per cell (= NMS upper bound)
+    int cand_base;            // first candidate slot of this level in the per-image arena
+    int quota;                // mnFeaturesPerLevel, :436-446
+    int nIni;                 // quad-tree roots, :543
+    int root_off;             // offset into root tables
+    int sel_cap, sel_base;    // survivor slots of this level
+    int xtab_off, ytab_off;   // resize coefficient tables
+    long long img_off;        // byte offset inside the per-image pyramid / blur arenas
+    float scale;              // mvScaleFactor[level]
+    float kp_size;            // (int)(PATCH_SIZE*scale), :837
+};
+
+struct OrbParams {
+    LevelGeom lv[OSLAM_MAX_LEVELS];
+    int nlevels;
+    int iniTh, minTh;
+    int total_cells;
+    int cand_per_image;   // u32 slots
+    int sel_per_image;    // u32 slots
+    int out_cap;          // keypoints per image in the output arrays
+    int node_cap;         // quad-tree node table size
+    int gk[7];            // 7-tap Gaussian, 8 fractional bits
+    int umax[16];         // IC_Angle row extents, :454-469
+};
+
+}  // namespace oslam

@@ -1,0 +1,95 @@
+"""GPU parity: HIP ORB extractor (through the C ABI) vs the CPU oracle, stage by stage and end to
+end.  Bit-exact: pyramid bytes, blurred bytes, FAST candidates (order, coords, score), quad-tree
+survivors (order), keypoints (all 7 fields) and descriptors."""
+import numpy as np
+import pytest
+
+from object_slam_amd import ORBextractor, synth
+
+pytestmark = pytest.mark.gpu
+
+TUM = dict(nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+KITTI = dict(nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7)
+
+
+def _stages(oracle, cfg, img):
+    h, w = img.shape
+    ex = ORBextractor(width=w, height=h, **cfg)
+    oe = oracle.OrbExtractor(cfg["nfeatures"], cfg["scaleFactor"], cfg["nlevels"], cfg["iniThFAST"], cfg["minThFAST"])
+    kps, desc = ex(img)
+    okps, odesc = oe.extract(img)
+    for l in range(cfg["nlevels"]):
+        assert ex.level_size(l) == oe.level_size(l)
+        np.testing.assert_array_equal(ex.pyramid_level(l), oe.level(l), err_msg="pyramid level %d" % l)
+        cand = ex.debug_candidates(l)
+        oc = oe.candidates(l)
+        assert len(cand) == len(oc), "level %d: %d vs %d candidates" % (l, len(cand), len(oc))
+        np.testing.assert_array_equal(cand[:, 0], oc["x"].astype(np.int32))
+        np.testing.assert_array_equal(cand[:, 1], oc["y"].astype(np.int32))
+        np.testing.assert_array_equal(cand[:, 2], oc["response"].astype(np.int32))
+        keys = ex.debug_level_keys(l)
+        ok = oe.level_keys(l)
+        assert len(keys) == len(ok), "level %d: %d vs %d survivors" % (l, len(keys), len(ok))
+        np.testing.assert_array_equal(keys[:, 0], ok["x"].astype(np.int32))
+        np.testing.assert_array_equal(keys[:, 1], ok["y"].astype(np.int32))
+        ob = oe.blurred(l)
+        if ob is not None:
+            np.testing.assert_array_equal(ex.debug_blurred(l), ob, err_msg="blur level %d" % l)
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        np.testing.assert_array_equal(kps[f], okps[f], err_msg=f)
+    np.testing.assert_array_equal(desc, odesc)
+    ex.close()
+    return len(kps)
+
+
+def test_tum_shape_stage_parity(oracle):
+    frames, _ = synth.make_stream(3, 640, 480)
+    for i in range(3):
+        n = _stages(oracle, TUM, frames[i])
+        assert 900 <= n <= 1100
+
+
+def test_kitti_shape_stage_parity(oracle):
+    frames, _ = synth.make_stream(1, 1241, 376, seed=7)
+    n = _stages(oracle, KITTI, frames[0])
+    assert 1800 <= n <= 2100
+
+
+def test_odd_sizes_and_flat_images(oracle):
+    rng = np.random.default_rng(5)
+    # small odd geometry, low-texture image (forces the minThFAST fallback and empty cells)
+    img = (rng.integers(0, 6, size=(211, 317)) + 100).astype(np.uint8)
+    img[60:120, 80:200] = 140
+    _stages(oracle, dict(nfeatures=300, scaleFactor=1.2, nlevels=4, iniThFAST=20, minThFAST=7), img)
+    # constant image: no keypoints at all
+    ex = ORBextractor(500, 1.2, 8, 20, 7, 640, 480)
+    k, d = ex(np.full((480, 640), 128, np.uint8))
+    assert len(k) == 0 and d.shape == (0, 32)
+    # empty image: silent return like the reference (src/ORBextractor.cc:1046)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0
+    ex.close()
+
+
+def test_noise_image_many_candidates(oracle):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(480, 640)).astype(np.uint8)
+    _stages(oracle, TUM, img)
+
+
+def test_batch_equals_single(oracle):
+    import torch
+    frames, _ = synth.make_stream(6, 640, 480, seed=3)
+    ex = ORBextractor(width=640, height=480, max_batch=6, **TUM)
+    d = torch.from_numpy(frames).cuda()
+    ex.extract_batch_device(d.data_ptr(), 6, 640, 640 * 480, torch.cuda.current_stream().cuda_stream)
+    oe = oracle.OrbExtractor()
+    for b in range(6):
+        k, de = ex.fetch(b)
+        ok, od = oe.extract(frames[b])
+        assert len(k) == len(ok)
+        for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            np.testing.assert_array_equal(k[f], ok[f])
+        np.testing.assert_array_equal(de, od)
+    ex.close()
