@@ -98,8 +98,106 @@ int oslam_orb_debug_get_candidates(oslam_orb_t* h, int b, int level, int32_t* ou
 /* Quad-tree survivors of a level in reference order (level coords): src/ORBextractor.cc:834-847. */
 int oslam_orb_debug_get_level_keys(oslam_orb_t* h, int b, int level, int32_t* out, int cap, int* n_out);
 
+/* Kernel-group timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * Groups: 0 pyramid (K1 x (nlevels-1)), 1 FAST cells (K2/K3), 2 blur (K6 x nlevels), 3 quad-tree (K4),
+ * 4 orientation + descriptors (K5/K7).  get_profile returns accumulated milliseconds since
+ * set_profiling(h, 1) and the number of batches / images they cover. */
+int oslam_orb_set_profiling(oslam_orb_t* h, int on);
+int oslam_orb_get_profile(oslam_orb_t* h, double ms[5], long long* batches, long long* images);
+
 /* Work model of one extract call: algorithmic bytes per image. */
 int64_t oslam_orb_algorithmic_bytes(const oslam_orb_t* h, int n_keypoints);
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher — replaces the projection searches of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:41-83)
+ * and the Frame grid they query (src/Frame.cc:455-470 AssignFeaturesToGrid, :567-620
+ * GetFeaturesInArea, :622-632 PosInGrid).  Constants TH_HIGH=100, TH_LOW=50, HISTO_LENGTH=30
+ * (src/ORBmatcher.cc:37-39).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oslam_matcher oslam_matcher_t;
+
+/* One projected map point: what SearchByProjection reads from the MapPoint (mTrackProjX/Y/XR,
+ * mnTrackScaleLevel, GetDescriptor(), Observations()) or computes from the last frame. 64 bytes. */
+typedef struct oslam_proj_query {
+    float u, v;            /* mTrackProjX, mTrackProjY (src/ORBmatcher.cc:67) / projection (:1370-1371) */
+    float ur;              /* mTrackProjXR (:93) / u - mbf*invzc (:1411) */
+    float radius;          /* r*mvScaleFactors[level] (:67) / th*mvScaleFactors[octave] (:1381) */
+    int32_t minLevel, maxLevel; /* GetFeaturesInArea level gate (src/Frame.cc:567) */
+    int32_t flags;         /* bit0: searched (mbTrackInView && !isBad()); bit1: Observations()>0 (blocks
+                              later candidates, src/ORBmatcher.cc:87-89) */
+    float angle;           /* LastFrame.mvKeysUn[i].angle for the rotation histogram (:1432) */
+    uint8_t desc[32];      /* pMP->GetDescriptor() */
+} oslam_proj_query_t;
+
+/* Frame side of a search, batch of frames in HBM (device pointers), fixed per-frame stride. */
+typedef struct oslam_match_frames {
+    const oslam_keypoint_t* keysUn; /* mvKeysUn [batch][kp_stride] */
+    int kp_stride;
+    const float* uRight;            /* mvuRight [batch][kp_stride], NULL = monocular (-1) */
+    const uint8_t* desc;            /* mDescriptors [batch][kp_stride][32] */
+    const uint8_t* blocked;         /* [batch][kp_stride]: mvpMapPoints[i] && Observations()>0 before the call; NULL = none */
+    const int32_t* n_kps;           /* [batch] (device) or NULL -> n_kps_const */
+    int n_kps_const;
+    float minX, minY, maxX, maxY;   /* mnMinX.. (src/Frame.cc:691-702) */
+} oslam_match_frames_t;
+
+/* Last-frame side of SearchByProjection(CurrentFrame, LastFrame, th, bMono) (src/ORBmatcher.cc:1328). */
+typedef struct oslam_match_last {
+    const float* Xw;                /* [batch][kp_stride][3] pMP->GetWorldPos() */
+    const uint8_t* has_mp;          /* bit0: mvpMapPoints[i] && !mvbOutlier[i]; bit1: Observations()>0 */
+    const oslam_keypoint_t* keys;   /* LastFrame.mvKeysUn (octave, angle) */
+    const uint8_t* mp_desc;         /* [batch][kp_stride][32] pMP->GetDescriptor() */
+    int kp_stride;
+    const int32_t* n_kps;           /* [batch] (device) or NULL -> n_kps_const */
+    int n_kps_const;
+} oslam_match_last_t;
+
+typedef struct oslam_camera { float fx, fy, cx, cy, bf, b; } oslam_camera_t;
+
+/* max_keypoints <= 2400: one frame's keypoints, descriptors and 64x48 grid live in 160 KiB of LDS. */
+int oslam_matcher_create(oslam_matcher_t** out, int max_batch, int max_keypoints, int max_queries, int device);
+void oslam_matcher_destroy(oslam_matcher_t* h);
+
+/* Windowed Hamming search with the reference's sequential claim order (a later query skips a keypoint
+ * claimed by an earlier observed map point).  use_ratio=1, check_ori=0: SearchByProjection(Frame&,
+ * vector<MapPoint*>&, th) (src/ORBmatcher.cc:45-129).  use_ratio=0: the search half of
+ * SearchByProjection(Cur, Last) (:1394-1467).  d_queries NULL = the handle's internal query buffer
+ * (filled by oslam_match_project_last_batch_device).  Asynchronous on `stream`. */
+int oslam_match_search_batch_device(oslam_matcher_t* h, const oslam_match_frames_t* frames,
+                                    const oslam_proj_query_t* d_queries, int q_stride, const int32_t* d_n_queries,
+                                    int n_queries_const, int batch, float nnratio, int use_ratio, int check_ori,
+                                    int th_high, void* stream);
+/* Projection half of SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1338-1392): fills the internal
+ * query buffer (stride last->kp_stride) from the last frame's map points. d_Tcw/d_Tlw: [batch][16]
+ * row-major float (cv::Mat CV_32F mTcw). */
+int oslam_match_project_last_batch_device(oslam_matcher_t* h, const oslam_match_last_t* last, const float* d_Tcw,
+                                          const float* d_Tlw, const oslam_camera_t* cam,
+                                          const oslam_match_frames_t* cur, const float* scaleFactors, int nlevels,
+                                          float th, int bMono, int batch, void* stream);
+/* Device results of the last search: q_match/q_dist [batch][q_stride] (keypoint index or -1, Hamming
+ * distance), kp_match [batch][max_keypoints] (query index now held in mvpMapPoints[k]; -1 untouched;
+ * -2 set to NULL by the rotation check), nmatches [batch] (return value of the reference call). */
+int oslam_match_results_device(const oslam_matcher_t* h, const int32_t** q_match, const int32_t** q_dist,
+                               const int32_t** kp_match, const int32_t** nmatches,
+                               const oslam_proj_query_t** queries, const int32_t** n_queries);
+int oslam_match_fetch(oslam_matcher_t* h, int b, int q_stride, int n_queries, int kp_stride, int n_kps,
+                      int32_t* q_match, int32_t* q_dist, int32_t* kp_match, int32_t* nmatches,
+                      int32_t* iterations, void* stream);
+
+/* Host drop-ins (one frame, host buffers in and out). bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY}. */
+int oslam_match_search_by_projection(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn,
+                                     const float* uRight, const uint8_t* desc, const uint8_t* blocked,
+                                     const float bounds[4], const oslam_proj_query_t* queries, int M,
+                                     float nnratio, int use_ratio, int check_ori, int32_t* q_match,
+                                     int32_t* q_dist, int32_t* kp_match, int32_t* nmatches);
+int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn, const float* uRight,
+                                   const uint8_t* desc, const uint8_t* blocked, const float bounds[4], int Nlast,
+                                   const float* Xw, const uint8_t* has_mp, const oslam_keypoint_t* last_keys,
+                                   const uint8_t* mp_desc, const float Tcw[16], const float Tlw[16],
+                                   const oslam_camera_t* cam, const float* scaleFactors, int nlevels, float th,
+                                   int bMono, int check_ori, int32_t* q_match, int32_t* q_dist,
+                                   int32_t* kp_match, int32_t* nmatches);
+int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,13 @@ struct oslam_orb {
     int* d_status = nullptr;
     size_t oct_lds = 0;
 
+    // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
+    int profiling = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double prof_ms[5] = {0, 0, 0, 0, 0};
+    long long prof_batches = 0, prof_images = 0;
+    bool prof_pending = false;
+
     // last batch
     OrbCtx ctx;
     int last_batch = 0;
@@ -104,6 +111,8 @@ void oslam_orb_destroy(oslam_orb_t* h) {
                     h->d_out_count, h->d_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : h->ev)
+        if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -322,6 +331,20 @@ int oslam_orb_set_blur_rounding(oslam_orb_t* h, int sse2) {
     return OSLAM_OK;
 }
 
+static int collect_profile(oslam_orb* h) {
+    if (!h->prof_pending) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipEventSynchronize(h->ev[5]));
+    for (int i = 0; i < 5; i++) {
+        float ms = 0;
+        OSLAM_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        h->prof_ms[i] += ms;
+    }
+    h->prof_batches++;
+    h->prof_images += h->last_batch;
+    h->prof_pending = false;
+    return OSLAM_OK;
+}
+
 static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stride, size_t image_stride, hipStream_t st) {
     const OrbParams& P = h->P;
     OrbCtx c;
@@ -332,21 +355,35 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.rtab = h->d_rtab; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
     c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
     c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status;
+    const bool prof = h->profiling != 0;
+    if (prof) {
+        int rc = collect_profile(h);   // previous batch, if not collected yet
+        if (rc) return rc;
+    }
     h->ctx = c; h->last_batch = batch; h->last_stream = st;
+#define PROF_MARK(i) do { if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[i], st)); } while (0)
 
+    PROF_MARK(0);
     for (int l = 1; l < P.nlevels; l++) {
         const LevelGeom& g = P.lv[l];
         dim3 grid(div_up(g.w, 256), div_up(g.h, 4), batch);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
+    PROF_MARK(1);
     hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
+    PROF_MARK(2);
     for (int l = 0; l < P.nlevels; l++) {
         const LevelGeom& g = P.lv[l];
         dim3 grid(div_up(g.w, kBlurTW), div_up(g.h, kBlurTH), batch);
         hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, c, l, h->blur_sse2);
     }
+    PROF_MARK(3);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
+    PROF_MARK(4);
     hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4), batch), dim3(256), 0, st, c);
+    PROF_MARK(5);
+#undef PROF_MARK
+    if (prof) h->prof_pending = true;
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
@@ -414,6 +451,27 @@ int oslam_orb_extract(oslam_orb_t* h, const uint8_t* gray, int width, int height
     int rc = launch_batch(h, h->d_stage, 1, h->stage_pitch, (size_t)h->stage_pitch * height, nullptr);
     if (rc) return rc;
     return oslam_orb_fetch(h, 0, kps, desc, cap, n_out);
+}
+
+int oslam_orb_set_profiling(oslam_orb_t* h, int on) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (on && !h->ev[0])
+        for (int i = 0; i < 6; i++) OSLAM_HIP_CHECK(hipEventCreate(&h->ev[i]));
+    h->profiling = on != 0;
+    for (int i = 0; i < 5; i++) h->prof_ms[i] = 0;
+    h->prof_batches = 0; h->prof_images = 0; h->prof_pending = false;
+    return OSLAM_OK;
+}
+
+int oslam_orb_get_profile(oslam_orb_t* h, double ms[5], long long* batches, long long* images) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    int rc = collect_profile(h);
+    if (rc) return rc;
+    for (int i = 0; i < 5; i++) ms[i] = h->prof_ms[i];
+    if (batches) *batches = h->prof_batches;
+    if (images) *images = h->prof_images;
+    return OSLAM_OK;
 }
 
 int oslam_orb_level_size(const oslam_orb_t* h, int level, int* w, int* hh) {

@@ -121,3 +121,13 @@ class ORBextractor:
 
     def algorithmic_bytes(self, n_keypoints):
         return int(self.L.oslam_orb_algorithmic_bytes(self.h, n_keypoints))
+
+    def set_profiling(self, on):
+        check(self.L.oslam_orb_set_profiling(self.h, int(on)))
+
+    def get_profile(self):
+        """Returns (ms[5] accumulated per kernel group, batches, images)."""
+        ms = (C.c_double * 5)()
+        nb, ni = C.c_longlong(), C.c_longlong()
+        check(self.L.oslam_orb_get_profile(self.h, ms, C.byref(nb), C.byref(ni)))
+        return list(ms), nb.value, ni.value

@@ -1,0 +1,229 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+#include "matcher_oracle.h"
+
+#include <algorithm>
+
+namespace oracle {
+
+// reference src/ORBmatcher.cc:1647-1663
+int DescriptorDistance(const uint8_t* a, const uint8_t* b) {
+    int32_t pa[8], pb[8];
+    memcpy(pa, a, 32);
+    memcpy(pb, b, 32);
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned int v = pa[i] ^ pb[i];
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+// reference src/Frame.cc:455-470, :622-632, grid constants :160-161
+void Grid::build(const FrameView& f) {
+    minX = f.minX;
+    minY = f.minY;
+    invW = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(f.maxX - f.minX);
+    invH = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(f.maxY - f.minY);
+    for (int i = 0; i < FRAME_GRID_COLS; i++)
+        for (int j = 0; j < FRAME_GRID_ROWS; j++) cells[i][j].clear();
+    for (int i = 0; i < f.N; i++) {
+        const KeyPoint& kp = f.keysUn[i];
+        int posX = round((kp.x - minX) * invW);
+        int posY = round((kp.y - minY) * invH);
+        if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) continue;
+        cells[posX][posY].push_back(i);
+    }
+}
+
+// reference src/Frame.cc:567-620
+std::vector<int> Grid::area(const FrameView& f, float x, float y, float r, int minLevel, int maxLevel) const {
+    std::vector<int> vIndices;
+    const int nMinCellX = std::max(0, (int)floor((x - minX - r) * invW));
+    if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)ceil((x - minX + r) * invW));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)floor((y - minY - r) * invH));
+    if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)ceil((y - minY + r) * invH));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const std::vector<int>& vCell = cells[ix][iy];
+            for (size_t j = 0; j < vCell.size(); j++) {
+                const KeyPoint& kpUn = f.keysUn[vCell[j]];
+                if (bCheckLevels) {
+                    if (kpUn.octave < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (kpUn.octave > maxLevel) continue;
+                }
+                const float distx = kpUn.x - x;
+                const float disty = kpUn.y - y;
+                if (fabs(distx) < r && fabs(disty) < r) vIndices.push_back(vCell[j]);
+            }
+        }
+    }
+    return vIndices;
+}
+
+// reference src/ORBmatcher.cc:1601-1642
+void ComputeThreeMaxima(const int* histo, int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+// reference src/ORBmatcher.cc:45-129 (use_ratio) and :1394-1467 (best only + rotation histogram)
+int SearchByProjection(const FrameView& f, const ProjQuery* q, int M, float nnratio, int use_ratio, int check_ori,
+                       int* q_match, int* q_dist, int* kp_match) {
+    Grid grid;
+    grid.build(f);
+    int nmatches = 0;
+    // mvpMapPoints model: holder[k] = query index holding keypoint k, -1 = pre-existing / none
+    std::vector<int> holder(f.N, -1);
+    std::vector<uint8_t> blocked(f.blocked, f.blocked + f.N);
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int k = 0; k < f.N; k++) kp_match[k] = -1;
+
+    for (int i = 0; i < M; i++) {
+        q_match[i] = -1;
+        q_dist[i] = 256;
+        const ProjQuery& p = q[i];
+        if (!(p.flags & 1)) continue;
+        const std::vector<int> vIndices = grid.area(f, p.u, p.v, p.radius, p.minLevel, p.maxLevel);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (size_t c = 0; c < vIndices.size(); c++) {
+            const int idx = vIndices[c];
+            if (blocked[idx]) continue;   // mvpMapPoints[idx] && Observations()>0
+            if (f.uRight[idx] > 0) {
+                const float er = fabs(p.ur - f.uRight[idx]);
+                if (er > p.radius) continue;
+            }
+            const int dist = DescriptorDistance(p.desc, f.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = f.keysUn[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = f.keysUn[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (use_ratio && bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            holder[bestIdx] = i;
+            blocked[bestIdx] = (p.flags & 2) ? 1 : 0;   // the new holder decides whether it blocks
+            q_match[i] = bestIdx;
+            q_dist[i] = bestDist;
+            nmatches++;
+            if (check_ori) {
+                float rot = p.angle - f.keysUn[bestIdx].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx);
+            }
+        }
+    }
+    for (int k = 0; k < f.N; k++) kp_match[k] = holder[k];
+    if (check_ori) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        int sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (size_t j = 0; j < rotHist[i].size(); j++) {
+                    kp_match[rotHist[i][j]] = -2;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
+// cv::Mat float product + add as one cv::gemm call (GEMMSingleMul<float,double>): double
+// accumulation, one rounding to float.  d = (float)(sum_k a[k]*b[k] + c).
+static inline float gemm_row(const float* a, const float* x, float c) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)x[k];
+    return (float)(s + (double)c);
+}
+
+// reference src/ORBmatcher.cc:1338-1392
+void ProjectLastFrame(const LastFrameView& last, const float* Tcw, const float* Tlw, float fx, float fy, float cx,
+                      float cy, float bf, float b, const FrameView& cur, const float* scaleFactors, float th,
+                      int bMono, ProjQuery* out) {
+    float Rcw[3][3], tcw[3], Rlw[3][3], tlw[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) { Rcw[r][c] = Tcw[r * 4 + c]; Rlw[r][c] = Tlw[r * 4 + c]; }
+        tcw[r] = Tcw[r * 4 + 3];
+        tlw[r] = Tlw[r * 4 + 3];
+    }
+    // twc = -Rcw.t()*tcw ; tlc = Rlw*twc + tlw
+    float twc[3], tlc[3];
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)Rcw[k][r] * (double)tcw[k];
+        twc[r] = (float)(-1.0 * s);
+    }
+    for (int r = 0; r < 3; r++) tlc[r] = gemm_row(Rlw[r], twc, tlw[r]);
+    const bool bForward = tlc[2] > b && !bMono;
+    const bool bBackward = -tlc[2] > b && !bMono;
+
+    for (int i = 0; i < last.N; i++) {
+        ProjQuery& q = out[i];
+        memset(&q, 0, sizeof(q));
+        q.minLevel = -1;
+        q.maxLevel = -1;
+        if (!(last.has_mp[i] & 1)) continue;
+        const float* X = last.Xw + 3 * i;
+        const float xc = gemm_row(Rcw[0], X, tcw[0]);
+        const float yc = gemm_row(Rcw[1], X, tcw[1]);
+        const float zc = gemm_row(Rcw[2], X, tcw[2]);
+        const float invzc = 1.0 / zc;
+        if (invzc < 0) continue;
+        float u = fx * xc * invzc + cx;
+        float v = fy * yc * invzc + cy;
+        if (u < cur.minX || u > cur.maxX) continue;
+        if (v < cur.minY || v > cur.maxY) continue;
+        const int nLastOctave = last.keys[i].octave;
+        const float radius = th * scaleFactors[nLastOctave];
+        if (bForward) { q.minLevel = nLastOctave; q.maxLevel = -1; }
+        else if (bBackward) { q.minLevel = 0; q.maxLevel = nLastOctave; }
+        else { q.minLevel = nLastOctave - 1; q.maxLevel = nLastOctave + 1; }
+        q.u = u;
+        q.v = v;
+        q.ur = u - bf * invzc;
+        q.radius = radius;
+        q.flags = 1 | ((last.has_mp[i] & 2) ? 2 : 0);
+        q.angle = last.keys[i].angle;
+        memcpy(q.desc, last.mp_desc + (size_t)i * 32, 32);
+    }
+}
+
+}  // namespace oracle

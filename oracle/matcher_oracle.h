@@ -1,0 +1,69 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).
+// CPU restatement of the Frame grid (reference src/Frame.cc:455-470,567-632) and of
+// ORBmatcher::SearchByProjection (reference src/ORBmatcher.cc:45-137, :1328-1470, :1601-1663).
+// All arithmetic of these functions is in-tree reference code, so this restatement is exact.
+#pragma once
+#include "oracle_common.h"
+
+namespace oracle {
+
+constexpr int FRAME_GRID_ROWS = 48;  // reference include/Frame.h:43
+constexpr int FRAME_GRID_COLS = 64;  // :44
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // src/ORBmatcher.cc:37-39
+
+// One projected map point (what SearchByProjection reads from MapPoint / computes per point).
+struct ProjQuery {
+    float u, v;        // mTrackProjX/Y (:67) or projected u,v (:1370-1371)
+    float ur;          // mTrackProjXR (:93) or u - mbf*invzc (:1411)
+    float radius;      // r*mvScaleFactors[level] (:67) or th*mvScaleFactors[octave] (:1381)
+    int32_t minLevel, maxLevel;  // level gate handed to GetFeaturesInArea
+    int32_t flags;     // bit0 valid (mbTrackInView && !isBad, or projected inside the image);
+                       // bit1 the map point has Observations()>0 (blocks later queries, :87-89)
+    float angle;       // LastFrame.mvKeysUn[i].angle (:1432)
+    uint8_t desc[32];
+};
+static_assert(sizeof(ProjQuery) == 64, "ProjQuery layout");
+
+struct FrameView {
+    int N;
+    const KeyPoint* keysUn;   // mvKeysUn
+    const float* uRight;      // mvuRight
+    const uint8_t* desc;      // mDescriptors, N x 32
+    const uint8_t* blocked;   // mvpMapPoints[i] && Observations()>0 before the call
+    float minX, minY, maxX, maxY;  // mnMinX ... (src/Frame.cc:691-702)
+};
+
+int DescriptorDistance(const uint8_t* a, const uint8_t* b);  // src/ORBmatcher.cc:1647-1663
+
+struct Grid {
+    float minX, minY, invW, invH;
+    std::vector<int> cells[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    void build(const FrameView& f);  // AssignFeaturesToGrid + PosInGrid
+    // GetFeaturesInArea (src/Frame.cc:567-620)
+    std::vector<int> area(const FrameView& f, float x, float y, float r, int minLevel, int maxLevel) const;
+};
+
+// Windowed search shared by SearchByProjection(F, vpMapPoints) [use_ratio=1, check_ori=0] and
+// SearchByProjection(Cur, Last) [use_ratio=0, check_ori=mbCheckOrientation].
+// q_match[i] = keypoint claimed by query i (or -1), q_dist[i] = its Hamming distance,
+// kp_match[k] = query whose map point ends up in mvpMapPoints[k]; -1 untouched; -2 set to NULL by
+// the rotation-consistency pass.  Returns nmatches.
+int SearchByProjection(const FrameView& f, const ProjQuery* q, int M, float nnratio, int use_ratio, int check_ori,
+                       int* q_match, int* q_dist, int* kp_match);
+
+// Projection front half of SearchByProjection(Cur, Last) (src/ORBmatcher.cc:1338-1392): builds the
+// queries from the last frame's map points.  Tcw / Tlw are row-major 4x4 float (cv::Mat CV_32F).
+struct LastFrameView {
+    int N;
+    const float* Xw;          // [N][3] world position of mvpMapPoints[i] (ignored if !has_mp[i])
+    const uint8_t* has_mp;    // bit0: mvpMapPoints[i] && !mvbOutlier[i]; bit1: Observations()>0
+    const KeyPoint* keys;     // mvKeys (octave) == mvKeysUn octave/angle
+    const uint8_t* mp_desc;   // [N][32] pMP->GetDescriptor()
+};
+void ProjectLastFrame(const LastFrameView& last, const float* Tcw, const float* Tlw, float fx, float fy, float cx,
+                      float cy, float bf, float b, const FrameView& cur, const float* scaleFactors, float th,
+                      int bMono, ProjQuery* out);
+
+void ComputeThreeMaxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3);  // :1601-1642
+
+}  // namespace oracle

@@ -104,3 +104,35 @@ float oo_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 const int8_t* oo_brief_pattern() { return brief_pattern(); }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+#include "matcher_oracle.h"
+extern "C" {
+int oo_descriptor_distance(const uint8_t* a, const uint8_t* b) { return DescriptorDistance(a, b); }
+
+int oo_search_by_projection(int N, const KeyPoint* keysUn, const float* uRight, const uint8_t* desc,
+                            const uint8_t* blocked, const float* bounds /*minX,minY,maxX,maxY*/, const ProjQuery* q,
+                            int M, float nnratio, int use_ratio, int check_ori, int* q_match, int* q_dist,
+                            int* kp_match) {
+    FrameView f{N, keysUn, uRight, desc, blocked, bounds[0], bounds[1], bounds[2], bounds[3]};
+    return SearchByProjection(f, q, M, nnratio, use_ratio, check_ori, q_match, q_dist, kp_match);
+}
+
+void oo_project_last_frame(int N, const float* Xw, const uint8_t* has_mp, const KeyPoint* keys, const uint8_t* mp_desc,
+                           const float* Tcw, const float* Tlw, const float* K /*fx,fy,cx,cy,bf,b*/,
+                           const float* bounds, const float* scaleFactors, float th, int bMono, ProjQuery* out) {
+    LastFrameView last{N, Xw, has_mp, keys, mp_desc};
+    FrameView cur{0, nullptr, nullptr, nullptr, nullptr, bounds[0], bounds[1], bounds[2], bounds[3]};
+    ProjectLastFrame(last, Tcw, Tlw, K[0], K[1], K[2], K[3], K[4], K[5], cur, scaleFactors, th, bMono, out);
+}
+
+int oo_features_in_area(int N, const KeyPoint* keysUn, const float* bounds, float x, float y, float r, int minLevel,
+                        int maxLevel, int* out, int cap) {
+    FrameView f{N, keysUn, nullptr, nullptr, nullptr, bounds[0], bounds[1], bounds[2], bounds[3]};
+    Grid g;
+    g.build(f);
+    auto v = g.area(f, x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = v[i];
+    return (int)v.size();
+}
+}

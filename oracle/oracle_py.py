@@ -147,3 +147,56 @@ def fast_atan2(y, x):
 def brief_pattern():
     p = lib().oo_brief_pattern()
     return np.ctypeslib.as_array(p, shape=(1024,)).copy()
+
+
+# ---------------------------------------------------------------------------------------------
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("minLevel", "<i4"),
+                        ("maxLevel", "<i4"), ("flags", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().oo_descriptor_distance(_p(a), _p(b))
+
+
+def search_by_projection(keysUn, uRight, desc, blocked, bounds, queries, nnratio, use_ratio, check_ori):
+    keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+    N, M = len(keysUn), len(queries)
+    uR = np.full(N, -1, np.float32) if uRight is None else np.ascontiguousarray(uRight, np.float32)
+    bl = np.zeros(N, np.uint8) if blocked is None else np.ascontiguousarray(blocked, np.uint8)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+    bnd = np.asarray(bounds, np.float32)
+    qm, qd = np.full(max(M, 1), -1, np.int32), np.full(max(M, 1), 256, np.int32)
+    km = np.full(max(N, 1), -1, np.int32)
+    L = lib()
+    L.oo_search_by_projection.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 3
+    nm = L.oo_search_by_projection(N, _p(keysUn), _p(uR), _p(desc), _p(bl), _p(bnd), _p(queries), M, nnratio,
+                                   int(use_ratio), int(check_ori), _p(qm), _p(qd), _p(km))
+    return nm, qm[:M], qd[:M], km[:N]
+
+
+def project_last_frame(Xw, has_mp, keys, mp_desc, Tcw, Tlw, cam, bounds, scaleFactors, th, bMono):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    N = len(keys)
+    out = np.zeros(max(N, 1), QUERY_DTYPE)
+    L = lib()
+    L.oo_project_last_frame.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_void_p]
+    L.oo_project_last_frame(N, _p(np.ascontiguousarray(Xw, np.float32)), _p(np.ascontiguousarray(has_mp, np.uint8)),
+                            _p(keys), _p(np.ascontiguousarray(mp_desc, np.uint8)),
+                            _p(np.ascontiguousarray(Tcw, np.float32)), _p(np.ascontiguousarray(Tlw, np.float32)),
+                            _p(np.asarray(cam, np.float32)), _p(np.asarray(bounds, np.float32)),
+                            _p(np.ascontiguousarray(scaleFactors, np.float32)), th, int(bMono), _p(out))
+    return out[:N]
+
+
+def features_in_area(keysUn, bounds, x, y, r, minLevel=-1, maxLevel=-1):
+    keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+    out = np.zeros(len(keysUn) + 1, np.int32)
+    L = lib()
+    L.oo_features_in_area.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int]
+    n = L.oo_features_in_area(len(keysUn), _p(keysUn), _p(np.asarray(bounds, np.float32)), x, y, r, minLevel, maxLevel,
+                              _p(out), len(out))
+    return out[:n]
