@@ -93,3 +93,25 @@ def test_batch_equals_single(oracle):
             np.testing.assert_array_equal(k[f], ok[f])
         np.testing.assert_array_equal(de, od)
     ex.close()
+
+
+def test_golden_fixture_frontend():
+    """HIP path vs the committed golden vectors (tests/golden/gen_golden.py), no oracle involved."""
+    import os
+    from object_slam_amd import ORBmatcher
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frontend_320x240.npz"))
+    ex = ORBextractor(300, 1.2, 5, 20, 7, 320, 240)
+    k0, d0 = ex(z["frame0"])
+    k1, d1 = ex(z["frame1"])
+    assert k0.tobytes() == z["k0"].tobytes() and k1.tobytes() == z["k1"].tobytes()
+    np.testing.assert_array_equal(d0, z["d0"])
+    np.testing.assert_array_equal(d1, z["d1"])
+    m = ORBmatcher(0.9, True, max_keypoints=ex.cap, max_queries=ex.cap)
+    nm, qm, qd, km = m.search_last_frame(k1, z["uR"], d1, None, tuple(z["bounds"]), z["Xw"], z["has"], k0, d0, z["Tcw"],
+                                         z["Tlw"], tuple(z["cam"]), z["scale"], 15.0, False)
+    assert nm == int(z["nm"])
+    np.testing.assert_array_equal(qm, z["qm"]); np.testing.assert_array_equal(qd, z["qd"]); np.testing.assert_array_equal(km, z["km"])
+    m2 = ORBmatcher(0.8, True, max_keypoints=ex.cap, max_queries=ex.cap)
+    nm2, qm2, qd2, km2 = m2.search_window(k1, z["uR"], d1, None, tuple(z["bounds"]), z["queries"], True, False)
+    assert nm2 == int(z["nm2"])
+    np.testing.assert_array_equal(qm2, z["qm2"]); np.testing.assert_array_equal(km2, z["km2"])
