@@ -199,6 +199,32 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
                                    int32_t* kp_match, int32_t* nmatches);
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer::PoseOptimization — motion-only BA (include/Optimizer.h:46, src/Optimizer.cc:239-451):
+ * 4 rounds x optimize(10) of g2o Levenberg-Marquardt on one SE3 vertex, Huber(sqrt(5.991) mono,
+ * sqrt(7.815) stereo) dropped after round index 2, chi2 re-classification after every round, every
+ * round restarted from the input pose.  State is float32 at the boundary (cv::Mat CV_32F), fp64
+ * inside (Converter::toSE3Quat / toCvMat, src/Converter.cc:38-72).
+ * Per keypoint i: has_mp[i] = pFrame->mvpMapPoints[i] != NULL, Xw = pMP->GetWorldPos(),
+ * obs = (mvKeysUn[i].pt.x, .pt.y, mvuRight[i]) with mvuRight < 0 => monocular edge,
+ * invSigma2 = mvInvLevelSigma2[mvKeysUn[i].octave].  K5 = {fx, fy, cx, cy, mbf}.
+ * Outputs: pose (pFrame->SetPose), outlier[i] = mvbOutlier[i], n_inliers = return value
+ * (nInitialCorrespondences - nBad; 0 and pose untouched if < 3 correspondences).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oslam_poseopt oslam_poseopt_t;
+int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, int device);
+void oslam_poseopt_destroy(oslam_poseopt_t* h);
+int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs,
+                        const float* invSigma2, const uint8_t* has_mp, const float K5[5], float Tcw_out[16],
+                        uint8_t* outlier, int32_t* n_inliers, int32_t stats[2] /* LM iterations, trials; may be NULL */);
+/* Batch of independent frames in HBM (device pointers, per-frame stride in points). Asynchronous. */
+int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, int n_const,
+                                     const float* d_Tcw, const float* d_Xw, const float* d_obs,
+                                     const float* d_invSigma2, const uint8_t* d_has_mp, const float K5[5],
+                                     void* stream);
+int oslam_poseopt_results_device(const oslam_poseopt_t* h, const float** d_Tcw_out, const uint8_t** d_outlier,
+                                 const int32_t** d_n_inliers, const int32_t** d_stats);
+
 #ifdef __cplusplus
 }
 #endif

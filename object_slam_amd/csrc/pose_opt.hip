@@ -1,0 +1,364 @@
+// gfx950 motion-only bundle adjustment: Optimizer::PoseOptimization (reference
+// src/Optimizer.cc:239-451) with the g2o Levenberg-Marquardt loop it drives,
+// one 256-thread workgroup per frame, whole 4 x optimize(10) schedule in a single launch.
+// Per-edge residuals / Jacobians / Huber weights in fp64, block reduction of the 6x6 normal
+// equations (21 + 6 + 1 doubles), in-register 6x6 Cholesky, everything wave-uniform after the
+// reduction so no broadcast is needed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "se3_math.h"
+
+namespace oslam {
+
+constexpr int kPoseThreads = 256;
+constexpr int kPoseWaves = kPoseThreads / 64;
+constexpr int kRedN = 29;   // 21 H (upper) + 6 b + chi + 1 spare
+
+struct PoseCtx {
+    const float* Tcw;        // [B][16]
+    const float* Xw;         // [B][stride][3]
+    const float* obs;        // [B][stride][3]  (u, v, uR; uR < 0 => monocular edge)
+    const float* invSigma2;  // [B][stride]
+    const uint8_t* has_mp;   // [B][stride]
+    const int* n; int n_const; int stride;
+    float fx, fy, cx, cy, bf;
+    float* Tcw_out;          // [B][16]
+    uint8_t* outlier;        // [B][stride]
+    int* n_inliers;          // [B]
+    int* stats;              // [B][2] LM iterations, trials
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Block-wide sums of NV doubles; every thread returns the same totals (fixed summation order).
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [2][kPoseWaves][kRedN] */, int& phase) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* buf = s_red + phase * kPoseWaves * kRedN;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const double s = wave_sum(v[i]);
+        if (lane == 0) buf[wv * kRedN + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        double s = buf[i];
+#pragma unroll
+        for (int w = 1; w < kPoseWaves; w++) s += buf[w * kRedN + i];
+        v[i] = s;
+    }
+    phase ^= 1;   // next reduction uses the other buffer: one barrier per reduction is enough
+}
+
+__global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = c.n ? c.n[b] : c.n_const;
+    const float* Xw = c.Xw + (long long)b * c.stride * 3;
+    const float* obsp = c.obs + (long long)b * c.stride * 3;
+    const float* inv = c.invSigma2 + (long long)b * c.stride;
+    const uint8_t* has = c.has_mp + (long long)b * c.stride;
+    uint8_t* outl = c.outlier + (long long)b * c.stride;
+    const float* T0f = c.Tcw + b * 16;
+
+    extern __shared__ __align__(16) uint8_t smem[];
+    double* s_chi2 = (double*)smem;                         // [stride] _error chi2 as last computed (may be stale)
+    uint8_t* s_level = (uint8_t*)(s_chi2 + c.stride);       // [stride] 0 active, 1 excluded, 255 no edge
+    __shared__ double s_red[2 * kPoseWaves * kRedN];
+    __shared__ int s_cnt[2];
+    int phase = 0;
+
+    const Cam cam = {(double)c.fx, (double)c.fy, (double)c.cx, (double)c.cy, (double)c.bf};
+    const double deltaMono = (double)(float)sqrt(5.991), deltaStereo = (double)(float)sqrt(7.815);
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+
+    if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    int ncorr = 0;
+    for (int i = tid; i < N; i += kPoseThreads) {
+        const bool h = has[i] != 0;
+        s_level[i] = h ? 0 : 255;
+        s_chi2[i] = 0;
+        outl[i] = 0;   // mvbOutlier[i] = false (:289,:323); entries without a map point are reported 0
+        if (h) ncorr++;
+    }
+    if (ncorr) atomicAdd(&s_cnt[0], ncorr);
+    __syncthreads();
+    const int nInitial = s_cnt[0];
+    if (nInitial < 3) {   // reference :364-365: return 0, pose untouched
+        if (tid < 16) c.Tcw_out[b * 16 + tid] = T0f[tid];
+        if (tid == 0) { c.n_inliers[b] = 0; if (c.stats) { c.stats[b * 2] = 0; c.stats[b * 2 + 1] = 0; } }
+        return;
+    }
+
+    const SE3 T0 = se3_from_T(T0f);
+    SE3 T = T0;
+    int nBad = 0, tot_its = 0, tot_trials = 0;
+
+    // residual pass over the active edges at pose P: stores chi2 per edge, returns sum of robust chi2
+    auto eval = [&](const SE3& P, bool robust) -> double {
+        double F = 0;
+        for (int i = tid; i < N; i += kPoseThreads) {
+            if (s_level[i] != 0) continue;
+            const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
+            const float ur = obsp[i * 3 + 2];
+            const bool stereo = !(ur < 0);
+            const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
+            double p[3], e[3];
+            se3_map(P, X, p);
+            const double c2 = edge_error(cam, p, ob, stereo, (double)inv[i], e);
+            s_chi2[i] = c2;
+            if (robust) {
+                double r0, r1;
+                huber(c2, stereo ? deltaStereo : deltaMono, r0, r1);
+                F += r0;
+            } else
+                F += c2;
+        }
+        return F;
+    };
+
+    for (int it = 0; it < 4; it++) {
+        const bool robust = it < 3;   // setRobustKernel(0) after round index 2 (:407,:436)
+        T = T0;                       // every round restarts from the input pose (:377)
+        // initializeOptimization(0): any active edge?
+        int nact = 0;
+        for (int i = tid; i < N; i += kPoseThreads) nact += (s_level[i] == 0);
+        {
+            double v[1] = {(double)nact};
+            block_sum<1>(v, s_red, phase);
+            nact = (int)v[0];
+        }
+        if (nact > 0) {
+            double lambda = 0, ni = 2;
+            for (int iter = 0; iter < 10; iter++) {
+                // computeActiveErrors + activeRobustChi2 + buildSystem in one pass over the edges
+                double acc[kRedN];
+#pragma unroll
+                for (int k = 0; k < kRedN; k++) acc[k] = 0;
+                for (int i = tid; i < N; i += kPoseThreads) {
+                    if (s_level[i] != 0) continue;
+                    const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
+                    const float ur = obsp[i * 3 + 2];
+                    const bool stereo = !(ur < 0);
+                    const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
+                    const double info = (double)inv[i];
+                    double p[3], e[3], J[18];
+                    se3_map(T, X, p);
+                    const double c2 = edge_error(cam, p, ob, stereo, info, e);
+                    s_chi2[i] = c2;
+                    double r0 = c2, w = 1.0;
+                    if (robust) huber(c2, stereo ? deltaStereo : deltaMono, r0, w);
+                    acc[27] += r0;
+                    jac_pose_onlypose(cam, p, stereo, J);
+                    const double wi = w * info;
+                    const int D = stereo ? 3 : 2;
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; a++) {
+                        double sb = 0;
+                        for (int d = 0; d < D; d++) sb += J[d * 6 + a] * (info * e[d]);
+                        acc[21 + a] -= w * sb;
+#pragma unroll
+                        for (int cc = a; cc < 6; cc++) {
+                            double sh = 0;
+                            for (int d = 0; d < D; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
+                            acc[k++] += sh;
+                        }
+                    }
+                }
+                block_sum<kRedN>(acc, s_red, phase);
+                double currentChi = acc[27];
+                double H[36], g[6];
+                {
+                    int k = 0;
+                    for (int a = 0; a < 6; a++)
+                        for (int cc = a; cc < 6; cc++) { H[a * 6 + cc] = acc[k]; H[cc * 6 + a] = acc[k]; k++; }
+                    for (int a = 0; a < 6; a++) g[a] = acc[21 + a];
+                }
+                if (iter == 0) {   // computeLambdaInit: 1e-5 * max |H_jj|
+                    double md = 0;
+                    for (int a = 0; a < 6; a++) md = fmax(fabs(H[a * 7]), md);
+                    lambda = 1e-5 * md;
+                    ni = 2;
+                }
+                double rho = 0;
+                int qmax = 0;
+                do {
+                    double A[36], x[6];
+                    for (int k = 0; k < 36; k++) A[k] = H[k];
+                    for (int a = 0; a < 6; a++) { A[a * 7] += lambda; x[a] = g[a]; }
+                    const bool ok2 = solve6(A, x);
+                    if (!ok2) for (int a = 0; a < 6; a++) x[a] = 0;
+                    const SE3 Tn = se3_mul(se3_exp(x), T);
+                    double v[1] = {eval(Tn, robust)};
+                    block_sum<1>(v, s_red, phase);
+                    double tempChi = v[0];
+                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    rho = currentChi - tempChi;
+                    double scale = 0;
+                    for (int a = 0; a < 6; a++) scale += x[a] * (lambda * x[a] + g[a]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    const bool finite = (tempChi - tempChi) == 0;
+                    if (rho > 0 && finite) {
+                        double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+                        alpha = fmin(alpha, 2. / 3.);
+                        lambda *= fmax(1. / 3., alpha);
+                        ni = 2;
+                        currentChi = tempChi;
+                        T = Tn;
+                    } else {
+                        lambda *= ni;
+                        ni *= 2;
+                    }
+                    qmax++;
+                    tot_trials++;
+                } while (rho < 0 && qmax < 10);
+                tot_its++;
+                if (qmax == 10 || rho == 0) break;   // OptimizationAlgorithm::Terminate
+            }
+        }
+        // inlier / outlier classification (:380-438): excluded edges get a fresh error at the final
+        // pose, active edges keep the error of the last LM trial (g2o's _error buffer)
+        int bad = 0;
+        for (int i = tid; i < N; i += kPoseThreads) {
+            const int lv = s_level[i];
+            if (lv == 255) continue;
+            const float ur = obsp[i * 3 + 2];
+            const bool stereo = !(ur < 0);
+            if (lv == 1) {
+                const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
+                const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
+                double p[3], e[3];
+                se3_map(T, X, p);
+                s_chi2[i] = edge_error(cam, p, ob, stereo, (double)inv[i], e);
+            }
+            const float chi2 = (float)s_chi2[i];
+            if (chi2 > (stereo ? chi2Stereo : chi2Mono)) { s_level[i] = 1; outl[i] = 1; bad++; }
+            else { s_level[i] = 0; outl[i] = 0; }
+        }
+        {
+            double v[1] = {(double)bad};
+            block_sum<1>(v, s_red, phase);
+            nBad = (int)v[0];
+        }
+        if (nInitial < 10) break;   // optimizer.edges().size()<10 (:440)
+    }
+
+    if (tid == 0) {
+        float To[16];
+        se3_to_T(T, To);
+        for (int k = 0; k < 16; k++) c.Tcw_out[b * 16 + k] = To[k];
+        c.n_inliers[b] = nInitial - nBad;
+        if (c.stats) { c.stats[b * 2] = tot_its; c.stats[b * 2 + 1] = tot_trials; }
+    }
+}
+
+}  // namespace oslam
+
+using namespace oslam;
+
+struct oslam_poseopt {
+    int device = 0, max_batch = 0, max_points = 0;
+    float* d_Tout = nullptr; uint8_t* d_outlier = nullptr; int* d_ninl = nullptr; int* d_stats = nullptr;
+    // staging for the host API
+    float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
+};
+
+extern "C" {
+
+void oslam_poseopt_destroy(oslam_poseopt_t* h) {
+    if (!h) return;
+    void* ptrs[] = {h->d_Tout, h->d_outlier, h->d_ninl, h->d_stats, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, int device) {
+    if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
+    *out = nullptr;
+    if (max_batch < 1 || max_points < 1 || max_points > 16000) { set_error("oslam_poseopt_create: invalid argument (max_points <= 16000)"); return OSLAM_E_INVALID; }
+    int ndev = oslam_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible: the gfx950 pose optimiser has no CPU fallback"); return OSLAM_E_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(device));
+    oslam_poseopt* h = new oslam_poseopt();
+    h->device = device; h->max_batch = max_batch; h->max_points = max_points;
+    const size_t B = max_batch, NP = max_points;
+#define ALLOC(ptr, bytes)                                                         \
+    do {                                                                          \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                       \
+        if (e_ != hipSuccess) {                                                   \
+            set_error("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+            oslam_poseopt_destroy(h);                                             \
+            return OSLAM_E_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+    ALLOC(h->d_Tout, B * 64); ALLOC(h->d_outlier, B * NP); ALLOC(h->d_ninl, B * 4); ALLOC(h->d_stats, B * 8);
+    ALLOC(h->d_T, 64); ALLOC(h->d_Xw, NP * 12); ALLOC(h->d_obs, NP * 12); ALLOC(h->d_inv, NP * 4); ALLOC(h->d_has, NP);
+#undef ALLOC
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
+    *out = h;
+    return OSLAM_OK;
+}
+
+int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, int n_const, const float* d_Tcw,
+                                     const float* d_Xw, const float* d_obs, const float* d_invSigma2, const uint8_t* d_has_mp,
+                                     const float K5[5], void* stream) {
+    if (!h || !d_Tcw || !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp || !K5) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (batch < 1 || batch > h->max_batch) { set_error("batch %d outside [1,%d]", batch, h->max_batch); return OSLAM_E_INVALID; }
+    if (stride < 1 || stride > h->max_points || (!d_n && (n_const < 0 || n_const > stride))) { set_error("stride/n exceed max_points %d", h->max_points); return OSLAM_E_CAPACITY; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    PoseCtx c;
+    c.Tcw = d_Tcw; c.Xw = d_Xw; c.obs = d_obs; c.invSigma2 = d_invSigma2; c.has_mp = d_has_mp;
+    c.n = d_n; c.n_const = n_const; c.stride = stride;
+    c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    const size_t lds = (size_t)stride * 9 + 64;
+    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(kPoseThreads), lds, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_poseopt_results_device(const oslam_poseopt_t* h, const float** d_Tcw_out, const uint8_t** d_outlier, const int32_t** d_n_inliers,
+                                 const int32_t** d_stats) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    if (d_Tcw_out) *d_Tcw_out = h->d_Tout;
+    if (d_outlier) *d_outlier = h->d_outlier;
+    if (d_n_inliers) *d_n_inliers = h->d_ninl;
+    if (d_stats) *d_stats = h->d_stats;
+    return OSLAM_OK;
+}
+
+int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs, const float* invSigma2,
+                        const uint8_t* has_mp, const float K5[5], float Tcw_out[16], uint8_t* outlier, int32_t* n_inliers,
+                        int32_t stats[2]) {
+    if (!h || !Tcw_in || !K5 || !Tcw_out || !n_inliers || (N > 0 && (!Xw || !obs || !invSigma2 || !has_mp || !outlier))) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (N < 0 || N > h->max_points) { set_error("%d points > capacity %d", N, h->max_points); return OSLAM_E_CAPACITY; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_T, Tcw_in, 64, hipMemcpyHostToDevice));
+    if (N > 0) {
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_Xw, Xw, (size_t)N * 12, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_obs, obs, (size_t)N * 12, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_inv, invSigma2, (size_t)N * 4, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_has, has_mp, (size_t)N, hipMemcpyHostToDevice));
+    }
+    int rc = oslam_pose_optimize_batch_device(h, 1, h->max_points, nullptr, N, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has, K5, nullptr);
+    if (rc) return rc;
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(Tcw_out, h->d_Tout, 64, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(n_inliers, h->d_ninl, 4, hipMemcpyDeviceToHost));
+    if (N > 0) OSLAM_HIP_CHECK(hipMemcpy(outlier, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost));
+    if (stats) OSLAM_HIP_CHECK(hipMemcpy(stats, h->d_stats, 8, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+}  // extern "C"

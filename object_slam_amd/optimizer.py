@@ -1,0 +1,53 @@
+"""Optimizer — Python mirror of ORB_SLAM2::Optimizer's hot entry points (reference
+include/Optimizer.h:45-46) over the C ABI.  All arithmetic runs in the HIP library."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr
+
+
+class PoseOptimizer:
+    """Optimizer::PoseOptimization (reference src/Optimizer.cc:239-451)."""
+
+    def __init__(self, max_points=4096, max_batch=1, device=0):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        check(self.L.oslam_poseopt_create(C.byref(self.h), max_batch, max_points, device))
+        self.max_points, self.max_batch = max_points, max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.oslam_poseopt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def PoseOptimization(self, Tcw, Xw, obs, invSigma2, has_mp, K5):
+        """Returns (n_inliers, Tcw_out[4,4] float32, outlier uint8[N], (LM iterations, trials))."""
+        Xw = np.ascontiguousarray(Xw, np.float32)
+        N = len(Xw)
+        obs = np.ascontiguousarray(obs, np.float32)
+        inv = np.ascontiguousarray(invSigma2, np.float32)
+        has = np.ascontiguousarray(has_mp, np.uint8)
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        K = np.ascontiguousarray(K5, np.float32)
+        out = np.zeros(16, np.float32)
+        outl = np.zeros(max(N, 1), np.uint8)
+        n = C.c_int(0)
+        stats = np.zeros(2, np.int32)
+        check(self.L.oslam_pose_optimize(self.h, N, ptr(T), ptr(Xw), ptr(obs), ptr(inv), ptr(has), ptr(K), ptr(out),
+                                         ptr(outl), C.byref(n), ptr(stats)))
+        return n.value, out.reshape(4, 4), outl[:N], (int(stats[0]), int(stats[1]))
+
+    def optimize_batch_device(self, batch, stride, d_n, n_const, d_Tcw, d_Xw, d_obs, d_inv, d_has, K5, stream=None):
+        K = np.ascontiguousarray(K5, np.float32)
+        check(self.L.oslam_pose_optimize_batch_device(self.h, batch, stride, C.c_void_p(d_n or 0), n_const, C.c_void_p(d_Tcw),
+                                                      C.c_void_p(d_Xw), C.c_void_p(d_obs), C.c_void_p(d_inv), C.c_void_p(d_has),
+                                                      ptr(K), C.c_void_p(stream or 0)))
+
+    def results_device(self):
+        a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(self.L.oslam_poseopt_results_device(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value

@@ -51,3 +51,131 @@ def make_stream(n_frames, width=640, height=480, seed=SEED, margin=96):
     for i in range(n_frames):
         frames[i] = canvas[oy[i]:oy[i] + height, ox[i]:ox[i] + width]
     return frames, np.stack([ox, oy], 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Geometric problems for the optimisers: no images needed.
+# ---------------------------------------------------------------------------------------------
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157, 386.1448)   # reference Examples/Stereo/KITTI00-02.yaml:8-20
+TUM_K = (520.908620, 521.007327, 325.141442, 249.701764, 40.0)   # reference Examples/RGB-D/TUM2.yaml
+
+
+def _rot(rv):
+    th = np.linalg.norm(rv)
+    if th < 1e-12:
+        return np.eye(3)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+
+def make_T(rv, t):
+    T = np.eye(4)
+    T[:3, :3] = _rot(np.asarray(rv, float))
+    T[:3, 3] = t
+    return T
+
+
+def level_sigma2(nlevels=8, sf=1.2):
+    s = np.float32(1.0)
+    out = [np.float32(1.0)]
+    for _ in range(1, nlevels):
+        s = np.float32(s * np.float32(sf))
+        out.append(np.float32(s * s))
+    return np.array(out, np.float32)
+
+
+def project(T, X, K):
+    fx, fy, cx, cy, bf = K
+    Xc = X @ T[:3, :3].T + T[:3, 3]
+    z = Xc[:, 2]
+    u = fx * Xc[:, 0] / z + cx
+    v = fy * Xc[:, 1] / z + cy
+    return u, v, u - bf / z, z
+
+
+def make_pose_problem(seed, N=1000, K=TUM_K, width=640, height=480, outlier_frac=0.1, stereo_frac=0.7,
+                      noise=1.0, pose_err=(0.02, 0.05), mp_frac=0.8):
+    """One PoseOptimization input: N keypoints, a fraction with map points."""
+    rng = np.random.default_rng(seed)
+    T_gt = make_T(rng.normal(0, 0.1, 3), rng.normal(0, 0.3, 3))
+    fx, fy, cx, cy, bf = K
+    u = rng.uniform(10, width - 10, N)
+    v = rng.uniform(10, height - 10, N)
+    z = rng.uniform(0.6, 8.0, N)
+    Xc = np.stack([(u - cx) * z / fx, (v - cy) * z / fy, z], 1)
+    Xw = (Xc - T_gt[:3, 3]) @ T_gt[:3, :3]          # R^T (Xc - t)
+    octave = rng.integers(0, 8, N)
+    sig2 = level_sigma2()[octave]
+    obs = np.stack([u, v, u - bf / z], 1)
+    obs[:, :2] += rng.normal(0, noise, (N, 2)) * np.sqrt(sig2)[:, None]
+    obs[:, 2] += rng.normal(0, noise, N) * np.sqrt(sig2)
+    mono = rng.random(N) > stereo_frac
+    obs[mono, 2] = -1.0
+    out = rng.random(N) < outlier_frac
+    obs[out, 0] += rng.choice([-1, 1], out.sum()) * rng.uniform(15, 60, out.sum())
+    has_mp = (rng.random(N) < mp_frac).astype(np.uint8)
+    T0 = make_T(rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)) @ T_gt
+    return dict(Tcw=T0.astype(np.float32), T_gt=T_gt, Xw=Xw.astype(np.float32), obs=obs.astype(np.float32),
+                invSigma2=(np.float32(1.0) / sig2).astype(np.float32), has_mp=has_mp, K=np.array(K, np.float32),
+                is_outlier=out)
+
+
+def make_lba_problem(seed, K_local=20, K_fixed=20, P=4000, track=6, K=KITTI_K, width=1241, height=376,
+                     outlier_frac=0.05, noise=1.0, pose_err=(0.005, 0.02), point_err=0.05, stereo_frac=0.85):
+    """S5-shaped local BA: keyframes along a forward path, each point seen by ~track keyframes."""
+    rng = np.random.default_rng(seed)
+    nKF = K_local + K_fixed
+    Ts = []
+    for k in range(nKF):
+        pos = np.array([0.05 * rng.normal(), 0.02 * rng.normal(), 0.6 * k])
+        R = _rot(np.array([0.01 * rng.normal(), 0.03 * np.sin(k / 5.0) + 0.01 * rng.normal(), 0.005 * rng.normal()]))
+        Twc = np.eye(4)
+        Twc[:3, :3] = R
+        Twc[:3, 3] = pos
+        Ts.append(np.linalg.inv(Twc))
+    Ts = np.array(Ts)
+    fixed = np.zeros(nKF, np.uint8)
+    # the oldest keyframes are the fixed cameras; keyframe id 0 is local-but-fixed when no fixed set
+    fixed[:K_fixed] = 1
+    if K_fixed == 0:
+        fixed[0] = 2
+    fx, fy, cx, cy, bf = K
+    pts, ekf, ept, eobs, einv = [], [], [], [], []
+    sig2 = level_sigma2()
+    pid = 0
+    while pid < P:
+        k0 = int(rng.integers(0, nKF))
+        Twc = np.linalg.inv(Ts[k0])
+        z = rng.uniform(4, 40)
+        u, v = rng.uniform(20, width - 20), rng.uniform(20, height - 20)
+        Xw = Twc[:3, :3] @ np.array([(u - cx) * z / fx, (v - cy) * z / fy, z]) + Twc[:3, 3]
+        seen = []
+        for k in range(max(0, k0 - track), min(nKF, k0 + track + 1)):
+            uu, vv, ur, zz = project(Ts[k], Xw[None], K)
+            if zz[0] > 0.5 and 0 <= uu[0] < width and 0 <= vv[0] < height and rng.random() < 0.5:
+                seen.append((k, uu[0], vv[0], ur[0]))
+        if len(seen) < 2 or not any(fixed[k] == 0 for k, *_ in seen):
+            continue
+        pts.append(Xw)
+        for k, uu, vv, ur in seen:
+            o = int(rng.integers(0, 8))
+            s = np.sqrt(sig2[o]) * noise
+            ob = [uu + rng.normal(0, s), vv + rng.normal(0, s), ur + rng.normal(0, s)]
+            if rng.random() > stereo_frac:
+                ob[2] = -1.0
+            if rng.random() < outlier_frac:
+                ob[0] += rng.choice([-1, 1]) * rng.uniform(20, 50)
+            ekf.append(k); ept.append(pid); eobs.append(ob); einv.append(np.float32(1.0) / sig2[o])
+        pid += 1
+    pts = np.array(pts)
+    poses0 = []
+    for k in range(nKF):
+        if fixed[k]:
+            poses0.append(Ts[k])
+        else:
+            poses0.append(make_T(rng.normal(0, pose_err[0], 3), rng.normal(0, pose_err[1], 3)) @ Ts[k])
+    return dict(poses=np.array(poses0, np.float32), poses_gt=Ts, fixed=fixed,
+                points=(pts + rng.normal(0, point_err, pts.shape)).astype(np.float32), points_gt=pts,
+                edge_kf=np.array(ekf, np.int32), edge_pt=np.array(ept, np.int32), edge_obs=np.array(eobs, np.float32),
+                edge_invSigma2=np.array(einv, np.float32), K=np.array(K, np.float32))

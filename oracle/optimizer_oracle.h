@@ -1,0 +1,80 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  PARITY UNPINNED.
+// CPU restatement of Optimizer::PoseOptimization (reference src/Optimizer.cc:239-451),
+// Optimizer::LocalBundleAdjustment (:453-778) and ObjectOptimizer::PoseOptimization2
+// (src/ObjectOptimizer.cc:624-1240) together with the arithmetic they delegate to the ORB_SLAM2
+// fork of g2o (Thirdparty/g2o, unversioned, NOT in /root/reference): SE3Quat / VertexSE3Expmap,
+// EdgeSE3ProjectXYZ[OnlyPose], EdgeStereoSE3ProjectXYZ[OnlyPose], RobustKernelHuber,
+// OptimizationAlgorithmLevenberg, BlockSolver_6_3 (Schur complement), restated from the published
+// g2o sources.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <vector>
+
+namespace oracle {
+
+struct SE3Quat {          // g2o::SE3Quat: unit quaternion (x,y,z,w) + translation, camera-from-world
+    double q[4];
+    double t[3];
+};
+
+SE3Quat se3_from_cvmat(const float* T16);          // Converter::toSE3Quat, src/Converter.cc:38-48
+void se3_to_cvmat(const SE3Quat& s, float* T16);   // Converter::toCvMat(SE3Quat), :64-72
+void se3_map(const SE3Quat& s, const double* X, double* out);
+SE3Quat se3_exp(const double* update6);            // SE3Quat::exp
+SE3Quat se3_mul(const SE3Quat& a, const SE3Quat& b);
+void se3_rotation(const SE3Quat& s, double R[9]);
+
+struct Camera { double fx, fy, cx, cy, bf; };
+
+struct GraphEdge {
+    int pose;             // pose vertex index
+    int point;            // point vertex index, or -1 for a pose-only edge (Xw fixed in the edge)
+    double Xw[3];         // pose-only edges
+    double obs[3];        // u, v, (ur)
+    bool stereo;
+    double info;          // invSigma2 (information = info * I)
+    bool robust;
+    double delta;         // Huber delta (double of the reference's float sqrt(5.991) / sqrt(7.815))
+    int level;            // g2o edge level: 0 active, 1 excluded
+    double err[3];        // _error buffer (as last computed; may be stale, like g2o's)
+    bool semantic;        // PoseOptimization2 extra edges (bookkeeping only)
+};
+
+struct Graph {
+    Camera cam;
+    std::vector<SE3Quat> poses;
+    std::vector<uint8_t> pose_fixed;
+    std::vector<std::array<double, 3>> points;
+    std::vector<GraphEdge> edges;
+    // statistics of the last optimize() call
+    int lm_iterations = 0, lm_trials = 0;
+};
+
+void edge_compute_error(const Graph& g, GraphEdge& e);
+double edge_chi2(const GraphEdge& e);
+bool edge_depth_positive(const Graph& g, const GraphEdge& e);
+
+// SparseOptimizer::initializeOptimization(level) + optimize(iterations) with
+// OptimizationAlgorithmLevenberg.  stop (may be NULL) is the force-stop flag polled like g2o does.
+// Returns the number of iterations performed.
+int graph_optimize(Graph& g, int iterations, int level, const volatile int* stop);
+void edge_jacobians(const Graph& g, const GraphEdge& e, double Jp[18], double Jx[9]);
+
+// reference src/Optimizer.cc:239-451.  has_mp[i] != 0 <=> pFrame->mvpMapPoints[i] != NULL.
+// obs[i] = (kpUn.pt.x, kpUn.pt.y, mvuRight[i]) ; mono iff mvuRight[i] < 0.
+int PoseOptimization(int N, const float* Tcw_in, const float* Xw, const float* obs, const float* invSigma2,
+                     const uint8_t* has_mp, const float* K5 /*fx,fy,cx,cy,bf*/, float* Tcw_out, uint8_t* outlier,
+                     int* stats /* [2] iterations, trials; may be NULL */);
+
+// reference src/Optimizer.cc:453-778 after the graph has been gathered:
+// poses [nKF][16] float (Tcw), fixed[k] = 1 for lFixedCameras, 2 for a local keyframe with mnId==0
+// (setFixed(true) at :529 but still written back at :762-768), 0 for free local keyframes; points [nP][3];
+// edges in insertion order: (kf, pt, u, v, ur, invSigma2).  Outputs poses/points rounded to float
+// like Converter::toCvMat, erase[e] = 1 for observations the reference erases (:711-743).
+void LocalBundleAdjustment(int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                           const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs,
+                           const float* edge_invSigma2, const float* K5, const volatile int* stop, float* poses_out,
+                           float* points_out, uint8_t* erase, int* stats /* [4] it1, trials1, it2, trials2 */);
+
+}  // namespace oracle

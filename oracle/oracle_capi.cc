@@ -136,3 +136,43 @@ int oo_features_in_area(int N, const KeyPoint* keysUn, const float* bounds, floa
     return (int)v.size();
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+#include "optimizer_oracle.h"
+extern "C" {
+int oo_pose_optimization(int N, const float* Tcw_in, const float* Xw, const float* obs, const float* invSigma2,
+                         const uint8_t* has_mp, const float* K5, float* Tcw_out, uint8_t* outlier, int* stats) {
+    return PoseOptimization(N, Tcw_in, Xw, obs, invSigma2, has_mp, K5, Tcw_out, outlier, stats);
+}
+void oo_local_bundle_adjustment(int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                                const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs,
+                                const float* edge_invSigma2, const float* K5, const int* stop, float* poses_out,
+                                float* points_out, uint8_t* erase, int* stats) {
+    LocalBundleAdjustment(nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, stop, poses_out,
+                          points_out, erase, stats);
+}
+// SE3 helpers for unit tests
+void oo_se3_exp_mul(const double* update6, const float* T_in, float* T_out) {
+    SE3Quat T = se3_from_cvmat(T_in);
+    SE3Quat r = se3_mul(se3_exp(update6), T);
+    se3_to_cvmat(r, T_out);
+}
+// error + Jacobians of one edge at a pose (pose-only if point == NULL)
+void oo_edge_eval(const float* T, const double* X, const double* obs, int stereo, int binary, const double* K5, double* err,
+                  double* Jp, double* Jx) {
+    Graph g;
+    g.cam = Camera{K5[0], K5[1], K5[2], K5[3], K5[4]};
+    g.poses.push_back(se3_from_cvmat(T));
+    g.pose_fixed.push_back(0);
+    GraphEdge e;
+    memset(&e, 0, sizeof(e));
+    e.pose = 0; e.stereo = stereo != 0; e.info = 1; e.point = -1;
+    for (int i = 0; i < 3; i++) { e.Xw[i] = X[i]; e.obs[i] = obs[i]; }
+    if (binary) { g.points.push_back({X[0], X[1], X[2]}); e.point = 0; }
+    edge_compute_error(g, e);
+    for (int i = 0; i < 3; i++) err[i] = e.err[i];
+    // Jacobians through the (file-static) routine: run one build via graph internals is overkill; expose directly
+    extern void oo_internal_edge_jac(const Graph&, const GraphEdge&, double*, double*);
+    oo_internal_edge_jac(g, e, Jp, Jx);
+}
+}

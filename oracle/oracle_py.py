@@ -200,3 +200,54 @@ def features_in_area(keysUn, bounds, x, y, r, minLevel=-1, maxLevel=-1):
     n = L.oo_features_in_area(len(keysUn), _p(keysUn), _p(np.asarray(bounds, np.float32)), x, y, r, minLevel, maxLevel,
                               _p(out), len(out))
     return out[:n]
+
+
+# ---------------------------------------------------------------------------------------------
+def pose_optimization(Tcw, Xw, obs, invSigma2, has_mp, K5):
+    """Oracle Optimizer::PoseOptimization. Returns (n_inliers, Tcw_out[4,4] f32, outlier u8[N], (its, trials))."""
+    Xw = np.ascontiguousarray(Xw, np.float32)
+    N = len(Xw)
+    obs = np.ascontiguousarray(obs, np.float32)
+    inv = np.ascontiguousarray(invSigma2, np.float32)
+    has = np.ascontiguousarray(has_mp, np.uint8)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    K = np.asarray(K5, np.float32)
+    out = np.zeros(16, np.float32)
+    outl = np.zeros(max(N, 1), np.uint8)
+    stats = np.zeros(2, np.int32)
+    n = lib().oo_pose_optimization(N, _p(T), _p(Xw), _p(obs), _p(inv), _p(has), _p(K), _p(out), _p(outl), _p(stats))
+    return n, out.reshape(4, 4), outl[:N], tuple(stats)
+
+
+def local_bundle_adjustment(poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_inv, K5, stop=0):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    fixed = np.ascontiguousarray(fixed, np.uint8)
+    points = np.ascontiguousarray(points, np.float32)
+    ekf = np.ascontiguousarray(edge_kf, np.int32)
+    ept = np.ascontiguousarray(edge_pt, np.int32)
+    eobs = np.ascontiguousarray(edge_obs, np.float32)
+    einv = np.ascontiguousarray(edge_inv, np.float32)
+    K = np.asarray(K5, np.float32)
+    pout = np.zeros_like(poses)
+    xout = np.zeros_like(points)
+    erase = np.zeros(max(len(ekf), 1), np.uint8)
+    stats = np.zeros(4, np.int32)
+    st = np.array([stop], np.int32)
+    lib().oo_local_bundle_adjustment(len(poses), _p(poses), _p(fixed), len(points), _p(points), len(ekf), _p(ekf), _p(ept),
+                                     _p(eobs), _p(einv), _p(K), _p(st), _p(pout), _p(xout), _p(erase), _p(stats))
+    return pout.reshape(-1, 4, 4), xout, erase[:len(ekf)], tuple(stats)
+
+
+def se3_exp_mul(update6, T):
+    out = np.zeros(16, np.float32)
+    lib().oo_se3_exp_mul(_p(np.ascontiguousarray(update6, np.float64)), _p(np.ascontiguousarray(T, np.float32).reshape(16)), _p(out))
+    return out.reshape(4, 4)
+
+
+def edge_eval(T, X, obs, stereo, binary, K5):
+    err, Jp, Jx = np.zeros(3), np.zeros(18), np.zeros(9)
+    lib().oo_edge_eval(_p(np.ascontiguousarray(T, np.float32).reshape(16)), _p(np.ascontiguousarray(X, np.float64)),
+                       _p(np.ascontiguousarray(obs, np.float64)), int(stereo), int(binary), _p(np.asarray(K5, np.float64)),
+                       _p(err), _p(Jp), _p(Jx))
+    D = 3 if stereo else 2
+    return err[:D], Jp.reshape(3, 6)[:D], Jx.reshape(3, 3)[:D]

@@ -1,0 +1,82 @@
+"""GPU parity: HIP Optimizer::PoseOptimization vs the CPU oracle.  Tolerance (BASELINE.json
+north_star): pose within 1e-4 relative; outlier flags and inlier counts identical (an edge within
+1e-9 of the chi2 gate could flip: none in these seeds)."""
+import numpy as np
+import pytest
+
+from object_slam_amd import PoseOptimizer, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("seed,N,K,frac", [(0, 1000, synth.TUM_K, 0.1), (1, 2000, synth.KITTI_K, 0.2), (2, 300, synth.TUM_K, 0.0),
+                                           (3, 1000, synth.TUM_K, 0.4), (4, 60, synth.KITTI_K, 0.1), (5, 1500, synth.TUM_K, 0.05)])
+def test_pose_optimization_matches_oracle(oracle, seed, N, K, frac):
+    w, h = (640, 480) if K is synth.TUM_K else (1241, 376)
+    p = synth.make_pose_problem(seed, N=N, K=K, width=w, height=h, outlier_frac=frac, stereo_frac=[0.7, 1.0, 0.0][seed % 3])
+    po = PoseOptimizer(max_points=2048)
+    n, T, outl, st = po.PoseOptimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], p["has_mp"], p["K"])
+    on, oT, ooutl, ost = oracle.pose_optimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], p["has_mp"], p["K"])
+    assert _rel(T, oT) <= RTOL, (T, oT)
+    np.testing.assert_array_equal(outl, ooutl)
+    assert n == on
+    # the LM schedule may differ by a few trials: at convergence F0-F1 is rounding noise, so the sign of
+    # rho depends on the summation order (parallel reduction vs the oracle's index order)
+    # (e.g. ten rejected trials in a converged round vs an early `rho == 0` exit), so only sanity-check it
+    assert 4 <= st[0] <= 40 and st[0] <= st[1] <= 400, (st, ost)
+    po.close()
+
+
+def test_pose_optimization_edge_cases(oracle):
+    po = PoseOptimizer(max_points=512)
+    p = synth.make_pose_problem(7, N=200)
+    # < 3 correspondences: returns 0 and leaves the pose untouched (reference :364-365)
+    has = np.zeros(200, np.uint8); has[[3, 50]] = 1
+    n, T, outl, st = po.PoseOptimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], has, p["K"])
+    assert n == 0 and np.array_equal(T, p["Tcw"]) and outl.sum() == 0
+    # < 10 edges: a single round (reference :440)
+    has = np.zeros(200, np.uint8); has[:8] = 1
+    r = po.PoseOptimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], has, p["K"])
+    o = oracle.pose_optimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], has, p["K"])
+    assert r[0] == o[0] and _rel(r[1], o[1]) <= RTOL and np.array_equal(r[2], o[2])
+    # zero-noise problem returns the ground truth
+    q = synth.make_pose_problem(8, N=400, outlier_frac=0.0, noise=0.0)
+    n, T, outl, st = po.PoseOptimization(q["Tcw"], q["Xw"], q["obs"], q["invSigma2"], q["has_mp"], q["K"])
+    assert n == int(q["has_mp"].sum()) and np.abs(T - q["T_gt"]).max() < 2e-4
+    # capacity is checked, not truncated
+    from object_slam_amd import OslamError
+    with pytest.raises(OslamError):
+        po.PoseOptimization(p["Tcw"], np.zeros((600, 3), np.float32), np.zeros((600, 3), np.float32), np.ones(600, np.float32),
+                            np.ones(600, np.uint8), p["K"])
+    po.close()
+
+
+def test_pose_optimization_batch(oracle):
+    import torch
+    B, N = 16, 1000
+    probs = [synth.make_pose_problem(100 + b, N=N) for b in range(B)]
+    t = lambda k, dt: torch.from_numpy(np.stack([p[k] for p in probs]).astype(dt)).cuda()
+    Tcw, Xw, obs, inv, has = t("Tcw", np.float32), t("Xw", np.float32), t("obs", np.float32), t("invSigma2", np.float32), t("has_mp", np.uint8)
+    po = PoseOptimizer(max_points=N, max_batch=B)
+    po.optimize_batch_device(B, N, None, N, Tcw.data_ptr(), Xw.data_ptr(), obs.data_ptr(), inv.data_ptr(), has.data_ptr(),
+                             probs[0]["K"], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    import ctypes as C
+    dT, dO, dN, dS = po.results_device()
+    Tout = np.zeros((B, 16), np.float32); outl = np.zeros((B, N), np.uint8); ninl = np.zeros(B, np.int32)
+    from object_slam_amd._lib import lib
+    hip = C.CDLL("libamdhip64.so")
+    for dst, src, nbytes in ((Tout, dT, Tout.nbytes), (outl, dO, outl.nbytes), (ninl, dN, ninl.nbytes)):
+        assert hip.hipMemcpy(dst.ctypes.data_as(C.c_void_p), C.c_void_p(src), C.c_size_t(nbytes), 2) == 0
+    for b in range(B):
+        on, oT, ooutl, _ = oracle.pose_optimization(probs[b]["Tcw"], probs[b]["Xw"], probs[b]["obs"], probs[b]["invSigma2"],
+                                                    probs[b]["has_mp"], probs[b]["K"])
+        assert ninl[b] == on and _rel(Tout[b].reshape(4, 4), oT) <= RTOL
+        np.testing.assert_array_equal(outl[b], ooutl)
+    po.close()
