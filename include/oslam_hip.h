@@ -225,6 +225,31 @@ int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, 
 int oslam_poseopt_results_device(const oslam_poseopt_t* h, const float** d_Tcw_out, const uint8_t** d_outlier,
                                  const int32_t** d_n_inliers, const int32_t** d_stats);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer::LocalBundleAdjustment (include/Optimizer.h:45, src/Optimizer.cc:453-778) after the
+ * covisibility gather (:456-504, pointer-graph walk, stays with the caller):
+ * g2o Levenberg-Marquardt + BlockSolver_6_3 Schur complement, optimize(5) with Huber, chi2 (5.991 /
+ * 7.815) and depth gating (:672-702), optimize(10) without robust kernel, erase list (:711-743).
+ * poses [nKF][16] Tcw float32; fixed[k]: 0 local keyframe (free), 1 fixed camera (lFixedCameras),
+ * 2 local keyframe with mnId==0 (setFixed(true) at :529 yet written back at :762-768);
+ * points [nP][3]; one edge per observation: (keyframe, point, kpUn.pt.x, kpUn.pt.y, mvuRight (<0 mono),
+ * mvInvLevelSigma2[octave]).  K5 = {fx, fy, cx, cy, mbf}.
+ * Outputs: poses / points rounded to float32 like Converter::toCvMat, erase[e] = 1 for observations
+ * the reference erases.  pbStopFlag (:517-518): oslam_lba_stop_flag() returns a pinned, device-visible
+ * int the caller may set from another thread (LocalMapping::InterruptBA, src/LocalMapping.cc:628-631);
+ * it is polled at the points g2o polls its force-stop flag when use_stop_flag != 0.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oslam_lba oslam_lba_t;
+int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes /* <= 128 */, int max_points,
+                     int max_edges, int device);
+void oslam_lba_destroy(oslam_lba_t* h);
+volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
+int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP,
+                       const float* points, int nE, const int32_t* edge_kf, const int32_t* edge_pt,
+                       const float* edge_obs, const float* edge_invSigma2, const float K5[5], int use_stop_flag,
+                       float* poses_out, float* points_out, uint8_t* erase,
+                       int32_t stats[4] /* iterations/trials of stage 1 and 2; may be NULL */);
+
 #ifdef __cplusplus
 }
 #endif

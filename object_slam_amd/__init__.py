@@ -6,4 +6,4 @@ Python is harness).  Class and method names mirror the reference's C++ API.
 from ._lib import KP_DTYPE, OslamError  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher, QUERY_DTYPE  # noqa: F401
-from .optimizer import PoseOptimizer  # noqa: F401
+from .optimizer import LocalBundleAdjuster, PoseOptimizer  # noqa: F401

@@ -1,0 +1,657 @@
+// gfx950 local bundle adjustment: Optimizer::LocalBundleAdjustment (reference
+// src/Optimizer.cc:453-778) after the graph has been gathered — g2o Levenberg-Marquardt with
+// BlockSolver_6_3's Schur complement, optimize(5) with Huber, chi2 / depth
+// gating, optimize(10) without, erase list.  One 1024-thread workgroup per BA problem runs the
+// whole schedule in one launch (batch = independent keyframe windows).  fp64 throughout.
+//
+// Deterministic by construction (no floating-point atomics):
+//   * point blocks (Hll, b_l, per-edge Hpl) : one thread per map point over its edge list;
+//   * pose blocks (Hpp, b_p)                : one wavefront per keyframe, shuffle reduction;
+//   * Schur complement                      : one wavefront per block-row a; for every edge (a,l)
+//     the lanes cover the other observations (b,l) of point l, so each lane owns a distinct
+//     (a,b) block of the row buffer in LDS; rows are then stored to the reduced system;
+//   * reduced camera system                 : blocked (6-wide) Cholesky U^T U with the right-hand
+//     side carried as an extra column, back-substitution by one wavefront.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "se3_math.h"
+
+namespace oslam {
+
+constexpr int kLbaThreads = 1024;
+constexpr int kLbaWaves = kLbaThreads / 64;
+constexpr int kLbaMaxKF = 128;
+constexpr int kRowBufBytes = 96 * 1024;
+
+struct LbaProblem {
+    int K, P, E;
+    const float* poses;       // [K][16] Tcw
+    const uint8_t* fixed;     // [K] 0 free, 1 fixed camera, 2 local keyframe with mnId==0 (fixed, written back)
+    const float* points;      // [P][3]
+    const int* e_kf;          // [E] point-major edge order
+    const int* e_pt;          // [E]
+    const float* e_obs;       // [E][3] u, v, uR (uR < 0: monocular)
+    const float* e_info;      // [E] invSigma2
+    const int* pt_start;      // [P+1]
+    const int* pose_start;    // [K+1]
+    const int* pose_edges;    // [E] edge ids grouped by keyframe, ascending
+    // scratch
+    double* Xa; double* Xb;   // [P][3] point state / trial state
+    double* chi2;             // [E] _error chi2 as last computed
+    uint8_t* level;           // [E]
+    double* Hpl;              // [E][18]
+    double* Hll; double* Dinv; double* bl; double* xl;   // [P][9],[P][9],[P][3],[P][3]
+    double* Hpp; double* bp;  // [K][36],[K][6]
+    double* Hs;               // [n][n+1] reduced system + rhs column
+    double* xp;               // [n]
+    // outputs
+    float* poses_out; float* points_out; uint8_t* erase; int* stats;   // stats[4]: it1, trials1, it2, trials2
+    const volatile int* stop; // may be NULL
+    float K5[5];              // fx, fy, cx, cy, bf (one sensor per window)
+};
+
+struct LbaShared {
+    SE3 T[kLbaMaxKF];      // current poses
+    SE3 Tn[kLbaMaxKF];     // trial poses
+    double R[kLbaMaxKF][9];
+    int blk[kLbaMaxKF];    // block index among free poses or -1
+    double red[2][kLbaWaves][4];
+    int flag;
+    int stopflag;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// block-wide sum / max of up to 2 values; all threads get identical results
+__device__ __forceinline__ void block_red2(double& a, double& b, bool is_max, LbaShared& S, int& phase) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double ra = is_max ? wmax(a) : wsum(a), rb = is_max ? wmax(b) : wsum(b);
+    if (lane == 0) { S.red[phase][wv][0] = ra; S.red[phase][wv][1] = rb; }
+    __syncthreads();
+    double sa = S.red[phase][0][0], sb = S.red[phase][0][1];
+    for (int w = 1; w < kLbaWaves; w++) {
+        if (is_max) { sa = fmax(sa, S.red[phase][w][0]); sb = fmax(sb, S.red[phase][w][1]); }
+        else { sa += S.red[phase][w][0]; sb += S.red[phase][w][1]; }
+    }
+    a = sa; b = sb;
+    phase ^= 1;
+}
+
+__global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
+    const LbaProblem pr = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int K = pr.K, P = pr.P, E = pr.E;
+    __shared__ LbaShared S;
+    extern __shared__ __align__(16) uint8_t dyn[];
+    double* rowbuf = (double*)dyn;   // [waves_used][6][n+1]
+    int phase = 0;
+
+    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+
+    // ---- setup ----
+    if (tid == 0) {
+        int nb = 0;
+        for (int a = 0; a < K; a++) S.blk[a] = pr.fixed[a] ? -1 : nb++;
+        S.flag = nb;
+    }
+    for (int a = tid; a < K; a += kLbaThreads) {
+        S.T[a] = se3_from_T(pr.poses + a * 16);
+        se3_R(S.T[a], S.R[a]);
+    }
+    for (int i = tid; i < P * 3; i += kLbaThreads) pr.Xa[i] = (double)pr.points[i];
+    for (int e = tid; e < E; e += kLbaThreads) { pr.level[e] = 0; pr.chi2[e] = 0; pr.erase[e] = 0; }
+    __syncthreads();
+    const int nfree = S.flag;
+    const int n = 6 * nfree, ld = n + 1;
+    int rw = kRowBufBytes / (6 * ld * 8);
+    if (rw > kLbaWaves) rw = kLbaWaves;
+    if (rw < 1) rw = 1;
+
+    double* X = pr.Xa;    // current points
+    double* Xn = pr.Xb;   // trial points
+    int st_its[2] = {0, 0}, st_trials[2] = {0, 0};
+    // force-stop flag (g2o setForceStopFlag): one lane polls, the workgroup agrees on the value
+    auto stopped = [&]() -> bool {
+        if (!pr.stop) return false;
+        __syncthreads();
+        if (tid == 0) S.stopflag = *pr.stop;
+        __syncthreads();
+        return S.stopflag != 0;
+    };
+
+    bool early = stopped();   // reference :655-657
+    bool robust = true;
+
+    // residual pass (thread per point) at (poses Tp, points Xp): stores chi2 per active edge, returns robust sum
+    auto eval = [&](const SE3* Tp, const double* Xp) -> double {
+        double F = 0;
+        for (int p = tid; p < P; p += kLbaThreads) {
+            const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
+            for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+                if (pr.level[e] != 0) continue;
+                const int a = pr.e_kf[e];
+                const float ur = pr.e_obs[e * 3 + 2];
+                const bool stereo = !(ur < 0);
+                const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+                double pc[3], er[3];
+                se3_map(Tp[a], Xw, pc);
+                const double c2 = edge_error(cam, pc, ob, stereo, (double)pr.e_info[e], er);
+                pr.chi2[e] = c2;
+                if (robust) { double r0, r1; huber(c2, stereo ? dStereo : dMono, r0, r1); F += r0; }
+                else F += c2;
+            }
+        }
+        return F;
+    };
+
+    for (int stage = 0; stage < 2 && !early; stage++) {
+        const int iters = stage == 0 ? 5 : 10;
+        double lambda = 0, ni = 2;
+        bool ok = true;
+        for (int iter = 0; iter < iters && !stopped() && ok; iter++) {
+            // ---------- linearise: point-major (errors, Hll, b_l, Hpl) ----------
+            double F0 = 0, dmax = 0;
+            for (int p = tid; p < P; p += kLbaThreads) {
+                const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+                double hl[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+                for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+                    if (pr.level[e] != 0) continue;
+                    const int a = pr.e_kf[e];
+                    const float ur = pr.e_obs[e * 3 + 2];
+                    const bool stereo = !(ur < 0);
+                    const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+                    const double info = (double)pr.e_info[e];
+                    double pc[3], er[3], Jp[18], Jx[9];
+                    se3_map(S.T[a], Xw, pc);
+                    const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+                    pr.chi2[e] = c2;
+                    double r0 = c2, w = 1.0;
+                    if (robust) huber(c2, stereo ? dStereo : dMono, r0, w);
+                    F0 += r0;
+                    jac_binary(cam, pc, S.R[a], stereo, Jp, Jx);
+                    const double wi = w * info;
+                    const int D = stereo ? 3 : 2;
+                    int k = 0;
+                    for (int i = 0; i < 3; i++) {
+                        double sb = 0;
+                        for (int d = 0; d < D; d++) sb += Jx[d * 3 + i] * (info * er[d]);
+                        bl[i] -= w * sb;
+                        for (int j = i; j < 3; j++) {
+                            double sh = 0;
+                            for (int d = 0; d < D; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
+                            hl[k++] += sh;
+                        }
+                    }
+                    if (S.blk[a] >= 0) {
+                        double* B = pr.Hpl + (long long)e * 18;
+                        for (int i = 0; i < 6; i++)
+                            for (int j = 0; j < 3; j++) {
+                                double sh = 0;
+                                for (int d = 0; d < D; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
+                                B[i * 3 + j] = sh;
+                            }
+                    }
+                }
+                double* H = pr.Hll + (long long)p * 9;
+                H[0] = hl[0]; H[1] = hl[1]; H[2] = hl[2]; H[3] = hl[1]; H[4] = hl[3]; H[5] = hl[4]; H[6] = hl[2]; H[7] = hl[4]; H[8] = hl[5];
+                pr.bl[p * 3] = bl[0]; pr.bl[p * 3 + 1] = bl[1]; pr.bl[p * 3 + 2] = bl[2];
+                dmax = fmax(dmax, fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5]))));
+            }
+            // ---------- linearise: pose-major (Hpp, b_p), one wavefront per keyframe ----------
+            for (int a = wv; a < K; a += kLbaWaves) {
+                if (S.blk[a] < 0) continue;
+                double acc[27];
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc[k] = 0;
+                for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
+                    const int e = pr.pose_edges[q];
+                    if (pr.level[e] != 0) continue;
+                    const int p = pr.e_pt[e];
+                    const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+                    const float ur = pr.e_obs[e * 3 + 2];
+                    const bool stereo = !(ur < 0);
+                    const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+                    const double info = (double)pr.e_info[e];
+                    double pc[3], er[3], Jp[18], Jx[9];
+                    se3_map(S.T[a], Xw, pc);
+                    const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+                    double r0 = c2, w = 1.0;
+                    if (robust) huber(c2, stereo ? dStereo : dMono, r0, w);
+                    jac_binary(cam, pc, S.R[a], stereo, Jp, Jx);
+                    const double wi = w * info;
+                    const int D = stereo ? 3 : 2;
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        double sb = 0;
+                        for (int d = 0; d < D; d++) sb += Jp[d * 6 + i] * (info * er[d]);
+                        acc[21 + i] -= w * sb;
+#pragma unroll
+                        for (int j = i; j < 6; j++) {
+                            double sh = 0;
+                            for (int d = 0; d < D; d++) sh += Jp[d * 6 + i] * wi * Jp[d * 6 + j];
+                            acc[k++] += sh;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 27; k++) acc[k] = wsum(acc[k]);
+                if (lane == 0) {
+                    double* H = pr.Hpp + a * 36;
+                    int k = 0;
+                    for (int i = 0; i < 6; i++)
+                        for (int j = i; j < 6; j++) { H[i * 6 + j] = acc[k]; H[j * 6 + i] = acc[k]; k++; }
+                    for (int i = 0; i < 6; i++) pr.bp[a * 6 + i] = acc[21 + i];
+                }
+            }
+            block_red2(F0, dmax, false, S, phase);   // F0 summed (dmax unused: lambda init recomputes the maxima)
+            double currentChi = F0;
+            if (iter == 0) {   // computeLambdaInit over pose and point diagonals
+                double m1 = 0, m2 = 0;
+                for (int p = tid; p < P; p += kLbaThreads) {
+                    const double* H = pr.Hll + (long long)p * 9;
+                    m1 = fmax(m1, fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8]))));
+                }
+                for (int a = tid; a < K; a += kLbaThreads)
+                    if (S.blk[a] >= 0)
+                        for (int i = 0; i < 6; i++) m2 = fmax(m2, fabs(pr.Hpp[a * 36 + i * 7]));
+                block_red2(m1, m2, true, S, phase);
+                lambda = 1e-5 * fmax(m1, m2);
+                ni = 2;
+            }
+
+            double rho = 0;
+            int qmax = 0;
+            do {
+                // ---------- D^-1 and D^-1 b_l per point ----------
+                for (int p = tid; p < P; p += kLbaThreads) {
+                    double D[9], Di[9];
+                    const double* H = pr.Hll + (long long)p * 9;
+                    for (int i = 0; i < 9; i++) D[i] = H[i];
+                    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                    inv3(D, Di);
+                    double* o = pr.Dinv + (long long)p * 9;
+                    for (int i = 0; i < 9; i++) o[i] = Di[i];
+                    const double* b = pr.bl + p * 3;
+                    for (int i = 0; i < 3; i++) pr.xl[p * 3 + i] = Di[i * 3] * b[0] + Di[i * 3 + 1] * b[1] + Di[i * 3 + 2] * b[2];   // db
+                }
+                __syncthreads();
+                // ---------- Schur complement, one wavefront per block-row ----------
+                if (wv < rw) {
+                    double* rb = rowbuf + (size_t)wv * 6 * ld;
+                    for (int a = wv; a < K; a += rw) {
+                        const int ba = S.blk[a];
+                        if (ba < 0) continue;
+                        const int c0 = 6 * ba;
+                        for (int i = lane; i < 6 * ld; i += 64) rb[i] = 0;
+                        if (lane < 36) {
+                            const int r = lane / 6, cc = lane % 6;
+                            rb[r * ld + c0 + cc] = pr.Hpp[a * 36 + lane] + (r == cc ? lambda : 0.0);
+                        }
+                        double bs[6];
+                        for (int i = 0; i < 6; i++) bs[i] = pr.bp[a * 6 + i];
+                        for (int q = pr.pose_start[a]; q < pr.pose_start[a + 1]; q++) {
+                            const int e = pr.pose_edges[q];
+                            if (pr.level[e] != 0) continue;
+                            const int p = pr.e_pt[e];
+                            const double* Ba = pr.Hpl + (long long)e * 18;
+                            const double* Di = pr.Dinv + (long long)p * 9;
+                            const double* db = pr.xl + p * 3;
+                            double BD[18];
+                            for (int i = 0; i < 6; i++) {
+                                const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2 = Ba[i * 3 + 2];
+                                BD[i * 3] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
+                                BD[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
+                                BD[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
+                                bs[i] -= b0 * db[0] + b1 * db[1] + b2 * db[2];
+                            }
+                            const int e0 = pr.pt_start[p], e1 = pr.pt_start[p + 1];
+                            for (int e2 = e0 + lane; e2 < e1; e2 += 64) {
+                                if (pr.level[e2] != 0) continue;
+                                const int bb = S.blk[pr.e_kf[e2]];
+                                if (bb < ba) continue;   // upper triangle only (fixed poses have bb = -1)
+                                const double* Bb = pr.Hpl + (long long)e2 * 18;
+                                double* dst = rb + 6 * bb;
+                                for (int i = 0; i < 6; i++)
+                                    for (int j = 0; j < 6; j++)
+                                        dst[i * ld + j] -= BD[i * 3] * Bb[j * 3] + BD[i * 3 + 1] * Bb[j * 3 + 1] + BD[i * 3 + 2] * Bb[j * 3 + 2];
+                            }
+                        }
+                        if (lane < 6) rb[lane * ld + n] = bs[lane];
+                        for (int i = lane; i < 6 * (ld - c0); i += 64) {
+                            const int r = i / (ld - c0), cc = c0 + i % (ld - c0);
+                            pr.Hs[(size_t)(c0 + r) * ld + cc] = rb[r * ld + cc];
+                        }
+                    }
+                }
+                __syncthreads();
+                // ---------- blocked Cholesky U^T U of the reduced system, rhs as column n ----------
+                if (tid == 0) S.flag = 1;
+                __syncthreads();
+                for (int j0 = 0; j0 < n; j0 += 6) {
+                    if (wv == 0) {   // panel: factor the 6x6 diagonal block, scale the 6 pivot rows
+                        double Dg[36];
+                        for (int i = 0; i < 6; i++)
+                            for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? pr.Hs[(size_t)(j0 + i) * ld + j0 + k] : 0.0;
+                        bool good = true;
+                        for (int j = 0; j < 6; j++) {   // U^T U on the 6x6 (all lanes redundantly)
+                            double d = Dg[j * 6 + j];
+                            if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
+                            d = sqrt(d);
+                            Dg[j * 6 + j] = d;
+                            for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] /= d;
+                            for (int i = j + 1; i < 6; i++)
+                                for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
+                        }
+                        if (!good && lane == 0) S.flag = 0;
+                        for (int k = j0 + 6 + lane; k <= n; k += 64) {   // columns right of the block (incl. rhs)
+                            double col[6];
+                            for (int i = 0; i < 6; i++) col[i] = pr.Hs[(size_t)(j0 + i) * ld + k];
+                            for (int j = 0; j < 6; j++) {   // forward substitution with U_diag^T
+                                double s = col[j];
+                                for (int i = 0; i < j; i++) s -= Dg[i * 6 + j] * col[i];
+                                col[j] = s / Dg[j * 6 + j];
+                            }
+                            for (int i = 0; i < 6; i++) pr.Hs[(size_t)(j0 + i) * ld + k] = col[i];
+                        }
+                        if (lane < 36) {
+                            const int r = lane / 6, cc = lane % 6;
+                            if (cc >= r) pr.Hs[(size_t)(j0 + r) * ld + j0 + cc] = Dg[lane];
+                        }
+                    }
+                    __syncthreads();
+                    // trailing update: A[i][k] -= sum_r P[r][i] P[r][k], i >= j0+6, k >= i (and rhs column)
+                    const int m = n - (j0 + 6);
+                    for (int ii = wv; ii < m; ii += kLbaWaves) {
+                        const int i = j0 + 6 + ii;
+                        double pi[6];
+                        for (int r = 0; r < 6; r++) pi[r] = pr.Hs[(size_t)(j0 + r) * ld + i];
+                        for (int k = i + lane; k <= n; k += 64) {
+                            double s = 0;
+                            for (int r = 0; r < 6; r++) s += pi[r] * pr.Hs[(size_t)(j0 + r) * ld + k];
+                            pr.Hs[(size_t)i * ld + k] -= s;
+                        }
+                    }
+                    __syncthreads();
+                }
+                const bool ok2 = S.flag != 0;
+                // back substitution U x = y (one wavefront)
+                if (wv == 0 && ok2) {
+                    double* xs = rowbuf;   // row buffers are idle here; LDS keeps the wave's stores/loads ordered
+                    for (int i = n - 1; i >= 0; i--) {
+                        double s = 0;
+                        for (int k = i + 1 + lane; k < n; k += 64) s += pr.Hs[(size_t)i * ld + k] * xs[k];
+                        s = wsum(s);
+                        if (lane == 0) xs[i] = (pr.Hs[(size_t)i * ld + n] - s) / pr.Hs[(size_t)i * ld + i];
+                    }
+                    for (int i = lane; i < n; i += 64) pr.xp[i] = xs[i];
+                }
+                if (!ok2) for (int i = tid; i < n; i += kLbaThreads) pr.xp[i] = 0;
+                __syncthreads();
+                // ---------- landmarks: x_l = Dinv (b_l - sum_a B_a^T x_a); trial state ----------
+                double sc = 0;
+                for (int p = tid; p < P; p += kLbaThreads) {
+                    double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
+                    double xo[3] = {0, 0, 0};
+                    if (ok2) {
+                        for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+                            if (pr.level[e] != 0) continue;
+                            const int ba = S.blk[pr.e_kf[e]];
+                            if (ba < 0) continue;
+                            const double* B = pr.Hpl + (long long)e * 18;
+                            const double* xa = pr.xp + 6 * ba;
+                            for (int j = 0; j < 3; j++) {
+                                double s = 0;
+                                for (int i = 0; i < 6; i++) s += B[i * 3 + j] * xa[i];
+                                cl[j] -= s;
+                            }
+                        }
+                        const double* Di = pr.Dinv + (long long)p * 9;
+                        for (int i = 0; i < 3; i++) xo[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
+                    }
+                    for (int i = 0; i < 3; i++) {
+                        Xn[p * 3 + i] = X[p * 3 + i] + xo[i];
+                        sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);   // computeScale, landmark part
+                    }
+                }
+                for (int a = tid; a < K; a += kLbaThreads) {
+                    const int ba = S.blk[a];
+                    if (ba < 0) { S.Tn[a] = S.T[a]; continue; }
+                    double xa[6];
+                    for (int i = 0; i < 6; i++) { xa[i] = pr.xp[6 * ba + i]; sc += xa[i] * (lambda * xa[i] + pr.bp[a * 6 + i]); }
+                    S.Tn[a] = se3_mul(se3_exp(xa), S.T[a]);
+                }
+                __syncthreads();
+                double F1 = eval(S.Tn, Xn);
+                block_red2(F1, sc, false, S, phase);
+                double tempChi = F1;
+                if (!ok2) tempChi = 1.7976931348623157e308;
+                rho = (currentChi - tempChi) / (sc + 1e-3);
+                const bool finite = (tempChi - tempChi) == 0;
+                if (rho > 0 && finite) {
+                    double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                    for (int a = tid; a < K; a += kLbaThreads) { S.T[a] = S.Tn[a]; se3_R(S.T[a], S.R[a]); }
+                    { double* t = X; X = Xn; Xn = t; }
+                } else {
+                    lambda *= ni;
+                    ni *= 2;
+                }
+                __syncthreads();
+                qmax++;
+                st_trials[stage]++;
+            } while (rho < 0 && qmax < 10 && !stopped());
+            st_its[stage]++;
+            if (qmax == 10 || rho == 0) ok = false;
+        }
+        if (stage == 0) {
+            if (stopped()) break;   // bDoMore = false (:664-666)
+            // gate observations, drop the robust kernel (:672-702)
+            for (int e = tid; e < E; e += kLbaThreads) {
+                const int a = pr.e_kf[e], p = pr.e_pt[e];
+                const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
+                const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+                double pc[3];
+                se3_map(S.T[a], Xw, pc);
+                if (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) pr.level[e] = 1;
+            }
+            robust = false;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- outputs (:711-777) ----
+    if (!early) {
+        for (int e = tid; e < E; e += kLbaThreads) {
+            const int a = pr.e_kf[e], p = pr.e_pt[e];
+            const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
+            const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+            double pc[3];
+            se3_map(S.T[a], Xw, pc);
+            pr.erase[e] = (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) ? 1 : 0;
+        }
+    }
+    for (int a = tid; a < K; a += kLbaThreads) {
+        if (pr.fixed[a] != 1 && !early) se3_to_T(S.T[a], pr.poses_out + a * 16);
+        else for (int i = 0; i < 16; i++) pr.poses_out[a * 16 + i] = pr.poses[a * 16 + i];
+    }
+    for (int i = tid; i < P * 3; i += kLbaThreads) pr.points_out[i] = early ? pr.points[i] : (float)X[i];
+    if (tid == 0) { pr.stats[0] = st_its[0]; pr.stats[1] = st_trials[0]; pr.stats[2] = st_its[1]; pr.stats[3] = st_trials[1]; }
+}
+
+}  // namespace oslam
+
+using namespace oslam;
+
+struct oslam_lba {
+    int device = 0, max_batch = 0, max_kf = 0, max_pts = 0, max_edges = 0;
+    // one slab per batch slot
+    struct Slot {
+        float* poses; uint8_t* fixed; float* points; int* e_kf; int* e_pt; float* e_obs; float* e_info; int* pt_start; int* pose_start; int* pose_edges;
+        double* Xa; double* Xb; double* chi2; uint8_t* level; double* Hpl; double* Hll; double* Dinv; double* bl; double* xl; double* Hpp; double* bp; double* Hs; double* xp;
+        float* poses_out; float* points_out; uint8_t* erase; int* stats;
+    };
+    std::vector<Slot> slots;
+    std::vector<void*> allocs;
+    LbaProblem* d_probs = nullptr;
+    int* h_stop = nullptr;       // pinned, device-visible stop flag
+    int* d_stop = nullptr;
+    size_t lds = 0;
+};
+
+extern "C" {
+
+void oslam_lba_destroy(oslam_lba_t* h) {
+    if (!h) return;
+    for (void* p : h->allocs)
+        if (p) (void)hipFree(p);
+    if (h->d_probs) (void)hipFree(h->d_probs);
+    if (h->h_stop) (void)hipHostFree(h->h_stop);
+    delete h;
+}
+
+int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int max_points, int max_edges, int device) {
+    if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
+    *out = nullptr;
+    if (max_batch < 1 || max_keyframes < 1 || max_keyframes > kLbaMaxKF || max_points < 1 || max_edges < 1) {
+        set_error("oslam_lba_create: invalid argument (max_keyframes <= %d)", kLbaMaxKF);
+        return OSLAM_E_INVALID;
+    }
+    int ndev = oslam_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible: the gfx950 local BA has no CPU fallback"); return OSLAM_E_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(device));
+    oslam_lba* h = new oslam_lba();
+    h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes; h->max_pts = max_points; h->max_edges = max_edges;
+    const size_t K = max_keyframes, P = max_points, E = max_edges, n = 6 * K;
+    auto alloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
+        h->allocs.push_back(p);
+        return p;
+    };
+    bool okalloc = true;
+    for (int b = 0; b < max_batch && okalloc; b++) {
+        oslam_lba::Slot s;
+#define A(field, type, count) s.field = (type*)alloc(sizeof(type) * (count)); okalloc = okalloc && s.field
+        A(poses, float, K * 16); A(fixed, uint8_t, K); A(points, float, P * 3); A(e_kf, int, E); A(e_pt, int, E); A(e_obs, float, E * 3);
+        A(e_info, float, E); A(pt_start, int, P + 1); A(pose_start, int, K + 1); A(pose_edges, int, E);
+        A(Xa, double, P * 3); A(Xb, double, P * 3); A(chi2, double, E); A(level, uint8_t, E); A(Hpl, double, E * 18); A(Hll, double, P * 9);
+        A(Dinv, double, P * 9); A(bl, double, P * 3); A(xl, double, P * 3); A(Hpp, double, K * 36); A(bp, double, K * 6);
+        A(Hs, double, n * (n + 1)); A(xp, double, n + 8);
+        A(poses_out, float, K * 16); A(points_out, float, P * 3); A(erase, uint8_t, E); A(stats, int, 16);
+#undef A
+        h->slots.push_back(s);
+    }
+    if (!okalloc || hipMalloc((void**)&h->d_probs, sizeof(LbaProblem) * max_batch) != hipSuccess ||
+        hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) {
+        set_error("LBA arena allocation failed");
+        oslam_lba_destroy(h);
+        return OSLAM_E_HIP;
+    }
+    *h->h_stop = 0;
+    OSLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0));
+    h->lds = kRowBufBytes + 64;
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    *out = h;
+    return OSLAM_OK;
+}
+
+volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h) { return h ? (volatile int32_t*)h->h_stop : nullptr; }
+
+// Host drop-in: gathers nothing (the caller flattens the graph), builds the point-major /
+// keyframe-major edge orders, uploads, runs, downloads.  Edge outputs are in the caller's order.
+int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                       const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4]) {
+    if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase))) {
+        set_error("NULL argument");
+        return OSLAM_E_INVALID;
+    }
+    if (nKF < 1 || nKF > h->max_kf || nP < 0 || nP > h->max_pts || nE < 0 || nE > h->max_edges) {
+        set_error("problem (%d keyframes, %d points, %d edges) exceeds the handle capacity (%d, %d, %d)", nKF, nP, nE, h->max_kf, h->max_pts, h->max_edges);
+        return OSLAM_E_CAPACITY;
+    }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    // stable sort by point; detect duplicate (kf, pt) observations (the reference has one per keyframe)
+    std::vector<int> order(nE);
+    for (int i = 0; i < nE; i++) {
+        if (edge_kf[i] < 0 || edge_kf[i] >= nKF || edge_pt[i] < 0 || edge_pt[i] >= nP) { set_error("edge %d references vertex out of range", i); return OSLAM_E_INVALID; }
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return edge_pt[a] < edge_pt[b]; });
+    std::vector<int> ekf(nE), ept(nE), pt_start(nP + 1, 0), pose_start(nKF + 1, 0), pose_edges(nE);
+    std::vector<float> eobs((size_t)nE * 3), einfo(nE);
+    for (int i = 0; i < nE; i++) {
+        const int s = order[i];
+        ekf[i] = edge_kf[s]; ept[i] = edge_pt[s]; einfo[i] = edge_invSigma2[s];
+        for (int k = 0; k < 3; k++) eobs[(size_t)i * 3 + k] = edge_obs[(size_t)s * 3 + k];
+        pt_start[ept[i] + 1]++;
+        pose_start[ekf[i] + 1]++;
+    }
+    for (int p = 0; p < nP; p++) pt_start[p + 1] += pt_start[p];
+    for (int k = 0; k < nKF; k++) pose_start[k + 1] += pose_start[k];
+    {
+        std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
+        for (int i = 0; i < nE; i++) pose_edges[cur[ekf[i]]++] = i;
+    }
+    for (int p = 0; p < nP; p++) {
+        if (pt_start[p + 1] - pt_start[p] > 64) { set_error("point %d has more than 64 observations", p); return OSLAM_E_CAPACITY; }
+        for (int i = pt_start[p]; i < pt_start[p + 1]; i++)
+            for (int j = i + 1; j < pt_start[p + 1]; j++)
+                if (ekf[i] == ekf[j]) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
+    }
+    oslam_lba::Slot& s = h->slots[0];
+#define UP(dst, src, bytes) if ((bytes) > 0) OSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
+    UP(s.poses, poses, (size_t)nKF * 64); UP(s.fixed, fixed, (size_t)nKF); UP(s.points, points, (size_t)nP * 12);
+    UP(s.e_kf, ekf.data(), (size_t)nE * 4); UP(s.e_pt, ept.data(), (size_t)nE * 4); UP(s.e_obs, eobs.data(), (size_t)nE * 12);
+    UP(s.e_info, einfo.data(), (size_t)nE * 4); UP(s.pt_start, pt_start.data(), (size_t)(nP + 1) * 4);
+    UP(s.pose_start, pose_start.data(), (size_t)(nKF + 1) * 4); UP(s.pose_edges, pose_edges.data(), (size_t)nE * 4);
+    int st[16] = {0};
+#undef UP
+    LbaProblem pr;
+    pr.K = nKF; pr.P = nP; pr.E = nE;
+    pr.poses = s.poses; pr.fixed = s.fixed; pr.points = s.points; pr.e_kf = s.e_kf; pr.e_pt = s.e_pt; pr.e_obs = s.e_obs; pr.e_info = s.e_info;
+    pr.pt_start = s.pt_start; pr.pose_start = s.pose_start; pr.pose_edges = s.pose_edges;
+    pr.Xa = s.Xa; pr.Xb = s.Xb; pr.chi2 = s.chi2; pr.level = s.level; pr.Hpl = s.Hpl; pr.Hll = s.Hll; pr.Dinv = s.Dinv; pr.bl = s.bl; pr.xl = s.xl;
+    pr.Hpp = s.Hpp; pr.bp = s.bp; pr.Hs = s.Hs; pr.xp = s.xp;
+    pr.poses_out = s.poses_out; pr.points_out = s.points_out; pr.erase = s.erase; pr.stats = s.stats;
+    pr.stop = use_stop_flag ? h->d_stop : nullptr;
+    for (int i = 0; i < 5; i++) pr.K5[i] = K5[i];
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, &pr, sizeof(pr), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(poses_out, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost));
+    if (nP > 0) OSLAM_HIP_CHECK(hipMemcpy(points_out, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost));
+    if (nE > 0) {
+        std::vector<uint8_t> er(nE);
+        OSLAM_HIP_CHECK(hipMemcpy(er.data(), s.erase, (size_t)nE, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nE; i++) erase[order[i]] = er[i];
+    }
+    if (stats) {
+        OSLAM_HIP_CHECK(hipMemcpy(st, s.stats, sizeof(st), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; i++) stats[i] = st[i];
+    }
+    return OSLAM_OK;
+}
+
+}  // extern "C"

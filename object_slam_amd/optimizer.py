@@ -51,3 +51,43 @@ class PoseOptimizer:
         a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(self.L.oslam_poseopt_results_device(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return a.value, b.value, c.value, d.value
+
+
+class LocalBundleAdjuster:
+    """Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:453-778) on a flattened graph."""
+
+    def __init__(self, max_keyframes=64, max_points=8192, max_edges=65536, max_batch=1, device=0):
+        self.L = _lib.lib()
+        self.L.oslam_lba_stop_flag.restype = C.POINTER(C.c_int32)
+        self.h = C.c_void_p()
+        check(self.L.oslam_lba_create(C.byref(self.h), max_batch, max_keyframes, max_points, max_edges, device))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.oslam_lba_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def stop_flag(self):
+        """The pbStopFlag: a pinned int visible to the running kernel (set [0] = 1 to abort)."""
+        return self.L.oslam_lba_stop_flag(self.h)
+
+    def LocalBundleAdjustment(self, poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag=False):
+        """Returns (poses_out [K,4,4] f32, points_out [P,3] f32, erase u8[E], stats(it1, trials1, it2, trials2))."""
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        ekf = np.ascontiguousarray(edge_kf, np.int32)
+        ept = np.ascontiguousarray(edge_pt, np.int32)
+        eobs = np.ascontiguousarray(edge_obs, np.float32).reshape(-1, 3)
+        einv = np.ascontiguousarray(edge_invSigma2, np.float32)
+        K = np.ascontiguousarray(K5, np.float32)
+        pout = np.zeros_like(poses)
+        xout = np.zeros_like(points)
+        erase = np.zeros(max(len(ekf), 1), np.uint8)
+        stats = np.zeros(4, np.int32)
+        check(self.L.oslam_lba_optimize(self.h, len(poses), ptr(poses), ptr(fixed), len(points), ptr(points), len(ekf), ptr(ekf),
+                                        ptr(ept), ptr(eobs), ptr(einv), ptr(K), int(use_stop_flag), ptr(pout), ptr(xout),
+                                        ptr(erase), ptr(stats)))
+        return pout.reshape(-1, 4, 4), xout, erase[:len(ekf)], tuple(int(v) for v in stats)

@@ -1,0 +1,60 @@
+"""GPU parity: HIP Optimizer::LocalBundleAdjustment vs the CPU oracle.  Tolerance (north_star):
+poses / landmarks within 1e-4 relative; erase flags identical."""
+import numpy as np
+import pytest
+
+from object_slam_amd import LocalBundleAdjuster, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def _run(oracle, ba, q, **kw):
+    a = ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], **kw)
+    o = oracle.local_bundle_adjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+    return a, o
+
+
+def _compare(a, o):
+    po, xo, er, st = a
+    opo, oxo, oer, ost = o
+    assert np.abs(po - opo).max() / max(1.0, np.abs(opo).max()) <= RTOL
+    assert np.abs(xo - oxo).max() / max(1.0, np.abs(oxo).max()) <= RTOL
+    np.testing.assert_array_equal(er, oer)
+    assert st[0] == ost[0] and st[2] == ost[2], (st, ost)
+
+
+@pytest.mark.parametrize("seed,KL,KF,P", [(3, 4, 2, 150), (4, 6, 3, 300), (5, 10, 0, 500), (6, 20, 20, 4000)])
+def test_lba_matches_oracle(oracle, seed, KL, KF, P):
+    q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, stereo_frac=[0.85, 1.0, 0.0][seed % 3])
+    ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536)
+    a, o = _run(oracle, ba, q)
+    _compare(a, o)
+    # edges in a shuffled (non point-major) order give the same answer
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(len(q["edge_kf"]))
+    q2 = dict(q, edge_kf=q["edge_kf"][perm], edge_pt=q["edge_pt"][perm], edge_obs=q["edge_obs"][perm], edge_invSigma2=q["edge_invSigma2"][perm])
+    a2 = ba.LocalBundleAdjustment(q2["poses"], q2["fixed"], q2["points"], q2["edge_kf"], q2["edge_pt"], q2["edge_obs"], q2["edge_invSigma2"], q2["K"])
+    np.testing.assert_array_equal(a2[2], a[2][perm])
+    assert np.abs(a2[0] - a[0]).max() < 1e-5
+    ba.close()
+
+
+def test_lba_stop_flag_and_errors(oracle):
+    q = synth.make_lba_problem(9, K_local=5, K_fixed=2, P=200)
+    ba = LocalBundleAdjuster(max_keyframes=16, max_points=512, max_edges=4096)
+    flag = ba.stop_flag()
+    flag[0] = 1   # set before the call: nothing changes (reference :655-657)
+    po, xo, er, st = ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], use_stop_flag=True)
+    assert np.array_equal(po.reshape(-1, 16), q["poses"].reshape(-1, 16)) and np.array_equal(xo, q["points"]) and er.sum() == 0 and st == (0, 0, 0, 0)
+    flag[0] = 0
+    a, o = _run(oracle, ba, q, use_stop_flag=True)
+    _compare(a, o)
+    from object_slam_amd import OslamError
+    with pytest.raises(OslamError):   # duplicate observation
+        ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], np.r_[q["edge_kf"], q["edge_kf"][:1]], np.r_[q["edge_pt"], q["edge_pt"][:1]],
+                                 np.r_[q["edge_obs"], q["edge_obs"][:1]], np.r_[q["edge_invSigma2"], q["edge_invSigma2"][:1]], q["K"])
+    with pytest.raises(OslamError):   # capacity
+        big = synth.make_lba_problem(10, K_local=20, K_fixed=0, P=600)
+        ba.LocalBundleAdjustment(big["poses"], big["fixed"], big["points"], big["edge_kf"], big["edge_pt"], big["edge_obs"], big["edge_invSigma2"], big["K"])
+    ba.close()
