@@ -7,9 +7,9 @@
 // Deterministic by construction (no floating-point atomics):
 //   * point blocks (Hll, b_l, per-edge Hpl) : one thread per map point over its edge list;
 //   * pose blocks (Hpp, b_p)                : one wavefront per keyframe, shuffle reduction;
-//   * Schur complement                      : one wavefront per block-row a; for every edge (a,l)
-//     the lanes cover the other observations (b,l) of point l, so each lane owns a distinct
-//     (a,b) block of the row buffer in LDS; rows are then stored to the reduced system;
+//   * Schur complement                      : one wavefront per 6x6 block (a<=b) of the reduced system;
+//     lanes stride over keyframe a's observations, find the partner observation of keyframe b in
+//     the point's edge list, accumulate B_a Dinv B_b^T in registers, shuffle-tree reduction;
 //   * reduced camera system                 : blocked (6-wide) Cholesky U^T U with the right-hand
 //     side carried as an extra column, back-substitution by one wavefront.
 #include <hip/hip_runtime.h>
@@ -23,10 +23,16 @@
 
 namespace oslam {
 
-constexpr int kLbaThreads = 1024;
+#ifdef OSLAM_LBA_PROFILE
+#define LBA_STAMP(i) do { if (tid == 0) { long long t_ = clock64(); prof[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define LBA_STAMP(i) do { } while (0)
+#endif
+
+constexpr int kLbaThreads = 512;
 constexpr int kLbaWaves = kLbaThreads / 64;
 constexpr int kLbaMaxKF = 128;
-constexpr int kRowBufBytes = 96 * 1024;
+constexpr int kRowBufBytes = 8 * 1024;   // LDS scratch: back-substitution vector (n <= 768 doubles)
 
 struct LbaProblem {
     int K, P, E;
@@ -60,6 +66,7 @@ struct LbaShared {
     SE3 Tn[kLbaMaxKF];     // trial poses
     double R[kLbaMaxKF][9];
     int blk[kLbaMaxKF];    // block index among free poses or -1
+    int free_pose[kLbaMaxKF];   // block index -> keyframe
     double red[2][kLbaWaves][4];
     int flag;
     int stopflag;
@@ -92,13 +99,17 @@ __device__ __forceinline__ void block_red2(double& a, double& b, bool is_max, Lb
 }
 
 __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
-    const LbaProblem pr = probs[blockIdx.x];
+    const LbaProblem& pr = probs[blockIdx.x];   // uniform, read-only: fields come from scalar loads on use
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int K = pr.K, P = pr.P, E = pr.E;
     __shared__ LbaShared S;
     extern __shared__ __align__(16) uint8_t dyn[];
-    double* rowbuf = (double*)dyn;   // [waves_used][6][n+1]
+    double* rowbuf = (double*)dyn;   // scratch: solution vector during back-substitution
     int phase = 0;
+#ifdef OSLAM_LBA_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
 
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
     const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
@@ -106,7 +117,10 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
     // ---- setup ----
     if (tid == 0) {
         int nb = 0;
-        for (int a = 0; a < K; a++) S.blk[a] = pr.fixed[a] ? -1 : nb++;
+        for (int a = 0; a < K; a++) {
+            if (pr.fixed[a]) S.blk[a] = -1;
+            else { S.free_pose[nb] = a; S.blk[a] = nb++; }
+        }
         S.flag = nb;
     }
     for (int a = tid; a < K; a += kLbaThreads) {
@@ -118,13 +132,10 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
     __syncthreads();
     const int nfree = S.flag;
     const int n = 6 * nfree, ld = n + 1;
-    int rw = kRowBufBytes / (6 * ld * 8);
-    if (rw > kLbaWaves) rw = kLbaWaves;
-    if (rw < 1) rw = 1;
 
     double* X = pr.Xa;    // current points
     double* Xn = pr.Xb;   // trial points
-    int st_its[2] = {0, 0}, st_trials[2] = {0, 0};
+    int st_its0 = 0, st_its1 = 0, st_trials0 = 0, st_trials1 = 0;
     // force-stop flag (g2o setForceStopFlag): one lane polls, the workgroup agrees on the value
     auto stopped = [&]() -> bool {
         if (!pr.stop) return false;
@@ -185,24 +196,28 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     F0 += r0;
                     jac_binary(cam, pc, S.R[a], stereo, Jp, Jx);
                     const double wi = w * info;
-                    const int D = stereo ? 3 : 2;
+                    // mono edges carry a zero third row (J, e): the 3-row loops add exact zeros
                     int k = 0;
+#pragma unroll
                     for (int i = 0; i < 3; i++) {
                         double sb = 0;
-                        for (int d = 0; d < D; d++) sb += Jx[d * 3 + i] * (info * er[d]);
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jx[d * 3 + i] * (info * er[d]);
                         bl[i] -= w * sb;
+#pragma unroll
                         for (int j = i; j < 3; j++) {
                             double sh = 0;
-                            for (int d = 0; d < D; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
+                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
                             hl[k++] += sh;
                         }
                     }
                     if (S.blk[a] >= 0) {
                         double* B = pr.Hpl + (long long)e * 18;
+#pragma unroll
                         for (int i = 0; i < 6; i++)
+#pragma unroll
                             for (int j = 0; j < 3; j++) {
                                 double sh = 0;
-                                for (int d = 0; d < D; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
+                                _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
                                 B[i * 3 + j] = sh;
                             }
                     }
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                 pr.bl[p * 3] = bl[0]; pr.bl[p * 3 + 1] = bl[1]; pr.bl[p * 3 + 2] = bl[2];
                 dmax = fmax(dmax, fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5]))));
             }
+            LBA_STAMP(0);
             // ---------- linearise: pose-major (Hpp, b_p), one wavefront per keyframe ----------
             for (int a = wv; a < K; a += kLbaWaves) {
                 if (S.blk[a] < 0) continue;
@@ -234,17 +250,17 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     if (robust) huber(c2, stereo ? dStereo : dMono, r0, w);
                     jac_binary(cam, pc, S.R[a], stereo, Jp, Jx);
                     const double wi = w * info;
-                    const int D = stereo ? 3 : 2;
+                    // mono edges carry a zero third row (J, e): the 3-row loops add exact zeros
                     int k = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++) {
                         double sb = 0;
-                        for (int d = 0; d < D; d++) sb += Jp[d * 6 + i] * (info * er[d]);
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jp[d * 6 + i] * (info * er[d]);
                         acc[21 + i] -= w * sb;
 #pragma unroll
                         for (int j = i; j < 6; j++) {
                             double sh = 0;
-                            for (int d = 0; d < D; d++) sh += Jp[d * 6 + i] * wi * Jp[d * 6 + j];
+                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jp[d * 6 + j];
                             acc[k++] += sh;
                         }
                     }
@@ -259,6 +275,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     for (int i = 0; i < 6; i++) pr.bp[a * 6 + i] = acc[21 + i];
                 }
             }
+            LBA_STAMP(1);
             block_red2(F0, dmax, false, S, phase);   // F0 summed (dmax unused: lambda init recomputes the maxima)
             double currentChi = F0;
             if (iter == 0) {   // computeLambdaInit over pose and point diagonals
@@ -291,82 +308,112 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     for (int i = 0; i < 3; i++) pr.xl[p * 3 + i] = Di[i * 3] * b[0] + Di[i * 3 + 1] * b[1] + Di[i * 3 + 2] * b[2];   // db
                 }
                 __syncthreads();
-                // ---------- Schur complement, one wavefront per block-row ----------
-                if (wv < rw) {
-                    double* rb = rowbuf + (size_t)wv * 6 * ld;
-                    for (int a = wv; a < K; a += rw) {
-                        const int ba = S.blk[a];
-                        if (ba < 0) continue;
-                        const int c0 = 6 * ba;
-                        for (int i = lane; i < 6 * ld; i += 64) rb[i] = 0;
-                        if (lane < 36) {
-                            const int r = lane / 6, cc = lane % 6;
-                            rb[r * ld + c0 + cc] = pr.Hpp[a * 36 + lane] + (r == cc ? lambda : 0.0);
-                        }
-                        double bs[6];
-                        for (int i = 0; i < 6; i++) bs[i] = pr.bp[a * 6 + i];
-                        for (int q = pr.pose_start[a]; q < pr.pose_start[a + 1]; q++) {
+                LBA_STAMP(2);
+                // ---------- Schur complement: one wavefront per (a <= b) block of the reduced system ----------
+                // Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_l B_al Dinv_l B_bl^T over points l seen by both;
+                // lanes stride over keyframe a's observations and look the partner edge up in point l's
+                // (short) edge list; fixed lane assignment + shuffle tree => deterministic sums.
+                {
+                    const int nblk = nfree * (nfree + 1) / 2;
+                    for (int t = wv; t < nblk; t += kLbaWaves) {
+                        // unrank t -> (ba <= bb) in row-major order of the upper triangle
+                        int ba = 0, rem = t;
+                        while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
+                        const int bb = ba + rem;
+                        const int a = S.free_pose[ba], b2 = S.free_pose[bb];
+                        double acc[36];
+#pragma unroll
+                        for (int i = 0; i < 36; i++) acc[i] = 0;
+                        double bsv[6] = {0, 0, 0, 0, 0, 0};
+                        for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
                             const int e = pr.pose_edges[q];
                             if (pr.level[e] != 0) continue;
                             const int p = pr.e_pt[e];
+                            int e2 = -1;
+                            if (a == b2) e2 = e;
+                            else
+                                for (int c2 = pr.pt_start[p]; c2 < pr.pt_start[p + 1]; c2++)
+                                    if (pr.e_kf[c2] == b2) { e2 = c2; break; }
+                            if (e2 < 0 || pr.level[e2] != 0) continue;
                             const double* Ba = pr.Hpl + (long long)e * 18;
+                            const double* Bb = pr.Hpl + (long long)e2 * 18;
                             const double* Di = pr.Dinv + (long long)p * 9;
-                            const double* db = pr.xl + p * 3;
                             double BD[18];
+#pragma unroll
                             for (int i = 0; i < 6; i++) {
-                                const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2 = Ba[i * 3 + 2];
-                                BD[i * 3] = b0 * Di[0] + b1 * Di[3] + b2 * Di[6];
-                                BD[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2 * Di[7];
-                                BD[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2 * Di[8];
-                                bs[i] -= b0 * db[0] + b1 * db[1] + b2 * db[2];
+                                const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
+                                BD[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
+                                BD[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
+                                BD[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
                             }
-                            const int e0 = pr.pt_start[p], e1 = pr.pt_start[p + 1];
-                            for (int e2 = e0 + lane; e2 < e1; e2 += 64) {
-                                if (pr.level[e2] != 0) continue;
-                                const int bb = S.blk[pr.e_kf[e2]];
-                                if (bb < ba) continue;   // upper triangle only (fixed poses have bb = -1)
-                                const double* Bb = pr.Hpl + (long long)e2 * 18;
-                                double* dst = rb + 6 * bb;
-                                for (int i = 0; i < 6; i++)
-                                    for (int j = 0; j < 6; j++)
-                                        dst[i * ld + j] -= BD[i * 3] * Bb[j * 3] + BD[i * 3 + 1] * Bb[j * 3 + 1] + BD[i * 3 + 2] * Bb[j * 3 + 2];
+                            if (a == b2) {
+                                const double* db = pr.xl + p * 3;
+#pragma unroll
+                                for (int i = 0; i < 6; i++) bsv[i] += Ba[i * 3] * db[0] + Ba[i * 3 + 1] * db[1] + Ba[i * 3 + 2] * db[2];
                             }
+#pragma unroll
+                            for (int i = 0; i < 6; i++)
+#pragma unroll
+                                for (int j = 0; j < 6; j++)
+                                    acc[i * 6 + j] += BD[i * 3] * Bb[j * 3] + BD[i * 3 + 1] * Bb[j * 3 + 1] + BD[i * 3 + 2] * Bb[j * 3 + 2];
                         }
-                        if (lane < 6) rb[lane * ld + n] = bs[lane];
-                        for (int i = lane; i < 6 * (ld - c0); i += 64) {
-                            const int r = i / (ld - c0), cc = c0 + i % (ld - c0);
-                            pr.Hs[(size_t)(c0 + r) * ld + cc] = rb[r * ld + cc];
+#pragma unroll
+                        for (int i = 0; i < 36; i++) acc[i] = wsum(acc[i]);
+                        if (a == b2) {
+#pragma unroll
+                            for (int i = 0; i < 6; i++) bsv[i] = wsum(bsv[i]);
+                        }
+                        if (lane == 0) {
+                            for (int i = 0; i < 6; i++)
+                                for (int j = 0; j < 6; j++) {
+                                    double v = -acc[i * 6 + j];
+                                    if (a == b2) v += pr.Hpp[a * 36 + i * 6 + j] + (i == j ? lambda : 0.0);
+                                    pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
+                                }
+                            if (a == b2)
+                                for (int i = 0; i < 6; i++) pr.Hs[(size_t)(6 * ba + i) * ld + n] = pr.bp[a * 6 + i] - bsv[i];
                         }
                     }
                 }
                 __syncthreads();
+                LBA_STAMP(3);
                 // ---------- blocked Cholesky U^T U of the reduced system, rhs as column n ----------
                 if (tid == 0) S.flag = 1;
                 __syncthreads();
                 for (int j0 = 0; j0 < n; j0 += 6) {
                     if (wv == 0) {   // panel: factor the 6x6 diagonal block, scale the 6 pivot rows
                         double Dg[36];
+#pragma unroll
                         for (int i = 0; i < 6; i++)
+#pragma unroll
                             for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? pr.Hs[(size_t)(j0 + i) * ld + j0 + k] : 0.0;
                         bool good = true;
+#pragma unroll
                         for (int j = 0; j < 6; j++) {   // U^T U on the 6x6 (all lanes redundantly)
                             double d = Dg[j * 6 + j];
                             if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
                             d = sqrt(d);
                             Dg[j * 6 + j] = d;
+#pragma unroll
                             for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] /= d;
+#pragma unroll
                             for (int i = j + 1; i < 6; i++)
+#pragma unroll
                                 for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
                         }
                         if (!good && lane == 0) S.flag = 0;
                         for (int k = j0 + 6 + lane; k <= n; k += 64) {   // columns right of the block (incl. rhs)
                             double col[6];
+#pragma unroll
                             for (int i = 0; i < 6; i++) col[i] = pr.Hs[(size_t)(j0 + i) * ld + k];
+#pragma unroll
                             for (int j = 0; j < 6; j++) {   // forward substitution with U_diag^T
                                 double s = col[j];
+#pragma unroll
                                 for (int i = 0; i < j; i++) s -= Dg[i * 6 + j] * col[i];
                                 col[j] = s / Dg[j * 6 + j];
                             }
+#pragma unroll
                             for (int i = 0; i < 6; i++) pr.Hs[(size_t)(j0 + i) * ld + k] = col[i];
                         }
                         if (lane < 36) {
@@ -380,9 +427,11 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     for (int ii = wv; ii < m; ii += kLbaWaves) {
                         const int i = j0 + 6 + ii;
                         double pi[6];
+#pragma unroll
                         for (int r = 0; r < 6; r++) pi[r] = pr.Hs[(size_t)(j0 + r) * ld + i];
                         for (int k = i + lane; k <= n; k += 64) {
                             double s = 0;
+#pragma unroll
                             for (int r = 0; r < 6; r++) s += pi[r] * pr.Hs[(size_t)(j0 + r) * ld + k];
                             pr.Hs[(size_t)i * ld + k] -= s;
                         }
@@ -403,6 +452,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                 }
                 if (!ok2) for (int i = tid; i < n; i += kLbaThreads) pr.xp[i] = 0;
                 __syncthreads();
+                LBA_STAMP(4);
                 // ---------- landmarks: x_l = Dinv (b_l - sum_a B_a^T x_a); trial state ----------
                 double sc = 0;
                 for (int p = tid; p < P; p += kLbaThreads) {
@@ -437,6 +487,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     S.Tn[a] = se3_mul(se3_exp(xa), S.T[a]);
                 }
                 __syncthreads();
+                LBA_STAMP(5);
                 double F1 = eval(S.Tn, Xn);
                 block_red2(F1, sc, false, S, phase);
                 double tempChi = F1;
@@ -456,10 +507,11 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
                     ni *= 2;
                 }
                 __syncthreads();
+                LBA_STAMP(6);
                 qmax++;
-                st_trials[stage]++;
+                if (stage == 0) st_trials0++; else st_trials1++;
             } while (rho < 0 && qmax < 10 && !stopped());
-            st_its[stage]++;
+            if (stage == 0) st_its0++; else st_its1++;
             if (qmax == 10 || rho == 0) ok = false;
         }
         if (stage == 0) {
@@ -494,7 +546,10 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
         else for (int i = 0; i < 16; i++) pr.poses_out[a * 16 + i] = pr.poses[a * 16 + i];
     }
     for (int i = tid; i < P * 3; i += kLbaThreads) pr.points_out[i] = early ? pr.points[i] : (float)X[i];
-    if (tid == 0) { pr.stats[0] = st_its[0]; pr.stats[1] = st_trials[0]; pr.stats[2] = st_its[1]; pr.stats[3] = st_trials[1]; }
+#ifdef OSLAM_LBA_PROFILE
+    if (tid == 0) for (int i = 0; i < 8; i++) pr.stats[8 + i] = (int)(prof[i] / 1000);
+#endif
+    if (tid == 0) { pr.stats[0] = st_its0; pr.stats[1] = st_trials0; pr.stats[2] = st_its1; pr.stats[3] = st_trials1; }
 }
 
 }  // namespace oslam
@@ -572,6 +627,12 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     h->lds = kRowBufBytes + 64;
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     *out = h;
+    return OSLAM_OK;
+}
+
+int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
+    if (!h) return OSLAM_E_INVALID;
+    OSLAM_HIP_CHECK(hipMemcpy(out, h->slots[0].stats, 64, hipMemcpyDeviceToHost));
     return OSLAM_OK;
 }
 

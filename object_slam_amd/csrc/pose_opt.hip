@@ -158,17 +158,17 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                     acc[27] += r0;
                     jac_pose_onlypose(cam, p, stereo, J);
                     const double wi = w * info;
-                    const int D = stereo ? 3 : 2;
+                    // mono edges carry a zero third row (J, e): the 3-row loops add exact zeros
                     int k = 0;
 #pragma unroll
                     for (int a = 0; a < 6; a++) {
                         double sb = 0;
-                        for (int d = 0; d < D; d++) sb += J[d * 6 + a] * (info * e[d]);
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) sb += J[d * 6 + a] * (info * e[d]);
                         acc[21 + a] -= w * sb;
 #pragma unroll
                         for (int cc = a; cc < 6; cc++) {
                             double sh = 0;
-                            for (int d = 0; d < D; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
+                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
                             acc[k++] += sh;
                         }
                     }

@@ -30,19 +30,27 @@ __host__ __device__ inline void quat_from_R(const double m[9], double q[4]) {   
         q[0] = (m[7] - m[5]) * t;
         q[1] = (m[2] - m[6]) * t;
         q[2] = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 4]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
-        double qq[4];
-        qq[i] = 0.5 * t;
+    } else if (!(m[4] > m[0]) && !(m[8] > m[0])) {   // i = 0, j = 1, k = 2 (explicit cases: no dynamic indexing)
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q[0] = 0.5 * t;
         t = 0.5 / t;
-        qq[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        qq[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        qq[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
-        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+        q[3] = (m[7] - m[5]) * t;
+        q[1] = (m[3] + m[1]) * t;
+        q[2] = (m[6] + m[2]) * t;
+    } else if ((m[4] > m[0]) && !(m[8] > m[4])) {    // i = 1, j = 2, k = 0
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[2] - m[6]) * t;
+        q[2] = (m[7] + m[5]) * t;
+        q[0] = (m[1] + m[3]) * t;
+    } else {                                         // i = 2, j = 0, k = 1
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[3] - m[1]) * t;
+        q[0] = (m[2] + m[6]) * t;
+        q[1] = (m[5] + m[7]) * t;
     }
 }
 
