@@ -200,6 +200,27 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);
 
 /* ------------------------------------------------------------------------------------------
+ * Frame::ComputeStereoMatches (src/Frame.cc:706-880): row-band Hamming search of left keypoints in the
+ * right image (levels +-1, u in [uL - bf/b, uL], best < (TH_HIGH+TH_LOW)/2), 11-shift 11x11 SAD on the
+ * left keypoint's pyramid level, parabola sub-pixel fit, depth = bf/disparity, rejection of matches
+ * with SAD >= 1.5*1.4*median.  Reads the pyramids of the two extractor handles' last batch
+ * (mvImagePyramid, include/ORBextractor.h:85).  Outputs mvuRight / mvDepth (-1 = no match).
+ * Window reads that would leave the image (unchecked in the reference) are skipped.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oslam_stereo oslam_stereo_t;
+int oslam_stereo_create(oslam_stereo_t** out, int max_batch, int max_keypoints /* <= 2400 */, int device);
+void oslam_stereo_destroy(oslam_stereo_t* h);
+int oslam_stereo_match(oslam_stereo_t* h, oslam_orb_t* orbL, oslam_orb_t* orbR, int N, const oslam_keypoint_t* keysL,
+                       const uint8_t* descL, int Nr, const oslam_keypoint_t* keysR, const uint8_t* descR, int nlevels,
+                       float bf, float b, float* uRight, float* depth);
+int oslam_stereo_match_batch_device(oslam_stereo_t* h, oslam_orb_t* orbL, oslam_orb_t* orbR, int batch, int kp_stride,
+                                    const oslam_keypoint_t* d_kpL, const uint8_t* d_descL, const int32_t* d_nL,
+                                    int nL_const, const oslam_keypoint_t* d_kpR, const uint8_t* d_descR,
+                                    const int32_t* d_nR, int nR_const, int nlevels, float bf, float b, void* stream);
+int oslam_stereo_results_device(const oslam_stereo_t* h, const float** d_uRight, const float** d_depth,
+                                const int32_t** d_n_matched);
+
+/* ------------------------------------------------------------------------------------------
  * Optimizer::PoseOptimization — motion-only BA (include/Optimizer.h:46, src/Optimizer.cc:239-451):
  * 4 rounds x optimize(10) of g2o Levenberg-Marquardt on one SE3 vertex, Huber(sqrt(5.991) mono,
  * sqrt(7.815) stereo) dropped after round index 2, chi2 re-classification after every round, every

@@ -116,3 +116,31 @@ class ORBmatcher:
         check(self.L.oslam_match_fetch(self.h, b, q_stride, n_q, kp_stride, n_kps, ptr(qm), ptr(qd), ptr(km),
                                        C.byref(nm), C.byref(it), C.c_void_p(stream or 0)))
         return nm.value, qm[:n_q], qd[:n_q], km[:n_kps], it.value
+
+
+class StereoMatcher:
+    """Frame::ComputeStereoMatches (reference src/Frame.cc:706-880) on two ORBextractor handles."""
+
+    def __init__(self, max_keypoints=2400, max_batch=1, device=0):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        check(self.L.oslam_stereo_create(C.byref(self.h), max_batch, max_keypoints, device))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.oslam_stereo_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def ComputeStereoMatches(self, orbL, orbR, keysL, descL, keysR, descR, bf, b):
+        """orbL / orbR: ORBextractor objects that just extracted the pair. Returns (mvuRight, mvDepth)."""
+        keysL = np.ascontiguousarray(keysL, KP_DTYPE)
+        keysR = np.ascontiguousarray(keysR, KP_DTYPE)
+        N = len(keysL)
+        uR = np.zeros(max(N, 1), np.float32)
+        dep = np.zeros(max(N, 1), np.float32)
+        check(self.L.oslam_stereo_match(self.h, orbL.h, orbR.h, N, ptr(keysL), ptr(np.ascontiguousarray(descL, np.uint8)),
+                                        len(keysR), ptr(keysR), ptr(np.ascontiguousarray(descR, np.uint8)), orbL.nlevels,
+                                        C.c_float(bf), C.c_float(b), ptr(uR), ptr(dep)))
+        return uR[:N], dep[:N]

@@ -2,6 +2,7 @@
 #include "matcher_oracle.h"
 
 #include <algorithm>
+#include <climits>
 
 namespace oracle {
 
@@ -226,4 +227,117 @@ void ProjectLastFrame(const LastFrameView& last, const float* Tcw, const float* 
     }
 }
 
+}  // namespace oracle
+
+namespace oracle {
+// reference src/Frame.cc:706-880
+void ComputeStereoMatches(int N, const KeyPoint* keysL, const uint8_t* descL, int Nr, const KeyPoint* keysR,
+                          const uint8_t* descR, const std::vector<Image>& pyrL, const std::vector<Image>& pyrR,
+                          const float* mvScaleFactors, const float* mvInvScaleFactors, float mbf, float mb, float* mvuRight,
+                          float* mvDepth) {
+    for (int i = 0; i < N; i++) { mvuRight[i] = -1.0f; mvDepth[i] = -1.0f; }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = pyrL[0].h;
+    std::vector<std::vector<size_t>> vRowIndices(nRows);
+    for (int iR = 0; iR < Nr; iR++) {
+        const KeyPoint& kp = keysR[iR];
+        const float kpY = kp.y;
+        const float r = 2.0f * mvScaleFactors[keysR[iR].octave];
+        const int maxr = ceil(kpY + r);
+        const int minr = floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);
+    }
+    const float minZ = mb;
+    const float minD = 0;
+    const float maxD = mbf / minZ;
+    std::vector<std::pair<int, int>> vDistIdx;
+    for (int iL = 0; iL < N; iL++) {
+        const KeyPoint& kpL = keysL[iL];
+        const int levelL = kpL.octave;
+        const float vL = kpL.y;
+        const float uL = kpL.x;
+        if ((int)vL < 0 || (int)vL >= nRows) continue;
+        const std::vector<size_t>& vCandidates = vRowIndices[(int)vL];
+        if (vCandidates.empty()) continue;
+        const float minU = uL - maxD;
+        const float maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH;
+        size_t bestIdxR = 0;
+        const uint8_t* dL = descL + (size_t)iL * 32;
+        for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+            const size_t iR = vCandidates[iC];
+            const KeyPoint& kpR = keysR[iR];
+            if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+            const float uR = kpR.x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = DescriptorDistance(dL, descR + iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            const float uR0 = keysR[bestIdxR].x;
+            const float scaleFactor = mvInvScaleFactors[kpL.octave];
+            const float scaleduL = round(kpL.x * scaleFactor);
+            const float scaledvL = round(kpL.y * scaleFactor);
+            const float scaleduR0 = round(uR0 * scaleFactor);
+            const int w = 5;
+            const Image& imL = pyrL[kpL.octave];
+            const Image& imR = pyrR[kpL.octave];
+            const int cy = (int)scaledvL, cxL = (int)scaleduL;
+            const float centerL = imL.row(cy)[cxL];
+            int bestDist2 = INT32_MAX;
+            int bestincR = 0;
+            const int L = 5;
+            std::vector<float> vDists(2 * L + 1);
+            const float iniu = scaleduR0 + L - w;
+            const float endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= imR.w) continue;
+            // The reference reads the left 11x11 window and the right windows [uR0-10, uR0+10] without
+            // checking them (its :810-811 test covers only part of the right side).  Skip where that
+            // would leave the image (undefined behaviour in the reference).
+            if (cy - w < 0 || cy + w >= imL.h || cxL - w < 0 || cxL + w >= imL.w || (int)scaleduR0 - L - w < 0 ||
+                (int)scaleduR0 + L + w >= imR.w)
+                continue;
+            for (int incR = -L; incR <= +L; incR++) {
+                const int cxR = (int)(scaleduR0 + incR);
+                const float centerR = imR.row(cy)[cxR];
+                double acc = 0;   // cv::norm(NORM_L1) on CV_32F accumulates in double
+                for (int dy = -w; dy <= w; dy++)
+                    for (int dx = -w; dx <= w; dx++) {
+                        const float a = (float)imL.row(cy + dy)[cxL + dx] - centerL;
+                        const float bb = (float)imR.row(cy + dy)[cxR + dx] - centerR;
+                        acc += std::fabs(a - bb);
+                    }
+                float dist = (float)acc;
+                if (dist < bestDist2) { bestDist2 = dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1];
+            const float dist2 = vDists[L + bestincR];
+            const float dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+                mvDepth[iL] = mbf / disparity;
+                mvuRight[iL] = bestuR;
+                vDistIdx.push_back(std::pair<int, int>(bestDist2, iL));
+            }
+        }
+    }
+    if (vDistIdx.empty()) return;
+    std::sort(vDistIdx.begin(), vDistIdx.end());
+    const float median = vDistIdx[vDistIdx.size() / 2].first;
+    const float thDist = 1.5f * 1.4f * median;
+    for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+        if (vDistIdx[i].first < thDist) break;
+        mvuRight[vDistIdx[i].second] = -1;
+        mvDepth[vDistIdx[i].second] = -1;
+    }
+}
 }  // namespace oracle

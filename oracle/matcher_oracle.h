@@ -67,3 +67,14 @@ void ProjectLastFrame(const LastFrameView& last, const float* Tcw, const float* 
 void ComputeThreeMaxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3);  // :1601-1642
 
 }  // namespace oracle
+
+namespace oracle {
+// Frame::ComputeStereoMatches, reference src/Frame.cc:706-880.  pyrL/pyrR: un-padded pyramid levels
+// (mvImagePyramid of the left / right extractor).  Out-of-image row indices of the row table
+// (:723-733, unchecked in the reference) are skipped.  Empty match set: nothing to filter (the
+// reference would index an empty vector, :867).
+void ComputeStereoMatches(int N, const KeyPoint* keysL, const uint8_t* descL, int Nr, const KeyPoint* keysR,
+                          const uint8_t* descR, const std::vector<Image>& pyrL, const std::vector<Image>& pyrR,
+                          const float* scaleFactors, const float* invScaleFactors, float bf, float b, float* uRight,
+                          float* depth);
+}  // namespace oracle

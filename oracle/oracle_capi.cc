@@ -176,3 +176,14 @@ void oo_edge_eval(const float* T, const double* X, const double* obs, int stereo
     oo_internal_edge_jac(g, e, Jp, Jx);
 }
 }
+
+extern "C" {
+// stereo: uses the pyramids held by two oracle extractors after extract()
+void oo_stereo_matches(void* orbL, void* orbR, int N, const KeyPoint* keysL, const uint8_t* descL, int Nr,
+                       const KeyPoint* keysR, const uint8_t* descR, float bf, float b, float* uRight, float* depth) {
+    OrbExtractor* L = (OrbExtractor*)orbL;
+    OrbExtractor* R = (OrbExtractor*)orbR;
+    ComputeStereoMatches(N, keysL, descL, Nr, keysR, descR, L->mvImagePyramid, R->mvImagePyramid, L->mvScaleFactor.data(),
+                         L->mvInvScaleFactor.data(), bf, b, uRight, depth);
+}
+}

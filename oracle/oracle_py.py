@@ -251,3 +251,18 @@ def edge_eval(T, X, obs, stereo, binary, K5):
                        _p(err), _p(Jp), _p(Jx))
     D = 3 if stereo else 2
     return err[:D], Jp.reshape(3, 6)[:D], Jx.reshape(3, 3)[:D]
+
+
+def stereo_matches(orbL, orbR, keysL, descL, keysR, descR, bf, b):
+    """Oracle Frame::ComputeStereoMatches; orbL/orbR are OrbExtractor objects that just extracted the pair."""
+    keysL = np.ascontiguousarray(keysL, KP_DTYPE)
+    keysR = np.ascontiguousarray(keysR, KP_DTYPE)
+    N = len(keysL)
+    uR = np.zeros(max(N, 1), np.float32)
+    dep = np.zeros(max(N, 1), np.float32)
+    L = lib()
+    L.oo_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+    L.oo_stereo_matches(orbL.h, orbR.h, N, _p(keysL), _p(np.ascontiguousarray(descL, np.uint8)), len(keysR), _p(keysR),
+                        _p(np.ascontiguousarray(descR, np.uint8)), bf, b, _p(uR), _p(dep))
+    return uR[:N], dep[:N]

@@ -1,0 +1,48 @@
+"""GPU parity: HIP Frame::ComputeStereoMatches vs the CPU oracle (bit-exact mvuRight / mvDepth)."""
+import numpy as np
+import pytest
+
+from object_slam_amd import ORBextractor, StereoMatcher, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,disp", [(5, 24), (6, 7), (7, 60)])
+def test_stereo_matches_kitti_shape(oracle, seed, disp):
+    W, H, NF = 1241, 376, 2000
+    canvas = synth.make_canvas(W + 200, H + 64, seed=seed)
+    left = np.ascontiguousarray(canvas[20:20 + H, 100:100 + W])
+    right = np.ascontiguousarray(canvas[20:20 + H, 100 + disp:100 + disp + W])
+    rng = np.random.default_rng(seed)
+    right = np.clip(right.astype(np.int32) + rng.integers(-2, 3, right.shape), 0, 255).astype(np.uint8)   # sensor noise
+    bf = 386.1448
+    b = bf / 718.856
+    exL, exR = ORBextractor(NF, 1.2, 8, 20, 7, W, H), ORBextractor(NF, 1.2, 8, 20, 7, W, H)
+    kL, dL = exL(left)
+    kR, dR = exR(right)
+    oL, oR = oracle.OrbExtractor(NF), oracle.OrbExtractor(NF)
+    okL, odL = oL.extract(left)
+    okR, odR = oR.extract(right)
+    assert kL.tobytes() == okL.tobytes() and kR.tobytes() == okR.tobytes()
+    sm = StereoMatcher()
+    uR, dep = sm.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, b)
+    ouR, odep = oracle.stereo_matches(oL, oR, okL, odL, okR, odR, bf, b)
+    np.testing.assert_array_equal(uR, ouR)
+    np.testing.assert_array_equal(dep, odep)
+    m = uR >= 0
+    assert m.sum() > 300
+    assert abs(np.median(kL["x"][m] - uR[m]) - disp) < 0.5
+    sm.close(); exL.close(); exR.close()
+
+
+def test_stereo_no_right_keypoints(oracle):
+    W, H = 640, 480
+    frames, _ = synth.make_stream(1, W, H, seed=2)
+    exL, exR = ORBextractor(500, 1.2, 8, 20, 7, W, H), ORBextractor(500, 1.2, 8, 20, 7, W, H)
+    kL, dL = exL(frames[0])
+    kR, dR = exR(np.full((H, W), 90, np.uint8))
+    assert len(kR) == 0
+    sm = StereoMatcher()
+    uR, dep = sm.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 40.0, 0.08)
+    assert np.all(uR == -1) and np.all(dep == -1)
+    sm.close(); exL.close(); exR.close()
