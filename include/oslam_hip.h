@@ -246,6 +246,27 @@ int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, 
 int oslam_poseopt_results_device(const oslam_poseopt_t* h, const float** d_Tcw_out, const uint8_t** d_outlier,
                                  const int32_t** d_n_inliers, const int32_t** d_stats);
 
+/* ObjectOptimizer::PoseOptimization2 (include/ObjectOptimizer.h:23, src/ObjectOptimizer.cc:624-1240), the
+ * pose optimisation Tracking::TrackLocalMap calls (src/Tracking.cc:1022): PoseOptimization plus
+ * semantic reprojection edges to the nearest object-mask pixel.  Host pointers.  The object layer
+ * (association, out of scope) supplies: the Object2D masks of the matched objects (uint8 {0,255},
+ * [nObj][H][W], tight), the world positions of every matched Object3D's map points (object-major),
+ * and the M_joint set (:721-726): keypoints whose map point belongs to object joint_obj[j] while
+ * mvObjectKpIndices[kp].first != that object.  Nearest pixel = exact NN under FLANN's float squared
+ * L2, ties -> first pixel in row-major order.  n_semantic = the reference's nSemNum (:1232). */
+typedef struct oslam_semantic {
+    int32_t nObj, H, W;
+    const uint8_t* masks;
+    int32_t nObjMp; const float* objmp_Xw; const int32_t* objmp_obj;
+    int32_t nJoint; const int32_t* joint_kp; const int32_t* joint_obj;
+    const float* kp_uv;      /* [N][2] mvKeysUn[i].pt */
+    float bounds[4];         /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    float invSigma2_0;       /* mvInvLevelSigma2[0] */
+} oslam_semantic_t;
+int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs,
+                         const float* invSigma2, const uint8_t* has_mp, const float K5[5], const oslam_semantic_t* sem,
+                         float Tcw_out[16], uint8_t* outlier, int32_t* n_inliers, int32_t* n_semantic);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer::LocalBundleAdjustment (include/Optimizer.h:45, src/Optimizer.cc:453-778) after the
  * covisibility gather (:456-504, pointer-graph walk, stays with the caller):

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "common.h"
 #include "se3_math.h"
 
@@ -15,6 +17,20 @@ namespace oslam {
 constexpr int kPoseThreads = 256;
 constexpr int kPoseWaves = kPoseThreads / 64;
 constexpr int kRedN = 29;   // 21 H (upper) + 6 b + chi + 1 spare
+
+// Semantic constraints of ObjectOptimizer::PoseOptimization2 (reference src/ObjectOptimizer.cc:624-1240)
+struct SemCtx {
+    int nObj;
+    const short2* area;        // mask pixels == 255 as (col,row), row-major scan order per object (:699-710)
+    const int* area_start;     // [nObj+1]
+    int nObjMp; const float* objmp_Xw; const int* objmp_obj;          // object map points, object-major
+    int nJoint; const int* joint_kp; const int* joint_obj;             // M_joint candidates (:721-726)
+    const float* kp_uv;        // [N][2] mvKeysUn[i].pt
+    float minX, minY, maxX, maxY, invSigma2_0;
+    // semantic edge store (capacity nJoint + nObjMp): M_joint edges first, then M_semantic
+    float* e_Xw; float* e_obs; uint8_t* e_level; double* e_chi2; int* e_obj; uint8_t* e_out; int* e_tmp;
+    int* nSem;                 // [B] semantic constraints used (nSemNum, :1232)
+};
 
 struct PoseCtx {
     const float* Tcw;        // [B][16]
@@ -28,6 +44,7 @@ struct PoseCtx {
     uint8_t* outlier;        // [B][stride]
     int* n_inliers;          // [B]
     int* stats;              // [B][2] LM iterations, trials
+    SemCtx sem;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -57,6 +74,37 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [2][
     phase ^= 1;   // next reduction uses the other buffer: one barrier per reduction is enough
 }
 
+// exact nearest mask pixel under FLANN's float L2 (squared); ties -> first in scan order
+__device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, float v, int& idx, float& d2) {
+    const int s0 = sm.area_start[o], s1 = sm.area_start[o + 1];
+    if (s1 <= s0) return false;
+    float best = 0;
+    int bi = -1;
+    for (int i = s0; i < s1; i++) {
+        const short2 p = sm.area[i];
+        const float dx = (float)p.x - u, dy = (float)p.y - v;
+        float d = 0;
+        d += dx * dx;
+        d += dy * dy;
+        if (bi < 0 || d < best) { best = d; bi = i; }
+    }
+    idx = bi;
+    d2 = best;
+    return true;
+}
+
+// cv::Mat R*P + t as a single gemm: fp64 accumulation, one rounding to float
+__device__ __forceinline__ void project_f32(const float* T, const float* P, float Pc[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) s += (double)T[r * 4 + k] * (double)P[k];
+        Pc[r] = (float)(s + (double)T[r * 4 + 3]);
+    }
+}
+
+template <bool SEM>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const int N = c.n ? c.n[b] : c.n_const;
@@ -93,13 +141,46 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     const int nInitial = s_cnt[0];
     if (nInitial < 3) {   // reference :364-365: return 0, pose untouched
         if (tid < 16) c.Tcw_out[b * 16 + tid] = T0f[tid];
-        if (tid == 0) { c.n_inliers[b] = 0; if (c.stats) { c.stats[b * 2] = 0; c.stats[b * 2 + 1] = 0; } }
+        if (tid == 0) { c.n_inliers[b] = 0; if (c.stats) { c.stats[b * 2] = 0; c.stats[b * 2 + 1] = 0; } if (SEM) c.sem.nSem[b] = 0; }
         return;
     }
 
     const SE3 T0 = se3_from_T(T0f);
     SE3 T = T0;
     int nBad = 0, tot_its = 0, tot_trials = 0;
+
+    // ---- semantic edges (PoseOptimization2) ----
+    const SemCtx& sm = c.sem;
+    __shared__ int s_nsem, s_ninit, s_semnum;
+    int nsem = 0, ninit = 0;
+    if (SEM) {
+        // M_joint constraints (:719-767): NN of the keypoint in its object's mask, skipped if d^2 < 1
+        for (int j = tid; j < sm.nJoint; j += kPoseThreads) {
+            const int kp = sm.joint_kp[j], o = sm.joint_obj[j];
+            int idx; float d2;
+            int ok = 0;
+            if (mask_nearest(sm, o, sm.kp_uv[kp * 2], sm.kp_uv[kp * 2 + 1], idx, d2) && !(d2 < 1.0f)) ok = 1 + idx;
+            sm.e_tmp[j] = ok;
+        }
+        __syncthreads();
+        if (tid == 0) {   // ordered compaction (creation order of the reference)
+            int n = 0;
+            for (int j = 0; j < sm.nJoint; j++) {
+                const int ok = sm.e_tmp[j];
+                if (!ok) continue;
+                const int kp = sm.joint_kp[j];
+                const short2 px = sm.area[ok - 1];
+                sm.e_Xw[n * 3] = Xw[kp * 3]; sm.e_Xw[n * 3 + 1] = Xw[kp * 3 + 1]; sm.e_Xw[n * 3 + 2] = Xw[kp * 3 + 2];
+                sm.e_obs[n * 2] = (float)px.x; sm.e_obs[n * 2 + 1] = (float)px.y;
+                sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.joint_obj[j]; sm.e_out[n] = 0;
+                n++;
+            }
+            s_ninit = n; s_nsem = n; s_semnum = n;
+        }
+        __syncthreads();
+        nsem = s_nsem; ninit = s_ninit;
+    }
+    const double infoSem = (double)sm.invSigma2_0;
 
     // residual pass over the active edges at pose P: stores chi2 per edge, returns sum of robust chi2
     auto eval = [&](const SE3& P, bool robust) -> double {
@@ -121,6 +202,20 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
             } else
                 F += c2;
         }
+        if (SEM) {   // semantic edges keep their Huber kernel in every round
+            for (int i = tid; i < nsem; i += kPoseThreads) {
+                if (sm.e_level[i] != 0) continue;
+                const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
+                const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
+                double p[3], e[3];
+                se3_map(P, X, p);
+                const double c2 = edge_error(cam, p, ob, false, infoSem, e);
+                sm.e_chi2[i] = c2;
+                double r0, r1;
+                huber(c2, deltaMono, r0, r1);
+                F += r0;
+            }
+        }
         return F;
     };
 
@@ -130,6 +225,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         // initializeOptimization(0): any active edge?
         int nact = 0;
         for (int i = tid; i < N; i += kPoseThreads) nact += (s_level[i] == 0);
+        if (SEM) for (int i = tid; i < nsem; i += kPoseThreads) nact += (sm.e_level[i] == 0);
         {
             double v[1] = {(double)nact};
             block_sum<1>(v, s_red, phase);
@@ -170,6 +266,35 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                             double sh = 0;
                             _Pragma("unroll") for (int d = 0; d < 3; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
                             acc[k++] += sh;
+                        }
+                    }
+                }
+                if (SEM) {
+                    for (int i = tid; i < nsem; i += kPoseThreads) {
+                        if (sm.e_level[i] != 0) continue;
+                        const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
+                        const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
+                        double p[3], e[3], J[18];
+                        se3_map(T, X, p);
+                        const double c2 = edge_error(cam, p, ob, false, infoSem, e);
+                        sm.e_chi2[i] = c2;
+                        double r0, w;
+                        huber(c2, deltaMono, r0, w);
+                        acc[27] += r0;
+                        jac_pose_onlypose(cam, p, false, J);
+                        const double wi = w * infoSem;
+                        int k = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; a++) {
+                            double sb = 0;
+                            _Pragma("unroll") for (int d = 0; d < 2; d++) sb += J[d * 6 + a] * (infoSem * e[d]);
+                            acc[21 + a] -= w * sb;
+#pragma unroll
+                            for (int cc = a; cc < 6; cc++) {
+                                double sh = 0;
+                                _Pragma("unroll") for (int d = 0; d < 2; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
+                                acc[k++] += sh;
+                            }
                         }
                     }
                 }
@@ -225,6 +350,64 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 if (qmax == 10 || rho == 0) break;   // OptimizationAlgorithm::Terminate
             }
         }
+        if (SEM) {
+            float Pose[16];
+            se3_to_T(T, Pose);   // Converter::toCvMat(vSE3->estimate())
+            // re-gate the M_joint edges (:928-973 after round 0, :1042-1098 afterwards)
+            int dsem = 0;
+            for (int i = tid; i < ninit; i += kPoseThreads) {
+                const float Pw[3] = {sm.e_Xw[i * 3], sm.e_Xw[i * 3 + 1], sm.e_Xw[i * 3 + 2]};
+                float Pc[3];
+                project_f32(Pose, Pw, Pc);
+                const float x = __fdiv_rn(Pc[0], Pc[2]), y = __fdiv_rn(Pc[1], Pc[2]);
+                const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+                bool out;
+                if (u < sm.minX || v < sm.minY || u > sm.maxX || v > sm.maxY) out = true;
+                else {
+                    int ni; float d2;
+                    if (!mask_nearest(sm, sm.e_obj[i], u, v, ni, d2)) continue;
+                    out = d2 > 10;
+                    if (!out) { sm.e_obs[i * 2] = u; sm.e_obs[i * 2 + 1] = v; }   // measurement := projection (:969-971)
+                }
+                if (out) {
+                    sm.e_level[i] = 1;
+                    if (!sm.e_out[i]) { sm.e_out[i] = 1; dsem--; }
+                } else {
+                    sm.e_level[i] = 0;
+                    if (sm.e_out[i]) { sm.e_out[i] = 0; dsem++; }
+                }
+            }
+            if (dsem) atomicAdd(&s_semnum, dsem);
+            if (it == 0) {
+                // M_semantic constraints (:978-1032)
+                for (int m = tid; m < sm.nObjMp; m += kPoseThreads) {
+                    const int o = sm.objmp_obj[m];
+                    float Pc[3];
+                    project_f32(Pose, sm.objmp_Xw + 3 * m, Pc);
+                    const float x = __fdiv_rn(Pc[0], Pc[2]), y = __fdiv_rn(Pc[1], Pc[2]);
+                    const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+                    int ni; float d2;
+                    sm.e_tmp[m] = (mask_nearest(sm, o, u, v, ni, d2) && d2 < 10) ? 1 + ni : 0;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int n = s_nsem;
+                    for (int m = 0; m < sm.nObjMp; m++) {
+                        const int ok = sm.e_tmp[m];
+                        if (!ok) continue;
+                        const short2 px = sm.area[ok - 1];
+                        sm.e_Xw[n * 3] = sm.objmp_Xw[m * 3]; sm.e_Xw[n * 3 + 1] = sm.objmp_Xw[m * 3 + 1]; sm.e_Xw[n * 3 + 2] = sm.objmp_Xw[m * 3 + 2];
+                        sm.e_obs[n * 2] = (float)px.x; sm.e_obs[n * 2 + 1] = (float)px.y;
+                        sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.objmp_obj[m]; sm.e_out[n] = 0;
+                        n++;
+                    }
+                    s_semnum += n - s_nsem;
+                    s_nsem = n;
+                }
+            }
+            __syncthreads();
+            nsem = s_nsem;
+        }
         // inlier / outlier classification (:380-438): excluded edges get a fresh error at the final
         // pose, active edges keep the error of the last LM trial (g2o's _error buffer)
         int bad = 0;
@@ -249,7 +432,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
             block_sum<1>(v, s_red, phase);
             nBad = (int)v[0];
         }
-        if (nInitial < 10) break;   // optimizer.edges().size()<10 (:440)
+        if (nInitial + nsem < 10) break;   // optimizer.edges().size()<10 (:440); semantic edges count too
     }
 
     if (tid == 0) {
@@ -258,6 +441,39 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         for (int k = 0; k < 16; k++) c.Tcw_out[b * 16 + k] = To[k];
         c.n_inliers[b] = nInitial - nBad;
         if (c.stats) { c.stats[b * 2] = tot_its; c.stats[b * 2 + 1] = tot_trials; }
+        if (SEM) sm.nSem[b] = s_semnum;
+    }
+}
+
+// Object2D mask -> ordered list of its 255-pixels (pcl cloud order of reference src/ObjectOptimizer.cc:699-710)
+__global__ __launch_bounds__(64) void k_mask_rowcount(const uint8_t* masks, int H, int W, int* rowcnt) {
+    const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
+    const uint8_t* m = masks + ((long long)o * H + row) * W;
+    int n = 0;
+    for (int x = lane; x < W; x += 64) n += (m[x] == 255);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if (lane == 0) rowcnt[o * H + row] = n;
+}
+
+__global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, int H, int W, int nObj, const int* rowcnt, short2* area,
+                                                  int* area_start) {
+    const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
+    int before = 0;
+    const int upto = o * H + row;
+    for (int i = lane; i < upto; i += 64) before += rowcnt[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
+    if (row == 0 && lane == 0) area_start[o] = before;
+    if (o == nObj - 1 && row == H - 1 && lane == 0) area_start[nObj] = before + rowcnt[upto];
+    const uint8_t* m = masks + ((long long)o * H + row) * W;
+    int base = before;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool f = x < W && m[x] == 255;
+        const unsigned long long bal = __ballot(f);
+        if (f) area[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_short2((short)x, (short)row);
+        base += __popcll(bal);
     }
 }
 
@@ -270,13 +486,27 @@ struct oslam_poseopt {
     float* d_Tout = nullptr; uint8_t* d_outlier = nullptr; int* d_ninl = nullptr; int* d_stats = nullptr;
     // staging for the host API
     float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
+    // semantic variant: grow-only device buffers
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf masks, rowcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
 };
+
+static int ensure(oslam_poseopt::Buf& b, size_t bytes) {
+    if (b.p && bytes <= b.cap) return OSLAM_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = bytes + bytes / 2 + 256;
+    OSLAM_HIP_CHECK(hipMalloc(&b.p, b.cap));
+    return OSLAM_OK;
+}
 
 extern "C" {
 
 void oslam_poseopt_destroy(oslam_poseopt_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_Tout, h->d_outlier, h->d_ninl, h->d_stats, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has};
+    void* ptrs[] = {h->d_Tout, h->d_outlier, h->d_ninl, h->d_stats, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has,
+                    h->masks.p, h->rowcnt.p, h->area.p, h->area_start.p, h->objmp_Xw.p, h->objmp_obj.p, h->joint_kp.p, h->joint_obj.p, h->kp_uv.p,
+                    h->eXw.p, h->eobs.p, h->elevel.p, h->echi2.p, h->eobj.p, h->eout.p, h->etmp.p, h->nsem.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -305,7 +535,8 @@ int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, i
     ALLOC(h->d_Tout, B * 64); ALLOC(h->d_outlier, B * NP); ALLOC(h->d_ninl, B * 4); ALLOC(h->d_stats, B * 8);
     ALLOC(h->d_T, 64); ALLOC(h->d_Xw, NP * 12); ALLOC(h->d_obs, NP * 12); ALLOC(h->d_inv, NP * 4); ALLOC(h->d_has, NP);
 #undef ALLOC
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
     *out = h;
     return OSLAM_OK;
 }
@@ -323,7 +554,8 @@ int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, 
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
     const size_t lds = (size_t)stride * 9 + 64;
-    hipLaunchKernelGGL(k_pose_optimize, dim3(batch), dim3(kPoseThreads), lds, (hipStream_t)stream, c);
+    memset(&c.sem, 0, sizeof(c.sem));
+    hipLaunchKernelGGL(k_pose_optimize<false>, dim3(batch), dim3(kPoseThreads), lds, (hipStream_t)stream, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
@@ -358,6 +590,76 @@ int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const
     OSLAM_HIP_CHECK(hipMemcpy(n_inliers, h->d_ninl, 4, hipMemcpyDeviceToHost));
     if (N > 0) OSLAM_HIP_CHECK(hipMemcpy(outlier, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost));
     if (stats) OSLAM_HIP_CHECK(hipMemcpy(stats, h->d_stats, 8, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+
+int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs, const float* invSigma2,
+                         const uint8_t* has_mp, const float K5[5], const oslam_semantic_t* sem, float Tcw_out[16], uint8_t* outlier,
+                         int32_t* n_inliers, int32_t* n_semantic) {
+    if (!h || !Tcw_in || !K5 || !Tcw_out || !n_inliers || !sem || !n_semantic || (N > 0 && (!Xw || !obs || !invSigma2 || !has_mp || !outlier))) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (N < 0 || N > h->max_points) { set_error("%d points > capacity %d", N, h->max_points); return OSLAM_E_CAPACITY; }
+    if (sem->nObj < 0 || sem->H < 0 || sem->W < 0 || sem->W >= 32768 || sem->H >= 32768 || sem->nObjMp < 0 || sem->nJoint < 0) { set_error("bad semantic sizes"); return OSLAM_E_INVALID; }
+    if (sem->nObj > 0 && (!sem->masks || (sem->nObjMp > 0 && (!sem->objmp_Xw || !sem->objmp_obj)) || (sem->nJoint > 0 && (!sem->joint_kp || !sem->joint_obj || !sem->kp_uv)))) { set_error("NULL semantic array"); return OSLAM_E_INVALID; }
+    for (int i = 0; i < sem->nObjMp; i++) if (sem->objmp_obj[i] < 0 || sem->objmp_obj[i] >= sem->nObj) { set_error("objmp_obj out of range"); return OSLAM_E_INVALID; }
+    for (int i = 0; i < sem->nJoint; i++) if (sem->joint_obj[i] < 0 || sem->joint_obj[i] >= sem->nObj || sem->joint_kp[i] < 0 || sem->joint_kp[i] >= N) { set_error("joint index out of range"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    const size_t npx = (size_t)sem->nObj * sem->H * sem->W;
+    const size_t nrows = (size_t)sem->nObj * sem->H;
+    const size_t nsemcap = (size_t)sem->nJoint + sem->nObjMp;
+    int rc;
+    if ((rc = ensure(h->masks, npx + 1)) || (rc = ensure(h->area, (npx + 1) * sizeof(short2))) || (rc = ensure(h->rowcnt, (nrows + 1) * 4)) ||
+        (rc = ensure(h->area_start, ((size_t)sem->nObj + 2) * 4)) || (rc = ensure(h->objmp_Xw, (size_t)sem->nObjMp * 12 + 12)) ||
+        (rc = ensure(h->objmp_obj, (size_t)sem->nObjMp * 4 + 4)) || (rc = ensure(h->joint_kp, (size_t)sem->nJoint * 4 + 4)) ||
+        (rc = ensure(h->joint_obj, (size_t)sem->nJoint * 4 + 4)) || (rc = ensure(h->kp_uv, (size_t)N * 8 + 8)) ||
+        (rc = ensure(h->eXw, nsemcap * 12 + 12)) || (rc = ensure(h->eobs, nsemcap * 8 + 8)) || (rc = ensure(h->elevel, nsemcap + 1)) ||
+        (rc = ensure(h->echi2, nsemcap * 8 + 8)) || (rc = ensure(h->eobj, nsemcap * 4 + 4)) || (rc = ensure(h->eout, nsemcap + 1)) ||
+        (rc = ensure(h->etmp, nsemcap * 4 + 4)) || (rc = ensure(h->nsem, 4)))
+        return rc;
+
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_T, Tcw_in, 64, hipMemcpyHostToDevice));
+    if (N > 0) {
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_Xw, Xw, (size_t)N * 12, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_obs, obs, (size_t)N * 12, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_inv, invSigma2, (size_t)N * 4, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_has, has_mp, (size_t)N, hipMemcpyHostToDevice));
+        if (sem->kp_uv) OSLAM_HIP_CHECK(hipMemcpy((float*)h->kp_uv.p, sem->kp_uv, (size_t)N * 8, hipMemcpyHostToDevice));
+    }
+    if (npx) OSLAM_HIP_CHECK(hipMemcpy((uint8_t*)h->masks.p, sem->masks, npx, hipMemcpyHostToDevice));
+    if (sem->nObjMp) {
+        OSLAM_HIP_CHECK(hipMemcpy((float*)h->objmp_Xw.p, sem->objmp_Xw, (size_t)sem->nObjMp * 12, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy((int*)h->objmp_obj.p, sem->objmp_obj, (size_t)sem->nObjMp * 4, hipMemcpyHostToDevice));
+    }
+    if (sem->nJoint) {
+        OSLAM_HIP_CHECK(hipMemcpy((int*)h->joint_kp.p, sem->joint_kp, (size_t)sem->nJoint * 4, hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy((int*)h->joint_obj.p, sem->joint_obj, (size_t)sem->nJoint * 4, hipMemcpyHostToDevice));
+    }
+    if (sem->nObj > 0 && sem->H > 0 && sem->W > 0) {
+        hipLaunchKernelGGL(k_mask_rowcount, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, sem->H, sem->W, (int*)h->rowcnt.p);
+        hipLaunchKernelGGL(k_mask_fill, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, sem->H, sem->W, sem->nObj, (int*)h->rowcnt.p, (short2*)h->area.p, (int*)h->area_start.p);
+    } else {
+        OSLAM_HIP_CHECK(hipMemset((int*)h->area_start.p, 0, 2 * sizeof(int)));
+    }
+    PoseCtx c;
+    c.Tcw = h->d_T; c.Xw = h->d_Xw; c.obs = h->d_obs; c.invSigma2 = h->d_inv; c.has_mp = h->d_has;
+    c.n = nullptr; c.n_const = N; c.stride = h->max_points;
+    c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    SemCtx& sm = c.sem;
+    sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.nObjMp = sem->nObjMp; sm.objmp_Xw = (float*)h->objmp_Xw.p; sm.objmp_obj = (int*)h->objmp_obj.p;
+    sm.nJoint = sem->nJoint; sm.joint_kp = (int*)h->joint_kp.p; sm.joint_obj = (int*)h->joint_obj.p; sm.kp_uv = (float*)h->kp_uv.p;
+    sm.minX = sem->bounds[0]; sm.minY = sem->bounds[1]; sm.maxX = sem->bounds[2]; sm.maxY = sem->bounds[3]; sm.invSigma2_0 = sem->invSigma2_0;
+    sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p; sm.e_out = (uint8_t*)h->eout.p; sm.e_tmp = (int*)h->etmp.p;
+    sm.nSem = (int*)h->nsem.p;
+    const size_t lds = (size_t)h->max_points * 9 + 64;
+    hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(kPoseThreads), lds, nullptr, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(Tcw_out, h->d_Tout, 64, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(n_inliers, h->d_ninl, 4, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(n_semantic, (int*)h->nsem.p, 4, hipMemcpyDeviceToHost));
+    if (N > 0) OSLAM_HIP_CHECK(hipMemcpy(outlier, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost));
     return OSLAM_OK;
 }
 

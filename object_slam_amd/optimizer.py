@@ -8,6 +8,12 @@ from . import _lib
 from ._lib import check, ptr
 
 
+class Semantic(C.Structure):
+    _fields_ = [("nObj", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("masks", C.c_void_p), ("nObjMp", C.c_int32),
+                ("objmp_Xw", C.c_void_p), ("objmp_obj", C.c_void_p), ("nJoint", C.c_int32), ("joint_kp", C.c_void_p),
+                ("joint_obj", C.c_void_p), ("kp_uv", C.c_void_p), ("bounds", C.c_float * 4), ("invSigma2_0", C.c_float)]
+
+
 class PoseOptimizer:
     """Optimizer::PoseOptimization (reference src/Optimizer.cc:239-451)."""
 
@@ -40,6 +46,33 @@ class PoseOptimizer:
         check(self.L.oslam_pose_optimize(self.h, N, ptr(T), ptr(Xw), ptr(obs), ptr(inv), ptr(has), ptr(K), ptr(out),
                                          ptr(outl), C.byref(n), ptr(stats)))
         return n.value, out.reshape(4, 4), outl[:N], (int(stats[0]), int(stats[1]))
+
+    def PoseOptimization2(self, p):
+        """ObjectOptimizer::PoseOptimization2 (reference src/ObjectOptimizer.cc:624) on a dict with the keys of
+        synth.make_semantic_problem.  Returns (n_inliers, Tcw_out, outlier, nSemNum)."""
+        Xw = np.ascontiguousarray(p["Xw"], np.float32)
+        N = len(Xw)
+        keep = [Xw, np.ascontiguousarray(p["obs"], np.float32), np.ascontiguousarray(p["invSigma2"], np.float32),
+                np.ascontiguousarray(p["has_mp"], np.uint8), np.ascontiguousarray(p["Tcw"], np.float32).reshape(16),
+                np.ascontiguousarray(p["K"], np.float32), np.ascontiguousarray(p["masks"], np.uint8),
+                np.ascontiguousarray(p["objmp_Xw"], np.float32), np.ascontiguousarray(p["objmp_obj"], np.int32),
+                np.ascontiguousarray(p["joint_kp"], np.int32), np.ascontiguousarray(p["joint_obj"], np.int32),
+                np.ascontiguousarray(p["kp_uv"], np.float32)]
+        sem = Semantic()
+        sem.nObj, sem.H, sem.W = keep[6].shape
+        sem.masks = keep[6].ctypes.data
+        sem.nObjMp, sem.objmp_Xw, sem.objmp_obj = len(keep[8]), keep[7].ctypes.data, keep[8].ctypes.data
+        sem.nJoint, sem.joint_kp, sem.joint_obj = len(keep[9]), keep[9].ctypes.data, keep[10].ctypes.data
+        sem.kp_uv = keep[11].ctypes.data
+        for i in range(4):
+            sem.bounds[i] = float(p["bounds"][i])
+        sem.invSigma2_0 = float(p["invSigma2_0"])
+        out = np.zeros(16, np.float32)
+        outl = np.zeros(max(N, 1), np.uint8)
+        n, ns = C.c_int(0), C.c_int(0)
+        check(self.L.oslam_pose_optimize2(self.h, N, ptr(keep[4]), ptr(Xw), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[5]),
+                                          C.byref(sem), ptr(out), ptr(outl), C.byref(n), C.byref(ns)))
+        return n.value, out.reshape(4, 4), outl[:N], ns.value
 
     def optimize_batch_device(self, batch, stride, d_n, n_const, d_Tcw, d_Xw, d_obs, d_inv, d_has, K5, stream=None):
         K = np.ascontiguousarray(K5, np.float32)

@@ -179,3 +179,46 @@ def make_lba_problem(seed, K_local=20, K_fixed=20, P=4000, track=6, K=KITTI_K, w
                 points=(pts + rng.normal(0, point_err, pts.shape)).astype(np.float32), points_gt=pts,
                 edge_kf=np.array(ekf, np.int32), edge_pt=np.array(ept, np.int32), edge_obs=np.array(eobs, np.float32),
                 edge_invSigma2=np.array(einv, np.float32), K=np.array(K, np.float32))
+
+
+def make_semantic_problem(seed, N=1000, n_obj=3, K=TUM_K, width=640, height=480, **kw):
+    """PoseOptimization2 input: a pose problem plus object masks (boxes with ragged edges), object map
+    points (projecting in / near their mask) and the M_joint set (keypoints with a map point of an
+    object that lie just outside its mask)."""
+    p = make_pose_problem(seed, N=N, K=K, width=width, height=height, **kw)
+    rng = np.random.default_rng(seed + 77)
+    fx, fy, cx, cy, bf = K
+    T = p["T_gt"]
+    masks = np.zeros((n_obj, height, width), np.uint8)
+    boxes = []
+    for o in range(n_obj):
+        w, h = rng.integers(60, 180), rng.integers(60, 160)
+        x0, y0 = rng.integers(20, width - w - 20), rng.integers(20, height - h - 20)
+        masks[o, y0:y0 + h, x0:x0 + w] = 255
+        # ragged border so nearest pixels are not trivially axis aligned
+        for _ in range(40):
+            rx, ry = rng.integers(x0, x0 + w), rng.integers(y0, y0 + h)
+            masks[o, max(ry - 3, 0):ry + 3, max(rx - 3, 0):rx + 3] = rng.choice([0, 255])
+        boxes.append((x0, y0, w, h))
+    objmp_Xw, objmp_obj = [], []
+    for o, (x0, y0, w, h) in enumerate(boxes):
+        m = int(rng.integers(30, 120))
+        u = rng.uniform(x0 - 12, x0 + w + 12, m)
+        v = rng.uniform(y0 - 12, y0 + h + 12, m)
+        z = rng.uniform(1.0, 5.0, m)
+        Xc = np.stack([(u - cx) * z / fx, (v - cy) * z / fy, z], 1)
+        Xw = (Xc - T[:3, 3]) @ T[:3, :3]
+        objmp_Xw.append(Xw)
+        objmp_obj += [o] * m
+    kp_uv = p["obs"][:, :2].copy()
+    joint_kp, joint_obj = [], []
+    for o, (x0, y0, w, h) in enumerate(boxes):
+        near = np.where((p["has_mp"] > 0) & (kp_uv[:, 0] > x0 - 15) & (kp_uv[:, 0] < x0 + w + 15) & (kp_uv[:, 1] > y0 - 15) &
+                        (kp_uv[:, 1] < y0 + h + 15))[0]
+        sel = near[rng.random(len(near)) < 0.5]
+        joint_kp += list(sel)
+        joint_obj += [o] * len(sel)
+    p.update(masks=masks, objmp_Xw=np.concatenate(objmp_Xw).astype(np.float32), objmp_obj=np.array(objmp_obj, np.int32),
+             joint_kp=np.array(joint_kp, np.int32), joint_obj=np.array(joint_obj, np.int32), kp_uv=kp_uv.astype(np.float32),
+             bounds=np.array([0, 0, width, height], np.float32), invSigma2_0=np.float32(1.0))
+    return p

@@ -655,3 +655,168 @@ extern "C" void oo_internal_edge_jac(const oracle::Graph& g, const oracle::Graph
     for (int i = 0; i < 18; i++) Jp[i] = a[i];
     for (int i = 0; i < 9; i++) Jx[i] = b[i];
 }
+
+namespace oracle {
+namespace {
+struct MaskArea {
+    std::vector<float> x, y;   // pcl::PointXY(col, row) in row-major scan order (:699-710)
+    // nearestKSearch(p, 1): exact NN, squared float L2 (FLANN L2_Simple: ((0 + dx*dx) + dy*dy))
+    bool nearest(float u, float v, int& idx, float& d2) const {
+        if (x.empty()) return false;
+        float best = 0;
+        int bi = -1;
+        for (size_t i = 0; i < x.size(); i++) {
+            const float dx = x[i] - u, dy = y[i] - v;
+            float d = 0;
+            d += dx * dx;
+            d += dy * dy;
+            if (bi < 0 || d < best) { best = d; bi = (int)i; }
+        }
+        idx = bi;
+        d2 = best;
+        return true;
+    }
+};
+// cv::Mat  R(3x3 float) * P(3x1 float) + t  as one gemm: double accumulation, one rounding
+inline void project_f32(const float* T, const float* P, float Pc[3]) {
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += (double)T[r * 4 + k] * (double)P[k];
+        Pc[r] = (float)(s + (double)T[r * 4 + 3]);
+    }
+}
+}  // namespace
+
+int PoseOptimization2(int N, const float* Tcw_in, const float* Xw, const float* obs, const float* invSigma2,
+                      const uint8_t* has_mp, const float* K5, int nObj, int H, int W, const uint8_t* masks,
+                      int nObjMp, const float* objmp_Xw, const int32_t* objmp_obj, int nJoint, const int32_t* joint_kp,
+                      const int32_t* joint_obj, const float* kp_uv, const float* bounds, float invSigma2_0,
+                      float* Tcw_out, uint8_t* outlier, int* nSemNumOut) {
+    Graph g;
+    g.cam = Camera{K5[0], K5[1], K5[2], K5[3], K5[4]};
+    const float fx = K5[0], fy = K5[1], cx = K5[2], cy = K5[3];
+    g.poses.push_back(se3_from_cvmat(Tcw_in));
+    g.pose_fixed.push_back(0);
+    const float deltaMono = sqrt(5.991);
+    const float deltaStereo = sqrt(7.815);
+    int nSemNum = 0;
+
+    std::vector<MaskArea> areas(nObj);
+    for (int o = 0; o < nObj; o++)
+        for (int row = 0; row < H; row++)
+            for (int col = 0; col < W; col++)
+                if (masks[((size_t)o * H + row) * W + col] == 255) { areas[o].x.push_back((float)col); areas[o].y.push_back((float)row); }
+
+    auto sem_edge = [&](const float* X, float ox, float oy) {
+        GraphEdge e;
+        memset(&e, 0, sizeof(e));
+        e.pose = 0; e.point = -1; e.stereo = false;
+        e.obs[0] = ox; e.obs[1] = oy;
+        e.info = invSigma2_0;
+        e.robust = true; e.delta = deltaMono; e.level = 0; e.semantic = true;
+        for (int k = 0; k < 3; k++) e.Xw[k] = X[k];
+        return e;
+    };
+    // M_joint constraints for the initial optimisation (:719-767)
+    std::vector<int> initEdge, initObj;
+    std::vector<uint8_t> initOutlier;
+    for (int j = 0; j < nJoint; j++) {
+        const int kp = joint_kp[j], o = joint_obj[j];
+        int idx; float d2;
+        if (areas[o].nearest(kp_uv[kp * 2], kp_uv[kp * 2 + 1], idx, d2)) {
+            if (d2 < 1.0) continue;
+            g.edges.push_back(sem_edge(Xw + 3 * kp, areas[o].x[idx], areas[o].y[idx]));
+            initEdge.push_back((int)g.edges.size() - 1);
+            initObj.push_back(o);
+            initOutlier.push_back(0);
+            nSemNum++;
+        }
+    }
+    // regular edges (:800-905), identical to PoseOptimization
+    std::vector<int> idx, regEdge;
+    int nInitialCorrespondences = 0;
+    for (int i = 0; i < N; i++) {
+        if (!has_mp[i]) continue;
+        nInitialCorrespondences++;
+        outlier[i] = 0;
+        GraphEdge e;
+        memset(&e, 0, sizeof(e));
+        e.pose = 0; e.point = -1;
+        e.stereo = !(obs[i * 3 + 2] < 0);
+        e.obs[0] = obs[i * 3]; e.obs[1] = obs[i * 3 + 1]; e.obs[2] = e.stereo ? obs[i * 3 + 2] : 0;
+        e.info = invSigma2[i];
+        e.robust = true;
+        e.delta = e.stereo ? deltaStereo : deltaMono;
+        for (int k = 0; k < 3; k++) e.Xw[k] = Xw[i * 3 + k];
+        g.edges.push_back(e);
+        regEdge.push_back((int)g.edges.size() - 1);
+        idx.push_back(i);
+    }
+    *nSemNumOut = 0;
+    if (nInitialCorrespondences < 3) { memcpy(Tcw_out, Tcw_in, 64); return 0; }
+
+    const float chi2Mono[4] = {5.991, 5.991, 5.991, 5.991};
+    const float chi2Stereo[4] = {7.815, 7.815, 7.815, 7.815};
+    int nBad = 0;
+    for (size_t it = 0; it < 4; it++) {
+        g.poses[0] = se3_from_cvmat(Tcw_in);
+        graph_optimize(g, 10, 0, nullptr);
+        float Pose[16];
+        se3_to_cvmat(g.poses[0], Pose);
+        // re-gate the M_joint edges (:928-973 for it==0, :1042-1098 for it>=1)
+        for (size_t i = 0; i < initEdge.size(); i++) {
+            GraphEdge& e = g.edges[initEdge[i]];
+            const float Pw[3] = {(float)e.Xw[0], (float)e.Xw[1], (float)e.Xw[2]};
+            float Pc[3];
+            project_f32(Pose, Pw, Pc);
+            const float x = Pc[0] / Pc[2], y = Pc[1] / Pc[2];
+            const float u = fx * x + cx, v = fy * y + cy;
+            bool out;
+            if (u < bounds[0] || v < bounds[1] || u > bounds[2] || v > bounds[3]) out = true;
+            else {
+                int ni; float d2;
+                if (!areas[initObj[i]].nearest(u, v, ni, d2)) continue;   // nearestKSearch returned 0: edge untouched
+                out = d2 > 10;
+                if (!out) { e.obs[0] = u; e.obs[1] = v; }   // measurement := the projection itself (:969-971)
+            }
+            if (out) {
+                e.level = 1;
+                if (!initOutlier[i]) { initOutlier[i] = 1; nSemNum--; }
+            } else {
+                e.level = 0;
+                if (initOutlier[i]) { initOutlier[i] = 0; nSemNum++; }
+            }
+        }
+        if (it == 0) {
+            // M_semantic constraints (:978-1032): every object map point whose projection is near the mask
+            for (int m = 0; m < nObjMp; m++) {
+                const int o = objmp_obj[m];
+                float Pc[3];
+                project_f32(Pose, objmp_Xw + 3 * m, Pc);
+                const float x = Pc[0] / Pc[2], y = Pc[1] / Pc[2];
+                const float u = fx * x + cx, v = fy * y + cy;
+                int ni; float d2;
+                if (areas[o].nearest(u, v, ni, d2) && d2 < 10) {
+                    g.edges.push_back(sem_edge(objmp_Xw + 3 * m, areas[o].x[ni], areas[o].y[ni]));
+                    nSemNum++;
+                }
+            }
+        }
+        nBad = 0;
+        for (size_t k = 0; k < regEdge.size(); k++) {
+            GraphEdge& e = g.edges[regEdge[k]];
+            const int i = idx[k];
+            if (outlier[i]) edge_compute_error(g, e);
+            const float chi2 = edge_chi2(e);
+            const float th = e.stereo ? chi2Stereo[it] : chi2Mono[it];
+            if (chi2 > th) { outlier[i] = 1; e.level = 1; nBad++; }
+            else { outlier[i] = 0; e.level = 0; }
+            if (it == 2) e.robust = false;
+        }
+        if (g.edges.size() < 10) break;
+    }
+    se3_to_cvmat(g.poses[0], Tcw_out);
+    *nSemNumOut = nSemNum;
+    return nInitialCorrespondences - nBad;
+}
+}  // namespace oracle

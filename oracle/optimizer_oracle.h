@@ -78,3 +78,20 @@ void LocalBundleAdjustment(int nKF, const float* poses, const uint8_t* fixed, in
                            float* points_out, uint8_t* erase, int* stats /* [4] it1, trials1, it2, trials2 */);
 
 }  // namespace oracle
+
+namespace oracle {
+// ObjectOptimizer::PoseOptimization2, reference src/ObjectOptimizer.cc:624-1240, on flat inputs.
+// Regular inputs as PoseOptimization.  Semantic inputs (the object layer's outputs):
+//   masks    [nObj][H][W] uint8 {0,255}: Object2D.mask of every matched object (mvpObject3Ds[i] != NULL),
+//   objmp_Xw [nObjMp][3], objmp_obj [nObjMp]: world positions of pObj3D->mvpMapPoints, object-major,
+//   joint_kp / joint_obj [nJoint]: keypoints whose map point belongs to object joint_obj but whose
+//            mvObjectKpIndices[idx].first differs (the M_joint set, :721-726), in creation order,
+//   kp_uv [N][2]: mvKeysUn[i].pt, bounds = {mnMinX, mnMinY, mnMaxX, mnMaxY}, invSigma2_0 = mvInvLevelSigma2[0].
+// Nearest mask pixel = exact NN under FLANN's float L2 (squared); ties -> first pixel in row-major order
+// (PCL's order is unspecified).  Returns nInitialCorrespondences - nBad; *nSemNum = semantic constraints used.
+int PoseOptimization2(int N, const float* Tcw_in, const float* Xw, const float* obs, const float* invSigma2,
+                      const uint8_t* has_mp, const float* K5, int nObj, int H, int W, const uint8_t* masks,
+                      int nObjMp, const float* objmp_Xw, const int32_t* objmp_obj, int nJoint, const int32_t* joint_kp,
+                      const int32_t* joint_obj, const float* kp_uv, const float* bounds, float invSigma2_0,
+                      float* Tcw_out, uint8_t* outlier, int* nSemNum);
+}  // namespace oracle

@@ -187,3 +187,14 @@ void oo_stereo_matches(void* orbL, void* orbR, int N, const KeyPoint* keysL, con
                          L->mvInvScaleFactor.data(), bf, b, uRight, depth);
 }
 }
+
+extern "C" {
+int oo_pose_optimization2(int N, const float* Tcw_in, const float* Xw, const float* obs, const float* invSigma2,
+                          const uint8_t* has_mp, const float* K5, int nObj, int H, int W, const uint8_t* masks, int nObjMp,
+                          const float* objmp_Xw, const int32_t* objmp_obj, int nJoint, const int32_t* joint_kp,
+                          const int32_t* joint_obj, const float* kp_uv, const float* bounds, float invSigma2_0, float* Tcw_out,
+                          uint8_t* outlier, int* nSemNum) {
+    return PoseOptimization2(N, Tcw_in, Xw, obs, invSigma2, has_mp, K5, nObj, H, W, masks, nObjMp, objmp_Xw, objmp_obj, nJoint,
+                             joint_kp, joint_obj, kp_uv, bounds, invSigma2_0, Tcw_out, outlier, nSemNum);
+}
+}

@@ -266,3 +266,27 @@ def stereo_matches(orbL, orbR, keysL, descL, keysR, descR, bf, b):
     L.oo_stereo_matches(orbL.h, orbR.h, N, _p(keysL), _p(np.ascontiguousarray(descL, np.uint8)), len(keysR), _p(keysR),
                         _p(np.ascontiguousarray(descR, np.uint8)), bf, b, _p(uR), _p(dep))
     return uR[:N], dep[:N]
+
+
+def pose_optimization2(p):
+    """Oracle ObjectOptimizer::PoseOptimization2 on a synth.make_semantic_problem dict.
+    Returns (n_inliers, Tcw_out, outlier, nSemNum)."""
+    Xw = np.ascontiguousarray(p["Xw"], np.float32)
+    N = len(Xw)
+    masks = np.ascontiguousarray(p["masks"], np.uint8)
+    nObj, H, W = masks.shape
+    out = np.zeros(16, np.float32)
+    outl = np.zeros(max(N, 1), np.uint8)
+    nsem = C.c_int(0)
+    L = lib()
+    L.oo_pose_optimization2.argtypes = [C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = L.oo_pose_optimization2(N, _p(np.ascontiguousarray(p["Tcw"], np.float32).reshape(16)), _p(Xw),
+                                _p(np.ascontiguousarray(p["obs"], np.float32)), _p(np.ascontiguousarray(p["invSigma2"], np.float32)),
+                                _p(np.ascontiguousarray(p["has_mp"], np.uint8)), _p(np.asarray(p["K"], np.float32)), nObj, H, W, _p(masks),
+                                len(p["objmp_obj"]), _p(np.ascontiguousarray(p["objmp_Xw"], np.float32)),
+                                _p(np.ascontiguousarray(p["objmp_obj"], np.int32)), len(p["joint_kp"]),
+                                _p(np.ascontiguousarray(p["joint_kp"], np.int32)), _p(np.ascontiguousarray(p["joint_obj"], np.int32)),
+                                _p(np.ascontiguousarray(p["kp_uv"], np.float32)), _p(np.asarray(p["bounds"], np.float32)),
+                                float(p["invSigma2_0"]), _p(out), _p(outl), C.byref(nsem))
+    return n, out.reshape(4, 4), outl[:N], nsem.value

@@ -80,3 +80,24 @@ def test_pose_optimization_batch(oracle):
         assert ninl[b] == on and _rel(Tout[b].reshape(4, 4), oT) <= RTOL
         np.testing.assert_array_equal(outl[b], ooutl)
     po.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_pose_optimization2_semantic_matches_oracle(oracle, seed):
+    """ObjectOptimizer::PoseOptimization2: semantic M_joint / M_semantic edges with mask nearest-pixel search."""
+    p = synth.make_semantic_problem(seed, N=800, n_obj=3, outlier_frac=0.1)
+    po = PoseOptimizer(max_points=1024)
+    n, T, outl, nsem = po.PoseOptimization2(p)
+    on, oT, ooutl, onsem = oracle.pose_optimization2(p)
+    assert nsem == onsem and nsem > 20, (nsem, onsem)
+    assert _rel(T, oT) <= RTOL
+    np.testing.assert_array_equal(outl, ooutl)
+    assert n == on
+    # the semantic edges change the result w.r.t. plain PoseOptimization
+    n0, T0, _, _ = po.PoseOptimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], p["has_mp"], p["K"])
+    assert np.abs(T0 - T).max() > 0
+    # no objects: identical to PoseOptimization
+    q = dict(p, masks=p["masks"][:0], objmp_Xw=p["objmp_Xw"][:0], objmp_obj=p["objmp_obj"][:0], joint_kp=p["joint_kp"][:0], joint_obj=p["joint_obj"][:0])
+    n1, T1, outl1, ns1 = po.PoseOptimization2(q)
+    assert ns1 == 0 and n1 == n0 and np.array_equal(T1, T0)
+    po.close()
