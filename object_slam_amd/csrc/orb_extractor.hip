@@ -255,6 +255,26 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     }
     (void)pyr_off;
     P.total_cells = cell_base;
+    {
+        // blur launch geometry (k_blur_strip): interior strips x4 = 4..last, border strips = left + 1-2 right;
+        // sized for word-aligned rows, and for the all-border layout of an unaligned caller image at level 0
+        int bi = 0, bbord = 0;
+        P.any_big_cell = 0;
+        for (int l = 0; l < nlevels; l++) {
+            const int w = P.lv[l].w, hh = P.lv[l].h;
+            const int last = ((w - 8) / 4) * 4, nint = w >= 12 ? last / 4 : 0;
+            P.blur_block_base[l] = bi;
+            bi += div_up(nint, 64) * div_up(hh, 4 * kBlurRows);
+            const int nb_aligned = 1 + div_up(w - (nint ? last + 4 : 4), 4);
+            const int nb_all = 1 + div_up(w - 4, 4);   // unaligned rows: every strip goes through the byte path
+            const int nb = l == 0 ? nb_all : nb_aligned;
+            P.blurb_block_base[l] = bbord;
+            bbord += div_up(nb * div_up(hh, kBlurRows), 256);
+            if (P.lv[l].wCell > kWCell || P.lv[l].hCell > kWCell) P.any_big_cell = 1;
+        }
+        P.blur_block_base[nlevels] = bi;
+        P.blurb_block_base[nlevels] = bbord;
+    }
     P.cand_per_image = cand_base;
     P.sel_per_image = sel_base;
     P.out_cap = sel_base;
@@ -370,13 +390,11 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);
-    hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4), batch), dim3(256), 0, st, c);
+    if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
     PROF_MARK(2);
-    for (int l = 0; l < P.nlevels; l++) {
-        const LevelGeom& g = P.lv[l];
-        dim3 grid(div_up(g.w, kBlurTW), div_up(g.h, kBlurTH), batch);
-        hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, st, c, l, h->blur_sse2);
-    }
+    hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, st, c, h->blur_sse2);
+    hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], batch), dim3(256), 0, st, c, h->blur_sse2);
     PROF_MARK(3);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
     PROF_MARK(4);

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
     for (int l = 1; l < P->nlevels; l++)
         if (cell >= P->lv[l].cell_base) level = l;
     const LevelGeom& g = P->lv[level];
+    if (g.wCell <= 40 && g.hCell <= 40) return;   // handled by k_fast_cells_wave
     cell -= g.cell_base;
     const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
     int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
@@ -295,6 +296,299 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
         __syncthreads();
     }
     if (tid == 0) {
+        if (running > g.cell_cap) { atomicOr(c.status, 1); running = g.cell_cap; }
+        *count_out = running;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6 (v2): 7x7 Gaussian, register sliding window.  One thread produces a 4-pixel-wide, kBlurRows
+// tall strip: per input row it loads three aligned u32 words (x-4 .. x+7), forms four horizontal
+// sums and keeps the last seven rows of sums in registers; no LDS, no barriers.  All levels of
+// all images in one launch (blockIdx.x -> level through OrbParams::blur_block_base).
+// ------------------------------------------------------------------------------------------
+constexpr int kBlurRows = 16;
+
+// horizontal 7-tap sums of 4 adjacent pixels.  Interior: three aligned words, byte windows by
+// v_alignbyte, taps by two v_dot4_u32_u8 per pixel (taps 18,34,49,55 fit a byte).
+template <bool BORDER>
+__device__ __forceinline__ void blur_hsum4(const uint8_t* row, int x4, int w, uint32_t KA, uint32_t KB, int k0, int k1, int k2, int k3,
+                                           int out[4]) {
+    if (!BORDER) {
+        const uint32_t w0 = *(const uint32_t*)(row + x4 - 4), w1 = *(const uint32_t*)(row + x4), w2 = *(const uint32_t*)(row + x4 + 4);
+        out[0] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), KB, 0u, false), false);
+        out[1] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), KB, 0u, false), false);
+        out[2] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), KB, 0u, false), false);
+        out[3] = (int)__builtin_amdgcn_udot4(w1, KA, __builtin_amdgcn_udot4(w2, KB, 0u, false), false);
+    } else {
+        int px[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) px[i] = row[reflect101(min(x4 - 3 + i, w + 2), w)];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = k0 * (px[i] + px[i + 6]) + k1 * (px[i + 1] + px[i + 5]) + k2 * (px[i + 2] + px[i + 4]) + k3 * px[i + 3];
+    }
+}
+
+// BORDER=false: strips x4 = 4, 8, ... with all taps inside the row (word loads, no divergence).
+// BORDER=true : the left strip (x4 = 0) and the 1-2 right strips whose taps reflect (byte loads).
+template <bool BORDER>
+__global__ __launch_bounds__(256) void k_blur_strip(OrbCtx c, int sse2_rounding) {
+    const OrbParams* P = c.P;
+    const int* base = BORDER ? P->blurb_block_base : P->blur_block_base;
+    int level = 0;
+    for (int l = 1; l < P->nlevels; l++)
+        if ((int)blockIdx.x >= base[l]) level = l;
+    const LevelGeom& g = P->lv[level];
+    const int b = blockIdx.y;
+    const int bl = blockIdx.x - base[level];
+    int spitch;
+    const uint8_t* src = level_image(c, P, b, level, spitch);
+    const bool aligned = ((spitch & 3) == 0) && ((((unsigned long long)src) & 3ull) == 0);
+    // interior strips: x4 = 4 .. last (last + 8 <= w); when rows are not word aligned every strip is "border"
+    const int last = aligned ? ((g.w - 8) / 4) * 4 : 0;
+    const int nint = aligned && g.w >= 12 ? last / 4 : 0;
+    int x4, y0;
+    if (!BORDER) {
+        const int nbx = (nint + 63) / 64;
+        if (nbx == 0) return;
+        const int bx = bl % nbx, by = bl / nbx;
+        const int si = bx * 64 + (threadIdx.x & 63);
+        if (si >= nint) return;
+        x4 = 4 + si * 4;
+        y0 = (by * 4 + (threadIdx.x >> 6)) * kBlurRows;
+    } else {
+        // border strips: index 0 -> x4 = 0; index k>=1 -> x4 = first strip after the interior + 4*(k-1)
+        const int first_right = nint ? last + 4 : 4;
+        const int nright = (g.w - first_right + 3) / 4;
+        const int nb = 1 + (nright > 0 ? nright : 0);
+        const int t = bl * 256 + threadIdx.x;
+        const int sidx = t % nb, rg = t / nb;
+        x4 = sidx == 0 ? 0 : first_right + (sidx - 1) * 4;
+        y0 = rg * kBlurRows;
+    }
+    if (x4 >= g.w || y0 >= g.h) return;
+    uint8_t* dst = c.blur + (long long)b * c.blur_stride + g.img_off;
+    const int k0 = P->gk[0], k1 = P->gk[1], k2 = P->gk[2], k3 = P->gk[3];
+    const int wvec = g.w & ~3;
+    const uint32_t KA = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
+    const uint32_t KB = (uint32_t)k2 | ((uint32_t)k1 << 8) | ((uint32_t)k0 << 16);
+    int win[7][4];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+        blur_hsum4<BORDER>(src + (long long)reflect101(min(y0 - 3 + r, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[r]);
+#pragma unroll
+    for (int iy = 0; iy < kBlurRows; iy++) {
+        const int y = y0 + iy;
+        if (y >= g.h) break;
+        blur_hsum4<BORDER>(src + (long long)reflect101(min(y + 3, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[6]);
+        uint32_t outw = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int s = k0 * (win[0][i] + win[6][i]) + k1 * (win[1][i] + win[5][i]) + k2 * (win[2][i] + win[4][i]) + k3 * win[3][i];
+            // s <= 257*65535 < 2^24; half-to-even = (s + 0x7FFF + bit16(s)) >> 16, half-up = (s + 0x8000) >> 16
+            const bool rne = sse2_rounding && (BORDER ? (x4 + i) < wvec : true);
+            const int v = rne ? (s + 0x7FFF + ((s >> 16) & 1)) >> 16 : (s + 0x8000) >> 16;
+            outw |= (uint32_t)min(v, 255) << (8 * i);
+        }
+        *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) win[r][i] = win[r + 1][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2+K3 (v2): one WAVEFRONT per FAST cell (cells up to 40x40 interior): no workgroup barriers.
+// Tile rows are fetched as aligned u32 words, scores use min3/max3 trees
+// (arc minimum of 9 = min3 of three min3-of-3), the ini/min threshold vote and the ordered
+// compaction are ballots.  Larger cells fall back to k_fast_cells.
+// ------------------------------------------------------------------------------------------
+constexpr int kWCell = 40;            // max interior edge handled per wavefront
+constexpr int kWTileP = 52;           // tile pitch in bytes (>= kWCell + 6 + 3 alignment slack, multiple of 4)
+constexpr int kWTileRows = kWCell + 6;
+
+template <int TP>
+__device__ __forceinline__ int fast_score3(const uint8_t* t) {
+    constexpr int off[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,        -TP + 3, -2 * TP + 2, -3 * TP + 1,
+                             -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3, -3,       TP - 3,  2 * TP - 2,  3 * TP - 1};
+    const int v = t[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - (int)t[off[k]];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
+    }
+    int A = -256, Bm = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int lo9 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
+        const int hi9 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
+        A = max(A, lo9);
+        Bm = min(Bm, hi9);
+    }
+    return max(max(A, -Bm) - 1, 0);
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
+    const OrbParams* P = c.P;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int cell = blockIdx.x * 4 + wv;
+    if (cell >= P->total_cells) return;
+    int level = 0;
+    for (int l = 1; l < P->nlevels; l++)
+        if (cell >= P->lv[l].cell_base) level = l;
+    const LevelGeom& g = P->lv[level];
+    if (g.wCell > kWCell || g.hCell > kWCell) return;   // handled by k_fast_cells
+    cell -= g.cell_base;
+    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
+    int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
+
+    const int minBX = kRegionBorder, minBY = kRegionBorder;
+    const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
+    const int iniY = minBY + ci * g.hCell, iniX = minBX + cj * g.wCell;
+    int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
+    const bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);
+    if (maxY > maxBY) maxY = maxBY;
+    if (maxX > maxBX) maxX = maxBX;
+    const int cw = maxX - iniX - 6, ch = maxY - iniY - 6;
+    if (skip || cw <= 0 || ch <= 0) {
+        if (lane == 0) *count_out = 0;
+        return;
+    }
+    __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
+    __shared__ uint8_t s_sc[4][kWCell * 64];          // scores, pitch 64
+    __shared__ uint16_t s_work[4][kWCell * kWCell];   // worklist: y*64 + x of pixels passing the quick test, row-major
+    uint8_t* tile = s_tile[wv];
+    uint8_t* sc = s_sc[wv];
+    uint16_t* work = s_work[wv];
+
+    int pitch;
+    const uint8_t* img = level_image(c, P, b, level, pitch);
+    const int rw = cw + 6, rh = ch + 6;
+    const int xa = iniX & ~3, sh = iniX - xa;          // aligned start, byte shift inside the tile
+    const int nwords = (sh + rw + 3) >> 2;              // words per row (<= 13)
+    if (((pitch & 3) == 0) && ((((unsigned long long)img) & 3ull) == 0)) {
+        for (int i = lane; i < nwords * rh; i += 64) {
+            const int ry = i / nwords, wx = i - ry * nwords;
+            // the aligned word may start before the ROI but never before the image row, and ends before column w
+            const uint32_t wv32 = *(const uint32_t*)(img + (long long)(iniY + ry) * pitch + xa + wx * 4);
+            *(uint32_t*)(tile + ry * kWTileP + wx * 4) = wv32;
+        }
+    } else {   // caller's level-0 buffer with an unaligned pitch: byte loads
+        for (int i = lane; i < rw * rh; i += 64) {
+            const int ry = i / rw, rx = i - ry * rw;
+            tile[ry * kWTileP + sh + rx] = img[(long long)(iniY + ry) * pitch + iniX + rx];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* t0 = tile + sh + 3 * kWTileP + 3;   // t0[y*kWTileP + x] = interior pixel (x, y)
+    const int minTh = P->minTh, iniTh = P->iniTh;
+
+    // A. quick rejection at minTh: an arc of 9 of 16 contains >= 2 of the 4 compass pixels, so a corner
+    //    needs two compass pixels brighter than v+t or two darker than v-t.  Survivors -> ordered worklist.
+    int nwork = 0;
+    if (cw <= 32) {   // two rows per pass, no divisions; lanes 0-31 = row y, 32-63 = row y+1 (row-major ballot order)
+        const int x = lane & 31;
+        for (int yb = 0; yb < ch; yb += 2) {
+            const int y = yb + (lane >> 5);
+            bool pass = false;
+            if (x < cw && y < ch) {
+                const uint8_t* t = t0 + y * kWTileP + x;
+                const int v = t[0];
+                const int hi = v + minTh, lo = v - minTh;
+                const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
+                const int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
+                const int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
+                pass = nb >= 2 || nd >= 2;
+                sc[y * 64 + x] = 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) work[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x);
+            nwork += __popcll(m);
+        }
+    } else {
+        const int npx = cw * ch;
+        for (int base = 0; base < npx; base += 64) {
+            const int p = base + lane;
+            bool pass = false;
+            int x = 0, y = 0;
+            if (p < npx) {
+                y = p / cw; x = p - y * cw;
+                const uint8_t* t = t0 + y * kWTileP + x;
+                const int v = t[0];
+                const int hi = v + minTh, lo = v - minTh;
+                const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
+                const int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
+                const int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
+                pass = nb >= 2 || nd >= 2;
+                sc[y * 64 + x] = 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) work[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x);
+            nwork += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // B. exact scores of the survivors (others stay 0 = "not a corner at minTh")
+    for (int i = lane; i < nwork; i += 64) {
+        const int q = work[i], y = q >> 6, x = q & 63;
+        sc[q] = (uint8_t)fast_score3<kWTileP>(t0 + y * kWTileP + x);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // C. NMS over the worklist (strictly greater than the 8 in-cell neighbours), ini/min vote
+    unsigned long long keepmask = 0;   // bit it: this lane's worklist entry of pass `it` survives
+    bool hit_ini = false;
+    {
+        int it = 0;
+        for (int i = lane; i < nwork; i += 64, it++) {
+            const int q = work[i], y = q >> 6, x = q & 63;
+            const int s = sc[q];
+            bool keep = s >= minTh;
+            if (keep) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int xx = x + dx, yy = y + dy;
+                        const int n = (xx >= 0 && xx < cw && yy >= 0 && yy < ch) ? sc[yy * 64 + xx] : 0;
+                        keep = keep && (s > n);
+                    }
+            }
+            if (keep) { keepmask |= 1ull << it; hit_ini = hit_ini || (s >= iniTh); }
+        }
+    }
+    const int th = __any(hit_ini) ? iniTh : minTh;
+    // D. ordered output (worklist order is row-major)
+    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
+    int running = 0;
+    {
+        int it = 0;
+        for (int base = 0; base < nwork; base += 64, it++) {
+            const int i = base + lane;
+            bool flag = false;
+            int s = 0, x = 0, y = 0;
+            if (i < nwork && ((keepmask >> it) & 1ull)) {
+                const int q = work[i];
+                y = q >> 6; x = q & 63;
+                s = sc[q];
+                flag = s >= th;
+            }
+            const unsigned long long m = __ballot(flag);
+            if (flag) {
+                const int slot = running + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < g.cell_cap) out[slot] = pack_xys(cj * g.wCell + x + 3, ci * g.hCell + y + 3, s);
+            }
+            running += __popcll(m);
+        }
+    }
+    if (lane == 0) {
         if (running > g.cell_cap) { atomicOr(c.status, 1); running = g.cell_cap; }
         *count_out = running;
     }

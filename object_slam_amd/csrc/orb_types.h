@@ -49,6 +49,9 @@ struct OrbParams {
     int node_cap;         // quad-tree node table size
     int gk[7];            // 7-tap Gaussian, 8 fractional bits
     int umax[16];         // IC_Angle row extents, :454-469
+    int blur_block_base[OSLAM_MAX_LEVELS + 1];   // first blockIdx.x of each level in k_blur_strip<false> (interior strips)
+    int blurb_block_base[OSLAM_MAX_LEVELS + 1];  // ... in k_blur_strip<true> (border strips)
+    int any_big_cell;     // some level has FAST cells larger than the per-wavefront kernel handles
 };
 
 }  // namespace oslam
