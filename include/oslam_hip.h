@@ -286,6 +286,9 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes /* <= 1
                      int max_edges, int device);
 void oslam_lba_destroy(oslam_lba_t* h);
 volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
+/* 1 (default): a single problem is spread over the whole GPU (multi-kernel LM, device-side control);
+ * 0: one workgroup per problem in one launch (the batch-of-windows layout).  Same arithmetic. */
+int oslam_lba_set_mode(oslam_lba_t* h, int wide);
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]);   /* [0..3] stats, [8..15] per-phase kilo-cycles in profiling builds */
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP,
                        const float* points, int nE, const int32_t* edge_kf, const int32_t* edge_pt,

@@ -552,9 +552,571 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
     if (tid == 0) { pr.stats[0] = st_its0; pr.stats[1] = st_trials0; pr.stats[2] = st_its1; pr.stats[3] = st_trials1; }
 }
 
+
+// ==========================================================================================
+// Wide mode: the same LM schedule spread over the whole GPU as a fixed sequence of small kernels
+// per LM trial, with the Levenberg-Marquardt control flow (accept / reject, lambda, iteration and
+// stage transitions, force-stop polling) decided on the device in LbaCtrl.  Every kernel reads
+// the control block and returns immediately when its phase is not due, so the host only enqueues
+// "trial slots" and checks ctrl.done every few slots.  All reductions are two-level with a fixed
+// order (per-block partials summed in block order), so results do not depend on scheduling.
+// ==========================================================================================
+struct LbaCtrl {
+    int stage, iter, qmax, need_lin, gate, done, ok2, cur, robust, ok, early;
+    int its[2], trials[2];
+    int nfree, n;
+    double lambda, ni, currentChi, rho;
+};
+
+struct LbaWide {
+    LbaCtrl* ct;
+    SE3* T;          // [2][K]
+    double* R;       // [2][K][9]
+    int* blk;        // [K]
+    int* free_pose;  // [K]
+    double* partF;   // [nblk_pt]
+    double* partS;   // [nblk_pt + 1] scale partials (last = poses)
+    double* partM;   // [nblk_pt] max |Hll diag|
+    int nblk_pt;
+};
+
+constexpr int kWPt = 128;   // threads per block of the per-point kernels
+
+__device__ __forceinline__ double* w_X(const LbaProblem& pr, int which) { return which ? pr.Xb : pr.Xa; }
+
+__global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const int tid = threadIdx.x;
+    LbaCtrl* ct = w.ct;
+    if (tid == 0) {
+        int nb = 0;
+        for (int a = 0; a < pr.K; a++) {
+            if (pr.fixed[a]) w.blk[a] = -1;
+            else { w.free_pose[nb] = a; w.blk[a] = nb++; }
+        }
+        ct->stage = 0; ct->iter = 0; ct->qmax = 0; ct->need_lin = 1; ct->gate = 0; ct->done = 0; ct->ok2 = 1; ct->cur = 0; ct->robust = 1; ct->ok = 1;
+        ct->its[0] = ct->its[1] = ct->trials[0] = ct->trials[1] = 0;
+        ct->nfree = nb; ct->n = 6 * nb;
+        ct->lambda = 0; ct->ni = 2; ct->currentChi = 0; ct->rho = 0;
+        ct->early = pr.stop ? (*pr.stop != 0) : 0;   // reference :655-657
+        if (ct->early) ct->done = 1;
+    }
+    for (int a = tid; a < pr.K; a += 256) {
+        w.T[a] = se3_from_T(pr.poses + a * 16);
+        se3_R(w.T[a], w.R + a * 9);
+    }
+    for (int i = tid; i < pr.P * 3; i += 256) pr.Xa[i] = (double)pr.points[i];
+    for (int e = tid; e < pr.E; e += 256) { pr.level[e] = 0; pr.chi2[e] = 0; pr.erase[e] = 0; }
+}
+
+// gate observations after stage 0 (:672-702)
+__global__ __launch_bounds__(256) void k_w_gate(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done || !ct->gate) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= pr.E) return;
+    const double* X = w_X(pr, ct->cur);
+    const SE3* T = w.T + ct->cur * pr.K;
+    const int a = pr.e_kf[e], p = pr.e_pt[e];
+    const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
+    const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+    double pc[3];
+    se3_map(T[a], Xw, pc);
+    if (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) pr.level[e] = 1;
+}
+
+__global__ __launch_bounds__(kWPt) void k_w_lin_pt(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done || !ct->need_lin) return;
+    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const bool robust = ct->robust != 0;
+    const double* X = w_X(pr, ct->cur);
+    const SE3* T = w.T + ct->cur * pr.K;
+    const double* Rm = w.R + (size_t)ct->cur * pr.K * 9;
+    const int p = blockIdx.x * kWPt + threadIdx.x;
+    double F0 = 0, dmax = 0;
+    if (p < pr.P) {
+        const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+        double hl[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+        for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+            if (pr.level[e] != 0) continue;
+            const int a = pr.e_kf[e];
+            const float ur = pr.e_obs[e * 3 + 2];
+            const bool stereo = !(ur < 0);
+            const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+            const double info = (double)pr.e_info[e];
+            double pc[3], er[3], Jp[18], Jx[9];
+            se3_map(T[a], Xw, pc);
+            const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+            pr.chi2[e] = c2;
+            double r0 = c2, wgt = 1.0;
+            if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
+            F0 += r0;
+            jac_binary(cam, pc, Rm + a * 9, stereo, Jp, Jx);
+            const double wi = wgt * info;
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                double sb = 0;
+                _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jx[d * 3 + i] * (info * er[d]);
+                bl[i] -= wgt * sb;
+#pragma unroll
+                for (int j = i; j < 3; j++) {
+                    double sh = 0;
+                    _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
+                    hl[k++] += sh;
+                }
+            }
+            if (w.blk[a] >= 0) {
+                double* B = pr.Hpl + (long long)e * 18;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        double sh = 0;
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
+                        B[i * 3 + j] = sh;
+                    }
+            }
+        }
+        double* H = pr.Hll + (long long)p * 9;
+        H[0] = hl[0]; H[1] = hl[1]; H[2] = hl[2]; H[3] = hl[1]; H[4] = hl[3]; H[5] = hl[4]; H[6] = hl[2]; H[7] = hl[4]; H[8] = hl[5];
+        pr.bl[p * 3] = bl[0]; pr.bl[p * 3 + 1] = bl[1]; pr.bl[p * 3 + 2] = bl[2];
+        dmax = fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5])));
+    }
+    __shared__ double sF[kWPt / 64], sM[kWPt / 64];
+    const double f = wsum(F0), m = wmax(dmax);
+    if ((threadIdx.x & 63) == 0) { sF[threadIdx.x >> 6] = f; sM[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sF[0], bm = sM[0];
+        for (int i = 1; i < kWPt / 64; i++) { a += sF[i]; bm = fmax(bm, sM[i]); }
+        w.partF[blockIdx.x] = a;
+        w.partM[blockIdx.x] = bm;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_w_lin_pose(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done || !ct->need_lin) return;
+    const int a = blockIdx.x, lane = threadIdx.x;
+    if (a >= pr.K || w.blk[a] < 0) return;
+    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const bool robust = ct->robust != 0;
+    const double* X = w_X(pr, ct->cur);
+    const SE3 Ta = w.T[ct->cur * pr.K + a];
+    const double* Ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = 0;
+    for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
+        const int e = pr.pose_edges[q];
+        if (pr.level[e] != 0) continue;
+        const int p = pr.e_pt[e];
+        const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+        const float ur = pr.e_obs[e * 3 + 2];
+        const bool stereo = !(ur < 0);
+        const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+        const double info = (double)pr.e_info[e];
+        double pc[3], er[3], Jp[18], Jx[9];
+        se3_map(Ta, Xw, pc);
+        const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+        double r0 = c2, wgt = 1.0;
+        if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
+        jac_binary(cam, pc, Ra, stereo, Jp, Jx);
+        const double wi = wgt * info;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double sb = 0;
+            _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jp[d * 6 + i] * (info * er[d]);
+            acc[21 + i] -= wgt * sb;
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                double sh = 0;
+                _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jp[d * 6 + j];
+                acc[k++] += sh;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 27; k++) acc[k] = wsum(acc[k]);
+    if (lane == 0) {
+        double* H = pr.Hpp + a * 36;
+        int k = 0;
+        for (int i = 0; i < 6; i++)
+            for (int j = i; j < 6; j++) { H[i * 6 + j] = acc[k]; H[j * 6 + i] = acc[k]; k++; }
+        for (int i = 0; i < 6; i++) pr.bp[a * 6 + i] = acc[21 + i];
+    }
+}
+
+// after linearisation: F0 and (first iteration) lambda = 1e-5 * max diag
+__global__ __launch_bounds__(64) void k_w_ctrlA(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    if (threadIdx.x != 0) return;
+    if (ct->gate) { ct->gate = 0; }
+    if (!ct->need_lin) return;
+    double F = 0, m = 0;
+    for (int i = 0; i < w.nblk_pt; i++) { F += w.partF[i]; m = fmax(m, w.partM[i]); }
+    ct->currentChi = F;
+    if (ct->iter == 0) {
+        for (int a = 0; a < pr.K; a++)
+            if (w.blk[a] >= 0)
+                for (int i = 0; i < 6; i++) m = fmax(m, fabs(pr.Hpp[a * 36 + i * 7]));
+        ct->lambda = 1e-5 * m;
+        ct->ni = 2;
+    }
+    ct->need_lin = 0;
+    ct->qmax = 0;
+}
+
+__global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const int nfree = ct->nfree, n = ct->n, ld = n + 1;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= nfree * (nfree + 1) / 2) return;
+    const double lambda = ct->lambda;
+    int ba = 0, rem = t;
+    while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
+    const int bb = ba + rem;
+    const int a = w.free_pose[ba], b2 = w.free_pose[bb];
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+    double bsv[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
+        const int e = pr.pose_edges[q];
+        if (pr.level[e] != 0) continue;
+        const int p = pr.e_pt[e];
+        int e2 = -1;
+        if (a == b2) e2 = e;
+        else
+            for (int c2 = pr.pt_start[p]; c2 < pr.pt_start[p + 1]; c2++)
+                if (pr.e_kf[c2] == b2) { e2 = c2; break; }
+        if (e2 < 0 || pr.level[e2] != 0) continue;
+        const double* Ba = pr.Hpl + (long long)e * 18;
+        const double* Bb = pr.Hpl + (long long)e2 * 18;
+        double D[9], Di[9];
+        const double* H = pr.Hll + (long long)p * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) D[i] = H[i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        inv3(D, Di);
+        double BD[18];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
+            BD[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
+            BD[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
+            BD[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+        }
+        if (a == b2) {
+            const double* bl = pr.bl + p * 3;
+            double db[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) db[i] = Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) bsv[i] += Ba[i * 3] * db[0] + Ba[i * 3 + 1] * db[1] + Ba[i * 3 + 2] * db[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                acc[i * 6 + j] += BD[i * 3] * Bb[j * 3] + BD[i * 3 + 1] * Bb[j * 3 + 1] + BD[i * 3 + 2] * Bb[j * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = wsum(acc[i]);
+    if (a == b2) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) bsv[i] = wsum(bsv[i]);
+    }
+    if (lane == 0) {
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < 6; j++) {
+                double v = -acc[i * 6 + j];
+                if (a == b2) v += pr.Hpp[a * 36 + i * 6 + j] + (i == j ? lambda : 0.0);
+                pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
+            }
+        if (a == b2)
+            for (int i = 0; i < 6; i++) pr.Hs[(size_t)(6 * ba + i) * ld + n] = pr.bp[a * 6 + i] - bsv[i];
+    }
+}
+
+// blocked Cholesky + back substitution of the reduced camera system (one workgroup)
+__global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = ct->n, ld = n + 1;
+    __shared__ int s_ok;
+    __shared__ double xs[6 * kLbaMaxKF];
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += 6) {
+        if (wv == 0) {
+            double Dg[36];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? pr.Hs[(size_t)(j0 + i) * ld + j0 + k] : 0.0;
+            bool good = true;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double d = Dg[j * 6 + j];
+                if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
+                d = sqrt(d);
+                Dg[j * 6 + j] = d;
+#pragma unroll
+                for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] /= d;
+#pragma unroll
+                for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                    for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
+            }
+            if (!good && lane == 0) s_ok = 0;
+            for (int k = j0 + 6 + lane; k <= n; k += 64) {
+                double col[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) col[i] = pr.Hs[(size_t)(j0 + i) * ld + k];
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    double sv = col[j];
+#pragma unroll
+                    for (int i = 0; i < j; i++) sv -= Dg[i * 6 + j] * col[i];
+                    col[j] = sv / Dg[j * 6 + j];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) pr.Hs[(size_t)(j0 + i) * ld + k] = col[i];
+            }
+            if (lane < 36) {
+                const int r = lane / 6, cc = lane % 6;
+                if (cc >= r) pr.Hs[(size_t)(j0 + r) * ld + j0 + cc] = Dg[lane];
+            }
+        }
+        __syncthreads();
+        const int m = n - (j0 + 6);
+        for (int ii = wv; ii < m; ii += 16) {
+            const int i = j0 + 6 + ii;
+            double pi[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) pi[r] = pr.Hs[(size_t)(j0 + r) * ld + i];
+            for (int k = i + lane; k <= n; k += 64) {
+                double sv = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) sv += pi[r] * pr.Hs[(size_t)(j0 + r) * ld + k];
+                pr.Hs[(size_t)i * ld + k] -= sv;
+            }
+        }
+        __syncthreads();
+    }
+    const bool ok2 = s_ok != 0;
+    if (wv == 0 && ok2) {
+        for (int i = n - 1; i >= 0; i--) {
+            double sv = 0;
+            for (int k = i + 1 + lane; k < n; k += 64) sv += pr.Hs[(size_t)i * ld + k] * xs[k];
+            sv = wsum(sv);
+            if (lane == 0) xs[i] = (pr.Hs[(size_t)i * ld + n] - sv) / pr.Hs[(size_t)i * ld + i];
+        }
+        for (int i = lane; i < n; i += 64) pr.xp[i] = xs[i];
+    }
+    if (!ok2) for (int i = tid; i < n; i += 1024) pr.xp[i] = 0;
+    if (tid == 0) ct->ok2 = ok2 ? 1 : 0;
+}
+
+// landmark back-substitution, trial state, computeScale partials
+__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const double lambda = ct->lambda;
+    const bool ok2 = ct->ok2 != 0;
+    const int cur = ct->cur;
+    const double* X = w_X(pr, cur);
+    double* Xn = w_X(pr, cur ^ 1);
+    double sc = 0;
+    if ((int)blockIdx.x == w.nblk_pt) {   // poses
+        for (int a = threadIdx.x; a < pr.K; a += kWPt) {
+            const int ba = w.blk[a];
+            SE3* Tn = w.T + (cur ^ 1) * pr.K + a;
+            const SE3 Tc = w.T[cur * pr.K + a];
+            if (ba < 0) { *Tn = Tc; }
+            else {
+                double xa[6];
+                for (int i = 0; i < 6; i++) { xa[i] = pr.xp[6 * ba + i]; sc += xa[i] * (lambda * xa[i] + pr.bp[a * 6 + i]); }
+                *Tn = se3_mul(se3_exp(xa), Tc);
+            }
+            se3_R(*Tn, w.R + ((size_t)(cur ^ 1) * pr.K + a) * 9);
+        }
+    } else {
+        const int p = blockIdx.x * kWPt + threadIdx.x;
+        if (p < pr.P) {
+            double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
+            double xo[3] = {0, 0, 0};
+            if (ok2) {
+                for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+                    if (pr.level[e] != 0) continue;
+                    const int ba = w.blk[pr.e_kf[e]];
+                    if (ba < 0) continue;
+                    const double* B = pr.Hpl + (long long)e * 18;
+                    const double* xa = pr.xp + 6 * ba;
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        double sv = 0;
+#pragma unroll
+                        for (int i = 0; i < 6; i++) sv += B[i * 3 + j] * xa[i];
+                        cl[j] -= sv;
+                    }
+                }
+                double D[9], Di[9];
+                const double* H = pr.Hll + (long long)p * 9;
+#pragma unroll
+                for (int i = 0; i < 9; i++) D[i] = H[i];
+                D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                inv3(D, Di);
+#pragma unroll
+                for (int i = 0; i < 3; i++) xo[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                Xn[p * 3 + i] = X[p * 3 + i] + xo[i];
+                sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);
+            }
+        }
+    }
+    __shared__ double sS[kWPt / 64];
+    const double s1 = wsum(sc);
+    if ((threadIdx.x & 63) == 0) sS[threadIdx.x >> 6] = s1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sS[0];
+        for (int i = 1; i < kWPt / 64; i++) a += sS[i];
+        w.partS[blockIdx.x] = a;
+    }
+}
+
+__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const bool robust = ct->robust != 0;
+    const int tr = ct->cur ^ 1;
+    const double* Xp = w_X(pr, tr);
+    const SE3* Tp = w.T + tr * pr.K;
+    const int p = blockIdx.x * kWPt + threadIdx.x;
+    double F = 0;
+    if (p < pr.P) {
+        const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
+        for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+            if (pr.level[e] != 0) continue;
+            const int a = pr.e_kf[e];
+            const float ur = pr.e_obs[e * 3 + 2];
+            const bool stereo = !(ur < 0);
+            const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+            double pc[3], er[3];
+            se3_map(Tp[a], Xw, pc);
+            const double c2 = edge_error(cam, pc, ob, stereo, (double)pr.e_info[e], er);
+            pr.chi2[e] = c2;
+            if (robust) { double r0, r1; huber(c2, stereo ? dStereo : dMono, r0, r1); F += r0; }
+            else F += c2;
+        }
+    }
+    __shared__ double sF[kWPt / 64];
+    const double f = wsum(F);
+    if ((threadIdx.x & 63) == 0) sF[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = sF[0];
+        for (int i = 1; i < kWPt / 64; i++) a += sF[i];
+        w.partF[blockIdx.x] = a;
+    }
+}
+
+// Levenberg-Marquardt decision + schedule transitions (g2o OptimizationAlgorithmLevenberg::solve tail,
+// SparseOptimizer::optimize loop, and the stage logic of reference src/Optimizer.cc:660-707)
+__global__ __launch_bounds__(64) void k_w_ctrlB(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    LbaCtrl* ct = w.ct;
+    if (ct->done || threadIdx.x != 0) return;
+    double F1 = 0, sc = 0;
+    for (int i = 0; i < w.nblk_pt; i++) { F1 += w.partF[i]; sc += w.partS[i]; }
+    sc += w.partS[w.nblk_pt];
+    double tempChi = F1;
+    if (!ct->ok2) tempChi = 1.7976931348623157e308;
+    const double rho = (ct->currentChi - tempChi) / (sc + 1e-3);
+    const bool finite = (tempChi - tempChi) == 0;
+    if (rho > 0 && finite) {
+        double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
+        alpha = fmin(alpha, 2. / 3.);
+        ct->lambda *= fmax(1. / 3., alpha);
+        ct->ni = 2;
+        ct->currentChi = tempChi;
+        ct->cur ^= 1;
+    } else {
+        ct->lambda *= ct->ni;
+        ct->ni *= 2;
+    }
+    ct->rho = rho;
+    ct->qmax++;
+    ct->trials[ct->stage]++;
+    const bool stop = pr.stop ? (*pr.stop != 0) : false;
+    if (rho < 0 && ct->qmax < 10 && !stop) return;   // another trial with the new lambda
+    // iteration finished
+    ct->its[ct->stage]++;
+    if (ct->qmax == 10 || rho == 0) ct->ok = 0;
+    ct->iter++;
+    const int iters = ct->stage == 0 ? 5 : 10;
+    const bool stop2 = pr.stop ? (*pr.stop != 0) : false;
+    if (ct->iter < iters && !stop2 && ct->ok) { ct->need_lin = 1; return; }
+    // stage finished
+    if (ct->stage == 0) {
+        const bool stop3 = pr.stop ? (*pr.stop != 0) : false;
+        if (stop3) { ct->done = 1; return; }   // bDoMore = false (:664-666)
+        ct->stage = 1; ct->iter = 0; ct->ok = 1; ct->robust = 0; ct->need_lin = 1; ct->gate = 1;
+    } else {
+        ct->done = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_w_final(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const bool early = ct->early != 0;
+    const double* X = w_X(pr, ct->cur);
+    const SE3* T = w.T + ct->cur * pr.K;
+    if (gid < pr.E && !early) {
+        const int e = gid, a = pr.e_kf[e], p = pr.e_pt[e];
+        const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
+        const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+        double pc[3];
+        se3_map(T[a], Xw, pc);
+        pr.erase[e] = (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) ? 1 : 0;
+    }
+    if (gid < pr.K) {
+        const int a = gid;
+        if (pr.fixed[a] != 1 && !early) se3_to_T(T[a], pr.poses_out + a * 16);
+        else for (int i = 0; i < 16; i++) pr.poses_out[a * 16 + i] = pr.poses[a * 16 + i];
+    }
+    if (gid < pr.P * 3) pr.points_out[gid] = early ? pr.points[gid] : (float)X[gid];
+    if (gid == 0) { pr.stats[0] = ct->its[0]; pr.stats[1] = ct->trials[0]; pr.stats[2] = ct->its[1]; pr.stats[3] = ct->trials[1]; }
+}
+
 }  // namespace oslam
 
 using namespace oslam;
+
 
 struct oslam_lba {
     int device = 0, max_batch = 0, max_kf = 0, max_pts = 0, max_edges = 0;
@@ -567,6 +1129,10 @@ struct oslam_lba {
     std::vector<Slot> slots;
     std::vector<void*> allocs;
     LbaProblem* d_probs = nullptr;
+    // wide mode (batch 1)
+    LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
+    double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
+    int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
     int* h_stop = nullptr;       // pinned, device-visible stop flag
     int* d_stop = nullptr;
     size_t lds = 0;
@@ -580,6 +1146,7 @@ void oslam_lba_destroy(oslam_lba_t* h) {
         if (p) (void)hipFree(p);
     if (h->d_probs) (void)hipFree(h->d_probs);
     if (h->h_stop) (void)hipHostFree(h->h_stop);
+    if (h->h_done) (void)hipHostFree(h->h_done);
     delete h;
 }
 
@@ -623,6 +1190,17 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
         return OSLAM_E_HIP;
     }
     *h->h_stop = 0;
+    {
+        const size_t nb = (P + kWPt - 1) / kWPt + 2;
+        h->d_ctrl = (LbaCtrl*)alloc(sizeof(LbaCtrl)); h->d_T2 = (SE3*)alloc(sizeof(SE3) * 2 * K); h->d_R2 = (double*)alloc(8 * 18 * K);
+        h->d_blk = (int*)alloc(4 * K); h->d_free = (int*)alloc(4 * K); h->d_partF = (double*)alloc(8 * nb); h->d_partS = (double*)alloc(8 * nb); h->d_partM = (double*)alloc(8 * nb);
+        if (!h->d_ctrl || !h->d_T2 || !h->d_R2 || !h->d_blk || !h->d_free || !h->d_partF || !h->d_partS || !h->d_partM ||
+            hipHostMalloc((void**)&h->h_done, sizeof(int), 0) != hipSuccess) {
+            set_error("LBA wide-mode allocation failed");
+            oslam_lba_destroy(h);
+            return OSLAM_E_HIP;
+        }
+    }
     OSLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0));
     h->lds = kRowBufBytes + 64;
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
@@ -633,6 +1211,12 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
     if (!h) return OSLAM_E_INVALID;
     OSLAM_HIP_CHECK(hipMemcpy(out, h->slots[0].stats, 64, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
+    if (!h) return OSLAM_E_INVALID;
+    h->wide = wide != 0;
     return OSLAM_OK;
 }
 
@@ -698,9 +1282,44 @@ int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_
     pr.stop = use_stop_flag ? h->d_stop : nullptr;
     for (int i = 0; i < 5; i++) pr.K5[i] = K5[i];
     OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, &pr, sizeof(pr), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
-    OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    if (!h->wide) {
+        hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
+        OSLAM_HIP_CHECK(hipGetLastError());
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    } else {
+        LbaWide w;
+        w.ct = h->d_ctrl; w.T = h->d_T2; w.R = h->d_R2; w.blk = h->d_blk; w.free_pose = h->d_free;
+        w.partF = h->d_partF; w.partS = h->d_partS; w.partM = h->d_partM;
+        w.nblk_pt = div_up(std::max(nP, 1), kWPt);
+        int nfree = 0;
+        for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
+        const int nblk = std::max(1, nfree * (nfree + 1) / 2);
+        hipStream_t st = nullptr;
+        hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
+        // worst case 15 iterations x 10 trials; slots past `done` return at once
+        int slots_done = 0;
+        *h->h_done = 0;
+        while (slots_done < 160) {
+            for (int sl = 0; sl < 4; sl++, slots_done++) {
+                hipLaunchKernelGGL(k_w_gate, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_lin_pt, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_lin_pose, dim3(nKF), dim3(64), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_ctrlA, dim3(1), dim3(64), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_schur, dim3(nblk), dim3(64), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_chol, dim3(1), dim3(1024), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_update, dim3(w.nblk_pt + 1), dim3(kWPt), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_eval, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_ctrlB, dim3(1), dim3(64), 0, st, h->d_probs, w);
+            }
+            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_done, &h->d_ctrl->done, sizeof(int), hipMemcpyDeviceToHost, st));
+            OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+            if (*h->h_done) break;
+        }
+        const int nfin = std::max(std::max(nE, nKF), nP * 3);
+        hipLaunchKernelGGL(k_w_final, dim3(div_up(std::max(nfin, 1), 256)), dim3(256), 0, st, h->d_probs, w);
+        OSLAM_HIP_CHECK(hipGetLastError());
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    }
     OSLAM_HIP_CHECK(hipMemcpy(poses_out, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost));
     if (nP > 0) OSLAM_HIP_CHECK(hipMemcpy(points_out, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost));
     if (nE > 0) {

@@ -102,6 +102,10 @@ class LocalBundleAdjuster:
 
     __del__ = close
 
+    def set_mode(self, wide):
+        """wide=True: one problem over the whole GPU (multi-kernel LM); False: one workgroup per problem."""
+        check(self.L.oslam_lba_set_mode(self.h, int(wide)))
+
     def stop_flag(self):
         """The pbStopFlag: a pinned int visible to the running kernel (set [0] = 1 to abort)."""
         return self.L.oslam_lba_stop_flag(self.h)

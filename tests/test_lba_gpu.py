@@ -24,10 +24,12 @@ def _compare(a, o):
     assert st[0] == ost[0] and st[2] == ost[2], (st, ost)
 
 
+@pytest.mark.parametrize("wide", [True, False])
 @pytest.mark.parametrize("seed,KL,KF,P", [(3, 4, 2, 150), (4, 6, 3, 300), (5, 10, 0, 500), (6, 20, 20, 4000)])
-def test_lba_matches_oracle(oracle, seed, KL, KF, P):
+def test_lba_matches_oracle(oracle, seed, KL, KF, P, wide):
     q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, stereo_frac=[0.85, 1.0, 0.0][seed % 3])
     ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536)
+    ba.set_mode(wide)
     a, o = _run(oracle, ba, q)
     _compare(a, o)
     # edges in a shuffled (non point-major) order give the same answer
@@ -40,9 +42,11 @@ def test_lba_matches_oracle(oracle, seed, KL, KF, P):
     ba.close()
 
 
-def test_lba_stop_flag_and_errors(oracle):
+@pytest.mark.parametrize("wide", [True, False])
+def test_lba_stop_flag_and_errors(oracle, wide):
     q = synth.make_lba_problem(9, K_local=5, K_fixed=2, P=200)
     ba = LocalBundleAdjuster(max_keyframes=16, max_points=512, max_edges=4096)
+    ba.set_mode(wide)
     flag = ba.stop_flag()
     flag[0] = 1   # set before the call: nothing changes (reference :655-657)
     po, xo, er, st = ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], use_stop_flag=True)

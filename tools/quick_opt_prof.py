@@ -29,6 +29,9 @@ for (KL, KF, P) in ((20, 20, 4000), (6, 0, 200), (40, 60, 10000)):
     args = (q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
     r = ba.LocalBundleAdjustment(*args)
     t0 = time.time(); r = ba.LocalBundleAdjustment(*args); dt = time.time() - t0
+    ba.set_mode(False); ba.LocalBundleAdjustment(*args)
+    t0 = time.time(); rc = ba.LocalBundleAdjustment(*args); dtc = time.time() - t0
+    print("   compact mode %.2f ms, max |wide - compact| pose diff %.2e" % (dtc * 1e3, np.abs(rc[0] - r[0]).max()))
     t0 = time.time(); o = O.local_bundle_adjustment(*args); do = time.time() - t0
     print("LBA %d+%d KF, %d pts, %d edges: GPU %.2f ms (host API incl. copies) stats %s | oracle %.1f ms stats %s | max pose diff %.2e" % (
         KL, KF, P, len(q["edge_kf"]), dt * 1e3, r[3], do * 1e3, o[3], np.abs(r[0] - o[0]).max()))
