@@ -197,6 +197,20 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
                                    const oslam_camera_t* cam, const float* scaleFactors, int nlevels, float th,
                                    int bMono, int check_ori, int32_t* q_match, int32_t* q_dist,
                                    int32_t* kp_match, int32_t* nmatches);
+/* Search half of ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:888-947):
+ * KeyFrame::GetFeaturesInArea window (src/KeyFrame.cc:569-608), level gate [minLevel, maxLevel] =
+ * [nPredictedLevel-1, nPredictedLevel], chi2 reprojection gate (7.8 if mvuRight>=0 else 5.99) with
+ * mvInvLevelSigma2, best Hamming <= TH_LOW.  q_match[i] = keypoint to fuse map point i with (or -1).
+ * The per-point projection / distance / viewing-angle gates (:851-886) fill the queries and the
+ * Replace / AddObservation surgery (:950-970) is applied by the caller in query order. */
+int oslam_match_fuse_search(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn, const float* uRight,
+                            const uint8_t* desc, const float bounds[4], const oslam_proj_query_t* queries, int M,
+                            const float* invLevelSigma2, int nlevels, int32_t* q_match, int32_t* q_dist,
+                            int32_t* n_fused);
+int oslam_match_fuse_batch_device(oslam_matcher_t* h, const oslam_match_frames_t* frames,
+                                  const oslam_proj_query_t* d_queries, int q_stride, const int32_t* d_n_queries,
+                                  int n_queries_const, int batch, const float* invLevelSigma2, int nlevels,
+                                  void* stream);
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);
 
 /* ------------------------------------------------------------------------------------------

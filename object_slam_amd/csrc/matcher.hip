@@ -32,6 +32,8 @@ struct MatchCtx {
     const oslam_proj_query_t* q; int q_stride;
     const int* n_q; int n_q_const;
     float nnratio; int use_ratio, check_ori, th_high;
+    int fuse;                 // Fuse search (src/ORBmatcher.cc:888-947): chi2 reprojection gate, no claims
+    float invSigma2[OSLAM_MAX_LEVELS];
     // outputs
     int* q_match; int* q_dist; int* kp_match; int* nmatches;
     int* iters;               // [B] fixpoint iterations used (diagnostic)
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                 const int nMinCellY = max(0, (int)floorf((y - c.minY - r) * c.invH));
                 const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - c.minY + r) * c.invH));
                 if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0) {
-                    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+                    const bool bCheckLevels = !c.fuse && ((minLevel > 0) || (maxLevel >= 0));   // KeyFrame::GetFeaturesInArea has no level filter
                     uint32_t qd[8];
                     const uint32_t* qdp = (const uint32_t*)qp->desc;
 #pragma unroll
@@ -174,11 +176,25 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                             }
                             const float2 p = s_xy[k];
                             if (!(fabsf(p.x - x) < r && fabsf(p.y - y) < r)) continue;
-                            if (s_blk[k] || s_Bprev[k] < j) continue;
                             const float kur = s_ur[k];
-                            if (kur > 0) {
-                                const float er = fabsf(qur - kur);
-                                if (er > r) continue;
+                            if (c.fuse) {
+                                // level gate is explicit in Fuse (:903-906); chi2 gates :908-934
+                                if (oct < minLevel || oct > maxLevel) continue;
+                                const float ex = x - p.x, ey = y - p.y;
+                                if (kur >= 0) {
+                                    const float er = qur - kur;
+                                    const float e2 = ex * ex + ey * ey + er * er;
+                                    if ((double)(e2 * c.invSigma2[oct]) > 7.8) continue;
+                                } else {
+                                    const float e2 = ex * ex + ey * ey;
+                                    if ((double)(e2 * c.invSigma2[oct]) > 5.99) continue;
+                                }
+                            } else {
+                                if (s_blk[k] || s_Bprev[k] < j) continue;
+                                if (kur > 0) {
+                                    const float er = fabsf(qur - kur);
+                                    if (er > r) continue;
+                                }
                             }
                             const uint32_t* d = s_desc + k * 8;
                             int dist = 0;
@@ -439,9 +455,26 @@ static int check_frames(const oslam_matcher* h, const oslam_match_frames_t* f, i
     return OSLAM_OK;
 }
 
+static int search_impl(oslam_matcher_t* h, const oslam_match_frames_t* f, const oslam_proj_query_t* d_queries, int q_stride,
+                       const int32_t* d_n_queries, int n_queries_const, int batch, float nnratio, int use_ratio, int check_ori,
+                       int th_high, const float* invLevelSigma2, int nlevels, void* stream);
+
 int oslam_match_search_batch_device(oslam_matcher_t* h, const oslam_match_frames_t* f, const oslam_proj_query_t* d_queries,
                                     int q_stride, const int32_t* d_n_queries, int n_queries_const, int batch, float nnratio,
                                     int use_ratio, int check_ori, int th_high, void* stream) {
+    return search_impl(h, f, d_queries, q_stride, d_n_queries, n_queries_const, batch, nnratio, use_ratio, check_ori, th_high, nullptr, 0, stream);
+}
+
+int oslam_match_fuse_batch_device(oslam_matcher_t* h, const oslam_match_frames_t* f, const oslam_proj_query_t* d_queries, int q_stride,
+                                  const int32_t* d_n_queries, int n_queries_const, int batch, const float* invLevelSigma2, int nlevels,
+                                  void* stream) {
+    if (!invLevelSigma2 || nlevels < 1 || nlevels > OSLAM_MAX_LEVELS) { set_error("bad invLevelSigma2/nlevels"); return OSLAM_E_INVALID; }
+    return search_impl(h, f, d_queries, q_stride, d_n_queries, n_queries_const, batch, 0.f, 0, 0, 50, invLevelSigma2, nlevels, stream);
+}
+
+static int search_impl(oslam_matcher_t* h, const oslam_match_frames_t* f, const oslam_proj_query_t* d_queries, int q_stride,
+                       const int32_t* d_n_queries, int n_queries_const, int batch, float nnratio, int use_ratio, int check_ori,
+                       int th_high, const float* invLevelSigma2, int nlevels, void* stream) {
     int rc = check_frames(h, f, batch);
     if (rc) return rc;
     if (!d_queries) d_queries = h->d_queries;
@@ -456,6 +489,8 @@ int oslam_match_search_batch_device(oslam_matcher_t* h, const oslam_match_frames
     c.invH = (float)kGridRows / (float)(f->maxY - f->minY);
     c.q = d_queries; c.q_stride = q_stride; c.n_q = d_n_queries; c.n_q_const = n_queries_const;
     c.nnratio = nnratio; c.use_ratio = use_ratio; c.check_ori = check_ori; c.th_high = th_high;
+    c.fuse = invLevelSigma2 ? 1 : 0;
+    for (int i = 0; i < OSLAM_MAX_LEVELS; i++) c.invSigma2[i] = (invLevelSigma2 && i < nlevels) ? invLevelSigma2[i] : 0.f;
     c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters;
     // per-frame output strides equal the input strides; outputs were sized for max_q / max_kps
     if ((size_t)f->kp_stride > (size_t)h->max_kps) { set_error("kp_stride %d > max_keypoints %d", f->kp_stride, h->max_kps); return OSLAM_E_CAPACITY; }
@@ -572,6 +607,21 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
     rc = oslam_match_search_batch_device(h, &f, nullptr, h->max_q, nullptr, Nlast, 1, 0.f, 0, check_ori, 100, nullptr);
     if (rc) return rc;
     return oslam_match_fetch(h, 0, h->max_q, Nlast, h->max_kps, N, q_match, q_dist, kp_match, nmatches, nullptr, nullptr);
+}
+
+int oslam_match_fuse_search(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn, const float* uRight, const uint8_t* desc,
+                            const float bounds[4], const oslam_proj_query_t* queries, int M, const float* invLevelSigma2, int nlevels,
+                            int32_t* q_match, int32_t* q_dist, int32_t* n_fused) {
+    if (!h || !bounds || (N > 0 && (!keysUn || !desc)) || (M > 0 && !queries) || !invLevelSigma2) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (M < 0 || M > h->max_q) { set_error("%d queries > capacity %d", M, h->max_q); return OSLAM_E_CAPACITY; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    oslam_match_frames_t f;
+    int rc = stage_frame(h, N, keysUn, uRight, desc, nullptr, bounds, &f);
+    if (rc) return rc;
+    if (M > 0) OSLAM_HIP_CHECK(hipMemcpy(h->d_queries, queries, (size_t)M * sizeof(oslam_proj_query_t), hipMemcpyHostToDevice));
+    rc = oslam_match_fuse_batch_device(h, &f, h->d_queries, h->max_q, nullptr, M, 1, invLevelSigma2, nlevels, nullptr);
+    if (rc) return rc;
+    return oslam_match_fetch(h, 0, h->max_q, M, h->max_kps, 0, q_match, q_dist, nullptr, n_fused, nullptr, nullptr);
 }
 
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out) {

@@ -91,6 +91,21 @@ class ORBmatcher:
             int(self.mbCheckOrientation), ptr(qm), ptr(qd), ptr(km), C.byref(nm)))
         return nm.value, qm[:NL], qd[:NL], km[:N]
 
+    # search half of Fuse(KeyFrame*, vpMapPoints, th): src/ORBmatcher.cc:825
+    def fuse_search(self, keysUn, uRight, desc, bounds, queries, invLevelSigma2):
+        keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+        N, M = len(keysUn), len(queries)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        uR = None if uRight is None else np.ascontiguousarray(uRight, np.float32)
+        inv = np.ascontiguousarray(invLevelSigma2, np.float32)
+        bnd = (C.c_float * 4)(*bounds)
+        qm, qd = np.full(max(M, 1), -1, np.int32), np.full(max(M, 1), 256, np.int32)
+        nf = C.c_int(0)
+        check(self.L.oslam_match_fuse_search(self.h, N, ptr(keysUn), ptr(uR) if uR is not None else None, ptr(desc), bnd,
+                                             ptr(queries), M, ptr(inv), len(inv), ptr(qm), ptr(qd), C.byref(nf)))
+        return nf.value, qm[:M], qd[:M]
+
     def debug_queries(self, n, b=0, q_stride=None):
         out = np.zeros(max(n, 1), QUERY_DTYPE)
         check(self.L.oslam_match_debug_get_queries(self.h, b, q_stride or self.max_q, n, ptr(out)))

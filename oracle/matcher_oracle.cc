@@ -341,3 +341,41 @@ void ComputeStereoMatches(int N, const KeyPoint* keysL, const uint8_t* descL, in
     }
 }
 }  // namespace oracle
+
+namespace oracle {
+// reference src/ORBmatcher.cc:888-947
+int FuseSearch(const FrameView& f, const ProjQuery* q, int M, const float* invLevelSigma2, int* q_match, int* q_dist) {
+    Grid grid;
+    grid.build(f);
+    int n = 0;
+    for (int i = 0; i < M; i++) {
+        q_match[i] = -1;
+        q_dist[i] = 256;
+        const ProjQuery& p = q[i];
+        if (!(p.flags & 1)) continue;
+        const float u = p.u, v = p.v, ur = p.ur;
+        const std::vector<int> vIndices = grid.area(f, u, v, p.radius, -1, -1);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (size_t c = 0; c < vIndices.size(); c++) {
+            const int idx = vIndices[c];
+            const KeyPoint& kp = f.keysUn[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < p.minLevel || kpLevel > p.maxLevel) continue;
+            if (f.uRight[idx] >= 0) {
+                const float ex = u - kp.x, ey = v - kp.y, er = ur - f.uRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = DescriptorDistance(p.desc, f.desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { q_match[i] = bestIdx; q_dist[i] = bestDist; n++; }
+    }
+    return n;
+}
+}  // namespace oracle

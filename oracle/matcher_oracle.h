@@ -66,6 +66,13 @@ void ProjectLastFrame(const LastFrameView& last, const float* Tcw, const float* 
 
 void ComputeThreeMaxima(const int* histo_sizes, int L, int& ind1, int& ind2, int& ind3);  // :1601-1642
 
+// Search half of ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (src/ORBmatcher.cc:888-947): window query
+// KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:569-608, no level filter), level gate [minLevel, maxLevel],
+// chi2 reprojection gate (7.8 stereo if mvuRight>=0, 5.99 mono), best Hamming, accepted if <= TH_LOW.
+// The projection / distance / viewing-angle gates (:851-886) and the map surgery (:950-970) stay with the
+// caller.  q_match[i] = keypoint or -1.
+int FuseSearch(const FrameView& f, const ProjQuery* q, int M, const float* invLevelSigma2, int* q_match, int* q_dist);
+
 }  // namespace oracle
 
 namespace oracle {

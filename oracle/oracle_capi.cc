@@ -198,3 +198,11 @@ int oo_pose_optimization2(int N, const float* Tcw_in, const float* Xw, const flo
                              joint_kp, joint_obj, kp_uv, bounds, invSigma2_0, Tcw_out, outlier, nSemNum);
 }
 }
+
+extern "C" {
+int oo_fuse_search(int N, const KeyPoint* keysUn, const float* uRight, const uint8_t* desc, const float* bounds, const ProjQuery* q,
+                   int M, const float* invLevelSigma2, int* q_match, int* q_dist) {
+    FrameView f{N, keysUn, uRight, desc, nullptr, bounds[0], bounds[1], bounds[2], bounds[3]};
+    return FuseSearch(f, q, M, invLevelSigma2, q_match, q_dist);
+}
+}

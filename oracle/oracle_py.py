@@ -290,3 +290,15 @@ def pose_optimization2(p):
                                 _p(np.ascontiguousarray(p["kp_uv"], np.float32)), _p(np.asarray(p["bounds"], np.float32)),
                                 float(p["invSigma2_0"]), _p(out), _p(outl), C.byref(nsem))
     return n, out.reshape(4, 4), outl[:N], nsem.value
+
+
+def fuse_search(keysUn, uRight, desc, bounds, queries, invLevelSigma2):
+    keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+    N, M = len(keysUn), len(queries)
+    uR = np.full(N, -1, np.float32) if uRight is None else np.ascontiguousarray(uRight, np.float32)
+    qm, qd = np.full(max(M, 1), -1, np.int32), np.full(max(M, 1), 256, np.int32)
+    L = lib()
+    L.oo_fuse_search.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 3
+    n = L.oo_fuse_search(N, _p(keysUn), _p(uR), _p(np.ascontiguousarray(desc, np.uint8)), _p(np.asarray(bounds, np.float32)),
+                         _p(np.ascontiguousarray(queries, QUERY_DTYPE)), M, _p(np.ascontiguousarray(invLevelSigma2, np.float32)), _p(qm), _p(qd))
+    return n, qm[:M], qd[:M]

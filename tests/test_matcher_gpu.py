@@ -134,3 +134,21 @@ def test_last_frame_projection_on_extracted_frames(oracle):
         assert nm > 300, nm   # the same scene 3 frames apart: most points re-found
         m.close()
     ex.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuse_search(oracle, seed):
+    """Search half of ORBmatcher::Fuse: chi2-gated best match <= TH_LOW."""
+    rng = np.random.default_rng(100 + seed)
+    N, M = [(1000, 800), (2000, 3000), (200, 60), (1500, 1500)][seed]
+    k, uR, desc = _rand_frame(rng, N, clustered=(seed == 1))
+    q = _rand_queries(rng, k, uR, desc, M, 0.05)
+    q["radius"] = (3.0 * SCALE[np.clip(q["maxLevel"], 0, 7)]).astype(np.float32)
+    inv = (1.0 / (SCALE * SCALE)).astype(np.float32)
+    m = ORBmatcher(0.6, True, max_keypoints=2400, max_queries=4096)
+    nf, qm, qd = m.fuse_search(k, uR, desc, (0.0, 0.0, 640.0, 480.0), q, inv)
+    onf, oqm, oqd = oracle.fuse_search(k, uR, desc, (0.0, 0.0, 640.0, 480.0), q, inv)
+    np.testing.assert_array_equal(qm, oqm)
+    np.testing.assert_array_equal(qd, oqd)
+    assert nf == onf and (nf > 10 or N < 300)
+    m.close()
