@@ -18,6 +18,7 @@ constexpr int kGridCells = kGridCols * kGridRows;
 constexpr int kHistoLen = 30;                   // src/ORBmatcher.cc:39
 constexpr int kMatchThreads = 1024;
 constexpr int kMaxMatchKps = 2400;              // LDS budget, see lds_bytes()
+constexpr int kCacheCap = 48;                   // cached candidates per query for the claim-order fixpoint
 
 struct MatchCtx {
     // frame side
@@ -37,6 +38,8 @@ struct MatchCtx {
     // outputs
     int* q_match; int* q_dist; int* kp_match; int* nmatches;
     int* iters;               // [B] fixpoint iterations used (diagnostic)
+    uint32_t* cache;          // [B][q_stride][kCacheCap] gate-passing candidates of every query: dist << 16 | index, reference order
+    int* ccount;              // [B][q_stride] cached count, or -1 if the query has more than kCacheCap candidates
 };
 
 __host__ __device__ inline size_t match_lds_bytes(int ncap) {
@@ -56,6 +59,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     int* q_match = c.q_match + (long long)b * c.q_stride;
     int* q_dist = c.q_dist + (long long)b * c.q_stride;
     int* kp_match = c.kp_match + (long long)b * c.kp_stride;
+    uint32_t* cache = c.cache + (long long)b * c.q_stride * kCacheCap;
+    int* ccount = c.ccount + (long long)b * c.q_stride;
 
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_desc = (uint32_t*)smem;                     // [ncap][8]
@@ -149,7 +154,32 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
             const oslam_proj_query_t* qp = Q + j;
             int bestIdx = -1, bestDist = 256;
             const int flags = qp->flags;
-            if (flags & 1) {
+            const int ncached = it > 0 ? ccount[j] : -1;
+            if ((flags & 1) && ncached >= 0) {
+                // iterations >= 1: the gate-passing candidates and their distances do not change, only the
+                // claims do: replay the cached list (reference order) against the current claim table
+                int bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
+                const uint32_t* cl = cache + (long long)j * kCacheCap;
+                for (int t = 0; t < ncached; t++) {
+                    const uint32_t en = cl[t];
+                    const int k = en & 0xFFFF, dist = en >> 16;
+                    if (s_Bprev[k] < j) continue;
+                    const int oct = s_oct[k];
+                    if (dist < bestDist) {
+                        bestDist2 = bestDist; bestDist = dist;
+                        bestLevel2 = bestLevel; bestLevel = oct;
+                        bestIdx = k;
+                    } else if (dist < bestDist2) {
+                        bestLevel2 = oct; bestDist2 = dist;
+                    }
+                }
+                if (bestDist <= c.th_high) {
+                    if (c.use_ratio && bestLevel == bestLevel2 && (float)bestDist > c.nnratio * (float)bestDist2) bestIdx = -1;
+                } else
+                    bestIdx = -1;
+            } else if (flags & 1) {
+                int nc = 0;   // candidates cached in iteration 0
+                uint32_t* cl = cache + (long long)j * kCacheCap;
                 const float x = qp->u, y = qp->v, r = qp->radius, qur = qp->ur;
                 const int minLevel = qp->minLevel, maxLevel = qp->maxLevel;
                 // GetFeaturesInArea (:567-620)
@@ -190,7 +220,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                                     if ((double)(e2 * c.invSigma2[oct]) > 5.99) continue;
                                 }
                             } else {
-                                if (s_blk[k] || s_Bprev[k] < j) continue;
+                                if (s_blk[k]) continue;
                                 if (kur > 0) {
                                     const float er = fabsf(qur - kur);
                                     if (er > r) continue;
@@ -200,6 +230,11 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                             int dist = 0;
 #pragma unroll
                             for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ d[w]);
+                            if (it == 0) {
+                                if (nc < kCacheCap) cl[nc] = ((uint32_t)dist << 16) | (uint32_t)k;
+                                nc++;
+                            }
+                            if (!c.fuse && s_Bprev[k] < j) continue;   // claimed by an earlier observed map point (:87-89)
                             if (dist < bestDist) {
                                 bestDist2 = bestDist; bestDist = dist;
                                 bestLevel2 = bestLevel; bestLevel = oct;
@@ -214,6 +249,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                     } else
                         bestIdx = -1;
                 }
+                if (it == 0) ccount[j] = nc <= kCacheCap ? nc : -1;
             }
             q_match[j] = bestIdx;
             q_dist[j] = bestIdx >= 0 ? bestDist : 256;
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
         __syncthreads();
         const int changed = s_changed;
         __syncthreads();
-        if (!changed) break;
+        if (!changed || c.fuse) break;   // Fuse has no claims: one pass
         { int* t = s_Bcur; s_Bcur = s_Bprev; s_Bprev = t; }
     }
 
@@ -392,6 +428,7 @@ struct oslam_matcher {
     size_t lds = 0;
     // device-owned
     int* d_q_match = nullptr; int* d_q_dist = nullptr; int* d_kp_match = nullptr; int* d_nm = nullptr; int* d_iters = nullptr;
+    uint32_t* d_cache = nullptr; int* d_ccount = nullptr;
     oslam_proj_query_t* d_queries = nullptr;   // internal query buffer (project_last / host API)
     int* d_nq = nullptr;
     // staging for the host API (batch 1)
@@ -403,7 +440,7 @@ extern "C" {
 
 void oslam_matcher_destroy(oslam_matcher_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
+    void* ptrs[] = {h->d_cache, h->d_ccount, h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
                     h->d_desc, h->d_blocked, h->d_Xw, h->d_has, h->d_lkeys, h->d_ldesc, h->d_T};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -436,6 +473,7 @@ int oslam_matcher_create(oslam_matcher_t** out, int max_batch, int max_keypoints
         }                                                                         \
     } while (0)
     ALLOC(h->d_q_match, B * NQ * 4); ALLOC(h->d_q_dist, B * NQ * 4); ALLOC(h->d_kp_match, B * NK * 4);
+    ALLOC(h->d_cache, B * NQ * kCacheCap * 4); ALLOC(h->d_ccount, B * NQ * 4);
     ALLOC(h->d_nm, B * 4); ALLOC(h->d_iters, B * 4); ALLOC(h->d_queries, B * NQ * sizeof(oslam_proj_query_t)); ALLOC(h->d_nq, B * 4);
     ALLOC(h->d_kps, NK * sizeof(oslam_keypoint_t)); ALLOC(h->d_ur, NK * 4); ALLOC(h->d_desc, NK * 32); ALLOC(h->d_blocked, NK);
     ALLOC(h->d_Xw, NQ * 12); ALLOC(h->d_has, NQ); ALLOC(h->d_lkeys, NQ * sizeof(oslam_keypoint_t)); ALLOC(h->d_ldesc, NQ * 32); ALLOC(h->d_T, 32 * 4);
@@ -492,6 +530,7 @@ static int search_impl(oslam_matcher_t* h, const oslam_match_frames_t* f, const 
     c.fuse = invLevelSigma2 ? 1 : 0;
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) c.invSigma2[i] = (invLevelSigma2 && i < nlevels) ? invLevelSigma2[i] : 0.f;
     c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters;
+    c.cache = h->d_cache; c.ccount = h->d_ccount;
     // per-frame output strides equal the input strides; outputs were sized for max_q / max_kps
     if ((size_t)f->kp_stride > (size_t)h->max_kps) { set_error("kp_stride %d > max_keypoints %d", f->kp_stride, h->max_kps); return OSLAM_E_CAPACITY; }
     hipLaunchKernelGGL(k_search_window, dim3(batch), dim3(kMatchThreads), h->lds, (hipStream_t)stream, c, h->max_kps);

@@ -176,6 +176,11 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
             ++v0;
         }
     }
+    {
+        static const int kUmax15[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // packed in k_orient_describe
+        for (int i = 0; i < 16; i++)
+            if (P.umax[i] != kUmax15[i]) { set_error("umax table mismatch"); delete h; return OSLAM_E_INVALID; }
+    }
     // Gaussian 7 taps sigma 2 -> 8-bit fixed point (OpenCV 3.2 getGaussianKernel + convertTo(CV_32S, 256))
     {
         float cf[7];
@@ -224,7 +229,6 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
         g.cand_base = cand_base;
         cell_base += g.nCols * g.nRows;
         cand_base += g.nCols * g.nRows * g.cell_cap;
-        if (g.nCols * g.nRows > kCandCap / 2) { set_error("too many FAST cells at level %d", l); delete h; return OSLAM_E_INVALID; }
         g.quota = h->quota[l];
         // quad-tree roots, :543-563
         g.nIni = (int)std::round((float)g.region_w / g.region_h);
@@ -279,6 +283,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     P.sel_per_image = sel_base;
     P.out_cap = sel_base;
     P.node_cap = node_cap + 8;
+    for (int l = 0; l < nlevels; l++)
+        if (P.lv[l].nCols * P.lv[l].nRows > 18 * P.node_cap) { set_error("too many FAST cells at level %d for the quad-tree kernel", l); delete h; return OSLAM_E_INVALID; }
     h->pyr_stride = blur_off;
     h->blur_stride = blur_off;
     {
@@ -398,7 +404,10 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     PROF_MARK(3);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
     PROF_MARK(4);
-    hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4), batch), dim3(256), 0, st, c);
+    {
+        const int kpw = batch >= 32 ? 16 : (batch >= 8 ? 4 : 1);
+        hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4 * kpw), batch), dim3(256), 0, st, c, kpw);
+    }
     PROF_MARK(5);
 #undef PROF_MARK
     if (prof) h->prof_pending = true;

@@ -888,14 +888,14 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(OrbCtx c) {
     uint32_t* ent = (uint32_t*)smem;                       // [kCandCap]
     uint16_t* knode = (uint16_t*)(ent + kCandCap);         // [kCandCap]
     int* ibase = (int*)(knode + kCandCap);
-    int* scratch = ibase;                                  // wave totals of the scan below (area is re-initialised by the body)
+    int* scratch = ibase + 18 * P->node_cap + 2;           // the body's 32-int scratch slot
     int* sel_count = c.sel_count + (long long)b * P->nlevels + level;
 
-    // prefix of the per-cell counts, kept in the LDS node-id area: the gather reads it while
-    // writing only `ent`; the body first writes node ids after the gather's barrier
+    // prefix of the per-cell counts, kept in the LDS node-table area: the gather reads it while writing
+    // only `ent`; the body first writes its tables after the gather's barrier
     const int ncells = g.nCols * g.nRows;
     const int* cell_count = c.cell_count + (long long)b * P->total_cells + g.cell_base;
-    int* cellofs = (int*)knode;   // ncells <= kCandCap/2 ints, checked at create time
+    int* cellofs = ibase;         // ncells <= 18*node_cap ints (checked at create time); the body re-initialises this area after the gather
     for (int i = tid; i < ncells; i += kOctThreads) cellofs[i] = cell_count[i];
     __syncthreads();
     const int n = block_exclusive_scan(cellofs, ncells, scratch);
@@ -949,79 +949,121 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c) {
+// 64 keypoint slots per 256-thread workgroup, three phases:
+//  1. each wavefront computes the integer moments of its 16 keypoints (two patch rows per pass,
+//     lanes 0-30 / 32-62 = columns -15..15, no divisions);
+//  2. 64 lanes in parallel: fastAtan2 polynomial and the fp64 cos/sin of 64 keypoints at once
+//     (the reference's (float)cos((double)angle)), instead of once per wavefront;
+//  3. each wavefront writes the descriptors of its 16 keypoints (4 tests per lane).
+__global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* keypoints per wavefront: 16 for big batches, 1 for latency */) {
     const OrbParams* P = c.P;
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);   // index in the concatenated output
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nslot = 4 * kpw;
+    const int slot0 = blockIdx.x * nslot;
     const int* sel_count = c.sel_count + (long long)b * P->nlevels;
-    int level = -1, idx = slot, total = 0;
-    for (int l = 0; l < P->nlevels; l++) {
-        const int cnt = sel_count[l];
-        if (level < 0 && idx < cnt) level = l;
-        if (level < 0) idx -= cnt;
-        total += cnt;
-    }
-    if (slot == 0 && lane == 0) {
-        c.out_count[b] = total;
-        if (total > P->out_cap) atomicOr(c.status, 16);
-    }
-    if (level < 0 || slot >= P->out_cap) return;
-    const LevelGeom& g = P->lv[level];
-    const uint32_t e = c.sel[(long long)b * P->sel_per_image + g.sel_base + idx];
-    const int kx = ent_x(e), ky = ent_y(e), score = ent_s(e);
+    __shared__ int s_level[64], s_kx[64], s_ky[64], s_score[64], s_m01[64], s_m10[64];
+    __shared__ float s_angle[64], s_a[64], s_b[64];
 
-    // IC_Angle: integer moments over the r=15 circular patch (749 px)
-    int pitch;
-    const uint8_t* img = level_image(c, P, b, level, pitch);
-    const uint8_t* center = img + (long long)ky * pitch + kx;
-    int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int v = i / 31 - 15, u = i - (v + 15) * 31 - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= P->umax[av]) {
-            const int val = center[v * pitch + u];
-            m10 += u * val;
-            m01 += v * val;
+    // phase 0: slot -> (level, keypoint)
+    if (tid < nslot) {
+        const int slot = slot0 + tid;
+        int level = -1, idx = slot, total = 0;
+        for (int l = 0; l < P->nlevels; l++) {
+            const int cnt = sel_count[l];
+            if (level < 0 && idx < cnt) level = l;
+            if (level < 0) idx -= cnt;
+            total += cnt;
+        }
+        if (slot == 0) {
+            c.out_count[b] = total;
+            if (total > P->out_cap) atomicOr(c.status, 16);
+        }
+        if (slot >= P->out_cap) level = -1;
+        s_level[tid] = level;
+        if (level >= 0) {
+            const uint32_t e = c.sel[(long long)b * P->sel_per_image + P->lv[level].sel_base + idx];
+            s_kx[tid] = ent_x(e); s_ky[tid] = ent_y(e); s_score[tid] = ent_s(e);
         }
     }
+    __syncthreads();
+    // phase 1: IC_Angle moments (reference :77-104), integer exact
+    const int u = (lane & 31) - 15;
+    const bool ucol = (lane & 31) < 31;
+    const int au = u < 0 ? -u : u;
+    for (int q = 0; q < kpw; q++) {
+        const int s = wv * kpw + q;
+        const int level = s_level[s];
+        if (level < 0) continue;
+        int pitch;
+        const uint8_t* img = level_image(c, P, b, level, pitch);
+        const uint8_t* center = img + (long long)s_ky[s] * pitch + s_kx[s];
+        int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d, 64);
-        m01 += __shfl_xor(m01, d, 64);
-    }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // steered BRIEF on the blurred level: 4 tests per lane
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float ang = angle * factorPI;
-    const float a = (float)cos((double)ang), bb = (float)sin((double)ang);
-    const uint8_t* bimg = c.blur + (long long)b * c.blur_stride + g.img_off;
-    const uint8_t* bc = bimg + (long long)ky * g.pitch + kx;
-    int nib = 0;
+        for (int it = 0; it < 16; it++) {
+            const int v = -15 + 2 * it + (lane >> 5);
+            const int av = v < 0 ? -v : v;
+            // umax for HALF_PATCH_SIZE = 15 (reference :454-469): 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 packed 4 bits each
+            const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);
+            if (ucol && v <= 15 && au <= um) {
+                const int val = center[v * pitch + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int8_t* pt = &c_pattern[(lane * 4 + t) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
-        const int r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
-        const int t0 = bc[r0 * g.pitch + c0], t1 = bc[r1 * g.pitch + c1];
-        nib |= (t0 < t1) << t;
+        for (int d = 32; d >= 1; d >>= 1) {
+            m10 += __shfl_xor(m10, d, 64);
+            m01 += __shfl_xor(m01, d, 64);
+        }
+        if (lane == 0) { s_m10[s] = m10; s_m01[s] = m01; }
     }
-    const int other = __shfl_xor(nib, 1, 64);
-    const long long o = (long long)b * P->out_cap + slot;
-    if ((lane & 1) == 0) c.out_desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
-    if (lane == 0) {
-        oslam_keypoint_t kp;
-        const float fx = (float)kx, fy = (float)ky;
-        kp.x = level ? fx * g.scale : fx;
-        kp.y = level ? fy * g.scale : fy;
-        kp.size = g.kp_size;
-        kp.angle = angle;
-        kp.response = (float)score;
-        kp.octave = level;
-        kp.class_id = -1;
-        c.out_kp[o] = kp;
+    __syncthreads();
+    // phase 2: orientation and rotation coefficients, one lane per keypoint
+    if (tid < nslot && s_level[tid] >= 0) {
+        const float angle = fast_atan2_deg((float)s_m01[tid], (float)s_m10[tid]);
+        const float factorPI = (float)(3.14159265358979323846 / 180.f);
+        const float ang = angle * factorPI;
+        s_angle[tid] = angle;
+        s_a[tid] = (float)cos((double)ang);
+        s_b[tid] = (float)sin((double)ang);
+    }
+    __syncthreads();
+    // phase 3: steered BRIEF on the blurred level (:108-147) + keypoint record (:1090-1104)
+    for (int q = 0; q < kpw; q++) {
+        const int s = wv * kpw + q;
+        const int level = s_level[s];
+        if (level < 0) continue;
+        const LevelGeom& g = P->lv[level];
+        const int kx = s_kx[s], ky = s_ky[s];
+        const float a = s_a[s], bb = s_b[s];
+        const uint8_t* bimg = c.blur + (long long)b * c.blur_stride + g.img_off;
+        const uint8_t* bc = bimg + (long long)ky * g.pitch + kx;
+        int nib = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int8_t* pt = &c_pattern[(lane * 4 + t) * 4];
+            const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+            const int r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
+            const int r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
+            const int t0 = bc[r0 * g.pitch + c0], t1 = bc[r1 * g.pitch + c1];
+            nib |= (t0 < t1) << t;
+        }
+        const int other = __shfl_xor(nib, 1, 64);
+        const long long o = (long long)b * P->out_cap + slot0 + s;
+        if ((lane & 1) == 0) c.out_desc[o * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+        if (lane == 0) {
+            oslam_keypoint_t kp;
+            const float fx = (float)kx, fy = (float)ky;
+            kp.x = level ? fx * g.scale : fx;
+            kp.y = level ? fy * g.scale : fy;
+            kp.size = g.kp_size;
+            kp.angle = s_angle[s];
+            kp.response = (float)s_score[s];
+            kp.octave = level;
+            kp.class_id = -1;
+            c.out_kp[o] = kp;
+        }
     }
 }
 

@@ -10,7 +10,7 @@ constexpr int kPatchSize = 31;       // :72
 constexpr int kRegionBorder = 16;    // EDGE_THRESHOLD-3, :773
 constexpr int kMaxCell = 64;         // max FAST cell interior edge handled by one workgroup
 constexpr int kTilePitch = 72;       // LDS tile pitch (>= kMaxCell + 6)
-constexpr int kCandCap = 16384;      // FAST candidates per (image, level) the quad-tree kernel holds in LDS
+constexpr int kCandCap = 4096;       // FAST candidates per (image, level) the quad-tree kernel holds in LDS (more: HBM spill path)
 constexpr int kMaxRoots = 64;        // nIni upper bound
 
 // candidate / survivor entry: x (12 bit) | y (12 bit) << 12 | score (8 bit) << 24
