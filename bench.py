@@ -57,6 +57,25 @@ def cpu_baseline(frames, offs, n_sample):
     return done / dt, dt
 
 
+def pmc_traffic(kernel_substr, frames_per_launch):
+    """HBM-side bytes per launch of one kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv; FETCH_SIZE / WRITE_SIZE are in KB and, for the
+    4-byte-per-lane loads these kernels issue, FETCH_SIZE matched the algorithmic byte count 1:1 on the
+    calibration kernels (blur: 927 KB read vs 950 KB algorithmic), so no x2 correction is applied).
+    The profile was taken at 256 frames per launch; scaled linearly to this run's batch."""
+    import csv
+    tot = 0.0
+    for f in ("r01_pmc_fetch_size.csv", "r01_pmc_write_size.csv"):
+        path = os.path.join(ROOT, "profiles", f)
+        if not os.path.exists(path):
+            return None
+        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
+        if not vals:
+            return None
+        tot += sum(vals) / len(vals)
+    return tot * 1024.0 * frames_per_launch / 256.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,10 +225,14 @@ def main():
         per_frame_us["match(K8-K10)"] = float(np.mean(match_ms)) / B * 1e3
         M = N = n_kp
         alg["match(K8-K10)"] = 44 * M + 36 * N + 12288 + 8 * M
-        dom = max((n for n in names), key=lambda n: per_frame_us[n])
+        dom = max(per_frame_us.keys(), key=lambda n: per_frame_us[n])
         achieved = alg[dom] / (per_frame_us[dom] * 1e-6) / 1e9
+        kname = {"pyramid(K1)": "k_resize", "fast_cells(K2/K3)": "k_fast_cells_wave", "blur(K6)": "k_blur_strip<false>",
+                 "octree(K4)": "k_octree", "orient_describe(K5/K7)": "k_orient_describe", "match(K8-K10)": "k_search_window"}[dom]
+        traffic = pmc_traffic(kname, B)
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else int(traffic),
+                "algorithmic_bytes_per_launch": int(alg[dom] * B),
                 "launch_us": round(per_frame_us[dom] * B, 1),
                 "per_frame_us": {k: round(v, 3) for k, v in per_frame_us.items()},
                 "alg_bytes_per_frame": {k: int(v) for k, v in alg.items()},
@@ -222,6 +245,47 @@ def main():
         cpu = {"value": round(v, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same stream: oracle extract + SearchByProjection(Cur,Last), %.1f s" % (ns, dt)}
 
+    extras = None
+    if rank == 0 and world == 1:
+        # other rows of the hot path (SURVEY.md §8(d) S5 and the pose optimisers), reported beside the headline
+        try:
+            from object_slam_amd import LocalBundleAdjuster, PoseOptimizer
+            extras = {}
+            PB, PN = 128, 1000
+            probs = [synth.make_pose_problem(100 + i, N=PN) for i in range(PB)]
+            tt = lambda k, dt: torch.from_numpy(np.stack([q[k] for q in probs]).astype(dt)).cuda()
+            a_T, a_X, a_o, a_i, a_h = tt("Tcw", np.float32), tt("Xw", np.float32), tt("obs", np.float32), tt("invSigma2", np.float32), tt("has_mp", np.uint8)
+            po = PoseOptimizer(max_points=PN, max_batch=PB, device=local_rank)
+            for _ in range(2):
+                po.optimize_batch_device(PB, PN, None, PN, a_T.data_ptr(), a_X.data_ptr(), a_o.data_ptr(), a_i.data_ptr(), a_h.data_ptr(), probs[0]["K"], st)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                po.optimize_batch_device(PB, PN, None, PN, a_T.data_ptr(), a_X.data_ptr(), a_o.data_ptr(), a_i.data_ptr(), a_h.data_ptr(), probs[0]["K"], st)
+            torch.cuda.synchronize()
+            extras["pose_optimization_frames_per_s"] = round(PB * 5 / (time.perf_counter() - t1), 1)
+            extras["pose_optimization_config"] = "Optimizer::PoseOptimization, %d frames/launch x %d keypoints (80%% with map points, 10%% outliers)" % (PB, PN)
+            q5 = synth.make_lba_problem(1234)
+            ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536, device=local_rank)
+            lba_args = (q5["poses"], q5["fixed"], q5["points"], q5["edge_kf"], q5["edge_pt"], q5["edge_obs"], q5["edge_invSigma2"], q5["K"])
+            ba.LocalBundleAdjustment(*lba_args)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                r5 = ba.LocalBundleAdjustment(*lba_args)
+            extras["lba_S5_ms"] = round((time.perf_counter() - t1) / 3 * 1e3, 3)
+            extras["lba_S5_config"] = "S5: 20 local + 20 fixed KF, 4000 points, %d edges, host-to-host incl. PCIe" % len(q5["edge_kf"])
+            if not args.no_cpu_baseline:
+                from oracle import oracle_py as O
+                t1 = time.perf_counter()
+                for q in probs[:10]:
+                    O.pose_optimization(q["Tcw"], q["Xw"], q["obs"], q["invSigma2"], q["has_mp"], q["K"])
+                extras["pose_optimization_cpu_oracle_frames_per_s"] = round(10 / (time.perf_counter() - t1), 1)
+                t1 = time.perf_counter()
+                O.local_bundle_adjustment(*lba_args)
+                extras["lba_S5_cpu_oracle_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+        except Exception as ex:   # never let the side measurements break the headline line
+            extras = {"error": repr(ex)}
+
     if rank == 0:
         out = {"metric": "frames/sec tracking front-end (ORBextractor+ORBmatcher)", "value": round(total_frames / elapsed, 1),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,7 +296,7 @@ def main():
                           "batch_frames_per_step": B, "frames_per_gpu_per_step": B, "keypoints_per_frame": float(counts.mean()),
                           "matches_frame_mid": int(nm), "claim_fixpoint_iterations": int(iters),
                           "parallelism": "independent sequences, one per GPU; no data-path collective"},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "extras": extras}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
