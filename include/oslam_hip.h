@@ -105,6 +105,9 @@ int oslam_orb_debug_get_level_keys(oslam_orb_t* h, int b, int level, int32_t* ou
 int oslam_orb_set_profiling(oslam_orb_t* h, int on);
 int oslam_orb_get_profile(oslam_orb_t* h, double ms[5], long long* batches, long long* images);
 
+/* Phase cycle counters of profiling builds (-DOSLAM_FAST_PROFILE); zeros otherwise. */
+int oslam_orb_debug_counters(oslam_orb_t* h, unsigned long long out[16], int reset);
+
 /* Work model of one extract call: algorithmic bytes per image. */
 int64_t oslam_orb_algorithmic_bytes(const oslam_orb_t* h, int n_keypoints);
 

@@ -43,6 +43,7 @@ struct oslam_orb {
     // device
     OrbParams* dP = nullptr;
     int2* d_rtab = nullptr;
+    int* d_qbase = nullptr; uint4* d_qpx = nullptr;
     uint8_t* d_root_of_x = nullptr;
     short* d_root_x = nullptr;
     uint8_t* d_stage = nullptr;   // [B][H][pitch0] staging for host images
@@ -61,6 +62,7 @@ struct oslam_orb {
     uint8_t* d_out_desc = nullptr;
     int* d_out_count = nullptr;
     int* d_status = nullptr;
+    unsigned long long* d_dbg = nullptr;
     size_t oct_lds = 0;
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
@@ -106,9 +108,9 @@ int oslam_device_count(void) {
 
 void oslam_orb_destroy(oslam_orb_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
+    void* ptrs[] = {h->d_qbase, h->d_qpx, h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
                     h->d_cell_count, h->d_cand, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
-                    h->d_out_count, h->d_status};
+                    h->d_out_count, h->d_status, h->d_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
@@ -198,6 +200,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     }
 
     std::vector<int2> rtab;
+    std::vector<int> qbase;
+    std::vector<uint4> qpx;
     std::vector<uint8_t> root_of_x((size_t)nlevels * 4096, 0);
     std::vector<short> root_x;
     long long pyr_off = 0, blur_off = 0;
@@ -255,6 +259,25 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
             build_resize_tab(P.lv[l - 1].w, g.w, true, rtab);
             g.ytab_off = (int)rtab.size();
             build_resize_tab(P.lv[l - 1].h, g.h, false, rtab);
+            // quad tables for the word-load kernel: every 4-pixel group must fit a 12-byte aligned window
+            g.qtab_off = (int)qbase.size();
+            bool fits = true;
+            const int nq = div_up(g.w, 4);
+            for (int q = 0; q < nq && fits; q++) {
+                const int xb = rtab[g.xtab_off + q * 4].x & ~3;
+                uint32_t t[4];
+                for (int i = 0; i < 4; i++) {
+                    const int x = std::min(q * 4 + i, g.w - 1);
+                    const int2 e = rtab[g.xtab_off + x];
+                    const int o = e.x - xb;
+                    const int a0 = (short)(e.y & 0xFFFF), a1 = (short)(e.y >> 16);
+                    if (o < 0 || o > 10 || a0 < 0 || a0 > 2048 || a1 < 0 || a1 > 2048) { fits = false; break; }
+                    t[i] = (uint32_t)o | ((uint32_t)a0 << 4) | ((uint32_t)a1 << 16);
+                }
+                qbase.push_back(xb);
+                qpx.push_back(make_uint4(t[0], t[1], t[2], t[3]));
+            }
+            if (!fits) { qbase.resize(g.qtab_off); qpx.resize(g.qtab_off); g.qtab_off = -1; }
         }
     }
     (void)pyr_off;
@@ -309,6 +332,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     } while (0)
     ALLOC(h->dP, sizeof(OrbParams));
     ALLOC(h->d_rtab, std::max<size_t>(rtab.size(), 1) * sizeof(int2));
+    ALLOC(h->d_qbase, std::max<size_t>(qbase.size(), 1) * sizeof(int));
+    ALLOC(h->d_qpx, std::max<size_t>(qpx.size(), 1) * sizeof(uint4));
     ALLOC(h->d_root_of_x, root_of_x.size());
     ALLOC(h->d_root_x, root_x.size() * sizeof(short));
     h->stage_pitch = (int)align_up(width, 64);
@@ -325,9 +350,15 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_out_desc, B * (size_t)P.out_cap * 32);
     ALLOC(h->d_out_count, B * sizeof(int));
     ALLOC(h->d_status, sizeof(int));
+    ALLOC(h->d_dbg, 16 * sizeof(unsigned long long));
+    OSLAM_HIP_CHECK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
 #undef ALLOC
     OSLAM_HIP_CHECK(hipMemcpy(h->dP, &P, sizeof(P), hipMemcpyHostToDevice));
     if (!rtab.empty()) OSLAM_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(int2), hipMemcpyHostToDevice));
+    if (!qbase.empty()) {
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_qbase, qbase.data(), qbase.size() * sizeof(int), hipMemcpyHostToDevice));
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_qpx, qpx.data(), qpx.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     OSLAM_HIP_CHECK(hipMemcpy(h->d_root_of_x, root_of_x.data(), root_of_x.size(), hipMemcpyHostToDevice));
     OSLAM_HIP_CHECK(hipMemcpy(h->d_root_x, root_x.data(), root_x.size() * sizeof(short), hipMemcpyHostToDevice));
     OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
@@ -378,9 +409,9 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.img0 = d_gray; c.img0_pitch = stride; c.img0_stride = (long long)image_stride;
     c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
     c.blur = h->d_blur; c.blur_stride = h->blur_stride;
-    c.rtab = h->d_rtab; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
+    c.rtab = h->d_rtab; c.qbase = h->d_qbase; c.qpx = h->d_qpx; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
     c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
-    c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status;
+    c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status; c.dbg = h->d_dbg;
     const bool prof = h->profiling != 0;
     if (prof) {
         int rc = collect_profile(h);   // previous batch, if not collected yet
@@ -393,7 +424,10 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     for (int l = 1; l < P.nlevels; l++) {
         const LevelGeom& g = P.lv[l];
         dim3 grid(div_up(g.w, 256), div_up(g.h, 4), batch);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
+        // source rows 4-byte aligned? (levels >= 1 always; level 0 is the caller's buffer)
+        const bool src_aligned = l > 1 || (((stride & 3) == 0) && ((((uintptr_t)d_gray) & 3) == 0) && ((image_stride & 3) == 0));
+        if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, grid, dim3(256), 0, st, c, l);
+        else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);
     hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4), batch), dim3(256), 0, st, c);
@@ -498,6 +532,14 @@ int oslam_orb_get_profile(oslam_orb_t* h, double ms[5], long long* batches, long
     for (int i = 0; i < 5; i++) ms[i] = h->prof_ms[i];
     if (batches) *batches = h->prof_batches;
     if (images) *images = h->prof_images;
+    return OSLAM_OK;
+}
+
+int oslam_orb_debug_counters(oslam_orb_t* h, unsigned long long out[16], int reset) {
+    if (!h) return OSLAM_E_INVALID;
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(out, h->d_dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) OSLAM_HIP_CHECK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
     return OSLAM_OK;
 }
 

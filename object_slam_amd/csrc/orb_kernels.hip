@@ -19,6 +19,8 @@ struct OrbCtx {
     uint8_t* blur;            // [B][blur_stride]  levels 0..n-1
     long long blur_stride;
     const int2* rtab;         // resize tables: (src index, a0 | a1 << 16)
+    const int* qbase;         // k_resize_words: aligned source byte offset per dst quad
+    const uint4* qpx;         // k_resize_words: per pixel (window offset | a0 << 4 | a1 << 16)
     const uint8_t* root_of_x; // per level: region x -> root index
     const short* root_x;      // per level: nIni+1 root boundaries
     int* cell_count;          // [B][total_cells]
@@ -31,6 +33,7 @@ struct OrbCtx {
     uint8_t* out_desc;        // [B][out_cap][32]
     int* out_count;           // [B]
     int* status;              // [1]
+    unsigned long long* dbg;  // [16] phase cycle counters (profiling builds only)
 };
 
 __device__ __forceinline__ const uint8_t* level_image(const OrbCtx& c, const OrbParams* P, int b, int l,
@@ -77,6 +80,52 @@ __global__ __launch_bounds__(256) void k_resize(OrbCtx c, int level) {
         outw |= (uint32_t)v << (8 * i);
     }
     // pitch is a multiple of 64 so the 4-byte store is aligned and stays inside the row's padding
+    *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
+}
+
+// K1 (v2): word-load variant for 4-byte aligned source rows and scale factors <= 2.
+// Per quad of 4 dst pixels the host tables give the aligned byte offset of a 12-byte source window
+// and, per pixel, (byte offset in the window | a0 << 4 | a1 << 16); three words per source row replace
+// eight byte gathers, pixel pairs are cut out with v_alignbyte.
+__global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
+    const OrbParams* P = c.P;
+    const LevelGeom& g = P->lv[level];
+    const LevelGeom& gs = P->lv[level - 1];
+    const int b = blockIdx.z;
+    const int q = blockIdx.x * 64 + (threadIdx.x & 63);   // quad index
+    const int x4 = q * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= g.h || x4 >= g.w) return;
+    int spitch;
+    const uint8_t* src = level_image(c, P, b, level - 1, spitch);
+    uint8_t* dst = c.pyr + (long long)b * c.pyr_stride + g.img_off;
+    const int2 ty = c.rtab[g.ytab_off + y];
+    const int sy0 = min(max(ty.x, 0), gs.h - 1), sy1 = min(max(ty.x + 1, 0), gs.h - 1);
+    const int b0 = (short)(ty.y & 0xFFFF), b1 = (short)(ty.y >> 16);
+    const int xb = c.qbase[g.qtab_off + q];
+    const uint4 tq = c.qpx[g.qtab_off + q];
+    const int maxoff = (gs.w - 1) & ~3;
+    const int o1 = min(xb + 4, maxoff), o2 = min(xb + 8, maxoff);
+    const uint8_t* S0 = src + (long long)sy0 * spitch;
+    const uint8_t* S1 = src + (long long)sy1 * spitch;
+    const uint32_t u0 = *(const uint32_t*)(S0 + xb), u1 = *(const uint32_t*)(S0 + o1), u2 = *(const uint32_t*)(S0 + o2);
+    const uint32_t v0 = *(const uint32_t*)(S1 + xb), v1 = *(const uint32_t*)(S1 + o1), v2 = *(const uint32_t*)(S1 + o2);
+    const uint32_t tp[4] = {tq.x, tq.y, tq.z, tq.w};
+    uint32_t outw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t t = tp[i];
+        const int o = t & 15, a0 = (t >> 4) & 0xFFF, a1 = (t >> 16) & 0xFFF;
+        const int sel = o >> 2, sh = o & 3;
+        const uint32_t ulo = sel == 0 ? u0 : (sel == 1 ? u1 : u2), uhi = sel == 0 ? u1 : (sel == 1 ? u2 : 0u);
+        const uint32_t vlo = sel == 0 ? v0 : (sel == 1 ? v1 : v2), vhi = sel == 0 ? v1 : (sel == 1 ? v2 : 0u);
+        const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, sh), pv = __builtin_amdgcn_alignbyte(vhi, vlo, sh);
+        const int r0 = (int)(pu & 0xFF) * a0 + (int)((pu >> 8) & 0xFF) * a1;
+        const int r1 = (int)(pv & 0xFF) * a0 + (int)((pv >> 8) & 0xFF) * a1;
+        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        outw |= (uint32_t)v << (8 * i);
+    }
     *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
 }
 
@@ -380,7 +429,8 @@ __global__ __launch_bounds__(256) void k_blur_strip(OrbCtx c, int sse2_rounding)
 #pragma unroll
     for (int iy = 0; iy < kBlurRows; iy++) {
         const int y = y0 + iy;
-        if (y >= g.h) break;
+        // no early exit: rows past the image are computed from clamped/reflected addresses and not stored, so
+        // the unrolled loop has no control dependence and all row loads can be issued up front
         blur_hsum4<BORDER>(src + (long long)reflect101(min(y + 3, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[6]);
         uint32_t outw = 0;
 #pragma unroll
@@ -391,7 +441,7 @@ __global__ __launch_bounds__(256) void k_blur_strip(OrbCtx c, int sse2_rounding)
             const int v = rne ? (s + 0x7FFF + ((s >> 16) & 1)) >> 16 : (s + 0x8000) >> 16;
             outw |= (uint32_t)min(v, 255) << (8 * i);
         }
-        *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
+        if (y < g.h) *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
 #pragma unroll
         for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -434,8 +484,17 @@ __device__ __forceinline__ int fast_score3(const uint8_t* t) {
     return max(max(A, -Bm) - 1, 0);
 }
 
+#ifdef OSLAM_FAST_PROFILE
+#define FSTAMP(i) do { const long long t_ = clock64(); if (lane == 0) atomicAdd(&c.dbg[i], (unsigned long long)(t_ - tl_)); tl_ = clock64(); } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const OrbParams* P = c.P;
+#ifdef OSLAM_FAST_PROFILE
+    long long tl_ = clock64();
+#endif
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int cell = blockIdx.x * 4 + wv;
@@ -448,6 +507,8 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     cell -= g.cell_base;
     const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
     int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
+    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
+    const int cell_cap = g.cell_cap, wCellOut = g.wCell, hCellOut = g.hCell;
 
     const int minBX = kRegionBorder, minBY = kRegionBorder;
     const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
@@ -471,46 +532,77 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     int pitch;
     const uint8_t* img = level_image(c, P, b, level, pitch);
     const int rw = cw + 6, rh = ch + 6;
-    const int xa = iniX & ~3, sh = iniX - xa;          // aligned start, byte shift inside the tile
-    const int nwords = (sh + rw + 3) >> 2;              // words per row (<= 13)
+    // Tile layout: ROI column cc (0..rw-1) at tile byte cc+1, i.e. interior pixel x at byte x+4 (word aligned
+    // for x % 4 == 0).  Tile word j = global bytes base+s+4j.., base = (iniX-1) & ~3, s = (iniX-1) & 3
+    // (iniX >= 16, so the window never starts before the row; it ends before column w).
+    const int gbase = (iniX - 1) & ~3, gsh = (iniX - 1) & 3;
+    const int nwt = (rw + 1 + 3) >> 2;   // tile words per row (<= 12)
     if (((pitch & 3) == 0) && ((((unsigned long long)img) & 3ull) == 0)) {
-        for (int i = lane; i < nwords * rh; i += 64) {
-            const int ry = i / nwords, wx = i - ry * nwords;
-            // the aligned word may start before the ROI but never before the image row, and ends before column w
-            const uint32_t wv32 = *(const uint32_t*)(img + (long long)(iniY + ry) * pitch + xa + wx * 4);
-            *(uint32_t*)(tile + ry * kWTileP + wx * 4) = wv32;
+        // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by shuffle
+        const int wx = lane & 15, rsub = lane >> 4;
+#pragma unroll
+        for (int k = 0; k < (kWTileRows + 3) / 4; k++) {
+            const int ry = 4 * k + rsub;
+            uint32_t gw = 0;
+            if (ry < rh && wx <= nwt) gw = *(const uint32_t*)(img + (long long)(iniY + ry) * pitch + gbase + wx * 4);
+            const uint32_t gn = __shfl_down(gw, 1, 64);
+            if (ry < rh && wx < nwt) *(uint32_t*)(tile + ry * kWTileP + wx * 4) = __builtin_amdgcn_alignbyte(gn, gw, gsh);
         }
     } else {   // caller's level-0 buffer with an unaligned pitch: byte loads
         for (int i = lane; i < rw * rh; i += 64) {
             const int ry = i / rw, rx = i - ry * rw;
-            tile[ry * kWTileP + sh + rx] = img[(long long)(iniY + ry) * pitch + iniX + rx];
+            tile[ry * kWTileP + 1 + rx] = img[(long long)(iniY + ry) * pitch + iniX + rx];
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const uint8_t* t0 = tile + sh + 3 * kWTileP + 3;   // t0[y*kWTileP + x] = interior pixel (x, y)
+    FSTAMP(0);
+    const uint8_t* t0 = tile + 3 * kWTileP + 4;   // t0[y*kWTileP + x] = interior pixel (x, y)
     const int minTh = P->minTh, iniTh = P->iniTh;
 
-    // A. quick rejection at minTh: an arc of 9 of 16 contains >= 2 of the 4 compass pixels, so a corner
-    //    needs two compass pixels brighter than v+t or two darker than v-t.  Survivors -> ordered worklist.
+    // A. quick rejection at minTh: an arc of 9 of 16 contains one pixel of every opposite pair, so a
+    //    corner needs (p0|p8) and (p4|p12) brighter than v+t, or both darker than v-t.  Survivors ->
+    //    ordered worklist.
     int nwork = 0;
-    if (cw <= 32) {   // two rows per pass, no divisions; lanes 0-31 = row y, 32-63 = row y+1 (row-major ballot order)
-        const int x = lane & 31;
-        for (int yb = 0; yb < ch; yb += 2) {
-            const int y = yb + (lane >> 5);
-            bool pass = false;
-            if (x < cw && y < ch) {
-                const uint8_t* t = t0 + y * kWTileP + x;
-                const int v = t[0];
-                const int hi = v + minTh, lo = v - minTh;
-                const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
-                const int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
-                const int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
-                pass = nb >= 2 || nd >= 2;
-                sc[y * 64 + x] = 0;
+    if (cw <= 32) {
+        // 4 pixels per lane (one aligned word), 8 rows per pass; 16-bit SWAR fields (two pixels per register):
+        // bit 15 of ((a | H) - b) per field is set iff a >= b (all values < 2^15).
+        const int x4 = (lane & 7) * 4;
+        const uint32_t H = 0x80008000u, M8 = 0x00FF00FFu;
+        const uint32_t tp1 = (uint32_t)(minTh + 1) * 0x00010001u;
+        for (int yb = 0; yb < ch; yb += 8) {
+            const int y = yb + (lane >> 3);
+            uint32_t f = 0;   // bit i: pixel x4+i passes
+            if (y < ch) {
+                const uint8_t* tr = t0 + y * kWTileP + x4;
+                const uint32_t wv4 = *(const uint32_t*)tr;
+                const uint32_t wl = *(const uint32_t*)(tr - 4), wr = *(const uint32_t*)(tr + 4);
+                const uint32_t w0 = *(const uint32_t*)(tr + 3 * kWTileP), w8 = *(const uint32_t*)(tr - 3 * kWTileP);
+                const uint32_t w4 = __builtin_amdgcn_alignbyte(wr, wv4, 3), w12 = __builtin_amdgcn_alignbyte(wv4, wl, 1);
+                uint32_t pass[2];
+#pragma unroll
+                for (int par = 0; par < 2; par++) {
+                    const int shf = par * 8;
+                    const uint32_t v2 = (wv4 >> shf) & M8;
+                    const uint32_t vH = v2 | H, vt = v2 + tp1;
+                    const uint32_t a0 = (w0 >> shf) & M8, a8 = (w8 >> shf) & M8, a4 = (w4 >> shf) & M8, a12 = (w12 >> shf) & M8;
+                    const uint32_t b0 = (a0 | H) - vt, b8 = (a8 | H) - vt, b4 = (a4 | H) - vt, b12 = (a12 | H) - vt;       // p > v + t
+                    const uint32_t d0 = vH - (a0 + tp1), d8 = vH - (a8 + tp1), d4 = vH - (a4 + tp1), d12 = vH - (a12 + tp1);   // p < v - t
+                    pass[par] = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & H;
+                }
+                f = ((pass[0] >> 15) & 1u) | ((pass[1] >> 14) & 2u) | ((pass[0] >> 29) & 4u) | ((pass[1] >> 28) & 8u);
+                const int nvalid = cw - x4;   // pixels of this word inside the cell
+                f &= nvalid >= 4 ? 15u : (nvalid > 0 ? (1u << nvalid) - 1u : 0u);
+                if (nvalid > 0) *(uint32_t*)(sc + y * 64 + x4) = 0u;
             }
-            const unsigned long long m = __ballot(pass);
-            if (pass) work[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x);
-            nwork += __popcll(m);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot(f & 2u), m2 = __ballot(f & 4u), m3 = __ballot(f & 8u);
+            int pos = nwork + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const int q0 = y * 64 + x4;
+            if (f & 1u) work[pos++] = (uint16_t)q0;
+            if (f & 2u) work[pos++] = (uint16_t)(q0 + 1);
+            if (f & 4u) work[pos++] = (uint16_t)(q0 + 2);
+            if (f & 8u) work[pos++] = (uint16_t)(q0 + 3);
+            nwork += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
         }
     } else {
         const int npx = cw * ch;
@@ -524,9 +616,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                 const int v = t[0];
                 const int hi = v + minTh, lo = v - minTh;
                 const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
-                const int nb = (p0 > hi) + (p4 > hi) + (p8 > hi) + (p12 > hi);
-                const int nd = (p0 < lo) + (p4 < lo) + (p8 < lo) + (p12 < lo);
-                pass = nb >= 2 || nd >= 2;
+                pass = (((p0 > hi) || (p8 > hi)) && ((p4 > hi) || (p12 > hi))) || (((p0 < lo) || (p8 < lo)) && ((p4 < lo) || (p12 < lo)));
                 sc[y * 64 + x] = 0;
             }
             const unsigned long long m = __ballot(pass);
@@ -535,12 +625,14 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
         }
     }
     __builtin_amdgcn_wave_barrier();
+    FSTAMP(1);
     // B. exact scores of the survivors (others stay 0 = "not a corner at minTh")
     for (int i = lane; i < nwork; i += 64) {
         const int q = work[i], y = q >> 6, x = q & 63;
         sc[q] = (uint8_t)fast_score3<kWTileP>(t0 + y * kWTileP + x);
     }
     __builtin_amdgcn_wave_barrier();
+    FSTAMP(2);
     // C. NMS over the worklist (strictly greater than the 8 in-cell neighbours), ini/min vote
     unsigned long long keepmask = 0;   // bit it: this lane's worklist entry of pass `it` survives
     bool hit_ini = false;
@@ -565,8 +657,8 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
         }
     }
     const int th = __any(hit_ini) ? iniTh : minTh;
+    FSTAMP(3);
     // D. ordered output (worklist order is row-major)
-    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
     int running = 0;
     {
         int it = 0;
@@ -583,15 +675,19 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
             const unsigned long long m = __ballot(flag);
             if (flag) {
                 const int slot = running + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < g.cell_cap) out[slot] = pack_xys(cj * g.wCell + x + 3, ci * g.hCell + y + 3, s);
+                if (slot < cell_cap) out[slot] = pack_xys(cj * wCellOut + x + 3, ci * hCellOut + y + 3, s);
             }
             running += __popcll(m);
         }
     }
     if (lane == 0) {
-        if (running > g.cell_cap) { atomicOr(c.status, 1); running = g.cell_cap; }
+        if (running > cell_cap) { atomicOr(c.status, 1); running = cell_cap; }
         *count_out = running;
     }
+    FSTAMP(4);
+#ifdef OSLAM_FAST_PROFILE
+    if (lane == 0) { atomicAdd(&c.dbg[5], (unsigned long long)nwork); atomicAdd(&c.dbg[6], 1ull); atomicAdd(&c.dbg[7], (unsigned long long)(cw * ch)); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

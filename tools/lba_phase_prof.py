@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_slam_amd import LocalBundleAdjuster, synth
 q = synth.make_lba_problem(1234, K_local=20, K_fixed=20, P=4000)
 ba = LocalBundleAdjuster(max_keyframes=128, max_points=16384, max_edges=131072)

@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_slam_amd import PoseOptimizer, LocalBundleAdjuster, synth
 from oracle import oracle_py as O
 B, N = 256, 1000

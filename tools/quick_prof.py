@@ -1,6 +1,6 @@
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_slam_amd import ORBextractor, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 W, H, NF = (640, 480, 1000) if len(sys.argv) < 3 or sys.argv[2] == 'tum' else (1241, 376, 2000)
