@@ -283,6 +283,21 @@ def main():
                 t1 = time.perf_counter()
                 O.local_bundle_adjustment(*lba_args)
                 extras["lba_S5_cpu_oracle_ms"] = round((time.perf_counter() - t1) * 1e3, 1)
+            # end-to-end tracking + local-BA harness (object_slam_amd/e2e.py), single sequence, host-driven
+            from object_slam_amd import e2e
+            ef, eo = synth.make_stream(64, W, H, seed=11)
+            ecam = (FX, FY, CX, CY, BF)
+            hb = e2e.HipBackend(W, H, device=local_rank)
+            e2e.run_sequence(hb, ef[:4], eo[:4], ecam, Z0)
+            trk, edt, eate = e2e.run_sequence(hb, ef, eo, ecam, Z0)
+            extras["e2e_tracking_localBA_frames_per_s"] = round(len(ef) / edt, 1)
+            extras["e2e_ate_rmse_m"] = round(eate, 6)
+            extras["e2e_config"] = "S1-shaped synthetic RGB-D, 64 frames 640x480, 1 sequence, %d keyframes, %d local BAs (harness: e2e.py)" % (len(trk.kfs), trk.stats["lba_calls"])
+            if not args.no_cpu_baseline:
+                from oracle.oracle_backend import OracleBackend
+                trc, cdt, cate = e2e.run_sequence(OracleBackend(W, H), ef[:24], eo[:24], ecam, Z0)
+                extras["e2e_cpu_oracle_frames_per_s"] = round(24 / cdt, 2)
+                extras["e2e_cpu_oracle_ate_rmse_m"] = round(cate, 6)
         except Exception as ex:   # never let the side measurements break the headline line
             extras = {"error": repr(ex)}
 
