@@ -59,6 +59,10 @@ struct LbaProblem {
     float* poses_out; float* points_out; uint8_t* erase; int* stats;   // stats[4]: it1, trials1, it2, trials2
     const volatile int* stop; // may be NULL
     float K5[5];              // fx, fy, cx, cy, bf (one sensor per window)
+    // schedule: LocalBundleAdjustment = {5, 10, 2 stages, robust, Huber sqrt(5.991)/sqrt(7.815)} (src/Optimizer.cc:569-707);
+    // BundleAdjustment = {nIterations, -, 1 stage, bRobust, Huber sqrt(5.99)/sqrt(7.815)} (src/Optimizer.cc:85-188)
+    int iters0, iters1, nstages, robust0;
+    float delta_mono, delta_stereo;
 };
 
 struct LbaShared {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
 #endif
 
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
-    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
 
     // ---- setup ----
     if (tid == 0) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
     };
 
     bool early = stopped();   // reference :655-657
-    bool robust = true;
+    bool robust = pr.robust0 != 0;
 
     // residual pass (thread per point) at (poses Tp, points Xp): stores chi2 per active edge, returns robust sum
     auto eval = [&](const SE3* Tp, const double* Xp) -> double {
@@ -170,8 +174,8 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
         return F;
     };
 
-    for (int stage = 0; stage < 2 && !early; stage++) {
-        const int iters = stage == 0 ? 5 : 10;
+    for (int stage = 0; stage < pr.nstages && !early; stage++) {
+        const int iters = stage == 0 ? pr.iters0 : pr.iters1;
         double lambda = 0, ni = 2;
         bool ok = true;
         for (int iter = 0; iter < iters && !stopped() && ok; iter++) {
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
             if (stage == 0) st_its0++; else st_its1++;
             if (qmax == 10 || rho == 0) ok = false;
         }
-        if (stage == 0) {
+        if (stage == 0 && pr.nstages > 1) {
             if (stopped()) break;   // bDoMore = false (:664-666)
             // gate observations, drop the robust kernel (:672-702)
             for (int e = tid; e < E; e += kLbaThreads) {
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide
             if (pr.fixed[a]) w.blk[a] = -1;
             else { w.free_pose[nb] = a; w.blk[a] = nb++; }
         }
-        ct->stage = 0; ct->iter = 0; ct->qmax = 0; ct->need_lin = 1; ct->gate = 0; ct->done = 0; ct->ok2 = 1; ct->cur = 0; ct->robust = 1; ct->ok = 1;
+        ct->stage = 0; ct->iter = 0; ct->qmax = 0; ct->need_lin = 1; ct->gate = 0; ct->done = 0; ct->ok2 = 1; ct->cur = 0; ct->robust = pr.robust0; ct->ok = 1;
         ct->its[0] = ct->its[1] = ct->trials[0] = ct->trials[1] = 0;
         ct->nfree = nb; ct->n = 6 * nb;
         ct->lambda = 0; ct->ni = 2; ct->currentChi = 0; ct->rho = 0;
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(kWPt) void k_w_lin_pt(const LbaProblem* probs, LbaW
     const LbaCtrl* ct = w.ct;
     if (ct->done || !ct->need_lin) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
-    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
     const double* X = w_X(pr, ct->cur);
     const SE3* T = w.T + ct->cur * pr.K;
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(64) void k_w_lin_pose(const LbaProblem* probs, LbaW
     const int a = blockIdx.x, lane = threadIdx.x;
     if (a >= pr.K || w.blk[a] < 0) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
-    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
     const double* X = w_X(pr, ct->cur);
     const SE3 Ta = w.T[ct->cur * pr.K + a];
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWid
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
-    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
     const int tr = ct->cur ^ 1;
     const double* Xp = w_X(pr, tr);
@@ -1076,11 +1080,11 @@ __global__ __launch_bounds__(64) void k_w_ctrlB(const LbaProblem* probs, LbaWide
     ct->its[ct->stage]++;
     if (ct->qmax == 10 || rho == 0) ct->ok = 0;
     ct->iter++;
-    const int iters = ct->stage == 0 ? 5 : 10;
+    const int iters = ct->stage == 0 ? pr.iters0 : pr.iters1;
     const bool stop2 = pr.stop ? (*pr.stop != 0) : false;
     if (ct->iter < iters && !stop2 && ct->ok) { ct->need_lin = 1; return; }
     // stage finished
-    if (ct->stage == 0) {
+    if (ct->stage == 0 && pr.nstages > 1) {
         const bool stop3 = pr.stop ? (*pr.stop != 0) : false;
         if (stop3) { ct->done = 1; return; }   // bDoMore = false (:664-666)
         ct->stage = 1; ct->iter = 0; ct->ok = 1; ct->robust = 0; ct->need_lin = 1; ct->gate = 1;
@@ -1224,9 +1228,31 @@ volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h) { return h ? (volatile int
 
 // Host drop-in: gathers nothing (the caller flattens the graph), builds the point-major /
 // keyframe-major edge orders, uploads, runs, downloads.  Edge outputs are in the caller's order.
+static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                   const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                   const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
+                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo);
+
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                        const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                        const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4]) {
+    return lba_run(h, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out,
+                   erase, stats, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
+}
+
+int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                      const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                      const float K5[5], int nIterations, int bRobust, int use_stop_flag, float* poses_out, float* points_out) {
+    if (nIterations < 0) { set_error("nIterations < 0"); return OSLAM_E_INVALID; }
+    std::vector<uint8_t> erase(nE > 0 ? nE : 1);
+    return lba_run(h, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out,
+                   erase.data(), nullptr, nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
+}
+
+static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                   const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                   const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
+                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo) {
     if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase))) {
         set_error("NULL argument");
         return OSLAM_E_INVALID;
@@ -1281,6 +1307,7 @@ int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_
     pr.poses_out = s.poses_out; pr.points_out = s.points_out; pr.erase = s.erase; pr.stats = s.stats;
     pr.stop = use_stop_flag ? h->d_stop : nullptr;
     for (int i = 0; i < 5; i++) pr.K5[i] = K5[i];
+    pr.iters0 = iters0; pr.iters1 = iters1; pr.nstages = nstages; pr.robust0 = robust0; pr.delta_mono = delta_mono; pr.delta_stereo = delta_stereo;
     OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, &pr, sizeof(pr), hipMemcpyHostToDevice));
     if (!h->wide) {
         hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
@@ -1299,7 +1326,8 @@ int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_
         // worst case 15 iterations x 10 trials; slots past `done` return at once
         int slots_done = 0;
         *h->h_done = 0;
-        while (slots_done < 160) {
+        const int max_slots = (iters0 + (nstages > 1 ? iters1 : 0)) * 10 + 8;
+        while (slots_done < max_slots) {
             for (int sl = 0; sl < 4; sl++, slots_done++) {
                 hipLaunchKernelGGL(k_w_gate, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_lin_pt, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);

@@ -128,3 +128,18 @@ class LocalBundleAdjuster:
                                         ptr(ept), ptr(eobs), ptr(einv), ptr(K), int(use_stop_flag), ptr(pout), ptr(xout),
                                         ptr(erase), ptr(stats)))
         return pout.reshape(-1, 4, 4), xout, erase[:len(ekf)], tuple(int(v) for v in stats)
+
+    def BundleAdjustment(self, poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, nIterations=5, bRobust=True):
+        """Optimizer::BundleAdjustment (reference src/Optimizer.cc:49-237). Returns (poses_out, points_out)."""
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        fixed = np.ascontiguousarray(fixed, np.uint8)
+        points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        ekf = np.ascontiguousarray(edge_kf, np.int32)
+        ept = np.ascontiguousarray(edge_pt, np.int32)
+        eobs = np.ascontiguousarray(edge_obs, np.float32).reshape(-1, 3)
+        einv = np.ascontiguousarray(edge_invSigma2, np.float32)
+        K = np.ascontiguousarray(K5, np.float32)
+        pout, xout = np.zeros_like(poses), np.zeros_like(points)
+        check(self.L.oslam_ba_optimize(self.h, len(poses), ptr(poses), ptr(fixed), len(points), ptr(points), len(ekf), ptr(ekf), ptr(ept),
+                                       ptr(eobs), ptr(einv), ptr(K), int(nIterations), int(bRobust), 0, ptr(pout), ptr(xout)))
+        return pout.reshape(-1, 4, 4), xout

@@ -820,3 +820,33 @@ int PoseOptimization2(int N, const float* Tcw_in, const float* Xw, const float* 
     return nInitialCorrespondences - nBad;
 }
 }  // namespace oracle
+
+namespace oracle {
+// reference src/Optimizer.cc:49-237
+void BundleAdjustment(int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                      const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                      const float* K5, int nIterations, int bRobust, float* poses_out, float* points_out) {
+    Graph g;
+    g.cam = Camera{K5[0], K5[1], K5[2], K5[3], K5[4]};
+    for (int k = 0; k < nKF; k++) { g.poses.push_back(se3_from_cvmat(poses + 16 * k)); g.pose_fixed.push_back(fixed[k]); }
+    for (int p = 0; p < nP; p++) g.points.push_back({(double)points[3 * p], (double)points[3 * p + 1], (double)points[3 * p + 2]});
+    const float thHuber2D = sqrt(5.99);
+    const float thHuber3D = sqrt(7.815);
+    for (int i = 0; i < nE; i++) {
+        GraphEdge e;
+        memset(&e, 0, sizeof(e));
+        e.pose = edge_kf[i];
+        e.point = edge_pt[i];
+        e.stereo = !(edge_obs[3 * i + 2] < 0);
+        e.obs[0] = edge_obs[3 * i]; e.obs[1] = edge_obs[3 * i + 1]; e.obs[2] = e.stereo ? edge_obs[3 * i + 2] : 0;
+        e.info = edge_invSigma2[i];
+        e.robust = bRobust != 0;
+        e.delta = e.stereo ? thHuber3D : thHuber2D;
+        g.edges.push_back(e);
+    }
+    graph_optimize(g, nIterations, 0, nullptr);
+    for (int k = 0; k < nKF; k++) se3_to_cvmat(g.poses[k], poses_out + 16 * k);
+    for (int p = 0; p < nP; p++)
+        for (int c = 0; c < 3; c++) points_out[3 * p + c] = (float)g.points[p][c];
+}
+}  // namespace oracle

@@ -77,6 +77,10 @@ void LocalBundleAdjustment(int nKF, const float* poses, const uint8_t* fixed, in
                            const float* edge_invSigma2, const float* K5, const volatile int* stop, float* poses_out,
                            float* points_out, uint8_t* erase, int* stats /* [4] it1, trials1, it2, trials2 */);
 
+// Optimizer::BundleAdjustment, reference src/Optimizer.cc:49-237 (graph already gathered).
+void BundleAdjustment(int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                      const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                      const float* K5, int nIterations, int bRobust, float* poses_out, float* points_out);
 }  // namespace oracle
 
 namespace oracle {

@@ -206,3 +206,11 @@ int oo_fuse_search(int N, const KeyPoint* keysUn, const float* uRight, const uin
     return FuseSearch(f, q, M, invLevelSigma2, q_match, q_dist);
 }
 }
+
+extern "C" {
+void oo_bundle_adjustment(int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE, const int32_t* edge_kf,
+                          const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2, const float* K5, int nIterations,
+                          int bRobust, float* poses_out, float* points_out) {
+    BundleAdjustment(nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, nIterations, bRobust, poses_out, points_out);
+}
+}

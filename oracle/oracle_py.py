@@ -302,3 +302,15 @@ def fuse_search(keysUn, uRight, desc, bounds, queries, invLevelSigma2):
     n = L.oo_fuse_search(N, _p(keysUn), _p(uR), _p(np.ascontiguousarray(desc, np.uint8)), _p(np.asarray(bounds, np.float32)),
                          _p(np.ascontiguousarray(queries, QUERY_DTYPE)), M, _p(np.ascontiguousarray(invLevelSigma2, np.float32)), _p(qm), _p(qd))
     return n, qm[:M], qd[:M]
+
+
+def bundle_adjustment(poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_inv, K5, nIterations, bRobust):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    points = np.ascontiguousarray(points, np.float32)
+    ekf = np.ascontiguousarray(edge_kf, np.int32)
+    pout, xout = np.zeros_like(poses), np.zeros_like(points)
+    lib().oo_bundle_adjustment(len(poses), _p(poses), _p(np.ascontiguousarray(fixed, np.uint8)), len(points), _p(points), len(ekf), _p(ekf),
+                               _p(np.ascontiguousarray(edge_pt, np.int32)), _p(np.ascontiguousarray(edge_obs, np.float32)),
+                               _p(np.ascontiguousarray(edge_inv, np.float32)), _p(np.asarray(K5, np.float32)), int(nIterations), int(bRobust),
+                               _p(pout), _p(xout))
+    return pout.reshape(-1, 4, 4), xout

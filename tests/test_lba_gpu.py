@@ -62,3 +62,19 @@ def test_lba_stop_flag_and_errors(oracle, wide):
         big = synth.make_lba_problem(10, K_local=20, K_fixed=0, P=600)
         ba.LocalBundleAdjustment(big["poses"], big["fixed"], big["points"], big["edge_kf"], big["edge_pt"], big["edge_obs"], big["edge_invSigma2"], big["K"])
     ba.close()
+
+
+@pytest.mark.parametrize("wide,robust,its", [(True, True, 5), (False, False, 20), (True, False, 10)])
+def test_bundle_adjustment_matches_oracle(oracle, wide, robust, its):
+    """Optimizer::BundleAdjustment (one optimize(n), optional Huber sqrt(5.99)/sqrt(7.815))."""
+    # without the Huber kernel gross outliers make the problem chaotic (both implementations diverge
+    # on the affected points), so the non-robust runs use inlier-only data
+    q = synth.make_lba_problem(21, K_local=8, K_fixed=0, P=400, outlier_frac=0.02 if robust else 0.0)
+    fixed = np.zeros(8, np.uint8); fixed[0] = 1
+    ba = LocalBundleAdjuster(max_keyframes=16, max_points=1024, max_edges=8192)
+    ba.set_mode(wide)
+    po, xo = ba.BundleAdjustment(q["poses"], fixed, q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], its, robust)
+    opo, oxo = oracle.bundle_adjustment(q["poses"], fixed, q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], its, robust)
+    assert np.abs(po - opo).max() / max(1.0, np.abs(opo).max()) <= RTOL
+    assert np.abs(xo - oxo).max() / max(1.0, np.abs(oxo).max()) <= RTOL
+    ba.close()
