@@ -313,6 +313,15 @@ int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_
                        float* poses_out, float* points_out, uint8_t* erase,
                        int32_t stats[4] /* iterations/trials of stage 1 and 2; may be NULL */);
 
+/* Batch of independent local-BA problems (one workgroup each, ONE launch): the batch-of-sequences layout. */
+typedef struct oslam_lba_problem {
+    int32_t nKF; const float* poses; const uint8_t* fixed;
+    int32_t nP; const float* points;
+    int32_t nE; const int32_t* edge_kf; const int32_t* edge_pt; const float* edge_obs; const float* edge_invSigma2;
+    float* poses_out; float* points_out; uint8_t* erase; int32_t* stats;   /* stats may be NULL */
+} oslam_lba_problem_t;
+int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* probs, const float K5[5]);
+
 /* Optimizer::BundleAdjustment (include/Optimizer.h:38, src/Optimizer.cc:49-237) on the same flattened graph:
  * one optimize(nIterations), Huber sqrt(5.99) / sqrt(7.815) only if bRobust, no gating, no erase list.
  * fixed[k] = 1 for the keyframe with mnId == 0 (:79). */

@@ -1137,6 +1137,8 @@ struct oslam_lba {
     LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
     double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
     int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
+    std::vector<LbaProblem> host_probs;           // batch mode: prepared problems
+    std::vector<std::vector<int>> orders;         // batch mode: edge permutation of every slot
     int* h_stop = nullptr;       // pinned, device-visible stop flag
     int* d_stop = nullptr;
     size_t lds = 0;
@@ -1231,7 +1233,7 @@ volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h) { return h ? (volatile int
 static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                    const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                    const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
-                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo);
+                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo, int slot = 0, int phase = 2);
 
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                        const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
@@ -1252,7 +1254,7 @@ int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t
 static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                    const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                    const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
-                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo) {
+                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo, int slot, int phase) {
     if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase))) {
         set_error("NULL argument");
         return OSLAM_E_INVALID;
@@ -1290,7 +1292,7 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
             for (int j = i + 1; j < pt_start[p + 1]; j++)
                 if (ekf[i] == ekf[j]) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
     }
-    oslam_lba::Slot& s = h->slots[0];
+    oslam_lba::Slot& s = h->slots[slot];
 #define UP(dst, src, bytes) if ((bytes) > 0) OSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
     UP(s.poses, poses, (size_t)nKF * 64); UP(s.fixed, fixed, (size_t)nKF); UP(s.points, points, (size_t)nP * 12);
     UP(s.e_kf, ekf.data(), (size_t)nE * 4); UP(s.e_pt, ept.data(), (size_t)nE * 4); UP(s.e_obs, eobs.data(), (size_t)nE * 12);
@@ -1308,6 +1310,12 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
     pr.stop = use_stop_flag ? h->d_stop : nullptr;
     for (int i = 0; i < 5; i++) pr.K5[i] = K5[i];
     pr.iters0 = iters0; pr.iters1 = iters1; pr.nstages = nstages; pr.robust0 = robust0; pr.delta_mono = delta_mono; pr.delta_stereo = delta_stereo;
+    if (phase == 0) {   // batch mode: keep the prepared problem, the caller launches all slots together
+        if ((int)h->host_probs.size() <= slot) { h->host_probs.resize(slot + 1); h->orders.resize(slot + 1); }
+        h->host_probs[slot] = pr;
+        h->orders[slot] = order;
+        return OSLAM_OK;
+    }
     OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, &pr, sizeof(pr), hipMemcpyHostToDevice));
     if (!h->wide) {
         hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
@@ -1358,6 +1366,41 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
     if (stats) {
         OSLAM_HIP_CHECK(hipMemcpy(st, s.stats, sizeof(st), hipMemcpyDeviceToHost));
         for (int i = 0; i < 4; i++) stats[i] = st[i];
+    }
+    return OSLAM_OK;
+}
+
+
+// Batch of independent keyframe windows (the batch-of-sequences layout): every problem is staged into its
+// own slot, then ONE launch of k_lba runs one workgroup per problem.
+int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* probs, const float K5[5]) {
+    if (!h || !probs || !K5) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (n < 1 || n > h->max_batch) { set_error("batch %d outside [1,%d]", n, h->max_batch); return OSLAM_E_INVALID; }
+    for (int i = 0; i < n; i++) {
+        const oslam_lba_problem_t& q = probs[i];
+        int rc = lba_run(h, q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, K5, 0, q.poses_out,
+                         q.points_out, q.erase, nullptr, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815), i, 0);
+        if (rc) return rc;
+    }
+    OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    for (int i = 0; i < n; i++) {
+        const oslam_lba_problem_t& q = probs[i];
+        oslam_lba::Slot& s = h->slots[i];
+        OSLAM_HIP_CHECK(hipMemcpy(q.poses_out, s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost));
+        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpy(q.points_out, s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost));
+        if (q.nE > 0) {
+            std::vector<uint8_t> er(q.nE);
+            OSLAM_HIP_CHECK(hipMemcpy(er.data(), s.erase, (size_t)q.nE, hipMemcpyDeviceToHost));
+            for (int e = 0; e < q.nE; e++) q.erase[h->orders[i][e]] = er[e];
+        }
+        if (q.stats) {
+            int st[16];
+            OSLAM_HIP_CHECK(hipMemcpy(st, s.stats, sizeof(st), hipMemcpyDeviceToHost));
+            for (int k = 0; k < 4; k++) q.stats[k] = st[k];
+        }
     }
     return OSLAM_OK;
 }

@@ -86,6 +86,12 @@ class PoseOptimizer:
         return a.value, b.value, c.value, d.value
 
 
+class LbaProblem(C.Structure):
+    _fields_ = [("nKF", C.c_int32), ("poses", C.c_void_p), ("fixed", C.c_void_p), ("nP", C.c_int32), ("points", C.c_void_p),
+                ("nE", C.c_int32), ("edge_kf", C.c_void_p), ("edge_pt", C.c_void_p), ("edge_obs", C.c_void_p), ("edge_invSigma2", C.c_void_p),
+                ("poses_out", C.c_void_p), ("points_out", C.c_void_p), ("erase", C.c_void_p), ("stats", C.c_void_p)]
+
+
 class LocalBundleAdjuster:
     """Optimizer::LocalBundleAdjustment (reference src/Optimizer.cc:453-778) on a flattened graph."""
 
@@ -143,3 +149,30 @@ class LocalBundleAdjuster:
         check(self.L.oslam_ba_optimize(self.h, len(poses), ptr(poses), ptr(fixed), len(points), ptr(points), len(ekf), ptr(ekf), ptr(ept),
                                        ptr(eobs), ptr(einv), ptr(K), int(nIterations), int(bRobust), 0, ptr(pout), ptr(xout)))
         return pout.reshape(-1, 4, 4), xout
+
+    def LocalBundleAdjustmentBatch(self, problems, K5):
+        """Independent keyframe windows in ONE launch (one workgroup per problem). `problems`: list of dicts with the
+        keys of synth.make_lba_problem. Returns a list of (poses_out, points_out, erase, stats)."""
+        n = len(problems)
+        arr = (LbaProblem * n)()
+        keep, outs = [], []
+        for i, q in enumerate(problems):
+            poses = np.ascontiguousarray(q["poses"], np.float32).reshape(-1, 16)
+            fixed = np.ascontiguousarray(q["fixed"], np.uint8)
+            points = np.ascontiguousarray(q["points"], np.float32).reshape(-1, 3)
+            ekf = np.ascontiguousarray(q["edge_kf"], np.int32)
+            ept = np.ascontiguousarray(q["edge_pt"], np.int32)
+            eobs = np.ascontiguousarray(q["edge_obs"], np.float32).reshape(-1, 3)
+            einv = np.ascontiguousarray(q["edge_invSigma2"], np.float32)
+            pout, xout = np.zeros_like(poses), np.zeros_like(points)
+            erase, stats = np.zeros(max(len(ekf), 1), np.uint8), np.zeros(4, np.int32)
+            keep.append((poses, fixed, points, ekf, ept, eobs, einv))
+            outs.append((pout, xout, erase, stats))
+            a = arr[i]
+            a.nKF, a.poses, a.fixed = len(poses), poses.ctypes.data, fixed.ctypes.data
+            a.nP, a.points = len(points), points.ctypes.data
+            a.nE, a.edge_kf, a.edge_pt, a.edge_obs, a.edge_invSigma2 = len(ekf), ekf.ctypes.data, ept.ctypes.data, eobs.ctypes.data, einv.ctypes.data
+            a.poses_out, a.points_out, a.erase, a.stats = pout.ctypes.data, xout.ctypes.data, erase.ctypes.data, stats.ctypes.data
+        K = np.ascontiguousarray(K5, np.float32)
+        check(self.L.oslam_lba_optimize_batch(self.h, n, arr, ptr(K)))
+        return [(po.reshape(-1, 4, 4), xo, er[:len(k[3])], tuple(int(v) for v in st)) for (po, xo, er, st), k in zip(outs, keep)]

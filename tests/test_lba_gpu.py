@@ -78,3 +78,14 @@ def test_bundle_adjustment_matches_oracle(oracle, wide, robust, its):
     assert np.abs(po - opo).max() / max(1.0, np.abs(opo).max()) <= RTOL
     assert np.abs(xo - oxo).max() / max(1.0, np.abs(oxo).max()) <= RTOL
     ba.close()
+
+
+def test_lba_batch_of_windows(oracle):
+    """Batch-of-sequences layout: 12 independent windows of different sizes in one launch."""
+    probs = [synth.make_lba_problem(40 + i, K_local=3 + i % 5, K_fixed=i % 3, P=100 + 40 * i) for i in range(12)]
+    ba = LocalBundleAdjuster(max_keyframes=16, max_points=1024, max_edges=8192, max_batch=12)
+    res = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])
+    for q, r in zip(probs, res):
+        o = oracle.local_bundle_adjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+        _compare(r, o)
+    ba.close()
