@@ -217,6 +217,37 @@ int oslam_match_fuse_batch_device(oslam_matcher_t* h, const oslam_match_frames_t
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);
 
 /* ------------------------------------------------------------------------------------------
+ * BoW-guided matchers: ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (src/ORBmatcher.cc:159-288)
+ * and ORBmatcher::SearchForTriangulation (:657-823).  DBoW2 and its vocabulary are not in the reference tree:
+ * the DBoW2::FeatureVector of each side (node id -> keypoint indices) is an INPUT.  Side 1 is the flat list the
+ * reference iterates (std::map order: node ascending, indices in vector order); side 2 is CSR over its sorted,
+ * unique node ids.  Host pointers, one pair per call.
+ * SearchByBoW: side1.flag[i] = pKF map point exists && !isBad(); match_f[k] = keyframe keypoint whose map point is
+ *   written to vpMapPointMatches[k] (-1 none, -2 removed by the rotation check); nmatches = return value.
+ *   The claim order (:211-212: a frame keypoint matched by an earlier keyframe keypoint is skipped) is reproduced.
+ * SearchForTriangulation: side1.flag[i] = pKF1->GetMapPoint(i) != NULL (skipped); side2.has_mp likewise;
+ *   F12 row-major 3x3 (cv::Mat CV_32F), (ex, ey) = epipole in image 2 (:663-670); match12[i] = keypoint of KF2 or -1.
+ *   (vbMatched2 is never set in the reference, :722 — queries are independent and so they are here.)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct oslam_bow oslam_bow_t;
+typedef struct oslam_bow_side1 {
+    int32_t N; const oslam_keypoint_t* keys; const uint8_t* desc; const float* uRight /* NULL = all -1 */; const uint8_t* flag;
+    int32_t nq; const int32_t* q_idx; const uint32_t* q_node;
+} oslam_bow_side1_t;
+typedef struct oslam_bow_side2 {
+    int32_t N; const oslam_keypoint_t* keys; const uint8_t* desc; const float* uRight /* NULL = all -1 */; const uint8_t* has_mp /* NULL = none */;
+    int32_t nNodes; const uint32_t* nodes; const int32_t* start; const int32_t* items;
+} oslam_bow_side2_t;
+int oslam_bow_create(oslam_bow_t** out, int max_keypoints /* <= 2400 */, int device);
+void oslam_bow_destroy(oslam_bow_t* h);
+int oslam_match_search_by_bow(oslam_bow_t* h, const oslam_bow_side1_t* kf, const oslam_bow_side2_t* frame, float nnratio,
+                              int checkOri, int32_t* match_f, int32_t* nmatches);
+int oslam_match_search_for_triangulation(oslam_bow_t* h, const oslam_bow_side1_t* kf1, const oslam_bow_side2_t* kf2,
+                                         const float F12[9], float ex, float ey, const float* scaleFactors,
+                                         const float* levelSigma2, int nlevels, int bOnlyStereo, int checkOri,
+                                         int32_t* match12, int32_t* nmatches);
+
+/* ------------------------------------------------------------------------------------------
  * Frame::ComputeStereoMatches (src/Frame.cc:706-880): row-band Hamming search of left keypoints in the
  * right image (levels +-1, u in [uL - bf/b, uL], best < (TH_HIGH+TH_LOW)/2), 11-shift 11x11 SAD on the
  * left keypoint's pyramid level, parabola sub-pixel fit, depth = bf/disparity, rejection of matches

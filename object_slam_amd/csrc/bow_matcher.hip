@@ -1,0 +1,303 @@
+// gfx950 BoW-guided matchers: ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (reference
+// src/ORBmatcher.cc:159-288) and ORBmatcher::SearchForTriangulation (:657-823).  The DBoW2 vocabulary
+// is not part of the reference tree, so the FeatureVectors are inputs: side 1 as a flat list in the
+// std::map iteration order (node ascending, indices in vector order), side 2 as CSR over its sorted
+// node ids.  One 1024-thread workgroup per keyframe/frame pair; side-2 descriptors live in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace oslam {
+
+constexpr int kBowThreads = 1024;
+constexpr int kBowMaxKps = 2400;
+constexpr int kBowHisto = 30;
+
+struct BowCtx {
+    int mode;   // 0 SearchByBoW, 1 SearchForTriangulation
+    int nq; const int* q_idx1; const uint32_t* q_node;
+    int N1; const oslam_keypoint_t* keys1; const uint8_t* desc1; const float* uRight1; const uint8_t* flag1;
+    int N2; const oslam_keypoint_t* keys2; const uint8_t* desc2; const float* uRight2; const uint8_t* has_mp2;
+    int nNodes; const uint32_t* nodes; const int* start; const int* items;
+    float nnratio; int checkOri; int bOnlyStereo;
+    float F12[9], ex, ey, scale[OSLAM_MAX_LEVELS], sigma2[OSLAM_MAX_LEVELS];
+    int* out; int* nmatches; int* q_best;   // q_best [nq] scratch: accepted side-2 index per query or -1
+};
+
+__device__ __forceinline__ int bow_find_node(const BowCtx& c, uint32_t node) {
+    int lo = 0, hi = c.nNodes;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c.nodes[mid] < node) lo = mid + 1; else hi = mid;
+    }
+    return (lo < c.nNodes && c.nodes[lo] == node) ? lo : -1;
+}
+
+__global__ __launch_bounds__(kBowThreads) void k_search_bow(BowCtx c, int ncap) {
+    const int tid = threadIdx.x;
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint32_t* s_desc = (uint32_t*)smem;               // [ncap][8] side-2 descriptors
+    int* s_Bcur = (int*)(s_desc + (size_t)ncap * 8);  // [ncap]
+    int* s_Bprev = s_Bcur + ncap;                     // [ncap]
+    __shared__ int s_hist[kBowHisto], s_changed, s_nm, s_ind[3];
+    const int N2 = c.N2, nq = c.nq;
+    if (N2 > ncap || N2 < 0 || nq < 0) {
+        if (tid == 0) *c.nmatches = -1;
+        return;
+    }
+    const uint32_t* g2 = (const uint32_t*)c.desc2;
+    for (int i = tid; i < N2 * 8; i += kBowThreads) s_desc[i] = g2[i];
+    for (int i = tid; i < N2; i += kBowThreads) s_Bprev[i] = 0x7fffffff;
+    if (c.mode == 0) for (int i = tid; i < N2; i += kBowThreads) c.out[i] = -1;
+    else for (int i = tid; i < c.N1; i += kBowThreads) c.out[i] = -1;
+    __syncthreads();
+
+    const int maxit = c.mode == 0 ? nq + 2 : 1;
+    for (int it = 0; it < maxit; it++) {
+        for (int i = tid; i < N2; i += kBowThreads) s_Bcur[i] = 0x7fffffff;
+        if (tid == 0) s_changed = 0;
+        __syncthreads();
+        for (int q = tid; q < nq; q += kBowThreads) {
+            const int idx1 = c.q_idx1[q];
+            int best = -1;
+            bool ok = c.mode == 0 ? (c.flag1[idx1] != 0) : (c.flag1[idx1] == 0);
+            const bool bStereo1 = c.mode == 1 && c.uRight1[idx1] >= 0;
+            if (c.mode == 1 && c.bOnlyStereo && !bStereo1) ok = false;
+            const int nd = ok ? bow_find_node(c, c.q_node[q]) : -1;
+            if (nd >= 0) {
+                uint32_t qd[8];
+                const uint32_t* qp = (const uint32_t*)(c.desc1 + (size_t)idx1 * 32);
+#pragma unroll
+                for (int w = 0; w < 8; w++) qd[w] = qp[w];
+                if (c.mode == 0) {
+                    int bestDist1 = 256, bestDist2 = 256;
+                    for (int t = c.start[nd]; t < c.start[nd + 1]; t++) {
+                        const int k = c.items[t];
+                        if (s_Bprev[k] < q) continue;   // vpMapPointMatches[realIdxF] already set (:211-212)
+                        const uint32_t* d = s_desc + k * 8;
+                        int dist = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ d[w]);
+                        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; best = k; }
+                        else if (dist < bestDist2) bestDist2 = dist;
+                    }
+                    if (!(bestDist1 <= 50 && (float)bestDist1 < c.nnratio * (float)bestDist2)) best = -1;
+                } else {
+                    const oslam_keypoint_t kp1 = c.keys1[idx1];
+                    // epipolar line l = x1' F12 (:142-145)
+                    const float la = kp1.x * c.F12[0] + kp1.y * c.F12[3] + c.F12[6];
+                    const float lb = kp1.x * c.F12[1] + kp1.y * c.F12[4] + c.F12[7];
+                    const float lc = kp1.x * c.F12[2] + kp1.y * c.F12[5] + c.F12[8];
+                    const float den = la * la + lb * lb;
+                    int bestDist = 50;
+                    for (int t = c.start[nd]; t < c.start[nd + 1]; t++) {
+                        const int k = c.items[t];
+                        if (c.has_mp2[k]) continue;
+                        const bool bStereo2 = c.uRight2[k] >= 0;
+                        if (c.bOnlyStereo && !bStereo2) continue;
+                        const uint32_t* d = s_desc + k * 8;
+                        int dist = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dist += __popc(qd[w] ^ d[w]);
+                        if (dist > 50 || dist > bestDist) continue;
+                        const oslam_keypoint_t kp2 = c.keys2[k];
+                        if (!bStereo1 && !bStereo2) {
+                            const float dx = c.ex - kp2.x, dy = c.ey - kp2.y;
+                            if (dx * dx + dy * dy < 100 * c.scale[kp2.octave]) continue;
+                        }
+                        const float num = la * kp2.x + lb * kp2.y + lc;
+                        if (den == 0) continue;
+                        const float dsqr = __fdiv_rn(num * num, den);
+                        if ((double)dsqr < 3.84 * (double)c.sigma2[kp2.octave]) { best = k; bestDist = dist; }
+                    }
+                }
+            }
+            c.q_best[q] = best;
+            if (c.mode == 0 && best >= 0) atomicMin(&s_Bcur[best], q);
+        }
+        __syncthreads();
+        int diff = 0;
+        for (int i = tid; i < N2; i += kBowThreads) diff |= (s_Bcur[i] != s_Bprev[i]);
+        if (diff) s_changed = 1;
+        __syncthreads();
+        const int changed = s_changed;
+        __syncthreads();
+        if (!changed || c.mode == 1) break;
+        { int* t = s_Bcur; s_Bcur = s_Bprev; s_Bprev = t; }
+    }
+
+    // results + rotation consistency (:264-283 / :785-805)
+    if (tid < kBowHisto) s_hist[tid] = 0;
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    const float factor = 1.0f / kBowHisto;
+    int local = 0;
+    for (int q = tid; q < nq; q += kBowThreads) {
+        const int k = c.q_best[q];
+        if (k < 0) continue;
+        local++;
+        const int idx1 = c.q_idx1[q];
+        if (c.mode == 0) c.out[k] = idx1; else c.out[idx1] = k;
+        if (c.checkOri) {
+            float rot = c.keys1[idx1].angle - c.keys2[k].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == kBowHisto) bin = 0;
+            atomicAdd(&s_hist[bin], 1);
+        }
+    }
+    if (local) atomicAdd(&s_nm, local);
+    __syncthreads();
+    if (c.checkOri) {
+        if (tid == 0) {
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < kBowHisto; i++) {
+                const int s = s_hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { ind3 = -1; }
+            s_ind[0] = ind1; s_ind[1] = ind2; s_ind[2] = ind3;
+        }
+        __syncthreads();
+        int removed = 0;
+        for (int q = tid; q < nq; q += kBowThreads) {
+            const int k = c.q_best[q];
+            if (k < 0) continue;
+            const int idx1 = c.q_idx1[q];
+            float rot = c.keys1[idx1].angle - c.keys2[k].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == kBowHisto) bin = 0;
+            if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) {
+                removed++;
+                if (c.mode == 0) c.out[k] = -2; else c.out[idx1] = -1;
+            }
+        }
+        if (removed) atomicSub(&s_nm, removed);
+        __syncthreads();
+    }
+    if (tid == 0) *c.nmatches = s_nm;
+}
+
+}  // namespace oslam
+
+using namespace oslam;
+
+struct oslam_bow {
+    int device = 0, max_kps = 0;
+    size_t lds = 0;
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf q_idx1, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm;
+};
+
+static int bow_ensure(oslam_bow::Buf& b, size_t bytes) {
+    if (b.p && bytes <= b.cap) return OSLAM_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = bytes + bytes / 2 + 256;
+    OSLAM_HIP_CHECK(hipMalloc(&b.p, b.cap));
+    return OSLAM_OK;
+}
+static int bow_up(oslam_bow::Buf& b, const void* src, size_t bytes) {
+    int rc = bow_ensure(b, bytes ? bytes : 4);
+    if (rc) return rc;
+    if (bytes && src) OSLAM_HIP_CHECK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return OSLAM_OK;
+}
+
+extern "C" {
+
+void oslam_bow_destroy(oslam_bow_t* h) {
+    if (!h) return;
+    oslam_bow::Buf* bs[] = {&h->q_idx1, &h->q_node, &h->keys1, &h->desc1, &h->ur1, &h->flag1, &h->keys2, &h->desc2, &h->ur2, &h->mp2,
+                            &h->nodes, &h->start, &h->items, &h->out, &h->qbest, &h->nm};
+    for (auto* b : bs)
+        if (b->p) (void)hipFree(b->p);
+    delete h;
+}
+
+int oslam_bow_create(oslam_bow_t** out, int max_keypoints, int device) {
+    if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
+    *out = nullptr;
+    if (max_keypoints < 1 || max_keypoints > kBowMaxKps) { set_error("oslam_bow_create: max_keypoints must be in [1,%d]", kBowMaxKps); return OSLAM_E_INVALID; }
+    int ndev = oslam_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible: the gfx950 BoW matchers have no CPU fallback"); return OSLAM_E_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(device));
+    oslam_bow* h = new oslam_bow();
+    h->device = device; h->max_kps = max_keypoints;
+    h->lds = (size_t)max_keypoints * 40 + 64;
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_search_bow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    *out = h;
+    return OSLAM_OK;
+}
+
+static int bow_run(oslam_bow_t* h, int mode, const oslam_bow_side1_t* s1, const oslam_bow_side2_t* s2, float nnratio, int checkOri,
+                   const float* F12, float ex, float ey, const float* scaleFactors, const float* levelSigma2, int nlevels, int bOnlyStereo,
+                   int32_t* out, int32_t* nmatches) {
+    if (!h || !s1 || !s2 || !out || !nmatches) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (s1->N < 0 || s2->N < 0 || s1->nq < 0 || s2->nNodes < 0 || s2->N > h->max_kps || s1->N > 65536 * 16) { set_error("keypoint counts exceed capacity %d", h->max_kps); return OSLAM_E_CAPACITY; }
+    for (int q = 0; q < s1->nq; q++)
+        if (s1->q_idx[q] < 0 || s1->q_idx[q] >= s1->N) { set_error("side-1 index out of range"); return OSLAM_E_INVALID; }
+    const int nitems = s2->nNodes ? s2->start[s2->nNodes] : 0;
+    for (int i = 0; i < nitems; i++)
+        if (s2->items[i] < 0 || s2->items[i] >= s2->N) { set_error("side-2 index out of range"); return OSLAM_E_INVALID; }
+    for (int i = 1; i < s2->nNodes; i++)
+        if (!(s2->nodes[i - 1] < s2->nodes[i])) { set_error("side-2 node ids must be strictly ascending"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    int rc;
+    std::vector<float> negs((size_t)std::max(std::max(s1->N, s2->N), 1), -1.0f);
+    std::vector<uint8_t> zeros((size_t)std::max(std::max(s1->N, s2->N), 1), 0);
+    if ((rc = bow_up(h->q_idx1, s1->q_idx, (size_t)s1->nq * 4)) || (rc = bow_up(h->q_node, s1->q_node, (size_t)s1->nq * 4)) ||
+        (rc = bow_up(h->keys1, s1->keys, (size_t)s1->N * sizeof(oslam_keypoint_t))) || (rc = bow_up(h->desc1, s1->desc, (size_t)s1->N * 32)) ||
+        (rc = bow_up(h->ur1, s1->uRight ? s1->uRight : negs.data(), (size_t)s1->N * 4)) || (rc = bow_up(h->flag1, s1->flag ? s1->flag : zeros.data(), (size_t)s1->N)) ||
+        (rc = bow_up(h->keys2, s2->keys, (size_t)s2->N * sizeof(oslam_keypoint_t))) || (rc = bow_up(h->desc2, s2->desc, (size_t)s2->N * 32)) ||
+        (rc = bow_up(h->ur2, s2->uRight ? s2->uRight : negs.data(), (size_t)s2->N * 4)) || (rc = bow_up(h->mp2, s2->has_mp ? s2->has_mp : zeros.data(), (size_t)s2->N)) ||
+        (rc = bow_up(h->nodes, s2->nodes, (size_t)s2->nNodes * 4)) || (rc = bow_up(h->start, s2->start, (size_t)(s2->nNodes + 1) * 4)) ||
+        (rc = bow_up(h->items, s2->items, (size_t)nitems * 4)) || (rc = bow_ensure(h->out, (size_t)std::max(std::max(s1->N, s2->N), 1) * 4)) ||
+        (rc = bow_ensure(h->qbest, (size_t)std::max(s1->nq, 1) * 4)) || (rc = bow_ensure(h->nm, 4)))
+        return rc;
+    BowCtx c;
+    memset(&c, 0, sizeof(c));
+    c.mode = mode; c.nq = s1->nq; c.q_idx1 = (const int*)h->q_idx1.p; c.q_node = (const uint32_t*)h->q_node.p;
+    c.N1 = s1->N; c.keys1 = (const oslam_keypoint_t*)h->keys1.p; c.desc1 = (const uint8_t*)h->desc1.p; c.uRight1 = (const float*)h->ur1.p; c.flag1 = (const uint8_t*)h->flag1.p;
+    c.N2 = s2->N; c.keys2 = (const oslam_keypoint_t*)h->keys2.p; c.desc2 = (const uint8_t*)h->desc2.p; c.uRight2 = (const float*)h->ur2.p; c.has_mp2 = (const uint8_t*)h->mp2.p;
+    c.nNodes = s2->nNodes; c.nodes = (const uint32_t*)h->nodes.p; c.start = (const int*)h->start.p; c.items = (const int*)h->items.p;
+    c.nnratio = nnratio; c.checkOri = checkOri; c.bOnlyStereo = bOnlyStereo;
+    if (F12) for (int i = 0; i < 9; i++) c.F12[i] = F12[i];
+    c.ex = ex; c.ey = ey;
+    for (int i = 0; i < OSLAM_MAX_LEVELS; i++) {
+        c.scale[i] = (scaleFactors && i < nlevels) ? scaleFactors[i] : 0.f;
+        c.sigma2[i] = (levelSigma2 && i < nlevels) ? levelSigma2[i] : 0.f;
+    }
+    c.out = (int*)h->out.p; c.nmatches = (int*)h->nm.p; c.q_best = (int*)h->qbest.p;
+    hipLaunchKernelGGL(k_search_bow, dim3(1), dim3(kBowThreads), h->lds, nullptr, c, h->max_kps);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(nmatches, h->nm.p, 4, hipMemcpyDeviceToHost));
+    if (*nmatches < 0) { set_error("BoW matcher kernel rejected the pair (capacity)"); return OSLAM_E_CAPACITY; }
+    const int nout = mode == 0 ? s2->N : s1->N;
+    if (nout > 0) OSLAM_HIP_CHECK(hipMemcpy(out, h->out.p, (size_t)nout * 4, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+int oslam_match_search_by_bow(oslam_bow_t* h, const oslam_bow_side1_t* kf, const oslam_bow_side2_t* frame, float nnratio, int checkOri,
+                              int32_t* match_f, int32_t* nmatches) {
+    return bow_run(h, 0, kf, frame, nnratio, checkOri, nullptr, 0.f, 0.f, nullptr, nullptr, 0, 0, match_f, nmatches);
+}
+
+int oslam_match_search_for_triangulation(oslam_bow_t* h, const oslam_bow_side1_t* kf1, const oslam_bow_side2_t* kf2, const float F12[9], float ex,
+                                         float ey, const float* scaleFactors, const float* levelSigma2, int nlevels, int bOnlyStereo,
+                                         int checkOri, int32_t* match12, int32_t* nmatches) {
+    if (!F12 || !scaleFactors || !levelSigma2 || nlevels < 1 || nlevels > OSLAM_MAX_LEVELS) { set_error("bad F12 / scale tables"); return OSLAM_E_INVALID; }
+    return bow_run(h, 1, kf1, kf2, 0.f, checkOri, F12, ex, ey, scaleFactors, levelSigma2, nlevels, bOnlyStereo, match12, nmatches);
+}
+
+}  // extern "C"

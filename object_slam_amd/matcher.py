@@ -159,3 +159,79 @@ class StereoMatcher:
                                         len(keysR), ptr(keysR), ptr(np.ascontiguousarray(descR, np.uint8)), orbL.nlevels,
                                         C.c_float(bf), C.c_float(b), ptr(uR), ptr(dep)))
         return uR[:N], dep[:N]
+
+
+class BowSide1(C.Structure):
+    _fields_ = [("N", C.c_int32), ("keys", C.c_void_p), ("desc", C.c_void_p), ("uRight", C.c_void_p), ("flag", C.c_void_p),
+                ("nq", C.c_int32), ("q_idx", C.c_void_p), ("q_node", C.c_void_p)]
+
+
+class BowSide2(C.Structure):
+    _fields_ = [("N", C.c_int32), ("keys", C.c_void_p), ("desc", C.c_void_p), ("uRight", C.c_void_p), ("has_mp", C.c_void_p),
+                ("nNodes", C.c_int32), ("nodes", C.c_void_p), ("start", C.c_void_p), ("items", C.c_void_p)]
+
+
+def feature_vector(node_of_kp):
+    """node id per keypoint -> (flat (idx, node) list in std::map order, CSR (nodes, start, items))."""
+    node_of_kp = np.asarray(node_of_kp, np.uint32)
+    order = np.argsort(node_of_kp, kind="stable").astype(np.int32)
+    nodes, start = np.unique(node_of_kp[order], return_index=True)
+    start = np.concatenate([start, [len(order)]]).astype(np.int32)
+    return order, node_of_kp[order].astype(np.uint32), nodes.astype(np.uint32), start, order.copy()
+
+
+class BowMatcher:
+    """SearchByBoW(KeyFrame*, Frame&) and SearchForTriangulation (reference src/ORBmatcher.cc:159, :657) with
+    caller-supplied FeatureVectors (the DBoW2 vocabulary is not part of the reference tree)."""
+
+    def __init__(self, max_keypoints=2400, device=0):
+        self.L = _lib.lib()
+        self.h = C.c_void_p()
+        check(self.L.oslam_bow_create(C.byref(self.h), max_keypoints, device))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.oslam_bow_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _sides(keys1, desc1, uR1, flag1, node1, keys2, desc2, uR2, mp2, node2):
+        keep = []
+        k1 = np.ascontiguousarray(keys1, KP_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8)
+        k2 = np.ascontiguousarray(keys2, KP_DTYPE); d2 = np.ascontiguousarray(desc2, np.uint8)
+        f1 = np.ascontiguousarray(flag1, np.uint8)
+        qi, qn, _, _, _ = feature_vector(node1)
+        _, _, nodes, start, items = feature_vector(node2)
+        keep += [k1, d1, k2, d2, f1, qi, qn, nodes, start, items]
+        s1, s2 = BowSide1(), BowSide2()
+        s1.N, s1.keys, s1.desc, s1.flag = len(k1), k1.ctypes.data, d1.ctypes.data, f1.ctypes.data
+        s1.nq, s1.q_idx, s1.q_node = len(qi), qi.ctypes.data, qn.ctypes.data
+        s2.N, s2.keys, s2.desc = len(k2), k2.ctypes.data, d2.ctypes.data
+        s2.nNodes, s2.nodes, s2.start, s2.items = len(nodes), nodes.ctypes.data, start.ctypes.data, items.ctypes.data
+        if uR1 is not None:
+            a = np.ascontiguousarray(uR1, np.float32); keep.append(a); s1.uRight = a.ctypes.data
+        if uR2 is not None:
+            a = np.ascontiguousarray(uR2, np.float32); keep.append(a); s2.uRight = a.ctypes.data
+        if mp2 is not None:
+            a = np.ascontiguousarray(mp2, np.uint8); keep.append(a); s2.has_mp = a.ctypes.data
+        return s1, s2, keep
+
+    def SearchByBoW(self, keysKF, descKF, validKF, nodeKF, keysF, descF, nodeF, nnratio=0.7, checkOri=True):
+        s1, s2, keep = self._sides(keysKF, descKF, None, validKF, nodeKF, keysF, descF, None, None, nodeF)
+        out = np.full(max(s2.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        check(self.L.oslam_match_search_by_bow(self.h, C.byref(s1), C.byref(s2), C.c_float(nnratio), int(checkOri), ptr(out), C.byref(nm)))
+        return nm.value, out[:s2.N]
+
+    def SearchForTriangulation(self, keys1, desc1, uR1, hasmp1, node1, keys2, desc2, uR2, hasmp2, node2, F12, ex, ey, scaleFactors,
+                               levelSigma2, bOnlyStereo=False, checkOri=True):
+        s1, s2, keep = self._sides(keys1, desc1, uR1, hasmp1, node1, keys2, desc2, uR2, hasmp2, node2)
+        out = np.full(max(s1.N, 1), -1, np.int32)
+        nm = C.c_int(0)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sf = np.ascontiguousarray(scaleFactors, np.float32); s2l = np.ascontiguousarray(levelSigma2, np.float32)
+        check(self.L.oslam_match_search_for_triangulation(self.h, C.byref(s1), C.byref(s2), ptr(F), C.c_float(ex), C.c_float(ey), ptr(sf), ptr(s2l),
+                                                          len(sf), int(bOnlyStereo), int(checkOri), ptr(out), C.byref(nm)))
+        return nm.value, out[:s1.N]

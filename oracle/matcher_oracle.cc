@@ -379,3 +379,129 @@ int FuseSearch(const FrameView& f, const ProjQuery* q, int M, const float* invLe
     return n;
 }
 }  // namespace oracle
+
+namespace oracle {
+static int find_node(const BowSide2& s2, uint32_t node) {
+    const uint32_t* e = s2.nodes + s2.nNodes;
+    const uint32_t* p = std::lower_bound(s2.nodes, e, node);
+    return (p != e && *p == node) ? (int)(p - s2.nodes) : -1;
+}
+
+// reference src/ORBmatcher.cc:159-288
+int SearchByBoW(int nq, const int32_t* q_idx1, const uint32_t* q_node, const KeyPoint* keys1, const uint8_t* desc1,
+                const uint8_t* valid1, int N2, const KeyPoint* keys2, const uint8_t* desc2, const BowSide2& s2, float nnratio,
+                int checkOri, int* match_f) {
+    for (int k = 0; k < N2; k++) match_f[k] = -1;
+    int nmatches = 0;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int q = 0; q < nq; q++) {
+        const int realIdxKF = q_idx1[q];
+        if (!valid1[realIdxKF]) continue;
+        const int nd = find_node(s2, q_node[q]);
+        if (nd < 0) continue;
+        const uint8_t* dKF = desc1 + (size_t)realIdxKF * 32;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int t = s2.start[nd]; t < s2.start[nd + 1]; t++) {
+            const int realIdxF = s2.items[t];
+            if (match_f[realIdxF] >= 0) continue;
+            const int dist = DescriptorDistance(dKF, desc2 + (size_t)realIdxF * 32);
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+            if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                match_f[bestIdxF] = realIdxKF;
+                if (checkOri) {
+                    float rot = keys1[realIdxKF].angle - keys2[bestIdxF].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(bestIdxF);
+                }
+                nmatches++;
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match_f[rotHist[i][j]] = -2; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// reference src/ORBmatcher.cc:140-157
+static bool CheckDistEpipolarLine(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, const float* levelSigma2) {
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[kp2.octave];
+}
+
+// reference src/ORBmatcher.cc:657-823
+int SearchForTriangulation(int nq, const int32_t* q_idx1, const uint32_t* q_node, int N1, const KeyPoint* keys1,
+                           const uint8_t* desc1, const float* uRight1, const uint8_t* skip1, int N2, const KeyPoint* keys2,
+                           const uint8_t* desc2, const float* uRight2, const uint8_t* has_mp2, const BowSide2& s2,
+                           const float* F12, float ex, float ey, const float* scaleFactors, const float* levelSigma2,
+                           int bOnlyStereo, int checkOri, int* match12) {
+    for (int i = 0; i < N1; i++) match12[i] = -1;
+    int nmatches = 0;
+    std::vector<std::vector<int>> rotHist(HISTO_LENGTH);
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int q = 0; q < nq; q++) {
+        const int idx1 = q_idx1[q];
+        if (skip1[idx1]) continue;
+        const bool bStereo1 = uRight1[idx1] >= 0;
+        if (bOnlyStereo && !bStereo1) continue;
+        const int nd = find_node(s2, q_node[q]);
+        if (nd < 0) continue;
+        const KeyPoint& kp1 = keys1[idx1];
+        const uint8_t* d1 = desc1 + (size_t)idx1 * 32;
+        int bestDist = TH_LOW, bestIdx2 = -1;
+        for (int t = s2.start[nd]; t < s2.start[nd + 1]; t++) {
+            const int idx2 = s2.items[t];
+            if (has_mp2[idx2]) continue;   // vbMatched2 is never set in the reference
+            const bool bStereo2 = uRight2[idx2] >= 0;
+            if (bOnlyStereo && !bStereo2) continue;
+            const int dist = DescriptorDistance(d1, desc2 + (size_t)idx2 * 32);
+            if (dist > TH_LOW || dist > bestDist) continue;
+            const KeyPoint& kp2 = keys2[idx2];
+            if (!bStereo1 && !bStereo2) {
+                const float distex = ex - kp2.x, distey = ey - kp2.y;
+                if (distex * distex + distey * distey < 100 * scaleFactors[kp2.octave]) continue;
+            }
+            if (CheckDistEpipolarLine(kp1, kp2, F12, levelSigma2)) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+            match12[idx1] = bestIdx2;
+            nmatches++;
+            if (checkOri) {
+                float rot = kp1.angle - keys2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(idx1);
+            }
+        }
+    }
+    if (checkOri) {
+        int ind1 = -1, ind2 = -1, ind3 = -1, sizes[HISTO_LENGTH];
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        ComputeThreeMaxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { match12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+}  // namespace oracle

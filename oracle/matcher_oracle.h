@@ -85,3 +85,25 @@ void ComputeStereoMatches(int N, const KeyPoint* keysL, const uint8_t* descL, in
                           const float* scaleFactors, const float* invScaleFactors, float bf, float b, float* uRight,
                           float* depth);
 }  // namespace oracle
+
+namespace oracle {
+// BoW-guided matchers.  The DBoW2 vocabulary is not in the reference tree, so the FeatureVectors
+// (node id -> keypoint indices, std::map order) are inputs: side 1 as a flat list in iteration order
+// (node ascending, indices in vector order), side 2 as CSR over its sorted node ids.
+struct BowSide2 {
+    int nNodes; const uint32_t* nodes; const int32_t* start; const int32_t* items;
+};
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches), reference src/ORBmatcher.cc:159-288.
+// q_idx1/q_node: KF entries in FeatureVector order; valid1[idx1] = map point exists && !isBad().
+// match_f[k] = KF keypoint whose map point lands in vpMapPointMatches[k] (-1 none, -2 nulled by rotation check).
+int SearchByBoW(int nq, const int32_t* q_idx1, const uint32_t* q_node, const KeyPoint* keys1, const uint8_t* desc1,
+                const uint8_t* valid1, int N2, const KeyPoint* keys2, const uint8_t* desc2, const BowSide2& s2, float nnratio,
+                int checkOri, int* match_f);
+// ORBmatcher::SearchForTriangulation, reference src/ORBmatcher.cc:657-823 (vbMatched2 is never set there, so
+// queries are independent).  skip1[idx1] = pKF1 map point exists; has_mp2[idx2] likewise; F12 row-major 3x3 float.
+int SearchForTriangulation(int nq, const int32_t* q_idx1, const uint32_t* q_node, int N1, const KeyPoint* keys1,
+                           const uint8_t* desc1, const float* uRight1, const uint8_t* skip1, int N2, const KeyPoint* keys2,
+                           const uint8_t* desc2, const float* uRight2, const uint8_t* has_mp2, const BowSide2& s2,
+                           const float* F12, float ex, float ey, const float* scaleFactors, const float* levelSigma2,
+                           int bOnlyStereo, int checkOri, int* match12);
+}  // namespace oracle

@@ -214,3 +214,21 @@ void oo_bundle_adjustment(int nKF, const float* poses, const uint8_t* fixed, int
     BundleAdjustment(nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, nIterations, bRobust, poses_out, points_out);
 }
 }
+
+extern "C" {
+int oo_search_by_bow(int nq, const int32_t* q_idx1, const uint32_t* q_node, const KeyPoint* keys1, const uint8_t* desc1,
+                     const uint8_t* valid1, int N2, const KeyPoint* keys2, const uint8_t* desc2, int nNodes, const uint32_t* nodes,
+                     const int32_t* start, const int32_t* items, float nnratio, int checkOri, int* match_f) {
+    BowSide2 s2{nNodes, nodes, start, items};
+    return SearchByBoW(nq, q_idx1, q_node, keys1, desc1, valid1, N2, keys2, desc2, s2, nnratio, checkOri, match_f);
+}
+int oo_search_for_triangulation(int nq, const int32_t* q_idx1, const uint32_t* q_node, int N1, const KeyPoint* keys1, const uint8_t* desc1,
+                                const float* uRight1, const uint8_t* skip1, int N2, const KeyPoint* keys2, const uint8_t* desc2,
+                                const float* uRight2, const uint8_t* has_mp2, int nNodes, const uint32_t* nodes, const int32_t* start,
+                                const int32_t* items, const float* F12, float ex, float ey, const float* scaleFactors,
+                                const float* levelSigma2, int bOnlyStereo, int checkOri, int* match12) {
+    BowSide2 s2{nNodes, nodes, start, items};
+    return SearchForTriangulation(nq, q_idx1, q_node, N1, keys1, desc1, uRight1, skip1, N2, keys2, desc2, uRight2, has_mp2, s2, F12, ex, ey,
+                                  scaleFactors, levelSigma2, bOnlyStereo, checkOri, match12);
+}
+}

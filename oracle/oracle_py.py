@@ -314,3 +314,41 @@ def bundle_adjustment(poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_inv
                                _p(np.ascontiguousarray(edge_inv, np.float32)), _p(np.asarray(K5, np.float32)), int(nIterations), int(bRobust),
                                _p(pout), _p(xout))
     return pout.reshape(-1, 4, 4), xout
+
+
+def _fv(node_of_kp):
+    node_of_kp = np.asarray(node_of_kp, np.uint32)
+    order = np.argsort(node_of_kp, kind="stable").astype(np.int32)
+    nodes, start = np.unique(node_of_kp[order], return_index=True)
+    return order, node_of_kp[order].astype(np.uint32), nodes.astype(np.uint32), np.concatenate([start, [len(order)]]).astype(np.int32), order.copy()
+
+
+def search_by_bow(keysKF, descKF, validKF, nodeKF, keysF, descF, nodeF, nnratio, checkOri):
+    k1, k2 = np.ascontiguousarray(keysKF, KP_DTYPE), np.ascontiguousarray(keysF, KP_DTYPE)
+    qi, qn, _, _, _ = _fv(nodeKF)
+    _, _, nodes, start, items = _fv(nodeF)
+    out = np.full(max(len(k2), 1), -1, np.int32)
+    L = lib()
+    L.oo_search_by_bow.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_int, C.c_void_p]
+    n = L.oo_search_by_bow(len(qi), _p(qi), _p(qn), _p(k1), _p(np.ascontiguousarray(descKF, np.uint8)), _p(np.ascontiguousarray(validKF, np.uint8)),
+                           len(k2), _p(k2), _p(np.ascontiguousarray(descF, np.uint8)), len(nodes), _p(nodes), _p(start), _p(items),
+                           nnratio, int(checkOri), _p(out))
+    return n, out[:len(k2)]
+
+
+def search_for_triangulation(keys1, desc1, uR1, hasmp1, node1, keys2, desc2, uR2, hasmp2, node2, F12, ex, ey, scaleFactors, levelSigma2,
+                             bOnlyStereo, checkOri):
+    k1, k2 = np.ascontiguousarray(keys1, KP_DTYPE), np.ascontiguousarray(keys2, KP_DTYPE)
+    qi, qn, _, _, _ = _fv(node1)
+    _, _, nodes, start, items = _fv(node2)
+    out = np.full(max(len(k1), 1), -1, np.int32)
+    L = lib()
+    L.oo_search_for_triangulation.argtypes = ([C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 +
+                                              [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
+    n = L.oo_search_for_triangulation(len(qi), _p(qi), _p(qn), len(k1), _p(k1), _p(np.ascontiguousarray(desc1, np.uint8)),
+                                      _p(np.ascontiguousarray(uR1, np.float32)), _p(np.ascontiguousarray(hasmp1, np.uint8)), len(k2), _p(k2),
+                                      _p(np.ascontiguousarray(desc2, np.uint8)), _p(np.ascontiguousarray(uR2, np.float32)),
+                                      _p(np.ascontiguousarray(hasmp2, np.uint8)), len(nodes), _p(nodes), _p(start), _p(items),
+                                      _p(np.ascontiguousarray(F12, np.float32).reshape(9)), ex, ey, _p(np.ascontiguousarray(scaleFactors, np.float32)),
+                                      _p(np.ascontiguousarray(levelSigma2, np.float32)), int(bOnlyStereo), int(checkOri), _p(out))
+    return n, out[:len(k1)]

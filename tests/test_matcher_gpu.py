@@ -152,3 +152,56 @@ def test_fuse_search(oracle, seed):
     np.testing.assert_array_equal(qd, oqd)
     assert nf == onf and (nf > 10 or N < 300)
     m.close()
+
+
+def _bow_pair(rng, N1, N2, n_nodes):
+    k1, uR1, d1 = _rand_frame(rng, N1)
+    src = rng.integers(0, N1, N2)
+    k2 = np.zeros(N2, KP_DTYPE)
+    k2["x"] = k1["x"][src] - rng.uniform(2, 30, N2)
+    k2["y"] = k1["y"][src] + rng.normal(0, 1.0, N2)
+    k2["octave"] = np.clip(k1["octave"][src] + rng.integers(-1, 2, N2), 0, 7)
+    k2["angle"] = (k1["angle"][src] + rng.normal(0, 8, N2)) % 360
+    d2 = d1[src].copy()
+    d2 ^= np.packbits(rng.random((N2, 256)) < 0.06, axis=1, bitorder="little")
+    node1 = rng.integers(0, n_nodes, N1).astype(np.uint32)
+    node2 = node1[src].copy()
+    wrong = rng.random(N2) < 0.15
+    node2[wrong] = rng.integers(0, n_nodes, wrong.sum())
+    uR2 = np.where(rng.random(N2) < 0.6, k2["x"] - rng.uniform(1, 30, N2), -1).astype(np.float32)
+    return k1, uR1, d1, node1, k2, uR2, d2, node2
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_search_by_bow(oracle, seed):
+    from object_slam_amd import BowMatcher
+    rng = np.random.default_rng(200 + seed)
+    N1, N2, nn = [(1000, 1000, 120), (2000, 2300, 40), (50, 80, 5), (1500, 900, 600)][seed]
+    k1, uR1, d1, node1, k2, uR2, d2, node2 = _bow_pair(rng, N1, N2, nn)
+    valid1 = (rng.random(N1) < 0.8).astype(np.uint8)
+    bm = BowMatcher()
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        nm, mf = bm.SearchByBoW(k1, d1, valid1, node1, k2, d2, node2, ratio, ori)
+        onm, omf = oracle.search_by_bow(k1, d1, valid1, node1, k2, d2, node2, ratio, ori)
+        np.testing.assert_array_equal(mf, omf)
+        assert nm == onm and (nm > 5 or N1 < 100)
+    bm.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_search_for_triangulation(oracle, seed):
+    from object_slam_amd import BowMatcher
+    rng = np.random.default_rng(300 + seed)
+    N1, N2, nn = [(1000, 1000, 100), (2000, 2200, 50), (300, 200, 10)][seed]
+    k1, uR1, d1, node1, k2, uR2, d2, node2 = _bow_pair(rng, N1, N2, nn)
+    mp1 = (rng.random(N1) < 0.4).astype(np.uint8)
+    mp2 = (rng.random(N2) < 0.4).astype(np.uint8)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-7, (3, 3)).astype(np.float32)
+    sigma2 = (SCALE * SCALE).astype(np.float32)
+    bm = BowMatcher()
+    for only_stereo in (False, True):
+        nm, m12 = bm.SearchForTriangulation(k1, d1, uR1, mp1, node1, k2, d2, uR2, mp2, node2, F12, 700.0, 240.0, SCALE, sigma2, only_stereo, True)
+        onm, om12 = oracle.search_for_triangulation(k1, d1, uR1, mp1, node1, k2, d2, uR2, mp2, node2, F12, 700.0, 240.0, SCALE, sigma2, only_stereo, True)
+        np.testing.assert_array_equal(m12, om12)
+        assert nm == onm and (nm > 5 or N1 < 400)
+    bm.close()
