@@ -360,6 +360,41 @@ int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t
                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                       const float K5[5], int nIterations, int bRobust, int use_stop_flag, float* poses_out, float* points_out);
 
+/* ---------------- MapPoint maintenance + Frame::isInFrustum ----------------
+ * Batched over map points. Observations of point p are rows obs_start[p] .. obs_start[p+1]-1 of the obs_* tables,
+ * in the iteration order of the reference's std::map<KeyFrame*,size_t> (the caller keeps that order). */
+typedef struct oslam_mappoint oslam_mappoint_t;
+int oslam_mappoint_create(oslam_mappoint_t** out, int device);
+void oslam_mappoint_destroy(oslam_mappoint_t* h);
+
+/* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:345-410): for each point the observation whose
+ * median Hamming distance to the others (sorted row, element int(0.5*(N-1))) is the first strict minimum.
+ * best_idx[p] = index inside the point's list (-1 if it has no observation; out_desc row then zero). */
+int oslam_mp_distinctive_descriptors(oslam_mappoint_t* h, int P, const int32_t* obs_start, const uint8_t* obs_desc /*[total][32]*/,
+                                     int32_t* best_idx /*[P]*/, uint8_t* out_desc /*[P][32]*/);
+
+/* MapPoint::UpdateNormalAndDepth (reference src/MapPoint.cc:433-474). obs_Ow = camera centres of the observing
+ * keyframes, OwRef = reference keyframe centre, levelScaleFactor[p] = mvScaleFactors[level of the point in the
+ * reference keyframe], lastScaleFactor = mvScaleFactors[nLevels-1].
+ * out[p] = {normal.x, normal.y, normal.z, mfMaxDistance, mfMinDistance}. */
+int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*[P][3]*/, const int32_t* obs_start, const float* obs_Ow /*[total][3]*/,
+                                 const float* OwRef /*[P][3]*/, const float* levelScaleFactor /*[P]*/, float lastScaleFactor, float* out /*[P][5]*/);
+
+/* Frame::isInFrustum (reference src/Frame.cc:509-565) + MapPoint::PredictScale (src/MapPoint.cc:505-521) + the window
+ * radius of ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:57-67, RadiusByViewingCos :93-99),
+ * for M map points against one frame pose. Tcw row-major 4x4; K5 = fx,fy,cx,cy,bf; bounds = mnMinX,mnMinY,mnMaxX,mnMaxY;
+ * maxDist/minDist = the raw mfMaxDistance/mfMinDistance (the 1.2/0.8 invariance factors are applied inside);
+ * obs_gt0[i] = pMP->Observations() > 0. Writes one oslam_proj_query_t per point, ready for
+ * oslam_match_search_by_projection: flags bit0 = mbTrackInView, bit1 = obs>0, angle = mTrackViewCos,
+ * minLevel = nPredictedLevel-1, maxLevel = nPredictedLevel, desc = the point's descriptor. Points outside the frustum get flags=0. */
+int oslam_frame_is_in_frustum(oslam_mappoint_t* h, int M, const float* Pw /*[M][3]*/, const float* Pn /*[M][3]*/, const float* maxDist, const float* minDist,
+                              const uint8_t* obs_gt0, const uint8_t* mp_desc /*[M][32]*/, const float Tcw[16], const float K5[5], const float bounds[4],
+                              float viewingCosLimit, float logScaleFactor, const float* scaleFactors, int nLevels, float th, oslam_proj_query_t* out);
+/* same, all per-point arrays and the output in device memory, asynchronous on `stream` (hipStream_t) */
+int oslam_frame_is_in_frustum_device(int M, const float* d_Pw, const float* d_Pn, const float* d_maxDist, const float* d_minDist, const uint8_t* d_obs_gt0,
+                                     const uint8_t* d_mp_desc, const float Tcw[16], const float K5[5], const float bounds[4], float viewingCosLimit,
+                                     float logScaleFactor, const float* scaleFactors, int nLevels, float th, oslam_proj_query_t* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

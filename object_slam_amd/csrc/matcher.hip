@@ -344,11 +344,11 @@ struct ProjectCtx {
     oslam_proj_query_t* out; int q_stride; int* n_q;
 };
 
+// cv::Mat 3x3*3x1+3x1 = one cv::gemm, flags==0, len==3: float accumulation (OpenCV small-matrix branch),
+// then (float)(t0*1.0 + c*1.0) in double
 __device__ __forceinline__ float gemm_row(const float* a, const float* x, float cc) {
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)x[k];
-    return (float)(s + (double)cc);
+    const float t0 = a[0] * x[0] + a[1] * x[1] + a[2] * x[2];
+    return (float)((double)t0 + (double)cc);
 }
 
 __global__ __launch_bounds__(256) void k_project_last(ProjectCtx c) {

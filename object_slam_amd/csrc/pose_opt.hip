@@ -93,14 +93,12 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
     return true;
 }
 
-// cv::Mat R*P + t as a single gemm: fp64 accumulation, one rounding to float
+// cv::Mat R*P + t as a single cv::gemm (flags==0, len==3): float accumulation, then (float)(t0 + t) in double
 __device__ __forceinline__ void project_f32(const float* T, const float* P, float Pc[3]) {
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 3; k++) s += (double)T[r * 4 + k] * (double)P[k];
-        Pc[r] = (float)(s + (double)T[r * 4 + 3]);
+        const float t0 = T[r * 4] * P[0] + T[r * 4 + 1] * P[1] + T[r * 4 + 2] * P[2];
+        Pc[r] = (float)((double)t0 + (double)T[r * 4 + 3]);
     }
 }
 

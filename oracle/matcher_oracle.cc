@@ -167,12 +167,13 @@ int SearchByProjection(const FrameView& f, const ProjQuery* q, int M, float nnra
     return nmatches;
 }
 
-// cv::Mat float product + add as one cv::gemm call (GEMMSingleMul<float,double>): double
-// accumulation, one rounding to float.  d = (float)(sum_k a[k]*b[k] + c).
+// cv::Mat float 3x3 * 3x1 + 3x1 is ONE cv::gemm call with flags==0 and len==3, which OpenCV 3.2 serves from
+// its small-matrix branch (modules/core/src/matmul.cpp, "flags == 0 && 2 <= len && len <= 4"): the dot product is
+// accumulated in float, left to right, then  d = (float)(t0*alpha + c*beta)  with alpha = beta = 1.0 (double).
+// (Products with a transposed operand, e.g. -Rcw.t()*tcw, take the generic GEMMSingleMul<float,double> path.)
 static inline float gemm_row(const float* a, const float* x, float c) {
-    double s = 0;
-    for (int k = 0; k < 3; k++) s += (double)a[k] * (double)x[k];
-    return (float)(s + (double)c);
+    const float t0 = a[0] * x[0] + a[1] * x[1] + a[2] * x[2];
+    return (float)((double)t0 * 1.0 + (double)c * 1.0);
 }
 
 // reference src/ORBmatcher.cc:1338-1392

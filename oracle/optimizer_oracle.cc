@@ -677,12 +677,12 @@ struct MaskArea {
         return true;
     }
 };
-// cv::Mat  R(3x3 float) * P(3x1 float) + t  as one gemm: double accumulation, one rounding
+// cv::Mat  R(3x3 float) * P(3x1 float) + t  as one cv::gemm (flags==0, len==3): OpenCV 3.2's small-matrix
+// branch accumulates the row product in float, then d = (float)(t0*alpha + c*beta), alpha = beta = 1.0 (double)
 inline void project_f32(const float* T, const float* P, float Pc[3]) {
     for (int r = 0; r < 3; r++) {
-        double s = 0;
-        for (int k = 0; k < 3; k++) s += (double)T[r * 4 + k] * (double)P[k];
-        Pc[r] = (float)(s + (double)T[r * 4 + 3]);
+        const float t0 = T[r * 4] * P[0] + T[r * 4 + 1] * P[1] + T[r * 4 + 2] * P[2];
+        Pc[r] = (float)((double)t0 * 1.0 + (double)T[r * 4 + 3] * 1.0);
     }
 }
 }  // namespace

@@ -352,3 +352,37 @@ def search_for_triangulation(keys1, desc1, uR1, hasmp1, node1, keys2, desc2, uR2
                                       _p(np.ascontiguousarray(F12, np.float32).reshape(9)), ex, ey, _p(np.ascontiguousarray(scaleFactors, np.float32)),
                                       _p(np.ascontiguousarray(levelSigma2, np.float32)), int(bOnlyStereo), int(checkOri), _p(out))
     return n, out[:len(k1)]
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors for one point: index of the chosen observation (-1 if none)."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    L = lib()
+    L.oo_distinctive_descriptor.argtypes = [C.c_int, C.c_void_p]
+    return L.oo_distinctive_descriptor(len(desc), _p(desc)) if len(desc) else -1
+
+
+def update_normal_depth(Pos, Ow, OwRef, levelScaleFactor, lastScaleFactor):
+    """MapPoint::UpdateNormalAndDepth for one point -> [nx, ny, nz, maxD, minD]."""
+    Ow = np.ascontiguousarray(Ow, np.float32).reshape(-1, 3)
+    out = np.zeros(5, np.float32)
+    L = lib()
+    L.oo_update_normal_depth.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    L.oo_update_normal_depth(_p(np.ascontiguousarray(Pos, np.float32)), len(Ow), _p(Ow), _p(np.ascontiguousarray(OwRef, np.float32)),
+                             float(levelScaleFactor), float(lastScaleFactor), _p(out))
+    return out
+
+
+def is_in_frustum(Pw, Pn, maxDist, minDist, obs_gt0, mp_desc, Tcw, K5, bounds, viewingCosLimit, logScaleFactor, scaleFactors, th):
+    Pw = np.ascontiguousarray(Pw, np.float32).reshape(-1, 3)
+    M = len(Pw)
+    out = np.zeros(max(M, 1), QUERY_DTYPE)
+    sf = np.ascontiguousarray(scaleFactors, np.float32)
+    L = lib()
+    L.oo_is_in_frustum.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.oo_is_in_frustum(M, _p(Pw), _p(np.ascontiguousarray(Pn, np.float32)), _p(np.ascontiguousarray(maxDist, np.float32)),
+                       _p(np.ascontiguousarray(minDist, np.float32)), _p(np.ascontiguousarray(obs_gt0, np.uint8)),
+                       _p(np.ascontiguousarray(mp_desc, np.uint8)), _p(np.ascontiguousarray(Tcw, np.float32)),
+                       _p(np.asarray(K5, np.float32)), _p(np.asarray(bounds, np.float32)), float(viewingCosLimit),
+                       float(logScaleFactor), _p(sf), len(sf), float(th), _p(out))
+    return out[:M]
