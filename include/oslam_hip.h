@@ -395,6 +395,26 @@ int oslam_frame_is_in_frustum_device(int M, const float* d_Pw, const float* d_Pn
                                      const uint8_t* d_mp_desc, const float Tcw[16], const float K5[5], const float bounds[4], float viewingCosLimit,
                                      float logScaleFactor, const float* scaleFactors, int nLevels, float th, oslam_proj_query_t* d_out, void* stream);
 
+/* LocalMapping::CreateNewMapPoints, per-match numeric core (reference src/LocalMapping.cc:291-432):
+ * parallax test, 4x4 DLT by cv::SVD (one-sided Jacobi) or KeyFrame::UnprojectStereo (src/KeyFrame.cc:615-631),
+ * cheirality, chi2 reprojection gates (5.991 / 7.8 x sigma2[octave]; the second view uses the CURRENT keyframe's mbf
+ * like the reference, :399) and the scale-consistency gate.  kf1 = mpCurrentKeyFrame, kf2[p] = the neighbours that
+ * passed the baseline test (:246-263), matches of pair p = rows pair_start[p] .. pair_start[p+1]-1 of idx1/idx2
+ * (SearchForTriangulation output order).  Map insertion (:408-430) stays with the caller. */
+typedef struct oslam_tri_kf {
+    float Tcw[16];   /* row-major 4x4: GetRotation / GetTranslation */
+    float Twc[16];   /* row-major 4x4: Rwc = Rcw.t(), column 3 = GetCameraCenter */
+    float fx, fy, cx, cy, invfx, invfy, mbf, mb;
+    const oslam_keypoint_t* keysUn;   /* mvKeysUn */
+    const oslam_keypoint_t* keys;     /* mvKeys (UnprojectStereo reads the raw keypoint) */
+    const float* uRight;              /* mvuRight */
+    const float* depth;               /* mvDepth */
+    int32_t n_kps;
+} oslam_tri_kf_t;
+int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* kf1, int nPairs, const oslam_tri_kf_t* kf2, const int32_t* pair_start,
+                         const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
+                         float ratioFactor /* 1.5f*mfScaleFactor */, uint8_t* ok /*[M]*/, float* x3D /*[M][3]*/, int32_t* nnew);
+
 #ifdef __cplusplus
 }
 #endif

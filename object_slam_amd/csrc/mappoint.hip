@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -73,17 +75,17 @@ __global__ __launch_bounds__(256) void k_update_normal_depth(int P, const float*
     float nx = 0, ny = 0, nz = 0;
     for (int i = 0; i < n; i++) {
         const float ax = px - obs_Ow[(s + i) * 3], ay = py - obs_Ow[(s + i) * 3 + 1], az = pz - obs_Ow[(s + i) * 3 + 2];
-        const double inv = 1.0 / norm3d(ax, ay, az);
-        nx = nx + (float)((double)ax * inv);
-        ny = ny + (float)((double)ay * inv);
-        nz = nz + (float)((double)az * inv);
+        const float inv = (float)(1.0 / norm3d(ax, ay, az));   // cv::scaleAdd with float alpha
+        nx = ax * inv + nx;
+        ny = ay * inv + ny;
+        nz = az * inv + nz;
     }
     const float dist = (float)norm3d(px - OwRef[p * 3], py - OwRef[p * 3 + 1], pz - OwRef[p * 3 + 2]);
     const float maxD = dist * levelScale[p];
-    const double invn = 1.0 / n;
-    out[p * 5] = (float)((double)nx * invn);
-    out[p * 5 + 1] = (float)((double)ny * invn);
-    out[p * 5 + 2] = (float)((double)nz * invn);
+    const float invn = (float)(1.0 / (double)n);   // convertTo(alpha = 1/n): float scale
+    out[p * 5] = nx * invn + 0.0f;
+    out[p * 5 + 1] = ny * invn + 0.0f;
+    out[p * 5 + 2] = nz * invn + 0.0f;
     out[p * 5 + 3] = maxD;
     out[p * 5 + 4] = __fdiv_rn(maxD, lastScale);
 }
@@ -164,7 +166,7 @@ using namespace oslam;
 struct oslam_mappoint {
     int device = 0;
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf a, b, c, d, e, f, g, o1, o2;
+    Buf a, b, c, d, e, f, g, g2, o1, o2;
 };
 
 static int mp_ensure(oslam_mappoint::Buf& b, size_t bytes) {
@@ -186,7 +188,7 @@ extern "C" {
 
 void oslam_mappoint_destroy(oslam_mappoint_t* h) {
     if (!h) return;
-    oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->f, &h->g, &h->o1, &h->o2};
+    oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->f, &h->g, &h->g2, &h->o1, &h->o2};
     for (auto* b : bs)
         if (b->p) (void)hipFree(b->p);
     delete h;
@@ -288,3 +290,291 @@ int oslam_frame_is_in_frustum(oslam_mappoint_t* h, int M, const float* Pw, const
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// LocalMapping::CreateNewMapPoints, per-match numeric core (reference src/LocalMapping.cc:291-432).
+// One thread per candidate match; all neighbour keyframes of one current keyframe in one launch.
+// ---------------------------------------------------------------------------------------------------------------
+namespace oslam {
+
+struct TriKfDev {
+    float Tcw[16], Twc[16];
+    float fx, fy, cx, cy, invfx, invfy, mbf, mb;
+    int kp_off;   // first keypoint of this keyframe in the concatenated per-keypoint tables
+};
+
+struct TriCtx {
+    int M, nLevels;
+    TriKfDev kf1;
+    const TriKfDev* kf2;          // [nPairs]
+    const int* pair_of;           // [M]
+    const int* idx1; const int* idx2;
+    const oslam_keypoint_t* keysUn; const oslam_keypoint_t* keys; const float* uRight; const float* depth;   // concatenated: kf1 first
+    float scale[OSLAM_MAX_LEVELS], sigma2[OSLAM_MAX_LEVELS];
+    float ratioFactor;
+    uint8_t* ok; float* x3D;
+};
+
+__device__ __forceinline__ double dot3d(const float* a, const float* b) {
+    double r = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) r += (double)a[k] * (double)b[k];
+    return r;
+}
+// cv::gemm small-matrix branch (float accumulation), optional + c
+__device__ __forceinline__ float rowmul3(const float* row, const float* x) { return row[0] * x[0] + row[1] * x[1] + row[2] * x[2]; }
+
+// one Jacobi rotation between rows I and J of At (and of Vt); returns whether it rotated
+template <int I, int J>
+__device__ __forceinline__ bool jacobi_pair(float (&At)[16], float (&Vt)[16], double (&W)[4]) {
+    double a = W[I], b = W[J], p = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) p += (double)At[I * 4 + k] * (double)At[J * 4 + k];
+    const float eps = 2.0f * 1.1920928955078125e-07f;
+    if (fabs(p) <= (double)eps * sqrt(a * b)) return false;
+    p *= 2;
+    const double beta = a - b, gamma = hypot(p, beta);
+    float c, s;
+    if (beta < 0) {
+        const double delta = (gamma - beta) * 0.5;
+        s = (float)sqrt(delta / gamma);
+        c = (float)(p / (gamma * (double)s * 2));
+    } else {
+        c = (float)sqrt((gamma + beta) / (gamma * 2));
+        s = (float)(p / (gamma * (double)c * 2));
+    }
+    a = b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float ai = At[I * 4 + k], aj = At[J * 4 + k];
+        const float t0 = c * ai + s * aj, t1 = -s * ai + c * aj;
+        At[I * 4 + k] = t0; At[J * 4 + k] = t1;
+        a += (double)t0 * (double)t0; b += (double)t1 * (double)t1;
+    }
+    W[I] = a; W[J] = b;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float vi = Vt[I * 4 + k], vj = Vt[J * 4 + k];
+        Vt[I * 4 + k] = c * vi + s * vj;
+        Vt[J * 4 + k] = -s * vi + c * vj;
+    }
+    return true;
+}
+
+// last right singular vector of a 4x4 float matrix (row-major A), as cv::SVD::compute(...).vt.row(3)
+__device__ void svd4_last_row(const float (&A)[16], float (&out)[4]) {
+    float At[16], Vt[16];
+    double W[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { At[i * 4 + k] = A[k * 4 + i]; sd += (double)At[i * 4 + k] * (double)At[i * 4 + k]; Vt[i * 4 + k] = (i == k) ? 1.f : 0.f; }
+        W[i] = sd;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        changed |= jacobi_pair<0, 1>(At, Vt, W);
+        changed |= jacobi_pair<0, 2>(At, Vt, W);
+        changed |= jacobi_pair<0, 3>(At, Vt, W);
+        changed |= jacobi_pair<1, 2>(At, Vt, W);
+        changed |= jacobi_pair<1, 3>(At, Vt, W);
+        changed |= jacobi_pair<2, 3>(At, Vt, W);
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sd += (double)At[i * 4 + k] * (double)At[i * 4 + k];
+        W[i] = sqrt(sd);
+    }
+    // selection sort by decreasing W (strict <), tracking only which original row ends up last
+    int perm[4] = {0, 1, 2, 3};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int j = i;
+#pragma unroll
+        for (int k = i + 1; k < 4; k++)
+            if (W[j] < W[k]) j = k;
+        if (j != i) {
+            // static-index swap
+#pragma unroll
+            for (int k = i + 1; k < 4; k++)
+                if (k == j) { const double tw = W[i]; W[i] = W[k]; W[k] = tw; const int tp = perm[i]; perm[i] = perm[k]; perm[k] = tp; }
+        }
+    }
+    const int r = perm[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = r == 0 ? Vt[k] : r == 1 ? Vt[4 + k] : r == 2 ? Vt[8 + k] : Vt[12 + k];
+}
+
+__device__ __forceinline__ bool tri_reproj_ok(const TriKfDev& kf, float mbf, float kx, float ky, float kur, bool bStereo, float x, float y, float z, float sig) {
+    const float invz = (float)(1.0 / (double)z);
+    const float u = kf.fx * x * invz + kf.cx;
+    const float v = kf.fy * y * invz + kf.cy;
+    const float ex = u - kx, ey = v - ky;
+    if (!bStereo) return !((double)(ex * ex + ey * ey) > 5.991 * (double)sig);
+    const float u_r = u - mbf * invz;
+    const float er = u_r - kur;
+    return !((double)(ex * ex + ey * ey + er * er) > 7.8 * (double)sig);
+}
+
+__device__ __forceinline__ bool tri_unproject(const TriKfDev& kf, float rawx, float rawy, float z, float (&out)[3]) {
+    if (!(z > 0)) return false;
+    const float x = (rawx - kf.cx) * z * kf.invfx;
+    const float y = (rawy - kf.cy) * z * kf.invfy;
+    const float xc[3] = {x, y, z};
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[r] = (float)((double)rowmul3(kf.Twc + r * 4, xc) + (double)kf.Twc[r * 4 + 3]);
+    return true;
+}
+
+__global__ __launch_bounds__(128) void k_triangulate(TriCtx c) {
+    const int m = blockIdx.x * 128 + threadIdx.x;
+    if (m >= c.M) return;
+    const TriKfDev& k1 = c.kf1;
+    const TriKfDev k2 = c.kf2[c.pair_of[m]];
+    const int i1 = k1.kp_off + c.idx1[m], i2 = k2.kp_off + c.idx2[m];
+    const oslam_keypoint_t kp1 = c.keysUn[i1], kp2 = c.keysUn[i2];
+    const float ur1 = c.uRight[i1], ur2 = c.uRight[i2];
+    const bool bS1 = ur1 >= 0, bS2 = ur2 >= 0;
+    bool ok = true;
+    float X[3] = {0, 0, 0};
+
+    const float xn1[3] = {(kp1.x - k1.cx) * k1.invfx, (kp1.y - k1.cy) * k1.invfy, 1.0f};
+    const float xn2[3] = {(kp2.x - k2.cx) * k2.invfx, (kp2.y - k2.cy) * k2.invfy, 1.0f};
+    float ray1[3], ray2[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { ray1[r] = rowmul3(k1.Twc + r * 4, xn1); ray2[r] = rowmul3(k2.Twc + r * 4, xn2); }
+    const float cosRays = (float)(dot3d(ray1, ray2) / (sqrt(dot3d(ray1, ray1)) * sqrt(dot3d(ray2, ray2))));
+    float cs1 = cosRays + 1, cs2 = cosRays + 1;
+    // std::atan2(float,float) / std::cos(float): evaluated in fp64 and rounded (glibc's float versions are within 1 ulp)
+    if (bS1) cs1 = (float)cos((double)(2 * (float)atan2((double)(k1.mb / 2), (double)c.depth[i1])));
+    else if (bS2) cs2 = (float)cos((double)(2 * (float)atan2((double)(k2.mb / 2), (double)c.depth[i2])));
+    const float cosStereo = fminf(cs1, cs2);
+
+    if (cosRays < cosStereo && cosRays > 0 && (bS1 || bS2 || (double)cosRays < 0.9998)) {
+        float A[16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {   // cv::addWeighted in double, one rounding
+            A[k] = (float)((double)k1.Tcw[8 + k] * (double)xn1[0] + (double)k1.Tcw[k] * -1.0 + 0.0);
+            A[4 + k] = (float)((double)k1.Tcw[8 + k] * (double)xn1[1] + (double)k1.Tcw[4 + k] * -1.0 + 0.0);
+            A[8 + k] = (float)((double)k2.Tcw[8 + k] * (double)xn2[0] + (double)k2.Tcw[k] * -1.0 + 0.0);
+            A[12 + k] = (float)((double)k2.Tcw[8 + k] * (double)xn2[1] + (double)k2.Tcw[4 + k] * -1.0 + 0.0);
+        }
+        float v[4];
+        svd4_last_row(A, v);
+        if (v[3] == 0) ok = false;
+        else {
+            const float inv = (float)(1.0 / (double)v[3]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) X[k] = v[k] * inv + 0.0f;
+        }
+    } else if (bS1 && cs1 < cs2) {
+        ok = tri_unproject(k1, c.keys[i1].x, c.keys[i1].y, c.depth[i1], X);
+    } else if (bS2 && cs2 < cs1) {
+        ok = tri_unproject(k2, c.keys[i2].x, c.keys[i2].y, c.depth[i2], X);
+    } else
+        ok = false;
+
+    if (ok) {
+        const float z1 = (float)(dot3d(k1.Tcw + 8, X) + (double)k1.Tcw[11]);
+        const float z2 = (float)(dot3d(k2.Tcw + 8, X) + (double)k2.Tcw[11]);
+        ok = !(z1 <= 0) && !(z2 <= 0);
+        if (ok) {
+            const float x1 = (float)(dot3d(k1.Tcw, X) + (double)k1.Tcw[3]), y1 = (float)(dot3d(k1.Tcw + 4, X) + (double)k1.Tcw[7]);
+            ok = tri_reproj_ok(k1, k1.mbf, kp1.x, kp1.y, ur1, bS1, x1, y1, z1, c.sigma2[kp1.octave]);
+        }
+        if (ok) {
+            const float x2 = (float)(dot3d(k2.Tcw, X) + (double)k2.Tcw[3]), y2 = (float)(dot3d(k2.Tcw + 4, X) + (double)k2.Tcw[7]);
+            ok = tri_reproj_ok(k2, k1.mbf, kp2.x, kp2.y, ur2, bS2, x2, y2, z2, c.sigma2[kp2.octave]);
+        }
+        if (ok) {
+            const float n1[3] = {X[0] - k1.Twc[3], X[1] - k1.Twc[7], X[2] - k1.Twc[11]};
+            const float n2[3] = {X[0] - k2.Twc[3], X[1] - k2.Twc[7], X[2] - k2.Twc[11]};
+            const float d1 = (float)sqrt(dot3d(n1, n1)), d2 = (float)sqrt(dot3d(n2, n2));
+            ok = !(d1 == 0 || d2 == 0);
+            if (ok) {
+                const float ratioDist = __fdiv_rn(d2, d1);
+                const float ratioOct = __fdiv_rn(c.scale[kp1.octave], c.scale[kp2.octave]);
+                ok = !(ratioDist * c.ratioFactor < ratioOct || ratioDist > ratioOct * c.ratioFactor);
+            }
+        }
+    }
+    c.ok[m] = ok ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) c.x3D[m * 3 + k] = ok ? X[k] : 0.f;
+}
+
+}  // namespace oslam
+
+extern "C" int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* kf1, int nPairs, const oslam_tri_kf_t* kf2, const int32_t* pair_start,
+                                    const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
+                                    float ratioFactor, uint8_t* ok, float* x3D, int32_t* nnew) {
+    if (!h || !kf1 || nPairs < 0 || (nPairs > 0 && (!kf2 || !pair_start)) || !scaleFactors || !levelSigma2 || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS) {
+        set_error("bad argument");
+        return OSLAM_E_INVALID;
+    }
+    if (nnew) *nnew = 0;
+    const int M = nPairs ? pair_start[nPairs] : 0;
+    if (M == 0) return OSLAM_OK;
+    if (M < 0 || !idx1 || !idx2 || !ok || !x3D) { set_error("bad match table"); return OSLAM_E_INVALID; }
+    // validate every index on the host: the kernel trusts them
+    auto kf_ok = [&](const oslam_tri_kf_t& k) { return k.n_kps >= 0 && (k.n_kps == 0 || (k.keysUn && k.keys && k.uRight && k.depth)); };
+    if (!kf_ok(*kf1)) { set_error("kf1 tables missing"); return OSLAM_E_INVALID; }
+    std::vector<int> pair_of(M);
+    std::vector<TriKfDev> dev2(nPairs);
+    size_t total = (size_t)kf1->n_kps;
+    auto fill = [](TriKfDev& d, const oslam_tri_kf_t& k, int off) {
+        for (int i = 0; i < 16; i++) { d.Tcw[i] = k.Tcw[i]; d.Twc[i] = k.Twc[i]; }
+        d.fx = k.fx; d.fy = k.fy; d.cx = k.cx; d.cy = k.cy; d.invfx = k.invfx; d.invfy = k.invfy; d.mbf = k.mbf; d.mb = k.mb;
+        d.kp_off = off;
+    };
+    for (int p = 0; p < nPairs; p++) {
+        if (!kf_ok(kf2[p]) || pair_start[p + 1] < pair_start[p] || pair_start[0] != 0) { set_error("bad pair %d", p); return OSLAM_E_INVALID; }
+        fill(dev2[p], kf2[p], (int)total);
+        for (int m = pair_start[p]; m < pair_start[p + 1]; m++) {
+            pair_of[m] = p;
+            if (idx1[m] < 0 || idx1[m] >= kf1->n_kps || idx2[m] < 0 || idx2[m] >= kf2[p].n_kps) { set_error("match %d: keypoint index out of range", m); return OSLAM_E_INVALID; }
+        }
+        total += (size_t)kf2[p].n_kps;
+    }
+    // levels of the matched keypoints index the scale tables
+    for (int m = 0; m < M; m++) {
+        const int o1 = kf1->keysUn[idx1[m]].octave, o2 = kf2[pair_of[m]].keysUn[idx2[m]].octave;
+        if (o1 < 0 || o1 >= nLevels || o2 < 0 || o2 >= nLevels) { set_error("match %d: octave out of range", m); return OSLAM_E_INVALID; }
+    }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    std::vector<oslam_keypoint_t> kun(total), kraw(total);
+    std::vector<float> ur(total), dep(total);
+    auto put = [&](const oslam_tri_kf_t& k, size_t off) {
+        if (!k.n_kps) return;
+        memcpy(&kun[off], k.keysUn, (size_t)k.n_kps * sizeof(oslam_keypoint_t));
+        memcpy(&kraw[off], k.keys, (size_t)k.n_kps * sizeof(oslam_keypoint_t));
+        memcpy(&ur[off], k.uRight, (size_t)k.n_kps * 4);
+        memcpy(&dep[off], k.depth, (size_t)k.n_kps * 4);
+    };
+    put(*kf1, 0);
+    for (int p = 0; p < nPairs; p++) put(kf2[p], (size_t)dev2[p].kp_off);
+    int rc;
+    if ((rc = mp_up(h->a, kun.data(), total * sizeof(oslam_keypoint_t))) || (rc = mp_up(h->b, kraw.data(), total * sizeof(oslam_keypoint_t))) ||
+        (rc = mp_up(h->c, ur.data(), total * 4)) || (rc = mp_up(h->d, dep.data(), total * 4)) || (rc = mp_up(h->e, dev2.data(), dev2.size() * sizeof(TriKfDev))) ||
+        (rc = mp_up(h->f, pair_of.data(), (size_t)M * 4)) || (rc = mp_up(h->g, idx1, (size_t)M * 4)) || (rc = mp_up(h->g2, idx2, (size_t)M * 4)) ||
+        (rc = mp_ensure(h->o1, (size_t)M)) || (rc = mp_ensure(h->o2, (size_t)M * 12)))
+        return rc;
+    TriCtx c;
+    c.M = M; c.nLevels = nLevels;
+    fill(c.kf1, *kf1, 0);
+    c.kf2 = (const TriKfDev*)h->e.p; c.pair_of = (const int*)h->f.p; c.idx1 = (const int*)h->g.p; c.idx2 = (const int*)h->g2.p;
+    c.keysUn = (const oslam_keypoint_t*)h->a.p; c.keys = (const oslam_keypoint_t*)h->b.p; c.uRight = (const float*)h->c.p; c.depth = (const float*)h->d.p;
+    for (int i = 0; i < OSLAM_MAX_LEVELS; i++) { c.scale[i] = i < nLevels ? scaleFactors[i] : 1.f; c.sigma2[i] = i < nLevels ? levelSigma2[i] : 1.f; }
+    c.ratioFactor = ratioFactor;
+    c.ok = (uint8_t*)h->o1.p; c.x3D = (float*)h->o2.p;
+    hipLaunchKernelGGL(k_triangulate, dim3(div_up(M, 128)), dim3(128), 0, nullptr, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipMemcpy(ok, h->o1.p, (size_t)M, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(x3D, h->o2.p, (size_t)M * 12, hipMemcpyDeviceToHost));
+    if (nnew) { int n = 0; for (int m = 0; m < M; m++) n += ok[m]; *nnew = n; }
+    return OSLAM_OK;
+}

@@ -71,3 +71,49 @@ class MapPointBatch:
             (C.c_float * 5)(*np.asarray(K5, np.float32)), (C.c_float * 4)(*np.asarray(bounds, np.float32)),
             C.c_float(viewingCosLimit), C.c_float(logScaleFactor), ptr(sf), len(sf), C.c_float(th), ptr(out)))
         return out[:M]
+
+
+class TriKF(C.Structure):
+    """oslam_tri_kf_t"""
+    _fields_ = [("Tcw", C.c_float * 16), ("Twc", C.c_float * 16), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float), ("mbf", C.c_float), ("mb", C.c_float),
+                ("keysUn", C.c_void_p), ("keys", C.c_void_p), ("uRight", C.c_void_p), ("depth", C.c_void_p), ("n_kps", C.c_int32)]
+
+
+def make_tri_kf(Tcw, Twc, cam8, keysUn, keys, uRight, depth):
+    """cam8 = fx, fy, cx, cy, invfx, invfy, mbf, mb.  Returns (struct, keepalive)."""
+    from ._lib import KP_DTYPE
+    keep = [np.ascontiguousarray(keysUn, KP_DTYPE), np.ascontiguousarray(keys, KP_DTYPE), np.ascontiguousarray(uRight, np.float32),
+            np.ascontiguousarray(depth, np.float32)]
+    k = TriKF()
+    k.Tcw[:] = [float(v) for v in np.asarray(Tcw, np.float32).reshape(-1)]
+    k.Twc[:] = [float(v) for v in np.asarray(Twc, np.float32).reshape(-1)]
+    k.fx, k.fy, k.cx, k.cy, k.invfx, k.invfy, k.mbf, k.mb = [float(np.float32(v)) for v in cam8]
+    k.keysUn, k.keys, k.uRight, k.depth = [a.ctypes.data for a in keep]
+    k.n_kps = len(keep[0])
+    return k, keep
+
+
+def triangulate(self, kf1, kf2_list, matches, scaleFactors, levelSigma2, ratioFactor):
+    """LocalMapping::CreateNewMapPoints numeric core.  kf1 / kf2_list entries from make_tri_kf; matches[p] = (idx1[], idx2[]).
+    Returns (ok[M] u8, x3D[M][3]) over the concatenated matches."""
+    nP = len(kf2_list)
+    start = np.zeros(nP + 1, np.int32)
+    for p, (a, _) in enumerate(matches):
+        start[p + 1] = start[p] + len(a)
+    M = int(start[-1])
+    i1 = np.concatenate([np.asarray(a, np.int32) for a, _ in matches] + [np.zeros(0, np.int32)]).astype(np.int32)
+    i2 = np.concatenate([np.asarray(b, np.int32) for _, b in matches] + [np.zeros(0, np.int32)]).astype(np.int32)
+    arr = (TriKF * max(nP, 1))(*[k for k, _ in kf2_list])
+    sf = np.ascontiguousarray(scaleFactors, np.float32)
+    ls = np.ascontiguousarray(levelSigma2, np.float32)
+    ok = np.zeros(max(M, 1), np.uint8)
+    x = np.zeros((max(M, 1), 3), np.float32)
+    nnew = C.c_int32(0)
+    check(self.L.oslam_mp_triangulate(self.h, C.byref(kf1[0]), nP, arr, ptr(start), ptr(i1) if M else None, ptr(i2) if M else None,
+                                      ptr(sf), ptr(ls), len(sf), C.c_float(ratioFactor), ptr(ok), ptr(x), C.byref(nnew)))
+    assert nnew.value == int(ok[:M].sum())
+    return ok[:M], x[:M]
+
+
+MapPointBatch.triangulate = triangulate

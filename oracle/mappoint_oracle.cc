@@ -42,14 +42,17 @@ void UpdateNormalAndDepth(const float* Pos, int n, const float* Ow, const float*
     float normal[3] = {0, 0, 0};
     for (int i = 0; i < n; i++) {
         float ni[3] = {Pos[0] - Ow[3 * i], Pos[1] - Ow[3 * i + 1], Pos[2] - Ow[3 * i + 2]};
-        const double inv = 1.0 / norm3(ni);                       // Mat / double -> scale by 1/norm in double
-        for (int k = 0; k < 3; k++) normal[k] = normal[k] + (float)((double)ni[k] * inv);
+        // normal + normali/norm: the MatExpr folds to AddEx(a=normali, alpha=1/norm, b=normal, beta=1), evaluated by
+        // cv::scaleAdd, which for CV_32F narrows alpha to float: dst = src1*falpha + src2
+        const float inv = (float)(1.0 / norm3(ni));
+        for (int k = 0; k < 3; k++) normal[k] = ni[k] * inv + normal[k];
     }
     float PC[3] = {Pos[0] - OwRef[0], Pos[1] - OwRef[1], Pos[2] - OwRef[2]};
     const float dist = (float)norm3(PC);
     const float maxD = dist * levelScaleFactor;
-    const double invn = 1.0 / n;
-    for (int k = 0; k < 3; k++) out[k] = (float)((double)normal[k] * invn);
+    // normal/n -> convertTo(alpha = 1/n): cvtScale 32f->32f works in float: src*(float)alpha + 0.f
+    const float invn = (float)(1.0 / (double)n);
+    for (int k = 0; k < 3; k++) out[k] = normal[k] * invn + 0.0f;
     out[3] = maxD;
     out[4] = maxD / lastScaleFactor;
 }

@@ -386,3 +386,25 @@ def is_in_frustum(Pw, Pn, maxDist, minDist, obs_gt0, mp_desc, Tcw, K5, bounds, v
                        _p(np.asarray(K5, np.float32)), _p(np.asarray(bounds, np.float32)), float(viewingCosLimit),
                        float(logScaleFactor), _p(sf), len(sf), float(th), _p(out))
     return out[:M]
+
+
+def triangulate(kf1, kf2, idx1, idx2, scaleFactors, levelSigma2, ratioFactor):
+    """LocalMapping::CreateNewMapPoints per-match core for ONE keyframe pair.
+    kfN = (Tcw[4x4], Twc[4x4], cam8, keysUn, keys, uRight, depth)."""
+    def pack(kf):
+        Tcw, Twc, cam8, ku, k, ur, d = kf
+        p = np.concatenate([np.asarray(Tcw, np.float32).reshape(-1), np.asarray(Twc, np.float32).reshape(-1), np.asarray(cam8, np.float32)])
+        return [np.ascontiguousarray(p, np.float32), np.ascontiguousarray(ku, KP_DTYPE), np.ascontiguousarray(k, KP_DTYPE),
+                np.ascontiguousarray(ur, np.float32), np.ascontiguousarray(d, np.float32)]
+    a, b = pack(kf1), pack(kf2)
+    idx1 = np.ascontiguousarray(idx1, np.int32)
+    idx2 = np.ascontiguousarray(idx2, np.int32)
+    M = len(idx1)
+    ok = np.zeros(max(M, 1), np.uint8)
+    x = np.zeros((max(M, 1), 3), np.float32)
+    L = lib()
+    L.oo_triangulate.argtypes = [C.c_void_p] * 10 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p, C.c_void_p]
+    n = L.oo_triangulate(*[_p(v) for v in a], *[_p(v) for v in b], M, _p(idx1), _p(idx2), _p(np.ascontiguousarray(scaleFactors, np.float32)),
+                         _p(np.ascontiguousarray(levelSigma2, np.float32)), float(ratioFactor), _p(ok), _p(x))
+    assert n == int(ok[:M].sum())
+    return ok[:M], x[:M]
