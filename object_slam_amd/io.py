@@ -1,0 +1,230 @@
+"""Data formats either side of the hot path: host-side Python, no device work.
+
+* association file reader                 reference Examples/RGB-D/rgbd_tum.cc:144-169 (LoadImages)
+* TUM / KITTI trajectory writers          reference src/System.cc:378-432, :435-470, :472-528
+* KITTI ground-truth pose reader          ExpResults/KITTI/groundtruth/NN.txt (rows of a 3x4 T_w_c)
+* semantic directory reader               reference src/Semantic.cc:14-96
+* timestamp association + ATE evaluation  reference ExpResults/TUM/Localization/associate.py:71-101, evaluate_ate.py:47-83
+"""
+import os
+
+import numpy as np
+
+VALID_LABELS_TUM = (0, 39, 41, 56, 58, 62, 63, 64, 65, 66, 73, 77)   # src/Semantic.cc:10
+VALID_LABELS_KITTI = (2,)                                             # src/Semantic.cc:11
+
+
+def load_associations(path):
+    """rgbd_tum.cc LoadImages: rows `t_rgb rgb_file t_depth depth_file`; the frame timestamp is the RGB one.
+    Returns (rgb_files, depth_files, timestamps float64)."""
+    rgb, dep, ts = [], [], []
+    with open(path) as f:
+        for s in f.read().split("\n"):
+            if not s:
+                continue
+            tok = s.split()
+            ts.append(float(tok[0]))
+            rgb.append(tok[1] if len(tok) > 1 else "")
+            dep.append(tok[3] if len(tok) > 3 else "")
+    return rgb, dep, np.asarray(ts, np.float64)
+
+
+def load_kitti_poses(path):
+    """KITTI ground truth: each row 12 floats = row-major 3x4 [R|t] of T_w_c.  Returns [n][4][4] float64."""
+    rows = np.loadtxt(path, dtype=np.float64, ndmin=2)
+    T = np.tile(np.eye(4), (len(rows), 1, 1))
+    T[:, :3, :] = rows.reshape(-1, 3, 4)
+    return T
+
+
+def _quat_xyzw(R):
+    """Eigen::Quaterniond(Matrix3d) (Converter::toQuaternion, src/Converter.cc:138-150): x, y, z, w as float32."""
+    R = np.asarray(R, np.float64)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    q = np.zeros(4)   # w, x, y, z
+    if t > 0:
+        t = np.sqrt(t + 1.0)
+        q[0] = 0.5 * t
+        t = 0.5 / t
+        q[1] = (R[2, 1] - R[1, 2]) * t
+        q[2] = (R[0, 2] - R[2, 0]) * t
+        q[3] = (R[1, 0] - R[0, 1]) * t
+    else:
+        i = 0
+        if R[1, 1] > R[0, 0]:
+            i = 1
+        if R[2, 2] > R[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q[1 + i] = 0.5 * t
+        t = 0.5 / t
+        q[0] = (R[k, j] - R[j, k]) * t
+        q[1 + j] = (R[j, i] + R[i, j]) * t
+        q[1 + k] = (R[k, i] + R[i, k]) * t
+    return np.array([q[1], q[2], q[3], q[0]]).astype(np.float32)
+
+
+def _rwc_twc(Tcw):
+    """Rwc = Rcw.t(); twc = -Rwc*tcw  (one cv::gemm, alpha = -1, float accumulation: src/System.cc:424-425)."""
+    T = np.asarray(Tcw, np.float32)
+    Rwc = T[:3, :3].T.copy()
+    t = T[:3, 3]
+    twc = np.empty(3, np.float32)
+    for r in range(3):
+        t0 = np.float32(np.float32(np.float32(Rwc[r, 0] * t[0]) + np.float32(Rwc[r, 1] * t[1])) + np.float32(Rwc[r, 2] * t[2]))
+        twc[r] = np.float32(np.float64(t0) * -1.0)
+    return Rwc, twc
+
+
+def _fx(v, prec):
+    return "%.*f" % (prec, float(v))   # ostream << fixed << setprecision(prec) << float (promoted to double)
+
+
+def save_trajectory_tum(path, timestamps, Tcw_list, lost=None):
+    """System::SaveTrajectoryTUM line format (src/System.cc:429): `t tx ty tz qx qy qz qw`, t with 6 decimals,
+    the rest with 9; lost frames skipped.  Tcw_list = final per-frame camera poses (the relative-pose chaining of
+    :408-422 is the caller's bookkeeping)."""
+    with open(path, "w") as f:
+        for i, (t, T) in enumerate(zip(timestamps, Tcw_list)):
+            if lost is not None and lost[i]:
+                continue
+            Rwc, twc = _rwc_twc(T)
+            q = _quat_xyzw(Rwc)
+            f.write(_fx(t, 6) + " " + " ".join(_fx(v, 9) for v in (twc[0], twc[1], twc[2], q[0], q[1], q[2], q[3])) + "\n")
+
+
+def save_keyframe_trajectory_tum(path, timestamps, Tcw_list, bad=None):
+    """System::SaveKeyFrameTrajectoryTUM (src/System.cc:435-470): keyframes sorted by id, bad ones skipped; 7 decimals."""
+    with open(path, "w") as f:
+        for i, (t, T) in enumerate(zip(timestamps, Tcw_list)):
+            if bad is not None and bad[i]:
+                continue
+            Rwc, Ow = _rwc_twc(T)   # GetCameraCenter = -Rwc*tcw (src/KeyFrame.cc:74)
+            q = _quat_xyzw(Rwc)
+            f.write(_fx(t, 6) + " " + " ".join(_fx(v, 7) for v in (Ow[0], Ow[1], Ow[2], q[0], q[1], q[2], q[3])) + "\n")
+
+
+def save_trajectory_kitti(path, Tcw_list):
+    """System::SaveTrajectoryKITTI (src/System.cc:521-523): row-major 3x4 [Rwc|twc], 9 decimals, every frame."""
+    with open(path, "w") as f:
+        for T in Tcw_list:
+            Rwc, twc = _rwc_twc(T)
+            vals = []
+            for r in range(3):
+                vals += [Rwc[r, 0], Rwc[r, 1], Rwc[r, 2], twc[r]]
+            f.write(" ".join(_fx(v, 9) for v in vals) + "\n")
+
+
+def _read_mask(path):
+    from PIL import Image   # cv::imread(path, -1): unchanged bit depth / channels
+    if not os.path.exists(path):
+        return np.zeros((0, 0), np.uint8)   # imread returns an empty Mat
+    return np.asarray(Image.open(path))
+
+
+def _read_semantic_dir(semanticpath, filename, valid, prob_threshold, remap_63):
+    out = []
+    txt = os.path.join(semanticpath, filename + ".txt")
+    if not os.path.exists(txt):
+        return out
+    with open(txt) as f:
+        for line in f.read().split("\n"):
+            if not line:
+                continue
+            tok = line.split()
+            label = int(tok[0])
+            if remap_63 and label == 63:   # src/Semantic.cc:75-78
+                label = 62
+            prob = float(np.float32(tok[1]))
+            if prob <= prob_threshold:
+                continue
+            x, y, w, h, inst = (int(v) for v in tok[2:7])
+            if label in valid:
+                out.append({"label": label, "prob": prob, "x": x, "y": y, "w": w, "h": h,
+                            "mask": _read_mask(os.path.join(semanticpath, "%d.png" % inst))})
+    return out
+
+
+def read_semantic_tum(path, timestamp, prob_threshold):
+    """Semantic::ReadSemanticTUMRGBD (src/Semantic.cc:59-96): directory `<path><to_string(timestamp)>/`, i.e. "%f"."""
+    name = "%f" % timestamp
+    return _read_semantic_dir(path + name, name, VALID_LABELS_TUM, prob_threshold, True)
+
+
+def read_semantic_kitti(path, kitti_id, prob_threshold):
+    """Semantic::ReadSemanticKittiStereo (src/Semantic.cc:14-57): directory `<path><%06d frame id>/`."""
+    name = "%06d" % kitti_id
+    return _read_semantic_dir(path + name, name, VALID_LABELS_KITTI, prob_threshold, False)
+
+
+def read_file_list(path):
+    """associate.py:50-69: `stamp d1 d2 ...` rows, '#' comments, commas / tabs as separators -> {stamp: [fields]}."""
+    out = {}
+    with open(path) as f:
+        for line in f.read().replace(",", " ").replace("\t", " ").split("\n"):
+            if len(line) > 0 and line[0] != "#":
+                v = [s.strip() for s in line.split(" ") if s.strip() != ""]
+                if len(v) > 1:
+                    out[float(v[0])] = v[1:]
+    return out
+
+
+def associate(first_stamps, second_stamps, offset=0.0, max_difference=0.02):
+    """associate.py:71-101: all pairs closer than max_difference, sorted by (difference, a, b), greedily matched;
+    result sorted by a.  Windowed candidate generation instead of the reference's n*m scan; same output."""
+    a = np.asarray(sorted(first_stamps), np.float64)
+    b = np.asarray(sorted(second_stamps), np.float64)
+    cand = []
+    lo = 0
+    for x in a:
+        while lo < len(b) and (b[lo] + offset) <= x - max_difference - 1e-9:
+            lo += 1
+        j = lo
+        while j < len(b) and (b[j] + offset) < x + max_difference + 1e-9:
+            d = abs(x - (b[j] + offset))
+            if d < max_difference:
+                cand.append((d, float(x), float(b[j])))
+            j += 1
+    cand.sort()
+    ua, ub, matches = set(), set(), []
+    for d, x, y in cand:
+        if x not in ua and y not in ub:
+            ua.add(x)
+            ub.add(y)
+            matches.append((x, y))
+    matches.sort()
+    return matches
+
+
+def align_horn(model, data):
+    """evaluate_ate.py:47-83: rigid alignment of model (3xn) onto data (3xn); returns rot, trans, per-point error."""
+    model = np.asarray(model, np.float64)
+    data = np.asarray(data, np.float64)
+    mz = model - model.mean(1, keepdims=True)
+    dz = data - data.mean(1, keepdims=True)
+    W = np.zeros((3, 3))
+    for c in range(model.shape[1]):
+        W += np.outer(mz[:, c], dz[:, c])
+    U, d, Vh = np.linalg.svd(W.T)
+    S = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vh) < 0:
+        S[2, 2] = -1
+    rot = U @ S @ Vh
+    trans = data.mean(1, keepdims=True) - rot @ model.mean(1, keepdims=True)
+    err = rot @ model + trans - data
+    return rot, trans, np.sqrt((err * err).sum(0))
+
+
+def evaluate_ate(gt_file, est_file, offset=0.0, scale=1.0, max_difference=0.02):
+    """evaluate_ate.py main (:118-161): associate ground truth (first) with the estimate (second), align the estimate
+    onto the ground truth, return the statistics it prints (rmse, mean, median, std, min, max) and the pair count."""
+    first, second = read_file_list(gt_file), read_file_list(est_file)
+    matches = associate(list(first.keys()), list(second.keys()), offset, max_difference)
+    if len(matches) < 2:
+        raise ValueError("Couldn't find matching timestamp pairs between groundtruth and estimated trajectory!")
+    first_xyz = np.array([[float(v) for v in first[a][0:3]] for a, _ in matches]).T
+    second_xyz = np.array([[float(v) * scale for v in second[b][0:3]] for _, b in matches]).T
+    _, _, e = align_horn(second_xyz, first_xyz)
+    return {"pairs": len(e), "rmse": float(np.sqrt(np.dot(e, e) / len(e))), "mean": float(e.mean()), "median": float(np.median(e)),
+            "std": float(e.std()), "min": float(e.min()), "max": float(e.max())}

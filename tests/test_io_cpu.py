@@ -1,0 +1,114 @@
+"""Host-side data formats: readers/writers against the reference's formats and shipped data rows."""
+import json
+import os
+
+import numpy as np
+
+from object_slam_amd import io as oio
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_load_associations_reference_rows():
+    rgb, dep, ts = oio.load_associations(os.path.join(G, "fr2_desk_head.txt"))
+    assert len(ts) == 8 and ts.dtype == np.float64
+    assert ts[0] == 1311868164.363181 and rgb[0] == "rgb/1311868164.363181.png" and dep[0] == "depth/1311868164.373557.png"
+    assert rgb[7].startswith("rgb/") and dep[7].startswith("depth/")
+
+
+def test_read_file_list_matches_reference_python():
+    gold = json.load(open(os.path.join(G, "io_golden.json")))["read_file_list"]
+    got = oio.read_file_list(os.path.join(G, "fr2_desk_head.txt"))
+    assert sorted([[k, v] for k, v in got.items()]) == gold
+
+
+def test_kitti_pose_reader_and_writer_roundtrip(tmp_path):
+    T = oio.load_kitti_poses(os.path.join(G, "kitti00_head.txt"))
+    assert T.shape == (3, 4, 4) and abs(T[1, 2, 3] - 8.586941e-01) < 1e-12 and np.all(T[:, 3] == [0, 0, 0, 1])
+    Tcw = [np.linalg.inv(t).astype(np.float32) for t in T]
+    p = tmp_path / "traj.txt"
+    oio.save_trajectory_kitti(str(p), Tcw)
+    back = oio.load_kitti_poses(str(p))
+    assert np.abs(back - T).max() < 1e-5
+    line = open(p).read().split("\n")[0].split(" ")
+    assert len(line) == 12 and all(len(v.split(".")[1]) == 9 for v in line)
+
+
+def test_tum_writer_known_answer(tmp_path):
+    # camera at (1, 2, 3), rotated 90 deg about z: Rwc = Rz(90)
+    Rwc = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+    twc = np.array([1, 2, 3], np.float32)
+    Tcw = np.eye(4, dtype=np.float32)
+    Tcw[:3, :3] = Rwc.T
+    Tcw[:3, 3] = -Rwc.T @ twc
+    p = tmp_path / "t.txt"
+    oio.save_trajectory_tum(str(p), [1311868164.363181, 1311868164.399026], [Tcw, Tcw], lost=[False, True])
+    rows = open(p).read().strip().split("\n")
+    assert rows == ["1311868164.363181 1.000000000 2.000000000 3.000000000 0.000000000 0.000000000 0.707106769 0.707106769"]
+    oio.save_keyframe_trajectory_tum(str(p), [0.5], [Tcw])
+    assert open(p).read() == "0.500000 1.0000000 2.0000000 3.0000000 0.0000000 0.0000000 0.7071068 0.7071068\n"
+
+
+def test_quaternion_branches():
+    for axis in range(3):   # 180 degree turns exercise the trace <= 0 branches of Eigen's conversion
+        R = -np.eye(3)
+        R[axis, axis] = 1
+        q = oio._quat_xyzw(R)
+        want = np.zeros(4, np.float32)
+        want[axis] = 1
+        assert np.allclose(q, want)
+    assert np.allclose(oio._quat_xyzw(np.eye(3)), [0, 0, 0, 1])
+
+
+def test_semantic_directory_reader(tmp_path):
+    from PIL import Image
+    ts = 1311868164.363181
+    d = tmp_path / ("%f" % ts)
+    d.mkdir()
+    mask = np.zeros((48, 64), np.uint8)
+    mask[10:20, 5:30] = 255
+    for inst in (0, 1, 2, 3):
+        Image.fromarray(mask).save(str(d / ("%d.png" % inst)))
+    (d / ("%f.txt" % ts)).write_text("63 0.95 5 10 25 10 0\n56 0.40 1 1 2 2 1\n7 0.99 1 1 2 2 2\n\n41 0.91 0 0 4 4 3\n")
+    sem = oio.read_semantic_tum(str(tmp_path) + "/", ts, 0.9)
+    assert [s["label"] for s in sem] == [62, 41]            # 63 -> 62; prob <= threshold and invalid labels dropped
+    assert sem[0]["mask"].shape == (48, 64) and sem[0]["mask"][12, 6] == 255 and sem[0]["mask"][0, 0] == 0
+    assert (sem[0]["x"], sem[0]["y"], sem[0]["w"], sem[0]["h"]) == (5, 10, 25, 10)
+    kd = tmp_path / "000007"
+    kd.mkdir()
+    Image.fromarray(mask).save(str(kd / "4.png"))
+    (kd / "000007.txt").write_text("2 0.8 1 2 3 4 4\n0 0.99 1 2 3 4 4\n")
+    semk = oio.read_semantic_kitti(str(tmp_path) + "/", 7, 0.5)
+    assert len(semk) == 1 and semk[0]["label"] == 2
+    assert oio.read_semantic_tum(str(tmp_path) + "/", 1.0, 0.9) == []
+
+
+def test_associate_equals_brute_force_and_ate(tmp_path):
+    rng = np.random.default_rng(3)
+    a = np.cumsum(rng.uniform(0.02, 0.05, 300))
+    b = a + rng.normal(0, 0.012, 300)
+    b = np.concatenate([b[::2], b[1::7] + 0.004])
+    pot = sorted((abs(x - y), x, y) for x in a for y in b if abs(x - y) < 0.02)
+    fa, fb, want = set(a), set(b), []
+    for d, x, y in pot:
+        if x in fa and y in fb:
+            fa.remove(x)
+            fb.remove(y)
+            want.append((x, y))
+    want.sort()
+    assert oio.associate(a, b) == want and len(want) > 100
+    # ATE of a rigidly moved + noisy copy
+    n = 200
+    ts = 100 + np.arange(n) * 0.033
+    gt = np.cumsum(rng.normal(0, 0.05, (n, 3)), 0)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    noise = rng.normal(0, 0.01, (n, 3))
+    est = (gt + noise) @ R.T + [3, -2, 1]
+    fg, fe = tmp_path / "gt.txt", tmp_path / "est.txt"
+    fg.write_text("# ground truth\n" + "\n".join("%.6f %.9f %.9f %.9f 0 0 0 1" % (t, *p) for t, p in zip(ts, gt)))
+    fe.write_text("\n".join("%.6f %.9f %.9f %.9f 0 0 0 1" % (t + 0.003, *p) for t, p in zip(ts, est)))
+    st = oio.evaluate_ate(str(fg), str(fe))
+    assert st["pairs"] == n and 0.012 < st["rmse"] < 0.02 and st["min"] <= st["median"] <= st["max"]
+    from object_slam_amd.e2e import horn_align_ate
+    assert abs(horn_align_ate(est, gt) - st["rmse"]) < 1e-6
