@@ -239,7 +239,7 @@ def main():
                 "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * world * args.steps / elapsed / 1e9, 1)}
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0, N=1 only (bounded sample)
         ns = min(args.cpu_sample, B)
         v, dt = cpu_baseline(frames, offs, ns)
         cpu = {"value": round(v, 2), "unit": "frames/s", "cores": 1, "kind": "port",
@@ -314,6 +314,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu, "extras": extras}
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()   # ranks leave together (rank 0 runs the profiling passes alone)
         dist.destroy_process_group()
 
 
