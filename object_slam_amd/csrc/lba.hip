@@ -582,6 +582,9 @@ struct LbaWide {
     double* partS;   // [nblk_pt + 1] scale partials (last = poses)
     double* partM;   // [nblk_pt] max |Hll diag|
     int nblk_pt;
+    const int2* pairs;        // (edge in pose a, edge in pose b) of every point both poses see, grouped by Schur block, point order
+    const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
+    double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
 };
 
 constexpr int kWPt = 128;   // threads per block of the per-point kernels
@@ -781,6 +784,36 @@ __global__ __launch_bounds__(64) void k_w_ctrlA(const LbaProblem* probs, LbaWide
     ct->qmax = 0;
 }
 
+// W_e = B_e (Hll_p + lambda I)^-1 for every active edge of a free keyframe: one inversion per edge instead of one per
+// (block, edge) pair inside the Schur kernel
+__global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, LbaWide w) {
+    const LbaProblem& pr = probs[0];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= pr.E || pr.level[e] != 0 || w.blk[pr.e_kf[e]] < 0) return;
+    const double lambda = ct->lambda;
+    const int p = pr.e_pt[e];
+    double D[9], Di[9];
+    const double* H = pr.Hll + (long long)p * 9;
+#pragma unroll
+    for (int i = 0; i < 9; i++) D[i] = H[i];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    inv3(D, Di);
+    const double* Ba = pr.Hpl + (long long)e * 18;
+    double* We = w.W + (long long)e * 18;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
+        We[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
+        We[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
+        We[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+    }
+}
+
+// Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
+// wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
+// rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, LbaWide w) {
     const LbaProblem& pr = probs[0];
     const LbaCtrl* ct = w.ct;
@@ -792,87 +825,96 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, LbaWide
     int ba = 0, rem = t;
     while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
     const int bb = ba + rem;
-    const int a = w.free_pose[ba], b2 = w.free_pose[bb];
+    const int a = w.free_pose[ba];
+    const bool diag = ba == bb;
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
     double bsv[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
-        const int e = pr.pose_edges[q];
-        if (pr.level[e] != 0) continue;
-        const int p = pr.e_pt[e];
-        int e2 = -1;
-        if (a == b2) e2 = e;
-        else
-            for (int c2 = pr.pt_start[p]; c2 < pr.pt_start[p + 1]; c2++)
-                if (pr.e_kf[c2] == b2) { e2 = c2; break; }
-        if (e2 < 0 || pr.level[e2] != 0) continue;
-        const double* Ba = pr.Hpl + (long long)e * 18;
-        const double* Bb = pr.Hpl + (long long)e2 * 18;
-        double D[9], Di[9];
-        const double* H = pr.Hll + (long long)p * 9;
+    for (int q = w.pair_start[t] + lane; q < w.pair_start[t + 1]; q += 64) {
+        const int2 pe = w.pairs[q];
+        if (pr.level[pe.x] != 0 || pr.level[pe.y] != 0) continue;
+        const double* Wa = w.W + (long long)pe.x * 18;
+        const double* Bb = pr.Hpl + (long long)pe.y * 18;
+        double BD[18], B2[18];
 #pragma unroll
-        for (int i = 0; i < 9; i++) D[i] = H[i];
-        D[0] += lambda; D[4] += lambda; D[8] += lambda;
-        inv3(D, Di);
-        double BD[18];
+        for (int i = 0; i < 18; i++) { BD[i] = Wa[i]; B2[i] = Bb[i]; }
+        if (diag) {
+            const double* bl = pr.bl + (long long)pr.e_pt[pe.x] * 3;
+            const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
-            BD[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
-            BD[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
-            BD[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
-        }
-        if (a == b2) {
-            const double* bl = pr.bl + p * 3;
-            double db[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++) db[i] = Di[i * 3] * bl[0] + Di[i * 3 + 1] * bl[1] + Di[i * 3 + 2] * bl[2];
-#pragma unroll
-            for (int i = 0; i < 6; i++) bsv[i] += Ba[i * 3] * db[0] + Ba[i * 3 + 1] * db[1] + Ba[i * 3 + 2] * db[2];
+            for (int i = 0; i < 6; i++) bsv[i] += BD[i * 3] * l0 + BD[i * 3 + 1] * l1 + BD[i * 3 + 2] * l2;
         }
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
             for (int j = 0; j < 6; j++)
-                acc[i * 6 + j] += BD[i * 3] * Bb[j * 3] + BD[i * 3 + 1] * Bb[j * 3 + 1] + BD[i * 3 + 2] * Bb[j * 3 + 2];
+                acc[i * 6 + j] += BD[i * 3] * B2[j * 3] + BD[i * 3 + 1] * B2[j * 3 + 1] + BD[i * 3 + 2] * B2[j * 3 + 2];
     }
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = wsum(acc[i]);
-    if (a == b2) {
+    if (diag) {
 #pragma unroll
         for (int i = 0; i < 6; i++) bsv[i] = wsum(bsv[i]);
     }
-    if (lane == 0) {
-        for (int i = 0; i < 6; i++)
-            for (int j = 0; j < 6; j++) {
-                double v = -acc[i * 6 + j];
-                if (a == b2) v += pr.Hpp[a * 36 + i * 6 + j] + (i == j ? lambda : 0.0);
-                pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
-            }
-        if (a == b2)
-            for (int i = 0; i < 6; i++) pr.Hs[(size_t)(6 * ba + i) * ld + n] = pr.bp[a * 6 + i] - bsv[i];
+    // lanes 0..35 write one entry each (36 stores in parallel instead of a serial loop on lane 0)
+    double mine = 0;
+#pragma unroll
+    for (int i = 0; i < 36; i++) mine = lane == i ? acc[i] : mine;
+    if (lane < 36) {
+        const int i = lane / 6, j = lane - i * 6;
+        double v = -mine;
+        if (diag) v += pr.Hpp[a * 36 + lane] + (i == j ? lambda : 0.0);
+        pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
+    }
+    if (diag) {
+        double bm = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) bm = lane == i ? bsv[i] : bm;
+        if (lane < 6) pr.Hs[(size_t)(6 * ba + lane) * ld + n] = pr.bp[a * 6 + lane] - bm;
     }
 }
 
-// blocked Cholesky + back substitution of the reduced camera system (one workgroup)
+// Blocked Cholesky (U^T U, 6-wide panels) + back substitution of the reduced camera system, one workgroup.
+// LDS_RESIDENT: the whole augmented system [n][n+1] fp64 is staged into LDS once (n <= kCholLdsN: 20 free keyframes
+// = 116 KB of the CU's 160 KB), so the 2 barriers per panel and the n sequential back-substitution steps run at
+// LDS latency instead of HBM latency; larger systems work in place in global memory (L2 resident).
+// Pivot rows are scaled by one reciprocal per pivot (1 sqrt + 1 div on the critical path instead of 1 + 5).
+constexpr int kCholLdsN = 132;   // 132*133*8 = 140 448 B
+
+template <bool LDS_RESIDENT>
 __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWide w) {
     const LbaProblem& pr = probs[0];
     LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n = ct->n, ld = n + 1;
+    extern __shared__ __align__(16) double s_A[];
     __shared__ int s_ok;
     __shared__ double xs[6 * kLbaMaxKF];
+    __shared__ double rdiag[LDS_RESIDENT ? kCholLdsN : 6 * kLbaMaxKF];
+    if (LDS_RESIDENT && n > kCholLdsN) {   // host launches <true> only when 6*nfree fits; never index past the LDS image
+        if (tid == 0) ct->ok2 = 0;
+        for (int i = tid; i < n; i += 1024) pr.xp[i] = 0;
+        return;
+    }
+    // compile-time address space: ds_* for the LDS image, global_* otherwise (a runtime-selected generic pointer
+    // would turn every access into a flat op that waits on both counters)
+    auto A = [&](size_t idx) -> double& {
+        if constexpr (LDS_RESIDENT) return s_A[idx];
+        else return pr.Hs[idx];
+    };
     if (tid == 0) s_ok = 1;
+    if (LDS_RESIDENT)
+        for (int i = tid; i < n * ld; i += 1024) s_A[i] = pr.Hs[i];
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += 6) {
         if (wv == 0) {
-            double Dg[36];
+            double Dg[36], rinv[6];
 #pragma unroll
             for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? pr.Hs[(size_t)(j0 + i) * ld + j0 + k] : 0.0;
+                for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? A((size_t)(j0 + i) * ld + j0 + k) : 0.0;
             bool good = true;
 #pragma unroll
             for (int j = 0; j < 6; j++) {
@@ -880,8 +922,9 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
                 if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
                 d = sqrt(d);
                 Dg[j * 6 + j] = d;
+                rinv[j] = 1.0 / d;
 #pragma unroll
-                for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] /= d;
+                for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] *= rinv[j];
 #pragma unroll
                 for (int i = j + 1; i < 6; i++)
 #pragma unroll
@@ -891,20 +934,20 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
             for (int k = j0 + 6 + lane; k <= n; k += 64) {
                 double col[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) col[i] = pr.Hs[(size_t)(j0 + i) * ld + k];
+                for (int i = 0; i < 6; i++) col[i] = A((size_t)(j0 + i) * ld + k);
 #pragma unroll
                 for (int j = 0; j < 6; j++) {
                     double sv = col[j];
 #pragma unroll
                     for (int i = 0; i < j; i++) sv -= Dg[i * 6 + j] * col[i];
-                    col[j] = sv / Dg[j * 6 + j];
+                    col[j] = sv * rinv[j];
                 }
 #pragma unroll
-                for (int i = 0; i < 6; i++) pr.Hs[(size_t)(j0 + i) * ld + k] = col[i];
+                for (int i = 0; i < 6; i++) A((size_t)(j0 + i) * ld + k) = col[i];
             }
             if (lane < 36) {
                 const int r = lane / 6, cc = lane % 6;
-                if (cc >= r) pr.Hs[(size_t)(j0 + r) * ld + j0 + cc] = Dg[lane];
+                if (cc >= r) A((size_t)(j0 + r) * ld + j0 + cc) = Dg[lane];
             }
         }
         __syncthreads();
@@ -913,23 +956,30 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
             const int i = j0 + 6 + ii;
             double pi[6];
 #pragma unroll
-            for (int r = 0; r < 6; r++) pi[r] = pr.Hs[(size_t)(j0 + r) * ld + i];
+            for (int r = 0; r < 6; r++) pi[r] = A((size_t)(j0 + r) * ld + i);
             for (int k = i + lane; k <= n; k += 64) {
                 double sv = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++) sv += pi[r] * pr.Hs[(size_t)(j0 + r) * ld + k];
-                pr.Hs[(size_t)i * ld + k] -= sv;
+                for (int r = 0; r < 6; r++) sv += pi[r] * A((size_t)(j0 + r) * ld + k);
+                A((size_t)i * ld + k) -= sv;
             }
         }
         __syncthreads();
     }
     const bool ok2 = s_ok != 0;
     if (wv == 0 && ok2) {
+        // U x = y, column oriented: x_i = y_i / U_ii, then y_k -= U_ki x_i for k < i (no reduction on the critical path)
+        for (int i = lane; i < n; i += 64) { xs[i] = A((size_t)i * ld + n); rdiag[i] = 1.0 / A((size_t)i * ld + i); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (int i = n - 1; i >= 0; i--) {
-            double sv = 0;
-            for (int k = i + 1 + lane; k < n; k += 64) sv += pr.Hs[(size_t)i * ld + k] * xs[k];
-            sv = wsum(sv);
-            if (lane == 0) xs[i] = (pr.Hs[(size_t)i * ld + n] - sv) / pr.Hs[(size_t)i * ld + i];
+            const double xi = xs[i] * rdiag[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < i; k += 64) xs[k] -= A((size_t)k * ld + i) * xi;
+            if (lane == 0) xs[i] = xi;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         for (int i = lane; i < n; i += 64) pr.xp[i] = xs[i];
     }
@@ -1136,6 +1186,7 @@ struct oslam_lba {
     // wide mode (batch 1)
     LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
     double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
+    double* d_W = nullptr; int2* d_pairs = nullptr; size_t pairs_cap = 0; int* d_pair_start = nullptr;
     int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
     std::vector<LbaProblem> host_probs;           // batch mode: prepared problems
     std::vector<std::vector<int>> orders;         // batch mode: edge permutation of every slot
@@ -1153,6 +1204,7 @@ void oslam_lba_destroy(oslam_lba_t* h) {
     if (h->d_probs) (void)hipFree(h->d_probs);
     if (h->h_stop) (void)hipHostFree(h->h_stop);
     if (h->h_done) (void)hipHostFree(h->h_done);
+    if (h->d_pairs) (void)hipFree(h->d_pairs);
     delete h;
 }
 
@@ -1199,8 +1251,9 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     {
         const size_t nb = (P + kWPt - 1) / kWPt + 2;
         h->d_ctrl = (LbaCtrl*)alloc(sizeof(LbaCtrl)); h->d_T2 = (SE3*)alloc(sizeof(SE3) * 2 * K); h->d_R2 = (double*)alloc(8 * 18 * K);
+        h->d_W = (double*)alloc(8 * 18 * E); h->d_pair_start = (int*)alloc(4 * (K * (K + 1) / 2 + 1));
         h->d_blk = (int*)alloc(4 * K); h->d_free = (int*)alloc(4 * K); h->d_partF = (double*)alloc(8 * nb); h->d_partS = (double*)alloc(8 * nb); h->d_partM = (double*)alloc(8 * nb);
-        if (!h->d_ctrl || !h->d_T2 || !h->d_R2 || !h->d_blk || !h->d_free || !h->d_partF || !h->d_partS || !h->d_partM ||
+        if (!h->d_W || !h->d_pair_start || !h->d_ctrl || !h->d_T2 || !h->d_R2 || !h->d_blk || !h->d_free || !h->d_partF || !h->d_partS || !h->d_partM ||
             hipHostMalloc((void**)&h->h_done, sizeof(int), 0) != hipSuccess) {
             set_error("LBA wide-mode allocation failed");
             oslam_lba_destroy(h);
@@ -1210,6 +1263,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     OSLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0));
     h->lds = kRowBufBytes + 64;
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)));
     *out = h;
     return OSLAM_OK;
 }
@@ -1329,6 +1383,45 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         int nfree = 0;
         for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
         const int nblk = std::max(1, nfree * (nfree + 1) / 2);
+        {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
+            std::vector<int> blk(nKF);
+            for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
+            auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
+            std::vector<int> pstart(nblk + 1, 0);
+            for (int p = 0; p < nP; p++)
+                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                    const int bi = blk[ekf[i]];
+                    if (bi < 0) continue;
+                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                        const int bj = blk[ekf[j]];
+                        if (bj >= bi) pstart[tof(bi, bj) + 1]++;
+                    }
+                }
+            for (int t2 = 0; t2 < nblk; t2++) pstart[t2 + 1] += pstart[t2];
+            const size_t npairs = (size_t)pstart[nblk];
+            std::vector<int2> pairs(npairs ? npairs : 1);
+            std::vector<int> cur(pstart.begin(), pstart.end() - 1);
+            for (int p = 0; p < nP; p++)
+                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                    const int bi = blk[ekf[i]];
+                    if (bi < 0) continue;
+                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                        const int bj = blk[ekf[j]];
+                        if (bj >= bi) pairs[cur[tof(bi, bj)]++] = make_int2(i, j);
+                    }
+                }
+            if (npairs > h->pairs_cap) {
+                if (h->d_pairs) (void)hipFree(h->d_pairs);
+                h->d_pairs = nullptr; h->pairs_cap = 0;
+                const size_t cap = npairs + npairs / 2 + 1024;
+                OSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pairs, cap * sizeof(int2)));
+                h->pairs_cap = cap;
+            }
+            if (npairs) OSLAM_HIP_CHECK(hipMemcpy(h->d_pairs, pairs.data(), npairs * sizeof(int2), hipMemcpyHostToDevice));
+            OSLAM_HIP_CHECK(hipMemcpy(h->d_pair_start, pstart.data(), (size_t)(nblk + 1) * 4, hipMemcpyHostToDevice));
+            w.pairs = h->d_pairs; w.pair_start = h->d_pair_start; w.W = h->d_W;
+        }
+        const size_t chol_lds = 6 * nfree <= kCholLdsN ? (size_t)(6 * nfree) * (6 * nfree + 1) * sizeof(double) : 0;
         hipStream_t st = nullptr;
         hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
         // worst case 15 iterations x 10 trials; slots past `done` return at once
@@ -1341,8 +1434,10 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
                 hipLaunchKernelGGL(k_w_lin_pt, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_lin_pose, dim3(nKF), dim3(64), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_ctrlA, dim3(1), dim3(64), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_schur, dim3(nblk), dim3(64), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_chol, dim3(1), dim3(1024), 0, st, h->d_probs, w);
+                if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1), dim3(1024), chol_lds, st, h->d_probs, w);
+                else hipLaunchKernelGGL(k_w_chol<false>, dim3(1), dim3(1024), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_update, dim3(w.nblk_pt + 1), dim3(kWPt), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_eval, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1), dim3(64), 0, st, h->d_probs, w);
