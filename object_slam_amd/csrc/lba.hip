@@ -13,6 +13,7 @@
 //   * reduced camera system                 : blocked (6-wide) Cholesky U^T U with the right-hand
 //     side carried as an extra column, back-substitution by one wavefront.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #include <algorithm>
@@ -633,7 +634,13 @@ __global__ __launch_bounds__(256) void k_w_gate(const LbaProblem* probs, LbaWide
     if (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) pr.level[e] = 1;
 }
 
-__global__ __launch_bounds__(kWPt) void k_w_lin_pt(const LbaProblem* probs, LbaWide w) {
+// Linearisation of one LM iteration in ONE launch: blocks [0, nblk_pt) own kWPt landmarks each (4 lanes per landmark
+// split its edge list, combined by a fixed xor-shuffle tree: Hll, bl, Hpl blocks, robust chi2 partial), blocks
+// [nblk_pt, nblk_pt + K) own one keyframe each (8 wavefronts split its edge list: Hpp, bp).  Both roles are independent,
+// so they overlap instead of running back to back.
+constexpr int kLinThreads = 4 * kWPt;   // 512
+
+__global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, LbaWide w) {
     const LbaProblem& pr = probs[0];
     const LbaCtrl* ct = w.ct;
     if (ct->done || !ct->need_lin) return;
@@ -641,87 +648,90 @@ __global__ __launch_bounds__(kWPt) void k_w_lin_pt(const LbaProblem* probs, LbaW
     const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
     const double* X = w_X(pr, ct->cur);
-    const SE3* T = w.T + ct->cur * pr.K;
-    const double* Rm = w.R + (size_t)ct->cur * pr.K * 9;
-    const int p = blockIdx.x * kWPt + threadIdx.x;
-    double F0 = 0, dmax = 0;
-    if (p < pr.P) {
-        const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ double sF[kLinThreads / 64], sM[kLinThreads / 64], sAcc[kLinThreads / 64][27];
+    if ((int)blockIdx.x < w.nblk_pt) {
+        const SE3* T = w.T + ct->cur * pr.K;
+        const double* Rm = w.R + (size_t)ct->cur * pr.K * 9;
+        const int p = blockIdx.x * kWPt + (tid >> 2), sub = tid & 3;
+        double F0 = 0, dmax = 0;
         double hl[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
-        for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
-            if (pr.level[e] != 0) continue;
-            const int a = pr.e_kf[e];
-            const float ur = pr.e_obs[e * 3 + 2];
-            const bool stereo = !(ur < 0);
-            const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
-            const double info = (double)pr.e_info[e];
-            double pc[3], er[3], Jp[18], Jx[9];
-            se3_map(T[a], Xw, pc);
-            const double c2 = edge_error(cam, pc, ob, stereo, info, er);
-            pr.chi2[e] = c2;
-            double r0 = c2, wgt = 1.0;
-            if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
-            F0 += r0;
-            jac_binary(cam, pc, Rm + a * 9, stereo, Jp, Jx);
-            const double wi = wgt * info;
-            int k = 0;
+        if (p < pr.P) {
+            const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+            for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
+                if (pr.level[e] != 0) continue;
+                const int a = pr.e_kf[e];
+                const float ur = pr.e_obs[e * 3 + 2];
+                const bool stereo = !(ur < 0);
+                const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+                const double info = (double)pr.e_info[e];
+                double pc[3], er[3], Jp[18], Jx[9];
+                se3_map(T[a], Xw, pc);
+                const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+                pr.chi2[e] = c2;
+                double r0 = c2, wgt = 1.0;
+                if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
+                F0 += r0;
+                jac_binary(cam, pc, Rm + a * 9, stereo, Jp, Jx);
+                const double wi = wgt * info;
+                int k = 0;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                double sb = 0;
-                _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jx[d * 3 + i] * (info * er[d]);
-                bl[i] -= wgt * sb;
+                for (int i = 0; i < 3; i++) {
+                    double sb = 0;
+                    _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jx[d * 3 + i] * (info * er[d]);
+                    bl[i] -= wgt * sb;
 #pragma unroll
-                for (int j = i; j < 3; j++) {
-                    double sh = 0;
-                    _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
-                    hl[k++] += sh;
+                    for (int j = i; j < 3; j++) {
+                        double sh = 0;
+                        _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
+                        hl[k++] += sh;
+                    }
+                }
+                if (w.blk[a] >= 0) {
+                    double* B = pr.Hpl + (long long)e * 18;
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) {
+                            double sh = 0;
+                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
+                            B[i * 3 + j] = sh;
+                        }
                 }
             }
-            if (w.blk[a] >= 0) {
-                double* B = pr.Hpl + (long long)e * 18;
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        double sh = 0;
-                        _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
-                        B[i * 3 + j] = sh;
-                    }
-            }
         }
-        double* H = pr.Hll + (long long)p * 9;
-        H[0] = hl[0]; H[1] = hl[1]; H[2] = hl[2]; H[3] = hl[1]; H[4] = hl[3]; H[5] = hl[4]; H[6] = hl[2]; H[7] = hl[4]; H[8] = hl[5];
-        pr.bl[p * 3] = bl[0]; pr.bl[p * 3 + 1] = bl[1]; pr.bl[p * 3 + 2] = bl[2];
-        dmax = fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5])));
+        // the 4 lanes of a landmark: (s0 + s1) + (s2 + s3)
+#pragma unroll
+        for (int k = 0; k < 6; k++) { hl[k] += __shfl_xor(hl[k], 1, 64); hl[k] += __shfl_xor(hl[k], 2, 64); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { bl[k] += __shfl_xor(bl[k], 1, 64); bl[k] += __shfl_xor(bl[k], 2, 64); }
+        F0 += __shfl_xor(F0, 1, 64); F0 += __shfl_xor(F0, 2, 64);
+        if (p < pr.P && sub == 0) {
+            double* H = pr.Hll + (long long)p * 9;
+            H[0] = hl[0]; H[1] = hl[1]; H[2] = hl[2]; H[3] = hl[1]; H[4] = hl[3]; H[5] = hl[4]; H[6] = hl[2]; H[7] = hl[4]; H[8] = hl[5];
+            pr.bl[p * 3] = bl[0]; pr.bl[p * 3 + 1] = bl[1]; pr.bl[p * 3 + 2] = bl[2];
+            dmax = fmax(fabs(hl[0]), fmax(fabs(hl[3]), fabs(hl[5])));
+        }
+        if (sub != 0) F0 = 0;
+        const double f = wsum(F0), m = wmax(dmax);
+        if (lane == 0) { sF[wv] = f; sM[wv] = m; }
+        __syncthreads();
+        if (tid == 0) {
+            double a = sF[0], bm = sM[0];
+            for (int i = 1; i < kLinThreads / 64; i++) { a += sF[i]; bm = fmax(bm, sM[i]); }
+            w.partF[blockIdx.x] = a;
+            w.partM[blockIdx.x] = bm;
+        }
+        return;
     }
-    __shared__ double sF[kWPt / 64], sM[kWPt / 64];
-    const double f = wsum(F0), m = wmax(dmax);
-    if ((threadIdx.x & 63) == 0) { sF[threadIdx.x >> 6] = f; sM[threadIdx.x >> 6] = m; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = sF[0], bm = sM[0];
-        for (int i = 1; i < kWPt / 64; i++) { a += sF[i]; bm = fmax(bm, sM[i]); }
-        w.partF[blockIdx.x] = a;
-        w.partM[blockIdx.x] = bm;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_w_lin_pose(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
-    const LbaCtrl* ct = w.ct;
-    if (ct->done || !ct->need_lin) return;
-    const int a = blockIdx.x, lane = threadIdx.x;
+    const int a = (int)blockIdx.x - w.nblk_pt;
     if (a >= pr.K || w.blk[a] < 0) return;
-    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
-    const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
-    const bool robust = ct->robust != 0;
-    const double* X = w_X(pr, ct->cur);
     const SE3 Ta = w.T[ct->cur * pr.K + a];
     const double* Ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) acc[k] = 0;
-    for (int q = pr.pose_start[a] + lane; q < pr.pose_start[a + 1]; q += 64) {
+    for (int q = pr.pose_start[a] + tid; q < pr.pose_start[a + 1]; q += kLinThreads) {
         const int e = pr.pose_edges[q];
         if (pr.level[e] != 0) continue;
         const int p = pr.e_pt[e];
@@ -752,14 +762,23 @@ __global__ __launch_bounds__(64) void k_w_lin_pose(const LbaProblem* probs, LbaW
         }
     }
 #pragma unroll
-    for (int k = 0; k < 27; k++) acc[k] = wsum(acc[k]);
-    if (lane == 0) {
-        double* H = pr.Hpp + a * 36;
-        int k = 0;
-        for (int i = 0; i < 6; i++)
-            for (int j = i; j < 6; j++) { H[i * 6 + j] = acc[k]; H[j * 6 + i] = acc[k]; k++; }
-        for (int i = 0; i < 6; i++) pr.bp[a * 6 + i] = acc[21 + i];
+    for (int k = 0; k < 27; k++) {
+        const double sv = wsum(acc[k]);
+        if (lane == 0) sAcc[wv][k] = sv;
     }
+    __syncthreads();
+    if (tid < 27) {
+        double sv = sAcc[0][tid];
+        for (int i = 1; i < kLinThreads / 64; i++) sv += sAcc[i][tid];
+        sAcc[0][tid] = sv;
+    }
+    __syncthreads();
+    if (tid < 36) {
+        const int i = tid / 6, j = tid - i * 6;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        pr.Hpp[a * 36 + tid] = sAcc[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    }
+    if (tid < 6) pr.bp[a * 6 + tid] = sAcc[0][21 + tid];
 }
 
 // after linearisation: F0 and (first iteration) lambda = 1e-5 * max diag
@@ -884,6 +903,9 @@ constexpr int kCholLdsN = 132;   // 132*133*8 = 140 448 B
 
 template <bool LDS_RESIDENT>
 __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWide w) {
+    // dense solve of the reduced system: fused multiply-adds allowed here (the reference factors this matrix with a
+    // different algorithm anyway, Eigen LDLT inside g2o; the rest of the library stays -ffp-contract=off)
+#pragma clang fp contract(fast)
     const LbaProblem& pr = probs[0];
     LbaCtrl* ct = w.ct;
     if (ct->done) return;
@@ -892,7 +914,7 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
     extern __shared__ __align__(16) double s_A[];
     __shared__ int s_ok;
     __shared__ double xs[6 * kLbaMaxKF];
-    __shared__ double rdiag[LDS_RESIDENT ? kCholLdsN : 6 * kLbaMaxKF];
+    __shared__ double rdiag[LDS_RESIDENT ? 1 : 6 * kLbaMaxKF];
     if (LDS_RESIDENT && n > kCholLdsN) {   // host launches <true> only when 6*nfree fits; never index past the LDS image
         if (tid == 0) ct->ok2 = 0;
         for (int i = tid; i < n; i += 1024) pr.xp[i] = 0;
@@ -904,85 +926,167 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
         if constexpr (LDS_RESIDENT) return s_A[idx];
         else return pr.Hs[idx];
     };
+#ifdef OSLAM_LBA_PROFILE
+    long long tw_ = wall_clock64();
+#define CH_STAMP(i) do { if (tid == 0) { const long long t_ = wall_clock64(); pr.stats[8 + (i)] += (int)(t_ - tw_); tw_ = t_; } } while (0)
+#else
+#define CH_STAMP(i) do { } while (0)
+#endif
     if (tid == 0) s_ok = 1;
     if (LDS_RESIDENT)
         for (int i = tid; i < n * ld; i += 1024) s_A[i] = pr.Hs[i];
     __syncthreads();
-    for (int j0 = 0; j0 < n; j0 += 6) {
-        if (wv == 0) {
-            double Dg[36], rinv[6];
+    CH_STAMP(0);
+    // factor the 6x6 diagonal block at j0 and scale its row panel (columns j0+6 .. n): one wavefront
+    auto factor_panel = [&](int j0) {
+        double Dg[36], rinv[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++)
+        for (int i = 0; i < 6; i++)
 #pragma unroll
-                for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? A((size_t)(j0 + i) * ld + j0 + k) : 0.0;
-            bool good = true;
+            for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? A((size_t)(j0 + i) * ld + j0 + k) : 0.0;
+        bool good = true;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double d = Dg[j * 6 + j];
+            if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
+            const double r = rsqrt(d);      // one transcendental on the critical path; pivot = d * d^-1/2
+            rinv[j] = r;
+            Dg[j * 6 + j] = d * r;
+#pragma unroll
+            for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] *= r;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++)
+#pragma unroll
+                for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
+        }
+        if (!good && lane == 0) s_ok = 0;
+        for (int k = j0 + 6 + lane; k <= n; k += 64) {
+            double col[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) col[i] = A((size_t)(j0 + i) * ld + k);
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                double d = Dg[j * 6 + j];
-                if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
-                d = sqrt(d);
-                Dg[j * 6 + j] = d;
-                rinv[j] = 1.0 / d;
+                double sv = col[j];
 #pragma unroll
-                for (int k = j + 1; k < 6; k++) Dg[j * 6 + k] *= rinv[j];
-#pragma unroll
-                for (int i = j + 1; i < 6; i++)
-#pragma unroll
-                    for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
+                for (int i = 0; i < j; i++) sv -= Dg[i * 6 + j] * col[i];
+                col[j] = sv * rinv[j];
             }
-            if (!good && lane == 0) s_ok = 0;
-            for (int k = j0 + 6 + lane; k <= n; k += 64) {
-                double col[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) col[i] = A((size_t)(j0 + i) * ld + k);
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    double sv = col[j];
-#pragma unroll
-                    for (int i = 0; i < j; i++) sv -= Dg[i * 6 + j] * col[i];
-                    col[j] = sv * rinv[j];
-                }
-#pragma unroll
-                for (int i = 0; i < 6; i++) A((size_t)(j0 + i) * ld + k) = col[i];
-            }
-            if (lane < 36) {
-                const int r = lane / 6, cc = lane % 6;
-                if (cc >= r) A((size_t)(j0 + r) * ld + j0 + cc) = Dg[lane];
-            }
+            for (int i = 0; i < 6; i++) A((size_t)(j0 + i) * ld + k) = col[i];
         }
-        __syncthreads();
-        const int m = n - (j0 + 6);
-        for (int ii = wv; ii < m; ii += 16) {
-            const int i = j0 + 6 + ii;
-            double pi[6];
+        // static-index select: a dynamic Dg[lane] would push the whole block into scratch memory
+        double mine = 0;
 #pragma unroll
-            for (int r = 0; r < 6; r++) pi[r] = A((size_t)(j0 + r) * ld + i);
-            for (int k = i + lane; k <= n; k += 64) {
+        for (int q = 0; q < 36; q++) mine = lane == q ? Dg[q] : mine;
+        if (lane < 36) {
+            const int r = lane / 6, cc = lane % 6;
+            if (cc >= r) A((size_t)(j0 + r) * ld + j0 + cc) = mine;
+        }
+    };
+    // NR rows of the trailing matrix (i0 .. i0+NR-1, columns >= kmin) minus the contribution of panel j0, one wavefront;
+    // the rows are independent, so their load -> fma -> store chains overlap
+    auto update_rows = [&](int j0, int i0, int kmin, auto nr_tag) {
+        constexpr int NR = decltype(nr_tag)::value;
+        double P[NR][6];
+#pragma unroll
+        for (int ii = 0; ii < NR; ii++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) P[ii][r] = A((size_t)(j0 + r) * ld + i0 + ii);
+        for (int k = kmin + lane; k <= n; k += 64) {
+            double cpan[6], tv[NR];
+#pragma unroll
+            for (int r = 0; r < 6; r++) cpan[r] = A((size_t)(j0 + r) * ld + k);
+#pragma unroll
+            for (int ii = 0; ii < NR; ii++) tv[ii] = A((size_t)(i0 + ii) * ld + k);
+#pragma unroll
+            for (int ii = 0; ii < NR; ii++) {
                 double sv = 0;
 #pragma unroll
-                for (int r = 0; r < 6; r++) sv += pi[r] * A((size_t)(j0 + r) * ld + k);
-                A((size_t)i * ld + k) -= sv;
+                for (int r = 0; r < 6; r++) sv += P[ii][r] * cpan[r];
+                A((size_t)(i0 + ii) * ld + k) = tv[ii] - sv;
             }
+        }
+    };
+    if (wv == 0 && n > 0) factor_panel(0);
+    __syncthreads();
+    CH_STAMP(1);
+    // look-ahead: wavefront 0 updates the next panel's six rows first and factors that panel while the other 15
+    // wavefronts finish the trailing update, so each step costs max(panel, trailing) and one barrier
+    for (int j0 = 0; j0 + 6 < n; j0 += 6) {
+        if (wv == 0) {
+            update_rows(j0, j0 + 6, j0 + 6, std::integral_constant<int, 6>());
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            factor_panel(j0 + 6);
+        } else {
+            for (int i0 = j0 + 12 + 3 * (wv - 1); i0 < n; i0 += 45) update_rows(j0, i0, i0, std::integral_constant<int, 3>());
         }
         __syncthreads();
     }
+    CH_STAMP(2);
     const bool ok2 = s_ok != 0;
     if (wv == 0 && ok2) {
         // U x = y, column oriented: x_i = y_i / U_ii, then y_k -= U_ki x_i for k < i (no reduction on the critical path)
-        for (int i = lane; i < n; i += 64) { xs[i] = A((size_t)i * ld + n); rdiag[i] = 1.0 / A((size_t)i * ld + i); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int i = n - 1; i >= 0; i--) {
-            const double xi = xs[i] * rdiag[i];
+        if (LDS_RESIDENT) {
+            // y and 1/U_ii live in registers (lane l holds entries l, l+64, l+128); x_i is broadcast by readlane and the
+            // next column of U is fetched while the current one is applied
+            double y0 = 0, y1 = 0, y2 = 0, r0 = 0, r1 = 0, r2 = 0;
+            if (lane < n) { y0 = A((size_t)lane * ld + n); r0 = 1.0 / A((size_t)lane * ld + lane); }
+            if (lane + 64 < n) { y1 = A((size_t)(lane + 64) * ld + n); r1 = 1.0 / A((size_t)(lane + 64) * ld + lane + 64); }
+            if (lane + 128 < n) { y2 = A((size_t)(lane + 128) * ld + n); r2 = 1.0 / A((size_t)(lane + 128) * ld + lane + 128); }
+            auto bcast = [&](double v, int src) -> double {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+                return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            };
+            // One loop per 64-entry segment so the segment is a compile-time constant (no selects between registers),
+            // unconditional loads from clamped rows (no exec-masked branches), and the raw column loaded in step i is
+            // masked and consumed in step i-1, a full iteration after its ds_read was issued.
+            const int row0 = min(lane, n - 1), row1 = min(lane + 64, n - 1), row2 = min(lane + 128, n - 1);
+            double v0 = 0, v1 = 0, v2 = 0;   // raw U(row, i) of the column about to be applied
+            if (n > 0) { v0 = A((size_t)row0 * ld + n - 1); v1 = A((size_t)row1 * ld + n - 1); v2 = A((size_t)row2 * ld + n - 1); }
+            auto run = [&](auto seg_tag, int ihi, int ilo) {
+                constexpr int S = decltype(seg_tag)::value;
+                for (int i = ihi; i >= ilo; i--) {
+                    const int inext = i > 0 ? i - 1 : 0;
+                    const double w0 = A((size_t)row0 * ld + inext);
+                    double w1 = 0, w2 = 0;
+                    if (S >= 1) w1 = A((size_t)row1 * ld + inext);
+                    if (S >= 2) w2 = A((size_t)row2 * ld + inext);
+                    const int src = i & 63;
+                    const double xi = bcast(S == 0 ? y0 : S == 1 ? y1 : y2, src) * bcast(S == 0 ? r0 : S == 1 ? r1 : r2, src);
+                    y0 -= (lane < i ? v0 : 0.0) * xi;
+                    if (S >= 1) y1 -= (lane + 64 < i ? v1 : 0.0) * xi;
+                    if (S >= 2) y2 -= (lane + 128 < i ? v2 : 0.0) * xi;
+                    if (S == 0) y0 = lane == src ? xi : y0;
+                    if (S == 1) y1 = lane == src ? xi : y1;
+                    if (S == 2) y2 = lane == src ? xi : y2;
+                    v0 = w0; v1 = w1; v2 = w2;
+                }
+            };
+            if (n > 128) run(std::integral_constant<int, 2>(), n - 1, 128);
+            if (n > 64) run(std::integral_constant<int, 1>(), min(n - 1, 127), 64);
+            if (n > 0) run(std::integral_constant<int, 0>(), min(n - 1, 63), 0);
+            if (lane < n) pr.xp[lane] = y0;
+            if (lane + 64 < n) pr.xp[lane + 64] = y1;
+            if (lane + 128 < n) pr.xp[lane + 128] = y2;
+        } else {
+            for (int i = lane; i < n; i += 64) { xs[i] = A((size_t)i * ld + n); rdiag[i] = 1.0 / A((size_t)i * ld + i); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < i; k += 64) xs[k] -= A((size_t)k * ld + i) * xi;
-            if (lane == 0) xs[i] = xi;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int i = n - 1; i >= 0; i--) {
+                const double xi = xs[i] * rdiag[i];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < i; k += 64) xs[k] -= A((size_t)k * ld + i) * xi;
+                if (lane == 0) xs[i] = xi;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = lane; i < n; i += 64) pr.xp[i] = xs[i];
         }
-        for (int i = lane; i < n; i += 64) pr.xp[i] = xs[i];
     }
+    CH_STAMP(3);
     if (!ok2) for (int i = tid; i < n; i += 1024) pr.xp[i] = 0;
     if (tid == 0) ct->ok2 = ok2 ? 1 : 0;
 }
@@ -1431,8 +1535,7 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         while (slots_done < max_slots) {
             for (int sl = 0; sl < 4; sl++, slots_done++) {
                 hipLaunchKernelGGL(k_w_gate, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_lin_pt, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_lin_pose, dim3(nKF), dim3(64), 0, st, h->d_probs, w);
+                hipLaunchKernelGGL(k_w_lin, dim3(w.nblk_pt + nKF), dim3(kLinThreads), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_ctrlA, dim3(1), dim3(64), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_schur, dim3(nblk), dim3(64), 0, st, h->d_probs, w);
