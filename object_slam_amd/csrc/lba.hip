@@ -13,6 +13,7 @@
 //   * reduced camera system                 : blocked (6-wide) Cholesky U^T U with the right-hand
 //     side carried as an extra column, back-substitution by one wavefront.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <type_traits>
 #include <stdint.h>
 
@@ -570,6 +571,7 @@ struct LbaCtrl {
     int stage, iter, qmax, need_lin, gate, done, ok2, cur, robust, ok, early;
     int its[2], trials[2];
     int nfree, n;
+    int ticket[2];   // blocks finished in k_w_lin / k_w_eval: the last one runs the LM control step
     double lambda, ni, currentChi, rho;
 };
 
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide
         }
         ct->stage = 0; ct->iter = 0; ct->qmax = 0; ct->need_lin = 1; ct->gate = 0; ct->done = 0; ct->ok2 = 1; ct->cur = 0; ct->robust = pr.robust0; ct->ok = 1;
         ct->its[0] = ct->its[1] = ct->trials[0] = ct->trials[1] = 0;
+        ct->ticket[0] = ct->ticket[1] = 0;
         ct->nfree = nb; ct->n = 6 * nb;
         ct->lambda = 0; ct->ni = 2; ct->currentChi = 0; ct->rho = 0;
         ct->early = pr.stop ? (*pr.stop != 0) : 0;   // reference :655-657
@@ -613,25 +616,30 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide
         w.T[a] = se3_from_T(pr.poses + a * 16);
         se3_R(w.T[a], w.R + a * 9);
     }
-    for (int i = tid; i < pr.P * 3; i += 256) pr.Xa[i] = (double)pr.points[i];
-    for (int e = tid; e < pr.E; e += 256) { pr.level[e] = 0; pr.chi2[e] = 0; pr.erase[e] = 0; }
 }
 
-// gate observations after stage 0 (:672-702)
-__global__ __launch_bounds__(256) void k_w_gate(const LbaProblem* probs, LbaWide w) {
+// state arrays of a fresh problem (grid-wide; k_w_init's single block only sets the control block and the poses)
+__global__ __launch_bounds__(256) void k_w_init_arrays(const LbaProblem* probs) {
     const LbaProblem& pr = probs[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < pr.P * 3) pr.Xa[i] = (double)pr.points[i];
+    if (i < pr.E) { pr.level[i] = 0; pr.chi2[i] = 0; pr.erase[i] = 0; }
+}
+
+// Between the two optimisation stages (reference src/Optimizer.cc:668-689): edges with chi2 above the gate or behind the
+// camera leave the problem (level 1).  Runs once per LBA, inside the last block of the k_w_eval launch that ended stage 0.
+__device__ void w_gate_block(const LbaProblem& pr, const LbaWide& w) {
     const LbaCtrl* ct = w.ct;
-    if (ct->done || !ct->gate) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= pr.E) return;
     const double* X = w_X(pr, ct->cur);
     const SE3* T = w.T + ct->cur * pr.K;
-    const int a = pr.e_kf[e], p = pr.e_pt[e];
-    const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
-    const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
-    double pc[3];
-    se3_map(T[a], Xw, pc);
-    if (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) pr.level[e] = 1;
+    for (int e = threadIdx.x; e < pr.E; e += blockDim.x) {
+        const int a = pr.e_kf[e], p = pr.e_pt[e];
+        const bool stereo = !(pr.e_obs[e * 3 + 2] < 0);
+        const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
+        double pc[3];
+        se3_map(T[a], Xw, pc);
+        if (pr.chi2[e] > (stereo ? 7.815 : 5.991) || !(pc[2] > 0.0)) pr.level[e] = 1;
+    }
 }
 
 // Linearisation of one LM iteration in ONE launch: blocks [0, nblk_pt) own kWPt landmarks each (4 lanes per landmark
@@ -639,6 +647,10 @@ __global__ __launch_bounds__(256) void k_w_gate(const LbaProblem* probs, LbaWide
 // [nblk_pt, nblk_pt + K) own one keyframe each (8 wavefronts split its edge list: Hpp, bp).  Both roles are independent,
 // so they overlap instead of running back to back.
 constexpr int kLinThreads = 4 * kWPt;   // 512
+
+__device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w);
+__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
+__device__ __forceinline__ bool last_block_done(int* ticket);
 
 __global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, LbaWide w) {
     const LbaProblem& pr = probs[0];
@@ -722,10 +734,14 @@ __global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, 
             w.partF[blockIdx.x] = a;
             w.partM[blockIdx.x] = bm;
         }
+        if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
         return;
     }
     const int a = (int)blockIdx.x - w.nblk_pt;
-    if (a >= pr.K || w.blk[a] < 0) return;
+    if (a >= pr.K || w.blk[a] < 0) {   // fixed keyframe: nothing to accumulate, but the block still reports in
+        if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
+        return;
+    }
     const SE3 Ta = w.T[ct->cur * pr.K + a];
     const double* Ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
     double acc[27];
@@ -779,14 +795,27 @@ __global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, 
         pr.Hpp[a * 36 + tid] = sAcc[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
     }
     if (tid < 6) pr.bp[a * 6 + tid] = sAcc[0][21 + tid];
+    if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
 }
 
 // after linearisation: F0 and (first iteration) lambda = 1e-5 * max diag
-__global__ __launch_bounds__(64) void k_w_ctrlA(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+// true in exactly one block per launch: the one whose ticket is the last (all other blocks' global writes are visible)
+__device__ __forceinline__ bool last_block_done(int* ticket) {
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(ticket, 1);
+        s_last = (t == (int)gridDim.x - 1);
+        if (s_last) { *ticket = 0; __threadfence(); }
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+// LM control after the linearisation (one thread: the last block of k_w_lin): chi2 of the current state, lambda init
+__device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
-    if (ct->done) return;
-    if (threadIdx.x != 0) return;
     if (ct->gate) { ct->gate = 0; }
     if (!ct->need_lin) return;
     double F = 0, m = 0;
@@ -937,18 +966,22 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
         for (int i = tid; i < n * ld; i += 1024) s_A[i] = pr.Hs[i];
     __syncthreads();
     CH_STAMP(0);
-    // factor the 6x6 diagonal block at j0 and scale its row panel (columns j0+6 .. n): one wavefront
-    auto factor_panel = [&](int j0) {
+    __shared__ double s_Dg[36], s_rinv[6];
+    // factor the 6x6 diagonal block at j0 (one wavefront, every lane redundantly): publishes the factor and the pivot
+    // reciprocals for scale_cols
+    auto factor_diag = [&](int j0) {
         double Dg[36], rinv[6];
 #pragma unroll
         for (int i = 0; i < 6; i++)
 #pragma unroll
             for (int k = 0; k < 6; k++) Dg[i * 6 + k] = k >= i ? A((size_t)(j0 + i) * ld + j0 + k) : 0.0;
+        // validity is tested off the critical path: a non-positive or non-finite pivot poisons its own row with NaN/inf
+        // and the flag turns the whole solve into "failed" (ok2 = 0) afterwards
         bool good = true;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double d = Dg[j * 6 + j];
-            if (!(d > 0) || !(d < 1.7e308)) { good = false; d = 1; }
+            const double d = Dg[j * 6 + j];
+            good = good && (d > 0) && (d < 1.7e308);
             const double r = rsqrt(d);      // one transcendental on the critical path; pivot = d * d^-1/2
             rinv[j] = r;
             Dg[j * 6 + j] = d * r;
@@ -959,40 +992,43 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
 #pragma unroll
                 for (int k = i; k < 6; k++) Dg[i * 6 + k] -= Dg[j * 6 + i] * Dg[j * 6 + k];
         }
-        if (!good && lane == 0) s_ok = 0;
-        for (int k = j0 + 6 + lane; k <= n; k += 64) {
-            double col[6];
+        if (lane == 0) {   // every lane holds the same factor: one lane publishes it (independent stores, no select chain)
+            if (!good) s_ok = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) col[i] = A((size_t)(j0 + i) * ld + k);
+            for (int i = 0; i < 6; i++) {
+                s_rinv[i] = rinv[i];
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                double sv = col[j];
-#pragma unroll
-                for (int i = 0; i < j; i++) sv -= Dg[i * 6 + j] * col[i];
-                col[j] = sv * rinv[j];
+                for (int k = i; k < 6; k++) { s_Dg[i * 6 + k] = Dg[i * 6 + k]; A((size_t)(j0 + i) * ld + j0 + k) = Dg[i * 6 + k]; }
             }
-#pragma unroll
-            for (int i = 0; i < 6; i++) A((size_t)(j0 + i) * ld + k) = col[i];
-        }
-        // static-index select: a dynamic Dg[lane] would push the whole block into scratch memory
-        double mine = 0;
-#pragma unroll
-        for (int q = 0; q < 36; q++) mine = lane == q ? Dg[q] : mine;
-        if (lane < 36) {
-            const int r = lane / 6, cc = lane % 6;
-            if (cc >= r) A((size_t)(j0 + r) * ld + j0 + cc) = mine;
         }
     };
-    // NR rows of the trailing matrix (i0 .. i0+NR-1, columns >= kmin) minus the contribution of panel j0, one wavefront;
-    // the rows are independent, so their load -> fma -> store chains overlap
-    auto update_rows = [&](int j0, int i0, int kmin, auto nr_tag) {
+    // row panel of block j0: U(j0.., k) = L^-1 H(j0.., k) for the columns k > j0+5, one column per thread
+    auto scale_cols = [&](int j0) {
+        const int k = j0 + 6 + tid;
+        if (k > n) return;
+        double col[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) col[i] = A((size_t)(j0 + i) * ld + k);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double sv = col[j];
+#pragma unroll
+            for (int i = 0; i < j; i++) sv -= s_Dg[i * 6 + j] * col[i];
+            col[j] = sv * s_rinv[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) A((size_t)(j0 + i) * ld + k) = col[i];
+    };
+    // NR rows of the trailing matrix (i0 .. i0+NR-1, columns kmin .. kend) minus the contribution of panel j0, one
+    // wavefront; the rows are independent, so their load -> fma -> store chains overlap
+    auto update_rows = [&](int j0, int i0, int kmin, int kend, auto nr_tag) {
         constexpr int NR = decltype(nr_tag)::value;
         double P[NR][6];
 #pragma unroll
         for (int ii = 0; ii < NR; ii++)
 #pragma unroll
             for (int r = 0; r < 6; r++) P[ii][r] = A((size_t)(j0 + r) * ld + i0 + ii);
-        for (int k = kmin + lane; k <= n; k += 64) {
+        for (int k = kmin + lane; k <= kend; k += 64) {
             double cpan[6], tv[NR];
 #pragma unroll
             for (int r = 0; r < 6; r++) cpan[r] = A((size_t)(j0 + r) * ld + k);
@@ -1007,20 +1043,24 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
             }
         }
     };
-    if (wv == 0 && n > 0) factor_panel(0);
+    if (wv == 0 && n > 0) factor_diag(0);
+    __syncthreads();
+    scale_cols(0);
     __syncthreads();
     CH_STAMP(1);
-    // look-ahead: wavefront 0 updates the next panel's six rows first and factors that panel while the other 15
-    // wavefronts finish the trailing update, so each step costs max(panel, trailing) and one barrier
+    // look-ahead: while 15 wavefronts apply panel j0 to the trailing matrix, wavefront 0 updates only the next 6x6
+    // diagonal block and factors it; the (cheap, column-parallel) scaling of the next row panel follows the barrier
     for (int j0 = 0; j0 + 6 < n; j0 += 6) {
         if (wv == 0) {
-            update_rows(j0, j0 + 6, j0 + 6, std::integral_constant<int, 6>());
+            update_rows(j0, j0 + 6, j0 + 6, j0 + 11, std::integral_constant<int, 6>());
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            factor_panel(j0 + 6);
+            factor_diag(j0 + 6);
         } else {
-            for (int i0 = j0 + 12 + 3 * (wv - 1); i0 < n; i0 += 45) update_rows(j0, i0, i0, std::integral_constant<int, 3>());
+            for (int i0 = j0 + 6 + 3 * (wv - 1); i0 < n; i0 += 45) update_rows(j0, i0, max(i0, j0 + 12), n, std::integral_constant<int, 3>());
         }
+        __syncthreads();
+        scale_cols(j0 + 6);
         __syncthreads();
     }
     CH_STAMP(2);
@@ -1199,14 +1239,24 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWid
         for (int i = 1; i < kWPt / 64; i++) a += sF[i];
         w.partF[blockIdx.x] = a;
     }
+    if (last_block_done(&w.ct->ticket[1])) {
+        if (threadIdx.x == 0) w_ctrlB(pr, w);
+        __threadfence();
+        __syncthreads();
+        if (w.ct->gate && !w.ct->done) {   // uniform over the block: stage 0 just ended
+            w_gate_block(pr, w);
+            __syncthreads();
+            if (threadIdx.x == 0) w.ct->gate = 0;
+        }
+    }
 }
 
 // Levenberg-Marquardt decision + schedule transitions (g2o OptimizationAlgorithmLevenberg::solve tail,
 // SparseOptimizer::optimize loop, and the stage logic of reference src/Optimizer.cc:660-707)
-__global__ __launch_bounds__(64) void k_w_ctrlB(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+// LM control after the trial evaluation (one thread: the last block of k_w_eval): gain ratio, accept / reject, lambda
+// update, iteration / stage bookkeeping of g2o's OptimizationAlgorithmLevenberg + SparseOptimizer::optimize
+__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
-    if (ct->done || threadIdx.x != 0) return;
     double F1 = 0, sc = 0;
     for (int i = 0; i < w.nblk_pt; i++) { F1 += w.partF[i]; sc += w.partS[i]; }
     sc += w.partS[w.nblk_pt];
@@ -1291,6 +1341,8 @@ struct oslam_lba {
     LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
     double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
     double* d_W = nullptr; int2* d_pairs = nullptr; size_t pairs_cap = 0; int* d_pair_start = nullptr;
+    uint8_t* h_stage = nullptr; size_t stage_cap = 0, stage_off = 0;   // pinned staging of the per-call uploads
+    uint8_t* h_out = nullptr; size_t out_cap = 0;                      // pinned landing zone of the results
     int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
     std::vector<LbaProblem> host_probs;           // batch mode: prepared problems
     std::vector<std::vector<int>> orders;         // batch mode: edge permutation of every slot
@@ -1309,6 +1361,8 @@ void oslam_lba_destroy(oslam_lba_t* h) {
     if (h->h_stop) (void)hipHostFree(h->h_stop);
     if (h->h_done) (void)hipHostFree(h->h_done);
     if (h->d_pairs) (void)hipFree(h->d_pairs);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_out) (void)hipHostFree(h->h_out);
     delete h;
 }
 
@@ -1409,6 +1463,26 @@ int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t
                    erase.data(), nullptr, nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
 }
 
+// Copies `bytes` from `src` into the pinned staging buffer and enqueues the upload on the default stream: no host
+// synchronisation per array (a pageable hipMemcpy costs ~25 us each; a local BA call has a dozen of them).
+static int stage_upload(oslam_lba_t* h, void* dst, const void* src, size_t bytes) {
+    if (!bytes) return OSLAM_OK;
+    const size_t need = h->stage_off + ((bytes + 255) & ~(size_t)255);
+    if (need > h->stage_cap) {
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());   // earlier uploads of this call have left the old buffer
+        const size_t cap = need + need / 2 + (1u << 20);
+        uint8_t* nb = nullptr;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&nb, cap, 0));
+        if (h->h_stage) (void)hipHostFree(h->h_stage);
+        h->h_stage = nb; h->stage_cap = cap; h->stage_off = 0;
+    }
+    uint8_t* at = h->h_stage + h->stage_off;
+    memcpy(at, src, bytes);
+    OSLAM_HIP_CHECK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, nullptr));
+    h->stage_off += (bytes + 255) & ~(size_t)255;
+    return OSLAM_OK;
+}
+
 static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                    const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                    const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
@@ -1423,23 +1497,26 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
     }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     // stable sort by point; detect duplicate (kf, pt) observations (the reference has one per keyframe)
-    std::vector<int> order(nE);
+    // stable counting sort of the edges by point (O(E); the caller's order inside a point is kept)
+    std::vector<int> order(nE), pt_start(nP + 1, 0), pose_start(nKF + 1, 0);
     for (int i = 0; i < nE; i++) {
         if (edge_kf[i] < 0 || edge_kf[i] >= nKF || edge_pt[i] < 0 || edge_pt[i] >= nP) { set_error("edge %d references vertex out of range", i); return OSLAM_E_INVALID; }
-        order[i] = i;
+        pt_start[edge_pt[i] + 1]++;
+        pose_start[edge_kf[i] + 1]++;
     }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return edge_pt[a] < edge_pt[b]; });
-    std::vector<int> ekf(nE), ept(nE), pt_start(nP + 1, 0), pose_start(nKF + 1, 0), pose_edges(nE);
+    for (int p = 0; p < nP; p++) pt_start[p + 1] += pt_start[p];
+    for (int k = 0; k < nKF; k++) pose_start[k + 1] += pose_start[k];
+    {
+        std::vector<int> cur(pt_start.begin(), pt_start.end() - 1);
+        for (int i = 0; i < nE; i++) order[cur[edge_pt[i]]++] = i;
+    }
+    std::vector<int> ekf(nE), ept(nE), pose_edges(nE);
     std::vector<float> eobs((size_t)nE * 3), einfo(nE);
     for (int i = 0; i < nE; i++) {
         const int s = order[i];
         ekf[i] = edge_kf[s]; ept[i] = edge_pt[s]; einfo[i] = edge_invSigma2[s];
         for (int k = 0; k < 3; k++) eobs[(size_t)i * 3 + k] = edge_obs[(size_t)s * 3 + k];
-        pt_start[ept[i] + 1]++;
-        pose_start[ekf[i] + 1]++;
     }
-    for (int p = 0; p < nP; p++) pt_start[p + 1] += pt_start[p];
-    for (int k = 0; k < nKF; k++) pose_start[k + 1] += pose_start[k];
     {
         std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
         for (int i = 0; i < nE; i++) pose_edges[cur[ekf[i]]++] = i;
@@ -1451,7 +1528,8 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
                 if (ekf[i] == ekf[j]) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
     }
     oslam_lba::Slot& s = h->slots[slot];
-#define UP(dst, src, bytes) if ((bytes) > 0) OSLAM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice))
+    if (phase != 0 || slot == 0) h->stage_off = 0;   // batch mode appends slot after slot
+#define UP(dst, src, bytes) { const int rc_ = stage_upload(h, dst, src, bytes); if (rc_) return rc_; }
     UP(s.poses, poses, (size_t)nKF * 64); UP(s.fixed, fixed, (size_t)nKF); UP(s.points, points, (size_t)nP * 12);
     UP(s.e_kf, ekf.data(), (size_t)nE * 4); UP(s.e_pt, ept.data(), (size_t)nE * 4); UP(s.e_obs, eobs.data(), (size_t)nE * 12);
     UP(s.e_info, einfo.data(), (size_t)nE * 4); UP(s.pt_start, pt_start.data(), (size_t)(nP + 1) * 4);
@@ -1474,7 +1552,7 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         h->orders[slot] = order;
         return OSLAM_OK;
     }
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, &pr, sizeof(pr), hipMemcpyHostToDevice));
+    { const int rc_ = stage_upload(h, h->d_probs, &pr, sizeof(pr)); if (rc_) return rc_; }
     if (!h->wide) {
         hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
         OSLAM_HIP_CHECK(hipGetLastError());
@@ -1521,49 +1599,62 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
                 OSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pairs, cap * sizeof(int2)));
                 h->pairs_cap = cap;
             }
-            if (npairs) OSLAM_HIP_CHECK(hipMemcpy(h->d_pairs, pairs.data(), npairs * sizeof(int2), hipMemcpyHostToDevice));
-            OSLAM_HIP_CHECK(hipMemcpy(h->d_pair_start, pstart.data(), (size_t)(nblk + 1) * 4, hipMemcpyHostToDevice));
+            if (npairs) { const int rc_ = stage_upload(h, h->d_pairs, pairs.data(), npairs * sizeof(int2)); if (rc_) return rc_; }
+            { const int rc_ = stage_upload(h, h->d_pair_start, pstart.data(), (size_t)(nblk + 1) * 4); if (rc_) return rc_; }
             w.pairs = h->d_pairs; w.pair_start = h->d_pair_start; w.W = h->d_W;
         }
         const size_t chol_lds = 6 * nfree <= kCholLdsN ? (size_t)(6 * nfree) * (6 * nfree + 1) * sizeof(double) : 0;
         hipStream_t st = nullptr;
         hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
+        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(std::max(std::max(nP * 3, nE), 1), 256)), dim3(256), 0, st, h->d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once
         int slots_done = 0;
         *h->h_done = 0;
         const int max_slots = (iters0 + (nstages > 1 ? iters1 : 0)) * 10 + 8;
+        // first group = the minimum number of LM trials (one per iteration), so the common case needs a single
+        // host round trip; rejected steps add groups of 4
+        int group = std::max(4, iters0 + (nstages > 1 ? iters1 : 0));
         while (slots_done < max_slots) {
-            for (int sl = 0; sl < 4; sl++, slots_done++) {
-                hipLaunchKernelGGL(k_w_gate, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
+            for (int sl = 0; sl < group; sl++, slots_done++) {
                 hipLaunchKernelGGL(k_w_lin, dim3(w.nblk_pt + nKF), dim3(kLinThreads), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_ctrlA, dim3(1), dim3(64), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_schur, dim3(nblk), dim3(64), 0, st, h->d_probs, w);
                 if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1), dim3(1024), chol_lds, st, h->d_probs, w);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1), dim3(1024), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_update, dim3(w.nblk_pt + 1), dim3(kWPt), 0, st, h->d_probs, w);
                 hipLaunchKernelGGL(k_w_eval, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_ctrlB, dim3(1), dim3(64), 0, st, h->d_probs, w);
             }
             OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_done, &h->d_ctrl->done, sizeof(int), hipMemcpyDeviceToHost, st));
             OSLAM_HIP_CHECK(hipStreamSynchronize(st));
             if (*h->h_done) break;
+            group = 4;
         }
         const int nfin = std::max(std::max(nE, nKF), nP * 3);
         hipLaunchKernelGGL(k_w_final, dim3(div_up(std::max(nfin, 1), 256)), dim3(256), 0, st, h->d_probs, w);
         OSLAM_HIP_CHECK(hipGetLastError());
-        OSLAM_HIP_CHECK(hipDeviceSynchronize());
     }
-    OSLAM_HIP_CHECK(hipMemcpy(poses_out, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost));
-    if (nP > 0) OSLAM_HIP_CHECK(hipMemcpy(points_out, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost));
-    if (nE > 0) {
-        std::vector<uint8_t> er(nE);
-        OSLAM_HIP_CHECK(hipMemcpy(er.data(), s.erase, (size_t)nE, hipMemcpyDeviceToHost));
+    {   // results: four async copies into one pinned landing zone, one synchronisation
+        const size_t o_pose = 0, o_pts = o_pose + (((size_t)nKF * 64 + 255) & ~(size_t)255), o_er = o_pts + (((size_t)nP * 12 + 255) & ~(size_t)255),
+                     o_st = o_er + (((size_t)nE + 255) & ~(size_t)255), total = o_st + 256;
+        if (total > h->out_cap) {
+            if (h->h_out) (void)hipHostFree(h->h_out);
+            h->h_out = nullptr; h->out_cap = 0;
+            OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
+            h->out_cap = total + total / 2;
+        }
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost, nullptr));
+        if (nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost, nullptr));
+        if (nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er, s.erase, (size_t)nE, hipMemcpyDeviceToHost, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st, s.stats, sizeof(st), hipMemcpyDeviceToHost, nullptr));
+        OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        memcpy(poses_out, h->h_out + o_pose, (size_t)nKF * 64);
+        if (nP > 0) memcpy(points_out, h->h_out + o_pts, (size_t)nP * 12);
+        const uint8_t* er = h->h_out + o_er;
         for (int i = 0; i < nE; i++) erase[order[i]] = er[i];
-    }
-    if (stats) {
-        OSLAM_HIP_CHECK(hipMemcpy(st, s.stats, sizeof(st), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 4; i++) stats[i] = st[i];
+        if (stats) {
+            memcpy(st, h->h_out + o_st, sizeof(st));
+            for (int i = 0; i < 4; i++) stats[i] = st[i];
+        }
     }
     return OSLAM_OK;
 }
