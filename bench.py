@@ -69,9 +69,11 @@ def pmc_traffic(kernel_substr, frames_per_launch):
         path = os.path.join(ROOT, "profiles", f)
         if not os.path.exists(path):
             return None
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
-        if not vals:
+        rows = [r for r in csv.DictReader(open(path)) if kernel_substr in r["Kernel_Name"]]
+        if not rows:
             return None
+        gmax = max(int(r["Grid_Size"]) for r in rows)   # the 256-frame launches of the bench, not batch-1 calls of the extras
+        vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == gmax]
         tot += sum(vals) / len(vals)
     return tot * 1024.0 * frames_per_launch / 256.0
 
