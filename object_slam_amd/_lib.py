@@ -56,4 +56,5 @@ def check(rc):
 
 
 def ptr(a):
-    return a.ctypes.data_as(C.c_void_p)
+    # ndarray.ctypes builds a helper object per call (~15 us); the array interface gives the address directly
+    return C.c_void_p(a.__array_interface__["data"][0])

@@ -24,4 +24,41 @@ void set_error(const char* fmt, ...);
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
+// Pinned host staging for the single-frame host-pointer entry points: uploads are memcpy'd into the pinned block and
+// enqueued as async copies on the default stream, downloads land in the block and are handed out after ONE stream
+// synchronisation.  (A pageable hipMemcpy costs ~15-25 us of host time each; the drop-in calls have 5-10 of them.)
+struct PinStage {
+    uint8_t* p = nullptr;
+    size_t cap = 0, off = 0;
+    void reset() { off = 0; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; off = 0; }
+    // reserve `bytes` (256-aligned); grows only while empty, so call reserve_total() first for a whole call
+    int reserve_total(size_t bytes) {
+        if (bytes <= cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        release();
+        const size_t ncap = bytes + bytes / 2 + 4096;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&p, ncap, 0));
+        cap = ncap;
+        return OSLAM_OK;
+    }
+    uint8_t* take(size_t bytes) { uint8_t* at = p + off; off += align_up(bytes ? bytes : 1, 256); return at; }
+    int upload(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return OSLAM_OK;
+        if (off + align_up(bytes, 256) > cap) { set_error("pinned staging overflow"); return OSLAM_E_CAPACITY; }
+        uint8_t* at = take(bytes);
+        memcpy(at, src, bytes);
+        OSLAM_HIP_CHECK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, nullptr));
+        return OSLAM_OK;
+    }
+    // enqueue a download; returns the pinned address the data will be at after the stream has drained
+    int download(const void* src, size_t bytes, uint8_t** at_out) {
+        if (off + align_up(bytes ? bytes : 1, 256) > cap) { set_error("pinned staging overflow"); return OSLAM_E_CAPACITY; }
+        uint8_t* at = take(bytes);
+        if (bytes) OSLAM_HIP_CHECK(hipMemcpyAsync(at, src, bytes, hipMemcpyDeviceToHost, nullptr));
+        *at_out = at;
+        return OSLAM_OK;
+    }
+};
+
 }  // namespace oslam

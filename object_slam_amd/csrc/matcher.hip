@@ -434,6 +434,7 @@ struct oslam_matcher {
     // staging for the host API (batch 1)
     oslam_keypoint_t* d_kps = nullptr; float* d_ur = nullptr; uint8_t* d_desc = nullptr; uint8_t* d_blocked = nullptr;
     float* d_Xw = nullptr; uint8_t* d_has = nullptr; oslam_keypoint_t* d_lkeys = nullptr; uint8_t* d_ldesc = nullptr; float* d_T = nullptr;
+    PinStage pin;   // host-pointer entry points
 };
 
 extern "C" {
@@ -444,6 +445,7 @@ void oslam_matcher_destroy(oslam_matcher_t* h) {
                     h->d_desc, h->d_blocked, h->d_Xw, h->d_has, h->d_lkeys, h->d_ldesc, h->d_T};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    h->pin.release();
     delete h;
 }
 
@@ -588,14 +590,37 @@ int oslam_match_fetch(oslam_matcher_t* h, int b, int q_stride, int n_q, int kp_s
     return OSLAM_OK;
 }
 
+// results of frame 0 through the pinned block: five async copies, one synchronisation
+static int fetch_host(oslam_matcher* h, int n_q, int n_kps, int32_t* q_match, int32_t* q_dist, int32_t* kp_match, int32_t* nmatches) {
+    uint8_t *a_nm = nullptr, *a_qm = nullptr, *a_qd = nullptr, *a_km = nullptr;
+    int rc;
+    if ((rc = h->pin.download(h->d_nm, 4, &a_nm))) return rc;
+    if (q_match && n_q > 0 && (rc = h->pin.download(h->d_q_match, (size_t)n_q * 4, &a_qm))) return rc;
+    if (q_dist && n_q > 0 && (rc = h->pin.download(h->d_q_dist, (size_t)n_q * 4, &a_qd))) return rc;
+    if (kp_match && n_kps > 0 && (rc = h->pin.download(h->d_kp_match, (size_t)n_kps * 4, &a_km))) return rc;
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    int nm;
+    memcpy(&nm, a_nm, 4);
+    if (nm < 0) { set_error("matcher kernel rejected the frame (keypoints or queries exceed the handle capacity)"); return OSLAM_E_CAPACITY; }
+    if (nmatches) *nmatches = nm;
+    if (a_qm) memcpy(q_match, a_qm, (size_t)n_q * 4);
+    if (a_qd) memcpy(q_dist, a_qd, (size_t)n_q * 4);
+    if (a_km) memcpy(kp_match, a_km, (size_t)n_kps * 4);
+    return OSLAM_OK;
+}
+
 static int stage_frame(oslam_matcher* h, int N, const oslam_keypoint_t* keysUn, const float* uRight, const uint8_t* desc,
                        const uint8_t* blocked, const float bounds[4], oslam_match_frames_t* f) {
     if (N < 0 || N > h->max_kps) { set_error("%d keypoints > capacity %d", N, h->max_kps); return OSLAM_E_CAPACITY; }
+    // one pinned block sized for everything a host-pointer call moves (frame, queries / last frame, results)
+    int rc = h->pin.reserve_total((size_t)h->max_kps * (sizeof(oslam_keypoint_t) + 32 + 4 + 1 + 4) +
+                                  (size_t)h->max_q * (sizeof(oslam_proj_query_t) + 12 + 1 + sizeof(oslam_keypoint_t) + 32 + 8) + 64 * 1024);
+    if (rc) return rc;
+    h->pin.reset();
     if (N > 0) {
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_kps, keysUn, (size_t)N * sizeof(oslam_keypoint_t), hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_desc, desc, (size_t)N * 32, hipMemcpyHostToDevice));
-        if (uRight) OSLAM_HIP_CHECK(hipMemcpy(h->d_ur, uRight, (size_t)N * 4, hipMemcpyHostToDevice));
-        if (blocked) OSLAM_HIP_CHECK(hipMemcpy(h->d_blocked, blocked, (size_t)N, hipMemcpyHostToDevice));
+        if ((rc = h->pin.upload(h->d_kps, keysUn, (size_t)N * sizeof(oslam_keypoint_t))) || (rc = h->pin.upload(h->d_desc, desc, (size_t)N * 32))) return rc;
+        if (uRight && (rc = h->pin.upload(h->d_ur, uRight, (size_t)N * 4))) return rc;
+        if (blocked && (rc = h->pin.upload(h->d_blocked, blocked, (size_t)N))) return rc;
     }
     f->keysUn = h->d_kps; f->kp_stride = h->max_kps; f->uRight = uRight ? h->d_ur : nullptr; f->desc = h->d_desc;
     f->blocked = blocked ? h->d_blocked : nullptr; f->n_kps = nullptr; f->n_kps_const = N;
@@ -613,10 +638,10 @@ int oslam_match_search_by_projection(oslam_matcher_t* h, int N, const oslam_keyp
     oslam_match_frames_t f;
     int rc = stage_frame(h, N, keysUn, uRight, desc, blocked, bounds, &f);
     if (rc) return rc;
-    if (M > 0) OSLAM_HIP_CHECK(hipMemcpy(h->d_queries, queries, (size_t)M * sizeof(oslam_proj_query_t), hipMemcpyHostToDevice));
+    if (M > 0 && (rc = h->pin.upload(h->d_queries, queries, (size_t)M * sizeof(oslam_proj_query_t)))) return rc;
     rc = oslam_match_search_batch_device(h, &f, h->d_queries, h->max_q, nullptr, M, 1, nnratio, use_ratio, check_ori, 100, nullptr);
     if (rc) return rc;
-    return oslam_match_fetch(h, 0, h->max_q, M, h->max_kps, N, q_match, q_dist, kp_match, nmatches, nullptr, nullptr);
+    return fetch_host(h, M, N, q_match, q_dist, kp_match, nmatches);
 }
 
 int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn, const float* uRight, const uint8_t* desc,
@@ -631,13 +656,11 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
     int rc = stage_frame(h, N, keysUn, uRight, desc, blocked, bounds, &f);
     if (rc) return rc;
     if (Nlast > 0) {
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_Xw, Xw, (size_t)Nlast * 12, hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_has, has_mp, (size_t)Nlast, hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_lkeys, last_keys, (size_t)Nlast * sizeof(oslam_keypoint_t), hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_ldesc, mp_desc, (size_t)Nlast * 32, hipMemcpyHostToDevice));
+        if ((rc = h->pin.upload(h->d_Xw, Xw, (size_t)Nlast * 12)) || (rc = h->pin.upload(h->d_has, has_mp, (size_t)Nlast)) ||
+            (rc = h->pin.upload(h->d_lkeys, last_keys, (size_t)Nlast * sizeof(oslam_keypoint_t))) || (rc = h->pin.upload(h->d_ldesc, mp_desc, (size_t)Nlast * 32)))
+            return rc;
     }
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_T, Tcw, 64, hipMemcpyHostToDevice));
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_T + 16, Tlw, 64, hipMemcpyHostToDevice));
+    if ((rc = h->pin.upload(h->d_T, Tcw, 64)) || (rc = h->pin.upload(h->d_T + 16, Tlw, 64))) return rc;
     oslam_match_last_t last;
     last.Xw = h->d_Xw; last.has_mp = h->d_has; last.keys = h->d_lkeys; last.mp_desc = h->d_ldesc;
     last.kp_stride = h->max_q; last.n_kps = nullptr; last.n_kps_const = Nlast;
@@ -645,7 +668,7 @@ int oslam_match_project_last_frame(oslam_matcher_t* h, int N, const oslam_keypoi
     if (rc) return rc;
     rc = oslam_match_search_batch_device(h, &f, nullptr, h->max_q, nullptr, Nlast, 1, 0.f, 0, check_ori, 100, nullptr);
     if (rc) return rc;
-    return oslam_match_fetch(h, 0, h->max_q, Nlast, h->max_kps, N, q_match, q_dist, kp_match, nmatches, nullptr, nullptr);
+    return fetch_host(h, Nlast, N, q_match, q_dist, kp_match, nmatches);
 }
 
 int oslam_match_fuse_search(oslam_matcher_t* h, int N, const oslam_keypoint_t* keysUn, const float* uRight, const uint8_t* desc,
@@ -657,10 +680,10 @@ int oslam_match_fuse_search(oslam_matcher_t* h, int N, const oslam_keypoint_t* k
     oslam_match_frames_t f;
     int rc = stage_frame(h, N, keysUn, uRight, desc, nullptr, bounds, &f);
     if (rc) return rc;
-    if (M > 0) OSLAM_HIP_CHECK(hipMemcpy(h->d_queries, queries, (size_t)M * sizeof(oslam_proj_query_t), hipMemcpyHostToDevice));
+    if (M > 0 && (rc = h->pin.upload(h->d_queries, queries, (size_t)M * sizeof(oslam_proj_query_t)))) return rc;
     rc = oslam_match_fuse_batch_device(h, &f, h->d_queries, h->max_q, nullptr, M, 1, invLevelSigma2, nlevels, nullptr);
     if (rc) return rc;
-    return oslam_match_fetch(h, 0, h->max_q, M, h->max_kps, 0, q_match, q_dist, nullptr, n_fused, nullptr, nullptr);
+    return fetch_host(h, M, 0, q_match, q_dist, nullptr, n_fused);
 }
 
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out) {

@@ -5,6 +5,7 @@
 // equations (21 + 6 + 1 doubles), in-register 6x6 Cholesky, everything wave-uniform after the
 // reduction so no broadcast is needed.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -484,6 +485,7 @@ struct oslam_poseopt {
     float* d_Tout = nullptr; uint8_t* d_outlier = nullptr; int* d_ninl = nullptr; int* d_stats = nullptr;
     // staging for the host API
     float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
+    uint8_t* h_pin = nullptr; size_t pin_cap = 0;   // pinned staging of the single-frame host API (inputs, then results)
     // semantic variant: grow-only device buffers
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf masks, rowcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
@@ -507,6 +509,7 @@ void oslam_poseopt_destroy(oslam_poseopt_t* h) {
                     h->eXw.p, h->eobs.p, h->elevel.p, h->echi2.p, h->eobj.p, h->eout.p, h->etmp.p, h->nsem.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->h_pin) (void)hipHostFree(h->h_pin);
     delete h;
 }
 
@@ -574,20 +577,39 @@ int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const
     if (!h || !Tcw_in || !K5 || !Tcw_out || !n_inliers || (N > 0 && (!Xw || !obs || !invSigma2 || !has_mp || !outlier))) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (N < 0 || N > h->max_points) { set_error("%d points > capacity %d", N, h->max_points); return OSLAM_E_CAPACITY; }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_T, Tcw_in, 64, hipMemcpyHostToDevice));
+    // inputs and results travel through one pinned buffer as async copies with a single synchronisation
+    // (ten pageable hipMemcpy calls cost ~0.2 ms, a third of the kernel itself)
+    const size_t a256 = 255;
+    const size_t o_T = 0, o_X = 256, o_o = o_X + (((size_t)N * 12 + a256) & ~a256), o_i = o_o + (((size_t)N * 12 + a256) & ~a256),
+                 o_h = o_i + (((size_t)N * 4 + a256) & ~a256), o_out = o_h + (((size_t)N + a256) & ~a256), total = o_out + 512 + (((size_t)N + a256) & ~a256);
+    if (total > h->pin_cap) {
+        if (h->h_pin) (void)hipHostFree(h->h_pin);
+        h->h_pin = nullptr; h->pin_cap = 0;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_pin, total + total / 2, 0));
+        h->pin_cap = total + total / 2;
+    }
+    uint8_t* pin = h->h_pin;
+    memcpy(pin + o_T, Tcw_in, 64);
+    OSLAM_HIP_CHECK(hipMemcpyAsync(h->d_T, pin + o_T, 64, hipMemcpyHostToDevice, nullptr));
     if (N > 0) {
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_Xw, Xw, (size_t)N * 12, hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_obs, obs, (size_t)N * 12, hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_inv, invSigma2, (size_t)N * 4, hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_has, has_mp, (size_t)N, hipMemcpyHostToDevice));
+        memcpy(pin + o_X, Xw, (size_t)N * 12); memcpy(pin + o_o, obs, (size_t)N * 12); memcpy(pin + o_i, invSigma2, (size_t)N * 4); memcpy(pin + o_h, has_mp, (size_t)N);
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->d_Xw, pin + o_X, (size_t)N * 12, hipMemcpyHostToDevice, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->d_obs, pin + o_o, (size_t)N * 12, hipMemcpyHostToDevice, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->d_inv, pin + o_i, (size_t)N * 4, hipMemcpyHostToDevice, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->d_has, pin + o_h, (size_t)N, hipMemcpyHostToDevice, nullptr));
     }
     int rc = oslam_pose_optimize_batch_device(h, 1, h->max_points, nullptr, N, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has, K5, nullptr);
     if (rc) return rc;
-    OSLAM_HIP_CHECK(hipDeviceSynchronize());
-    OSLAM_HIP_CHECK(hipMemcpy(Tcw_out, h->d_Tout, 64, hipMemcpyDeviceToHost));
-    OSLAM_HIP_CHECK(hipMemcpy(n_inliers, h->d_ninl, 4, hipMemcpyDeviceToHost));
-    if (N > 0) OSLAM_HIP_CHECK(hipMemcpy(outlier, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost));
-    if (stats) OSLAM_HIP_CHECK(hipMemcpy(stats, h->d_stats, 8, hipMemcpyDeviceToHost));
+    uint8_t* po = pin + o_out;   // [0,64) pose, [64,68) inliers, [128,136) stats, [512, 512+N) outlier flags
+    OSLAM_HIP_CHECK(hipMemcpyAsync(po, h->d_Tout, 64, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(po + 64, h->d_ninl, 4, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(po + 128, h->d_stats, 8, hipMemcpyDeviceToHost, nullptr));
+    if (N > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(po + 512, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    memcpy(Tcw_out, po, 64);
+    memcpy(n_inliers, po + 64, 4);
+    if (N > 0) memcpy(outlier, po + 512, (size_t)N);
+    if (stats) memcpy(stats, po + 128, 8);
     return OSLAM_OK;
 }
 
