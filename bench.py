@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (profiling runs: every launch of a kernel is then the S2 batch)")
     args = ap.parse_args()
 
     import torch
@@ -248,7 +249,7 @@ def main():
                "sample": "%d frames of the same stream: oracle extract + SearchByProjection(Cur,Last), %.1f s" % (ns, dt)}
 
     extras = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         # other rows of the hot path (SURVEY.md §8(d) S5 and the pose optimisers), reported beside the headline
         try:
             from object_slam_amd import LocalBundleAdjuster, PoseOptimizer

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(OrbCtx c) {
 // level; one wavefront per keypoint.  Replaces reference src/ORBextractor.cc:77-147,472-479,
 // 1090-1104 (IC_Angle, computeOrbDescriptor, the level concat and the pt *= scale).
 // ------------------------------------------------------------------------------------------
-__constant__ int8_t c_pattern[1024] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "brief_pattern.inc"
 };
 
@@ -1087,26 +1087,39 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
     const int u = (lane & 31) - 15;
     const bool ucol = (lane & 31) < 31;
     const int au = u < 0 ? -u : u;
-    for (int q = 0; q < kpw; q++) {
+    // the 16 patch bytes of this lane for the NEXT keypoint are in flight while the current one is reduced
+    int ov[16];
+    auto fetch_orient = [&](int q) {
         const int s = wv * kpw + q;
-        const int level = s_level[s];
-        if (level < 0) continue;
+        const int level = q < kpw ? s_level[s] : -1;
+#pragma unroll
+        for (int it = 0; it < 16; it++) ov[it] = 0;
+        if (level < 0) return;
         int pitch;
         const uint8_t* img = level_image(c, P, b, level, pitch);
         const uint8_t* center = img + (long long)s_ky[s] * pitch + s_kx[s];
-        int m10 = 0, m01 = 0;
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = -15 + 2 * it + (lane >> 5);
             const int av = v < 0 ? -v : v;
             // umax for HALF_PATCH_SIZE = 15 (reference :454-469): 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 packed 4 bits each
             const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);
-            if (ucol && v <= 15 && au <= um) {
-                const int val = center[v * pitch + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
+            if (ucol && v <= 15 && au <= um) ov[it] = center[v * pitch + u];
         }
+    };
+    fetch_orient(0);
+    for (int q = 0; q < kpw; q++) {
+        const int s = wv * kpw + q;
+        const int level = s_level[s];
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int v = -15 + 2 * it + (lane >> 5);
+            m10 += u * ov[it];
+            m01 += v * ov[it];
+        }
+        fetch_orient(q + 1);
+        if (level < 0) continue;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             m10 += __shfl_xor(m10, d, 64);
@@ -1125,24 +1138,60 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
         s_b[tid] = (float)sin((double)ang);
     }
     __syncthreads();
-    // phase 3: steered BRIEF on the blurred level (:108-147) + keypoint record (:1090-1104)
+    // phase 3: steered BRIEF on the blurred level (:108-147) + keypoint record (:1090-1104).
+    // The 37x37 neighbourhood (pattern radius 18.38 -> |row|,|col| <= 18 after rounding) is staged into LDS with
+    // row-coalesced aligned word loads (6 wave loads of ~9 cache lines each instead of 8 byte gathers that touch up
+    // to 37 lines each); the next keypoint's patch is fetched into registers while the current one is sampled.
+    constexpr int kPW = 10, kPR = 37;                 // words per patch row, rows
+    __shared__ uint32_t s_patch[4][kPR * kPW];
+    uint32_t* patch = s_patch[wv];
+    uint32_t nxt[6];
+    auto fetch_patch = [&](int q) {                   // global -> registers for this wavefront's q-th keypoint
+        const int s = wv * kpw + q;
+        const int level = q < kpw ? s_level[s] : -1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) nxt[k] = 0;
+        if (level < 0) return;
+        const LevelGeom& g = P->lv[level];
+        const uint8_t* bimg = c.blur + (long long)b * c.blur_stride + g.img_off;
+        const int x0 = s_kx[s] - 18, y0 = s_ky[s] - 18;
+        const int wbase = x0 >> 2, wmax = (g.pitch >> 2) - 1;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k;
+            const int row = i / kPW, wi = i - row * kPW;
+            if (i < kPR * kPW) nxt[k] = *(const uint32_t*)(bimg + (long long)(y0 + row) * g.pitch + 4 * min(wbase + wi, wmax));
+        }
+    };
+    // this lane's four point pairs of the pattern (16 int8, the same for every keypoint): loaded once
+    const int4 patw = *(const int4*)&c_pattern[lane * 16];
+    const int patv[4] = {patw.x, patw.y, patw.z, patw.w};
+    fetch_patch(0);
     for (int q = 0; q < kpw; q++) {
         const int s = wv * kpw + q;
         const int level = s_level[s];
+        __builtin_amdgcn_wave_barrier();              // the previous keypoint's samples are done with the LDS patch
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k;
+            if (i < kPR * kPW) patch[i] = nxt[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        fetch_patch(q + 1);                            // in flight while this keypoint is described
         if (level < 0) continue;
         const LevelGeom& g = P->lv[level];
         const int kx = s_kx[s], ky = s_ky[s];
         const float a = s_a[s], bb = s_b[s];
-        const uint8_t* bimg = c.blur + (long long)b * c.blur_stride + g.img_off;
-        const uint8_t* bc = bimg + (long long)ky * g.pitch + kx;
+        const uint8_t* pb = (const uint8_t*)patch + 18 * (kPW * 4) + ((kx - 18) & 3) + 18;   // pb[r*40 + c] = blurred(ky + r, kx + c)
         int nib = 0;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int8_t* pt = &c_pattern[(lane * 4 + t) * 4];
-            const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+            const int pw = patv[t];   // bytes: x0, y0, x1, y1 (signed)
+            const float x0 = (float)(int8_t)(pw & 0xff), y0 = (float)(int8_t)((pw >> 8) & 0xff), x1 = (float)(int8_t)((pw >> 16) & 0xff), y1 = (float)(int8_t)(pw >> 24);
             const int r0 = __float2int_rn(x0 * bb + y0 * a), c0 = __float2int_rn(x0 * a - y0 * bb);
             const int r1 = __float2int_rn(x1 * bb + y1 * a), c1 = __float2int_rn(x1 * a - y1 * bb);
-            const int t0 = bc[r0 * g.pitch + c0], t1 = bc[r1 * g.pitch + c1];
+            const int t0 = pb[r0 * (kPW * 4) + c0], t1 = pb[r1 * (kPW * 4) + c1];
             nib |= (t0 < t1) << t;
         }
         const int other = __shfl_xor(nib, 1, 64);
