@@ -430,7 +430,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);
-    hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4), batch), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), batch), dim3(256), 0, st, c);
     if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
     PROF_MARK(2);
     hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, st, c, h->blur_sse2);

@@ -490,14 +490,15 @@ __device__ __forceinline__ int fast_score3(const uint8_t* t) {
 #define FSTAMP(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
-    const OrbParams* P = c.P;
-#ifdef OSLAM_FAST_PROFILE
-    long long tl_ = clock64();
-#endif
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int cell = blockIdx.x * 4 + wv;
+// Geometry of one FAST cell as a wavefront sees it (all wave-uniform).
+struct FastCell {
+    int valid;             // 0: nothing to do (out of range / handled by k_fast_cells); 1: process; 2: empty cell, count = 0
+    int level, ci, cj, cw, ch, iniX, iniY, rw, rh, pitch, gbase, gsh, nwt, aligned, cell_in_level;
+    const uint8_t* img;
+};
+
+__device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, const OrbParams* P, int b, int cell, FastCell& G) {
+    G.valid = 0;
     if (cell >= P->total_cells) return;
     int level = 0;
     for (int l = 1; l < P->nlevels; l++)
@@ -505,59 +506,95 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const LevelGeom& g = P->lv[level];
     if (g.wCell > kWCell || g.hCell > kWCell) return;   // handled by k_fast_cells
     cell -= g.cell_base;
-    const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
-    int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
-    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
-    const int cell_cap = g.cell_cap, wCellOut = g.wCell, hCellOut = g.hCell;
-
+    G.level = level; G.cell_in_level = cell;
+    G.ci = cell / g.nCols; G.cj = cell - G.ci * g.nCols;
     const int minBX = kRegionBorder, minBY = kRegionBorder;
     const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
-    const int iniY = minBY + ci * g.hCell, iniX = minBX + cj * g.wCell;
-    int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
-    const bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);
+    G.iniY = minBY + G.ci * g.hCell; G.iniX = minBX + G.cj * g.wCell;
+    int maxY = G.iniY + g.hCell + 6, maxX = G.iniX + g.wCell + 6;
+    const bool skip = (G.iniY >= maxBY - 3) || (G.iniX >= maxBX - 6);
     if (maxY > maxBY) maxY = maxBY;
     if (maxX > maxBX) maxX = maxBX;
-    const int cw = maxX - iniX - 6, ch = maxY - iniY - 6;
-    if (skip || cw <= 0 || ch <= 0) {
-        if (lane == 0) *count_out = 0;
-        return;
-    }
+    G.cw = maxX - G.iniX - 6; G.ch = maxY - G.iniY - 6;
+    if (skip || G.cw <= 0 || G.ch <= 0) { G.valid = 2; return; }
+    G.valid = 1;
+    G.img = level_image(c, P, b, level, G.pitch);
+    G.rw = G.cw + 6; G.rh = G.ch + 6;
+    // Tile layout: ROI column cc (0..rw-1) at tile byte cc+1, i.e. interior pixel x at byte x+4 (word aligned
+    // for x % 4 == 0).  Tile word j = global bytes base+s+4j.., base = (iniX-1) & ~3, s = (iniX-1) & 3
+    // (iniX >= 16, so the window never starts before the row; it ends before column w).
+    G.gbase = (G.iniX - 1) & ~3; G.gsh = (G.iniX - 1) & 3;
+    G.nwt = (G.rw + 1 + 3) >> 2;   // tile words per row (<= 12)
+    G.aligned = ((G.pitch & 3) == 0) && ((((unsigned long long)G.img) & 3ull) == 0);
+}
+
+constexpr int kFastCellsPerWave = 1;   // cells per wavefront (measured: 1 -> 2.64 us/frame, 2 -> 3.2, 4 -> 3.15 at B=64: the kernel is VALU bound, fewer and longer waves only add tail)
+
+__global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
+    const OrbParams* P = c.P;
+#ifdef OSLAM_FAST_PROFILE
+    long long tl_ = clock64();
+#endif
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int cell_first = (blockIdx.x * 4 + wv) * kFastCellsPerWave;
     __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
     __shared__ uint8_t s_sc[4][kWCell * 64];          // scores, pitch 64
     __shared__ uint16_t s_work[4][kWCell * kWCell];   // worklist: y*64 + x of pixels passing the quick test, row-major
     uint8_t* tile = s_tile[wv];
     uint8_t* sc = s_sc[wv];
     uint16_t* work = s_work[wv];
-
-    int pitch;
-    const uint8_t* img = level_image(c, P, b, level, pitch);
-    const int rw = cw + 6, rh = ch + 6;
-    // Tile layout: ROI column cc (0..rw-1) at tile byte cc+1, i.e. interior pixel x at byte x+4 (word aligned
-    // for x % 4 == 0).  Tile word j = global bytes base+s+4j.., base = (iniX-1) & ~3, s = (iniX-1) & 3
-    // (iniX >= 16, so the window never starts before the row; it ends before column w).
-    const int gbase = (iniX - 1) & ~3, gsh = (iniX - 1) & 3;
-    const int nwt = (rw + 1 + 3) >> 2;   // tile words per row (<= 12)
-    if (((pitch & 3) == 0) && ((((unsigned long long)img) & 3ull) == 0)) {
-        // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by shuffle
-        const int wx = lane & 15, rsub = lane >> 4;
+    const int minTh = P->minTh, iniTh = P->iniTh;
+    // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by shuffle
+    const int wx = lane & 15, rsub = lane >> 4;
+    constexpr int kLoadIters = (kWTileRows + 3) / 4;
+    uint32_t gw[kLoadIters];                           // raw aligned words of the NEXT cell's tile, in flight
+    FastCell N;                                        // geometry of the next cell
+    auto issue_loads = [&](const FastCell& G) {
 #pragma unroll
-        for (int k = 0; k < (kWTileRows + 3) / 4; k++) {
+        for (int k = 0; k < kLoadIters; k++) {
             const int ry = 4 * k + rsub;
-            uint32_t gw = 0;
-            if (ry < rh && wx <= nwt) gw = *(const uint32_t*)(img + (long long)(iniY + ry) * pitch + gbase + wx * 4);
-            const uint32_t gn = __shfl_down(gw, 1, 64);
-            if (ry < rh && wx < nwt) *(uint32_t*)(tile + ry * kWTileP + wx * 4) = __builtin_amdgcn_alignbyte(gn, gw, gsh);
+            gw[k] = 0;
+            if (G.valid == 1 && G.aligned && ry < G.rh && wx <= G.nwt) gw[k] = *(const uint32_t*)(G.img + (long long)(G.iniY + ry) * G.pitch + G.gbase + wx * 4);
+        }
+    };
+    fast_cell_geom(c, P, b, cell_first, N);
+    issue_loads(N);
+    for (int jc = 0; jc < kFastCellsPerWave; jc++) {
+    const FastCell G = N;
+    if (G.valid == 0) { if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); } continue; }
+    const LevelGeom& g = P->lv[G.level];
+    const int cell = G.cell_in_level, ci = G.ci, cj = G.cj, cw = G.cw, ch = G.ch;
+    int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
+    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
+    const int cell_cap = g.cell_cap, wCellOut = g.wCell, hCellOut = g.hCell;
+    if (G.valid == 2) {
+        if (lane == 0) *count_out = 0;
+        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+        continue;
+    }
+    const int rw = G.rw, rh = G.rh;
+    __builtin_amdgcn_wave_barrier();                   // the previous cell no longer reads the LDS tile
+    if (G.aligned) {
+#pragma unroll
+        for (int k = 0; k < kLoadIters; k++) {
+            const int ry = 4 * k + rsub;
+            const uint32_t gn = __shfl_down(gw[k], 1, 64);
+            if (ry < rh && wx < G.nwt) *(uint32_t*)(tile + ry * kWTileP + wx * 4) = __builtin_amdgcn_alignbyte(gn, gw[k], G.gsh);
         }
     } else {   // caller's level-0 buffer with an unaligned pitch: byte loads
         for (int i = lane; i < rw * rh; i += 64) {
             const int ry = i / rw, rx = i - ry * rw;
-            tile[ry * kWTileP + 1 + rx] = img[(long long)(iniY + ry) * pitch + iniX + rx];
+            tile[ry * kWTileP + 1 + rx] = G.img[(long long)(G.iniY + ry) * G.pitch + G.iniX + rx];
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // the next cell's tile words travel while this cell is processed
+    if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+    else N.valid = 0;
     FSTAMP(0);
     const uint8_t* t0 = tile + 3 * kWTileP + 4;   // t0[y*kWTileP + x] = interior pixel (x, y)
-    const int minTh = P->minTh, iniTh = P->iniTh;
 
     // A. quick rejection at minTh: an arc of 9 of 16 contains one pixel of every opposite pair, so a
     //    corner needs (p0|p8) and (p4|p12) brighter than v+t, or both darker than v-t.  Survivors ->
@@ -688,6 +725,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
 #ifdef OSLAM_FAST_PROFILE
     if (lane == 0) { atomicAdd(&c.dbg[5], (unsigned long long)nwork); atomicAdd(&c.dbg[6], 1ull); atomicAdd(&c.dbg[7], (unsigned long long)(cw * ch)); }
 #endif
+    }   // cells of this wavefront
 }
 
 // ------------------------------------------------------------------------------------------
