@@ -415,6 +415,30 @@ int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* kf1, int nPa
                          const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
                          float ratioFactor /* 1.5f*mfScaleFactor */, uint8_t* ok /*[M]*/, float* x3D /*[M][3]*/, int32_t* nnew);
 
+/* ---------------- Frame construction between the extractor and the grid / matchers ----------------
+ * Frame::UndistortKeyPoints (reference src/Frame.cc:644-675: cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK), OpenCV 3.2
+ * cvUndistortPoints: fp64, 5 fixed-point iterations), Frame::ComputeImageBounds (:677-704) and Frame::ComputeStereoFromRGBD
+ * (:883-904).  K4 = fx, fy, cx, cy (mK, CV_32F); dist = mDistCoef (k1, k2, p1, p2[, k3]; ndist 0 or dist[0] == 0 -> mvKeysUn = mvKeys,
+ * bounds = the image rectangle).  The *_batch_device forms work on the extractor's device arrays ([batch][stride] keypoints,
+ * counts per frame or n_const) and are asynchronous on `stream`; `image_stride` of the depth batch is in floats. */
+typedef struct oslam_frame oslam_frame_t;
+int oslam_frame_create(oslam_frame_t** out, int device);
+void oslam_frame_destroy(oslam_frame_t* h);
+int oslam_frame_undistort_keypoints(oslam_frame_t* h, int n, const oslam_keypoint_t* keys, const float K4[4], const float* dist, int ndist,
+                                    oslam_keypoint_t* keysUn);
+int oslam_frame_undistort_batch_device(const oslam_keypoint_t* d_keys, oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const, int stride,
+                                       int batch, const float K4[4], const float* dist, int ndist, void* stream);
+/* bounds = mnMinX, mnMinY, mnMaxX, mnMaxY (the order every matcher entry point takes) */
+int oslam_frame_image_bounds(oslam_frame_t* h, int cols, int rows, const float K4[4], const float* dist, int ndist, float bounds[4]);
+/* depth = imDepth after the mDepthMapFactor scaling (CV_32F, `pitch` floats per row); keys = mvKeys (raw pixel, truncated to
+ * the depth pixel like Mat::at<float>(v,u)), keysUn = mvKeysUn; uRight / mvDepth = -1 where depth <= 0.  A keypoint outside the
+ * depth image is an error (the reference would read out of bounds). */
+int oslam_frame_stereo_from_rgbd(oslam_frame_t* h, int n, const oslam_keypoint_t* keys, const oslam_keypoint_t* keysUn, const float* depth, int rows,
+                                 int cols, int pitch, float mbf, float* uRight, float* mvDepth);
+int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
+                                              int stride, int batch, const float* d_depth, int rows, int cols, int pitch, size_t image_stride,
+                                              float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

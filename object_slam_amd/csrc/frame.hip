@@ -1,0 +1,222 @@
+// gfx950 Frame construction steps between the extractor and the grid / matchers (the callers' side of SURVEY.md §8 A-8/A-9):
+//   Frame::UndistortKeyPoints      reference src/Frame.cc:644-675 (cv::undistortPoints, OpenCV 3.2 cvUndistortPoints)
+//   Frame::ComputeImageBounds      reference src/Frame.cc:677-704
+//   Frame::ComputeStereoFromRGBD   reference src/Frame.cc:883-904
+// Batched over the frames of one extractor batch; everything stays in HBM between the extractor and the matcher.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace oslam {
+
+struct UndistortCtx {
+    const oslam_keypoint_t* keys; oslam_keypoint_t* keysUn; const int* counts; int n_const; int stride;
+    double fx, fy, cx, cy, ifx, ify, k[12];
+    int iters, passthrough;
+};
+
+// cvUndistortPoints with R = I, P = K: fp64 fixed-point inversion of the distortion model
+__device__ __forceinline__ void undistort_point(const UndistortCtx& c, float xin, float yin, float& xo, float& yo) {
+    double x = (double)xin, y = (double)yin, x0, y0;
+    x0 = x = (x - c.cx) * c.ifx;
+    y0 = y = (y - c.cy) * c.ify;
+    for (int j = 0; j < c.iters; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((c.k[7] * r2 + c.k[6]) * r2 + c.k[5]) * r2) / (1 + ((c.k[4] * r2 + c.k[1]) * r2 + c.k[0]) * r2);
+        const double deltaX = 2 * c.k[2] * x * y + c.k[3] * (r2 + 2 * x * x) + c.k[8] * r2 + c.k[9] * r2 * r2;
+        const double deltaY = c.k[2] * (r2 + 2 * y * y) + 2 * c.k[3] * x * y + c.k[10] * r2 + c.k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    // RR = K * I: rows (fx, 0, cx), (0, fy, cy), (0, 0, 1)
+    const double xx = c.fx * x + 0.0 * y + c.cx;
+    const double yy = 0.0 * x + c.fy * y + c.cy;
+    const double ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    xo = (float)(xx * ww);
+    yo = (float)(yy * ww);
+}
+
+__global__ __launch_bounds__(256) void k_undistort(UndistortCtx c) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = c.counts ? c.counts[b] : c.n_const;
+    if (i >= n || i >= c.stride) return;
+    oslam_keypoint_t kp = c.keys[(long long)b * c.stride + i];
+    if (!c.passthrough) undistort_point(c, kp.x, kp.y, kp.x, kp.y);
+    c.keysUn[(long long)b * c.stride + i] = kp;
+}
+
+struct RgbdCtx {
+    const oslam_keypoint_t* keys; const oslam_keypoint_t* keysUn; const int* counts; int n_const; int stride;
+    const float* depth; int pitch; long long image_stride; int rows, cols;
+    float mbf; float* uRight; float* mvDepth; int* status;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdCtx c) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = c.counts ? c.counts[b] : c.n_const;
+    if (i >= c.stride) return;
+    const long long o = (long long)b * c.stride + i;
+    float ur = -1.f, dp = -1.f;
+    if (i < n) {
+        const oslam_keypoint_t kp = c.keys[o];
+        const int row = (int)kp.y, col = (int)kp.x;   // Mat::at<float>(v, u) with float arguments: truncation
+        if (row < 0 || row >= c.rows || col < 0 || col >= c.cols) atomicOr(c.status, 1);   // the reference would read out of the image
+        else {
+            const float d = c.depth[(long long)b * c.image_stride + (long long)row * c.pitch + col];
+            if (d > 0) { dp = d; ur = c.keysUn[o].x - __fdiv_rn(c.mbf, d); }
+        }
+    }
+    c.uRight[o] = ur;
+    c.mvDepth[o] = dp;
+}
+
+static int fill_undistort(UndistortCtx& c, const float K4[4], const float* dist, int ndist) {
+    if (!K4 || ndist < 0 || ndist > 12 || (ndist > 0 && !dist) || (ndist != 0 && ndist != 4 && ndist != 5 && ndist != 8 && ndist != 12)) {
+        set_error("distortion vector must have 0, 4, 5, 8 or 12 entries");
+        return OSLAM_E_INVALID;
+    }
+    for (int i = 0; i < 12; i++) c.k[i] = i < ndist ? (double)dist[i] : 0.0;
+    c.iters = ndist > 0 ? 5 : 1;
+    c.passthrough = (ndist == 0 || dist[0] == 0.0f) ? 1 : 0;   // mDistCoef.at<float>(0)==0.0 -> mvKeysUn = mvKeys
+    c.fx = (double)K4[0]; c.fy = (double)K4[1]; c.cx = (double)K4[2]; c.cy = (double)K4[3];
+    c.ifx = 1. / c.fx; c.ify = 1. / c.fy;
+    return OSLAM_OK;
+}
+
+}  // namespace oslam
+
+using namespace oslam;
+
+struct oslam_frame {
+    int device = 0;
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf keys, keysUn, depth, ur, dp, status;
+    PinStage pin;
+};
+
+static int fr_ensure(oslam_frame::Buf& b, size_t bytes) {
+    if (b.p && bytes <= b.cap) return OSLAM_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = bytes + bytes / 2 + 256;
+    OSLAM_HIP_CHECK(hipMalloc(&b.p, b.cap));
+    return OSLAM_OK;
+}
+
+extern "C" {
+
+void oslam_frame_destroy(oslam_frame_t* h) {
+    if (!h) return;
+    oslam_frame::Buf* bs[] = {&h->keys, &h->keysUn, &h->depth, &h->ur, &h->dp, &h->status};
+    for (auto* b : bs)
+        if (b->p) (void)hipFree(b->p);
+    h->pin.release();
+    delete h;
+}
+
+int oslam_frame_create(oslam_frame_t** out, int device) {
+    if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
+    *out = nullptr;
+    int ndev = oslam_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible: the gfx950 frame kernels have no CPU fallback"); return OSLAM_E_HIP; }
+    if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(device));
+    oslam_frame* h = new oslam_frame();
+    h->device = device;
+    *out = h;
+    return OSLAM_OK;
+}
+
+int oslam_frame_undistort_batch_device(const oslam_keypoint_t* d_keys, oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const, int stride,
+                                       int batch, const float K4[4], const float* dist, int ndist, void* stream) {
+    if (!d_keys || !d_keysUn || batch < 1 || stride < 1 || (!d_counts && (n_const < 0 || n_const > stride))) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    UndistortCtx c;
+    int rc = fill_undistort(c, K4, dist, ndist);
+    if (rc) return rc;
+    c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
+    hipLaunchKernelGGL(k_undistort, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
+                                              int stride, int batch, const float* d_depth, int rows, int cols, int pitch, size_t image_stride,
+                                              float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream) {
+    if (!d_keys || !d_keysUn || !d_depth || !d_uRight || !d_mvDepth || !d_status || batch < 1 || stride < 1 || rows < 1 || cols < 1 || pitch < cols ||
+        (!d_counts && (n_const < 0 || n_const > stride))) {
+        set_error("bad argument");
+        return OSLAM_E_INVALID;
+    }
+    RgbdCtx c;
+    c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
+    c.depth = d_depth; c.pitch = pitch; c.image_stride = (long long)image_stride; c.rows = rows; c.cols = cols;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status;
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_frame_undistort_keypoints(oslam_frame_t* h, int n, const oslam_keypoint_t* keys, const float K4[4], const float* dist, int ndist,
+                                    oslam_keypoint_t* keysUn) {
+    if (!h || n < 0 || (n > 0 && (!keys || !keysUn))) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    if (n == 0) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    const size_t bytes = (size_t)n * sizeof(oslam_keypoint_t);
+    int rc;
+    if ((rc = fr_ensure(h->keys, bytes)) || (rc = fr_ensure(h->keysUn, bytes)) || (rc = h->pin.reserve_total(2 * bytes + 4096))) return rc;
+    h->pin.reset();
+    if ((rc = h->pin.upload(h->keys.p, keys, bytes))) return rc;
+    if ((rc = oslam_frame_undistort_batch_device((const oslam_keypoint_t*)h->keys.p, (oslam_keypoint_t*)h->keysUn.p, nullptr, n, n, 1, K4, dist, ndist, nullptr))) return rc;
+    uint8_t* at = nullptr;
+    if ((rc = h->pin.download(h->keysUn.p, bytes, &at))) return rc;
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    memcpy(keysUn, at, bytes);
+    return OSLAM_OK;
+}
+
+int oslam_frame_image_bounds(oslam_frame_t* h, int cols, int rows, const float K4[4], const float* dist, int ndist, float bounds[4]) {
+    if (!h || !bounds || cols < 1 || rows < 1 || !K4) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    if (ndist == 0 || (dist && dist[0] == 0.0f)) { bounds[0] = 0.f; bounds[1] = 0.f; bounds[2] = (float)cols; bounds[3] = (float)rows; return OSLAM_OK; }
+    oslam_keypoint_t c[4], u[4];
+    memset(c, 0, sizeof(c));
+    c[1].x = (float)cols; c[2].y = (float)rows; c[3].x = (float)cols; c[3].y = (float)rows;
+    int rc = oslam_frame_undistort_keypoints(h, 4, c, K4, dist, ndist, u);
+    if (rc) return rc;
+    bounds[0] = fminf(u[0].x, u[2].x);   // mnMinX
+    bounds[2] = fmaxf(u[1].x, u[3].x);   // mnMaxX
+    bounds[1] = fminf(u[0].y, u[1].y);   // mnMinY
+    bounds[3] = fmaxf(u[2].y, u[3].y);   // mnMaxY
+    return OSLAM_OK;
+}
+
+int oslam_frame_stereo_from_rgbd(oslam_frame_t* h, int n, const oslam_keypoint_t* keys, const oslam_keypoint_t* keysUn, const float* depth, int rows,
+                                 int cols, int pitch, float mbf, float* uRight, float* mvDepth) {
+    if (!h || n < 0 || !depth || rows < 1 || cols < 1 || pitch < cols || (n > 0 && (!keys || !keysUn || !uRight || !mvDepth))) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    if (n == 0) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    const size_t kb = (size_t)n * sizeof(oslam_keypoint_t), db = (size_t)rows * pitch * 4;
+    int rc;
+    if ((rc = fr_ensure(h->keys, kb)) || (rc = fr_ensure(h->keysUn, kb)) || (rc = fr_ensure(h->depth, db)) || (rc = fr_ensure(h->ur, (size_t)n * 4)) ||
+        (rc = fr_ensure(h->dp, (size_t)n * 4)) || (rc = fr_ensure(h->status, 4)) || (rc = h->pin.reserve_total(2 * kb + db + (size_t)n * 8 + 8192)))
+        return rc;
+    h->pin.reset();
+    OSLAM_HIP_CHECK(hipMemsetAsync(h->status.p, 0, 4, nullptr));
+    if ((rc = h->pin.upload(h->keys.p, keys, kb)) || (rc = h->pin.upload(h->keysUn.p, keysUn, kb)) || (rc = h->pin.upload(h->depth.p, depth, db))) return rc;
+    if ((rc = oslam_frame_stereo_from_rgbd_batch_device((const oslam_keypoint_t*)h->keys.p, (const oslam_keypoint_t*)h->keysUn.p, nullptr, n, n, 1,
+                                                        (const float*)h->depth.p, rows, cols, pitch, 0, mbf, (float*)h->ur.p, (float*)h->dp.p,
+                                                        (int32_t*)h->status.p, nullptr)))
+        return rc;
+    uint8_t *a_u = nullptr, *a_d = nullptr, *a_s = nullptr;
+    if ((rc = h->pin.download(h->ur.p, (size_t)n * 4, &a_u)) || (rc = h->pin.download(h->dp.p, (size_t)n * 4, &a_d)) || (rc = h->pin.download(h->status.p, 4, &a_s))) return rc;
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    int st;
+    memcpy(&st, a_s, 4);
+    if (st) { set_error("a keypoint lies outside the depth image"); return OSLAM_E_INVALID; }
+    memcpy(uRight, a_u, (size_t)n * 4);
+    memcpy(mvDepth, a_d, (size_t)n * 4);
+    return OSLAM_OK;
+}
+
+}  // extern "C"

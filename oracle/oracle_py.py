@@ -408,3 +408,34 @@ def triangulate(kf1, kf2, idx1, idx2, scaleFactors, levelSigma2, ratioFactor):
                          _p(np.ascontiguousarray(levelSigma2, np.float32)), float(ratioFactor), _p(ok), _p(x))
     assert n == int(ok[:M].sum())
     return ok[:M], x[:M]
+
+
+def undistort_keypoints(keys, K4, dist):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    out = np.zeros(max(len(keys), 1), KP_DTYPE)
+    d = np.ascontiguousarray(dist if dist is not None else [], np.float32)
+    L = lib()
+    L.oo_undistort_keypoints.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oo_undistort_keypoints(len(keys), _p(keys), _p(np.asarray(K4, np.float32)), _p(d) if len(d) else None, len(d), _p(out))
+    return out[:len(keys)]
+
+
+def image_bounds(cols, rows, K4, dist):
+    d = np.ascontiguousarray(dist if dist is not None else [], np.float32)
+    b = np.zeros(4, np.float32)
+    L = lib()
+    L.oo_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.oo_image_bounds(cols, rows, _p(np.asarray(K4, np.float32)), _p(d) if len(d) else None, len(d), _p(b))
+    return np.array([b[0], b[1], b[2], b[3]], np.float32)
+
+
+def stereo_from_rgbd(keys, keysUn, depth, mbf):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+    depth = np.ascontiguousarray(depth, np.float32)
+    n = len(keys)
+    ur, dp = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    L = lib()
+    L.oo_stereo_from_rgbd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.oo_stereo_from_rgbd(n, _p(keys), _p(keysUn), _p(depth), depth.shape[1], float(mbf), _p(ur), _p(dp))
+    return ur[:n], dp[:n]
