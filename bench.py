@@ -200,6 +200,15 @@ def main():
     from object_slam_amd.parallel import aggregate_stats
     total_frames, elapsed = aggregate_stats(elapsed, B * args.steps, device="cuda")
 
+    if os.environ.get("OSLAM_MATCH_DEBUG"):   # phase stamps of the matcher kernel (profiling builds)
+        import ctypes as _C
+        dbg = (_C.c_longlong * 8)()
+        mt.L.oslam_match_debug_counters(mt.h, dbg, 1)
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        mt.L.oslam_match_debug_counters(mt.h, dbg, 1)
+        print("MATCH_PHASES_us_per_launch", [round(v * 0.01 / 10, 1) for v in dbg], file=sys.stderr)
     # sanity on results (outside the timed region): matches found, no arena overflow
     nm, qm, qd, km, iters = mt.fetch(B // 2, cap, int(last_n[B // 2]), cap, int(counts[B // 2]), st)
     k_chk, _ = ex.fetch(B // 2)   # raises on overflow status

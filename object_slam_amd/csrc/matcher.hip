@@ -40,6 +40,7 @@ struct MatchCtx {
     int* iters;               // [B] fixpoint iterations used (diagnostic)
     uint32_t* cache;          // [B][q_stride][kCacheCap] gate-passing candidates of every query: dist << 16 | index, reference order
     int* ccount;              // [B][q_stride] cached count, or -1 if the query has more than kCacheCap candidates
+    long long* dbg;           // [8] phase stamps of frame 0 (profiling builds, -DOSLAM_MATCH_PROFILE)
 };
 
 __host__ __device__ inline size_t match_lds_bytes(int ncap) {
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     int* ccount = c.ccount + (long long)b * c.q_stride;
 
     extern __shared__ __align__(16) uint8_t smem[];
-    uint32_t* s_desc = (uint32_t*)smem;                     // [ncap][8]
+    uint32_t* s_desc = (uint32_t*)smem;                     // [ncap][8] (a word-major layout was measured slower: 8 ds_read_b32 instead of 2 ds_read_b128 per candidate)
     float2* s_xy = (float2*)(s_desc + (size_t)ncap * 8);    // [ncap]
     float* s_ur = (float*)(s_xy + ncap);                    // [ncap]
     int* s_Bcur = (int*)(s_ur + ncap);                      // [ncap] min blocking claimer (this iteration)
@@ -77,6 +78,12 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     __shared__ int s_changed, s_nm, s_ind[3];
     __shared__ int s_wtot[kMatchThreads / 64];
 
+#ifdef OSLAM_MATCH_PROFILE
+    long long tw_ = wall_clock64();
+#define MSTAMP(i) do { __syncthreads(); if (b == 0 && tid == 0) { const long long t_ = wall_clock64(); c.dbg[i] += t_ - tw_; tw_ = t_; } } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
     if (N > ncap || N < 0 || M < 0 || M > c.q_stride) {   // host validates; never truncate silently
         if (tid == 0) c.nmatches[b] = -1;
         return;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     }
     for (int i = tid; i < N * 8; i += kMatchThreads) s_desc[i] = gdesc[i];
     __syncthreads();
+    MSTAMP(0);
     // exclusive scan of the 3072 cell counts (3 per thread)
     {
         const int lane = tid & 63, wv = tid >> 6;
@@ -144,26 +152,49 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     }
     __syncthreads();
 
+    MSTAMP(1);
+#if defined(OSLAM_MATCH_ABLATE) && OSLAM_MATCH_ABLATE == 1
+    if (tid == 0) { c.nmatches[b] = 0; if (c.iters) c.iters[b] = 0; }
+    return;   // timing experiment: staging + grid only
+#endif
     // ---- fixpoint over the sequential claim order (:87-89, :123 / :1402-1404, :1428) ----
+    // A thread's first query (j == tid) keeps its flags, its cached-candidate count and the first kRegCache cached
+    // candidates in registers after iteration 0, so the replay iterations of frames with <= 1024 queries touch no
+    // global memory (each replay used to walk the per-query list in HBM/L2 with one exposed latency per entry).
+    constexpr int kRegCache = 16;
+    uint32_t rc[kRegCache];
+#pragma unroll
+    for (int t = 0; t < kRegCache; t++) rc[t] = 0;
+    int my_flags = 0, my_nc = -1;
     int it = 0;
     for (; it < M + 2; it++) {
         for (int i = tid; i < N; i += kMatchThreads) s_Bcur[i] = 0x7fffffff;
         if (tid == 0) s_changed = 0;
         __syncthreads();
+        if (it == 1 && tid < M) {   // this thread wrote the list in iteration 0: read it back once, as vectors
+            my_nc = ccount[tid];
+            const uint4* cv = (const uint4*)(cache + (long long)tid * kCacheCap);
+#pragma unroll
+            for (int t = 0; t < kRegCache / 4; t++) {
+                const uint4 v = cv[t];
+                rc[4 * t] = v.x; rc[4 * t + 1] = v.y; rc[4 * t + 2] = v.z; rc[4 * t + 3] = v.w;
+            }
+        }
         for (int j = tid; j < M; j += kMatchThreads) {
             const oslam_proj_query_t* qp = Q + j;
             int bestIdx = -1, bestDist = 256;
-            const int flags = qp->flags;
-            const int ncached = it > 0 ? ccount[j] : -1;
+            const bool mine = (j == tid) && it > 0;
+            const int flags = mine ? my_flags : qp->flags;
+            if (j == tid && it == 0) my_flags = flags;
+            const int ncached = it > 0 ? (mine ? my_nc : ccount[j]) : -1;
             if ((flags & 1) && ncached >= 0) {
                 // iterations >= 1: the gate-passing candidates and their distances do not change, only the
                 // claims do: replay the cached list (reference order) against the current claim table
                 int bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
                 const uint32_t* cl = cache + (long long)j * kCacheCap;
-                for (int t = 0; t < ncached; t++) {
-                    const uint32_t en = cl[t];
+                auto consider = [&](uint32_t en) {
                     const int k = en & 0xFFFF, dist = en >> 16;
-                    if (s_Bprev[k] < j) continue;
+                    if (s_Bprev[k] < j) return;
                     const int oct = s_oct[k];
                     if (dist < bestDist) {
                         bestDist2 = bestDist; bestDist = dist;
@@ -172,6 +203,14 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                     } else if (dist < bestDist2) {
                         bestLevel2 = oct; bestDist2 = dist;
                     }
+                };
+                if (mine) {
+#pragma unroll
+                    for (int t = 0; t < kRegCache; t++)
+                        if (t < ncached) consider(rc[t]);
+                    for (int t = kRegCache; t < ncached; t++) consider(cl[t]);
+                } else {
+                    for (int t = 0; t < ncached; t++) consider(cl[t]);
                 }
                 if (bestDist <= c.th_high) {
                     if (c.use_ratio && bestLevel == bestLevel2 && (float)bestDist > c.nnratio * (float)bestDist2) bestIdx = -1;
@@ -180,8 +219,9 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
             } else if (flags & 1) {
                 int nc = 0;   // candidates cached in iteration 0
                 uint32_t* cl = cache + (long long)j * kCacheCap;
-                const float x = qp->u, y = qp->v, r = qp->radius, qur = qp->ur;
-                const int minLevel = qp->minLevel, maxLevel = qp->maxLevel;
+                const uint4 qa = ((const uint4*)qp)[0], qb = ((const uint4*)qp)[1];   // u, v, ur, radius | minLevel, maxLevel, flags, angle
+                const float x = __uint_as_float(qa.x), y = __uint_as_float(qa.y), qur = __uint_as_float(qa.z), r = __uint_as_float(qa.w);
+                const int minLevel = (int)qb.x, maxLevel = (int)qb.y;
                 // GetFeaturesInArea (:567-620)
                 const int nMinCellX = max(0, (int)floorf((x - c.minX - r) * c.invW));
                 const int nMaxCellX = min(kGridCols - 1, (int)ceilf((x - c.minX + r) * c.invW));
@@ -189,10 +229,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                 const int nMaxCellY = min(kGridRows - 1, (int)ceilf((y - c.minY + r) * c.invH));
                 if (nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows && nMaxCellY >= 0) {
                     const bool bCheckLevels = !c.fuse && ((minLevel > 0) || (maxLevel >= 0));   // KeyFrame::GetFeaturesInArea has no level filter
-                    uint32_t qd[8];
-                    const uint32_t* qdp = (const uint32_t*)qp->desc;
-#pragma unroll
-                    for (int w = 0; w < 8; w++) qd[w] = qdp[w];
+                    const uint4 qd0 = ((const uint4*)qp)[2], qd1 = ((const uint4*)qp)[3];
+                    const uint32_t qd[8] = {qd0.x, qd0.y, qd0.z, qd0.w, qd1.x, qd1.y, qd1.z, qd1.w};
                     int bestLevel = -1, bestDist2 = 256, bestLevel2 = -1;
                     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
                         const int c0 = ix * kGridRows + nMinCellY;
@@ -262,6 +300,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
         __syncthreads();
         const int changed = s_changed;
         __syncthreads();
+        if (it == 0) MSTAMP(2); else MSTAMP(3);
+#if defined(OSLAM_MATCH_ABLATE) && OSLAM_MATCH_ABLATE == 2
+        break;   // timing experiment: first pass only
+#endif
         if (!changed || c.fuse) break;   // Fuse has no claims: one pass
         { int* t = s_Bcur; s_Bcur = s_Bprev; s_Bprev = t; }
     }
@@ -329,6 +371,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
         c.nmatches[b] = s_nm;
         if (c.iters) c.iters[b] = it + 1;
     }
+    MSTAMP(4);
 }
 
 // Projection half of SearchByProjection(Cur, Last), reference src/ORBmatcher.cc:1338-1392.
@@ -430,6 +473,7 @@ struct oslam_matcher {
     int* d_q_match = nullptr; int* d_q_dist = nullptr; int* d_kp_match = nullptr; int* d_nm = nullptr; int* d_iters = nullptr;
     uint32_t* d_cache = nullptr; int* d_ccount = nullptr;
     oslam_proj_query_t* d_queries = nullptr;   // internal query buffer (project_last / host API)
+    long long* d_dbg = nullptr;
     int* d_nq = nullptr;
     // staging for the host API (batch 1)
     oslam_keypoint_t* d_kps = nullptr; float* d_ur = nullptr; uint8_t* d_desc = nullptr; uint8_t* d_blocked = nullptr;
@@ -441,7 +485,7 @@ extern "C" {
 
 void oslam_matcher_destroy(oslam_matcher_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_cache, h->d_ccount, h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
+    void* ptrs[] = {h->d_dbg, h->d_cache, h->d_ccount, h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
                     h->d_desc, h->d_blocked, h->d_Xw, h->d_has, h->d_lkeys, h->d_ldesc, h->d_T};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -476,7 +520,7 @@ int oslam_matcher_create(oslam_matcher_t** out, int max_batch, int max_keypoints
     } while (0)
     ALLOC(h->d_q_match, B * NQ * 4); ALLOC(h->d_q_dist, B * NQ * 4); ALLOC(h->d_kp_match, B * NK * 4);
     ALLOC(h->d_cache, B * NQ * kCacheCap * 4); ALLOC(h->d_ccount, B * NQ * 4);
-    ALLOC(h->d_nm, B * 4); ALLOC(h->d_iters, B * 4); ALLOC(h->d_queries, B * NQ * sizeof(oslam_proj_query_t)); ALLOC(h->d_nq, B * 4);
+    ALLOC(h->d_nm, B * 4); ALLOC(h->d_iters, B * 4); ALLOC(h->d_dbg, 64); ALLOC(h->d_queries, B * NQ * sizeof(oslam_proj_query_t)); ALLOC(h->d_nq, B * 4);
     ALLOC(h->d_kps, NK * sizeof(oslam_keypoint_t)); ALLOC(h->d_ur, NK * 4); ALLOC(h->d_desc, NK * 32); ALLOC(h->d_blocked, NK);
     ALLOC(h->d_Xw, NQ * 12); ALLOC(h->d_has, NQ); ALLOC(h->d_lkeys, NQ * sizeof(oslam_keypoint_t)); ALLOC(h->d_ldesc, NQ * 32); ALLOC(h->d_T, 32 * 4);
 #undef ALLOC
@@ -531,7 +575,7 @@ static int search_impl(oslam_matcher_t* h, const oslam_match_frames_t* f, const 
     c.nnratio = nnratio; c.use_ratio = use_ratio; c.check_ori = check_ori; c.th_high = th_high;
     c.fuse = invLevelSigma2 ? 1 : 0;
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) c.invSigma2[i] = (invLevelSigma2 && i < nlevels) ? invLevelSigma2[i] : 0.f;
-    c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters;
+    c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters; c.dbg = h->d_dbg;
     c.cache = h->d_cache; c.ccount = h->d_ccount;
     // per-frame output strides equal the input strides; outputs were sized for max_q / max_kps
     if ((size_t)f->kp_stride > (size_t)h->max_kps) { set_error("kp_stride %d > max_keypoints %d", f->kp_stride, h->max_kps); return OSLAM_E_CAPACITY; }
@@ -571,6 +615,13 @@ int oslam_match_results_device(const oslam_matcher_t* h, const int32_t** q_match
     if (nmatches) *nmatches = h->d_nm;
     if (queries) *queries = h->d_queries;
     if (n_queries) *n_queries = h->d_nq;
+    return OSLAM_OK;
+}
+
+int oslam_match_debug_counters(oslam_matcher_t* h, long long out[8], int reset) {
+    if (!h || !out) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipMemcpy(out, h->d_dbg, 64, hipMemcpyDeviceToHost));
+    if (reset) OSLAM_HIP_CHECK(hipMemset(h->d_dbg, 0, 64));
     return OSLAM_OK;
 }
 
