@@ -424,9 +424,10 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     for (int l = 1; l < P.nlevels; l++) {
         const LevelGeom& g = P.lv[l];
         dim3 grid(div_up(g.w, 256), div_up(g.h, 4), batch);
+        dim3 gridw(div_up(g.w, 256), div_up(g.h, 4 * kResizeRows), batch);
         // source rows 4-byte aligned? (levels >= 1 always; level 0 is the caller's buffer)
         const bool src_aligned = l > 1 || (((stride & 3) == 0) && ((((uintptr_t)d_gray) & 3) == 0) && ((image_stride & 3) == 0));
-        if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, grid, dim3(256), 0, st, c, l);
+        if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, gridw, dim3(256), 0, st, c, l);
         else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);

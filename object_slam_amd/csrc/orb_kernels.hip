@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void k_resize(OrbCtx c, int level) {
 // Per quad of 4 dst pixels the host tables give the aligned byte offset of a 12-byte source window
 // and, per pixel, (byte offset in the window | a0 << 4 | a1 << 16); three words per source row replace
 // eight byte gathers, pixel pairs are cut out with v_alignbyte.
+constexpr int kResizeRows = 4;   // destination rows per thread: the per-quad x tables (20 B) are loaded once for all of them
+
 __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     const OrbParams* P = c.P;
     const LevelGeom& g = P->lv[level];
@@ -94,39 +96,49 @@ __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     const int b = blockIdx.z;
     const int q = blockIdx.x * 64 + (threadIdx.x & 63);   // quad index
     const int x4 = q * 4;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= g.h || x4 >= g.w) return;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kResizeRows;
+    if (y0 >= g.h || x4 >= g.w) return;
     int spitch;
     const uint8_t* src = level_image(c, P, b, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)b * c.pyr_stride + g.img_off;
-    const int2 ty = c.rtab[g.ytab_off + y];
-    const int sy0 = min(max(ty.x, 0), gs.h - 1), sy1 = min(max(ty.x + 1, 0), gs.h - 1);
-    const int b0 = (short)(ty.y & 0xFFFF), b1 = (short)(ty.y >> 16);
     const int xb = c.qbase[g.qtab_off + q];
     const uint4 tq = c.qpx[g.qtab_off + q];
     const int maxoff = (gs.w - 1) & ~3;
     const int o1 = min(xb + 4, maxoff), o2 = min(xb + 8, maxoff);
-    const uint8_t* S0 = src + (long long)sy0 * spitch;
-    const uint8_t* S1 = src + (long long)sy1 * spitch;
-    const uint32_t u0 = *(const uint32_t*)(S0 + xb), u1 = *(const uint32_t*)(S0 + o1), u2 = *(const uint32_t*)(S0 + o2);
-    const uint32_t v0 = *(const uint32_t*)(S1 + xb), v1 = *(const uint32_t*)(S1 + o1), v2 = *(const uint32_t*)(S1 + o2);
     const uint32_t tp[4] = {tq.x, tq.y, tq.z, tq.w};
-    uint32_t outw = 0;
+    // all source words of the kResizeRows rows are requested before the first one is used
+    uint32_t u0[kResizeRows], u1[kResizeRows], u2[kResizeRows], v0[kResizeRows], v1[kResizeRows], v2[kResizeRows];
+    int b0[kResizeRows], b1[kResizeRows];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t t = tp[i];
-        const int o = t & 15, a0 = (t >> 4) & 0xFFF, a1 = (t >> 16) & 0xFFF;
-        const int sel = o >> 2, sh = o & 3;
-        const uint32_t ulo = sel == 0 ? u0 : (sel == 1 ? u1 : u2), uhi = sel == 0 ? u1 : (sel == 1 ? u2 : 0u);
-        const uint32_t vlo = sel == 0 ? v0 : (sel == 1 ? v1 : v2), vhi = sel == 0 ? v1 : (sel == 1 ? v2 : 0u);
-        const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, sh), pv = __builtin_amdgcn_alignbyte(vhi, vlo, sh);
-        const int r0 = (int)(pu & 0xFF) * a0 + (int)((pu >> 8) & 0xFF) * a1;
-        const int r1 = (int)(pv & 0xFF) * a0 + (int)((pv >> 8) & 0xFF) * a1;
-        int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
-        outw |= (uint32_t)v << (8 * i);
+    for (int r = 0; r < kResizeRows; r++) {
+        const int y = min(y0 + r, g.h - 1);
+        const int2 ty = c.rtab[g.ytab_off + y];
+        const int sy0 = min(max(ty.x, 0), gs.h - 1), sy1 = min(max(ty.x + 1, 0), gs.h - 1);
+        b0[r] = (short)(ty.y & 0xFFFF); b1[r] = (short)(ty.y >> 16);
+        const uint8_t* S0 = src + (long long)sy0 * spitch;
+        const uint8_t* S1 = src + (long long)sy1 * spitch;
+        u0[r] = *(const uint32_t*)(S0 + xb); u1[r] = *(const uint32_t*)(S0 + o1); u2[r] = *(const uint32_t*)(S0 + o2);
+        v0[r] = *(const uint32_t*)(S1 + xb); v1[r] = *(const uint32_t*)(S1 + o1); v2[r] = *(const uint32_t*)(S1 + o2);
     }
-    *(uint32_t*)(dst + (long long)y * g.pitch + x4) = outw;
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) {
+        uint32_t outw = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t t = tp[i];
+            const int o = t & 15, a0 = (t >> 4) & 0xFFF, a1 = (t >> 16) & 0xFFF;
+            const int sel = o >> 2, sh = o & 3;
+            const uint32_t ulo = sel == 0 ? u0[r] : (sel == 1 ? u1[r] : u2[r]), uhi = sel == 0 ? u1[r] : (sel == 1 ? u2[r] : 0u);
+            const uint32_t vlo = sel == 0 ? v0[r] : (sel == 1 ? v1[r] : v2[r]), vhi = sel == 0 ? v1[r] : (sel == 1 ? v2[r] : 0u);
+            const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, sh), pv = __builtin_amdgcn_alignbyte(vhi, vlo, sh);
+            const int r0 = (int)(pu & 0xFF) * a0 + (int)((pu >> 8) & 0xFF) * a1;
+            const int r1 = (int)(pv & 0xFF) * a0 + (int)((pv >> 8) & 0xFF) * a1;
+            int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            outw |= (uint32_t)v << (8 * i);
+        }
+        if (y0 + r < g.h) *(uint32_t*)(dst + (long long)(y0 + r) * g.pitch + x4) = outw;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
