@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
 // sums and keeps the last seven rows of sums in registers; no LDS, no barriers.  All levels of
 // all images in one launch (blockIdx.x -> level through OrbParams::blur_block_base).
 // ------------------------------------------------------------------------------------------
-constexpr int kBlurRows = 16;
+constexpr int kBlurRows = 8;   // measured at B=256 with the up-front loads: 4 -> 1.49, 6 -> 1.30, 8 -> 1.25, 12 -> 2.3, 16 -> 1.43 us/frame
 
 // horizontal 7-tap sums of 4 adjacent pixels.  Interior: three aligned words, byte windows by
 // v_alignbyte, taps by two v_dot4_u32_u8 per pixel (taps 18,34,49,55 fit a byte).
@@ -435,15 +435,36 @@ __global__ __launch_bounds__(256) void k_blur_strip(OrbCtx c, int sse2_rounding)
     const uint32_t KA = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
     const uint32_t KB = (uint32_t)k2 | ((uint32_t)k1 << 8) | ((uint32_t)k0 << 16);
     int win[7][4];
+    // Interior strips: every source word of the strip (kBlurRows + 6 rows x 3 words) is requested before the first
+    // one is used.  Left to itself the compiler issued the three loads of a row right before that row's sums, so a
+    // wavefront paid one full memory latency per row (22 per strip) and the SIMDs idled ~85 % of the time.
+    uint32_t pw0[BORDER ? 1 : kBlurRows + 6], pw1[BORDER ? 1 : kBlurRows + 6], pw2[BORDER ? 1 : kBlurRows + 6];
+    if (!BORDER) {
 #pragma unroll
-    for (int r = 0; r < 6; r++)
-        blur_hsum4<BORDER>(src + (long long)reflect101(min(y0 - 3 + r, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[r]);
+        for (int r = 0; r < kBlurRows + 6; r++) {
+            const uint8_t* row = src + (long long)reflect101(min(y0 - 3 + r, g.h + 2), g.h) * spitch;
+            pw0[r] = *(const uint32_t*)(row + x4 - 4); pw1[r] = *(const uint32_t*)(row + x4); pw2[r] = *(const uint32_t*)(row + x4 + 4);
+        }
+    }
+    auto hsum_pre = [&](int r, int (&out)[4]) {   // the four horizontal sums of prefetched row r
+        const uint32_t w0 = pw0[r], w1 = pw1[r], w2 = pw2[r];
+        out[0] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), KB, 0u, false), false);
+        out[1] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), KB, 0u, false), false);
+        out[2] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), KA, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), KB, 0u, false), false);
+        out[3] = (int)__builtin_amdgcn_udot4(w1, KA, __builtin_amdgcn_udot4(w2, KB, 0u, false), false);
+    };
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        if (!BORDER) hsum_pre(r, win[r]);
+        else blur_hsum4<BORDER>(src + (long long)reflect101(min(y0 - 3 + r, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[r]);
+    }
 #pragma unroll
     for (int iy = 0; iy < kBlurRows; iy++) {
         const int y = y0 + iy;
         // no early exit: rows past the image are computed from clamped/reflected addresses and not stored, so
-        // the unrolled loop has no control dependence and all row loads can be issued up front
-        blur_hsum4<BORDER>(src + (long long)reflect101(min(y + 3, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[6]);
+        // the unrolled loop has no control dependence
+        if (!BORDER) hsum_pre(iy + 6, win[6]);
+        else blur_hsum4<BORDER>(src + (long long)reflect101(min(y + 3, g.h + 2), g.h) * spitch, x4, g.w, KA, KB, k0, k1, k2, k3, win[6]);
         uint32_t outw = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
