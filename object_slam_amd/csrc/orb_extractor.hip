@@ -64,6 +64,8 @@ struct oslam_orb {
     int* d_status = nullptr;
     unsigned long long* d_dbg = nullptr;
     size_t oct_lds = 0;
+    hipStream_t side_stream = nullptr;             // blur runs here, concurrently with FAST + quad-tree
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
     int profiling = 0;
@@ -115,6 +117,9 @@ void oslam_orb_destroy(oslam_orb_t* h) {
         if (p) (void)hipFree(p);
     for (hipEvent_t e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     delete h;
 }
 
@@ -364,6 +369,9 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
     OSLAM_HIP_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     *out = h;
     return OSLAM_OK;
 }
@@ -431,13 +439,25 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);
+    // The blur needs only the pyramid; FAST + quad-tree need only the pyramid too.  Outside profiling runs the blur goes
+    // to a side stream and overlaps the (VALU-bound) FAST kernel and the (barrier-latency-bound) quad-tree kernel.
+    const bool overlap = !prof && h->side_stream != nullptr;
+    hipStream_t sb = overlap ? h->side_stream : st;
+    if (overlap) {
+        OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork, st));
+        OSLAM_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
+    }
     hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), batch), dim3(256), 0, st, c);
     if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
     PROF_MARK(2);
-    hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, st, c, h->blur_sse2);
-    hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], batch), dim3(256), 0, st, c, h->blur_sse2);
+    hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
+    hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
     PROF_MARK(3);
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
+    if (overlap) {
+        OSLAM_HIP_CHECK(hipEventRecord(h->ev_join, sb));
+        OSLAM_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
     PROF_MARK(4);
     {
         const int kpw = batch >= 32 ? 16 : (batch >= 8 ? 4 : 1);
