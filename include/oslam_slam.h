@@ -1,0 +1,174 @@
+/*
+ * oslam_slam.h — C ABI of the batch-of-sequences tracking + local-mapping driver.
+ *
+ * S independent RGB-D sequences advance in lockstep on one GPU: every stage of the reference's per-frame call
+ * pattern (Tracking::GrabImageRGBD -> Track, src/Tracking.cc:241-587; LocalMapping::Run, src/LocalMapping.cc:48-113)
+ * is executed for all sequences as ONE batch of the hot-path operators of oslam_hip.h.  The map bookkeeping between
+ * the operator calls (MapPoint / KeyFrame / covisibility graph / spanning tree) is host C++ over flat, index-based
+ * arrays.  The driver reproduces the reference's control flow for the STEREO/RGBD SLAM mode:
+ *   StereoInitialization :590-642, CheckReplacedInLastFrame :820, TrackReferenceKeyFrame :838, UpdateLastFrame :882,
+ *   TrackWithMotionModel :948, TrackLocalMap :1011 (UpdateLocalKeyFrames :1496, UpdateLocalPoints :1470,
+ *   SearchLocalPoints :1408), NeedNewKeyFrame :1242, CreateNewKeyFrame :1328, and on the mapping side
+ *   ProcessNewKeyFrame (src/LocalMapping.cc:129), MapPointCulling :171, CreateNewMapPoints :208, SearchInNeighbors :455,
+ *   Optimizer::LocalBundleAdjustment's graph gather / write-back (src/Optimizer.cc:456-504, :746-777), KeyFrameCulling :633.
+ * Normalisations (the reference is not deterministic there):
+ *   - LocalMapping runs synchronously after the frame that inserted the keyframe (the reference runs it on a second
+ *     thread; AcceptKeyFrames() is therefore always true and the BA is never interrupted);
+ *   - containers ordered by pointer value (std::map<KeyFrame*,..>, std::set<KeyFrame*>, pair<int,KeyFrame*> sorts)
+ *     are ordered by keyframe id;
+ *   - DBoW2 and its vocabulary are not in the reference tree: ComputeBoW uses a substitute vocabulary (k = 10, two
+ *     levels of seeded random 256-bit words, nearest child by Hamming distance) that yields the same FeatureVector
+ *     structure (node id at the 4th level from the leaves -> keypoint indices);
+ *   - out of scope: Relocalization (a lost sequence stays LOST), loop closing, the object layer
+ *     (TrackObject / UpdateCurrentObject), the viewer.  PoseOptimization2 without matched objects is PoseOptimization.
+ */
+#ifndef OSLAM_SLAM_H
+#define OSLAM_SLAM_H
+
+#include "oslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oslam_slam oslam_slam_t;
+
+/* Settings the reference reads from the YAML file (src/Tracking.cc:60-170). */
+typedef struct oslam_slam_config {
+    int32_t width, height;
+    float fx, fy, cx, cy;        /* Camera.fx .. */
+    float dist[5]; int32_t ndist; /* Camera.k1,k2,p1,p2[,k3] */
+    float bf;                    /* Camera.bf */
+    float thDepth;               /* ThDepth: mThDepth = bf * ThDepth / fx (:159) */
+    float fps;                   /* Camera.fps: mMaxFrames = fps, mMinFrames = 0 (:109-110) */
+    int32_t nFeatures; float scaleFactor; int32_t nLevels, iniThFAST, minThFAST;   /* ORBextractor.* */
+    int32_t n_sequences;         /* S: sequences advanced per call */
+    int32_t device;
+    int32_t host_threads;        /* worker threads for the per-sequence bookkeeping (0 = 1) */
+    int32_t local_mapping;       /* bit0 MapPointCulling, bit1 CreateNewMapPoints, bit2 SearchInNeighbors, bit3 LocalBundleAdjustment,
+                                    bit4 KeyFrameCulling; 0x1F = the reference's LocalMapping::Run */
+} oslam_slam_config_t;
+
+#define OSLAM_SLAM_NOT_INITIALIZED 1   /* Tracking::eTrackingState, include/Tracking.h:91-97 */
+#define OSLAM_SLAM_OK 2
+#define OSLAM_SLAM_LOST 3
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Operator table: the batched hot-path calls the driver makes.  oslam_slam_create() binds the HIP implementation
+ * (slam_ops_hip.hip: the kernels behind oslam_hip.h, chained on the device); the table is a public type only so that
+ * tests can run the same driver over another implementation and compare trajectories.  All pointers are host
+ * pointers unless a field says otherwise; every call is synchronous (results are in the job structs on return).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct oslam_slam_frame {          /* what Frame::Frame leaves behind (src/Frame.cc:117-172) */
+    int32_t N;
+    oslam_keypoint_t* keys;                /* mvKeys   [cap] */
+    oslam_keypoint_t* keysUn;              /* mvKeysUn [cap] */
+    uint8_t* desc;                         /* mDescriptors [cap][32] */
+    float* uRight;                         /* mvuRight [cap] */
+    float* depth;                          /* mvDepth  [cap] */
+} oslam_slam_frame_t;
+
+typedef struct oslam_job_search_last {     /* ORBmatcher::SearchByProjection(Cur, Last, th, bMono), src/ORBmatcher.cc:1328 */
+    int32_t slot;                          /* sequence index: cur is the frame built for this slot in this step */
+    const oslam_slam_frame_t* cur;
+    int32_t Nlast; const float* Xw; const uint8_t* has_mp; const oslam_keypoint_t* last_keysUn; const uint8_t* mp_desc;
+    float Tcw[16], Tlw[16]; float th;
+    int32_t* kp_match;                     /* out [cur->N]: last-frame keypoint whose map point is now in mvpMapPoints[k]; < 0 none */
+    int32_t nmatches;                      /* out */
+} oslam_job_search_last_t;
+
+typedef struct oslam_job_search_local {    /* Frame::isInFrustum(pMP, 0.5) over the local points + SearchByProjection(F, points, th), nnratio 0.8 */
+    int32_t slot; const oslam_slam_frame_t* cur; const uint8_t* blocked /* [N] mvpMapPoints[i] && Observations()>0 */;
+    int32_t M; const float* Pw; const float* Pn; const float* maxDist; const float* minDist; const uint8_t* obs_gt0; const uint8_t* mp_desc;
+    float Tcw[16]; float th;
+    uint8_t* in_view;                      /* out [M]: mbTrackInView */
+    int32_t* kp_match;                     /* out [N]: local point index now in mvpMapPoints[k]; < 0 none */
+    int32_t nmatches;
+} oslam_job_search_local_t;
+
+typedef struct oslam_job_pose {            /* Optimizer::PoseOptimization, src/Optimizer.cc:239 */
+    int32_t slot; int32_t N; float Tcw_in[16];
+    const float* Xw; const float* obs; const float* invSigma2; const uint8_t* has_mp;
+    float Tcw_out[16]; uint8_t* outlier; int32_t n_inliers;   /* out */
+} oslam_job_pose_t;
+
+typedef struct oslam_job_mp_update {       /* MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over P points (CSR observations) */
+    int32_t P; const int32_t* obs_start; const uint8_t* obs_desc; const float* obs_Ow;
+    const float* Pos; const float* OwRef; const float* levelScaleFactor;
+    int32_t do_desc, do_normal;
+    int32_t* best_idx; uint8_t* out_desc; float* out5;      /* out: see oslam_mp_distinctive_descriptors / oslam_mp_update_normal_depth */
+} oslam_job_mp_update_t;
+
+typedef struct oslam_job_fuse {            /* search half of ORBmatcher::Fuse on one keyframe, src/ORBmatcher.cc:888-947 */
+    int32_t N; const oslam_keypoint_t* keysUn; const float* uRight; const uint8_t* desc;
+    int32_t M; const oslam_proj_query_t* queries;
+    int32_t* q_match;                      /* out [M] */
+} oslam_job_fuse_t;
+
+typedef struct oslam_job_bow {             /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657) */
+    oslam_bow_side1_t s1; oslam_bow_side2_t s2;
+    int32_t triangulation;                 /* 0: SearchByBoW nnratio 0.7 checkOri 1; 1: SearchForTriangulation nnratio 0.6 checkOri 0 */
+    float nnratio; int32_t checkOri;
+    float F12[9]; float ex, ey;
+    int32_t* match;                        /* out: SearchByBoW [s2.N] keyframe keypoint per frame keypoint; triangulation [s1.N] */
+    int32_t nmatches;
+} oslam_job_bow_t;
+
+typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (current keyframe, neighbour) pair */
+    oslam_tri_kf_t kf1, kf2; int32_t M; const int32_t* idx1; const int32_t* idx2;
+    uint8_t* ok; float* x3D;
+} oslam_job_triangulate_t;
+
+typedef struct oslam_slam_ops {
+    void* ctx;
+    /* capacity of the per-frame arrays the driver must allocate */
+    int (*max_keypoints)(void* ctx);
+    /* scale tables of the extractor (include/ORBextractor.h:63-83) */
+    int (*scale_tables)(void* ctx, float* scale, float* invScale, float* sigma2, float* invSigma2);
+    /* Frame::ComputeImageBounds */
+    int (*image_bounds)(void* ctx, float bounds[4]);
+    /* Frame::Frame for n RGB-D frames: ExtractORB + UndistortKeyPoints + ComputeStereoFromRGBD.  gray[i]: width x height u8 with row
+     * pitch gray_stride; depth[i]: CV_32F metres with row pitch depth_pitch floats; on_device != 0: both are device pointers. */
+    int (*frames_rgbd)(void* ctx, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth,
+                       int depth_pitch, int on_device, oslam_slam_frame_t* const* out);
+    int (*search_last)(void* ctx, int n, oslam_job_search_last_t* jobs);
+    int (*search_local)(void* ctx, int n, oslam_job_search_local_t* jobs);
+    int (*pose_opt)(void* ctx, int n, oslam_job_pose_t* jobs);
+    int (*mp_update)(void* ctx, oslam_job_mp_update_t* job);
+    int (*lba)(void* ctx, int n, const oslam_lba_problem_t* probs);
+    int (*fuse)(void* ctx, int n, oslam_job_fuse_t* jobs);
+    int (*bow)(void* ctx, int n, oslam_job_bow_t* jobs);
+    int (*triangulate)(void* ctx, int n, oslam_job_triangulate_t* jobs);
+    void (*destroy)(void* ctx);
+} oslam_slam_ops_t;
+
+/* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
+int oslam_slam_create(oslam_slam_t** out, const oslam_slam_config_t* cfg);
+/* Same driver over a caller-supplied operator table (ownership of ops->ctx passes to the handle). Test seam. */
+int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cfg, const oslam_slam_ops_t* ops);
+void oslam_slam_destroy(oslam_slam_t* h);
+
+/* System::TrackRGBD (include/System.h:75) for every sequence: gray[s] / depth[s] = next frame of sequence s (depth in metres,
+ * i.e. after the DepthMapFactor scaling of src/Tracking.cc:262).  Tcw_out [S][16] = mCurrentFrame.mTcw (zeros while the sequence has no
+ * pose), state_out [S] = mState after the frame. */
+int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch,
+                          int on_device, const double* timestamps, float* Tcw_out, int32_t* state_out);
+
+/* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
+ * Twc [n][12] = rows of [Rwc | twc]; lost frames are skipped like the reference.  Returns the count in *n_out (cap < n -> OSLAM_E_CAPACITY). */
+int oslam_slam_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out);
+/* System::SaveKeyFrameTrajectoryTUM (:443-477): non-bad keyframes by id. */
+int oslam_slam_keyframe_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out);
+
+/* Counters of one sequence: [0] frames, [1] keyframes created, [2] keyframes in map, [3] map points created, [4] map points in map,
+ * [5] local BAs, [6] frames tracked by the motion model, [7] by the reference keyframe, [8] lost frames, [9] points fused,
+ * [10] points triangulated, [11] keyframes culled, [12] map points culled, [13] last mnMatchesInliers, [14] LBA edges total, [15] map-consistency violations (0). */
+int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]);
+/* Wall-clock seconds spent per stage since creation: [0] frames, [1] search_last, [2] pose_opt, [3] search_local, [4] host tracking,
+ * [5] mp_update, [6] lba, [7] host mapping, [8] fuse/bow/triangulate. */
+int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSLAM_SLAM_H */

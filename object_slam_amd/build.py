@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboslam_hip.so")
-SOURCES = ["orb_extractor.hip", "matcher.hip", "pose_opt.hip", "lba.hip", "stereo.hip", "bow_matcher.hip", "mappoint.hip", "frame.hip"]
+SOURCES = ["orb_extractor.hip", "matcher.hip", "pose_opt.hip", "lba.hip", "stereo.hip", "bow_matcher.hip", "mappoint.hip", "frame.hip", "slam_driver.hip", "slam_ops_hip.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (["-DOSLAM_LBA_PROFILE"] if os.environ.get("OSLAM_LBA_PROFILE") else []) + (["-DOSLAM_FAST_PROFILE"] if os.environ.get("OSLAM_FAST_PROFILE") else []) + (["-DOSLAM_MATCH_PROFILE"] if os.environ.get("OSLAM_MATCH_PROFILE") else []) + (["-DOSLAM_MATCH_ABLATE=" + os.environ["OSLAM_MATCH_ABLATE"]] if os.environ.get("OSLAM_MATCH_ABLATE") else []) + ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
          "-ffp-contract=off",  # host AND device: reference float expressions round once per operator
@@ -18,6 +18,7 @@ def _deps():
     for root, _, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files]
     out.append(os.path.join(HERE, "..", "include", "oslam_hip.h"))
+    out.append(os.path.join(HERE, "..", "include", "oslam_slam.h"))
     return out
 
 

@@ -1,0 +1,1313 @@
+// slam_driver.hip — batch-of-sequences Tracking + LocalMapping driver (include/oslam_slam.h).
+// Host C++ only: the control flow of the reference's Tracking::Track (src/Tracking.cc:310-587) and LocalMapping::Run
+// (src/LocalMapping.cc:48-113) restated as lockstep STAGES over S sequences; every hot-path operator is issued once per
+// stage for all sequences through the operator table (slam_ops_hip.hip binds the HIP kernels).  No CPU fallback lives
+// here: oslam_slam_create() fails without a HIP device.  Never includes oracle/.
+#include <chrono>
+#include <memory>
+
+#include "common.h"
+#include "slam_map.h"
+
+int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* out);   // slam_ops_hip.hip
+
+namespace oslam_drv {
+
+// ---- substitute vocabulary (see include/oslam_slam.h): k = 10, two levels -> 100 feature-vector nodes ----
+struct Vocab {
+    uint64_t top[10][4], sub[10][10][4];
+    Vocab() {
+        uint64_t s = 0x853c49e6748fea9bULL;   // PCG32, fixed seed
+        auto next = [&]() {
+            const uint64_t old = s;
+            s = old * 6364136223846793005ULL + 1442695040888963407ULL;
+            const uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), r = (uint32_t)(old >> 59u);
+            return (x >> r) | (x << ((-r) & 31));
+        };
+        for (int i = 0; i < 10; i++)
+            for (int w = 0; w < 4; w++) top[i][w] = ((uint64_t)next() << 32) | next();
+        for (int i = 0; i < 10; i++)
+            for (int j = 0; j < 10; j++)
+                for (int w = 0; w < 4; w++) sub[i][j][w] = ((uint64_t)next() << 32) | next();
+    }
+    static int dist(const uint64_t* a, const uint64_t* b) {
+        return __builtin_popcountll(a[0] ^ b[0]) + __builtin_popcountll(a[1] ^ b[1]) + __builtin_popcountll(a[2] ^ b[2]) + __builtin_popcountll(a[3] ^ b[3]);
+    }
+    uint32_t node(const uint8_t* d) const {   // DBoW2 tree descent: nearest child, first on ties
+        uint64_t v[4];
+        memcpy(v, d, 32);
+        int b1 = 0, bd = 1 << 30;
+        for (int i = 0; i < 10; i++) { const int dd = dist(v, top[i]); if (dd < bd) { bd = dd; b1 = i; } }
+        int b2 = 0; bd = 1 << 30;
+        for (int j = 0; j < 10; j++) { const int dd = dist(v, sub[b1][j]); if (dd < bd) { bd = dd; b2 = j; } }
+        return 11u + (uint32_t)(b1 * 10 + b2);
+    }
+};
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap() {
+        auto t1 = std::chrono::steady_clock::now();
+        const double d = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+        return d;
+    }
+};
+
+enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
+
+// Per-sequence Tracking + LocalMapping state (include/Tracking.h, include/LocalMapping.h members).
+struct Seq {
+    Map map;
+    Frame fa, fb;
+    Frame* cur = &fa;
+    Frame* last = &fb;
+    int state = ST_NOT_INITIALIZED;
+    int nextFrameId = 0;
+    bool hasVelocity = false;
+    M4 velocity;
+    int refKF = -1, lastKFFrameId = 0, lastRelocFrameId = 0;
+    int matchesInliers = 0;
+    std::vector<int> localKFs, localMPs;
+    std::vector<RelPose> rel;
+    std::vector<int> recentAdded;          // mlpRecentAddedMapPoints
+    std::vector<int> newKFs;               // mlNewKeyFrames (at most one per step)
+    std::vector<int> counter;              // scratch, indexed by keyframe id
+    int64_t st[16] = {0};
+    // per-step scratch
+    int path = 0;                          // 0 none, 1 motion model, 2 reference keyframe
+    bool ok = false;
+    int curKF = -1;                        // keyframe being processed by local mapping this step
+    std::vector<float> jXw, jObs, jInv, jPw, jPn, jMax, jMin;
+    std::vector<uint8_t> jHas, jDesc, jBlocked, jObsGt0, jInView, jOutlier;
+    std::vector<int> jMatch, jLocalIds;
+    std::vector<KP> jKeys;
+};
+
+struct Ctx {
+    oslam_slam_config_t cfg;
+    oslam_slam_ops_t ops;
+    int S = 0, cap = 0;
+    float scale[OSLAM_MAX_LEVELS], invScale[OSLAM_MAX_LEVELS], sigma2[OSLAM_MAX_LEVELS], invSigma2[OSLAM_MAX_LEVELS];
+    float bounds[4];
+    float invfx, invfy, thDepth, mb, logScale;
+    int maxFrames, minFrames;
+    Vocab voc;
+    std::vector<std::unique_ptr<Seq>> seq;
+    double sec[16] = {0};
+};
+
+}  // namespace oslam_drv
+
+using namespace oslam_drv;
+
+struct oslam_slam { Ctx c; };
+
+namespace oslam_drv {
+
+static void compute_bow(const Ctx& c, int N, const uint8_t* desc, std::vector<uint32_t>& out) {
+    if (!out.empty()) return;   // Frame::ComputeBoW / KeyFrame::ComputeBoW: only once
+    out.resize(N);
+    for (int i = 0; i < N; i++) out[i] = c.voc.node(desc + (size_t)i * 32);
+}
+
+// Frame::UnprojectStereo (src/Frame.cc:904-919): mRwc*x3Dc + mOw (gemm small-matrix branch with C)
+static bool unproject_frame(const Ctx& c, const Frame& f, int i, float out[3]) {
+    const float z = f.depth[i];
+    if (!(z > 0)) return false;
+    const float u = f.keysUn[i].x, v = f.keysUn[i].y;
+    const float x = (u - c.cfg.cx) * z * c.invfx, y = (v - c.cfg.cy) * z * c.invfy;
+    for (int r = 0; r < 3; r++) {
+        float s = f.pose.Rwc[r * 3] * x;
+        s += f.pose.Rwc[r * 3 + 1] * y;
+        s += f.pose.Rwc[r * 3 + 2] * z;
+        out[r] = (float)((double)s + (double)f.pose.Ow[r]);
+    }
+    return true;
+}
+
+// KeyFrame::KeyFrame(Frame&, ...) (src/KeyFrame.cc:30-58)
+static int new_keyframe(Seq& s, const Frame& f) {
+    s.map.kfs.emplace_back();
+    KeyFrm& k = s.map.kfs.back();
+    k.id = (int)s.map.kfs.size() - 1;
+    k.frameId = f.id; k.stamp = f.stamp; k.N = f.N;
+    k.keys.assign(f.keys.begin(), f.keys.begin() + f.N);
+    k.keysUn.assign(f.keysUn.begin(), f.keysUn.begin() + f.N);
+    k.desc.assign(f.desc.begin(), f.desc.begin() + (size_t)f.N * 32);
+    k.uRight.assign(f.uRight.begin(), f.uRight.begin() + f.N);
+    k.depth.assign(f.depth.begin(), f.depth.begin() + f.N);
+    k.mp.assign(f.mp.begin(), f.mp.begin() + f.N);
+    k.bowNode = f.bowNode;
+    k.pose.set_keyframe(f.pose.Tcw);
+    k.Tcp = eye4();
+    s.counter.resize(s.map.kfs.size() + 8, 0);
+    s.st[1]++;
+    return k.id;
+}
+
+// ---- batched MapPoint::ComputeDistinctiveDescriptors / UpdateNormalAndDepth over points of several sequences ----
+struct MpUpdate {
+    struct Item { int seq, p; };
+    std::vector<Item> items;
+    std::vector<int> start;
+    std::vector<uint8_t> odesc, outdesc;
+    std::vector<float> oOw, pos, owref, lsf, out5;
+    std::vector<int> best;
+    void clear() { items.clear(); }
+    void add(int seq, int p) { items.push_back({seq, p}); }
+    int run(Ctx& c, bool do_desc, bool do_normal) {
+        const int P = (int)items.size();
+        if (P == 0) return OSLAM_OK;
+        start.assign(P + 1, 0);
+        odesc.clear(); oOw.clear();
+        pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
+        for (int i = 0; i < P; i++) {
+            Map& m = c.seq[items[i].seq]->map;
+            const MapPt& p = m.mps[items[i].p];
+            int n = 0;
+            if (!p.bad)
+                for (auto& e : p.obs) {
+                    const KeyFrm& k = m.kfs[e.first];
+                    // ComputeDistinctiveDescriptors skips bad keyframes (src/MapPoint.cc:362-368), UpdateNormalAndDepth does not: a culled
+                    // keyframe has already erased its observations (KeyFrame::SetBadFlag), so both see the same list.
+                    odesc.insert(odesc.end(), k.desc.begin() + (size_t)e.second * 32, k.desc.begin() + (size_t)e.second * 32 + 32);
+                    oOw.insert(oOw.end(), k.pose.Ow, k.pose.Ow + 3);
+                    n++;
+                }
+            start[i + 1] = start[i] + n;
+            for (int d = 0; d < 3; d++) pos[(size_t)i * 3 + d] = p.pos[d];
+            float lf = 1.f;
+            const float* ow = p.pos;
+            if (n > 0 && p.refKF >= 0) {
+                const KeyFrm& rk = m.kfs[p.refKF];
+                const int idx = p.obs_index(p.refKF);
+                ow = rk.pose.Ow;
+                if (idx >= 0) lf = c.scale[rk.keysUn[idx].octave];
+            }
+            for (int d = 0; d < 3; d++) owref[(size_t)i * 3 + d] = ow[d];
+            lsf[i] = lf;
+        }
+        best.resize(P); outdesc.resize((size_t)P * 32); out5.resize((size_t)P * 5);
+        if (odesc.empty()) { odesc.resize(32); oOw.resize(3); }
+        oslam_job_mp_update_t j;
+        j.P = P; j.obs_start = start.data(); j.obs_desc = odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
+        j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
+        const int rc = c.ops.mp_update(c.ops.ctx, &j);
+        if (rc) return rc;
+        for (int i = 0; i < P; i++) {
+            if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
+            MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
+            if (do_desc) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);
+            if (do_normal) {
+                const float* o = &out5[(size_t)i * 5];
+                p.normal[0] = o[0]; p.normal[1] = o[1]; p.normal[2] = o[2]; p.maxD = o[3]; p.minD = o[4];
+            }
+        }
+        return OSLAM_OK;
+    }
+};
+
+// Creates the stereo points of StereoInitialization (:603-619) / CreateNewKeyFrame (:1338-1398) for frame f, keyframe kf.
+static void create_stereo_points(Ctx& c, int si, Seq& s, Frame& f, int kf, bool all, MpUpdate& upd) {
+    Map& m = s.map;
+    auto make = [&](int i) {
+        float x[3];
+        if (!unproject_frame(c, f, i, x)) return;
+        const int p = m.new_point(x, kf, m.kfs[kf].frameId);
+        m.add_observation(p, kf, i);
+        m.kfs[kf].mp[i] = p;
+        m.nMPsInMap++; s.st[3]++;
+        f.mp[i] = p;
+        upd.add(si, p);
+    };
+    if (all) {
+        for (int i = 0; i < f.N; i++) if (f.depth[i] > 0) make(i);
+        return;
+    }
+    std::vector<std::pair<float, int>> v;
+    v.reserve(f.N);
+    for (int i = 0; i < f.N; i++) if (f.depth[i] > 0) v.push_back(std::make_pair(f.depth[i], i));
+    if (v.empty()) return;
+    std::sort(v.begin(), v.end());
+    int nPoints = 0;
+    for (size_t j = 0; j < v.size(); j++) {
+        const int i = v[j].second;
+        bool create = false;
+        const int p = f.mp[i];
+        if (p < 0) create = true;
+        else if (m.mps[p].nObs < 1) { create = true; f.mp[i] = -1; }
+        if (create) make(i);
+        nPoints++;
+        if (v[j].first > c.thDepth && nPoints > 100) break;
+    }
+}
+
+// Tracking::UpdateLocalKeyFrames (:1496-1604) + UpdateLocalPoints (:1470-1493)
+static void update_local_map(Seq& s) {
+    Map& m = s.map;
+    Frame& f = *s.cur;
+    std::vector<int> touched;
+    for (int i = 0; i < f.N; i++) {
+        const int p = f.mp[i];
+        if (p < 0) continue;
+        if (m.mps[p].bad) { f.mp[i] = -1; continue; }
+        for (auto& e : m.mps[p].obs)
+            if (s.counter[e.first]++ == 0) touched.push_back(e.first);
+    }
+    if (!touched.empty()) {
+        std::sort(touched.begin(), touched.end());
+        int mx = 0, kmax = -1;
+        s.localKFs.clear();
+        for (int k : touched) {
+            const int cnt = s.counter[k];
+            s.counter[k] = 0;
+            if (m.kfs[k].bad) continue;
+            if (cnt > mx) { mx = cnt; kmax = k; }
+            s.localKFs.push_back(k);
+            m.kfs[k].trackRefForFrame = f.id;
+        }
+        const size_t n0 = s.localKFs.size();
+        for (size_t q = 0; q < n0; q++) {
+            if (s.localKFs.size() > 80) break;
+            const int k = s.localKFs[q];
+            for (int nb : m.best_covisibles(k, 10))
+                if (!m.kfs[nb].bad && m.kfs[nb].trackRefForFrame != f.id) { s.localKFs.push_back(nb); m.kfs[nb].trackRefForFrame = f.id; break; }
+            for (int ch : m.kfs[k].children)
+                if (!m.kfs[ch].bad && m.kfs[ch].trackRefForFrame != f.id) { s.localKFs.push_back(ch); m.kfs[ch].trackRefForFrame = f.id; break; }
+            const int par = m.kfs[k].parent;
+            if (par >= 0 && m.kfs[par].trackRefForFrame != f.id) {
+                s.localKFs.push_back(par);
+                m.kfs[par].trackRefForFrame = f.id;
+                break;   // the reference leaves the loop here (:1593)
+            }
+        }
+        if (kmax >= 0) { s.refKF = kmax; f.refKF = kmax; }
+    }
+    s.localMPs.clear();
+    for (int k : s.localKFs) {
+        const KeyFrm& kf = m.kfs[k];
+        for (int i = 0; i < kf.N; i++) {
+            const int p = kf.mp[i];
+            if (p < 0) continue;
+            MapPt& mp = m.mps[p];
+            if (mp.trackRefForFrame == f.id) continue;
+            if (!mp.bad) { s.localMPs.push_back(p); mp.trackRefForFrame = f.id; }
+        }
+    }
+}
+
+// fills the PoseOptimization job arrays of the current frame
+static void fill_pose_job(Ctx& c, Seq& s, int si, oslam_job_pose_t& j) {
+    Frame& f = *s.cur;
+    const int N = f.N;
+    s.jXw.assign((size_t)N * 3, 0.f); s.jObs.resize((size_t)N * 3); s.jInv.resize(N); s.jHas.assign(N, 0); s.jOutlier.assign(N, 0);
+    for (int i = 0; i < N; i++) {
+        s.jObs[(size_t)i * 3] = f.keysUn[i].x; s.jObs[(size_t)i * 3 + 1] = f.keysUn[i].y; s.jObs[(size_t)i * 3 + 2] = f.uRight[i];
+        s.jInv[i] = c.invSigma2[f.keysUn[i].octave];
+        const int p = f.mp[i];
+        if (p >= 0) {
+            s.jHas[i] = 1;
+            const float* x = s.map.mps[p].pos;
+            s.jXw[(size_t)i * 3] = x[0]; s.jXw[(size_t)i * 3 + 1] = x[1]; s.jXw[(size_t)i * 3 + 2] = x[2];
+        }
+    }
+    j.slot = si; j.N = N;
+    memcpy(j.Tcw_in, f.pose.Tcw.m, 64);
+    j.Xw = s.jXw.data(); j.obs = s.jObs.data(); j.invSigma2 = s.jInv.data(); j.has_mp = s.jHas.data();
+    j.outlier = s.jOutlier.data(); j.n_inliers = 0;
+    memcpy(j.Tcw_out, f.pose.Tcw.m, 64);
+}
+
+// after PoseOptimization in TrackWithMotionModel / TrackReferenceKeyFrame: discard outliers (:858-879, :981-1008)
+static bool finish_initial_pose(Seq& s, const oslam_job_pose_t& j) {
+    Frame& f = *s.cur;
+    M4 T; memcpy(T.m, j.Tcw_out, 64);
+    f.pose.set_frame(T);
+    int nmatchesMap = 0;
+    for (int i = 0; i < f.N; i++) {
+        const int p = f.mp[i];
+        if (p < 0) continue;
+        if (j.outlier[i]) {
+            f.mp[i] = -1; f.outlier[i] = 0;
+            s.map.mps[p].lastFrameSeen = f.id;
+        } else {
+            f.outlier[i] = 0;
+            if (s.map.mps[p].nObs > 0) nmatchesMap++;
+        }
+    }
+    return nmatchesMap >= 10;
+}
+
+// flat FeatureVector views for the BoW matchers (see oslam_hip.h): side 1 = (node asc, index order) list, side 2 = CSR over node ids
+struct BowViews {
+    std::vector<int32_t> q_idx; std::vector<uint32_t> q_node;
+    std::vector<uint32_t> nodes; std::vector<int32_t> start, items;
+    void side1(const std::vector<uint32_t>& node) {
+        const int N = (int)node.size();
+        std::vector<std::pair<uint32_t, int>> v(N);
+        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
+        std::sort(v.begin(), v.end());
+        q_idx.resize(N); q_node.resize(N);
+        for (int i = 0; i < N; i++) { q_idx[i] = v[i].second; q_node[i] = v[i].first; }
+    }
+    void side2(const std::vector<uint32_t>& node) {
+        const int N = (int)node.size();
+        std::vector<std::pair<uint32_t, int>> v(N);
+        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
+        std::sort(v.begin(), v.end());
+        nodes.clear(); start.clear(); items.resize(N);
+        for (int i = 0; i < N; i++) {
+            if (i == 0 || v[i].first != v[i - 1].first) { nodes.push_back(v[i].first); start.push_back(i); }
+            items[i] = v[i].second;
+        }
+        start.push_back(N);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Local mapping for the sequences that inserted a keyframe this step (LocalMapping::Run, src/LocalMapping.cc:48-113)
+// ------------------------------------------------------------------------------------------------------------------
+static void map_point_culling(Seq& s) {   // :171-206
+    Map& m = s.map;
+    const int cur = s.curKF;
+    std::vector<int> keep;
+    for (int p : s.recentAdded) {
+        MapPt& mp = m.mps[p];
+        if (mp.bad) continue;
+        if ((float)mp.found / mp.visible < 0.25f) { m.set_bad_point(p); s.st[12]++; continue; }
+        if (cur - mp.firstKF >= 2 && mp.nObs <= 3) { m.set_bad_point(p); s.st[12]++; continue; }
+        if (cur - mp.firstKF >= 3) continue;
+        keep.push_back(p);
+    }
+    s.recentAdded.swap(keep);
+}
+
+// 3x3 helpers for ComputeF12 (src/LocalMapping.cc:537-554); the cv::Mat chain is evaluated in double and rounded once per product
+static void mat3_mul(const double* a, const double* b, double* r) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += a[i * 3 + k] * b[k * 3 + j]; r[i * 3 + j] = (double)(float)s; }
+}
+static void compute_F12(const Ctx& c, const KeyFrm& k1, const KeyFrm& k2, float F12[9]) {
+    double R1[9], R2t[9], t1[3], t2[3];
+    for (int r = 0; r < 3; r++) {
+        for (int cc = 0; cc < 3; cc++) { R1[r * 3 + cc] = k1.pose.Tcw.m[r * 4 + cc]; R2t[r * 3 + cc] = k2.pose.Tcw.m[cc * 4 + r]; }
+        t1[r] = k1.pose.Tcw.m[r * 4 + 3]; t2[r] = k2.pose.Tcw.m[r * 4 + 3];
+    }
+    double R12[9];
+    mat3_mul(R1, R2t, R12);
+    double t12[3];
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += -R12[r * 3 + k] * t2[k];
+        t12[r] = (double)(float)((double)(float)s + t1[r]);
+    }
+    const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+    const double fx = c.cfg.fx, fy = c.cfg.fy, cx = c.cfg.cx, cy = c.cfg.cy;
+    // K^-1 = [[1/fx, 0, -cx/fx], [0, 1/fy, -cy/fy], [0, 0, 1]]; K1.t().inv() = (K^-1)^T
+    const double Ki[9] = {(double)(float)(1.0 / fx), 0, (double)(float)(-cx / fx), 0, (double)(float)(1.0 / fy), (double)(float)(-cy / fy), 0, 0, 1};
+    const double KiT[9] = {Ki[0], 0, 0, 0, Ki[4], 0, Ki[2], Ki[5], 1};
+    double a[9], b[9], f[9];
+    mat3_mul(KiT, tx, a);
+    mat3_mul(a, R12, b);
+    mat3_mul(b, Ki, f);
+    for (int i = 0; i < 9; i++) F12[i] = (float)f[i];
+}
+
+static void fill_tri_kf(const Ctx& c, const KeyFrm& k, oslam_tri_kf_t& t) {
+    memcpy(t.Tcw, k.pose.Tcw.m, 64); memcpy(t.Twc, k.pose.Twc.m, 64);
+    t.fx = c.cfg.fx; t.fy = c.cfg.fy; t.cx = c.cfg.cx; t.cy = c.cfg.cy; t.invfx = c.invfx; t.invfy = c.invfy; t.mbf = c.cfg.bf; t.mb = c.mb;
+    t.keysUn = k.keysUn.data(); t.keys = k.keys.data(); t.uRight = k.uRight.data(); t.depth = k.depth.data(); t.n_kps = k.N;
+}
+
+// MapPoint::PredictScale(dist, KeyFrame*) (src/MapPoint.cc:488-503)
+static int predict_scale(const Ctx& c, float maxD, float dist) {
+    const float ratio = maxD / dist;
+    int n = (int)std::ceil(std::log(ratio) / c.logScale);
+    if (n < 0) n = 0;
+    else if (n >= c.cfg.nLevels) n = c.cfg.nLevels - 1;
+    return n;
+}
+
+// projection gates of ORBmatcher::Fuse (src/ORBmatcher.cc:840-890) for candidate points `pts` against keyframe k
+static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<int>& pts, float th, std::vector<oslam_proj_query_t>& q, std::vector<int>& qpt) {
+    const KeyFrm& kf = m.kfs[k];
+    const float* T = kf.pose.Tcw.m;
+    q.clear(); qpt.clear();
+    for (int p : pts) {
+        if (p < 0) continue;
+        const MapPt& mp = m.mps[p];
+        if (mp.bad || mp.obs_index(k) >= 0) continue;
+        float pc[3];
+        for (int r = 0; r < 3; r++) {
+            float s = T[r * 4] * mp.pos[0];
+            s += T[r * 4 + 1] * mp.pos[1];
+            s += T[r * 4 + 2] * mp.pos[2];
+            pc[r] = (float)((double)s + (double)T[r * 4 + 3]);
+        }
+        if (pc[2] < 0.0f) continue;
+        const float invz = 1 / pc[2];
+        const float x = pc[0] * invz, y = pc[1] * invz;
+        const float u = c.cfg.fx * x + c.cfg.cx, v = c.cfg.fy * y + c.cfg.cy;
+        if (!(u >= c.bounds[0] && u < c.bounds[2] && v >= c.bounds[1] && v < c.bounds[3])) continue;   // KeyFrame::IsInImage
+        const float ur = u - c.cfg.bf * invz;
+        const float maxDistance = 1.2f * mp.maxD, minDistance = 0.8f * mp.minD;
+        const float PO[3] = {mp.pos[0] - kf.pose.Ow[0], mp.pos[1] - kf.pose.Ow[1], mp.pos[2] - kf.pose.Ow[2]};
+        const float dist3D = norm3(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const double dot = (double)PO[0] * mp.normal[0] + (double)PO[1] * mp.normal[1] + (double)PO[2] * mp.normal[2];
+        if (dot < 0.5 * dist3D) continue;
+        const int lvl = predict_scale(c, mp.maxD, dist3D);
+        oslam_proj_query_t e;
+        memset(&e, 0, sizeof(e));
+        e.u = u; e.v = v; e.ur = ur; e.radius = th * c.scale[lvl]; e.minLevel = lvl - 1; e.maxLevel = lvl; e.flags = 1;
+        memcpy(e.desc, mp.desc, 32);
+        q.push_back(e); qpt.push_back(p);
+    }
+}
+
+// surgery of ORBmatcher::Fuse (:950-970) in query order; points whose descriptor must be recomputed go to `upd`
+static void fuse_apply(Seq& s, int si, int k, const std::vector<int>& qpt, const int32_t* q_match, MpUpdate& upd) {
+    Map& m = s.map;
+    for (size_t i = 0; i < qpt.size(); i++) {
+        const int best = q_match[i];
+        if (best < 0) continue;
+        const int p = qpt[i];
+        if (m.mps[p].bad) continue;
+        const int inKF = m.kfs[k].mp[best];
+        if (inKF >= 0) {
+            if (!m.mps[inKF].bad) {
+                if (m.mps[inKF].nObs > m.mps[p].nObs) { if (m.replace_point(p, inKF)) upd.add(si, inKF); }
+                else { if (m.replace_point(inKF, p)) upd.add(si, p); }
+            }
+        } else {
+            m.add_observation(p, k, best);
+            m.kfs[k].mp[best] = p;
+        }
+        s.st[9]++;
+    }
+}
+
+static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
+    if (who.empty()) return OSLAM_OK;
+    Timer tm;
+    int rc;
+    MpUpdate upd;
+    const int flags = c.cfg.local_mapping;
+    // --- ProcessNewKeyFrame (:129-169) ---
+    for (int si : who) {
+        Seq& s = *c.seq[si];
+        Map& m = s.map;
+        s.curKF = s.newKFs.front();
+        s.newKFs.clear();
+        KeyFrm& kf = m.kfs[s.curKF];
+        compute_bow(c, kf.N, kf.desc.data(), kf.bowNode);
+        for (int i = 0; i < kf.N; i++) {
+            const int p = kf.mp[i];
+            if (p < 0 || m.mps[p].bad) continue;
+            if (m.mps[p].obs_index(s.curKF) < 0) { m.add_observation(p, s.curKF, i); upd.add(si, p); }
+            else s.recentAdded.push_back(p);
+        }
+    }
+    c.sec[7] += tm.lap();
+    if ((rc = upd.run(c, true, true))) return rc;
+    c.sec[5] += tm.lap();
+    for (int si : who) {
+        Seq& s = *c.seq[si];
+        s.map.update_connections(s.curKF, s.counter);
+        s.map.nKFsInMap++;
+        if (flags & 1) map_point_culling(s);
+    }
+    c.sec[7] += tm.lap();
+
+    // --- CreateNewMapPoints (:208-453): neighbours in lockstep (the matches of neighbour i see the points created from neighbour i-1) ---
+    if (flags & 2) {
+        std::vector<std::vector<int>> neigh(who.size());
+        size_t maxn = 0;
+        for (size_t w = 0; w < who.size(); w++) {
+            Seq& s = *c.seq[who[w]];
+            neigh[w] = s.map.best_covisibles(s.curKF, 10);
+            maxn = std::max(maxn, neigh[w].size());
+        }
+        std::vector<BowViews> bv(who.size());
+        std::vector<std::vector<uint8_t>> flag1(who.size()), has2(who.size());
+        std::vector<std::vector<int32_t>> match(who.size());
+        std::vector<oslam_job_bow_t> bj;
+        std::vector<int> bjw;
+        for (size_t ni = 0; ni < maxn; ni++) {
+            bj.clear(); bjw.clear();
+            for (size_t w = 0; w < who.size(); w++) {
+                if (ni >= neigh[w].size()) continue;
+                Seq& s = *c.seq[who[w]];
+                Map& m = s.map;
+                const KeyFrm& k1 = m.kfs[s.curKF];
+                KeyFrm& k2 = m.kfs[neigh[w][ni]];
+                const float vb[3] = {k2.pose.Ow[0] - k1.pose.Ow[0], k2.pose.Ow[1] - k1.pose.Ow[1], k2.pose.Ow[2] - k1.pose.Ow[2]};
+                if (norm3(vb) < c.mb) continue;   // :251-254
+                compute_bow(c, k2.N, k2.desc.data(), k2.bowNode);
+                oslam_job_bow_t j;
+                memset(&j, 0, sizeof(j));
+                compute_F12(c, k1, k2, j.F12);
+                // epipole of camera 1 in image 2 (src/ORBmatcher.cc:663-670)
+                float C2[3];
+                for (int r = 0; r < 3; r++) {
+                    float sacc = k2.pose.Tcw.m[r * 4] * k1.pose.Ow[0];
+                    sacc += k2.pose.Tcw.m[r * 4 + 1] * k1.pose.Ow[1];
+                    sacc += k2.pose.Tcw.m[r * 4 + 2] * k1.pose.Ow[2];
+                    C2[r] = (float)((double)sacc + (double)k2.pose.Tcw.m[r * 4 + 3]);
+                }
+                const float invz = 1.0f / C2[2];
+                j.ex = c.cfg.fx * C2[0] * invz + c.cfg.cx; j.ey = c.cfg.fy * C2[1] * invz + c.cfg.cy;
+                bv[w].side1(k1.bowNode); bv[w].side2(k2.bowNode);
+                flag1[w].resize(k1.N); has2[w].resize(k2.N);
+                for (int i = 0; i < k1.N; i++) flag1[w][i] = k1.mp[i] >= 0;
+                for (int i = 0; i < k2.N; i++) has2[w][i] = k2.mp[i] >= 0;
+                match[w].assign(k1.N, -1);
+                j.s1.N = k1.N; j.s1.keys = k1.keysUn.data(); j.s1.desc = k1.desc.data(); j.s1.uRight = k1.uRight.data(); j.s1.flag = flag1[w].data();
+                j.s1.nq = k1.N; j.s1.q_idx = bv[w].q_idx.data(); j.s1.q_node = bv[w].q_node.data();
+                j.s2.N = k2.N; j.s2.keys = k2.keysUn.data(); j.s2.desc = k2.desc.data(); j.s2.uRight = k2.uRight.data(); j.s2.has_mp = has2[w].data();
+                j.s2.nNodes = (int)bv[w].nodes.size(); j.s2.nodes = bv[w].nodes.data(); j.s2.start = bv[w].start.data(); j.s2.items = bv[w].items.data();
+                j.triangulation = 1; j.nnratio = 0.6f; j.checkOri = 0; j.match = match[w].data();
+                bj.push_back(j); bjw.push_back((int)w);
+            }
+            if (bj.empty()) continue;
+            c.sec[7] += tm.lap();
+            if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
+            std::vector<oslam_job_triangulate_t> tj(bj.size());
+            std::vector<std::vector<int32_t>> i1(bj.size()), i2(bj.size());
+            std::vector<std::vector<uint8_t>> okv(bj.size());
+            std::vector<std::vector<float>> x3(bj.size());
+            for (size_t q = 0; q < bj.size(); q++) {
+                const size_t w = bjw[q];
+                Seq& s = *c.seq[who[w]];
+                const KeyFrm& k1 = s.map.kfs[s.curKF];
+                // vMatchedIndices order (:815-820): ascending index of keyframe 1
+                for (int i = 0; i < k1.N; i++) if (match[w][i] >= 0) { i1[q].push_back(i); i2[q].push_back(match[w][i]); }
+                oslam_job_triangulate_t& t = tj[q];
+                fill_tri_kf(c, k1, t.kf1); fill_tri_kf(c, s.map.kfs[neigh[w][ni]], t.kf2);
+                t.M = (int)i1[q].size(); t.idx1 = i1[q].data(); t.idx2 = i2[q].data();
+                okv[q].assign(t.M + 1, 0); x3[q].assign((size_t)t.M * 3 + 3, 0.f);
+                t.ok = okv[q].data(); t.x3D = x3[q].data();
+            }
+            if ((rc = c.ops.triangulate(c.ops.ctx, (int)tj.size(), tj.data()))) return rc;
+            c.sec[8] += tm.lap();
+            upd.clear();
+            for (size_t q = 0; q < bj.size(); q++) {
+                const size_t w = bjw[q];
+                const int si = who[w];
+                Seq& s = *c.seq[si];
+                Map& m = s.map;
+                const int k2 = neigh[w][ni];
+                for (int e = 0; e < tj[q].M; e++) {
+                    if (!okv[q][e]) continue;
+                    const int p = m.new_point(&x3[q][(size_t)e * 3], s.curKF, m.kfs[s.curKF].frameId);   // :408-430
+                    m.add_observation(p, s.curKF, i1[q][e]);
+                    m.add_observation(p, k2, i2[q][e]);
+                    m.kfs[s.curKF].mp[i1[q][e]] = p;
+                    m.kfs[k2].mp[i2[q][e]] = p;
+                    m.nMPsInMap++; s.st[3]++; s.st[10]++;
+                    s.recentAdded.push_back(p);
+                    upd.add(si, p);
+                }
+            }
+            c.sec[7] += tm.lap();
+            if ((rc = upd.run(c, true, true))) return rc;
+            c.sec[5] += tm.lap();
+        }
+    }
+
+    // --- SearchInNeighbors (:455-535) ---
+    // The target keyframes of one sequence are fused one after the other like the reference's loop (a fusion changes descriptors and
+    // observations the next target sees); round t handles target t of every sequence in one batch.
+    if (flags & 4) {
+        struct FuseSeq { std::vector<int> targets; std::vector<int> pts; std::vector<oslam_proj_query_t> q; std::vector<int> qpt; std::vector<int32_t> qm; int kf; };
+        std::vector<FuseSeq> fs(who.size());
+        std::vector<oslam_job_fuse_t> jobs;
+        std::vector<int> jw;
+        size_t maxt = 0;
+        for (size_t w = 0; w < who.size(); w++) {
+            Seq& s = *c.seq[who[w]];
+            Map& m = s.map;
+            const int cur = s.curKF;
+            for (int k : m.best_covisibles(cur, 10)) {
+                if (m.kfs[k].bad || m.kfs[k].fuseTargetForKF == cur) continue;
+                fs[w].targets.push_back(k);
+                m.kfs[k].fuseTargetForKF = cur;
+                for (int k2 : m.best_covisibles(k, 5)) {
+                    if (m.kfs[k2].bad || m.kfs[k2].fuseTargetForKF == cur || k2 == cur) continue;
+                    fs[w].targets.push_back(k2);
+                }
+            }
+            fs[w].pts.assign(m.kfs[cur].mp.begin(), m.kfs[cur].mp.end());   // vpMapPointMatches snapshot (:484)
+            maxt = std::max(maxt, fs[w].targets.size());
+        }
+        auto fuse_round = [&](bool into_current, size_t t) -> int {
+            jobs.clear(); jw.clear();
+            for (size_t w = 0; w < who.size(); w++) {
+                Seq& s = *c.seq[who[w]];
+                Map& m = s.map;
+                if (!into_current && t >= fs[w].targets.size()) continue;
+                if (into_current && fs[w].targets.empty()) continue;
+                const int k = into_current ? s.curKF : fs[w].targets[t];
+                fs[w].kf = k;
+                fuse_queries(c, m, k, fs[w].pts, 3.0f, fs[w].q, fs[w].qpt);
+                fs[w].qm.assign(fs[w].q.size() + 1, -1);
+                if (fs[w].q.empty()) continue;
+                const KeyFrm& kf = m.kfs[k];
+                oslam_job_fuse_t j;
+                j.N = kf.N; j.keysUn = kf.keysUn.data(); j.uRight = kf.uRight.data(); j.desc = kf.desc.data();
+                j.M = (int)fs[w].q.size(); j.queries = fs[w].q.data(); j.q_match = fs[w].qm.data();
+                jobs.push_back(j); jw.push_back((int)w);
+            }
+            c.sec[7] += tm.lap();
+            if (jobs.empty()) return OSLAM_OK;
+            int rc2 = c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
+            if (rc2) return rc2;
+            c.sec[8] += tm.lap();
+            upd.clear();
+            for (int w : jw) fuse_apply(*c.seq[who[w]], who[w], fs[w].kf, fs[w].qpt, fs[w].qm.data(), upd);
+            c.sec[7] += tm.lap();
+            rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
+            c.sec[5] += tm.lap();
+            return rc2;
+        };
+        for (size_t t = 0; t < maxt; t++)
+            if ((rc = fuse_round(false, t))) return rc;
+        // the targets' points into the current keyframe (:492-515)
+        for (size_t w = 0; w < who.size(); w++) {
+            Seq& s = *c.seq[who[w]];
+            Map& m = s.map;
+            const int cur = s.curKF;
+            fs[w].pts.clear();
+            for (int k : fs[w].targets)
+                for (int p : m.kfs[k].mp) {
+                    if (p < 0) continue;
+                    MapPt& mp = m.mps[p];
+                    if (mp.bad || mp.fuseCandidateForKF == cur) continue;
+                    mp.fuseCandidateForKF = cur;
+                    fs[w].pts.push_back(p);
+                }
+        }
+        if ((rc = fuse_round(true, 0))) return rc;
+        // update points of the current keyframe (:517-531) and its connections
+        upd.clear();
+        for (int si : who) {
+            Seq& s = *c.seq[si];
+            for (int p : s.map.kfs[s.curKF].mp)
+                if (p >= 0 && !s.map.mps[p].bad) upd.add(si, p);
+        }
+        c.sec[7] += tm.lap();
+        if ((rc = upd.run(c, true, true))) return rc;
+        c.sec[5] += tm.lap();
+        for (int si : who) { Seq& s = *c.seq[si]; s.map.update_connections(s.curKF, s.counter); }
+        c.sec[7] += tm.lap();
+    }
+
+    // --- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:453-778), all windows in one batch ---
+    if (flags & 8) {
+        struct Win {
+            int si; std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
+            std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref; int nLocal;
+        };
+        std::vector<Win> wins;
+        for (int si : who) {
+            Seq& s = *c.seq[si];
+            Map& m = s.map;
+            if (m.nKFsInMap <= 2) continue;   // src/LocalMapping.cc:81
+            const int cur = s.curKF;
+            wins.emplace_back();
+            Win& W = wins.back();
+            W.si = si;
+            W.kfs.push_back(cur);
+            m.kfs[cur].baLocalForKF = cur;
+            for (int k : m.kfs[cur].ordered) {
+                m.kfs[k].baLocalForKF = cur;
+                if (!m.kfs[k].bad) W.kfs.push_back(k);
+            }
+            W.nLocal = (int)W.kfs.size();
+            for (int q = 0; q < W.nLocal; q++)
+                for (int p : m.kfs[W.kfs[q]].mp)
+                    if (p >= 0 && !m.mps[p].bad && m.mps[p].baLocalForKF != cur) { W.pts.push_back(p); m.mps[p].baLocalForKF = cur; }
+            for (int p : W.pts)
+                for (auto& e : m.mps[p].obs) {
+                    KeyFrm& k = m.kfs[e.first];
+                    if (k.baLocalForKF != cur && k.baFixedForKF != cur) {
+                        k.baFixedForKF = cur;
+                        if (!k.bad) W.kfs.push_back(e.first);
+                    }
+                }
+            std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
+            for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
+            W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());
+            for (size_t q = 0; q < W.kfs.size(); q++) {
+                memcpy(&W.poses[q * 16], m.kfs[W.kfs[q]].pose.Tcw.m, 64);
+                W.fixed[q] = (int)q >= W.nLocal ? 1 : (W.kfs[q] == 0 ? 2 : 0);
+            }
+            W.points.resize(W.pts.size() * 3);
+            for (size_t j = 0; j < W.pts.size(); j++) {
+                const MapPt& mp = m.mps[W.pts[j]];
+                for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
+                for (auto& e : mp.obs) {
+                    const KeyFrm& k = m.kfs[e.first];
+                    if (k.bad) continue;
+                    const int q = slot[e.first] - 1;
+                    if (q < 0) continue;
+                    W.ekf.push_back(q); W.ept.push_back((int)j);
+                    W.eobs.push_back(k.keysUn[e.second].x); W.eobs.push_back(k.keysUn[e.second].y); W.eobs.push_back(k.uRight[e.second]);
+                    W.einv.push_back(c.invSigma2[k.keysUn[e.second].octave]);
+                    W.eref.push_back(std::make_pair(e.first, W.pts[j]));
+                }
+            }
+            for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = 0;
+            W.poses_out.resize(W.poses.size()); W.points_out.resize(W.points.size() + 3); W.erase.assign(W.ekf.size() + 1, 0);
+            s.st[5]++; s.st[14] += (int64_t)W.ekf.size();
+        }
+        std::vector<oslam_lba_problem_t> probs(wins.size());
+        for (size_t i = 0; i < wins.size(); i++) {
+            Win& W = wins[i];
+            oslam_lba_problem_t& p = probs[i];
+            p.nKF = (int)W.kfs.size(); p.poses = W.poses.data(); p.fixed = W.fixed.data(); p.nP = (int)W.pts.size(); p.points = W.points.data();
+            p.nE = (int)W.ekf.size(); p.edge_kf = W.ekf.data(); p.edge_pt = W.ept.data(); p.edge_obs = W.eobs.data(); p.edge_invSigma2 = W.einv.data();
+            p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data(); p.stats = nullptr;
+        }
+        c.sec[7] += tm.lap();
+        if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
+        c.sec[6] += tm.lap();
+        upd.clear();
+        for (Win& W : wins) {
+            Seq& s = *c.seq[W.si];
+            Map& m = s.map;
+            // erase list: mono edges first, then stereo edges (:711-757)
+            for (int pass = 0; pass < 2; pass++)
+                for (size_t e = 0; e < W.ekf.size(); e++) {
+                    if (!W.erase[e]) continue;
+                    const bool stereo = W.eobs[e * 3 + 2] >= 0;
+                    if ((pass == 1) != stereo) continue;
+                    const int k = W.eref[e].first, p = W.eref[e].second;
+                    const int idx = m.mps[p].obs_index(k);
+                    if (idx >= 0) m.kfs[k].mp[idx] = -1;
+                    m.erase_observation(p, k);
+                }
+            for (int q = 0; q < W.nLocal; q++) {
+                M4 T; memcpy(T.m, &W.poses_out[(size_t)q * 16], 64);
+                m.kfs[W.kfs[q]].pose.set_keyframe(T);
+            }
+            for (size_t j = 0; j < W.pts.size(); j++) {
+                MapPt& mp = m.mps[W.pts[j]];
+                for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
+                upd.add(W.si, W.pts[j]);
+            }
+        }
+        c.sec[7] += tm.lap();
+        if ((rc = upd.run(c, false, true))) return rc;
+        c.sec[5] += tm.lap();
+    }
+
+    // --- KeyFrameCulling (:633-697) ---
+    if (flags & 16)
+        for (int si : who) {
+            Seq& s = *c.seq[si];
+            Map& m = s.map;
+            const std::vector<int> local = m.kfs[s.curKF].ordered;
+            for (int k : local) {
+                if (k == 0) continue;
+                const KeyFrm& kf = m.kfs[k];
+                int nRed = 0, nMPs = 0;
+                for (int i = 0; i < kf.N; i++) {
+                    const int p = kf.mp[i];
+                    if (p < 0 || m.mps[p].bad) continue;
+                    if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
+                    nMPs++;
+                    if (m.mps[p].nObs > 3) {
+                        const int lvl = kf.keysUn[i].octave;
+                        int n = 0;
+                        for (auto& e : m.mps[p].obs) {
+                            if (e.first == k) continue;
+                            if (m.kfs[e.first].keysUn[e.second].octave <= lvl + 1) { n++; if (n >= 3) break; }
+                        }
+                        if (n >= 3) nRed++;
+                    }
+                }
+                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; }
+            }
+        }
+    c.sec[7] += tm.lap();
+    return OSLAM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One lockstep step of Tracking::Track for all sequences
+// ------------------------------------------------------------------------------------------------------------------
+static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
+                      const double* stamps, float* Tcw_out, int32_t* state_out) {
+    const int S = c.S;
+    Timer tm;
+    int rc;
+    // Frame::Frame for every sequence
+    {
+        std::vector<int32_t> slots(S);
+        std::vector<oslam_slam_frame_t*> outs(S);
+        for (int i = 0; i < S; i++) { slots[i] = i; outs[i] = &c.seq[i]->cur->view; }
+        if ((rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data()))) return rc;
+        for (int i = 0; i < S; i++) {
+            Seq& s = *c.seq[i];
+            const int fid = s.nextFrameId++;
+            s.cur->begin(fid, stamps ? stamps[i] : (double)fid);
+            s.st[0]++;
+            s.path = 0; s.ok = false;
+        }
+    }
+    c.sec[0] += tm.lap();
+    MpUpdate upd;
+    std::vector<int> tracking;   // sequences in the "system is initialised" branch
+    for (int i = 0; i < S; i++) {
+        Seq& s = *c.seq[i];
+        Frame& f = *s.cur;
+        if (s.state == ST_NOT_INITIALIZED) {
+            // StereoInitialization (:590-642)
+            if (f.N > 500) {
+                f.pose.set_frame(eye4());
+                const int kf = new_keyframe(s, f);
+                // mpMap->AddKeyFrame (:601): counted when ProcessNewKeyFrame inserts it (same std::set entry in the reference)
+                create_stereo_points(c, i, s, f, kf, true, upd);
+                s.newKFs.push_back(kf);
+                s.lastKFFrameId = f.id;
+                s.localKFs.assign(1, kf);
+                s.localMPs.clear();
+                for (int p : s.map.kfs[kf].mp) if (p >= 0) s.localMPs.push_back(p);
+                s.refKF = kf; f.refKF = kf;
+                s.state = ST_OK;
+            }
+        } else if (s.state == ST_OK) {
+            tracking.push_back(i);
+        }
+    }
+    // ---------------- initial pose: motion model or reference keyframe ----------------
+    std::vector<oslam_job_search_last_t> sl;
+    std::vector<int> slw;
+    for (int i : tracking) {
+        Seq& s = *c.seq[i];
+        Frame& f = *s.cur; Frame& l = *s.last;
+        // CheckReplacedInLastFrame (:820-835)
+        for (int k = 0; k < l.N; k++) {
+            const int p = l.mp[k];
+            if (p >= 0 && s.map.mps[p].replaced >= 0) l.mp[k] = s.map.mps[p].replaced;
+        }
+        if (!s.hasVelocity || f.id < s.lastRelocFrameId + 2) { s.path = 2; continue; }
+        s.path = 1;
+        // UpdateLastFrame (:882-891)
+        l.pose.set_frame(mul4(s.rel.back().Tcr, s.map.kfs[l.refKF].pose.Tcw));
+        f.pose.set_frame(mul4(s.velocity, l.pose.Tcw));
+        const int NL = l.N;
+        s.jXw.assign((size_t)NL * 3, 0.f); s.jHas.assign(NL, 0); s.jDesc.assign((size_t)NL * 32, 0);
+        for (int k = 0; k < NL; k++) {
+            const int p = l.mp[k];
+            if (p < 0 || l.outlier[k]) continue;
+            const MapPt& mp = s.map.mps[p];
+            s.jHas[k] = 1 | (mp.nObs > 0 ? 2 : 0);
+            for (int d = 0; d < 3; d++) s.jXw[(size_t)k * 3 + d] = mp.pos[d];
+            memcpy(&s.jDesc[(size_t)k * 32], mp.desc, 32);
+        }
+        s.jMatch.assign(f.N + 1, -1);
+        oslam_job_search_last_t j;
+        j.slot = i; j.cur = &f.view; j.Nlast = NL; j.Xw = s.jXw.data(); j.has_mp = s.jHas.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data();
+        memcpy(j.Tcw, f.pose.Tcw.m, 64); memcpy(j.Tlw, l.pose.Tcw.m, 64);
+        j.th = 15.f;   // RGB-D (:961-965)
+        j.kp_match = s.jMatch.data(); j.nmatches = 0;
+        sl.push_back(j); slw.push_back(i);
+    }
+    c.sec[4] += tm.lap();
+    if (!sl.empty()) {
+        if ((rc = c.ops.search_last(c.ops.ctx, (int)sl.size(), sl.data()))) return rc;
+        std::vector<oslam_job_search_last_t> again;
+        std::vector<size_t> againAt;
+        for (size_t q = 0; q < sl.size(); q++)
+            if (sl[q].nmatches < 20) { sl[q].th = 30.f; again.push_back(sl[q]); againAt.push_back(q); }   // :969-973
+        if (!again.empty()) {
+            if ((rc = c.ops.search_last(c.ops.ctx, (int)again.size(), again.data()))) return rc;
+            for (size_t q = 0; q < again.size(); q++) sl[againAt[q]].nmatches = again[q].nmatches;
+        }
+    }
+    c.sec[1] += tm.lap();
+    std::vector<oslam_job_pose_t> pj;
+    std::vector<int> pjw;
+    for (size_t q = 0; q < sl.size(); q++) {
+        Seq& s = *c.seq[slw[q]];
+        Frame& f = *s.cur; Frame& l = *s.last;
+        if (sl[q].nmatches < 20) { s.path = 2; continue; }   // TrackWithMotionModel failed -> TrackReferenceKeyFrame (:365-366)
+        for (int k = 0; k < f.N; k++) f.mp[k] = s.jMatch[k] >= 0 ? l.mp[s.jMatch[k]] : -1;
+        pj.emplace_back();
+        fill_pose_job(c, s, slw[q], pj.back());
+        pjw.push_back(slw[q]);
+    }
+    c.sec[4] += tm.lap();
+    if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+    c.sec[2] += tm.lap();
+    for (size_t q = 0; q < pj.size(); q++) {
+        Seq& s = *c.seq[pjw[q]];
+        s.ok = finish_initial_pose(s, pj[q]);
+        if (s.ok) s.st[6]++;
+        else s.path = 2;
+    }
+    // TrackReferenceKeyFrame (:838-880) for the sequences without a motion model or whose motion-model tracking failed
+    {
+        std::vector<int> rk;
+        for (int i : tracking) if (c.seq[i]->path == 2) rk.push_back(i);
+        if (!rk.empty()) {
+            std::vector<oslam_job_bow_t> bj(rk.size());
+            std::vector<BowViews> bv(rk.size());
+            std::vector<std::vector<uint8_t>> flag(rk.size());
+            std::vector<std::vector<int32_t>> match(rk.size());
+            for (size_t q = 0; q < rk.size(); q++) {
+                Seq& s = *c.seq[rk[q]];
+                Frame& f = *s.cur;
+                KeyFrm& kf = s.map.kfs[s.refKF];
+                compute_bow(c, f.N, f.desc.data(), f.bowNode);
+                compute_bow(c, kf.N, kf.desc.data(), kf.bowNode);
+                bv[q].side1(kf.bowNode); bv[q].side2(f.bowNode);
+                flag[q].resize(kf.N);
+                for (int i = 0; i < kf.N; i++) flag[q][i] = kf.mp[i] >= 0 && !s.map.mps[kf.mp[i]].bad;
+                match[q].assign(f.N + 1, -1);
+                oslam_job_bow_t& j = bj[q];
+                memset(&j, 0, sizeof(j));
+                j.s1.N = kf.N; j.s1.keys = kf.keysUn.data(); j.s1.desc = kf.desc.data(); j.s1.uRight = nullptr; j.s1.flag = flag[q].data();
+                j.s1.nq = kf.N; j.s1.q_idx = bv[q].q_idx.data(); j.s1.q_node = bv[q].q_node.data();
+                j.s2.N = f.N; j.s2.keys = f.keysUn.data(); j.s2.desc = f.desc.data(); j.s2.uRight = nullptr; j.s2.has_mp = nullptr;
+                j.s2.nNodes = (int)bv[q].nodes.size(); j.s2.nodes = bv[q].nodes.data(); j.s2.start = bv[q].start.data(); j.s2.items = bv[q].items.data();
+                j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();
+            }
+            c.sec[4] += tm.lap();
+            if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
+            c.sec[8] += tm.lap();
+            pj.clear(); pjw.clear();
+            for (size_t q = 0; q < rk.size(); q++) {
+                Seq& s = *c.seq[rk[q]];
+                Frame& f = *s.cur;
+                s.ok = false;
+                if (bj[q].nmatches < 15) continue;
+                const KeyFrm& kf = s.map.kfs[s.refKF];
+                for (int k = 0; k < f.N; k++) f.mp[k] = match[q][k] >= 0 ? kf.mp[match[q][k]] : -1;
+                f.pose.set_frame(s.last->pose.Tcw);
+                pj.emplace_back();
+                fill_pose_job(c, s, rk[q], pj.back());
+                pjw.push_back(rk[q]);
+            }
+            if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+            c.sec[2] += tm.lap();
+            for (size_t q = 0; q < pj.size(); q++) {
+                Seq& s = *c.seq[pjw[q]];
+                s.ok = finish_initial_pose(s, pj[q]);
+                if (s.ok) s.st[7]++;
+            }
+        }
+    }
+    // ---------------- TrackLocalMap (:1011-1056) ----------------
+    std::vector<oslam_job_search_local_t> lj;
+    std::vector<int> ljw;
+    for (int i : tracking) {
+        Seq& s = *c.seq[i];
+        Frame& f = *s.cur;
+        f.refKF = s.refKF;   // :446
+        if (!s.ok) continue;
+        update_local_map(s);
+        // SearchLocalPoints (:1408-1458)
+        Map& m = s.map;
+        s.jBlocked.assign(f.N, 0);
+        for (int k = 0; k < f.N; k++) {
+            const int p = f.mp[k];
+            if (p < 0) continue;
+            if (m.mps[p].bad) { f.mp[k] = -1; continue; }
+            m.mps[p].visible++;
+            m.mps[p].lastFrameSeen = f.id;
+            s.jBlocked[k] = m.mps[p].nObs > 0;
+        }
+        s.jLocalIds.clear();
+        for (int p : s.localMPs) {
+            const MapPt& mp = m.mps[p];
+            if (mp.lastFrameSeen == f.id || mp.bad) continue;
+            s.jLocalIds.push_back(p);
+        }
+        const int M = (int)s.jLocalIds.size();
+        s.jPw.resize((size_t)M * 3 + 3); s.jPn.resize((size_t)M * 3 + 3); s.jMax.resize(M + 1); s.jMin.resize(M + 1); s.jObsGt0.resize(M + 1);
+        s.jDesc.resize((size_t)M * 32 + 32); s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
+        for (int q = 0; q < M; q++) {
+            const MapPt& mp = m.mps[s.jLocalIds[q]];
+            for (int d = 0; d < 3; d++) { s.jPw[(size_t)q * 3 + d] = mp.pos[d]; s.jPn[(size_t)q * 3 + d] = mp.normal[d]; }
+            s.jMax[q] = mp.maxD; s.jMin[q] = mp.minD; s.jObsGt0[q] = mp.nObs > 0;
+            memcpy(&s.jDesc[(size_t)q * 32], mp.desc, 32);
+        }
+        oslam_job_search_local_t j;
+        j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.jPw.data(); j.Pn = s.jPn.data(); j.maxDist = s.jMax.data();
+        j.minDist = s.jMin.data(); j.obs_gt0 = s.jObsGt0.data(); j.mp_desc = s.jDesc.data();
+        memcpy(j.Tcw, f.pose.Tcw.m, 64);
+        j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : 3.f;   // RGB-D th = 3 (:1450-1455)
+        j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;
+        lj.push_back(j); ljw.push_back(i);
+    }
+    c.sec[4] += tm.lap();
+    if (!lj.empty() && (rc = c.ops.search_local(c.ops.ctx, (int)lj.size(), lj.data()))) return rc;
+    c.sec[3] += tm.lap();
+    pj.clear(); pjw.clear();
+    for (size_t q = 0; q < lj.size(); q++) {
+        Seq& s = *c.seq[ljw[q]];
+        Frame& f = *s.cur;
+        for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.jLocalIds[e]].visible++;
+        for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.jLocalIds[s.jMatch[k]];
+        pj.emplace_back();
+        fill_pose_job(c, s, ljw[q], pj.back());   // ObjectOptimizer::PoseOptimization2 (:1022) without matched objects
+        pjw.push_back(ljw[q]);
+    }
+    c.sec[4] += tm.lap();
+    if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+    c.sec[2] += tm.lap();
+    for (size_t q = 0; q < pj.size(); q++) {
+        Seq& s = *c.seq[pjw[q]];
+        Frame& f = *s.cur;
+        M4 T; memcpy(T.m, pj[q].Tcw_out, 64);
+        f.pose.set_frame(T);
+        s.matchesInliers = 0;
+        for (int k = 0; k < f.N; k++) {
+            const int p = f.mp[k];
+            if (p < 0) continue;
+            f.outlier[k] = pj[q].outlier[k];
+            if (!f.outlier[k]) {
+                s.map.mps[p].found++;
+                if (s.map.mps[p].nObs > 0) s.matchesInliers++;
+            }
+        }
+        s.st[13] = s.matchesInliers;
+        if (f.id < s.lastRelocFrameId + c.maxFrames && s.matchesInliers < 50) s.ok = false;
+        else s.ok = s.matchesInliers >= 30;
+    }
+    // ---------------- after tracking (:470-566) ----------------
+    std::vector<int> mapping;
+    upd.items.reserve(upd.items.size() + 256);
+    for (int i : tracking) {
+        Seq& s = *c.seq[i];
+        Frame& f = *s.cur; Frame& l = *s.last;
+        Map& m = s.map;
+        s.state = s.ok ? ST_OK : ST_LOST;
+        if (s.ok) {
+            if (l.pose.valid) { s.velocity = mul4(f.pose.Tcw, l.pose.Twc); s.hasVelocity = true; }
+            else s.hasVelocity = false;
+            for (int k = 0; k < f.N; k++) {   // clean VO matches
+                const int p = f.mp[k];
+                if (p >= 0 && m.mps[p].nObs < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
+            }
+            // NeedNewKeyFrame (:1242-1326) with an idle local mapper
+            bool need = false;
+            {
+                const int nKFs = m.nKFsInMap;
+                if (!(f.id < s.lastRelocFrameId + c.maxFrames && nKFs > c.maxFrames)) {
+                    const int nMinObs = nKFs <= 2 ? 2 : 3;
+                    const int nRefMatches = m.tracked_map_points(s.refKF, nMinObs);
+                    int nNonTrackedClose = 0, nTrackedClose = 0;
+                    for (int k = 0; k < f.N; k++)
+                        if (f.depth[k] > 0 && f.depth[k] < c.thDepth) {
+                            if (f.mp[k] >= 0 && !f.outlier[k]) nTrackedClose++;
+                            else nNonTrackedClose++;
+                        }
+                    const bool bNeedToInsertClose = (nTrackedClose < 100) && (nNonTrackedClose > 70);
+                    const float thRefRatio = nKFs < 2 ? 0.4f : 0.75f;
+                    const bool c1a = f.id >= s.lastKFFrameId + c.maxFrames;
+                    const bool c1b = f.id >= s.lastKFFrameId + c.minFrames;
+                    const bool c1c = s.matchesInliers < nRefMatches * 0.25 || bNeedToInsertClose;
+                    const bool c2 = (s.matchesInliers < nRefMatches * thRefRatio || bNeedToInsertClose) && s.matchesInliers > 15;
+                    need = (c1a || c1b || c1c) && c2;
+                }
+            }
+            if (need) {   // CreateNewKeyFrame (:1328-1406)
+                const int kf = new_keyframe(s, f);
+                s.refKF = kf; f.refKF = kf;
+                create_stereo_points(c, i, s, f, kf, false, upd);
+                s.newKFs.push_back(kf);
+                s.lastKFFrameId = f.id;
+                mapping.push_back(i);
+            }
+            for (int k = 0; k < f.N; k++)
+                if (f.mp[k] >= 0 && f.outlier[k]) f.mp[k] = -1;
+        } else {
+            s.st[8]++;
+        }
+        if (f.refKF < 0) f.refKF = s.refKF;
+    }
+    // first frame: keyframe 0 goes through local mapping too
+    for (int i = 0; i < S; i++) {
+        Seq& s = *c.seq[i];
+        if (!s.newKFs.empty() && std::find(mapping.begin(), mapping.end(), i) == mapping.end()) mapping.push_back(i);
+    }
+    std::sort(mapping.begin(), mapping.end());
+    c.sec[4] += tm.lap();
+    if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
+    c.sec[5] += tm.lap();
+    // store relative poses (:569-585), swap frames
+    for (int i = 0; i < S; i++) {
+        Seq& s = *c.seq[i];
+        Frame& f = *s.cur;
+        if (f.pose.valid) {
+            RelPose r;
+            r.Tcr = mul4(f.pose.Tcw, s.map.kfs[f.refKF].pose.Twc);
+            r.refKF = s.refKF; r.stamp = f.stamp; r.lost = s.state == ST_LOST;
+            s.rel.push_back(r);
+        } else if (!s.rel.empty()) {
+            RelPose r = s.rel.back();
+            r.lost = s.state == ST_LOST;
+            s.rel.push_back(r);
+        }
+        if (Tcw_out) {
+            if (f.pose.valid) memcpy(Tcw_out + (size_t)i * 16, f.pose.Tcw.m, 64);
+            else memset(Tcw_out + (size_t)i * 16, 0, 64);
+        }
+        if (state_out) state_out[i] = s.state;
+        if (s.state != ST_NOT_INITIALIZED) std::swap(s.cur, s.last);   // mLastFrame = Frame(mCurrentFrame)
+    }
+    c.sec[4] += tm.lap();
+    return run_local_mapping(c, mapping);
+}
+
+// consistency of the observation graph (stats[15]): every observation points at a keypoint that points back
+static int64_t map_violations(const Map& m) {
+    int64_t bad = 0;
+    for (size_t p = 0; p < m.mps.size(); p++) {
+        const MapPt& mp = m.mps[p];
+        if (mp.bad) { bad += !mp.obs.empty(); continue; }
+        int n = 0;
+        for (auto& e : mp.obs) {
+            const KeyFrm& k = m.kfs[e.first];
+            if (e.second < 0 || e.second >= k.N || k.mp[e.second] != (int)p) bad++;
+            n += k.uRight[e.second] >= 0 ? 2 : 1;
+        }
+        if (n != mp.nObs) bad++;
+    }
+    for (size_t k = 0; k < m.kfs.size(); k++) {
+        const KeyFrm& kf = m.kfs[k];
+        if (kf.bad) continue;
+        for (int o : kf.ordered) if (m.kfs[o].bad) bad++;
+        if (kf.id != 0 && !kf.firstConnection && (kf.parent < 0 || m.kfs[kf.parent].bad)) bad++;
+    }
+    return bad;
+}
+
+}  // namespace oslam_drv
+
+extern "C" {
+
+int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cfg, const oslam_slam_ops_t* ops) {
+    if (!out || !cfg || !ops || cfg->n_sequences <= 0 || cfg->nLevels <= 0 || cfg->nLevels > OSLAM_MAX_LEVELS || !(cfg->fx > 0) || !(cfg->fy > 0)) {
+        oslam::set_error("oslam_slam_create: bad argument");
+        return OSLAM_E_INVALID;
+    }
+    oslam_slam* h = new oslam_slam;
+    Ctx& c = h->c;
+    c.cfg = *cfg; c.ops = *ops; c.S = cfg->n_sequences;
+    c.cap = c.ops.max_keypoints(c.ops.ctx);
+    int rc = c.ops.scale_tables(c.ops.ctx, c.scale, c.invScale, c.sigma2, c.invSigma2);
+    if (!rc) rc = c.ops.image_bounds(c.ops.ctx, c.bounds);
+    if (rc) { if (c.ops.destroy) c.ops.destroy(c.ops.ctx); delete h; return rc; }
+    c.invfx = 1.0f / cfg->fx; c.invfy = 1.0f / cfg->fy;
+    c.mb = cfg->bf / cfg->fx;                       // src/Frame.cc: mb = mbf/fx
+    c.thDepth = cfg->bf * cfg->thDepth / cfg->fx;   // src/Tracking.cc:159
+    c.logScale = std::log(cfg->scaleFactor);
+    c.maxFrames = (int)cfg->fps; c.minFrames = 0;
+    for (int i = 0; i < c.S; i++) {
+        c.seq.emplace_back(new Seq);
+        c.seq.back()->fa.alloc(c.cap);
+        c.seq.back()->fb.alloc(c.cap);
+        c.seq.back()->counter.assign(64, 0);
+    }
+    *out = h;
+    return OSLAM_OK;
+}
+
+int oslam_slam_create(oslam_slam_t** out, const oslam_slam_config_t* cfg) {
+    if (!out || !cfg) { oslam::set_error("oslam_slam_create: bad argument"); return OSLAM_E_INVALID; }
+    oslam_slam_ops_t ops;
+    const int rc = oslam_slam_make_hip_ops(cfg, &ops);   // fails without a HIP device: there is no CPU fallback
+    if (rc) return rc;
+    return oslam_slam_create_with_ops(out, cfg, &ops);
+}
+
+void oslam_slam_destroy(oslam_slam_t* h) {
+    if (!h) return;
+    if (h->c.ops.destroy) h->c.ops.destroy(h->c.ops.ctx);
+    delete h;
+}
+
+int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch,
+                          int on_device, const double* timestamps, float* Tcw_out, int32_t* state_out) {
+    if (!h || !gray || !depth) { oslam::set_error("oslam_slam_track_rgbd: bad argument"); return OSLAM_E_INVALID; }
+    return track_step(h->c, gray, gray_stride, depth, depth_pitch, on_device, timestamps, Tcw_out, state_out);
+}
+
+static void twc_rows(const M4& Tcw, float* o) {   // Rwc = Rcw.t(), twc = -Rwc*tcw (src/System.cc:423-424)
+    for (int r = 0; r < 3; r++) {
+        for (int cc = 0; cc < 3; cc++) o[r * 4 + cc] = Tcw.m[cc * 4 + r];
+        float s = Tcw.m[r] * Tcw.m[3];
+        s += Tcw.m[4 + r] * Tcw.m[7];
+        s += Tcw.m[8 + r] * Tcw.m[11];
+        o[r * 4 + 3] = (float)((double)s * -1.0);
+    }
+}
+
+int oslam_slam_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out) {
+    if (!h || seq < 0 || seq >= h->c.S || !n_out) { oslam::set_error("oslam_slam_trajectory: bad argument"); return OSLAM_E_INVALID; }
+    const Seq& s = *h->c.seq[seq];
+    const Map& m = s.map;
+    int n = 0;
+    if (m.kfs.empty()) { *n_out = 0; return OSLAM_OK; }
+    const M4 Two = m.kfs[0].pose.Twc;   // first keyframe by id (:389-393)
+    for (const RelPose& r : s.rel) {
+        if (r.lost) continue;
+        int k = r.refKF;
+        M4 Trw = eye4();
+        while (m.kfs[k].bad) { Trw = mul4(Trw, m.kfs[k].Tcp); k = m.kfs[k].parent; }
+        Trw = mul4(mul4(Trw, m.kfs[k].pose.Tcw), Two);
+        const M4 Tcw = mul4(r.Tcr, Trw);
+        if (n < cap) {
+            if (stamps) stamps[n] = r.stamp;
+            if (Twc) twc_rows(Tcw, Twc + (size_t)n * 12);
+        }
+        n++;
+    }
+    *n_out = n;
+    if (n > cap) { oslam::set_error("trajectory: cap %d < %d", cap, n); return OSLAM_E_CAPACITY; }
+    return OSLAM_OK;
+}
+
+int oslam_slam_keyframe_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out) {
+    if (!h || seq < 0 || seq >= h->c.S || !n_out) { oslam::set_error("oslam_slam_keyframe_trajectory: bad argument"); return OSLAM_E_INVALID; }
+    const Map& m = h->c.seq[seq]->map;
+    int n = 0;
+    for (const KeyFrm& k : m.kfs) {
+        if (k.bad) continue;
+        if (n < cap) {
+            if (stamps) stamps[n] = k.stamp;
+            if (Twc)
+                for (int r = 0; r < 3; r++) {
+                    for (int cc = 0; cc < 3; cc++) Twc[(size_t)n * 12 + r * 4 + cc] = k.pose.Rwc[r * 3 + cc];
+                    Twc[(size_t)n * 12 + r * 4 + 3] = k.pose.Ow[r];
+                }
+        }
+        n++;
+    }
+    *n_out = n;
+    if (n > cap) { oslam::set_error("keyframe trajectory: cap %d < %d", cap, n); return OSLAM_E_CAPACITY; }
+    return OSLAM_OK;
+}
+
+int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]) {
+    if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_stats: bad argument"); return OSLAM_E_INVALID; }
+    Seq& s = *h->c.seq[seq];
+    memcpy(out, s.st, sizeof(s.st));
+    out[2] = s.map.nKFsInMap; out[4] = s.map.nMPsInMap;
+    out[15] = map_violations(s.map);
+    return OSLAM_OK;
+}
+
+int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]) {
+    if (!h || !out) { oslam::set_error("oslam_slam_stage_seconds: bad argument"); return OSLAM_E_INVALID; }
+    memcpy(out, h->c.sec, sizeof(h->c.sec));
+    return OSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+// slam_map.h — host data model of the batch-of-sequences driver (include/oslam_slam.h): the reference's Frame / KeyFrame /
+// MapPoint / Map graph (include/Frame.h, include/KeyFrame.h, include/MapPoint.h, include/Map.h) restated over index-based
+// arrays, one Map per sequence.  Containers the reference orders by pointer value are ordered by keyframe id here.
+// Product code: never includes oracle/.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <set>
+#include <utility>
+#include <vector>
+
+#include "../../include/oslam_slam.h"
+
+namespace oslam_drv {
+
+typedef oslam_keypoint_t KP;
+
+struct M4 { float m[16]; };
+inline M4 eye4() { M4 r; memset(r.m, 0, sizeof(r.m)); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f; return r; }
+// cv::Mat CV_32F 4x4 * 4x4 (cv::gemm small-matrix branch: float products accumulated in float, left to right)
+inline M4 mul4(const M4& a, const M4& b) {
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float s = a.m[i * 4] * b.m[j];
+            s += a.m[i * 4 + 1] * b.m[4 + j];
+            s += a.m[i * 4 + 2] * b.m[8 + j];
+            s += a.m[i * 4 + 3] * b.m[12 + j];
+            r.m[i * 4 + j] = s;
+        }
+    return r;
+}
+inline float norm3(const float* v) {   // cv::norm L2 of a CV_32F 3x1: double accumulation, sqrt in double
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)v[k] * (double)v[k];
+    return (float)std::sqrt(s);
+}
+
+// Pose with the derived matrices the reference caches.
+struct PoseM {
+    M4 Tcw, Twc;
+    float Rwc[9], Ow[3];
+    bool valid = false;
+    // Frame::SetPose / UpdatePoseMatrices (src/Frame.cc:478-505): mOw = -mRcw.t()*mtcw (transposed operand -> generic gemm, fp64 sums)
+    void set_frame(const M4& T) {
+        Tcw = T; valid = true;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Rwc[r * 3 + c] = T.m[c * 4 + r];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)T.m[k * 4 + r] * (double)T.m[k * 4 + 3];
+            Ow[r] = (float)(-1.0 * s);
+        }
+        fill_twc();
+    }
+    // KeyFrame::SetPose (src/KeyFrame.cc:78-92): Rwc materialised, Ow = -Rwc*tcw (small-matrix branch, float sums)
+    void set_keyframe(const M4& T) {
+        Tcw = T; valid = true;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Rwc[r * 3 + c] = T.m[c * 4 + r];
+        for (int r = 0; r < 3; r++) {
+            float s = Rwc[r * 3] * T.m[3];
+            s += Rwc[r * 3 + 1] * T.m[7];
+            s += Rwc[r * 3 + 2] * T.m[11];
+            Ow[r] = (float)((double)s * -1.0);
+        }
+        fill_twc();
+    }
+    void fill_twc() {
+        Twc = eye4();
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) Twc.m[r * 4 + c] = Rwc[r * 3 + c];
+            Twc.m[r * 4 + 3] = Ow[r];
+        }
+    }
+};
+
+struct Frame {
+    int id = -1;
+    double stamp = 0;
+    int N = 0;
+    std::vector<KP> keys, keysUn;
+    std::vector<uint8_t> desc;
+    std::vector<float> uRight, depth;
+    std::vector<int> mp;            // mvpMapPoints: map point id or -1
+    std::vector<uint8_t> outlier;   // mvbOutlier
+    std::vector<uint32_t> bowNode;  // substitute FeatureVector: node id per keypoint (empty = not computed)
+    PoseM pose;
+    int refKF = -1;
+    oslam_slam_frame_t view;
+    void alloc(int cap) {
+        keys.resize(cap); keysUn.resize(cap); desc.resize((size_t)cap * 32); uRight.resize(cap); depth.resize(cap);
+        mp.assign(cap, -1); outlier.assign(cap, 0);
+        view.N = 0; view.keys = keys.data(); view.keysUn = keysUn.data(); view.desc = desc.data(); view.uRight = uRight.data(); view.depth = depth.data();
+    }
+    void begin(int id_, double stamp_) {
+        id = id_; stamp = stamp_; N = view.N;
+        std::fill(mp.begin(), mp.end(), -1);
+        std::fill(outlier.begin(), outlier.end(), 0);
+        bowNode.clear(); pose.valid = false; refKF = -1;
+    }
+};
+
+struct MapPt {
+    float pos[3];
+    float normal[3] = {0, 0, 0};
+    float minD = 0, maxD = 0;
+    uint8_t desc[32];
+    int nObs = 0, visible = 1, found = 1;        // src/MapPoint.cc:33-46
+    int firstKF = 0, firstFrame = 0, refKF = -1;
+    bool bad = false;
+    int replaced = -1;
+    std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
+    int lastFrameSeen = 0, trackRefForFrame = 0, baLocalForKF = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    int obs_index(int kf) const {
+        for (size_t i = 0; i < obs.size(); i++) if (obs[i].first == kf) return obs[i].second;
+        return -1;
+    }
+};
+
+struct KeyFrm {
+    int id = 0, frameId = 0;
+    double stamp = 0;
+    int N = 0;
+    std::vector<KP> keys, keysUn;
+    std::vector<uint8_t> desc;
+    std::vector<float> uRight, depth;
+    std::vector<int> mp;
+    std::vector<uint32_t> bowNode;
+    PoseM pose;
+    M4 Tcp;                                       // pose relative to the parent, set when the keyframe is culled
+    std::map<int, int> connW;                     // mConnectedKeyFrameWeights
+    std::vector<int> ordered, orderedW;           // mvpOrderedConnectedKeyFrames / mvOrderedWeights
+    int parent = -1;
+    std::set<int> children;
+    bool firstConnection = true, bad = false;
+    int trackRefForFrame = 0, fuseTargetForKF = 0, baLocalForKF = 0, baFixedForKF = 0;
+};
+
+struct RelPose { M4 Tcr; int refKF; double stamp; bool lost; };
+
+// One sequence's Map + the map-side methods of KeyFrame / MapPoint.
+struct Map {
+    std::vector<MapPt> mps;
+    std::vector<KeyFrm> kfs;
+    int nKFsInMap = 0, nMPsInMap = 0;
+    int64_t nCulledKF = 0, nCulledMP = 0;
+
+    // ---- MapPoint (src/MapPoint.cc) ----
+    int new_point(const float x[3], int refKF, int refFrame) {
+        MapPt p;
+        p.pos[0] = x[0]; p.pos[1] = x[1]; p.pos[2] = x[2];
+        memset(p.desc, 0, 32);
+        p.firstKF = refKF; p.firstFrame = refFrame; p.refKF = refKF;
+        mps.push_back(p);
+        return (int)mps.size() - 1;
+    }
+    void add_observation(int p, int kf, int idx) {   // :196-207
+        MapPt& m = mps[p];
+        size_t at = 0;
+        while (at < m.obs.size() && m.obs[at].first < kf) at++;
+        if (at < m.obs.size() && m.obs[at].first == kf) return;
+        m.obs.insert(m.obs.begin() + at, std::make_pair(kf, idx));
+        m.nObs += kfs[kf].uRight[idx] >= 0 ? 2 : 1;
+    }
+    void set_bad_point(int p) {                      // :253-270
+        MapPt& m = mps[p];
+        if (!m.bad) { nMPsInMap--; nCulledMP++; }
+        m.bad = true;
+        std::vector<std::pair<int, int>> o;
+        o.swap(m.obs);
+        for (auto& e : o) kfs[e.first].mp[e.second] = -1;
+    }
+    void erase_observation(int p, int kf) {          // :209-239
+        MapPt& m = mps[p];
+        bool bad = false;
+        for (size_t i = 0; i < m.obs.size(); i++)
+            if (m.obs[i].first == kf) {
+                m.nObs -= kfs[kf].uRight[m.obs[i].second] >= 0 ? 2 : 1;
+                m.obs.erase(m.obs.begin() + i);
+                if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
+                if (m.nObs <= 2) bad = true;
+                break;
+            }
+        if (bad) set_bad_point(p);
+    }
+    // MapPoint::Replace (:279-318) without the descriptor recomputation (the caller batches it): returns true if `by` changed
+    bool replace_point(int p, int by) {
+        if (p == by) return false;
+        MapPt& m = mps[p];
+        std::vector<std::pair<int, int>> o;
+        o.swap(m.obs);
+        if (!m.bad) { nMPsInMap--; }
+        m.bad = true;
+        m.replaced = by;
+        const int nvisible = m.visible, nfound = m.found;
+        for (auto& e : o) {
+            if (mps[by].obs_index(e.first) < 0) {
+                kfs[e.first].mp[e.second] = by;
+                add_observation(by, e.first, e.second);
+            } else {
+                kfs[e.first].mp[e.second] = -1;
+            }
+        }
+        mps[by].found += nfound;
+        mps[by].visible += nvisible;
+        return true;
+    }
+
+    // ---- KeyFrame covisibility graph (src/KeyFrame.cc:123-379) ----
+    void update_best_covisibles(int k) {             // :138-157: descending (weight, id)
+        KeyFrm& f = kfs[k];
+        std::vector<std::pair<int, int>> v;
+        v.reserve(f.connW.size());
+        for (auto& e : f.connW) v.push_back(std::make_pair(e.second, e.first));
+        std::sort(v.begin(), v.end());
+        f.ordered.clear(); f.orderedW.clear();
+        for (size_t i = v.size(); i-- > 0;) { f.ordered.push_back(v[i].second); f.orderedW.push_back(v[i].first); }
+    }
+    void add_connection(int k, int other, int w) {   // :123-136
+        KeyFrm& f = kfs[k];
+        auto it = f.connW.find(other);
+        if (it == f.connW.end()) f.connW[other] = w;
+        else if (it->second != w) it->second = w;
+        else return;
+        update_best_covisibles(k);
+    }
+    void erase_connection(int k, int other) {        // :553-567
+        if (kfs[k].connW.erase(other)) update_best_covisibles(k);
+    }
+    std::vector<int> best_covisibles(int k, int n) const {   // :174-182
+        const KeyFrm& f = kfs[k];
+        if ((int)f.ordered.size() < n) return f.ordered;
+        return std::vector<int>(f.ordered.begin(), f.ordered.begin() + n);
+    }
+    int weight(int k, int other) const {
+        auto it = kfs[k].connW.find(other);
+        return it == kfs[k].connW.end() ? 0 : it->second;
+    }
+    void update_connections(int k, std::vector<int>& counter /* scratch, size >= kfs.size(), zeros */) {   // :289-379
+        KeyFrm& f = kfs[k];
+        std::vector<int> touched;
+        for (int i = 0; i < f.N; i++) {
+            const int p = f.mp[i];
+            if (p < 0 || mps[p].bad) continue;
+            for (auto& e : mps[p].obs) {
+                if (e.first == k) continue;
+                if (counter[e.first]++ == 0) touched.push_back(e.first);
+            }
+        }
+        if (touched.empty()) return;
+        std::sort(touched.begin(), touched.end());
+        int nmax = 0, kmax = -1;
+        const int th = 15;
+        std::vector<std::pair<int, int>> v;
+        for (int o : touched) {
+            const int c = counter[o];
+            if (c > nmax) { nmax = c; kmax = o; }
+            if (c >= th) { v.push_back(std::make_pair(c, o)); add_connection(o, k, c); }
+        }
+        if (v.empty()) { v.push_back(std::make_pair(nmax, kmax)); add_connection(kmax, k, nmax); }
+        std::sort(v.begin(), v.end());
+        f.connW.clear();
+        for (int o : touched) { f.connW[o] = counter[o]; counter[o] = 0; }
+        f.ordered.clear(); f.orderedW.clear();
+        for (size_t i = v.size(); i-- > 0;) { f.ordered.push_back(v[i].second); f.orderedW.push_back(v[i].first); }
+        if (f.firstConnection && f.id != 0) {
+            f.parent = f.ordered.front();
+            kfs[f.parent].children.insert(k);
+            f.firstConnection = false;
+        }
+    }
+    int tracked_map_points(int k, int minObs) const {   // :250-275
+        const KeyFrm& f = kfs[k];
+        int n = 0;
+        for (int i = 0; i < f.N; i++) {
+            const int p = f.mp[i];
+            if (p < 0 || mps[p].bad) continue;
+            if (minObs > 0) { if (mps[p].nObs >= minObs) n++; }
+            else n++;
+        }
+        return n;
+    }
+    void set_bad_keyframe(int k) {                   // :453-545 (mbNotErase is only set by the loop closer: never here)
+        KeyFrm& f = kfs[k];
+        if (f.id == 0 || f.bad) return;
+        for (auto& e : f.connW) erase_connection(e.first, k);
+        for (int i = 0; i < f.N; i++)
+            if (f.mp[i] >= 0) erase_observation(f.mp[i], k);
+        f.connW.clear(); f.ordered.clear(); f.orderedW.clear();
+        std::set<int> cand;
+        cand.insert(f.parent);
+        while (!f.children.empty()) {
+            bool cont = false;
+            int maxw = -1, pC = -1, pP = -1;
+            for (int c : f.children) {
+                if (kfs[c].bad) continue;
+                for (int conn : kfs[c].ordered)
+                    for (int pc : cand)
+                        if (conn == pc) {
+                            const int w = weight(c, conn);
+                            if (w > maxw) { pC = c; pP = conn; maxw = w; cont = true; }
+                        }
+            }
+            if (!cont) break;
+            kfs[pC].parent = pP;
+            kfs[pP].children.insert(pC);
+            cand.insert(pC);
+            f.children.erase(pC);
+        }
+        for (int c : f.children) { kfs[c].parent = f.parent; kfs[f.parent].children.insert(c); }
+        kfs[f.parent].children.erase(k);
+        f.Tcp = mul4(f.pose.Tcw, kfs[f.parent].pose.Twc);
+        f.bad = true;
+        nKFsInMap--; nCulledKF++;
+    }
+};
+
+}  // namespace oslam_drv

@@ -1,0 +1,121 @@
+"""ctypes view of the batch-of-sequences tracking + local-mapping driver (include/oslam_slam.h).
+
+`System(cfg)` mirrors the reference's ORB_SLAM2::System for S RGB-D sequences advanced in lockstep on one GPU
+(System::TrackRGBD -> `TrackRGBD`, SaveTrajectoryTUM -> `trajectory`, SaveKeyFrameTrajectoryTUM -> `keyframe_trajectory`).
+The product constructor always binds the HIP operators; `ops=` takes the address of another oslam_slam_ops_t (tests pass
+the CPU oracle's table) and nothing in this module imports oracle/.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib, ptr
+
+
+class SlamConfig(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("dist", C.c_float * 5), ("ndist", C.c_int32), ("bf", C.c_float), ("thDepth", C.c_float), ("fps", C.c_float),
+                ("nFeatures", C.c_int32), ("scaleFactor", C.c_float), ("nLevels", C.c_int32), ("iniThFAST", C.c_int32), ("minThFAST", C.c_int32),
+                ("n_sequences", C.c_int32), ("device", C.c_int32), ("host_threads", C.c_int32), ("local_mapping", C.c_int32)]
+
+
+class SlamOps(C.Structure):
+    _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
+        "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
+        "triangulate", "destroy")]
+
+
+# reference Examples/RGB-D/TUM2.yaml (distortion left at zero: the synthetic streams are rendered without it)
+TUM2 = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, bf=40.0, thDepth=40.0, fps=30.0)
+
+OK, LOST, NOT_INITIALIZED = 2, 3, 1
+
+
+def make_config(width, height, n_sequences, cam=TUM2, dist=None, nFeatures=1000, scaleFactor=1.2, nLevels=8, iniThFAST=20, minThFAST=7, device=0,
+                host_threads=0, local_mapping=0x1F):
+    c = SlamConfig()
+    c.width, c.height = width, height
+    c.fx, c.fy, c.cx, c.cy, c.bf, c.thDepth, c.fps = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], cam["thDepth"], cam["fps"]
+    if dist is not None:
+        for i, v in enumerate(dist):
+            c.dist[i] = v
+        c.ndist = len(dist)
+    c.nFeatures, c.scaleFactor, c.nLevels, c.iniThFAST, c.minThFAST = nFeatures, scaleFactor, nLevels, iniThFAST, minThFAST
+    c.n_sequences, c.device, c.host_threads, c.local_mapping = n_sequences, device, host_threads, local_mapping
+    return c
+
+
+class System:
+    def __init__(self, cfg, ops=None):
+        self.L = lib()
+        self.cfg = cfg
+        self.S = cfg.n_sequences
+        self.h = C.c_void_p()
+        if ops is None:
+            check(self.L.oslam_slam_create(C.byref(self.h), C.byref(cfg)))
+        else:
+            check(self.L.oslam_slam_create_with_ops(C.byref(self.h), C.byref(cfg), C.byref(ops)))
+        self._gp = (C.c_void_p * self.S)()
+        self._dp = (C.c_void_p * self.S)()
+        self.Tcw = np.zeros((self.S, 4, 4), np.float32)
+        self.state = np.zeros(self.S, np.int32)
+
+    def __del__(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.L.oslam_slam_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def TrackRGBD(self, gray, depth, timestamps=None):
+        """gray: S uint8 arrays [H, W] (C-contiguous rows), depth: S float32 arrays [H, W] in metres."""
+        for i in range(self.S):
+            g, d = gray[i], depth[i]
+            assert g.dtype == np.uint8 and d.dtype == np.float32 and g.strides[1] == 1 and d.strides[1] == 4
+            self._gp[i] = g.__array_interface__["data"][0]
+            self._dp[i] = d.__array_interface__["data"][0]
+        ts = None
+        if timestamps is not None:
+            ts = np.ascontiguousarray(timestamps, np.float64)
+        check(self.L.oslam_slam_track_rgbd(self.h, self._gp, C.c_int(gray[0].strides[0]), self._dp, C.c_int(depth[0].strides[0] // 4), C.c_int(0),
+                                           ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
+        return self.Tcw, self.state
+
+    def TrackRGBD_device(self, gray_ptrs, gray_stride, depth_ptrs, depth_pitch, timestamps=None):
+        """Device-resident inputs: lists of S device addresses (e.g. torch tensors' data_ptr())."""
+        for i in range(self.S):
+            self._gp[i] = gray_ptrs[i]
+            self._dp[i] = depth_ptrs[i]
+        ts = None
+        if timestamps is not None:
+            ts = np.ascontiguousarray(timestamps, np.float64)
+        check(self.L.oslam_slam_track_rgbd(self.h, self._gp, C.c_int(gray_stride), self._dp, C.c_int(depth_pitch), C.c_int(1),
+                                           ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
+        return self.Tcw, self.state
+
+    def _traj(self, fn, seq):
+        n = C.c_int32(0)
+        cap = 1 << 16
+        st = np.zeros(cap, np.float64)
+        T = np.zeros((cap, 3, 4), np.float32)
+        check(fn(self.h, C.c_int(seq), C.c_int(cap), ptr(st), ptr(T), C.byref(n)))
+        return st[:n.value].copy(), T[:n.value].copy()
+
+    def trajectory(self, seq):
+        """(stamps, Twc[n,3,4]) as System::SaveTrajectoryTUM would write them (reference src/System.cc:378-440)."""
+        return self._traj(self.L.oslam_slam_trajectory, seq)
+
+    def keyframe_trajectory(self, seq):
+        return self._traj(self.L.oslam_slam_keyframe_trajectory, seq)
+
+    def stats(self, seq):
+        out = np.zeros(16, np.int64)
+        check(self.L.oslam_slam_stats(self.h, C.c_int(seq), ptr(out)))
+        names = ("frames", "keyframes_created", "keyframes_in_map", "points_created", "points_in_map", "local_bas", "tracked_motion_model",
+                 "tracked_reference_kf", "lost_frames", "points_fused", "points_triangulated", "keyframes_culled", "points_culled", "last_inliers",
+                 "lba_edges", "map_violations")
+        return dict(zip(names, out.tolist()))
+
+    def stage_seconds(self):
+        out = np.zeros(16, np.float64)
+        check(self.L.oslam_slam_stage_seconds(self.h, ptr(out)))
+        names = ("frames", "search_last", "pose_opt", "search_local", "host_tracking", "mp_update", "lba", "host_mapping", "fuse_bow_triangulate")
+        return dict(zip(names, out[:9].tolist()))

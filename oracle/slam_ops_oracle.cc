@@ -1,0 +1,221 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle_common.h).  PARITY UNPINNED.
+// Operator table of the batch-of-sequences driver (include/oslam_slam.h, oslam_slam_ops_t) implemented with the CPU
+// restatement: tests run the product's driver (object_slam_amd/csrc/slam_driver.hip) once over the HIP operators and once
+// over these and compare the trajectories / maps.  The product never links this file.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/oslam_slam.h"
+#include "matcher_oracle.h"
+#include "oracle_common.h"
+
+using oracle::KeyPoint;
+using oracle::ProjQuery;
+
+extern "C" {
+void* oo_orb_create(int, float, int, int, int);
+void oo_orb_destroy(void*);
+int oo_orb_extract(void*, const uint8_t*, int, int, int, KeyPoint*, uint8_t*, int, int*);
+void oo_orb_tables(void*, float*, float*, float*, float*, int*, int*);
+void oo_undistort_keypoints(int, const KeyPoint*, const float*, const float*, int, KeyPoint*);
+void oo_image_bounds(int, int, const float*, const float*, int, float*);
+void oo_stereo_from_rgbd(int, const KeyPoint*, const KeyPoint*, const float*, int, float, float*, float*);
+int oo_search_by_projection(int, const KeyPoint*, const float*, const uint8_t*, const uint8_t*, const float*, const ProjQuery*, int, float, int, int,
+                            int*, int*, int*);
+void oo_project_last_frame(int, const float*, const uint8_t*, const KeyPoint*, const uint8_t*, const float*, const float*, const float*, const float*,
+                           const float*, float, int, ProjQuery*);
+void oo_is_in_frustum(int, const float*, const float*, const float*, const float*, const uint8_t*, const uint8_t*, const float*, const float*,
+                      const float*, float, float, const float*, int, float, ProjQuery*);
+int oo_pose_optimization(int, const float*, const float*, const float*, const float*, const uint8_t*, const float*, float*, uint8_t*, int*);
+void oo_local_bundle_adjustment(int, const float*, const uint8_t*, int, const float*, int, const int32_t*, const int32_t*, const float*, const float*,
+                                const float*, const int*, float*, float*, uint8_t*, int*);
+int oo_distinctive_descriptor(int, const uint8_t*);
+void oo_update_normal_depth(const float*, int, const float*, const float*, float, float, float*);
+int oo_fuse_search(int, const KeyPoint*, const float*, const uint8_t*, const float*, const ProjQuery*, int, const float*, int*, int*);
+int oo_search_by_bow(int, const int32_t*, const uint32_t*, const KeyPoint*, const uint8_t*, const uint8_t*, int, const KeyPoint*, const uint8_t*, int,
+                     const uint32_t*, const int32_t*, const int32_t*, float, int, int*);
+int oo_search_for_triangulation(int, const int32_t*, const uint32_t*, int, const KeyPoint*, const uint8_t*, const float*, const uint8_t*, int,
+                                const KeyPoint*, const uint8_t*, const float*, const uint8_t*, int, const uint32_t*, const int32_t*, const int32_t*,
+                                const float*, float, float, const float*, const float*, int, int, int*);
+int oo_triangulate(const float*, const KeyPoint*, const KeyPoint*, const float*, const float*, const float*, const KeyPoint*, const KeyPoint*,
+                   const float*, const float*, int, const int32_t*, const int32_t*, const float*, const float*, float, uint8_t*, float*);
+}
+
+namespace {
+
+struct OCtx {
+    oslam_slam_config_t cfg;
+    void* orb;
+    int cap;
+    float scale[16], invScale[16], sigma2[16], invSigma2[16];
+    float bounds[4], K4[4], K5[5], K6[6];
+};
+
+int o_max_keypoints(void* p) { return ((OCtx*)p)->cap; }
+int o_scale_tables(void* p, float* a, float* b, float* c, float* d) {
+    OCtx* o = (OCtx*)p;
+    const int n = o->cfg.nLevels;
+    memcpy(a, o->scale, 4 * n); memcpy(b, o->invScale, 4 * n); memcpy(c, o->sigma2, 4 * n); memcpy(d, o->invSigma2, 4 * n);
+    return 0;
+}
+int o_image_bounds(void* p, float* b) { memcpy(b, ((OCtx*)p)->bounds, 16); return 0; }
+
+int o_frames(void* p, int n, const int32_t*, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
+             oslam_slam_frame_t* const* out) {
+    OCtx* o = (OCtx*)p;
+    if (on_device) return OSLAM_E_INVALID;
+    for (int i = 0; i < n; i++) {
+        oslam_slam_frame_t* f = out[i];
+        int N = 0;
+        if (oo_orb_extract(o->orb, gray[i], o->cfg.width, o->cfg.height, gray_stride, (KeyPoint*)f->keys, f->desc, o->cap, &N)) return OSLAM_E_CAPACITY;
+        f->N = N;
+        oo_undistort_keypoints(N, (const KeyPoint*)f->keys, o->K4, o->cfg.dist, o->cfg.ndist, (KeyPoint*)f->keysUn);
+        oo_stereo_from_rgbd(N, (const KeyPoint*)f->keys, (const KeyPoint*)f->keysUn, depth[i], depth_pitch, o->cfg.bf, f->uRight, f->depth);
+    }
+    return 0;
+}
+
+int o_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    std::vector<ProjQuery> q;
+    std::vector<int> qm, qd;
+    for (int i = 0; i < n; i++) {
+        oslam_job_search_last_t& j = jobs[i];
+        q.resize(j.Nlast + 1); qm.resize(j.Nlast + 1); qd.resize(j.Nlast + 1);
+        oo_project_last_frame(j.Nlast, j.Xw, j.has_mp, (const KeyPoint*)j.last_keysUn, j.mp_desc, j.Tcw, j.Tlw, o->K6, o->bounds, o->scale, j.th, 0, q.data());
+        std::vector<uint8_t> none(j.cur->N + 1, 0);
+        j.nmatches = oo_search_by_projection(j.cur->N, (const KeyPoint*)j.cur->keysUn, j.cur->uRight, j.cur->desc, none.data(), o->bounds, q.data(), j.Nlast,
+                                             0.9f, 0, 1, qm.data(), qd.data(), j.kp_match);
+    }
+    return 0;
+}
+
+int o_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    std::vector<ProjQuery> q;
+    std::vector<int> qm, qd;
+    const float logScale = std::log(o->cfg.scaleFactor);
+    for (int i = 0; i < n; i++) {
+        oslam_job_search_local_t& j = jobs[i];
+        q.resize(j.M + 1); qm.resize(j.M + 1); qd.resize(j.M + 1);
+        oo_is_in_frustum(j.M, j.Pw, j.Pn, j.maxDist, j.minDist, j.obs_gt0, j.mp_desc, j.Tcw, o->K5, o->bounds, 0.5f, logScale, o->scale, o->cfg.nLevels,
+                         j.th, q.data());
+        int nin = 0;
+        for (int e = 0; e < j.M; e++) { j.in_view[e] = q[e].flags & 1; nin += j.in_view[e]; }
+        for (int k = 0; k < j.cur->N; k++) j.kp_match[k] = -1;
+        j.nmatches = 0;
+        if (nin > 0)
+            j.nmatches = oo_search_by_projection(j.cur->N, (const KeyPoint*)j.cur->keysUn, j.cur->uRight, j.cur->desc, j.blocked, o->bounds, q.data(), j.M,
+                                                 0.8f, 1, 0, qm.data(), qd.data(), j.kp_match);
+    }
+    return 0;
+}
+
+int o_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < n; i++) {
+        oslam_job_pose_t& j = jobs[i];
+        int stats[2];
+        j.n_inliers = oo_pose_optimization(j.N, j.Tcw_in, j.Xw, j.obs, j.invSigma2, j.has_mp, o->K5, j.Tcw_out, j.outlier, stats);
+    }
+    return 0;
+}
+
+int o_mp_update(void* p, oslam_job_mp_update_t* j) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < j->P; i++) {
+        const int s = j->obs_start[i], n = j->obs_start[i + 1] - s;
+        if (j->do_desc) {
+            const int b = n > 0 ? oo_distinctive_descriptor(n, j->obs_desc + (size_t)s * 32) : -1;
+            j->best_idx[i] = b;
+            if (b >= 0) memcpy(j->out_desc + (size_t)i * 32, j->obs_desc + (size_t)(s + b) * 32, 32);
+            else memset(j->out_desc + (size_t)i * 32, 0, 32);
+        }
+        if (j->do_normal && n > 0)
+            oo_update_normal_depth(j->Pos + (size_t)i * 3, n, j->obs_Ow + (size_t)s * 3, j->OwRef + (size_t)i * 3, j->levelScaleFactor[i],
+                                   o->scale[o->cfg.nLevels - 1], j->out5 + (size_t)i * 5);
+    }
+    return 0;
+}
+
+int o_lba(void* p, int n, const oslam_lba_problem_t* pr) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < n; i++) {
+        int stats[4];
+        oo_local_bundle_adjustment(pr[i].nKF, pr[i].poses, pr[i].fixed, pr[i].nP, pr[i].points, pr[i].nE, pr[i].edge_kf, pr[i].edge_pt, pr[i].edge_obs,
+                                   pr[i].edge_invSigma2, o->K5, nullptr, pr[i].poses_out, pr[i].points_out, pr[i].erase, stats);
+    }
+    return 0;
+}
+
+int o_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    std::vector<int> qd;
+    for (int i = 0; i < n; i++) {
+        oslam_job_fuse_t& j = jobs[i];
+        qd.resize(j.M + 1);
+        oo_fuse_search(j.N, (const KeyPoint*)j.keysUn, j.uRight, j.desc, o->bounds, (const ProjQuery*)j.queries, j.M, o->invSigma2, j.q_match, qd.data());
+    }
+    return 0;
+}
+
+int o_bow(void* p, int n, oslam_job_bow_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < n; i++) {
+        oslam_job_bow_t& j = jobs[i];
+        if (!j.triangulation)
+            j.nmatches = oo_search_by_bow(j.s1.nq, j.s1.q_idx, j.s1.q_node, (const KeyPoint*)j.s1.keys, j.s1.desc, j.s1.flag, j.s2.N, (const KeyPoint*)j.s2.keys,
+                                          j.s2.desc, j.s2.nNodes, j.s2.nodes, j.s2.start, j.s2.items, j.nnratio, j.checkOri, j.match);
+        else
+            j.nmatches = oo_search_for_triangulation(j.s1.nq, j.s1.q_idx, j.s1.q_node, j.s1.N, (const KeyPoint*)j.s1.keys, j.s1.desc, j.s1.uRight, j.s1.flag,
+                                                     j.s2.N, (const KeyPoint*)j.s2.keys, j.s2.desc, j.s2.uRight, j.s2.has_mp, j.s2.nNodes, j.s2.nodes, j.s2.start,
+                                                     j.s2.items, j.F12, j.ex, j.ey, o->scale, o->sigma2, 0, j.checkOri, j.match);
+    }
+    return 0;
+}
+
+int o_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < n; i++) {
+        oslam_job_triangulate_t& j = jobs[i];
+        if (j.M == 0) continue;
+        float a[40], b[40];
+        auto pack = [](const oslam_tri_kf_t& k, float* d) {
+            memcpy(d, k.Tcw, 64); memcpy(d + 16, k.Twc, 64);
+            d[32] = k.fx; d[33] = k.fy; d[34] = k.cx; d[35] = k.cy; d[36] = k.invfx; d[37] = k.invfy; d[38] = k.mbf; d[39] = k.mb;
+        };
+        pack(j.kf1, a); pack(j.kf2, b);
+        oo_triangulate(a, (const KeyPoint*)j.kf1.keysUn, (const KeyPoint*)j.kf1.keys, j.kf1.uRight, j.kf1.depth, b, (const KeyPoint*)j.kf2.keysUn,
+                       (const KeyPoint*)j.kf2.keys, j.kf2.uRight, j.kf2.depth, j.M, j.idx1, j.idx2, o->scale, o->sigma2, 1.5f * o->cfg.scaleFactor, j.ok, j.x3D);
+    }
+    return 0;
+}
+
+void o_destroy(void* p) {
+    OCtx* o = (OCtx*)p;
+    oo_orb_destroy(o->orb);
+    delete o;
+}
+
+}  // namespace
+
+extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* ops) {
+    OCtx* o = new OCtx;
+    o->cfg = *cfg;
+    o->orb = oo_orb_create(cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST);
+    int nfeat[16], umax[16];
+    oo_orb_tables(o->orb, o->scale, o->invScale, o->sigma2, o->invSigma2, nfeat, umax);
+    o->cap = 0;
+    for (int l = 0; l < cfg->nLevels; l++) o->cap += nfeat[l] + 8;
+    o->cap += 64;
+    o->K4[0] = cfg->fx; o->K4[1] = cfg->fy; o->K4[2] = cfg->cx; o->K4[3] = cfg->cy;
+    memcpy(o->K5, o->K4, 16); o->K5[4] = cfg->bf;
+    memcpy(o->K6, o->K5, 20); o->K6[5] = cfg->bf / cfg->fx;
+    oo_image_bounds(cfg->width, cfg->height, o->K4, cfg->dist, cfg->ndist, o->bounds);
+    ops->ctx = o;
+    ops->max_keypoints = o_max_keypoints; ops->scale_tables = o_scale_tables; ops->image_bounds = o_image_bounds; ops->frames_rgbd = o_frames;
+    ops->search_last = o_search_last; ops->search_local = o_search_local; ops->pose_opt = o_pose_opt; ops->mp_update = o_mp_update; ops->lba = o_lba;
+    ops->fuse = o_fuse; ops->bow = o_bow; ops->triangulate = o_triangulate; ops->destroy = o_destroy;
+    return 0;
+}

@@ -1,0 +1,39 @@
+"""Shared helpers of the tracking-driver tests: the product driver (object_slam_amd/csrc/slam_driver.hip) is run over an
+operator table — the HIP one (product) or the CPU oracle's (oracle/slam_ops_oracle.cc, test infrastructure)."""
+import ctypes as C
+
+import numpy as np
+
+from object_slam_amd import slam, synth
+from object_slam_amd.e2e import horn_align_ate
+
+W, H, Z0 = 640, 480, 2.0
+
+
+def oracle_ops(cfg):
+    from oracle import oracle_py as O
+    ops = slam.SlamOps()
+    assert O.lib().oo_slam_make_ops(C.byref(cfg), C.byref(ops)) == 0
+    return ops
+
+
+def make_streams(S, n, margin=1200, seed0=11):
+    return [synth.make_stream(n, W, H, seed=seed0 + s, margin=margin) for s in range(S)]
+
+
+def run(system, streams, n):
+    S = len(streams)
+    depth = np.full((H, W), Z0, np.float32)
+    poses, states = [], []
+    for t in range(n):
+        T, st = system.TrackRGBD([streams[s][0][t] for s in range(S)], [depth] * S, [t / 30.0] * S)
+        poses.append(T.copy())
+        states.append(st.copy())
+    return np.array(poses), np.array(states)
+
+
+def ate(system, cfg, streams, s):
+    stamps, Twc = system.trajectory(s)
+    off = (streams[s][1] - streams[s][1][0]).astype(np.float64)
+    gt = np.stack([off[:, 0] * Z0 / cfg.fx, off[:, 1] * Z0 / cfg.fy, np.zeros(len(off))], 1)
+    return horn_align_ate(Twc[:, :, 3], gt[:len(stamps)]), Twc

@@ -1,0 +1,68 @@
+"""CPU: the batch-of-sequences tracking + local-mapping driver (include/oslam_slam.h) run over the oracle's operator table:
+control flow, map bookkeeping invariants, trajectory accuracy, determinism, independence of the sequences in a batch.
+(The HIP operator table is compared with this one in tests/test_slam_driver_gpu.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from object_slam_amd import slam
+from slam_common import H, W, ate, make_streams, oracle_ops, run
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from object_slam_amd import OslamError
+    with pytest.raises(OslamError) as ei:
+        slam.System(slam.make_config(W, H, 1))
+    assert "no CPU fallback" in str(ei.value)
+
+
+def test_driver_tracks_and_maps(oracle):
+    n = 36
+    cfg = slam.make_config(W, H, 1)
+    streams = make_streams(1, n)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    poses, states = run(sysm, streams, n)
+    assert (states == slam.OK).all()
+    st = sysm.stats(0)
+    assert st["frames"] == n and st["lost_frames"] == 0 and st["map_violations"] == 0
+    # frame 1 has no motion model yet: TrackReferenceKeyFrame (reference src/Tracking.cc:358-361); the rest use the motion model
+    assert st["tracked_reference_kf"] == 1 and st["tracked_motion_model"] == n - 2
+    assert st["keyframes_created"] >= 4 and st["local_bas"] >= 2 and st["points_fused"] > 0 and st["points_culled"] > 0
+    a, Twc = ate(sysm, cfg, streams, 0)
+    assert a < 0.01, a          # metres over a ~1.5 m path, scene at 2 m
+    # fronto-parallel translation: rotation stays at identity
+    assert np.abs(Twc[:, :, :3] - np.eye(3)).max() < 1e-2
+    kst, kT = sysm.keyframe_trajectory(0)
+    assert len(kst) == st["keyframes_in_map"]
+
+
+def test_driver_is_deterministic_and_sequences_are_independent(oracle):
+    n = 14
+    streams = make_streams(2, n)
+    cfg2 = slam.make_config(W, H, 2)
+    s2 = slam.System(cfg2, oracle_ops(cfg2))
+    p2, _ = run(s2, streams, n)
+    for s in range(2):
+        cfg1 = slam.make_config(W, H, 1)
+        s1 = slam.System(cfg1, oracle_ops(cfg1))
+        p1, _ = run(s1, [streams[s]], n)
+        assert np.array_equal(p1[:, 0], p2[:, s])
+        assert s1.stats(0) == s2.stats(s)
+
+
+def test_local_mapping_switches(oracle):
+    """Tracking only + LBA (no culling / fusion / triangulation) still tracks; the map then only grows."""
+    n = 16
+    cfg = slam.make_config(W, H, 1, local_mapping=0x8)
+    streams = make_streams(1, n)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    run(sysm, streams, n)
+    st = sysm.stats(0)
+    assert st["points_culled"] == 0 and st["points_fused"] == 0 and st["points_triangulated"] == 0 and st["keyframes_culled"] == 0
+    assert st["local_bas"] >= 1 and st["map_violations"] == 0
+    a, _ = ate(sysm, cfg, streams, 0)
+    assert a < 0.01

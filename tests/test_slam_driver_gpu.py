@@ -1,0 +1,50 @@
+"""GPU: the tracking + local-mapping driver over the HIP operator table (the product) against the same driver over the CPU
+oracle's table, on the same seeded RGB-D streams.  Matching and culling decisions are integer work and must agree exactly;
+poses agree within the 1e-4 relative tolerance of the optimisers as long as the discrete decisions are the same."""
+import numpy as np
+import pytest
+
+from object_slam_amd import slam
+from slam_common import H, W, ate, make_streams, oracle_ops, run
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_driver_matches_oracle_driver(oracle):
+    n, S = 30, 3
+    streams = make_streams(S, n)
+    cfg = slam.make_config(W, H, S)
+    hip = slam.System(cfg)
+    ph, sh = run(hip, streams, n)
+    cfg_o = slam.make_config(W, H, S)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run(ora, streams, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    for s in range(S):
+        a, b = hip.stats(s), ora.stats(s)
+        assert a["map_violations"] == 0
+        assert a == b, (s, a, b)     # same keyframes, points, fusions, cullings, inlier counts
+        ah, Th = ate(hip, cfg, streams, s)
+        ao, To = ate(ora, cfg_o, streams, s)
+        assert ah < 0.01 and ao < 0.01
+        assert np.abs(Th - To).max() < 2e-4, np.abs(Th - To).max()      # 1e-4 relative on a ~2 m scene
+    d = np.abs(ph - po).max()
+    assert d < 2e-4, d
+
+
+def test_hip_driver_device_resident_inputs():
+    import torch
+    n, S = 8, 4
+    streams = make_streams(S, n)
+    cfg = slam.make_config(W, H, S)
+    host = slam.System(cfg)
+    ph, _ = run(host, streams, n)
+    dev = slam.System(slam.make_config(W, H, S))
+    d_depth = torch.full((H, W), 2.0, dtype=torch.float32, device="cuda")
+    pd = []
+    for t in range(n):
+        imgs = [torch.from_numpy(streams[s][0][t]).cuda() for s in range(S)]
+        torch.cuda.synchronize()
+        T, st = dev.TrackRGBD_device([i.data_ptr() for i in imgs], W, [d_depth.data_ptr()] * S, W, [t / 30.0] * S)
+        pd.append(T.copy())
+    assert np.array_equal(np.array(pd), ph)
