@@ -397,6 +397,14 @@ int oslam_frame_is_in_frustum_device(int M, const float* d_Pw, const float* d_Pn
                                      const uint8_t* d_mp_desc, const float Tcw[16], const float K5[5], const float bounds[4], float viewingCosLimit,
                                      float logScaleFactor, const float* scaleFactors, int nLevels, float th, oslam_proj_query_t* d_out, void* stream);
 
+/* batch of frames (Tracking::SearchLocalPoints for several sequences): per-point arrays [batch][stride], d_M[b] points of frame b are
+ * tested against pose d_Tcw[b] (16 floats) with radius factor d_th[b]; d_out [batch][stride] feeds oslam_match_search_batch_device
+ * (q_stride = stride); d_in_view [batch][stride] = mbTrackInView (may be NULL). */
+int oslam_frame_is_in_frustum_batch_device(int batch, int stride, const int32_t* d_M, const float* d_Pw, const float* d_Pn, const float* d_maxDist,
+                                           const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc, const float* d_Tcw, const float* d_th,
+                                           const float K5[5], const float bounds[4], float viewingCosLimit, float logScaleFactor, const float* scaleFactors,
+                                           int nLevels, oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream);
+
 /* LocalMapping::CreateNewMapPoints, per-match numeric core (reference src/LocalMapping.cc:291-432):
  * parallax test, 4x4 DLT by cv::SVD (one-sided Jacobi) or KeyFrame::UnprojectStereo (src/KeyFrame.cc:615-631),
  * cheirality, chi2 reprojection gates (5.991 / 7.8 x sigma2[octave]; the second view uses the CURRENT keyframe's mbf

@@ -98,9 +98,27 @@ struct FrustumCtx {
     oslam_proj_query_t* out;
 };
 
+// one map point against one frame pose; T = the frame's Tcw, th = the search-radius factor
+__device__ __forceinline__ bool frustum_point(const FrustumCtx& c, const float* __restrict__ T, const float th, const int i, oslam_proj_query_t* out);
+
 __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumCtx c) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= c.M) return;
+    frustum_point(c, c.T, c.th, i, c.out + i);
+}
+
+// batch of frames: point arrays [batch][stride], one pose / th / count per frame; in_view[b][i] = mbTrackInView
+__global__ __launch_bounds__(256) void k_is_in_frustum_batch(FrustumCtx c, int stride, const int* __restrict__ d_M, const float* __restrict__ d_Tcw,
+                                                             const float* __restrict__ d_th, uint8_t* __restrict__ in_view) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d_M[b]) return;
+    const size_t at = (size_t)b * stride + i;
+    const bool ok = frustum_point(c, d_Tcw + (size_t)b * 16, d_th[b], (int)at, c.out + at);
+    if (in_view) in_view[at] = ok;
+}
+
+__device__ __forceinline__ bool frustum_point(const FrustumCtx& c, const float* __restrict__ Tm, const float th, const int i, oslam_proj_query_t* out) {
     oslam_proj_query_t q;
     q.u = q.v = q.ur = q.radius = 0.f; q.minLevel = -1; q.maxLevel = -1; q.flags = 0; q.angle = 0.f;
     float Ow[3];
@@ -108,15 +126,15 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumCtx c) {
     for (int r = 0; r < 3; r++) {
         double s = 0;
 #pragma unroll
-        for (int k = 0; k < 3; k++) s += (double)c.T[k * 4 + r] * (double)c.T[k * 4 + 3];
+        for (int k = 0; k < 3; k++) s += (double)Tm[k * 4 + r] * (double)Tm[k * 4 + 3];
         Ow[r] = (float)(-1.0 * s);
     }
     const float P[3] = {c.Pw[i * 3], c.Pw[i * 3 + 1], c.Pw[i * 3 + 2]};
     float Pc[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {   // cv::gemm small-matrix branch: float accumulation
-        const float t0 = c.T[r * 4] * P[0] + c.T[r * 4 + 1] * P[1] + c.T[r * 4 + 2] * P[2];
-        Pc[r] = (float)((double)t0 + (double)c.T[r * 4 + 3]);
+        const float t0 = Tm[r * 4] * P[0] + Tm[r * 4 + 1] * P[1] + Tm[r * 4 + 2] * P[2];
+        Pc[r] = (float)((double)t0 + (double)Tm[r * 4 + 3]);
     }
     bool ok = !(Pc[2] < 0.0f);
     float u = 0, v = 0, invz = 0, viewCos = 0;
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumCtx c) {
     }
     if (ok) {
         float r = (double)viewCos > 0.998 ? 2.5f : 4.0f;
-        if (c.th != 1.0f) r *= c.th;
+        if (th != 1.0f) r *= th;
         q.u = u; q.v = v; q.ur = u - c.bf * invz;
         q.radius = r * c.scale[nScale];
         q.minLevel = nScale - 1; q.maxLevel = nScale;
@@ -156,7 +174,8 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumCtx c) {
     uint32_t* qd = (uint32_t*)q.desc;
 #pragma unroll
     for (int w = 0; w < 8; w++) qd[w] = ok ? sd[w] : 0u;
-    c.out[i] = q;
+    *out = q;
+    return ok;
 }
 
 }  // namespace oslam
@@ -266,6 +285,25 @@ int oslam_frame_is_in_frustum_device(int M, const float* d_Pw, const float* d_Pn
     fill_frustum(c, M, Tcw, K5, bounds, viewingCosLimit, logScaleFactor, scaleFactors, nLevels, th);
     c.Pw = d_Pw; c.Pn = d_Pn; c.maxDist = d_maxDist; c.minDist = d_minDist; c.obs_gt0 = d_obs_gt0; c.mp_desc = d_mp_desc; c.out = d_out;
     hipLaunchKernelGGL(k_is_in_frustum, dim3(div_up(M, 256)), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_frame_is_in_frustum_batch_device(int batch, int stride, const int32_t* d_M, const float* d_Pw, const float* d_Pn, const float* d_maxDist,
+                                           const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc, const float* d_Tcw, const float* d_th,
+                                           const float K5[5], const float bounds[4], float viewingCosLimit, float logScaleFactor, const float* scaleFactors,
+                                           int nLevels, oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream) {
+    if (batch < 0 || stride < 0 || !K5 || !bounds || !scaleFactors || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS ||
+        (batch > 0 && stride > 0 && (!d_M || !d_Pw || !d_Pn || !d_maxDist || !d_minDist || !d_obs_gt0 || !d_mp_desc || !d_Tcw || !d_th || !d_out))) {
+        set_error("bad argument");
+        return OSLAM_E_INVALID;
+    }
+    if (batch == 0 || stride == 0) return OSLAM_OK;
+    FrustumCtx c;
+    const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    fill_frustum(c, 0, I, K5, bounds, viewingCosLimit, logScaleFactor, scaleFactors, nLevels, 1.0f);
+    c.Pw = d_Pw; c.Pn = d_Pn; c.maxDist = d_maxDist; c.minDist = d_minDist; c.obs_gt0 = d_obs_gt0; c.mp_desc = d_mp_desc; c.out = d_out;
+    hipLaunchKernelGGL(k_is_in_frustum_batch, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c, stride, d_M, d_Tcw, d_th, d_in_view);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }

@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "slam_map.h"
+#include "slam_pool.h"
 
 int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* out);   // slam_ops_hip.hip
 
@@ -82,6 +83,9 @@ struct Seq {
     std::vector<uint8_t> jHas, jDesc, jBlocked, jObsGt0, jInView, jOutlier;
     std::vector<int> jMatch, jLocalIds;
     std::vector<KP> jKeys;
+    oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
+    bool hasSL = false, hasLoc = false;
+    std::vector<int> updList;             // points created by tracking this step (descriptor / normal pending)
 };
 
 struct Ctx {
@@ -94,6 +98,7 @@ struct Ctx {
     int maxFrames, minFrames;
     Vocab voc;
     std::vector<std::unique_ptr<Seq>> seq;
+    std::unique_ptr<Pool> pool;
     double sec[16] = {0};
 };
 
@@ -209,7 +214,7 @@ struct MpUpdate {
 };
 
 // Creates the stereo points of StereoInitialization (:603-619) / CreateNewKeyFrame (:1338-1398) for frame f, keyframe kf.
-static void create_stereo_points(Ctx& c, int si, Seq& s, Frame& f, int kf, bool all, MpUpdate& upd) {
+static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
     Map& m = s.map;
     auto make = [&](int i) {
         float x[3];
@@ -219,7 +224,7 @@ static void create_stereo_points(Ctx& c, int si, Seq& s, Frame& f, int kf, bool 
         m.kfs[kf].mp[i] = p;
         m.nMPsInMap++; s.st[3]++;
         f.mp[i] = p;
-        upd.add(si, p);
+        s.updList.push_back(p);
     };
     if (all) {
         for (int i = 0; i < f.N; i++) if (f.depth[i] > 0) make(i);
@@ -467,7 +472,7 @@ static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<in
 }
 
 // surgery of ORBmatcher::Fuse (:950-970) in query order; points whose descriptor must be recomputed go to `upd`
-static void fuse_apply(Seq& s, int si, int k, const std::vector<int>& qpt, const int32_t* q_match, MpUpdate& upd) {
+static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t* q_match) {
     Map& m = s.map;
     for (size_t i = 0; i < qpt.size(); i++) {
         const int best = q_match[i];
@@ -477,8 +482,8 @@ static void fuse_apply(Seq& s, int si, int k, const std::vector<int>& qpt, const
         const int inKF = m.kfs[k].mp[best];
         if (inKF >= 0) {
             if (!m.mps[inKF].bad) {
-                if (m.mps[inKF].nObs > m.mps[p].nObs) { if (m.replace_point(p, inKF)) upd.add(si, inKF); }
-                else { if (m.replace_point(inKF, p)) upd.add(si, p); }
+                if (m.mps[inKF].nObs > m.mps[p].nObs) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
+                else { if (m.replace_point(inKF, p)) s.updList.push_back(p); }
             }
         } else {
             m.add_observation(p, k, best);
@@ -495,9 +500,13 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     MpUpdate upd;
     const int flags = c.cfg.local_mapping;
     // --- ProcessNewKeyFrame (:129-169) ---
-    for (int si : who) {
-        Seq& s = *c.seq[si];
+    Pool& pool = *c.pool;
+    const int nW = (int)who.size();
+    auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
+    pool.parallel_for(nW, [&](int w) {
+        Seq& s = *c.seq[who[w]];
         Map& m = s.map;
+        s.updList.clear();
         s.curKF = s.newKFs.front();
         s.newKFs.clear();
         KeyFrm& kf = m.kfs[s.curKF];
@@ -505,19 +514,20 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         for (int i = 0; i < kf.N; i++) {
             const int p = kf.mp[i];
             if (p < 0 || m.mps[p].bad) continue;
-            if (m.mps[p].obs_index(s.curKF) < 0) { m.add_observation(p, s.curKF, i); upd.add(si, p); }
+            if (m.mps[p].obs_index(s.curKF) < 0) { m.add_observation(p, s.curKF, i); s.updList.push_back(p); }
             else s.recentAdded.push_back(p);
         }
-    }
+    });
+    merge_upd();
     c.sec[7] += tm.lap();
     if ((rc = upd.run(c, true, true))) return rc;
     c.sec[5] += tm.lap();
-    for (int si : who) {
-        Seq& s = *c.seq[si];
+    pool.parallel_for(nW, [&](int w) {
+        Seq& s = *c.seq[who[w]];
         s.map.update_connections(s.curKF, s.counter);
         s.map.nKFsInMap++;
         if (flags & 1) map_point_culling(s);
-    }
+    });
     c.sec[7] += tm.lap();
 
     // --- CreateNewMapPoints (:208-453): neighbours in lockstep (the matches of neighbour i see the points created from neighbour i-1) ---
@@ -643,16 +653,21 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         }
         auto fuse_round = [&](bool into_current, size_t t) -> int {
             jobs.clear(); jw.clear();
+            pool.parallel_for(nW, [&](int w) {
+                Seq& s = *c.seq[who[w]];
+                fs[w].q.clear(); fs[w].qpt.clear();
+                if (!into_current && t >= fs[w].targets.size()) return;
+                if (into_current && fs[w].targets.empty()) return;
+                const int k = into_current ? s.curKF : fs[w].targets[t];
+                fs[w].kf = k;
+                fuse_queries(c, s.map, k, fs[w].pts, 3.0f, fs[w].q, fs[w].qpt);
+                fs[w].qm.assign(fs[w].q.size() + 1, -1);
+            });
             for (size_t w = 0; w < who.size(); w++) {
                 Seq& s = *c.seq[who[w]];
                 Map& m = s.map;
-                if (!into_current && t >= fs[w].targets.size()) continue;
-                if (into_current && fs[w].targets.empty()) continue;
-                const int k = into_current ? s.curKF : fs[w].targets[t];
-                fs[w].kf = k;
-                fuse_queries(c, m, k, fs[w].pts, 3.0f, fs[w].q, fs[w].qpt);
-                fs[w].qm.assign(fs[w].q.size() + 1, -1);
                 if (fs[w].q.empty()) continue;
+                const int k = fs[w].kf;
                 const KeyFrm& kf = m.kfs[k];
                 oslam_job_fuse_t j;
                 j.N = kf.N; j.keysUn = kf.keysUn.data(); j.uRight = kf.uRight.data(); j.desc = kf.desc.data();
@@ -664,8 +679,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             int rc2 = c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
             if (rc2) return rc2;
             c.sec[8] += tm.lap();
-            upd.clear();
-            for (int w : jw) fuse_apply(*c.seq[who[w]], who[w], fs[w].kf, fs[w].qpt, fs[w].qm.data(), upd);
+            pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].qpt, fs[w].qm.data()); });
+            merge_upd();
             c.sec[7] += tm.lap();
             rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
             c.sec[5] += tm.lap();
@@ -709,14 +724,15 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             int si; std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
             std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref; int nLocal;
         };
-        std::vector<Win> wins;
-        for (int si : who) {
+        std::vector<Win> wins(who.size());
+        pool.parallel_for(nW, [&](int w) {
+            const int si = who[w];
             Seq& s = *c.seq[si];
             Map& m = s.map;
-            if (m.nKFsInMap <= 2) continue;   // src/LocalMapping.cc:81
+            Win& W = wins[w];
+            W.si = -1;
+            if (m.nKFsInMap <= 2) return;   // src/LocalMapping.cc:81
             const int cur = s.curKF;
-            wins.emplace_back();
-            Win& W = wins.back();
             W.si = si;
             W.kfs.push_back(cur);
             m.kfs[cur].baLocalForKF = cur;
@@ -761,7 +777,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = 0;
             W.poses_out.resize(W.poses.size()); W.points_out.resize(W.points.size() + 3); W.erase.assign(W.ekf.size() + 1, 0);
             s.st[5]++; s.st[14] += (int64_t)W.ekf.size();
-        }
+        });
+        wins.erase(std::remove_if(wins.begin(), wins.end(), [](const Win& W) { return W.si < 0; }), wins.end());
         std::vector<oslam_lba_problem_t> probs(wins.size());
         for (size_t i = 0; i < wins.size(); i++) {
             Win& W = wins[i];
@@ -773,8 +790,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         c.sec[7] += tm.lap();
         if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
         c.sec[6] += tm.lap();
-        upd.clear();
-        for (Win& W : wins) {
+        pool.parallel_for((int)wins.size(), [&](int wi) {
+            Win& W = wins[wi];
             Seq& s = *c.seq[W.si];
             Map& m = s.map;
             // erase list: mono edges first, then stereo edges (:711-757)
@@ -795,9 +812,10 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (size_t j = 0; j < W.pts.size(); j++) {
                 MapPt& mp = m.mps[W.pts[j]];
                 for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
-                upd.add(W.si, W.pts[j]);
+                s.updList.push_back(W.pts[j]);
             }
-        }
+        });
+        merge_upd();
         c.sec[7] += tm.lap();
         if ((rc = upd.run(c, false, true))) return rc;
         c.sec[5] += tm.lap();
@@ -805,8 +823,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
 
     // --- KeyFrameCulling (:633-697) ---
     if (flags & 16)
-        for (int si : who) {
-            Seq& s = *c.seq[si];
+        pool.parallel_for(nW, [&](int w) {
+            Seq& s = *c.seq[who[w]];
             Map& m = s.map;
             const std::vector<int> local = m.kfs[s.curKF].ordered;
             for (int k : local) {
@@ -830,9 +848,165 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
                 if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; }
             }
-        }
+        });
     c.sec[7] += tm.lap();
     return OSLAM_OK;
+}
+
+// Stage helpers of track_step (each runs for one sequence; the sequences of a batch are independent, so a stage is a parallel_for).
+static void stage_motion_model_prepare(Ctx& c, int i) {
+    Seq& s = *c.seq[i];
+    Frame& f = *s.cur; Frame& l = *s.last;
+    s.hasSL = false;
+    // CheckReplacedInLastFrame (:820-835)
+    for (int k = 0; k < l.N; k++) {
+        const int p = l.mp[k];
+        if (p >= 0 && s.map.mps[p].replaced >= 0) l.mp[k] = s.map.mps[p].replaced;
+    }
+    if (!s.hasVelocity || f.id < s.lastRelocFrameId + 2) { s.path = 2; return; }
+    s.path = 1;
+    // UpdateLastFrame (:882-891)
+    l.pose.set_frame(mul4(s.rel.back().Tcr, s.map.kfs[l.refKF].pose.Tcw));
+    f.pose.set_frame(mul4(s.velocity, l.pose.Tcw));
+    const int NL = l.N;
+    s.jXw.assign((size_t)NL * 3, 0.f); s.jHas.assign(NL, 0); s.jDesc.assign((size_t)NL * 32, 0);
+    for (int k = 0; k < NL; k++) {
+        const int p = l.mp[k];
+        if (p < 0 || l.outlier[k]) continue;
+        const MapPt& mp = s.map.mps[p];
+        s.jHas[k] = 1 | (mp.nObs > 0 ? 2 : 0);
+        for (int d = 0; d < 3; d++) s.jXw[(size_t)k * 3 + d] = mp.pos[d];
+        memcpy(&s.jDesc[(size_t)k * 32], mp.desc, 32);
+    }
+    s.jMatch.assign(f.N + 1, -1);
+    oslam_job_search_last_t& j = s.jSL;
+    j.slot = i; j.cur = &f.view; j.Nlast = NL; j.Xw = s.jXw.data(); j.has_mp = s.jHas.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data();
+    memcpy(j.Tcw, f.pose.Tcw.m, 64); memcpy(j.Tlw, l.pose.Tcw.m, 64);
+    j.th = 15.f;   // RGB-D (:961-965)
+    j.kp_match = s.jMatch.data(); j.nmatches = 0;
+    s.hasSL = true;
+}
+
+static void stage_local_map_prepare(Ctx& c, int i) {
+    Seq& s = *c.seq[i];
+    Frame& f = *s.cur;
+    s.hasLoc = false;
+    f.refKF = s.refKF;   // :446
+    if (!s.ok) return;
+    update_local_map(s);
+    // SearchLocalPoints (:1408-1458)
+    Map& m = s.map;
+    s.jBlocked.assign(f.N, 0);
+    for (int k = 0; k < f.N; k++) {
+        const int p = f.mp[k];
+        if (p < 0) continue;
+        if (m.mps[p].bad) { f.mp[k] = -1; continue; }
+        m.mps[p].visible++;
+        m.mps[p].lastFrameSeen = f.id;
+        s.jBlocked[k] = m.mps[p].nObs > 0;
+    }
+    s.jLocalIds.clear();
+    for (int p : s.localMPs) {
+        const MapPt& mp = m.mps[p];
+        if (mp.lastFrameSeen == f.id || mp.bad) continue;
+        s.jLocalIds.push_back(p);
+    }
+    const int M = (int)s.jLocalIds.size();
+    s.jPw.resize((size_t)M * 3 + 3); s.jPn.resize((size_t)M * 3 + 3); s.jMax.resize(M + 1); s.jMin.resize(M + 1); s.jObsGt0.resize(M + 1);
+    s.jDesc.resize((size_t)M * 32 + 32); s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
+    for (int q = 0; q < M; q++) {
+        const MapPt& mp = m.mps[s.jLocalIds[q]];
+        for (int d = 0; d < 3; d++) { s.jPw[(size_t)q * 3 + d] = mp.pos[d]; s.jPn[(size_t)q * 3 + d] = mp.normal[d]; }
+        s.jMax[q] = mp.maxD; s.jMin[q] = mp.minD; s.jObsGt0[q] = mp.nObs > 0;
+        memcpy(&s.jDesc[(size_t)q * 32], mp.desc, 32);
+    }
+    oslam_job_search_local_t& j = s.jLoc;
+    j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.jPw.data(); j.Pn = s.jPn.data(); j.maxDist = s.jMax.data();
+    j.minDist = s.jMin.data(); j.obs_gt0 = s.jObsGt0.data(); j.mp_desc = s.jDesc.data();
+    memcpy(j.Tcw, f.pose.Tcw.m, 64);
+    j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : 3.f;   // RGB-D th = 3 (:1450-1455)
+    j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;
+    s.hasLoc = true;
+}
+
+static void stage_after_local_pose(Ctx& c, int i) {
+    Seq& s = *c.seq[i];
+    Frame& f = *s.cur;
+    const oslam_job_pose_t& j = s.jPose;
+    M4 T; memcpy(T.m, j.Tcw_out, 64);
+    f.pose.set_frame(T);
+    s.matchesInliers = 0;
+    for (int k = 0; k < f.N; k++) {
+        const int p = f.mp[k];
+        if (p < 0) continue;
+        f.outlier[k] = j.outlier[k];
+        if (!f.outlier[k]) {
+            s.map.mps[p].found++;
+            if (s.map.mps[p].nObs > 0) s.matchesInliers++;
+        }
+    }
+    s.st[13] = s.matchesInliers;
+    if (f.id < s.lastRelocFrameId + c.maxFrames && s.matchesInliers < 50) s.ok = false;
+    else s.ok = s.matchesInliers >= 30;
+}
+
+// the part of Tracking::Track after TrackLocalMap (:470-566)
+static void stage_after_tracking(Ctx& c, int i) {
+    Seq& s = *c.seq[i];
+    Frame& f = *s.cur; Frame& l = *s.last;
+    Map& m = s.map;
+    s.state = s.ok ? ST_OK : ST_LOST;
+    if (s.ok) {
+        if (l.pose.valid) { s.velocity = mul4(f.pose.Tcw, l.pose.Twc); s.hasVelocity = true; }
+        else s.hasVelocity = false;
+        for (int k = 0; k < f.N; k++) {   // clean VO matches
+            const int p = f.mp[k];
+            if (p >= 0 && m.mps[p].nObs < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
+        }
+        // NeedNewKeyFrame (:1242-1326) with an idle local mapper
+        bool need = false;
+        {
+            const int nKFs = m.nKFsInMap;
+            if (!(f.id < s.lastRelocFrameId + c.maxFrames && nKFs > c.maxFrames)) {
+                const int nMinObs = nKFs <= 2 ? 2 : 3;
+                const int nRefMatches = m.tracked_map_points(s.refKF, nMinObs);
+                int nNonTrackedClose = 0, nTrackedClose = 0;
+                for (int k = 0; k < f.N; k++)
+                    if (f.depth[k] > 0 && f.depth[k] < c.thDepth) {
+                        if (f.mp[k] >= 0 && !f.outlier[k]) nTrackedClose++;
+                        else nNonTrackedClose++;
+                    }
+                const bool bNeedToInsertClose = (nTrackedClose < 100) && (nNonTrackedClose > 70);
+                const float thRefRatio = nKFs < 2 ? 0.4f : 0.75f;
+                const bool c1a = f.id >= s.lastKFFrameId + c.maxFrames;
+                const bool c1b = f.id >= s.lastKFFrameId + c.minFrames;
+                const bool c1c = s.matchesInliers < nRefMatches * 0.25 || bNeedToInsertClose;
+                const bool c2 = (s.matchesInliers < nRefMatches * thRefRatio || bNeedToInsertClose) && s.matchesInliers > 15;
+                need = (c1a || c1b || c1c) && c2;
+            }
+        }
+        if (need) {   // CreateNewKeyFrame (:1328-1406)
+            const int kf = new_keyframe(s, f);
+            s.refKF = kf; f.refKF = kf;
+            create_stereo_points(c, s, f, kf, false);
+            s.newKFs.push_back(kf);
+            s.lastKFFrameId = f.id;
+        }
+        for (int k = 0; k < f.N; k++)
+            if (f.mp[k] >= 0 && f.outlier[k]) f.mp[k] = -1;
+    } else {
+        s.st[8]++;
+    }
+    if (f.refKF < 0) f.refKF = s.refKF;
+}
+
+static int run_pose_jobs(Ctx& c, const std::vector<int>& who) {
+    if (who.empty()) return OSLAM_OK;
+    std::vector<oslam_job_pose_t> pj(who.size());
+    for (size_t q = 0; q < who.size(); q++) pj[q] = c.seq[who[q]]->jPose;
+    const int rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data());
+    for (size_t q = 0; q < who.size(); q++) c.seq[who[q]]->jPose = pj[q];
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -843,79 +1017,47 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
     const int S = c.S;
     Timer tm;
     int rc;
+    Pool& pool = *c.pool;
     // Frame::Frame for every sequence
     {
         std::vector<int32_t> slots(S);
         std::vector<oslam_slam_frame_t*> outs(S);
         for (int i = 0; i < S; i++) { slots[i] = i; outs[i] = &c.seq[i]->cur->view; }
         if ((rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data()))) return rc;
-        for (int i = 0; i < S; i++) {
-            Seq& s = *c.seq[i];
-            const int fid = s.nextFrameId++;
-            s.cur->begin(fid, stamps ? stamps[i] : (double)fid);
-            s.st[0]++;
-            s.path = 0; s.ok = false;
-        }
     }
     c.sec[0] += tm.lap();
-    MpUpdate upd;
     std::vector<int> tracking;   // sequences in the "system is initialised" branch
-    for (int i = 0; i < S; i++) {
+    pool.parallel_for(S, [&](int i) {
         Seq& s = *c.seq[i];
+        const int fid = s.nextFrameId++;
+        s.cur->begin(fid, stamps ? stamps[i] : (double)fid);
+        s.st[0]++;
+        s.path = 0; s.ok = false; s.hasSL = s.hasLoc = false;
+        s.updList.clear();
         Frame& f = *s.cur;
-        if (s.state == ST_NOT_INITIALIZED) {
+        if (s.state == ST_NOT_INITIALIZED && f.N > 500) {
             // StereoInitialization (:590-642)
-            if (f.N > 500) {
-                f.pose.set_frame(eye4());
-                const int kf = new_keyframe(s, f);
-                // mpMap->AddKeyFrame (:601): counted when ProcessNewKeyFrame inserts it (same std::set entry in the reference)
-                create_stereo_points(c, i, s, f, kf, true, upd);
-                s.newKFs.push_back(kf);
-                s.lastKFFrameId = f.id;
-                s.localKFs.assign(1, kf);
-                s.localMPs.clear();
-                for (int p : s.map.kfs[kf].mp) if (p >= 0) s.localMPs.push_back(p);
-                s.refKF = kf; f.refKF = kf;
-                s.state = ST_OK;
-            }
-        } else if (s.state == ST_OK) {
-            tracking.push_back(i);
+            f.pose.set_frame(eye4());
+            const int kf = new_keyframe(s, f);
+            // mpMap->AddKeyFrame (:601): counted when ProcessNewKeyFrame inserts it (same std::set entry in the reference)
+            create_stereo_points(c, s, f, kf, true);
+            s.newKFs.push_back(kf);
+            s.lastKFFrameId = f.id;
+            s.localKFs.assign(1, kf);
+            s.localMPs.clear();
+            for (int p : s.map.kfs[kf].mp) if (p >= 0) s.localMPs.push_back(p);
+            s.refKF = kf; f.refKF = kf;
+            s.state = ST_OK;
+            s.path = -1;   // initialised in this step: not tracked
         }
-    }
+    });
+    for (int i = 0; i < S; i++) if (c.seq[i]->state == ST_OK && c.seq[i]->path != -1) tracking.push_back(i);
+    const int nT = (int)tracking.size();
     // ---------------- initial pose: motion model or reference keyframe ----------------
+    pool.parallel_for(nT, [&](int q) { stage_motion_model_prepare(c, tracking[q]); });
     std::vector<oslam_job_search_last_t> sl;
     std::vector<int> slw;
-    for (int i : tracking) {
-        Seq& s = *c.seq[i];
-        Frame& f = *s.cur; Frame& l = *s.last;
-        // CheckReplacedInLastFrame (:820-835)
-        for (int k = 0; k < l.N; k++) {
-            const int p = l.mp[k];
-            if (p >= 0 && s.map.mps[p].replaced >= 0) l.mp[k] = s.map.mps[p].replaced;
-        }
-        if (!s.hasVelocity || f.id < s.lastRelocFrameId + 2) { s.path = 2; continue; }
-        s.path = 1;
-        // UpdateLastFrame (:882-891)
-        l.pose.set_frame(mul4(s.rel.back().Tcr, s.map.kfs[l.refKF].pose.Tcw));
-        f.pose.set_frame(mul4(s.velocity, l.pose.Tcw));
-        const int NL = l.N;
-        s.jXw.assign((size_t)NL * 3, 0.f); s.jHas.assign(NL, 0); s.jDesc.assign((size_t)NL * 32, 0);
-        for (int k = 0; k < NL; k++) {
-            const int p = l.mp[k];
-            if (p < 0 || l.outlier[k]) continue;
-            const MapPt& mp = s.map.mps[p];
-            s.jHas[k] = 1 | (mp.nObs > 0 ? 2 : 0);
-            for (int d = 0; d < 3; d++) s.jXw[(size_t)k * 3 + d] = mp.pos[d];
-            memcpy(&s.jDesc[(size_t)k * 32], mp.desc, 32);
-        }
-        s.jMatch.assign(f.N + 1, -1);
-        oslam_job_search_last_t j;
-        j.slot = i; j.cur = &f.view; j.Nlast = NL; j.Xw = s.jXw.data(); j.has_mp = s.jHas.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data();
-        memcpy(j.Tcw, f.pose.Tcw.m, 64); memcpy(j.Tlw, l.pose.Tcw.m, 64);
-        j.th = 15.f;   // RGB-D (:961-965)
-        j.kp_match = s.jMatch.data(); j.nmatches = 0;
-        sl.push_back(j); slw.push_back(i);
-    }
+    for (int i : tracking) if (c.seq[i]->hasSL) { sl.push_back(c.seq[i]->jSL); slw.push_back(i); }
     c.sec[4] += tm.lap();
     if (!sl.empty()) {
         if ((rc = c.ops.search_last(c.ops.ctx, (int)sl.size(), sl.data()))) return rc;
@@ -929,26 +1071,27 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
         }
     }
     c.sec[1] += tm.lap();
-    std::vector<oslam_job_pose_t> pj;
     std::vector<int> pjw;
     for (size_t q = 0; q < sl.size(); q++) {
         Seq& s = *c.seq[slw[q]];
-        Frame& f = *s.cur; Frame& l = *s.last;
         if (sl[q].nmatches < 20) { s.path = 2; continue; }   // TrackWithMotionModel failed -> TrackReferenceKeyFrame (:365-366)
-        for (int k = 0; k < f.N; k++) f.mp[k] = s.jMatch[k] >= 0 ? l.mp[s.jMatch[k]] : -1;
-        pj.emplace_back();
-        fill_pose_job(c, s, slw[q], pj.back());
         pjw.push_back(slw[q]);
     }
-    c.sec[4] += tm.lap();
-    if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
-    c.sec[2] += tm.lap();
-    for (size_t q = 0; q < pj.size(); q++) {
+    pool.parallel_for((int)pjw.size(), [&](int q) {
         Seq& s = *c.seq[pjw[q]];
-        s.ok = finish_initial_pose(s, pj[q]);
+        Frame& f = *s.cur; Frame& l = *s.last;
+        for (int k = 0; k < f.N; k++) f.mp[k] = s.jMatch[k] >= 0 ? l.mp[s.jMatch[k]] : -1;
+        fill_pose_job(c, s, pjw[q], s.jPose);
+    });
+    c.sec[4] += tm.lap();
+    if ((rc = run_pose_jobs(c, pjw))) return rc;
+    c.sec[2] += tm.lap();
+    pool.parallel_for((int)pjw.size(), [&](int q) {
+        Seq& s = *c.seq[pjw[q]];
+        s.ok = finish_initial_pose(s, s.jPose);
         if (s.ok) s.st[6]++;
         else s.path = 2;
-    }
+    });
     // TrackReferenceKeyFrame (:838-880) for the sequences without a motion model or whose motion-model tracking failed
     {
         std::vector<int> rk;
@@ -958,7 +1101,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
             std::vector<BowViews> bv(rk.size());
             std::vector<std::vector<uint8_t>> flag(rk.size());
             std::vector<std::vector<int32_t>> match(rk.size());
-            for (size_t q = 0; q < rk.size(); q++) {
+            pool.parallel_for((int)rk.size(), [&](int q) {
                 Seq& s = *c.seq[rk[q]];
                 Frame& f = *s.cur;
                 KeyFrm& kf = s.map.kfs[s.refKF];
@@ -966,7 +1109,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
                 compute_bow(c, kf.N, kf.desc.data(), kf.bowNode);
                 bv[q].side1(kf.bowNode); bv[q].side2(f.bowNode);
                 flag[q].resize(kf.N);
-                for (int i = 0; i < kf.N; i++) flag[q][i] = kf.mp[i] >= 0 && !s.map.mps[kf.mp[i]].bad;
+                for (int k = 0; k < kf.N; k++) flag[q][k] = kf.mp[k] >= 0 && !s.map.mps[kf.mp[k]].bad;
                 match[q].assign(f.N + 1, -1);
                 oslam_job_bow_t& j = bj[q];
                 memset(&j, 0, sizeof(j));
@@ -975,11 +1118,11 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
                 j.s2.N = f.N; j.s2.keys = f.keysUn.data(); j.s2.desc = f.desc.data(); j.s2.uRight = nullptr; j.s2.has_mp = nullptr;
                 j.s2.nNodes = (int)bv[q].nodes.size(); j.s2.nodes = bv[q].nodes.data(); j.s2.start = bv[q].start.data(); j.s2.items = bv[q].items.data();
                 j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();
-            }
+            });
             c.sec[4] += tm.lap();
             if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             c.sec[8] += tm.lap();
-            pj.clear(); pjw.clear();
+            pjw.clear();
             for (size_t q = 0; q < rk.size(); q++) {
                 Seq& s = *c.seq[rk[q]];
                 Frame& f = *s.cur;
@@ -988,155 +1131,46 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
                 const KeyFrm& kf = s.map.kfs[s.refKF];
                 for (int k = 0; k < f.N; k++) f.mp[k] = match[q][k] >= 0 ? kf.mp[match[q][k]] : -1;
                 f.pose.set_frame(s.last->pose.Tcw);
-                pj.emplace_back();
-                fill_pose_job(c, s, rk[q], pj.back());
+                fill_pose_job(c, s, rk[q], s.jPose);
                 pjw.push_back(rk[q]);
             }
-            if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+            if ((rc = run_pose_jobs(c, pjw))) return rc;
             c.sec[2] += tm.lap();
-            for (size_t q = 0; q < pj.size(); q++) {
-                Seq& s = *c.seq[pjw[q]];
-                s.ok = finish_initial_pose(s, pj[q]);
+            for (int i : pjw) {
+                Seq& s = *c.seq[i];
+                s.ok = finish_initial_pose(s, s.jPose);
                 if (s.ok) s.st[7]++;
             }
         }
     }
     // ---------------- TrackLocalMap (:1011-1056) ----------------
+    pool.parallel_for(nT, [&](int q) { stage_local_map_prepare(c, tracking[q]); });
     std::vector<oslam_job_search_local_t> lj;
     std::vector<int> ljw;
-    for (int i : tracking) {
-        Seq& s = *c.seq[i];
-        Frame& f = *s.cur;
-        f.refKF = s.refKF;   // :446
-        if (!s.ok) continue;
-        update_local_map(s);
-        // SearchLocalPoints (:1408-1458)
-        Map& m = s.map;
-        s.jBlocked.assign(f.N, 0);
-        for (int k = 0; k < f.N; k++) {
-            const int p = f.mp[k];
-            if (p < 0) continue;
-            if (m.mps[p].bad) { f.mp[k] = -1; continue; }
-            m.mps[p].visible++;
-            m.mps[p].lastFrameSeen = f.id;
-            s.jBlocked[k] = m.mps[p].nObs > 0;
-        }
-        s.jLocalIds.clear();
-        for (int p : s.localMPs) {
-            const MapPt& mp = m.mps[p];
-            if (mp.lastFrameSeen == f.id || mp.bad) continue;
-            s.jLocalIds.push_back(p);
-        }
-        const int M = (int)s.jLocalIds.size();
-        s.jPw.resize((size_t)M * 3 + 3); s.jPn.resize((size_t)M * 3 + 3); s.jMax.resize(M + 1); s.jMin.resize(M + 1); s.jObsGt0.resize(M + 1);
-        s.jDesc.resize((size_t)M * 32 + 32); s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
-        for (int q = 0; q < M; q++) {
-            const MapPt& mp = m.mps[s.jLocalIds[q]];
-            for (int d = 0; d < 3; d++) { s.jPw[(size_t)q * 3 + d] = mp.pos[d]; s.jPn[(size_t)q * 3 + d] = mp.normal[d]; }
-            s.jMax[q] = mp.maxD; s.jMin[q] = mp.minD; s.jObsGt0[q] = mp.nObs > 0;
-            memcpy(&s.jDesc[(size_t)q * 32], mp.desc, 32);
-        }
-        oslam_job_search_local_t j;
-        j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.jPw.data(); j.Pn = s.jPn.data(); j.maxDist = s.jMax.data();
-        j.minDist = s.jMin.data(); j.obs_gt0 = s.jObsGt0.data(); j.mp_desc = s.jDesc.data();
-        memcpy(j.Tcw, f.pose.Tcw.m, 64);
-        j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : 3.f;   // RGB-D th = 3 (:1450-1455)
-        j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;
-        lj.push_back(j); ljw.push_back(i);
-    }
+    for (int i : tracking) if (c.seq[i]->hasLoc) { lj.push_back(c.seq[i]->jLoc); ljw.push_back(i); }
     c.sec[4] += tm.lap();
     if (!lj.empty() && (rc = c.ops.search_local(c.ops.ctx, (int)lj.size(), lj.data()))) return rc;
     c.sec[3] += tm.lap();
-    pj.clear(); pjw.clear();
-    for (size_t q = 0; q < lj.size(); q++) {
+    pool.parallel_for((int)ljw.size(), [&](int q) {
         Seq& s = *c.seq[ljw[q]];
         Frame& f = *s.cur;
         for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.jLocalIds[e]].visible++;
         for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.jLocalIds[s.jMatch[k]];
-        pj.emplace_back();
-        fill_pose_job(c, s, ljw[q], pj.back());   // ObjectOptimizer::PoseOptimization2 (:1022) without matched objects
-        pjw.push_back(ljw[q]);
-    }
+        fill_pose_job(c, s, ljw[q], s.jPose);   // ObjectOptimizer::PoseOptimization2 (:1022) without matched objects
+    });
     c.sec[4] += tm.lap();
-    if (!pj.empty() && (rc = c.ops.pose_opt(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+    if ((rc = run_pose_jobs(c, ljw))) return rc;
     c.sec[2] += tm.lap();
-    for (size_t q = 0; q < pj.size(); q++) {
-        Seq& s = *c.seq[pjw[q]];
-        Frame& f = *s.cur;
-        M4 T; memcpy(T.m, pj[q].Tcw_out, 64);
-        f.pose.set_frame(T);
-        s.matchesInliers = 0;
-        for (int k = 0; k < f.N; k++) {
-            const int p = f.mp[k];
-            if (p < 0) continue;
-            f.outlier[k] = pj[q].outlier[k];
-            if (!f.outlier[k]) {
-                s.map.mps[p].found++;
-                if (s.map.mps[p].nObs > 0) s.matchesInliers++;
-            }
-        }
-        s.st[13] = s.matchesInliers;
-        if (f.id < s.lastRelocFrameId + c.maxFrames && s.matchesInliers < 50) s.ok = false;
-        else s.ok = s.matchesInliers >= 30;
-    }
+    pool.parallel_for((int)ljw.size(), [&](int q) { stage_after_local_pose(c, ljw[q]); });
     // ---------------- after tracking (:470-566) ----------------
+    pool.parallel_for(nT, [&](int q) { stage_after_tracking(c, tracking[q]); });
     std::vector<int> mapping;
-    upd.items.reserve(upd.items.size() + 256);
-    for (int i : tracking) {
-        Seq& s = *c.seq[i];
-        Frame& f = *s.cur; Frame& l = *s.last;
-        Map& m = s.map;
-        s.state = s.ok ? ST_OK : ST_LOST;
-        if (s.ok) {
-            if (l.pose.valid) { s.velocity = mul4(f.pose.Tcw, l.pose.Twc); s.hasVelocity = true; }
-            else s.hasVelocity = false;
-            for (int k = 0; k < f.N; k++) {   // clean VO matches
-                const int p = f.mp[k];
-                if (p >= 0 && m.mps[p].nObs < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
-            }
-            // NeedNewKeyFrame (:1242-1326) with an idle local mapper
-            bool need = false;
-            {
-                const int nKFs = m.nKFsInMap;
-                if (!(f.id < s.lastRelocFrameId + c.maxFrames && nKFs > c.maxFrames)) {
-                    const int nMinObs = nKFs <= 2 ? 2 : 3;
-                    const int nRefMatches = m.tracked_map_points(s.refKF, nMinObs);
-                    int nNonTrackedClose = 0, nTrackedClose = 0;
-                    for (int k = 0; k < f.N; k++)
-                        if (f.depth[k] > 0 && f.depth[k] < c.thDepth) {
-                            if (f.mp[k] >= 0 && !f.outlier[k]) nTrackedClose++;
-                            else nNonTrackedClose++;
-                        }
-                    const bool bNeedToInsertClose = (nTrackedClose < 100) && (nNonTrackedClose > 70);
-                    const float thRefRatio = nKFs < 2 ? 0.4f : 0.75f;
-                    const bool c1a = f.id >= s.lastKFFrameId + c.maxFrames;
-                    const bool c1b = f.id >= s.lastKFFrameId + c.minFrames;
-                    const bool c1c = s.matchesInliers < nRefMatches * 0.25 || bNeedToInsertClose;
-                    const bool c2 = (s.matchesInliers < nRefMatches * thRefRatio || bNeedToInsertClose) && s.matchesInliers > 15;
-                    need = (c1a || c1b || c1c) && c2;
-                }
-            }
-            if (need) {   // CreateNewKeyFrame (:1328-1406)
-                const int kf = new_keyframe(s, f);
-                s.refKF = kf; f.refKF = kf;
-                create_stereo_points(c, i, s, f, kf, false, upd);
-                s.newKFs.push_back(kf);
-                s.lastKFFrameId = f.id;
-                mapping.push_back(i);
-            }
-            for (int k = 0; k < f.N; k++)
-                if (f.mp[k] >= 0 && f.outlier[k]) f.mp[k] = -1;
-        } else {
-            s.st[8]++;
-        }
-        if (f.refKF < 0) f.refKF = s.refKF;
-    }
-    // first frame: keyframe 0 goes through local mapping too
+    MpUpdate upd;
     for (int i = 0; i < S; i++) {
         Seq& s = *c.seq[i];
-        if (!s.newKFs.empty() && std::find(mapping.begin(), mapping.end(), i) == mapping.end()) mapping.push_back(i);
+        if (!s.newKFs.empty()) mapping.push_back(i);
+        for (int p : s.updList) upd.add(i, p);
     }
-    std::sort(mapping.begin(), mapping.end());
     c.sec[4] += tm.lap();
     if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
     c.sec[5] += tm.lap();
@@ -1165,7 +1199,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
     return run_local_mapping(c, mapping);
 }
 
-// consistency of the observation graph (stats[15]): every observation points at a keypoint that points back
+
+// consistency of the observation graph (stats[15]): observation indices in range, Observations() = sum over the list, no observations on
+// bad points, no covisibility links to culled keyframes, spanning-tree parents alive
 static int64_t map_violations(const Map& m) {
     int64_t bad = 0;
     for (size_t p = 0; p < m.mps.size(); p++) {
@@ -1174,10 +1210,12 @@ static int64_t map_violations(const Map& m) {
         int n = 0;
         for (auto& e : mp.obs) {
             const KeyFrm& k = m.kfs[e.first];
-            if (e.second < 0 || e.second >= k.N || k.mp[e.second] != (int)p) bad++;
+            // (k.mp[idx] may legitimately differ from p: SearchForTriangulation never sets vbMatched2, reference src/ORBmatcher.cc:722, so two
+            // keypoints of the current keyframe can triangulate against the same neighbour keypoint and the second AddMapPoint wins)
+            if (e.second < 0 || e.second >= k.N) { bad++; continue; }
             n += k.uRight[e.second] >= 0 ? 2 : 1;
         }
-        if (n != mp.nObs) bad++;
+        if (n != mp.nObs) { bad++; if (getenv("OSLAM_SLAM_DEBUG")) fprintf(stderr, "violation: point %d nObs %d != %d\n", (int)p, mp.nObs, n); }
     }
     for (size_t k = 0; k < m.kfs.size(); k++) {
         const KeyFrm& kf = m.kfs[k];
@@ -1209,6 +1247,7 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
     c.thDepth = cfg->bf * cfg->thDepth / cfg->fx;   // src/Tracking.cc:159
     c.logScale = std::log(cfg->scaleFactor);
     c.maxFrames = (int)cfg->fps; c.minFrames = 0;
+    c.pool.reset(new Pool(cfg->host_threads > 1 ? cfg->host_threads : 1));
     for (int i = 0; i < c.S; i++) {
         c.seq.emplace_back(new Seq);
         c.seq.back()->fa.alloc(c.cap);

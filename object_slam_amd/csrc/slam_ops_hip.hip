@@ -1,11 +1,13 @@
 // slam_ops_hip.hip — the HIP operator table of the batch-of-sequences driver (include/oslam_slam.h): every stage of the
 // lockstep step becomes batch launches of the kernels behind oslam_hip.h.  Host glue only (the kernels live in the other
 // translation units).  No CPU fallback: creation fails without a HIP device.  Never includes oracle/.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
 #include "../../include/oslam_slam.h"
 #include "common.h"
+#include "slam_pool.h"
 
 namespace {
 
@@ -29,8 +31,55 @@ struct HipOps {
     // device-resident batch state of the current step
     uint8_t* d_gray = nullptr; float* d_depth = nullptr; size_t gray_pitch = 0;
     oslam_keypoint_t* d_keysUn = nullptr; float* d_uRight = nullptr; float* d_mvDepth = nullptr; int32_t* d_status = nullptr;
+    const oslam_keypoint_t* d_kp = nullptr; const uint8_t* d_desc = nullptr; const int32_t* d_cnt = nullptr;
     std::vector<oslam_proj_query_t> q;
     std::vector<int32_t> qm, qd;
+    // staging: one pinned upload block mirrored on the device, one pinned download block; a stage of the lockstep step is
+    // fill (parallel memcpy) -> ONE host-to-device copy -> batch kernels -> result copies -> ONE synchronisation -> scatter
+    uint8_t* up_h = nullptr; uint8_t* up_d = nullptr; size_t up_cap = 0;
+    uint8_t* dn_h = nullptr; size_t dn_cap = 0;
+    oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
+    oslam_drv::Pool* pool = nullptr;
+    int ensure_up(size_t bytes) {
+        if (bytes <= up_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (up_h) (void)hipHostFree(up_h);
+        if (up_d) (void)hipFree(up_d);
+        up_h = nullptr; up_d = nullptr; up_cap = 0;
+        const size_t ncap = bytes + bytes / 2 + 4096;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&up_h, ncap, 0));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&up_d, ncap));
+        up_cap = ncap;
+        return OSLAM_OK;
+    }
+    int ensure_dn(size_t bytes) {
+        if (bytes <= dn_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (dn_h) (void)hipHostFree(dn_h);
+        dn_h = nullptr; dn_cap = 0;
+        const size_t ncap = bytes + bytes / 2 + 4096;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&dn_h, ncap, 0));
+        dn_cap = ncap;
+        return OSLAM_OK;
+    }
+    int ensure_lq(size_t entries) {
+        if (entries <= lq_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (d_lq) (void)hipFree(d_lq);
+        if (d_inview) (void)hipFree(d_inview);
+        d_lq = nullptr; d_inview = nullptr; lq_cap = 0;
+        const size_t ncap = entries + entries / 2 + 1024;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&d_lq, ncap * sizeof(oslam_proj_query_t)));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&d_inview, ncap));
+        lq_cap = ncap;
+        return OSLAM_OK;
+    }
+};
+
+// bump layout of the staging blocks
+struct Layout {
+    size_t off = 0;
+    size_t take(size_t bytes) { const size_t at = off; off += oslam::align_up(bytes ? bytes : 1, 256); return at; }
 };
 
 #define OPS_CHECK(x) do { const int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -63,68 +112,193 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, nullptr));
     OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
                                                         o->d_mvDepth, o->d_status, nullptr));
-    std::vector<int32_t> cnt(n);
-    int32_t st[2] = {0, 0};
-    OSLAM_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, 4 * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(&st[0], d_st, 4, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(&st[1], o->d_status, 4, hipMemcpyDeviceToHost, nullptr));
+    o->d_kp = d_kp; o->d_desc = d_desc; o->d_cnt = d_cnt;
+    const size_t cap = o->cap;
+    Layout L;
+    const size_t oCnt = L.take(4 * (size_t)n), oSt = L.take(8), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * n), oKeysUn = L.take(sizeof(oslam_keypoint_t) * cap * n),
+                 oDesc = L.take(32 * cap * n), oUr = L.take(4 * cap * n), oDp = L.take(4 * cap * n);
+    OPS_CHECK(o->ensure_dn(L.off));
+    uint8_t* D = o->dn_h;
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, o->d_uRight, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, o->d_mvDepth, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
     OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    const int32_t* st = (const int32_t*)(D + oSt);
     if (st[0]) { oslam::set_error("extractor arena overflow"); return OSLAM_E_CAPACITY; }
     if (st[1]) { oslam::set_error("keypoint outside the depth image"); return OSLAM_E_INVALID; }
-    for (int i = 0; i < n; i++) {
+    const int32_t* cnt = (const int32_t*)(D + oCnt);
+    o->pool->parallel_for(n, [&](int i) {
         oslam_slam_frame_t* f = out[i];
-        const int N = cnt[i];
-        f->N = N;
-        const size_t at = (size_t)i * o->cap;
-        OSLAM_HIP_CHECK(hipMemcpyAsync(f->keys, d_kp + at, sizeof(oslam_keypoint_t) * N, hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(f->keysUn, o->d_keysUn + at, sizeof(oslam_keypoint_t) * N, hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(f->desc, d_desc + at * 32, (size_t)N * 32, hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(f->uRight, o->d_uRight + at, (size_t)N * 4, hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(f->depth, o->d_mvDepth + at, (size_t)N * 4, hipMemcpyDeviceToHost, nullptr));
-    }
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        const size_t N = cnt[i], at = (size_t)i * cap;
+        f->N = (int)N;
+        memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
+        memcpy(f->keysUn, D + oKeysUn + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
+        memcpy(f->desc, D + oDesc + at * 32, N * 32);
+        memcpy(f->uRight, D + oUr + at * 4, N * 4);
+        memcpy(f->depth, D + oDp + at * 4, N * 4);
+    });
     (void)slots;
     return OSLAM_OK;
 }
 
+static void frames_view(HipOps* o, oslam_match_frames_t& fr, const uint8_t* d_blocked) {
+    fr.keysUn = o->d_keysUn; fr.kp_stride = o->cap; fr.uRight = o->d_uRight; fr.desc = o->d_desc; fr.blocked = d_blocked;
+    fr.n_kps = o->d_cnt; fr.n_kps_const = 0;
+    fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
+}
+
+// ORBmatcher::SearchByProjection(Cur, Last) for the sequences in `jobs`: the current frames are still on the device (slot-major, from
+// frames_rgbd); the last frames' map-point arrays are uploaded slot-major (slots without a job get zero queries), then one projection
+// launch and one search launch cover all slots.
 int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     HipOps* o = (HipOps*)p;
-    for (int i = 0; i < n; i++) {
+    if (n == 0) return OSLAM_OK;
+    const size_t S = o->S, cap = o->cap;
+    Layout L;
+    const size_t oN = L.take(4 * S), oTc = L.take(64 * S), oTl = L.take(64 * S), oXw = L.take(12 * cap * S), oHas = L.take(cap * S),
+                 oKeys = L.take(sizeof(oslam_keypoint_t) * cap * S), oDesc = L.take(32 * cap * S);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    memset(U + oN, 0, 4 * S);
+    for (int i = 0; i < n; i++)
+        if (jobs[i].slot < 0 || jobs[i].slot >= (int)S || jobs[i].Nlast > (int)cap) { oslam::set_error("search_last: bad slot / size"); return OSLAM_E_INVALID; }
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_search_last_t& j = jobs[i];
+        const size_t b = j.slot, N = j.Nlast;
+        ((int32_t*)(U + oN))[b] = j.Nlast;
+        memcpy(U + oTc + 64 * b, j.Tcw, 64); memcpy(U + oTl + 64 * b, j.Tlw, 64);
+        memcpy(U + oXw + 12 * cap * b, j.Xw, 12 * N); memcpy(U + oHas + cap * b, j.has_mp, N);
+        memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * b, j.last_keysUn, sizeof(oslam_keypoint_t) * N);
+        memcpy(U + oDesc + 32 * cap * b, j.mp_desc, 32 * N);
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    uint8_t* Dv = o->up_d;
+    oslam_match_frames_t fr;
+    frames_view(o, fr, nullptr);
+    oslam_match_last_t la;
+    la.Xw = (const float*)(Dv + oXw); la.has_mp = Dv + oHas; la.keys = (const oslam_keypoint_t*)(Dv + oKeys); la.mp_desc = Dv + oDesc;
+    la.kp_stride = (int)cap; la.n_kps = (const int32_t*)(Dv + oN); la.n_kps_const = 0;
+    OPS_CHECK(oslam_match_project_last_batch_device(o->m_last, &la, (const float*)(Dv + oTc), (const float*)(Dv + oTl), &o->cam, &fr, o->scale, o->cfg.nLevels,
+                                                    jobs[0].th, 0, (int)S, nullptr));
+    const int32_t* d_km; const int32_t* d_nm; const int32_t* d_nq;
+    OPS_CHECK(oslam_match_results_device(o->m_last, nullptr, nullptr, &d_km, &d_nm, nullptr, &d_nq));
+    OPS_CHECK(oslam_match_search_batch_device(o->m_last, &fr, nullptr, (int)cap, d_nq, 0, (int)S, 0.9f, 0, 1, 100, nullptr));
+    Layout R;
+    const size_t rKm = R.take(4 * cap * S), rNm = R.take(4 * S);
+    OPS_CHECK(o->ensure_dn(R.off));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_last_t& j = jobs[i];
-        o->qm.resize(j.Nlast + 1); o->qd.resize(j.Nlast + 1);
-        OPS_CHECK(oslam_match_project_last_frame(o->m_last, j.cur->N, j.cur->keysUn, j.cur->uRight, j.cur->desc, nullptr, o->bounds, j.Nlast, j.Xw, j.has_mp,
-                                                 j.last_keysUn, j.mp_desc, j.Tcw, j.Tlw, &o->cam, o->scale, o->cfg.nLevels, j.th, 0, 1, o->qm.data(),
-                                                 o->qd.data(), j.kp_match, &j.nmatches));
-    }
+        memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
+        j.nmatches = ((const int32_t*)(o->dn_h + rNm))[j.slot];
+    });
     return OSLAM_OK;
 }
 
+// Tracking::SearchLocalPoints for the sequences in `jobs`: local points uploaded slot-major, ONE Frame::isInFrustum launch writes the
+// projection queries on the device, ONE windowed search launch consumes them; only the match table and the in-view flags come back.
 int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     HipOps* o = (HipOps*)p;
+    if (n == 0) return OSLAM_OK;
+    const size_t S = o->S, cap = o->cap;
+    int maxM = 0;
     for (int i = 0; i < n; i++) {
-        oslam_job_search_local_t& j = jobs[i];
-        for (int k = 0; k < j.cur->N; k++) j.kp_match[k] = -1;
-        j.nmatches = 0;
-        if (j.M == 0) continue;
-        if (j.M > o->max_local) { oslam::set_error("search_local: %d local points > capacity %d", j.M, o->max_local); return OSLAM_E_CAPACITY; }
-        o->q.resize(j.M); o->qm.resize(j.M); o->qd.resize(j.M);
-        OPS_CHECK(oslam_frame_is_in_frustum(o->mp, j.M, j.Pw, j.Pn, j.maxDist, j.minDist, j.obs_gt0, j.mp_desc, j.Tcw, o->K5, o->bounds, 0.5f, o->logScale,
-                                            o->scale, o->cfg.nLevels, j.th, o->q.data()));
-        int nin = 0;
-        for (int e = 0; e < j.M; e++) { j.in_view[e] = o->q[e].flags & 1; nin += j.in_view[e]; }
-        if (nin == 0) continue;
-        OPS_CHECK(oslam_match_search_by_projection(o->m_map, j.cur->N, j.cur->keysUn, j.cur->uRight, j.cur->desc, j.blocked, o->bounds, o->q.data(), j.M,
-                                                   0.8f, 1, 0, o->qm.data(), o->qd.data(), j.kp_match, &j.nmatches));
+        if (jobs[i].slot < 0 || jobs[i].slot >= (int)S) { oslam::set_error("search_local: bad slot"); return OSLAM_E_INVALID; }
+        if (jobs[i].M > o->max_local) { oslam::set_error("search_local: %d local points > capacity %d", jobs[i].M, o->max_local); return OSLAM_E_CAPACITY; }
+        maxM = std::max(maxM, jobs[i].M);
     }
+    const size_t st = oslam::align_up((size_t)std::max(maxM, 1), 64);
+    Layout L;
+    const size_t oM = L.take(4 * S), oTc = L.take(64 * S), oTh = L.take(4 * S), oBl = L.take(cap * S), oPw = L.take(12 * st * S), oPn = L.take(12 * st * S),
+                 oMax = L.take(4 * st * S), oMin = L.take(4 * st * S), oObs = L.take(st * S), oDesc = L.take(32 * st * S);
+    OPS_CHECK(o->ensure_up(L.off));
+    OPS_CHECK(o->ensure_lq(st * S));
+    uint8_t* U = o->up_h;
+    memset(U + oM, 0, 4 * S);
+    memset(U + oTh, 0, 4 * S);
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_search_local_t& j = jobs[i];
+        const size_t b = j.slot, M = j.M;
+        ((int32_t*)(U + oM))[b] = j.M;
+        ((float*)(U + oTh))[b] = j.th;
+        memcpy(U + oTc + 64 * b, j.Tcw, 64);
+        memcpy(U + oBl + cap * b, j.blocked, (size_t)j.cur->N);
+        memcpy(U + oPw + 12 * st * b, j.Pw, 12 * M); memcpy(U + oPn + 12 * st * b, j.Pn, 12 * M);
+        memcpy(U + oMax + 4 * st * b, j.maxDist, 4 * M); memcpy(U + oMin + 4 * st * b, j.minDist, 4 * M);
+        memcpy(U + oObs + st * b, j.obs_gt0, M); memcpy(U + oDesc + 32 * st * b, j.mp_desc, 32 * M);
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    uint8_t* Dv = o->up_d;
+    OPS_CHECK(oslam_frame_is_in_frustum_batch_device((int)S, (int)st, (const int32_t*)(Dv + oM), (const float*)(Dv + oPw), (const float*)(Dv + oPn),
+                                                     (const float*)(Dv + oMax), (const float*)(Dv + oMin), Dv + oObs, Dv + oDesc, (const float*)(Dv + oTc),
+                                                     (const float*)(Dv + oTh), o->K5, o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview,
+                                                     nullptr));
+    oslam_match_frames_t fr;
+    frames_view(o, fr, Dv + oBl);
+    OPS_CHECK(oslam_match_search_batch_device(o->m_map, &fr, o->d_lq, (int)st, (const int32_t*)(Dv + oM), 0, (int)S, 0.8f, 1, 0, 100, nullptr));
+    const int32_t* d_km; const int32_t* d_nm;
+    OPS_CHECK(oslam_match_results_device(o->m_map, nullptr, nullptr, &d_km, &d_nm, nullptr, nullptr));
+    Layout R;
+    const size_t rKm = R.take(4 * cap * S), rNm = R.take(4 * S), rIn = R.take(st * S);
+    OPS_CHECK(o->ensure_dn(R.off));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rIn, o->d_inview, st * S, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    o->pool->parallel_for(n, [&](int i) {
+        oslam_job_search_local_t& j = jobs[i];
+        memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
+        memcpy(j.in_view, o->dn_h + rIn + st * j.slot, (size_t)j.M);
+        j.nmatches = ((const int32_t*)(o->dn_h + rNm))[j.slot];
+    });
     return OSLAM_OK;
 }
 
+// Optimizer::PoseOptimization for n frames in one launch (one workgroup per frame).
 int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     HipOps* o = (HipOps*)p;
-    for (int i = 0; i < n; i++) {
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("pose_opt: n > n_sequences"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap, B = n;
+    for (int i = 0; i < n; i++) if (jobs[i].N > (int)cap) { oslam::set_error("pose_opt: N > capacity"); return OSLAM_E_CAPACITY; }
+    Layout L;
+    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_pose_t& j = jobs[i];
+        const size_t N = j.N;
+        ((int32_t*)(U + oN))[i] = j.N;
+        memcpy(U + oT + 64 * i, j.Tcw_in, 64);
+        memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
+        memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    uint8_t* Dv = o->up_d;
+    OPS_CHECK(oslam_pose_optimize_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), 0, (const float*)(Dv + oT), (const float*)(Dv + oXw),
+                                               (const float*)(Dv + oObs), (const float*)(Dv + oInv), Dv + oHas, o->K5, nullptr));
+    const float* d_T; const uint8_t* d_out; const int32_t* d_ni;
+    OPS_CHECK(oslam_poseopt_results_device(o->po, &d_T, &d_out, &d_ni, nullptr));
+    Layout R;
+    const size_t rT = R.take(64 * B), rO = R.take(cap * B), rN = R.take(4 * B);
+    OPS_CHECK(o->ensure_dn(R.off));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    o->pool->parallel_for(n, [&](int i) {
         oslam_job_pose_t& j = jobs[i];
-        OPS_CHECK(oslam_pose_optimize(o->po, j.N, j.Tcw_in, j.Xw, j.obs, j.invSigma2, j.has_mp, o->K5, j.Tcw_out, j.outlier, &j.n_inliers, nullptr));
-    }
+        memcpy(j.Tcw_out, o->dn_h + rT + 64 * i, 64);
+        memcpy(j.outlier, o->dn_h + rO + cap * i, (size_t)j.N);
+        j.n_inliers = ((const int32_t*)(o->dn_h + rN))[i];
+    });
     return OSLAM_OK;
 }
 
@@ -186,6 +360,10 @@ void h_destroy(void* p) {
     HipOps* o = (HipOps*)p;
     oslam_orb_destroy(o->orb); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
+    if (o->up_h) (void)hipHostFree(o->up_h);
+    if (o->dn_h) (void)hipHostFree(o->dn_h);
+    (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview);
+    delete o->pool;
     (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
     delete o;
 }
@@ -199,6 +377,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     }
     HipOps* o = new HipOps;
     o->cfg = *cfg; o->S = cfg->n_sequences;
+    o->pool = new oslam_drv::Pool(cfg->host_threads > 1 ? cfg->host_threads : 1);
     const int dev = cfg->device;
     int rc = oslam_orb_create(&o->orb, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
     if (!rc) {
