@@ -249,6 +249,18 @@ int oslam_match_search_for_triangulation(oslam_bow_t* h, const oslam_bow_side1_t
                                          const float* levelSigma2, int nlevels, int bOnlyStereo, int checkOri,
                                          int32_t* match12, int32_t* nmatches);
 
+/* Batch of independent pairs, one workgroup each in one launch (the batch-of-sequences layout).  triangulation == 0: SearchByBoW, match
+ * [s2.N]; != 0: SearchForTriangulation (bOnlyStereo = false), match [s1.N].  nmatches is written per job. */
+typedef struct oslam_bow_job {
+    oslam_bow_side1_t s1; oslam_bow_side2_t s2;
+    int32_t triangulation;
+    float nnratio; int32_t checkOri;
+    float F12[9]; float ex, ey;
+    int32_t* match;
+    int32_t nmatches;
+} oslam_bow_job_t;
+int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const float* scaleFactors, const float* levelSigma2, int nlevels);
+
 /* ------------------------------------------------------------------------------------------
  * Frame::ComputeStereoMatches (src/Frame.cc:706-880): row-band Hamming search of left keypoints in the
  * right image (levels +-1, u in [uL - bf/b, uL], best < (TH_HIGH+TH_LOW)/2), 11-shift 11x11 SAD on the
@@ -424,6 +436,11 @@ typedef struct oslam_tri_kf {
 int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* kf1, int nPairs, const oslam_tri_kf_t* kf2, const int32_t* pair_start,
                          const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
                          float ratioFactor /* 1.5f*mfScaleFactor */, uint8_t* ok /*[M]*/, float* x3D /*[M][3]*/, int32_t* nnew);
+
+/* Same numeric core for nPairs independent (current keyframe, neighbour) pairs, e.g. one pair per sequence of a batch: pair p = (kf1[p], kf2[p]). */
+int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const oslam_tri_kf_t* kf1, const oslam_tri_kf_t* kf2, const int32_t* pair_start,
+                               const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
+                               float ratioFactor, uint8_t* ok /*[M]*/, float* x3D /*[M][3]*/);
 
 /* ---------------- Frame construction between the extractor and the grid / matchers ----------------
  * Frame::UndistortKeyPoints (reference src/Frame.cc:644-675: cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK), OpenCV 3.2

@@ -105,14 +105,7 @@ typedef struct oslam_job_fuse {            /* search half of ORBmatcher::Fuse on
     int32_t* q_match;                      /* out [M] */
 } oslam_job_fuse_t;
 
-typedef struct oslam_job_bow {             /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657) */
-    oslam_bow_side1_t s1; oslam_bow_side2_t s2;
-    int32_t triangulation;                 /* 0: SearchByBoW nnratio 0.7 checkOri 1; 1: SearchForTriangulation nnratio 0.6 checkOri 0 */
-    float nnratio; int32_t checkOri;
-    float F12[9]; float ex, ey;
-    int32_t* match;                        /* out: SearchByBoW [s2.N] keyframe keypoint per frame keypoint; triangulation [s1.N] */
-    int32_t nmatches;
-} oslam_job_bow_t;
+typedef oslam_bow_job_t oslam_job_bow_t;   /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657), see oslam_hip.h */
 
 typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (current keyframe, neighbour) pair */
     oslam_tri_kf_t kf1, kf2; int32_t M; const int32_t* idx1; const int32_t* idx2;

@@ -37,7 +37,7 @@ __device__ __forceinline__ int bow_find_node(const BowCtx& c, uint32_t node) {
     return (lo < c.nNodes && c.nodes[lo] == node) ? lo : -1;
 }
 
-__global__ __launch_bounds__(kBowThreads) void k_search_bow(BowCtx c, int ncap) {
+__device__ __forceinline__ void bow_body(const BowCtx& c, const int ncap) {
     const int tid = threadIdx.x;
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_desc = (uint32_t*)smem;               // [ncap][8] side-2 descriptors
@@ -186,6 +186,10 @@ __global__ __launch_bounds__(kBowThreads) void k_search_bow(BowCtx c, int ncap) 
     if (tid == 0) *c.nmatches = s_nm;
 }
 
+__global__ __launch_bounds__(kBowThreads) void k_search_bow(BowCtx c, int ncap) { bow_body(c, ncap); }
+// one workgroup per pair; the contexts live in device memory
+__global__ __launch_bounds__(kBowThreads) void k_search_bow_batch(const BowCtx* cs, int ncap) { bow_body(cs[blockIdx.x], ncap); }
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -195,6 +199,7 @@ struct oslam_bow {
     size_t lds = 0;
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf q_idx1, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm;
+    uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;   // batch staging: pinned block mirrored on the device
 };
 
 static int bow_ensure(oslam_bow::Buf& b, size_t bytes) {
@@ -220,6 +225,8 @@ void oslam_bow_destroy(oslam_bow_t* h) {
                             &h->nodes, &h->start, &h->items, &h->out, &h->qbest, &h->nm};
     for (auto* b : bs)
         if (b->p) (void)hipFree(b->p);
+    if (h->st_h) (void)hipHostFree(h->st_h);
+    if (h->st_d) (void)hipFree(h->st_d);
     delete h;
 }
 
@@ -301,3 +308,95 @@ int oslam_match_search_for_triangulation(oslam_bow_t* h, const oslam_bow_side1_t
 }
 
 }  // extern "C"
+
+// Batch of independent pairs (SearchByBoW and / or SearchForTriangulation), one workgroup each in ONE launch: all inputs are packed into one
+// pinned block and reach the device in one copy; the results come back in one copy after one synchronisation.
+extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const float* scaleFactors, const float* levelSigma2, int nlevels) {
+    if (!h || n < 0 || (n > 0 && !jobs)) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (n == 0) return OSLAM_OK;
+    bool anyTri = false;
+    for (int i = 0; i < n; i++) anyTri = anyTri || jobs[i].triangulation;
+    if (anyTri && (!scaleFactors || !levelSigma2 || nlevels < 1 || nlevels > OSLAM_MAX_LEVELS)) { set_error("bad scale tables"); return OSLAM_E_INVALID; }
+    struct Off { size_t q_idx, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm; int nitems, nout; };
+    std::vector<Off> off(n);
+    size_t at = align_up(sizeof(BowCtx) * (size_t)n, 256);
+    auto take = [&](size_t bytes) { const size_t a = at; at += align_up(bytes ? bytes : 4, 256); return a; };
+    for (int i = 0; i < n; i++) {
+        const oslam_bow_side1_t& s1 = jobs[i].s1;
+        const oslam_bow_side2_t& s2 = jobs[i].s2;
+        if (!jobs[i].match || s1.N < 0 || s2.N < 0 || s1.nq < 0 || s2.nNodes < 0 || s2.N > h->max_kps || (s1.N > 0 && (!s1.keys || !s1.desc)) || (s2.N > 0 && (!s2.keys || !s2.desc)) ||
+            (s1.nq > 0 && (!s1.q_idx || !s1.q_node)) || (s2.nNodes > 0 && (!s2.nodes || !s2.start || !s2.items))) { set_error("bow batch: bad job %d", i); return OSLAM_E_INVALID; }
+        for (int q = 0; q < s1.nq; q++)
+            if (s1.q_idx[q] < 0 || s1.q_idx[q] >= s1.N) { set_error("side-1 index out of range"); return OSLAM_E_INVALID; }
+        const int nitems = s2.nNodes ? s2.start[s2.nNodes] : 0;
+        for (int k = 0; k < nitems; k++)
+            if (s2.items[k] < 0 || s2.items[k] >= s2.N) { set_error("side-2 index out of range"); return OSLAM_E_INVALID; }
+        for (int k = 1; k < s2.nNodes; k++)
+            if (!(s2.nodes[k - 1] < s2.nodes[k])) { set_error("side-2 node ids must be strictly ascending"); return OSLAM_E_INVALID; }
+        Off& o = off[i];
+        o.nitems = nitems; o.nout = jobs[i].triangulation ? s1.N : s2.N;
+        o.q_idx = take((size_t)s1.nq * 4); o.q_node = take((size_t)s1.nq * 4); o.keys1 = take((size_t)s1.N * sizeof(oslam_keypoint_t)); o.desc1 = take((size_t)s1.N * 32);
+        o.ur1 = take((size_t)s1.N * 4); o.flag1 = take((size_t)s1.N); o.keys2 = take((size_t)s2.N * sizeof(oslam_keypoint_t)); o.desc2 = take((size_t)s2.N * 32);
+        o.ur2 = take((size_t)s2.N * 4); o.mp2 = take((size_t)s2.N); o.nodes = take((size_t)s2.nNodes * 4); o.start = take((size_t)(s2.nNodes + 1) * 4);
+        o.items = take((size_t)nitems * 4);
+    }
+    const size_t in_bytes = at;
+    for (int i = 0; i < n; i++) { off[i].out = take((size_t)std::max(off[i].nout, 1) * 4); off[i].nm = take(4); }
+    const size_t io_bytes = at;
+    for (int i = 0; i < n; i++) off[i].qbest = take((size_t)std::max(jobs[i].s1.nq, 1) * 4);
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (at > h->st_cap) {
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (h->st_h) (void)hipHostFree(h->st_h);
+        if (h->st_d) (void)hipFree(h->st_d);
+        h->st_h = nullptr; h->st_d = nullptr; h->st_cap = 0;
+        const size_t ncap = at + at / 2;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->st_h, ncap, 0));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&h->st_d, ncap));
+        h->st_cap = ncap;
+    }
+    uint8_t* H = h->st_h;
+    uint8_t* D = h->st_d;
+    BowCtx* cs = (BowCtx*)H;
+    for (int i = 0; i < n; i++) {
+        const oslam_bow_job_t& j = jobs[i];
+        const oslam_bow_side1_t& s1 = j.s1;
+        const oslam_bow_side2_t& s2 = j.s2;
+        const Off& o = off[i];
+        memcpy(H + o.q_idx, s1.q_idx, (size_t)s1.nq * 4); memcpy(H + o.q_node, s1.q_node, (size_t)s1.nq * 4);
+        memcpy(H + o.keys1, s1.keys, (size_t)s1.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc1, s1.desc, (size_t)s1.N * 32);
+        if (s1.uRight) memcpy(H + o.ur1, s1.uRight, (size_t)s1.N * 4); else for (int k = 0; k < s1.N; k++) ((float*)(H + o.ur1))[k] = -1.0f;
+        if (s1.flag) memcpy(H + o.flag1, s1.flag, (size_t)s1.N); else memset(H + o.flag1, 0, (size_t)s1.N);
+        memcpy(H + o.keys2, s2.keys, (size_t)s2.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc2, s2.desc, (size_t)s2.N * 32);
+        if (s2.uRight) memcpy(H + o.ur2, s2.uRight, (size_t)s2.N * 4); else for (int k = 0; k < s2.N; k++) ((float*)(H + o.ur2))[k] = -1.0f;
+        if (s2.has_mp) memcpy(H + o.mp2, s2.has_mp, (size_t)s2.N); else memset(H + o.mp2, 0, (size_t)s2.N);
+        memcpy(H + o.nodes, s2.nodes, (size_t)s2.nNodes * 4);
+        if (s2.nNodes) memcpy(H + o.start, s2.start, (size_t)(s2.nNodes + 1) * 4); else *(int*)(H + o.start) = 0;
+        memcpy(H + o.items, s2.items, (size_t)o.nitems * 4);
+        BowCtx& c = cs[i];
+        memset(&c, 0, sizeof(c));
+        c.mode = j.triangulation ? 1 : 0; c.nq = s1.nq; c.q_idx1 = (const int*)(D + o.q_idx); c.q_node = (const uint32_t*)(D + o.q_node);
+        c.N1 = s1.N; c.keys1 = (const oslam_keypoint_t*)(D + o.keys1); c.desc1 = D + o.desc1; c.uRight1 = (const float*)(D + o.ur1); c.flag1 = D + o.flag1;
+        c.N2 = s2.N; c.keys2 = (const oslam_keypoint_t*)(D + o.keys2); c.desc2 = D + o.desc2; c.uRight2 = (const float*)(D + o.ur2); c.has_mp2 = D + o.mp2;
+        c.nNodes = s2.nNodes; c.nodes = (const uint32_t*)(D + o.nodes); c.start = (const int*)(D + o.start); c.items = (const int*)(D + o.items);
+        c.nnratio = j.nnratio; c.checkOri = j.checkOri; c.bOnlyStereo = 0;
+        for (int k = 0; k < 9; k++) c.F12[k] = j.F12[k];
+        c.ex = j.ex; c.ey = j.ey;
+        for (int k = 0; k < OSLAM_MAX_LEVELS; k++) {
+            c.scale[k] = (scaleFactors && k < nlevels) ? scaleFactors[k] : 0.f;
+            c.sigma2[k] = (levelSigma2 && k < nlevels) ? levelSigma2[k] : 0.f;
+        }
+        c.out = (int*)(D + o.out); c.nmatches = (int*)(D + o.nm); c.q_best = (int*)(D + o.qbest);
+    }
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_search_bow_batch, dim3(n), dim3(kBowThreads), h->lds, nullptr, (const BowCtx*)D, h->max_kps);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipMemcpyAsync(H + in_bytes, D + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < n; i++) {
+        jobs[i].nmatches = *(const int*)(H + off[i].nm);
+        if (jobs[i].nmatches < 0) { set_error("BoW matcher kernel rejected pair %d (capacity)", i); return OSLAM_E_CAPACITY; }
+        memcpy(jobs[i].match, H + off[i].out, (size_t)off[i].nout * 4);
+    }
+    return OSLAM_OK;
+}

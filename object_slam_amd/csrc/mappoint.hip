@@ -185,7 +185,7 @@ using namespace oslam;
 struct oslam_mappoint {
     int device = 0;
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf a, b, c, d, e, f, g, g2, o1, o2;
+    Buf a, b, c, d, e, e2, f, g, g2, o1, o2;
 };
 
 static int mp_ensure(oslam_mappoint::Buf& b, size_t bytes) {
@@ -207,7 +207,7 @@ extern "C" {
 
 void oslam_mappoint_destroy(oslam_mappoint_t* h) {
     if (!h) return;
-    oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->f, &h->g, &h->g2, &h->o1, &h->o2};
+    oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->e2, &h->f, &h->g, &h->g2, &h->o1, &h->o2};
     for (auto* b : bs)
         if (b->p) (void)hipFree(b->p);
     delete h;
@@ -344,6 +344,7 @@ struct TriKfDev {
 struct TriCtx {
     int M, nLevels;
     TriKfDev kf1;
+    const TriKfDev* kf1s;         // [nPairs] or NULL: one current keyframe (kf1) for all pairs
     const TriKfDev* kf2;          // [nPairs]
     const int* pair_of;           // [M]
     const int* idx1; const int* idx2;
@@ -471,7 +472,7 @@ __device__ __forceinline__ bool tri_unproject(const TriKfDev& kf, float rawx, fl
 __global__ __launch_bounds__(128) void k_triangulate(TriCtx c) {
     const int m = blockIdx.x * 128 + threadIdx.x;
     if (m >= c.M) return;
-    const TriKfDev& k1 = c.kf1;
+    const TriKfDev k1 = c.kf1s ? c.kf1s[c.pair_of[m]] : c.kf1;
     const TriKfDev k2 = c.kf2[c.pair_of[m]];
     const int i1 = k1.kp_off + c.idx1[m], i2 = k2.kp_off + c.idx2[m];
     const oslam_keypoint_t kp1 = c.keysUn[i1], kp2 = c.keysUn[i2];
@@ -604,6 +605,7 @@ extern "C" int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* k
     TriCtx c;
     c.M = M; c.nLevels = nLevels;
     fill(c.kf1, *kf1, 0);
+    c.kf1s = nullptr;
     c.kf2 = (const TriKfDev*)h->e.p; c.pair_of = (const int*)h->f.p; c.idx1 = (const int*)h->g.p; c.idx2 = (const int*)h->g2.p;
     c.keysUn = (const oslam_keypoint_t*)h->a.p; c.keys = (const oslam_keypoint_t*)h->b.p; c.uRight = (const float*)h->c.p; c.depth = (const float*)h->d.p;
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) { c.scale[i] = i < nLevels ? scaleFactors[i] : 1.f; c.sigma2[i] = i < nLevels ? levelSigma2[i] : 1.f; }
@@ -614,5 +616,66 @@ extern "C" int oslam_mp_triangulate(oslam_mappoint_t* h, const oslam_tri_kf_t* k
     OSLAM_HIP_CHECK(hipMemcpy(ok, h->o1.p, (size_t)M, hipMemcpyDeviceToHost));
     OSLAM_HIP_CHECK(hipMemcpy(x3D, h->o2.p, (size_t)M * 12, hipMemcpyDeviceToHost));
     if (nnew) { int n = 0; for (int m = 0; m < M; m++) n += ok[m]; *nnew = n; }
+    return OSLAM_OK;
+}
+
+// Batch form for several (current keyframe, neighbour) pairs that may belong to different maps: pair p = (kf1[p], kf2[p]).  Only the matched
+// keypoints travel: the kernel gathers through per-match rows (2m, 2m+1) of compact tables built here.
+extern "C" int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const oslam_tri_kf_t* kf1, const oslam_tri_kf_t* kf2, const int32_t* pair_start,
+                                          const int32_t* idx1, const int32_t* idx2, const float* scaleFactors, const float* levelSigma2, int nLevels,
+                                          float ratioFactor, uint8_t* ok, float* x3D) {
+    if (!h || nPairs < 0 || (nPairs > 0 && (!kf1 || !kf2 || !pair_start)) || !scaleFactors || !levelSigma2 || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS) {
+        set_error("bad argument");
+        return OSLAM_E_INVALID;
+    }
+    const int M = nPairs ? pair_start[nPairs] : 0;
+    if (M == 0) return OSLAM_OK;
+    if (M < 0 || !idx1 || !idx2 || !ok || !x3D || pair_start[0] != 0) { set_error("bad match table"); return OSLAM_E_INVALID; }
+    std::vector<int> pair_of(M), d1(M), d2(M);
+    std::vector<TriKfDev> dev1(nPairs), dev2(nPairs);
+    std::vector<oslam_keypoint_t> kun((size_t)2 * M), kraw((size_t)2 * M);
+    std::vector<float> ur((size_t)2 * M), dep((size_t)2 * M);
+    auto fill = [](TriKfDev& d, const oslam_tri_kf_t& k) {
+        for (int i = 0; i < 16; i++) { d.Tcw[i] = k.Tcw[i]; d.Twc[i] = k.Twc[i]; }
+        d.fx = k.fx; d.fy = k.fy; d.cx = k.cx; d.cy = k.cy; d.invfx = k.invfx; d.invfy = k.invfy; d.mbf = k.mbf; d.mb = k.mb;
+        d.kp_off = 0;
+    };
+    for (int p = 0; p < nPairs; p++) {
+        const oslam_tri_kf_t& a = kf1[p];
+        const oslam_tri_kf_t& b = kf2[p];
+        if (pair_start[p + 1] < pair_start[p]) { set_error("bad pair %d", p); return OSLAM_E_INVALID; }
+        fill(dev1[p], a); fill(dev2[p], b);
+        for (int m = pair_start[p]; m < pair_start[p + 1]; m++) {
+            if (idx1[m] < 0 || idx1[m] >= a.n_kps || idx2[m] < 0 || idx2[m] >= b.n_kps || !a.keysUn || !a.keys || !a.uRight || !a.depth || !b.keysUn || !b.keys ||
+                !b.uRight || !b.depth) { set_error("match %d: keypoint index out of range", m); return OSLAM_E_INVALID; }
+            const int o1 = a.keysUn[idx1[m]].octave, o2 = b.keysUn[idx2[m]].octave;
+            if (o1 < 0 || o1 >= nLevels || o2 < 0 || o2 >= nLevels) { set_error("match %d: octave out of range", m); return OSLAM_E_INVALID; }
+            pair_of[m] = p; d1[m] = 2 * m; d2[m] = 2 * m + 1;
+            kun[(size_t)2 * m] = a.keysUn[idx1[m]]; kraw[(size_t)2 * m] = a.keys[idx1[m]]; ur[(size_t)2 * m] = a.uRight[idx1[m]]; dep[(size_t)2 * m] = a.depth[idx1[m]];
+            kun[(size_t)2 * m + 1] = b.keysUn[idx2[m]]; kraw[(size_t)2 * m + 1] = b.keys[idx2[m]]; ur[(size_t)2 * m + 1] = b.uRight[idx2[m]]; dep[(size_t)2 * m + 1] = b.depth[idx2[m]];
+        }
+    }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    int rc;
+    const size_t total = (size_t)2 * M;
+    if ((rc = mp_up(h->a, kun.data(), total * sizeof(oslam_keypoint_t))) || (rc = mp_up(h->b, kraw.data(), total * sizeof(oslam_keypoint_t))) ||
+        (rc = mp_up(h->c, ur.data(), total * 4)) || (rc = mp_up(h->d, dep.data(), total * 4)) || (rc = mp_up(h->e, dev2.data(), dev2.size() * sizeof(TriKfDev))) ||
+        (rc = mp_up(h->e2, dev1.data(), dev1.size() * sizeof(TriKfDev))) || (rc = mp_up(h->f, pair_of.data(), (size_t)M * 4)) ||
+        (rc = mp_up(h->g, d1.data(), (size_t)M * 4)) || (rc = mp_up(h->g2, d2.data(), (size_t)M * 4)) || (rc = mp_ensure(h->o1, (size_t)M)) ||
+        (rc = mp_ensure(h->o2, (size_t)M * 12)))
+        return rc;
+    TriCtx c;
+    c.M = M; c.nLevels = nLevels;
+    fill(c.kf1, kf1[0]);
+    c.kf1s = (const TriKfDev*)h->e2.p;
+    c.kf2 = (const TriKfDev*)h->e.p; c.pair_of = (const int*)h->f.p; c.idx1 = (const int*)h->g.p; c.idx2 = (const int*)h->g2.p;
+    c.keysUn = (const oslam_keypoint_t*)h->a.p; c.keys = (const oslam_keypoint_t*)h->b.p; c.uRight = (const float*)h->c.p; c.depth = (const float*)h->d.p;
+    for (int i = 0; i < OSLAM_MAX_LEVELS; i++) { c.scale[i] = i < nLevels ? scaleFactors[i] : 1.f; c.sigma2[i] = i < nLevels ? levelSigma2[i] : 1.f; }
+    c.ratioFactor = ratioFactor;
+    c.ok = (uint8_t*)h->o1.p; c.x3D = (float*)h->o2.p;
+    hipLaunchKernelGGL(k_triangulate, dim3(div_up(M, 128)), dim3(128), 0, nullptr, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipMemcpy(ok, h->o1.p, (size_t)M, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(x3D, h->o2.p, (size_t)M * 12, hipMemcpyDeviceToHost));
     return OSLAM_OK;
 }

@@ -318,40 +318,72 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     return oslam_lba_optimize_batch(o->ba, n, pr, o->K5);   // one workgroup per window, one launch
 }
 
+// search half of ORBmatcher::Fuse for n (keyframe, candidate list) jobs in one launch (one workgroup per keyframe)
 int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
     HipOps* o = (HipOps*)p;
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("fuse: n > n_sequences"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap, B = n;
+    int maxM = 1;
     for (int i = 0; i < n; i++) {
-        oslam_job_fuse_t& j = jobs[i];
-        if (j.M > o->max_local) { oslam::set_error("fuse: %d queries > capacity %d", j.M, o->max_local); return OSLAM_E_CAPACITY; }
-        o->qd.resize(j.M + 1);
-        int32_t nf = 0;
-        OPS_CHECK(oslam_match_fuse_search(o->m_map, j.N, j.keysUn, j.uRight, j.desc, o->bounds, j.queries, j.M, o->invSigma2, o->cfg.nLevels, j.q_match,
-                                          o->qd.data(), &nf));
+        if (jobs[i].M > o->max_local || jobs[i].N > (int)cap) { oslam::set_error("fuse: %d queries / %d keypoints exceed capacity", jobs[i].M, jobs[i].N); return OSLAM_E_CAPACITY; }
+        maxM = std::max(maxM, jobs[i].M);
     }
+    const size_t st = oslam::align_up((size_t)maxM, 64);
+    Layout L;
+    const size_t oN = L.take(4 * B), oM = L.take(4 * B), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * B), oUr = L.take(4 * cap * B), oDesc = L.take(32 * cap * B),
+                 oQ = L.take(sizeof(oslam_proj_query_t) * st * B);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_fuse_t& j = jobs[i];
+        const size_t N = j.N, M = j.M;
+        ((int32_t*)(U + oN))[i] = j.N; ((int32_t*)(U + oM))[i] = j.M;
+        memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * i, j.keysUn, sizeof(oslam_keypoint_t) * N);
+        memcpy(U + oUr + 4 * cap * i, j.uRight, 4 * N); memcpy(U + oDesc + 32 * cap * i, j.desc, 32 * N);
+        memcpy(U + oQ + sizeof(oslam_proj_query_t) * st * i, j.queries, sizeof(oslam_proj_query_t) * M);
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    uint8_t* Dv = o->up_d;
+    oslam_match_frames_t fr;
+    fr.keysUn = (const oslam_keypoint_t*)(Dv + oKeys); fr.kp_stride = (int)cap; fr.uRight = (const float*)(Dv + oUr); fr.desc = Dv + oDesc; fr.blocked = nullptr;
+    fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
+    fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
+    OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels,
+                                            nullptr));
+    const int32_t* d_qm;
+    OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
+    OPS_CHECK(o->ensure_dn(4 * st * B));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
 }
 
 int h_bow(void* p, int n, oslam_job_bow_t* jobs) {
     HipOps* o = (HipOps*)p;
-    for (int i = 0; i < n; i++) {
-        oslam_job_bow_t& j = jobs[i];
-        if (!j.triangulation) OPS_CHECK(oslam_match_search_by_bow(o->bow, &j.s1, &j.s2, j.nnratio, j.checkOri, j.match, &j.nmatches));
-        else
-            OPS_CHECK(oslam_match_search_for_triangulation(o->bow, &j.s1, &j.s2, j.F12, j.ex, j.ey, o->scale, o->sigma2, o->cfg.nLevels, 0, j.checkOri, j.match,
-                                                           &j.nmatches));
-    }
-    return OSLAM_OK;
+    return oslam_match_bow_batch(o->bow, n, jobs, o->scale, o->sigma2, o->cfg.nLevels);
 }
 
 int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
     HipOps* o = (HipOps*)p;
+    std::vector<oslam_tri_kf_t> k1(n), k2(n);
+    std::vector<int32_t> ps(n + 1, 0), i1, i2;
     for (int i = 0; i < n; i++) {
-        oslam_job_triangulate_t& j = jobs[i];
-        if (j.M == 0) continue;
-        const int32_t ps[2] = {0, j.M};
-        int32_t nnew = 0;
-        OPS_CHECK(oslam_mp_triangulate(o->mp, &j.kf1, 1, &j.kf2, ps, j.idx1, j.idx2, o->scale, o->sigma2, o->cfg.nLevels, 1.5f * o->cfg.scaleFactor, j.ok, j.x3D,
-                                       &nnew));
+        k1[i] = jobs[i].kf1; k2[i] = jobs[i].kf2;
+        ps[i + 1] = ps[i] + jobs[i].M;
+        i1.insert(i1.end(), jobs[i].idx1, jobs[i].idx1 + jobs[i].M);
+        i2.insert(i2.end(), jobs[i].idx2, jobs[i].idx2 + jobs[i].M);
+    }
+    const int M = ps[n];
+    if (M == 0) return OSLAM_OK;
+    std::vector<uint8_t> ok(M);
+    std::vector<float> x3(3 * (size_t)M);
+    OPS_CHECK(oslam_mp_triangulate_pairs(o->mp, n, k1.data(), k2.data(), ps.data(), i1.data(), i2.data(), o->scale, o->sigma2, o->cfg.nLevels,
+                                         1.5f * o->cfg.scaleFactor, ok.data(), x3.data()));
+    for (int i = 0; i < n; i++) {
+        memcpy(jobs[i].ok, &ok[ps[i]], (size_t)jobs[i].M);
+        memcpy(jobs[i].x3D, &x3[3 * (size_t)ps[i]], 12 * (size_t)jobs[i].M);
     }
     return OSLAM_OK;
 }
