@@ -55,7 +55,35 @@ struct Timer {
     }
 };
 
+// flat FeatureVector views for the BoW matchers (see oslam_hip.h): side 1 = (node asc, index order) list, side 2 = CSR over node ids
+struct BowViews {
+    std::vector<int32_t> q_idx; std::vector<uint32_t> q_node;
+    std::vector<uint32_t> nodes; std::vector<int32_t> start, items;
+    void side1(const std::vector<uint32_t>& node) {
+        const int N = (int)node.size();
+        std::vector<std::pair<uint32_t, int>> v(N);
+        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
+        std::sort(v.begin(), v.end());
+        q_idx.resize(N); q_node.resize(N);
+        for (int i = 0; i < N; i++) { q_idx[i] = v[i].second; q_node[i] = v[i].first; }
+    }
+    void side2(const std::vector<uint32_t>& node) {
+        const int N = (int)node.size();
+        std::vector<std::pair<uint32_t, int>> v(N);
+        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
+        std::sort(v.begin(), v.end());
+        nodes.clear(); start.clear(); items.resize(N);
+        for (int i = 0; i < N; i++) {
+            if (i == 0 || v[i].first != v[i - 1].first) { nodes.push_back(v[i].first); start.push_back(i); }
+            items[i] = v[i].second;
+        }
+        start.push_back(N);
+    }
+};
+
 enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
+
+struct Ctx;
 
 // Per-sequence Tracking + LocalMapping state (include/Tracking.h, include/LocalMapping.h members).
 struct Seq {
@@ -86,6 +114,8 @@ struct Seq {
     oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
     bool hasSL = false, hasLoc = false;
     std::vector<int> updList;             // points created by tracking this step (descriptor / normal pending)
+    std::vector<std::unique_ptr<BowViews>> kfBow;   // FeatureVector views per keyframe id (built once: the descriptors are immutable)
+    BowViews& bow_views(const Ctx& c, int kf);
 };
 
 struct Ctx {
@@ -114,6 +144,18 @@ static void compute_bow(const Ctx& c, int N, const uint8_t* desc, std::vector<ui
     if (!out.empty()) return;   // Frame::ComputeBoW / KeyFrame::ComputeBoW: only once
     out.resize(N);
     for (int i = 0; i < N; i++) out[i] = c.voc.node(desc + (size_t)i * 32);
+}
+
+BowViews& Seq::bow_views(const Ctx& c, int kf) {
+    if ((int)kfBow.size() <= kf) kfBow.resize(kf + 1);
+    if (!kfBow[kf]) {
+        KeyFrm& k = map.kfs[kf];
+        compute_bow(c, k.N, k.desc.data(), k.bowNode);
+        kfBow[kf].reset(new BowViews);
+        kfBow[kf]->side1(k.bowNode);
+        kfBow[kf]->side2(k.bowNode);
+    }
+    return *kfBow[kf];
 }
 
 // Frame::UnprojectStereo (src/Frame.cc:904-919): mRwc*x3Dc + mOw (gemm small-matrix branch with C)
@@ -165,41 +207,50 @@ struct MpUpdate {
         const int P = (int)items.size();
         if (P == 0) return OSLAM_OK;
         start.assign(P + 1, 0);
-        odesc.clear(); oOw.clear();
-        pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
         for (int i = 0; i < P; i++) {
-            Map& m = c.seq[items[i].seq]->map;
-            const MapPt& p = m.mps[items[i].p];
-            int n = 0;
-            if (!p.bad)
-                for (auto& e : p.obs) {
-                    const KeyFrm& k = m.kfs[e.first];
-                    // ComputeDistinctiveDescriptors skips bad keyframes (src/MapPoint.cc:362-368), UpdateNormalAndDepth does not: a culled
-                    // keyframe has already erased its observations (KeyFrame::SetBadFlag), so both see the same list.
-                    odesc.insert(odesc.end(), k.desc.begin() + (size_t)e.second * 32, k.desc.begin() + (size_t)e.second * 32 + 32);
-                    oOw.insert(oOw.end(), k.pose.Ow, k.pose.Ow + 3);
-                    n++;
-                }
-            start[i + 1] = start[i] + n;
-            for (int d = 0; d < 3; d++) pos[(size_t)i * 3 + d] = p.pos[d];
-            float lf = 1.f;
-            const float* ow = p.pos;
-            if (n > 0 && p.refKF >= 0) {
-                const KeyFrm& rk = m.kfs[p.refKF];
-                const int idx = p.obs_index(p.refKF);
-                ow = rk.pose.Ow;
-                if (idx >= 0) lf = c.scale[rk.keysUn[idx].octave];
-            }
-            for (int d = 0; d < 3; d++) owref[(size_t)i * 3 + d] = ow[d];
-            lsf[i] = lf;
+            const MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
+            start[i + 1] = start[i] + (p.bad ? 0 : (int)p.obs.size());
         }
+        const size_t total = (size_t)start[P];
+        odesc.resize(std::max<size_t>(total, 1) * 32); oOw.resize(std::max<size_t>(total, 1) * 3);
+        pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
+        // ComputeDistinctiveDescriptors skips bad keyframes (src/MapPoint.cc:362-368), UpdateNormalAndDepth does not: a culled keyframe has
+        // already erased its observations (KeyFrame::SetBadFlag), so both see the same list.
+        const int chunk = 256, nchunks = (P + chunk - 1) / chunk;
+        c.pool->parallel_for(nchunks, [&](int ch) {
+            const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
+            for (int i = i0; i < i1; i++) {
+                const Map& m = c.seq[items[i].seq]->map;
+                const MapPt& p = m.mps[items[i].p];
+                const int n = start[i + 1] - start[i];
+                size_t at = (size_t)start[i];
+                if (n > 0)
+                    for (auto& e : p.obs) {
+                        const KeyFrm& k = m.kfs[e.first];
+                        memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
+                        oOw[at * 3] = k.pose.Ow[0]; oOw[at * 3 + 1] = k.pose.Ow[1]; oOw[at * 3 + 2] = k.pose.Ow[2];
+                        at++;
+                    }
+                for (int d = 0; d < 3; d++) pos[(size_t)i * 3 + d] = p.pos[d];
+                float lf = 1.f;
+                const float* ow = p.pos;
+                if (n > 0 && p.refKF >= 0) {
+                    const KeyFrm& rk = m.kfs[p.refKF];
+                    const int idx = p.obs_index(p.refKF);
+                    ow = rk.pose.Ow;
+                    if (idx >= 0) lf = c.scale[rk.keysUn[idx].octave];
+                }
+                for (int d = 0; d < 3; d++) owref[(size_t)i * 3 + d] = ow[d];
+                lsf[i] = lf;
+            }
+        });
         best.resize(P); outdesc.resize((size_t)P * 32); out5.resize((size_t)P * 5);
-        if (odesc.empty()) { odesc.resize(32); oOw.resize(3); }
         oslam_job_mp_update_t j;
         j.P = P; j.obs_start = start.data(); j.obs_desc = odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
         j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
         const int rc = c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
+        // (an item can be listed twice after fusions; both copies carry the same result)
         for (int i = 0; i < P; i++) {
             if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
             MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
@@ -343,32 +394,6 @@ static bool finish_initial_pose(Seq& s, const oslam_job_pose_t& j) {
     }
     return nmatchesMap >= 10;
 }
-
-// flat FeatureVector views for the BoW matchers (see oslam_hip.h): side 1 = (node asc, index order) list, side 2 = CSR over node ids
-struct BowViews {
-    std::vector<int32_t> q_idx; std::vector<uint32_t> q_node;
-    std::vector<uint32_t> nodes; std::vector<int32_t> start, items;
-    void side1(const std::vector<uint32_t>& node) {
-        const int N = (int)node.size();
-        std::vector<std::pair<uint32_t, int>> v(N);
-        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
-        std::sort(v.begin(), v.end());
-        q_idx.resize(N); q_node.resize(N);
-        for (int i = 0; i < N; i++) { q_idx[i] = v[i].second; q_node[i] = v[i].first; }
-    }
-    void side2(const std::vector<uint32_t>& node) {
-        const int N = (int)node.size();
-        std::vector<std::pair<uint32_t, int>> v(N);
-        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
-        std::sort(v.begin(), v.end());
-        nodes.clear(); start.clear(); items.resize(N);
-        for (int i = 0; i < N; i++) {
-            if (i == 0 || v[i].first != v[i - 1].first) { nodes.push_back(v[i].first); start.push_back(i); }
-            items[i] = v[i].second;
-        }
-        start.push_back(N);
-    }
-};
 
 // ------------------------------------------------------------------------------------------------------------------
 // Local mapping for the sequences that inserted a keyframe this step (LocalMapping::Run, src/LocalMapping.cc:48-113)
@@ -539,23 +564,23 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             neigh[w] = s.map.best_covisibles(s.curKF, 10);
             maxn = std::max(maxn, neigh[w].size());
         }
-        std::vector<BowViews> bv(who.size());
         std::vector<std::vector<uint8_t>> flag1(who.size()), has2(who.size());
         std::vector<std::vector<int32_t>> match(who.size());
         std::vector<oslam_job_bow_t> bj;
         std::vector<int> bjw;
         for (size_t ni = 0; ni < maxn; ni++) {
             bj.clear(); bjw.clear();
-            for (size_t w = 0; w < who.size(); w++) {
-                if (ni >= neigh[w].size()) continue;
+            std::vector<oslam_job_bow_t> cand(who.size());
+            std::vector<uint8_t> have(who.size(), 0);
+            pool.parallel_for(nW, [&](int w) {
+                if (ni >= neigh[w].size()) return;
                 Seq& s = *c.seq[who[w]];
                 Map& m = s.map;
                 const KeyFrm& k1 = m.kfs[s.curKF];
                 KeyFrm& k2 = m.kfs[neigh[w][ni]];
                 const float vb[3] = {k2.pose.Ow[0] - k1.pose.Ow[0], k2.pose.Ow[1] - k1.pose.Ow[1], k2.pose.Ow[2] - k1.pose.Ow[2]};
-                if (norm3(vb) < c.mb) continue;   // :251-254
-                compute_bow(c, k2.N, k2.desc.data(), k2.bowNode);
-                oslam_job_bow_t j;
+                if (norm3(vb) < c.mb) return;   // :251-254
+                oslam_job_bow_t& j = cand[w];
                 memset(&j, 0, sizeof(j));
                 compute_F12(c, k1, k2, j.F12);
                 // epipole of camera 1 in image 2 (src/ORBmatcher.cc:663-670)
@@ -568,18 +593,20 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
                 const float invz = 1.0f / C2[2];
                 j.ex = c.cfg.fx * C2[0] * invz + c.cfg.cx; j.ey = c.cfg.fy * C2[1] * invz + c.cfg.cy;
-                bv[w].side1(k1.bowNode); bv[w].side2(k2.bowNode);
+                const BowViews& v1 = s.bow_views(c, s.curKF);
+                const BowViews& v2 = s.bow_views(c, neigh[w][ni]);
                 flag1[w].resize(k1.N); has2[w].resize(k2.N);
                 for (int i = 0; i < k1.N; i++) flag1[w][i] = k1.mp[i] >= 0;
                 for (int i = 0; i < k2.N; i++) has2[w][i] = k2.mp[i] >= 0;
                 match[w].assign(k1.N, -1);
                 j.s1.N = k1.N; j.s1.keys = k1.keysUn.data(); j.s1.desc = k1.desc.data(); j.s1.uRight = k1.uRight.data(); j.s1.flag = flag1[w].data();
-                j.s1.nq = k1.N; j.s1.q_idx = bv[w].q_idx.data(); j.s1.q_node = bv[w].q_node.data();
+                j.s1.nq = k1.N; j.s1.q_idx = v1.q_idx.data(); j.s1.q_node = v1.q_node.data();
                 j.s2.N = k2.N; j.s2.keys = k2.keysUn.data(); j.s2.desc = k2.desc.data(); j.s2.uRight = k2.uRight.data(); j.s2.has_mp = has2[w].data();
-                j.s2.nNodes = (int)bv[w].nodes.size(); j.s2.nodes = bv[w].nodes.data(); j.s2.start = bv[w].start.data(); j.s2.items = bv[w].items.data();
+                j.s2.nNodes = (int)v2.nodes.size(); j.s2.nodes = v2.nodes.data(); j.s2.start = v2.start.data(); j.s2.items = v2.items.data();
                 j.triangulation = 1; j.nnratio = 0.6f; j.checkOri = 0; j.match = match[w].data();
-                bj.push_back(j); bjw.push_back((int)w);
-            }
+                have[w] = 1;
+            });
+            for (size_t w = 0; w < who.size(); w++) if (have[w]) { bj.push_back(cand[w]); bjw.push_back((int)w); }
             if (bj.empty()) continue;
             c.sec[7] += tm.lap();
             if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
@@ -1106,15 +1133,15 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
                 Frame& f = *s.cur;
                 KeyFrm& kf = s.map.kfs[s.refKF];
                 compute_bow(c, f.N, f.desc.data(), f.bowNode);
-                compute_bow(c, kf.N, kf.desc.data(), kf.bowNode);
-                bv[q].side1(kf.bowNode); bv[q].side2(f.bowNode);
+                const BowViews& vk = s.bow_views(c, s.refKF);
+                bv[q].side2(f.bowNode);
                 flag[q].resize(kf.N);
                 for (int k = 0; k < kf.N; k++) flag[q][k] = kf.mp[k] >= 0 && !s.map.mps[kf.mp[k]].bad;
                 match[q].assign(f.N + 1, -1);
                 oslam_job_bow_t& j = bj[q];
                 memset(&j, 0, sizeof(j));
                 j.s1.N = kf.N; j.s1.keys = kf.keysUn.data(); j.s1.desc = kf.desc.data(); j.s1.uRight = nullptr; j.s1.flag = flag[q].data();
-                j.s1.nq = kf.N; j.s1.q_idx = bv[q].q_idx.data(); j.s1.q_node = bv[q].q_node.data();
+                j.s1.nq = kf.N; j.s1.q_idx = vk.q_idx.data(); j.s1.q_node = vk.q_node.data();
                 j.s2.N = f.N; j.s2.keys = f.keysUn.data(); j.s2.desc = f.desc.data(); j.s2.uRight = nullptr; j.s2.has_mp = nullptr;
                 j.s2.nNodes = (int)bv[q].nodes.size(); j.s2.nodes = bv[q].nodes.data(); j.s2.start = bv[q].start.data(); j.s2.items = bv[q].items.data();
                 j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();

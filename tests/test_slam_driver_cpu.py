@@ -43,7 +43,7 @@ def test_driver_tracks_and_maps(oracle):
 def test_driver_is_deterministic_and_sequences_are_independent(oracle):
     n = 14
     streams = make_streams(2, n)
-    cfg2 = slam.make_config(W, H, 2)
+    cfg2 = slam.make_config(W, H, 2, host_threads=4)   # worker pool on: results must not depend on it
     s2 = slam.System(cfg2, oracle_ops(cfg2))
     p2, _ = run(s2, streams, n)
     for s in range(2):
