@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_functions():
-    txt = open(os.path.join(ROOT, "include", "oslam_hip.h")).read()
+    txt = open(os.path.join(ROOT, "include", "oslam_hip.h")).read() + open(os.path.join(ROOT, "include", "oslam_slam.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     names = re.findall(r"\b(oslam_[a-z0-9_]+)\s*\(", txt)
     return sorted(set(names))
