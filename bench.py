@@ -357,6 +357,43 @@ def main():
                 extras["slam_cpu_oracle_config"] = "same driver over the CPU oracle's operator table, 1 sequence x %d frames, 1 core" % NO
                 # same frames, same driver: the HIP trajectory of sequence 0 against the oracle's
                 extras["slam_hip_vs_oracle_max_abs_pose_diff"] = float(np.abs(np.array(s_poses[:NO]) - np.array(o_poses)).max())
+            # S3/S4 shape (BASELINE.json configs[3],[4]): KITTI-shaped rectified stereo, 1241x376, 2000 features, STEREO sensor, local BA on every keyframe
+            KW_, KH_, KD_, SK, NK, NKB = 1241, 376, 32, 32, 40, 4
+            kbase = [synth.make_stereo_stream(NK, KW_, KH_, seed=21 + s, margin=600, disparity=KD_) for s in range(NKB)]
+            kpitch = (KW_ + 63) // 64 * 64
+            d_kl = [torch.zeros((NK, KH_, kpitch), dtype=torch.uint8, device="cuda") for _ in range(NKB)]
+            d_kr = [torch.zeros((NK, KH_, kpitch), dtype=torch.uint8, device="cuda") for _ in range(NKB)]
+            for b_ in range(NKB):
+                d_kl[b_][:, :, :KW_] = torch.from_numpy(kbase[b_][0]).cuda()
+                d_kr[b_][:, :, :KW_] = torch.from_numpy(kbase[b_][1]).cuda()
+            kcfg = slam.make_config(KW_, KH_, SK, cam=slam.KITTI00, nFeatures=2000, sensor=slam.STEREO, device=local_rank, host_threads=min(16, os.cpu_count() or 1))
+            ksys = slam.System(kcfg)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for t in range(NK):
+                ksys.TrackStereo([d_kl[s % NKB][t].data_ptr() for s in range(SK)], [d_kr[s % NKB][t].data_ptr() for s in range(SK)], [t / 10.0] * SK,
+                                 on_device=True, stride=kpitch)
+            kdt = time.perf_counter() - t1
+            kst = ksys.stats(0)
+            _, kTwc = ksys.trajectory(0)
+            kz0 = kcfg.bf / KD_
+            koff = (kbase[0][2] - kbase[0][2][0]).astype(np.float64)
+            kgt = np.stack([koff[:, 0] * kz0 / kcfg.fx, koff[:, 1] * kz0 / kcfg.fy, np.zeros(len(koff))], 1)
+            extras["slam_stereo_batched_frames_per_s"] = round(SK * NK / kdt, 1)
+            extras["slam_stereo_batched_ate_rmse_m"] = round(e2e.horn_align_ate(kTwc[:, :, 3], kgt[:len(kTwc)]), 6)
+            extras["slam_stereo_batched_config"] = ("S3/S4 shape: %d KITTI-shaped stereo sequences x %d frames in lockstep, 1241x376, 2000 features, KITTI00-02.yaml calibration, "
+                                                    "plane at %.2f m; seq 0: %d keyframes, %d local BAs, %d lost frames" % (SK, NK, kz0, kst["keyframes_created"], kst["local_bas"], kst["lost_frames"]))
+            extras["slam_stereo_batched_stage_seconds"] = {k: round(v, 4) for k, v in ksys.stage_seconds().items()}
+            if not args.no_cpu_baseline:
+                kocfg = slam.make_config(KW_, KH_, 1, cam=slam.KITTI00, nFeatures=2000, sensor=slam.STEREO)
+                koops = slam.SlamOps()
+                assert O.lib().oo_slam_make_ops(C.byref(kocfg), C.byref(koops)) == 0
+                kosys = slam.System(kocfg, koops)
+                NKO = 12
+                t1 = time.perf_counter()
+                for t in range(NKO):
+                    kosys.TrackStereo([kbase[0][0][t]], [kbase[0][1][t]], [t / 10.0])
+                extras["slam_stereo_cpu_oracle_frames_per_s"] = round(NKO / (time.perf_counter() - t1), 2)
         except Exception as ex:   # never let the side measurements break the headline line
             extras = {"error": repr(ex)}
 

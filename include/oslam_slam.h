@@ -47,6 +47,7 @@ typedef struct oslam_slam_config {
     int32_t host_threads;        /* worker threads for the per-sequence bookkeeping (0 = 1) */
     int32_t local_mapping;       /* bit0 MapPointCulling, bit1 CreateNewMapPoints, bit2 SearchInNeighbors, bit3 LocalBundleAdjustment,
                                     bit4 KeyFrameCulling; 0x1F = the reference's LocalMapping::Run */
+    int32_t sensor;              /* System::eSensor (include/System.h:60-64): 1 STEREO, 2 RGBD; 0 = RGBD */
 } oslam_slam_config_t;
 
 #define OSLAM_SLAM_NOT_INITIALIZED 1   /* Tracking::eTrackingState, include/Tracking.h:91-97 */
@@ -133,6 +134,9 @@ typedef struct oslam_slam_ops {
     int (*bow)(void* ctx, int n, oslam_job_bow_t* jobs);
     int (*triangulate)(void* ctx, int n, oslam_job_triangulate_t* jobs);
     void (*destroy)(void* ctx);
+    /* Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): two ExtractORB + ComputeStereoMatches (:706-880); NULL if unsupported */
+    int (*frames_stereo)(void* ctx, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride,
+                         int on_device, oslam_slam_frame_t* const* out);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
@@ -146,6 +150,10 @@ void oslam_slam_destroy(oslam_slam_t* h);
  * pose), state_out [S] = mState after the frame. */
 int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch,
                           int on_device, const double* timestamps, float* Tcw_out, int32_t* state_out);
+
+/* System::TrackStereo (include/System.h:69) for every sequence (cfg.sensor = 1): rectified left / right images. */
+int oslam_slam_track_stereo(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                            const double* timestamps, float* Tcw_out, int32_t* state_out);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
  * Twc [n][12] = rows of [Rwc | twc]; lost frames are skipped like the reference.  Returns the count in *n_out (cap < n -> OSLAM_E_CAPACITY). */

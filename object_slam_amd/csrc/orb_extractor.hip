@@ -69,7 +69,7 @@ struct oslam_orb {
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
     int profiling = 0;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6], [7]: blur begin / end on its own stream
     double prof_ms[5] = {0, 0, 0, 0, 0};
     long long prof_batches = 0, prof_images = 0;
     bool prof_pending = false;
@@ -399,9 +399,12 @@ int oslam_orb_set_blur_rounding(oslam_orb_t* h, int sse2) {
 static int collect_profile(oslam_orb* h) {
     if (!h->prof_pending) return OSLAM_OK;
     OSLAM_HIP_CHECK(hipEventSynchronize(h->ev[5]));
+    // groups: 0 pyramid, 1 FAST, 2 blur (on its own stream, overlapping FAST + quad-tree exactly as in un-profiled runs), 3 quad-tree, 4 orientation + descriptors
+    const int a[5] = {0, 1, 6, 2, 4}, b[5] = {1, 2, 7, 3, 5};
+    OSLAM_HIP_CHECK(hipEventSynchronize(h->ev[7]));
     for (int i = 0; i < 5; i++) {
         float ms = 0;
-        OSLAM_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        OSLAM_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[a[i]], h->ev[b[i]]));
         h->prof_ms[i] += ms;
     }
     h->prof_batches++;
@@ -439,9 +442,9 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
     }
     PROF_MARK(1);
-    // The blur needs only the pyramid; FAST + quad-tree need only the pyramid too.  Outside profiling runs the blur goes
+    // The blur needs only the pyramid; FAST + quad-tree need only the pyramid too.  The blur goes
     // to a side stream and overlaps the (VALU-bound) FAST kernel and the (barrier-latency-bound) quad-tree kernel.
-    const bool overlap = !prof && h->side_stream != nullptr;
+    const bool overlap = h->side_stream != nullptr;
     hipStream_t sb = overlap ? h->side_stream : st;
     if (overlap) {
         OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork, st));
@@ -450,10 +453,12 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), batch), dim3(256), 0, st, c);
     if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
     PROF_MARK(2);
+    if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[6], sb));
     hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
     hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
-    PROF_MARK(3);
+    if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[7], sb));
     hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
+    PROF_MARK(3);
     if (overlap) {
         OSLAM_HIP_CHECK(hipEventRecord(h->ev_join, sb));
         OSLAM_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -539,7 +544,7 @@ int oslam_orb_set_profiling(oslam_orb_t* h, int on) {
     if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     if (on && !h->ev[0])
-        for (int i = 0; i < 6; i++) OSLAM_HIP_CHECK(hipEventCreate(&h->ev[i]));
+        for (int i = 0; i < 8; i++) OSLAM_HIP_CHECK(hipEventCreate(&h->ev[i]));
     h->profiling = on != 0;
     for (int i = 0; i < 5; i++) h->prof_ms[i] = 0;
     h->prof_batches = 0; h->prof_images = 0; h->prof_pending = false;

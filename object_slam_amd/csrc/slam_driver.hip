@@ -126,6 +126,7 @@ struct Ctx {
     float bounds[4];
     float invfx, invfy, thDepth, mb, logScale;
     int maxFrames, minFrames;
+    bool stereo = false;
     Vocab voc;
     std::vector<std::unique_ptr<Seq>> seq;
     std::unique_ptr<Pool> pool;
@@ -909,7 +910,7 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     oslam_job_search_last_t& j = s.jSL;
     j.slot = i; j.cur = &f.view; j.Nlast = NL; j.Xw = s.jXw.data(); j.has_mp = s.jHas.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data();
     memcpy(j.Tcw, f.pose.Tcw.m, 64); memcpy(j.Tlw, l.pose.Tcw.m, 64);
-    j.th = 15.f;   // RGB-D (:961-965)
+    j.th = c.stereo ? 7.f : 15.f;   // :961-965
     j.kp_match = s.jMatch.data(); j.nmatches = 0;
     s.hasSL = true;
 }
@@ -951,7 +952,7 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.jPw.data(); j.Pn = s.jPn.data(); j.maxDist = s.jMax.data();
     j.minDist = s.jMin.data(); j.obs_gt0 = s.jObsGt0.data(); j.mp_desc = s.jDesc.data();
     memcpy(j.Tcw, f.pose.Tcw.m, 64);
-    j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : 3.f;   // RGB-D th = 3 (:1450-1455)
+    j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : (c.stereo ? 1.f : 3.f);   // th = 1, RGB-D 3, after a relocalisation 5 (:1450-1455)
     j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;
     s.hasLoc = true;
 }
@@ -970,6 +971,8 @@ static void stage_after_local_pose(Ctx& c, int i) {
         if (!f.outlier[k]) {
             s.map.mps[p].found++;
             if (s.map.mps[p].nObs > 0) s.matchesInliers++;
+        } else if (c.stereo) {
+            f.mp[k] = -1;   // :1041-1042
         }
     }
     s.st[13] = s.matchesInliers;
@@ -1039,8 +1042,8 @@ static int run_pose_jobs(Ctx& c, const std::vector<int>& who) {
 // ------------------------------------------------------------------------------------------------------------------
 // One lockstep step of Tracking::Track for all sequences
 // ------------------------------------------------------------------------------------------------------------------
-static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
-                      const double* stamps, float* Tcw_out, int32_t* state_out) {
+static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* right, int gray_stride, const float* const* depth, int depth_pitch,
+                      int on_device, const double* stamps, float* Tcw_out, int32_t* state_out) {
     const int S = c.S;
     Timer tm;
     int rc;
@@ -1050,7 +1053,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
         std::vector<int32_t> slots(S);
         std::vector<oslam_slam_frame_t*> outs(S);
         for (int i = 0; i < S; i++) { slots[i] = i; outs[i] = &c.seq[i]->cur->view; }
-        if ((rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data()))) return rc;
+        if (right) rc = c.ops.frames_stereo(c.ops.ctx, S, slots.data(), gray, right, gray_stride, on_device, outs.data());
+        else rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data());
+        if (rc) return rc;
     }
     c.sec[0] += tm.lap();
     std::vector<int> tracking;   // sequences in the "system is initialised" branch
@@ -1091,7 +1096,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, int gray_stride, const
         std::vector<oslam_job_search_last_t> again;
         std::vector<size_t> againAt;
         for (size_t q = 0; q < sl.size(); q++)
-            if (sl[q].nmatches < 20) { sl[q].th = 30.f; again.push_back(sl[q]); againAt.push_back(q); }   // :969-973
+            if (sl[q].nmatches < 20) { sl[q].th = c.stereo ? 14.f : 30.f; again.push_back(sl[q]); againAt.push_back(q); }   // :969-973 (2*th)
         if (!again.empty()) {
             if ((rc = c.ops.search_last(c.ops.ctx, (int)again.size(), again.data()))) return rc;
             for (size_t q = 0; q < again.size(); q++) sl[againAt[q]].nmatches = again[q].nmatches;
@@ -1274,6 +1279,7 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
     c.thDepth = cfg->bf * cfg->thDepth / cfg->fx;   // src/Tracking.cc:159
     c.logScale = std::log(cfg->scaleFactor);
     c.maxFrames = (int)cfg->fps; c.minFrames = 0;
+    c.stereo = cfg->sensor == 1;
     c.pool.reset(new Pool(cfg->host_threads > 1 ? cfg->host_threads : 1));
     for (int i = 0; i < c.S; i++) {
         c.seq.emplace_back(new Seq);
@@ -1302,7 +1308,15 @@ void oslam_slam_destroy(oslam_slam_t* h) {
 int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch,
                           int on_device, const double* timestamps, float* Tcw_out, int32_t* state_out) {
     if (!h || !gray || !depth) { oslam::set_error("oslam_slam_track_rgbd: bad argument"); return OSLAM_E_INVALID; }
-    return track_step(h->c, gray, gray_stride, depth, depth_pitch, on_device, timestamps, Tcw_out, state_out);
+    if (h->c.stereo) { oslam::set_error("oslam_slam_track_rgbd on a STEREO handle"); return OSLAM_E_INVALID; }
+    return track_step(h->c, gray, nullptr, gray_stride, depth, depth_pitch, on_device, timestamps, Tcw_out, state_out);
+}
+
+int oslam_slam_track_stereo(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                            const double* timestamps, float* Tcw_out, int32_t* state_out) {
+    if (!h || !left || !right) { oslam::set_error("oslam_slam_track_stereo: bad argument"); return OSLAM_E_INVALID; }
+    if (!h->c.stereo || !h->c.ops.frames_stereo) { oslam::set_error("oslam_slam_track_stereo needs cfg.sensor = 1 (STEREO) and a stereo-capable operator table"); return OSLAM_E_INVALID; }
+    return track_step(h->c, left, right, gray_stride, nullptr, 0, on_device, timestamps, Tcw_out, state_out);
 }
 
 static void twc_rows(const M4& Tcw, float* o) {   // Rwc = Rcw.t(), twc = -Rwc*tcw (src/System.cc:423-424)

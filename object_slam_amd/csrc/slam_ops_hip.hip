@@ -15,6 +15,10 @@ struct HipOps {
     oslam_slam_config_t cfg;
     int S = 0, cap = 0;
     oslam_orb_t* orb = nullptr;
+    oslam_orb_t* orbR = nullptr;          // STEREO: right image extractor (src/Tracking.cc:145)
+    oslam_stereo_t* st = nullptr;
+    uint8_t* d_grayR = nullptr;
+    const float* cur_uRight = nullptr;    // mvuRight of the current batch on the device (RGB-D: d_uRight, STEREO: the stereo matcher's output)
     oslam_matcher_t* m_last = nullptr;
     oslam_matcher_t* m_map = nullptr;
     oslam_poseopt_t* po = nullptr;
@@ -93,6 +97,42 @@ int h_scale_tables(void* p, float* a, float* b, float* c, float* d) {
 }
 int h_image_bounds(void* p, float* b) { memcpy(b, ((HipOps*)p)->bounds, 16); return OSLAM_OK; }
 
+// keypoints / descriptors / stereo coordinates of the n frames just built: one pass of pinned copies, one synchronisation, parallel scatter
+static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const uint8_t* d_desc, const int32_t* d_cnt, const int32_t* d_st, const float* d_uR,
+                           const float* d_dp, oslam_slam_frame_t* const* out) {
+    o->d_kp = d_kp; o->d_desc = d_desc; o->d_cnt = d_cnt; o->cur_uRight = d_uR;
+    const size_t cap = o->cap;
+    Layout L;
+    const size_t oCnt = L.take(4 * (size_t)n), oSt = L.take(8), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * n), oKeysUn = L.take(sizeof(oslam_keypoint_t) * cap * n),
+                 oDesc = L.take(32 * cap * n), oUr = L.take(4 * cap * n), oDp = L.take(4 * cap * n);
+    OPS_CHECK(o->ensure_dn(L.off));
+    uint8_t* D = o->dn_h;
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, d_dp, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    const int32_t* st = (const int32_t*)(D + oSt);
+    if (st[0]) { oslam::set_error("extractor arena overflow"); return OSLAM_E_CAPACITY; }
+    if (st[1]) { oslam::set_error("keypoint outside the depth image / right extractor arena overflow"); return OSLAM_E_INVALID; }
+    const int32_t* cnt = (const int32_t*)(D + oCnt);
+    o->pool->parallel_for(n, [&](int i) {
+        oslam_slam_frame_t* f = out[i];
+        const size_t N = cnt[i], at = (size_t)i * cap;
+        f->N = (int)N;
+        memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
+        memcpy(f->keysUn, D + oKeysUn + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
+        memcpy(f->desc, D + oDesc + at * 32, N * 32);
+        memcpy(f->uRight, D + oUr + at * 4, N * 4);
+        memcpy(f->depth, D + oDp + at * 4, N * 4);
+    });
+    return OSLAM_OK;
+}
+
 // Frame::Frame (src/Frame.cc:117-172) for n frames: one batched extraction, one undistort launch, one depth lookup launch; the
 // keypoints / descriptors come back in one pass of copies after a single synchronisation.
 int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
@@ -112,42 +152,42 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, nullptr));
     OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
                                                         o->d_mvDepth, o->d_status, nullptr));
-    o->d_kp = d_kp; o->d_desc = d_desc; o->d_cnt = d_cnt;
-    const size_t cap = o->cap;
-    Layout L;
-    const size_t oCnt = L.take(4 * (size_t)n), oSt = L.take(8), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * n), oKeysUn = L.take(sizeof(oslam_keypoint_t) * cap * n),
-                 oDesc = L.take(32 * cap * n), oUr = L.take(4 * cap * n), oDp = L.take(4 * cap * n);
-    OPS_CHECK(o->ensure_dn(L.off));
-    uint8_t* D = o->dn_h;
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, o->d_uRight, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, o->d_mvDepth, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
-    const int32_t* st = (const int32_t*)(D + oSt);
-    if (st[0]) { oslam::set_error("extractor arena overflow"); return OSLAM_E_CAPACITY; }
-    if (st[1]) { oslam::set_error("keypoint outside the depth image"); return OSLAM_E_INVALID; }
-    const int32_t* cnt = (const int32_t*)(D + oCnt);
-    o->pool->parallel_for(n, [&](int i) {
-        oslam_slam_frame_t* f = out[i];
-        const size_t N = cnt[i], at = (size_t)i * cap;
-        f->N = (int)N;
-        memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
-        memcpy(f->keysUn, D + oKeysUn + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
-        memcpy(f->desc, D + oDesc + at * 32, N * 32);
-        memcpy(f->uRight, D + oUr + at * 4, N * 4);
-        memcpy(f->depth, D + oDp + at * 4, N * 4);
-    });
     (void)slots;
-    return OSLAM_OK;
+    return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out);
+}
+
+// Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): both images extracted as two batches, UndistortKeyPoints, then ONE
+// Frame::ComputeStereoMatches launch (one workgroup per pair) reading the two extractors' pyramids in HBM.
+int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                    oslam_slam_frame_t* const* out) {
+    HipOps* o = (HipOps*)p;
+    if (!o->orbR || !o->st) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
+    if (n > o->S) { oslam::set_error("frames_stereo: n > n_sequences"); return OSLAM_E_INVALID; }
+    const int W = o->cfg.width, H = o->cfg.height;
+    const size_t gimg = o->gray_pitch * H;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    for (int i = 0; i < n; i++) {
+        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, left[i], gray_stride, W, H, kind, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_grayR + gimg * i, o->gray_pitch, right[i], gray_stride, W, H, kind, nullptr));
+    }
+    OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, nullptr));
+    OPS_CHECK(oslam_orb_extract_batch_device(o->orbR, o->d_grayR, n, (int)o->gray_pitch, gimg, nullptr));
+    const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
+    const oslam_keypoint_t* d_kpR; const uint8_t* d_descR; const int32_t* d_cntR; const int32_t* d_stR;
+    OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
+    OPS_CHECK(oslam_orb_results_device(o->orbR, &d_kpR, &d_descR, &d_cntR, &d_stR));
+    OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, nullptr));
+    OPS_CHECK(oslam_stereo_match_batch_device(o->st, o->orb, o->orbR, n, o->cap, d_kp, d_desc, d_cnt, 0, d_kpR, d_descR, d_cntR, 0, o->cfg.nLevels, o->cfg.bf,
+                                              o->cfg.bf / o->cfg.fx, nullptr));
+    const float* d_uR; const float* d_dp;
+    OPS_CHECK(oslam_stereo_results_device(o->st, &d_uR, &d_dp, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_status, d_stR, 4, hipMemcpyDeviceToDevice, nullptr));   // right extractor's overflow flag rides in the second status word
+    (void)slots;
+    return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, d_uR, d_dp, out);
 }
 
 static void frames_view(HipOps* o, oslam_match_frames_t& fr, const uint8_t* d_blocked) {
-    fr.keysUn = o->d_keysUn; fr.kp_stride = o->cap; fr.uRight = o->d_uRight; fr.desc = o->d_desc; fr.blocked = d_blocked;
+    fr.keysUn = o->d_keysUn; fr.kp_stride = o->cap; fr.uRight = o->cur_uRight; fr.desc = o->d_desc; fr.blocked = d_blocked;
     fr.n_kps = o->d_cnt; fr.n_kps_const = 0;
     fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
 }
@@ -390,7 +430,7 @@ int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 
 void h_destroy(void* p) {
     HipOps* o = (HipOps*)p;
-    oslam_orb_destroy(o->orb); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
+    oslam_orb_destroy(o->orb); oslam_orb_destroy(o->orbR); oslam_stereo_destroy(o->st); (void)hipFree(o->d_grayR); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
     if (o->dn_h) (void)hipHostFree(o->dn_h);
@@ -418,6 +458,8 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         rc = oslam_matcher_create(&o->m_last, o->S, o->cap, o->cap, dev);
     }
     if (!rc) rc = oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, dev);
+    if (!rc && cfg->sensor == 1) rc = oslam_orb_create(&o->orbR, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
+    if (!rc && cfg->sensor == 1) rc = oslam_stereo_create(&o->st, o->S, o->cap, dev);
     if (!rc) rc = oslam_poseopt_create(&o->po, o->S, o->cap, dev);
     if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 32768, 262144, dev);
     if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 32768, 262144, dev);
@@ -435,6 +477,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         o->gray_pitch = oslam::align_up((size_t)cfg->width, 64);
         const size_t S = o->S;
         hipError_t e = hipMalloc((void**)&o->d_gray, o->gray_pitch * cfg->height * S);
+        if (e == hipSuccess && cfg->sensor == 1) e = hipMalloc((void**)&o->d_grayR, o->gray_pitch * cfg->height * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_depth, (size_t)cfg->width * cfg->height * 4 * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_keysUn, sizeof(oslam_keypoint_t) * o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_uRight, 4 * (size_t)o->cap * S);
@@ -447,6 +490,6 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->ctx = o;
     ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames;
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
-    ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy;
+    ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     return OSLAM_OK;
 }

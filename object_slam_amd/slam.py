@@ -16,23 +16,27 @@ class SlamConfig(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("dist", C.c_float * 5), ("ndist", C.c_int32), ("bf", C.c_float), ("thDepth", C.c_float), ("fps", C.c_float),
                 ("nFeatures", C.c_int32), ("scaleFactor", C.c_float), ("nLevels", C.c_int32), ("iniThFAST", C.c_int32), ("minThFAST", C.c_int32),
-                ("n_sequences", C.c_int32), ("device", C.c_int32), ("host_threads", C.c_int32), ("local_mapping", C.c_int32)]
+                ("n_sequences", C.c_int32), ("device", C.c_int32), ("host_threads", C.c_int32), ("local_mapping", C.c_int32), ("sensor", C.c_int32)]
 
 
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy")]
+        "triangulate", "destroy", "frames_stereo")]
 
 
 # reference Examples/RGB-D/TUM2.yaml (distortion left at zero: the synthetic streams are rendered without it)
 TUM2 = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, bf=40.0, thDepth=40.0, fps=30.0)
 
+# reference Examples/Stereo/KITTI00-02.yaml
+KITTI00 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, thDepth=35.0, fps=10.0)
+
 OK, LOST, NOT_INITIALIZED = 2, 3, 1
+STEREO, RGBD = 1, 2
 
 
 def make_config(width, height, n_sequences, cam=TUM2, dist=None, nFeatures=1000, scaleFactor=1.2, nLevels=8, iniThFAST=20, minThFAST=7, device=0,
-                host_threads=0, local_mapping=0x1F):
+                host_threads=0, local_mapping=0x1F, sensor=RGBD):
     c = SlamConfig()
     c.width, c.height = width, height
     c.fx, c.fy, c.cx, c.cy, c.bf, c.thDepth, c.fps = cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"], cam["thDepth"], cam["fps"]
@@ -41,7 +45,7 @@ def make_config(width, height, n_sequences, cam=TUM2, dist=None, nFeatures=1000,
             c.dist[i] = v
         c.ndist = len(dist)
     c.nFeatures, c.scaleFactor, c.nLevels, c.iniThFAST, c.minThFAST = nFeatures, scaleFactor, nLevels, iniThFAST, minThFAST
-    c.n_sequences, c.device, c.host_threads, c.local_mapping = n_sequences, device, host_threads, local_mapping
+    c.n_sequences, c.device, c.host_threads, c.local_mapping, c.sensor = n_sequences, device, host_threads, local_mapping, sensor
     return c
 
 
@@ -77,6 +81,23 @@ class System:
             ts = np.ascontiguousarray(timestamps, np.float64)
         check(self.L.oslam_slam_track_rgbd(self.h, self._gp, C.c_int(gray[0].strides[0]), self._dp, C.c_int(depth[0].strides[0] // 4), C.c_int(0),
                                            ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
+        return self.Tcw, self.state
+
+    def TrackStereo(self, left, right, timestamps=None, on_device=False, stride=None):
+        """left / right: S uint8 arrays [H, W] (or device addresses with on_device=True and the row stride in bytes)."""
+        if not hasattr(self, "_rp"):
+            self._rp = (C.c_void_p * self.S)()
+        for i in range(self.S):
+            if on_device:
+                self._gp[i], self._rp[i] = left[i], right[i]
+            else:
+                assert left[i].dtype == np.uint8 and right[i].dtype == np.uint8 and left[i].strides == right[i].strides
+                self._gp[i] = left[i].__array_interface__["data"][0]
+                self._rp[i] = right[i].__array_interface__["data"][0]
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        st = stride if on_device else left[0].strides[0]
+        check(self.L.oslam_slam_track_stereo(self.h, self._gp, self._rp, C.c_int(st), C.c_int(1 if on_device else 0),
+                                             ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
         return self.Tcw, self.state
 
     def TrackRGBD_device(self, gray_ptrs, gray_stride, depth_ptrs, depth_pitch, timestamps=None):

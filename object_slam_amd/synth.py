@@ -53,6 +53,20 @@ def make_stream(n_frames, width=640, height=480, seed=SEED, margin=96):
     return frames, np.stack([ox, oy], 1)
 
 
+def make_stereo_stream(n_frames, width=1241, height=376, seed=SEED, margin=96, disparity=32):
+    """Rectified stereo pair stream of the same fronto-parallel plane (SURVEY.md §8(d) S3 shape): the right camera sees every
+    point `disparity` pixels further left (uR = uL - disparity), i.e. its crop starts `disparity` columns to the right; the plane
+    depth is Z0 = bf / disparity.  Returns (left uint8 [n,h,w], right uint8 [n,h,w], offsets int64 [n,2])."""
+    canvas = make_canvas(width + margin + disparity, height + margin, seed)
+    ox, oy = stream_offsets(n_frames, margin, margin, seed)
+    left = np.empty((n_frames, height, width), np.uint8)
+    right = np.empty((n_frames, height, width), np.uint8)
+    for i in range(n_frames):
+        left[i] = canvas[oy[i]:oy[i] + height, ox[i]:ox[i] + width]
+        right[i] = canvas[oy[i]:oy[i] + height, ox[i] + disparity:ox[i] + disparity + width]
+    return left, right, np.stack([ox, oy], 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # Geometric problems for the optimisers (SURVEY.md §8(d) S5): no images needed.
 # ---------------------------------------------------------------------------------------------

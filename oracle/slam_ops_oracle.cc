@@ -38,6 +38,7 @@ int oo_search_by_bow(int, const int32_t*, const uint32_t*, const KeyPoint*, cons
 int oo_search_for_triangulation(int, const int32_t*, const uint32_t*, int, const KeyPoint*, const uint8_t*, const float*, const uint8_t*, int,
                                 const KeyPoint*, const uint8_t*, const float*, const uint8_t*, int, const uint32_t*, const int32_t*, const int32_t*,
                                 const float*, float, float, const float*, const float*, int, int, int*);
+void oo_stereo_matches(void*, void*, int, const KeyPoint*, const uint8_t*, int, const KeyPoint*, const uint8_t*, float, float, float*, float*);
 int oo_triangulate(const float*, const KeyPoint*, const KeyPoint*, const float*, const float*, const float*, const KeyPoint*, const KeyPoint*,
                    const float*, const float*, int, const int32_t*, const int32_t*, const float*, const float*, float, uint8_t*, float*);
 }
@@ -47,6 +48,7 @@ namespace {
 struct OCtx {
     oslam_slam_config_t cfg;
     void* orb;
+    void* orbR;
     int cap;
     float scale[16], invScale[16], sigma2[16], invSigma2[16];
     float bounds[4], K4[4], K5[5], K6[6];
@@ -72,6 +74,24 @@ int o_frames(void* p, int n, const int32_t*, const uint8_t* const* gray, int gra
         f->N = N;
         oo_undistort_keypoints(N, (const KeyPoint*)f->keys, o->K4, o->cfg.dist, o->cfg.ndist, (KeyPoint*)f->keysUn);
         oo_stereo_from_rgbd(N, (const KeyPoint*)f->keys, (const KeyPoint*)f->keysUn, depth[i], depth_pitch, o->cfg.bf, f->uRight, f->depth);
+    }
+    return 0;
+}
+
+int o_frames_stereo(void* p, int n, const int32_t*, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                    oslam_slam_frame_t* const* out) {
+    OCtx* o = (OCtx*)p;
+    if (on_device) return OSLAM_E_INVALID;
+    std::vector<KeyPoint> kr(o->cap);
+    std::vector<uint8_t> dr((size_t)o->cap * 32);
+    for (int i = 0; i < n; i++) {
+        oslam_slam_frame_t* f = out[i];
+        int N = 0, NR = 0;
+        if (oo_orb_extract(o->orb, left[i], o->cfg.width, o->cfg.height, gray_stride, (KeyPoint*)f->keys, f->desc, o->cap, &N)) return OSLAM_E_CAPACITY;
+        if (oo_orb_extract(o->orbR, right[i], o->cfg.width, o->cfg.height, gray_stride, kr.data(), dr.data(), o->cap, &NR)) return OSLAM_E_CAPACITY;
+        f->N = N;
+        oo_undistort_keypoints(N, (const KeyPoint*)f->keys, o->K4, o->cfg.dist, o->cfg.ndist, (KeyPoint*)f->keysUn);
+        oo_stereo_matches(o->orb, o->orbR, N, (const KeyPoint*)f->keys, f->desc, NR, kr.data(), dr.data(), o->cfg.bf, o->cfg.bf / o->cfg.fx, f->uRight, f->depth);
     }
     return 0;
 }
@@ -195,6 +215,7 @@ int o_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 void o_destroy(void* p) {
     OCtx* o = (OCtx*)p;
     oo_orb_destroy(o->orb);
+    oo_orb_destroy(o->orbR);
     delete o;
 }
 
@@ -204,6 +225,7 @@ extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t
     OCtx* o = new OCtx;
     o->cfg = *cfg;
     o->orb = oo_orb_create(cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST);
+    o->orbR = oo_orb_create(cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST);
     int nfeat[16], umax[16];
     oo_orb_tables(o->orb, o->scale, o->invScale, o->sigma2, o->invSigma2, nfeat, umax);
     o->cap = 0;
@@ -216,6 +238,6 @@ extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t
     ops->ctx = o;
     ops->max_keypoints = o_max_keypoints; ops->scale_tables = o_scale_tables; ops->image_bounds = o_image_bounds; ops->frames_rgbd = o_frames;
     ops->search_last = o_search_last; ops->search_local = o_search_local; ops->pose_opt = o_pose_opt; ops->mp_update = o_mp_update; ops->lba = o_lba;
-    ops->fuse = o_fuse; ops->bow = o_bow; ops->triangulate = o_triangulate; ops->destroy = o_destroy;
+    ops->fuse = o_fuse; ops->bow = o_bow; ops->triangulate = o_triangulate; ops->destroy = o_destroy; ops->frames_stereo = o_frames_stereo;
     return 0;
 }

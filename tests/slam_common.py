@@ -37,3 +37,32 @@ def ate(system, cfg, streams, s):
     off = (streams[s][1] - streams[s][1][0]).astype(np.float64)
     gt = np.stack([off[:, 0] * Z0 / cfg.fx, off[:, 1] * Z0 / cfg.fy, np.zeros(len(off))], 1)
     return horn_align_ate(Twc[:, :, 3], gt[:len(stamps)]), Twc
+
+
+KW, KH, KDISP = 1241, 376, 32
+
+
+def make_stereo_streams(S, n, margin=600, seed0=21):
+    return [synth.make_stereo_stream(n, KW, KH, seed=seed0 + s, margin=margin, disparity=KDISP) for s in range(S)]
+
+
+def stereo_config(S, **kw):
+    return slam.make_config(KW, KH, S, cam=slam.KITTI00, nFeatures=2000, iniThFAST=20, minThFAST=7, sensor=slam.STEREO, **kw)
+
+
+def run_stereo(system, streams, n):
+    S = len(streams)
+    poses, states = [], []
+    for t in range(n):
+        T, st = system.TrackStereo([streams[s][0][t] for s in range(S)], [streams[s][1][t] for s in range(S)], [t / 10.0] * S)
+        poses.append(T.copy())
+        states.append(st.copy())
+    return np.array(poses), np.array(states)
+
+
+def ate_stereo(system, cfg, streams, s):
+    z0 = cfg.bf / KDISP
+    stamps, Twc = system.trajectory(s)
+    off = (streams[s][2] - streams[s][2][0]).astype(np.float64)
+    gt = np.stack([off[:, 0] * z0 / cfg.fx, off[:, 1] * z0 / cfg.fy, np.zeros(len(off))], 1)
+    return horn_align_ate(Twc[:, :, 3], gt[:len(stamps)]), Twc

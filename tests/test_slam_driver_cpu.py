@@ -66,3 +66,19 @@ def test_local_mapping_switches(oracle):
     assert st["local_bas"] >= 1 and st["map_violations"] == 0
     a, _ = ate(sysm, cfg, streams, 0)
     assert a < 0.01
+
+
+def test_stereo_driver_kitti_shape(oracle):
+    """STEREO sensor on a KITTI-shaped pair stream (1241x376, 2000 features, KITTI00-02.yaml calibration): Frame::ComputeStereoMatches
+    feeds the same tracking / mapping flow with the stereo thresholds (th = 7 / 1, outliers dropped in TrackLocalMap)."""
+    from slam_common import ate_stereo, make_stereo_streams, run_stereo, stereo_config
+    n = 10
+    cfg = stereo_config(1)
+    streams = make_stereo_streams(1, n)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    poses, states = run_stereo(sysm, streams, n)
+    assert (states == slam.OK).all()
+    st = sysm.stats(0)
+    assert st["lost_frames"] == 0 and st["map_violations"] == 0 and st["points_created"] > 1000
+    a, _ = ate_stereo(sysm, cfg, streams, 0)
+    assert a < 0.05, a          # metres; plane at 12 m, 1.7 cm per pixel

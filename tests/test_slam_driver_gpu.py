@@ -48,3 +48,24 @@ def test_hip_driver_device_resident_inputs():
         T, st = dev.TrackRGBD_device([i.data_ptr() for i in imgs], W, [d_depth.data_ptr()] * S, W, [t / 30.0] * S)
         pd.append(T.copy())
     assert np.array_equal(np.array(pd), ph)
+
+
+def test_hip_stereo_driver_matches_oracle_driver(oracle):
+    from slam_common import ate_stereo, make_stereo_streams, run_stereo, stereo_config
+    n, S = 16, 2
+    streams = make_stereo_streams(S, n)
+    cfg = stereo_config(S)
+    hip = slam.System(cfg)
+    ph, sh = run_stereo(hip, streams, n)
+    cfg_o = stereo_config(S)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run_stereo(ora, streams, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    for s in range(S):
+        a, b = hip.stats(s), ora.stats(s)
+        assert a == b, (s, a, b)
+        assert a["map_violations"] == 0 and a["keyframes_created"] >= 2
+        ah, _ = ate_stereo(hip, cfg, streams, s)
+        assert ah < 0.05, ah
+    # 1e-4 relative on a scene at 12 m
+    assert np.abs(ph - po).max() < 2e-3, np.abs(ph - po).max()
