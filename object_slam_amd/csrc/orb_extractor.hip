@@ -66,6 +66,11 @@ struct oslam_orb {
     size_t oct_lds = 0;
     hipStream_t side_stream = nullptr;             // blur runs here, concurrently with FAST + quad-tree
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream = nullptr, aux_side_stream = nullptr;   // second half of a large batch (see launch_batch)
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
+    int split_min = 1 << 30;                       // batches of at least this many images are cut in two halves (off by default: measured +4 % frames/s at
+                                                   // B = 256, but the halves share the chip, so every kernel's own duration doubles; OSLAM_ORB_SPLIT_MIN enables it)
+    int prof_batch_images = 0;
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
     int profiling = 0;
@@ -120,6 +125,9 @@ void oslam_orb_destroy(oslam_orb_t* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+    if (h->aux_side_stream) (void)hipStreamDestroy(h->aux_side_stream);
+    for (hipEvent_t e : {h->ev_fork2, h->ev_join2, h->ev_fork3, h->ev_join3}) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -372,6 +380,12 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (getenv("OSLAM_ORB_SPLIT_MIN")) h->split_min = atoi(getenv("OSLAM_ORB_SPLIT_MIN"));   // kernel experiments
+    if (max_batch >= h->split_min) {
+        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_side_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&h->ev_fork2, &h->ev_join2, &h->ev_fork3, &h->ev_join3}) OSLAM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     *out = h;
     return OSLAM_OK;
 }
@@ -408,7 +422,7 @@ static int collect_profile(oslam_orb* h) {
         h->prof_ms[i] += ms;
     }
     h->prof_batches++;
-    h->prof_images += h->last_batch;
+    h->prof_images += h->prof_batch_images;
     h->prof_pending = false;
     return OSLAM_OK;
 }
@@ -429,47 +443,75 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         if (rc) return rc;
     }
     h->ctx = c; h->last_batch = batch; h->last_stream = st;
-#define PROF_MARK(i) do { if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[i], st)); } while (0)
-
-    PROF_MARK(0);
-    for (int l = 1; l < P.nlevels; l++) {
-        const LevelGeom& g = P.lv[l];
-        dim3 grid(div_up(g.w, 256), div_up(g.h, 4), batch);
-        dim3 gridw(div_up(g.w, 256), div_up(g.h, 4 * kResizeRows), batch);
-        // source rows 4-byte aligned? (levels >= 1 always; level 0 is the caller's buffer)
-        const bool src_aligned = l > 1 || (((stride & 3) == 0) && ((((uintptr_t)d_gray) & 3) == 0) && ((image_stride & 3) == 0));
-        if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, gridw, dim3(256), 0, st, c, l);
-        else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, c, l);
-    }
-    PROF_MARK(1);
-    // The blur needs only the pyramid; FAST + quad-tree need only the pyramid too.  The blur goes
-    // to a side stream and overlaps the (VALU-bound) FAST kernel and the (barrier-latency-bound) quad-tree kernel.
-    const bool overlap = h->side_stream != nullptr;
-    hipStream_t sb = overlap ? h->side_stream : st;
-    if (overlap) {
-        OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork, st));
-        OSLAM_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
-    }
-    hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), batch), dim3(256), 0, st, c);
-    if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, batch), dim3(256), 0, st, c);
-    PROF_MARK(2);
-    if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[6], sb));
-    hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
-    hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], batch), dim3(256), 0, sb, c, h->blur_sse2);
-    if (prof) OSLAM_HIP_CHECK(hipEventRecord(h->ev[7], sb));
-    hipLaunchKernelGGL(k_octree, dim3(P.nlevels, batch), dim3(kOctThreads), h->oct_lds, st, c);
-    PROF_MARK(3);
-    if (overlap) {
-        OSLAM_HIP_CHECK(hipEventRecord(h->ev_join, sb));
-        OSLAM_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join, 0));
-    }
-    PROF_MARK(4);
-    {
-        const int kpw = batch >= 32 ? 16 : (batch >= 8 ? 4 : 1);
-        hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4 * kpw), batch), dim3(256), 0, st, c, kpw);
-    }
-    PROF_MARK(5);
+    // One sub-batch = the whole kernel sequence for images [b0, b0 + nb) on a (main, blur) stream pair.  The blur needs only the pyramid and
+    // so do FAST + quad-tree: the blur goes to the pair's second stream and overlaps the (VALU-bound) FAST kernel and the
+    // (barrier-latency-bound) quad-tree kernel.  Large batches are cut in two halves on two stream pairs so that the kernels of one half
+    // (each bound by a different resource) overlap the kernels of the other; profiling events bracket the kernels of the first half.
+    auto issue = [&](const OrbCtx& cs, int nb, hipStream_t sm, hipStream_t sb, hipEvent_t fork, hipEvent_t join, bool pr) -> int {
+#define PROF_MARK(i) do { if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[i], sm)); } while (0)
+        PROF_MARK(0);
+        for (int l = 1; l < P.nlevels; l++) {
+            const LevelGeom& g = P.lv[l];
+            dim3 grid(div_up(g.w, 256), div_up(g.h, 4), nb);
+            dim3 gridw(div_up(g.w, 256), div_up(g.h, 4 * kResizeRows), nb);
+            // source rows 4-byte aligned? (levels >= 1 always; level 0 is the caller's buffer)
+            const bool src_aligned = l > 1 || (((stride & 3) == 0) && ((((uintptr_t)cs.img0) & 3) == 0) && ((image_stride & 3) == 0));
+            if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, gridw, dim3(256), 0, sm, cs, l);
+            else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, sm, cs, l);
+        }
+        PROF_MARK(1);
+        const bool overlap = sb != sm;
+        if (overlap) {
+            OSLAM_HIP_CHECK(hipEventRecord(fork, sm));
+            OSLAM_HIP_CHECK(hipStreamWaitEvent(sb, fork, 0));
+        }
+        hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), nb), dim3(256), 0, sm, cs);
+        if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, nb), dim3(256), 0, sm, cs);
+        PROF_MARK(2);
+        if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[6], sb));
+        hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], nb), dim3(256), 0, sb, cs, h->blur_sse2);
+        hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], nb), dim3(256), 0, sb, cs, h->blur_sse2);
+        if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[7], sb));
+        hipLaunchKernelGGL(k_octree, dim3(P.nlevels, nb), dim3(kOctThreads), h->oct_lds, sm, cs);
+        PROF_MARK(3);
+        if (overlap) {
+            OSLAM_HIP_CHECK(hipEventRecord(join, sb));
+            OSLAM_HIP_CHECK(hipStreamWaitEvent(sm, join, 0));
+        }
+        PROF_MARK(4);
+        {
+            const int kpw = nb >= 32 ? 16 : (nb >= 8 ? 4 : 1);
+            hipLaunchKernelGGL(k_orient_describe, dim3(div_up(P.out_cap, 4 * kpw), nb), dim3(256), 0, sm, cs, kpw);
+        }
+        PROF_MARK(5);
 #undef PROF_MARK
+        return OSLAM_OK;
+    };
+    auto sub_ctx = [&](int b0) {
+        OrbCtx cs = c;
+        const long long o = b0;
+        cs.img0 += o * c.img0_stride; cs.pyr += o * c.pyr_stride; cs.blur += o * c.blur_stride;
+        cs.cell_count += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
+        cs.sel += o * P.sel_per_image; cs.sel_count += o * P.nlevels;
+        cs.out_kp += o * P.out_cap; cs.out_desc += o * P.out_cap * 32; cs.out_count += o;
+        return cs;
+    };
+    int rc;
+    const bool split = batch >= h->split_min && h->aux_stream != nullptr;
+    if (!split) {
+        rc = issue(c, batch, st, h->side_stream ? h->side_stream : st, h->ev_fork, h->ev_join, prof);
+        if (rc) return rc;
+        h->prof_batch_images = batch;
+    } else {
+        const int nb0 = batch / 2, nb1 = batch - nb0;
+        OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork2, st));
+        OSLAM_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_fork2, 0));
+        if ((rc = issue(c, nb0, st, h->side_stream, h->ev_fork, h->ev_join, prof))) return rc;
+        if ((rc = issue(sub_ctx(nb0), nb1, h->aux_stream, h->aux_side_stream, h->ev_fork3, h->ev_join3, false))) return rc;
+        OSLAM_HIP_CHECK(hipEventRecord(h->ev_join2, h->aux_stream));
+        OSLAM_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join2, 0));
+        h->prof_batch_images = nb0;
+    }
     if (prof) h->prof_pending = true;
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;

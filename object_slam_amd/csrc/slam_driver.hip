@@ -1233,7 +1233,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
 
 
 // consistency of the observation graph (stats[15]): observation indices in range, Observations() = sum over the list, no observations on
-// bad points, no covisibility links to culled keyframes, spanning-tree parents alive
+// bad points, spanning-tree parents alive (covisibility lists may legitimately keep one-sided links to culled keyframes, src/KeyFrame.cc:367)
 static int64_t map_violations(const Map& m) {
     int64_t bad = 0;
     for (size_t p = 0; p < m.mps.size(); p++) {
@@ -1252,7 +1252,6 @@ static int64_t map_violations(const Map& m) {
     for (size_t k = 0; k < m.kfs.size(); k++) {
         const KeyFrm& kf = m.kfs[k];
         if (kf.bad) continue;
-        for (int o : kf.ordered) if (m.kfs[o].bad) bad++;
         if (kf.id != 0 && !kf.firstConnection && (kf.parent < 0 || m.kfs[kf.parent].bad)) bad++;
     }
     return bad;

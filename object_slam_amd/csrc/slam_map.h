@@ -286,7 +286,8 @@ struct Map {
     }
     void set_bad_keyframe(int k) {                   // :453-545 (mbNotErase is only set by the loop closer: never here)
         KeyFrm& f = kfs[k];
-        if (f.id == 0 || f.bad) return;
+        if (f.id == 0) return;
+        const bool first = !f.bad;   // KeyFrameCulling can reach a culled keyframe again through a stale one-sided link; the reference then repeats the body
         for (auto& e : f.connW) erase_connection(e.first, k);
         for (int i = 0; i < f.N; i++)
             if (f.mp[i] >= 0) erase_observation(f.mp[i], k);
@@ -315,7 +316,7 @@ struct Map {
         kfs[f.parent].children.erase(k);
         f.Tcp = mul4(f.pose.Tcw, kfs[f.parent].pose.Twc);
         f.bad = true;
-        nKFsInMap--; nCulledKF++;
+        if (first) { nKFsInMap--; nCulledKF++; }
     }
 };
 

@@ -82,3 +82,15 @@ def test_stereo_driver_kitti_shape(oracle):
     assert st["lost_frames"] == 0 and st["map_violations"] == 0 and st["points_created"] > 1000
     a, _ = ate_stereo(sysm, cfg, streams, 0)
     assert a < 0.05, a          # metres; plane at 12 m, 1.7 cm per pixel
+
+
+def test_map_bookkeeping_unit_checks(tmp_path):
+    """tests/slam_map_check.cc: covisibility weights / ordering, spanning tree, Observations() accounting, EraseObservation, Replace and
+    KeyFrame::SetBadFlag of csrc/slam_map.h on a hand-built map (host C++, no GPU, no oracle)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "slam_map_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(here, "slam_map_check.cc"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
