@@ -313,30 +313,42 @@ def main():
             # batch-of-sequences tracking + local mapping (include/oslam_slam.h): S sequences in lockstep on this GPU, images resident in HBM
             import ctypes as C
             from object_slam_amd import slam
-            SB, NF, NBASE = 64, 60, 8
+            import threading
+            SB, NF, NBASE, NG = 256, 60, 8, 4
+            SG = SB // NG
             base = [synth.make_stream(NF, W, H, seed=11 + s, margin=1200) for s in range(NBASE)]
             d_base = [torch.from_numpy(b[0]).cuda() for b in base]
             d_depth = torch.full((H, W), Z0, dtype=torch.float32, device="cuda")
-            scfg = slam.make_config(W, H, SB, device=local_rank, host_threads=min(16, os.cpu_count() or 1))
-            ssys = slam.System(scfg)
-            dptr = [d_depth.data_ptr()] * SB
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            nthr = max(1, min(16, os.cpu_count() or 1) // NG)
+            groups = [slam.System(slam.make_config(W, H, SG, device=local_rank, host_threads=nthr)) for _ in range(NG)]
             s_poses = []
-            for t in range(NF):
-                Tb, _ = ssys.TrackRGBD_device([d_base[s % NBASE][t].data_ptr() for s in range(SB)], W, dptr, W, [t / 30.0] * SB)
-                s_poses.append(Tb[0].copy())
+            torch.cuda.synchronize()
+
+            def _drive(g):   # one host thread per handle: the bookkeeping of one group overlaps the kernels of the others (each handle has its own stream)
+                dptr = [d_depth.data_ptr()] * SG
+                for t in range(NF):
+                    Tb, _ = groups[g].TrackRGBD_device([d_base[(g * SG + s) % NBASE][t].data_ptr() for s in range(SG)], W, dptr, W, [t / 30.0] * SG)
+                    if g == 0:
+                        s_poses.append(Tb[0].copy())
+
+            t1 = time.perf_counter()
+            ths = [threading.Thread(target=_drive, args=(g,)) for g in range(NG)]
+            for th_ in ths:
+                th_.start()
+            for th_ in ths:
+                th_.join()
             sdt = time.perf_counter() - t1
+            ssys = groups[0]
             sst = ssys.stats(0)
             _, sTwc = ssys.trajectory(0)
             off = (base[0][1] - base[0][1][0]).astype(np.float64)
             sgt = np.stack([off[:, 0] * Z0 / FX, off[:, 1] * Z0 / FY, np.zeros(len(off))], 1)
             extras["slam_batched_frames_per_s"] = round(SB * NF / sdt, 1)
             extras["slam_batched_ate_rmse_m"] = round(e2e.horn_align_ate(sTwc[:, :, 3], sgt[:len(sTwc)]), 6)
-            extras["slam_batched_config"] = ("oslam_slam driver (Tracking::Track + LocalMapping::Run control flow), %d sequences x %d frames in lockstep, "
-                                             "640x480 RGB-D synthetic, images in HBM, %d host threads; seq 0: %d keyframes, %d local BAs, %d points fused, %d culled"
-                                             % (SB, NF, scfg.host_threads, sst["keyframes_created"], sst["local_bas"], sst["points_fused"], sst["points_culled"]))
-            extras["slam_batched_stage_seconds"] = {k: round(v, 4) for k, v in ssys.stage_seconds().items()}
+            extras["slam_batched_config"] = ("oslam_slam driver (Tracking::Track + LocalMapping::Run control flow), %d sequences x %d frames: %d handles of %d sequences in lockstep, "
+                                             "one host thread + %d workers per handle, 640x480 RGB-D synthetic, images in HBM; seq 0: %d keyframes, %d local BAs, %d points fused, %d culled"
+                                             % (SB, NF, NG, SG, nthr, sst["keyframes_created"], sst["local_bas"], sst["points_fused"], sst["points_culled"]))
+            extras["slam_batched_stage_seconds_handle0"] = {k: round(v, 4) for k, v in ssys.stage_seconds().items()}
             if not args.no_cpu_baseline:
                 from oracle import oracle_py as O
                 ocfg = slam.make_config(W, H, 1)
@@ -358,7 +370,7 @@ def main():
                 # same frames, same driver: the HIP trajectory of sequence 0 against the oracle's
                 extras["slam_hip_vs_oracle_max_abs_pose_diff"] = float(np.abs(np.array(s_poses[:NO]) - np.array(o_poses)).max())
             # S3/S4 shape (BASELINE.json configs[3],[4]): KITTI-shaped rectified stereo, 1241x376, 2000 features, STEREO sensor, local BA on every keyframe
-            KW_, KH_, KD_, SK, NK, NKB = 1241, 376, 32, 32, 40, 4
+            KW_, KH_, KD_, SK, NK, NKB = 1241, 376, 32, 64, 40, 4
             kbase = [synth.make_stereo_stream(NK, KW_, KH_, seed=21 + s, margin=600, disparity=KD_) for s in range(NKB)]
             kpitch = (KW_ + 63) // 64 * 64
             d_kl = [torch.zeros((NK, KH_, kpitch), dtype=torch.uint8, device="cuda") for _ in range(NKB)]
@@ -366,14 +378,26 @@ def main():
             for b_ in range(NKB):
                 d_kl[b_][:, :, :KW_] = torch.from_numpy(kbase[b_][0]).cuda()
                 d_kr[b_][:, :, :KW_] = torch.from_numpy(kbase[b_][1]).cuda()
-            kcfg = slam.make_config(KW_, KH_, SK, cam=slam.KITTI00, nFeatures=2000, sensor=slam.STEREO, device=local_rank, host_threads=min(16, os.cpu_count() or 1))
-            ksys = slam.System(kcfg)
+            KG = 2
+            SKG = SK // KG
+            kthr = max(1, min(16, os.cpu_count() or 1) // KG)
+            kgroups = [slam.System(slam.make_config(KW_, KH_, SKG, cam=slam.KITTI00, nFeatures=2000, sensor=slam.STEREO, device=local_rank, host_threads=kthr)) for _ in range(KG)]
+            kcfg = kgroups[0].cfg
             torch.cuda.synchronize()
+
+            def _drive_k(g):
+                for t in range(NK):
+                    kgroups[g].TrackStereo([d_kl[(g * SKG + s) % NKB][t].data_ptr() for s in range(SKG)], [d_kr[(g * SKG + s) % NKB][t].data_ptr() for s in range(SKG)],
+                                           [t / 10.0] * SKG, on_device=True, stride=kpitch)
+
             t1 = time.perf_counter()
-            for t in range(NK):
-                ksys.TrackStereo([d_kl[s % NKB][t].data_ptr() for s in range(SK)], [d_kr[s % NKB][t].data_ptr() for s in range(SK)], [t / 10.0] * SK,
-                                 on_device=True, stride=kpitch)
+            ths = [threading.Thread(target=_drive_k, args=(g,)) for g in range(KG)]
+            for th_ in ths:
+                th_.start()
+            for th_ in ths:
+                th_.join()
             kdt = time.perf_counter() - t1
+            ksys = kgroups[0]
             kst = ksys.stats(0)
             _, kTwc = ksys.trajectory(0)
             kz0 = kcfg.bf / KD_
@@ -381,9 +405,9 @@ def main():
             kgt = np.stack([koff[:, 0] * kz0 / kcfg.fx, koff[:, 1] * kz0 / kcfg.fy, np.zeros(len(koff))], 1)
             extras["slam_stereo_batched_frames_per_s"] = round(SK * NK / kdt, 1)
             extras["slam_stereo_batched_ate_rmse_m"] = round(e2e.horn_align_ate(kTwc[:, :, 3], kgt[:len(kTwc)]), 6)
-            extras["slam_stereo_batched_config"] = ("S3/S4 shape: %d KITTI-shaped stereo sequences x %d frames in lockstep, 1241x376, 2000 features, KITTI00-02.yaml calibration, "
+            extras["slam_stereo_batched_config"] = ("S3/S4 shape: %d KITTI-shaped stereo sequences x %d frames (2 handles in lockstep), 1241x376, 2000 features, KITTI00-02.yaml calibration, "
                                                     "plane at %.2f m; seq 0: %d keyframes, %d local BAs, %d lost frames" % (SK, NK, kz0, kst["keyframes_created"], kst["local_bas"], kst["lost_frames"]))
-            extras["slam_stereo_batched_stage_seconds"] = {k: round(v, 4) for k, v in ksys.stage_seconds().items()}
+            extras["slam_stereo_batched_stage_seconds_handle0"] = {k: round(v, 4) for k, v in ksys.stage_seconds().items()}
             if not args.no_cpu_baseline:
                 kocfg = slam.make_config(KW_, KH_, 1, cam=slam.KITTI00, nFeatures=2000, sensor=slam.STEREO)
                 koops = slam.SlamOps()

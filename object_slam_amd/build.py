@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboslam_hip.so")
 SOURCES = ["orb_extractor.hip", "matcher.hip", "pose_opt.hip", "lba.hip", "stereo.hip", "bow_matcher.hip", "mappoint.hip", "frame.hip", "slam_driver.hip", "slam_ops_hip.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = (["-DOSLAM_LBA_PROFILE"] if os.environ.get("OSLAM_LBA_PROFILE") else []) + (["-DOSLAM_FAST_PROFILE"] if os.environ.get("OSLAM_FAST_PROFILE") else []) + (["-DOSLAM_MATCH_PROFILE"] if os.environ.get("OSLAM_MATCH_PROFILE") else []) + (["-DOSLAM_MATCH_ABLATE=" + os.environ["OSLAM_MATCH_ABLATE"]] if os.environ.get("OSLAM_MATCH_ABLATE") else []) + ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+FLAGS = (os.environ["OSLAM_EXTRA_FLAGS"].split() if os.environ.get("OSLAM_EXTRA_FLAGS") else []) + (["-DOSLAM_LBA_PROFILE"] if os.environ.get("OSLAM_LBA_PROFILE") else []) + (["-DOSLAM_FAST_PROFILE"] if os.environ.get("OSLAM_FAST_PROFILE") else []) + (["-DOSLAM_MATCH_PROFILE"] if os.environ.get("OSLAM_MATCH_PROFILE") else []) + (["-DOSLAM_MATCH_ABLATE=" + os.environ["OSLAM_MATCH_ABLATE"]] if os.environ.get("OSLAM_MATCH_ABLATE") else []) + ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
          "-ffp-contract=off",  # host AND device: reference float expressions round once per operator
          "-Wall", "-Wno-unused-function"]
 

@@ -16,7 +16,7 @@ struct HipOps {
     int S = 0, cap = 0;
     oslam_orb_t* orb = nullptr;
     oslam_orb_t* orbR = nullptr;          // STEREO: right image extractor (src/Tracking.cc:145)
-    oslam_stereo_t* st = nullptr;
+    oslam_stereo_t* stereo = nullptr;
     uint8_t* d_grayR = nullptr;
     const float* cur_uRight = nullptr;    // mvuRight of the current batch on the device (RGB-D: d_uRight, STEREO: the stereo matcher's output)
     oslam_matcher_t* m_last = nullptr;
@@ -44,6 +44,7 @@ struct HipOps {
     uint8_t* dn_h = nullptr; size_t dn_cap = 0;
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     oslam_drv::Pool* pool = nullptr;
+    hipStream_t strm = nullptr;   // this handle's stream (non-blocking): several handles on one GPU, each driven by its own host thread, overlap
     int ensure_up(size_t bytes) {
         if (bytes <= up_cap) return OSLAM_OK;
         OSLAM_HIP_CHECK(hipDeviceSynchronize());
@@ -107,15 +108,15 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
                  oDesc = L.take(32 * cap * n), oUr = L.take(4 * cap * n), oDp = L.take(4 * cap * n);
     OPS_CHECK(o->ensure_dn(L.off));
     uint8_t* D = o->dn_h;
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, d_dp, 4 * cap * n, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, d_dp, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     const int32_t* st = (const int32_t*)(D + oSt);
     if (st[0]) { oslam::set_error("extractor arena overflow"); return OSLAM_E_CAPACITY; }
     if (st[1]) { oslam::set_error("keypoint outside the depth image / right extractor arena overflow"); return OSLAM_E_INVALID; }
@@ -141,17 +142,30 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H, dimg = (size_t)W * H;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int i = 0; i < n; i++) {
-        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, gray[i], gray_stride, W, H, kind, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_depth + dimg * i, (size_t)W * 4, depth[i], (size_t)depth_pitch * 4, (size_t)W * 4, H, kind, nullptr));
+    if (on_device) {
+        for (int i = 0; i < n; i++) {
+            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, gray[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
+            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_depth + dimg * i, (size_t)W * 4, depth[i], (size_t)depth_pitch * 4, (size_t)W * 4, H, hipMemcpyDeviceToDevice, o->strm));
+        }
+    } else {
+        // host images: rows packed into the pinned block in the device layout (parallel), then ONE copy per plane (a pageable 2-D copy is row-by-row)
+        OPS_CHECK(o->ensure_up((gimg + dimg * 4) * n));
+        uint8_t* U = o->up_h;
+        o->pool->parallel_for(n, [&](int i) {
+            for (int r = 0; r < H; r++) {
+                memcpy(U + gimg * i + o->gray_pitch * r, gray[i] + (size_t)gray_stride * r, W);
+                memcpy(U + gimg * n + (dimg * i + (size_t)W * r) * 4, depth[i] + (size_t)depth_pitch * r, (size_t)W * 4);
+            }
+        });
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_gray, U, gimg * n, hipMemcpyHostToDevice, o->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_depth, U + gimg * n, dimg * 4 * n, hipMemcpyHostToDevice, o->strm));
     }
-    OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, nullptr));
+    OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, o->strm));
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
     OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
-    OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, nullptr));
+    OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, o->strm));
     OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
-                                                        o->d_mvDepth, o->d_status, nullptr));
+                                                        o->d_mvDepth, o->d_status, o->strm));
     (void)slots;
     return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out);
 }
@@ -161,27 +175,39 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
 int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                     oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
-    if (!o->orbR || !o->st) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
+    if (!o->orbR || !o->stereo) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
     if (n > o->S) { oslam::set_error("frames_stereo: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    for (int i = 0; i < n; i++) {
-        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, left[i], gray_stride, W, H, kind, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_grayR + gimg * i, o->gray_pitch, right[i], gray_stride, W, H, kind, nullptr));
+    if (on_device) {
+        for (int i = 0; i < n; i++) {
+            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, left[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
+            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_grayR + gimg * i, o->gray_pitch, right[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
+        }
+    } else {
+        OPS_CHECK(o->ensure_up(2 * gimg * n));
+        uint8_t* U = o->up_h;
+        o->pool->parallel_for(n, [&](int i) {
+            for (int r = 0; r < H; r++) {
+                memcpy(U + gimg * i + o->gray_pitch * r, left[i] + (size_t)gray_stride * r, W);
+                memcpy(U + gimg * (n + i) + o->gray_pitch * r, right[i] + (size_t)gray_stride * r, W);
+            }
+        });
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_gray, U, gimg * n, hipMemcpyHostToDevice, o->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_grayR, U + gimg * n, gimg * n, hipMemcpyHostToDevice, o->strm));
     }
-    OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, nullptr));
-    OPS_CHECK(oslam_orb_extract_batch_device(o->orbR, o->d_grayR, n, (int)o->gray_pitch, gimg, nullptr));
+    OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, o->strm));
+    OPS_CHECK(oslam_orb_extract_batch_device(o->orbR, o->d_grayR, n, (int)o->gray_pitch, gimg, o->strm));
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
     const oslam_keypoint_t* d_kpR; const uint8_t* d_descR; const int32_t* d_cntR; const int32_t* d_stR;
     OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
     OPS_CHECK(oslam_orb_results_device(o->orbR, &d_kpR, &d_descR, &d_cntR, &d_stR));
-    OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, nullptr));
-    OPS_CHECK(oslam_stereo_match_batch_device(o->st, o->orb, o->orbR, n, o->cap, d_kp, d_desc, d_cnt, 0, d_kpR, d_descR, d_cntR, 0, o->cfg.nLevels, o->cfg.bf,
-                                              o->cfg.bf / o->cfg.fx, nullptr));
+    OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, o->strm));
+    OPS_CHECK(oslam_stereo_match_batch_device(o->stereo, o->orb, o->orbR, n, o->cap, d_kp, d_desc, d_cnt, 0, d_kpR, d_descR, d_cntR, 0, o->cfg.nLevels, o->cfg.bf,
+                                              o->cfg.bf / o->cfg.fx, o->strm));
     const float* d_uR; const float* d_dp;
-    OPS_CHECK(oslam_stereo_results_device(o->st, &d_uR, &d_dp, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_status, d_stR, 4, hipMemcpyDeviceToDevice, nullptr));   // right extractor's overflow flag rides in the second status word
+    OPS_CHECK(oslam_stereo_results_device(o->stereo, &d_uR, &d_dp, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_status, d_stR, 4, hipMemcpyDeviceToDevice, o->strm));   // right extractor's overflow flag rides in the second status word
     (void)slots;
     return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, d_uR, d_dp, out);
 }
@@ -216,7 +242,7 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
         memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * b, j.last_keysUn, sizeof(oslam_keypoint_t) * N);
         memcpy(U + oDesc + 32 * cap * b, j.mp_desc, 32 * N);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
     oslam_match_frames_t fr;
     frames_view(o, fr, nullptr);
@@ -224,16 +250,16 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     la.Xw = (const float*)(Dv + oXw); la.has_mp = Dv + oHas; la.keys = (const oslam_keypoint_t*)(Dv + oKeys); la.mp_desc = Dv + oDesc;
     la.kp_stride = (int)cap; la.n_kps = (const int32_t*)(Dv + oN); la.n_kps_const = 0;
     OPS_CHECK(oslam_match_project_last_batch_device(o->m_last, &la, (const float*)(Dv + oTc), (const float*)(Dv + oTl), &o->cam, &fr, o->scale, o->cfg.nLevels,
-                                                    jobs[0].th, 0, (int)S, nullptr));
+                                                    jobs[0].th, 0, (int)S, o->strm));
     const int32_t* d_km; const int32_t* d_nm; const int32_t* d_nq;
     OPS_CHECK(oslam_match_results_device(o->m_last, nullptr, nullptr, &d_km, &d_nm, nullptr, &d_nq));
-    OPS_CHECK(oslam_match_search_batch_device(o->m_last, &fr, nullptr, (int)cap, d_nq, 0, (int)S, 0.9f, 0, 1, 100, nullptr));
+    OPS_CHECK(oslam_match_search_batch_device(o->m_last, &fr, nullptr, (int)cap, d_nq, 0, (int)S, 0.9f, 0, 1, 100, o->strm));
     Layout R;
     const size_t rKm = R.take(4 * cap * S), rNm = R.take(4 * S);
     OPS_CHECK(o->ensure_dn(R.off));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_last_t& j = jobs[i];
         memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
@@ -274,24 +300,23 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         memcpy(U + oMax + 4 * st * b, j.maxDist, 4 * M); memcpy(U + oMin + 4 * st * b, j.minDist, 4 * M);
         memcpy(U + oObs + st * b, j.obs_gt0, M); memcpy(U + oDesc + 32 * st * b, j.mp_desc, 32 * M);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
     OPS_CHECK(oslam_frame_is_in_frustum_batch_device((int)S, (int)st, (const int32_t*)(Dv + oM), (const float*)(Dv + oPw), (const float*)(Dv + oPn),
                                                      (const float*)(Dv + oMax), (const float*)(Dv + oMin), Dv + oObs, Dv + oDesc, (const float*)(Dv + oTc),
-                                                     (const float*)(Dv + oTh), o->K5, o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview,
-                                                     nullptr));
+                                                     (const float*)(Dv + oTh), o->K5, o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview, o->strm));
     oslam_match_frames_t fr;
     frames_view(o, fr, Dv + oBl);
-    OPS_CHECK(oslam_match_search_batch_device(o->m_map, &fr, o->d_lq, (int)st, (const int32_t*)(Dv + oM), 0, (int)S, 0.8f, 1, 0, 100, nullptr));
+    OPS_CHECK(oslam_match_search_batch_device(o->m_map, &fr, o->d_lq, (int)st, (const int32_t*)(Dv + oM), 0, (int)S, 0.8f, 1, 0, 100, o->strm));
     const int32_t* d_km; const int32_t* d_nm;
     OPS_CHECK(oslam_match_results_device(o->m_map, nullptr, nullptr, &d_km, &d_nm, nullptr, nullptr));
     Layout R;
     const size_t rKm = R.take(4 * cap * S), rNm = R.take(4 * S), rIn = R.take(st * S);
     OPS_CHECK(o->ensure_dn(R.off));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rIn, o->d_inview, st * S, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rIn, o->d_inview, st * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_local_t& j = jobs[i];
         memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
@@ -320,19 +345,19 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
         memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
         memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
     OPS_CHECK(oslam_pose_optimize_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), 0, (const float*)(Dv + oT), (const float*)(Dv + oXw),
-                                               (const float*)(Dv + oObs), (const float*)(Dv + oInv), Dv + oHas, o->K5, nullptr));
+                                               (const float*)(Dv + oObs), (const float*)(Dv + oInv), Dv + oHas, o->K5, o->strm));
     const float* d_T; const uint8_t* d_out; const int32_t* d_ni;
     OPS_CHECK(oslam_poseopt_results_device(o->po, &d_T, &d_out, &d_ni, nullptr));
     Layout R;
     const size_t rT = R.take(64 * B), rO = R.take(cap * B), rN = R.take(4 * B);
     OPS_CHECK(o->ensure_dn(R.off));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_pose_t& j = jobs[i];
         memcpy(j.Tcw_out, o->dn_h + rT + 64 * i, 64);
@@ -383,19 +408,18 @@ int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
         memcpy(U + oUr + 4 * cap * i, j.uRight, 4 * N); memcpy(U + oDesc + 32 * cap * i, j.desc, 32 * N);
         memcpy(U + oQ + sizeof(oslam_proj_query_t) * st * i, j.queries, sizeof(oslam_proj_query_t) * M);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
     oslam_match_frames_t fr;
     fr.keysUn = (const oslam_keypoint_t*)(Dv + oKeys); fr.kp_stride = (int)cap; fr.uRight = (const float*)(Dv + oUr); fr.desc = Dv + oDesc; fr.blocked = nullptr;
     fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
     fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
-    OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels,
-                                            nullptr));
+    OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels, o->strm));
     const int32_t* d_qm;
     OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
     OPS_CHECK(o->ensure_dn(4 * st * B));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
 }
@@ -430,12 +454,13 @@ int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 
 void h_destroy(void* p) {
     HipOps* o = (HipOps*)p;
-    oslam_orb_destroy(o->orb); oslam_orb_destroy(o->orbR); oslam_stereo_destroy(o->st); (void)hipFree(o->d_grayR); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
+    oslam_orb_destroy(o->orb); oslam_orb_destroy(o->orbR); oslam_stereo_destroy(o->stereo); (void)hipFree(o->d_grayR); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
     if (o->dn_h) (void)hipHostFree(o->dn_h);
     (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview);
     delete o->pool;
+    if (o->strm) (void)hipStreamDestroy(o->strm);
     (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
     delete o;
 }
@@ -450,16 +475,17 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     HipOps* o = new HipOps;
     o->cfg = *cfg; o->S = cfg->n_sequences;
     o->pool = new oslam_drv::Pool(cfg->host_threads > 1 ? cfg->host_threads : 1);
+    if (hipStreamCreateWithFlags(&o->strm, hipStreamNonBlocking) != hipSuccess) o->strm = nullptr;
     const int dev = cfg->device;
     int rc = oslam_orb_create(&o->orb, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
     if (!rc) {
         o->cap = oslam_orb_max_keypoints(o->orb);
-        o->max_local = 16384;
+        o->max_local = 32768;
         rc = oslam_matcher_create(&o->m_last, o->S, o->cap, o->cap, dev);
     }
     if (!rc) rc = oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, dev);
     if (!rc && cfg->sensor == 1) rc = oslam_orb_create(&o->orbR, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
-    if (!rc && cfg->sensor == 1) rc = oslam_stereo_create(&o->st, o->S, o->cap, dev);
+    if (!rc && cfg->sensor == 1) rc = oslam_stereo_create(&o->stereo, o->S, o->cap, dev);
     if (!rc) rc = oslam_poseopt_create(&o->po, o->S, o->cap, dev);
     if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 32768, 262144, dev);
     if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 32768, 262144, dev);
@@ -486,6 +512,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         if (e == hipSuccess) e = hipMemset(o->d_status, 0, 64);
         if (e != hipSuccess) { oslam::set_error("slam ops: hipMalloc failed: %s", hipGetErrorString(e)); rc = OSLAM_E_HIP; }
     }
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { oslam::set_error("slam ops: device synchronisation failed"); rc = OSLAM_E_HIP; }   // creation-time fills ran on the null stream
     if (rc) { h_destroy(o); return rc; }
     ops->ctx = o;
     ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames;

@@ -64,10 +64,17 @@ class System:
         self.Tcw = np.zeros((self.S, 4, 4), np.float32)
         self.state = np.zeros(self.S, np.int32)
 
+    def close(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            self.L.oslam_slam_destroy(h)
+            h.value = None
+
     def __del__(self):
-        if getattr(self, "h", None) is not None and self.h.value:
-            self.L.oslam_slam_destroy(self.h)
-            self.h = C.c_void_p()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: module globals may already be gone
+            pass
 
     def TrackRGBD(self, gray, depth, timestamps=None):
         """gray: S uint8 arrays [H, W] (C-contiguous rows), depth: S float32 arrays [H, W] in metres."""
