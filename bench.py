@@ -38,7 +38,9 @@ def cpu_baseline(frames, offs, n_sample):
     t0 = time.perf_counter()
     prev = None
     done = 0
-    for i in range(n_sample):
+    nB = len(frames)
+    for j in range(n_sample):
+        i = j % nB   # the stream is replayed if the sample is longer than the batch
         k, d = oe.extract(frames[i])
         if prev is not None:
             kl, dl, ol = prev
@@ -84,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=400)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (profiling runs: every launch of a kernel is then the S2 batch)")
     args = ap.parse_args()
@@ -252,7 +254,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0, N=1 only (bounded sample)
-        ns = min(args.cpu_sample, B)
+        ns = args.cpu_sample
         v, dt = cpu_baseline(frames, offs, ns)
         cpu = {"value": round(v, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": "%d frames of the same stream: oracle extract + SearchByProjection(Cur,Last), %.1f s" % (ns, dt)}

@@ -15,7 +15,10 @@
 
 namespace oslam {
 
-constexpr int kPoseThreads = 256;
+#ifndef OSLAM_POSE_THREADS
+#define OSLAM_POSE_THREADS 256
+#endif
+constexpr int kPoseThreads = OSLAM_POSE_THREADS;   // threads per frame (kernel experiments: -DOSLAM_POSE_THREADS=512)
 constexpr int kPoseWaves = kPoseThreads / 64;
 constexpr int kRedN = 29;   // 21 H (upper) + 6 b + chi + 1 spare
 
