@@ -94,3 +94,26 @@ def test_map_bookkeeping_unit_checks(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(here, "slam_map_check.cc"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_not_initialised_and_lost_states(oracle):
+    """A textureless first frame leaves the sequence NOT_INITIALIZED (StereoInitialization needs > 500 keypoints, reference
+    src/Tracking.cc:592); textureless frames in the middle lose the track and — Relocalization being out of scope — it stays LOST;
+    the trajectory skips lost frames like System::SaveTrajectoryTUM."""
+    cfg = slam.make_config(W, H, 1)
+    streams = make_streams(1, 12)
+    blank = np.full((H, W), 90, np.uint8)
+    seq = [blank] + list(streams[0][0][:6]) + [blank, blank] + list(streams[0][0][6:9])
+    depth = np.full((H, W), 2.0, np.float32)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    states = []
+    for t, img in enumerate(seq):
+        T, st = sysm.TrackRGBD([img], [depth], [t / 30.0])
+        states.append(int(st[0]))
+    assert states[0] == slam.NOT_INITIALIZED
+    assert states[1:7] == [slam.OK] * 6
+    assert states[7:] == [slam.LOST] * 5
+    st = sysm.stats(0)
+    assert st["lost_frames"] == 1 and st["map_violations"] == 0      # counted once: a LOST sequence is not tracked again
+    stamps, Twc = sysm.trajectory(0)
+    assert len(stamps) == 6
