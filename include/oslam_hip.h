@@ -394,6 +394,11 @@ int oslam_mp_distinctive_descriptors(oslam_mappoint_t* h, int P, const int32_t* 
 int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*[P][3]*/, const int32_t* obs_start, const float* obs_Ow /*[total][3]*/,
                                  const float* OwRef /*[P][3]*/, const float* levelScaleFactor /*[P]*/, float lastScaleFactor, float* out /*[P][5]*/);
 
+/* device-pointer forms (asynchronous on `stream`); d_out_desc rows of points without observations are left untouched (zero-fill them first) */
+int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream);
+int oslam_mp_update_normal_depth_device(int P, const float* d_Pos, const int32_t* d_obs_start, const float* d_obs_Ow, const float* d_OwRef,
+                                        const float* d_levelScaleFactor, float lastScaleFactor, float* d_out, void* stream);
+
 /* Frame::isInFrustum (reference src/Frame.cc:509-565) + MapPoint::PredictScale (src/MapPoint.cc:505-521) + the window
  * radius of ORBmatcher::SearchByProjection(F, vpMapPoints, th) (src/ORBmatcher.cc:57-67, RadiusByViewingCos :93-99),
  * for M map points against one frame pose. Tcw row-major 4x4; K5 = fx,fy,cx,cy,bf; bounds = mnMinX,mnMinY,mnMaxX,mnMaxY;

@@ -245,6 +245,25 @@ int oslam_mp_distinctive_descriptors(oslam_mappoint_t* h, int P, const int32_t* 
     return OSLAM_OK;
 }
 
+// Device-pointer forms of the two MapPoint updates (everything in HBM, asynchronous on `stream`): the batch-of-sequences driver packs the touched
+// points of all sequences into one block.  d_out_desc must be zero-filled by the caller for points without observations (best_idx = -1).
+int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream) {
+    if (P < 0 || (P > 0 && (!d_obs_start || !d_obs_desc || !d_best_idx || !d_out_desc))) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    if (P == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_distinctive, dim3(div_up(P, 4)), dim3(256), 0, (hipStream_t)stream, P, d_obs_start, d_obs_desc, d_best_idx, d_out_desc);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+int oslam_mp_update_normal_depth_device(int P, const float* d_Pos, const int32_t* d_obs_start, const float* d_obs_Ow, const float* d_OwRef,
+                                        const float* d_levelScaleFactor, float lastScaleFactor, float* d_out, void* stream) {
+    if (P < 0 || (P > 0 && (!d_Pos || !d_obs_start || !d_obs_Ow || !d_OwRef || !d_levelScaleFactor || !d_out))) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    if (P == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_update_normal_depth, dim3(div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, P, d_Pos, d_obs_start, d_obs_Ow, d_OwRef, d_levelScaleFactor,
+                       lastScaleFactor, d_out);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos, const int32_t* obs_start, const float* obs_Ow, const float* OwRef,
                                  const float* levelScaleFactor, float lastScaleFactor, float* out) {
     if (!h || P < 0 || (P > 0 && (!Pos || !obs_start || !OwRef || !levelScaleFactor || !out))) { set_error("bad argument"); return OSLAM_E_INVALID; }

@@ -367,11 +367,40 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     return OSLAM_OK;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over the touched points of all sequences: one block up, two launches, one block down
 int h_mp_update(void* p, oslam_job_mp_update_t* j) {
     HipOps* o = (HipOps*)p;
-    if (j->do_desc) OPS_CHECK(oslam_mp_distinctive_descriptors(o->mp, j->P, j->obs_start, j->obs_desc, j->best_idx, j->out_desc));
-    if (j->do_normal)
-        OPS_CHECK(oslam_mp_update_normal_depth(o->mp, j->P, j->Pos, j->obs_start, j->obs_Ow, j->OwRef, j->levelScaleFactor, o->scale[o->cfg.nLevels - 1], j->out5));
+    const size_t P = j->P;
+    if (P == 0) return OSLAM_OK;
+    const size_t total = (size_t)j->obs_start[P];
+    Layout L;
+    const size_t oStart = L.take(4 * (P + 1)), oDesc = L.take(32 * total), oOw = L.take(12 * total), oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P);
+    const size_t in_bytes = L.off;
+    const size_t oBest = L.take(4 * P), oOut = L.take(32 * P), oOut5 = L.take(20 * P);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    uint8_t* Dv = o->up_d;
+    memcpy(U + oStart, j->obs_start, 4 * (P + 1));
+    if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * total);
+    if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
+    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    Layout R;
+    const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
+    OPS_CHECK(o->ensure_dn(R.off));
+    if (j->do_desc) {
+        OSLAM_HIP_CHECK(hipMemsetAsync(Dv + oOut, 0, 32 * P, o->strm));
+        OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(Dv + oStart), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rBest, Dv + oBest, 4 * P, hipMemcpyDeviceToHost, o->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut, Dv + oOut, 32 * P, hipMemcpyDeviceToHost, o->strm));
+    }
+    if (j->do_normal) {
+        OPS_CHECK(oslam_mp_update_normal_depth_device((int)P, (const float*)(Dv + oPos), (const int32_t*)(Dv + oStart), (const float*)(Dv + oOw), (const float*)(Dv + oRef),
+                                                      (const float*)(Dv + oLsf), o->scale[o->cfg.nLevels - 1], (float*)(Dv + oOut5), o->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut5, Dv + oOut5, 20 * P, hipMemcpyDeviceToHost, o->strm));
+    }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
+    if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
     return OSLAM_OK;
 }
 
