@@ -1674,22 +1674,37 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
     OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    // results of all windows: async copies into the pinned block, ONE synchronisation, then the scatter (erase flags back in caller edge order)
+    std::vector<size_t> o_pose(n), o_pts(n), o_er(n), o_st(n);
+    size_t total = 0;
+    auto take = [&](size_t bytes) { const size_t at = total; total += (bytes + 255) & ~(size_t)255; return at; };
+    for (int i = 0; i < n; i++) {
+        const oslam_lba_problem_t& q = probs[i];
+        o_pose[i] = take((size_t)q.nKF * 64); o_pts[i] = take((size_t)q.nP * 12); o_er[i] = take((size_t)q.nE); o_st[i] = take(64);
+    }
+    if (total > h->out_cap) {
+        OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        if (h->h_out) (void)hipHostFree(h->h_out);
+        h->h_out = nullptr; h->out_cap = 0;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
+        h->out_cap = total + total / 2;
+    }
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
         oslam_lba::Slot& s = h->slots[i];
-        OSLAM_HIP_CHECK(hipMemcpy(q.poses_out, s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost));
-        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpy(q.points_out, s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost));
-        if (q.nE > 0) {
-            std::vector<uint8_t> er(q.nE);
-            OSLAM_HIP_CHECK(hipMemcpy(er.data(), s.erase, (size_t)q.nE, hipMemcpyDeviceToHost));
-            for (int e = 0; e < q.nE; e++) q.erase[h->orders[i][e]] = er[e];
-        }
-        if (q.stats) {
-            int st[16];
-            OSLAM_HIP_CHECK(hipMemcpy(st, s.stats, sizeof(st), hipMemcpyDeviceToHost));
-            for (int k = 0; k < 4; k++) q.stats[k] = st[k];
-        }
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose[i], s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost, nullptr));
+        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts[i], s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost, nullptr));
+        if (q.nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er[i], s.erase, (size_t)q.nE, hipMemcpyDeviceToHost, nullptr));
+        if (q.stats) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st[i], s.stats, 64, hipMemcpyDeviceToHost, nullptr));
+    }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < n; i++) {
+        const oslam_lba_problem_t& q = probs[i];
+        memcpy(q.poses_out, h->h_out + o_pose[i], (size_t)q.nKF * 64);
+        if (q.nP > 0) memcpy(q.points_out, h->h_out + o_pts[i], (size_t)q.nP * 12);
+        const uint8_t* er = h->h_out + o_er[i];
+        for (int e = 0; e < q.nE; e++) q.erase[h->orders[i][e]] = er[e];
+        if (q.stats) { const int* st = (const int*)(h->h_out + o_st[i]); for (int k = 0; k < 4; k++) q.stats[k] = st[k]; }
     }
     return OSLAM_OK;
 }
