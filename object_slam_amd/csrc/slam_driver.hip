@@ -25,11 +25,12 @@ struct Vocab {
             const uint32_t x = (uint32_t)(((old >> 18u) ^ old) >> 27u), r = (uint32_t)(old >> 59u);
             return (x >> r) | (x << ((-r) & 31));
         };
+        auto word = [&]() { const uint64_t hi = next(); const uint64_t lo = next(); return (hi << 32) | lo; };   // high half drawn first
         for (int i = 0; i < 10; i++)
-            for (int w = 0; w < 4; w++) top[i][w] = ((uint64_t)next() << 32) | next();
+            for (int w = 0; w < 4; w++) top[i][w] = word();
         for (int i = 0; i < 10; i++)
             for (int j = 0; j < 10; j++)
-                for (int w = 0; w < 4; w++) sub[i][j][w] = ((uint64_t)next() << 32) | next();
+                for (int w = 0; w < 4; w++) sub[i][j][w] = word();
     }
     static int dist(const uint64_t* a, const uint64_t* b) {
         return __builtin_popcountll(a[0] ^ b[0]) + __builtin_popcountll(a[1] ^ b[1]) + __builtin_popcountll(a[2] ^ b[2]) + __builtin_popcountll(a[3] ^ b[3]);

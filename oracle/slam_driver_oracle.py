@@ -1,0 +1,1014 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (the reference cannot be built or run here).
+
+Independent restatement of the reference's Tracking / LocalMapping control flow for ONE RGB-D or stereo sequence, written in the
+reference's own object style (MapPoint / KeyFrame / Frame objects holding references to each other, the reference's method names)
+on top of the CPU oracle operators (oracle_py).  It exists to pin the product's driver (object_slam_amd/csrc/slam_driver.hip, an
+index-based, lockstep, multi-sequence formulation of the same flow): tests run both over the same oracle operators and require the
+same states, map statistics and poses.
+
+Reference lines followed: src/Tracking.cc:310-587 (Track), :590-642 (StereoInitialization), :820-835, :838-880, :882-891, :948-1009,
+:1011-1056, :1242-1326, :1328-1406, :1408-1458, :1470-1604; src/LocalMapping.cc:48-113, :129-206, :208-453, :455-535, :537-554, :633-697;
+src/KeyFrame.cc:123-567; src/MapPoint.cc:196-521; src/ORBmatcher.cc:825-975 (Fuse gates and surgery); src/Optimizer.cc:456-504, :711-777
+(LocalBundleAdjustment gather / write-back); src/System.cc:378-440 (SaveTrajectoryTUM).
+The same normalisations as include/oslam_slam.h apply (synchronous LocalMapping, keyframe-id order for pointer-ordered containers,
+substitute vocabulary, no relocalisation / loop closing / object layer).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import oracle_py as O
+
+f32 = np.float32
+_libm = C.CDLL("libm.so.6")
+_libm.logf.restype = C.c_float
+_libm.logf.argtypes = [C.c_float]
+
+QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("minLevel", "<i4"), ("maxLevel", "<i4"),
+                        ("flags", "<i4"), ("angle", "<f4"), ("desc", "u1", (32,))])
+
+NOT_INITIALIZED, OK, LOST = 1, 2, 3
+
+
+def logf(x):
+    return f32(_libm.logf(float(x)))
+
+
+# ---- cv::Mat arithmetic the host code of the reference performs (float accumulation order as in cv::gemm's small-matrix branch) ----
+def mul4(a, b):
+    s = a[:, 0:1] * b[0:1, :]
+    s = s + a[:, 1:2] * b[1:2, :]
+    s = s + a[:, 2:3] * b[2:3, :]
+    s = s + a[:, 3:4] * b[3:4, :]
+    return s.astype(f32)
+
+
+def norm3(v):
+    s = 0.0
+    for k in range(3):
+        s += float(v[k]) * float(v[k])
+    return f32(math.sqrt(s))
+
+
+class Pose:
+    """mTcw with the cached Rwc / Ow / Twc (Frame::UpdatePoseMatrices, KeyFrame::SetPose)."""
+
+    def __init__(self):
+        self.Tcw = None
+
+    def _fill(self):
+        self.Twc = np.eye(4, dtype=f32)
+        self.Twc[:3, :3] = self.Rwc
+        self.Twc[:3, 3] = self.Ow
+
+    def set_frame(self, T):     # src/Frame.cc:478-505: mOw = -mRcw.t()*mtcw (generic gemm, fp64 sums)
+        self.Tcw = np.array(T, f32)
+        self.Rwc = self.Tcw[:3, :3].T.copy()
+        self.Ow = np.zeros(3, f32)
+        for r in range(3):
+            s = 0.0
+            for k in range(3):
+                s += float(self.Tcw[k, r]) * float(self.Tcw[k, 3])
+            self.Ow[r] = f32(-1.0 * s)
+        self._fill()
+
+    def set_keyframe(self, T):  # src/KeyFrame.cc:78-92: Ow = -Rwc*tcw (float sums)
+        self.Tcw = np.array(T, f32)
+        self.Rwc = self.Tcw[:3, :3].T.copy()
+        self.Ow = np.zeros(3, f32)
+        for r in range(3):
+            s = self.Rwc[r, 0] * self.Tcw[0, 3]
+            s = s + self.Rwc[r, 1] * self.Tcw[1, 3]
+            s = s + self.Rwc[r, 2] * self.Tcw[2, 3]
+            self.Ow[r] = f32(float(s) * -1.0)
+        self._fill()
+
+
+# ---- substitute vocabulary (include/oslam_slam.h): k = 10, two levels of PCG32 words ----
+class Vocab:
+    def __init__(self):
+        st = [0x853c49e6748fea9b]
+
+        def nxt():
+            old = st[0]
+            st[0] = (old * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+            x = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+            r = old >> 59
+            return ((x >> r) | (x << ((-r) & 31))) & 0xFFFFFFFF
+        w = lambda: (nxt() << 32) | nxt()
+        self.top = np.array([[w() for _ in range(4)] for _ in range(10)], np.uint64)
+        self.sub = np.array([[[w() for _ in range(4)] for _ in range(10)] for _ in range(10)], np.uint64)
+
+    @staticmethod
+    def _dist(v, c):   # v [N,4] u64, c [K,4] u64 -> [N,K]
+        x = v[:, None, :] ^ c[None, :, :]
+        return np.unpackbits(x.view(np.uint8).reshape(x.shape[0], x.shape[1], 32), axis=2).sum(2)
+
+    def nodes(self, desc):
+        v = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32).view(np.uint64).reshape(-1, 4)
+        b1 = self._dist(v, self.top).argmin(1)
+        out = np.zeros(len(v), np.uint32)
+        for i in range(len(v)):
+            b2 = self._dist(v[i:i + 1], self.sub[b1[i]]).argmin(1)[0]
+            out[i] = 11 + b1[i] * 10 + b2
+        return out
+
+
+class MapPoint:
+    def __init__(self, pos, pRefKF):
+        self.mWorldPos = np.array(pos, f32)
+        self.mNormalVector = np.zeros(3, f32)
+        self.mfMinDistance = f32(0)
+        self.mfMaxDistance = f32(0)
+        self.mDescriptor = np.zeros(32, np.uint8)
+        self.nObs, self.mnVisible, self.mnFound = 0, 1, 1
+        self.mnFirstKFid, self.mpRefKF = pRefKF.mnId, pRefKF
+        self.mbBad, self.mpReplaced = False, None
+        self.mObservations = {}            # KeyFrame -> idx
+        self.mnLastFrameSeen = self.mnTrackReferenceForFrame = self.mnBALocalForKF = self.mnFuseCandidateForKF = 0
+
+    def obs_sorted(self):
+        return sorted(self.mObservations.items(), key=lambda e: e[0].mnId)
+
+    def AddObservation(self, pKF, idx):
+        if pKF in self.mObservations:
+            return
+        self.mObservations[pKF] = idx
+        self.nObs += 2 if pKF.mvuRight[idx] >= 0 else 1
+
+    def SetBadFlag(self, slam):
+        if not self.mbBad:
+            slam.nMPsInMap -= 1
+            slam.st["points_culled_total"] += 1
+        self.mbBad = True
+        obs, self.mObservations = self.mObservations, {}
+        for pKF, idx in obs.items():
+            pKF.mvpMapPoints[idx] = None
+
+    def EraseObservation(self, pKF, slam):
+        bad = False
+        if pKF in self.mObservations:
+            idx = self.mObservations[pKF]
+            self.nObs -= 2 if pKF.mvuRight[idx] >= 0 else 1
+            del self.mObservations[pKF]
+            if self.mpRefKF is pKF and self.mObservations:
+                self.mpRefKF = self.obs_sorted()[0][0]
+            if self.nObs <= 2:
+                bad = True
+        if bad:
+            self.SetBadFlag(slam)
+
+    def Replace(self, pMP, slam):     # returns True if pMP changed (its descriptor must be recomputed)
+        if pMP is self:
+            return False
+        obs, self.mObservations = self.obs_sorted(), {}
+        if not self.mbBad:
+            slam.nMPsInMap -= 1
+        self.mbBad, self.mpReplaced = True, pMP
+        for pKF, idx in obs:
+            if pKF not in pMP.mObservations:
+                pKF.mvpMapPoints[idx] = pMP
+                pMP.AddObservation(pKF, idx)
+            else:
+                pKF.mvpMapPoints[idx] = None
+        pMP.mnFound += self.mnFound
+        pMP.mnVisible += self.mnVisible
+        return True
+
+
+class KeyFrame:
+    def __init__(self, F, mnId):
+        self.mnId, self.mnFrameId, self.mTimeStamp, self.N = mnId, F.mnId, F.mTimeStamp, F.N
+        self.mvKeys, self.mvKeysUn, self.mDescriptors = F.mvKeys.copy(), F.mvKeysUn.copy(), F.mDescriptors.copy()
+        self.mvuRight, self.mvDepth = F.mvuRight.copy(), F.mvDepth.copy()
+        self.mvpMapPoints = list(F.mvpMapPoints)
+        self.bowNode = None if F.bowNode is None else F.bowNode.copy()
+        self.pose = Pose()
+        self.pose.set_keyframe(F.pose.Tcw)
+        self.mTcp = np.eye(4, dtype=f32)
+        self.mConnectedKeyFrameWeights = {}
+        self.mvpOrderedConnectedKeyFrames, self.mvOrderedWeights = [], []
+        self.mpParent, self.mspChildrens, self.mbFirstConnection, self.mbBad = None, set(), True, False
+        self.mnTrackReferenceForFrame = self.mnFuseTargetForKF = self.mnBALocalForKF = self.mnBAFixedForKF = 0
+
+    def __hash__(self):
+        return self.mnId
+
+    def __eq__(self, o):
+        return self is o
+
+    def UpdateBestCovisibles(self):
+        v = sorted(((w, k.mnId, k) for k, w in self.mConnectedKeyFrameWeights.items()), key=lambda e: (e[0], e[1]))
+        self.mvpOrderedConnectedKeyFrames = [e[2] for e in reversed(v)]
+        self.mvOrderedWeights = [e[0] for e in reversed(v)]
+
+    def AddConnection(self, pKF, w):
+        if self.mConnectedKeyFrameWeights.get(pKF) == w:
+            return
+        self.mConnectedKeyFrameWeights[pKF] = w
+        self.UpdateBestCovisibles()
+
+    def EraseConnection(self, pKF):
+        if pKF in self.mConnectedKeyFrameWeights:
+            del self.mConnectedKeyFrameWeights[pKF]
+            self.UpdateBestCovisibles()
+
+    def GetBestCovisibilityKeyFrames(self, n):
+        return list(self.mvpOrderedConnectedKeyFrames[:n])
+
+    def GetWeight(self, pKF):
+        return self.mConnectedKeyFrameWeights.get(pKF, 0)
+
+    def UpdateConnections(self):
+        counter = {}
+        for pMP in self.mvpMapPoints:
+            if pMP is None or pMP.mbBad:
+                continue
+            for pKF in pMP.mObservations:
+                if pKF.mnId == self.mnId:
+                    continue
+                counter[pKF] = counter.get(pKF, 0) + 1
+        if not counter:
+            return
+        items = sorted(counter.items(), key=lambda e: e[0].mnId)
+        nmax, pKFmax, vPairs = 0, None, []
+        for pKF, c in items:
+            if c > nmax:
+                nmax, pKFmax = c, pKF
+            if c >= 15:
+                vPairs.append((c, pKF.mnId, pKF))
+                pKF.AddConnection(self, c)
+        if not vPairs:
+            vPairs.append((nmax, pKFmax.mnId, pKFmax))
+            pKFmax.AddConnection(self, nmax)
+        vPairs.sort(key=lambda e: (e[0], e[1]))
+        self.mConnectedKeyFrameWeights = dict(items)
+        self.mvpOrderedConnectedKeyFrames = [e[2] for e in reversed(vPairs)]
+        self.mvOrderedWeights = [e[0] for e in reversed(vPairs)]
+        if self.mbFirstConnection and self.mnId != 0:
+            self.mpParent = self.mvpOrderedConnectedKeyFrames[0]
+            self.mpParent.mspChildrens.add(self)
+            self.mbFirstConnection = False
+
+    def TrackedMapPoints(self, minObs):
+        n = 0
+        for pMP in self.mvpMapPoints:
+            if pMP is None or pMP.mbBad:
+                continue
+            if minObs > 0:
+                n += pMP.nObs >= minObs
+            else:
+                n += 1
+        return n
+
+    def SetBadFlag(self, slam):
+        if self.mnId == 0:
+            return
+        first = not self.mbBad
+        for pKF in sorted(self.mConnectedKeyFrameWeights, key=lambda k: k.mnId):
+            pKF.EraseConnection(self)
+        for pMP in self.mvpMapPoints:
+            if pMP is not None:
+                pMP.EraseObservation(self, slam)
+        self.mConnectedKeyFrameWeights, self.mvpOrderedConnectedKeyFrames, self.mvOrderedWeights = {}, [], []
+        cand = {self.mpParent}
+        while self.mspChildrens:
+            best = None
+            mx = -1
+            for pKF in sorted(self.mspChildrens, key=lambda k: k.mnId):
+                if pKF.mbBad:
+                    continue
+                for conn in pKF.mvpOrderedConnectedKeyFrames:
+                    for pc in sorted(cand, key=lambda k: k.mnId):
+                        if conn.mnId == pc.mnId:
+                            w = pKF.GetWeight(conn)
+                            if w > mx:
+                                best, mx = (pKF, conn), w
+            if best is None:
+                break
+            pC, pP = best
+            pC.mpParent = pP
+            pP.mspChildrens.add(pC)
+            cand.add(pC)
+            self.mspChildrens.discard(pC)
+        for pKF in self.mspChildrens:
+            pKF.mpParent = self.mpParent
+            self.mpParent.mspChildrens.add(pKF)
+        self.mpParent.mspChildrens.discard(self)
+        self.mTcp = mul4(self.pose.Tcw, self.mpParent.pose.Twc)
+        self.mbBad = True
+        if first:
+            slam.nKFsInMap -= 1
+            slam.st["keyframes_culled"] += 1
+
+
+class Frame:
+    def __init__(self, mnId, stamp, keys, keysUn, desc, uRight, depth):
+        self.mnId, self.mTimeStamp, self.N = mnId, stamp, len(keys)
+        self.mvKeys, self.mvKeysUn, self.mDescriptors, self.mvuRight, self.mvDepth = keys, keysUn, desc, uRight, depth
+        self.mvpMapPoints = [None] * self.N
+        self.mvbOutlier = np.zeros(self.N, bool)
+        self.pose = Pose()
+        self.mpReferenceKF = None
+        self.bowNode = None
+
+
+class Slam:
+    """One sequence.  cfg: dict with width, height, fx, fy, cx, cy, bf, thDepth, fps, nFeatures, scaleFactor, nLevels, iniThFAST, minThFAST,
+    sensor (1 STEREO, 2 RGBD), local_mapping (bit flags as in oslam_slam_config_t)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        g = lambda k: f32(cfg[k])
+        self.fx, self.fy, self.cx, self.cy, self.bf = g("fx"), g("fy"), g("cx"), g("cy"), g("bf")
+        self.invfx, self.invfy = f32(1.0) / self.fx, f32(1.0) / self.fy
+        self.mb = self.bf / self.fx
+        self.thDepth = self.bf * g("thDepth") / self.fx
+        self.maxFrames, self.minFrames = int(cfg["fps"]), 0
+        self.stereo = cfg.get("sensor", 2) == 1
+        self.flags = cfg.get("local_mapping", 0x1F)
+        self.nLevels = cfg["nLevels"]
+        self.scaleFactor = f32(cfg["scaleFactor"])
+        self.logScale = logf(self.scaleFactor)
+        self.orb = O.OrbExtractor(cfg["nFeatures"], cfg["scaleFactor"], cfg["nLevels"], cfg["iniThFAST"], cfg["minThFAST"])
+        self.orbR = O.OrbExtractor(cfg["nFeatures"], cfg["scaleFactor"], cfg["nLevels"], cfg["iniThFAST"], cfg["minThFAST"]) if self.stereo else None
+        t = self.orb.tables()
+        self.scale, self.sigma2, self.invSigma2 = t["scale"], t["sigma2"], t["inv_sigma2"]
+        self.K4 = np.array([self.fx, self.fy, self.cx, self.cy], f32)
+        self.K5 = np.array([self.fx, self.fy, self.cx, self.cy, self.bf], f32)
+        self.cam6 = (self.fx, self.fy, self.cx, self.cy, self.bf, self.mb)
+        self.bounds = O.image_bounds(cfg["width"], cfg["height"], self.K4, None)
+        self.voc = Vocab()
+        # Tracking / LocalMapping members
+        self.mState = NOT_INITIALIZED
+        self.nextFrameId = 0
+        self.mVelocity = None
+        self.mpReferenceKF = None
+        self.mnLastKeyFrameId = 0
+        self.mnLastRelocFrameId = 0
+        self.mnMatchesInliers = 0
+        self.mvpLocalKeyFrames, self.mvpLocalMapPoints = [], []
+        self.mlRelativeFramePoses = []     # (Tcr, refKF, stamp, lost)
+        self.mlpRecentAddedMapPoints = []
+        self.mlNewKeyFrames = []
+        self.mLastFrame = None
+        self.keyframes = []
+        self.nKFsInMap = self.nMPsInMap = 0
+        self.st = dict(frames=0, keyframes_created=0, points_created=0, local_bas=0, tracked_motion_model=0, tracked_reference_kf=0, lost_frames=0,
+                       points_fused=0, points_triangulated=0, keyframes_culled=0, points_culled=0, last_inliers=0, lba_edges=0, points_culled_total=0)
+
+    # ------------------------------------------------------------------ operators
+    def _compute_bow(self, obj):
+        if obj.bowNode is None:
+            obj.bowNode = self.voc.nodes(obj.mDescriptors)
+
+    def _update_points(self, pts, do_desc, do_normal):
+        """ComputeDistinctiveDescriptors (src/MapPoint.cc:345-410) / UpdateNormalAndDepth (:433-474) for each point."""
+        for pMP in pts:
+            if pMP.mbBad or not pMP.mObservations:
+                continue
+            obs = pMP.obs_sorted()
+            if do_desc:
+                d = np.stack([k.mDescriptors[i] for k, i in obs])
+                b = O.distinctive_descriptor(d)
+                pMP.mDescriptor = d[b].copy()
+            if do_normal:
+                Ow = np.stack([k.pose.Ow for k, _ in obs])
+                ref = pMP.mpRefKF
+                idx = pMP.mObservations.get(ref, -1)
+                lsf = self.scale[ref.mvKeysUn["octave"][idx]] if idx >= 0 else f32(1)
+                o = O.update_normal_depth(pMP.mWorldPos, Ow, ref.pose.Ow, lsf, self.scale[self.nLevels - 1])
+                pMP.mNormalVector = o[:3].copy()
+                pMP.mfMaxDistance, pMP.mfMinDistance = o[3], o[4]
+
+    def _pose_optimization(self, F):
+        N = F.N
+        has = np.array([p is not None for p in F.mvpMapPoints], np.uint8)
+        Xw = np.zeros((N, 3), f32)
+        for i, p in enumerate(F.mvpMapPoints):
+            if p is not None:
+                Xw[i] = p.mWorldPos
+        obs = np.stack([F.mvKeysUn["x"], F.mvKeysUn["y"], F.mvuRight], 1).astype(f32)
+        inv = self.invSigma2[F.mvKeysUn["octave"]].astype(f32)
+        n, T, outl, _ = O.pose_optimization(F.pose.Tcw, Xw, obs, inv, has, self.K5)
+        return np.array(T, f32), outl
+
+    def _new_keyframe(self, F):
+        kf = KeyFrame(F, len(self.keyframes))
+        self.keyframes.append(kf)
+        self.st["keyframes_created"] += 1
+        return kf
+
+    def _unproject(self, F, i):
+        z = F.mvDepth[i]
+        if not (z > 0):
+            return None
+        x = (F.mvKeysUn["x"][i] - self.cx) * z * self.invfx
+        y = (F.mvKeysUn["y"][i] - self.cy) * z * self.invfy
+        out = np.zeros(3, f32)
+        for r in range(3):
+            s = F.pose.Rwc[r, 0] * x
+            s = s + F.pose.Rwc[r, 1] * y
+            s = s + F.pose.Rwc[r, 2] * z
+            out[r] = f32(float(s) + float(F.pose.Ow[r]))
+        return out
+
+    def _create_stereo_points(self, F, kf, every, created):
+        def make(i):
+            x = self._unproject(F, i)
+            if x is None:
+                return
+            p = MapPoint(x, kf)
+            p.AddObservation(kf, i)
+            kf.mvpMapPoints[i] = p
+            self.nMPsInMap += 1
+            self.st["points_created"] += 1
+            F.mvpMapPoints[i] = p
+            created.append(p)
+        if every:
+            for i in range(F.N):
+                if F.mvDepth[i] > 0:
+                    make(i)
+            return
+        v = sorted((float(F.mvDepth[i]), i) for i in range(F.N) if F.mvDepth[i] > 0)
+        nPoints = 0
+        for z, i in v:
+            p = F.mvpMapPoints[i]
+            create = False
+            if p is None:
+                create = True
+            elif p.nObs < 1:
+                create = True
+                F.mvpMapPoints[i] = None
+            if create:
+                make(i)
+            nPoints += 1
+            if f32(z) > self.thDepth and nPoints > 100:
+                break
+
+    # ------------------------------------------------------------------ Tracking
+    def _make_frame(self, images, stamp):
+        if self.stereo:
+            left, right = images
+            keys, desc = self.orb.extract(left)
+            kr, dr = self.orbR.extract(right)
+            keysUn = O.undistort_keypoints(keys, self.K4, None)
+            uR, dp = O.stereo_matches(self.orb, self.orbR, keys, desc, kr, dr, self.bf, self.mb)
+        else:
+            gray, depth = images
+            keys, desc = self.orb.extract(gray)
+            keysUn = O.undistort_keypoints(keys, self.K4, None)
+            uR, dp = O.stereo_from_rgbd(keys, keysUn, depth, self.bf)
+        F = Frame(self.nextFrameId, stamp, keys, keysUn, desc, np.array(uR, f32), np.array(dp, f32))
+        self.nextFrameId += 1
+        return F
+
+    def _discard_after_initial_pose(self, F, T, outl):
+        F.pose.set_frame(T)
+        nmap = 0
+        for i, p in enumerate(F.mvpMapPoints):
+            if p is None:
+                continue
+            if outl[i]:
+                F.mvpMapPoints[i] = None
+                p.mnLastFrameSeen = F.mnId
+            elif p.nObs > 0:
+                nmap += 1
+            F.mvbOutlier[i] = False
+        return nmap >= 10
+
+    def TrackWithMotionModel(self, F):
+        L = self.mLastFrame
+        Tlr, ref = self.mlRelativeFramePoses[-1][0], L.mpReferenceKF
+        L.pose.set_frame(mul4(Tlr, ref.pose.Tcw))                       # UpdateLastFrame
+        F.pose.set_frame(mul4(self.mVelocity, L.pose.Tcw))
+        NL = L.N
+        Xw, has, mpd = np.zeros((NL, 3), f32), np.zeros(NL, np.uint8), np.zeros((NL, 32), np.uint8)
+        for k, p in enumerate(L.mvpMapPoints):
+            if p is None or L.mvbOutlier[k]:
+                continue
+            has[k] = 1 | (2 if p.nObs > 0 else 0)
+            Xw[k], mpd[k] = p.mWorldPos, p.mDescriptor
+        th = 7.0 if self.stereo else 15.0
+        for t in (th, 2 * th):
+            q = O.project_last_frame(Xw, has, L.mvKeysUn, mpd, F.pose.Tcw, L.pose.Tcw, self.cam6, self.bounds, self.scale, t, False)
+            nm, qm, qd, km = O.search_by_projection(F.mvKeysUn, F.mvuRight, F.mDescriptors, None, self.bounds, q, 0.9, False, True)
+            if nm >= 20:
+                break
+        if nm < 20:
+            return False
+        F.mvpMapPoints = [L.mvpMapPoints[km[k]] if km[k] >= 0 else None for k in range(F.N)]
+        T, outl = self._pose_optimization(F)
+        return self._discard_after_initial_pose(F, T, outl)
+
+    def TrackReferenceKeyFrame(self, F):
+        kf = self.mpReferenceKF
+        self._compute_bow(F)
+        self._compute_bow(kf)
+        valid = np.array([p is not None and not p.mbBad for p in kf.mvpMapPoints], np.uint8)
+        nm, mf = O.search_by_bow(kf.mvKeysUn, kf.mDescriptors, valid, kf.bowNode, F.mvKeysUn, F.mDescriptors, F.bowNode, 0.7, True)
+        if nm < 15:
+            return False
+        F.mvpMapPoints = [kf.mvpMapPoints[mf[k]] if mf[k] >= 0 else None for k in range(F.N)]
+        F.pose.set_frame(self.mLastFrame.pose.Tcw)
+        T, outl = self._pose_optimization(F)
+        return self._discard_after_initial_pose(F, T, outl)
+
+    def UpdateLocalMap(self, F):
+        counter = {}
+        for i, p in enumerate(F.mvpMapPoints):
+            if p is None:
+                continue
+            if p.mbBad:
+                F.mvpMapPoints[i] = None
+                continue
+            for k in p.mObservations:
+                counter[k] = counter.get(k, 0) + 1
+        if counter:
+            mx, kmax = 0, None
+            self.mvpLocalKeyFrames = []
+            for k, c in sorted(counter.items(), key=lambda e: e[0].mnId):
+                if k.mbBad:
+                    continue
+                if c > mx:
+                    mx, kmax = c, k
+                self.mvpLocalKeyFrames.append(k)
+                k.mnTrackReferenceForFrame = F.mnId
+            for k in list(self.mvpLocalKeyFrames):
+                if len(self.mvpLocalKeyFrames) > 80:
+                    break
+                for nb in k.GetBestCovisibilityKeyFrames(10):
+                    if not nb.mbBad and nb.mnTrackReferenceForFrame != F.mnId:
+                        self.mvpLocalKeyFrames.append(nb)
+                        nb.mnTrackReferenceForFrame = F.mnId
+                        break
+                for ch in sorted(k.mspChildrens, key=lambda c_: c_.mnId):
+                    if not ch.mbBad and ch.mnTrackReferenceForFrame != F.mnId:
+                        self.mvpLocalKeyFrames.append(ch)
+                        ch.mnTrackReferenceForFrame = F.mnId
+                        break
+                par = k.mpParent
+                if par is not None and par.mnTrackReferenceForFrame != F.mnId:
+                    self.mvpLocalKeyFrames.append(par)
+                    par.mnTrackReferenceForFrame = F.mnId
+                    break
+            if kmax is not None:
+                self.mpReferenceKF = kmax
+                F.mpReferenceKF = kmax
+        self.mvpLocalMapPoints = []
+        for k in self.mvpLocalKeyFrames:
+            for p in k.mvpMapPoints:
+                if p is None or p.mnTrackReferenceForFrame == F.mnId:
+                    continue
+                if not p.mbBad:
+                    self.mvpLocalMapPoints.append(p)
+                    p.mnTrackReferenceForFrame = F.mnId
+
+    def TrackLocalMap(self, F):
+        self.UpdateLocalMap(F)
+        blocked = np.zeros(F.N, np.uint8)
+        for k, p in enumerate(F.mvpMapPoints):          # SearchLocalPoints
+            if p is None:
+                continue
+            if p.mbBad:
+                F.mvpMapPoints[k] = None
+                continue
+            p.mnVisible += 1
+            p.mnLastFrameSeen = F.mnId
+            blocked[k] = p.nObs > 0
+        cand = [p for p in self.mvpLocalMapPoints if p.mnLastFrameSeen != F.mnId and not p.mbBad]
+        if cand:
+            M = len(cand)
+            Pw = np.stack([p.mWorldPos for p in cand])
+            Pn = np.stack([p.mNormalVector for p in cand])
+            mx = np.array([p.mfMaxDistance for p in cand], f32)
+            mn = np.array([p.mfMinDistance for p in cand], f32)
+            og = np.array([p.nObs > 0 for p in cand], np.uint8)
+            dd = np.stack([p.mDescriptor for p in cand])
+            th = 5.0 if F.mnId < self.mnLastRelocFrameId + 2 else (1.0 if self.stereo else 3.0)
+            q = O.is_in_frustum(Pw, Pn, mx, mn, og, dd, F.pose.Tcw, self.K5, self.bounds, 0.5, self.logScale, self.scale, th)
+            inview = (q["flags"] & 1) != 0
+            for e in range(M):
+                if inview[e]:
+                    cand[e].mnVisible += 1
+            if inview.any():
+                nm, qm, qd, km = O.search_by_projection(F.mvKeysUn, F.mvuRight, F.mDescriptors, blocked, self.bounds, q, 0.8, True, False)
+                for k in range(F.N):
+                    if km[k] >= 0:
+                        F.mvpMapPoints[k] = cand[km[k]]
+        T, outl = self._pose_optimization(F)
+        F.pose.set_frame(T)
+        self.mnMatchesInliers = 0
+        for k, p in enumerate(F.mvpMapPoints):
+            if p is None:
+                continue
+            F.mvbOutlier[k] = bool(outl[k])
+            if not outl[k]:
+                p.mnFound += 1
+                if p.nObs > 0:
+                    self.mnMatchesInliers += 1
+            elif self.stereo:
+                F.mvpMapPoints[k] = None
+        self.st["last_inliers"] = self.mnMatchesInliers
+        if F.mnId < self.mnLastRelocFrameId + self.maxFrames and self.mnMatchesInliers < 50:
+            return False
+        return self.mnMatchesInliers >= 30
+
+    def NeedNewKeyFrame(self, F):
+        nKFs = self.nKFsInMap
+        if F.mnId < self.mnLastRelocFrameId + self.maxFrames and nKFs > self.maxFrames:
+            return False
+        nRefMatches = self.mpReferenceKF.TrackedMapPoints(2 if nKFs <= 2 else 3)
+        nNon = nTr = 0
+        for k in range(F.N):
+            if F.mvDepth[k] > 0 and F.mvDepth[k] < self.thDepth:
+                if F.mvpMapPoints[k] is not None and not F.mvbOutlier[k]:
+                    nTr += 1
+                else:
+                    nNon += 1
+        close = nTr < 100 and nNon > 70
+        thRef = f32(0.4) if nKFs < 2 else f32(0.75)
+        c1a = F.mnId >= self.mnLastKeyFrameId + self.maxFrames
+        c1b = F.mnId >= self.mnLastKeyFrameId + self.minFrames
+        c1c = self.mnMatchesInliers < nRefMatches * 0.25 or close
+        c2 = (f32(self.mnMatchesInliers) < f32(nRefMatches) * thRef or close) and self.mnMatchesInliers > 15
+        return (c1a or c1b or c1c) and c2
+
+    def Track(self, images, stamp):
+        """System::TrackRGBD / TrackStereo for one frame.  Returns (Tcw or None, state)."""
+        F = self._make_frame(images, stamp)
+        self.st["frames"] += 1
+        created = []
+        if self.mState == NOT_INITIALIZED:
+            if F.N > 500:                                            # StereoInitialization
+                F.pose.set_frame(np.eye(4, dtype=f32))
+                kf = self._new_keyframe(F)
+                self._create_stereo_points(F, kf, True, created)
+                self.mlNewKeyFrames.append(kf)
+                self.mnLastKeyFrameId = F.mnId
+                self.mvpLocalKeyFrames = [kf]
+                self.mvpLocalMapPoints = [p for p in kf.mvpMapPoints if p is not None]
+                self.mpReferenceKF = kf
+                F.mpReferenceKF = kf
+                self.mState = OK
+        elif self.mState == OK:
+            L = self.mLastFrame
+            for k, p in enumerate(L.mvpMapPoints):                     # CheckReplacedInLastFrame
+                if p is not None and p.mpReplaced is not None:
+                    L.mvpMapPoints[k] = p.mpReplaced
+            ok = False
+            if self.mVelocity is None or F.mnId < self.mnLastRelocFrameId + 2:
+                ok = self.TrackReferenceKeyFrame(F)
+                self.st["tracked_reference_kf"] += ok
+            else:
+                ok = self.TrackWithMotionModel(F)
+                if ok:
+                    self.st["tracked_motion_model"] += 1
+                else:
+                    ok = self.TrackReferenceKeyFrame(F)
+                    self.st["tracked_reference_kf"] += ok
+            F.mpReferenceKF = self.mpReferenceKF
+            if ok:
+                ok = self.TrackLocalMap(F)
+            self.mState = OK if ok else LOST
+            if ok:
+                self.mVelocity = mul4(F.pose.Tcw, L.pose.Twc) if L.pose.Tcw is not None else None
+                for k, p in enumerate(F.mvpMapPoints):
+                    if p is not None and p.nObs < 1:
+                        F.mvbOutlier[k] = False
+                        F.mvpMapPoints[k] = None
+                if self.NeedNewKeyFrame(F):                             # CreateNewKeyFrame
+                    kf = self._new_keyframe(F)
+                    self.mpReferenceKF = kf
+                    F.mpReferenceKF = kf
+                    self._create_stereo_points(F, kf, False, created)
+                    self.mlNewKeyFrames.append(kf)
+                    self.mnLastKeyFrameId = F.mnId
+                for k in range(F.N):
+                    if F.mvpMapPoints[k] is not None and F.mvbOutlier[k]:
+                        F.mvpMapPoints[k] = None
+            else:
+                self.st["lost_frames"] += 1
+            if F.mpReferenceKF is None:
+                F.mpReferenceKF = self.mpReferenceKF
+        self._update_points(created, True, True)
+        if F.pose.Tcw is not None:
+            self.mlRelativeFramePoses.append((mul4(F.pose.Tcw, F.mpReferenceKF.pose.Twc), self.mpReferenceKF, stamp, self.mState == LOST))
+        elif self.mlRelativeFramePoses:
+            a = self.mlRelativeFramePoses[-1]
+            self.mlRelativeFramePoses.append((a[0], a[1], a[2], self.mState == LOST))
+        if self.mState != NOT_INITIALIZED:
+            self.mLastFrame = F
+        Tcw = None if F.pose.Tcw is None else F.pose.Tcw.copy()
+        if self.mlNewKeyFrames:
+            self.LocalMapping()
+        return Tcw, self.mState
+
+    # ------------------------------------------------------------------ LocalMapping
+    def PredictScale(self, maxD, dist):
+        ratio = f32(maxD) / f32(dist)
+        n = int(math.ceil(float(logf(ratio) / self.logScale)))
+        return min(max(n, 0), self.nLevels - 1)
+
+    def _fuse_queries(self, kf, pts, th):
+        q, qp = [], []
+        T = kf.pose.Tcw
+        for p in pts:
+            if p is None or p.mbBad or kf in p.mObservations:
+                continue
+            pc = np.zeros(3, f32)
+            for r in range(3):
+                s = T[r, 0] * p.mWorldPos[0]
+                s = s + T[r, 1] * p.mWorldPos[1]
+                s = s + T[r, 2] * p.mWorldPos[2]
+                pc[r] = f32(float(s) + float(T[r, 3]))
+            if pc[2] < 0:
+                continue
+            invz = f32(1) / pc[2]
+            x, y = pc[0] * invz, pc[1] * invz
+            u, v = self.fx * x + self.cx, self.fy * y + self.cy
+            if not (u >= self.bounds[0] and u < self.bounds[2] and v >= self.bounds[1] and v < self.bounds[3]):
+                continue
+            ur = u - self.bf * invz
+            maxD, minD = f32(1.2) * p.mfMaxDistance, f32(0.8) * p.mfMinDistance
+            PO = (p.mWorldPos - kf.pose.Ow).astype(f32)
+            dist = norm3(PO)
+            if dist < minD or dist > maxD:
+                continue
+            dot = float(PO[0]) * float(p.mNormalVector[0]) + float(PO[1]) * float(p.mNormalVector[1]) + float(PO[2]) * float(p.mNormalVector[2])
+            if dot < 0.5 * float(dist):
+                continue
+            lvl = self.PredictScale(p.mfMaxDistance, dist)
+            e = np.zeros(1, QUERY_DTYPE)[0]
+            e["u"], e["v"], e["ur"], e["radius"], e["minLevel"], e["maxLevel"], e["flags"] = u, v, ur, f32(th) * self.scale[lvl], lvl - 1, lvl, 1
+            e["desc"] = p.mDescriptor
+            q.append(e)
+            qp.append(p)
+        return (np.array(q, QUERY_DTYPE) if q else np.zeros(0, QUERY_DTYPE)), qp
+
+    def Fuse(self, kf, pts, th=3.0):
+        q, qp = self._fuse_queries(kf, pts, th)
+        if not len(q):
+            return
+        _, qm, _ = O.fuse_search(kf.mvKeysUn, kf.mvuRight, kf.mDescriptors, self.bounds, q, self.invSigma2)
+        changed = []
+        for i, p in enumerate(qp):
+            best = qm[i]
+            if best < 0 or p.mbBad:
+                continue
+            inKF = kf.mvpMapPoints[best]
+            if inKF is not None:
+                if not inKF.mbBad:
+                    if inKF.nObs > p.nObs:
+                        if p.Replace(inKF, self):
+                            changed.append(inKF)
+                    else:
+                        if inKF.Replace(p, self):
+                            changed.append(p)
+            else:
+                p.AddObservation(kf, best)
+                kf.mvpMapPoints[best] = p
+            self.st["points_fused"] += 1
+        self._update_points(changed, True, False)
+
+    def ComputeF12(self, k1, k2):
+        r = lambda x: float(f32(x))
+        R1 = [[float(k1.pose.Tcw[i, j]) for j in range(3)] for i in range(3)]
+        R2t = [[float(k2.pose.Tcw[j, i]) for j in range(3)] for i in range(3)]
+        t1 = [float(k1.pose.Tcw[i, 3]) for i in range(3)]
+        t2 = [float(k2.pose.Tcw[i, 3]) for i in range(3)]
+
+        def mm(a, b):
+            out = [[0.0] * 3 for _ in range(3)]
+            for i in range(3):
+                for j in range(3):
+                    s = 0.0
+                    for k in range(3):
+                        s += a[i][k] * b[k][j]
+                    out[i][j] = r(s)
+            return out
+        R12 = mm(R1, R2t)
+        t12 = []
+        for i in range(3):
+            s = 0.0
+            for k in range(3):
+                s += -R12[i][k] * t2[k]
+            t12.append(r(r(s) + t1[i]))
+        tx = [[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]]
+        fx, fy, cx, cy = float(self.fx), float(self.fy), float(self.cx), float(self.cy)
+        Ki = [[r(1.0 / fx), 0, r(-cx / fx)], [0, r(1.0 / fy), r(-cy / fy)], [0, 0, 1]]
+        KiT = [[Ki[0][0], 0, 0], [0, Ki[1][1], 0], [Ki[0][2], Ki[1][2], 1]]
+        F = mm(mm(mm(KiT, tx), R12), Ki)
+        return np.array(F, f32)
+
+    def LocalMapping(self):
+        cur = self.mlNewKeyFrames.pop(0)
+        self.mlNewKeyFrames = []
+        self._compute_bow(cur)
+        upd = []
+        for i, p in enumerate(cur.mvpMapPoints):                       # ProcessNewKeyFrame
+            if p is None or p.mbBad:
+                continue
+            if cur not in p.mObservations:
+                p.AddObservation(cur, i)
+                upd.append(p)
+            else:
+                self.mlpRecentAddedMapPoints.append(p)
+        self._update_points(upd, True, True)
+        cur.UpdateConnections()
+        self.nKFsInMap += 1
+        if self.flags & 1:                                             # MapPointCulling
+            keep = []
+            for p in self.mlpRecentAddedMapPoints:
+                if p.mbBad:
+                    continue
+                if f32(p.mnFound) / f32(p.mnVisible) < f32(0.25):
+                    p.SetBadFlag(self)
+                    self.st["points_culled"] += 1
+                elif cur.mnId - p.mnFirstKFid >= 2 and p.nObs <= 3:
+                    p.SetBadFlag(self)
+                    self.st["points_culled"] += 1
+                elif cur.mnId - p.mnFirstKFid >= 3:
+                    pass
+                else:
+                    keep.append(p)
+            self.mlpRecentAddedMapPoints = keep
+        if self.flags & 2:                                             # CreateNewMapPoints
+            for k2 in cur.GetBestCovisibilityKeyFrames(10):
+                vb = (k2.pose.Ow - cur.pose.Ow).astype(f32)
+                if norm3(vb) < self.mb:
+                    continue
+                self._compute_bow(k2)
+                F12 = self.ComputeF12(cur, k2)
+                C2 = np.zeros(3, f32)
+                for r in range(3):
+                    s = k2.pose.Tcw[r, 0] * cur.pose.Ow[0]
+                    s = s + k2.pose.Tcw[r, 1] * cur.pose.Ow[1]
+                    s = s + k2.pose.Tcw[r, 2] * cur.pose.Ow[2]
+                    C2[r] = f32(float(s) + float(k2.pose.Tcw[r, 3]))
+                invz = f32(1.0) / C2[2]
+                ex, ey = self.fx * C2[0] * invz + self.cx, self.fy * C2[1] * invz + self.cy
+                has1 = np.array([p is not None for p in cur.mvpMapPoints], np.uint8)
+                has2 = np.array([p is not None for p in k2.mvpMapPoints], np.uint8)
+                nm, m12 = O.search_for_triangulation(cur.mvKeysUn, cur.mDescriptors, cur.mvuRight, has1, cur.bowNode, k2.mvKeysUn, k2.mDescriptors,
+                                                     k2.mvuRight, has2, k2.bowNode, F12, float(ex), float(ey), self.scale, self.sigma2, False, False)
+                i1 = [i for i in range(cur.N) if m12[i] >= 0]
+                i2 = [int(m12[i]) for i in i1]
+                if not i1:
+                    continue
+                cam8 = (self.fx, self.fy, self.cx, self.cy, self.invfx, self.invfy, self.bf, self.mb)
+                pk = lambda k: (k.pose.Tcw, k.pose.Twc, cam8, k.mvKeysUn, k.mvKeys, k.mvuRight, k.mvDepth)
+                ok, x3 = O.triangulate(pk(cur), pk(k2), i1, i2, self.scale, self.sigma2, f32(1.5) * self.scaleFactor)
+                new = []
+                for e in range(len(i1)):
+                    if not ok[e]:
+                        continue
+                    p = MapPoint(x3[e], cur)
+                    p.AddObservation(cur, i1[e])
+                    p.AddObservation(k2, i2[e])
+                    cur.mvpMapPoints[i1[e]] = p
+                    k2.mvpMapPoints[i2[e]] = p
+                    self.nMPsInMap += 1
+                    self.st["points_created"] += 1
+                    self.st["points_triangulated"] += 1
+                    self.mlpRecentAddedMapPoints.append(p)
+                    new.append(p)
+                self._update_points(new, True, True)
+        if self.flags & 4:                                             # SearchInNeighbors
+            targets = []
+            for k in cur.GetBestCovisibilityKeyFrames(10):
+                if k.mbBad or k.mnFuseTargetForKF == cur.mnId:
+                    continue
+                targets.append(k)
+                k.mnFuseTargetForKF = cur.mnId
+                for k2 in k.GetBestCovisibilityKeyFrames(5):
+                    if k2.mbBad or k2.mnFuseTargetForKF == cur.mnId or k2.mnId == cur.mnId:
+                        continue
+                    targets.append(k2)
+            snapshot = list(cur.mvpMapPoints)
+            for k in targets:
+                self.Fuse(k, snapshot)
+            cand = []
+            for k in targets:
+                for p in k.mvpMapPoints:
+                    if p is None or p.mbBad or p.mnFuseCandidateForKF == cur.mnId:
+                        continue
+                    p.mnFuseCandidateForKF = cur.mnId
+                    cand.append(p)
+            if targets:
+                self.Fuse(cur, cand)
+            self._update_points([p for p in cur.mvpMapPoints if p is not None and not p.mbBad], True, True)
+            cur.UpdateConnections()
+        if self.flags & 8 and self.nKFsInMap > 2:                      # LocalBundleAdjustment
+            self.LocalBundleAdjustment(cur)
+        if self.flags & 16:                                            # KeyFrameCulling
+            for k in list(cur.mvpOrderedConnectedKeyFrames):
+                if k.mnId == 0:
+                    continue
+                nRed = nMPs = 0
+                for i, p in enumerate(k.mvpMapPoints):
+                    if p is None or p.mbBad:
+                        continue
+                    if k.mvDepth[i] > self.thDepth or k.mvDepth[i] < 0:
+                        continue
+                    nMPs += 1
+                    if p.nObs > 3:
+                        lvl = k.mvKeysUn["octave"][i]
+                        n = 0
+                        for ko, io in p.obs_sorted():
+                            if ko is k:
+                                continue
+                            if ko.mvKeysUn["octave"][io] <= lvl + 1:
+                                n += 1
+                                if n >= 3:
+                                    break
+                        if n >= 3:
+                            nRed += 1
+                if nRed > 0.9 * nMPs:
+                    k.SetBadFlag(self)
+
+    def LocalBundleAdjustment(self, cur):
+        kfs = [cur]
+        cur.mnBALocalForKF = cur.mnId
+        for k in cur.mvpOrderedConnectedKeyFrames:
+            k.mnBALocalForKF = cur.mnId
+            if not k.mbBad:
+                kfs.append(k)
+        nLocal = len(kfs)
+        pts = []
+        for k in kfs[:nLocal]:
+            for p in k.mvpMapPoints:
+                if p is not None and not p.mbBad and p.mnBALocalForKF != cur.mnId:
+                    pts.append(p)
+                    p.mnBALocalForKF = cur.mnId
+        for p in pts:
+            for k, _ in p.obs_sorted():
+                if k.mnBALocalForKF != cur.mnId and k.mnBAFixedForKF != cur.mnId:
+                    k.mnBAFixedForKF = cur.mnId
+                    if not k.mbBad:
+                        kfs.append(k)
+        slot = {k: i for i, k in enumerate(kfs)}
+        poses = np.stack([k.pose.Tcw for k in kfs])
+        fixed = np.array([1 if i >= nLocal else (2 if k.mnId == 0 else 0) for i, k in enumerate(kfs)], np.uint8)
+        points = np.stack([p.mWorldPos for p in pts])
+        ekf, ept, eobs, einv, eref = [], [], [], [], []
+        for j, p in enumerate(pts):
+            for k, idx in p.obs_sorted():
+                if k.mbBad or k not in slot:
+                    continue
+                ekf.append(slot[k])
+                ept.append(j)
+                eobs.append((k.mvKeysUn["x"][idx], k.mvKeysUn["y"][idx], k.mvuRight[idx]))
+                einv.append(self.invSigma2[k.mvKeysUn["octave"][idx]])
+                eref.append((k, p))
+        self.st["local_bas"] += 1
+        self.st["lba_edges"] += len(ekf)
+        po, xo, erase, _ = O.local_bundle_adjustment(poses, fixed, points, ekf, ept, np.array(eobs, f32), np.array(einv, f32), self.K5)
+        for stereo_pass in (False, True):
+            for e in range(len(ekf)):
+                if not erase[e] or (eobs[e][2] >= 0) != stereo_pass:
+                    continue
+                k, p = eref[e]
+                idx = p.mObservations.get(k, -1)
+                if idx >= 0:
+                    k.mvpMapPoints[idx] = None
+                p.EraseObservation(k, self)
+        for i in range(nLocal):
+            kfs[i].pose.set_keyframe(po[i])
+        for j, p in enumerate(pts):
+            p.mWorldPos = np.array(xo[j], f32)
+        self._update_points(pts, False, True)
+
+    # ------------------------------------------------------------------ outputs
+    def trajectory(self):
+        """System::SaveTrajectoryTUM: list of (stamp, Twc[3,4])."""
+        if not self.keyframes:
+            return []
+        Two = self.keyframes[0].pose.Twc
+        out = []
+        for Tcr, ref, stamp, lost in self.mlRelativeFramePoses:
+            if lost:
+                continue
+            k = ref
+            Trw = np.eye(4, dtype=f32)
+            while k.mbBad:
+                Trw = mul4(Trw, k.mTcp)
+                k = k.mpParent
+            Trw = mul4(mul4(Trw, k.pose.Tcw), Two)
+            Tcw = mul4(Tcr, Trw)
+            T = np.zeros((3, 4), f32)
+            T[:, :3] = Tcw[:3, :3].T
+            for r in range(3):
+                s = Tcw[0, r] * Tcw[0, 3]
+                s = s + Tcw[1, r] * Tcw[1, 3]
+                s = s + Tcw[2, r] * Tcw[2, 3]
+                T[r, 3] = f32(float(s) * -1.0)
+            out.append((stamp, T))
+        return out
+
+    def stats(self):
+        s = dict(self.st)
+        s["keyframes_in_map"], s["points_in_map"] = self.nKFsInMap, self.nMPsInMap
+        del s["points_culled_total"]
+        return s

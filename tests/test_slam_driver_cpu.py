@@ -117,3 +117,51 @@ def test_not_initialised_and_lost_states(oracle):
     assert st["lost_frames"] == 1 and st["map_violations"] == 0      # counted once: a LOST sequence is not tracked again
     stamps, Twc = sysm.trajectory(0)
     assert len(stamps) == 6
+
+
+def _cfg_dict(cfg):
+    return dict(width=cfg.width, height=cfg.height, fx=cfg.fx, fy=cfg.fy, cx=cfg.cx, cy=cfg.cy, bf=cfg.bf, thDepth=cfg.thDepth, fps=cfg.fps,
+                nFeatures=cfg.nFeatures, scaleFactor=cfg.scaleFactor, nLevels=cfg.nLevels, iniThFAST=cfg.iniThFAST, minThFAST=cfg.minThFAST,
+                sensor=cfg.sensor, local_mapping=cfg.local_mapping)
+
+
+def test_driver_against_independent_restatement(oracle):
+    """The product's driver (index-based, staged, C++) against oracle/slam_driver_oracle.py (object-style Python restatement of the
+    reference's Tracking / LocalMapping flow), both over the CPU oracle operators: same states, same map statistics, same poses."""
+    from oracle import slam_driver_oracle as R
+    n = 26
+    cfg = slam.make_config(W, H, 1)
+    streams = make_streams(1, n)
+    depth = np.full((H, W), 2.0, np.float32)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
+    for t in range(n):
+        img = streams[0][0][t]
+        T, st = sysm.TrackRGBD([img], [depth], [t / 30.0])
+        Tr, sr = ref.Track((img, depth), t / 30.0)
+        assert int(st[0]) == sr, t
+        assert np.array_equal(T[0], Tr), (t, np.abs(T[0] - Tr).max())
+        a, b = sysm.stats(0), ref.stats()
+        assert all(a[k] == b[k] for k in b), (t, a, b)
+    assert sysm.stats(0)["keyframes_created"] >= 4 and sysm.stats(0)["points_fused"] > 0 and sysm.stats(0)["points_triangulated"] > 0
+    stamps, Twc = sysm.trajectory(0)
+    tr = ref.trajectory()
+    assert len(tr) == len(stamps)
+    assert np.array_equal(Twc, np.stack([x[1] for x in tr]))
+
+
+def test_stereo_driver_against_independent_restatement(oracle):
+    from oracle import slam_driver_oracle as R
+    from slam_common import make_stereo_streams, stereo_config
+    n = 10
+    cfg = stereo_config(1)
+    streams = make_stereo_streams(1, n)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
+    for t in range(n):
+        T, st = sysm.TrackStereo([streams[0][0][t]], [streams[0][1][t]], [t / 10.0])
+        Tr, sr = ref.Track((streams[0][0][t], streams[0][1][t]), t / 10.0)
+        assert int(st[0]) == sr and np.array_equal(T[0], Tr), t
+        a, b = sysm.stats(0), ref.stats()
+        assert all(a[k] == b[k] for k in b), (t, a, b)
+    assert sysm.stats(0)["keyframes_created"] >= 2
