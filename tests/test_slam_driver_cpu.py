@@ -153,7 +153,7 @@ def test_driver_against_independent_restatement(oracle):
 def test_stereo_driver_against_independent_restatement(oracle):
     from oracle import slam_driver_oracle as R
     from slam_common import make_stereo_streams, stereo_config
-    n = 10
+    n = 14
     cfg = stereo_config(1)
     streams = make_stereo_streams(1, n)
     sysm = slam.System(cfg, oracle_ops(cfg))
