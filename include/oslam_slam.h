@@ -19,7 +19,8 @@
  *   - DBoW2 and its vocabulary are not in the reference tree: ComputeBoW uses a substitute vocabulary (k = 10, two
  *     levels of seeded random 256-bit words, nearest child by Hamming distance) that yields the same FeatureVector
  *     structure (node id at the 4th level from the leaves -> keypoint indices);
- *   - out of scope: Relocalization (a lost sequence stays LOST), loop closing, the object layer
+ *   - out of scope: Relocalization (a sequence lost with more than 5 keyframes stays LOST; with <= 5 the
+ *     system resets like src/Tracking.cc:553-561 and re-initialises on the next frame), loop closing, the object layer
  *     (TrackObject / UpdateCurrentObject), the viewer.  PoseOptimization2 without matched objects is PoseOptimization.
  */
 #ifndef OSLAM_SLAM_H

@@ -114,6 +114,14 @@ struct Seq {
     std::vector<KP> jKeys;
     oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
     bool hasSL = false, hasLoc = false;
+    bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
+    void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
+        map = Map();
+        state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
+        localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear();
+        std::fill(counter.begin(), counter.end(), 0);
+        resetRequested = false;
+    }
     std::vector<int> updList;             // points created by tracking this step (descriptor / normal pending)
     std::vector<std::unique_ptr<BowViews>> kfBow;   // FeatureVector views per keyframe id (built once: the descriptors are immutable)
     BowViews& bow_views(const Ctx& c, int kf);
@@ -1027,6 +1035,7 @@ static void stage_after_tracking(Ctx& c, int i) {
             if (f.mp[k] >= 0 && f.outlier[k]) f.mp[k] = -1;
     } else {
         s.st[8]++;
+        if (m.nKFsInMap <= 5) s.resetRequested = true;   // "Track lost soon after initialisation, reseting..." (:553-561): Track() returns here
     }
     if (f.refKF < 0) f.refKF = s.refKF;
 }
@@ -1062,6 +1071,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     std::vector<int> tracking;   // sequences in the "system is initialised" branch
     pool.parallel_for(S, [&](int i) {
         Seq& s = *c.seq[i];
+        if (s.resetRequested) s.reset();   // System::TrackRGBD: if(mbReset) mpTracker->Reset() before the frame is grabbed (src/System.cc:262-266)
         const int fid = s.nextFrameId++;
         s.cur->begin(fid, stamps ? stamps[i] : (double)fid);
         s.st[0]++;
@@ -1211,7 +1221,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     for (int i = 0; i < S; i++) {
         Seq& s = *c.seq[i];
         Frame& f = *s.cur;
-        if (f.pose.valid) {
+        if (s.resetRequested) {
+            // Track() returned before the relative pose was stored and before mLastFrame was replaced
+        } else if (f.pose.valid) {
             RelPose r;
             r.Tcr = mul4(f.pose.Tcw, s.map.kfs[f.refKF].pose.Twc);
             r.refKF = s.refKF; r.stamp = f.stamp; r.lost = s.state == ST_LOST;

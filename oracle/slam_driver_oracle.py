@@ -353,10 +353,22 @@ class Slam:
         self.mlpRecentAddedMapPoints = []
         self.mlNewKeyFrames = []
         self.mLastFrame = None
+        self.mbReset = False
         self.keyframes = []
         self.nKFsInMap = self.nMPsInMap = 0
         self.st = dict(frames=0, keyframes_created=0, points_created=0, local_bas=0, tracked_motion_model=0, tracked_reference_kf=0, lost_frames=0,
                        points_fused=0, points_triangulated=0, keyframes_culled=0, points_culled=0, last_inliers=0, lba_edges=0, points_culled_total=0)
+
+    def Reset(self):
+        """Tracking::Reset (src/Tracking.cc:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; Frame / KeyFrame ids restart at 0."""
+        self.mState = NOT_INITIALIZED
+        self.nextFrameId = 0
+        self.mpReferenceKF = None
+        self.mvpLocalKeyFrames, self.mvpLocalMapPoints = [], []
+        self.mlRelativeFramePoses, self.mlpRecentAddedMapPoints, self.mlNewKeyFrames = [], [], []
+        self.keyframes = []
+        self.nKFsInMap = self.nMPsInMap = 0
+        self.mbReset = False
 
     # ------------------------------------------------------------------ operators
     def _compute_bow(self, obj):
@@ -637,6 +649,8 @@ class Slam:
 
     def Track(self, images, stamp):
         """System::TrackRGBD / TrackStereo for one frame.  Returns (Tcw or None, state)."""
+        if self.mbReset:                                             # System::TrackRGBD: if(mbReset) mpTracker->Reset() (src/System.cc:262-266)
+            self.Reset()
         F = self._make_frame(images, stamp)
         self.st["frames"] += 1
         created = []
@@ -690,9 +704,13 @@ class Slam:
                         F.mvpMapPoints[k] = None
             else:
                 self.st["lost_frames"] += 1
+                if self.nKFsInMap <= 5:                                 # :553-561: mpSystem->Reset(); return
+                    self.mbReset = True
             if F.mpReferenceKF is None:
                 F.mpReferenceKF = self.mpReferenceKF
         self._update_points(created, True, True)
+        if self.mbReset:
+            return (None if F.pose.Tcw is None else F.pose.Tcw.copy()), self.mState
         if F.pose.Tcw is not None:
             self.mlRelativeFramePoses.append((mul4(F.pose.Tcw, F.mpReferenceKF.pose.Twc), self.mpReferenceKF, stamp, self.mState == LOST))
         elif self.mlRelativeFramePoses:

@@ -96,27 +96,38 @@ def test_map_bookkeeping_unit_checks(tmp_path):
     assert out.returncode == 0, out.stderr
 
 
-def test_not_initialised_and_lost_states(oracle):
+def test_not_initialised_lost_and_reset(oracle):
     """A textureless first frame leaves the sequence NOT_INITIALIZED (StereoInitialization needs > 500 keypoints, reference
-    src/Tracking.cc:592); textureless frames in the middle lose the track and — Relocalization being out of scope — it stays LOST;
-    the trajectory skips lost frames like System::SaveTrajectoryTUM."""
+    src/Tracking.cc:592).  Losing the track with <= 5 keyframes resets the system (:553-561): the next textured frame initialises a new
+    map whose ids restart at 0.  The independent restatement goes through the same states with the same poses."""
+    from oracle import slam_driver_oracle as R
     cfg = slam.make_config(W, H, 1)
     streams = make_streams(1, 12)
     blank = np.full((H, W), 90, np.uint8)
-    seq = [blank] + list(streams[0][0][:6]) + [blank, blank] + list(streams[0][0][6:9])
+    seq = [blank] + list(streams[0][0][:6]) + [blank, blank] + list(streams[0][0][6:10])
     depth = np.full((H, W), 2.0, np.float32)
     sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
     states = []
     for t, img in enumerate(seq):
         T, st = sysm.TrackRGBD([img], [depth], [t / 30.0])
+        Tr, sr = ref.Track((img, depth), t / 30.0)
         states.append(int(st[0]))
+        assert int(st[0]) == sr, t
+        if Tr is not None:
+            assert np.array_equal(T[0], Tr), t
     assert states[0] == slam.NOT_INITIALIZED
     assert states[1:7] == [slam.OK] * 6
-    assert states[7:] == [slam.LOST] * 5
+    assert states[7] == slam.LOST                      # lost with <= 5 keyframes -> reset requested
+    assert states[8] == slam.NOT_INITIALIZED           # reset applied, textureless frame cannot initialise
+    assert states[9:] == [slam.OK] * 4                 # new map
     st = sysm.stats(0)
-    assert st["lost_frames"] == 1 and st["map_violations"] == 0      # counted once: a LOST sequence is not tracked again
+    assert st["lost_frames"] == 1 and st["map_violations"] == 0 and st["keyframes_in_map"] >= 1
     stamps, Twc = sysm.trajectory(0)
-    assert len(stamps) == 6
+    assert len(stamps) == 4                            # the trajectory of the new map only (mlRelativeFramePoses was cleared)
+    assert np.array_equal(Twc[0], np.eye(4, dtype=np.float32)[:3])
+    tr = ref.trajectory()
+    assert len(tr) == 4 and np.array_equal(Twc, np.stack([x[1] for x in tr]))
 
 
 def _cfg_dict(cfg):
