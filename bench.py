@@ -239,6 +239,13 @@ def main():
         per_frame_us["match(K8-K10)"] = float(np.mean(match_ms)) / B * 1e3
         M = N = n_kp
         alg["match(K8-K10)"] = 44 * M + 36 * N + 12288 + 8 * M
+        # matching work model: descriptor pairs compared per second against the v_bcnt_u32_b32 issue peak
+        # (8 popcounts per pair; 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s -> 4.9 T pairs/s if nothing else issued)
+        pairs = C.c_int64(0)
+        check(mt.L.oslam_match_hamming_pairs(mt.h, B, C.byref(pairs)))
+        match_pairs_per_s = pairs.value / (float(np.mean(match_ms)) * 1e-3)
+        match_model = {"hamming_pairs_per_frame": round(pairs.value / B, 1), "hamming_pairs_per_s": round(match_pairs_per_s, 1),
+                       "frac_of_bcnt_issue_peak": round(match_pairs_per_s * 8 / (256 * 4 * 16 * 2.4e9), 5)}
         dom = max(per_frame_us.keys(), key=lambda n: per_frame_us[n])
         achieved = alg[dom] / (per_frame_us[dom] * 1e-6) / 1e9
         kname = {"pyramid(K1)": "k_resize", "fast_cells(K2/K3)": "k_fast_cells_wave", "blur(K6)": "k_blur_strip<false>",
@@ -250,7 +257,8 @@ def main():
                 "launch_us": round(per_frame_us[dom] * B, 1),
                 "per_frame_us": {k: round(v, 3) for k, v in per_frame_us.items()},
                 "alg_bytes_per_frame": {k: int(v) for k, v in alg.items()},
-                "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * world * args.steps / elapsed / 1e9, 1)}
+                "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * world * args.steps / elapsed / 1e9, 1),
+                "matching": match_model}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0, N=1 only (bounded sample)

@@ -214,6 +214,9 @@ int oslam_match_fuse_batch_device(oslam_matcher_t* h, const oslam_match_frames_t
                                   const oslam_proj_query_t* d_queries, int q_stride, const int32_t* d_n_queries,
                                   int n_queries_const, int batch, const float* invLevelSigma2, int nlevels,
                                   void* stream);
+/* Descriptor pairs compared (256-bit XOR + popcount) by the first pass of the last search over `batch` frames — the work unit of the
+ * matching roofline; synchronises the device. */
+int oslam_match_hamming_pairs(oslam_matcher_t* h, int batch, int64_t* total);
 /* Phase wall-clock counters (100 MHz ticks) of frame 0, profiling builds (-DOSLAM_MATCH_PROFILE); zeros otherwise. */
 int oslam_match_debug_counters(oslam_matcher_t* h, long long out[8], int reset);
 int oslam_match_debug_get_queries(oslam_matcher_t* h, int b, int q_stride, int n, oslam_proj_query_t* out);

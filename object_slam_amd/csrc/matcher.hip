@@ -38,6 +38,7 @@ struct MatchCtx {
     // outputs
     int* q_match; int* q_dist; int* kp_match; int* nmatches;
     int* iters;               // [B] fixpoint iterations used (diagnostic)
+    int* pairs;               // [B] descriptor pairs compared in the first pass (work model of SURVEY.md §8(d))
     uint32_t* cache;          // [B][q_stride][kCacheCap] gate-passing candidates of every query: dist << 16 | index, reference order
     int* ccount;              // [B][q_stride] cached count, or -1 if the query has more than kCacheCap candidates
     long long* dbg;           // [8] phase stamps of frame 0 (profiling builds, -DOSLAM_MATCH_PROFILE)
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     uint8_t* s_oct = (uint8_t*)(s_items + ncap);            // [ncap]
     uint8_t* s_blk = s_oct + ncap;                          // [ncap]
     __shared__ int s_hist[kHistoLen];
-    __shared__ int s_changed, s_nm, s_ind[3];
+    __shared__ int s_changed, s_nm, s_ind[3], s_pairs;
+    if (threadIdx.x == 0) s_pairs = 0;   // (barriers of the staging phase follow before the first use)
     __shared__ int s_wtot[kMatchThreads / 64];
 
 #ifdef OSLAM_MATCH_PROFILE
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
 
     MSTAMP(1);
 #if defined(OSLAM_MATCH_ABLATE) && OSLAM_MATCH_ABLATE == 1
-    if (tid == 0) { c.nmatches[b] = 0; if (c.iters) c.iters[b] = 0; }
+    if (tid == 0) { c.nmatches[b] = 0; if (c.iters) c.iters[b] = 0; if (c.pairs) c.pairs[b] = 0; }
     return;   // timing experiment: staging + grid only
 #endif
     // ---- fixpoint over the sequential claim order (:87-89, :123 / :1402-1404, :1428) ----
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
                     } else
                         bestIdx = -1;
                 }
-                if (it == 0) ccount[j] = nc <= kCacheCap ? nc : -1;
+                if (it == 0) { ccount[j] = nc <= kCacheCap ? nc : -1; if (nc) atomicAdd(&s_pairs, nc); }
             }
             q_match[j] = bestIdx;
             q_dist[j] = bestIdx >= 0 ? bestDist : 256;
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     if (tid == 0) {
         c.nmatches[b] = s_nm;
         if (c.iters) c.iters[b] = it + 1;
+        if (c.pairs) c.pairs[b] = s_pairs;
     }
     MSTAMP(4);
 }
@@ -470,7 +473,7 @@ struct oslam_matcher {
     int device = 0, max_batch = 0, max_kps = 0, max_q = 0;
     size_t lds = 0;
     // device-owned
-    int* d_q_match = nullptr; int* d_q_dist = nullptr; int* d_kp_match = nullptr; int* d_nm = nullptr; int* d_iters = nullptr;
+    int* d_q_match = nullptr; int* d_q_dist = nullptr; int* d_kp_match = nullptr; int* d_nm = nullptr; int* d_iters = nullptr; int* d_pairs = nullptr;
     uint32_t* d_cache = nullptr; int* d_ccount = nullptr;
     oslam_proj_query_t* d_queries = nullptr;   // internal query buffer (project_last / host API)
     long long* d_dbg = nullptr;
@@ -485,7 +488,7 @@ extern "C" {
 
 void oslam_matcher_destroy(oslam_matcher_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_dbg, h->d_cache, h->d_ccount, h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
+    void* ptrs[] = {h->d_dbg, h->d_cache, h->d_ccount, h->d_q_match, h->d_q_dist, h->d_kp_match, h->d_nm, h->d_iters, h->d_pairs, h->d_queries, h->d_nq, h->d_kps, h->d_ur,
                     h->d_desc, h->d_blocked, h->d_Xw, h->d_has, h->d_lkeys, h->d_ldesc, h->d_T};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -520,7 +523,7 @@ int oslam_matcher_create(oslam_matcher_t** out, int max_batch, int max_keypoints
     } while (0)
     ALLOC(h->d_q_match, B * NQ * 4); ALLOC(h->d_q_dist, B * NQ * 4); ALLOC(h->d_kp_match, B * NK * 4);
     ALLOC(h->d_cache, B * NQ * kCacheCap * 4); ALLOC(h->d_ccount, B * NQ * 4);
-    ALLOC(h->d_nm, B * 4); ALLOC(h->d_iters, B * 4); ALLOC(h->d_dbg, 64); ALLOC(h->d_queries, B * NQ * sizeof(oslam_proj_query_t)); ALLOC(h->d_nq, B * 4);
+    ALLOC(h->d_nm, B * 4); ALLOC(h->d_iters, B * 4); ALLOC(h->d_pairs, B * 4); ALLOC(h->d_dbg, 64); ALLOC(h->d_queries, B * NQ * sizeof(oslam_proj_query_t)); ALLOC(h->d_nq, B * 4);
     ALLOC(h->d_kps, NK * sizeof(oslam_keypoint_t)); ALLOC(h->d_ur, NK * 4); ALLOC(h->d_desc, NK * 32); ALLOC(h->d_blocked, NK);
     ALLOC(h->d_Xw, NQ * 12); ALLOC(h->d_has, NQ); ALLOC(h->d_lkeys, NQ * sizeof(oslam_keypoint_t)); ALLOC(h->d_ldesc, NQ * 32); ALLOC(h->d_T, 32 * 4);
 #undef ALLOC
@@ -575,7 +578,7 @@ static int search_impl(oslam_matcher_t* h, const oslam_match_frames_t* f, const 
     c.nnratio = nnratio; c.use_ratio = use_ratio; c.check_ori = check_ori; c.th_high = th_high;
     c.fuse = invLevelSigma2 ? 1 : 0;
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) c.invSigma2[i] = (invLevelSigma2 && i < nlevels) ? invLevelSigma2[i] : 0.f;
-    c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters; c.dbg = h->d_dbg;
+    c.q_match = h->d_q_match; c.q_dist = h->d_q_dist; c.kp_match = h->d_kp_match; c.nmatches = h->d_nm; c.iters = h->d_iters; c.pairs = h->d_pairs; c.dbg = h->d_dbg;
     c.cache = h->d_cache; c.ccount = h->d_ccount;
     // per-frame output strides equal the input strides; outputs were sized for max_q / max_kps
     if ((size_t)f->kp_stride > (size_t)h->max_kps) { set_error("kp_stride %d > max_keypoints %d", f->kp_stride, h->max_kps); return OSLAM_E_CAPACITY; }
@@ -615,6 +618,18 @@ int oslam_match_results_device(const oslam_matcher_t* h, const int32_t** q_match
     if (nmatches) *nmatches = h->d_nm;
     if (queries) *queries = h->d_queries;
     if (n_queries) *n_queries = h->d_nq;
+    return OSLAM_OK;
+}
+
+int oslam_match_hamming_pairs(oslam_matcher_t* h, int batch, int64_t* total) {
+    if (!h || !total || batch < 1 || batch > h->max_batch) { set_error("bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    std::vector<int> v(batch);
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpy(v.data(), h->d_pairs, (size_t)batch * 4, hipMemcpyDeviceToHost));
+    int64_t t = 0;
+    for (int x : v) t += x;
+    *total = t;
     return OSLAM_OK;
 }
 
