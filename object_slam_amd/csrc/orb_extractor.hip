@@ -71,6 +71,7 @@ struct oslam_orb {
     int split_min = 1 << 30;                       // batches of at least this many images are cut in two halves (off by default: measured +4 % frames/s at
                                                    // B = 256, but the halves share the chip, so every kernel's own duration doubles; OSLAM_ORB_SPLIT_MIN enables it)
     int prof_batch_images = 0;
+    bool no_lds_resize = false;                    // OSLAM_ORB_NO_LDS_RESIZE: kernel experiments
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
     int profiling = 0;
@@ -277,20 +278,41 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
             bool fits = true;
             const int nq = div_up(g.w, 4);
             for (int q = 0; q < nq && fits; q++) {
-                const int xb = rtab[g.xtab_off + q * 4].x & ~3;
-                uint32_t t[4];
+                const int x0s = rtab[g.xtab_off + q * 4].x;
+                const int xb = x0s & ~3, o0 = x0s & 3;
+                uint32_t t[4], sl[4];
                 for (int i = 0; i < 4; i++) {
                     const int x = std::min(q * 4 + i, g.w - 1);
                     const int2 e = rtab[g.xtab_off + x];
-                    const int o = e.x - xb;
+                    const int d = e.x - x0s;   // left tap of pixel i inside the 8 bytes that start at the first pixel's left tap
                     const int a0 = (short)(e.y & 0xFFFF), a1 = (short)(e.y >> 16);
-                    if (o < 0 || o > 10 || a0 < 0 || a0 > 2048 || a1 < 0 || a1 > 2048) { fits = false; break; }
-                    t[i] = (uint32_t)o | ((uint32_t)a0 << 4) | ((uint32_t)a1 << 16);
+                    if (x0s < 0 || d < 0 || d > 6 || a0 < 0 || a0 > 2048 || a1 < 0 || a1 > 2048) { fits = false; break; }
+                    t[i] = (uint32_t)a0 | ((uint32_t)a1 << 16);
+                    sl[i] = (uint32_t)d | (0x0cu << 8) | ((uint32_t)(d + 1) << 16) | (0x0cu << 24);   // v_perm: bytes d, d+1 -> two zero-extended 16-bit fields
                 }
-                qbase.push_back(xb);
+                qbase.push_back(xb | o0);
                 qpx.push_back(make_uint4(t[0], t[1], t[2], t[3]));
+                qpx.push_back(make_uint4(sl[0], sl[1], sl[2], sl[3]));
             }
-            if (!fits) { qbase.resize(g.qtab_off); qpx.resize(g.qtab_off); g.qtab_off = -1; }
+            if (!fits) { qbase.resize(g.qtab_off); qpx.resize((size_t)2 * g.qtab_off); g.qtab_off = -1; }
+            // can every 256 x 16 destination tile stage its source window in the LDS tile of k_resize_lds?
+            g.lds_tile_ok = 0;
+            if (fits) {
+                const LevelGeom& gsrc = P.lv[l - 1];
+                bool ok = true;
+                const int maxoff = (gsrc.w - 1) & ~3;
+                for (int q0 = 0; q0 < nq && ok; q0 += kRzTW / 4) {
+                    const int q1 = std::min(q0 + kRzTW / 4, nq) - 1;
+                    const int sx0 = (qbase[g.qtab_off + q0] & ~3) & ~15, sx1 = std::min((qbase[g.qtab_off + q1] & ~3) + 12, maxoff + 4);
+                    if (sx1 - sx0 > kRzLdsPitch || sx0 < 0) ok = false;
+                }
+                for (int y0 = 0; y0 < g.h && ok; y0 += kRzTH) {
+                    const int y1 = std::min(y0 + kRzTH, g.h) - 1;
+                    const int sy0 = std::min(std::max(rtab[g.ytab_off + y0].x, 0), gsrc.h - 1), sy1 = std::min(std::max(rtab[g.ytab_off + y1].x + 1, 0), gsrc.h - 1);
+                    if (sy1 - sy0 + 1 > kRzLdsRows) ok = false;
+                }
+                g.lds_tile_ok = ok ? 1 : 0;
+            }
         }
     }
     (void)pyr_off;
@@ -381,6 +403,7 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_SPLIT_MIN")) h->split_min = atoi(getenv("OSLAM_ORB_SPLIT_MIN"));   // kernel experiments
+    h->no_lds_resize = getenv("OSLAM_ORB_NO_LDS_RESIZE") != nullptr;
     if (max_batch >= h->split_min) {
         OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
         OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_side_stream, hipStreamNonBlocking));
@@ -456,7 +479,11 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
             dim3 gridw(div_up(g.w, 256), div_up(g.h, 4 * kResizeRows), nb);
             // source rows 4-byte aligned? (levels >= 1 always; level 0 is the caller's buffer)
             const bool src_aligned = l > 1 || (((stride & 3) == 0) && ((((uintptr_t)cs.img0) & 3) == 0) && ((image_stride & 3) == 0));
-            if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, gridw, dim3(256), 0, sm, cs, l);
+            // source rows 16-byte aligned (LDS-staged variant)?
+            const bool src_aligned16 = l > 1 || (((stride & 15) == 0) && ((((uintptr_t)cs.img0) & 15) == 0) && ((image_stride & 15) == 0));
+            if (g.qtab_off >= 0 && g.lds_tile_ok && src_aligned16 && !h->no_lds_resize)
+                hipLaunchKernelGGL(k_resize_lds, dim3(div_up(g.w, kRzTW), div_up(g.h, kRzTH), nb), dim3(256), 0, sm, cs, l);
+            else if (g.qtab_off >= 0 && src_aligned) hipLaunchKernelGGL(k_resize_words, gridw, dim3(256), 0, sm, cs, l);
             else hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, sm, cs, l);
         }
         PROF_MARK(1);

@@ -84,10 +84,13 @@ __global__ __launch_bounds__(256) void k_resize(OrbCtx c, int level) {
 }
 
 // K1 (v2): word-load variant for 4-byte aligned source rows and scale factors <= 2.
-// Per quad of 4 dst pixels the host tables give the aligned byte offset of a 12-byte source window
-// and, per pixel, (byte offset in the window | a0 << 4 | a1 << 16); three words per source row replace
-// eight byte gathers, pixel pairs are cut out with v_alignbyte.
-constexpr int kResizeRows = 4;   // destination rows per thread: the per-quad x tables (20 B) are loaded once for all of them
+// Per quad of 4 dst pixels the host tables give the aligned byte offset of a 12-byte source window (low 2 bits: offset o0 of the first
+// pixel's left tap inside it) and, per pixel, the packed taps (a0 | a1 << 16) and a v_perm selector that picks the pixel's two source
+// bytes out of the 8 bytes starting at o0 into two 16-bit fields: a row costs two v_alignbyte for the 8-byte window and, per pixel and
+// source row, one v_perm + one v_dot2_u32_u16 (the kernel is VALU-issue bound: 40 -> 17 vector instructions per pixel).
+constexpr int kResizeRows = 4;   // destination rows per thread: the per-quad x tables (36 B) are loaded once for all of them
+
+typedef unsigned short oslam_u16x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     const OrbParams* P = c.P;
@@ -101,11 +104,13 @@ __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     int spitch;
     const uint8_t* src = level_image(c, P, b, level - 1, spitch);
     uint8_t* dst = c.pyr + (long long)b * c.pyr_stride + g.img_off;
-    const int xb = c.qbase[g.qtab_off + q];
-    const uint4 tq = c.qpx[g.qtab_off + q];
+    const int xq = c.qbase[g.qtab_off + q];
+    const int xb = xq & ~3;
+    const uint32_t o0 = (uint32_t)(xq & 3);
+    const uint4 ta = c.qpx[2 * (g.qtab_off + q)], ts = c.qpx[2 * (g.qtab_off + q) + 1];
     const int maxoff = (gs.w - 1) & ~3;
     const int o1 = min(xb + 4, maxoff), o2 = min(xb + 8, maxoff);
-    const uint32_t tp[4] = {tq.x, tq.y, tq.z, tq.w};
+    const uint32_t tap[4] = {ta.x, ta.y, ta.z, ta.w}, sel[4] = {ts.x, ts.y, ts.z, ts.w};
     // all source words of the kResizeRows rows are requested before the first one is used
     uint32_t u0[kResizeRows], u1[kResizeRows], u2[kResizeRows], v0[kResizeRows], v1[kResizeRows], v2[kResizeRows];
     int b0[kResizeRows], b1[kResizeRows];
@@ -122,22 +127,90 @@ __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     }
 #pragma unroll
     for (int r = 0; r < kResizeRows; r++) {
+        // bytes o0 .. o0+7 of the 12-byte windows of the two source rows
+        const uint32_t ul = __builtin_amdgcn_alignbyte(u1[r], u0[r], o0), uh = __builtin_amdgcn_alignbyte(u2[r], u1[r], o0);
+        const uint32_t vl = __builtin_amdgcn_alignbyte(v1[r], v0[r], o0), vh = __builtin_amdgcn_alignbyte(v2[r], v1[r], o0);
         uint32_t outw = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t t = tp[i];
-            const int o = t & 15, a0 = (t >> 4) & 0xFFF, a1 = (t >> 16) & 0xFFF;
-            const int sel = o >> 2, sh = o & 3;
-            const uint32_t ulo = sel == 0 ? u0[r] : (sel == 1 ? u1[r] : u2[r]), uhi = sel == 0 ? u1[r] : (sel == 1 ? u2[r] : 0u);
-            const uint32_t vlo = sel == 0 ? v0[r] : (sel == 1 ? v1[r] : v2[r]), vhi = sel == 0 ? v1[r] : (sel == 1 ? v2[r] : 0u);
-            const uint32_t pu = __builtin_amdgcn_alignbyte(uhi, ulo, sh), pv = __builtin_amdgcn_alignbyte(vhi, vlo, sh);
-            const int r0 = (int)(pu & 0xFF) * a0 + (int)((pu >> 8) & 0xFF) * a1;
-            const int r1 = (int)(pv & 0xFF) * a0 + (int)((pv >> 8) & 0xFF) * a1;
+            const oslam_u16x2 a = __builtin_bit_cast(oslam_u16x2, tap[i]);
+            const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(oslam_u16x2, __builtin_amdgcn_perm(uh, ul, sel[i])), a, 0u, false);
+            const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(oslam_u16x2, __builtin_amdgcn_perm(vh, vl, sel[i])), a, 0u, false);
             int v = (((b0[r] * (r0 >> 4)) >> 16) + ((b1[r] * (r1 >> 4)) >> 16) + 2) >> 2;
             v = min(max(v, 0), 255);
             outw |= (uint32_t)v << (8 * i);
         }
         if (y0 + r < g.h) *(uint32_t*)(dst + (long long)(y0 + r) * g.pitch + x4) = outw;
+    }
+}
+
+// K1 (v3): same arithmetic and tables as k_resize_words, but the source window of a 256 x 16 destination tile is first staged into LDS
+// with 16-byte coalesced loads (a dword-per-lane kernel keeps too few bytes in flight per CU: 1.4 TB/s), then every thread cuts its
+// 12-byte windows out of LDS.  Requires 16-byte aligned source rows (pyramid levels always; level 0 if the caller's buffer is).
+constexpr int kRzTW = 256, kRzTH = 16;           // destination tile
+constexpr int kRzLdsPitch = 352, kRzLdsRows = 24;   // source window capacity (scale factors up to ~1.3; checked on the host per level)
+
+__global__ __launch_bounds__(256) void k_resize_lds(OrbCtx c, int level) {
+    const OrbParams* P = c.P;
+    const LevelGeom& g = P->lv[level];
+    const LevelGeom& gs = P->lv[level - 1];
+    const int b = blockIdx.z, tid = threadIdx.x;
+    __shared__ __align__(16) uint8_t s_src[kRzLdsRows * kRzLdsPitch];
+    int spitch;
+    const uint8_t* src = level_image(c, P, b, level - 1, spitch);
+    uint8_t* dst = c.pyr + (long long)b * c.pyr_stride + g.img_off;
+    const int nq = (g.w + 3) >> 2;
+    const int q0 = blockIdx.x * (kRzTW / 4), q1 = min(q0 + kRzTW / 4, nq) - 1;      // quads of this tile
+    const int ty0 = blockIdx.y * kRzTH, ty1 = min(ty0 + kRzTH, g.h) - 1;             // destination rows of this tile
+    const int maxoff = (gs.w - 1) & ~3;
+    // source window (wave-uniform): bytes [sx0, sx1) of rows [sy0, sy1]
+    const int sx0 = (c.qbase[g.qtab_off + q0] & ~3) & ~15;
+    const int sx1 = min((c.qbase[g.qtab_off + q1] & ~3) + 12, maxoff + 4);
+    const int sy0 = min(max(c.rtab[g.ytab_off + ty0].x, 0), gs.h - 1);
+    const int sy1 = min(max(c.rtab[g.ytab_off + ty1].x + 1, 0), gs.h - 1);
+    const int nch = (sx1 - sx0 + 15) >> 4, nrows = sy1 - sy0 + 1;
+    // this thread's table entries are requested before the tile so that both travel together
+    const int q = min(q0 + (tid & 63), q1);
+    const int y0 = ty0 + (tid >> 6) * kResizeRows;
+    const int xq = c.qbase[g.qtab_off + q];
+    const uint4 ta = c.qpx[2 * (g.qtab_off + q)], ts = c.qpx[2 * (g.qtab_off + q) + 1];
+    int2 tyr[kResizeRows];
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) tyr[r] = c.rtab[g.ytab_off + min(y0 + r, g.h - 1)];
+    for (int i = tid; i < nch * nrows; i += 256) {
+        const int r = i / nch, ch = i - r * nch;
+        const uint4 v = *(const uint4*)(src + (long long)(sy0 + r) * spitch + sx0 + ch * 16);
+        *(uint4*)(s_src + r * kRzLdsPitch + ch * 16) = v;
+    }
+    __syncthreads();
+    if (q0 + (tid & 63) > q1 || y0 > ty1) return;
+    const int x4 = q * 4;
+    const int xb = xq & ~3;
+    const uint32_t o0 = (uint32_t)(xq & 3);
+    const int l0 = xb - sx0, l1 = min(xb + 4, maxoff) - sx0, l2 = min(xb + 8, maxoff) - sx0;   // window words inside the LDS rows
+    const uint32_t tap[4] = {ta.x, ta.y, ta.z, ta.w}, sel[4] = {ts.x, ts.y, ts.z, ts.w};
+#pragma unroll
+    for (int r = 0; r < kResizeRows; r++) {
+        const int2 ty = tyr[r];
+        const int ra = min(max(ty.x, 0), gs.h - 1) - sy0, rb = min(max(ty.x + 1, 0), gs.h - 1) - sy0;
+        const int b0 = (short)(ty.y & 0xFFFF), b1 = (short)(ty.y >> 16);
+        const uint8_t* S0 = s_src + ra * kRzLdsPitch;
+        const uint8_t* S1 = s_src + rb * kRzLdsPitch;
+        const uint32_t u0 = *(const uint32_t*)(S0 + l0), u1 = *(const uint32_t*)(S0 + l1), u2 = *(const uint32_t*)(S0 + l2);
+        const uint32_t v0 = *(const uint32_t*)(S1 + l0), v1 = *(const uint32_t*)(S1 + l1), v2 = *(const uint32_t*)(S1 + l2);
+        const uint32_t ul = __builtin_amdgcn_alignbyte(u1, u0, o0), uh = __builtin_amdgcn_alignbyte(u2, u1, o0);
+        const uint32_t vl = __builtin_amdgcn_alignbyte(v1, v0, o0), vh = __builtin_amdgcn_alignbyte(v2, v1, o0);
+        uint32_t outw = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const oslam_u16x2 a = __builtin_bit_cast(oslam_u16x2, tap[i]);
+            const int r0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(oslam_u16x2, __builtin_amdgcn_perm(uh, ul, sel[i])), a, 0u, false);
+            const int r1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(oslam_u16x2, __builtin_amdgcn_perm(vh, vl, sel[i])), a, 0u, false);
+            int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            v = min(max(v, 0), 255);
+            outw |= (uint32_t)v << (8 * i);
+        }
+        if (y0 + r <= ty1) *(uint32_t*)(dst + (long long)(y0 + r) * g.pitch + x4) = outw;
     }
 }
 

@@ -34,6 +34,7 @@ struct LevelGeom {
     int sel_cap, sel_base;    // survivor slots of this level
     int xtab_off, ytab_off;   // resize coefficient tables
     int qtab_off;             // quad tables of k_resize_words (-1: level cannot use it)
+    int lds_tile_ok;          // every 256 x 16 destination tile's source window fits the LDS tile of k_resize_lds
     long long img_off;        // byte offset inside the per-image pyramid / blur arenas
     float scale;              // mvScaleFactor[level]
     float kp_size;            // (int)(PATCH_SIZE*scale), :837
