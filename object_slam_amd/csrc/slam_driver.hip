@@ -111,7 +111,6 @@ struct Seq {
     std::vector<float> jXw, jObs, jInv, jPw, jPn, jMax, jMin;
     std::vector<uint8_t> jHas, jDesc, jBlocked, jObsGt0, jInView, jOutlier;
     std::vector<int> jMatch, jLocalIds;
-    std::vector<KP> jKeys;
     oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
     bool hasSL = false, hasLoc = false;
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
