@@ -69,3 +69,30 @@ def test_hip_stereo_driver_matches_oracle_driver(oracle):
         assert ah < 0.05, ah
     # 1e-4 relative on a scene at 12 m
     assert np.abs(ph - po).max() < 2e-3, np.abs(ph - po).max()
+
+
+def test_two_handles_on_two_threads_match_sequential_runs():
+    """Several driver handles on one GPU, each advanced by its own host thread (the deployment bench.py measures): every handle owns its
+    stream and buffers, so the concurrent runs must reproduce the sequential ones bit for bit."""
+    import threading
+    n, S = 14, 2
+    streams = [make_streams(S, n, seed0=11), make_streams(S, n, seed0=31)]
+    ref = []
+    for g in range(2):
+        sysm = slam.System(slam.make_config(W, H, S))
+        p, _ = run(sysm, streams[g], n)
+        ref.append((p, [sysm.stats(s) for s in range(S)]))
+    systems = [slam.System(slam.make_config(W, H, S, host_threads=2)) for _ in range(2)]
+    out = [None, None]
+
+    def work(g):
+        out[g] = run(systems[g], streams[g], n)[0]
+
+    ths = [threading.Thread(target=work, args=(g,)) for g in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for g in range(2):
+        assert np.array_equal(out[g], ref[g][0])
+        assert [systems[g].stats(s) for s in range(S)] == ref[g][1]
