@@ -96,3 +96,19 @@ def test_two_handles_on_two_threads_match_sequential_runs():
     for g in range(2):
         assert np.array_equal(out[g], ref[g][0])
         assert [systems[g].stats(s) for s in range(S)] == ref[g][1]
+
+
+def test_hip_driver_with_lens_distortion_matches_oracle_driver(oracle):
+    """Camera.k1..k3 of the reference's Examples/RGB-D/TUM2.yaml: Frame::UndistortKeyPoints and the undistorted image bounds are in the loop."""
+    n = 12
+    dist = [0.231222, -0.784899, -0.003257, -0.000105, 0.917205]
+    streams = make_streams(1, n)
+    cfg = slam.make_config(W, H, 1, dist=dist)
+    hip = slam.System(cfg)
+    ph, sh = run(hip, streams, n)
+    cfg_o = slam.make_config(W, H, 1, dist=dist)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run(ora, streams, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    assert hip.stats(0) == ora.stats(0)
+    assert np.abs(ph - po).max() < 2e-4
