@@ -1195,6 +1195,29 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 //  2. 64 lanes in parallel: fastAtan2 polynomial and the fp64 cos/sin of 64 keypoints at once
 //     (the reference's (float)cos((double)angle)), instead of once per wavefront;
 //  3. each wavefront writes the descriptors of its 16 keypoints (4 tests per lane).
+// IC_Angle weights (reference :77-104) for a patch fetched as aligned words: entry (sh, i) belongs to word i = row * 9 + wi of the 31 x 9-word
+// window whose first word holds column kx - 15 at byte sh.  w = (u + 15) per byte for the columns u inside the circular patch (|u| <= umax[|v|]), 0
+// elsewhere; o = 1 / 0 likewise.  m10 = sum dot4(pixels, w) - 15 * dot4(pixels, o), m01 = sum v * dot4(pixels, o): two v_dot4_u32_u8 per word.
+constexpr int kMomW = 9, kMomR = 31, kMomN = kMomR * kMomW, kMomStride = 280;
+struct MomentLut { uint32_t w[4 * kMomStride]; uint32_t o[4 * kMomStride]; };
+constexpr MomentLut make_moment_lut() {
+    MomentLut L{};
+    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // HALF_PATCH_SIZE = 15, reference :454-469
+    for (int sh = 0; sh < 4; sh++)
+        for (int i = 0; i < kMomN; i++) {
+            const int r = i / kMomW, wi = i - r * kMomW;
+            const int v = r - 15, av = v < 0 ? -v : v;
+            uint32_t W = 0, O = 0;
+            for (int j = 0; j < 4; j++) {
+                const int u15 = 4 * wi + j - sh, u = u15 - 15, au = u < 0 ? -u : u;
+                if (u15 >= 0 && u15 <= 30 && au <= umax[av]) { W |= (uint32_t)u15 << (8 * j); O |= 1u << (8 * j); }
+            }
+            L.w[sh * kMomStride + i] = W; L.o[sh * kMomStride + i] = O;
+        }
+    return L;
+}
+__constant__ MomentLut c_mlut = make_moment_lut();
+
 __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* keypoints per wavefront: 16 for big batches, 1 for latency */) {
     const OrbParams* P = c.P;
     const int b = blockIdx.y;
@@ -1226,29 +1249,51 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
             s_kx[tid] = ent_x(e); s_ky[tid] = ent_y(e); s_score[tid] = ent_s(e);
         }
     }
+    __shared__ uint2 s_mlut[4 * kMomStride];
+    for (int i = tid; i < 4 * kMomStride; i += 256) s_mlut[i] = make_uint2(c_mlut.w[i], c_mlut.o[i]);
     __syncthreads();
     // phase 1: IC_Angle moments (reference :77-104), integer exact
-    const int u = (lane & 31) - 15;
-    const bool ucol = (lane & 31) < 31;
-    const int au = u < 0 ? -u : u;
-    // the 16 patch bytes of this lane for the NEXT keypoint are in flight while the current one is reduced
-    int ov[16];
+    // The 31 x 31 patch is fetched as 31 rows x 9 aligned words (279 words = 5 wave loads instead of 16 byte gathers); lane l owns the words
+    // l, l + 64, ... and multiplies each with its two table words.  The words of the NEXT keypoint are in flight while the current one is reduced.
+    uint32_t ow[5];
+    int osh = 0;
+    int vrow[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) vrow[k] = (lane + 64 * k) / kMomW - 15;
     auto fetch_orient = [&](int q) {
         const int s = wv * kpw + q;
         const int level = q < kpw ? s_level[s] : -1;
 #pragma unroll
-        for (int it = 0; it < 16; it++) ov[it] = 0;
+        for (int k = 0; k < 5; k++) ow[k] = 0;
         if (level < 0) return;
         int pitch;
         const uint8_t* img = level_image(c, P, b, level, pitch);
-        const uint8_t* center = img + (long long)s_ky[s] * pitch + s_kx[s];
+        const int x0 = s_kx[s] - 15, y0 = s_ky[s] - 15;
+        osh = x0 & 3;
+        const bool al = ((pitch & 3) == 0) && ((((unsigned long long)img) & 3ull) == 0);
+        if (al) {
+            const int wbase = x0 >> 2, wmax = (pitch >> 2) - 1;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -15 + 2 * it + (lane >> 5);
-            const int av = v < 0 ? -v : v;
-            // umax for HALF_PATCH_SIZE = 15 (reference :454-469): 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 packed 4 bits each
-            const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull);
-            if (ucol && v <= 15 && au <= um) ov[it] = center[v * pitch + u];
+            for (int k = 0; k < 5; k++) {
+                const int i = lane + 64 * k;
+                const int row = i / kMomW, wi = i - row * kMomW;
+                if (i < kMomN) ow[k] = *(const uint32_t*)(img + (long long)(y0 + row) * pitch + 4 * min(wbase + wi, wmax));
+            }
+        } else {   // caller's level-0 buffer with an unaligned pitch: the same words from byte loads (bytes past the patch carry zero weights)
+            const int w = P->lv[level].w;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int i = lane + 64 * k;
+                const int row = i / kMomW, wi = i - row * kMomW;
+                if (i < kMomN) {
+                    const uint8_t* rp = img + (long long)(y0 + row) * pitch;
+                    const int cb = (x0 & ~3) + 4 * wi;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v |= (uint32_t)rp[min(cb + j, w - 1)] << (8 * j);
+                    ow[k] = v;
+                }
+            }
         }
     };
     fetch_orient(0);
@@ -1256,11 +1301,16 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
         const int s = wv * kpw + q;
         const int level = s_level[s];
         int m10 = 0, m01 = 0;
+        const uint2* lut = s_mlut + osh * kMomStride;
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = -15 + 2 * it + (lane >> 5);
-            m10 += u * ov[it];
-            m01 += v * ov[it];
+        for (int k = 0; k < 5; k++) {
+            const int i = lane + 64 * k;
+            if (i < kMomN) {
+                const uint2 t = lut[i];
+                const int d1 = (int)__builtin_amdgcn_udot4(ow[k], t.x, 0u, false), d0 = (int)__builtin_amdgcn_udot4(ow[k], t.y, 0u, false);
+                m10 += d1 - 15 * d0;
+                m01 += vrow[k] * d0;
+            }
         }
         fetch_orient(q + 1);
         if (level < 0) continue;
