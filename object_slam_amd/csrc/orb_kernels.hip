@@ -1228,6 +1228,15 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
     __shared__ int s_level[64], s_kx[64], s_ky[64], s_score[64], s_m01[64], s_m10[64];
     __shared__ float s_angle[64], s_a[64], s_b[64];
 
+    // the moment weight table travels to LDS: requested here, before the dependent loads of phase 0, stored after them
+    __shared__ uint2 s_mlut[4 * kMomStride];
+    constexpr int kLutPerThread = (4 * kMomStride + 255) / 256;
+    uint2 lutreg[kLutPerThread];
+#pragma unroll
+    for (int k = 0; k < kLutPerThread; k++) {
+        const int i = min(tid + 256 * k, 4 * kMomStride - 1);
+        lutreg[k] = make_uint2(c_mlut.w[i], c_mlut.o[i]);
+    }
     // phase 0: slot -> (level, keypoint)
     if (tid < nslot) {
         const int slot = slot0 + tid;
@@ -1249,8 +1258,11 @@ __global__ __launch_bounds__(256) void k_orient_describe(OrbCtx c, int kpw /* ke
             s_kx[tid] = ent_x(e); s_ky[tid] = ent_y(e); s_score[tid] = ent_s(e);
         }
     }
-    __shared__ uint2 s_mlut[4 * kMomStride];
-    for (int i = tid; i < 4 * kMomStride; i += 256) s_mlut[i] = make_uint2(c_mlut.w[i], c_mlut.o[i]);
+#pragma unroll
+    for (int k = 0; k < kLutPerThread; k++) {
+        const int i = tid + 256 * k;
+        if (i < 4 * kMomStride) s_mlut[i] = lutreg[k];
+    }
     __syncthreads();
     // phase 1: IC_Angle moments (reference :77-104), integer exact
     // The 31 x 31 patch is fetched as 31 rows x 9 aligned words (279 words = 5 wave loads instead of 16 byte gathers); lane l owns the words
