@@ -54,6 +54,7 @@ struct oslam_orb {
     long long blur_stride = 0;
     int* d_cell_count = nullptr;
     uint32_t* d_cand = nullptr;
+    int* d_ovf_count = nullptr; int2* d_ovf_list = nullptr;   // FAST cells handed from the wavefront kernel to the workgroup kernel
     uint32_t* d_ent_g = nullptr;
     uint16_t* d_knode_g = nullptr;
     uint32_t* d_sel = nullptr;
@@ -117,7 +118,7 @@ int oslam_device_count(void) {
 void oslam_orb_destroy(oslam_orb_t* h) {
     if (!h) return;
     void* ptrs[] = {h->d_qbase, h->d_qpx, h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
-                    h->d_cell_count, h->d_cand, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
+                    h->d_cell_count, h->d_cand, h->d_ovf_count, h->d_ovf_list, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
                     h->d_out_count, h->d_status, h->d_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -377,6 +378,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_blur, B * (size_t)h->blur_stride);
     ALLOC(h->d_cell_count, B * (size_t)P.total_cells * sizeof(int));
     ALLOC(h->d_cand, B * (size_t)P.cand_per_image * sizeof(uint32_t));
+    ALLOC(h->d_ovf_count, 64);
+    ALLOC(h->d_ovf_list, B * (size_t)P.total_cells * sizeof(int2));
     ALLOC(h->d_ent_g, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_knode_g, B * (size_t)P.cand_per_image * sizeof(uint16_t));
     ALLOC(h->d_sel, B * (size_t)P.sel_per_image * sizeof(uint32_t));
@@ -458,7 +461,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
     c.blur = h->d_blur; c.blur_stride = h->blur_stride;
     c.rtab = h->d_rtab; c.qbase = h->d_qbase; c.qpx = h->d_qpx; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
-    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
+    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ovf_count = h->d_ovf_count; c.ovf_list = h->d_ovf_list; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
     c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status; c.dbg = h->d_dbg;
     const bool prof = h->profiling != 0;
     if (prof) {
@@ -492,7 +495,10 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
             OSLAM_HIP_CHECK(hipEventRecord(fork, sm));
             OSLAM_HIP_CHECK(hipStreamWaitEvent(sb, fork, 0));
         }
+        OSLAM_HIP_CHECK(hipMemsetAsync(cs.ovf_count, 0, sizeof(int), sm));
         hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), nb), dim3(256), 0, sm, cs);
+        hipLaunchKernelGGL(k_fast_cells_ovf, dim3(256), dim3(256), 0, sm, cs);   // exits at once unless a cell overflowed the wavefront kernel's worklist
+        if (getenv("OSLAM_ORB_DEBUG_OVF")) { int n = 0; (void)hipStreamSynchronize(sm); (void)hipMemcpy(&n, cs.ovf_count, 4, hipMemcpyDeviceToHost); fprintf(stderr, "fast overflow cells: %d of %d\n", n, P.total_cells * nb); }
         if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, nb), dim3(256), 0, sm, cs);
         PROF_MARK(2);
         if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[6], sb));
@@ -518,7 +524,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         OrbCtx cs = c;
         const long long o = b0;
         cs.img0 += o * c.img0_stride; cs.pyr += o * c.pyr_stride; cs.blur += o * c.blur_stride;
-        cs.cell_count += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
+        cs.cell_count += o * P.total_cells; cs.ovf_count += 1; cs.ovf_list += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
         cs.sel += o * P.sel_per_image; cs.sel_count += o * P.nlevels;
         cs.out_kp += o * P.out_cap; cs.out_desc += o * P.out_cap * 32; cs.out_count += o;
         return cs;

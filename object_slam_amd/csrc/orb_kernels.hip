@@ -25,6 +25,8 @@ struct OrbCtx {
     const short* root_x;      // per level: nIni+1 root boundaries
     int* cell_count;          // [B][total_cells]
     uint32_t* cand;           // [B][cand_per_image]
+    int* ovf_count;           // cells whose quick-test worklist did not fit k_fast_cells_wave's LDS part ...
+    int2* ovf_list;           // ... as (image, global cell id): redone by k_fast_cells_ovf
     uint32_t* ent_g;          // [B][cand_per_image] quad-tree spill (levels with > kCandCap candidates)
     uint16_t* knode_g;        // [B][cand_per_image]
     uint32_t* sel;            // [B][sel_per_image]
@@ -313,15 +315,15 @@ __device__ __forceinline__ int fast_score(const uint8_t* t) {
     return max(s, 0);
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
-    const OrbParams* P = c.P;
-    const int b = blockIdx.y;
-    int cell = blockIdx.x;
+// One FAST cell by a whole workgroup: exact scores for every pixel of the cell, NMS, ordered output.  BIG_ONLY: cells wider than one wavefront
+// handles (k_fast_cells); otherwise any cell (k_fast_cells_ovf).  All threads of the workgroup must call.
+template <bool BIG_ONLY>
+__device__ __forceinline__ void fast_cell_workgroup(const OrbCtx& c, const OrbParams* P, const int b, int cell) {
     int level = 0;
     for (int l = 1; l < P->nlevels; l++)
         if (cell >= P->lv[l].cell_base) level = l;
     const LevelGeom& g = P->lv[level];
-    if (g.wCell <= 40 && g.hCell <= 40) return;   // handled by k_fast_cells_wave
+    if (BIG_ONLY && g.wCell <= 40 && g.hCell <= 40) return;   // handled by k_fast_cells_wave
     cell -= g.cell_base;
     const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
     int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
@@ -432,6 +434,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) {
     if (tid == 0) {
         if (running > g.cell_cap) { atomicOr(c.status, 1); running = g.cell_cap; }
         *count_out = running;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) { fast_cell_workgroup<true>(c, c.P, blockIdx.y, blockIdx.x); }
+
+// Cells that k_fast_cells_wave handed back (worklist longer than its LDS part): a fixed grid walks the list; no entries -> immediate exit.
+__global__ __launch_bounds__(256) void k_fast_cells_ovf(OrbCtx c) {
+    const int n = *c.ovf_count;
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int2 e = c.ovf_list[i];
+        fast_cell_workgroup<false>(c, c.P, e.x, e.y);
+        __syncthreads();   // the shared tiles are reused by the next cell
     }
 }
 
@@ -564,6 +578,10 @@ __global__ __launch_bounds__(256) void k_blur_strip(OrbCtx c, int sse2_rounding)
 constexpr int kWCell = 40;            // max interior edge handled per wavefront
 constexpr int kWTileP = 52;           // tile pitch in bytes (>= kWCell + 6 + 3 alignment slack, multiple of 4)
 constexpr int kWTileRows = kWCell + 6;
+// Worklist of pixels that pass the quick test: kFastWorkLds entries in LDS (a workgroup then needs 23 KB instead of 32 KB: 7 instead of 5
+// workgroups per CU; 3.33 -> 2.82 us/frame beside the blur).  A cell with more survivors is handed to k_fast_cells_ovf through a list.
+constexpr int kFastWorkLds = 880;
+constexpr int kScP = 40;              // pitch of the score array (worklist entries keep the y * 64 + x encoding)
 
 template <int TP>
 __device__ __forceinline__ int fast_score3(const uint8_t* t) {
@@ -645,8 +663,8 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cell_first = (blockIdx.x * 4 + wv) * kFastCellsPerWave;
     __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
-    __shared__ uint8_t s_sc[4][kWCell * 64];          // scores, pitch 64
-    __shared__ uint16_t s_work[4][kWCell * kWCell];   // worklist: y*64 + x of pixels passing the quick test, row-major
+    __shared__ __align__(4) uint8_t s_sc[4][kWCell * kScP];   // scores
+    __shared__ uint16_t s_work[4][kFastWorkLds];      // worklist: y*64 + x of pixels passing the quick test, row-major
     uint8_t* tile = s_tile[wv];
     uint8_t* sc = s_sc[wv];
     uint16_t* work = s_work[wv];
@@ -735,16 +753,16 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                 f = ((pass[0] >> 15) & 1u) | ((pass[1] >> 14) & 2u) | ((pass[0] >> 29) & 4u) | ((pass[1] >> 28) & 8u);
                 const int nvalid = cw - x4;   // pixels of this word inside the cell
                 f &= nvalid >= 4 ? 15u : (nvalid > 0 ? (1u << nvalid) - 1u : 0u);
-                if (nvalid > 0) *(uint32_t*)(sc + y * 64 + x4) = 0u;
+                if (nvalid > 0) *(uint32_t*)(sc + y * kScP + x4) = 0u;
             }
             const unsigned long long lt = (1ull << lane) - 1ull;
             const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot(f & 2u), m2 = __ballot(f & 4u), m3 = __ballot(f & 8u);
             int pos = nwork + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
             const int q0 = y * 64 + x4;
-            if (f & 1u) work[pos++] = (uint16_t)q0;
-            if (f & 2u) work[pos++] = (uint16_t)(q0 + 1);
-            if (f & 4u) work[pos++] = (uint16_t)(q0 + 2);
-            if (f & 8u) work[pos++] = (uint16_t)(q0 + 3);
+            if (f & 1u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)q0; pos++; }
+            if (f & 2u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 1); pos++; }
+            if (f & 4u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 2); pos++; }
+            if (f & 8u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 3); pos++; }
             nwork += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
         }
     } else {
@@ -760,19 +778,24 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                 const int hi = v + minTh, lo = v - minTh;
                 const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
                 pass = (((p0 > hi) || (p8 > hi)) && ((p4 > hi) || (p12 > hi))) || (((p0 < lo) || (p8 < lo)) && ((p4 < lo) || (p12 < lo)));
-                sc[y * 64 + x] = 0;
+                sc[y * kScP + x] = 0;
             }
             const unsigned long long m = __ballot(pass);
-            if (pass) work[nwork + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(y * 64 + x);
+            if (pass) { const int pos = nwork + __popcll(m & ((1ull << lane) - 1ull)); if (pos < kFastWorkLds) work[pos] = (uint16_t)(y * 64 + x); }
             nwork += __popcll(m);
         }
+    }
+    if (nwork > kFastWorkLds) {   // (wave-uniform) too many survivors for the LDS worklist: the whole cell is redone by k_fast_cells_ovf
+        if (lane == 0) c.ovf_list[atomicAdd(c.ovf_count, 1)] = make_int2(b, g.cell_base + cell);
+        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+        continue;
     }
     __builtin_amdgcn_wave_barrier();
     FSTAMP(1);
     // B. exact scores of the survivors (others stay 0 = "not a corner at minTh")
     for (int i = lane; i < nwork; i += 64) {
         const int q = work[i], y = q >> 6, x = q & 63;
-        sc[q] = (uint8_t)fast_score3<kWTileP>(t0 + y * kWTileP + x);
+        sc[y * kScP + x] = (uint8_t)fast_score3<kWTileP>(t0 + y * kWTileP + x);
     }
     __builtin_amdgcn_wave_barrier();
     FSTAMP(2);
@@ -783,7 +806,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
         int it = 0;
         for (int i = lane; i < nwork; i += 64, it++) {
             const int q = work[i], y = q >> 6, x = q & 63;
-            const int s = sc[q];
+            const int s = sc[y * kScP + x];
             bool keep = s >= minTh;
             if (keep) {
 #pragma unroll
@@ -792,7 +815,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                     for (int dx = -1; dx <= 1; dx++) {
                         if (dx == 0 && dy == 0) continue;
                         const int xx = x + dx, yy = y + dy;
-                        const int n = (xx >= 0 && xx < cw && yy >= 0 && yy < ch) ? sc[yy * 64 + xx] : 0;
+                        const int n = (xx >= 0 && xx < cw && yy >= 0 && yy < ch) ? sc[yy * kScP + xx] : 0;
                         keep = keep && (s > n);
                     }
             }
@@ -812,7 +835,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
             if (i < nwork && ((keepmask >> it) & 1ull)) {
                 const int q = work[i];
                 y = q >> 6; x = q & 63;
-                s = sc[q];
+                s = sc[y * kScP + x];
                 flag = s >= th;
             }
             const unsigned long long m = __ballot(flag);
