@@ -248,10 +248,13 @@ def main():
                        "frac_of_bcnt_issue_peak": round(match_pairs_per_s * 8 / (256 * 4 * 16 * 2.4e9), 5)}
         dom = max(per_frame_us.keys(), key=lambda n: per_frame_us[n])
         achieved = alg[dom] / (per_frame_us[dom] * 1e-6) / 1e9
-        kname = {"pyramid(K1)": "k_resize", "fast_cells(K2/K3)": "k_fast_cells_wave", "blur(K6)": "k_blur_strip<false>",
-                 "octree(K4)": "k_octree", "orient_describe(K5/K7)": "k_orient_describe", "match(K8-K10)": "k_search_window"}[dom]
-        traffic = pmc_traffic(kname, B)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # kernels of each timed group (the HIP events bracket the group; rocprofv3 lists the kernels separately)
+        knames = {"pyramid(K1)": ["k_resize_lds"], "fast_cells(K2/K3)": ["k_fast_cells_wave", "k_fast_cells_ovf"],
+                  "blur(K6)": ["k_blur_strip<false>", "k_blur_strip<true>"], "octree(K4)": ["k_octree"],
+                  "orient_describe(K5/K7)": ["k_orient_describe"], "match(K8-K10)": ["k_project_last", "k_search_window"]}[dom]
+        parts = [pmc_traffic(k, B) for k in knames]
+        traffic = None if any(p is None for p in parts[:1]) else sum(p for p in parts if p is not None)
+        roof = {"bound": "hbm", "kernel": dom, "kernels": knames, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else int(traffic),
                 "algorithmic_bytes_per_launch": int(alg[dom] * B),
                 "launch_us": round(per_frame_us[dom] * B, 1),
