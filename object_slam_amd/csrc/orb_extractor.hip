@@ -402,7 +402,11 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
     OSLAM_HIP_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
-    OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    {   // the blur stream runs at the lowest priority: FAST, the overflow cells and the quad-tree on the caller's stream are dispatched first
+        int least = 0, greatest = 0;
+        OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+    }
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_SPLIT_MIN")) h->split_min = atoi(getenv("OSLAM_ORB_SPLIT_MIN"));   // kernel experiments

@@ -115,3 +115,15 @@ def test_golden_fixture_frontend():
     nm2, qm2, qd2, km2 = m2.search_window(k1, z["uR"], d1, None, tuple(z["bounds"]), z["queries"], True, False)
     assert nm2 == int(z["nm2"])
     np.testing.assert_array_equal(qm2, z["qm2"]); np.testing.assert_array_equal(km2, z["km2"])
+
+
+def test_fast_worklist_overflow_cells(oracle):
+    """A 3x3-block checkerboard (plus noise so that scores differ) makes almost every pixel pass FAST's quick test: the wavefront kernel's 880-entry
+    LDS worklist overflows in nearly every cell and the cells are redone by k_fast_cells_ovf.  Candidates, keypoints and descriptors stay bit-exact."""
+    rng = np.random.default_rng(11)
+    h, w = 240, 320
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.where(((xx // 3 + yy // 3) & 1) == 0, 60, 190).astype(np.int32) + rng.integers(-25, 26, size=(h, w))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    n = _stages(oracle, TUM, img)
+    assert n > 500
