@@ -53,6 +53,26 @@ def make_stream(n_frames, width=640, height=480, seed=SEED, margin=96):
     return frames, np.stack([ox, oy], 1)
 
 
+def make_occluded_stream(n_frames, width=640, height=480, seed=SEED, margin=60, period=30, every=2, frac=55):
+    """A stream that makes the local mapper cull keyframes: the camera swings back and forth over `margin` pixels (so the map
+    is soon complete) while every `every`-th frame has `frac` % of its width, alternately at the right and the left edge,
+    covered by foreign texture.  The covered frames track too few of their reference keyframe's points, a keyframe is inserted
+    in known territory, and older keyframes become redundant (reference src/LocalMapping.cc:KeyFrameCulling).
+    Returns (frames uint8 [n,h,w], offsets int64 [n,2])."""
+    canvas = make_canvas(width + margin, height + margin, seed)
+    t = np.arange(n_frames)
+    ox = np.rint((0.5 - 0.5 * np.cos(2 * np.pi * t / period)) * margin).astype(np.int64)
+    oy = np.rint((0.5 - 0.5 * np.cos(2 * np.pi * t / period)) * margin * 0.3).astype(np.int64)
+    frames = np.empty((n_frames, height, width), np.uint8)
+    ow = width * frac // 100
+    for i in range(n_frames):
+        frames[i] = canvas[oy[i]:oy[i] + height, ox[i]:ox[i] + width]
+        if i % every == every - 1:
+            x0 = 0 if (i // every) % 2 else width - ow
+            frames[i][:, x0:x0 + ow] = make_canvas(ow, height, seed + 1000 + i)
+    return frames, np.stack([ox, oy], 1)
+
+
 def make_stereo_stream(n_frames, width=1241, height=376, seed=SEED, margin=96, disparity=32):
     """Rectified stereo pair stream of the same fronto-parallel plane (SURVEY.md §8(d) S3 shape): the right camera sees every
     point `disparity` pixels further left (uR = uL - disparity), i.e. its crop starts `disparity` columns to the right; the plane

@@ -161,6 +161,35 @@ def test_driver_against_independent_restatement(oracle):
     assert np.array_equal(Twc, np.stack([x[1] for x in tr]))
 
 
+def test_keyframe_culling_against_independent_restatement(oracle):
+    """A stream with foreign texture over half of every second frame makes the tracker insert keyframes in mapped territory, so
+    LocalMapping::KeyFrameCulling (reference src/LocalMapping.cc:638-713) removes redundant ones: both drivers must take the same
+    decisions (the culled keyframes change covisibility, the spanning tree, the local map and the trajectory anchors)."""
+    from oracle import slam_driver_oracle as R
+    from object_slam_amd import synth
+    n = 54
+    cfg = slam.make_config(W, H, 1)
+    frames, _ = synth.make_occluded_stream(n, W, H, seed=11)
+    depth = np.full((H, W), 2.0, np.float32)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
+    for t in range(n):
+        T, st = sysm.TrackRGBD([frames[t]], [depth], [t / 30.0])
+        Tr, sr = ref.Track((frames[t], depth), t / 30.0)
+        assert int(st[0]) == sr, t
+        assert np.array_equal(T[0], Tr), (t, np.abs(T[0] - Tr).max())
+        a, b = sysm.stats(0), ref.stats()
+        assert all(a[k] == b[k] for k in b), (t, a, b)
+    a = sysm.stats(0)
+    assert a["keyframes_culled"] >= 2 and a["keyframes_in_map"] == a["keyframes_created"] - a["keyframes_culled"] and a["map_violations"] == 0, a
+    stamps, Twc = sysm.trajectory(0)
+    tr = ref.trajectory()
+    assert len(tr) == len(stamps) == n
+    assert np.array_equal(Twc, np.stack([x[1] for x in tr]))
+    sk, Tk = sysm.keyframe_trajectory(0)
+    assert len(sk) == a["keyframes_in_map"]
+
+
 def test_stereo_driver_against_independent_restatement(oracle):
     from oracle import slam_driver_oracle as R
     from slam_common import make_stereo_streams, stereo_config

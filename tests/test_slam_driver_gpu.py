@@ -112,3 +112,25 @@ def test_hip_driver_with_lens_distortion_matches_oracle_driver(oracle):
     assert np.array_equal(sh, so) and (sh == slam.OK).all()
     assert hip.stats(0) == ora.stats(0)
     assert np.abs(ph - po).max() < 2e-4
+
+
+def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle):
+    """Occluded stream (synth.make_occluded_stream): keyframes are inserted in mapped territory and LocalMapping::KeyFrameCulling removes
+    redundant ones; the HIP operator table must lead the driver to the same culling decisions as the CPU oracle's table."""
+    from object_slam_amd import synth
+    n, S = 54, 2
+    streams = [synth.make_occluded_stream(n, W, H, seed=sd) for sd in (11, 14)]
+    cfg = slam.make_config(W, H, S)
+    hip = slam.System(cfg)
+    ph, sh = run(hip, streams, n)
+    cfg_o = slam.make_config(W, H, S)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run(ora, streams, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    for s in range(S):
+        a, b = hip.stats(s), ora.stats(s)
+        assert a == b, (s, a, b)
+        assert a["keyframes_culled"] >= 2 and a["map_violations"] == 0, a
+        assert np.array_equal(hip.keyframe_trajectory(s)[0], ora.keyframe_trajectory(s)[0])
+    d = np.abs(ph - po).max()
+    assert d < 2e-4, d
