@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_resize(OrbCtx c, int level) {
 constexpr int kResizeRows = 4;   // destination rows per thread: the per-quad x tables (36 B) are loaded once for all of them
 
 typedef unsigned short oslam_u16x2 __attribute__((ext_vector_type(2)));
+typedef short oslam_i16x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_resize_words(OrbCtx c, int level) {
     const OrbParams* P = c.P;
@@ -582,30 +583,34 @@ constexpr int kWTileRows = kWCell + 6;
 // workgroups per CU; 3.33 -> 2.82 us/frame beside the blur).  A cell with more survivors is handed to k_fast_cells_ovf through a list.
 constexpr int kFastWorkLds = 880;
 constexpr int kScP = 40;              // pitch of the score array (worklist entries keep the y * 64 + x encoding)
+// Score array of one wavefront: rows -1 .. kWCell of kScP bytes behind 4 leading bytes, all zeroed before the quick test, so the NMS reads the 8
+// neighbours of a pixel without bounds checks when the cell is narrower than the pitch (column cw of row y and column -1 of row y + 1 are then zeros).
+constexpr int kScBytes = 4 + (kWCell + 2) * kScP;
 
 template <int TP>
 __device__ __forceinline__ int fast_score3(const uint8_t* t) {
     constexpr int off[16] = {3 * TP,      3 * TP + 1,  2 * TP + 2,  TP + 3,  3,        -TP + 3, -2 * TP + 2, -3 * TP + 1,
                              -3 * TP,     -3 * TP - 1, -2 * TP - 2, -TP - 3, -3,       TP - 3,  2 * TP - 2,  3 * TP - 1};
+    // min over an arc of (v - p) = v - max over the arc of p: the trees run on the raw circle pixels, v enters once at the end
     const int v = t[0];
-    int d[16];
+    int p[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) d[k] = v - (int)t[off[k]];
-    int lo3[16], hi3[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = min(min(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-        hi3[k] = max(max(d[k], d[(k + 1) & 15]), d[(k + 2) & 15]);
-    }
-    int A = -256, Bm = 256;
+    for (int k = 0; k < 16; k++) p[k] = (int)t[off[k]];
+    int mx3[16], mn3[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo3[k], lo3[(k + 3) & 15]), lo3[(k + 6) & 15]);
-        const int hi9 = max(max(hi3[k], hi3[(k + 3) & 15]), hi3[(k + 6) & 15]);
-        A = max(A, lo9);
-        Bm = min(Bm, hi9);
+        mx3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+        mn3[k] = min(min(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
     }
-    return max(max(A, -Bm) - 1, 0);
+    int minmax = 255, maxmin = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+        const int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        minmax = min(minmax, mx9);
+        maxmin = max(maxmin, mn9);
+    }
+    return max(max(v - minmax, maxmin - v) - 1, 0);
 }
 
 #ifdef OSLAM_FAST_PROFILE
@@ -663,10 +668,10 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int cell_first = (blockIdx.x * 4 + wv) * kFastCellsPerWave;
     __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
-    __shared__ __align__(4) uint8_t s_sc[4][kWCell * kScP];   // scores
+    __shared__ __align__(4) uint8_t s_sc[4][kScBytes];   // scores, zero ring around the cell (see kScBytes)
     __shared__ uint16_t s_work[4][kFastWorkLds];      // worklist: y*64 + x of pixels passing the quick test, row-major
     uint8_t* tile = s_tile[wv];
-    uint8_t* sc = s_sc[wv];
+    uint8_t* sc = s_sc[wv] + kScP + 4;   // sc[y * kScP + x], rows -1 .. kWCell and column -1 exist
     uint16_t* work = s_work[wv];
     const int minTh = P->minTh, iniTh = P->iniTh;
     // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by shuffle
@@ -699,6 +704,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     }
     const int rw = G.rw, rh = G.rh;
     __builtin_amdgcn_wave_barrier();                   // the previous cell no longer reads the LDS tile
+    for (int i = lane; i < kScBytes / 4; i += 64) ((uint32_t*)s_sc[wv])[i] = 0u;   // while the tile words travel
     if (G.aligned) {
 #pragma unroll
         for (int k = 0; k < kLoadIters; k++) {
@@ -725,14 +731,16 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     //    ordered worklist.
     int nwork = 0;
     if (cw <= 32) {
-        // 4 pixels per lane (one aligned word), 8 rows per pass; 16-bit SWAR fields (two pixels per register):
-        // bit 15 of ((a | H) - b) per field is set iff a >= b (all values < 2^15).
+        // 4 pixels per lane (one aligned word), 8 rows per pass; two pixels per register in 16-bit fields (`v_perm` extraction, packed
+        // 16-bit min / max / sub): brighter needs min(max(p0,p8), max(p4,p12)) > v + t, darker max(min(p0,p8), min(p4,p12)) < v - t.
+        // Flags of the word's pixels 0..3 sit at bits 0, 1, 16, 17 of f.
         const int x4 = (lane & 7) * 4;
-        const uint32_t H = 0x80008000u, M8 = 0x00FF00FFu;
-        const uint32_t tp1 = (uint32_t)(minTh + 1) * 0x00010001u;
+        const oslam_i16x2 tt = {(short)minTh, (short)minTh};
+        const int nvalid = cw - x4;   // pixels of this lane's word inside the cell
+        const uint32_t fmask = nvalid >= 4 ? 0x00030003u : nvalid == 3 ? 0x00010003u : nvalid == 2 ? 0x00000003u : nvalid == 1 ? 1u : 0u;
         for (int yb = 0; yb < ch; yb += 8) {
             const int y = yb + (lane >> 3);
-            uint32_t f = 0;   // bit i: pixel x4+i passes
+            uint32_t f = 0;
             if (y < ch) {
                 const uint8_t* tr = t0 + y * kWTileP + x4;
                 const uint32_t wv4 = *(const uint32_t*)tr;
@@ -742,27 +750,31 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                 uint32_t pass[2];
 #pragma unroll
                 for (int par = 0; par < 2; par++) {
-                    const int shf = par * 8;
-                    const uint32_t v2 = (wv4 >> shf) & M8;
-                    const uint32_t vH = v2 | H, vt = v2 + tp1;
-                    const uint32_t a0 = (w0 >> shf) & M8, a8 = (w8 >> shf) & M8, a4 = (w4 >> shf) & M8, a12 = (w12 >> shf) & M8;
-                    const uint32_t b0 = (a0 | H) - vt, b8 = (a8 | H) - vt, b4 = (a4 | H) - vt, b12 = (a12 | H) - vt;       // p > v + t
-                    const uint32_t d0 = vH - (a0 + tp1), d8 = vH - (a8 + tp1), d4 = vH - (a4 + tp1), d12 = vH - (a12 + tp1);   // p < v - t
-                    pass[par] = (((b0 | b8) & (b4 | b12)) | ((d0 | d8) & (d4 | d12))) & H;
+                    const uint32_t sel = par ? 0x0c030c01u : 0x0c020c00u;
+                    const oslam_i16x2 v2 = __builtin_bit_cast(oslam_i16x2, __builtin_amdgcn_perm(0u, wv4, sel));
+                    const oslam_i16x2 a0 = __builtin_bit_cast(oslam_i16x2, __builtin_amdgcn_perm(0u, w0, sel));
+                    const oslam_i16x2 a8 = __builtin_bit_cast(oslam_i16x2, __builtin_amdgcn_perm(0u, w8, sel));
+                    const oslam_i16x2 a4 = __builtin_bit_cast(oslam_i16x2, __builtin_amdgcn_perm(0u, w4, sel));
+                    const oslam_i16x2 a12 = __builtin_bit_cast(oslam_i16x2, __builtin_amdgcn_perm(0u, w12, sel));
+                    const oslam_i16x2 mB = __builtin_elementwise_min(__builtin_elementwise_max(a0, a8), __builtin_elementwise_max(a4, a12));
+                    const oslam_i16x2 mD = __builtin_elementwise_max(__builtin_elementwise_min(a0, a8), __builtin_elementwise_min(a4, a12));
+                    const oslam_i16x2 s1 = (v2 + tt) - mB;      // negative iff mB > v + t
+                    const oslam_i16x2 s2 = mD - (v2 - tt);      // negative iff mD < v - t
+                    pass[par] = __builtin_bit_cast(uint32_t, s1) | __builtin_bit_cast(uint32_t, s2);
                 }
-                f = ((pass[0] >> 15) & 1u) | ((pass[1] >> 14) & 2u) | ((pass[0] >> 29) & 4u) | ((pass[1] >> 28) & 8u);
-                const int nvalid = cw - x4;   // pixels of this word inside the cell
-                f &= nvalid >= 4 ? 15u : (nvalid > 0 ? (1u << nvalid) - 1u : 0u);
-                if (nvalid > 0) *(uint32_t*)(sc + y * kScP + x4) = 0u;
+                f = (((pass[0] >> 15) & 0x00010001u) | ((pass[1] >> 14) & 0x00020002u)) & fmask;
             }
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot(f & 2u), m2 = __ballot(f & 4u), m3 = __ballot(f & 8u);
-            int pos = nwork + __popcll(m0 & lt) + __popcll(m1 & lt) + __popcll(m2 & lt) + __popcll(m3 & lt);
+            const unsigned long long m0 = __ballot(f & 1u), m1 = __ballot(f & 2u), m2 = __ballot(f & 0x10000u), m3 = __ballot(f & 0x20000u);
+            int pos = nwork;
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, pos));
+            pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3, pos));
             const int q0 = y * 64 + x4;
             if (f & 1u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)q0; pos++; }
             if (f & 2u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 1); pos++; }
-            if (f & 4u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 2); pos++; }
-            if (f & 8u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 3); pos++; }
+            if (f & 0x10000u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 2); pos++; }
+            if (f & 0x20000u) { if (pos < kFastWorkLds) work[pos] = (uint16_t)(q0 + 3); pos++; }
             nwork += __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
         }
     } else {
@@ -778,7 +790,6 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
                 const int hi = v + minTh, lo = v - minTh;
                 const int p0 = t[3 * kWTileP], p4 = t[3], p8 = t[-3 * kWTileP], p12 = t[-3];
                 pass = (((p0 > hi) || (p8 > hi)) && ((p4 > hi) || (p12 > hi))) || (((p0 < lo) || (p8 < lo)) && ((p4 < lo) || (p12 < lo)));
-                sc[y * kScP + x] = 0;
             }
             const unsigned long long m = __ballot(pass);
             if (pass) { const int pos = nwork + __popcll(m & ((1ull << lane) - 1ull)); if (pos < kFastWorkLds) work[pos] = (uint16_t)(y * 64 + x); }
@@ -802,7 +813,17 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     // C. NMS over the worklist (strictly greater than the 8 in-cell neighbours), ini/min vote
     unsigned long long keepmask = 0;   // bit it: this lane's worklist entry of pass `it` survives
     bool hit_ini = false;
-    {
+    if (cw < kScP) {   // zero ring: no bounds checks
+        int it = 0;
+        for (int i = lane; i < nwork; i += 64, it++) {
+            const int q = work[i], y = q >> 6, x = q & 63;
+            const uint8_t* n = sc + (y - 1) * kScP + x - 1;
+            const int s = n[kScP + 1];
+            const int m = max(max(max((int)n[0], (int)n[1]), max((int)n[2], (int)n[kScP])),
+                              max(max((int)n[kScP + 2], (int)n[2 * kScP]), max((int)n[2 * kScP + 1], (int)n[2 * kScP + 2])));
+            if (s >= minTh && s > m) { keepmask |= 1ull << it; hit_ini = hit_ini || (s >= iniTh); }
+        }
+    } else {
         int it = 0;
         for (int i = lane; i < nwork; i += 64, it++) {
             const int q = work[i], y = q >> 6, x = q & 63;
