@@ -54,6 +54,7 @@ struct oslam_orb {
     long long blur_stride = 0;
     int* d_cell_count = nullptr;
     uint32_t* d_cand = nullptr;
+    FastCellRec* d_fast_cells = nullptr;   // per-cell geometry of k_fast_cells_wave
     int* d_ovf_count = nullptr; int2* d_ovf_list = nullptr;   // FAST cells handed from the wavefront kernel to the workgroup kernel
     uint32_t* d_ent_g = nullptr;
     uint16_t* d_knode_g = nullptr;
@@ -118,7 +119,7 @@ int oslam_device_count(void) {
 void oslam_orb_destroy(oslam_orb_t* h) {
     if (!h) return;
     void* ptrs[] = {h->d_qbase, h->d_qpx, h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
-                    h->d_cell_count, h->d_cand, h->d_ovf_count, h->d_ovf_list, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
+                    h->d_cell_count, h->d_cand, h->d_fast_cells, h->d_ovf_count, h->d_ovf_list, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
                     h->d_out_count, h->d_status, h->d_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -392,6 +393,37 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
 #undef ALLOC
     OSLAM_HIP_CHECK(hipMemcpy(h->dP, &P, sizeof(P), hipMemcpyHostToDevice));
+    {   // FAST cell records (the cell grid of reference src/ORBextractor.cc:784-808, one record per cell of every level)
+        std::vector<FastCellRec> cells((size_t)P.total_cells);
+        for (int l = 0; l < nlevels; l++) {
+            const LevelGeom& g = P.lv[l];
+            const int ncell = g.nCols * g.nRows;
+            for (int cell = 0; cell < ncell; cell++) {
+                FastCellRec r{};
+                const int ci = cell / g.nCols, cj = cell - ci * g.nCols;
+                const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
+                const int iniY = kRegionBorder + ci * g.hCell, iniX = kRegionBorder + cj * g.wCell;
+                int maxY = iniY + g.hCell + 6, maxX = iniX + g.wCell + 6;
+                const bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);
+                if (maxY > maxBY) maxY = maxBY;
+                if (maxX > maxBX) maxX = maxBX;
+                const int cw = maxX - iniX - 6, ch = maxY - iniY - 6;
+                int valid = 1;
+                if (g.wCell > kWCell || g.hCell > kWCell) valid = 0;          // k_fast_cells handles the level
+                else if (skip || cw <= 0 || ch <= 0) valid = 2;
+                if (iniX > 0xFFFF || iniY > 0xFFFF || g.img_off > 0xFFFFFFFFll) { set_error("oslam_orb_create: image too large for the FAST cell records"); oslam_orb_destroy(h); return OSLAM_E_INVALID; }
+                r.xy = (uint32_t)iniX | ((uint32_t)iniY << 16);
+                r.dims = (uint32_t)(valid == 1 ? cw : 0) | ((uint32_t)(valid == 1 ? ch : 0) << 8) | ((uint32_t)l << 16) | ((uint32_t)valid << 24);
+                r.cand_ofs = (uint32_t)(g.cand_base + (long long)cell * g.cell_cap);
+                r.img_off = (uint32_t)g.img_off;
+                r.cell_cap = (uint32_t)g.cell_cap;
+                r.pitch = (uint32_t)g.pitch;
+                cells[(size_t)g.cell_base + cell] = r;
+            }
+        }
+        if (hipMalloc((void**)&h->d_fast_cells, cells.size() * sizeof(FastCellRec)) != hipSuccess) { set_error("hipMalloc of the FAST cell records failed"); oslam_orb_destroy(h); return OSLAM_E_HIP; }
+        OSLAM_HIP_CHECK(hipMemcpy(h->d_fast_cells, cells.data(), cells.size() * sizeof(FastCellRec), hipMemcpyHostToDevice));
+    }
     if (!rtab.empty()) OSLAM_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(int2), hipMemcpyHostToDevice));
     if (!qbase.empty()) {
         OSLAM_HIP_CHECK(hipMemcpy(h->d_qbase, qbase.data(), qbase.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -465,7 +497,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
     c.blur = h->d_blur; c.blur_stride = h->blur_stride;
     c.rtab = h->d_rtab; c.qbase = h->d_qbase; c.qpx = h->d_qpx; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
-    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.ovf_count = h->d_ovf_count; c.ovf_list = h->d_ovf_list; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
+    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.fast_cells = h->d_fast_cells; c.ovf_count = h->d_ovf_count; c.ovf_list = h->d_ovf_list; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
     c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status; c.dbg = h->d_dbg;
     const bool prof = h->profiling != 0;
     if (prof) {

@@ -25,6 +25,7 @@ struct OrbCtx {
     const short* root_x;      // per level: nIni+1 root boundaries
     int* cell_count;          // [B][total_cells]
     uint32_t* cand;           // [B][cand_per_image]
+    const FastCellRec* fast_cells;   // [total_cells] per-cell geometry of k_fast_cells_wave
     int* ovf_count;           // cells whose quick-test worklist did not fit k_fast_cells_wave's LDS part ...
     int2* ovf_list;           // ... as (image, global cell id): redone by k_fast_cells_ovf
     uint32_t* ent_g;          // [B][cand_per_image] quad-tree spill (levels with > kCandCap candidates)
@@ -619,35 +620,25 @@ __device__ __forceinline__ int fast_score3(const uint8_t* t) {
 #define FSTAMP(i) do { } while (0)
 #endif
 
-// Geometry of one FAST cell as a wavefront sees it (all wave-uniform).
+// Geometry of one FAST cell as a wavefront sees it: everything is wave-uniform and comes from the cell's FastCellRec through one scalar load.
 struct FastCell {
     int valid;             // 0: nothing to do (out of range / handled by k_fast_cells); 1: process; 2: empty cell, count = 0
-    int level, ci, cj, cw, ch, iniX, iniY, rw, rh, pitch, gbase, gsh, nwt, aligned, cell_in_level;
+    int cw, ch, iniX, iniY, rw, rh, pitch, gbase, gsh, nwt, aligned, cell_cap;
+    uint32_t cand_ofs;
     const uint8_t* img;
 };
 
-__device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, const OrbParams* P, int b, int cell, FastCell& G) {
+__device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, const OrbParams* P, int b, int cell /* wave-uniform */, FastCell& G) {
     G.valid = 0;
     if (cell >= P->total_cells) return;
-    int level = 0;
-    for (int l = 1; l < P->nlevels; l++)
-        if (cell >= P->lv[l].cell_base) level = l;
-    const LevelGeom& g = P->lv[level];
-    if (g.wCell > kWCell || g.hCell > kWCell) return;   // handled by k_fast_cells
-    cell -= g.cell_base;
-    G.level = level; G.cell_in_level = cell;
-    G.ci = cell / g.nCols; G.cj = cell - G.ci * g.nCols;
-    const int minBX = kRegionBorder, minBY = kRegionBorder;
-    const int maxBX = g.w - kRegionBorder, maxBY = g.h - kRegionBorder;
-    G.iniY = minBY + G.ci * g.hCell; G.iniX = minBX + G.cj * g.wCell;
-    int maxY = G.iniY + g.hCell + 6, maxX = G.iniX + g.wCell + 6;
-    const bool skip = (G.iniY >= maxBY - 3) || (G.iniX >= maxBX - 6);
-    if (maxY > maxBY) maxY = maxBY;
-    if (maxX > maxBX) maxX = maxBX;
-    G.cw = maxX - G.iniX - 6; G.ch = maxY - G.iniY - 6;
-    if (skip || G.cw <= 0 || G.ch <= 0) { G.valid = 2; return; }
-    G.valid = 1;
-    G.img = level_image(c, P, b, level, G.pitch);
+    const FastCellRec r = c.fast_cells[cell];
+    G.valid = (int)(r.dims >> 24);
+    G.cand_ofs = r.cand_ofs; G.cell_cap = (int)r.cell_cap;
+    if (G.valid != 1) return;
+    G.iniX = (int)(r.xy & 0xFFFFu); G.iniY = (int)(r.xy >> 16);
+    G.cw = (int)(r.dims & 0xFFu); G.ch = (int)((r.dims >> 8) & 0xFFu);
+    if (((r.dims >> 16) & 0xFFu) == 0u) { G.pitch = c.img0_pitch; G.img = c.img0 + (long long)b * c.img0_stride; }
+    else { G.pitch = (int)r.pitch; G.img = c.pyr + (long long)b * c.pyr_stride + r.img_off; }
     G.rw = G.cw + 6; G.rh = G.ch + 6;
     // Tile layout: ROI column cc (0..rw-1) at tile byte cc+1, i.e. interior pixel x at byte x+4 (word aligned
     // for x % 4 == 0).  Tile word j = global bytes base+s+4j.., base = (iniX-1) & ~3, s = (iniX-1) & 3
@@ -665,7 +656,8 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     long long tl_ = clock64();
 #endif
     const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the cell geometry lives in scalar registers
     const int cell_first = (blockIdx.x * 4 + wv) * kFastCellsPerWave;
     __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
     __shared__ __align__(4) uint8_t s_sc[4][kScBytes];   // scores, zero ring around the cell (see kScBytes)
@@ -674,29 +666,31 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     uint8_t* sc = s_sc[wv] + kScP + 4;   // sc[y * kScP + x], rows -1 .. kWCell and column -1 exist
     uint16_t* work = s_work[wv];
     const int minTh = P->minTh, iniTh = P->iniTh;
-    // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by shuffle
+    // lanes 0..15 = word in row, lane >> 4 = row inside a group of 4: no divisions; neighbour word by a row shift
     const int wx = lane & 15, rsub = lane >> 4;
     constexpr int kLoadIters = (kWTileRows + 3) / 4;
     uint32_t gw[kLoadIters];                           // raw aligned words of the NEXT cell's tile, in flight
     FastCell N;                                        // geometry of the next cell
     auto issue_loads = [&](const FastCell& G) {
+        const uint32_t lane_off = (uint32_t)(rsub * G.pitch + wx * 4);
+        const bool col_ok = G.valid == 1 && G.aligned && wx <= G.nwt;
 #pragma unroll
         for (int k = 0; k < kLoadIters; k++) {
-            const int ry = 4 * k + rsub;
             gw[k] = 0;
-            if (G.valid == 1 && G.aligned && ry < G.rh && wx <= G.nwt) gw[k] = *(const uint32_t*)(G.img + (long long)(G.iniY + ry) * G.pitch + G.gbase + wx * 4);
+            if (col_ok && 4 * k + rsub < G.rh) gw[k] = *(const uint32_t*)(G.img + ((long long)(G.iniY + 4 * k) * G.pitch + G.gbase) + lane_off);
         }
     };
     fast_cell_geom(c, P, b, cell_first, N);
     issue_loads(N);
     for (int jc = 0; jc < kFastCellsPerWave; jc++) {
     const FastCell G = N;
+    const int cell = cell_first + jc;
     if (G.valid == 0) { if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); } continue; }
-    const LevelGeom& g = P->lv[G.level];
-    const int cell = G.cell_in_level, ci = G.ci, cj = G.cj, cw = G.cw, ch = G.ch;
-    int* count_out = c.cell_count + (long long)b * P->total_cells + g.cell_base + cell;
-    uint32_t* out = c.cand + (long long)b * P->cand_per_image + g.cand_base + (long long)cell * g.cell_cap;
-    const int cell_cap = g.cell_cap, wCellOut = g.wCell, hCellOut = g.hCell;
+    const int cw = G.cw, ch = G.ch;
+    int* count_out = c.cell_count + (long long)b * P->total_cells + cell;
+    uint32_t* out = c.cand + (long long)b * P->cand_per_image + G.cand_ofs;
+    const int cell_cap = G.cell_cap;
+    const int xout0 = G.iniX - kRegionBorder + 3, yout0 = G.iniY - kRegionBorder + 3;   // cj * wCell + 3, ci * hCell + 3
     if (G.valid == 2) {
         if (lane == 0) *count_out = 0;
         if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
@@ -709,7 +703,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
 #pragma unroll
         for (int k = 0; k < kLoadIters; k++) {
             const int ry = 4 * k + rsub;
-            const uint32_t gn = __shfl_down(gw[k], 1, 64);
+            const uint32_t gn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)gw[k], 0x101 /* row_shl:1: lane i reads lane i + 1 of its 16-lane row */, 0xf, 0xf, true);
             if (ry < rh && wx < G.nwt) *(uint32_t*)(tile + ry * kWTileP + wx * 4) = __builtin_amdgcn_alignbyte(gn, gw[k], G.gsh);
         }
     } else {   // caller's level-0 buffer with an unaligned pitch: byte loads
@@ -797,7 +791,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
         }
     }
     if (nwork > kFastWorkLds) {   // (wave-uniform) too many survivors for the LDS worklist: the whole cell is redone by k_fast_cells_ovf
-        if (lane == 0) c.ovf_list[atomicAdd(c.ovf_count, 1)] = make_int2(b, g.cell_base + cell);
+        if (lane == 0) c.ovf_list[atomicAdd(c.ovf_count, 1)] = make_int2(b, cell);
         if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
         continue;
     }
@@ -862,7 +856,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
             const unsigned long long m = __ballot(flag);
             if (flag) {
                 const int slot = running + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < cell_cap) out[slot] = pack_xys(cj * wCellOut + x + 3, ci * hCellOut + y + 3, s);
+                if (slot < cell_cap) out[slot] = pack_xys(xout0 + x, yout0 + y, s);
             }
             running += __popcll(m);
         }

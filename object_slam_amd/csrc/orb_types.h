@@ -40,6 +40,18 @@ struct LevelGeom {
     float kp_size;            // (int)(PATCH_SIZE*scale), :837
 };
 
+// One FAST cell as k_fast_cells_wave needs it (built on the host once per extractor: the geometry does not depend on the image of the
+// batch).  32 bytes, read with one scalar load.
+struct FastCellRec {
+    uint32_t xy;         // iniX | iniY << 16 (first ROI column / row of the cell in its level image)
+    uint32_t dims;       // cw | ch << 8 | level << 16 | valid << 24  (valid 0: not handled here, 1: process, 2: empty cell)
+    uint32_t cand_ofs;   // first candidate slot of the cell in the per-image arena
+    uint32_t img_off;    // byte offset of the level image in the per-image pyramid arena (levels >= 1)
+    uint32_t cell_cap;   // candidate slots of the cell
+    uint32_t pitch;      // level image pitch (levels >= 1)
+    uint32_t pad0, pad1;
+};
+
 struct OrbParams {
     LevelGeom lv[OSLAM_MAX_LEVELS];
     int nlevels;
