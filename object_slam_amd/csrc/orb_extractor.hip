@@ -55,7 +55,7 @@ struct oslam_orb {
     int* d_cell_count = nullptr;
     uint32_t* d_cand = nullptr;
     FastCellRec* d_fast_cells = nullptr;   // per-cell geometry of k_fast_cells_wave
-    int* d_ovf_count = nullptr; int2* d_ovf_list = nullptr;   // FAST cells handed from the wavefront kernel to the workgroup kernel
+    int* d_ovf_count = nullptr;   // FAST cells that took k_fast_cells_wave's every-pixel path since creation (diagnostics)
     uint32_t* d_ent_g = nullptr;
     uint16_t* d_knode_g = nullptr;
     uint32_t* d_sel = nullptr;
@@ -68,6 +68,8 @@ struct oslam_orb {
     size_t oct_lds = 0;
     hipStream_t side_stream = nullptr;             // blur runs here, concurrently with FAST + quad-tree
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t fast0_stream = nullptr;            // FAST of level 0 (needs only the caller's image) runs here, beside the pyramid kernels
+    hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;
     hipStream_t aux_stream = nullptr, aux_side_stream = nullptr;   // second half of a large batch (see launch_batch)
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     int split_min = 1 << 30;                       // batches of at least this many images are cut in two halves (off by default: measured +4 % frames/s at
@@ -77,10 +79,10 @@ struct oslam_orb {
 
     // per-kernel-group timing (HIP events on the launch stream), enabled by oslam_orb_set_profiling
     int profiling = 0;
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6], [7]: blur begin / end on its own stream
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // [6], [7]: blur begin / end on its own stream; [8], [9]: level-0 FAST on its stream
     double prof_ms[5] = {0, 0, 0, 0, 0};
     long long prof_batches = 0, prof_images = 0;
-    bool prof_pending = false;
+    bool prof_pending = false, prof_fast0 = false;
 
     // last batch
     OrbCtx ctx;
@@ -119,7 +121,7 @@ int oslam_device_count(void) {
 void oslam_orb_destroy(oslam_orb_t* h) {
     if (!h) return;
     void* ptrs[] = {h->d_qbase, h->d_qpx, h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
-                    h->d_cell_count, h->d_cand, h->d_fast_cells, h->d_ovf_count, h->d_ovf_list, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
+                    h->d_cell_count, h->d_cand, h->d_fast_cells, h->d_ovf_count, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
                     h->d_out_count, h->d_status, h->d_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -128,6 +130,9 @@ void oslam_orb_destroy(oslam_orb_t* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->fast0_stream) (void)hipStreamDestroy(h->fast0_stream);
+    if (h->ev_fork0) (void)hipEventDestroy(h->ev_fork0);
+    if (h->ev_join0) (void)hipEventDestroy(h->ev_join0);
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     if (h->aux_side_stream) (void)hipStreamDestroy(h->aux_side_stream);
     for (hipEvent_t e : {h->ev_fork2, h->ev_join2, h->ev_fork3, h->ev_join3}) if (e) (void)hipEventDestroy(e);
@@ -380,7 +385,7 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_cell_count, B * (size_t)P.total_cells * sizeof(int));
     ALLOC(h->d_cand, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_ovf_count, 64);
-    ALLOC(h->d_ovf_list, B * (size_t)P.total_cells * sizeof(int2));
+    OSLAM_HIP_CHECK(hipMemset(h->d_ovf_count, 0, 64));
     ALLOC(h->d_ent_g, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_knode_g, B * (size_t)P.cand_per_image * sizeof(uint16_t));
     ALLOC(h->d_sel, B * (size_t)P.sel_per_image * sizeof(uint32_t));
@@ -440,6 +445,11 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
         OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
     }
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    if (getenv("OSLAM_ORB_FAST0_STREAM")) {   // kernel experiments (off: measured no gain at B = 512, the pyramid kernels slow down by what FAST gains: 2.60 ms per batch either way)
+        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->fast0_stream, hipStreamNonBlocking));
+        OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming));
+        OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join0, hipEventDisableTiming));
+    }
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_SPLIT_MIN")) h->split_min = atoi(getenv("OSLAM_ORB_SPLIT_MIN"));   // kernel experiments
     h->no_lds_resize = getenv("OSLAM_ORB_NO_LDS_RESIZE") != nullptr;
@@ -483,6 +493,12 @@ static int collect_profile(oslam_orb* h) {
         OSLAM_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[a[i]], h->ev[b[i]]));
         h->prof_ms[i] += ms;
     }
+    if (h->prof_fast0) {   // level 0's FAST cells ran on their own stream: their launch counts to the FAST group
+        float ms = 0;
+        OSLAM_HIP_CHECK(hipEventSynchronize(h->ev[9]));
+        OSLAM_HIP_CHECK(hipEventElapsedTime(&ms, h->ev[8], h->ev[9]));
+        h->prof_ms[1] += ms;
+    }
     h->prof_batches++;
     h->prof_images += h->prof_batch_images;
     h->prof_pending = false;
@@ -497,7 +513,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
     c.blur = h->d_blur; c.blur_stride = h->blur_stride;
     c.rtab = h->d_rtab; c.qbase = h->d_qbase; c.qpx = h->d_qpx; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
-    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.fast_cells = h->d_fast_cells; c.ovf_count = h->d_ovf_count; c.ovf_list = h->d_ovf_list; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
+    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.fast_cells = h->d_fast_cells; c.ovf_count = h->d_ovf_count; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
     c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status; c.dbg = h->d_dbg;
     const bool prof = h->profiling != 0;
     if (prof) {
@@ -509,9 +525,20 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     // so do FAST + quad-tree: the blur goes to the pair's second stream and overlaps the (VALU-bound) FAST kernel and the
     // (barrier-latency-bound) quad-tree kernel.  Large batches are cut in two halves on two stream pairs so that the kernels of one half
     // (each bound by a different resource) overlap the kernels of the other; profiling events bracket the kernels of the first half.
-    auto issue = [&](const OrbCtx& cs, int nb, hipStream_t sm, hipStream_t sb, hipEvent_t fork, hipEvent_t join, bool pr) -> int {
+    auto issue = [&](const OrbCtx& cs, int nb, hipStream_t sm, hipStream_t sb, hipStream_t f0, hipEvent_t fork, hipEvent_t join, bool pr) -> int {
 #define PROF_MARK(i) do { if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[i], sm)); } while (0)
+        if (pr) h->prof_fast0 = false;
         PROF_MARK(0);
+        // level 0's FAST cells need only the caller's image: they run on their own stream beside the (HBM / latency bound) pyramid kernels
+        const int cells0 = (f0 && P.nlevels > 1) ? P.lv[1].cell_base : 0;
+        if (cells0 > 0) {
+            OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork0, sm));
+            OSLAM_HIP_CHECK(hipStreamWaitEvent(f0, h->ev_fork0, 0));
+            if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[8], f0));
+            hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(cells0, 4 * kFastCellsPerWave), nb), dim3(256), 0, f0, cs, 0, cells0);
+            if (pr) { OSLAM_HIP_CHECK(hipEventRecord(h->ev[9], f0)); h->prof_fast0 = true; }
+            OSLAM_HIP_CHECK(hipEventRecord(h->ev_join0, f0));
+        }
         for (int l = 1; l < P.nlevels; l++) {
             const LevelGeom& g = P.lv[l];
             dim3 grid(div_up(g.w, 256), div_up(g.h, 4), nb);
@@ -531,10 +558,9 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
             OSLAM_HIP_CHECK(hipEventRecord(fork, sm));
             OSLAM_HIP_CHECK(hipStreamWaitEvent(sb, fork, 0));
         }
-        OSLAM_HIP_CHECK(hipMemsetAsync(cs.ovf_count, 0, sizeof(int), sm));
-        hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells, 4 * kFastCellsPerWave), nb), dim3(256), 0, sm, cs);
-        hipLaunchKernelGGL(k_fast_cells_ovf, dim3(256), dim3(256), 0, sm, cs);   // exits at once unless a cell overflowed the wavefront kernel's worklist
-        if (getenv("OSLAM_ORB_DEBUG_OVF")) { int n = 0; (void)hipStreamSynchronize(sm); (void)hipMemcpy(&n, cs.ovf_count, 4, hipMemcpyDeviceToHost); fprintf(stderr, "fast overflow cells: %d of %d\n", n, P.total_cells * nb); }
+        hipLaunchKernelGGL(k_fast_cells_wave, dim3(div_up(P.total_cells - cells0, 4 * kFastCellsPerWave), nb), dim3(256), 0, sm, cs, cells0, P.total_cells);
+        if (cells0 > 0) OSLAM_HIP_CHECK(hipStreamWaitEvent(sm, h->ev_join0, 0));
+        if (getenv("OSLAM_ORB_DEBUG_OVF")) { int n = 0; (void)hipStreamSynchronize(sm); (void)hipMemcpy(&n, cs.ovf_count, 4, hipMemcpyDeviceToHost); fprintf(stderr, "fast overflow cells since creation: %d (this batch has %d cells)\n", n, P.total_cells * nb); }
         if (P.any_big_cell) hipLaunchKernelGGL(k_fast_cells, dim3(P.total_cells, nb), dim3(256), 0, sm, cs);
         PROF_MARK(2);
         if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[6], sb));
@@ -560,7 +586,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         OrbCtx cs = c;
         const long long o = b0;
         cs.img0 += o * c.img0_stride; cs.pyr += o * c.pyr_stride; cs.blur += o * c.blur_stride;
-        cs.cell_count += o * P.total_cells; cs.ovf_count += 1; cs.ovf_list += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
+        cs.cell_count += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
         cs.sel += o * P.sel_per_image; cs.sel_count += o * P.nlevels;
         cs.out_kp += o * P.out_cap; cs.out_desc += o * P.out_cap * 32; cs.out_count += o;
         return cs;
@@ -568,15 +594,15 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     int rc;
     const bool split = batch >= h->split_min && h->aux_stream != nullptr;
     if (!split) {
-        rc = issue(c, batch, st, h->side_stream ? h->side_stream : st, h->ev_fork, h->ev_join, prof);
+        rc = issue(c, batch, st, h->side_stream ? h->side_stream : st, h->fast0_stream, h->ev_fork, h->ev_join, prof);
         if (rc) return rc;
         h->prof_batch_images = batch;
     } else {
         const int nb0 = batch / 2, nb1 = batch - nb0;
         OSLAM_HIP_CHECK(hipEventRecord(h->ev_fork2, st));
         OSLAM_HIP_CHECK(hipStreamWaitEvent(h->aux_stream, h->ev_fork2, 0));
-        if ((rc = issue(c, nb0, st, h->side_stream, h->ev_fork, h->ev_join, prof))) return rc;
-        if ((rc = issue(sub_ctx(nb0), nb1, h->aux_stream, h->aux_side_stream, h->ev_fork3, h->ev_join3, false))) return rc;
+        if ((rc = issue(c, nb0, st, h->side_stream, h->fast0_stream, h->ev_fork, h->ev_join, prof))) return rc;
+        if ((rc = issue(sub_ctx(nb0), nb1, h->aux_stream, h->aux_side_stream, nullptr, h->ev_fork3, h->ev_join3, false))) return rc;
         OSLAM_HIP_CHECK(hipEventRecord(h->ev_join2, h->aux_stream));
         OSLAM_HIP_CHECK(hipStreamWaitEvent(st, h->ev_join2, 0));
         h->prof_batch_images = nb0;
@@ -655,7 +681,7 @@ int oslam_orb_set_profiling(oslam_orb_t* h, int on) {
     if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     if (on && !h->ev[0])
-        for (int i = 0; i < 8; i++) OSLAM_HIP_CHECK(hipEventCreate(&h->ev[i]));
+        for (int i = 0; i < 10; i++) OSLAM_HIP_CHECK(hipEventCreate(&h->ev[i]));
     h->profiling = on != 0;
     for (int i = 0; i < 5; i++) h->prof_ms[i] = 0;
     h->prof_batches = 0; h->prof_images = 0; h->prof_pending = false;

@@ -26,8 +26,7 @@ struct OrbCtx {
     int* cell_count;          // [B][total_cells]
     uint32_t* cand;           // [B][cand_per_image]
     const FastCellRec* fast_cells;   // [total_cells] per-cell geometry of k_fast_cells_wave
-    int* ovf_count;           // cells whose quick-test worklist did not fit k_fast_cells_wave's LDS part ...
-    int2* ovf_list;           // ... as (image, global cell id): redone by k_fast_cells_ovf
+    int* ovf_count;           // cells whose quick-test worklist did not fit k_fast_cells_wave's LDS part (every-pixel path), cumulative
     uint32_t* ent_g;          // [B][cand_per_image] quad-tree spill (levels with > kCandCap candidates)
     uint16_t* knode_g;        // [B][cand_per_image]
     uint32_t* sel;            // [B][sel_per_image]
@@ -318,7 +317,7 @@ __device__ __forceinline__ int fast_score(const uint8_t* t) {
 }
 
 // One FAST cell by a whole workgroup: exact scores for every pixel of the cell, NMS, ordered output.  BIG_ONLY: cells wider than one wavefront
-// handles (k_fast_cells); otherwise any cell (k_fast_cells_ovf).  All threads of the workgroup must call.
+// handles (k_fast_cells); otherwise any cell.  All threads of the workgroup must call.
 template <bool BIG_ONLY>
 __device__ __forceinline__ void fast_cell_workgroup(const OrbCtx& c, const OrbParams* P, const int b, int cell) {
     int level = 0;
@@ -440,16 +439,6 @@ __device__ __forceinline__ void fast_cell_workgroup(const OrbCtx& c, const OrbPa
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(OrbCtx c) { fast_cell_workgroup<true>(c, c.P, blockIdx.y, blockIdx.x); }
-
-// Cells that k_fast_cells_wave handed back (worklist longer than its LDS part): a fixed grid walks the list; no entries -> immediate exit.
-__global__ __launch_bounds__(256) void k_fast_cells_ovf(OrbCtx c) {
-    const int n = *c.ovf_count;
-    for (int i = blockIdx.x; i < n; i += gridDim.x) {
-        const int2 e = c.ovf_list[i];
-        fast_cell_workgroup<false>(c, c.P, e.x, e.y);
-        __syncthreads();   // the shared tiles are reused by the next cell
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // K6 (v2): 7x7 Gaussian, register sliding window.  One thread produces a 4-pixel-wide, kBlurRows
@@ -581,7 +570,7 @@ constexpr int kWCell = 40;            // max interior edge handled per wavefront
 constexpr int kWTileP = 52;           // tile pitch in bytes (>= kWCell + 6 + 3 alignment slack, multiple of 4)
 constexpr int kWTileRows = kWCell + 6;
 // Worklist of pixels that pass the quick test: kFastWorkLds entries in LDS (a workgroup then needs 23 KB instead of 32 KB: 7 instead of 5
-// workgroups per CU; 3.33 -> 2.82 us/frame beside the blur).  A cell with more survivors is handed to k_fast_cells_ovf through a list.
+// workgroups per CU; 3.33 -> 2.82 us/frame beside the blur).  A cell with more survivors takes the every-pixel path of the same wavefront.
 constexpr int kFastWorkLds = 880;
 constexpr int kScP = 40;              // pitch of the score array (worklist entries keep the y * 64 + x encoding)
 // Score array of one wavefront: rows -1 .. kWCell of kScP bytes behind 4 leading bytes, all zeroed before the quick test, so the NMS reads the 8
@@ -628,9 +617,9 @@ struct FastCell {
     const uint8_t* img;
 };
 
-__device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, const OrbParams* P, int b, int cell /* wave-uniform */, FastCell& G) {
+__device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, int cell_end, int b, int cell /* wave-uniform */, FastCell& G) {
     G.valid = 0;
-    if (cell >= P->total_cells) return;
+    if (cell >= cell_end) return;
     const FastCellRec r = c.fast_cells[cell];
     G.valid = (int)(r.dims >> 24);
     G.cand_ofs = r.cand_ofs; G.cell_cap = (int)r.cell_cap;
@@ -650,7 +639,8 @@ __device__ __forceinline__ void fast_cell_geom(const OrbCtx& c, const OrbParams*
 
 constexpr int kFastCellsPerWave = 1;   // cells per wavefront (measured: 1 -> 2.64 us/frame, 2 -> 3.2, 4 -> 3.15 at B=64: the kernel is VALU bound, fewer and longer waves only add tail)
 
-__global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
+// Cells [cell_begin, cell_end) of every image: level 0's cells need only the caller's image and are launched beside the pyramid kernels.
+__global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c, int cell_begin, int cell_end) {
     const OrbParams* P = c.P;
 #ifdef OSLAM_FAST_PROFILE
     long long tl_ = clock64();
@@ -658,10 +648,11 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the cell geometry lives in scalar registers
-    const int cell_first = (blockIdx.x * 4 + wv) * kFastCellsPerWave;
+    const int cell_first = cell_begin + (blockIdx.x * 4 + wv) * kFastCellsPerWave;
     __shared__ __align__(4) uint8_t s_tile[4][kWTileRows * kWTileP];
     __shared__ __align__(4) uint8_t s_sc[4][kScBytes];   // scores, zero ring around the cell (see kScBytes)
-    __shared__ uint16_t s_work[4][kFastWorkLds];      // worklist: y*64 + x of pixels passing the quick test, row-major
+    __shared__ __align__(8) uint16_t s_work[4][kFastWorkLds];      // worklist: y*64 + x of pixels passing the quick test, row-major
+    static_assert((kFastWorkLds * 2) % 8 == 0 && kWCell * 8 <= kFastWorkLds * 2, "the overflow path parks 8-byte row masks in the worklist");
     uint8_t* tile = s_tile[wv];
     uint8_t* sc = s_sc[wv] + kScP + 4;   // sc[y * kScP + x], rows -1 .. kWCell and column -1 exist
     uint16_t* work = s_work[wv];
@@ -680,12 +671,12 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
             if (col_ok && 4 * k + rsub < G.rh) gw[k] = *(const uint32_t*)(G.img + ((long long)(G.iniY + 4 * k) * G.pitch + G.gbase) + lane_off);
         }
     };
-    fast_cell_geom(c, P, b, cell_first, N);
+    fast_cell_geom(c, cell_end, b, cell_first, N);
     issue_loads(N);
     for (int jc = 0; jc < kFastCellsPerWave; jc++) {
     const FastCell G = N;
     const int cell = cell_first + jc;
-    if (G.valid == 0) { if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); } continue; }
+    if (G.valid == 0) { if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, cell_end, b, cell_first + jc + 1, N); issue_loads(N); } continue; }
     const int cw = G.cw, ch = G.ch;
     int* count_out = c.cell_count + (long long)b * P->total_cells + cell;
     uint32_t* out = c.cand + (long long)b * P->cand_per_image + G.cand_ofs;
@@ -693,7 +684,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     const int xout0 = G.iniX - kRegionBorder + 3, yout0 = G.iniY - kRegionBorder + 3;   // cj * wCell + 3, ci * hCell + 3
     if (G.valid == 2) {
         if (lane == 0) *count_out = 0;
-        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, cell_end, b, cell_first + jc + 1, N); issue_loads(N); }
         continue;
     }
     const int rw = G.rw, rh = G.rh;
@@ -715,7 +706,7 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // the next cell's tile words travel while this cell is processed
-    if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+    if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, cell_end, b, cell_first + jc + 1, N); issue_loads(N); }
     else N.valid = 0;
     FSTAMP(0);
     const uint8_t* t0 = tile + 3 * kWTileP + 4;   // t0[y*kWTileP + x] = interior pixel (x, y)
@@ -790,9 +781,57 @@ __global__ __launch_bounds__(256) void k_fast_cells_wave(OrbCtx c) {
             nwork += __popcll(m);
         }
     }
-    if (nwork > kFastWorkLds) {   // (wave-uniform) too many survivors for the LDS worklist: the whole cell is redone by k_fast_cells_ovf
-        if (lane == 0) c.ovf_list[atomicAdd(c.ovf_count, 1)] = make_int2(b, cell);
-        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, P, b, cell_first + jc + 1, N); issue_loads(N); }
+    if (nwork > kFastWorkLds) {
+        // (wave-uniform, rare) more survivors than the LDS worklist holds: exact scores for every pixel of the cell, one row of
+        // the cell per pass (lane = column), then the same NMS / threshold vote / row-major output from per-row keep masks that
+        // are parked in the worklist's LDS.  "corner at t" <=> score >= t, so skipping the quick test changes nothing.
+        __builtin_amdgcn_wave_barrier();
+        for (int y = 0; y < ch; y++)
+            if (lane < cw) sc[y * kScP + lane] = (uint8_t)fast_score3<kWTileP>(t0 + y * kWTileP + lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long* rowmask = (unsigned long long*)s_work[wv];   // ch <= kWCell masks of 8 bytes: 320 B of the 1760 B worklist (8-byte aligned: see the static_assert)
+        bool hit = false;
+        for (int y = 0; y < ch; y++) {
+            bool keep = false;
+            if (lane < cw) {
+                const int sv = sc[y * kScP + lane];
+                keep = sv >= minTh;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int xx = lane + dx, yy = y + dy;
+                        const int nb = (xx >= 0 && xx < cw && yy >= 0 && yy < ch) ? sc[yy * kScP + xx] : 0;
+                        keep = keep && (sv > nb);
+                    }
+                hit = hit || (keep && sv >= iniTh);
+            }
+            const unsigned long long km = __ballot(keep);
+            if (lane == 0) rowmask[y] = km;
+        }
+        const int th_s = __any(hit) ? iniTh : minTh;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int run = 0;
+        for (int y = 0; y < ch; y++) {
+            const unsigned long long km = rowmask[y];
+            const int sv = lane < cw ? sc[y * kScP + lane] : 0;
+            const bool flag = ((km >> lane) & 1ull) && sv >= th_s;
+            const unsigned long long m = __ballot(flag);
+            if (flag) {
+                const int slot = run + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cell_cap) out[slot] = pack_xys(xout0 + lane, yout0 + y, sv);
+            }
+            run += __popcll(m);
+        }
+        if (lane == 0) {
+            if (run > cell_cap) { atomicOr(c.status, 1); run = cell_cap; }
+            *count_out = run;
+            atomicAdd(c.ovf_count, 1);
+        }
+        if (jc + 1 < kFastCellsPerWave) { fast_cell_geom(c, cell_end, b, cell_first + jc + 1, N); issue_loads(N); }
         continue;
     }
     __builtin_amdgcn_wave_barrier();
