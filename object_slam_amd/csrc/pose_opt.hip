@@ -106,21 +106,72 @@ __device__ __forceinline__ void project_f32(const float* T, const float* P, floa
     }
 }
 
-template <bool SEM>
+#ifdef OSLAM_POSE_PROFILE
+__device__ unsigned long long g_pose_prof[8];   // cycles of frame 0 per phase: build, sum28, solve+exp, eval, sum1, classify, prologue, total
+#define PSTAMP(i) do { if (b == 0 && tid == 0) { const long long t_ = clock64(); pacc[i] += (unsigned long long)(t_ - tp_); tp_ = t_; } } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
+
+// Block-wide sums of the 28 accumulators of the build pass (21 H + 6 b + chi2), every thread returns the same totals (fixed order).
+// Transposed through LDS: every thread parks its 28 partials, 8 threads per value add 32 partials each and combine with three
+// shuffle steps -- 28 writes + 32 reads per thread instead of the 168 double-precision shuffle steps of 28 wavefront butterflies.
+constexpr int kSumN = 28, kSumPitch = kPoseThreads + 8;   // pitch = 8 mod 32 doubles: the 8 value rows of a wavefront's reads fall on different banks
+static_assert(kSumN * 8 <= kPoseThreads && kPoseThreads % 8 == 0, "block_sum_wide: 8 summing threads per value");
+__device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_part /* [kSumN][kSumPitch] */, double* s_tot /* [kSumN] */) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < kSumN; i++) s_part[i * kSumPitch + tid] = v[i];
+    __syncthreads();
+    if (tid < kSumN * 8) {
+        const double* row = s_part + (tid >> 3) * kSumPitch + (tid & 7);
+        double s = row[0];
+#pragma unroll
+        for (int k = 1; k < kPoseThreads / 8; k++) s += row[8 * k];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if ((tid & 7) == 0) s_tot[tid >> 3] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSumN; i++) v[i] = s_tot[i];
+}
+
+// STAGE: the edge data (Xw, obs, invSigma2: 28 B per edge) are copied into LDS once; every pass of the ~100 over the edges then reads them at LDS
+// latency instead of paying a global-memory round trip per edge (one wavefront per SIMD: nothing else hides it).
+template <bool SEM, bool STAGE>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     const int b = blockIdx.x, tid = threadIdx.x;
+#ifdef OSLAM_POSE_PROFILE
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tp_ = clock64();
+    const long long tstart_ = tp_;
+#endif
     const int N = c.n ? c.n[b] : c.n_const;
-    const float* Xw = c.Xw + (long long)b * c.stride * 3;
-    const float* obsp = c.obs + (long long)b * c.stride * 3;
-    const float* inv = c.invSigma2 + (long long)b * c.stride;
+    const float* gXw = c.Xw + (long long)b * c.stride * 3;
+    const float* gobs = c.obs + (long long)b * c.stride * 3;
+    const float* ginv = c.invSigma2 + (long long)b * c.stride;
     const uint8_t* has = c.has_mp + (long long)b * c.stride;
     uint8_t* outl = c.outlier + (long long)b * c.stride;
     const float* T0f = c.Tcw + b * 16;
 
     extern __shared__ __align__(16) uint8_t smem[];
     double* s_chi2 = (double*)smem;                         // [stride] _error chi2 as last computed (may be stale)
-    uint8_t* s_level = (uint8_t*)(s_chi2 + c.stride);       // [stride] 0 active, 1 excluded, 255 no edge
+    float* s_edge = (float*)(s_chi2 + c.stride);            // STAGE: [stride][3] Xw, [stride][3] obs, [stride] invSigma2
+    uint8_t* s_level = (uint8_t*)(s_edge + (STAGE ? 7 * c.stride : 0));   // [stride] 0 active, 1 excluded, 255 no edge
+    const float* Xw = STAGE ? s_edge : gXw;
+    const float* obsp = STAGE ? s_edge + 3 * c.stride : gobs;
+    const float* inv = STAGE ? s_edge + 6 * c.stride : ginv;
+    if (STAGE) {
+        for (int i = tid; i < 3 * N; i += kPoseThreads) { s_edge[i] = gXw[i]; s_edge[3 * c.stride + i] = gobs[i]; }
+        for (int i = tid; i < N; i += kPoseThreads) s_edge[6 * c.stride + i] = ginv[i];
+    }
     __shared__ double s_red[2 * kPoseWaves * kRedN];
+    __shared__ double s_part[kSumN * kSumPitch], s_tot[kSumN];   // block_sum_wide (59 KB)
+    constexpr int kCandN = 14;                                   // candidate pose (q, t), step x, solve ok
+    __shared__ double s_cand[kPoseWaves * kCandN];
+    const int wv = tid >> 6;
     __shared__ int s_cnt[2];
     int phase = 0;
 
@@ -221,6 +272,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         return F;
     };
 
+    PSTAMP(6);
     for (int it = 0; it < 4; it++) {
         const bool robust = it < 3;   // setRobustKernel(0) after round index 2 (:407,:436)
         T = T0;                       // every round restarts from the input pose (:377)
@@ -300,7 +352,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                         }
                     }
                 }
-                block_sum<kRedN>(acc, s_red, phase);
+                PSTAMP(0);
+                block_sum_wide(acc, s_part, s_tot);
+                PSTAMP(1);
                 double currentChi = acc[27];
                 double H[36], g[6];
                 {
@@ -318,14 +372,42 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 double rho = 0;
                 int qmax = 0;
                 do {
-                    double A[36], x[6];
-                    for (int k = 0; k < 36; k++) A[k] = H[k];
-                    for (int a = 0; a < 6; a++) { A[a * 7] += lambda; x[a] = g[a]; }
-                    const bool ok2 = solve6(A, x);
-                    if (!ok2) for (int a = 0; a < 6; a++) x[a] = 0;
-                    const SE3 Tn = se3_mul(se3_exp(x), T);
+                    // A rejected trial multiplies lambda by ni and doubles ni, so the damping of the next trials is known in advance: wavefront w
+                    // solves for trial qmax + w (the 6x6 Cholesky and the exponential map are ~5 k cycles of dependent fp64 divisions,
+                    // square roots, sin / cos), the candidates wait in LDS and are evaluated one after the other exactly as before.
+                    if ((qmax % kPoseWaves) == 0) {
+                        double lw = lambda, nw = ni;
+                        for (int k = 0; k < wv; k++) { lw *= nw; nw *= 2; }
+                        double A[36], xw[6];
+                        for (int k = 0; k < 36; k++) A[k] = H[k];
+                        for (int a = 0; a < 6; a++) { A[a * 7] += lw; xw[a] = g[a]; }
+                        const bool okw = solve6(A, xw);
+                        if (!okw) for (int a = 0; a < 6; a++) xw[a] = 0;
+                        const SE3 Tw = se3_mul(se3_exp(xw), T);
+                        if ((tid & 63) == 0) {
+                            double* cd = s_cand + wv * kCandN;
+                            for (int k = 0; k < 4; k++) cd[k] = Tw.q[k];
+                            for (int k = 0; k < 3; k++) cd[4 + k] = Tw.t[k];
+                            for (int k = 0; k < 6; k++) cd[7 + k] = xw[k];
+                            cd[13] = okw ? 1.0 : 0.0;
+                        }
+                        __syncthreads();
+                    }
+                    double x[6];
+                    SE3 Tn;
+                    bool ok2;
+                    {
+                        const double* cd = s_cand + (qmax % kPoseWaves) * kCandN;
+                        for (int k = 0; k < 4; k++) Tn.q[k] = cd[k];
+                        for (int k = 0; k < 3; k++) Tn.t[k] = cd[4 + k];
+                        for (int k = 0; k < 6; k++) x[k] = cd[7 + k];
+                        ok2 = cd[13] != 0.0;
+                    }
+                    PSTAMP(2);
                     double v[1] = {eval(Tn, robust)};
+                    PSTAMP(3);
                     block_sum<1>(v, s_red, phase);
+                    PSTAMP(4);
                     double tempChi = v[0];
                     if (!ok2) tempChi = 1.7976931348623157e308;
                     rho = currentChi - tempChi;
@@ -434,6 +516,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
             block_sum<1>(v, s_red, phase);
             nBad = (int)v[0];
         }
+        PSTAMP(5);
         if (nInitial + nsem < 10) break;   // optimizer.edges().size()<10 (:440); semantic edges count too
     }
 
@@ -444,6 +527,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         c.n_inliers[b] = nInitial - nBad;
         if (c.stats) { c.stats[b * 2] = tot_its; c.stats[b * 2 + 1] = tot_trials; }
         if (SEM) sm.nSem[b] = s_semnum;
+#ifdef OSLAM_POSE_PROFILE
+        if (b == 0) { pacc[7] = (unsigned long long)(clock64() - tstart_); for (int k = 0; k < 8; k++) g_pose_prof[k] = pacc[k]; }
+#endif
     }
 }
 
@@ -483,8 +569,13 @@ __global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, int H, i
 
 using namespace oslam;
 
+// dynamic LDS of k_pose_optimize: chi2 (8 B) + level (1 B) per edge slot, + the staged edge data (28 B) when STAGE
+static size_t pose_lds_bytes(size_t stride, bool stage) { return stride * (stage ? 37 : 9) + 64; }
+constexpr size_t kPoseLdsBudget = 98 * 1024;   // 160 KB per workgroup minus the kernel's static arrays (59 KB of them block_sum_wide's)
+
 struct oslam_poseopt {
     int device = 0, max_batch = 0, max_points = 0;
+    bool stage = false;   // edge data staged in LDS (fits for max_points <= 2700)
     float* d_Tout = nullptr; uint8_t* d_outlier = nullptr; int* d_ninl = nullptr; int* d_stats = nullptr;
     // staging for the host API
     float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
@@ -519,7 +610,7 @@ void oslam_poseopt_destroy(oslam_poseopt_t* h) {
 int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, int device) {
     if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
     *out = nullptr;
-    if (max_batch < 1 || max_points < 1 || max_points > 16000) { set_error("oslam_poseopt_create: invalid argument (max_points <= 16000)"); return OSLAM_E_INVALID; }
+    if (max_batch < 1 || max_points < 1 || max_points > 11000) { set_error("oslam_poseopt_create: invalid argument (max_points <= 11000: chi2 + level per edge slot live in LDS)"); return OSLAM_E_INVALID; }
     int ndev = oslam_device_count();
     if (ndev <= 0) { set_error("no HIP device visible: the gfx950 pose optimiser has no CPU fallback"); return OSLAM_E_HIP; }
     if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
@@ -539,11 +630,24 @@ int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, i
     ALLOC(h->d_Tout, B * 64); ALLOC(h->d_outlier, B * NP); ALLOC(h->d_ninl, B * 4); ALLOC(h->d_stats, B * 8);
     ALLOC(h->d_T, 64); ALLOC(h->d_Xw, NP * 12); ALLOC(h->d_obs, NP * 12); ALLOC(h->d_inv, NP * 4); ALLOC(h->d_has, NP);
 #undef ALLOC
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(NP * 9 + 64)));
+    h->stage = pose_lds_bytes(NP, true) <= kPoseLdsBudget;
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes(NP, false)));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes(NP, false)));
+    if (h->stage) {
+        OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes(NP, true)));
+        OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_pose_optimize<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pose_lds_bytes(NP, true)));
+    }
     *out = h;
     return OSLAM_OK;
 }
+
+#ifdef OSLAM_POSE_PROFILE
+int oslam_pose_debug_profile(unsigned long long out[8]) {
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    OSLAM_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pose_prof), 64));
+    return OSLAM_OK;
+}
+#endif
 
 int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, int n_const, const float* d_Tcw,
                                      const float* d_Xw, const float* d_obs, const float* d_invSigma2, const uint8_t* d_has_mp,
@@ -557,9 +661,9 @@ int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, 
     c.n = d_n; c.n_const = n_const; c.stride = stride;
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
-    const size_t lds = (size_t)stride * 9 + 64;
     memset(&c.sem, 0, sizeof(c.sem));
-    hipLaunchKernelGGL(k_pose_optimize<false>, dim3(batch), dim3(kPoseThreads), lds, (hipStream_t)stream, c);
+    if (h->stage) hipLaunchKernelGGL((k_pose_optimize<false, true>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, true), (hipStream_t)stream, c);
+    else hipLaunchKernelGGL((k_pose_optimize<false, false>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, false), (hipStream_t)stream, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
@@ -675,8 +779,8 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     sm.minX = sem->bounds[0]; sm.minY = sem->bounds[1]; sm.maxX = sem->bounds[2]; sm.maxY = sem->bounds[3]; sm.invSigma2_0 = sem->invSigma2_0;
     sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p; sm.e_out = (uint8_t*)h->eout.p; sm.e_tmp = (int*)h->etmp.p;
     sm.nSem = (int*)h->nsem.p;
-    const size_t lds = (size_t)h->max_points * 9 + 64;
-    hipLaunchKernelGGL(k_pose_optimize<true>, dim3(1), dim3(kPoseThreads), lds, nullptr, c);
+    if (h->stage) hipLaunchKernelGGL((k_pose_optimize<true, true>), dim3(1), dim3(kPoseThreads), pose_lds_bytes(h->max_points, true), nullptr, c);
+    else hipLaunchKernelGGL((k_pose_optimize<true, false>), dim3(1), dim3(kPoseThreads), pose_lds_bytes(h->max_points, false), nullptr, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipDeviceSynchronize());
     OSLAM_HIP_CHECK(hipMemcpy(Tcw_out, h->d_Tout, 64, hipMemcpyDeviceToHost));

@@ -18,3 +18,10 @@ for nb in (1, 16, 64, 128, 256):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / 5
     print("pose-opt batch %d: %.3f ms/launch, %.1f us/frame" % (nb, dt * 1e3, dt / nb * 1e6))
+if hasattr(po.L, "oslam_pose_debug_profile"):   # profiling build (OSLAM_EXTRA_FLAGS=-DOSLAM_POSE_PROFILE): phase cycles of frame 0
+    import ctypes as C
+    po.optimize_batch_device(1, N, None, N, Tcw.data_ptr(), Xw.data_ptr(), obs.data_ptr(), inv.data_ptr(), has.data_ptr(), probs[0]["K"], st)
+    out = (C.c_ulonglong * 8)()
+    po.L.oslam_pose_debug_profile(out)
+    names = ["build pass", "sum of 28", "solve + exp", "eval pass", "sum of 1", "classify", "prologue", "total"]
+    for n_, v in zip(names, out): print("%-12s %10d cyc %5.1f%%" % (n_, v, 100.0 * v / max(out[7], 1)))
