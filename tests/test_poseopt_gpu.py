@@ -33,6 +33,25 @@ def test_pose_optimization_matches_oracle(oracle, seed, N, K, frac):
     po.close()
 
 
+def test_pose_optimization_large_capacity_reads_edges_from_global_memory(oracle):
+    """max_points above 2700 no longer leaves room for the staged edge data beside the reduction buffer in LDS: the kernel variant that
+    reads Xw / obs / invSigma2 from global memory must give the same result as the staged one and as the oracle."""
+    p = synth.make_pose_problem(7, N=1800, K=synth.KITTI_K, width=1241, height=376, outlier_frac=0.15, stereo_frac=0.8)
+    args = (p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], p["has_mp"], p["K"])
+    big, small = PoseOptimizer(max_points=6000), PoseOptimizer(max_points=2048)
+    nb, Tb, ob, _ = big.PoseOptimization(*args)
+    ns, Ts, os_, _ = small.PoseOptimization(*args)
+    on, oT, ooutl, _ = oracle.pose_optimization(*args)
+    assert nb == ns == on
+    np.testing.assert_array_equal(ob, os_)
+    np.testing.assert_array_equal(ob, ooutl)
+    assert np.array_equal(Tb, Ts)          # same arithmetic, only the source of the operands differs
+    assert _rel(Tb, oT) <= RTOL
+    with pytest.raises(Exception):
+        PoseOptimizer(max_points=20000)    # chi2 + level per edge slot would not fit in LDS
+    big.close(); small.close()
+
+
 def test_pose_optimization_edge_cases(oracle):
     po = PoseOptimizer(max_points=512)
     p = synth.make_pose_problem(7, N=200)
