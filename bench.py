@@ -327,7 +327,7 @@ def main():
             import ctypes as C
             from object_slam_amd import slam
             import threading
-            SB, NF, NBASE, NG = 256, 60, 8, 4
+            SB, NF, NBASE, NG = 512, 60, 8, 4   # 4 handles x 128 sequences (measured: 256 in 4 -> 14.5 k, 384 in 6 -> 17.1 k, 512 in 4 -> 17.9 k, 512 in 8 -> 16.2 k frames/s)
             SG = SB // NG
             base = [synth.make_stream(NF, W, H, seed=11 + s, margin=1200) for s in range(NBASE)]
             d_base = [torch.from_numpy(b[0]).cuda() for b in base]

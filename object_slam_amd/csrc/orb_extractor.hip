@@ -66,6 +66,7 @@ struct oslam_orb {
     int* d_status = nullptr;
     unsigned long long* d_dbg = nullptr;
     size_t oct_lds = 0;
+    int* d_oct_nodes = nullptr; long long oct_nodes_stride = 0;   // quad-tree node tables in HBM when they exceed the LDS
     hipStream_t side_stream = nullptr;             // blur runs here, concurrently with FAST + quad-tree
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t fast0_stream = nullptr;            // FAST of level 0 (needs only the caller's image) runs here, beside the pyramid kernels
@@ -121,7 +122,7 @@ int oslam_device_count(void) {
 void oslam_orb_destroy(oslam_orb_t* h) {
     if (!h) return;
     void* ptrs[] = {h->d_qbase, h->d_qpx, h->dP, h->d_rtab, h->d_root_of_x, h->d_root_x, h->d_stage, h->d_pyr, h->d_blur,
-                    h->d_cell_count, h->d_cand, h->d_fast_cells, h->d_ovf_count, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
+                    h->d_cell_count, h->d_cand, h->d_oct_nodes, h->d_fast_cells, h->d_ovf_count, h->d_ent_g, h->d_knode_g, h->d_sel, h->d_sel_count, h->d_out_kp, h->d_out_desc,
                     h->d_out_count, h->d_status, h->d_dbg};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -355,10 +356,9 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     {
         const size_t NC = P.node_cap;
         h->oct_lds = (size_t)kCandCap * 6 + (4 * NC + 4 * NC + NC * 3 + 2 * (NC + 1) + NC * 5 + 32) * 4 + 8 * NC * 2 + 64;
-        if (h->oct_lds > 160 * 1024 - 512) {
-            set_error("nfeatures=%d needs %zu B of LDS for the quad-tree kernel (limit 160 KiB)", nfeatures, h->oct_lds);
-            delete h;
-            return OSLAM_E_INVALID;
+        if (h->oct_lds > 160 * 1024 - 512) {   // the node tables go to HBM (one slice per image and level), the kernel keeps 64 B of LDS
+            h->oct_nodes_stride = (long long)align_up((4 * NC + 4 * NC + NC * 3 + 2 * (NC + 1) + NC * 5 + 32) + 4 * NC + 16, 64);
+            h->oct_lds = 64;
         }
     }
 
@@ -385,6 +385,7 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_cell_count, B * (size_t)P.total_cells * sizeof(int));
     ALLOC(h->d_cand, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_ovf_count, 64);
+    if (h->oct_nodes_stride) ALLOC(h->d_oct_nodes, B * (size_t)nlevels * h->oct_nodes_stride * sizeof(int));
     OSLAM_HIP_CHECK(hipMemset(h->d_ovf_count, 0, 64));
     ALLOC(h->d_ent_g, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_knode_g, B * (size_t)P.cand_per_image * sizeof(uint16_t));
@@ -439,6 +440,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
     OSLAM_HIP_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree_spill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
     {   // the blur stream runs at the lowest priority: FAST, the overflow cells and the quad-tree on the caller's stream are dispatched first
         int least = 0, greatest = 0;
         OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -513,7 +516,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
     c.pyr = h->d_pyr; c.pyr_stride = h->pyr_stride;
     c.blur = h->d_blur; c.blur_stride = h->blur_stride;
     c.rtab = h->d_rtab; c.qbase = h->d_qbase; c.qpx = h->d_qpx; c.root_of_x = h->d_root_of_x; c.root_x = h->d_root_x;
-    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.fast_cells = h->d_fast_cells; c.ovf_count = h->d_ovf_count; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
+    c.cell_count = h->d_cell_count; c.cand = h->d_cand; c.fast_cells = h->d_fast_cells; c.oct_nodes = h->d_oct_nodes; c.oct_nodes_stride = h->oct_nodes_stride; c.ovf_count = h->d_ovf_count; c.ent_g = h->d_ent_g; c.knode_g = h->d_knode_g; c.sel = h->d_sel; c.sel_count = h->d_sel_count;
     c.out_kp = h->d_out_kp; c.out_desc = h->d_out_desc; c.out_count = h->d_out_count; c.status = h->d_status; c.dbg = h->d_dbg;
     const bool prof = h->profiling != 0;
     if (prof) {
@@ -567,7 +570,11 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         hipLaunchKernelGGL(k_blur_strip<false>, dim3(P.blur_block_base[P.nlevels], nb), dim3(256), 0, sb, cs, h->blur_sse2);
         hipLaunchKernelGGL(k_blur_strip<true>, dim3(P.blurb_block_base[P.nlevels], nb), dim3(256), 0, sb, cs, h->blur_sse2);
         if (pr) OSLAM_HIP_CHECK(hipEventRecord(h->ev[7], sb));
-        hipLaunchKernelGGL(k_octree, dim3(P.nlevels, nb), dim3(kOctThreads), h->oct_lds, sm, cs);
+        if (cs.oct_nodes) hipLaunchKernelGGL(k_octree_hbm, dim3(P.nlevels, nb), dim3(kOctThreads), h->oct_lds, sm, cs);
+        else {
+            hipLaunchKernelGGL(k_octree, dim3(P.nlevels, nb), dim3(kOctThreads), h->oct_lds, sm, cs);
+            hipLaunchKernelGGL(k_octree_spill, dim3(P.nlevels, nb), dim3(kOctThreads), h->oct_lds, sm, cs);
+        }
         PROF_MARK(3);
         if (overlap) {
             OSLAM_HIP_CHECK(hipEventRecord(join, sb));
@@ -586,7 +593,7 @@ static int launch_batch(oslam_orb* h, const uint8_t* d_gray, int batch, int stri
         OrbCtx cs = c;
         const long long o = b0;
         cs.img0 += o * c.img0_stride; cs.pyr += o * c.pyr_stride; cs.blur += o * c.blur_stride;
-        cs.cell_count += o * P.total_cells; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
+        cs.cell_count += o * P.total_cells; if (cs.oct_nodes) cs.oct_nodes += o * P.nlevels * c.oct_nodes_stride; cs.cand += o * P.cand_per_image; cs.ent_g += o * P.cand_per_image; cs.knode_g += o * P.cand_per_image;
         cs.sel += o * P.sel_per_image; cs.sel_count += o * P.nlevels;
         cs.out_kp += o * P.out_cap; cs.out_desc += o * P.out_cap * 32; cs.out_count += o;
         return cs;

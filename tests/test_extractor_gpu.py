@@ -127,3 +127,13 @@ def test_fast_worklist_overflow_cells(oracle):
     img = np.clip(img, 0, 255).astype(np.uint8)
     n = _stages(oracle, TUM, img)
     assert n > 500
+
+
+def test_large_quota_on_few_levels_node_tables_in_hbm(oracle):
+    """2600 features on one or two levels: the quad-tree's node tables (88 B per node) no longer fit the 160 KB of LDS, the kernel then
+    keeps them (and the candidate list) in HBM; same algorithm, same result."""
+    from object_slam_amd import synth
+    img = synth.make_stream(1, 640, 480, seed=77)[0][0]
+    for nl in (1, 2):
+        n = _stages(oracle, dict(nfeatures=2600, scaleFactor=1.2, nlevels=nl, iniThFAST=20, minThFAST=7), img)
+        assert n > 1200, n
