@@ -1,7 +1,7 @@
 // gfx950 stereo association: Frame::ComputeStereoMatches (reference src/Frame.cc:706-880) —
 // row-band Hamming search left->right, 11-shift 11x11 SAD refinement on the pyramid level of the
 // left keypoint, parabola sub-pixel fit, depth = bf/disparity, median-SAD outlier cut.
-// One 1024-thread workgroup per stereo pair; right keypoints + descriptors staged in LDS.
+// Scan and outlier cut: one 1024-thread workgroup per stereo pair (right keypoints + descriptors staged in LDS); SAD refinement: one wavefront per left keypoint over the whole GPU.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,12 +29,30 @@ struct StereoCtx {
     float* uRight; float* depth;   // [B][kp_stride]
     int* sad;                      // [B][kp_stride] scratch: best SAD of accepted matches or -1
     int* n_matched;                // [B]
+    short* best;                   // [B][kp_stride] scratch: best right index of the Hamming scan or -1
+    unsigned short* row_items;     // [B][ncap * kRowItemsPerKp] scratch: row table items
 };
 
-__global__ __launch_bounds__(kStereoThreads) void k_stereo(StereoCtx c, int ncap) {
-    const int bidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int N = c.nL ? c.nL[bidx] : c.nL_const;
-    const int Nr = c.nR ? c.nR[bidx] : c.nR_const;
+// ------------------------------------------------------------------------------------------
+// Three kernels.  k_stereo_scan (one workgroup per pair): right keypoints + descriptors into LDS, the reference's row table
+// (vRowIndices, :716-733) as a counting sort over the image rows (items in HBM scratch), then one thread per left keypoint scans
+// the candidates of its row.  The reference keeps the FIRST minimum in right-keypoint order; the lists here are unordered, so the
+// scan takes the minimum of (distance, right index), which is the same keypoint.  k_stereo_sad (one wavefront per left keypoint,
+// the whole GPU): 11-shift SAD + parabola.  k_stereo_cut (one workgroup per pair): median SAD by bisection, outlier cut.
+// ------------------------------------------------------------------------------------------
+constexpr int kStereoMaxRows = 4096;      // level-0 height limit of the extractor
+constexpr int kRowItemsPerKp = 24;        // capacity of the row table: items per right keypoint (band of 2 * 2 * scale + 1 rows; 17 at 1.2^7)
+
+__device__ __forceinline__ bool stereo_counts(const StereoCtx& c, int bidx, int ncap, int& N, int& Nr) {
+    N = c.nL ? c.nL[bidx] : c.nL_const;
+    Nr = c.nR ? c.nR[bidx] : c.nR_const;
+    return !(N > ncap || Nr > ncap || N < 0 || Nr < 0);
+}
+
+__global__ __launch_bounds__(kStereoThreads) void k_stereo_scan(StereoCtx c, int ncap) {
+    const int bidx = blockIdx.x, tid = threadIdx.x;
+    int N, Nr;
+    const bool ok = stereo_counts(c, bidx, ncap, N, Nr);
     const oslam_keypoint_t* kpL = c.kpL + (long long)bidx * c.kp_stride;
     const oslam_keypoint_t* kpR = c.kpR + (long long)bidx * c.kp_stride;
     const uint32_t* dL = (const uint32_t*)(c.descL + (long long)bidx * c.kp_stride * 32);
@@ -42,37 +60,69 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(StereoCtx c, int ncap
     float* uRight = c.uRight + (long long)bidx * c.kp_stride;
     float* depth = c.depth + (long long)bidx * c.kp_stride;
     int* sad = c.sad + (long long)bidx * c.kp_stride;
+    short* best_out = c.best + (long long)bidx * c.kp_stride;
+    unsigned short* items = c.row_items + (long long)bidx * ncap * kRowItemsPerKp;
 
     extern __shared__ __align__(16) uint8_t smem[];
     uint32_t* s_desc = (uint32_t*)smem;                 // [ncap][8] right descriptors
     float* s_x = (float*)(s_desc + (size_t)ncap * 8);   // [ncap] right u
-    short* s_minr = (short*)(s_x + ncap);               // [ncap]
+    int* s_row = (int*)(s_x + ncap);                    // [kStereoMaxRows + 1] row starts (counting sort)
+    short* s_minr = (short*)(s_row + kStereoMaxRows + 1);   // [ncap]
     short* s_maxr = s_minr + ncap;                      // [ncap]
-    short* s_best = s_maxr + ncap;                      // [ncap] per LEFT keypoint: best right index or -1
-    uint8_t* s_oct = (uint8_t*)(s_best + ncap);         // [ncap]
-    __shared__ int s_cnt, s_median;
+    uint8_t* s_oct = (uint8_t*)(s_maxr + ncap);         // [ncap]
+    __shared__ int s_total;
+    __shared__ int s_wtot[kStereoThreads / 64];
 
-    if (N > ncap || Nr > ncap || N < 0 || Nr < 0) {
-        if (tid == 0) c.n_matched[bidx] = -1;
-        return;
-    }
-    const int nRows = c.L.h[0];
-    // ---- row table (:716-733) kept implicit: right keypoint iR is a candidate of row y iff minr <= y <= maxr ----
+    if (tid == 0) c.n_matched[bidx] = ok ? 0 : -1;
+    if (!ok) return;
+    const int nRows = min(c.L.h[0], kStereoMaxRows);
+    for (int i = tid; i <= nRows; i += kStereoThreads) s_row[i] = 0;
+    __syncthreads();
     for (int i = tid; i < Nr; i += kStereoThreads) {
         const oslam_keypoint_t kp = kpR[i];
         const float r = 2.0f * c.scale[kp.octave];
-        s_maxr[i] = (short)(int)ceilf(kp.y + r);
-        s_minr[i] = (short)(int)floorf(kp.y - r);
+        const int maxr = (int)ceilf(kp.y + r), minr = (int)floorf(kp.y - r);
+        s_maxr[i] = (short)maxr;
+        s_minr[i] = (short)minr;
         s_x[i] = kp.x;
         s_oct[i] = (uint8_t)kp.octave;
+        for (int y = max(minr, 0); y <= min(maxr, nRows - 1); y++) atomicAdd(&s_row[y], 1);
     }
     for (int i = tid; i < Nr * 8; i += kStereoThreads) s_desc[i] = dR[i];
-    if (tid == 0) s_cnt = 0;
     __syncthreads();
+    // exclusive scan of the row counts (4 rows per thread)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        int cnt[4], local = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int y = tid * 4 + k; cnt[k] = y < nRows ? s_row[y] : 0; local += cnt[k]; }
+        int incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int start = incl - local;
+        for (int i = 0; i < wv; i++) start += s_wtot[i];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int y = tid * 4 + k; if (y < nRows) s_row[y] = start; start += cnt[k]; }
+        if (tid == kStereoThreads - 1) s_total = start;
+    }
+    __syncthreads();
+    const bool table = s_total <= ncap * kRowItemsPerKp;   // otherwise (extreme scale factors) every left keypoint walks all right keypoints
+    if (table) {
+        // scatter with the row starts as cursors (afterwards s_row[y] = end of row y = start of row y + 1)
+        for (int i = tid; i < Nr; i += kStereoThreads)
+            for (int y = max((int)s_minr[i], 0); y <= min((int)s_maxr[i], nRows - 1); y++) items[atomicAdd(&s_row[y], 1)] = (unsigned short)i;
+        __threadfence_block();
+        __syncthreads();
+    }
 
     const float minZ = c.b, minD = 0.f, maxD = c.bf / minZ;
     const int thOrbDist = (100 + 50) / 2;
-    // ---- Hamming scan (:744-789): candidates of the row in right-keypoint index order ----
+    // ---- Hamming scan (:744-789) ----
     for (int iL = tid; iL < N; iL += kStereoThreads) {
         const oslam_keypoint_t kp = kpL[iL];
         uRight[iL] = -1.0f;
@@ -85,75 +135,97 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(StereoCtx c, int ncap
             uint32_t q[8];
 #pragma unroll
             for (int w = 0; w < 8; w++) q[w] = dL[(size_t)iL * 8 + w];
-            int bestDist = 100;   // TH_HIGH
+            int bestKey = (100 << 16);   // TH_HIGH | index: strict minimum of (distance, right index)
             const int levelL = kp.octave;
-            for (int iR = 0; iR < Nr; iR++) {
-                if (row < s_minr[iR] || row > s_maxr[iR]) continue;
+            auto consider = [&](int iR) {
                 const int o = s_oct[iR];
-                if (o < levelL - 1 || o > levelL + 1) continue;
+                if (o < levelL - 1 || o > levelL + 1) return;
                 const float uR = s_x[iR];
                 if (uR >= minU && uR <= maxU) {
-                    const uint32_t* d = s_desc + iR * 8;
-                    int dist = 0;
-#pragma unroll
-                    for (int w = 0; w < 8; w++) dist += __popc(q[w] ^ d[w]);
-                    if (dist < bestDist) { bestDist = dist; best = iR; }
+                    const uint4* d = (const uint4*)(s_desc + iR * 8);
+                    const uint4 d0 = d[0], d1 = d[1];
+                    const int dist = __popc(q[0] ^ d0.x) + __popc(q[1] ^ d0.y) + __popc(q[2] ^ d0.z) + __popc(q[3] ^ d0.w) +
+                                     __popc(q[4] ^ d1.x) + __popc(q[5] ^ d1.y) + __popc(q[6] ^ d1.z) + __popc(q[7] ^ d1.w);
+                    const int key = (dist << 16) | iR;
+                    if (key < bestKey) bestKey = key;
                 }
+            };
+            if (table) {
+                const int st = row > 0 ? s_row[row - 1] : 0, en = s_row[row];
+                for (int t = st; t < en; t++) consider((int)items[t]);
+            } else {
+                for (int iR = 0; iR < Nr; iR++)
+                    if (row >= s_minr[iR] && row <= s_maxr[iR]) consider(iR);
             }
-            if (!(bestDist < thOrbDist)) best = -1;
+            const int bestDist = bestKey >> 16;
+            if (bestDist < 100 && bestDist < thOrbDist) best = bestKey & 0xFFFF;
         }
-        s_best[iL] = (short)best;
+        best_out[iL] = (short)best;
     }
-    __syncthreads();
+}
 
-    // ---- SAD refinement (:792-863), one wavefront per left keypoint ----
-    for (int iL = wv; iL < N; iL += kStereoThreads / 64) {
-        const int bestIdxR = s_best[iL];
-        if (bestIdxR < 0) continue;
-        const oslam_keypoint_t kp = kpL[iL];
+// ---- SAD refinement (:792-863), one wavefront per left keypoint ----
+__global__ __launch_bounds__(256) void k_stereo_sad(StereoCtx c, int ncap) {
+    const int bidx = blockIdx.y, lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int N, Nr;
+    if (!stereo_counts(c, bidx, ncap, N, Nr) || iL >= N) return;
+    const int bestIdxR = c.best[(long long)bidx * c.kp_stride + iL];
+    if (bestIdxR < 0) return;
+    const oslam_keypoint_t kp = c.kpL[(long long)bidx * c.kp_stride + iL];
+    const float uR0 = c.kpR[(long long)bidx * c.kp_stride + bestIdxR].x;
+    float* uRight = c.uRight + (long long)bidx * c.kp_stride;
+    float* depth = c.depth + (long long)bidx * c.kp_stride;
+    int* sad = c.sad + (long long)bidx * c.kp_stride;
+    const float minZ = c.b, minD = 0.f, maxD = c.bf / minZ;
+    {
         const int oct = kp.octave;
-        const float uR0 = s_x[bestIdxR];
         const float sf = c.invScale[oct];
         const float scaleduL = roundf(kp.x * sf), scaledvL = roundf(kp.y * sf), scaleduR0 = roundf(uR0 * sf);
         const int w = 5, L = 5;
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
-        if (iniu < 0 || endu >= (float)c.R.w[oct]) continue;
+        if (iniu < 0 || endu >= (float)c.R.w[oct]) return;
         const uint8_t* imL = c.L.lv[oct] + (oct == 0 ? c.img0_stride_L : c.pyr_stride_L) * bidx;
         const uint8_t* imR = c.R.lv[oct] + (oct == 0 ? c.img0_stride_R : c.pyr_stride_R) * bidx;
         const int pL = c.L.pitch[oct], pR = c.R.pitch[oct];
         const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
         // guard the window reads (the reference does not check the left window / the right -10 side)
-        if (cy - w < 0 || cy + w >= c.L.h[oct] || cxL - w < 0 || cxL + w >= c.L.w[oct] || cxR0 - L - w < 0 || cxR0 + L + w >= c.R.w[oct]) continue;
-        const int centerL = imL[(long long)cy * pL + cxL];
-        // lanes hold the 121 left-patch values (2 per lane)
-        int lv0 = 0, lv1 = 0, dy0 = 0, dx0 = 0, dy1 = 0, dx1 = 0;
+        if (cy - w < 0 || cy + w >= c.L.h[oct] || cxL - w < 0 || cxL + w >= c.L.w[oct] || cxR0 - L - w < 0 || cxR0 + L + w >= c.R.w[oct]) return;
+        // lanes hold the 121 left-patch values (2 per lane); every byte of the left patch and of the 11 x 21 right strip is requested
+        // before the first one is used
         const bool has1 = lane + 64 < 121;
-        dy0 = lane / 11 - w; dx0 = lane % 11 - w;
-        lv0 = (int)imL[(long long)(cy + dy0) * pL + cxL + dx0] - centerL;
-        if (has1) {
-            dy1 = (lane + 64) / 11 - w; dx1 = (lane + 64) % 11 - w;
-            lv1 = (int)imL[(long long)(cy + dy1) * pL + cxL + dx1] - centerL;
+        const int dy0 = lane / 11 - w, dx0 = lane % 11 - w;
+        const int dy1 = has1 ? (lane + 64) / 11 - w : 0, dx1 = has1 ? (lane + 64) % 11 - w : 0;
+        const int centerL = imL[(long long)cy * pL + cxL];
+        const int l0 = imL[(long long)(cy + dy0) * pL + cxL + dx0];
+        const int l1 = imL[(long long)(cy + dy1) * pL + cxL + dx1];
+        int r0[11], r1[11], rc[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const int cxR = cxR0 + k - 5;
+            rc[k] = imR[(long long)cy * pR + cxR];
+            r0[k] = imR[(long long)(cy + dy0) * pR + cxR + dx0];
+            r1[k] = imR[(long long)(cy + dy1) * pR + cxR + dx1];
         }
+        const int lv0 = l0 - centerL, lv1 = l1 - centerL;
         int bestDist = 0x7fffffff, bestinc = 0;
         float d_m1 = 0, d_0 = 0, d_p1 = 0;
         float vd[11];
 #pragma unroll
         for (int inc = -5; inc <= 5; inc++) {
-            const int cxR = cxR0 + inc;
-            const int centerR = imR[(long long)cy * pR + cxR];
-            int s = abs(lv0 - ((int)imR[(long long)(cy + dy0) * pR + cxR + dx0] - centerR));
-            if (has1) s += abs(lv1 - ((int)imR[(long long)(cy + dy1) * pR + cxR + dx1] - centerR));
+            int s = abs(lv0 - (r0[inc + 5] - rc[inc + 5]));
+            if (has1) s += abs(lv1 - (r1[inc + 5] - rc[inc + 5]));
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
             vd[inc + 5] = (float)s;
             if ((float)s < (float)bestDist) { bestDist = s; bestinc = inc; }
         }
-        if (bestinc == -L || bestinc == L) continue;
+        if (bestinc == -L || bestinc == L) return;
 #pragma unroll
         for (int k = 1; k < 10; k++)
             if (k == bestinc + 5) { d_m1 = vd[k - 1]; d_0 = vd[k]; d_p1 = vd[k + 1]; }
         const float deltaR = __fdiv_rn(d_m1 - d_p1, 2.0f * (d_m1 + d_p1 - 2.0f * d_0));
-        if (deltaR < -1 || deltaR > 1) continue;   // NaN (flat SAD) passes, exactly like the reference's comparison
+        if (deltaR < -1 || deltaR > 1) return;   // NaN (flat SAD) passes, exactly like the reference's comparison
         float bestuR = c.scale[oct] * ((float)scaleduR0 + (float)bestinc + deltaR);
         float disparity = kp.x - bestuR;
         if (disparity >= minD && disparity < maxD) {
@@ -162,35 +234,54 @@ __global__ __launch_bounds__(kStereoThreads) void k_stereo(StereoCtx c, int ncap
                 depth[iL] = __fdiv_rn(c.bf, disparity);
                 uRight[iL] = bestuR;
                 sad[iL] = bestDist;
-                atomicAdd(&s_cnt, 1);
+                atomicAdd(&c.n_matched[bidx], 1);
             }
         }
     }
+}
+
+// ---- median-SAD outlier cut (:866-879): median = element size/2 of the distance-sorted list, found by bisection on the value ----
+__global__ __launch_bounds__(kStereoThreads) void k_stereo_cut(StereoCtx c, int ncap) {
+    const int bidx = blockIdx.x, tid = threadIdx.x;
+    int N, Nr;
+    if (!stereo_counts(c, bidx, ncap, N, Nr)) return;
+    const int M = c.n_matched[bidx];
+    if (M <= 0) return;
+    float* uRight = c.uRight + (long long)bidx * c.kp_stride;
+    float* depth = c.depth + (long long)bidx * c.kp_stride;
+    const int* sad = c.sad + (long long)bidx * c.kp_stride;
+    constexpr int kPer = (kStereoMaxKps + kStereoThreads - 1) / kStereoThreads;
+    int mine[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) { const int i = tid + k * kStereoThreads; mine[k] = i < N ? sad[i] : -1; }
+    __shared__ int s_count[2];
+    // smallest d with #{sad <= d} >= M/2 + 1: the value of element M/2 of the sorted list (SAD <= 121 * 510 < 2^16)
+    int lo = 0, hi = 65535;
+    if (tid < 2) s_count[tid] = 0;
     __syncthreads();
-    // ---- median-SAD outlier cut (:866-879): median = element size/2 of the (dist, iL)-sorted list ----
-    const int M = s_cnt;
-    if (tid == 0) s_median = -1;
-    __syncthreads();
-    if (M > 0) {
-        for (int i = tid; i < N; i += kStereoThreads) {
-            const int di = sad[i];
-            if (di < 0) continue;
-            int rank = 0;
-            for (int j = 0; j < N; j++) {
-                const int dj = sad[j];
-                if (dj >= 0 && (dj < di || (dj == di && j < i))) rank++;
-            }
-            if (rank == M / 2) s_median = di;
-        }
+    int ph = 0;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kPer; k++) cnt += (mine[k] >= 0 && mine[k] <= mid);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if ((tid & 63) == 0 && cnt) atomicAdd(&s_count[ph], cnt);
         __syncthreads();
-        const float median = (float)s_median;
-        const float thDist = 1.5f * 1.4f * median;
-        for (int i = tid; i < N; i += kStereoThreads) {
-            const int di = sad[i];
-            if (di >= 0 && !((float)di < thDist)) { uRight[i] = -1.0f; depth[i] = -1.0f; }
-        }
+        const int total = s_count[ph];
+        if (tid == 0) s_count[ph ^ 1] = 0;
+        ph ^= 1;
+        __syncthreads();
+        if (total >= M / 2 + 1) hi = mid; else lo = mid + 1;
     }
-    if (tid == 0) c.n_matched[bidx] = M;
+    const float median = (float)lo;
+    const float thDist = 1.5f * 1.4f * median;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        const int i = tid + k * kStereoThreads;
+        if (i < N && mine[k] >= 0 && !((float)mine[k] < thDist)) { uRight[i] = -1.0f; depth[i] = -1.0f; }
+    }
 }
 
 }  // namespace oslam
@@ -201,6 +292,7 @@ struct oslam_stereo {
     int device = 0, max_batch = 0, max_kps = 0;
     size_t lds = 0;
     float* d_uRight = nullptr; float* d_depth = nullptr; int* d_sad = nullptr; int* d_nm = nullptr;
+    short* d_best = nullptr; unsigned short* d_items = nullptr;
     oslam_keypoint_t* d_kpL = nullptr; oslam_keypoint_t* d_kpR = nullptr; uint8_t* d_descL = nullptr; uint8_t* d_descR = nullptr;
 };
 
@@ -208,7 +300,7 @@ extern "C" {
 
 void oslam_stereo_destroy(oslam_stereo_t* h) {
     if (!h) return;
-    void* ptrs[] = {h->d_uRight, h->d_depth, h->d_sad, h->d_nm, h->d_kpL, h->d_kpR, h->d_descL, h->d_descR};
+    void* ptrs[] = {h->d_uRight, h->d_depth, h->d_sad, h->d_nm, h->d_best, h->d_items, h->d_kpL, h->d_kpR, h->d_descL, h->d_descR};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -224,7 +316,7 @@ int oslam_stereo_create(oslam_stereo_t** out, int max_batch, int max_keypoints, 
     OSLAM_HIP_CHECK(hipSetDevice(device));
     oslam_stereo* h = new oslam_stereo();
     h->device = device; h->max_batch = max_batch; h->max_kps = max_keypoints;
-    h->lds = (size_t)max_keypoints * (32 + 4 + 2 + 2 + 2 + 1) + 64;
+    h->lds = (size_t)max_keypoints * (32 + 4 + 2 + 2 + 1) + (kStereoMaxRows + 1) * 4 + 64;   // k_stereo_scan: descriptors, u, row band, octave + row starts
     const size_t B = max_batch, NK = max_keypoints;
 #define ALLOC(ptr, bytes)                                                         \
     do {                                                                          \
@@ -236,9 +328,10 @@ int oslam_stereo_create(oslam_stereo_t** out, int max_batch, int max_keypoints, 
         }                                                                         \
     } while (0)
     ALLOC(h->d_uRight, B * NK * 4); ALLOC(h->d_depth, B * NK * 4); ALLOC(h->d_sad, B * NK * 4); ALLOC(h->d_nm, B * 4);
+    ALLOC(h->d_best, B * NK * sizeof(short)); ALLOC(h->d_items, B * NK * kRowItemsPerKp * sizeof(unsigned short));
     ALLOC(h->d_kpL, NK * sizeof(oslam_keypoint_t)); ALLOC(h->d_kpR, NK * sizeof(oslam_keypoint_t)); ALLOC(h->d_descL, NK * 32); ALLOC(h->d_descR, NK * 32);
 #undef ALLOC
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_stereo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_stereo_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
     *out = h;
     return OSLAM_OK;
 }
@@ -282,8 +375,11 @@ int oslam_stereo_match_batch_device(oslam_stereo_t* h, oslam_orb_t* orbL, oslam_
     c.kpL = d_kpL; c.descL = d_descL; c.nL = d_nL; c.nL_const = nL_const;
     c.kpR = d_kpR; c.descR = d_descR; c.nR = d_nR; c.nR_const = nR_const;
     c.kp_stride = kp_stride; c.bf = bf; c.b = b;
-    c.uRight = h->d_uRight; c.depth = h->d_depth; c.sad = h->d_sad; c.n_matched = h->d_nm;
-    hipLaunchKernelGGL(k_stereo, dim3(batch), dim3(kStereoThreads), h->lds, (hipStream_t)stream, c, h->max_kps);
+    c.uRight = h->d_uRight; c.depth = h->d_depth; c.sad = h->d_sad; c.n_matched = h->d_nm; c.best = h->d_best; c.row_items = h->d_items;
+    if (c.L.h[0] > kStereoMaxRows) { set_error("image height %d above the stereo row table (%d)", c.L.h[0], kStereoMaxRows); return OSLAM_E_CAPACITY; }
+    hipLaunchKernelGGL(k_stereo_scan, dim3(batch), dim3(kStereoThreads), h->lds, (hipStream_t)stream, c, h->max_kps);
+    hipLaunchKernelGGL(k_stereo_sad, dim3((kp_stride + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, c, h->max_kps);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(batch), dim3(kStereoThreads), 0, (hipStream_t)stream, c, h->max_kps);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
