@@ -46,3 +46,30 @@ def test_stereo_no_right_keypoints(oracle):
     uR, dep = sm.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, 40.0, 0.08)
     assert np.all(uR == -1) and np.all(dep == -1)
     sm.close(); exL.close(); exR.close()
+
+
+def test_stereo_row_table_overflow_falls_back_to_full_scan(oracle):
+    """All keypoints relabelled to the top level of a 1.3^7 pyramid: every right keypoint then covers a band of ~27 rows, the row table
+    (24 items per right keypoint) overflows and the kernel walks all right keypoints per left keypoint instead; same result."""
+    W, H, NF, SF = 640, 480, 1500, 1.3
+    canvas = synth.make_canvas(W + 100, H + 32, seed=9)
+    left = np.ascontiguousarray(canvas[10:10 + H, 50:50 + W])
+    right = np.ascontiguousarray(canvas[10:10 + H, 62:62 + W])
+    exL, exR = ORBextractor(NF, SF, 8, 20, 7, W, H), ORBextractor(NF, SF, 8, 20, 7, W, H)
+    kL, dL = exL(left)
+    kR, dR = exR(right)
+    oL, oR = oracle.OrbExtractor(NF, SF, 8, 20, 7), oracle.OrbExtractor(NF, SF, 8, 20, 7)
+    okL, odL = oL.extract(left)
+    okR, odR = oR.extract(right)
+    assert kL.tobytes() == okL.tobytes() and kR.tobytes() == okR.tobytes()
+    kL = kL.copy(); kR = kR.copy()
+    kL["octave"] = 7; kR["octave"] = 7
+    bf, b = 40.0, 40.0 / 520.9
+    sm = StereoMatcher(max_keypoints=max(len(kL), len(kR)))   # capacity = 24 items per keypoint SLOT: a tight handle makes 27 per keypoint overflow
+    assert 27 * len(kR) > 24 * max(len(kL), len(kR))
+    uR, dep = sm.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, b)
+    ouR, odep = oracle.stereo_matches(oL, oR, kL, dL, kR, dR, bf, b)
+    np.testing.assert_array_equal(uR, ouR)
+    np.testing.assert_array_equal(dep, odep)
+    assert (uR >= 0).sum() > 50
+    sm.close(); exL.close(); exR.close()
