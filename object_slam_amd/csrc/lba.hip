@@ -1341,6 +1341,7 @@ struct oslam_lba {
     LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
     double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
     double* d_W = nullptr; int2* d_pairs = nullptr; size_t pairs_cap = 0; int* d_pair_start = nullptr;
+    hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
     uint8_t* h_stage = nullptr; size_t stage_cap = 0, stage_off = 0;   // pinned staging of the per-call uploads
     uint8_t* h_out = nullptr; size_t out_cap = 0;                      // pinned landing zone of the results
     int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
@@ -1363,6 +1364,7 @@ void oslam_lba_destroy(oslam_lba_t* h) {
     if (h->d_pairs) (void)hipFree(h->d_pairs);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_out) (void)hipHostFree(h->h_out);
+    if (h->strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
 
@@ -1378,6 +1380,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (device < 0 || device >= ndev) { set_error("device out of range"); return OSLAM_E_INVALID; }
     OSLAM_HIP_CHECK(hipSetDevice(device));
     oslam_lba* h = new oslam_lba();
+    if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes; h->max_pts = max_points; h->max_edges = max_edges;
     const size_t K = max_keyframes, P = max_points, E = max_edges, n = 6 * K;
     auto alloc = [&](size_t bytes) -> void* {
@@ -1478,7 +1481,7 @@ static int stage_upload(oslam_lba_t* h, void* dst, const void* src, size_t bytes
     }
     uint8_t* at = h->h_stage + h->stage_off;
     memcpy(at, src, bytes);
-    OSLAM_HIP_CHECK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, h->strm));
     h->stage_off += (bytes + 255) & ~(size_t)255;
     return OSLAM_OK;
 }
@@ -1554,9 +1557,9 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
     }
     { const int rc_ = stage_upload(h, h->d_probs, &pr, sizeof(pr)); if (rc_) return rc_; }
     if (!h->wide) {
-        hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
+        hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
         OSLAM_HIP_CHECK(hipGetLastError());
-        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
     } else {
         LbaWide w;
         w.ct = h->d_ctrl; w.T = h->d_T2; w.R = h->d_R2; w.blk = h->d_blk; w.free_pose = h->d_free;
@@ -1604,7 +1607,7 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
             w.pairs = h->d_pairs; w.pair_start = h->d_pair_start; w.W = h->d_W;
         }
         const size_t chol_lds = 6 * nfree <= kCholLdsN ? (size_t)(6 * nfree) * (6 * nfree + 1) * sizeof(double) : 0;
-        hipStream_t st = nullptr;
+        hipStream_t st = h->strm;
         hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(std::max(std::max(nP * 3, nE), 1), 256)), dim3(256), 0, st, h->d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once
@@ -1642,11 +1645,11 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
             OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
             h->out_cap = total + total / 2;
         }
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost, nullptr));
-        if (nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost, nullptr));
-        if (nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er, s.erase, (size_t)nE, hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st, s.stats, sizeof(st), hipMemcpyDeviceToHost, nullptr));
-        OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost, h->strm));
+        if (nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost, h->strm));
+        if (nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er, s.erase, (size_t)nE, hipMemcpyDeviceToHost, h->strm));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st, s.stats, sizeof(st), hipMemcpyDeviceToHost, h->strm));
+        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
         memcpy(poses_out, h->h_out + o_pose, (size_t)nKF * 64);
         if (nP > 0) memcpy(points_out, h->h_out + o_pts, (size_t)nP * 12);
         const uint8_t* er = h->h_out + o_er;
@@ -1671,8 +1674,8 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
                          q.points_out, q.erase, nullptr, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815), i, 0);
         if (rc) return rc;
     }
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, nullptr, h->d_probs);
+    { const int rc_ = stage_upload(h, h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n); if (rc_) return rc_; }
+    hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
     OSLAM_HIP_CHECK(hipGetLastError());
     // results of all windows: async copies into the pinned block, ONE synchronisation, then the scatter (erase flags back in caller edge order)
     std::vector<size_t> o_pose(n), o_pts(n), o_er(n), o_st(n);
@@ -1683,7 +1686,7 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
         o_pose[i] = take((size_t)q.nKF * 64); o_pts[i] = take((size_t)q.nP * 12); o_er[i] = take((size_t)q.nE); o_st[i] = take(64);
     }
     if (total > h->out_cap) {
-        OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
         if (h->h_out) (void)hipHostFree(h->h_out);
         h->h_out = nullptr; h->out_cap = 0;
         OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
@@ -1692,12 +1695,12 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
         oslam_lba::Slot& s = h->slots[i];
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose[i], s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost, nullptr));
-        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts[i], s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost, nullptr));
-        if (q.nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er[i], s.erase, (size_t)q.nE, hipMemcpyDeviceToHost, nullptr));
-        if (q.stats) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st[i], s.stats, 64, hipMemcpyDeviceToHost, nullptr));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose[i], s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost, h->strm));
+        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts[i], s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost, h->strm));
+        if (q.nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er[i], s.erase, (size_t)q.nE, hipMemcpyDeviceToHost, h->strm));
+        if (q.stats) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st[i], s.stats, 64, hipMemcpyDeviceToHost, h->strm));
     }
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
         memcpy(q.poses_out, h->h_out + o_pose[i], (size_t)q.nKF * 64);
