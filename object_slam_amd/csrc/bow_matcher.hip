@@ -200,6 +200,7 @@ struct oslam_bow {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf q_idx1, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm;
     uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;   // batch staging: pinned block mirrored on the device
+    hipStream_t strm = nullptr;   // the batch form runs on the handle's own non-blocking stream (created on first use)
 };
 
 static int bow_ensure(oslam_bow::Buf& b, size_t bytes) {
@@ -227,6 +228,7 @@ void oslam_bow_destroy(oslam_bow_t* h) {
         if (b->p) (void)hipFree(b->p);
     if (h->st_h) (void)hipHostFree(h->st_h);
     if (h->st_d) (void)hipFree(h->st_d);
+    if (h->strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
 
@@ -388,11 +390,12 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
         }
         c.out = (int*)(D + o.out); c.nmatches = (int*)(D + o.nm); c.q_best = (int*)(D + o.qbest);
     }
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, nullptr));
-    hipLaunchKernelGGL(k_search_bow_batch, dim3(n), dim3(kBowThreads), h->lds, nullptr, (const BowCtx*)D, h->max_kps);
+    if (!h->strm) OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, h->strm));
+    hipLaunchKernelGGL(k_search_bow_batch, dim3(n), dim3(kBowThreads), h->lds, h->strm, (const BowCtx*)D, h->max_kps);
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(hipMemcpyAsync(H + in_bytes, D + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, nullptr));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(nullptr));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(H + in_bytes, D + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, h->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
     for (int i = 0; i < n; i++) {
         jobs[i].nmatches = *(const int*)(H + off[i].nm);
         if (jobs[i].nmatches < 0) { set_error("BoW matcher kernel rejected pair %d (capacity)", i); return OSLAM_E_CAPACITY; }
