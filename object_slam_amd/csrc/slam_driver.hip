@@ -99,6 +99,7 @@ struct Seq {
     int refKF = -1, lastKFFrameId = 0, lastRelocFrameId = 0;
     int matchesInliers = 0;
     std::vector<int> localKFs, localMPs;
+    std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
     std::vector<RelPose> rel;
     std::vector<int> recentAdded;          // mlpRecentAddedMapPoints
     std::vector<int> newKFs;               // mlNewKeyFrames (at most one per step)
@@ -119,6 +120,7 @@ struct Seq {
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
         localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear();
         std::fill(counter.begin(), counter.end(), 0);
+        std::fill(mpMark.begin(), mpMark.end(), 0);
         resetRequested = false;
     }
     std::vector<int> updList;             // points created by tracking this step (descriptor / normal pending)
@@ -349,15 +351,20 @@ static void update_local_map(Seq& s) {
         }
         if (kmax >= 0) { s.refKF = kmax; f.refKF = kmax; }
     }
+    // mnTrackReferenceForFrame of the map points as a dense per-sequence array: the loop below visits 10-20 k keyframe slots per frame and
+    // most of them hit an already marked point, so it should touch 4 bytes per slot, not a 136-byte MapPt.  A bad point is marked too (it
+    // is never pushed either way), which leaves the list unchanged.
+    if (s.mpMark.size() < m.mps.size()) s.mpMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+    int* mark = s.mpMark.data();
     s.localMPs.clear();
     for (int k : s.localKFs) {
         const KeyFrm& kf = m.kfs[k];
+        const int* kmp = kf.mp.data();
         for (int i = 0; i < kf.N; i++) {
-            const int p = kf.mp[i];
-            if (p < 0) continue;
-            MapPt& mp = m.mps[p];
-            if (mp.trackRefForFrame == f.id) continue;
-            if (!mp.bad) { s.localMPs.push_back(p); mp.trackRefForFrame = f.id; }
+            const int p = kmp[i];
+            if (p < 0 || mark[p] == f.id) continue;
+            mark[p] = f.id;
+            if (!m.mps[p].bad) s.localMPs.push_back(p);
         }
     }
 }
