@@ -273,7 +273,7 @@ int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const fl
  * Window reads that would leave the image (unchecked in the reference) are skipped.
  * ---------------------------------------------------------------------------------------- */
 typedef struct oslam_stereo oslam_stereo_t;
-int oslam_stereo_create(oslam_stereo_t** out, int max_batch, int max_keypoints /* <= 2400 */, int device);
+int oslam_stereo_create(oslam_stereo_t** out, int max_batch, int max_keypoints /* <= 2400; level-0 image height <= 4096 */, int device);
 void oslam_stereo_destroy(oslam_stereo_t* h);
 int oslam_stereo_match(oslam_stereo_t* h, oslam_orb_t* orbL, oslam_orb_t* orbR, int N, const oslam_keypoint_t* keysL,
                        const uint8_t* descL, int Nr, const oslam_keypoint_t* keysR, const uint8_t* descR, int nlevels,
@@ -298,7 +298,7 @@ int oslam_stereo_results_device(const oslam_stereo_t* h, const float** d_uRight,
  * (nInitialCorrespondences - nBad; 0 and pose untouched if < 3 correspondences).
  * ---------------------------------------------------------------------------------------- */
 typedef struct oslam_poseopt oslam_poseopt_t;
-int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points, int device);
+int oslam_poseopt_create(oslam_poseopt_t** out, int max_batch, int max_points /* <= 11000 (chi2 + level per edge slot live in LDS) */, int device);
 void oslam_poseopt_destroy(oslam_poseopt_t* h);
 int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs,
                         const float* invSigma2, const uint8_t* has_mp, const float K5[5], float Tcw_out[16],
