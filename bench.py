@@ -276,6 +276,38 @@ def main():
         try:
             from object_slam_amd import LocalBundleAdjuster, PoseOptimizer
             extras = {}
+            # the same S2 step software-pipelined over two handle sets on two streams (batch i + 1 is extracted while batch i is matched): what a
+            # caller with a queue of batches gets.  Not the headline: the kernels of two batches then overlap, so the per-kernel durations that
+            # `roofline` reports (one batch at a time, as in the rocprofv3 summary) would no longer describe the timed region.
+            ex2 = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, W, H, max_batch=B, device=local_rank)
+            mt2 = ORBmatcher(0.9, True, max_keypoints=cap, max_queries=cap, max_batch=B, device=local_rank)
+            d_kp2, d_desc2, d_cnt2, _ = ex2.results_device()
+            fr2 = MatchFrames()
+            fr2.keysUn, fr2.kp_stride, fr2.uRight, fr2.desc, fr2.blocked = d_kp2, cap, t_uR.data_ptr(), d_desc2, None
+            fr2.n_kps, fr2.n_kps_const = d_cnt2, 0
+            fr2.minX, fr2.minY, fr2.maxX, fr2.maxY = 0.0, 0.0, float(W), float(H)
+            q_nq2 = C.c_void_p()
+            check(mt2.L.oslam_match_results_device(mt2.h, None, None, None, None, None, C.byref(q_nq2)))
+            ps = [torch.cuda.Stream(), torch.cuda.Stream()]
+            psets = [(ex, mt, fr, q_nq, ps[0].cuda_stream), (ex2, mt2, fr2, q_nq2, ps[1].cuda_stream)]
+
+            def pstep(i):
+                e_, m_, f_, q_, s_ = psets[i & 1]
+                e_.extract_batch_device(d_img.data_ptr(), B, pitch, pitch * H, s_)
+                m_.project_last_batch_device(la, t_Tcw.data_ptr(), t_Tlw.data_ptr(), cam, f_, sf, TH, False, B, s_)
+                m_.search_batch_device(f_, None, cap, q_.value, 0, B, False, True, s_)
+
+            for i in range(4):
+                pstep(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                pstep(i)
+            torch.cuda.synchronize()
+            extras["pipelined_two_batches_frames_per_s"] = round(B * args.steps / (time.perf_counter() - t1), 1)
+            k2, _ = ex2.fetch(B // 2)
+            assert len(k2) == counts[B // 2]
+            ex2.close(); mt2.close()
             PB, PN = 128, 1000
             probs = [synth.make_pose_problem(100 + i, N=PN) for i in range(PB)]
             tt = lambda k, dt: torch.from_numpy(np.stack([q[k] for q in probs]).astype(dt)).cuda()
