@@ -444,8 +444,11 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
     {   // the blur stream runs at the lowest priority: FAST, the overflow cells and the quad-tree on the caller's stream are dispatched first
         int least = 0, greatest = 0;
-        OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least));
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();   // no stream priorities here: an ordinary side stream still overlaps the blur
+            h->side_stream = nullptr;
+            OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        }
     }
     OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_FAST0_STREAM")) {   // kernel experiments (off: measured no gain at B = 512, the pyramid kernels slow down by what FAST gains: 2.60 ms per batch either way)
