@@ -16,7 +16,10 @@ namespace oslam {
 constexpr int kGridCols = 64, kGridRows = 48;   // reference include/Frame.h:43-44
 constexpr int kGridCells = kGridCols * kGridRows;
 constexpr int kHistoLen = 30;                   // src/ORBmatcher.cc:39
-constexpr int kMatchThreads = 1024;
+#ifndef OSLAM_MATCH_THREADS
+#define OSLAM_MATCH_THREADS 1024
+#endif
+constexpr int kMatchThreads = OSLAM_MATCH_THREADS;   // kernel experiments: -DOSLAM_MATCH_THREADS=512 (two queries per thread, two workgroups per CU)
 constexpr int kMaxMatchKps = 2400;              // LDS budget, see lds_bytes()
 constexpr int kCacheCap = 48;                   // cached candidates per query for the claim-order fixpoint
 
@@ -109,12 +112,16 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
     for (int i = tid; i < N * 8; i += kMatchThreads) s_desc[i] = gdesc[i];
     __syncthreads();
     MSTAMP(0);
-    // exclusive scan of the 3072 cell counts (3 per thread)
+    // exclusive scan of the 3072 cell counts (kCellsPer per thread)
     {
+        constexpr int kCellsPer = kGridCells / kMatchThreads;
+        static_assert(kCellsPer * kMatchThreads == kGridCells, "the cell scan gives every thread the same number of cells");
         const int lane = tid & 63, wv = tid >> 6;
-        const int base = tid * 3;
-        const int c0 = s_cell[base], c1 = s_cell[base + 1], c2 = s_cell[base + 2];
-        int incl = c0 + c1 + c2;
+        const int base = tid * kCellsPer;
+        int cc[kCellsPer];
+        int incl = 0;
+#pragma unroll
+        for (int k = 0; k < kCellsPer; k++) { cc[k] = s_cell[base + k]; incl += cc[k]; }
         const int local = incl;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -123,12 +130,10 @@ __global__ __launch_bounds__(kMatchThreads) void k_search_window(MatchCtx c, int
         }
         if (lane == 63) s_wtot[wv] = incl;
         __syncthreads();
-        int wbase = 0;
-        for (int i = 0; i < wv; i++) wbase += s_wtot[i];
-        const int start = wbase + incl - local;
-        s_cell[base] = start;
-        s_cell[base + 1] = start + c0;
-        s_cell[base + 2] = start + c0 + c1;
+        int start = incl - local;
+        for (int i = 0; i < wv; i++) start += s_wtot[i];
+#pragma unroll
+        for (int k = 0; k < kCellsPer; k++) { s_cell[base + k] = start; start += cc[k]; }
     }
     __syncthreads();
     // scatter with the cell starts as cursors (afterwards s_cell[c] = end of cell c = start of c+1),
