@@ -137,3 +137,32 @@ def test_large_quota_on_few_levels_node_tables_in_hbm(oracle):
     for nl in (1, 2):
         n = _stages(oracle, dict(nfeatures=2600, scaleFactor=1.2, nlevels=nl, iniThFAST=20, minThFAST=7), img)
         assert n > 1200, n
+
+
+def test_experiment_knobs_keep_results(oracle, monkeypatch):
+    """Off-by-default stream layouts (level-0 FAST beside the pyramid kernels, batches cut in two halves on two stream pairs, resize without the
+    LDS-staged kernel) must not change a bit of the output."""
+    from object_slam_amd import synth
+    import torch
+    B = 6
+    frames, _ = synth.make_stream(B, 640, 480, seed=31)
+    d = torch.from_numpy(frames).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        ex = ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, max_batch=B)
+        ex.extract_batch_device(d.data_ptr(), B, 640, 640 * 480, st)
+        torch.cuda.synchronize()
+        out = [ex.fetch(b) for b in range(B)]
+        ex.close()
+        return out
+
+    ref = run()
+    for env in ({"OSLAM_ORB_FAST0_STREAM": "1"}, {"OSLAM_ORB_SPLIT_MIN": "2"}, {"OSLAM_ORB_NO_LDS_RESIZE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        for (ka, da), (kb, db) in zip(ref, got):
+            assert ka.tobytes() == kb.tobytes() and np.array_equal(da, db), env
