@@ -73,3 +73,29 @@ def test_stereo_row_table_overflow_falls_back_to_full_scan(oracle):
     np.testing.assert_array_equal(dep, odep)
     assert (uR >= 0).sum() > 50
     sm.close(); exL.close(); exR.close()
+
+
+@pytest.mark.parametrize("seed,disp,W,H,NF", [(11, 13, 640, 480, 1000), (12, 41, 752, 480, 1200), (13, 3, 511, 389, 700)])
+def test_stereo_matches_other_shapes(oracle, seed, disp, W, H, NF):
+    """TUM / EuRoC-like and odd image shapes (row table sizes, partial last words) against the oracle, bit-exact."""
+    canvas = synth.make_canvas(W + 160, H + 48, seed=seed)
+    left = np.ascontiguousarray(canvas[16:16 + H, 70:70 + W])
+    right = np.ascontiguousarray(canvas[16:16 + H, 70 + disp:70 + disp + W])
+    rng = np.random.default_rng(seed)
+    right = np.clip(right.astype(np.int32) + rng.integers(-3, 4, right.shape), 0, 255).astype(np.uint8)
+    bf = 47.9
+    b = bf / 458.6
+    exL, exR = ORBextractor(NF, 1.2, 8, 20, 7, W, H), ORBextractor(NF, 1.2, 8, 20, 7, W, H)
+    kL, dL = exL(left)
+    kR, dR = exR(right)
+    oL, oR = oracle.OrbExtractor(NF), oracle.OrbExtractor(NF)
+    okL, odL = oL.extract(left)
+    okR, odR = oR.extract(right)
+    assert kL.tobytes() == okL.tobytes() and kR.tobytes() == okR.tobytes()
+    sm = StereoMatcher()
+    uR, dep = sm.ComputeStereoMatches(exL, exR, kL, dL, kR, dR, bf, b)
+    ouR, odep = oracle.stereo_matches(oL, oR, okL, odL, okR, odR, bf, b)
+    np.testing.assert_array_equal(uR, ouR)
+    np.testing.assert_array_equal(dep, odep)
+    assert (uR >= 0).sum() > 100
+    sm.close(); exL.close(); exR.close()
