@@ -354,6 +354,9 @@ volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
 /* 1 (default): a single problem is spread over the whole GPU (multi-kernel LM, device-side control);
  * 0: one workgroup per problem in one launch (the batch-of-windows layout).  Same arithmetic. */
 int oslam_lba_set_mode(oslam_lba_t* h, int wide);
+/* Kernel timing for bench.py's roofline: HIP events on the handle's stream around the solve kernels of every later call.
+ * Returns and clears the accumulated milliseconds / kernel launches, then sets the switch to `enable`. */
+int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long* launches_out);
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]);   /* [0..3] stats, [8..15] per-phase kilo-cycles in profiling builds */
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP,
                        const float* points, int nE, const int32_t* edge_kf, const int32_t* edge_pt,

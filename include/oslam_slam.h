@@ -114,6 +114,8 @@ typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (curr
     uint8_t* ok; float* x3D;
 } oslam_job_triangulate_t;
 
+#define OSLAM_SLAM_KT_GROUPS 4   /* kernel-time groups: 0 Frame::Frame (extraction .. stereo), 1 pose optimisation, 2 local BA, 3 window searches */
+
 typedef struct oslam_slam_ops {
     void* ctx;
     /* capacity of the per-frame arrays the driver must allocate */
@@ -138,6 +140,8 @@ typedef struct oslam_slam_ops {
     /* Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): two ExtractORB + ComputeStereoMatches (:706-880); NULL if unsupported */
     int (*frames_stereo)(void* ctx, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride,
                          int on_device, oslam_slam_frame_t* const* out);
+    /* optional (NULL in tables without a device): see oslam_slam_kernel_times */
+    int (*kernel_times)(void* ctx, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
@@ -169,6 +173,13 @@ int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]);
 /* Wall-clock seconds spent per stage since creation: [0] frames, [1] search_last, [2] pose_opt, [3] search_local, [4] host tracking,
  * [5] mp_update, [6] lba, [7] host mapping, [8] fuse/bow/triangulate. */
 int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]);
+/* Device time of the kernel groups of the HIP operator table, measured with HIP events on the stream each group is launched on
+ * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:
+ * out[3g] = milliseconds, out[3g+1] = kernel launches, out[3g+2] = algorithmic work of those launches — bytes for group 0 (SURVEY.md
+ * §8(d) extraction model), fp64 flop for groups 1 and 2 (§8(d): 700 flop per edge and linearisation, 90 per edge and trial evaluation,
+ * Schur 324 k_p^2 per point, Cholesky (6K)^3/3, back-substitution 2(6K)^2 + 45P per trial), descriptor pairs for group 3.
+ * OSLAM_E_INVALID on a table without device timing (the test seam). */
+int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
 
 #ifdef __cplusplus
 }

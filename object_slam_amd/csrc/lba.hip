@@ -1350,12 +1350,38 @@ struct oslam_lba {
     int* h_stop = nullptr;       // pinned, device-visible stop flag
     int* d_stop = nullptr;
     size_t lds = 0;
+    // kernel timing (bench.py's roofline): HIP events on this handle's stream around the solve kernels
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int timing = 0;
+    double kern_ms = 0;
+    long long kern_launches = 0;
 };
+
+static void lba_time_begin(oslam_lba* h) { if (h->timing && h->ev0) (void)hipEventRecord(h->ev0, h->strm); }
+static void lba_time_end(oslam_lba* h) { if (h->timing && h->ev1) (void)hipEventRecord(h->ev1, h->strm); }
+static void lba_time_collect(oslam_lba* h, long long launches) {   // after the stream has been synchronised
+    if (!h->timing || !h->ev0 || !h->ev1) return;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_launches += launches; }
+}
 
 extern "C" {
 
+int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long* launches_out) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (enable && !h->ev0) { OSLAM_HIP_CHECK(hipEventCreate(&h->ev0)); OSLAM_HIP_CHECK(hipEventCreate(&h->ev1)); }
+    if (ms_out) *ms_out = h->kern_ms;
+    if (launches_out) *launches_out = h->kern_launches;
+    h->kern_ms = 0; h->kern_launches = 0;
+    h->timing = enable;
+    return OSLAM_OK;
+}
+
 void oslam_lba_destroy(oslam_lba_t* h) {
     if (!h) return;
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (void* p : h->allocs)
         if (p) (void)hipFree(p);
     if (h->d_probs) (void)hipFree(h->d_probs);
@@ -1557,9 +1583,12 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
     }
     { const int rc_ = stage_upload(h, h->d_probs, &pr, sizeof(pr)); if (rc_) return rc_; }
     if (!h->wide) {
+        lba_time_begin(h);
         hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
+        lba_time_end(h);
         OSLAM_HIP_CHECK(hipGetLastError());
         OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+        lba_time_collect(h, 1);
     } else {
         LbaWide w;
         w.ct = h->d_ctrl; w.T = h->d_T2; w.R = h->d_R2; w.blk = h->d_blk; w.free_pose = h->d_free;
@@ -1608,6 +1637,7 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         }
         const size_t chol_lds = 6 * nfree <= kCholLdsN ? (size_t)(6 * nfree) * (6 * nfree + 1) * sizeof(double) : 0;
         hipStream_t st = h->strm;
+        lba_time_begin(h);
         hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(std::max(std::max(nP * 3, nE), 1), 256)), dim3(256), 0, st, h->d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once
@@ -1634,7 +1664,10 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         }
         const int nfin = std::max(std::max(nE, nKF), nP * 3);
         hipLaunchKernelGGL(k_w_final, dim3(div_up(std::max(nfin, 1), 256)), dim3(256), 0, st, h->d_probs, w);
+        lba_time_end(h);
         OSLAM_HIP_CHECK(hipGetLastError());
+        OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+        lba_time_collect(h, 3 + 6 * (long long)slots_done);
     }
     {   // results: four async copies into one pinned landing zone, one synchronisation
         const size_t o_pose = 0, o_pts = o_pose + (((size_t)nKF * 64 + 255) & ~(size_t)255), o_er = o_pts + (((size_t)nP * 12 + 255) & ~(size_t)255),
@@ -1675,7 +1708,9 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
         if (rc) return rc;
     }
     { const int rc_ = stage_upload(h, h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n); if (rc_) return rc_; }
+    lba_time_begin(h);
     hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
+    lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());
     // results of all windows: async copies into the pinned block, ONE synchronisation, then the scatter (erase flags back in caller edge order)
     std::vector<size_t> o_pose(n), o_pts(n), o_er(n), o_st(n);
@@ -1701,6 +1736,7 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
         if (q.stats) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st[i], s.stats, 64, hipMemcpyDeviceToHost, h->strm));
     }
     OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    lba_time_collect(h, 1);
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
         memcpy(q.poses_out, h->h_out + o_pose[i], (size_t)q.nKF * 64);

@@ -155,6 +155,8 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     OSLAM_HIP_CHECK(hipSetDevice(device));
 
     oslam_orb* h = new oslam_orb();
+    // a HIP failure below releases what was allocated so far (oslam_orb_destroy tolerates a half-built handle)
+#define ORB_CREATE_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); oslam_orb_destroy(h); return OSLAM_E_HIP; } } while (0)
     h->device = device; h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = iniTh; h->minTh = minTh;
     h->scaleFactor = scaleFactor_;   // float -> double member, reference include/ORBextractor.h:96
     h->width = width; h->height = height; h->max_batch = max_batch;
@@ -386,7 +388,7 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_cand, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_ovf_count, 64);
     if (h->oct_nodes_stride) ALLOC(h->d_oct_nodes, B * (size_t)nlevels * h->oct_nodes_stride * sizeof(int));
-    OSLAM_HIP_CHECK(hipMemset(h->d_ovf_count, 0, 64));
+    ORB_CREATE_CHECK(hipMemset(h->d_ovf_count, 0, 64));
     ALLOC(h->d_ent_g, B * (size_t)P.cand_per_image * sizeof(uint32_t));
     ALLOC(h->d_knode_g, B * (size_t)P.cand_per_image * sizeof(uint16_t));
     ALLOC(h->d_sel, B * (size_t)P.sel_per_image * sizeof(uint32_t));
@@ -396,9 +398,9 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ALLOC(h->d_out_count, B * sizeof(int));
     ALLOC(h->d_status, sizeof(int));
     ALLOC(h->d_dbg, 16 * sizeof(unsigned long long));
-    OSLAM_HIP_CHECK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
+    ORB_CREATE_CHECK(hipMemset(h->d_dbg, 0, 16 * sizeof(unsigned long long)));
 #undef ALLOC
-    OSLAM_HIP_CHECK(hipMemcpy(h->dP, &P, sizeof(P), hipMemcpyHostToDevice));
+    ORB_CREATE_CHECK(hipMemcpy(h->dP, &P, sizeof(P), hipMemcpyHostToDevice));
     {   // FAST cell records (the cell grid of reference src/ORBextractor.cc:784-808, one record per cell of every level)
         std::vector<FastCellRec> cells((size_t)P.total_cells);
         for (int l = 0; l < nlevels; l++) {
@@ -428,42 +430,43 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
             }
         }
         if (hipMalloc((void**)&h->d_fast_cells, cells.size() * sizeof(FastCellRec)) != hipSuccess) { set_error("hipMalloc of the FAST cell records failed"); oslam_orb_destroy(h); return OSLAM_E_HIP; }
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_fast_cells, cells.data(), cells.size() * sizeof(FastCellRec), hipMemcpyHostToDevice));
+        ORB_CREATE_CHECK(hipMemcpy(h->d_fast_cells, cells.data(), cells.size() * sizeof(FastCellRec), hipMemcpyHostToDevice));
     }
-    if (!rtab.empty()) OSLAM_HIP_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(int2), hipMemcpyHostToDevice));
+    if (!rtab.empty()) ORB_CREATE_CHECK(hipMemcpy(h->d_rtab, rtab.data(), rtab.size() * sizeof(int2), hipMemcpyHostToDevice));
     if (!qbase.empty()) {
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_qbase, qbase.data(), qbase.size() * sizeof(int), hipMemcpyHostToDevice));
-        OSLAM_HIP_CHECK(hipMemcpy(h->d_qpx, qpx.data(), qpx.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        ORB_CREATE_CHECK(hipMemcpy(h->d_qbase, qbase.data(), qbase.size() * sizeof(int), hipMemcpyHostToDevice));
+        ORB_CREATE_CHECK(hipMemcpy(h->d_qpx, qpx.data(), qpx.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_root_of_x, root_of_x.data(), root_of_x.size(), hipMemcpyHostToDevice));
-    OSLAM_HIP_CHECK(hipMemcpy(h->d_root_x, root_x.data(), root_x.size() * sizeof(short), hipMemcpyHostToDevice));
-    OSLAM_HIP_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
-    OSLAM_HIP_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree_spill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_octree_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    ORB_CREATE_CHECK(hipMemcpy(h->d_root_of_x, root_of_x.data(), root_of_x.size(), hipMemcpyHostToDevice));
+    ORB_CREATE_CHECK(hipMemcpy(h->d_root_x, root_x.data(), root_x.size() * sizeof(short), hipMemcpyHostToDevice));
+    ORB_CREATE_CHECK(hipMemset(h->d_status, 0, sizeof(int)));
+    ORB_CREATE_CHECK(hipMemset(h->d_out_count, 0, B * sizeof(int)));
+    ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree_spill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
+    ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
     {   // the blur stream runs at the lowest priority: FAST, the overflow cells and the quad-tree on the caller's stream are dispatched first
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least) != hipSuccess) {
             (void)hipGetLastError();   // no stream priorities here: an ordinary side stream still overlaps the blur
             h->side_stream = nullptr;
-            OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            ORB_CREATE_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         }
     }
-    OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    ORB_CREATE_CHECK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_FAST0_STREAM")) {   // kernel experiments (off: measured no gain at B = 512, the pyramid kernels slow down by what FAST gains: 2.60 ms per batch either way)
-        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->fast0_stream, hipStreamNonBlocking));
-        OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming));
-        OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join0, hipEventDisableTiming));
+        ORB_CREATE_CHECK(hipStreamCreateWithFlags(&h->fast0_stream, hipStreamNonBlocking));
+        ORB_CREATE_CHECK(hipEventCreateWithFlags(&h->ev_fork0, hipEventDisableTiming));
+        ORB_CREATE_CHECK(hipEventCreateWithFlags(&h->ev_join0, hipEventDisableTiming));
     }
-    OSLAM_HIP_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    ORB_CREATE_CHECK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     if (getenv("OSLAM_ORB_SPLIT_MIN")) h->split_min = atoi(getenv("OSLAM_ORB_SPLIT_MIN"));   // kernel experiments
     h->no_lds_resize = getenv("OSLAM_ORB_NO_LDS_RESIZE") != nullptr;
     if (max_batch >= h->split_min) {
-        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-        OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->aux_side_stream, hipStreamNonBlocking));
-        for (hipEvent_t* e : {&h->ev_fork2, &h->ev_join2, &h->ev_fork3, &h->ev_join3}) OSLAM_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        ORB_CREATE_CHECK(hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+        ORB_CREATE_CHECK(hipStreamCreateWithFlags(&h->aux_side_stream, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&h->ev_fork2, &h->ev_join2, &h->ev_fork3, &h->ev_join3}) ORB_CREATE_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
+#undef ORB_CREATE_CHECK
     *out = h;
     return OSLAM_OK;
 }

@@ -1402,6 +1402,12 @@ int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]) {
     return OSLAM_OK;
 }
 
+int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]) {
+    if (!h) { oslam::set_error("oslam_slam_kernel_times: bad argument"); return OSLAM_E_INVALID; }
+    if (!h->c.ops.kernel_times) { oslam::set_error("oslam_slam_kernel_times: this operator table has no device timing"); return OSLAM_E_INVALID; }
+    return h->c.ops.kernel_times(h->c.ops.ctx, enable, out);
+}
+
 int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]) {
     if (!h || !out) { oslam::set_error("oslam_slam_stage_seconds: bad argument"); return OSLAM_E_INVALID; }
     memcpy(out, h->c.sec, sizeof(h->c.sec));

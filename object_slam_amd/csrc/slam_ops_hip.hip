@@ -45,6 +45,17 @@ struct HipOps {
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     oslam_drv::Pool* pool = nullptr;
     hipStream_t strm = nullptr;   // this handle's stream (non-blocking): several handles on one GPU, each driven by its own host thread, overlap
+    // kernel-time groups (oslam_slam_kernel_times): HIP events on `strm` around the launches of a group, read after the stage's synchronisation
+    int timing = 0;
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;
+    double kt[OSLAM_SLAM_KT_GROUPS * 3] = {0};
+    void t_begin() { if (timing) (void)hipEventRecord(tev0, strm); }
+    void t_end() { if (timing) (void)hipEventRecord(tev1, strm); }
+    void t_collect(int g, double launches, double work) {   // after the stream has been synchronised
+        if (!timing) return;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tev0, tev1) == hipSuccess) { kt[3 * g] += ms; kt[3 * g + 1] += launches; kt[3 * g + 2] += work; }
+    }
     int ensure_up(size_t bytes) {
         if (bytes <= up_cap) return OSLAM_OK;
         OSLAM_HIP_CHECK(hipDeviceSynchronize());
@@ -139,6 +150,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
 int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
              oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H, dimg = (size_t)W * H;
@@ -160,14 +172,18 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_gray, U, gimg * n, hipMemcpyHostToDevice, o->strm));
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_depth, U + gimg * n, dimg * 4 * n, hipMemcpyHostToDevice, o->strm));
     }
+    o->t_begin();
     OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, o->strm));
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
     OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
     OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, o->strm));
     OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
                                                         o->d_mvDepth, o->d_status, o->strm));
+    o->t_end();
     (void)slots;
-    return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out);
+    OPS_CHECK(download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out));
+    if (o->timing) { double bytes = 0; for (int i = 0; i < n; i++) bytes += (double)oslam_orb_algorithmic_bytes(o->orb, out[i]->N); o->t_collect(0, 14, bytes); }
+    return OSLAM_OK;
 }
 
 // Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): both images extracted as two batches, UndistortKeyPoints, then ONE
@@ -175,6 +191,7 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
 int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                     oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (!o->orbR || !o->stereo) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
     if (n > o->S) { oslam::set_error("frames_stereo: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
@@ -196,6 +213,7 @@ int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* 
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_gray, U, gimg * n, hipMemcpyHostToDevice, o->strm));
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_grayR, U + gimg * n, gimg * n, hipMemcpyHostToDevice, o->strm));
     }
+    o->t_begin();
     OPS_CHECK(oslam_orb_extract_batch_device(o->orb, o->d_gray, n, (int)o->gray_pitch, gimg, o->strm));
     OPS_CHECK(oslam_orb_extract_batch_device(o->orbR, o->d_grayR, n, (int)o->gray_pitch, gimg, o->strm));
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
@@ -207,9 +225,12 @@ int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* 
                                               o->cfg.bf / o->cfg.fx, o->strm));
     const float* d_uR; const float* d_dp;
     OPS_CHECK(oslam_stereo_results_device(o->stereo, &d_uR, &d_dp, nullptr));
+    o->t_end();
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_status, d_stR, 4, hipMemcpyDeviceToDevice, o->strm));   // right extractor's overflow flag rides in the second status word
     (void)slots;
-    return download_frames(o, n, d_kp, d_desc, d_cnt, d_st, d_uR, d_dp, out);
+    OPS_CHECK(download_frames(o, n, d_kp, d_desc, d_cnt, d_st, d_uR, d_dp, out));
+    if (o->timing) { double bytes = 0; for (int i = 0; i < n; i++) bytes += 2.0 * (double)oslam_orb_algorithmic_bytes(o->orb, out[i]->N); o->t_collect(0, 28, bytes); }
+    return OSLAM_OK;
 }
 
 static void frames_view(HipOps* o, oslam_match_frames_t& fr, const uint8_t* d_blocked) {
@@ -223,6 +244,7 @@ static void frames_view(HipOps* o, oslam_match_frames_t& fr, const uint8_t* d_bl
 // launch and one search launch cover all slots.
 int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     const size_t S = o->S, cap = o->cap;
     Layout L;
@@ -249,17 +271,20 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     oslam_match_last_t la;
     la.Xw = (const float*)(Dv + oXw); la.has_mp = Dv + oHas; la.keys = (const oslam_keypoint_t*)(Dv + oKeys); la.mp_desc = Dv + oDesc;
     la.kp_stride = (int)cap; la.n_kps = (const int32_t*)(Dv + oN); la.n_kps_const = 0;
+    o->t_begin();
     OPS_CHECK(oslam_match_project_last_batch_device(o->m_last, &la, (const float*)(Dv + oTc), (const float*)(Dv + oTl), &o->cam, &fr, o->scale, o->cfg.nLevels,
                                                     jobs[0].th, 0, (int)S, o->strm));
     const int32_t* d_km; const int32_t* d_nm; const int32_t* d_nq;
     OPS_CHECK(oslam_match_results_device(o->m_last, nullptr, nullptr, &d_km, &d_nm, nullptr, &d_nq));
     OPS_CHECK(oslam_match_search_batch_device(o->m_last, &fr, nullptr, (int)cap, d_nq, 0, (int)S, 0.9f, 0, 1, 100, o->strm));
+    o->t_end();
     Layout R;
     const size_t rKm = R.take(4 * cap * S), rNm = R.take(4 * S);
     OPS_CHECK(o->ensure_dn(R.off));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(3, 2, 0);
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_last_t& j = jobs[i];
         memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
@@ -272,6 +297,7 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
 // projection queries on the device, ONE windowed search launch consumes them; only the match table and the in-view flags come back.
 int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     const size_t S = o->S, cap = o->cap;
     int maxM = 0;
@@ -302,12 +328,14 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    o->t_begin();
     OPS_CHECK(oslam_frame_is_in_frustum_batch_device((int)S, (int)st, (const int32_t*)(Dv + oM), (const float*)(Dv + oPw), (const float*)(Dv + oPn),
                                                      (const float*)(Dv + oMax), (const float*)(Dv + oMin), Dv + oObs, Dv + oDesc, (const float*)(Dv + oTc),
                                                      (const float*)(Dv + oTh), o->K5, o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview, o->strm));
     oslam_match_frames_t fr;
     frames_view(o, fr, Dv + oBl);
     OPS_CHECK(oslam_match_search_batch_device(o->m_map, &fr, o->d_lq, (int)st, (const int32_t*)(Dv + oM), 0, (int)S, 0.8f, 1, 0, 100, o->strm));
+    o->t_end();
     const int32_t* d_km; const int32_t* d_nm;
     OPS_CHECK(oslam_match_results_device(o->m_map, nullptr, nullptr, &d_km, &d_nm, nullptr, nullptr));
     Layout R;
@@ -317,6 +345,7 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rIn, o->d_inview, st * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(3, 2, 0);
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_local_t& j = jobs[i];
         memcpy(j.kp_match, o->dn_h + rKm + 4 * cap * j.slot, 4 * (size_t)j.cur->N);
@@ -329,6 +358,7 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
 // Optimizer::PoseOptimization for n frames in one launch (one workgroup per frame).
 int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     if (n > o->S) { oslam::set_error("pose_opt: n > n_sequences"); return OSLAM_E_INVALID; }
     const size_t cap = o->cap, B = n;
@@ -347,17 +377,30 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    o->t_begin();
     OPS_CHECK(oslam_pose_optimize_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), 0, (const float*)(Dv + oT), (const float*)(Dv + oXw),
                                                (const float*)(Dv + oObs), (const float*)(Dv + oInv), Dv + oHas, o->K5, o->strm));
-    const float* d_T; const uint8_t* d_out; const int32_t* d_ni;
-    OPS_CHECK(oslam_poseopt_results_device(o->po, &d_T, &d_out, &d_ni, nullptr));
+    o->t_end();
+    const float* d_T; const uint8_t* d_out; const int32_t* d_ni; const int32_t* d_stats;
+    OPS_CHECK(oslam_poseopt_results_device(o->po, &d_T, &d_out, &d_ni, &d_stats));
     Layout R;
-    const size_t rT = R.take(64 * B), rO = R.take(cap * B), rN = R.take(4 * B);
+    const size_t rT = R.take(64 * B), rO = R.take(cap * B), rN = R.take(4 * B), rS = R.take(8 * B);
     OPS_CHECK(o->ensure_dn(R.off));
+    if (o->timing) OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rS, d_stats, 8 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    if (o->timing) {   // 700 flop per edge and linearisation, 90 per edge and trial evaluation
+        double flop = 0;
+        const int32_t* stt = (const int32_t*)(o->dn_h + rS);
+        for (int i = 0; i < n; i++) {
+            int ne = 0;
+            for (int k = 0; k < jobs[i].N; k++) ne += jobs[i].has_mp[k] != 0;
+            flop += (double)ne * (700.0 * stt[2 * i] + 90.0 * stt[2 * i + 1]);
+        }
+        o->t_collect(1, 1, flop);
+    }
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_pose_t& j = jobs[i];
         memcpy(j.Tcw_out, o->dn_h + rT + 64 * i, 64);
@@ -370,6 +413,7 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
 // MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over the touched points of all sequences: one block up, two launches, one block down
 int h_mp_update(void* p, oslam_job_mp_update_t* j) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     const size_t P = j->P;
     if (P == 0) return OSLAM_OK;
     const size_t total = (size_t)j->obs_start[P];
@@ -404,17 +448,61 @@ int h_mp_update(void* p, oslam_job_mp_update_t* j) {
     return OSLAM_OK;
 }
 
+// fp64 work of one local BA: per LM trial 700 flop per edge (linearise + accumulate), Schur 324 k_p^2 per point, Cholesky (6K)^3/3,
+// back-substitution 2(6K)^2 + 45P; trials = stats[1] + stats[3]
+static double lba_flop(const oslam_lba_problem_t& q, const int32_t st[4]) {
+    std::vector<int> k(q.nP, 0);
+    for (int e = 0; e < q.nE; e++) k[q.edge_pt[e]]++;
+    double schur = 0;
+    for (int i = 0; i < q.nP; i++) schur += 324.0 * k[i] * k[i];
+    int nfree = 0;
+    for (int i = 0; i < q.nKF; i++) nfree += q.fixed[i] == 0;
+    const double n6 = 6.0 * nfree;
+    return (double)(st[1] + st[3]) * (700.0 * q.nE + schur + n6 * n6 * n6 / 3.0 + 2.0 * n6 * n6 + 45.0 * q.nP);
+}
+
 int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
+    std::vector<oslam_lba_problem_t> tp;
+    std::vector<int32_t> st;
+    if (o->timing) {
+        tp.assign(pr, pr + n); st.assign((size_t)4 * n, 0);
+        for (int i = 0; i < n; i++) tp[i].stats = &st[4 * (size_t)i];
+        pr = tp.data();
+    }
+    oslam_lba_t* ba = n == 1 ? o->ba1 : o->ba;
+    int rc;
     if (n == 1)   // one window: spread over the whole GPU
-        return oslam_lba_optimize(o->ba1, pr[0].nKF, pr[0].poses, pr[0].fixed, pr[0].nP, pr[0].points, pr[0].nE, pr[0].edge_kf, pr[0].edge_pt, pr[0].edge_obs,
-                                  pr[0].edge_invSigma2, o->K5, 0, pr[0].poses_out, pr[0].points_out, pr[0].erase, nullptr);
-    return oslam_lba_optimize_batch(o->ba, n, pr, o->K5);   // one workgroup per window, one launch
+        rc = oslam_lba_optimize(o->ba1, pr[0].nKF, pr[0].poses, pr[0].fixed, pr[0].nP, pr[0].points, pr[0].nE, pr[0].edge_kf, pr[0].edge_pt, pr[0].edge_obs,
+                                pr[0].edge_invSigma2, o->K5, 0, pr[0].poses_out, pr[0].points_out, pr[0].erase, pr[0].stats);
+    else rc = oslam_lba_optimize_batch(o->ba, n, pr, o->K5);   // one workgroup per window, one launch
+    if (!rc && o->timing) {
+        double ms = 0; long long launches = 0;
+        OPS_CHECK(oslam_lba_kernel_time(ba, 1, &ms, &launches));
+        double flop = 0;
+        for (int i = 0; i < n; i++) flop += lba_flop(pr[i], pr[i].stats);
+        o->kt[6] += ms; o->kt[7] += (double)launches; o->kt[8] += flop;
+    }
+    return rc;
+}
+
+int h_kernel_times(void* p, int enable, double* out) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (enable && !o->tev0) { OSLAM_HIP_CHECK(hipEventCreate(&o->tev0)); OSLAM_HIP_CHECK(hipEventCreate(&o->tev1)); }
+    if (out) memcpy(out, o->kt, sizeof(o->kt));
+    memset(o->kt, 0, sizeof(o->kt));
+    o->timing = enable;
+    OPS_CHECK(oslam_lba_kernel_time(o->ba, enable, nullptr, nullptr));
+    OPS_CHECK(oslam_lba_kernel_time(o->ba1, enable, nullptr, nullptr));
+    return OSLAM_OK;
 }
 
 // search half of ORBmatcher::Fuse for n (keyframe, candidate list) jobs in one launch (one workgroup per keyframe)
 int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     if (n > o->S) { oslam::set_error("fuse: n > n_sequences"); return OSLAM_E_INVALID; }
     const size_t cap = o->cap, B = n;
@@ -455,11 +543,13 @@ int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
 
 int h_bow(void* p, int n, oslam_job_bow_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     return oslam_match_bow_batch(o->bow, n, jobs, o->scale, o->sigma2, o->cfg.nLevels);
 }
 
 int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
     HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     std::vector<oslam_tri_kf_t> k1(n), k2(n);
     std::vector<int32_t> ps(n + 1, 0), i1, i2;
     for (int i = 0; i < n; i++) {
@@ -483,12 +573,15 @@ int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 
 void h_destroy(void* p) {
     HipOps* o = (HipOps*)p;
+    (void)hipSetDevice(o->cfg.device);
     oslam_orb_destroy(o->orb); oslam_orb_destroy(o->orbR); oslam_stereo_destroy(o->stereo); (void)hipFree(o->d_grayR); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
     if (o->dn_h) (void)hipHostFree(o->dn_h);
     (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview);
     delete o->pool;
+    if (o->tev0) (void)hipEventDestroy(o->tev0);
+    if (o->tev1) (void)hipEventDestroy(o->tev1);
     if (o->strm) (void)hipStreamDestroy(o->strm);
     (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
     delete o;
@@ -501,6 +594,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         oslam::set_error("oslam_slam_create: no HIP device (the tracking driver has no CPU fallback)");
         return OSLAM_E_HIP;
     }
+    memset(ops, 0, sizeof(*ops));
     HipOps* o = new HipOps;
     o->cfg = *cfg; o->S = cfg->n_sequences;
     o->pool = new oslam_drv::Pool(cfg->host_threads > 1 ? cfg->host_threads : 1);
@@ -547,5 +641,6 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames;
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
+    ops->kernel_times = h_kernel_times;
     return OSLAM_OK;
 }

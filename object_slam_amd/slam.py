@@ -22,7 +22,7 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo")]
+        "triangulate", "destroy", "frames_stereo", "kernel_times")]
 
 
 # reference Examples/RGB-D/TUM2.yaml (distortion left at zero: the synthetic streams are rendered without it)
@@ -141,6 +141,14 @@ class System:
                  "tracked_reference_kf", "lost_frames", "points_fused", "points_triangulated", "keyframes_culled", "points_culled", "last_inliers",
                  "lba_edges", "map_violations")
         return dict(zip(names, out.tolist()))
+
+    KT_GROUPS = ("frames", "pose_opt", "lba", "search")
+
+    def kernel_times(self, enable=True):
+        """Device milliseconds / launches / algorithmic work (bytes, flop, flop, -) per kernel group since the last call (include/oslam_slam.h)."""
+        out = np.zeros(len(self.KT_GROUPS) * 3, np.float64)
+        check(self.L.oslam_slam_kernel_times(self.h, C.c_int(1 if enable else 0), ptr(out)))
+        return {g: dict(ms=out[3 * i], launches=out[3 * i + 1], work=out[3 * i + 2]) for i, g in enumerate(self.KT_GROUPS)}
 
     def stage_seconds(self):
         out = np.zeros(16, np.float64)

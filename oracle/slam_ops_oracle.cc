@@ -222,6 +222,7 @@ void o_destroy(void* p) {
 }  // namespace
 
 extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* ops) {
+    memset(ops, 0, sizeof(*ops));
     OCtx* o = new OCtx;
     o->cfg = *cfg;
     o->orb = oo_orb_create(cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST);

@@ -66,3 +66,39 @@ def ate_stereo(system, cfg, streams, s):
     off = (streams[s][2] - streams[s][2][0]).astype(np.float64)
     gt = np.stack([off[:, 0] * z0 / cfg.fx, off[:, 1] * z0 / cfg.fy, np.zeros(len(off))], 1)
     return horn_align_ate(Twc[:, :, 3], gt[:len(stamps)]), Twc
+
+
+# ---- 3-D scenes (object_slam_amd/scene.py): SE3 motion with rotation, depth variation, object masks ----
+def make_scene_streams(S, n, seed0=0, speed=2.0):
+    from object_slam_amd import scene
+    return [scene.make_rgbd_sequence(seed0 + s, n, speed=speed) for s in range(S)]
+
+
+def run_scene(system, seqs, n):
+    S = len(seqs)
+    poses, states = [], []
+    for t in range(n):
+        T, st = system.TrackRGBD([seqs[s]["gray"][t] for s in range(S)], [seqs[s]["depth"][t] for s in range(S)], [t / 30.0] * S)
+        poses.append(T.copy())
+        states.append(st.copy())
+    return np.array(poses), np.array(states)
+
+
+def ate_scene(system, seqs, s):
+    stamps, Twc = system.trajectory(s)
+    return horn_align_ate(Twc[:, :, 3], seqs[s]["Twc"][:len(stamps), :3, 3]), Twc
+
+
+def make_scene_stereo(S, n, seed0=0):
+    from object_slam_amd import scene
+    return [scene.make_stereo_sequence(seed0 + s, n) for s in range(S)]
+
+
+def run_scene_stereo(system, seqs, n):
+    S = len(seqs)
+    poses, states = [], []
+    for t in range(n):
+        T, st = system.TrackStereo([seqs[s]["gray"][t] for s in range(S)], [seqs[s]["right"][t] for s in range(S)], [t / 10.0] * S)
+        poses.append(T.copy())
+        states.append(st.copy())
+    return np.array(poses), np.array(states)

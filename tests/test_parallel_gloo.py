@@ -1,9 +1,10 @@
-"""CPU, world_size 2 over gloo: the batch-of-sequences sharding and the end-of-run reduction that
-bench.py uses at N>1 (RCCL on the GPU box)."""
+"""CPU, world_size 2 over gloo: the batch-of-sequences entry point bench.py runs on every rank (`seqbench.run_rank`: sharding,
+barriers around the timed region, max-over-ranks time, all-gather of the per-rank record) — here over the CPU oracle's operator table
+instead of the HIP one (RCCL on the GPU box)."""
 import os
 import socket
 
-import torch
+import numpy as np
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -18,38 +19,65 @@ def _free_port():
     return p
 
 
+def _oracle_system(cfg):
+    import ctypes as C
+
+    from object_slam_amd import slam
+    from oracle import oracle_py as O
+    ops = slam.SlamOps()
+    assert O.lib().oo_slam_make_ops(C.byref(cfg), C.byref(ops)) == 0
+    return slam.System(cfg, ops)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    mine = shard_sequences(8, world, rank)
-    frames = 100 * len(mine) + rank
-    elapsed = 1.0 + 0.5 * rank
-    dist.barrier()
-    tot, tmax = aggregate_stats(elapsed, frames)
-    rec = gather_records([rank, frames, elapsed])
-    q.put((rank, mine, tot, tmax, rec.tolist()))
-    dist.destroy_process_group()
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_slam_amd import seqbench
+    wl = seqbench.rgbd_workload(n_base=2, stagger=1)
+    summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=3, warmup=2, on_device=False, collect_poses=True)
+    poses = np.array(extra["poses"])          # [handles, frames, 1, 4, 4]
+    q.put((rank, summ, rec.tolist(), poses, extra["groups"]))
+    if world > 1:
+        dist.destroy_process_group()
 
 
-def test_shard_and_aggregate_world2():
+def _run(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
     for p in ps:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
-    for r in res:
-        assert r[2] == 400 + 401 and abs(r[3] - 1.5) < 1e-12
-        assert r[4] == [[0.0, 400.0, 1.0], [1.0, 401.0, 1.5]]
+    return res
 
 
-def test_single_process_passthrough():
+def test_run_rank_world2_over_gloo(oracle):
+    res = _run(2)
+    s0, s1 = res[0][1], res[1][1]
+    # every rank sees the same whole-job summary: frames summed, time = max over ranks
+    assert s0["total_frames"] == s1["total_frames"] == 2 * 2 * 3 and s0["n_ranks"] == 2
+    assert s0["elapsed_s"] == s1["elapsed_s"] and s0["frames_per_s"] == s1["frames_per_s"]
+    rec = np.array(res[0][2])
+    assert np.array_equal(rec, np.array(res[1][2])) and rec.shape[0] == 2
+    assert list(rec[:, 0]) == [0, 1] and list(rec[:, 2]) == [6, 6]
+    assert s0["elapsed_s"] == max(rec[:, 3])
+    assert res[0][4] == [[0], [2]] and res[1][4] == [[1], [3]]        # sequence i -> rank i mod 2, dealt to the rank's handles in order
+    assert s0["lost_frames"] == 0 and s0["map_violations"] == 0 and s0["keyframes"] >= 4
+    # the shard a rank runs does not depend on the world size: rank 0 of the 2-rank job = the same sequences run alone
+    one = _run(1)
+    assert one[0][4] == [[0], [1]]
+    # sequence 0 is in both runs (same base sequence and offset): identical poses
+    assert np.array_equal(one[0][3][0], res[0][3][0])
+
+
+def test_shard_and_aggregate_passthrough():
     assert shard_sequences(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert shard_sequences(8, 2, 1) == [1, 3, 5, 7]
     assert aggregate_stats(2.0, 10) == (10, 2.0)
     assert gather_records([1.0, 2.0]).tolist() == [[1.0, 2.0]]

@@ -134,3 +134,46 @@ def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle):
         assert np.array_equal(hip.keyframe_trajectory(s)[0], ora.keyframe_trajectory(s)[0])
     d = np.abs(ph - po).max()
     assert d < 2e-4, d
+
+
+def test_hip_driver_matches_oracle_driver_on_3d_scene(oracle):
+    """S1 as SURVEY.md §8(d) specifies it: SE3 path with rotation and forward / backward motion over walls and boxes at 1.3 - 4.6 m, so matches
+    change pyramid level, triangulation fires and the local BA windows are not planar."""
+    from slam_common import ate_scene, make_scene_streams, run_scene
+    n, S = 36, 2
+    seqs = make_scene_streams(S, n)
+    cfg = slam.make_config(W, H, S)
+    hip = slam.System(cfg)
+    ph, sh = run_scene(hip, seqs, n)
+    cfg_o = slam.make_config(W, H, S)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run_scene(ora, seqs, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    for s in range(S):
+        a, b = hip.stats(s), ora.stats(s)
+        assert a == b, (s, a, b)
+        assert a["map_violations"] == 0 and a["local_bas"] >= 2 and a["points_triangulated"] > 0, a
+        ah, Th = ate_scene(hip, seqs, s)
+        ao, To = ate_scene(ora, seqs, s)
+        assert ah < 0.03 and ao < 0.03, (ah, ao)
+        assert np.abs(Th - To).max() < 4e-4, np.abs(Th - To).max()      # 1e-4 relative on a scene of up to 4.6 m
+    assert np.abs(ph - po).max() < 4e-4, np.abs(ph - po).max()
+
+
+def test_hip_stereo_driver_matches_oracle_driver_on_street_scene(oracle):
+    """S3 shape with forward motion (0.35 m per frame) along a street of facades at 5 - 60 m: stereo depth varies per keypoint."""
+    from slam_common import make_scene_stereo, run_scene_stereo, stereo_config
+    n, S = 14, 2
+    seqs = make_scene_stereo(S, n)
+    cfg = stereo_config(S)
+    hip = slam.System(cfg)
+    ph, sh = run_scene_stereo(hip, seqs, n)
+    cfg_o = stereo_config(S)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run_scene_stereo(ora, seqs, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all()
+    for s in range(S):
+        a, b = hip.stats(s), ora.stats(s)
+        assert a == b, (s, a, b)
+        assert a["map_violations"] == 0 and a["keyframes_created"] >= 2
+    assert np.abs(ph - po).max() < 6e-3, np.abs(ph - po).max()      # 1e-4 relative on a scene of up to 60 m
