@@ -263,15 +263,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
+    backend = "nccl"        # = RCCL on ROCm
     if local_rank >= ndev:
         if not os.environ.get("OSLAM_BENCH_SHARE_GPU"):
             raise SystemExit("rank %d: only %d GPU(s) visible (set OSLAM_BENCH_SHARE_GPU=1 to rehearse several ranks on one card)" % (local_rank, ndev))
         local_rank %= ndev
+    if world > ndev:
+        backend = "gloo"    # rehearsal of several ranks on one card: RCCL refuses two ranks on the same device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     threads_per_handle = max(1, min(16, share) // G)
     kt = {}
@@ -281,7 +287,7 @@ def main():
             for sy in systems:
                 sy.kernel_times(True)
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
-                                                      host_threads=max(1, min(16, share) // G_), sequences=seqs, after_warmup=reset_timers)
+                                                      host_threads=max(1, min(16, share) // G_), sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl")
         tot = {}
         for sy in systems:
             for g, v in sy.kernel_times(False).items():

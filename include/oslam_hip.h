@@ -332,6 +332,24 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
                          const float* invSigma2, const uint8_t* has_mp, const float K5[5], const oslam_semantic_t* sem,
                          float Tcw_out[16], uint8_t* outlier, int32_t* n_inliers, int32_t* n_semantic);
 
+/* Batch form (Tracking::TrackLocalMap of several sequences, src/Tracking.cc:1022): device pointers, asynchronous on `stream`.  The base arrays are those
+ * of oslam_pose_optimize_batch_device.  Frame b uses masks d_mask_ptrs[obj0 .. obj0 + nObj) (device pointers to uint8 {0,255} images of H x W, rows
+ * mask_pitch bytes apart: nothing is copied), object map points objmp0 .. objmp0 + nObjMp of the pools (objmp_obj = object index INSIDE the frame)
+ * and M_joint entries joint0 .. joint0 + nJoint; mvKeysUn[kp].pt is read from the frame's obs rows.  n_semantic per frame through
+ * oslam_poseopt_semantic_results_device; a frame with fewer than 3 correspondences reports 0. */
+typedef struct oslam_sem_frame { int32_t nObj, obj0, nObjMp, objmp0, nJoint, joint0; } oslam_sem_frame_t;
+int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, const float* d_Tcw, const float* d_Xw, const float* d_obs,
+                                      const float* d_invSigma2, const uint8_t* d_has_mp, const float K5[5], const oslam_sem_frame_t* d_frames, int total_obj,
+                                      const uint8_t* const* d_mask_ptrs, int H, int W, int mask_pitch, int total_objmp, const float* d_objmp_Xw,
+                                      const int32_t* d_objmp_obj, int total_joint, const int32_t* d_joint_kp, const int32_t* d_joint_obj, const float bounds[4],
+                                      float invSigma2_0, void* stream);
+int oslam_poseopt_semantic_results_device(const oslam_poseopt_t* h, const int32_t** d_n_semantic);
+/* Frame::BuildObject2DsRGBD / BuildObject2DsStereo keypoint test (src/Frame.cc:262-272, :336-346): bit o of d_out[b][k] is set iff every pixel
+ * (int)(kpUn.y + row), (int)(kpUn.x + col), row / col in [-10, 10), of mask d_mask_ptrs[d_mask0[b] + o] equals 255 (a pixel outside the image fails: the
+ * reference reads out of bounds there); at most 8 masks per frame.  The depth gate and the sequential assignment (:273-301) stay with the caller. */
+int oslam_frame_object_kp_test_batch_device(const oslam_keypoint_t* d_keysUn, int kp_stride, const int32_t* d_n_kps, int batch, const uint8_t* const* d_mask_ptrs,
+                                            const int32_t* d_mask0, const int32_t* d_n_masks, int H, int W, int mask_pitch, uint8_t* d_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer::LocalBundleAdjustment (include/Optimizer.h:45, src/Optimizer.cc:453-778) after the
  * covisibility gather (:456-504, pointer-graph walk, stays with the caller):

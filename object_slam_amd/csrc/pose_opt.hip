@@ -34,6 +34,8 @@ struct SemCtx {
     // semantic edge store (capacity nJoint + nObjMp): M_joint edges first, then M_semantic
     float* e_Xw; float* e_obs; uint8_t* e_level; double* e_chi2; int* e_obj; uint8_t* e_out; int* e_tmp;
     int* nSem;                 // [B] semantic constraints used (nSemNum, :1232)
+    const oslam_sem_frame_t* frames;   // batch form: frame b uses objects [obj0, obj0 + nObj) of the pools above, its own slice of the objmp / joint /
+                                       // edge-store pools, and the keypoint coordinates of its obs rows (kp_uv == nullptr)
 };
 
 struct PoseCtx {
@@ -203,7 +205,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     int nBad = 0, tot_its = 0, tot_trials = 0;
 
     // ---- semantic edges (PoseOptimization2) ----
-    const SemCtx& sm = c.sem;
+    SemCtx sm = c.sem;
+    if (SEM && c.sem.frames) {
+        const oslam_sem_frame_t f = c.sem.frames[b];
+        const int e0 = f.objmp0 + f.joint0;
+        sm.nObj = f.nObj; sm.area_start += f.obj0;
+        sm.nObjMp = f.nObjMp; sm.objmp_Xw += 3 * (long long)f.objmp0; sm.objmp_obj += f.objmp0;
+        sm.nJoint = f.nJoint; sm.joint_kp += f.joint0; sm.joint_obj += f.joint0;
+        sm.e_Xw += 3 * (long long)e0; sm.e_obs += 2 * (long long)e0; sm.e_level += e0; sm.e_chi2 += e0; sm.e_obj += e0; sm.e_out += e0; sm.e_tmp += e0;
+        sm.nSem = c.sem.nSem;
+    }
     __shared__ int s_nsem, s_ninit, s_semnum;
     int nsem = 0, ninit = 0;
     if (SEM) {
@@ -212,7 +223,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
             const int kp = sm.joint_kp[j], o = sm.joint_obj[j];
             int idx; float d2;
             int ok = 0;
-            if (mask_nearest(sm, o, sm.kp_uv[kp * 2], sm.kp_uv[kp * 2 + 1], idx, d2) && !(d2 < 1.0f)) ok = 1 + idx;
+            const float ku = sm.kp_uv ? sm.kp_uv[kp * 2] : gobs[kp * 3], kv = sm.kp_uv ? sm.kp_uv[kp * 2 + 1] : gobs[kp * 3 + 1];   // mvKeysUn[kp].pt
+            if (mask_nearest(sm, o, ku, kv, idx, d2) && !(d2 < 1.0f)) ok = 1 + idx;
             sm.e_tmp[j] = ok;
         }
         __syncthreads();
@@ -533,10 +545,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     }
 }
 
-// Object2D mask -> ordered list of its 255-pixels (pcl cloud order of reference src/ObjectOptimizer.cc:699-710)
-__global__ __launch_bounds__(64) void k_mask_rowcount(const uint8_t* masks, int H, int W, int* rowcnt) {
+// Object2D mask -> ordered list of its 255-pixels (pcl cloud order of reference src/ObjectOptimizer.cc:699-710).
+// Mask o is masks + o*H*pitch (ptrs == nullptr) or ptrs[o], rows `pitch` bytes apart.  Three steps: per-row counts, per-object exclusive
+// scan of the rows + a scan over the objects (area_start), then the ordered fill.
+__device__ __forceinline__ const uint8_t* mask_row(const uint8_t* masks, const uint8_t* const* ptrs, int o, int H, int pitch, int row) {
+    return (ptrs ? ptrs[o] : masks + (long long)o * H * pitch) + (long long)row * pitch;
+}
+
+__global__ __launch_bounds__(64) void k_mask_rowcount(const uint8_t* masks, const uint8_t* const* ptrs, int H, int W, int pitch, int* rowcnt) {
     const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
-    const uint8_t* m = masks + ((long long)o * H + row) * W;
+    const uint8_t* m = mask_row(masks, ptrs, o, H, pitch, row);
     int n = 0;
     for (int x = lane; x < W; x += 64) n += (m[x] == 255);
 #pragma unroll
@@ -544,18 +562,44 @@ __global__ __launch_bounds__(64) void k_mask_rowcount(const uint8_t* masks, int 
     if (lane == 0) rowcnt[o * H + row] = n;
 }
 
-__global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, int H, int W, int nObj, const int* rowcnt, short2* area,
-                                                  int* area_start) {
-    const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
-    int before = 0;
-    const int upto = o * H + row;
-    for (int i = lane; i < upto; i += 64) before += rowcnt[i];
+// one wavefront per object: rowcnt[o*H + row] becomes the number of mask pixels in the rows before `row`; objcnt[o] = the object's total
+__global__ __launch_bounds__(64) void k_mask_rowscan(int H, int* rowcnt, int* objcnt) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    int* rc = rowcnt + (long long)o * H;
+    int carry = 0;
+    for (int r0 = 0; r0 < H; r0 += 64) {
+        const int r = r0 + lane;
+        const int v = r < H ? rc[r] : 0;
+        int incl = v;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d, 64);
-    if (row == 0 && lane == 0) area_start[o] = before;
-    if (o == nObj - 1 && row == H - 1 && lane == 0) area_start[nObj] = before + rowcnt[upto];
-    const uint8_t* m = masks + ((long long)o * H + row) * W;
-    int base = before;
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (r < H) rc[r] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) objcnt[o] = carry;
+}
+
+// one wavefront: area_start[o] = pixels of the objects before o, area_start[nObj] = total
+__global__ __launch_bounds__(64) void k_mask_objscan(int nObj, const int* objcnt, int* area_start) {
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int o0 = 0; o0 < nObj; o0 += 64) {
+        const int o = o0 + lane;
+        const int v = o < nObj ? objcnt[o] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (o < nObj) area_start[o] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) area_start[nObj] = carry;
+}
+
+__global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, const uint8_t* const* ptrs, int H, int W, int pitch, const int* rowstart,
+                                                  const int* area_start, short2* area) {
+    const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
+    const uint8_t* m = mask_row(masks, ptrs, o, H, pitch, row);
+    int base = area_start[o] + rowstart[o * H + row];
     for (int x0 = 0; x0 < W; x0 += 64) {
         const int x = x0 + lane;
         const bool f = x < W && m[x] == 255;
@@ -563,6 +607,29 @@ __global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, int H, i
         if (f) area[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_short2((short)x, (short)row);
         base += __popcll(bal);
     }
+}
+
+// Frame::BuildObject2DsRGBD keypoint test (reference src/Frame.cc:262-272): every mask pixel (int)(kp.pt.y + row), (int)(kp.pt.x + col), row / col in
+// [-10, 10), equals 255.  One wavefront per (keypoint, mask): 400 byte reads, one ballot.  A pixel outside the image fails the test (the reference
+// reads out of bounds there).  out[b][k] gets bit o.
+__global__ __launch_bounds__(256) void k_object_kp_test(const oslam_keypoint_t* keysUn, int kp_stride, const int* n_kps, const uint8_t* const* mask_ptrs,
+                                                        const int* mask0, const int* n_masks, int H, int W, int pitch, uint8_t* out) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_kps[b]) return;
+    const oslam_keypoint_t kp = keysUn[(long long)b * kp_stride + k];
+    uint8_t bits = 0;
+    for (int o = 0; o < n_masks[b]; o++) {
+        const uint8_t* m = mask_ptrs[mask0[b] + o];
+        bool ok = true;
+        for (int i = lane; i < 400; i += 64) {
+            const int row = i / 20 - 10, col = i % 20 - 10;
+            const int y = (int)(kp.y + (float)row), x = (int)(kp.x + (float)col);
+            ok = ok && y >= 0 && y < H && x >= 0 && x < W && m[(long long)y * pitch + x] == 255;
+        }
+        if (__ballot(!ok) == 0ull) bits |= (uint8_t)(1u << o);
+    }
+    if (lane == 0) out[(long long)b * kp_stride + k] = bits;
 }
 
 }  // namespace oslam
@@ -582,7 +649,7 @@ struct oslam_poseopt {
     uint8_t* h_pin = nullptr; size_t pin_cap = 0;   // pinned staging of the single-frame host API (inputs, then results)
     // semantic variant: grow-only device buffers
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf masks, rowcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
+    Buf masks, rowcnt, objcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
 };
 
 static int ensure(oslam_poseopt::Buf& b, size_t bytes) {
@@ -599,7 +666,7 @@ extern "C" {
 void oslam_poseopt_destroy(oslam_poseopt_t* h) {
     if (!h) return;
     void* ptrs[] = {h->d_Tout, h->d_outlier, h->d_ninl, h->d_stats, h->d_T, h->d_Xw, h->d_obs, h->d_inv, h->d_has,
-                    h->masks.p, h->rowcnt.p, h->area.p, h->area_start.p, h->objmp_Xw.p, h->objmp_obj.p, h->joint_kp.p, h->joint_obj.p, h->kp_uv.p,
+                    h->masks.p, h->rowcnt.p, h->objcnt.p, h->area.p, h->area_start.p, h->objmp_Xw.p, h->objmp_obj.p, h->joint_kp.p, h->joint_obj.p, h->kp_uv.p,
                     h->eXw.p, h->eobs.p, h->elevel.p, h->echi2.p, h->eobj.p, h->eout.p, h->etmp.p, h->nsem.p};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -736,6 +803,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     const size_t nsemcap = (size_t)sem->nJoint + sem->nObjMp;
     int rc;
     if ((rc = ensure(h->masks, npx + 1)) || (rc = ensure(h->area, (npx + 1) * sizeof(short2))) || (rc = ensure(h->rowcnt, (nrows + 1) * 4)) ||
+        (rc = ensure(h->objcnt, ((size_t)sem->nObj + 1) * 4)) ||
         (rc = ensure(h->area_start, ((size_t)sem->nObj + 2) * 4)) || (rc = ensure(h->objmp_Xw, (size_t)sem->nObjMp * 12 + 12)) ||
         (rc = ensure(h->objmp_obj, (size_t)sem->nObjMp * 4 + 4)) || (rc = ensure(h->joint_kp, (size_t)sem->nJoint * 4 + 4)) ||
         (rc = ensure(h->joint_obj, (size_t)sem->nJoint * 4 + 4)) || (rc = ensure(h->kp_uv, (size_t)N * 8 + 8)) ||
@@ -762,8 +830,10 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
         OSLAM_HIP_CHECK(hipMemcpy((int*)h->joint_obj.p, sem->joint_obj, (size_t)sem->nJoint * 4, hipMemcpyHostToDevice));
     }
     if (sem->nObj > 0 && sem->H > 0 && sem->W > 0) {
-        hipLaunchKernelGGL(k_mask_rowcount, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, sem->H, sem->W, (int*)h->rowcnt.p);
-        hipLaunchKernelGGL(k_mask_fill, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, sem->H, sem->W, sem->nObj, (int*)h->rowcnt.p, (short2*)h->area.p, (int*)h->area_start.p);
+        hipLaunchKernelGGL(k_mask_rowcount, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, nullptr, sem->H, sem->W, sem->W, (int*)h->rowcnt.p);
+        hipLaunchKernelGGL(k_mask_rowscan, dim3(sem->nObj), dim3(64), 0, nullptr, sem->H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
+        hipLaunchKernelGGL(k_mask_objscan, dim3(1), dim3(64), 0, nullptr, sem->nObj, (int*)h->objcnt.p, (int*)h->area_start.p);
+        hipLaunchKernelGGL(k_mask_fill, dim3(sem->H, sem->nObj), dim3(64), 0, nullptr, (uint8_t*)h->masks.p, nullptr, sem->H, sem->W, sem->W, (int*)h->rowcnt.p, (int*)h->area_start.p, (short2*)h->area.p);
     } else {
         OSLAM_HIP_CHECK(hipMemset((int*)h->area_start.p, 0, 2 * sizeof(int)));
     }
@@ -779,6 +849,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     sm.minX = sem->bounds[0]; sm.minY = sem->bounds[1]; sm.maxX = sem->bounds[2]; sm.maxY = sem->bounds[3]; sm.invSigma2_0 = sem->invSigma2_0;
     sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p; sm.e_out = (uint8_t*)h->eout.p; sm.e_tmp = (int*)h->etmp.p;
     sm.nSem = (int*)h->nsem.p;
+    sm.frames = nullptr;
     if (h->stage) hipLaunchKernelGGL((k_pose_optimize<true, true>), dim3(1), dim3(kPoseThreads), pose_lds_bytes(h->max_points, true), nullptr, c);
     else hipLaunchKernelGGL((k_pose_optimize<true, false>), dim3(1), dim3(kPoseThreads), pose_lds_bytes(h->max_points, false), nullptr, c);
     OSLAM_HIP_CHECK(hipGetLastError());
@@ -787,6 +858,72 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     OSLAM_HIP_CHECK(hipMemcpy(n_inliers, h->d_ninl, 4, hipMemcpyDeviceToHost));
     OSLAM_HIP_CHECK(hipMemcpy(n_semantic, (int*)h->nsem.p, 4, hipMemcpyDeviceToHost));
     if (N > 0) OSLAM_HIP_CHECK(hipMemcpy(outlier, h->d_outlier, (size_t)N, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
+
+// Batch of frames with semantic constraints (Tracking::TrackLocalMap of several sequences): the base arrays as in
+// oslam_pose_optimize_batch_device; the Object2D masks of all frames through a table of device pointers (no copy), the object map points and
+// the M_joint sets as pools with one oslam_sem_frame_t per frame.  Asynchronous on `stream`; results through oslam_poseopt_results_device +
+// oslam_poseopt_semantic_results_device.
+int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, const float* d_Tcw, const float* d_Xw, const float* d_obs,
+                                      const float* d_invSigma2, const uint8_t* d_has_mp, const float K5[5], const oslam_sem_frame_t* d_frames, int total_obj,
+                                      const uint8_t* const* d_mask_ptrs, int H, int W, int mask_pitch, int total_objmp, const float* d_objmp_Xw,
+                                      const int32_t* d_objmp_obj, int total_joint, const int32_t* d_joint_kp, const int32_t* d_joint_obj, const float bounds[4],
+                                      float invSigma2_0, void* stream) {
+    if (!h || !d_n || !d_Tcw || !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp || !K5 || !d_frames || !bounds) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (batch < 1 || batch > h->max_batch) { set_error("batch %d outside [1,%d]", batch, h->max_batch); return OSLAM_E_INVALID; }
+    if (stride < 1 || stride > h->max_points) { set_error("stride exceeds max_points %d", h->max_points); return OSLAM_E_CAPACITY; }
+    if (total_obj < 0 || total_objmp < 0 || total_joint < 0 || H < 1 || W < 1 || W >= 32768 || H >= 32768 || mask_pitch < W || (total_obj > 0 && !d_mask_ptrs) ||
+        (total_objmp > 0 && (!d_objmp_Xw || !d_objmp_obj)) || (total_joint > 0 && (!d_joint_kp || !d_joint_obj))) { set_error("bad semantic sizes"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npx = (size_t)total_obj * H * W, nrows = (size_t)total_obj * H, nsemcap = (size_t)total_joint + total_objmp;
+    int rc;
+    if ((rc = ensure(h->area, (npx + 1) * sizeof(short2))) || (rc = ensure(h->rowcnt, (nrows + 1) * 4)) || (rc = ensure(h->objcnt, ((size_t)total_obj + 1) * 4)) ||
+        (rc = ensure(h->area_start, ((size_t)total_obj + 2) * 4)) || (rc = ensure(h->eXw, nsemcap * 12 + 12)) || (rc = ensure(h->eobs, nsemcap * 8 + 8)) ||
+        (rc = ensure(h->elevel, nsemcap + 1)) || (rc = ensure(h->echi2, nsemcap * 8 + 8)) || (rc = ensure(h->eobj, nsemcap * 4 + 4)) || (rc = ensure(h->eout, nsemcap + 1)) ||
+        (rc = ensure(h->etmp, nsemcap * 4 + 4)) || (rc = ensure(h->nsem, (size_t)h->max_batch * 4)))
+        return rc;
+    if (total_obj > 0) {
+        hipLaunchKernelGGL(k_mask_rowcount, dim3(H, total_obj), dim3(64), 0, st, nullptr, d_mask_ptrs, H, W, mask_pitch, (int*)h->rowcnt.p);
+        hipLaunchKernelGGL(k_mask_rowscan, dim3(total_obj), dim3(64), 0, st, H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
+        hipLaunchKernelGGL(k_mask_objscan, dim3(1), dim3(64), 0, st, total_obj, (int*)h->objcnt.p, (int*)h->area_start.p);
+        hipLaunchKernelGGL(k_mask_fill, dim3(H, total_obj), dim3(64), 0, st, nullptr, d_mask_ptrs, H, W, mask_pitch, (int*)h->rowcnt.p, (int*)h->area_start.p, (short2*)h->area.p);
+    } else {
+        OSLAM_HIP_CHECK(hipMemsetAsync((int*)h->area_start.p, 0, 2 * sizeof(int), st));
+    }
+    PoseCtx c;
+    c.Tcw = d_Tcw; c.Xw = d_Xw; c.obs = d_obs; c.invSigma2 = d_invSigma2; c.has_mp = d_has_mp;
+    c.n = d_n; c.n_const = 0; c.stride = stride;
+    c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    SemCtx& sm = c.sem;
+    memset(&sm, 0, sizeof(sm));
+    sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.objmp_Xw = d_objmp_Xw; sm.objmp_obj = d_objmp_obj; sm.joint_kp = d_joint_kp; sm.joint_obj = d_joint_obj; sm.kp_uv = nullptr;
+    sm.minX = bounds[0]; sm.minY = bounds[1]; sm.maxX = bounds[2]; sm.maxY = bounds[3]; sm.invSigma2_0 = invSigma2_0;
+    sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p;
+    sm.e_out = (uint8_t*)h->eout.p; sm.e_tmp = (int*)h->etmp.p; sm.nSem = (int*)h->nsem.p; sm.frames = d_frames;
+    if (h->stage) hipLaunchKernelGGL((k_pose_optimize<true, true>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, true), st, c);
+    else hipLaunchKernelGGL((k_pose_optimize<true, false>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, false), st, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_poseopt_semantic_results_device(const oslam_poseopt_t* h, const int32_t** d_n_semantic) {
+    if (!h || !d_n_semantic) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    *d_n_semantic = (const int32_t*)h->nsem.p;
+    return OSLAM_OK;
+}
+
+// Frame::BuildObject2DsRGBD keypoint test for a batch of frames (see k_object_kp_test).  d_out [batch][kp_stride], bit o = mask mask0[b] + o passes.
+int oslam_frame_object_kp_test_batch_device(const oslam_keypoint_t* d_keysUn, int kp_stride, const int32_t* d_n_kps, int batch, const uint8_t* const* d_mask_ptrs,
+                                            const int32_t* d_mask0, const int32_t* d_n_masks, int H, int W, int mask_pitch, uint8_t* d_out, void* stream) {
+    if (!d_keysUn || !d_n_kps || !d_mask_ptrs || !d_mask0 || !d_n_masks || !d_out || batch < 1 || kp_stride < 1 || H < 1 || W < 1 || mask_pitch < W) { set_error("object_kp_test: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_object_kp_test, dim3(div_up(kp_stride, 4), batch), dim3(256), 0, (hipStream_t)stream, d_keysUn, kp_stride, d_n_kps, d_mask_ptrs, d_mask0, d_n_masks, H, W,
+                       mask_pitch, d_out);
+    OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
 

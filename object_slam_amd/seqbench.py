@@ -102,7 +102,7 @@ def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1):
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,
-             sequences=None, after_warmup=None):
+             sequences=None, after_warmup=None, coll_on_device=True):
     """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread), `warmup`
     untimed lockstep steps, then exactly `steps` timed steps bracketed by a barrier + device synchronisation on both sides.
     Returns (summary dict on every rank, per-rank records [world, len(RECORD_FIELDS)], systems, extra)."""
@@ -148,7 +148,7 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
         dist.barrier()
     elapsed = time.perf_counter() - tstart
     frames = seqs_per_rank * steps
-    total_frames, max_elapsed = aggregate_stats(elapsed, frames, device=device if on_device else None)
+    total_frames, max_elapsed = aggregate_stats(elapsed, frames, device=device if (on_device and coll_on_device) else None)
 
     # per-rank record (fixed size, all-gathered once): counters summed over the rank's sequences, ATE of its first sequence
     kf = lba = lost = viol = sem = 0
@@ -161,7 +161,7 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     gt = inp.gt(groups[0][0], n_frames)
     ate = horn_align_ate(Twc[:, :, 3], gt[:len(Twc), :3, 3]) if len(Twc) >= 3 else float("nan")
     rec = [rank, seqs_per_rank, frames, elapsed, kf, lba, lost, ate, viol, sem]
-    records = gather_records(rec, device=device if on_device else None).numpy()
+    records = gather_records(rec, device=device if (on_device and coll_on_device) else None).numpy()
     summary = {"frames_per_s": total_frames / max_elapsed, "total_frames": total_frames, "elapsed_s": max_elapsed,
                "ms_per_step": max_elapsed / steps * 1e3, "n_ranks": int(records.shape[0]),
                "keyframes": int(records[:, 4].sum()), "local_bas": int(records[:, 5].sum()), "lost_frames": int(records[:, 6].sum()),
