@@ -109,6 +109,8 @@ int oslam_orb_get_profile(oslam_orb_t* h, double ms[5], long long* batches, long
 int oslam_orb_debug_counters(oslam_orb_t* h, unsigned long long out[16], int reset);
 
 /* Work model of one extract call: algorithmic bytes per image. */
+/* Synchronous device-to-host copy (tests and tools read the *_results_device arrays with it). */
+int oslam_memcpy_from_device(void* dst, const void* d_src, size_t bytes);
 int64_t oslam_orb_algorithmic_bytes(const oslam_orb_t* h, int n_keypoints);
 
 /* ------------------------------------------------------------------------------------------

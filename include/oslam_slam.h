@@ -21,7 +21,16 @@
  *     structure (node id at the 4th level from the leaves -> keypoint indices);
  *   - out of scope: Relocalization (a sequence lost with more than 5 keyframes stays LOST; with <= 5 the
  *     system resets like src/Tracking.cc:553-561 and re-initialises on the next frame), loop closing, the object layer
- *     (TrackObject / UpdateCurrentObject), the viewer.  PoseOptimization2 without matched objects is PoseOptimization.
+ *     (ObjectMatcher, Object3D outlier rejection, ObjectMapRegularization), the viewer.
+ * Semantic constraints (BASELINE.json configs[2]): oslam_slam_track_rgbd_objects / _stereo_objects take the frame's instance masks.  The driver
+ * builds the Object2Ds (Frame::BuildObject2DsRGBD, src/Frame.cc:240-312: 20x20 mask window test, depth gate, > 5 keypoints) and calls
+ * ObjectOptimizer::PoseOptimization2 in TrackLocalMap (src/Tracking.cc:1022) with the M_joint / M_semantic edges of src/ObjectOptimizer.cc:687-1100.
+ * What the out-of-scope object layer would supply is replaced by a minimal substitute, stated here so that nobody mistakes it for the reference's:
+ *   - association (Tracking::TrackObject: ObjectMatcher::MatchTwoFrame / MatchMapToFrame) = the caller's `track_id` per detection: mvpObject3Ds[o] is
+ *     the Object3D created earlier for that id (PoseOptimization2 without matched objects is PoseOptimization);
+ *   - Object3D bookkeeping (Tracking::UpdateCurrentObject :1079-1210, Object3D::Update src/ObjectTypes.cc:56-140) keeps its list logic — a new
+ *     Object3D from the Object2D's keypoints with map points when there are more than MIN_OBJ3DMP_NUM = 5 of them, later frames append the
+ *     non-bad, non-outlier map points not yet listed — without the PCL Euclidean clustering / RejectOutliers steps.
  */
 #ifndef OSLAM_SLAM_H
 #define OSLAM_SLAM_H
@@ -107,6 +116,29 @@ typedef struct oslam_job_fuse {            /* search half of ORBmatcher::Fuse on
     int32_t* q_match;                      /* out [M] */
 } oslam_job_fuse_t;
 
+#define OSLAM_SLAM_MAX_OBJECTS 8           /* detections per frame (one bit each in the keypoint test) */
+
+typedef struct oslam_slam_objects {        /* the semantic detections of ONE frame (reference include/Semantic.h; src/Semantic.cc:14-96) */
+    int32_t n;                             /* <= OSLAM_SLAM_MAX_OBJECTS, in the order of the semantic file */
+    const uint8_t* const* masks;           /* n images of width x height, uint8 {0, 255}, rows mask_stride bytes apart (host or device like the frames) */
+    const int32_t* track_id;               /* n: identity of the physical object (substitute for ObjectMatcher, see the head comment); < 0 = unknown */
+    const int32_t* label;                  /* n: class label (recorded, not used on this path); may be NULL */
+} oslam_slam_objects_t;
+
+typedef struct oslam_job_object_kps {      /* keypoint test of Frame::BuildObject2DsRGBD (src/Frame.cc:262-272) for the frame built for `slot` */
+    int32_t slot; const oslam_slam_frame_t* cur;
+    int32_t n_masks; const uint8_t* const* masks; int32_t mask_stride; int32_t on_device;
+    uint8_t* in_mask;                      /* out [cur->N]: bit o = every pixel of the 20x20 window around mvKeysUn[k] equals 255 in mask o */
+} oslam_job_object_kps_t;
+
+typedef struct oslam_job_pose2 {           /* ObjectOptimizer::PoseOptimization2 (src/ObjectOptimizer.cc:624-1240), see oslam_semantic_t in oslam_hip.h */
+    oslam_job_pose_t base;
+    int32_t nObj; const uint8_t* const* masks; int32_t mask_stride; int32_t on_device;   /* Object2D masks of the matched objects, idx_obj order */
+    int32_t nObjMp; const float* objmp_Xw; const int32_t* objmp_obj;
+    int32_t nJoint; const int32_t* joint_kp; const int32_t* joint_obj;
+    int32_t n_semantic;                    /* out: nSemNum (:1232) */
+} oslam_job_pose2_t;
+
 typedef oslam_bow_job_t oslam_job_bow_t;   /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657), see oslam_hip.h */
 
 typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (current keyframe, neighbour) pair */
@@ -140,6 +172,9 @@ typedef struct oslam_slam_ops {
     /* Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): two ExtractORB + ComputeStereoMatches (:706-880); NULL if unsupported */
     int (*frames_stereo)(void* ctx, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride,
                          int on_device, oslam_slam_frame_t* const* out);
+    /* semantic constraints (NULL = the table cannot run frames with objects) */
+    int (*object_kps)(void* ctx, int n, oslam_job_object_kps_t* jobs);
+    int (*pose_opt2)(void* ctx, int n, oslam_job_pose2_t* jobs);
     /* optional (NULL in tables without a device): see oslam_slam_kernel_times */
     int (*kernel_times)(void* ctx, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
 } oslam_slam_ops_t;
@@ -159,6 +194,15 @@ int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_
 /* System::TrackStereo (include/System.h:69) for every sequence (cfg.sensor = 1): rectified left / right images. */
 int oslam_slam_track_stereo(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                             const double* timestamps, float* Tcw_out, int32_t* state_out);
+
+/* The same with the frame's semantic detections (objs [S]; objs[s].n = 0 or objs == NULL: no detections); on_device applies to the masks too. */
+int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
+                                  const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
+int oslam_slam_track_stereo_objects(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                                    const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
+/* Object layer counters of one sequence: [0] N_AllSemanticConstraintNum (src/ObjectOptimizer.cc:1233), [1] frames optimised with matched objects,
+ * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built. */
+int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
  * Twc [n][12] = rows of [Rwc | twc]; lost frames are skipped like the reference.  Returns the count in *n_out (cap < n -> OSLAM_E_CAPACITY). */

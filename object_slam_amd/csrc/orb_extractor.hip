@@ -791,6 +791,11 @@ int oslam_orb_debug_get_level_keys(oslam_orb_t* h, int b, int level, int32_t* ou
     return OSLAM_OK;
 }
 
+int oslam_memcpy_from_device(void* dst, const void* d_src, size_t bytes) {
+    OSLAM_HIP_CHECK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return OSLAM_OK;
+}
+
 int64_t oslam_orb_algorithmic_bytes(const oslam_orb_t* h, int n_kp) {
     // W*H + (P-p_last)+(P-p0) + P + 2P + 749 N + 512 N + 60 N
     if (!h) return 0;

@@ -25,8 +25,9 @@ constexpr int kRedN = 29;   // 21 H (upper) + 6 b + chi + 1 spare
 // Semantic constraints of ObjectOptimizer::PoseOptimization2 (reference src/ObjectOptimizer.cc:624-1240)
 struct SemCtx {
     int nObj;
-    const short2* area;        // mask pixels == 255 as (col,row), row-major scan order per object (:699-710)
+    const short2* area;        // BOUNDARY pixels of the mask (== 255 with a 4-neighbour that is not, or on the image border) as (col,row), row-major scan order per object
     const int* area_start;     // [nObj+1]
+    const uint8_t* masks; const uint8_t* const* mask_ptrs; int H, W, pitch;   // the masks themselves (mask o = mask_ptrs[o] or masks + o*H*pitch), for the pixels around a query
     int nObjMp; const float* objmp_Xw; const int* objmp_obj;          // object map points, object-major
     int nJoint; const int* joint_kp; const int* joint_obj;             // M_joint candidates (:721-726)
     const float* kp_uv;        // [N][2] mvKeysUn[i].pt
@@ -80,21 +81,40 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [2][
     phase ^= 1;   // next reduction uses the other buffer: one barrier per reduction is enough
 }
 
-// exact nearest mask pixel under FLANN's float L2 (squared); ties -> first in scan order
-__device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, float v, int& idx, float& d2) {
+// Exact nearest mask pixel under FLANN's float L2 (squared) over ALL pixels == 255 (the pcl cloud of reference src/ObjectOptimizer.cc:699-710); ties ->
+// first in row-major scan order, i.e. smaller (row, col).  Only the mask's boundary pixels and the (at most four) pixels of the unit cell around the
+// query can be that pixel: an interior pixel more than half a pixel away in x or y has a 4-neighbour inside the mask that is strictly nearer, and a
+// pixel within one pixel in both x and y is one of the floor / ceil combinations.  (Pixel minus query is exact in float for |difference| <= 1.)
+// px = col | row << 15.
+__device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, float v, int& px, float& d2) {
     const int s0 = sm.area_start[o], s1 = sm.area_start[o + 1];
-    if (s1 <= s0) return false;
+    if (s1 <= s0) return false;   // no boundary pixel = empty mask
     float best = 0;
-    int bi = -1;
-    for (int i = s0; i < s1; i++) {
+    int bx = -1, by = -1;
+    for (int i = s0; i < s1; i++) {   // list order = scan order: the first minimum wins
         const short2 p = sm.area[i];
         const float dx = (float)p.x - u, dy = (float)p.y - v;
         float d = 0;
         d += dx * dx;
         d += dy * dy;
-        if (bi < 0 || d < best) { best = d; bi = i; }
+        if (bx < 0 || d < best) { best = d; bx = p.x; by = p.y; }
     }
-    idx = bi;
+    const uint8_t* m = sm.mask_ptrs ? sm.mask_ptrs[o] : sm.masks + (long long)o * sm.H * sm.pitch;
+    const float fu = floorf(u), fv = floorf(v);
+    if (fu >= -1.f && fu < (float)sm.W && fv >= -1.f && fv < (float)sm.H) {
+        const int x0 = (int)fu, y0 = (int)fv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + (k & 1), y = y0 + (k >> 1);
+            if (x < 0 || y < 0 || x >= sm.W || y >= sm.H || m[(long long)y * sm.pitch + x] != 255) continue;
+            const float dx = (float)x - u, dy = (float)y - v;
+            float d = 0;
+            d += dx * dx;
+            d += dy * dy;
+            if (d < best || (d == best && (y < by || (y == by && x < bx)))) { best = d; bx = x; by = y; }
+        }
+    }
+    px = bx | (by << 15);
     d2 = best;
     return true;
 }
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     if (SEM && c.sem.frames) {
         const oslam_sem_frame_t f = c.sem.frames[b];
         const int e0 = f.objmp0 + f.joint0;
-        sm.nObj = f.nObj; sm.area_start += f.obj0;
+        sm.nObj = f.nObj; sm.area_start += f.obj0; sm.mask_ptrs += f.obj0;
         sm.nObjMp = f.nObjMp; sm.objmp_Xw += 3 * (long long)f.objmp0; sm.objmp_obj += f.objmp0;
         sm.nJoint = f.nJoint; sm.joint_kp += f.joint0; sm.joint_obj += f.joint0;
         sm.e_Xw += 3 * (long long)e0; sm.e_obs += 2 * (long long)e0; sm.e_level += e0; sm.e_chi2 += e0; sm.e_obj += e0; sm.e_out += e0; sm.e_tmp += e0;
@@ -234,9 +254,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 const int ok = sm.e_tmp[j];
                 if (!ok) continue;
                 const int kp = sm.joint_kp[j];
-                const short2 px = sm.area[ok - 1];
+                const int px = ok - 1;
                 sm.e_Xw[n * 3] = Xw[kp * 3]; sm.e_Xw[n * 3 + 1] = Xw[kp * 3 + 1]; sm.e_Xw[n * 3 + 2] = Xw[kp * 3 + 2];
-                sm.e_obs[n * 2] = (float)px.x; sm.e_obs[n * 2 + 1] = (float)px.y;
+                sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
                 sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.joint_obj[j]; sm.e_out[n] = 0;
                 n++;
             }
@@ -491,9 +511,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                     for (int m = 0; m < sm.nObjMp; m++) {
                         const int ok = sm.e_tmp[m];
                         if (!ok) continue;
-                        const short2 px = sm.area[ok - 1];
+                        const int px = ok - 1;
                         sm.e_Xw[n * 3] = sm.objmp_Xw[m * 3]; sm.e_Xw[n * 3 + 1] = sm.objmp_Xw[m * 3 + 1]; sm.e_Xw[n * 3 + 2] = sm.objmp_Xw[m * 3 + 2];
-                        sm.e_obs[n * 2] = (float)px.x; sm.e_obs[n * 2 + 1] = (float)px.y;
+                        sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
                         sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.objmp_obj[m]; sm.e_out[n] = 0;
                         n++;
                     }
@@ -552,11 +572,18 @@ __device__ __forceinline__ const uint8_t* mask_row(const uint8_t* masks, const u
     return (ptrs ? ptrs[o] : masks + (long long)o * H * pitch) + (long long)row * pitch;
 }
 
+// boundary pixel of the mask: == 255 and on the image border or next to a 4-neighbour that is not 255 (see mask_nearest)
+__device__ __forceinline__ bool mask_boundary(const uint8_t* m, int pitch, int x, int row, int H, int W) {
+    if (m[x] != 255) return false;
+    if (x == 0 || x == W - 1 || row == 0 || row == H - 1) return true;
+    return m[x - 1] != 255 || m[x + 1] != 255 || m[x - pitch] != 255 || m[x + pitch] != 255;
+}
+
 __global__ __launch_bounds__(64) void k_mask_rowcount(const uint8_t* masks, const uint8_t* const* ptrs, int H, int W, int pitch, int* rowcnt) {
     const int row = blockIdx.x, o = blockIdx.y, lane = threadIdx.x;
     const uint8_t* m = mask_row(masks, ptrs, o, H, pitch, row);
     int n = 0;
-    for (int x = lane; x < W; x += 64) n += (m[x] == 255);
+    for (int x = lane; x < W; x += 64) n += mask_boundary(m, pitch, x, row, H, W);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
     if (lane == 0) rowcnt[o * H + row] = n;
@@ -602,7 +629,7 @@ __global__ __launch_bounds__(64) void k_mask_fill(const uint8_t* masks, const ui
     int base = area_start[o] + rowstart[o * H + row];
     for (int x0 = 0; x0 < W; x0 += 64) {
         const int x = x0 + lane;
-        const bool f = x < W && m[x] == 255;
+        const bool f = x < W && mask_boundary(m, pitch, x, row, H, W);
         const unsigned long long bal = __ballot(f);
         if (f) area[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_short2((short)x, (short)row);
         base += __popcll(bal);
@@ -844,6 +871,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
     SemCtx& sm = c.sem;
     sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.masks = (const uint8_t*)h->masks.p; sm.mask_ptrs = nullptr; sm.H = sem->H; sm.W = sem->W; sm.pitch = sem->W;
     sm.nObjMp = sem->nObjMp; sm.objmp_Xw = (float*)h->objmp_Xw.p; sm.objmp_obj = (int*)h->objmp_obj.p;
     sm.nJoint = sem->nJoint; sm.joint_kp = (int*)h->joint_kp.p; sm.joint_obj = (int*)h->joint_obj.p; sm.kp_uv = (float*)h->kp_uv.p;
     sm.minX = sem->bounds[0]; sm.minY = sem->bounds[1]; sm.maxX = sem->bounds[2]; sm.maxY = sem->bounds[3]; sm.invSigma2_0 = sem->invSigma2_0;
@@ -901,6 +929,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
     SemCtx& sm = c.sem;
     memset(&sm, 0, sizeof(sm));
     sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.masks = nullptr; sm.mask_ptrs = d_mask_ptrs; sm.H = H; sm.W = W; sm.pitch = mask_pitch;
     sm.objmp_Xw = d_objmp_Xw; sm.objmp_obj = d_objmp_obj; sm.joint_kp = d_joint_kp; sm.joint_obj = d_joint_obj; sm.kp_uv = nullptr;
     sm.minX = bounds[0]; sm.minY = bounds[1]; sm.maxX = bounds[2]; sm.maxY = bounds[3]; sm.invSigma2_0 = invSigma2_0;
     sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p;

@@ -4,6 +4,7 @@
 // stage for all sequences through the operator table (slam_ops_hip.hip binds the HIP kernels).  No CPU fallback lives
 // here: oslam_slam_create() fails without a HIP device.  Never includes oracle/.
 #include <chrono>
+#include <map>
 #include <memory>
 
 #include "common.h"
@@ -114,11 +115,22 @@ struct Seq {
     std::vector<int> jMatch, jLocalIds;
     oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
     bool hasSL = false, hasLoc = false;
+    // object layer substitute (include/oslam_slam.h head comment): Object3Ds keyed by the caller's track id
+    struct Obj3D { int track = -1, updateCnt = 0; std::vector<int> mps; std::vector<uint8_t> member; };   // mvpMapPoints in insertion order + membership by point id
+    std::vector<Obj3D> obj3ds;
+    std::map<int, int> objOfTrack;
+    int64_t sem[8] = {0};
+    std::vector<uint8_t> jInMask;                       // object_kps output
+    std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
+    std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj;
+    oslam_job_pose2_t jPose2; bool hasPose2 = false;
+    const oslam_slam_objects_t* det = nullptr;           // this step's detections (NULL or n == 0: none)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
         map = Map();
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
         localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear();
+        obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
         resetRequested = false;
@@ -141,6 +153,7 @@ struct Ctx {
     std::vector<std::unique_ptr<Seq>> seq;
     std::unique_ptr<Pool> pool;
     double sec[16] = {0};
+    int mask_stride = 0, masks_on_device = 0;
 };
 
 }  // namespace oslam_drv
@@ -896,6 +909,111 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     return OSLAM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Object layer (include/oslam_slam.h head comment)
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::BuildObject2DsRGBD / BuildObject2DsStereo (src/Frame.cc:240-312, :314-386) from the keypoint test bits: detection i takes, in keypoint order, the
+// keypoints still in the pool whose window lies in its mask and whose depth is in (0, mThDepth]; they leave the pool even if the detection then
+// fails the "> 5 keypoints" test and builds no Object2D (the erase at :283 comes before the test at :291).
+static void build_object2ds(const Ctx& c, Seq& s) {
+    Frame& f = *s.cur;
+    const oslam_slam_objects_t& d = *s.det;
+    std::vector<uint8_t> taken(f.N, 0);
+    for (int i = 0; i < d.n; i++) {
+        Frame::Obj2D o;
+        o.det = i; o.track = d.track_id ? d.track_id[i] : -1;
+        for (int k = 0; k < f.N; k++) {
+            if (taken[k] || !((s.jInMask[k] >> i) & 1)) continue;
+            const float z = f.depth[k];
+            if (!(z > 0 && z <= c.thDepth)) continue;
+            taken[k] = 1;
+            o.kps.push_back(k);
+        }
+        if ((int)o.kps.size() > 5) {
+            const int idx = (int)f.objs.size();
+            for (int k : o.kps) f.objOfKp[k] = idx;
+            f.objs.push_back(std::move(o));
+            s.sem[5]++;
+        }
+    }
+}
+
+// Tracking::TrackObject substitute: mvpObject3Ds[o] = the Object3D of the detection's track id, if one exists
+static void track_objects(Seq& s) {
+    for (auto& o : s.cur->objs) {
+        o.obj3d = -1;
+        if (o.track < 0) continue;
+        auto it = s.objOfTrack.find(o.track);
+        if (it != s.objOfTrack.end()) o.obj3d = it->second;
+    }
+}
+
+// ObjectOptimizer::PoseOptimization2 inputs (src/ObjectOptimizer.cc:685-767, :978-990): masks and map points of the matched objects, M_joint candidates
+static void fill_pose2_job(Ctx& c, Seq& s, int si) {
+    Frame& f = *s.cur;
+    s.hasPose2 = false;
+    s.jMaskPtrs.clear(); s.jObjXw.clear(); s.jObjOf.clear(); s.jJointKp.clear(); s.jJointObj.clear();
+    int m = 0;
+    for (size_t io = 0; io < f.objs.size(); io++) {
+        const Frame::Obj2D& o = f.objs[io];
+        if (o.obj3d < 0) continue;
+        const Seq::Obj3D& ob = s.obj3ds[o.obj3d];
+        s.jMaskPtrs.push_back(s.det->masks[o.det]);
+        for (int p : ob.mps) {
+            const float* x = s.map.mps[p].pos;
+            s.jObjXw.push_back(x[0]); s.jObjXw.push_back(x[1]); s.jObjXw.push_back(x[2]);
+            s.jObjOf.push_back(m);
+        }
+        for (int k = 0; k < f.N; k++) {
+            const int p = f.mp[k];
+            if (p < 0 || p >= (int)ob.member.size() || !ob.member[p]) continue;
+            if (f.objOfKp[k] != (int)io) { s.jJointKp.push_back(k); s.jJointObj.push_back(m); }
+        }
+        m++;
+    }
+    if (m == 0) return;
+    oslam_job_pose2_t& j = s.jPose2;
+    j.base = s.jPose;
+    j.nObj = m; j.masks = s.jMaskPtrs.data(); j.mask_stride = c.mask_stride; j.on_device = c.masks_on_device;
+    j.nObjMp = (int)s.jObjOf.size(); j.objmp_Xw = s.jObjXw.data(); j.objmp_obj = s.jObjOf.data();
+    j.nJoint = (int)s.jJointKp.size(); j.joint_kp = s.jJointKp.data(); j.joint_obj = s.jJointObj.data();
+    j.n_semantic = 0;
+    s.hasPose2 = true;
+    (void)si;
+}
+
+// Tracking::UpdateCurrentObject (src/Tracking.cc:1079-1210) + Object3D::Update (src/ObjectTypes.cc:56-140), list logic only
+static void update_current_objects(Seq& s) {
+    Frame& f = *s.cur;
+    Map& m = s.map;
+    auto mark = [](Seq::Obj3D& ob, int p) { if ((int)ob.member.size() <= p) ob.member.resize(p + 1 + p / 2, 0); ob.member[p] = 1; };
+    for (auto& o : f.objs) {
+        if (o.obj3d >= 0) {
+            Seq::Obj3D& ob = s.obj3ds[o.obj3d];
+            ob.updateCnt++;
+            std::vector<int> cand;
+            for (int k : o.kps) {
+                const int p = f.mp[k];
+                if (p < 0 || m.mps[p].bad || f.outlier[k]) continue;
+                if (!(p < (int)ob.member.size() && ob.member[p])) cand.push_back(p);
+            }
+            for (int p : cand) { ob.mps.push_back(p); mark(ob, p); s.sem[4]++; }
+        } else {
+            std::vector<int> cand;
+            for (int k : o.kps) if (f.mp[k] >= 0) cand.push_back(f.mp[k]);
+            if ((int)cand.size() > 5) {   // MIN_OBJ3DMP_NUM (include/ObjectTypes.h:19)
+                Seq::Obj3D ob;
+                ob.track = o.track; ob.mps = cand;
+                for (int p : cand) mark(ob, p);
+                o.obj3d = (int)s.obj3ds.size();
+                if (o.track >= 0 && !s.objOfTrack.count(o.track)) s.objOfTrack[o.track] = o.obj3d;
+                s.obj3ds.push_back(std::move(ob));
+                s.sem[3]++; s.sem[4] += (int64_t)cand.size();
+            }
+        }
+    }
+}
+
 // Stage helpers of track_step (each runs for one sequence; the sequences of a batch are independent, so a stage is a parallel_for).
 static void stage_motion_model_prepare(Ctx& c, int i) {
     Seq& s = *c.seq[i];
@@ -1039,6 +1157,7 @@ static void stage_after_tracking(Ctx& c, int i) {
         }
         for (int k = 0; k < f.N; k++)
             if (f.mp[k] >= 0 && f.outlier[k]) f.mp[k] = -1;
+        if (!f.objs.empty()) update_current_objects(s);   // UpdateCurrentObject(true) (:537)
     } else {
         s.st[8]++;
         if (m.nKFsInMap <= 5) s.resetRequested = true;   // "Track lost soon after initialisation, reseting..." (:553-561): Track() returns here
@@ -1059,7 +1178,7 @@ static int run_pose_jobs(Ctx& c, const std::vector<int>& who) {
 // One lockstep step of Tracking::Track for all sequences
 // ------------------------------------------------------------------------------------------------------------------
 static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* right, int gray_stride, const float* const* depth, int depth_pitch,
-                      int on_device, const double* stamps, float* Tcw_out, int32_t* state_out) {
+                      int on_device, const double* stamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
     const int S = c.S;
     Timer tm;
     int rc;
@@ -1100,6 +1219,28 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             s.path = -1;   // initialised in this step: not tracked
         }
     });
+    // Frame::BuildObject2DsRGBD / BuildObject2DsStereo (src/Frame.cc:179, :119): part of the Frame constructor, whatever the tracking state
+    {
+        std::vector<oslam_job_object_kps_t> oj;
+        std::vector<int> ojw;
+        c.mask_stride = mask_stride; c.masks_on_device = on_device;
+        for (int i = 0; i < S; i++) {
+            Seq& s = *c.seq[i];
+            s.det = (objs && objs[i].n > 0) ? &objs[i] : nullptr;
+            if (!s.det) continue;
+            if (s.det->n > OSLAM_SLAM_MAX_OBJECTS || !s.det->masks) { oslam::set_error("track: sequence %d has %d detections (max %d) or no masks", i, s.det->n, OSLAM_SLAM_MAX_OBJECTS); return OSLAM_E_INVALID; }
+            if (!c.ops.object_kps || !c.ops.pose_opt2) { oslam::set_error("track: this operator table has no semantic operators"); return OSLAM_E_INVALID; }
+            s.jInMask.assign(s.cur->N + 1, 0);
+            oslam_job_object_kps_t j;
+            j.slot = i; j.cur = &s.cur->view; j.n_masks = s.det->n; j.masks = s.det->masks; j.mask_stride = mask_stride; j.on_device = on_device; j.in_mask = s.jInMask.data();
+            oj.push_back(j); ojw.push_back(i);
+        }
+        if (!oj.empty()) {
+            if ((rc = c.ops.object_kps(c.ops.ctx, (int)oj.size(), oj.data()))) return rc;
+            pool.parallel_for((int)ojw.size(), [&](int q) { build_object2ds(c, *c.seq[ojw[q]]); });
+        }
+        c.sec[0] += tm.lap();
+    }
     for (int i = 0; i < S; i++) if (c.seq[i]->state == ST_OK && c.seq[i]->path != -1) tracking.push_back(i);
     const int nT = (int)tracking.size();
     // ---------------- initial pose: motion model or reference keyframe ----------------
@@ -1205,10 +1346,29 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         Frame& f = *s.cur;
         for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.jLocalIds[e]].visible++;
         for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.jLocalIds[s.jMatch[k]];
-        fill_pose_job(c, s, ljw[q], s.jPose);   // ObjectOptimizer::PoseOptimization2 (:1022) without matched objects
+        fill_pose_job(c, s, ljw[q], s.jPose);
+        s.hasPose2 = false;
+        if (s.det && !f.objs.empty()) {   // TrackObject (:453) then ObjectOptimizer::PoseOptimization2 (:1022); without matched objects it is PoseOptimization
+            track_objects(s);
+            fill_pose2_job(c, s, ljw[q]);
+        }
     });
     c.sec[4] += tm.lap();
-    if ((rc = run_pose_jobs(c, ljw))) return rc;
+    {
+        std::vector<int> plain, sem;
+        for (int i : ljw) (c.seq[i]->hasPose2 ? sem : plain).push_back(i);
+        if ((rc = run_pose_jobs(c, plain))) return rc;
+        if (!sem.empty()) {
+            std::vector<oslam_job_pose2_t> pj(sem.size());
+            for (size_t q = 0; q < sem.size(); q++) pj[q] = c.seq[sem[q]]->jPose2;
+            if ((rc = c.ops.pose_opt2(c.ops.ctx, (int)pj.size(), pj.data()))) return rc;
+            for (size_t q = 0; q < sem.size(); q++) {
+                Seq& s = *c.seq[sem[q]];
+                s.jPose = pj[q].base;
+                s.sem[0] += pj[q].n_semantic; s.sem[1]++; s.sem[2] += pj[q].n_semantic > 0;
+            }
+        }
+    }
     c.sec[2] += tm.lap();
     pool.parallel_for((int)ljw.size(), [&](int q) { stage_after_local_pose(c, ljw[q]); });
     // ---------------- after tracking (:470-566) ----------------
@@ -1327,14 +1487,36 @@ int oslam_slam_track_rgbd(oslam_slam_t* h, const uint8_t* const* gray, int gray_
                           int on_device, const double* timestamps, float* Tcw_out, int32_t* state_out) {
     if (!h || !gray || !depth) { oslam::set_error("oslam_slam_track_rgbd: bad argument"); return OSLAM_E_INVALID; }
     if (h->c.stereo) { oslam::set_error("oslam_slam_track_rgbd on a STEREO handle"); return OSLAM_E_INVALID; }
-    return track_step(h->c, gray, nullptr, gray_stride, depth, depth_pitch, on_device, timestamps, Tcw_out, state_out);
+    return track_step(h->c, gray, nullptr, gray_stride, depth, depth_pitch, on_device, timestamps, nullptr, 0, Tcw_out, state_out);
+}
+
+int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
+                                  const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
+    if (!h || !gray || !depth) { oslam::set_error("oslam_slam_track_rgbd_objects: bad argument"); return OSLAM_E_INVALID; }
+    if (h->c.stereo) { oslam::set_error("oslam_slam_track_rgbd_objects on a STEREO handle"); return OSLAM_E_INVALID; }
+    if (objs && mask_stride < h->c.cfg.width) { oslam::set_error("oslam_slam_track_rgbd_objects: mask_stride < width"); return OSLAM_E_INVALID; }
+    return track_step(h->c, gray, nullptr, gray_stride, depth, depth_pitch, on_device, timestamps, objs, mask_stride, Tcw_out, state_out);
+}
+
+int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
+    if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_object_stats: bad argument"); return OSLAM_E_INVALID; }
+    memcpy(out, h->c.seq[seq]->sem, sizeof(h->c.seq[seq]->sem));
+    return OSLAM_OK;
 }
 
 int oslam_slam_track_stereo(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                             const double* timestamps, float* Tcw_out, int32_t* state_out) {
     if (!h || !left || !right) { oslam::set_error("oslam_slam_track_stereo: bad argument"); return OSLAM_E_INVALID; }
     if (!h->c.stereo || !h->c.ops.frames_stereo) { oslam::set_error("oslam_slam_track_stereo needs cfg.sensor = 1 (STEREO) and a stereo-capable operator table"); return OSLAM_E_INVALID; }
-    return track_step(h->c, left, right, gray_stride, nullptr, 0, on_device, timestamps, Tcw_out, state_out);
+    return track_step(h->c, left, right, gray_stride, nullptr, 0, on_device, timestamps, nullptr, 0, Tcw_out, state_out);
+}
+
+int oslam_slam_track_stereo_objects(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
+                                    const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
+    if (!h || !left || !right) { oslam::set_error("oslam_slam_track_stereo_objects: bad argument"); return OSLAM_E_INVALID; }
+    if (!h->c.stereo || !h->c.ops.frames_stereo) { oslam::set_error("oslam_slam_track_stereo_objects needs cfg.sensor = 1 (STEREO) and a stereo-capable operator table"); return OSLAM_E_INVALID; }
+    if (objs && mask_stride < h->c.cfg.width) { oslam::set_error("oslam_slam_track_stereo_objects: mask_stride < width"); return OSLAM_E_INVALID; }
+    return track_step(h->c, left, right, gray_stride, nullptr, 0, on_device, timestamps, objs, mask_stride, Tcw_out, state_out);
 }
 
 static void twc_rows(const M4& Tcw, float* o) {   // Rwc = Rcw.t(), twc = -Rwc*tcw (src/System.cc:423-424)

@@ -91,6 +91,10 @@ struct Frame {
     PoseM pose;
     int refKF = -1;
     oslam_slam_frame_t view;
+    // object layer (reference include/Frame.h:110-119): mvObject2Ds (detection index, caller's track id, mvFrameKpIndices), mvpObject3Ds, mvObjectKpIndices[k].first
+    struct Obj2D { int det = -1, track = -1, obj3d = -1; std::vector<int> kps; };
+    std::vector<Obj2D> objs;
+    std::vector<int> objOfKp;
     void alloc(int cap) {
         keys.resize(cap); keysUn.resize(cap); desc.resize((size_t)cap * 32); uRight.resize(cap); depth.resize(cap);
         mp.assign(cap, -1); outlier.assign(cap, 0);
@@ -101,6 +105,7 @@ struct Frame {
         std::fill(mp.begin(), mp.end(), -1);
         std::fill(outlier.begin(), outlier.end(), 0);
         bowNode.clear(); pose.valid = false; refKF = -1;
+        objs.clear(); objOfKp.assign(N, -1);
     }
 };
 

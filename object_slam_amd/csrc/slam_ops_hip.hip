@@ -43,6 +43,18 @@ struct HipOps {
     uint8_t* up_h = nullptr; uint8_t* up_d = nullptr; size_t up_cap = 0;
     uint8_t* dn_h = nullptr; size_t dn_cap = 0;
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
+    uint8_t* d_objbits = nullptr;                        // [S][cap] keypoint test bits (object_kps)
+    uint8_t* d_maskstage = nullptr; size_t mask_cap = 0;  // host masks of a stage, packed H x W
+    int ensure_masks(size_t bytes) {
+        if (bytes <= mask_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (d_maskstage) (void)hipFree(d_maskstage);
+        d_maskstage = nullptr; mask_cap = 0;
+        const size_t ncap = bytes + bytes / 2 + 4096;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&d_maskstage, ncap));
+        mask_cap = ncap;
+        return OSLAM_OK;
+    }
     oslam_drv::Pool* pool = nullptr;
     hipStream_t strm = nullptr;   // this handle's stream (non-blocking): several handles on one GPU, each driven by its own host thread, overlap
     // kernel-time groups (oslam_slam_kernel_times): HIP events on `strm` around the launches of a group, read after the stage's synchronisation
@@ -410,6 +422,138 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     return OSLAM_OK;
 }
 
+// host masks of a stage -> d_maskstage (rows packed to W), returns the device pointer of mask m in ptrs[m]; device masks are used where they are
+static int stage_masks(HipOps* o, int total, const std::vector<const uint8_t*>& src, int mask_stride, int on_device, std::vector<const uint8_t*>& ptrs, int& pitch) {
+    const size_t W = o->cfg.width, H = o->cfg.height;
+    ptrs.resize(total);
+    if (on_device) { for (int m = 0; m < total; m++) ptrs[m] = src[m]; pitch = mask_stride; return OSLAM_OK; }
+    pitch = (int)W;
+    OPS_CHECK(o->ensure_masks(W * H * (size_t)total));
+    for (int m = 0; m < total; m++) {
+        OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_maskstage + W * H * m, W, src[m], mask_stride, W, H, hipMemcpyHostToDevice, o->strm));
+        ptrs[m] = o->d_maskstage + W * H * m;
+    }
+    return OSLAM_OK;
+}
+
+// Frame::BuildObject2DsRGBD keypoint test for the frames still on the device (slot-major): one launch, one byte per keypoint back
+int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    const size_t S = o->S, cap = o->cap;
+    std::vector<const uint8_t*> src;
+    std::vector<int32_t> mask0(S, 0), nmask(S, 0);
+    for (int i = 0; i < n; i++) {
+        const oslam_job_object_kps_t& j = jobs[i];
+        if (j.slot < 0 || j.slot >= (int)S || j.n_masks < 0 || j.n_masks > OSLAM_SLAM_MAX_OBJECTS || j.on_device != jobs[0].on_device || j.mask_stride != jobs[0].mask_stride) {
+            oslam::set_error("object_kps: bad slot / mask count / mixed mask layouts"); return OSLAM_E_INVALID;
+        }
+        mask0[j.slot] = (int32_t)src.size(); nmask[j.slot] = j.n_masks;
+        for (int m = 0; m < j.n_masks; m++) src.push_back(j.masks[m]);
+    }
+    const int total = (int)src.size();
+    if (total == 0) { for (int i = 0; i < n; i++) memset(jobs[i].in_mask, 0, (size_t)jobs[i].cur->N); return OSLAM_OK; }
+    std::vector<const uint8_t*> ptrs;
+    int pitch = 0;
+    OPS_CHECK(stage_masks(o, total, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
+    Layout L;
+    const size_t oPtr = L.take(8 * (size_t)total), oM0 = L.take(4 * S), oNm = L.take(4 * S);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    memcpy(U + oPtr, ptrs.data(), 8 * (size_t)total); memcpy(U + oM0, mask0.data(), 4 * S); memcpy(U + oNm, nmask.data(), 4 * S);
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
+    uint8_t* Dv = o->up_d;
+    OPS_CHECK(oslam_frame_object_kp_test_batch_device(o->d_keysUn, (int)cap, o->d_cnt, (int)S, (const uint8_t* const*)(Dv + oPtr), (const int32_t*)(Dv + oM0),
+                                                      (const int32_t*)(Dv + oNm), o->cfg.height, o->cfg.width, pitch, o->d_objbits, o->strm));
+    OPS_CHECK(o->ensure_dn(cap * S));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, o->d_objbits, cap * S, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    for (int i = 0; i < n; i++) memcpy(jobs[i].in_mask, o->dn_h + cap * jobs[i].slot, (size_t)jobs[i].cur->N);
+    return OSLAM_OK;
+}
+
+// ObjectOptimizer::PoseOptimization2 for n frames in one launch (one workgroup per frame); the masks are read where they are (device) or staged (host)
+int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("pose_opt2: n > n_sequences"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap, B = n;
+    std::vector<oslam_sem_frame_t> fr(n);
+    std::vector<const uint8_t*> src;
+    int tObj = 0, tMp = 0, tJ = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_pose2_t& j = jobs[i];
+        if (j.base.N > (int)cap || j.nObj < 0 || j.nObj > OSLAM_SLAM_MAX_OBJECTS || j.on_device != jobs[0].on_device || j.mask_stride != jobs[0].mask_stride) {
+            oslam::set_error("pose_opt2: N > capacity / bad object count / mixed mask layouts"); return OSLAM_E_INVALID;
+        }
+        fr[i].nObj = j.nObj; fr[i].obj0 = tObj; fr[i].nObjMp = j.nObjMp; fr[i].objmp0 = tMp; fr[i].nJoint = j.nJoint; fr[i].joint0 = tJ;
+        for (int m = 0; m < j.nObj; m++) src.push_back(j.masks[m]);
+        tObj += j.nObj; tMp += j.nObjMp; tJ += j.nJoint;
+    }
+    std::vector<const uint8_t*> ptrs;
+    int pitch = o->cfg.width;
+    if (tObj) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
+    Layout L;
+    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B),
+                 oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
+                 oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    memcpy(U + oFr, fr.data(), sizeof(oslam_sem_frame_t) * B);
+    if (tObj) memcpy(U + oPtr, ptrs.data(), 8 * (size_t)tObj);
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_pose2_t& j2 = jobs[i];
+        const oslam_job_pose_t& j = j2.base;
+        const size_t N = j.N;
+        ((int32_t*)(U + oN))[i] = j.N;
+        memcpy(U + oT + 64 * i, j.Tcw_in, 64);
+        memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
+        memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
+        if (j2.nObjMp) { memcpy(U + oMx + 12 * (size_t)fr[i].objmp0, j2.objmp_Xw, 12 * (size_t)j2.nObjMp); memcpy(U + oMo + 4 * (size_t)fr[i].objmp0, j2.objmp_obj, 4 * (size_t)j2.nObjMp); }
+        if (j2.nJoint) { memcpy(U + oJk + 4 * (size_t)fr[i].joint0, j2.joint_kp, 4 * (size_t)j2.nJoint); memcpy(U + oJo + 4 * (size_t)fr[i].joint0, j2.joint_obj, 4 * (size_t)j2.nJoint); }
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
+    uint8_t* Dv = o->up_d;
+    o->t_begin();
+    OPS_CHECK(oslam_pose_optimize2_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), (const float*)(Dv + oT), (const float*)(Dv + oXw), (const float*)(Dv + oObs),
+                                                (const float*)(Dv + oInv), Dv + oHas, o->K5, (const oslam_sem_frame_t*)(Dv + oFr), tObj, (const uint8_t* const*)(Dv + oPtr),
+                                                o->cfg.height, o->cfg.width, pitch, tMp, (const float*)(Dv + oMx), (const int32_t*)(Dv + oMo), tJ, (const int32_t*)(Dv + oJk),
+                                                (const int32_t*)(Dv + oJo), o->bounds, o->invSigma2[0], o->strm));
+    o->t_end();
+    const float* d_T; const uint8_t* d_out; const int32_t* d_ni; const int32_t* d_stats; const int32_t* d_ns;
+    OPS_CHECK(oslam_poseopt_results_device(o->po, &d_T, &d_out, &d_ni, &d_stats));
+    OPS_CHECK(oslam_poseopt_semantic_results_device(o->po, &d_ns));
+    Layout R;
+    const size_t rT = R.take(64 * B), rO = R.take(cap * B), rN = R.take(4 * B), rS = R.take(8 * B), rNs = R.take(4 * B);
+    OPS_CHECK(o->ensure_dn(R.off));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rS, d_stats, 8 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNs, d_ns, 4 * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    if (o->timing) {
+        double flop = 0;
+        const int32_t* stt = (const int32_t*)(o->dn_h + rS);
+        for (int i = 0; i < n; i++) {
+            int ne = jobs[i].nObjMp + jobs[i].nJoint;   // upper bound of the semantic edges
+            for (int k = 0; k < jobs[i].base.N; k++) ne += jobs[i].base.has_mp[k] != 0;
+            flop += (double)ne * (700.0 * stt[2 * i] + 90.0 * stt[2 * i + 1]);
+        }
+        o->t_collect(1, 5, flop);
+    }
+    o->pool->parallel_for(n, [&](int i) {
+        oslam_job_pose_t& j = jobs[i].base;
+        memcpy(j.Tcw_out, o->dn_h + rT + 64 * i, 64);
+        memcpy(j.outlier, o->dn_h + rO + cap * i, (size_t)j.N);
+        j.n_inliers = ((const int32_t*)(o->dn_h + rN))[i];
+        jobs[i].n_semantic = ((const int32_t*)(o->dn_h + rNs))[i];
+    });
+    return OSLAM_OK;
+}
+
 // MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over the touched points of all sequences: one block up, two launches, one block down
 int h_mp_update(void* p, oslam_job_mp_update_t* j) {
     HipOps* o = (HipOps*)p;
@@ -578,7 +722,7 @@ void h_destroy(void* p) {
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
     if (o->dn_h) (void)hipHostFree(o->dn_h);
-    (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview);
+    (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
     if (o->tev1) (void)hipEventDestroy(o->tev1);
@@ -631,6 +775,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_keysUn, sizeof(oslam_keypoint_t) * o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_uRight, 4 * (size_t)o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_mvDepth, 4 * (size_t)o->cap * S);
+        if (e == hipSuccess) e = hipMalloc((void**)&o->d_objbits, (size_t)o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_status, 64);
         if (e == hipSuccess) e = hipMemset(o->d_status, 0, 64);
         if (e != hipSuccess) { oslam::set_error("slam ops: hipMalloc failed: %s", hipGetErrorString(e)); rc = OSLAM_E_HIP; }
@@ -641,6 +786,6 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames;
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
-    ops->kernel_times = h_kernel_times;
+    ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
     return OSLAM_OK;
 }

@@ -65,6 +65,24 @@ class _Inputs:
             return x.data_ptr()
         return self.seqs[b][key][tt]
 
+    @property
+    def has_masks(self):
+        return any(q.get("masks") is not None for q in self.seqs.values())
+
+    def objects(self, g, t):
+        """The frame's detections for slam.System.TrackRGBD: the three instance masks of the scene with their ground-truth identities."""
+        b, tt = self.base[g], t + self.off[g]
+        q = self.seqs[b]
+        if q.get("masks") is None:
+            return None
+        n = q["masks"].shape[1]
+        if self.on_device:
+            m = self.dev[b]["masks"]
+            masks = [m[tt, o].data_ptr() for o in range(n)]
+        else:
+            masks = [q["masks"][tt, o] for o in range(n)]
+        return dict(masks=masks, track_ids=q["track_ids"], labels=q.get("labels", [0] * n))
+
     def gt(self, g, n):
         b, o = self.base[g], self.off[g]
         T = self.seqs[b]["Twc"][o:o + n]
@@ -80,10 +98,10 @@ def _drive(system, wl, inp, seq_ids, t0, t1, poses_out=None):
             left = [inp.frame(g, t, "gray") for g in seq_ids]
             right = [inp.frame(g, t, "right") for g in seq_ids]
             T, _ = system.TrackStereo(left, right, stamps, on_device=inp.on_device, stride=inp.pitch)
-        elif inp.on_device:
-            T, _ = system.TrackRGBD_device([inp.frame(g, t, "gray") for g in seq_ids], inp.pitch, [inp.frame(g, t, "depth") for g in seq_ids], wl.width, stamps)
         else:
-            T, _ = system.TrackRGBD([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "depth") for g in seq_ids], stamps)
+            objs = [inp.objects(g, t) for g in seq_ids] if inp.has_masks else None
+            T, _ = system.TrackRGBD([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "depth") for g in seq_ids], stamps, objects=objs,
+                                    on_device=inp.on_device, gray_stride=inp.pitch, depth_pitch=wl.width, mask_stride=wl.width)
         if poses_out is not None:
             poses_out.append(T.copy())
 

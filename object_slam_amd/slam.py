@@ -22,7 +22,12 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "kernel_times")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "kernel_times")]
+
+
+class SlamObjects(C.Structure):
+    """oslam_slam_objects_t: the semantic detections of one frame."""
+    _fields_ = [("n", C.c_int32), ("masks", C.POINTER(C.c_void_p)), ("track_id", C.POINTER(C.c_int32)), ("label", C.POINTER(C.c_int32))]
 
 
 # reference Examples/RGB-D/TUM2.yaml (distortion left at zero: the synthetic streams are rendered without it)
@@ -76,8 +81,50 @@ class System:
         except Exception:   # interpreter shutdown: module globals may already be gone
             pass
 
-    def TrackRGBD(self, gray, depth, timestamps=None):
-        """gray: S uint8 arrays [H, W] (C-contiguous rows), depth: S float32 arrays [H, W] in metres."""
+    def _objects(self, objects, on_device):
+        """objects: per sequence None or dict(masks = list of uint8 [H,W] arrays (device addresses with on_device), track_ids, labels (optional)).
+        Returns (array of SlamObjects, mask stride in bytes, keep-alive list)."""
+        arr = (SlamObjects * self.S)()
+        keep, stride = [], 0
+        for i in range(self.S):
+            ob = objects[i] if objects is not None else None
+            n = 0 if ob is None else len(ob["masks"])
+            arr[i].n = n
+            if n == 0:
+                continue
+            mp = (C.c_void_p * n)()
+            for m in range(n):
+                if on_device:
+                    mp[m] = ob["masks"][m]
+                else:
+                    a = ob["masks"][m]
+                    assert a.dtype == np.uint8 and a.strides[1] == 1
+                    mp[m] = a.__array_interface__["data"][0]
+                    stride = a.strides[0]
+            tid = (C.c_int32 * n)(*[int(t) for t in ob["track_ids"]])
+            lab = (C.c_int32 * n)(*[int(t) for t in ob.get("labels", [0] * n)])
+            arr[i].masks, arr[i].track_id, arr[i].label = C.cast(mp, C.POINTER(C.c_void_p)), tid, lab
+            keep += [mp, tid, lab]
+        return arr, stride, keep
+
+    def TrackRGBD(self, gray, depth, timestamps=None, objects=None, on_device=False, gray_stride=None, depth_pitch=None, mask_stride=None):
+        """gray: S uint8 arrays [H, W] (C-contiguous rows), depth: S float32 arrays [H, W] in metres; with on_device=True both are lists of device
+        addresses with gray_stride (bytes) / depth_pitch (floats).  objects: the frames' semantic detections (see _objects) for
+        ObjectOptimizer::PoseOptimization2 in TrackLocalMap."""
+        if objects is not None:
+            for i in range(self.S):
+                self._gp[i] = gray[i] if on_device else gray[i].__array_interface__["data"][0]
+                self._dp[i] = depth[i] if on_device else depth[i].__array_interface__["data"][0]
+            ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+            arr, ms, keep = self._objects(objects, on_device)
+            gs = gray_stride if on_device else gray[0].strides[0]
+            dpp = depth_pitch if on_device else depth[0].strides[0] // 4
+            check(self.L.oslam_slam_track_rgbd_objects(self.h, self._gp, C.c_int(gs), self._dp, C.c_int(dpp), C.c_int(1 if on_device else 0),
+                                                       ptr(ts) if ts is not None else None, arr, C.c_int(mask_stride if on_device else (ms or self.cfg.width)),
+                                                       ptr(self.Tcw), ptr(self.state)))
+            return self.Tcw, self.state
+        if on_device:
+            return self.TrackRGBD_device(gray, gray_stride, depth, depth_pitch, timestamps)
         for i in range(self.S):
             g, d = gray[i], depth[i]
             assert g.dtype == np.uint8 and d.dtype == np.float32 and g.strides[1] == 1 and d.strides[1] == 4
@@ -140,7 +187,11 @@ class System:
         names = ("frames", "keyframes_created", "keyframes_in_map", "points_created", "points_in_map", "local_bas", "tracked_motion_model",
                  "tracked_reference_kf", "lost_frames", "points_fused", "points_triangulated", "keyframes_culled", "points_culled", "last_inliers",
                  "lba_edges", "map_violations")
-        return dict(zip(names, out.tolist()))
+        d = dict(zip(names, out.tolist()))
+        so = np.zeros(8, np.int64)
+        check(self.L.oslam_slam_object_stats(self.h, C.c_int(seq), ptr(so)))
+        d.update(zip(("semantic_edges", "semantic_frames", "semantic_frames_nonzero", "object3ds", "object_points", "object2ds"), so[:6].tolist()))
+        return d
 
     KT_GROUPS = ("frames", "pose_opt", "lba", "search")
 

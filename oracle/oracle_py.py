@@ -292,6 +292,20 @@ def pose_optimization2(p):
     return n, out.reshape(4, 4), outl[:N], nsem.value
 
 
+def object_kp_test(keysUn, masks):
+    """Oracle keypoint test of Frame::BuildObject2DsRGBD: bit o of out[k] = the 20x20 window around keysUn[k] lies inside mask o (masks [n,H,W] uint8)."""
+    keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
+    masks = np.ascontiguousarray(masks, np.uint8)
+    n, H, W = masks.shape
+    ptrs = (C.c_void_p * max(n, 1))(*[masks[i].ctypes.data for i in range(n)])
+    out = np.zeros(max(len(keysUn), 1), np.uint8)
+    L = lib()
+    L.oo_object_kp_test.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.oo_object_kp_test.restype = None
+    L.oo_object_kp_test(len(keysUn), _p(keysUn), n, ptrs, H, W, W, _p(out))
+    return out[:len(keysUn)]
+
+
 def fuse_search(keysUn, uRight, desc, bounds, queries, invLevelSigma2):
     keysUn = np.ascontiguousarray(keysUn, KP_DTYPE)
     N, M = len(keysUn), len(queries)

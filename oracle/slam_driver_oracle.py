@@ -312,6 +312,19 @@ class Frame:
         self.pose = Pose()
         self.mpReferenceKF = None
         self.bowNode = None
+        # object layer (reference include/Frame.h:110-119)
+        self.mvObject2Ds = []                      # Object2D: dict(mask, track_id, mvFrameKpIndices)
+        self.mvpObject3Ds = []                     # Object3D or None per Object2D
+        self.mvObjectKpIndices = [-1] * self.N     # .first of the reference's pair
+
+
+class Object3D:
+    """include/ObjectTypes.h:84-135, the members PoseOptimization2 reads: mvpMapPoints in insertion order."""
+
+    def __init__(self, mps, track_id):
+        self.mvpMapPoints = list(mps)
+        self.mTrackID = track_id
+        self.mUpdateCnt = 0
 
 
 class Slam:
@@ -358,6 +371,10 @@ class Slam:
         self.nKFsInMap = self.nMPsInMap = 0
         self.st = dict(frames=0, keyframes_created=0, points_created=0, local_bas=0, tracked_motion_model=0, tracked_reference_kf=0, lost_frames=0,
                        points_fused=0, points_triangulated=0, keyframes_culled=0, points_culled=0, last_inliers=0, lba_edges=0, points_culled_total=0)
+        # object layer substitute (include/oslam_slam.h head comment): Object3Ds of the map keyed by the caller's track id
+        self.mspObject3Ds = []
+        self.objOfTrack = {}
+        self.sem = dict(semantic_edges=0, semantic_frames=0, semantic_frames_nonzero=0, object3ds=0, object_points=0, object2ds=0)
 
     def Reset(self):
         """Tracking::Reset (src/Tracking.cc:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; Frame / KeyFrame ids restart at 0."""
@@ -369,6 +386,94 @@ class Slam:
         self.keyframes = []
         self.nKFsInMap = self.nMPsInMap = 0
         self.mbReset = False
+        self.mspObject3Ds, self.objOfTrack = [], {}          # Map::clear()
+
+    # ------------------------------------------------------------------ object layer
+    def BuildObject2Ds(self, F, objects):
+        """Frame::BuildObject2DsRGBD / BuildObject2DsStereo (src/Frame.cc:240-312, :314-386)."""
+        masks = np.stack(objects["masks"])
+        bits = O.object_kp_test(F.mvKeysUn, masks)
+        pool = list(range(F.N))                                  # vIndex_Kp
+        for i in range(len(masks)):
+            vFrameKpIndices, rest = [], []
+            for k in pool:
+                z = F.mvDepth[k]
+                if (bits[k] >> i) & 1 and z > 0 and z <= self.thDepth:
+                    vFrameKpIndices.append(k)                    # erased from the pool whatever happens next (:283)
+                else:
+                    rest.append(k)
+            pool = rest
+            if len(vFrameKpIndices) > 5:
+                idx = len(F.mvObject2Ds)
+                for k in vFrameKpIndices:
+                    F.mvObjectKpIndices[k] = idx
+                F.mvObject2Ds.append(dict(mask=masks[i], track_id=int(objects["track_ids"][i]), mvFrameKpIndices=vFrameKpIndices))
+                F.mvpObject3Ds.append(None)
+                self.sem["object2ds"] += 1
+
+    def TrackObject(self, F):
+        """Tracking::TrackObject substitute: the Object3D of the detection's track id."""
+        for i, o2 in enumerate(F.mvObject2Ds):
+            F.mvpObject3Ds[i] = self.objOfTrack.get(o2["track_id"]) if o2["track_id"] >= 0 else None
+
+    def _pose_optimization2(self, F):
+        """ObjectOptimizer::PoseOptimization2 (src/ObjectOptimizer.cc:624-1240); returns None when no Object2D has a matched Object3D."""
+        matched = [i for i, o3 in enumerate(F.mvpObject3Ds) if o3 is not None]
+        if not matched:
+            return None
+        N = F.N
+        has = np.array([p is not None for p in F.mvpMapPoints], np.uint8)
+        Xw = np.zeros((N, 3), f32)
+        for i, p in enumerate(F.mvpMapPoints):
+            if p is not None:
+                Xw[i] = p.mWorldPos
+        obs = np.stack([F.mvKeysUn["x"], F.mvKeysUn["y"], F.mvuRight], 1).astype(f32)
+        inv = self.invSigma2[F.mvKeysUn["octave"]].astype(f32)
+        objmp_Xw, objmp_obj, joint_kp, joint_obj = [], [], [], []
+        for m, idx_obj in enumerate(matched):
+            o3 = F.mvpObject3Ds[idx_obj]
+            ids = set(id(p) for p in o3.mvpMapPoints)
+            for p in o3.mvpMapPoints:
+                objmp_Xw.append(p.mWorldPos)
+                objmp_obj.append(m)
+            for idx_mp, p in enumerate(F.mvpMapPoints):
+                if p is not None and id(p) in ids and F.mvObjectKpIndices[idx_mp] != idx_obj:
+                    joint_kp.append(idx_mp)
+                    joint_obj.append(m)
+        q = dict(Tcw=F.pose.Tcw, Xw=Xw, obs=obs, invSigma2=inv, has_mp=has, K=self.K5, masks=np.stack([F.mvObject2Ds[i]["mask"] for i in matched]),
+                 objmp_Xw=np.array(objmp_Xw, f32).reshape(-1, 3), objmp_obj=np.array(objmp_obj, np.int32), joint_kp=np.array(joint_kp, np.int32),
+                 joint_obj=np.array(joint_obj, np.int32), kp_uv=np.ascontiguousarray(obs[:, :2]), bounds=np.array(self.bounds, f32), invSigma2_0=self.invSigma2[0])
+        n, T, outl, nsem = O.pose_optimization2(q)
+        self.sem["semantic_edges"] += nsem
+        self.sem["semantic_frames"] += 1
+        self.sem["semantic_frames_nonzero"] += nsem > 0
+        return np.array(T, f32), outl
+
+    def UpdateCurrentObject(self, F):
+        """Tracking::UpdateCurrentObject (src/Tracking.cc:1079-1210) + Object3D::Update (src/ObjectTypes.cc:56-140), list logic only."""
+        for i, o2 in enumerate(F.mvObject2Ds):
+            o3 = F.mvpObject3Ds[i]
+            if o3 is not None:
+                o3.mUpdateCnt += 1
+                cand = []
+                for k in o2["mvFrameKpIndices"]:
+                    p = F.mvpMapPoints[k]
+                    if p is None or p.mbBad or F.mvbOutlier[k]:
+                        continue
+                    if not any(q is p for q in o3.mvpMapPoints):
+                        cand.append(p)
+                o3.mvpMapPoints += cand
+                self.sem["object_points"] += len(cand)
+            else:
+                cand = [F.mvpMapPoints[k] for k in o2["mvFrameKpIndices"] if F.mvpMapPoints[k] is not None]
+                if len(cand) > 5:                                # MIN_OBJ3DMP_NUM
+                    o3 = Object3D(cand, o2["track_id"])
+                    F.mvpObject3Ds[i] = o3
+                    self.mspObject3Ds.append(o3)
+                    if o2["track_id"] >= 0 and o2["track_id"] not in self.objOfTrack:
+                        self.objOfTrack[o2["track_id"]] = o3
+                    self.sem["object3ds"] += 1
+                    self.sem["object_points"] += len(cand)
 
     # ------------------------------------------------------------------ operators
     def _compute_bow(self, obj):
@@ -609,7 +714,8 @@ class Slam:
                 for k in range(F.N):
                     if km[k] >= 0:
                         F.mvpMapPoints[k] = cand[km[k]]
-        T, outl = self._pose_optimization(F)
+        r2 = self._pose_optimization2(F) if F.mvObject2Ds else None        # ObjectOptimizer::PoseOptimization2 (:1022)
+        T, outl = r2 if r2 is not None else self._pose_optimization(F)
         F.pose.set_frame(T)
         self.mnMatchesInliers = 0
         for k, p in enumerate(F.mvpMapPoints):
@@ -647,11 +753,13 @@ class Slam:
         c2 = (f32(self.mnMatchesInliers) < f32(nRefMatches) * thRef or close) and self.mnMatchesInliers > 15
         return (c1a or c1b or c1c) and c2
 
-    def Track(self, images, stamp):
-        """System::TrackRGBD / TrackStereo for one frame.  Returns (Tcw or None, state)."""
+    def Track(self, images, stamp, objects=None):
+        """System::TrackRGBD / TrackStereo for one frame.  objects: dict(masks = list of uint8 [H,W], track_ids) or None.  Returns (Tcw or None, state)."""
         if self.mbReset:                                             # System::TrackRGBD: if(mbReset) mpTracker->Reset() (src/System.cc:262-266)
             self.Reset()
         F = self._make_frame(images, stamp)
+        if objects is not None and len(objects["masks"]) > 0:
+            self.BuildObject2Ds(F, objects)
         self.st["frames"] += 1
         created = []
         if self.mState == NOT_INITIALIZED:
@@ -684,6 +792,7 @@ class Slam:
                     self.st["tracked_reference_kf"] += ok
             F.mpReferenceKF = self.mpReferenceKF
             if ok:
+                self.TrackObject(F)                                     # :453
                 ok = self.TrackLocalMap(F)
             self.mState = OK if ok else LOST
             if ok:
@@ -702,6 +811,8 @@ class Slam:
                 for k in range(F.N):
                     if F.mvpMapPoints[k] is not None and F.mvbOutlier[k]:
                         F.mvpMapPoints[k] = None
+                if F.mvObject2Ds:
+                    self.UpdateCurrentObject(F)                         # :537
             else:
                 self.st["lost_frames"] += 1
                 if self.nKFsInMap <= 5:                                 # :553-561: mpSystem->Reset(); return
@@ -1029,4 +1140,5 @@ class Slam:
         s = dict(self.st)
         s["keyframes_in_map"], s["points_in_map"] = self.nKFsInMap, self.nMPsInMap
         del s["points_culled_total"]
+        s.update(self.sem)
         return s

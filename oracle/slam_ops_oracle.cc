@@ -2,6 +2,7 @@
 // Operator table of the batch-of-sequences driver (include/oslam_slam.h, oslam_slam_ops_t) implemented with the CPU
 // restatement: tests run the product's driver (object_slam_amd/csrc/slam_driver.hip) once over the HIP operators and once
 // over these and compare the trajectories / maps.  The product never links this file.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -28,6 +29,8 @@ void oo_project_last_frame(int, const float*, const uint8_t*, const KeyPoint*, c
 void oo_is_in_frustum(int, const float*, const float*, const float*, const float*, const uint8_t*, const uint8_t*, const float*, const float*,
                       const float*, float, float, const float*, int, float, ProjQuery*);
 int oo_pose_optimization(int, const float*, const float*, const float*, const float*, const uint8_t*, const float*, float*, uint8_t*, int*);
+int oo_pose_optimization2(int, const float*, const float*, const float*, const float*, const uint8_t*, const float*, int, int, int, const uint8_t*, int, const float*,
+                          const int32_t*, int, const int32_t*, const int32_t*, const float*, const float*, float, float*, uint8_t*, int*);
 void oo_local_bundle_adjustment(int, const float*, const uint8_t*, int, const float*, int, const int32_t*, const int32_t*, const float*, const float*,
                                 const float*, const int*, float*, float*, uint8_t*, int*);
 int oo_distinctive_descriptor(int, const uint8_t*);
@@ -142,6 +145,55 @@ int o_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     return 0;
 }
 
+// Frame::BuildObject2DsRGBD keypoint test (reference src/Frame.cc:262-272): semantic_flag stays true iff every mask pixel
+// mask.at<uchar>(kp.pt.y + row, kp.pt.x + col), row / col in [-10, 10), equals 255 (float sum truncated to int by the call).  A pixel outside the image
+// fails the test (normalisation: the reference reads out of bounds there).
+extern "C" void oo_object_kp_test(int N, const oslam_keypoint_t* keysUn, int n_masks, const uint8_t* const* masks, int H, int W, int stride, uint8_t* in_mask) {
+    for (int k = 0; k < N; k++) {
+        uint8_t bits = 0;
+        for (int o = 0; o < n_masks; o++) {
+            bool flag = true;
+            for (int row = -10; row < 10; row++)
+                for (int col = -10; col < 10; col++) {
+                    const int y = (int)(keysUn[k].y + row), x = (int)(keysUn[k].x + col);
+                    if (y < 0 || y >= H || x < 0 || x >= W || masks[o][(size_t)y * stride + x] != 255) flag = false;
+                }
+            if (flag) bits |= (uint8_t)(1u << o);
+        }
+        in_mask[k] = bits;
+    }
+}
+
+int o_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    for (int i = 0; i < n; i++) {
+        oslam_job_object_kps_t& j = jobs[i];
+        if (j.on_device) return -1;
+        oo_object_kp_test(j.cur->N, j.cur->keysUn, j.n_masks, j.masks, o->cfg.height, o->cfg.width, j.mask_stride, j.in_mask);
+    }
+    return 0;
+}
+
+int o_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
+    OCtx* o = (OCtx*)p;
+    const int H = o->cfg.height, W = o->cfg.width;
+    for (int i = 0; i < n; i++) {
+        oslam_job_pose2_t& j = jobs[i];
+        if (j.on_device) return -1;
+        std::vector<uint8_t> masks((size_t)std::max(j.nObj, 1) * H * W);
+        for (int m = 0; m < j.nObj; m++)
+            for (int r = 0; r < H; r++) memcpy(&masks[((size_t)m * H + r) * W], j.masks[m] + (size_t)r * j.mask_stride, W);
+        std::vector<float> kp_uv((size_t)std::max(j.base.N, 1) * 2);
+        for (int k = 0; k < j.base.N; k++) { kp_uv[2 * k] = j.base.obs[3 * k]; kp_uv[2 * k + 1] = j.base.obs[3 * k + 1]; }   // mvKeysUn[k].pt
+        int nsem = 0;
+        j.base.n_inliers = oo_pose_optimization2(j.base.N, j.base.Tcw_in, j.base.Xw, j.base.obs, j.base.invSigma2, j.base.has_mp, o->K5, j.nObj, H, W, masks.data(),
+                                                 j.nObjMp, j.objmp_Xw, j.objmp_obj, j.nJoint, j.joint_kp, j.joint_obj, kp_uv.data(), o->bounds, o->invSigma2[0],
+                                                 j.base.Tcw_out, j.base.outlier, &nsem);
+        j.n_semantic = nsem;
+    }
+    return 0;
+}
+
 int o_mp_update(void* p, oslam_job_mp_update_t* j) {
     OCtx* o = (OCtx*)p;
     for (int i = 0; i < j->P; i++) {
@@ -240,5 +292,6 @@ extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t
     ops->max_keypoints = o_max_keypoints; ops->scale_tables = o_scale_tables; ops->image_bounds = o_image_bounds; ops->frames_rgbd = o_frames;
     ops->search_last = o_search_last; ops->search_local = o_search_local; ops->pose_opt = o_pose_opt; ops->mp_update = o_mp_update; ops->lba = o_lba;
     ops->fuse = o_fuse; ops->bow = o_bow; ops->triangulate = o_triangulate; ops->destroy = o_destroy; ops->frames_stereo = o_frames_stereo;
+    ops->object_kps = o_object_kps; ops->pose_opt2 = o_pose_opt2;
     return 0;
 }

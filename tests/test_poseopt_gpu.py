@@ -120,3 +120,66 @@ def test_pose_optimization2_semantic_matches_oracle(oracle, seed):
     n1, T1, outl1, ns1 = po.PoseOptimization2(q)
     assert ns1 == 0 and n1 == n0 and np.array_equal(T1, T0)
     po.close()
+
+
+def test_pose_optimization2_batch_matches_oracle(oracle):
+    """Batch form of ObjectOptimizer::PoseOptimization2 (the driver's TrackLocalMap stage): frames with different object counts, one frame without
+    objects and one with fewer than 3 correspondences in the same launch, masks read through a pointer table."""
+    import ctypes as C
+
+    import torch
+
+    from object_slam_amd import synth
+    from object_slam_amd._lib import check, lib
+    L = lib()
+    probs = [synth.make_semantic_problem(40 + i, N=600 + 50 * i, n_obj=(3, 1, 2, 0, 2)[i]) if (3, 1, 2, 0, 2)[i] else dict(synth.make_pose_problem(44, N=700), masks=np.zeros((0, 480, 640), np.uint8),
+             objmp_Xw=np.zeros((0, 3), np.float32), objmp_obj=np.zeros(0, np.int32), joint_kp=np.zeros(0, np.int32), joint_obj=np.zeros(0, np.int32),
+             bounds=np.array([0, 0, 640, 480], np.float32), invSigma2_0=np.float32(1.0)) for i in range(5)]
+    probs[4]["has_mp"][:] = 0
+    probs[4]["has_mp"][:2] = 1            # < 3 correspondences: pose untouched, nSemNum 0
+    B, cap = len(probs), 1024
+    h = C.c_void_p()
+    check(L.oslam_poseopt_create(C.byref(h), B, cap, 0))
+    Tcw = np.stack([p["Tcw"] for p in probs]).astype(np.float32)
+    n = np.array([len(p["Xw"]) for p in probs], np.int32)
+    Xw = np.zeros((B, cap, 3), np.float32); obs = np.zeros((B, cap, 3), np.float32); inv = np.zeros((B, cap), np.float32); has = np.zeros((B, cap), np.uint8)
+    fr = np.zeros((B, 6), np.int32)
+    masks, oXw, oObj, jk, jo = [], [], [], [], []
+    for i, p in enumerate(probs):
+        N = n[i]
+        Xw[i, :N], obs[i, :N], inv[i, :N], has[i, :N] = p["Xw"], p["obs"], p["invSigma2"], p["has_mp"]
+        fr[i] = (len(p["masks"]), len(masks), len(p["objmp_obj"]), sum(len(x) for x in oObj), len(p["joint_kp"]), sum(len(x) for x in jk))
+        masks += [torch.from_numpy(m.copy()).cuda() for m in p["masks"]]
+        oXw.append(p["objmp_Xw"]); oObj.append(p["objmp_obj"]); jk.append(p["joint_kp"]); jo.append(p["joint_obj"])
+    cat = lambda xs, dt, shp: torch.from_numpy(np.concatenate(xs).astype(dt).reshape(shp)).cuda() if sum(len(x) for x in xs) else torch.zeros(1, dtype=torch.float32).cuda()
+    t = lambda a: torch.from_numpy(a).cuda()
+    d = dict(T=t(Tcw), n=t(n), Xw=t(Xw), obs=t(obs), inv=t(inv), has=t(has), fr=t(fr), ptr=t(np.array([m.data_ptr() for m in masks], np.int64)),
+             oXw=cat(oXw, np.float32, (-1, 3)), oObj=cat(oObj, np.int32, (-1,)), jk=cat(jk, np.int32, (-1,)), jo=cat(jo, np.int32, (-1,)))
+    K5 = np.asarray(probs[0]["K"], np.float32)
+    bounds = np.array([0, 0, 640, 480], np.float32)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    check(L.oslam_pose_optimize2_batch_device(h, B, cap, vp(d["n"]), vp(d["T"]), vp(d["Xw"]), vp(d["obs"]), vp(d["inv"]), vp(d["has"]), C.c_void_p(K5.ctypes.data),
+                                              vp(d["fr"]), len(masks), vp(d["ptr"]), 480, 640, 640, int(sum(len(x) for x in oObj)), vp(d["oXw"]), vp(d["oObj"]),
+                                              int(sum(len(x) for x in jk)), vp(d["jk"]), vp(d["jo"]), C.c_void_p(bounds.ctypes.data), C.c_float(1.0), None))
+    torch.cuda.synchronize()
+    pT, pO, pN, pS = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    check(L.oslam_poseopt_results_device(h, C.byref(pT), C.byref(pO), C.byref(pN), None))
+    check(L.oslam_poseopt_semantic_results_device(h, C.byref(pS)))
+    import ctypes
+    def fetch(ptr_, nbytes, dt):
+        out = np.zeros(nbytes // np.dtype(dt).itemsize, dt)
+        check(L.oslam_memcpy_from_device(C.c_void_p(out.ctypes.data), ptr_, C.c_size_t(nbytes)))
+        return out
+    To = fetch(pT, B * 64, np.float32).reshape(B, 4, 4); outl = fetch(pO, B * cap, np.uint8).reshape(B, cap); ninl = fetch(pN, B * 4, np.int32); nsem = fetch(pS, B * 4, np.int32)
+    for i, p in enumerate(probs):
+        if len(p["masks"]):
+            q = dict(p, kp_uv=p["obs"][:, :2].copy())
+            on, oT, oo, os_ = oracle.pose_optimization2(q)
+        else:
+            on, oT, oo, _ = oracle.pose_optimization(p["Tcw"], p["Xw"], p["obs"], p["invSigma2"], p["has_mp"], p["K"])
+            os_ = 0
+        assert ninl[i] == on and nsem[i] == os_, (i, ninl[i], on, nsem[i], os_)
+        assert np.array_equal(outl[i, :n[i]], oo), i
+        assert np.abs(To[i] - oT).max() < 1e-4 * max(1.0, np.abs(oT).max()), i
+    assert nsem[0] > 0 and nsem[2] > 0 and nsem[3] == 0 and nsem[4] == 0 and ninl[4] == 0
+    L.oslam_poseopt_destroy(h)

@@ -205,3 +205,34 @@ def test_stereo_driver_against_independent_restatement(oracle):
         a, b = sysm.stats(0), ref.stats()
         assert all(a[k] == b[k] for k in b), (t, a, b)
     assert sysm.stats(0)["keyframes_created"] >= 2
+
+
+def test_semantic_tracking_against_independent_restatement(oracle):
+    """BASELINE.json configs[2] shape: S1 scene with three box objects and their instance masks.  Frame::BuildObject2DsRGBD, the Object3D lists and
+    ObjectOptimizer::PoseOptimization2 in TrackLocalMap (reference src/Tracking.cc:1022) — C++ driver against the Python restatement, and against a
+    run without masks (the semantic edges must change the trajectory)."""
+    from oracle import slam_driver_oracle as R
+    from slam_common import make_scene_streams
+    n = 16
+    q = make_scene_streams(1, n)[0]
+    cfg = slam.make_config(W, H, 1)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
+    plain = slam.System(slam.make_config(W, H, 1), oracle_ops(cfg))
+    diff = 0.0
+    for t in range(n):
+        objs = dict(masks=[q["masks"][t, o] for o in range(3)], track_ids=q["track_ids"])
+        T, st = sysm.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0], objects=[objs])
+        Tr, sr = ref.Track((q["gray"][t], q["depth"][t]), t / 30.0, objects=objs)
+        Tp, _ = plain.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0])
+        assert int(st[0]) == sr == slam.OK, t
+        assert np.array_equal(T[0], Tr), (t, np.abs(T[0] - Tr).max())
+        a, b = sysm.stats(0), ref.stats()
+        assert all(a[k] == b[k] for k in b), (t, a, b)
+        diff = max(diff, float(np.abs(T[0] - Tp[0]).max()))
+    a = sysm.stats(0)
+    # frames 0 (initialisation) and 1 (no Object3D yet) carry no semantic edges; every later tracked frame does
+    assert a["object3ds"] == 3 and a["semantic_frames"] == n - 2 and a["semantic_frames_nonzero"] == n - 2 and a["semantic_edges"] > 100 * (n - 2), a
+    assert a["object2ds"] == 3 * n
+    assert diff > 1e-5, diff
+    assert plain.stats(0)["semantic_edges"] == 0

@@ -177,3 +177,45 @@ def test_hip_stereo_driver_matches_oracle_driver_on_street_scene(oracle):
         assert a == b, (s, a, b)
         assert a["map_violations"] == 0 and a["keyframes_created"] >= 2
     assert np.abs(ph - po).max() < 6e-3, np.abs(ph - po).max()      # 1e-4 relative on a scene of up to 60 m
+
+
+def _semantic_run(system, q, n, on_device=False):
+    import torch
+    poses = []
+    for t in range(n):
+        if on_device:
+            g = torch.from_numpy(q["gray"][t]).cuda(); d = torch.from_numpy(q["depth"][t]).cuda(); m = torch.from_numpy(q["masks"][t]).cuda()
+            torch.cuda.synchronize()
+            objs = [dict(masks=[m[o].data_ptr() for o in range(3)], track_ids=q["track_ids"])]
+            T, st = system.TrackRGBD([g.data_ptr()], [d.data_ptr()], [t / 30.0], objects=objs, on_device=True, gray_stride=W, depth_pitch=W, mask_stride=W)
+        else:
+            objs = [dict(masks=[q["masks"][t, o] for o in range(3)], track_ids=q["track_ids"])]
+            T, st = system.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0], objects=objs)
+        assert st[0] == slam.OK, t
+        poses.append(T[0].copy())
+    return np.array(poses)
+
+
+def test_hip_semantic_tracking_matches_oracle_driver(oracle):
+    """BASELINE.json configs[2]: instance masks in, Frame::BuildObject2DsRGBD + ObjectOptimizer::PoseOptimization2 inside TrackLocalMap (reference
+    src/Tracking.cc:1022).  HIP operator table (k_object_kp_test, k_pose_optimize<true> batch form) against the CPU oracle's table: identical object
+    bookkeeping and nSemNum totals, poses within the optimiser tolerance; masks on the host and resident in HBM give the same result; the semantic
+    edges change the trajectory."""
+    from slam_common import make_scene_streams
+    n = 24
+    q = make_scene_streams(1, n)[0]
+    hip = slam.System(slam.make_config(W, H, 1))
+    ph = _semantic_run(hip, q, n)
+    cfg_o = slam.make_config(W, H, 1)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po = _semantic_run(ora, q, n)
+    a, b = hip.stats(0), ora.stats(0)
+    assert a == b, (a, b)
+    assert a["semantic_frames"] == n - 2 and a["semantic_frames_nonzero"] == n - 2 and a["object3ds"] == 3 and a["semantic_edges"] > 100 * (n - 2), a
+    assert np.abs(ph - po).max() < 4e-4, np.abs(ph - po).max()
+    dev = slam.System(slam.make_config(W, H, 1))
+    pd = _semantic_run(dev, q, n, on_device=True)
+    assert np.array_equal(pd, ph) and dev.stats(0) == a
+    plain = slam.System(slam.make_config(W, H, 1))
+    pp = np.array([plain.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0])[0][0].copy() for t in range(n)])
+    assert np.abs(pp - ph).max() > 1e-5
