@@ -594,8 +594,9 @@ constexpr int kWPt = 128;   // threads per block of the per-point kernels
 
 __device__ __forceinline__ double* w_X(const LbaProblem& pr, int which) { return which ? pr.Xb : pr.Xa; }
 
-__global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const int tid = threadIdx.x;
     LbaCtrl* ct = w.ct;
     if (tid == 0) {
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, LbaWide
 
 // state arrays of a fresh problem (grid-wide; k_w_init's single block only sets the control block and the poses)
 __global__ __launch_bounds__(256) void k_w_init_arrays(const LbaProblem* probs) {
-    const LbaProblem& pr = probs[0];
+    const LbaProblem& pr = probs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < pr.P * 3) pr.Xa[i] = (double)pr.points[i];
     if (i < pr.E) { pr.level[i] = 0; pr.chi2[i] = 0; pr.erase[i] = 0; }
@@ -650,10 +651,10 @@ constexpr int kLinThreads = 4 * kWPt;   // 512
 
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w);
 __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
-__device__ __forceinline__ bool last_block_done(int* ticket);
 
-__global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     if (ct->done || !ct->need_lin) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
@@ -734,14 +735,10 @@ __global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, 
             w.partF[blockIdx.x] = a;
             w.partM[blockIdx.x] = bm;
         }
-        if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
         return;
     }
     const int a = (int)blockIdx.x - w.nblk_pt;
-    if (a >= pr.K || w.blk[a] < 0) {   // fixed keyframe: nothing to accumulate, but the block still reports in
-        if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
-        return;
-    }
+    if (a >= pr.K || w.blk[a] < 0) return;   // fixed keyframe, or a padding block of a batched launch
     const SE3 Ta = w.T[ct->cur * pr.K + a];
     const double* Ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
     double acc[27];
@@ -795,25 +792,11 @@ __global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, 
         pr.Hpp[a * 36 + tid] = sAcc[0][lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
     }
     if (tid < 6) pr.bp[a * 6 + tid] = sAcc[0][21 + tid];
-    if (last_block_done(&w.ct->ticket[0]) && tid == 0) w_ctrlA(pr, w);
 }
 
-// after linearisation: F0 and (first iteration) lambda = 1e-5 * max diag
-// true in exactly one block per launch: the one whose ticket is the last (all other blocks' global writes are visible)
-__device__ __forceinline__ bool last_block_done(int* ticket) {
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(ticket, 1);
-        s_last = (t == (int)gridDim.x - 1);
-        if (s_last) { *ticket = 0; __threadfence(); }
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
-// LM control after the linearisation (one thread: the last block of k_w_lin): chi2 of the current state, lambda init
+// LM control after the linearisation (k_w_ctrlA, one thread per window): chi2 of the current state, lambda init.
+// The control steps are their own tiny launches: a kernel boundary makes every block's partial sums visible, whereas a "last block to
+// finish" scheme needs an agent-scope release per block (an L2 write-back each): 185 us per k_w_lin launch of 28 windows x 20 blocks.
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
     if (ct->gate) { ct->gate = 0; }
@@ -834,8 +817,9 @@ __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
 
 // W_e = B_e (Hll_p + lambda I)^-1 for every active edge of a free keyframe: one inversion per edge instead of one per
 // (block, edge) pair inside the Schur kernel
-__global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -862,8 +846,9 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, LbaWid
 // Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
 // wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
 // rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
-__global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int nfree = ct->nfree, n = ct->n, ld = n + 1;
@@ -931,11 +916,12 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, LbaWide
 constexpr int kCholLdsN = 132;   // 132*133*8 = 140 448 B
 
 template <bool LDS_RESIDENT>
-__global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWide w) {
+__global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, const LbaWide* ws) {
     // dense solve of the reduced system: fused multiply-adds allowed here (the reference factors this matrix with a
     // different algorithm anyway, Eigen LDLT inside g2o; the rest of the library stays -ffp-contract=off)
 #pragma clang fp contract(fast)
-    const LbaProblem& pr = probs[0];
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1132,8 +1118,9 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, LbaWid
 }
 
 // landmark back-substitution, trial state, computeScale partials
-__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const double lambda = ct->lambda;
@@ -1142,6 +1129,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, LbaW
     const double* X = w_X(pr, cur);
     double* Xn = w_X(pr, cur ^ 1);
     double sc = 0;
+    if ((int)blockIdx.x > w.nblk_pt) return;   // padding block of a batched launch (the grid is sized for the largest window)
     if ((int)blockIdx.x == w.nblk_pt) {   // poses
         for (int a = threadIdx.x; a < pr.K; a += kWPt) {
             const int ba = w.blk[a];
@@ -1202,8 +1190,9 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, LbaW
     }
 }
 
-__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
@@ -1213,8 +1202,9 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWid
     const double* Xp = w_X(pr, tr);
     const SE3* Tp = w.T + tr * pr.K;
     const int p = blockIdx.x * kWPt + threadIdx.x;
+    const bool padding = (int)blockIdx.x >= w.nblk_pt;   // batched launch: blocks past this window's points only report in
     double F = 0;
-    if (p < pr.P) {
+    if (p < pr.P && !padding) {
         const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
         for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
             if (pr.level[e] != 0) continue;
@@ -1234,20 +1224,10 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, LbaWid
     const double f = wsum(F);
     if ((threadIdx.x & 63) == 0) sF[threadIdx.x >> 6] = f;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !padding) {
         double a = sF[0];
         for (int i = 1; i < kWPt / 64; i++) a += sF[i];
         w.partF[blockIdx.x] = a;
-    }
-    if (last_block_done(&w.ct->ticket[1])) {
-        if (threadIdx.x == 0) w_ctrlB(pr, w);
-        __threadfence();
-        __syncthreads();
-        if (w.ct->gate && !w.ct->done) {   // uniform over the block: stage 0 just ended
-            w_gate_block(pr, w);
-            __syncthreads();
-            if (threadIdx.x == 0) w.ct->gate = 0;
-        }
     }
 }
 
@@ -1297,8 +1277,34 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_w_final(const LbaProblem* probs, LbaWide w) {
-    const LbaProblem& pr = probs[0];
+__global__ __launch_bounds__(64) void k_w_ctrlA(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    if (w.ct->done) return;
+    if (threadIdx.x == 0) w_ctrlA(pr, w);
+}
+
+// gain ratio / accept / reject / stage transitions, then (once per LBA, when stage 0 has just ended) the observation gate
+__global__ __launch_bounds__(256) void k_w_ctrlB(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    if (w.ct->done) return;
+    __shared__ int s_gate;
+    if (threadIdx.x == 0) {
+        w_ctrlB(pr, w);
+        s_gate = w.ct->gate && !w.ct->done;
+    }
+    __syncthreads();
+    if (s_gate) {
+        w_gate_block(pr, w);
+        __syncthreads();
+        if (threadIdx.x == 0) w.ct->gate = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_w_final(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const bool early = ct->early != 0;
@@ -1327,27 +1333,27 @@ using namespace oslam;
 
 
 struct oslam_lba {
-    int device = 0, max_batch = 0, max_kf = 0, max_pts = 0, max_edges = 0;
-    // one slab per batch slot
-    struct Slot {
-        float* poses; uint8_t* fixed; float* points; int* e_kf; int* e_pt; float* e_obs; float* e_info; int* pt_start; int* pose_start; int* pose_edges;
-        double* Xa; double* Xb; double* chi2; uint8_t* level; double* Hpl; double* Hll; double* Dinv; double* bl; double* xl; double* Hpp; double* bp; double* Hs; double* xp;
-        float* poses_out; float* points_out; uint8_t* erase; int* stats;
-    };
-    std::vector<Slot> slots;
-    std::vector<void*> allocs;
-    LbaProblem* d_probs = nullptr;
-    // wide mode (batch 1)
-    LbaCtrl* d_ctrl = nullptr; SE3* d_T2 = nullptr; double* d_R2 = nullptr; int* d_blk = nullptr; int* d_free = nullptr;
-    double* d_partF = nullptr; double* d_partS = nullptr; double* d_partM = nullptr; int* h_done = nullptr;
-    double* d_W = nullptr; int2* d_pairs = nullptr; size_t pairs_cap = 0; int* d_pair_start = nullptr;
+    int device = 0, max_batch = 0, max_kf = 0;
+    // Grow-only arenas, carved per launch for the windows of that launch (no per-window capacity: points and edges are limited by memory only):
+    //   in   : LbaProblem[n], LbaWide[n], Schur pair lists, and every window's input arrays — filled in the pinned mirror, ONE upload per launch
+    //   work : solver state of every window (never copied)
+    //   out  : poses_out / points_out / erase / stats of every window — ONE download per launch
+    struct Pool { void* p = nullptr; size_t cap = 0; };
+    Pool in_d, work_d, out_d;
+    uint8_t* in_h = nullptr; size_t in_h_cap = 0, in_off = 0;
+    uint8_t* out_h = nullptr; size_t out_h_cap = 0;
+    LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
-    uint8_t* h_stage = nullptr; size_t stage_cap = 0, stage_off = 0;   // pinned staging of the per-call uploads
-    uint8_t* h_out = nullptr; size_t out_cap = 0;                      // pinned landing zone of the results
-    int wide = 1;                // 1: multi-kernel whole-GPU schedule for single problems, 0: one workgroup per problem
-    std::vector<LbaProblem> host_probs;           // batch mode: prepared problems
-    std::vector<std::vector<int>> orders;         // batch mode: edge permutation of every slot
-    int* h_stop = nullptr;       // pinned, device-visible stop flag
+    int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch
+    struct Prep {                 // one prepared window: offsets into the `in` arena + host-side bookkeeping
+        LbaProblem pr;            // scalar fields valid; pointers filled at launch
+        size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
+        size_t o_out_poses, o_out_points, o_out_erase, o_out_stats;   // offsets into the `out` arena
+        int nfree = 0, nblk = 1; size_t npairs = 0;
+        std::vector<int> order;   // edge permutation (caller order -> point-major)
+    };
+    std::vector<Prep> prep;
+    int* h_stop = nullptr;        // pinned, device-visible stop flag
     int* d_stop = nullptr;
     size_t lds = 0;
     // kernel timing (bench.py's roofline): HIP events on this handle's stream around the solve kernels
@@ -1365,6 +1371,40 @@ static void lba_time_collect(oslam_lba* h, long long launches) {   // after the 
     if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_launches += launches; }
 }
 
+static int pool_ensure(oslam_lba::Pool& q, size_t bytes) {
+    if (bytes <= q.cap) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    if (q.p) (void)hipFree(q.p);
+    q.p = nullptr; q.cap = 0;
+    const size_t cap = bytes + bytes / 2 + (1u << 20);
+    hipError_t e = hipMalloc(&q.p, cap);
+    if (e != hipSuccess) { set_error("local BA: hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e)); return OSLAM_E_HIP; }
+    q.cap = cap;
+    return OSLAM_OK;
+}
+
+// reserves `bytes` (256-aligned) in the pinned mirror of the `in` arena and returns the offset; the mirror grows by copy
+static int in_take(oslam_lba* h, size_t bytes, size_t* off) {
+    const size_t need = h->in_off + ((bytes + 255) & ~(size_t)255);
+    if (need > h->in_h_cap) {
+        const size_t cap = need + need / 2 + (1u << 20);
+        uint8_t* nb = nullptr;
+        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));   // an earlier launch's upload may still read the old block
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&nb, cap, 0));
+        if (h->in_h) { memcpy(nb, h->in_h, h->in_off); (void)hipHostFree(h->in_h); }
+        h->in_h = nb; h->in_h_cap = cap;
+    }
+    *off = h->in_off;
+    h->in_off = need;
+    return OSLAM_OK;
+}
+static int in_put(oslam_lba* h, const void* src, size_t bytes, size_t* off) {
+    const int rc = in_take(h, bytes, off);
+    if (rc) return rc;
+    if (bytes) memcpy(h->in_h + *off, src, bytes);
+    return OSLAM_OK;
+}
+
 extern "C" {
 
 int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long* launches_out) {
@@ -1380,20 +1420,21 @@ int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long*
 
 void oslam_lba_destroy(oslam_lba_t* h) {
     if (!h) return;
+    (void)hipSetDevice(h->device);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (void* p : h->allocs)
-        if (p) (void)hipFree(p);
-    if (h->d_probs) (void)hipFree(h->d_probs);
+    for (oslam_lba::Pool* q : {&h->in_d, &h->work_d, &h->out_d})
+        if (q->p) (void)hipFree(q->p);
+    if (h->in_h) (void)hipHostFree(h->in_h);
+    if (h->out_h) (void)hipHostFree(h->out_h);
+    if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_stop) (void)hipHostFree(h->h_stop);
-    if (h->h_done) (void)hipHostFree(h->h_done);
-    if (h->d_pairs) (void)hipFree(h->d_pairs);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
-    if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
 
+// max_batch = windows per call; max_keyframes (<= 128) = keyframes per window; max_points / max_edges only size the first reservation: the
+// arenas grow with the problems (reference g2o has no such bounds).
 int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int max_points, int max_edges, int device) {
     if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
     *out = nullptr;
@@ -1407,57 +1448,22 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     OSLAM_HIP_CHECK(hipSetDevice(device));
     oslam_lba* h = new oslam_lba();
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
-    h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes; h->max_pts = max_points; h->max_edges = max_edges;
-    const size_t K = max_keyframes, P = max_points, E = max_edges, n = 6 * K;
-    auto alloc = [&](size_t bytes) -> void* {
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
-        h->allocs.push_back(p);
-        return p;
-    };
-    bool okalloc = true;
-    for (int b = 0; b < max_batch && okalloc; b++) {
-        oslam_lba::Slot s;
-#define A(field, type, count) s.field = (type*)alloc(sizeof(type) * (count)); okalloc = okalloc && s.field
-        A(poses, float, K * 16); A(fixed, uint8_t, K); A(points, float, P * 3); A(e_kf, int, E); A(e_pt, int, E); A(e_obs, float, E * 3);
-        A(e_info, float, E); A(pt_start, int, P + 1); A(pose_start, int, K + 1); A(pose_edges, int, E);
-        A(Xa, double, P * 3); A(Xb, double, P * 3); A(chi2, double, E); A(level, uint8_t, E); A(Hpl, double, E * 18); A(Hll, double, P * 9);
-        A(Dinv, double, P * 9); A(bl, double, P * 3); A(xl, double, P * 3); A(Hpp, double, K * 36); A(bp, double, K * 6);
-        A(Hs, double, n * (n + 1)); A(xp, double, n + 8);
-        A(poses_out, float, K * 16); A(points_out, float, P * 3); A(erase, uint8_t, E); A(stats, int, 16);
-#undef A
-        h->slots.push_back(s);
-    }
-    if (!okalloc || hipMalloc((void**)&h->d_probs, sizeof(LbaProblem) * max_batch) != hipSuccess ||
-        hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) {
-        set_error("LBA arena allocation failed");
-        oslam_lba_destroy(h);
-        return OSLAM_E_HIP;
-    }
+    h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
+    if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
-    {
-        const size_t nb = (P + kWPt - 1) / kWPt + 2;
-        h->d_ctrl = (LbaCtrl*)alloc(sizeof(LbaCtrl)); h->d_T2 = (SE3*)alloc(sizeof(SE3) * 2 * K); h->d_R2 = (double*)alloc(8 * 18 * K);
-        h->d_W = (double*)alloc(8 * 18 * E); h->d_pair_start = (int*)alloc(4 * (K * (K + 1) / 2 + 1));
-        h->d_blk = (int*)alloc(4 * K); h->d_free = (int*)alloc(4 * K); h->d_partF = (double*)alloc(8 * nb); h->d_partS = (double*)alloc(8 * nb); h->d_partM = (double*)alloc(8 * nb);
-        if (!h->d_W || !h->d_pair_start || !h->d_ctrl || !h->d_T2 || !h->d_R2 || !h->d_blk || !h->d_free || !h->d_partF || !h->d_partS || !h->d_partM ||
-            hipHostMalloc((void**)&h->h_done, sizeof(int), 0) != hipSuccess) {
-            set_error("LBA wide-mode allocation failed");
-            oslam_lba_destroy(h);
-            return OSLAM_E_HIP;
-        }
-    }
-    OSLAM_HIP_CHECK(hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0));
+    if (hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     h->lds = kRowBufBytes + 64;
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
-    OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)));
+    if (hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)) != hipSuccess) {
+        set_error("hipFuncSetAttribute failed"); oslam_lba_destroy(h); return OSLAM_E_HIP;
+    }
     *out = h;
     return OSLAM_OK;
 }
 
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
-    if (!h) return OSLAM_E_INVALID;
-    OSLAM_HIP_CHECK(hipMemcpy(out, h->slots[0].stats, 64, hipMemcpyDeviceToHost));
+    if (!h || h->prep.empty() || !h->out_h) return OSLAM_E_INVALID;
+    memcpy(out, h->out_h + h->prep[0].o_out_stats, 64);   // stats of window 0 of the last call
     return OSLAM_OK;
 }
 
@@ -1469,65 +1475,29 @@ int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
 
 volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h) { return h ? (volatile int32_t*)h->h_stop : nullptr; }
 
-// Host drop-in: gathers nothing (the caller flattens the graph), builds the point-major /
-// keyframe-major edge orders, uploads, runs, downloads.  Edge outputs are in the caller's order.
-static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
-                   const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
-                   const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
-                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo, int slot = 0, int phase = 2);
+}  // extern "C"
 
-int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
-                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
-                       const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4]) {
-    return lba_run(h, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out,
-                   erase, stats, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
-}
-
-int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
-                      const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
-                      const float K5[5], int nIterations, int bRobust, int use_stop_flag, float* poses_out, float* points_out) {
-    if (nIterations < 0) { set_error("nIterations < 0"); return OSLAM_E_INVALID; }
-    std::vector<uint8_t> erase(nE > 0 ? nE : 1);
-    return lba_run(h, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out,
-                   erase.data(), nullptr, nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
-}
-
-// Copies `bytes` from `src` into the pinned staging buffer and enqueues the upload on the default stream: no host
-// synchronisation per array (a pageable hipMemcpy costs ~25 us each; a local BA call has a dozen of them).
-static int stage_upload(oslam_lba_t* h, void* dst, const void* src, size_t bytes) {
-    if (!bytes) return OSLAM_OK;
-    const size_t need = h->stage_off + ((bytes + 255) & ~(size_t)255);
-    if (need > h->stage_cap) {
-        OSLAM_HIP_CHECK(hipDeviceSynchronize());   // earlier uploads of this call have left the old buffer
-        const size_t cap = need + need / 2 + (1u << 20);
-        uint8_t* nb = nullptr;
-        OSLAM_HIP_CHECK(hipHostMalloc((void**)&nb, cap, 0));
-        if (h->h_stage) (void)hipHostFree(h->h_stage);
-        h->h_stage = nb; h->stage_cap = cap; h->stage_off = 0;
-    }
-    uint8_t* at = h->h_stage + h->stage_off;
-    memcpy(at, src, bytes);
-    OSLAM_HIP_CHECK(hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, h->strm));
-    h->stage_off += (bytes + 255) & ~(size_t)255;
-    return OSLAM_OK;
-}
-
-static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
-                   const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
-                   const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4],
-                   int iters0, int iters1, int nstages, int robust0, float delta_mono, float delta_stereo, int slot, int phase) {
+// Prepares window `slot` of the coming launch: validates, builds the point-major / keyframe-major edge orders and the Schur pair lists,
+// and writes the input arrays into the pinned mirror of the `in` arena.  Edge outputs come back in the caller's order.
+static int lba_prepare(oslam_lba_t* h, int slot, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2, const float K5[5],
+                       int use_stop_flag, const float* poses_out, const float* points_out, const uint8_t* erase, int iters0, int iters1, int nstages,
+                       int robust0, float delta_mono, float delta_stereo) {
     if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase))) {
         set_error("NULL argument");
         return OSLAM_E_INVALID;
     }
-    if (nKF < 1 || nKF > h->max_kf || nP < 0 || nP > h->max_pts || nE < 0 || nE > h->max_edges) {
-        set_error("problem (%d keyframes, %d points, %d edges) exceeds the handle capacity (%d, %d, %d)", nKF, nP, nE, h->max_kf, h->max_pts, h->max_edges);
+    if (nKF < 1 || nKF > h->max_kf || nP < 0 || nE < 0) {
+        set_error("problem (%d keyframes, %d points, %d edges) exceeds the handle capacity (%d keyframes per window)", nKF, nP, nE, h->max_kf);
         return OSLAM_E_CAPACITY;
     }
-    OSLAM_HIP_CHECK(hipSetDevice(h->device));
-    // stable sort by point; detect duplicate (kf, pt) observations (the reference has one per keyframe)
+    if (slot == 0) { h->in_off = 0; h->prep.clear(); }
     // stable counting sort of the edges by point (O(E); the caller's order inside a point is kept)
-    std::vector<int> order(nE), pt_start(nP + 1, 0), pose_start(nKF + 1, 0);
+    std::vector<int> pt_start(nP + 1, 0), pose_start(nKF + 1, 0);
+    h->prep.emplace_back();
+    oslam_lba::Prep& q = h->prep.back();
+    std::vector<int>& order = q.order;
+    order.resize(nE);
     for (int i = 0; i < nE; i++) {
         if (edge_kf[i] < 0 || edge_kf[i] >= nKF || edge_pt[i] < 0 || edge_pt[i] >= nP) { set_error("edge %d references vertex out of range", i); return OSLAM_E_INVALID; }
         pt_start[edge_pt[i] + 1]++;
@@ -1550,201 +1520,232 @@ static int lba_run(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* f
         std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
         for (int i = 0; i < nE; i++) pose_edges[cur[ekf[i]]++] = i;
     }
-    for (int p = 0; p < nP; p++) {
-        if (pt_start[p + 1] - pt_start[p] > 64) { set_error("point %d has more than 64 observations", p); return OSLAM_E_CAPACITY; }
-        for (int i = pt_start[p]; i < pt_start[p + 1]; i++)
-            for (int j = i + 1; j < pt_start[p + 1]; j++)
-                if (ekf[i] == ekf[j]) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
+    {   // the reference has one observation of a point per keyframe
+        std::vector<int> seen(nKF, -1);
+        for (int p = 0; p < nP; p++)
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                if (seen[ekf[i]] == p) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
+                seen[ekf[i]] = p;
+            }
     }
-    oslam_lba::Slot& s = h->slots[slot];
-    if (phase != 0 || slot == 0) h->stage_off = 0;   // batch mode appends slot after slot
-#define UP(dst, src, bytes) { const int rc_ = stage_upload(h, dst, src, bytes); if (rc_) return rc_; }
-    UP(s.poses, poses, (size_t)nKF * 64); UP(s.fixed, fixed, (size_t)nKF); UP(s.points, points, (size_t)nP * 12);
-    UP(s.e_kf, ekf.data(), (size_t)nE * 4); UP(s.e_pt, ept.data(), (size_t)nE * 4); UP(s.e_obs, eobs.data(), (size_t)nE * 12);
-    UP(s.e_info, einfo.data(), (size_t)nE * 4); UP(s.pt_start, pt_start.data(), (size_t)(nP + 1) * 4);
-    UP(s.pose_start, pose_start.data(), (size_t)(nKF + 1) * 4); UP(s.pose_edges, pose_edges.data(), (size_t)nE * 4);
-    int st[16] = {0};
-#undef UP
-    LbaProblem pr;
+    int nfree = 0;
+    for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
+    if (nfree > kLbaMaxKF) { set_error("%d free keyframes > %d", nfree, kLbaMaxKF); return OSLAM_E_CAPACITY; }
+    q.nfree = nfree; q.nblk = std::max(1, nfree * (nfree + 1) / 2);
+    int rc;
+    if ((rc = in_put(h, poses, (size_t)nKF * 64, &q.o_poses)) || (rc = in_put(h, fixed, (size_t)nKF, &q.o_fixed)) || (rc = in_put(h, points, (size_t)nP * 12, &q.o_points)) ||
+        (rc = in_put(h, ekf.data(), (size_t)nE * 4, &q.o_ekf)) || (rc = in_put(h, ept.data(), (size_t)nE * 4, &q.o_ept)) || (rc = in_put(h, eobs.data(), (size_t)nE * 12, &q.o_eobs)) ||
+        (rc = in_put(h, einfo.data(), (size_t)nE * 4, &q.o_einfo)) || (rc = in_put(h, pt_start.data(), (size_t)(nP + 1) * 4, &q.o_ptstart)) ||
+        (rc = in_put(h, pose_start.data(), (size_t)(nKF + 1) * 4, &q.o_posestart)) || (rc = in_put(h, pose_edges.data(), (size_t)nE * 4, &q.o_poseedges)))
+        return rc;
+    q.npairs = 0; q.o_pairs = q.o_pstart = 0;
+    if (h->wide) {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
+        const int nblk = q.nblk;
+        std::vector<int> blk(nKF);
+        for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
+        auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
+        std::vector<int> pstart(nblk + 1, 0);
+        for (int p = 0; p < nP; p++)
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                const int bi = blk[ekf[i]];
+                if (bi < 0) continue;
+                for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                    const int bj = blk[ekf[j]];
+                    if (bj >= bi) pstart[tof(bi, bj) + 1]++;
+                }
+            }
+        for (int t2 = 0; t2 < nblk; t2++) pstart[t2 + 1] += pstart[t2];
+        q.npairs = (size_t)pstart[nblk];
+        if ((rc = in_take(h, q.npairs * sizeof(int2), &q.o_pairs))) return rc;
+        int2* pairs = (int2*)(h->in_h + q.o_pairs);
+        std::vector<int> cur(pstart.begin(), pstart.end() - 1);
+        for (int p = 0; p < nP; p++)
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                const int bi = blk[ekf[i]];
+                if (bi < 0) continue;
+                for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                    const int bj = blk[ekf[j]];
+                    if (bj >= bi) pairs[cur[tof(bi, bj)]++] = make_int2(i, j);
+                }
+            }
+        if ((rc = in_put(h, pstart.data(), (size_t)(nblk + 1) * 4, &q.o_pstart))) return rc;
+    }
+    LbaProblem& pr = q.pr;
+    memset(&pr, 0, sizeof(pr));
     pr.K = nKF; pr.P = nP; pr.E = nE;
-    pr.poses = s.poses; pr.fixed = s.fixed; pr.points = s.points; pr.e_kf = s.e_kf; pr.e_pt = s.e_pt; pr.e_obs = s.e_obs; pr.e_info = s.e_info;
-    pr.pt_start = s.pt_start; pr.pose_start = s.pose_start; pr.pose_edges = s.pose_edges;
-    pr.Xa = s.Xa; pr.Xb = s.Xb; pr.chi2 = s.chi2; pr.level = s.level; pr.Hpl = s.Hpl; pr.Hll = s.Hll; pr.Dinv = s.Dinv; pr.bl = s.bl; pr.xl = s.xl;
-    pr.Hpp = s.Hpp; pr.bp = s.bp; pr.Hs = s.Hs; pr.xp = s.xp;
-    pr.poses_out = s.poses_out; pr.points_out = s.points_out; pr.erase = s.erase; pr.stats = s.stats;
     pr.stop = use_stop_flag ? h->d_stop : nullptr;
     for (int i = 0; i < 5; i++) pr.K5[i] = K5[i];
     pr.iters0 = iters0; pr.iters1 = iters1; pr.nstages = nstages; pr.robust0 = robust0; pr.delta_mono = delta_mono; pr.delta_stereo = delta_stereo;
-    if (phase == 0) {   // batch mode: keep the prepared problem, the caller launches all slots together
-        if ((int)h->host_probs.size() <= slot) { h->host_probs.resize(slot + 1); h->orders.resize(slot + 1); }
-        h->host_probs[slot] = pr;
-        h->orders[slot] = order;
-        return OSLAM_OK;
-    }
-    { const int rc_ = stage_upload(h, h->d_probs, &pr, sizeof(pr)); if (rc_) return rc_; }
-    if (!h->wide) {
-        lba_time_begin(h);
-        hipLaunchKernelGGL(k_lba, dim3(1), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
-        lba_time_end(h);
-        OSLAM_HIP_CHECK(hipGetLastError());
-        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
-        lba_time_collect(h, 1);
-    } else {
-        LbaWide w;
-        w.ct = h->d_ctrl; w.T = h->d_T2; w.R = h->d_R2; w.blk = h->d_blk; w.free_pose = h->d_free;
-        w.partF = h->d_partF; w.partS = h->d_partS; w.partM = h->d_partM;
-        w.nblk_pt = div_up(std::max(nP, 1), kWPt);
-        int nfree = 0;
-        for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
-        const int nblk = std::max(1, nfree * (nfree + 1) / 2);
-        {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
-            std::vector<int> blk(nKF);
-            for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
-            auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
-            std::vector<int> pstart(nblk + 1, 0);
-            for (int p = 0; p < nP; p++)
-                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                    const int bi = blk[ekf[i]];
-                    if (bi < 0) continue;
-                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
-                        const int bj = blk[ekf[j]];
-                        if (bj >= bi) pstart[tof(bi, bj) + 1]++;
-                    }
-                }
-            for (int t2 = 0; t2 < nblk; t2++) pstart[t2 + 1] += pstart[t2];
-            const size_t npairs = (size_t)pstart[nblk];
-            std::vector<int2> pairs(npairs ? npairs : 1);
-            std::vector<int> cur(pstart.begin(), pstart.end() - 1);
-            for (int p = 0; p < nP; p++)
-                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                    const int bi = blk[ekf[i]];
-                    if (bi < 0) continue;
-                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
-                        const int bj = blk[ekf[j]];
-                        if (bj >= bi) pairs[cur[tof(bi, bj)]++] = make_int2(i, j);
-                    }
-                }
-            if (npairs > h->pairs_cap) {
-                if (h->d_pairs) (void)hipFree(h->d_pairs);
-                h->d_pairs = nullptr; h->pairs_cap = 0;
-                const size_t cap = npairs + npairs / 2 + 1024;
-                OSLAM_HIP_CHECK(hipMalloc((void**)&h->d_pairs, cap * sizeof(int2)));
-                h->pairs_cap = cap;
-            }
-            if (npairs) { const int rc_ = stage_upload(h, h->d_pairs, pairs.data(), npairs * sizeof(int2)); if (rc_) return rc_; }
-            { const int rc_ = stage_upload(h, h->d_pair_start, pstart.data(), (size_t)(nblk + 1) * 4); if (rc_) return rc_; }
-            w.pairs = h->d_pairs; w.pair_start = h->d_pair_start; w.W = h->d_W;
-        }
-        const size_t chol_lds = 6 * nfree <= kCholLdsN ? (size_t)(6 * nfree) * (6 * nfree + 1) * sizeof(double) : 0;
-        hipStream_t st = h->strm;
-        lba_time_begin(h);
-        hipLaunchKernelGGL(k_w_init, dim3(1), dim3(256), 0, st, h->d_probs, w);
-        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(std::max(std::max(nP * 3, nE), 1), 256)), dim3(256), 0, st, h->d_probs);
-        // worst case 15 iterations x 10 trials; slots past `done` return at once
-        int slots_done = 0;
-        *h->h_done = 0;
-        const int max_slots = (iters0 + (nstages > 1 ? iters1 : 0)) * 10 + 8;
-        // first group = the minimum number of LM trials (one per iteration), so the common case needs a single
-        // host round trip; rejected steps add groups of 4
-        int group = std::max(4, iters0 + (nstages > 1 ? iters1 : 0));
-        while (slots_done < max_slots) {
-            for (int sl = 0; sl < group; sl++, slots_done++) {
-                hipLaunchKernelGGL(k_w_lin, dim3(w.nblk_pt + nKF), dim3(kLinThreads), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(std::max(nE, 1), 256)), dim3(256), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_schur, dim3(nblk), dim3(64), 0, st, h->d_probs, w);
-                if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1), dim3(1024), chol_lds, st, h->d_probs, w);
-                else hipLaunchKernelGGL(k_w_chol<false>, dim3(1), dim3(1024), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_update, dim3(w.nblk_pt + 1), dim3(kWPt), 0, st, h->d_probs, w);
-                hipLaunchKernelGGL(k_w_eval, dim3(w.nblk_pt), dim3(kWPt), 0, st, h->d_probs, w);
-            }
-            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_done, &h->d_ctrl->done, sizeof(int), hipMemcpyDeviceToHost, st));
-            OSLAM_HIP_CHECK(hipStreamSynchronize(st));
-            if (*h->h_done) break;
-            group = 4;
-        }
-        const int nfin = std::max(std::max(nE, nKF), nP * 3);
-        hipLaunchKernelGGL(k_w_final, dim3(div_up(std::max(nfin, 1), 256)), dim3(256), 0, st, h->d_probs, w);
-        lba_time_end(h);
-        OSLAM_HIP_CHECK(hipGetLastError());
-        OSLAM_HIP_CHECK(hipStreamSynchronize(st));
-        lba_time_collect(h, 3 + 6 * (long long)slots_done);
-    }
-    {   // results: four async copies into one pinned landing zone, one synchronisation
-        const size_t o_pose = 0, o_pts = o_pose + (((size_t)nKF * 64 + 255) & ~(size_t)255), o_er = o_pts + (((size_t)nP * 12 + 255) & ~(size_t)255),
-                     o_st = o_er + (((size_t)nE + 255) & ~(size_t)255), total = o_st + 256;
-        if (total > h->out_cap) {
-            if (h->h_out) (void)hipHostFree(h->h_out);
-            h->h_out = nullptr; h->out_cap = 0;
-            OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
-            h->out_cap = total + total / 2;
-        }
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose, s.poses_out, (size_t)nKF * 64, hipMemcpyDeviceToHost, h->strm));
-        if (nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts, s.points_out, (size_t)nP * 12, hipMemcpyDeviceToHost, h->strm));
-        if (nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er, s.erase, (size_t)nE, hipMemcpyDeviceToHost, h->strm));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st, s.stats, sizeof(st), hipMemcpyDeviceToHost, h->strm));
-        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
-        memcpy(poses_out, h->h_out + o_pose, (size_t)nKF * 64);
-        if (nP > 0) memcpy(points_out, h->h_out + o_pts, (size_t)nP * 12);
-        const uint8_t* er = h->h_out + o_er;
-        for (int i = 0; i < nE; i++) erase[order[i]] = er[i];
-        if (stats) {
-            memcpy(st, h->h_out + o_st, sizeof(st));
-            for (int i = 0; i < 4; i++) stats[i] = st[i];
-        }
-    }
     return OSLAM_OK;
 }
 
+// Runs the prepared windows and brings their outputs into the pinned `out` mirror (the stream is drained on return).
+// Compact mode: ONE launch of k_lba, one workgroup per window.  Wide mode: every LM trial is eight launches whose grids cover ALL
+// windows (blockIdx.y = window, blockIdx.x sized for the largest one); windows that have finished return at once.
+static int lba_launch(oslam_lba_t* h) {
+    const int n = (int)h->prep.size();
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = h->strm;
+    int rc;
+    // ---- carve the arenas ----
+    size_t o_probs, o_ws;
+    if ((rc = in_take(h, sizeof(LbaProblem) * n, &o_probs)) || (rc = in_take(h, sizeof(LbaWide) * n, &o_ws))) return rc;
+    size_t work = 0, outb = 0;
+    auto takeW = [&](size_t bytes) { const size_t at = work; work += (bytes + 255) & ~(size_t)255; return at; };
+    auto takeO = [&](size_t bytes) { const size_t at = outb; outb += (bytes + 255) & ~(size_t)255; return at; };
+    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W; };
+    std::vector<WOff> wo(n);
+    int maxNbPt = 1, maxK = 1, maxE = 1, maxBlk = 1, maxFin = 1, maxInit = 1, max_slots = 0, min_group = 4, max_n6 = 0;
+    bool all_lds = true;
+    const size_t ctrl_base = takeW(sizeof(LbaCtrl) * n);   // contiguous: the host polls all of them with one copy
+    for (int i = 0; i < n; i++) {
+        oslam_lba::Prep& q = h->prep[i];
+        const size_t K = q.pr.K, P = q.pr.P, E = q.pr.E, n6 = 6 * (size_t)q.nfree;
+        const int nbpt = div_up(std::max((int)P, 1), kWPt);
+        WOff& o = wo[i];
+        o.Xa = takeW(P * 24); o.Xb = takeW(P * 24); o.chi2 = takeW(E * 8); o.level = takeW(E); o.Hpl = takeW(E * 144); o.Hll = takeW(P * 72); o.Dinv = takeW(P * 72);
+        o.bl = takeW(P * 24); o.xl = takeW(P * 24); o.Hpp = takeW(K * 288); o.bp = takeW(K * 48); o.Hs = takeW(n6 * (n6 + 1) * 8); o.xp = takeW((n6 + 8) * 8);
+        if (h->wide) {
+            o.ctrl = ctrl_base + sizeof(LbaCtrl) * i; o.T = takeW(sizeof(SE3) * 2 * K); o.R = takeW(144 * K); o.blk = takeW(4 * K); o.free_pose = takeW(4 * K);
+            o.partF = takeW(8 * (nbpt + 2)); o.partS = takeW(8 * (nbpt + 2)); o.partM = takeW(8 * (nbpt + 2)); o.W = takeW(E * 144);
+        }
+        q.o_out_poses = takeO(K * 64); q.o_out_points = takeO(P * 12); q.o_out_erase = takeO(E); q.o_out_stats = takeO(64);
+        maxNbPt = std::max(maxNbPt, nbpt); maxK = std::max(maxK, (int)K); maxE = std::max(maxE, (int)E); maxBlk = std::max(maxBlk, q.nblk);
+        maxFin = std::max(maxFin, (int)std::max(std::max(E, K), P * 3)); maxInit = std::max(maxInit, (int)std::max(P * 3, E));
+        const int its = q.pr.iters0 + (q.pr.nstages > 1 ? q.pr.iters1 : 0);
+        max_slots = std::max(max_slots, its * 10 + 8); min_group = std::max(min_group, its);
+        all_lds = all_lds && (int)n6 <= kCholLdsN; max_n6 = std::max(max_n6, (int)n6);
+    }
+    if ((rc = pool_ensure(h->in_d, h->in_off)) || (rc = pool_ensure(h->work_d, work)) || (rc = pool_ensure(h->out_d, outb))) return rc;
+    if (outb > h->out_h_cap) {
+        if (h->out_h) (void)hipHostFree(h->out_h);
+        h->out_h = nullptr; h->out_h_cap = 0;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->out_h, outb + outb / 2, 0));
+        h->out_h_cap = outb + outb / 2;
+    }
+    if (h->wide && sizeof(LbaCtrl) * n > h->h_ctrl_cap) {
+        if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
+        h->h_ctrl = nullptr; h->h_ctrl_cap = 0;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_ctrl, sizeof(LbaCtrl) * n * 2, 0));
+        h->h_ctrl_cap = sizeof(LbaCtrl) * n * 2;
+    }
+    uint8_t* I = (uint8_t*)h->in_d.p; uint8_t* Wk = (uint8_t*)h->work_d.p; uint8_t* O = (uint8_t*)h->out_d.p;
+    LbaProblem* hp = (LbaProblem*)(h->in_h + o_probs);
+    LbaWide* hw = (LbaWide*)(h->in_h + o_ws);
+    for (int i = 0; i < n; i++) {
+        const oslam_lba::Prep& q = h->prep[i];
+        const WOff& o = wo[i];
+        LbaProblem pr = q.pr;
+        pr.poses = (const float*)(I + q.o_poses); pr.fixed = I + q.o_fixed; pr.points = (const float*)(I + q.o_points); pr.e_kf = (const int*)(I + q.o_ekf);
+        pr.e_pt = (const int*)(I + q.o_ept); pr.e_obs = (const float*)(I + q.o_eobs); pr.e_info = (const float*)(I + q.o_einfo); pr.pt_start = (const int*)(I + q.o_ptstart);
+        pr.pose_start = (const int*)(I + q.o_posestart); pr.pose_edges = (const int*)(I + q.o_poseedges);
+        pr.Xa = (double*)(Wk + o.Xa); pr.Xb = (double*)(Wk + o.Xb); pr.chi2 = (double*)(Wk + o.chi2); pr.level = Wk + o.level; pr.Hpl = (double*)(Wk + o.Hpl);
+        pr.Hll = (double*)(Wk + o.Hll); pr.Dinv = (double*)(Wk + o.Dinv); pr.bl = (double*)(Wk + o.bl); pr.xl = (double*)(Wk + o.xl); pr.Hpp = (double*)(Wk + o.Hpp);
+        pr.bp = (double*)(Wk + o.bp); pr.Hs = (double*)(Wk + o.Hs); pr.xp = (double*)(Wk + o.xp);
+        pr.poses_out = (float*)(O + q.o_out_poses); pr.points_out = (float*)(O + q.o_out_points); pr.erase = O + q.o_out_erase; pr.stats = (int*)(O + q.o_out_stats);
+        hp[i] = pr;
+        LbaWide w;
+        memset(&w, 0, sizeof(w));
+        if (h->wide) {
+            w.ct = (LbaCtrl*)(Wk + o.ctrl); w.T = (SE3*)(Wk + o.T); w.R = (double*)(Wk + o.R); w.blk = (int*)(Wk + o.blk); w.free_pose = (int*)(Wk + o.free_pose);
+            w.partF = (double*)(Wk + o.partF); w.partS = (double*)(Wk + o.partS); w.partM = (double*)(Wk + o.partM); w.W = (double*)(Wk + o.W);
+            w.nblk_pt = div_up(std::max(pr.P, 1), kWPt);
+            w.pairs = (const int2*)(I + q.o_pairs); w.pair_start = (const int*)(I + q.o_pstart);
+        }
+        hw[i] = w;
+    }
+    OSLAM_HIP_CHECK(hipMemcpyAsync(I, h->in_h, h->in_off, hipMemcpyHostToDevice, st));   // the ONE upload
+    const LbaProblem* d_probs = (const LbaProblem*)(I + o_probs);
+    const LbaWide* d_ws = (const LbaWide*)(I + o_ws);
+    long long launches = 1;
+    lba_time_begin(h);
+    if (!h->wide) {
+        hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, st, d_probs);
+    } else {
+        const size_t chol_lds = all_lds ? (size_t)max_n6 * (max_n6 + 1) * sizeof(double) : 0;
+        hipLaunchKernelGGL(k_w_init, dim3(1, n), dim3(256), 0, st, d_probs, d_ws);
+        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n), dim3(256), 0, st, d_probs);
+        // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
+        // iteration), so the common case needs a single host round trip; rejected steps add groups of 4.
+        int slots_done = 0, group = min_group;
+        while (slots_done < max_slots) {
+            for (int sl = 0; sl < group; sl++, slots_done++) {
+                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, n), dim3(kLinThreads), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n), dim3(64), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n), dim3(256), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n), dim3(64), 0, st, d_probs, d_ws);
+                if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n), dim3(1024), chol_lds, st, d_probs, d_ws);
+                else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n), dim3(1024), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n), dim3(kWPt), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n), dim3(kWPt), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n), dim3(256), 0, st, d_probs, d_ws);
+            }
+            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n, hipMemcpyDeviceToHost, st));
+            OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+            bool all_done = true;
+            for (int i = 0; i < n; i++) all_done = all_done && h->h_ctrl[i].done != 0;
+            if (all_done) break;
+            group = 4;
+        }
+        hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n), dim3(256), 0, st, d_probs, d_ws);
+        launches = 3 + 8 * (long long)slots_done;
+    }
+    lba_time_end(h);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(hipMemcpyAsync(h->out_h, O, outb, hipMemcpyDeviceToHost, st));   // the ONE download
+    OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+    lba_time_collect(h, launches);
+    return OSLAM_OK;
+}
 
-// Batch of independent keyframe windows (the batch-of-sequences layout): every problem is staged into its
-// own slot, then ONE launch of k_lba runs one workgroup per problem.
+// scatter of window i's outputs (erase flags back in the caller's edge order)
+static void lba_fetch(oslam_lba_t* h, int i, float* poses_out, float* points_out, uint8_t* erase, int32_t* stats) {
+    const oslam_lba::Prep& q = h->prep[i];
+    memcpy(poses_out, h->out_h + q.o_out_poses, (size_t)q.pr.K * 64);
+    if (q.pr.P > 0) memcpy(points_out, h->out_h + q.o_out_points, (size_t)q.pr.P * 12);
+    const uint8_t* er = h->out_h + q.o_out_erase;
+    for (int e = 0; e < q.pr.E; e++) erase[q.order[e]] = er[e];
+    if (stats) { const int* st = (const int*)(h->out_h + q.o_out_stats); for (int k = 0; k < 4; k++) stats[k] = st[k]; }
+}
+
+extern "C" {
+
+// Host drop-in: the caller flattens the graph (the covisibility gather stays with it).
+int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                       const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4]) {
+    int rc = lba_prepare(h, 0, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out, erase,
+                         5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
+    if (!rc) rc = lba_launch(h);
+    if (!rc) lba_fetch(h, 0, poses_out, points_out, erase, stats);
+    return rc;
+}
+
+int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
+                      const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
+                      const float K5[5], int nIterations, int bRobust, int use_stop_flag, float* poses_out, float* points_out) {
+    if (nIterations < 0) { set_error("nIterations < 0"); return OSLAM_E_INVALID; }
+    std::vector<uint8_t> erase(nE > 0 ? nE : 1);
+    int rc = lba_prepare(h, 0, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out, erase.data(),
+                         nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
+    if (!rc) rc = lba_launch(h);
+    if (!rc) lba_fetch(h, 0, poses_out, points_out, erase.data(), nullptr);
+    return rc;
+}
+
+// Batch of independent keyframe windows (the batch-of-sequences layout).
 int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* probs, const float K5[5]) {
     if (!h || !probs || !K5) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (n < 1 || n > h->max_batch) { set_error("batch %d outside [1,%d]", n, h->max_batch); return OSLAM_E_INVALID; }
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
-        int rc = lba_run(h, q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, K5, 0, q.poses_out,
-                         q.points_out, q.erase, nullptr, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815), i, 0);
+        const int rc = lba_prepare(h, i, q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, K5, 0, q.poses_out, q.points_out,
+                                   q.erase, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
         if (rc) return rc;
     }
-    { const int rc_ = stage_upload(h, h->d_probs, h->host_probs.data(), sizeof(LbaProblem) * n); if (rc_) return rc_; }
-    lba_time_begin(h);
-    hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, h->strm, h->d_probs);
-    lba_time_end(h);
-    OSLAM_HIP_CHECK(hipGetLastError());
-    // results of all windows: async copies into the pinned block, ONE synchronisation, then the scatter (erase flags back in caller edge order)
-    std::vector<size_t> o_pose(n), o_pts(n), o_er(n), o_st(n);
-    size_t total = 0;
-    auto take = [&](size_t bytes) { const size_t at = total; total += (bytes + 255) & ~(size_t)255; return at; };
-    for (int i = 0; i < n; i++) {
-        const oslam_lba_problem_t& q = probs[i];
-        o_pose[i] = take((size_t)q.nKF * 64); o_pts[i] = take((size_t)q.nP * 12); o_er[i] = take((size_t)q.nE); o_st[i] = take(64);
-    }
-    if (total > h->out_cap) {
-        OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
-        if (h->h_out) (void)hipHostFree(h->h_out);
-        h->h_out = nullptr; h->out_cap = 0;
-        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_out, total + total / 2, 0));
-        h->out_cap = total + total / 2;
-    }
-    for (int i = 0; i < n; i++) {
-        const oslam_lba_problem_t& q = probs[i];
-        oslam_lba::Slot& s = h->slots[i];
-        OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pose[i], s.poses_out, (size_t)q.nKF * 64, hipMemcpyDeviceToHost, h->strm));
-        if (q.nP > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_pts[i], s.points_out, (size_t)q.nP * 12, hipMemcpyDeviceToHost, h->strm));
-        if (q.nE > 0) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_er[i], s.erase, (size_t)q.nE, hipMemcpyDeviceToHost, h->strm));
-        if (q.stats) OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_out + o_st[i], s.stats, 64, hipMemcpyDeviceToHost, h->strm));
-    }
-    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
-    lba_time_collect(h, 1);
-    for (int i = 0; i < n; i++) {
-        const oslam_lba_problem_t& q = probs[i];
-        memcpy(q.poses_out, h->h_out + o_pose[i], (size_t)q.nKF * 64);
-        if (q.nP > 0) memcpy(q.points_out, h->h_out + o_pts[i], (size_t)q.nP * 12);
-        const uint8_t* er = h->h_out + o_er[i];
-        for (int e = 0; e < q.nE; e++) q.erase[h->orders[i][e]] = er[e];
-        if (q.stats) { const int* st = (const int*)(h->h_out + o_st[i]); for (int k = 0; k < 4; k++) q.stats[k] = st[k]; }
-    }
+    const int rc = lba_launch(h);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) lba_fetch(h, i, probs[i].poses_out, probs[i].points_out, probs[i].erase, probs[i].stats);
     return OSLAM_OK;
 }
 

@@ -754,9 +754,9 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (!rc && cfg->sensor == 1) rc = oslam_orb_create(&o->orbR, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
     if (!rc && cfg->sensor == 1) rc = oslam_stereo_create(&o->stereo, o->S, o->cap, dev);
     if (!rc) rc = oslam_poseopt_create(&o->po, o->S, o->cap, dev);
-    if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 32768, 262144, dev);
-    if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 32768, 262144, dev);
-    if (!rc) rc = oslam_lba_set_mode(o->ba, 0);
+    if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 4096, 32768, dev);    // points / edges per window grow on demand (include/oslam_hip.h); <= 128 keyframes per window
+    if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 4096, 32768, dev);
+    if (!rc) rc = oslam_lba_set_mode(o->ba, getenv("OSLAM_LBA_BATCH_COMPACT") ? 0 : 1);   // default: every LM trial of ALL windows as six whole-GPU launches; compact = one workgroup per window (A/B knob)
     if (!rc) rc = oslam_mappoint_create(&o->mp, dev);
     if (!rc) rc = oslam_frame_create(&o->fr, dev);
     if (!rc) rc = oslam_bow_create(&o->bow, o->cap, dev);
