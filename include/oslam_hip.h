@@ -377,6 +377,9 @@ int oslam_lba_set_mode(oslam_lba_t* h, int wide);
 /* Kernel timing for bench.py's roofline: HIP events on the handle's stream around the solve kernels of every later call.
  * Returns and clears the accumulated milliseconds / kernel launches, then sets the switch to `enable`. */
 int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long* launches_out);
+/* Reduced-camera-system solver of the wide mode: 0 (default) = the LDS-resident scalar kernel while the augmented system fits (6 x free keyframes <= 132),
+ * the matrix-core kernel (v_mfma_f64_16x16x4_f64 trailing updates, 16-wide panels) beyond; 1 = matrix cores for every size; 2 = never. */
+int oslam_lba_set_solver(oslam_lba_t* h, int mode);
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]);   /* [0..3] stats, [8..15] per-phase kilo-cycles in profiling builds */
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP,
                        const float* points, int nE, const int32_t* edge_kf, const int32_t* edge_pt,

@@ -1117,6 +1117,170 @@ __global__ __launch_bounds__(1024) void k_w_chol(const LbaProblem* probs, const 
     if (tid == 0) ct->ok2 = ok2 ? 1 : 0;
 }
 
+// Reduced camera system by MATRIX CORES: right-looking blocked Cholesky (U^T U, 16-wide panels) of the augmented system [n][n+1] in place in
+// global memory (L2 resident: 463 KB at n = 240), one 512-thread workgroup per window.  Per panel: wavefront 0 factors the 16x16 diagonal
+// block in LDS, one thread per column solves the row panel U12 = U11^-T A12 (kept in LDS, 16 x (n+1-j0) doubles), then the 8 wavefronts
+// apply the rank-16 trailing update A22 -= U12^T U12 tile by tile with v_mfma_f64_16x16x4_f64: four MFMAs per 16x16 tile, the A operand
+// (lane l: U12[4s + (l>>4)][i0 + (l&15)]) and the B operand (U12[4s + (l>>4)][k0 + (l&15)]) straight from the LDS row panel, C/D
+// (col = l&15, row = (l>>4) + 4 reg) read-modify-written in place.  The right-hand side rides along as column n.  Then a blocked back
+// substitution.  Used for systems that do not fit the LDS-resident kernel (6 nfree > kCholLdsN); OSLAM_LBA_CHOL_MFMA=1 forces it for all sizes.
+constexpr int kMB = 16;                       // panel width = MFMA tile edge
+constexpr int kMfmaMaxN = 6 * kLbaMaxKF;      // 768
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaThreads = 512;   // 8 wavefronts: 256 registers each (the four-tile trailing step needs ~150; 1024 threads would cap them at 128 and spill)
+__global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* probs, const LbaWide* ws) {
+#pragma clang fp contract(fast)
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = ct->n, ld = n + 1;
+    double* A = pr.Hs;
+    extern __shared__ __align__(16) double s_P[];          // [16][pw] row panel, pw = panel pitch (columns right of the block, incl. rhs, padded to 16)
+    __shared__ double s_D[kMB][kMB + 1], s_R[kMB], s_x[kMfmaMaxN + kMB];
+    __shared__ int s_ok;
+    if (tid == 0) s_ok = 1;
+    const int pw = ((n + 1 + kMB - 1) / kMB + 1) * kMB;   // pitch of the row panel in LDS
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += kMB) {
+        const int nb = min(kMB, n - j0), c0 = j0 + nb, m = n - c0;   // trailing rows / columns m, plus the rhs column
+        // ---- 1. diagonal block -> LDS, factored by wavefront 0 ----
+        if (tid < kMB * kMB) {
+            const int i = tid >> 4, k = tid & 15;
+            s_D[i][k] = (i < nb && k < nb && k >= i) ? A[(size_t)(j0 + i) * ld + j0 + k] : (i == k ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            bool good = true;
+            for (int j = 0; j < nb; j++) {
+                const double d = s_D[j][j];
+                good = good && (d > 0) && (d < 1.7e308);
+                const double r = rsqrt(d);
+                if (lane < kMB && lane > j) s_D[j][lane] *= r;
+                if (lane == 0) { s_D[j][j] = d * r; s_R[j] = r; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int e = lane; e < kMB * kMB; e += 64) {
+                    const int i = e >> 4, k = e & 15;
+                    if (i > j && k >= i) s_D[i][k] -= s_D[j][i] * s_D[j][k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (!good && lane == 0) s_ok = 0;
+            for (int e = lane; e < kMB * kMB; e += 64) {   // the factor back into the matrix (back substitution reads it)
+                const int i = e >> 4, k = e & 15;
+                if (i < nb && k < nb && k >= i) A[(size_t)(j0 + i) * ld + j0 + k] = s_D[i][k];
+            }
+        }
+        __syncthreads();
+        // ---- 2. row panel: U12 = U11^-T A12 (columns c0 .. n), one thread per column; rows >= nb and the padding columns are zero ----
+        for (int c = tid; c < pw; c += kMfmaThreads) {   // the column lives in LDS (a register array of 16 doubles per thread plus the factor spilled)
+            const int cg = c0 + c;
+            const bool live = c <= m;
+            for (int i = 0; i < kMB; i++) s_P[i * pw + c] = (live && i < nb) ? A[(size_t)(j0 + i) * ld + cg] : 0.0;
+            if (live) {
+                for (int j = 0; j < nb; j++) {
+                    double sv = s_P[j * pw + c];
+                    for (int i = 0; i < j; i++) sv -= s_D[i][j] * s_P[i * pw + c];
+                    sv *= s_R[j];
+                    s_P[j * pw + c] = sv;
+                    A[(size_t)(j0 + j) * ld + cg] = sv;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 3. trailing update by MFMA: tiles (ti <= tk) of the m x (m+1) trailing block ----
+        // A wavefront takes FOUR tiles at a time: their 16 accumulator loads (L2 latency each) are in flight while the four independent
+        // MFMA chains run, instead of one load -> MFMA -> store round trip per tile.
+        if (m > 0) {
+            const int Tm = (m + kMB - 1) / kMB, Tc = (m + 1 + kMB - 1) / kMB;
+            const int ntile = Tm * Tc - Tm * (Tm - 1) / 2;   // tiles with ti <= tk (Tc >= Tm)
+            auto unrank = [&](int t, int& ti, int& tk) {      // row-major over the rows of the upper block triangle: row ti has Tc - ti tiles
+                ti = 0;
+                while (t >= Tc - ti) { t -= Tc - ti; ti++; }
+                tk = ti + t;
+            };
+            for (int t0 = wv * 4; t0 < ntile; t0 += (kMfmaThreads / 64) * 4) {
+                int ti[4], tk[4];
+                double* cptr[4][4];
+                double cval[4][4];
+                bool live[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = min(t0 + u, ntile - 1);
+                    unrank(t, ti[u], tk[u]);
+                    const int k = kMB * tk[u] + (lane & 15);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const int i = kMB * ti[u] + (lane >> 4) + 4 * g;
+                        live[u][g] = (t0 + u < ntile) && i < m && k <= m;
+                        cptr[u][g] = A + (size_t)(c0 + min(i, m - 1)) * ld + c0 + min(k, m);
+                        cval[u][g] = *cptr[u][g];
+                    }
+                }
+                v4f64 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sx = 0; sx < kMB / 4; sx++) {
+                    const int r = 4 * sx + (lane >> 4);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const double a = s_P[r * pw + kMB * ti[u] + (lane & 15)];
+                        const double bb = s_P[r * pw + kMB * tk[u] + (lane & 15)];
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[u], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (live[u][g]) *cptr[u][g] = cval[u][g] - acc[u][g];
+            }
+        }
+        __syncthreads();
+    }
+    const bool ok2 = s_ok != 0;
+    // ---- blocked back substitution U x = y (y = column n) ----
+    if (ok2) {
+        for (int i = tid; i < n; i += kMfmaThreads) s_x[i] = A[(size_t)i * ld + n];
+        __syncthreads();
+        const int nblk = (n + kMB - 1) / kMB;
+        for (int jb = nblk - 1; jb >= 0; jb--) {
+            const int j0 = jb * kMB, nb = min(kMB, n - j0);
+            if (tid < kMB * kMB) {
+                const int i = tid >> 4, k = tid & 15;
+                s_D[i][k] = (i < nb && k < nb && k >= i) ? A[(size_t)(j0 + i) * ld + j0 + k] : (i == k ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            if (wv == 0) {   // 16x16 upper-triangular solve: lane l < nb holds y_l
+                double y = lane < nb ? s_x[j0 + lane] : 0.0;
+                const double rd = lane < nb ? 1.0 / s_D[lane][lane] : 0.0;
+                for (int i = nb - 1; i >= 0; i--) {
+                    const double xi = __shfl(y * rd, i, 64);
+                    if (lane < i) y -= s_D[lane][i] * xi;
+                    if (lane == i) y = xi;
+                }
+                if (lane < nb) s_x[j0 + lane] = y;
+            }
+            __syncthreads();
+            for (int r = tid; r < j0; r += kMfmaThreads) {   // rows above the block: y_r -= U[r][j0 .. j0+nb) x_blk
+                double sv = 0;
+                for (int c = 0; c < nb; c++) sv += A[(size_t)r * ld + j0 + c] * s_x[j0 + c];
+                s_x[r] -= sv;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += kMfmaThreads) pr.xp[i] = s_x[i];
+    } else {
+        for (int i = tid; i < n; i += kMfmaThreads) pr.xp[i] = 0;
+    }
+    if (tid == 0) ct->ok2 = ok2 ? 1 : 0;
+}
+
 // landmark back-substitution, trial state, computeScale partials
 __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws) {
     const LbaProblem& pr = probs[blockIdx.y];
@@ -1345,6 +1509,7 @@ struct oslam_lba {
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch
+    int chol_mode = 0;            // reduced-system solver: 0 auto (LDS-resident scalar kernel while it fits, matrix cores beyond), 1 always MFMA, 2 never
     struct Prep {                 // one prepared window: offsets into the `in` arena + host-side bookkeeping
         LbaProblem pr;            // scalar fields valid; pointers filled at launch
         size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
@@ -1449,12 +1614,14 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     oslam_lba* h = new oslam_lba();
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
+    if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
     if (hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     h->lds = kRowBufBytes + 64;
     if (hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_w_chol_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, kMB * (kMfmaMaxN + 2 * kMB) * (int)sizeof(double)) != hipSuccess) {
         set_error("hipFuncSetAttribute failed"); oslam_lba_destroy(h); return OSLAM_E_HIP;
     }
     *out = h;
@@ -1470,6 +1637,12 @@ int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
 int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
     if (!h) return OSLAM_E_INVALID;
     h->wide = wide != 0;
+    return OSLAM_OK;
+}
+
+int oslam_lba_set_solver(oslam_lba_t* h, int mode) {
+    if (!h || mode < 0 || mode > 2) { set_error("oslam_lba_set_solver: bad argument"); return OSLAM_E_INVALID; }
+    h->chol_mode = mode;
     return OSLAM_OK;
 }
 
@@ -1663,6 +1836,9 @@ static int lba_launch(oslam_lba_t* h) {
         hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, st, d_probs);
     } else {
         const size_t chol_lds = all_lds ? (size_t)max_n6 * (max_n6 + 1) * sizeof(double) : 0;
+        // systems beyond the LDS-resident kernel are factored by the matrix cores (k_w_chol_mfma); h->chol_mode 1 forces it, 2 forbids it
+        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds);
+        const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
         hipLaunchKernelGGL(k_w_init, dim3(1, n), dim3(256), 0, st, d_probs, d_ws);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n), dim3(256), 0, st, d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
@@ -1674,7 +1850,8 @@ static int lba_launch(oslam_lba_t* h) {
                 hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n), dim3(64), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n), dim3(256), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n), dim3(64), 0, st, d_probs, d_ws);
-                if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n), dim3(1024), chol_lds, st, d_probs, d_ws);
+                if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws);
+                else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n), dim3(1024), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n), dim3(kWPt), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n), dim3(kWPt), 0, st, d_probs, d_ws);

@@ -112,6 +112,10 @@ class LocalBundleAdjuster:
         """wide=True: one problem over the whole GPU (multi-kernel LM); False: one workgroup per problem."""
         check(self.L.oslam_lba_set_mode(self.h, int(wide)))
 
+    def set_solver(self, mode):
+        """Reduced-camera-system solver of the wide mode: 0 auto, 1 matrix cores (MFMA f64) for every size, 2 never (include/oslam_hip.h)."""
+        check(self.L.oslam_lba_set_solver(self.h, C.c_int(mode)))
+
     def stop_flag(self):
         """The pbStopFlag: a pinned int visible to the running kernel (set [0] = 1 to abort)."""
         return self.L.oslam_lba_stop_flag(self.h)

@@ -89,3 +89,31 @@ def test_lba_batch_of_windows(oracle):
         o = oracle.local_bundle_adjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
         _compare(r, o)
     ba.close()
+
+
+@pytest.mark.parametrize("seed,KL,KF,P", [(3, 4, 2, 150), (5, 10, 0, 500), (6, 20, 20, 4000), (7, 13, 5, 1500)])
+def test_lba_matrix_core_solver_matches_oracle(oracle, seed, KL, KF, P):
+    """The reduced camera system factored by v_mfma_f64_16x16x4_f64 (k_w_chol_mfma) for every size, including systems whose order is not a
+    multiple of the 16-wide panel (n = 24, 54, 120, 78)."""
+    q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, stereo_frac=[0.85, 1.0, 0.0][seed % 3])
+    ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536)
+    ba.set_solver(1)
+    a, o = _run(oracle, ba, q)
+    _compare(a, o)
+    ba.close()
+
+
+def test_lba_s5_large_matches_oracle(oracle):
+    """40 local + 60 fixed keyframes, 10 000 points, ~59 000 edges: the reduced system (n = 240) is beyond the LDS-resident
+    kernel and goes through the matrix-core Cholesky; the batch form runs two such windows with a small one in one launch."""
+    q = synth.make_lba_problem(1234, K_local=40, K_fixed=60, P=10000)
+    ba = LocalBundleAdjuster(max_batch=4, max_keyframes=128, max_points=8192, max_edges=65536)
+    a, o = _run(oracle, ba, q)
+    _compare(a, o)
+    small = synth.make_lba_problem(3, K_local=4, K_fixed=2, P=150)
+    outs = ba.LocalBundleAdjustmentBatch([q, small, q], q["K"])
+    for out in (outs[0], outs[2]):
+        assert np.array_equal(out[0].reshape(-1, 16), a[0].reshape(-1, 16)) and np.array_equal(out[1], a[1]) and np.array_equal(out[2], a[2])
+    so = oracle.local_bundle_adjustment(small["poses"], small["fixed"], small["points"], small["edge_kf"], small["edge_pt"], small["edge_obs"], small["edge_invSigma2"], small["K"])
+    _compare(outs[1], so)
+    ba.close()
