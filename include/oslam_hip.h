@@ -496,6 +496,10 @@ int oslam_frame_image_bounds(oslam_frame_t* h, int cols, int rows, const float K
  * depth image is an error (the reference would read out of bounds). */
 int oslam_frame_stereo_from_rgbd(oslam_frame_t* h, int n, const oslam_keypoint_t* keys, const oslam_keypoint_t* keysUn, const float* depth, int rows,
                                  int cols, int pitch, float mbf, float* uRight, float* mvDepth);
+/* n images given by a table of device pointers (rows src_pitch bytes apart) gathered into one contiguous batch [n][rows][dst_pitch]: the extractor's input
+ * layout, in one launch. */
+int oslam_frame_gather_images_device(const void* const* d_src_ptrs, int n, int src_pitch, int row_bytes, int rows, void* d_dst, size_t dst_image_stride, int dst_pitch,
+                                     void* stream);
 int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
                                               int stride, int batch, const float* d_depth, int rows, int cols, int pitch, size_t image_stride,
                                               float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);

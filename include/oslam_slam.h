@@ -215,7 +215,9 @@ int oslam_slam_keyframe_trajectory(oslam_slam_t* h, int seq, int cap, double* st
  * [10] points triangulated, [11] keyframes culled, [12] map points culled, [13] last mnMatchesInliers, [14] LBA edges total, [15] map-consistency violations (0). */
 int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]);
 /* Wall-clock seconds spent per stage since creation: [0] frames, [1] search_last, [2] pose_opt, [3] search_local, [4] host tracking,
- * [5] mp_update, [6] lba, [7] host mapping, [8] fuse/bow/triangulate. */
+ * [5] mp_update, [6] lba, [7] host mapping, [8] fuse/bow/triangulate; sub-splits of [7]: [9] ProcessNewKeyFrame / UpdateConnections / MapPointCulling,
+ * [10] CreateNewMapPoints, [11] SearchInNeighbors, [12] LocalBundleAdjustment gather + write-back, [13] KeyFrameCulling; of [4]: [14] motion model /
+ * reference keyframe / after-tracking bookkeeping, [15] UpdateLocalMap + SearchLocalPoints + pose job. */
 int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]);
 /* Device time of the kernel groups of the HIP operator table, measured with HIP events on the stream each group is launched on
  * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:

@@ -85,6 +85,18 @@ static int fill_undistort(UndistortCtx& c, const float K4[4], const float* dist,
     return OSLAM_OK;
 }
 
+// Gathers n images given by a table of device pointers into one contiguous batch [n][rows][dst_pitch] (the extractor's input layout): ONE launch
+// instead of n 2-D copies.  16-byte chunks where source and destination rows are 16-byte aligned, bytes otherwise.
+__global__ __launch_bounds__(256) void k_gather_images(const uint8_t* const* src, int src_pitch, int row_bytes, uint8_t* dst, size_t dst_image_stride, int dst_pitch) {
+    const int row = blockIdx.y, img = blockIdx.z;
+    const uint8_t* s = src[img] + (size_t)row * src_pitch;
+    uint8_t* d = dst + (size_t)img * dst_image_stride + (size_t)row * dst_pitch;
+    const bool wide = (((uintptr_t)s | (uintptr_t)d) & 15) == 0;
+    const int nchunk = wide ? row_bytes >> 4 : 0;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < nchunk; c += gridDim.x * 256) ((uint4*)d)[c] = ((const uint4*)s)[c];
+    for (int b = nchunk * 16 + blockIdx.x * 256 + threadIdx.x; b < row_bytes; b += gridDim.x * 256) d[b] = s[b];
+}
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -137,6 +149,13 @@ int oslam_frame_undistort_batch_device(const oslam_keypoint_t* d_keys, oslam_key
     if (rc) return rc;
     c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
     hipLaunchKernelGGL(k_undistort, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_frame_gather_images_device(const void* const* d_src_ptrs, int n, int src_pitch, int row_bytes, int rows, void* d_dst, size_t dst_image_stride, int dst_pitch, void* stream) {
+    if (!d_src_ptrs || !d_dst || n < 1 || rows < 1 || row_bytes < 1 || src_pitch < row_bytes || dst_pitch < row_bytes) { set_error("gather_images: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_gather_images, dim3(1, rows, n), dim3(256), 0, (hipStream_t)stream, (const uint8_t* const*)d_src_ptrs, src_pitch, row_bytes, (uint8_t*)d_dst, dst_image_stride, dst_pitch);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }

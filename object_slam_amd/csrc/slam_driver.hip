@@ -573,7 +573,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         }
     });
     merge_upd();
-    c.sec[7] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; }
     if ((rc = upd.run(c, true, true))) return rc;
     c.sec[5] += tm.lap();
     pool.parallel_for(nW, [&](int w) {
@@ -582,7 +582,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         s.map.nKFsInMap++;
         if (flags & 1) map_point_culling(s);
     });
-    c.sec[7] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; }
 
     // --- CreateNewMapPoints (:208-453): neighbours in lockstep (the matches of neighbour i see the points created from neighbour i-1) ---
     if (flags & 2) {
@@ -637,7 +637,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             });
             for (size_t w = 0; w < who.size(); w++) if (have[w]) { bj.push_back(cand[w]); bjw.push_back((int)w); }
             if (bj.empty()) continue;
-            c.sec[7] += tm.lap();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
             if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             std::vector<oslam_job_triangulate_t> tj(bj.size());
             std::vector<std::vector<int32_t>> i1(bj.size()), i2(bj.size());
@@ -676,7 +676,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     upd.add(si, p);
                 }
             }
-            c.sec[7] += tm.lap();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
             if ((rc = upd.run(c, true, true))) return rc;
             c.sec[5] += tm.lap();
         }
@@ -730,14 +730,14 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 j.M = (int)fs[w].q.size(); j.queries = fs[w].q.data(); j.q_match = fs[w].qm.data();
                 jobs.push_back(j); jw.push_back((int)w);
             }
-            c.sec[7] += tm.lap();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
             if (jobs.empty()) return OSLAM_OK;
             int rc2 = c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
             if (rc2) return rc2;
             c.sec[8] += tm.lap();
             pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].qpt, fs[w].qm.data()); });
             merge_upd();
-            c.sec[7] += tm.lap();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
             rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
             c.sec[5] += tm.lap();
             return rc2;
@@ -767,11 +767,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (int p : s.map.kfs[s.curKF].mp)
                 if (p >= 0 && !s.map.mps[p].bad) upd.add(si, p);
         }
-        c.sec[7] += tm.lap();
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
         if ((rc = upd.run(c, true, true))) return rc;
         c.sec[5] += tm.lap();
         for (int si : who) { Seq& s = *c.seq[si]; s.map.update_connections(s.curKF, s.counter); }
-        c.sec[7] += tm.lap();
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
     }
 
     // --- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:453-778), all windows in one batch ---
@@ -843,7 +843,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             p.nE = (int)W.ekf.size(); p.edge_kf = W.ekf.data(); p.edge_pt = W.ept.data(); p.edge_obs = W.eobs.data(); p.edge_invSigma2 = W.einv.data();
             p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data(); p.stats = nullptr;
         }
-        c.sec[7] += tm.lap();
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; }
         if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
         c.sec[6] += tm.lap();
         pool.parallel_for((int)wins.size(), [&](int wi) {
@@ -872,7 +872,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
         });
         merge_upd();
-        c.sec[7] += tm.lap();
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; }
         if ((rc = upd.run(c, false, true))) return rc;
         c.sec[5] += tm.lap();
     }
@@ -905,7 +905,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; }
             }
         });
-    c.sec[7] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; }
     return OSLAM_OK;
 }
 
@@ -1248,7 +1248,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     std::vector<oslam_job_search_last_t> sl;
     std::vector<int> slw;
     for (int i : tracking) if (c.seq[i]->hasSL) { sl.push_back(c.seq[i]->jSL); slw.push_back(i); }
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
     if (!sl.empty()) {
         if ((rc = c.ops.search_last(c.ops.ctx, (int)sl.size(), sl.data()))) return rc;
         std::vector<oslam_job_search_last_t> again;
@@ -1273,7 +1273,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         for (int k = 0; k < f.N; k++) f.mp[k] = s.jMatch[k] >= 0 ? l.mp[s.jMatch[k]] : -1;
         fill_pose_job(c, s, pjw[q], s.jPose);
     });
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
     if ((rc = run_pose_jobs(c, pjw))) return rc;
     c.sec[2] += tm.lap();
     pool.parallel_for((int)pjw.size(), [&](int q) {
@@ -1309,7 +1309,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 j.s2.nNodes = (int)bv[q].nodes.size(); j.s2.nodes = bv[q].nodes.data(); j.s2.start = bv[q].start.data(); j.s2.items = bv[q].items.data();
                 j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();
             });
-            c.sec[4] += tm.lap();
+            { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
             if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             c.sec[8] += tm.lap();
             pjw.clear();
@@ -1338,7 +1338,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     std::vector<oslam_job_search_local_t> lj;
     std::vector<int> ljw;
     for (int i : tracking) if (c.seq[i]->hasLoc) { lj.push_back(c.seq[i]->jLoc); ljw.push_back(i); }
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; }
     if (!lj.empty() && (rc = c.ops.search_local(c.ops.ctx, (int)lj.size(), lj.data()))) return rc;
     c.sec[3] += tm.lap();
     pool.parallel_for((int)ljw.size(), [&](int q) {
@@ -1353,7 +1353,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             fill_pose2_job(c, s, ljw[q]);
         }
     });
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; }
     {
         std::vector<int> plain, sem;
         for (int i : ljw) (c.seq[i]->hasPose2 ? sem : plain).push_back(i);
@@ -1380,7 +1380,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (!s.newKFs.empty()) mapping.push_back(i);
         for (int p : s.updList) upd.add(i, p);
     }
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
     if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
     c.sec[5] += tm.lap();
     // store relative poses (:569-585), swap frames
@@ -1406,7 +1406,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (state_out) state_out[i] = s.state;
         if (s.state != ST_NOT_INITIALIZED) std::swap(s.cur, s.last);   // mLastFrame = Frame(mCurrentFrame)
     }
-    c.sec[4] += tm.lap();
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
     return run_local_mapping(c, mapping);
 }
 

@@ -166,11 +166,13 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H, dimg = (size_t)W * H;
-    if (on_device) {
-        for (int i = 0; i < n; i++) {
-            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, gray[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
-            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_depth + dimg * i, (size_t)W * 4, depth[i], (size_t)depth_pitch * 4, (size_t)W * 4, H, hipMemcpyDeviceToDevice, o->strm));
-        }
+    if (on_device) {   // two pointer tables up, two gather launches (instead of 2n two-dimensional copies)
+        OPS_CHECK(o->ensure_up(16 * (size_t)n + 512));
+        memcpy(o->up_h, gray, 8 * (size_t)n); memcpy(o->up_h + 8 * (size_t)n + 256 - (8 * (size_t)n) % 256, depth, 8 * (size_t)n);
+        const size_t oD = 8 * (size_t)n + 256 - (8 * (size_t)n) % 256;
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, oD + 8 * (size_t)n, hipMemcpyHostToDevice, o->strm));
+        OPS_CHECK(oslam_frame_gather_images_device((const void* const*)o->up_d, n, gray_stride, W, H, o->d_gray, gimg, (int)o->gray_pitch, o->strm));
+        OPS_CHECK(oslam_frame_gather_images_device((const void* const*)(o->up_d + oD), n, depth_pitch * 4, W * 4, H, o->d_depth, dimg * 4, W * 4, o->strm));
     } else {
         // host images: rows packed into the pinned block in the device layout (parallel), then ONE copy per plane (a pageable 2-D copy is row-by-row)
         OPS_CHECK(o->ensure_up((gimg + dimg * 4) * n));
@@ -209,10 +211,12 @@ int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* 
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H;
     if (on_device) {
-        for (int i = 0; i < n; i++) {
-            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_gray + gimg * i, o->gray_pitch, left[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
-            OSLAM_HIP_CHECK(hipMemcpy2DAsync(o->d_grayR + gimg * i, o->gray_pitch, right[i], gray_stride, W, H, hipMemcpyDeviceToDevice, o->strm));
-        }
+        OPS_CHECK(o->ensure_up(16 * (size_t)n + 512));
+        const size_t oD = 8 * (size_t)n + 256 - (8 * (size_t)n) % 256;
+        memcpy(o->up_h, left, 8 * (size_t)n); memcpy(o->up_h + oD, right, 8 * (size_t)n);
+        OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, oD + 8 * (size_t)n, hipMemcpyHostToDevice, o->strm));
+        OPS_CHECK(oslam_frame_gather_images_device((const void* const*)o->up_d, n, gray_stride, W, H, o->d_gray, gimg, (int)o->gray_pitch, o->strm));
+        OPS_CHECK(oslam_frame_gather_images_device((const void* const*)(o->up_d + oD), n, gray_stride, W, H, o->d_grayR, gimg, (int)o->gray_pitch, o->strm));
     } else {
         OPS_CHECK(o->ensure_up(2 * gimg * n));
         uint8_t* U = o->up_h;

@@ -90,18 +90,25 @@ class _Inputs:
         return np.array([T0inv @ x for x in T])
 
 
-def _drive(system, wl, inp, seq_ids, t0, t1, poses_out=None):
+def _prepare(system, wl, inp, seq_ids, n_frames):
+    """The call arguments of every step of one handle, marshalled once (the frame loop then only crosses the C boundary)."""
     S = len(seq_ids)
-    for t in range(t0, t1):
+    out = []
+    for t in range(n_frames):
         stamps = [t / wl.fps] * S
         if wl.sensor == slam.STEREO:
-            left = [inp.frame(g, t, "gray") for g in seq_ids]
-            right = [inp.frame(g, t, "right") for g in seq_ids]
-            T, _ = system.TrackStereo(left, right, stamps, on_device=inp.on_device, stride=inp.pitch)
+            out.append(system.prepare_stereo([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "right") for g in seq_ids], stamps,
+                                             on_device=inp.on_device, stride=inp.pitch))
         else:
             objs = [inp.objects(g, t) for g in seq_ids] if inp.has_masks else None
-            T, _ = system.TrackRGBD([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "depth") for g in seq_ids], stamps, objects=objs,
-                                    on_device=inp.on_device, gray_stride=inp.pitch, depth_pitch=wl.width, mask_stride=wl.width)
+            out.append(system.prepare_rgbd([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "depth") for g in seq_ids], stamps, objects=objs,
+                                           on_device=inp.on_device, gray_stride=inp.pitch, depth_pitch=wl.width, mask_stride=wl.width))
+    return out
+
+
+def _drive(system, wl, calls, t0, t1, poses_out=None):
+    for t in range(t0, t1):
+        T, _ = system.track_stereo_prepared(calls[t]) if wl.sensor == slam.STEREO else system.track_prepared(calls[t])
         if poses_out is not None:
             poses_out.append(T.copy())
 
@@ -140,13 +147,14 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
                                device=(device.index if hasattr(device, "index") and device.index is not None else 0) if on_device else 0, host_threads=host_threads)
         systems.append(make_system(cfg))
     poses = [[] for _ in range(handles)] if collect_poses else [None] * handles
+    calls = [_prepare(systems[h], wl, inp, groups[h], n_frames) for h in range(handles)]
 
     def sync():
         if on_device:
             torch.cuda.synchronize()
 
     def phase(t0, t1):
-        ths = [threading.Thread(target=_drive, args=(systems[h], wl, inp, groups[h], t0, t1, poses[h])) for h in range(handles)]
+        ths = [threading.Thread(target=_drive, args=(systems[h], wl, calls[h], t0, t1, poses[h])) for h in range(handles)]
         for th in ths:
             th.start()
         for th in ths:

@@ -81,6 +81,44 @@ class System:
         except Exception:   # interpreter shutdown: module globals may already be gone
             pass
 
+    def prepare_rgbd(self, gray, depth, timestamps=None, objects=None, on_device=False, gray_stride=None, depth_pitch=None, mask_stride=None):
+        """Marshals one TrackRGBD call ahead of time (pointer tables as ctypes arrays): callers that replay recorded streams keep the Python work out of
+        their frame loop.  Returns an opaque tuple for `track_prepared`; the arrays behind the pointers must stay alive."""
+        gp, dp = (C.c_void_p * self.S)(), (C.c_void_p * self.S)()
+        for i in range(self.S):
+            gp[i] = gray[i] if on_device else gray[i].__array_interface__["data"][0]
+            dp[i] = depth[i] if on_device else depth[i].__array_interface__["data"][0]
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        gs = gray_stride if on_device else gray[0].strides[0]
+        dpp = depth_pitch if on_device else depth[0].strides[0] // 4
+        arr = keep = None
+        ms = 0
+        if objects is not None:
+            arr, ms, keep = self._objects(objects, on_device)
+            ms = mask_stride if on_device else (ms or self.cfg.width)
+        return (gp, dp, ts, C.c_int(gs), C.c_int(dpp), C.c_int(1 if on_device else 0), arr, C.c_int(ms), keep, (gray, depth, objects))
+
+    def track_prepared(self, prep):
+        gp, dp, ts, gs, dpp, dev, arr, ms, _, _ = prep
+        if arr is not None:
+            check(self.L.oslam_slam_track_rgbd_objects(self.h, gp, gs, dp, dpp, dev, ptr(ts) if ts is not None else None, arr, ms, ptr(self.Tcw), ptr(self.state)))
+        else:
+            check(self.L.oslam_slam_track_rgbd(self.h, gp, gs, dp, dpp, dev, ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
+        return self.Tcw, self.state
+
+    def prepare_stereo(self, left, right, timestamps=None, on_device=False, stride=None):
+        gp, rp = (C.c_void_p * self.S)(), (C.c_void_p * self.S)()
+        for i in range(self.S):
+            gp[i] = left[i] if on_device else left[i].__array_interface__["data"][0]
+            rp[i] = right[i] if on_device else right[i].__array_interface__["data"][0]
+        ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
+        return (gp, rp, ts, C.c_int(stride if on_device else left[0].strides[0]), C.c_int(1 if on_device else 0), (left, right))
+
+    def track_stereo_prepared(self, prep):
+        gp, rp, ts, st, dev, _ = prep
+        check(self.L.oslam_slam_track_stereo(self.h, gp, rp, st, dev, ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
+        return self.Tcw, self.state
+
     def _objects(self, objects, on_device):
         """objects: per sequence None or dict(masks = list of uint8 [H,W] arrays (device addresses with on_device), track_ids, labels (optional)).
         Returns (array of SlamObjects, mask stride in bytes, keep-alive list)."""
@@ -204,5 +242,6 @@ class System:
     def stage_seconds(self):
         out = np.zeros(16, np.float64)
         check(self.L.oslam_slam_stage_seconds(self.h, ptr(out)))
-        names = ("frames", "search_last", "pose_opt", "search_local", "host_tracking", "mp_update", "lba", "host_mapping", "fuse_bow_triangulate")
-        return dict(zip(names, out[:9].tolist()))
+        names = ("frames", "search_last", "pose_opt", "search_local", "host_tracking", "mp_update", "lba", "host_mapping", "fuse_bow_triangulate",
+                 "hm_process_kf", "hm_create_points", "hm_search_neighbors", "hm_lba_gather", "hm_kf_culling", "ht_initial_and_after", "ht_local_map")
+        return dict(zip(names, out[:16].tolist()))
