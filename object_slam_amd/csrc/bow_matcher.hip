@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "slam_pool.h"
 
 namespace oslam {
 
@@ -360,7 +361,7 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
     uint8_t* H = h->st_h;
     uint8_t* D = h->st_d;
     BowCtx* cs = (BowCtx*)H;
-    for (int i = 0; i < n; i++) {
+    oslam_drv::shared_parallel_for(n, [&](int i) {   // ~140 KB of keypoints / descriptors per job
         const oslam_bow_job_t& j = jobs[i];
         const oslam_bow_side1_t& s1 = j.s1;
         const oslam_bow_side2_t& s2 = j.s2;
@@ -389,7 +390,7 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
             c.sigma2[k] = (levelSigma2 && k < nlevels) ? levelSigma2[k] : 0.f;
         }
         c.out = (int*)(D + o.out); c.nmatches = (int*)(D + o.nm); c.q_best = (int*)(D + o.qbest);
-    }
+    });
     if (!h->strm) OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, h->strm));
     hipLaunchKernelGGL(k_search_bow_batch, dim3(n), dim3(kBowThreads), h->lds, h->strm, (const BowCtx*)D, h->max_kps);

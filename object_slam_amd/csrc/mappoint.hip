@@ -186,6 +186,9 @@ struct oslam_mappoint {
     int device = 0;
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf a, b, c, d, e, e2, f, g, g2, o1, o2;
+    // batch form (oslam_mp_triangulate_pairs): one pinned block mirrored on the device, one stream — ONE upload, one launch, ONE download per call
+    uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;
+    hipStream_t strm = nullptr;
 };
 
 static int mp_ensure(oslam_mappoint::Buf& b, size_t bytes) {
@@ -210,6 +213,9 @@ void oslam_mappoint_destroy(oslam_mappoint_t* h) {
     oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->e2, &h->f, &h->g, &h->g2, &h->o1, &h->o2};
     for (auto* b : bs)
         if (b->p) (void)hipFree(b->p);
+    if (h->st_h) (void)hipHostFree(h->st_h);
+    if (h->st_d) (void)hipFree(h->st_d);
+    if (h->strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
 
@@ -650,10 +656,33 @@ extern "C" int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const
     const int M = nPairs ? pair_start[nPairs] : 0;
     if (M == 0) return OSLAM_OK;
     if (M < 0 || !idx1 || !idx2 || !ok || !x3D || pair_start[0] != 0) { set_error("bad match table"); return OSLAM_E_INVALID; }
-    std::vector<int> pair_of(M), d1(M), d2(M);
-    std::vector<TriKfDev> dev1(nPairs), dev2(nPairs);
-    std::vector<oslam_keypoint_t> kun((size_t)2 * M), kraw((size_t)2 * M);
-    std::vector<float> ur((size_t)2 * M), dep((size_t)2 * M);
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    // layout of the staging block: inputs, then outputs
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t total = (size_t)2 * M;
+    const size_t o_kun = take(total * sizeof(oslam_keypoint_t)), o_kraw = take(total * sizeof(oslam_keypoint_t)), o_ur = take(total * 4), o_dep = take(total * 4),
+                 o_dev1 = take((size_t)nPairs * sizeof(TriKfDev)), o_dev2 = take((size_t)nPairs * sizeof(TriKfDev)), o_pair = take((size_t)M * 4), o_d1 = take((size_t)M * 4),
+                 o_d2 = take((size_t)M * 4);
+    const size_t in_bytes = at;
+    const size_t o_ok = take((size_t)M), o_x3 = take((size_t)M * 12);
+    if (at > h->st_cap) {
+        OSLAM_HIP_CHECK(hipDeviceSynchronize());
+        if (h->st_h) (void)hipHostFree(h->st_h);
+        if (h->st_d) (void)hipFree(h->st_d);
+        h->st_h = nullptr; h->st_d = nullptr; h->st_cap = 0;
+        const size_t ncap = at + at / 2 + 4096;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->st_h, ncap, 0));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&h->st_d, ncap));
+        h->st_cap = ncap;
+    }
+    if (!h->strm) OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking));
+    uint8_t* H = h->st_h;
+    uint8_t* D = h->st_d;
+    int* pair_of = (int*)(H + o_pair); int* d1 = (int*)(H + o_d1); int* d2 = (int*)(H + o_d2);
+    TriKfDev* dev1 = (TriKfDev*)(H + o_dev1); TriKfDev* dev2 = (TriKfDev*)(H + o_dev2);
+    oslam_keypoint_t* kun = (oslam_keypoint_t*)(H + o_kun); oslam_keypoint_t* kraw = (oslam_keypoint_t*)(H + o_kraw);
+    float* ur = (float*)(H + o_ur); float* dep = (float*)(H + o_dep);
     auto fill = [](TriKfDev& d, const oslam_tri_kf_t& k) {
         for (int i = 0; i < 16; i++) { d.Tcw[i] = k.Tcw[i]; d.Twc[i] = k.Twc[i]; }
         d.fx = k.fx; d.fy = k.fy; d.cx = k.cx; d.cy = k.cy; d.invfx = k.invfx; d.invfy = k.invfy; d.mbf = k.mbf; d.mb = k.mb;
@@ -674,27 +703,21 @@ extern "C" int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const
             kun[(size_t)2 * m + 1] = b.keysUn[idx2[m]]; kraw[(size_t)2 * m + 1] = b.keys[idx2[m]]; ur[(size_t)2 * m + 1] = b.uRight[idx2[m]]; dep[(size_t)2 * m + 1] = b.depth[idx2[m]];
         }
     }
-    OSLAM_HIP_CHECK(hipSetDevice(h->device));
-    int rc;
-    const size_t total = (size_t)2 * M;
-    if ((rc = mp_up(h->a, kun.data(), total * sizeof(oslam_keypoint_t))) || (rc = mp_up(h->b, kraw.data(), total * sizeof(oslam_keypoint_t))) ||
-        (rc = mp_up(h->c, ur.data(), total * 4)) || (rc = mp_up(h->d, dep.data(), total * 4)) || (rc = mp_up(h->e, dev2.data(), dev2.size() * sizeof(TriKfDev))) ||
-        (rc = mp_up(h->e2, dev1.data(), dev1.size() * sizeof(TriKfDev))) || (rc = mp_up(h->f, pair_of.data(), (size_t)M * 4)) ||
-        (rc = mp_up(h->g, d1.data(), (size_t)M * 4)) || (rc = mp_up(h->g2, d2.data(), (size_t)M * 4)) || (rc = mp_ensure(h->o1, (size_t)M)) ||
-        (rc = mp_ensure(h->o2, (size_t)M * 12)))
-        return rc;
+    OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, h->strm));
     TriCtx c;
     c.M = M; c.nLevels = nLevels;
     fill(c.kf1, kf1[0]);
-    c.kf1s = (const TriKfDev*)h->e2.p;
-    c.kf2 = (const TriKfDev*)h->e.p; c.pair_of = (const int*)h->f.p; c.idx1 = (const int*)h->g.p; c.idx2 = (const int*)h->g2.p;
-    c.keysUn = (const oslam_keypoint_t*)h->a.p; c.keys = (const oslam_keypoint_t*)h->b.p; c.uRight = (const float*)h->c.p; c.depth = (const float*)h->d.p;
+    c.kf1s = (const TriKfDev*)(D + o_dev1);
+    c.kf2 = (const TriKfDev*)(D + o_dev2); c.pair_of = (const int*)(D + o_pair); c.idx1 = (const int*)(D + o_d1); c.idx2 = (const int*)(D + o_d2);
+    c.keysUn = (const oslam_keypoint_t*)(D + o_kun); c.keys = (const oslam_keypoint_t*)(D + o_kraw); c.uRight = (const float*)(D + o_ur); c.depth = (const float*)(D + o_dep);
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) { c.scale[i] = i < nLevels ? scaleFactors[i] : 1.f; c.sigma2[i] = i < nLevels ? levelSigma2[i] : 1.f; }
     c.ratioFactor = ratioFactor;
-    c.ok = (uint8_t*)h->o1.p; c.x3D = (float*)h->o2.p;
-    hipLaunchKernelGGL(k_triangulate, dim3(div_up(M, 128)), dim3(128), 0, nullptr, c);
+    c.ok = D + o_ok; c.x3D = (float*)(D + o_x3);
+    hipLaunchKernelGGL(k_triangulate, dim3(div_up(M, 128)), dim3(128), 0, h->strm, c);
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(hipMemcpy(ok, h->o1.p, (size_t)M, hipMemcpyDeviceToHost));
-    OSLAM_HIP_CHECK(hipMemcpy(x3D, h->o2.p, (size_t)M * 12, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(H + o_ok, D + o_ok, at - in_bytes, hipMemcpyDeviceToHost, h->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    memcpy(ok, H + o_ok, (size_t)M);
+    memcpy(x3D, H + o_x3, (size_t)M * 12);
     return OSLAM_OK;
 }

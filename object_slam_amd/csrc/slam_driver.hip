@@ -274,16 +274,19 @@ struct MpUpdate {
         j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
         const int rc = c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
-        // (an item can be listed twice after fusions; both copies carry the same result)
-        for (int i = 0; i < P; i++) {
-            if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
-            MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
-            if (do_desc) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);
-            if (do_normal) {
-                const float* o = &out5[(size_t)i * 5];
-                p.normal[0] = o[0]; p.normal[1] = o[1]; p.normal[2] = o[2]; p.maxD = o[3]; p.minD = o[4];
+        // (an item can be listed twice after fusions; both copies carry the same result, so concurrent writers store the same bytes)
+        c.pool->parallel_for(nchunks, [&](int ch) {
+            const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
+            for (int i = i0; i < i1; i++) {
+                if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
+                MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
+                if (do_desc) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);
+                if (do_normal) {
+                    const float* o = &out5[(size_t)i * 5];
+                    p.normal[0] = o[0]; p.normal[1] = o[1]; p.normal[2] = o[2]; p.maxD = o[3]; p.minD = o[4];
+                }
             }
-        }
+        });
         return OSLAM_OK;
     }
 };
@@ -643,7 +646,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             std::vector<std::vector<int32_t>> i1(bj.size()), i2(bj.size());
             std::vector<std::vector<uint8_t>> okv(bj.size());
             std::vector<std::vector<float>> x3(bj.size());
-            for (size_t q = 0; q < bj.size(); q++) {
+            pool.parallel_for((int)bj.size(), [&](int q) {
                 const size_t w = bjw[q];
                 Seq& s = *c.seq[who[w]];
                 const KeyFrm& k1 = s.map.kfs[s.curKF];
@@ -654,14 +657,12 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 t.M = (int)i1[q].size(); t.idx1 = i1[q].data(); t.idx2 = i2[q].data();
                 okv[q].assign(t.M + 1, 0); x3[q].assign((size_t)t.M * 3 + 3, 0.f);
                 t.ok = okv[q].data(); t.x3D = x3[q].data();
-            }
+            });
             if ((rc = c.ops.triangulate(c.ops.ctx, (int)tj.size(), tj.data()))) return rc;
             c.sec[8] += tm.lap();
-            upd.clear();
-            for (size_t q = 0; q < bj.size(); q++) {
+            pool.parallel_for((int)bj.size(), [&](int q) {   // one job per sequence: independent maps
                 const size_t w = bjw[q];
-                const int si = who[w];
-                Seq& s = *c.seq[si];
+                Seq& s = *c.seq[who[w]];
                 Map& m = s.map;
                 const int k2 = neigh[w][ni];
                 for (int e = 0; e < tj[q].M; e++) {
@@ -673,9 +674,10 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     m.kfs[k2].mp[i2[q][e]] = p;
                     m.nMPsInMap++; s.st[3]++; s.st[10]++;
                     s.recentAdded.push_back(p);
-                    upd.add(si, p);
+                    s.updList.push_back(p);
                 }
-            }
+            });
+            merge_upd();
             { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
             if ((rc = upd.run(c, true, true))) return rc;
             c.sec[5] += tm.lap();
@@ -691,7 +693,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         std::vector<oslam_job_fuse_t> jobs;
         std::vector<int> jw;
         size_t maxt = 0;
-        for (size_t w = 0; w < who.size(); w++) {
+        pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];
             Map& m = s.map;
             const int cur = s.curKF;
@@ -705,8 +707,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
             }
             fs[w].pts.assign(m.kfs[cur].mp.begin(), m.kfs[cur].mp.end());   // vpMapPointMatches snapshot (:484)
-            maxt = std::max(maxt, fs[w].targets.size());
-        }
+        });
+        for (size_t w = 0; w < who.size(); w++) maxt = std::max(maxt, fs[w].targets.size());
         auto fuse_round = [&](bool into_current, size_t t) -> int {
             jobs.clear(); jw.clear();
             pool.parallel_for(nW, [&](int w) {
@@ -745,7 +747,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         for (size_t t = 0; t < maxt; t++)
             if ((rc = fuse_round(false, t))) return rc;
         // the targets' points into the current keyframe (:492-515)
-        for (size_t w = 0; w < who.size(); w++) {
+        pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];
             Map& m = s.map;
             const int cur = s.curKF;
@@ -758,7 +760,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     mp.fuseCandidateForKF = cur;
                     fs[w].pts.push_back(p);
                 }
-        }
+        });
         if ((rc = fuse_round(true, 0))) return rc;
         // update points of the current keyframe (:517-531) and its connections
         upd.clear();
@@ -770,7 +772,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
         if ((rc = upd.run(c, true, true))) return rc;
         c.sec[5] += tm.lap();
-        for (int si : who) { Seq& s = *c.seq[si]; s.map.update_connections(s.curKF, s.counter); }
+        pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; s.map.update_connections(s.curKF, s.counter); });
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
     }
 
