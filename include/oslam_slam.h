@@ -32,6 +32,14 @@
  *     Object3D from the Object2D's keypoints with map points when there are more than MIN_OBJ3DMP_NUM = 5 of them, later frames append the
  *     non-bad, non-outlier map points not yet listed — without the PCL Euclidean clustering / RejectOutliers steps.
  */
+/* Limits of the HIP operator table (the reference's containers are unbounded):
+ *   - keypoints per frame: the extractor's capacity (sum of the level quotas + slack, oslam_orb_max_keypoints) — never exceeded by construction;
+ *   - local map points searched per frame (Tracking::SearchLocalPoints): no fixed bound, the matcher's query buffers grow on demand;
+ *   - local BA: points and edges per window grow on demand; at most 128 keyframes (local + fixed) per window: fixed cameras beyond that are left
+ *     out of the window together with their observations (oslam_slam_object_stats [6] counts them) instead of failing the step;
+ *   - detections per frame: OSLAM_SLAM_MAX_OBJECTS.
+ * A capacity error of an operator (OSLAM_E_CAPACITY) aborts the lockstep step of ALL sequences of the handle: the map bookkeeping of that step has
+ * then partly run, so the handle must be discarded. */
 #ifndef OSLAM_SLAM_H
 #define OSLAM_SLAM_H
 
@@ -201,7 +209,8 @@ int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, i
 int oslam_slam_track_stereo_objects(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                                     const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
 /* Object layer counters of one sequence: [0] N_AllSemanticConstraintNum (src/ObjectOptimizer.cc:1233), [1] frames optimised with matched objects,
- * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built. */
+ * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] fixed keyframes left out of
+ * local-BA windows (see "Limits" below). */
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.

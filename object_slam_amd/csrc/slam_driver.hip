@@ -83,6 +83,8 @@ struct BowViews {
     }
 };
 
+constexpr int kMaxWindowKFs = 128;   // keyframes (local + fixed) per local-BA window: the limit of oslam_lba_create
+
 enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
 
 struct Ctx;
@@ -120,6 +122,7 @@ struct Seq {
     std::vector<Obj3D> obj3ds;
     std::map<int, int> objOfTrack;
     int64_t sem[8] = {0};
+    int64_t lbaFixedDropped = 0;           // fixed keyframes left out of local-BA windows because of the per-window keyframe limit
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
     std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj;
@@ -807,9 +810,12 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     KeyFrm& k = m.kfs[e.first];
                     if (k.baLocalForKF != cur && k.baFixedForKF != cur) {
                         k.baFixedForKF = cur;
-                        if (!k.bad) W.kfs.push_back(e.first);
+                        // the solver takes at most kMaxWindowKFs keyframes per window (include/oslam_slam.h): fixed cameras beyond that are left
+                        // out together with their observations (they only anchor the gauge; the reference has no bound), counted in stats
+                        if (!k.bad) { if ((int)W.kfs.size() < kMaxWindowKFs) W.kfs.push_back(e.first); else s.lbaFixedDropped++; }
                     }
                 }
+            if (W.nLocal > kMaxWindowKFs) { W.kfs.resize(kMaxWindowKFs); W.nLocal = kMaxWindowKFs; }
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
             W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());
@@ -1503,6 +1509,7 @@ int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, i
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
     if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_object_stats: bad argument"); return OSLAM_E_INVALID; }
     memcpy(out, h->c.seq[seq]->sem, sizeof(h->c.seq[seq]->sem));
+    out[6] = h->c.seq[seq]->lbaFixedDropped;
     return OSLAM_OK;
 }
 

@@ -319,8 +319,14 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     int maxM = 0;
     for (int i = 0; i < n; i++) {
         if (jobs[i].slot < 0 || jobs[i].slot >= (int)S) { oslam::set_error("search_local: bad slot"); return OSLAM_E_INVALID; }
-        if (jobs[i].M > o->max_local) { oslam::set_error("search_local: %d local points > capacity %d", jobs[i].M, o->max_local); return OSLAM_E_CAPACITY; }
         maxM = std::max(maxM, jobs[i].M);
+    }
+    if (maxM > o->max_local) {   // the reference's local map is unbounded: re-create the matcher with room to spare
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        oslam_matcher_destroy(o->m_map);
+        o->m_map = nullptr;
+        o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
+        OPS_CHECK(oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, o->cfg.device));
     }
     const size_t st = oslam::align_up((size_t)std::max(maxM, 1), 64);
     Layout L;
@@ -656,8 +662,15 @@ int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
     const size_t cap = o->cap, B = n;
     int maxM = 1;
     for (int i = 0; i < n; i++) {
-        if (jobs[i].M > o->max_local || jobs[i].N > (int)cap) { oslam::set_error("fuse: %d queries / %d keypoints exceed capacity", jobs[i].M, jobs[i].N); return OSLAM_E_CAPACITY; }
+        if (jobs[i].N > (int)cap) { oslam::set_error("fuse: %d keypoints exceed capacity", jobs[i].N); return OSLAM_E_CAPACITY; }
         maxM = std::max(maxM, jobs[i].M);
+    }
+    if (maxM > o->max_local) {
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        oslam_matcher_destroy(o->m_map);
+        o->m_map = nullptr;
+        o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
+        OPS_CHECK(oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, o->cfg.device));
     }
     const size_t st = oslam::align_up((size_t)maxM, 64);
     Layout L;
@@ -751,7 +764,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     int rc = oslam_orb_create(&o->orb, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
     if (!rc) {
         o->cap = oslam_orb_max_keypoints(o->orb);
-        o->max_local = 32768;
+        o->max_local = getenv("OSLAM_SLAM_MAX_LOCAL") ? atoi(getenv("OSLAM_SLAM_MAX_LOCAL")) : 8192;   // first reservation; grows on demand
         rc = oslam_matcher_create(&o->m_last, o->S, o->cap, o->cap, dev);
     }
     if (!rc) rc = oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, dev);

@@ -51,9 +51,15 @@ def test_tum_shape_stage_parity(oracle):
 
 
 def test_kitti_shape_stage_parity(oracle):
-    frames, _ = synth.make_stream(1, 1241, 376, seed=7)
-    n = _stages(oracle, KITTI, frames[0])
-    assert 1800 <= n <= 2100
+    """Full-size C-KITTI stage parity (pyramid, FAST cells, quad-tree, orientation, blur, descriptors) on 8 frames: 3 crops of the planar canvas and 5
+    frames (left and right cameras) of the street scene, whose facades at 5 - 60 m fill the pyramid levels unevenly."""
+    from object_slam_amd import scene
+    frames, _ = synth.make_stream(3, 1241, 376, seed=7)
+    st = scene.make_stereo_sequence(2, 3)
+    imgs = [frames[0], frames[1], frames[2], st["gray"][0], st["right"][0], st["gray"][1], st["gray"][2], st["right"][2]]
+    for i, im in enumerate(imgs):
+        n = _stages(oracle, KITTI, im)
+        assert (1800 if i < 3 else 1200) <= n <= 2100, (i, n)
 
 
 def test_odd_sizes_and_flat_images(oracle):

@@ -219,3 +219,39 @@ def test_hip_semantic_tracking_matches_oracle_driver(oracle):
     plain = slam.System(slam.make_config(W, H, 1))
     pp = np.array([plain.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0])[0][0].copy() for t in range(n)])
     assert np.abs(pp - ph).max() > 1e-5
+
+
+def test_local_search_capacity_grows_on_demand(oracle, monkeypatch):
+    """The reference's local map is unbounded.  With the first reservation of the local-point matcher forced below the size of the local map, the HIP
+    table re-creates the matcher instead of failing the step; the run equals the oracle table's."""
+    from slam_common import make_scene_streams, run_scene
+    monkeypatch.setenv("OSLAM_SLAM_MAX_LOCAL", "256")
+    n = 10
+    seqs = make_scene_streams(1, n)
+    hip = slam.System(slam.make_config(W, H, 1))
+    ph, sh = run_scene(hip, seqs, n)
+    cfg_o = slam.make_config(W, H, 1)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run_scene(ora, seqs, n)
+    assert np.array_equal(sh, so) and (sh == slam.OK).all() and hip.stats(0) == ora.stats(0)
+    assert np.abs(ph - po).max() < 4e-4
+
+
+def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle):
+    """Soak at the S1 specification: 200 frames at speed 1 (<= 2 cm, <= 0.5 deg per frame) with the three instance masks; the HIP and
+    the oracle operator tables must lead the driver through the same 200 frames (states, map statistics, object bookkeeping), ATE below 2 cm."""
+    from slam_common import ate_scene
+    from object_slam_amd import scene
+    n = 200
+    q = scene.make_rgbd_sequence(5, n, speed=1.0)
+    hip = slam.System(slam.make_config(W, H, 1))
+    ph = _semantic_run(hip, q, n)
+    cfg_o = slam.make_config(W, H, 1)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po = _semantic_run(ora, q, n)
+    a, b = hip.stats(0), ora.stats(0)
+    assert a == b, (a, b)
+    assert a["lost_frames"] == 0 and a["map_violations"] == 0 and a["keyframes_created"] >= 8 and a["local_bas"] >= 6 and a["semantic_frames_nonzero"] >= n - 3, a
+    assert np.abs(ph - po).max() < 4e-4, np.abs(ph - po).max()
+    ah, _ = ate_scene(hip, [q], 0)
+    assert ah < 0.02, ah
