@@ -202,19 +202,27 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
            "per_frame_us": {k: round(v, 3) for k, v in us.items()}, "alg_bytes_per_frame": {k: int(v) for k, v in alg.items()},
            "GBs": {k: round(alg[k] / (us[k] * 1e-6) / 1e9, 1) for k in us if us[k] > 0},
            "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * steps / dt / 1e9, 1),
-           "hamming_pairs_per_frame": round(pairs.value / B, 1)}
+           "hamming_pairs_per_frame": round(pairs.value / B, 1),
+           # committed PMC passes of this stage (profiles/r02_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
+           "pmc_hbm_KB_per_frame": {k: round(_pmc(k) / 512 / 1e3, 1) for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_blur_strip<true>", "k_octree",
+                                                                               "k_orient_describe", "k_search_window") if _pmc(k) is not None},
+           "pmc_valu_issue_frac": {k: _pmc(k, "valu_issue_frac_at_4_cycles") for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_octree", "k_orient_describe",
+                                                                                       "k_search_window") if _pmc(k, "valu_issue_frac_at_4_cycles") is not None},
+           "bound_note": "k_fast_cells_wave (70 %) and k_blur_strip (27 %) run concurrently and together saturate the VALU issue: the front-end phase is instruction bound, "
+                         "its GB/s figures are reported against the HBM roofline for completeness"}
     ex.close(); mt.close()
     return out
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this round (profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE passes of this same command, corrected as MI355X_MICROARCH.md §HBM prescribes); None when the summary has no row for it."""
+def _pmc(kernel, field="bytes_per_launch"):
+    """Per-launch PMC figure of `kernel` from the committed summary of this round (profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc passes of
+    the S2 stage at 512 frames per launch — FETCH_SIZE, WRITE_SIZE, SQ_* — corrected as MI355X_MICROARCH.md §HBM prescribes); None when the summary has
+    no row for it.  HBM bytes for the fp64 solver kernels were not collected (their bound is not HBM)."""
     path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     if not os.path.exists(path):
         return None
     try:
-        return json.load(open(path)).get(kernel, {}).get("bytes_per_launch")
+        return json.load(open(path)).get(kernel, {}).get(field)
     except Exception:
         return None
 
@@ -319,7 +327,9 @@ def main():
         k = kt["head"]
         names = {"frames": ("hbm", "Frame::Frame (k_resize_lds, k_fast_cells_wave, k_blur_strip, k_octree, k_orient_describe, undistort, depth lookup%s)"
                             % (", stereo association" if head is wl_st else "")),
-                 "pose_opt": ("mfma", "k_pose_optimize"), "lba": ("mfma", "k_lba")}
+                 "pose_opt": ("mfma", "k_pose_optimize"),
+                 "lba": ("mfma", "local BA, every LM trial of all windows as eight launches (k_w_lin, k_w_ctrlA, k_w_edgeW, k_w_schur, k_w_chol / k_w_chol_mfma, "
+                                 "k_w_update, k_w_eval, k_w_ctrlB)")}
         dom = max(names, key=lambda g: k[g]["ms"])
         bound, kname = names[dom]
         ms, launches, work = k[dom]["ms"], max(k[dom]["launches"], 1.0), k[dom]["work"]
@@ -339,7 +349,7 @@ def main():
             group_tab[g] = e
         busy = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
         roof = {"bound": bound, "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
-                "traffic": _pmc_traffic(kname.split(" ")[0]), "launch_us": round(ms / launches * 1e3, 1),
+                "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else None, "launch_us": round(ms / launches * 1e3, 1),
                 "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
                 "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4),
                 "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "
