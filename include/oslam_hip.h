@@ -265,6 +265,14 @@ typedef struct oslam_bow_job {
     int32_t nmatches;
 } oslam_bow_job_t;
 int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const float* scaleFactors, const float* levelSigma2, int nlevels);
+/* The same with device-resident copies of the keypoint (mvKeysUn), descriptor and mvuRight arrays of either side: res[i] members that are NULL fall back to
+ * the host arrays of jobs[i] (which are then packed and uploaded as above).  The resident arrays must be complete when the call is made. */
+typedef struct oslam_bow_resident {
+    const oslam_keypoint_t* d_keys1; const uint8_t* d_desc1; const float* d_uRight1;
+    const oslam_keypoint_t* d_keys2; const uint8_t* d_desc2; const float* d_uRight2;
+} oslam_bow_resident_t;
+int oslam_match_bow_batch_resident(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_bow_resident_t* res, const float* scaleFactors,
+                                   const float* levelSigma2, int nlevels);
 
 /* ------------------------------------------------------------------------------------------
  * Frame::ComputeStereoMatches (src/Frame.cc:706-880): row-band Hamming search of left keypoints in the
@@ -500,6 +508,10 @@ int oslam_frame_stereo_from_rgbd(oslam_frame_t* h, int n, const oslam_keypoint_t
  * layout, in one launch. */
 int oslam_frame_gather_images_device(const void* const* d_src_ptrs, int n, int src_pitch, int row_bytes, int rows, void* d_dst, size_t dst_image_stride, int dst_pitch,
                                      void* stream);
+/* Device-to-device helpers of the driver's resident keyframe store: n segments {const void* src; void* dst; uint32 bytes; uint32 pad} copied in one launch;
+ * d_out[i] = the 32-byte descriptor number d_rec[i][1] of the array d_desc_base[d_rec[i][0]]. */
+int oslam_copy_segments_device(const void* d_segs, int n, void* stream);
+int oslam_gather_descriptors_device(const uint8_t* const* d_desc_base, const int32_t* d_rec, int n, uint8_t* d_out, void* stream);
 int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
                                               int stride, int batch, const float* d_depth, int rows, int cols, int pitch, size_t image_stride,
                                               float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);

@@ -147,7 +147,8 @@ typedef struct oslam_job_pose2 {           /* ObjectOptimizer::PoseOptimization2
     int32_t n_semantic;                    /* out: nSemNum (:1232) */
 } oslam_job_pose2_t;
 
-typedef oslam_bow_job_t oslam_job_bow_t;   /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657), see oslam_hip.h */
+typedef oslam_bow_job_t oslam_job_bow_t;
+typedef struct oslam_kf_key { int32_t slot, kf1, kf2; } oslam_kf_key_t;   /* identity of the keyframes of a job (see register_keyframes) */   /* ORBmatcher::SearchByBoW(KF, F) (:159) or SearchForTriangulation (:657), see oslam_hip.h */
 
 typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (current keyframe, neighbour) pair */
     oslam_tri_kf_t kf1, kf2; int32_t M; const int32_t* idx1; const int32_t* idx2;
@@ -183,6 +184,15 @@ typedef struct oslam_slam_ops {
     /* semantic constraints (NULL = the table cannot run frames with objects) */
     int (*object_kps)(void* ctx, int n, oslam_job_object_kps_t* jobs);
     int (*pose_opt2)(void* ctx, int n, oslam_job_pose2_t* jobs);
+    /* Resident keyframes (optional, NULL in tables without a device).  register_keyframes: the frames built for `slots` in THIS step have become keyframes
+     * kf_ids of their sequences: the table keeps a device copy of their keypoints / descriptors / stereo coordinates (a device-to-device copy while the
+     * frame arrays are still in HBM; kf_id 0 restarts the sequence after a reset).  The *_keyed forms do what bow / fuse / mp_update do, with the identity
+     * of the keyframes beside the jobs, so their arrays are read from the resident copies instead of being packed and uploaded again (kf2 = -2: side 2 is
+     * the current frame of `slot`; obs_key [total][3] = (slot, keyframe id, keypoint index) of every observation). */
+    int (*register_keyframes)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids);
+    int (*bow_keyed)(void* ctx, int n, oslam_job_bow_t* jobs, const oslam_kf_key_t* keys);
+    int (*fuse_keyed)(void* ctx, int n, oslam_job_fuse_t* jobs, const oslam_kf_key_t* keys);
+    int (*mp_update_keyed)(void* ctx, oslam_job_mp_update_t* job, const int32_t* obs_key);
     /* optional (NULL in tables without a device): see oslam_slam_kernel_times */
     int (*kernel_times)(void* ctx, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
 } oslam_slam_ops_t;

@@ -314,7 +314,21 @@ int oslam_match_search_for_triangulation(oslam_bow_t* h, const oslam_bow_side1_t
 
 // Batch of independent pairs (SearchByBoW and / or SearchForTriangulation), one workgroup each in ONE launch: all inputs are packed into one
 // pinned block and reach the device in one copy; the results come back in one copy after one synchronisation.
+static int bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_bow_resident_t* res, const float* scaleFactors, const float* levelSigma2, int nlevels);
+
 extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const float* scaleFactors, const float* levelSigma2, int nlevels) {
+    return bow_batch(h, n, jobs, nullptr, scaleFactors, levelSigma2, nlevels);
+}
+
+// The same with device-resident keypoint / descriptor / stereo-coordinate arrays for either side of a job (res[i] members that are NULL fall back to the
+// job's host arrays): only the FeatureVector index lists and the flags travel.  The caller guarantees that the resident arrays are complete (its copies
+// have been synchronised) — the launch runs on the handle's own stream.
+extern "C" int oslam_match_bow_batch_resident(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_bow_resident_t* res, const float* scaleFactors,
+                                              const float* levelSigma2, int nlevels) {
+    return bow_batch(h, n, jobs, res, scaleFactors, levelSigma2, nlevels);
+}
+
+static int bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_bow_resident_t* res, const float* scaleFactors, const float* levelSigma2, int nlevels) {
     if (!h || n < 0 || (n > 0 && !jobs)) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (n == 0) return OSLAM_OK;
     bool anyTri = false;
@@ -338,9 +352,13 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
             if (!(s2.nodes[k - 1] < s2.nodes[k])) { set_error("side-2 node ids must be strictly ascending"); return OSLAM_E_INVALID; }
         Off& o = off[i];
         o.nitems = nitems; o.nout = jobs[i].triangulation ? s1.N : s2.N;
-        o.q_idx = take((size_t)s1.nq * 4); o.q_node = take((size_t)s1.nq * 4); o.keys1 = take((size_t)s1.N * sizeof(oslam_keypoint_t)); o.desc1 = take((size_t)s1.N * 32);
-        o.ur1 = take((size_t)s1.N * 4); o.flag1 = take((size_t)s1.N); o.keys2 = take((size_t)s2.N * sizeof(oslam_keypoint_t)); o.desc2 = take((size_t)s2.N * 32);
-        o.ur2 = take((size_t)s2.N * 4); o.mp2 = take((size_t)s2.N); o.nodes = take((size_t)s2.nNodes * 4); o.start = take((size_t)(s2.nNodes + 1) * 4);
+        const bool r1 = res && res[i].d_keys1 && res[i].d_desc1, r2 = res && res[i].d_keys2 && res[i].d_desc2;
+        const bool u1 = r1 && res[i].d_uRight1 && s1.uRight, u2 = r2 && res[i].d_uRight2 && s2.uRight;   // a NULL host uRight means "all -1": that is packed, resident or not
+        o.q_idx = take((size_t)s1.nq * 4); o.q_node = take((size_t)s1.nq * 4);
+        o.keys1 = r1 ? 0 : take((size_t)s1.N * sizeof(oslam_keypoint_t)); o.desc1 = r1 ? 0 : take((size_t)s1.N * 32);
+        o.ur1 = u1 ? 0 : take((size_t)s1.N * 4); o.flag1 = take((size_t)s1.N);
+        o.keys2 = r2 ? 0 : take((size_t)s2.N * sizeof(oslam_keypoint_t)); o.desc2 = r2 ? 0 : take((size_t)s2.N * 32);
+        o.ur2 = u2 ? 0 : take((size_t)s2.N * 4); o.mp2 = take((size_t)s2.N); o.nodes = take((size_t)s2.nNodes * 4); o.start = take((size_t)(s2.nNodes + 1) * 4);
         o.items = take((size_t)nitems * 4);
     }
     const size_t in_bytes = at;
@@ -367,11 +385,11 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
         const oslam_bow_side2_t& s2 = j.s2;
         const Off& o = off[i];
         memcpy(H + o.q_idx, s1.q_idx, (size_t)s1.nq * 4); memcpy(H + o.q_node, s1.q_node, (size_t)s1.nq * 4);
-        memcpy(H + o.keys1, s1.keys, (size_t)s1.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc1, s1.desc, (size_t)s1.N * 32);
-        if (s1.uRight) memcpy(H + o.ur1, s1.uRight, (size_t)s1.N * 4); else for (int k = 0; k < s1.N; k++) ((float*)(H + o.ur1))[k] = -1.0f;
+        if (o.keys1) { memcpy(H + o.keys1, s1.keys, (size_t)s1.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc1, s1.desc, (size_t)s1.N * 32); }
+        if (o.ur1) { if (s1.uRight) memcpy(H + o.ur1, s1.uRight, (size_t)s1.N * 4); else for (int k = 0; k < s1.N; k++) ((float*)(H + o.ur1))[k] = -1.0f; }
         if (s1.flag) memcpy(H + o.flag1, s1.flag, (size_t)s1.N); else memset(H + o.flag1, 0, (size_t)s1.N);
-        memcpy(H + o.keys2, s2.keys, (size_t)s2.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc2, s2.desc, (size_t)s2.N * 32);
-        if (s2.uRight) memcpy(H + o.ur2, s2.uRight, (size_t)s2.N * 4); else for (int k = 0; k < s2.N; k++) ((float*)(H + o.ur2))[k] = -1.0f;
+        if (o.keys2) { memcpy(H + o.keys2, s2.keys, (size_t)s2.N * sizeof(oslam_keypoint_t)); memcpy(H + o.desc2, s2.desc, (size_t)s2.N * 32); }
+        if (o.ur2) { if (s2.uRight) memcpy(H + o.ur2, s2.uRight, (size_t)s2.N * 4); else for (int k = 0; k < s2.N; k++) ((float*)(H + o.ur2))[k] = -1.0f; }
         if (s2.has_mp) memcpy(H + o.mp2, s2.has_mp, (size_t)s2.N); else memset(H + o.mp2, 0, (size_t)s2.N);
         memcpy(H + o.nodes, s2.nodes, (size_t)s2.nNodes * 4);
         if (s2.nNodes) memcpy(H + o.start, s2.start, (size_t)(s2.nNodes + 1) * 4); else *(int*)(H + o.start) = 0;
@@ -379,8 +397,10 @@ extern "C" int oslam_match_bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* job
         BowCtx& c = cs[i];
         memset(&c, 0, sizeof(c));
         c.mode = j.triangulation ? 1 : 0; c.nq = s1.nq; c.q_idx1 = (const int*)(D + o.q_idx); c.q_node = (const uint32_t*)(D + o.q_node);
-        c.N1 = s1.N; c.keys1 = (const oslam_keypoint_t*)(D + o.keys1); c.desc1 = D + o.desc1; c.uRight1 = (const float*)(D + o.ur1); c.flag1 = D + o.flag1;
-        c.N2 = s2.N; c.keys2 = (const oslam_keypoint_t*)(D + o.keys2); c.desc2 = D + o.desc2; c.uRight2 = (const float*)(D + o.ur2); c.has_mp2 = D + o.mp2;
+        c.N1 = s1.N; c.keys1 = o.keys1 ? (const oslam_keypoint_t*)(D + o.keys1) : res[i].d_keys1; c.desc1 = o.desc1 ? D + o.desc1 : res[i].d_desc1;
+        c.uRight1 = o.ur1 ? (const float*)(D + o.ur1) : res[i].d_uRight1; c.flag1 = D + o.flag1;
+        c.N2 = s2.N; c.keys2 = o.keys2 ? (const oslam_keypoint_t*)(D + o.keys2) : res[i].d_keys2; c.desc2 = o.desc2 ? D + o.desc2 : res[i].d_desc2;
+        c.uRight2 = o.ur2 ? (const float*)(D + o.ur2) : res[i].d_uRight2; c.has_mp2 = D + o.mp2;
         c.nNodes = s2.nNodes; c.nodes = (const uint32_t*)(D + o.nodes); c.start = (const int*)(D + o.start); c.items = (const int*)(D + o.items);
         c.nnratio = j.nnratio; c.checkOri = j.checkOri; c.bOnlyStereo = 0;
         for (int k = 0; k < 9; k++) c.F12[k] = j.F12[k];

@@ -97,6 +97,24 @@ __global__ __launch_bounds__(256) void k_gather_images(const uint8_t* const* src
     for (int b = nchunk * 16 + blockIdx.x * 256 + threadIdx.x; b < row_bytes; b += gridDim.x * 256) d[b] = s[b];
 }
 
+// n byte segments copied device to device in one launch (one workgroup per segment): the gather of resident keyframe arrays into a stage's batch layout
+struct CopySeg { const uint8_t* src; uint8_t* dst; uint32_t bytes, pad; };
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySeg* segs) {
+    const CopySeg g = segs[blockIdx.x];
+    const bool wide = (((uintptr_t)g.src | (uintptr_t)g.dst) & 15) == 0;
+    const uint32_t nchunk = wide ? g.bytes >> 4 : 0;
+    for (uint32_t c = threadIdx.x; c < nchunk; c += 256) ((uint4*)g.dst)[c] = ((const uint4*)g.src)[c];
+    for (uint32_t b = nchunk * 16 + threadIdx.x; b < g.bytes; b += 256) g.dst[b] = g.src[b];
+}
+
+// out[i] = the 32-byte descriptor at desc_base[rec[i].x] + 32 * rec[i].y (observations of map points gathered from resident keyframes)
+__global__ __launch_bounds__(256) void k_gather_desc(const uint8_t* const* desc_base, const int2* rec, int n, uint8_t* out) {
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (i >= n) return;
+    const int2 r = rec[i];
+    ((uint32_t*)out)[(size_t)i * 8 + part] = ((const uint32_t*)(desc_base[r.x] + (size_t)r.y * 32))[part];
+}
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -156,6 +174,20 @@ int oslam_frame_undistort_batch_device(const oslam_keypoint_t* d_keys, oslam_key
 int oslam_frame_gather_images_device(const void* const* d_src_ptrs, int n, int src_pitch, int row_bytes, int rows, void* d_dst, size_t dst_image_stride, int dst_pitch, void* stream) {
     if (!d_src_ptrs || !d_dst || n < 1 || rows < 1 || row_bytes < 1 || src_pitch < row_bytes || dst_pitch < row_bytes) { set_error("gather_images: bad argument"); return OSLAM_E_INVALID; }
     hipLaunchKernelGGL(k_gather_images, dim3(1, rows, n), dim3(256), 0, (hipStream_t)stream, (const uint8_t* const*)d_src_ptrs, src_pitch, row_bytes, (uint8_t*)d_dst, dst_image_stride, dst_pitch);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_copy_segments_device(const void* d_segs, int n, void* stream) {
+    if (!d_segs || n < 1) { set_error("copy_segments: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_copy_segments, dim3(n), dim3(256), 0, (hipStream_t)stream, (const CopySeg*)d_segs);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_gather_descriptors_device(const uint8_t* const* d_desc_base, const int32_t* d_rec /*[n][2]*/, int n, uint8_t* d_out, void* stream) {
+    if (!d_desc_base || !d_rec || !d_out || n < 1) { set_error("gather_descriptors: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_gather_desc, dim3(div_up(n, 32)), dim3(256), 0, (hipStream_t)stream, d_desc_base, (const int2*)d_rec, n, d_out);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }

@@ -106,6 +106,7 @@ struct Seq {
     std::vector<RelPose> rel;
     std::vector<int> recentAdded;          // mlpRecentAddedMapPoints
     std::vector<int> newKFs;               // mlNewKeyFrames (at most one per step)
+    std::vector<int> pendingKF;            // keyframes created in this step, not yet announced to the operator table (register_keyframes)
     std::vector<int> counter;              // scratch, indexed by keyframe id
     int64_t st[16] = {0};
     // per-step scratch
@@ -132,7 +133,7 @@ struct Seq {
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
         map = Map();
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
-        localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear();
+        localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear();
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
@@ -217,6 +218,7 @@ static int new_keyframe(Seq& s, const Frame& f) {
     k.Tcp = eye4();
     s.counter.resize(s.map.kfs.size() + 8, 0);
     s.st[1]++;
+    s.pendingKF.push_back(k.id);
     return k.id;
 }
 
@@ -226,6 +228,7 @@ struct MpUpdate {
     std::vector<Item> items;
     std::vector<int> start;
     std::vector<uint8_t> odesc, outdesc;
+    std::vector<int32_t> okey;
     std::vector<float> oOw, pos, owref, lsf, out5;
     std::vector<int> best;
     void clear() { items.clear(); }
@@ -239,7 +242,10 @@ struct MpUpdate {
             start[i + 1] = start[i] + (p.bad ? 0 : (int)p.obs.size());
         }
         const size_t total = (size_t)start[P];
-        odesc.resize(std::max<size_t>(total, 1) * 32); oOw.resize(std::max<size_t>(total, 1) * 3);
+        const bool keyed = c.ops.mp_update_keyed != nullptr && do_desc;   // the table gathers the descriptors from its resident keyframes
+        if (!keyed) odesc.resize(std::max<size_t>(total, 1) * 32);
+        else okey.resize(std::max<size_t>(total, 1) * 3);
+        oOw.resize(std::max<size_t>(total, 1) * 3);
         pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
         // ComputeDistinctiveDescriptors skips bad keyframes (src/MapPoint.cc:362-368), UpdateNormalAndDepth does not: a culled keyframe has
         // already erased its observations (KeyFrame::SetBadFlag), so both see the same list.
@@ -254,7 +260,8 @@ struct MpUpdate {
                 if (n > 0)
                     for (auto& e : p.obs) {
                         const KeyFrm& k = m.kfs[e.first];
-                        memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
+                        if (keyed) { okey[at * 3] = items[i].seq; okey[at * 3 + 1] = e.first; okey[at * 3 + 2] = e.second; }
+                        else memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
                         oOw[at * 3] = k.pose.Ow[0]; oOw[at * 3 + 1] = k.pose.Ow[1]; oOw[at * 3 + 2] = k.pose.Ow[2];
                         at++;
                     }
@@ -273,9 +280,9 @@ struct MpUpdate {
         });
         best.resize(P); outdesc.resize((size_t)P * 32); out5.resize((size_t)P * 5);
         oslam_job_mp_update_t j;
-        j.P = P; j.obs_start = start.data(); j.obs_desc = odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
+        j.P = P; j.obs_start = start.data(); j.obs_desc = keyed ? nullptr : odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
         j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
-        const int rc = c.ops.mp_update(c.ops.ctx, &j);
+        const int rc = keyed ? c.ops.mp_update_keyed(c.ops.ctx, &j, okey.data()) : c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
         // (an item can be listed twice after fusions; both copies carry the same result, so concurrent writers store the same bytes)
         c.pool->parallel_for(nchunks, [&](int ch) {
@@ -641,10 +648,12 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 j.triangulation = 1; j.nnratio = 0.6f; j.checkOri = 0; j.match = match[w].data();
                 have[w] = 1;
             });
-            for (size_t w = 0; w < who.size(); w++) if (have[w]) { bj.push_back(cand[w]); bjw.push_back((int)w); }
+            std::vector<oslam_kf_key_t> bkey;
+            for (size_t w = 0; w < who.size(); w++)
+                if (have[w]) { bj.push_back(cand[w]); bjw.push_back((int)w); bkey.push_back({who[w], c.seq[who[w]]->curKF, neigh[w][ni]}); }
             if (bj.empty()) continue;
             { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
-            if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
+            if ((rc = c.ops.bow_keyed ? c.ops.bow_keyed(c.ops.ctx, (int)bj.size(), bj.data(), bkey.data()) : c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             std::vector<oslam_job_triangulate_t> tj(bj.size());
             std::vector<std::vector<int32_t>> i1(bj.size()), i2(bj.size());
             std::vector<std::vector<uint8_t>> okv(bj.size());
@@ -695,6 +704,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         std::vector<FuseSeq> fs(who.size());
         std::vector<oslam_job_fuse_t> jobs;
         std::vector<int> jw;
+        std::vector<oslam_kf_key_t> fkey;
         size_t maxt = 0;
         pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];
@@ -713,7 +723,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         });
         for (size_t w = 0; w < who.size(); w++) maxt = std::max(maxt, fs[w].targets.size());
         auto fuse_round = [&](bool into_current, size_t t) -> int {
-            jobs.clear(); jw.clear();
+            jobs.clear(); jw.clear(); fkey.clear();
             pool.parallel_for(nW, [&](int w) {
                 Seq& s = *c.seq[who[w]];
                 fs[w].q.clear(); fs[w].qpt.clear();
@@ -733,11 +743,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 oslam_job_fuse_t j;
                 j.N = kf.N; j.keysUn = kf.keysUn.data(); j.uRight = kf.uRight.data(); j.desc = kf.desc.data();
                 j.M = (int)fs[w].q.size(); j.queries = fs[w].q.data(); j.q_match = fs[w].qm.data();
-                jobs.push_back(j); jw.push_back((int)w);
+                jobs.push_back(j); jw.push_back((int)w); fkey.push_back({who[w], k, -1});
             }
             { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
             if (jobs.empty()) return OSLAM_OK;
-            int rc2 = c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
+            int rc2 = c.ops.fuse_keyed ? c.ops.fuse_keyed(c.ops.ctx, (int)jobs.size(), jobs.data(), fkey.data()) : c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
             if (rc2) return rc2;
             c.sec[8] += tm.lap();
             pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].qpt, fs[w].qm.data()); });
@@ -1318,7 +1328,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();
             });
             { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
-            if ((rc = c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
+            std::vector<oslam_kf_key_t> bkey(rk.size());
+            for (size_t q = 0; q < rk.size(); q++) bkey[q] = {rk[q], c.seq[rk[q]]->refKF, -2};   // side 2 = the current frame, still on the device
+            if ((rc = c.ops.bow_keyed ? c.ops.bow_keyed(c.ops.ctx, (int)bj.size(), bj.data(), bkey.data()) : c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             c.sec[8] += tm.lap();
             pjw.clear();
             for (size_t q = 0; q < rk.size(); q++) {
@@ -1389,6 +1401,14 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         for (int p : s.updList) upd.add(i, p);
     }
     { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+    if (c.ops.register_keyframes) {   // the frames that became keyframes are still on the device: the table keeps them (include/oslam_slam.h)
+        std::vector<int32_t> rs, rk;
+        for (int i = 0; i < S; i++) {
+            for (int kf : c.seq[i]->pendingKF) { rs.push_back(i); rk.push_back(kf); }
+            c.seq[i]->pendingKF.clear();
+        }
+        if (!rs.empty() && (rc = c.ops.register_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
+    }
     if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
     c.sec[5] += tm.lap();
     // store relative poses (:569-585), swap frames

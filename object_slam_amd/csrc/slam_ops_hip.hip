@@ -44,6 +44,19 @@ struct HipOps {
     uint8_t* dn_h = nullptr; size_t dn_cap = 0;
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     uint8_t* d_objbits = nullptr;                        // [S][cap] keypoint test bits (object_kps)
+    // Resident keyframe store: one record per keyframe = device copies of mvKeysUn | mDescriptors | mvuRight (cap entries each), in chunks of kRecChunk records
+    static constexpr int kRecChunk = 256;
+    std::vector<uint8_t*> rec_chunks;
+    std::vector<std::vector<int>> rec_of_kf;              // [slot][kf id] -> record index or -1
+    int n_rec = 0;
+    uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
+    std::vector<uint8_t*> h_rec_desc;
+    size_t rec_bytes() const { return oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256) + oslam::align_up((size_t)cap * 32, 256) + oslam::align_up((size_t)cap * 4, 256); }
+    uint8_t* rec_ptr(int r) const { return rec_chunks[r / kRecChunk] + (size_t)(r % kRecChunk) * rec_bytes(); }
+    const oslam_keypoint_t* rec_keys(int r) const { return (const oslam_keypoint_t*)rec_ptr(r); }
+    const uint8_t* rec_desc(int r) const { return rec_ptr(r) + oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256); }
+    const float* rec_ur(int r) const { return (const float*)(rec_desc(r) + oslam::align_up((size_t)cap * 32, 256)); }
+    int rec_lookup(int slot, int kf) const { return (slot >= 0 && slot < (int)rec_of_kf.size() && kf >= 0 && kf < (int)rec_of_kf[slot].size()) ? rec_of_kf[slot][kf] : -1; }
     uint8_t* d_maskstage = nullptr; size_t mask_cap = 0;  // host masks of a stage, packed H x W
     int ensure_masks(size_t bytes) {
         if (bytes <= mask_cap) return OSLAM_OK;
@@ -565,23 +578,43 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
 }
 
 // MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over the touched points of all sequences: one block up, two launches, one block down
-int h_mp_update(void* p, oslam_job_mp_update_t* j) {
-    HipOps* o = (HipOps*)p;
+static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key);
+int h_mp_update(void* p, oslam_job_mp_update_t* j) { return mp_update_impl((HipOps*)p, j, nullptr); }
+int h_mp_update_keyed(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) { return mp_update_impl((HipOps*)p, j, obs_key); }
+
+static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key) {
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     const size_t P = j->P;
     if (P == 0) return OSLAM_OK;
     const size_t total = (size_t)j->obs_start[P];
     Layout L;
-    const size_t oStart = L.take(4 * (P + 1)), oDesc = L.take(32 * total), oOw = L.take(12 * total), oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P);
+    // with resident keyframes the observations' descriptors are gathered on the device from (record, keypoint) pairs: 8 bytes per observation travel
+    // instead of 32, and the caller did not have to collect them
+    std::vector<int32_t> rec;
+    bool keyed = obs_key && j->do_desc && total > 0;
+    if (keyed) {
+        rec.resize(2 * total);
+        for (size_t e = 0; e < total && keyed; e++) {
+            const int r = o->rec_lookup(obs_key[3 * e], obs_key[3 * e + 1]);
+            if (r < 0 || obs_key[3 * e + 2] < 0 || obs_key[3 * e + 2] >= o->cap) keyed = false;
+            rec[2 * e] = r; rec[2 * e + 1] = obs_key[3 * e + 2];
+        }
+        if (!keyed && !j->obs_desc) { oslam::set_error("mp_update: observation of a keyframe that is not resident"); return OSLAM_E_INVALID; }
+    }
+    const size_t oStart = L.take(4 * (P + 1)), oRec = L.take(keyed ? 8 * total : 0), oOw = L.take(12 * total), oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P),
+                 oDescUp = L.take(keyed ? 0 : 32 * total);
     const size_t in_bytes = L.off;
+    const size_t oDesc = keyed ? L.take(32 * total) : oDescUp;
     const size_t oBest = L.take(4 * P), oOut = L.take(32 * P), oOut5 = L.take(20 * P);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     uint8_t* Dv = o->up_d;
     memcpy(U + oStart, j->obs_start, 4 * (P + 1));
-    if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * total);
+    if (keyed) memcpy(U + oRec, rec.data(), 8 * total);
+    else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * total);
     if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)total, Dv + oDesc, o->strm));
     Layout R;
     const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
     OPS_CHECK(o->ensure_dn(R.off));
@@ -641,6 +674,72 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     return rc;
 }
 
+// ---- resident keyframes ----
+struct CopySegH { const uint8_t* src; uint8_t* dst; uint32_t bytes, pad; };
+
+int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf_ids) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if ((int)o->rec_of_kf.size() < o->S) o->rec_of_kf.resize(o->S);
+    const size_t cap = o->cap, rb = o->rec_bytes();
+    std::vector<CopySegH> segs;
+    for (int i = 0; i < n; i++) {
+        const int slot = slots[i], kf = kf_ids[i];
+        if (slot < 0 || slot >= o->S || kf < 0) { oslam::set_error("register_keyframes: bad slot / id"); return OSLAM_E_INVALID; }
+        if (kf == 0) o->rec_of_kf[slot].clear();   // the sequence was reset: its keyframe ids restart
+        if ((int)o->rec_of_kf[slot].size() <= kf) o->rec_of_kf[slot].resize(kf + 1, -1);
+        const int r = o->n_rec++;
+        if (r / HipOps::kRecChunk >= (int)o->rec_chunks.size()) {
+            uint8_t* c = nullptr;
+            OSLAM_HIP_CHECK(hipMalloc((void**)&c, rb * HipOps::kRecChunk));
+            o->rec_chunks.push_back(c);
+        }
+        o->rec_of_kf[slot][kf] = r;
+        o->h_rec_desc.push_back((uint8_t*)o->rec_desc(r));
+        // the frame built for `slot` in this step is still in the batch arrays
+        segs.push_back({(const uint8_t*)(o->d_keysUn + cap * slot), (uint8_t*)o->rec_keys(r), (uint32_t)(cap * sizeof(oslam_keypoint_t)), 0});
+        segs.push_back({o->d_desc + 32 * cap * slot, (uint8_t*)o->rec_desc(r), (uint32_t)(cap * 32), 0});
+        segs.push_back({(const uint8_t*)(o->cur_uRight + cap * slot), (uint8_t*)o->rec_ur(r), (uint32_t)(cap * 4), 0});
+    }
+    OPS_CHECK(o->ensure_up(segs.size() * sizeof(CopySegH)));
+    memcpy(o->up_h, segs.data(), segs.size() * sizeof(CopySegH));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, segs.size() * sizeof(CopySegH), hipMemcpyHostToDevice, o->strm));
+    OPS_CHECK(oslam_copy_segments_device(o->up_d, (int)segs.size(), o->strm));
+    // descriptor-array table for the observation gathers
+    if ((size_t)o->n_rec > o->rec_desc_cap) {
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
+        o->rec_desc_cap = (size_t)o->n_rec * 2 + 1024;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&o->d_rec_desc, o->rec_desc_cap * sizeof(uint8_t*)));
+        o->rec_desc_n = 0;
+    }
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_rec_desc + o->rec_desc_n, o->h_rec_desc.data() + o->rec_desc_n, (size_t)(o->n_rec - o->rec_desc_n) * sizeof(uint8_t*),
+                                   hipMemcpyHostToDevice, o->strm));
+    o->rec_desc_n = o->n_rec;
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
+    return OSLAM_OK;
+}
+
+int h_bow_keyed(void* p, int n, oslam_job_bow_t* jobs, const oslam_kf_key_t* keys) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    std::vector<oslam_bow_resident_t> res(n);
+    const size_t cap = o->cap;
+    for (int i = 0; i < n; i++) {
+        memset(&res[i], 0, sizeof(res[i]));
+        const int r1 = o->rec_lookup(keys[i].slot, keys[i].kf1);
+        if (r1 >= 0) { res[i].d_keys1 = o->rec_keys(r1); res[i].d_desc1 = o->rec_desc(r1); res[i].d_uRight1 = o->rec_ur(r1); }
+        if (keys[i].kf2 == -2 && keys[i].slot >= 0 && keys[i].slot < o->S) {   // side 2 = the current frame of the slot
+            res[i].d_keys2 = o->d_keysUn + cap * keys[i].slot; res[i].d_desc2 = o->d_desc + 32 * cap * keys[i].slot; res[i].d_uRight2 = o->cur_uRight + cap * keys[i].slot;
+        } else {
+            const int r2 = o->rec_lookup(keys[i].slot, keys[i].kf2);
+            if (r2 >= 0) { res[i].d_keys2 = o->rec_keys(r2); res[i].d_desc2 = o->rec_desc(r2); res[i].d_uRight2 = o->rec_ur(r2); }
+        }
+    }
+    return oslam_match_bow_batch_resident(o->bow, n, jobs, res.data(), o->scale, o->sigma2, o->cfg.nLevels);
+}
+
 int h_kernel_times(void* p, int enable, double* out) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
@@ -654,8 +753,11 @@ int h_kernel_times(void* p, int enable, double* out) {
 }
 
 // search half of ORBmatcher::Fuse for n (keyframe, candidate list) jobs in one launch (one workgroup per keyframe)
-int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
-    HipOps* o = (HipOps*)p;
+static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_key_t* keys);
+int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) { return fuse_impl((HipOps*)p, n, jobs, nullptr); }
+int h_fuse_keyed(void* p, int n, oslam_job_fuse_t* jobs, const oslam_kf_key_t* keys) { return fuse_impl((HipOps*)p, n, jobs, keys); }
+
+static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_key_t* keys) {
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     if (n > o->S) { oslam::set_error("fuse: n > n_sequences"); return OSLAM_E_INVALID; }
@@ -674,20 +776,37 @@ int h_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
     }
     const size_t st = oslam::align_up((size_t)maxM, 64);
     Layout L;
-    const size_t oN = L.take(4 * B), oM = L.take(4 * B), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * B), oUr = L.take(4 * cap * B), oDesc = L.take(32 * cap * B),
-                 oQ = L.take(sizeof(oslam_proj_query_t) * st * B);
+    // upload block: counts, queries, the segment table of the resident keyframes, and (last, so that a fully resident batch does not ship them) the
+    // keypoint / stereo / descriptor arrays of the keyframes that are not resident
+    const size_t oN = L.take(4 * B), oM = L.take(4 * B), oQ = L.take(sizeof(oslam_proj_query_t) * st * B), oSeg = L.take(sizeof(CopySegH) * 3 * B);
+    const size_t small_bytes = L.off;
+    const size_t oKeys = L.take(sizeof(oslam_keypoint_t) * cap * B), oUr = L.take(4 * cap * B), oDesc = L.take(32 * cap * B);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
+    uint8_t* Dv = o->up_d;
+    std::vector<int> rec(n, -1);
+    int nres = 0;
+    if (keys) for (int i = 0; i < n; i++) { rec[i] = o->rec_lookup(keys[i].slot, keys[i].kf1); nres += rec[i] >= 0; }
+    CopySegH* segs = (CopySegH*)(U + oSeg);
+    for (int i = 0, q = 0; i < n; i++)
+        if (rec[i] >= 0) {
+            const size_t N = jobs[i].N;
+            segs[q++] = {(const uint8_t*)o->rec_keys(rec[i]), Dv + oKeys + sizeof(oslam_keypoint_t) * cap * i, (uint32_t)(sizeof(oslam_keypoint_t) * N), 0};
+            segs[q++] = {(const uint8_t*)o->rec_ur(rec[i]), Dv + oUr + 4 * cap * i, (uint32_t)(4 * N), 0};
+            segs[q++] = {o->rec_desc(rec[i]), Dv + oDesc + 32 * cap * i, (uint32_t)(32 * N), 0};
+        }
     o->pool->parallel_for(n, [&](int i) {
         const oslam_job_fuse_t& j = jobs[i];
         const size_t N = j.N, M = j.M;
         ((int32_t*)(U + oN))[i] = j.N; ((int32_t*)(U + oM))[i] = j.M;
-        memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * i, j.keysUn, sizeof(oslam_keypoint_t) * N);
-        memcpy(U + oUr + 4 * cap * i, j.uRight, 4 * N); memcpy(U + oDesc + 32 * cap * i, j.desc, 32 * N);
+        if (rec[i] < 0) {
+            memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * i, j.keysUn, sizeof(oslam_keypoint_t) * N);
+            memcpy(U + oUr + 4 * cap * i, j.uRight, 4 * N); memcpy(U + oDesc + 32 * cap * i, j.desc, 32 * N);
+        }
         memcpy(U + oQ + sizeof(oslam_proj_query_t) * st * i, j.queries, sizeof(oslam_proj_query_t) * M);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
-    uint8_t* Dv = o->up_d;
+    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, nres == n ? small_bytes : L.off, hipMemcpyHostToDevice, o->strm));
+    if (nres) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 3 * nres, o->strm));
     oslam_match_frames_t fr;
     fr.keysUn = (const oslam_keypoint_t*)(Dv + oKeys); fr.kp_stride = (int)cap; fr.uRight = (const float*)(Dv + oUr); fr.desc = Dv + oDesc; fr.blocked = nullptr;
     fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
@@ -739,6 +858,8 @@ void h_destroy(void* p) {
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
     if (o->dn_h) (void)hipHostFree(o->dn_h);
+    for (uint8_t* c : o->rec_chunks) (void)hipFree(c);
+    if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
     (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
@@ -758,7 +879,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     memset(ops, 0, sizeof(*ops));
     HipOps* o = new HipOps;
     o->cfg = *cfg; o->S = cfg->n_sequences;
-    o->pool = new oslam_drv::Pool(cfg->host_threads > 1 ? cfg->host_threads : 1);
+    o->pool = new oslam_drv::Pool(cfg->host_threads > 1 ? cfg->host_threads : 1, /*own_workers*/ false);
     if (hipStreamCreateWithFlags(&o->strm, hipStreamNonBlocking) != hipSuccess) o->strm = nullptr;
     const int dev = cfg->device;
     int rc = oslam_orb_create(&o->orb, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
@@ -804,5 +925,6 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; }
     return OSLAM_OK;
 }

@@ -4,8 +4,11 @@
 // The workers are PROCESS-WIDE: every Pool(threads) adds threads - 1 workers to one shared set, and a parallel_for of any handle is served by
 // whichever workers are idle.  With several driver handles per GPU (each stepped by its own host thread) a handle that waits for the GPU leaves
 // its share of the cores to the handles that are in a host stage, instead of parking four private workers (measured: see DESIGN.md §9).
+// A step of the driver dispatches ~100 short parallel_for calls, so workers and owners first SPIN for a few tens of microseconds (new work usually
+// arrives within that) and only then sleep on the condition variable.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -20,69 +23,105 @@ public:
         std::function<void(int)>* fn = nullptr;
         int n = 0;
         std::atomic<int> next{0}, finished{0};
-        int users = 0;   // workers currently inside work() for this batch (guarded by the pool mutex): the owner may not leave before they have
+        std::atomic<int> users{0};   // workers inside work() for this batch (incremented under the pool mutex): the owner may not leave before they have
     };
     static SharedWorkers& instance() {
         static SharedWorkers* s = new SharedWorkers;   // never destroyed: the detached workers may outlive static destructors
         return *s;
     }
+    // A Pool asks for k workers while it lives: the set grows to the largest total ever asked for; workers beyond the CURRENT total park, so a later
+    // run with fewer or smaller pools does not inherit the thread count of an earlier one.
     void add_workers(int k) {
         std::lock_guard<std::mutex> g(m_);
-        for (int i = 0; i < k; i++) { std::thread([this] { loop(); }).detach(); nthreads_++; }
+        wanted_ += k;
+        while (nthreads_ < wanted_) { const int id = nthreads_++; std::thread([this, id] { loop(id); }).detach(); }
+        epoch_.fetch_add(1, std::memory_order_release);
+        cv_.notify_all();
+    }
+    void remove_workers(int k) {
+        std::lock_guard<std::mutex> g(m_);
+        wanted_ -= k;
     }
     int threads() {
         std::lock_guard<std::mutex> g(m_);
-        return nthreads_;
+        return wanted_;
     }
     // runs b.fn(i) for i in [0, n) on the caller and on idle workers; returns when all calls have finished
     void run(Batch& b) {
         {
             std::lock_guard<std::mutex> g(m_);
             active_.push_back(&b);
+            epoch_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_all();
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         work(b);
+        auto finished = [&] { return b.finished.load(std::memory_order_acquire) == b.n && b.users.load(std::memory_order_acquire) == 0; };
+        for (int spin = 0; spin < kSpin && !finished(); spin++) relax();
         std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return b.finished.load() == b.n && b.users == 0; });
+        while (!finished()) done_.wait_for(lk, std::chrono::microseconds(100));
         for (size_t i = 0; i < active_.size(); i++)
             if (active_[i] == &b) { active_.erase(active_.begin() + i); break; }
     }
 
 private:
+    static constexpr int kSpin = 4000;   // ~30-60 us of polling
+    static void relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
     void work(Batch& b) {
         for (;;) {
             const int i = b.next.fetch_add(1);
             if (i >= b.n) break;
             (*b.fn)(i);
-            if (b.finished.fetch_add(1) + 1 == b.n) {
-                std::lock_guard<std::mutex> g(m_);   // the owner checks `finished` under the lock: no lost wake-up
-                done_.notify_all();
-            }
+            b.finished.fetch_add(1, std::memory_order_release);
         }
     }
-    void loop() {
+    Batch* pick_locked() {
+        for (Batch* q : active_)
+            if (q->next.load() < q->n) { q->users.fetch_add(1); return q; }   // under the lock: the owner waits for users == 0 before the batch (on its stack) goes away
+        return nullptr;
+    }
+    void loop(int id) {
         for (;;) {
             Batch* b = nullptr;
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] {
-                    for (Batch* q : active_)
-                        if (q->next.load() < q->n) { b = q; return true; }
-                    return false;
-                });
-                b->users++;   // under the lock: the owner waits for users == 0 before the batch (on its stack) goes away
+                if (id >= wanted_) {   // parked: more workers exist than the live pools asked for
+                    cv_.wait_for(lk, std::chrono::milliseconds(20));
+                    continue;
+                }
+                b = pick_locked();
+                if (!b) {
+                    const unsigned long seen = epoch_.load(std::memory_order_acquire);
+                    lk.unlock();
+                    bool changed = false;
+                    for (int spin = 0; spin < kSpin; spin++) {
+                        if (epoch_.load(std::memory_order_acquire) != seen) { changed = true; break; }
+                        relax();
+                    }
+                    lk.lock();
+                    b = pick_locked();
+                    if (!b && !changed) {
+                        sleepers_.fetch_add(1);
+                        cv_.wait_for(lk, std::chrono::milliseconds(2), [&] { return epoch_.load(std::memory_order_acquire) != seen; });
+                        sleepers_.fetch_sub(1);
+                        b = pick_locked();
+                    }
+                }
             }
+            if (!b) continue;
             work(*b);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (--b->users == 0) done_.notify_all();
-            }
+            b->users.fetch_sub(1, std::memory_order_release);
         }
     }
     std::mutex m_;
     std::condition_variable cv_, done_;
     std::vector<Batch*> active_;
-    int nthreads_ = 0;
+    std::atomic<unsigned long> epoch_{0};
+    std::atomic<int> sleepers_{0};
+    int nthreads_ = 0, wanted_ = 0;
 };
 
 // parallel_for on the shared workers for library code that has no Pool of its own (runs on the caller alone when no driver handle has added workers)
@@ -98,9 +137,16 @@ inline void shared_parallel_for(int n, F&& fn) {
 
 class Pool {
 public:
-    explicit Pool(int threads) : threads_(threads < 1 ? 1 : threads) {
-        if (threads_ > 1) SharedWorkers::instance().add_workers(threads_ - 1);
+    // own_workers = false: use the shared workers without asking for more (the operator table of a handle runs on the handle's thread, between the
+    // driver's own parallel sections: the two never need workers at the same time)
+    explicit Pool(int threads, bool own_workers = true) : threads_(threads < 1 ? 1 : threads), own_(own_workers) {
+        if (threads_ > 1 && own_) SharedWorkers::instance().add_workers(threads_ - 1);
     }
+    ~Pool() {
+        if (threads_ > 1 && own_) SharedWorkers::instance().remove_workers(threads_ - 1);
+    }
+    Pool(const Pool&) = delete;
+    Pool& operator=(const Pool&) = delete;
     int threads() const { return threads_; }
     // fn(i) for i in [0, n); returns when all calls have finished.  The calling thread takes part.
     template <class F>
@@ -115,6 +161,7 @@ public:
 
 private:
     int threads_;
+    bool own_;
 };
 
 }  // namespace oslam_drv
