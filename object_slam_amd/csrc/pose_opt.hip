@@ -138,22 +138,28 @@ __device__ unsigned long long g_pose_prof[8];   // cycles of frame 0 per phase: 
 // Block-wide sums of the 28 accumulators of the build pass (21 H + 6 b + chi2), every thread returns the same totals (fixed order).
 // Transposed through LDS: every thread parks its 28 partials, 8 threads per value add 32 partials each and combine with three
 // shuffle steps -- 28 writes + 32 reads per thread instead of the 168 double-precision shuffle steps of 28 wavefront butterflies.
-constexpr int kSumN = 28, kSumPitch = kPoseThreads + 8;   // pitch = 8 mod 32 doubles: the 8 value rows of a wavefront's reads fall on different banks
-static_assert(kSumN * 8 <= kPoseThreads && kPoseThreads % 8 == 0, "block_sum_wide: 8 summing threads per value");
+// Neighbouring lanes are added first (one DPP step per value), so only every second thread parks a partial: the buffer is 30 KB instead of 59 KB and
+// TWO frames fit into a CU's LDS beside their staged edges (the kernel's 214-235 registers allow two wavefronts per SIMD; one workgroup per CU left every
+// SIMD with a single wavefront of dependent fp64 chains).
+constexpr int kSumN = 28, kSumCols = kPoseThreads / 2, kSumPitch = kSumCols + 8;   // pitch = 8 mod 32 doubles: the value rows of a wavefront's reads fall on different banks
+constexpr int kSumLanes = kSumN * 8 <= kPoseThreads ? 8 : 4;   // summing threads per value
+static_assert(kSumN * kSumLanes <= kPoseThreads && kSumCols % kSumLanes == 0, "block_sum_wide: summing threads per value");
 __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_part /* [kSumN][kSumPitch] */, double* s_tot /* [kSumN] */) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < kSumN; i++) s_part[i * kSumPitch + tid] = v[i];
+    for (int i = 0; i < kSumN; i++) {
+        const double s = v[i] + __shfl_xor(v[i], 1, 64);
+        if (!(tid & 1)) s_part[i * kSumPitch + (tid >> 1)] = s;
+    }
     __syncthreads();
-    if (tid < kSumN * 8) {
-        const double* row = s_part + (tid >> 3) * kSumPitch + (tid & 7);
+    if (tid < kSumN * kSumLanes) {
+        const double* row = s_part + (tid / kSumLanes) * kSumPitch + (tid % kSumLanes);
         double s = row[0];
 #pragma unroll
-        for (int k = 1; k < kPoseThreads / 8; k++) s += row[8 * k];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        if ((tid & 7) == 0) s_tot[tid >> 3] = s;
+        for (int k = 1; k < kSumCols / kSumLanes; k++) s += row[kSumLanes * k];
+#pragma unroll
+        for (int d = 1; d < kSumLanes; d <<= 1) s += __shfl_xor(s, d, 64);
+        if ((tid % kSumLanes) == 0) s_tot[tid / kSumLanes] = s;
     }
     __syncthreads();
 #pragma unroll
@@ -665,7 +671,10 @@ using namespace oslam;
 
 // dynamic LDS of k_pose_optimize: chi2 (8 B) + level (1 B) per edge slot, + the staged edge data (28 B) when STAGE
 static size_t pose_lds_bytes(size_t stride, bool stage) { return stride * (stage ? 37 : 9) + 64; }
-constexpr size_t kPoseLdsBudget = 98 * 1024;   // 160 KB per workgroup minus the kernel's static arrays (59 KB of them block_sum_wide's)
+#ifndef OSLAM_POSE_LDS_BUDGET
+#define OSLAM_POSE_LDS_BUDGET (48 * 1024)
+#endif
+constexpr size_t kPoseLdsBudget = OSLAM_POSE_LDS_BUDGET;   // two workgroups per CU: 80 KB each minus the kernel's static arrays (30 KB of them block_sum_wide's)
 
 struct oslam_poseopt {
     int device = 0, max_batch = 0, max_points = 0;
