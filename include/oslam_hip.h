@@ -313,6 +313,11 @@ void oslam_poseopt_destroy(oslam_poseopt_t* h);
 int oslam_pose_optimize(oslam_poseopt_t* h, int N, const float Tcw_in[16], const float* Xw, const float* obs,
                         const float* invSigma2, const uint8_t* has_mp, const float K5[5], float Tcw_out[16],
                         uint8_t* outlier, int32_t* n_inliers, int32_t stats[2] /* LM iterations, trials; may be NULL */);
+/* Test hook: record the Levenberg-Marquardt trials of frame 0 of the calls that follow (cap > 0; cap == 0 stops), and read them back as
+ * out[cap][6] = (F before the trial, F of the trial, rho, lambda of the trial, accepted, first trial of a round); *n = trials seen since the last read.  The parity
+ * tests compare this sequence with the oracle's (g2o OptimizationAlgorithmLevenberg::solve, replaced at src/Optimizer.cc:407-409). */
+int oslam_poseopt_trace(oslam_poseopt_t* h, int cap);
+int oslam_poseopt_trace_read(oslam_poseopt_t* h, double* out, int32_t* n);
 /* Batch of independent frames in HBM (device pointers, per-frame stride in points). Asynchronous. */
 int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, int n_const,
                                      const float* d_Tcw, const float* d_Xw, const float* d_obs,
@@ -385,6 +390,10 @@ int oslam_lba_set_mode(oslam_lba_t* h, int wide);
 /* Kernel timing for bench.py's roofline: HIP events on the handle's stream around the solve kernels of every later call.
  * Returns and clears the accumulated milliseconds / kernel launches, then sets the switch to `enable`. */
 int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long* launches_out);
+/* Test hook, as oslam_poseopt_trace: the LM trials of window 0 of the wide-mode calls that follow (g2o's OptimizationAlgorithmLevenberg::solve as
+ * driven from src/Optimizer.cc:659-660,706-707); field 5 = first trial of a stage.  Process-wide: one handle traces at a time. */
+int oslam_lba_trace(oslam_lba_t* h, int cap);
+int oslam_lba_trace_read(oslam_lba_t* h, double* out, int32_t* n);
 /* Reduced-camera-system solver of the wide mode: 0 (default) = the LDS-resident scalar kernel while the augmented system fits (6 x free keyframes <= 132),
  * the matrix-core kernel (v_mfma_f64_16x16x4_f64 trailing updates, 16-wide panels) beyond; 1 = matrix cores for every size; 2 = never. */
 int oslam_lba_set_solver(oslam_lba_t* h, int mode);
@@ -515,6 +524,11 @@ int oslam_gather_descriptors_device(const uint8_t* const* d_desc_base, const int
 int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
                                               int stride, int batch, const float* d_depth, int rows, int cols, int pitch, size_t image_stride,
                                               float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
+
+/* Frame::ComputeStereoFromRGBD with the depth images where they are: image b = d_depth_ptrs[b] (device table of device pointers), rows `pitch` floats apart. */
+int oslam_frame_stereo_from_rgbd_batch_ptrs_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
+                                                   int stride, int batch, const float* const* d_depth_ptrs, int rows, int cols, int pitch, float mbf,
+                                                   float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ struct RgbdCtx {
     const oslam_keypoint_t* keys; const oslam_keypoint_t* keysUn; const int* counts; int n_const; int stride;
     const float* depth; int pitch; long long image_stride; int rows, cols;
     float mbf; float* uRight; float* mvDepth; int* status;
+    const float* const* depth_ptrs;   // batch of depth images given by a pointer table (image b = depth_ptrs[b]) instead of base + b * image_stride
 };
 
 __global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdCtx c) {
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdCtx c) {
         const int row = (int)kp.y, col = (int)kp.x;   // Mat::at<float>(v, u) with float arguments: truncation
         if (row < 0 || row >= c.rows || col < 0 || col >= c.cols) atomicOr(c.status, 1);   // the reference would read out of the image
         else {
-            const float d = c.depth[(long long)b * c.image_stride + (long long)row * c.pitch + col];
+            const float d = c.depth_ptrs ? c.depth_ptrs[b][(long long)row * c.pitch + col] : c.depth[(long long)b * c.image_stride + (long long)row * c.pitch + col];
             if (d > 0) { dp = d; ur = c.keysUn[o].x - __fdiv_rn(c.mbf, d); }
         }
     }
@@ -203,7 +204,23 @@ int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, co
     RgbdCtx c;
     c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
     c.depth = d_depth; c.pitch = pitch; c.image_stride = (long long)image_stride; c.rows = rows; c.cols = cols;
-    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = nullptr;
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+// The same with the depth images where they are: image b = d_depth_ptrs[b] (device table of device pointers), rows `pitch` floats apart — only the ~1000
+// depth values at the keypoints are read, so the images need not be gathered into a batch first.
+int oslam_frame_stereo_from_rgbd_batch_ptrs_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const, int stride,
+                                                   int batch, const float* const* d_depth_ptrs, int rows, int cols, int pitch, float mbf, float* d_uRight,
+                                                   float* d_mvDepth, int32_t* d_status, void* stream) {
+    if (!d_keys || !d_keysUn || !d_depth_ptrs || !d_uRight || !d_mvDepth || !d_status || batch < 1 || stride < 1 || rows < 1 || cols < 1 || pitch < cols ||
+        (!d_counts && (n_const < 0 || n_const > stride))) { set_error("stereo_from_rgbd: bad argument"); return OSLAM_E_INVALID; }
+    RgbdCtx c;
+    c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
+    c.depth = nullptr; c.pitch = pitch; c.image_stride = 0; c.rows = rows; c.cols = cols;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = d_depth_ptrs;
     hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;

@@ -1399,6 +1399,11 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const 
 // SparseOptimizer::optimize loop, and the stage logic of reference src/Optimizer.cc:660-707)
 // LM control after the trial evaluation (one thread: the last block of k_w_eval): gain ratio, accept / reject, lambda
 // update, iteration / stage bookkeeping of g2o's OptimizationAlgorithmLevenberg + SparseOptimizer::optimize
+// Test hook (oslam_lba_trace): LM trials of window 0 of the wide layout. [0] = records seen, then [cap][6] = (F before, F of the trial, rho, lambda,
+// accepted, first trial of a stage).
+__device__ double* g_lba_trace = nullptr;
+__device__ int g_lba_trace_cap = 0;
+
 __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
     double F1 = 0, sc = 0;
@@ -1408,6 +1413,14 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     if (!ct->ok2) tempChi = 1.7976931348623157e308;
     const double rho = (ct->currentChi - tempChi) / (sc + 1e-3);
     const bool finite = (tempChi - tempChi) == 0;
+    if (g_lba_trace && blockIdx.y == 0) {
+        const int r = (int)g_lba_trace[0];
+        if (r < g_lba_trace_cap) {
+            double* t = g_lba_trace + 1 + 6 * r;
+            t[0] = ct->currentChi; t[1] = tempChi; t[2] = rho; t[3] = ct->lambda; t[4] = (rho > 0 && finite) ? 1.0 : 0.0; t[5] = (ct->iter == 0 && ct->qmax == 0) ? 1.0 : 0.0;
+        }
+        g_lba_trace[0] = r + 1;
+    }
     if (rho > 0 && finite) {
         double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
         alpha = fmin(alpha, 2. / 3.);
@@ -1580,6 +1593,40 @@ int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long*
     if (launches_out) *launches_out = h->kern_launches;
     h->kern_ms = 0; h->kern_launches = 0;
     h->timing = enable;
+    return OSLAM_OK;
+}
+
+// Test hook: record the LM trials of window 0 of the wide-layout calls that follow (cap > 0; cap == 0 stops).  The buffer is process-wide: one
+// handle traces at a time.
+static double* s_lba_trace_buf = nullptr;
+static int s_lba_trace_cap = 0;
+int oslam_lba_trace(oslam_lba_t* h, int cap) {
+    if (!h || cap < 0) { set_error("oslam_lba_trace: bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    double* none = nullptr; int zero = 0;
+    OSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lba_trace), &none, sizeof(none)));
+    OSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lba_trace_cap), &zero, sizeof(zero)));
+    if (s_lba_trace_buf) (void)hipFree(s_lba_trace_buf);
+    s_lba_trace_buf = nullptr; s_lba_trace_cap = 0;
+    if (cap == 0) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipMalloc((void**)&s_lba_trace_buf, sizeof(double) * (1 + 6 * (size_t)cap)));
+    OSLAM_HIP_CHECK(hipMemset(s_lba_trace_buf, 0, sizeof(double) * (1 + 6 * (size_t)cap)));
+    s_lba_trace_cap = cap;
+    OSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lba_trace), &s_lba_trace_buf, sizeof(s_lba_trace_buf)));
+    OSLAM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_lba_trace_cap), &cap, sizeof(cap)));
+    return OSLAM_OK;
+}
+
+int oslam_lba_trace_read(oslam_lba_t* h, double* out, int32_t* n) {
+    if (!h || !out || !n || !s_lba_trace_buf) { set_error("oslam_lba_trace_read: no trace"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    double cnt = 0;
+    OSLAM_HIP_CHECK(hipMemcpy(&cnt, s_lba_trace_buf, sizeof(double), hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(out, s_lba_trace_buf + 1, sizeof(double) * 6 * (size_t)s_lba_trace_cap, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemset(s_lba_trace_buf, 0, sizeof(double)));
+    *n = (int32_t)cnt;
     return OSLAM_OK;
 }
 

@@ -51,6 +51,7 @@ struct PoseCtx {
     uint8_t* outlier;        // [B][stride]
     int* n_inliers;          // [B]
     int* stats;              // [B][2] LM iterations, trials
+    double* trace; int trace_cap;   // optional LM trace of frame 0: trace[0] = records written, then [cap][6] = (F before, F of the trial, rho, lambda, accepted, first trial of a round)
     SemCtx sem;
 };
 
@@ -454,6 +455,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                     scale += 1e-3;
                     rho /= scale;
                     const bool finite = (tempChi - tempChi) == 0;
+                    if (c.trace && b == 0 && tid == 0) {
+                        const int r = (int)c.trace[0];
+                        if (r < c.trace_cap) {
+                            double* t = c.trace + 1 + 6 * r;
+                            t[0] = currentChi; t[1] = tempChi; t[2] = rho; t[3] = lambda; t[4] = (rho > 0 && finite) ? 1.0 : 0.0; t[5] = (iter == 0 && qmax == 0) ? 1.0 : 0.0;
+                        }
+                        c.trace[0] = r + 1;
+                    }
                     if (rho > 0 && finite) {
                         double alpha = 1. - (2 * rho - 1) * (2 * rho - 1) * (2 * rho - 1);
                         alpha = fmin(alpha, 2. / 3.);
@@ -683,6 +692,7 @@ struct oslam_poseopt {
     // staging for the host API
     float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
     uint8_t* h_pin = nullptr; size_t pin_cap = 0;   // pinned staging of the single-frame host API (inputs, then results)
+    double* d_trace = nullptr; int trace_cap = 0;   // LM trace of frame 0 (oslam_poseopt_trace), off by default
     // semantic variant: grow-only device buffers
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf masks, rowcnt, objcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
@@ -707,6 +717,7 @@ void oslam_poseopt_destroy(oslam_poseopt_t* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_pin) (void)hipHostFree(h->h_pin);
+    if (h->d_trace) (void)hipFree(h->d_trace);
     delete h;
 }
 
@@ -752,6 +763,34 @@ int oslam_pose_debug_profile(unsigned long long out[8]) {
 }
 #endif
 
+// Test hook: record the Levenberg-Marquardt trials of frame 0 of every following call (cap > 0), or stop recording (cap == 0).
+int oslam_poseopt_trace(oslam_poseopt_t* h, int cap) {
+    if (!h || cap < 0) { set_error("oslam_poseopt_trace: bad argument"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    if (h->d_trace) (void)hipFree(h->d_trace);
+    h->d_trace = nullptr; h->trace_cap = 0;
+    if (cap == 0) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipMalloc((void**)&h->d_trace, sizeof(double) * (1 + 6 * (size_t)cap)));
+    OSLAM_HIP_CHECK(hipMemset(h->d_trace, 0, sizeof(double) * (1 + 6 * (size_t)cap)));
+    h->trace_cap = cap;
+    return OSLAM_OK;
+}
+
+// Copies the trace out ([cap][6] doubles: F before the trial, F of the trial, rho, lambda of the trial, accepted, first trial of a round), returns the number of trials seen
+// since the last read in *n (it can exceed cap: only the first cap are kept) and clears the trace.
+int oslam_poseopt_trace_read(oslam_poseopt_t* h, double* out, int32_t* n) {
+    if (!h || !out || !n || !h->d_trace) { set_error("oslam_poseopt_trace_read: no trace"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    OSLAM_HIP_CHECK(hipDeviceSynchronize());
+    double cnt = 0;
+    OSLAM_HIP_CHECK(hipMemcpy(&cnt, h->d_trace, sizeof(double), hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemcpy(out, h->d_trace + 1, sizeof(double) * 6 * (size_t)h->trace_cap, hipMemcpyDeviceToHost));
+    OSLAM_HIP_CHECK(hipMemset(h->d_trace, 0, sizeof(double)));
+    *n = (int32_t)cnt;
+    return OSLAM_OK;
+}
+
 int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, const int32_t* d_n, int n_const, const float* d_Tcw,
                                      const float* d_Xw, const float* d_obs, const float* d_invSigma2, const uint8_t* d_has_mp,
                                      const float K5[5], void* stream) {
@@ -763,7 +802,7 @@ int oslam_pose_optimize_batch_device(oslam_poseopt_t* h, int batch, int stride, 
     c.Tcw = d_Tcw; c.Xw = d_Xw; c.obs = d_obs; c.invSigma2 = d_invSigma2; c.has_mp = d_has_mp;
     c.n = d_n; c.n_const = n_const; c.stride = stride;
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
-    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     memset(&c.sem, 0, sizeof(c.sem));
     if (h->stage) hipLaunchKernelGGL((k_pose_optimize<false, true>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, true), (hipStream_t)stream, c);
     else hipLaunchKernelGGL((k_pose_optimize<false, false>), dim3(batch), dim3(kPoseThreads), pose_lds_bytes(stride, false), (hipStream_t)stream, c);
@@ -877,7 +916,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     c.Tcw = h->d_T; c.Xw = h->d_Xw; c.obs = h->d_obs; c.invSigma2 = h->d_inv; c.has_mp = h->d_has;
     c.n = nullptr; c.n_const = N; c.stride = h->max_points;
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
-    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     SemCtx& sm = c.sem;
     sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
     sm.masks = (const uint8_t*)h->masks.p; sm.mask_ptrs = nullptr; sm.H = sem->H; sm.W = sem->W; sm.pitch = sem->W;
@@ -934,7 +973,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
     c.Tcw = d_Tcw; c.Xw = d_Xw; c.obs = d_obs; c.invSigma2 = d_invSigma2; c.has_mp = d_has_mp;
     c.n = d_n; c.n_const = 0; c.stride = stride;
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
-    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats;
+    c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     SemCtx& sm = c.sem;
     memset(&sm, 0, sizeof(sm));
     sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;

@@ -179,13 +179,14 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H, dimg = (size_t)W * H;
-    if (on_device) {   // two pointer tables up, two gather launches (instead of 2n two-dimensional copies)
+    const float* const* depth_table = nullptr;
+    if (on_device) {   // two pointer tables up, ONE gather launch for the gray images (instead of 2n two-dimensional copies)
         OPS_CHECK(o->ensure_up(16 * (size_t)n + 512));
         memcpy(o->up_h, gray, 8 * (size_t)n); memcpy(o->up_h + 8 * (size_t)n + 256 - (8 * (size_t)n) % 256, depth, 8 * (size_t)n);
         const size_t oD = 8 * (size_t)n + 256 - (8 * (size_t)n) % 256;
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, oD + 8 * (size_t)n, hipMemcpyHostToDevice, o->strm));
         OPS_CHECK(oslam_frame_gather_images_device((const void* const*)o->up_d, n, gray_stride, W, H, o->d_gray, gimg, (int)o->gray_pitch, o->strm));
-        OPS_CHECK(oslam_frame_gather_images_device((const void* const*)(o->up_d + oD), n, depth_pitch * 4, W * 4, H, o->d_depth, dimg * 4, W * 4, o->strm));
+        depth_table = (const float* const*)(o->up_d + oD);   // the depth images are read where they are: only the values at the keypoints are needed
     } else {
         // host images: rows packed into the pinned block in the device layout (parallel), then ONE copy per plane (a pageable 2-D copy is row-by-row)
         OPS_CHECK(o->ensure_up((gimg + dimg * 4) * n));
@@ -204,8 +205,10 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
     OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
     OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, o->strm));
-    OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
-                                                        o->d_mvDepth, o->d_status, o->strm));
+    if (depth_table) OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_ptrs_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, depth_table, H, W, depth_pitch, o->cfg.bf,
+                                                                              o->d_uRight, o->d_mvDepth, o->d_status, o->strm));
+    else OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
+                                                             o->d_mvDepth, o->d_status, o->strm));
     o->t_end();
     (void)slots;
     OPS_CHECK(download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out));

@@ -47,6 +47,19 @@ class PoseOptimizer:
                                          ptr(outl), C.byref(n), ptr(stats)))
         return n.value, out.reshape(4, 4), outl[:N], (int(stats[0]), int(stats[1]))
 
+    def lm_trace(self, fn, cap=512):
+        """Test hook: runs fn() with the kernel's LM trace on; returns (fn's result, trace[n, 6]) with rows
+        (F before the trial, F of the trial, rho, lambda of the trial, accepted, first trial of a round)."""
+        check(self.L.oslam_poseopt_trace(self.h, cap))
+        try:
+            r = fn()
+            buf = np.zeros((cap, 6), np.float64)
+            n = C.c_int32(0)
+            check(self.L.oslam_poseopt_trace_read(self.h, ptr(buf), C.byref(n)))
+        finally:
+            check(self.L.oslam_poseopt_trace(self.h, 0))
+        return r, buf[:min(n.value, cap)].copy()
+
     def PoseOptimization2(self, p):
         """ObjectOptimizer::PoseOptimization2 (reference src/ObjectOptimizer.cc:624) on a dict with the keys of
         synth.make_semantic_problem.  Returns (n_inliers, Tcw_out, outlier, nSemNum)."""
@@ -115,6 +128,19 @@ class LocalBundleAdjuster:
     def set_solver(self, mode):
         """Reduced-camera-system solver of the wide mode: 0 auto, 1 matrix cores (MFMA f64) for every size, 2 never (include/oslam_hip.h)."""
         check(self.L.oslam_lba_set_solver(self.h, C.c_int(mode)))
+
+    def lm_trace(self, fn, cap=512):
+        """Test hook: runs fn() with the LM trace of window 0 (wide layout) on; returns (fn's result, trace[n, 6]) with rows
+        (F before the trial, F of the trial, rho, lambda of the trial, accepted, first trial of a stage)."""
+        check(self.L.oslam_lba_trace(self.h, cap))
+        try:
+            r = fn()
+            buf = np.zeros((cap, 6), np.float64)
+            n = C.c_int32(0)
+            check(self.L.oslam_lba_trace_read(self.h, ptr(buf), C.byref(n)))
+        finally:
+            check(self.L.oslam_lba_trace(self.h, 0))
+        return r, buf[:min(n.value, cap)].copy()
 
     def stop_flag(self):
         """The pbStopFlag: a pinned int visible to the running kernel (set [0] = 1 to abort)."""

@@ -206,23 +206,25 @@ def depth_to_metres(depth_u16):
     return (depth_u16.astype(np.float64) * f).astype(np.float32)
 
 
-def make_rgbd_sequence(seed, n, width=640, height=480, speed=1.0, with_masks=True):
+def make_rgbd_sequence(seed, n, width=640, height=480, speed=1.0, with_masks=True, first=0, count=None):
     """S1: dict(gray [n,H,W] u8, depth [n,H,W] f32 metres, masks [n,3,H,W] u8 {0,255}, track_ids [3], labels [3], Twc [n,4,4] f64
-    relative to the first camera)."""
+    relative to the first camera).  first / count: render only frames [first, first + count) of the n-frame stream (the images of a frame do
+    not depend on the others, so a long stream can be rendered in pieces; Twc stays relative to frame 0 of the whole stream)."""
     planes = make_tum_scene(seed)
     Twc = tum_path(n, seed, speed)
-    gray = np.empty((n, height, width), np.uint8)
-    depth = np.empty((n, height, width), np.float32)
-    masks = np.zeros((n, 3, height, width), np.uint8) if with_masks else None
-    for i in range(n):
-        g, d, lab = render(planes, Twc[i], TUM_K, width, height)
+    m = n - first if count is None else count
+    gray = np.empty((m, height, width), np.uint8)
+    depth = np.empty((m, height, width), np.float32)
+    masks = np.zeros((m, 3, height, width), np.uint8) if with_masks else None
+    for i in range(m):
+        g, d, lab = render(planes, Twc[first + i], TUM_K, width, height)
         gray[i], depth[i] = g, depth_to_metres(d)
         if with_masks:
             for o in range(3):
                 masks[i, o] = (lab == o + 1) * np.uint8(255)
     T0inv = np.linalg.inv(Twc[0])
     return dict(gray=gray, depth=depth, masks=masks, track_ids=np.array([0, 1, 2], np.int32), labels=np.array([56, 62, 73], np.int32),
-                Twc=np.array([T0inv @ T for T in Twc]))
+                Twc=np.array([T0inv @ T for T in Twc[first:first + m]]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -437,6 +437,12 @@ bool solve_system(System& s, double lambda) {
 }
 }  // namespace
 
+// Test hook: the Levenberg-Marquardt trials of every graph_optimize call while set (F before, F of the trial, rho, lambda of the trial, accepted, first trial of the call).
+static double* g_trace = nullptr;
+static int g_trace_cap = 0, g_trace_n = 0;
+void lm_trace_set(double* buf, int cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+int lm_trace_count() { return g_trace_n; }
+
 int graph_optimize(Graph& g, int iterations, int level, const volatile int* stop) {
     System s;
     s.pose_idx.assign(g.poses.size(), -1);
@@ -504,6 +510,13 @@ int graph_optimize(Graph& g, int iterations, int level, const volatile int* stop
             for (size_t j = 0; j < s.x.size(); j++) scale += s.x[j] * (lambda * s.x[j] + s.b[j]);
             scale += 1e-3;
             rho /= scale;
+            if (g_trace) {
+                if (g_trace_n < g_trace_cap) {
+                    double* t = g_trace + 6 * (size_t)g_trace_n;
+                    t[0] = currentChi; t[1] = tempChi; t[2] = rho; t[3] = lambda; t[4] = (rho > 0 && std::isfinite(tempChi)) ? 1.0 : 0.0; t[5] = (it == 0 && qmax == 0) ? 1.0 : 0.0;
+                }
+                g_trace_n++;
+            }
             if (rho > 0 && std::isfinite(tempChi)) {
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, goodUp);

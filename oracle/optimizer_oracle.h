@@ -59,6 +59,9 @@ bool edge_depth_positive(const Graph& g, const GraphEdge& e);
 // OptimizationAlgorithmLevenberg.  stop (may be NULL) is the force-stop flag polled like g2o does.
 // Returns the number of iterations performed.
 int graph_optimize(Graph& g, int iterations, int level, const volatile int* stop);
+// test hook: record the LM trials of the graph_optimize calls that follow into buf[cap][6] (nullptr: stop); not thread safe
+void lm_trace_set(double* buf, int cap);
+int lm_trace_count();
 void edge_jacobians(const Graph& g, const GraphEdge& e, double Jp[18], double Jx[9]);
 
 // reference src/Optimizer.cc:239-451.  has_mp[i] != 0 <=> pFrame->mvpMapPoints[i] != NULL.

@@ -151,6 +151,12 @@ void oo_local_bundle_adjustment(int nKF, const float* poses, const uint8_t* fixe
     LocalBundleAdjustment(nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, stop, poses_out,
                           points_out, erase, stats);
 }
+// LM trace of the optimisations that follow (buf[cap][6]: F before, F of the trial, rho, lambda, accepted, first trial of a graph_optimize call); buf == NULL stops. Returns trials seen so far.
+int oo_lm_trace(double* buf, int cap) {
+    const int n = lm_trace_count();
+    lm_trace_set(buf, cap);
+    return n;
+}
 // SE3 helpers for unit tests
 void oo_se3_exp_mul(const double* update6, const float* T_in, float* T_out) {
     SE3Quat T = se3_from_cvmat(T_in);

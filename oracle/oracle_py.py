@@ -219,6 +219,21 @@ def pose_optimization(Tcw, Xw, obs, invSigma2, has_mp, K5):
     return n, out.reshape(4, 4), outl[:N], tuple(stats)
 
 
+def lm_trace(fn, cap=512):
+    """Runs fn() with the LM trace of the oracle's graph optimiser on; returns (fn's result, trace[n, 6]) with rows
+    (F before the trial, F of the trial, rho, lambda of the trial, accepted, first trial of a round)."""
+    buf = np.zeros((cap, 6), np.float64)
+    L = lib()
+    L.oo_lm_trace.argtypes = [C.c_void_p, C.c_int]
+    L.oo_lm_trace.restype = C.c_int
+    L.oo_lm_trace(_p(buf), cap)
+    try:
+        r = fn()
+    finally:
+        n = L.oo_lm_trace(None, 0)
+    return r, buf[:min(n, cap)].copy()
+
+
 def local_bundle_adjustment(poses, fixed, points, edge_kf, edge_pt, edge_obs, edge_inv, K5, stop=0):
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     fixed = np.ascontiguousarray(fixed, np.uint8)

@@ -24,6 +24,24 @@ def _compare(a, o):
     assert st[0] == ost[0] and st[2] == ost[2], (st, ost)
 
 
+@pytest.mark.parametrize("seed,KL,KF,P", [(3, 4, 2, 150), (4, 6, 3, 300), (6, 20, 20, 4000), (8, 12, 8, 2000)])
+def test_lba_lm_schedule_matches_oracle(oracle, seed, KL, KF, P):
+    """The LM loop of both optimize() calls (reference src/Optimizer.cc:659-660 and :706-707): accept / reject sequence, rho, lambda and costs of
+    every decidable trial, HIP (wide layout) vs oracle — see tests/lm_trace.py for what `decidable` means."""
+    from lm_trace import compare_lm_traces
+    q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, stereo_frac=[0.85, 1.0, 0.0][seed % 3])
+    args = (q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+    ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536)
+    a, th = ba.lm_trace(lambda: ba.LocalBundleAdjustment(*args))
+    o, to = oracle.lm_trace(lambda: oracle.local_bundle_adjustment(*args))
+    assert len(th) == a[3][1] + a[3][3] and len(to) == o[3][1] + o[3][3]
+    compared, undecidable = compare_lm_traces(th, to)
+    assert compared >= 4, (compared, undecidable, len(th), len(to))
+    if undecidable == 0:
+        assert tuple(a[3]) == tuple(o[3]), (a[3], o[3])
+    ba.close()
+
+
 @pytest.mark.parametrize("wide", [True, False])
 @pytest.mark.parametrize("seed,KL,KF,P", [(3, 4, 2, 150), (4, 6, 3, 300), (5, 10, 0, 500), (6, 20, 20, 4000)])
 def test_lba_matches_oracle(oracle, seed, KL, KF, P, wide):
