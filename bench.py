@@ -99,8 +99,11 @@ def cpu_baseline(wl, seq, n_frames):
 # --------------------------------------------------------------------------------------------------------------------------------
 # S2 stage entry: ORBextractor + ORBmatcher only (BASELINE.json configs[1]), per-kernel HBM table
 # --------------------------------------------------------------------------------------------------------------------------------
-def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
-    """Batched extraction of B frames + SearchByProjection(Cur, Last) with the ground-truth pose, everything resident in HBM."""
+def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
+    """Batched extraction of B frames + SearchByProjection(Cur, Last) with the ground-truth pose, everything resident in HBM.
+    The B frames of a step are cut into `parts` sub-batches, each with its own extractor / matcher handle and HIP stream: the quad-tree, descriptor
+    and matching kernels of one sub-batch (latency bound, few wavefronts) then run beside the FAST / blur kernels (VALU bound) of the others, the
+    way the driver's handles overlap.  parts = 1 is the single-stream form of round 1."""
     import ctypes as C
 
     import torch
@@ -108,66 +111,86 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
     from object_slam_amd import ORBextractor, ORBmatcher, slam
     from object_slam_amd._lib import check
     from object_slam_amd.matcher import MatchFrames, MatchLast
+    parts = parts or int(os.environ.get("OSLAM_S2_PARTS", "1"))   # measured on one MI355X: 1 -> 171 k, 2 -> 176 k, 4 -> 128 k, 8 -> 145 k frames/s (tools/frontend_parts.py)
+    assert B % parts == 0
     n_src, H, W = frames.shape
     NFEAT, NLEVELS, TH = 1000, 8, 15.0
     cam5 = slam.TUM2
     cam = (cam5["fx"], cam5["fy"], cam5["cx"], cam5["cy"], cam5["bf"], cam5["bf"] / cam5["fx"])
-    idx = np.arange(B) % (n_src - 1) + 1                 # frame b = source frame idx[b], its "last frame" = idx[b] - 1
+    idx_all = np.arange(B) % (n_src - 1) + 1                 # frame b = source frame idx[b], its "last frame" = idx[b] - 1
     pitch = (W + 63) // 64 * 64
-    d_img = torch.zeros((B, H, pitch), dtype=torch.uint8, device="cuda")
-    d_img[:, :, :W] = torch.from_numpy(frames[idx]).cuda()
-    st = torch.cuda.current_stream().cuda_stream
-    ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, W, H, max_batch=B, device=local_rank)
-    cap = ex.cap
-    mt = ORBmatcher(0.9, True, max_keypoints=cap, max_queries=cap, max_batch=B, device=local_rank)
-    sf = ex.GetScaleFactors()
-    d_kp, d_desc, d_cnt, _ = ex.results_device()
-    # "last frames": extraction of the previous source frames, map points from their depth
-    d_prev = torch.zeros((B, H, pitch), dtype=torch.uint8, device="cuda")
-    d_prev[:, :, :W] = torch.from_numpy(frames[idx - 1]).cuda()
-    ex.extract_batch_device(d_prev.data_ptr(), B, pitch, pitch * H, st)
+    Bp = B // parts
+
+    class Part:
+        pass
+
+    def make_part(k):
+        q = Part()
+        idx = idx_all[k * Bp:(k + 1) * Bp]
+        q.stream = torch.cuda.Stream() if parts > 1 else torch.cuda.current_stream()
+        st = q.st = q.stream.cuda_stream
+        q.d_img = torch.zeros((Bp, H, pitch), dtype=torch.uint8, device="cuda")
+        q.d_img[:, :, :W] = torch.from_numpy(frames[idx]).cuda()
+        ex = q.ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, W, H, max_batch=Bp, device=local_rank)
+        cap = q.cap = ex.cap
+        q.mt = ORBmatcher(0.9, True, max_keypoints=cap, max_queries=cap, max_batch=Bp, device=local_rank)
+        q.sf = ex.GetScaleFactors()
+        d_kp, d_desc, d_cnt, _ = ex.results_device()
+        # "last frames": extraction of the previous source frames, map points from their depth
+        d_prev = torch.zeros((Bp, H, pitch), dtype=torch.uint8, device="cuda")
+        d_prev[:, :, :W] = torch.from_numpy(frames[idx - 1]).cuda()
+        torch.cuda.synchronize()
+        ex.extract_batch_device(d_prev.data_ptr(), Bp, pitch, pitch * H, st)
+        torch.cuda.synchronize()
+        host = [ex.fetch(b) for b in range(Bp)]
+        last_keys = np.zeros((Bp, cap), dtype=host[0][0].dtype)
+        last_desc = np.zeros((Bp, cap, 32), np.uint8)
+        last_Xw = np.zeros((Bp, cap, 3), np.float32)
+        last_has = np.zeros((Bp, cap), np.uint8)
+        q.last_n = last_n = np.zeros(Bp, np.int32)
+        Tcw = np.zeros((Bp, 4, 4), np.float32)
+        Tlw = np.zeros((Bp, 4, 4), np.float32)
+        for b in range(Bp):
+            kl, dl = host[b]
+            n = len(kl)
+            Tl = np.linalg.inv(Twc[idx[b] - 1])
+            z = depth[idx[b] - 1][kl["y"].astype(np.int64), kl["x"].astype(np.int64)].astype(np.float64)
+            Xc = np.stack([(kl["x"] - cam[2]) * z / cam[0], (kl["y"] - cam[3]) * z / cam[1], z], 1)
+            Xw = (Xc - Tl[:3, 3]) @ Tl[:3, :3]
+            last_keys[b, :n], last_desc[b, :n], last_Xw[b, :n], last_n[b] = kl, dl, Xw, n
+            last_has[b, :n] = np.where(z > 0, 3, 0)
+            Tcw[b], Tlw[b] = np.linalg.inv(Twc[idx[b]]), Tl
+        q.keep = [torch.from_numpy(last_keys.view(np.uint8).reshape(Bp, -1)).cuda()] + [torch.from_numpy(a).cuda() for a in (last_desc, last_Xw, last_has, last_n, Tcw, Tlw)]
+        t_keys, t_desc, t_Xw, t_has, t_n, q.t_Tcw, q.t_Tlw = q.keep
+        q.t_uR = torch.full((Bp, cap), -1.0, dtype=torch.float32, device="cuda")
+        fr = q.fr = MatchFrames()
+        fr.keysUn, fr.kp_stride, fr.uRight, fr.desc, fr.blocked = d_kp, cap, q.t_uR.data_ptr(), d_desc, None
+        fr.n_kps, fr.n_kps_const = d_cnt, 0
+        fr.minX, fr.minY, fr.maxX, fr.maxY = 0.0, 0.0, float(W), float(H)
+        la = q.la = MatchLast()
+        la.Xw, la.has_mp, la.keys, la.mp_desc = t_Xw.data_ptr(), t_has.data_ptr(), t_keys.data_ptr(), t_desc.data_ptr()
+        la.kp_stride, la.n_kps, la.n_kps_const = cap, t_n.data_ptr(), 0
+        q.q_nq = C.c_void_p()
+        check(q.mt.L.oslam_match_results_device(q.mt.h, None, None, None, None, None, C.byref(q.q_nq)))
+        return q
+
+    P = [make_part(k) for k in range(parts)]
     torch.cuda.synchronize()
-    host = [ex.fetch(b) for b in range(B)]
-    last_keys = np.zeros((B, cap), dtype=host[0][0].dtype)
-    last_desc = np.zeros((B, cap, 32), np.uint8)
-    last_Xw = np.zeros((B, cap, 3), np.float32)
-    last_has = np.zeros((B, cap), np.uint8)
-    last_n = np.zeros(B, np.int32)
-    Tcw = np.zeros((B, 4, 4), np.float32)
-    Tlw = np.zeros((B, 4, 4), np.float32)
-    for b in range(B):
-        kl, dl = host[b]
-        n = len(kl)
-        Tl = np.linalg.inv(Twc[idx[b] - 1])
-        z = depth[idx[b] - 1][kl["y"].astype(np.int64), kl["x"].astype(np.int64)].astype(np.float64)
-        Xc = np.stack([(kl["x"] - cam[2]) * z / cam[0], (kl["y"] - cam[3]) * z / cam[1], z], 1)
-        Xw = (Xc - Tl[:3, 3]) @ Tl[:3, :3]
-        last_keys[b, :n], last_desc[b, :n], last_Xw[b, :n], last_n[b] = kl, dl, Xw, n
-        last_has[b, :n] = np.where(z > 0, 3, 0)
-        Tcw[b], Tlw[b] = np.linalg.inv(Twc[idx[b]]), Tl
-    t_keys = torch.from_numpy(last_keys.view(np.uint8).reshape(B, -1)).cuda()
-    t_desc, t_Xw, t_has, t_n = (torch.from_numpy(a).cuda() for a in (last_desc, last_Xw, last_has, last_n))
-    t_Tcw, t_Tlw = torch.from_numpy(Tcw).cuda(), torch.from_numpy(Tlw).cuda()
-    t_uR = torch.full((B, cap), -1.0, dtype=torch.float32, device="cuda")
-    fr = MatchFrames()
-    fr.keysUn, fr.kp_stride, fr.uRight, fr.desc, fr.blocked = d_kp, cap, t_uR.data_ptr(), d_desc, None
-    fr.n_kps, fr.n_kps_const = d_cnt, 0
-    fr.minX, fr.minY, fr.maxX, fr.maxY = 0.0, 0.0, float(W), float(H)
-    la = MatchLast()
-    la.Xw, la.has_mp, la.keys, la.mp_desc = t_Xw.data_ptr(), t_has.data_ptr(), t_keys.data_ptr(), t_desc.data_ptr()
-    la.kp_stride, la.n_kps, la.n_kps_const = cap, t_n.data_ptr(), 0
-    q_nq = C.c_void_p()
-    check(mt.L.oslam_match_results_device(mt.h, None, None, None, None, None, C.byref(q_nq)))
+    ex, mt, cap, last_n = P[0].ex, P[0].mt, P[0].cap, P[0].last_n
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def step(timed_match=False):
-        ex.extract_batch_device(d_img.data_ptr(), B, pitch, pitch * H, st)
+    def step_part(q, timed_match=False):
+        q.ex.extract_batch_device(q.d_img.data_ptr(), Bp, pitch, pitch * H, q.st)
         if timed_match:
-            ev0.record()
-        mt.project_last_batch_device(la, t_Tcw.data_ptr(), t_Tlw.data_ptr(), cam, fr, sf, TH, False, B, st)
-        mt.search_batch_device(fr, None, cap, q_nq.value, 0, B, False, True, st)
+            ev0.record(q.stream)
+        q.mt.project_last_batch_device(q.la, q.t_Tcw.data_ptr(), q.t_Tlw.data_ptr(), cam, q.fr, q.sf, TH, False, Bp, q.st)
+        q.mt.search_batch_device(q.fr, None, q.cap, q.q_nq.value, 0, Bp, False, True, q.st)
         if timed_match:
-            ev1.record()
+            ev1.record(q.stream)
+
+    def step():
+        for q in P:
+            step_part(q)
 
     for _ in range(3):
         step()
@@ -177,12 +200,13 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    counts = np.array([len(ex.fetch(b)[0]) for b in range(0, B, 37)])
-    nm = mt.fetch(B // 2, cap, int(last_n[B // 2]), cap, len(ex.fetch(B // 2)[0]), st)[0]
+    counts = np.array([len(q.ex.fetch(b)[0]) for q in P for b in range(0, Bp, 37)])
+    nm = mt.fetch(Bp // 2, cap, int(last_n[Bp // 2]), cap, len(ex.fetch(Bp // 2)[0]), P[0].st)[0]
+    # per-kernel table: sub-batch 0 alone (its kernels then have the GPU to themselves, as in the single-stream form)
     ex.set_profiling(1)
     match_ms = []
     for _ in range(5):
-        step(timed_match=True)
+        step_part(P[0], timed_match=True)
         torch.cuda.synchronize()
         match_ms.append(ev0.elapsed_time(ev1))
     ms, nb, ni = ex.get_profile()
@@ -193,16 +217,18 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
     alg = {"pyramid(K1)": (Ptot - pl) + (Ptot - p0), "fast_cells(K2/K3)": Ptot, "blur(K6)": 2 * Ptot, "octree(K4)": 0,
            "orient_describe(K5/K7)": (749 + 512 + 60) * n_kp}
     us = {n: m / ni * 1e3 for n, m in zip(alg.keys(), ms)}
-    us["match(K8-K10)"] = float(np.mean(match_ms)) / B * 1e3
+    us["match(K8-K10)"] = float(np.mean(match_ms)) / Bp * 1e3
     alg["match(K8-K10)"] = 44 * n_kp + 36 * n_kp + 12288 + 8 * n_kp
     pairs = C.c_int64(0)
-    check(mt.L.oslam_match_hamming_pairs(mt.h, B, C.byref(pairs)))
-    out = {"workload": "S2 (BASELINE.json configs[1]): %d frames of the S1 stream per step, ORBextractor + SearchByProjection(Cur, Last) with the ground-truth pose" % B,
+    check(mt.L.oslam_match_hamming_pairs(mt.h, Bp, C.byref(pairs)))
+    out = {"workload": "S2 (BASELINE.json configs[1]): %d frames of the S1 stream per step in %d sub-batches on their own streams, ORBextractor + SearchByProjection(Cur, Last) "
+                       "with the ground-truth pose; the per-kernel table is one sub-batch of %d frames alone" % (B, parts, Bp),
+           "parts": parts,
            "frames_per_s": round(B * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "keypoints_per_frame": round(n_kp, 1), "matches_frame_mid": int(nm),
            "per_frame_us": {k: round(v, 3) for k, v in us.items()}, "alg_bytes_per_frame": {k: int(v) for k, v in alg.items()},
            "GBs": {k: round(alg[k] / (us[k] * 1e-6) / 1e9, 1) for k in us if us[k] > 0},
            "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * steps / dt / 1e9, 1),
-           "hamming_pairs_per_frame": round(pairs.value / B, 1),
+           "hamming_pairs_per_frame": round(pairs.value / Bp, 1),
            # committed PMC passes of this stage (profiles/r02_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
            "pmc_hbm_KB_per_frame": {k: round(_pmc(k) / 512 / 1e3, 1) for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_blur_strip<true>", "k_octree",
                                                                                "k_orient_describe", "k_search_window") if _pmc(k) is not None},
@@ -210,7 +236,8 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512):
                                                                                        "k_search_window") if _pmc(k, "valu_issue_frac_at_4_cycles") is not None},
            "bound_note": "k_fast_cells_wave (70 %) and k_blur_strip (27 %) run concurrently and together saturate the VALU issue: the front-end phase is instruction bound, "
                          "its GB/s figures are reported against the HBM roofline for completeness"}
-    ex.close(); mt.close()
+    for q in P:
+        q.ex.close(); q.mt.close()
     return out
 
 
@@ -309,6 +336,13 @@ def main():
             for k, v in sy.stage_seconds().items():
                 stages[k] = stages.get(k, 0.0) + v
         summ["stage_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in stages.items()}
+        cores_s = {}
+        for sy in systems:
+            for k, v in sy.stage_seconds(cpu=True).items():
+                cores_s[k] = cores_s.get(k, 0.0) + v
+        summ["stage_core_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in cores_s.items()}
+        reuse = [sy.local_map_reuse() for sy in systems]
+        summ["local_map_reuse_frac"] = round(sum(r[0] for r in reuse) / max(1, sum(r[1] for r in reuse)), 4)
         for sy in systems:
             sy.close()
         return summ, rec
@@ -377,6 +411,8 @@ def main():
                "ate_rmse_m": round(summ["ate_rmse_m"], 6), "keyframes": summ["keyframes"], "local_bas": summ["local_bas"], "lost_frames": summ["lost_frames"],
                "map_violations": summ["map_violations"], "semantic_edges": summ["semantic_edges"],
                "stage_seconds_sum_over_handles": summ["stage_seconds_sum_over_handles"],
+               "stage_core_seconds_sum_over_handles": summ["stage_core_seconds_sum_over_handles"],
+               "local_map_reuse_frac": summ["local_map_reuse_frac"],
                "per_rank": [{"rank": int(r[0]), "frames": int(r[2]), "elapsed_s": round(float(r[3]), 4), "local_bas": int(r[5]), "ate_rmse_m": round(float(r[7]), 6)} for r in rec],
                "roofline": roof, "cpu_baseline": cpu, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
                "input_render_s": round(t_gen, 1)}

@@ -468,6 +468,15 @@ int oslam_frame_is_in_frustum_batch_device(int batch, int stride, const int32_t*
                                            const float K5[5], const float bounds[4], float viewingCosLimit, float logScaleFactor, const float* scaleFactors,
                                            int nLevels, oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream);
 
+/* same with the per-point arrays at their own stride ([batch][stride_in], a table that keeps the local points of every sequence resident) while the
+ * queries, in_view and the optional skip flags are [batch][stride_out], stride_out <= stride_in.  d_skip[b][i] != 0: point i of frame b already carries
+ * mnLastFrameSeen == the frame's id and is not projected (src/Tracking.cc:1413-1427): inactive query, in_view 0. */
+int oslam_frame_is_in_frustum_batch_resident_device(int batch, int stride_in, int stride_out, const int32_t* d_M, const float* d_Pw, const float* d_Pn,
+                                                    const float* d_maxDist, const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc,
+                                                    const uint8_t* d_skip, const float* d_Tcw, const float* d_th, const float K5[5], const float bounds[4],
+                                                    float viewingCosLimit, float logScaleFactor, const float* scaleFactors, int nLevels,
+                                                    oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream);
+
 /* LocalMapping::CreateNewMapPoints, per-match numeric core (reference src/LocalMapping.cc:291-432):
  * parallax test, 4x4 DLT by cv::SVD (one-sided Jacobi) or KeyFrame::UnprojectStereo (src/KeyFrame.cc:615-631),
  * cheirality, chi2 reprojection gates (5.991 / 7.8 x sigma2[octave]; the second view uses the CURRENT keyframe's mbf

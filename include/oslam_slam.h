@@ -100,6 +100,10 @@ typedef struct oslam_job_search_local {    /* Frame::isInFrustum(pMP, 0.5) over 
     int32_t slot; const oslam_slam_frame_t* cur; const uint8_t* blocked /* [N] mvpMapPoints[i] && Observations()>0 */;
     int32_t M; const float* Pw; const float* Pn; const float* maxDist; const float* minDist; const uint8_t* obs_gt0; const uint8_t* mp_desc;
     float Tcw[16]; float th;
+    const uint8_t* skip;                   /* [M] or NULL: != 0 = mnLastFrameSeen == this frame (already matched, or an outlier of the initial pose
+                                            * optimisation): the reference does not project it (src/Tracking.cc:1413-1427) — in_view 0, never matched */
+    int64_t content_id;                    /* identity of the CONTENT of Pw .. mp_desc (not of the pointers), 0 = none: a table that keeps the arrays of the
+                                            * slot's previous job resident may skip the upload when the id is the same; the pointers stay valid either way */
     uint8_t* in_view;                      /* out [M]: mbTrackInView */
     int32_t* kp_match;                     /* out [N]: local point index now in mvpMapPoints[k]; < 0 none */
     int32_t nmatches;
@@ -238,6 +242,12 @@ int oslam_slam_stats(oslam_slam_t* h, int seq, int64_t out[16]);
  * [10] CreateNewMapPoints, [11] SearchInNeighbors, [12] LocalBundleAdjustment gather + write-back, [13] KeyFrameCulling; of [4]: [14] motion model /
  * reference keyframe / after-tracking bookkeeping, [15] UpdateLocalMap + SearchLocalPoints + pose job. */
 int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]);
+/* Core-seconds of the same stages: CPU time of the stepping thread plus the time the shared workers spent on its parallel sections (for the device
+ * stages [0]-[3], [5], [6], [8] this is the host side of the operator: packing, launches, polling). */
+int oslam_slam_stage_cpu_seconds(oslam_slam_t* h, double out[16]);
+/* out[0] = tracked frames whose local map (mvpLocalMapPoints and the packed SearchLocalPoints arrays) was reused from the previous frame because neither
+ * the ordered local keyframe list nor the sequence's map had changed, out[1] = all tracked frames; summed over the sequences of the handle. */
+int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]);
 /* Device time of the kernel groups of the HIP operator table, measured with HIP events on the stream each group is launched on
  * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:
  * out[3g] = milliseconds, out[3g+1] = kernel launches, out[3g+2] = algorithmic work of those launches — bytes for group 0 (SURVEY.md

@@ -108,14 +108,26 @@ __global__ __launch_bounds__(256) void k_is_in_frustum(FrustumCtx c) {
 }
 
 // batch of frames: point arrays [batch][stride], one pose / th / count per frame; in_view[b][i] = mbTrackInView
-__global__ __launch_bounds__(256) void k_is_in_frustum_batch(FrustumCtx c, int stride, const int* __restrict__ d_M, const float* __restrict__ d_Tcw,
-                                                             const float* __restrict__ d_th, uint8_t* __restrict__ in_view) {
+// the point arrays are [batch][stride_in], the queries / in_view / skip flags [batch][stride_out]; skip[b][i] != 0: the point is not projected (an
+// inactive query, in_view 0)
+__global__ __launch_bounds__(256) void k_is_in_frustum_batch(FrustumCtx c, int stride_in, int stride_out, const int* __restrict__ d_M, const float* __restrict__ d_Tcw,
+                                                             const float* __restrict__ d_th, const uint8_t* __restrict__ skip, uint8_t* __restrict__ in_view) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d_M[b]) return;
-    const size_t at = (size_t)b * stride + i;
-    const bool ok = frustum_point(c, d_Tcw + (size_t)b * 16, d_th[b], (int)at, c.out + at);
-    if (in_view) in_view[at] = ok;
+    const size_t at = (size_t)b * stride_in + i, ao = (size_t)b * stride_out + i;
+    if (skip && skip[ao]) {
+        oslam_proj_query_t q;
+        q.u = q.v = q.ur = q.radius = 0.f; q.minLevel = -1; q.maxLevel = -1; q.flags = 0; q.angle = 0.f;
+        uint32_t* qd = (uint32_t*)q.desc;
+#pragma unroll
+        for (int w = 0; w < 8; w++) qd[w] = 0u;
+        c.out[ao] = q;
+        if (in_view) in_view[ao] = 0;
+        return;
+    }
+    const bool ok = frustum_point(c, d_Tcw + (size_t)b * 16, d_th[b], (int)at, c.out + ao);
+    if (in_view) in_view[ao] = ok;
 }
 
 __device__ __forceinline__ bool frustum_point(const FrustumCtx& c, const float* __restrict__ Tm, const float th, const int i, oslam_proj_query_t* out) {
@@ -314,23 +326,33 @@ int oslam_frame_is_in_frustum_device(int M, const float* d_Pw, const float* d_Pn
     return OSLAM_OK;
 }
 
-int oslam_frame_is_in_frustum_batch_device(int batch, int stride, const int32_t* d_M, const float* d_Pw, const float* d_Pn, const float* d_maxDist,
-                                           const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc, const float* d_Tcw, const float* d_th,
-                                           const float K5[5], const float bounds[4], float viewingCosLimit, float logScaleFactor, const float* scaleFactors,
-                                           int nLevels, oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream) {
-    if (batch < 0 || stride < 0 || !K5 || !bounds || !scaleFactors || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS ||
-        (batch > 0 && stride > 0 && (!d_M || !d_Pw || !d_Pn || !d_maxDist || !d_minDist || !d_obs_gt0 || !d_mp_desc || !d_Tcw || !d_th || !d_out))) {
+int oslam_frame_is_in_frustum_batch_resident_device(int batch, int stride_in, int stride_out, const int32_t* d_M, const float* d_Pw, const float* d_Pn,
+                                                    const float* d_maxDist, const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc,
+                                                    const uint8_t* d_skip, const float* d_Tcw, const float* d_th, const float K5[5], const float bounds[4],
+                                                    float viewingCosLimit, float logScaleFactor, const float* scaleFactors, int nLevels,
+                                                    oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream) {
+    if (batch < 0 || stride_in < 0 || stride_out < 0 || stride_out > stride_in || !K5 || !bounds || !scaleFactors || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS ||
+        (batch > 0 && stride_out > 0 && (!d_M || !d_Pw || !d_Pn || !d_maxDist || !d_minDist || !d_obs_gt0 || !d_mp_desc || !d_Tcw || !d_th || !d_out))) {
         set_error("bad argument");
         return OSLAM_E_INVALID;
     }
-    if (batch == 0 || stride == 0) return OSLAM_OK;
+    if (batch == 0 || stride_out == 0) return OSLAM_OK;
     FrustumCtx c;
     const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     fill_frustum(c, 0, I, K5, bounds, viewingCosLimit, logScaleFactor, scaleFactors, nLevels, 1.0f);
     c.Pw = d_Pw; c.Pn = d_Pn; c.maxDist = d_maxDist; c.minDist = d_minDist; c.obs_gt0 = d_obs_gt0; c.mp_desc = d_mp_desc; c.out = d_out;
-    hipLaunchKernelGGL(k_is_in_frustum_batch, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c, stride, d_M, d_Tcw, d_th, d_in_view);
+    hipLaunchKernelGGL(k_is_in_frustum_batch, dim3(div_up(stride_out, 256), batch), dim3(256), 0, (hipStream_t)stream, c, stride_in, stride_out, d_M, d_Tcw, d_th,
+                       d_skip, d_in_view);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
+}
+
+int oslam_frame_is_in_frustum_batch_device(int batch, int stride, const int32_t* d_M, const float* d_Pw, const float* d_Pn, const float* d_maxDist,
+                                           const float* d_minDist, const uint8_t* d_obs_gt0, const uint8_t* d_mp_desc, const float* d_Tcw, const float* d_th,
+                                           const float K5[5], const float bounds[4], float viewingCosLimit, float logScaleFactor, const float* scaleFactors,
+                                           int nLevels, oslam_proj_query_t* d_out, uint8_t* d_in_view, void* stream) {
+    return oslam_frame_is_in_frustum_batch_resident_device(batch, stride, stride, d_M, d_Pw, d_Pn, d_maxDist, d_minDist, d_obs_gt0, d_mp_desc, nullptr, d_Tcw, d_th, K5,
+                                                           bounds, viewingCosLimit, logScaleFactor, scaleFactors, nLevels, d_out, d_in_view, stream);
 }
 
 int oslam_frame_is_in_frustum(oslam_mappoint_t* h, int M, const float* Pw, const float* Pn, const float* maxDist, const float* minDist, const uint8_t* obs_gt0,

@@ -3,6 +3,7 @@
 // (src/LocalMapping.cc:48-113) restated as lockstep STAGES over S sequences; every hot-path operator is issued once per
 // stage for all sequences through the operator table (slam_ops_hip.hip binds the HIP kernels).  No CPU fallback lives
 // here: oslam_slam_create() fails without a HIP device.  Never includes oracle/.
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -49,10 +50,16 @@ struct Vocab {
 
 struct Timer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    long long c0 = thread_cpu_ns();
+    double cpu = 0;   // core-seconds of the last lap: this thread's CPU time + what the workers spent on its batches
     double lap() {
         auto t1 = std::chrono::steady_clock::now();
         const double d = std::chrono::duration<double>(t1 - t0).count();
         t0 = t1;
+        const long long c1 = thread_cpu_ns();
+        CpuAccount* a = thread_account();
+        cpu = 1e-9 * (double)((c1 - c0) + (a ? a->worker_ns.exchange(0, std::memory_order_relaxed) : 0));
+        c0 = c1;
         return d;
     }
 };
@@ -103,6 +110,16 @@ struct Seq {
     int matchesInliers = 0;
     std::vector<int> localKFs, localMPs;
     std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
+    // Local-map cache: mvpLocalMapPoints is a function of the ordered local keyframe list and of the map, and the map only changes when this sequence
+    // creates a keyframe or its local mapping runs (mapVersion counts both).  A frame whose list and version equal the cached ones reuses the walk of
+    // the keyframes' map points AND the packed SearchLocalPoints arrays (whose copy the operator table may keep resident: content id).
+    long long mapVersion = 0, locVersion = -1, locContentId = 0;
+    int locWalkFrame = -1;                // frame id of the cached walk: mpMark[p] == locWalkFrame <=> p was visited by it
+    bool locReused = false;
+    std::vector<int> locKFs, mpPos;       // cached keyframe list; position of a visited point in localMPs (-1: visited but bad)
+    std::vector<int> seenList;            // points given mnLastFrameSeen = this frame outside SearchLocalPoints (outliers of the initial pose optimisation)
+    std::vector<float> locPw, locPn, locMax, locMin;
+    std::vector<uint8_t> locObs, locDesc, jSkip;
     std::vector<RelPose> rel;
     std::vector<int> recentAdded;          // mlpRecentAddedMapPoints
     std::vector<int> newKFs;               // mlNewKeyFrames (at most one per step)
@@ -113,9 +130,9 @@ struct Seq {
     int path = 0;                          // 0 none, 1 motion model, 2 reference keyframe
     bool ok = false;
     int curKF = -1;                        // keyframe being processed by local mapping this step
-    std::vector<float> jXw, jObs, jInv, jPw, jPn, jMax, jMin;
-    std::vector<uint8_t> jHas, jDesc, jBlocked, jObsGt0, jInView, jOutlier;
-    std::vector<int> jMatch, jLocalIds;
+    std::vector<float> jXw, jObs, jInv;
+    std::vector<uint8_t> jHas, jDesc, jBlocked, jInView, jOutlier;
+    std::vector<int> jMatch;
     oslam_job_search_last_t jSL; oslam_job_search_local_t jLoc; oslam_job_pose_t jPose;
     bool hasSL = false, hasLoc = false;
     // object layer substitute (include/oslam_slam.h head comment): Object3Ds keyed by the caller's track id
@@ -137,6 +154,7 @@ struct Seq {
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
+        mapVersion++; locVersion = -1; locWalkFrame = -1; locKFs.clear();
         resetRequested = false;
     }
     std::vector<int> updList;             // points created by tracking this step (descriptor / normal pending)
@@ -157,6 +175,10 @@ struct Ctx {
     std::vector<std::unique_ptr<Seq>> seq;
     std::unique_ptr<Pool> pool;
     double sec[16] = {0};
+    double cpu[16] = {0};   // core-seconds of the same stages (host thread + workers)
+    CpuAccount acct;
+    std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
+    long long next_content_id() { return contentCounter.fetch_add(1, std::memory_order_relaxed) + 1; }
     int mask_stride = 0, masks_on_device = 0;
 };
 
@@ -203,6 +225,7 @@ static bool unproject_frame(const Ctx& c, const Frame& f, int i, float out[3]) {
 
 // KeyFrame::KeyFrame(Frame&, ...) (src/KeyFrame.cc:30-58)
 static int new_keyframe(Seq& s, const Frame& f) {
+    s.mapVersion++;
     s.map.kfs.emplace_back();
     KeyFrm& k = s.map.kfs.back();
     k.id = (int)s.map.kfs.size() - 1;
@@ -377,11 +400,14 @@ static void update_local_map(Seq& s) {
         }
         if (kmax >= 0) { s.refKF = kmax; f.refKF = kmax; }
     }
+    s.locReused = s.locVersion == s.mapVersion && s.locWalkFrame >= 0 && s.localKFs == s.locKFs;
+    if (s.locReused) return;   // same ordered keyframe list over an unchanged map: the walk below would rebuild the same list
     // mnTrackReferenceForFrame of the map points as a dense per-sequence array: the loop below visits 10-20 k keyframe slots per frame and
     // most of them hit an already marked point, so it should touch 4 bytes per slot, not a 136-byte MapPt.  A bad point is marked too (it
     // is never pushed either way), which leaves the list unchanged.
-    if (s.mpMark.size() < m.mps.size()) s.mpMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+    if (s.mpMark.size() < m.mps.size()) { const size_t n = m.mps.size() + m.mps.size() / 2 + 64; s.mpMark.resize(n, 0); s.mpPos.resize(n, -1); }
     int* mark = s.mpMark.data();
+    int* pos = s.mpPos.data();
     s.localMPs.clear();
     for (int k : s.localKFs) {
         const KeyFrm& kf = m.kfs[k];
@@ -390,9 +416,11 @@ static void update_local_map(Seq& s) {
             const int p = kmp[i];
             if (p < 0 || mark[p] == f.id) continue;
             mark[p] = f.id;
-            if (!m.mps[p].bad) s.localMPs.push_back(p);
+            if (!m.mps[p].bad) { pos[p] = (int)s.localMPs.size(); s.localMPs.push_back(p); }
+            else pos[p] = -1;
         }
     }
+    s.locKFs = s.localKFs; s.locVersion = s.mapVersion; s.locWalkFrame = f.id;
 }
 
 // fills the PoseOptimization job arrays of the current frame
@@ -429,6 +457,7 @@ static bool finish_initial_pose(Seq& s, const oslam_job_pose_t& j) {
         if (j.outlier[i]) {
             f.mp[i] = -1; f.outlier[i] = 0;
             s.map.mps[p].lastFrameSeen = f.id;
+            s.seenList.push_back(p);
         } else {
             f.outlier[i] = 0;
             if (s.map.mps[p].nObs > 0) nmatchesMap++;
@@ -569,6 +598,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     // --- ProcessNewKeyFrame (:129-169) ---
     Pool& pool = *c.pool;
     const int nW = (int)who.size();
+    for (int si : who) c.seq[si]->mapVersion++;   // the map of these sequences changes below: their cached local maps are stale
     auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
     pool.parallel_for(nW, [&](int w) {
         Seq& s = *c.seq[who[w]];
@@ -586,16 +616,16 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         }
     });
     merge_upd();
-    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; }
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; c.cpu[7] += tm.cpu; c.cpu[9] += tm.cpu; }
     if ((rc = upd.run(c, true, true))) return rc;
-    c.sec[5] += tm.lap();
+    { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
     pool.parallel_for(nW, [&](int w) {
         Seq& s = *c.seq[who[w]];
         s.map.update_connections(s.curKF, s.counter);
         s.map.nKFsInMap++;
         if (flags & 1) map_point_culling(s);
     });
-    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; }
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; c.cpu[7] += tm.cpu; c.cpu[9] += tm.cpu; }
 
     // --- CreateNewMapPoints (:208-453): neighbours in lockstep (the matches of neighbour i see the points created from neighbour i-1) ---
     if (flags & 2) {
@@ -652,7 +682,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (size_t w = 0; w < who.size(); w++)
                 if (have[w]) { bj.push_back(cand[w]); bjw.push_back((int)w); bkey.push_back({who[w], c.seq[who[w]]->curKF, neigh[w][ni]}); }
             if (bj.empty()) continue;
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; c.cpu[7] += tm.cpu; c.cpu[10] += tm.cpu; }
             if ((rc = c.ops.bow_keyed ? c.ops.bow_keyed(c.ops.ctx, (int)bj.size(), bj.data(), bkey.data()) : c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
             std::vector<oslam_job_triangulate_t> tj(bj.size());
             std::vector<std::vector<int32_t>> i1(bj.size()), i2(bj.size());
@@ -671,7 +701,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 t.ok = okv[q].data(); t.x3D = x3[q].data();
             });
             if ((rc = c.ops.triangulate(c.ops.ctx, (int)tj.size(), tj.data()))) return rc;
-            c.sec[8] += tm.lap();
+            { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
             pool.parallel_for((int)bj.size(), [&](int q) {   // one job per sequence: independent maps
                 const size_t w = bjw[q];
                 Seq& s = *c.seq[who[w]];
@@ -690,9 +720,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
             });
             merge_upd();
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; }
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; c.cpu[7] += tm.cpu; c.cpu[10] += tm.cpu; }
             if ((rc = upd.run(c, true, true))) return rc;
-            c.sec[5] += tm.lap();
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
         }
     }
 
@@ -745,16 +775,16 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 j.M = (int)fs[w].q.size(); j.queries = fs[w].q.data(); j.q_match = fs[w].qm.data();
                 jobs.push_back(j); jw.push_back((int)w); fkey.push_back({who[w], k, -1});
             }
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
             if (jobs.empty()) return OSLAM_OK;
             int rc2 = c.ops.fuse_keyed ? c.ops.fuse_keyed(c.ops.ctx, (int)jobs.size(), jobs.data(), fkey.data()) : c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
             if (rc2) return rc2;
-            c.sec[8] += tm.lap();
+            { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
             pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].qpt, fs[w].qm.data()); });
             merge_upd();
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
             rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
-            c.sec[5] += tm.lap();
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
             return rc2;
         };
         for (size_t t = 0; t < maxt; t++)
@@ -782,11 +812,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (int p : s.map.kfs[s.curKF].mp)
                 if (p >= 0 && !s.map.mps[p].bad) upd.add(si, p);
         }
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
         if ((rc = upd.run(c, true, true))) return rc;
-        c.sec[5] += tm.lap();
+        { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
         pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; s.map.update_connections(s.curKF, s.counter); });
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; }
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
     }
 
     // --- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:453-778), all windows in one batch ---
@@ -861,9 +891,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             p.nE = (int)W.ekf.size(); p.edge_kf = W.ekf.data(); p.edge_pt = W.ept.data(); p.edge_obs = W.eobs.data(); p.edge_invSigma2 = W.einv.data();
             p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data(); p.stats = nullptr;
         }
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; }
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
         if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
-        c.sec[6] += tm.lap();
+        { c.sec[6] += tm.lap(); c.cpu[6] += tm.cpu; }
         pool.parallel_for((int)wins.size(), [&](int wi) {
             Win& W = wins[wi];
             Seq& s = *c.seq[W.si];
@@ -890,9 +920,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
         });
         merge_upd();
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; }
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
         if ((rc = upd.run(c, false, true))) return rc;
-        c.sec[5] += tm.lap();
+        { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
     }
 
     // --- KeyFrameCulling (:633-697) ---
@@ -923,7 +953,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; }
             }
         });
-    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; }
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
     return OSLAM_OK;
 }
 
@@ -1084,24 +1114,34 @@ static void stage_local_map_prepare(Ctx& c, int i) {
         m.mps[p].lastFrameSeen = f.id;
         s.jBlocked[k] = m.mps[p].nObs > 0;
     }
-    s.jLocalIds.clear();
-    for (int p : s.localMPs) {
-        const MapPt& mp = m.mps[p];
-        if (mp.lastFrameSeen == f.id || mp.bad) continue;
-        s.jLocalIds.push_back(p);
+    // The job lists ALL local points; those the reference leaves out of the projection (mnLastFrameSeen == this frame, :1413-1427: matched above or
+    // discarded as outliers of the initial pose optimisation) are flagged in `skip`, so the packed arrays only depend on the local map and stay valid
+    // (here and, by content id, in the operator table's resident copy) until the keyframe list or the map changes.
+    const int M = (int)s.localMPs.size();
+    if (!s.locReused) {
+        s.locPw.resize((size_t)M * 3 + 3); s.locPn.resize((size_t)M * 3 + 3); s.locMax.resize(M + 1); s.locMin.resize(M + 1); s.locObs.resize(M + 1);
+        s.locDesc.resize((size_t)M * 32 + 32);
+        for (int q = 0; q < M; q++) {
+            const MapPt& mp = m.mps[s.localMPs[q]];
+            for (int d = 0; d < 3; d++) { s.locPw[(size_t)q * 3 + d] = mp.pos[d]; s.locPn[(size_t)q * 3 + d] = mp.normal[d]; }
+            s.locMax[q] = mp.maxD; s.locMin[q] = mp.minD; s.locObs[q] = mp.nObs > 0;
+            memcpy(&s.locDesc[(size_t)q * 32], mp.desc, 32);
+        }
+        s.locContentId = c.next_content_id();
+    } else c.locReuse.fetch_add(1, std::memory_order_relaxed);
+    c.locFrames.fetch_add(1, std::memory_order_relaxed);
+    s.jSkip.assign(M + 1, 0);
+    {
+        const int* mark = s.mpMark.data();
+        const int* pos = s.mpPos.data();
+        auto flag = [&](int p) { if ((size_t)p < s.mpMark.size() && mark[p] == s.locWalkFrame && pos[p] >= 0) s.jSkip[pos[p]] = 1; };
+        for (int k = 0; k < f.N; k++) if (f.mp[k] >= 0) flag(f.mp[k]);
+        for (int p : s.seenList) flag(p);
     }
-    const int M = (int)s.jLocalIds.size();
-    s.jPw.resize((size_t)M * 3 + 3); s.jPn.resize((size_t)M * 3 + 3); s.jMax.resize(M + 1); s.jMin.resize(M + 1); s.jObsGt0.resize(M + 1);
-    s.jDesc.resize((size_t)M * 32 + 32); s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
-    for (int q = 0; q < M; q++) {
-        const MapPt& mp = m.mps[s.jLocalIds[q]];
-        for (int d = 0; d < 3; d++) { s.jPw[(size_t)q * 3 + d] = mp.pos[d]; s.jPn[(size_t)q * 3 + d] = mp.normal[d]; }
-        s.jMax[q] = mp.maxD; s.jMin[q] = mp.minD; s.jObsGt0[q] = mp.nObs > 0;
-        memcpy(&s.jDesc[(size_t)q * 32], mp.desc, 32);
-    }
+    s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
     oslam_job_search_local_t& j = s.jLoc;
-    j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.jPw.data(); j.Pn = s.jPn.data(); j.maxDist = s.jMax.data();
-    j.minDist = s.jMin.data(); j.obs_gt0 = s.jObsGt0.data(); j.mp_desc = s.jDesc.data();
+    j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.locPw.data(); j.Pn = s.locPn.data(); j.maxDist = s.locMax.data();
+    j.minDist = s.locMin.data(); j.obs_gt0 = s.locObs.data(); j.mp_desc = s.locDesc.data(); j.skip = s.jSkip.data(); j.content_id = s.locContentId;
     memcpy(j.Tcw, f.pose.Tcw.m, 64);
     j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : (c.stereo ? 1.f : 3.f);   // th = 1, RGB-D 3, after a relocalisation 5 (:1450-1455)
     j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;
@@ -1198,6 +1238,8 @@ static int run_pose_jobs(Ctx& c, const std::vector<int>& who) {
 static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* right, int gray_stride, const float* const* depth, int depth_pitch,
                       int on_device, const double* stamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
     const int S = c.S;
+    thread_account() = &c.acct;   // the workers bill the tasks of this thread's batches (driver and operator table) to this handle
+    c.acct.worker_ns.store(0, std::memory_order_relaxed);
     Timer tm;
     int rc;
     Pool& pool = *c.pool;
@@ -1210,13 +1252,14 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         else rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data());
         if (rc) return rc;
     }
-    c.sec[0] += tm.lap();
+    { c.sec[0] += tm.lap(); c.cpu[0] += tm.cpu; }
     std::vector<int> tracking;   // sequences in the "system is initialised" branch
     pool.parallel_for(S, [&](int i) {
         Seq& s = *c.seq[i];
         if (s.resetRequested) s.reset();   // System::TrackRGBD: if(mbReset) mpTracker->Reset() before the frame is grabbed (src/System.cc:262-266)
         const int fid = s.nextFrameId++;
         s.cur->begin(fid, stamps ? stamps[i] : (double)fid);
+        s.seenList.clear();
         s.st[0]++;
         s.path = 0; s.ok = false; s.hasSL = s.hasLoc = false;
         s.updList.clear();
@@ -1232,6 +1275,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             s.localKFs.assign(1, kf);
             s.localMPs.clear();
             for (int p : s.map.kfs[kf].mp) if (p >= 0) s.localMPs.push_back(p);
+            s.locVersion = -1;   // not a walk of update_local_map: nothing cached
             s.refKF = kf; f.refKF = kf;
             s.state = ST_OK;
             s.path = -1;   // initialised in this step: not tracked
@@ -1257,7 +1301,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             if ((rc = c.ops.object_kps(c.ops.ctx, (int)oj.size(), oj.data()))) return rc;
             pool.parallel_for((int)ojw.size(), [&](int q) { build_object2ds(c, *c.seq[ojw[q]]); });
         }
-        c.sec[0] += tm.lap();
+        { c.sec[0] += tm.lap(); c.cpu[0] += tm.cpu; }
     }
     for (int i = 0; i < S; i++) if (c.seq[i]->state == ST_OK && c.seq[i]->path != -1) tracking.push_back(i);
     const int nT = (int)tracking.size();
@@ -1266,7 +1310,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     std::vector<oslam_job_search_last_t> sl;
     std::vector<int> slw;
     for (int i : tracking) if (c.seq[i]->hasSL) { sl.push_back(c.seq[i]->jSL); slw.push_back(i); }
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
     if (!sl.empty()) {
         if ((rc = c.ops.search_last(c.ops.ctx, (int)sl.size(), sl.data()))) return rc;
         std::vector<oslam_job_search_last_t> again;
@@ -1278,7 +1322,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             for (size_t q = 0; q < again.size(); q++) sl[againAt[q]].nmatches = again[q].nmatches;
         }
     }
-    c.sec[1] += tm.lap();
+    { c.sec[1] += tm.lap(); c.cpu[1] += tm.cpu; }
     std::vector<int> pjw;
     for (size_t q = 0; q < sl.size(); q++) {
         Seq& s = *c.seq[slw[q]];
@@ -1291,9 +1335,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         for (int k = 0; k < f.N; k++) f.mp[k] = s.jMatch[k] >= 0 ? l.mp[s.jMatch[k]] : -1;
         fill_pose_job(c, s, pjw[q], s.jPose);
     });
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
     if ((rc = run_pose_jobs(c, pjw))) return rc;
-    c.sec[2] += tm.lap();
+    { c.sec[2] += tm.lap(); c.cpu[2] += tm.cpu; }
     pool.parallel_for((int)pjw.size(), [&](int q) {
         Seq& s = *c.seq[pjw[q]];
         s.ok = finish_initial_pose(s, s.jPose);
@@ -1327,11 +1371,11 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 j.s2.nNodes = (int)bv[q].nodes.size(); j.s2.nodes = bv[q].nodes.data(); j.s2.start = bv[q].start.data(); j.s2.items = bv[q].items.data();
                 j.triangulation = 0; j.nnratio = 0.7f; j.checkOri = 1; j.match = match[q].data();
             });
-            { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+            { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
             std::vector<oslam_kf_key_t> bkey(rk.size());
             for (size_t q = 0; q < rk.size(); q++) bkey[q] = {rk[q], c.seq[rk[q]]->refKF, -2};   // side 2 = the current frame, still on the device
             if ((rc = c.ops.bow_keyed ? c.ops.bow_keyed(c.ops.ctx, (int)bj.size(), bj.data(), bkey.data()) : c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
-            c.sec[8] += tm.lap();
+            { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
             pjw.clear();
             for (size_t q = 0; q < rk.size(); q++) {
                 Seq& s = *c.seq[rk[q]];
@@ -1345,7 +1389,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 pjw.push_back(rk[q]);
             }
             if ((rc = run_pose_jobs(c, pjw))) return rc;
-            c.sec[2] += tm.lap();
+            { c.sec[2] += tm.lap(); c.cpu[2] += tm.cpu; }
             for (int i : pjw) {
                 Seq& s = *c.seq[i];
                 s.ok = finish_initial_pose(s, s.jPose);
@@ -1358,14 +1402,14 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     std::vector<oslam_job_search_local_t> lj;
     std::vector<int> ljw;
     for (int i : tracking) if (c.seq[i]->hasLoc) { lj.push_back(c.seq[i]->jLoc); ljw.push_back(i); }
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; c.cpu[4] += tm.cpu; c.cpu[15] += tm.cpu; }
     if (!lj.empty() && (rc = c.ops.search_local(c.ops.ctx, (int)lj.size(), lj.data()))) return rc;
-    c.sec[3] += tm.lap();
+    { c.sec[3] += tm.lap(); c.cpu[3] += tm.cpu; }
     pool.parallel_for((int)ljw.size(), [&](int q) {
         Seq& s = *c.seq[ljw[q]];
         Frame& f = *s.cur;
-        for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.jLocalIds[e]].visible++;
-        for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.jLocalIds[s.jMatch[k]];
+        for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.localMPs[e]].visible++;
+        for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.localMPs[s.jMatch[k]];
         fill_pose_job(c, s, ljw[q], s.jPose);
         s.hasPose2 = false;
         if (s.det && !f.objs.empty()) {   // TrackObject (:453) then ObjectOptimizer::PoseOptimization2 (:1022); without matched objects it is PoseOptimization
@@ -1373,7 +1417,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             fill_pose2_job(c, s, ljw[q]);
         }
     });
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[15] += d_; c.cpu[4] += tm.cpu; c.cpu[15] += tm.cpu; }
     {
         std::vector<int> plain, sem;
         for (int i : ljw) (c.seq[i]->hasPose2 ? sem : plain).push_back(i);
@@ -1389,7 +1433,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             }
         }
     }
-    c.sec[2] += tm.lap();
+    { c.sec[2] += tm.lap(); c.cpu[2] += tm.cpu; }
     pool.parallel_for((int)ljw.size(), [&](int q) { stage_after_local_pose(c, ljw[q]); });
     // ---------------- after tracking (:470-566) ----------------
     pool.parallel_for(nT, [&](int q) { stage_after_tracking(c, tracking[q]); });
@@ -1400,7 +1444,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (!s.newKFs.empty()) mapping.push_back(i);
         for (int p : s.updList) upd.add(i, p);
     }
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
     if (c.ops.register_keyframes) {   // the frames that became keyframes are still on the device: the table keeps them (include/oslam_slam.h)
         std::vector<int32_t> rs, rk;
         for (int i = 0; i < S; i++) {
@@ -1410,7 +1454,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (!rs.empty() && (rc = c.ops.register_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
     }
     if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
-    c.sec[5] += tm.lap();
+    { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
     // store relative poses (:569-585), swap frames
     for (int i = 0; i < S; i++) {
         Seq& s = *c.seq[i];
@@ -1434,7 +1478,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (state_out) state_out[i] = s.state;
         if (s.state != ST_NOT_INITIALIZED) std::swap(s.cur, s.last);   // mLastFrame = Frame(mCurrentFrame)
     }
-    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; }
+    { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
     return run_local_mapping(c, mapping);
 }
 
@@ -1617,6 +1661,18 @@ int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_K
     if (!h) { oslam::set_error("oslam_slam_kernel_times: bad argument"); return OSLAM_E_INVALID; }
     if (!h->c.ops.kernel_times) { oslam::set_error("oslam_slam_kernel_times: this operator table has no device timing"); return OSLAM_E_INVALID; }
     return h->c.ops.kernel_times(h->c.ops.ctx, enable, out);
+}
+
+int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]) {
+    if (!h || !out) { oslam::set_error("oslam_slam_local_map_reuse: bad argument"); return OSLAM_E_INVALID; }
+    out[0] = h->c.locReuse.load(); out[1] = h->c.locFrames.load();
+    return OSLAM_OK;
+}
+
+int oslam_slam_stage_cpu_seconds(oslam_slam_t* h, double out[16]) {
+    if (!h || !out) { oslam::set_error("oslam_slam_stage_cpu_seconds: bad argument"); return OSLAM_E_INVALID; }
+    memcpy(out, h->c.cpu, sizeof(h->c.cpu));
+    return OSLAM_OK;
 }
 
 int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]) {

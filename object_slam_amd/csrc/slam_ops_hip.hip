@@ -44,6 +44,27 @@ struct HipOps {
     uint8_t* dn_h = nullptr; size_t dn_cap = 0;
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     uint8_t* d_objbits = nullptr;                        // [S][cap] keypoint test bits (object_kps)
+    // Resident local maps: the packed SearchLocalPoints arrays of every slot stay on the device ([S][loc_st] each); a job whose content id equals the
+    // slot's is not uploaded again (the driver repacks only when the sequence's local keyframe list or map changed)
+    uint8_t* d_loc = nullptr; size_t loc_st = 0;
+    std::vector<long long> loc_id;
+    float* loc_Pw() const { return (float*)d_loc; }
+    float* loc_Pn() const { return (float*)(d_loc + 12 * loc_st * S); }
+    float* loc_Max() const { return (float*)(d_loc + 24 * loc_st * S); }
+    float* loc_Min() const { return (float*)(d_loc + 28 * loc_st * S); }
+    uint8_t* loc_Obs() const { return d_loc + 32 * loc_st * S; }
+    uint8_t* loc_Desc() const { return d_loc + 33 * loc_st * S; }
+    int ensure_loc() {   // follows max_local
+        const size_t want = oslam::align_up((size_t)std::max(max_local, 1), 64);
+        if (d_loc && loc_st == want) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+        if (d_loc) (void)hipFree(d_loc);
+        d_loc = nullptr;
+        loc_st = want;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&d_loc, 65 * loc_st * S));
+        loc_id.assign(S, 0);
+        return OSLAM_OK;
+    }
     // Resident keyframe store: one record per keyframe = device copies of mvKeysUn | mDescriptors | mvuRight (cap entries each), in chunks of kRecChunk records
     static constexpr int kRecChunk = 256;
     std::vector<uint8_t*> rec_chunks;
@@ -327,6 +348,8 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
 
 // Tracking::SearchLocalPoints for the sequences in `jobs`: local points uploaded slot-major, ONE Frame::isInFrustum launch writes the
 // projection queries on the device, ONE windowed search launch consumes them; only the match table and the in-view flags come back.
+struct CopySegH { const uint8_t* src; uint8_t* dst; uint32_t bytes, pad; };   // oslam_copy_segments_device's record
+
 int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
@@ -344,13 +367,27 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
         OPS_CHECK(oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, o->cfg.device));
     }
-    const size_t st = oslam::align_up((size_t)std::max(maxM, 1), 64);
+    OPS_CHECK(o->ensure_loc());
+    const size_t st = oslam::align_up((size_t)std::max(maxM, 1), 64), lst = o->loc_st;
+    const bool resident = getenv("OSLAM_SLAM_NO_RESIDENT_LOCAL") == nullptr;
+    // jobs whose packed arrays are not the ones the slot holds: their arrays travel (packed back to back) and one launch scatters them into the slots
+    std::vector<int> fresh;
+    std::vector<size_t> foff;
+    size_t fbytes = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_search_local_t& j = jobs[i];
+        if (resident && j.content_id != 0 && o->loc_id[j.slot] == j.content_id) continue;
+        fresh.push_back(i); foff.push_back(fbytes);
+        fbytes += oslam::align_up(65 * (size_t)j.M + 6 * 16, 64);   // six sub-arrays, each starting on a 16-byte boundary
+    }
     Layout L;
-    const size_t oM = L.take(4 * S), oTc = L.take(64 * S), oTh = L.take(4 * S), oBl = L.take(cap * S), oPw = L.take(12 * st * S), oPn = L.take(12 * st * S),
-                 oMax = L.take(4 * st * S), oMin = L.take(4 * st * S), oObs = L.take(st * S), oDesc = L.take(32 * st * S);
+    const size_t oM = L.take(4 * S), oTc = L.take(64 * S), oTh = L.take(4 * S), oBl = L.take(cap * S), oSk = L.take(st * S), oSeg = L.take(sizeof(CopySegH) * 6 * fresh.size());
+    const size_t small_bytes = L.off;
+    const size_t oF = L.take(fbytes);
     OPS_CHECK(o->ensure_up(L.off));
     OPS_CHECK(o->ensure_lq(st * S));
     uint8_t* U = o->up_h;
+    uint8_t* Dv = o->up_d;
     memset(U + oM, 0, 4 * S);
     memset(U + oTh, 0, 4 * S);
     o->pool->parallel_for(n, [&](int i) {
@@ -360,16 +397,33 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         ((float*)(U + oTh))[b] = j.th;
         memcpy(U + oTc + 64 * b, j.Tcw, 64);
         memcpy(U + oBl + cap * b, j.blocked, (size_t)j.cur->N);
-        memcpy(U + oPw + 12 * st * b, j.Pw, 12 * M); memcpy(U + oPn + 12 * st * b, j.Pn, 12 * M);
-        memcpy(U + oMax + 4 * st * b, j.maxDist, 4 * M); memcpy(U + oMin + 4 * st * b, j.minDist, 4 * M);
-        memcpy(U + oObs + st * b, j.obs_gt0, M); memcpy(U + oDesc + 32 * st * b, j.mp_desc, 32 * M);
+        if (j.skip) memcpy(U + oSk + st * b, j.skip, M);
+        else memset(U + oSk + st * b, 0, M);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
-    uint8_t* Dv = o->up_d;
+    o->pool->parallel_for((int)fresh.size(), [&](int q) {
+        const oslam_job_search_local_t& j = jobs[fresh[q]];
+        const size_t b = j.slot, M = j.M;
+        uint8_t* at = U + oF + foff[q];
+        const uint8_t* dv = Dv + oF + foff[q];
+        CopySegH* sg = (CopySegH*)(U + oSeg) + 6 * (size_t)q;
+        const void* src[6] = {j.Pw, j.Pn, j.maxDist, j.minDist, j.obs_gt0, j.mp_desc};
+        const size_t bytes[6] = {12 * M, 12 * M, 4 * M, 4 * M, M, 32 * M};
+        uint8_t* dst[6] = {(uint8_t*)(o->loc_Pw() + 3 * lst * b), (uint8_t*)(o->loc_Pn() + 3 * lst * b), (uint8_t*)(o->loc_Max() + lst * b),
+                           (uint8_t*)(o->loc_Min() + lst * b), o->loc_Obs() + lst * b, o->loc_Desc() + 32 * lst * b};
+        size_t off = 0;
+        for (int k = 0; k < 6; k++) {   // sources and destinations are 16-byte aligned: the copy kernel moves 16 bytes per lane
+            memcpy(at + off, src[k], bytes[k]);
+            sg[k].src = dv + off; sg[k].dst = dst[k]; sg[k].bytes = (uint32_t)bytes[k]; sg[k].pad = 0;
+            off += oslam::align_up(bytes[k], 16);
+        }
+        o->loc_id[b] = j.content_id;
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, fresh.empty() ? small_bytes : L.off, hipMemcpyHostToDevice, o->strm));
+    if (!fresh.empty()) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 6 * (int)fresh.size(), o->strm));   // (a zero-byte segment's workgroup returns at once)
     o->t_begin();
-    OPS_CHECK(oslam_frame_is_in_frustum_batch_device((int)S, (int)st, (const int32_t*)(Dv + oM), (const float*)(Dv + oPw), (const float*)(Dv + oPn),
-                                                     (const float*)(Dv + oMax), (const float*)(Dv + oMin), Dv + oObs, Dv + oDesc, (const float*)(Dv + oTc),
-                                                     (const float*)(Dv + oTh), o->K5, o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview, o->strm));
+    OPS_CHECK(oslam_frame_is_in_frustum_batch_resident_device((int)S, (int)lst, (int)st, (const int32_t*)(Dv + oM), o->loc_Pw(), o->loc_Pn(), o->loc_Max(), o->loc_Min(),
+                                                              o->loc_Obs(), o->loc_Desc(), Dv + oSk, (const float*)(Dv + oTc), (const float*)(Dv + oTh), o->K5,
+                                                              o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview, o->strm));
     oslam_match_frames_t fr;
     frames_view(o, fr, Dv + oBl);
     OPS_CHECK(oslam_match_search_batch_device(o->m_map, &fr, o->d_lq, (int)st, (const int32_t*)(Dv + oM), 0, (int)S, 0.8f, 1, 0, 100, o->strm));
@@ -678,7 +732,6 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
 }
 
 // ---- resident keyframes ----
-struct CopySegH { const uint8_t* src; uint8_t* dst; uint32_t bytes, pad; };
 
 int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf_ids) {
     HipOps* o = (HipOps*)p;
@@ -863,7 +916,7 @@ void h_destroy(void* p) {
     if (o->dn_h) (void)hipHostFree(o->dn_h);
     for (uint8_t* c : o->rec_chunks) (void)hipFree(c);
     if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
-    (void)hipFree(o->up_d); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
+    (void)hipFree(o->up_d); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
     if (o->tev1) (void)hipEventDestroy(o->tev1);

@@ -13,9 +13,20 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <time.h>
 #include <vector>
 
 namespace oslam_drv {
+
+// CPU-time account of one driver handle: the workers add the thread-CPU time of the tasks they run for a batch to the account the batch's owner has
+// set for its thread (the owner's own share is in its thread's CPU clock), so a stage's core-seconds can be told from its wall time.
+struct CpuAccount { std::atomic<long long> worker_ns{0}; };
+inline CpuAccount*& thread_account() { static thread_local CpuAccount* a = nullptr; return a; }
+inline long long thread_cpu_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
 
 class SharedWorkers {
 public:
@@ -23,6 +34,7 @@ public:
         std::function<void(int)>* fn = nullptr;
         int n = 0;
         std::atomic<int> next{0}, finished{0};
+        CpuAccount* acct = nullptr;  // owner's account (may be null)
         std::atomic<int> users{0};   // workers inside work() for this batch (incremented under the pool mutex): the owner may not leave before they have
     };
     static SharedWorkers& instance() {
@@ -48,6 +60,7 @@ public:
     }
     // runs b.fn(i) for i in [0, n) on the caller and on idle workers; returns when all calls have finished
     void run(Batch& b) {
+        b.acct = thread_account();
         {
             std::lock_guard<std::mutex> g(m_);
             active_.push_back(&b);
@@ -112,7 +125,11 @@ private:
                 }
             }
             if (!b) continue;
-            work(*b);
+            if (b->acct) {
+                const long long t0 = thread_cpu_ns();
+                work(*b);
+                b->acct->worker_ns.fetch_add(thread_cpu_ns() - t0, std::memory_order_relaxed);   // before users drops: the owner (and its account) is still there
+            } else work(*b);
             b->users.fetch_sub(1, std::memory_order_release);
         }
     }

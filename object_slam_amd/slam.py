@@ -239,9 +239,16 @@ class System:
         check(self.L.oslam_slam_kernel_times(self.h, C.c_int(1 if enable else 0), ptr(out)))
         return {g: dict(ms=out[3 * i], launches=out[3 * i + 1], work=out[3 * i + 2]) for i, g in enumerate(self.KT_GROUPS)}
 
-    def stage_seconds(self):
+    def local_map_reuse(self):
+        """(frames whose local map was reused from the previous frame, tracked frames) summed over the handle's sequences."""
+        out = np.zeros(2, np.int64)
+        check(self.L.oslam_slam_local_map_reuse(self.h, ptr(out)))
+        return int(out[0]), int(out[1])
+
+    def stage_seconds(self, cpu=False):
+        """Wall seconds per stage since creation; cpu=True: core-seconds (stepping thread + workers) of the same stages."""
         out = np.zeros(16, np.float64)
-        check(self.L.oslam_slam_stage_seconds(self.h, ptr(out)))
+        check((self.L.oslam_slam_stage_cpu_seconds if cpu else self.L.oslam_slam_stage_seconds)(self.h, ptr(out)))
         names = ("frames", "search_last", "pose_opt", "search_local", "host_tracking", "mp_update", "lba", "host_mapping", "fuse_bow_triangulate",
                  "hm_process_kf", "hm_create_points", "hm_search_neighbors", "hm_lba_gather", "hm_kf_culling", "ht_initial_and_after", "ht_local_map")
         return dict(zip(names, out[:16].tolist()))

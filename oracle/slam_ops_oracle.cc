@@ -124,6 +124,8 @@ int o_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         q.resize(j.M + 1); qm.resize(j.M + 1); qd.resize(j.M + 1);
         oo_is_in_frustum(j.M, j.Pw, j.Pn, j.maxDist, j.minDist, j.obs_gt0, j.mp_desc, j.Tcw, o->K5, o->bounds, 0.5f, logScale, o->scale, o->cfg.nLevels,
                          j.th, q.data());
+        if (j.skip)   // mnLastFrameSeen == this frame: left out of the projection (src/Tracking.cc:1413-1427)
+            for (int e = 0; e < j.M; e++) if (j.skip[e]) q[e].flags = 0;
         int nin = 0;
         for (int e = 0; e < j.M; e++) { j.in_view[e] = q[e].flags & 1; nin += j.in_view[e]; }
         for (int k = 0; k < j.cur->N; k++) j.kp_match[k] = -1;
