@@ -261,6 +261,7 @@ struct MpUpdate {
         if (P == 0) return OSLAM_OK;
         start.assign(P + 1, 0);
         for (int i = 0; i < P; i++) {
+            if (i + kPF < P) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
             const MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
             start[i + 1] = start[i] + (p.bad ? 0 : (int)p.obs.size());
         }
@@ -276,6 +277,8 @@ struct MpUpdate {
         c.pool->parallel_for(nchunks, [&](int ch) {
             const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
             for (int i = i0; i < i1; i++) {
+                if (i + kPF < i1) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
+                if (i + kPF / 2 < i1) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
                 const Map& m = c.seq[items[i].seq]->map;
                 const MapPt& p = m.mps[items[i].p];
                 const int n = start[i + 1] - start[i];
@@ -365,6 +368,7 @@ static void update_local_map(Seq& s) {
     Frame& f = *s.cur;
     std::vector<int> touched;
     for (int i = 0; i < f.N; i++) {
+        prefetch_obs_ahead(m.mps, f.mp, i, f.N);
         const int p = f.mp[i];
         if (p < 0) continue;
         if (m.mps[p].bad) { f.mp[i] = -1; continue; }
@@ -429,6 +433,7 @@ static void fill_pose_job(Ctx& c, Seq& s, int si, oslam_job_pose_t& j) {
     const int N = f.N;
     s.jXw.assign((size_t)N * 3, 0.f); s.jObs.resize((size_t)N * 3); s.jInv.resize(N); s.jHas.assign(N, 0); s.jOutlier.assign(N, 0);
     for (int i = 0; i < N; i++) {
+        prefetch_ahead(s.map.mps, f.mp, i, N);
         s.jObs[(size_t)i * 3] = f.keysUn[i].x; s.jObs[(size_t)i * 3 + 1] = f.keysUn[i].y; s.jObs[(size_t)i * 3 + 2] = f.uRight[i];
         s.jInv[i] = c.invSigma2[f.keysUn[i].octave];
         const int p = f.mp[i];
@@ -452,6 +457,7 @@ static bool finish_initial_pose(Seq& s, const oslam_job_pose_t& j) {
     f.pose.set_frame(T);
     int nmatchesMap = 0;
     for (int i = 0; i < f.N; i++) {
+        prefetch_ahead(s.map.mps, f.mp, i, f.N);
         const int p = f.mp[i];
         if (p < 0) continue;
         if (j.outlier[i]) {
@@ -535,7 +541,9 @@ static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<in
     const KeyFrm& kf = m.kfs[k];
     const float* T = kf.pose.Tcw.m;
     q.clear(); qpt.clear();
-    for (int p : pts) {
+    for (size_t pi = 0; pi < pts.size(); pi++) {
+        prefetch_obs_ahead(m.mps, pts, pi, pts.size());
+        const int p = pts[pi];
         if (p < 0) continue;
         const MapPt& mp = m.mps[p];
         if (mp.bad || mp.obs_index(k) >= 0) continue;
@@ -865,6 +873,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
             W.points.resize(W.pts.size() * 3);
             for (size_t j = 0; j < W.pts.size(); j++) {
+                prefetch_obs_ahead(m.mps, W.pts, j, W.pts.size());
                 const MapPt& mp = m.mps[W.pts[j]];
                 for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
                 for (auto& e : mp.obs) {
@@ -914,6 +923,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 m.kfs[W.kfs[q]].pose.set_keyframe(T);
             }
             for (size_t j = 0; j < W.pts.size(); j++) {
+                if (j + kPF < W.pts.size()) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
                 MapPt& mp = m.mps[W.pts[j]];
                 for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
                 s.updList.push_back(W.pts[j]);
@@ -1080,6 +1090,7 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     const int NL = l.N;
     s.jXw.assign((size_t)NL * 3, 0.f); s.jHas.assign(NL, 0); s.jDesc.assign((size_t)NL * 32, 0);
     for (int k = 0; k < NL; k++) {
+        prefetch_ahead(s.map.mps, l.mp, k, NL);
         const int p = l.mp[k];
         if (p < 0 || l.outlier[k]) continue;
         const MapPt& mp = s.map.mps[p];
@@ -1107,6 +1118,7 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     Map& m = s.map;
     s.jBlocked.assign(f.N, 0);
     for (int k = 0; k < f.N; k++) {
+        prefetch_ahead(m.mps, f.mp, k, f.N);
         const int p = f.mp[k];
         if (p < 0) continue;
         if (m.mps[p].bad) { f.mp[k] = -1; continue; }
@@ -1122,6 +1134,7 @@ static void stage_local_map_prepare(Ctx& c, int i) {
         s.locPw.resize((size_t)M * 3 + 3); s.locPn.resize((size_t)M * 3 + 3); s.locMax.resize(M + 1); s.locMin.resize(M + 1); s.locObs.resize(M + 1);
         s.locDesc.resize((size_t)M * 32 + 32);
         for (int q = 0; q < M; q++) {
+            prefetch_ahead(m.mps, s.localMPs, q, M);
             const MapPt& mp = m.mps[s.localMPs[q]];
             for (int d = 0; d < 3; d++) { s.locPw[(size_t)q * 3 + d] = mp.pos[d]; s.locPn[(size_t)q * 3 + d] = mp.normal[d]; }
             s.locMax[q] = mp.maxD; s.locMin[q] = mp.minD; s.locObs[q] = mp.nObs > 0;
@@ -1156,6 +1169,7 @@ static void stage_after_local_pose(Ctx& c, int i) {
     f.pose.set_frame(T);
     s.matchesInliers = 0;
     for (int k = 0; k < f.N; k++) {
+        prefetch_ahead(s.map.mps, f.mp, k, f.N);
         const int p = f.mp[k];
         if (p < 0) continue;
         f.outlier[k] = j.outlier[k];
@@ -1181,6 +1195,7 @@ static void stage_after_tracking(Ctx& c, int i) {
         if (l.pose.valid) { s.velocity = mul4(f.pose.Tcw, l.pose.Twc); s.hasVelocity = true; }
         else s.hasVelocity = false;
         for (int k = 0; k < f.N; k++) {   // clean VO matches
+            prefetch_ahead(m.mps, f.mp, k, f.N);
             const int p = f.mp[k];
             if (p >= 0 && m.mps[p].nObs < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
         }
@@ -1408,7 +1423,10 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     pool.parallel_for((int)ljw.size(), [&](int q) {
         Seq& s = *c.seq[ljw[q]];
         Frame& f = *s.cur;
-        for (int e = 0; e < lj[q].M; e++) if (s.jInView[e]) s.map.mps[s.localMPs[e]].visible++;
+        for (int e = 0, Me = lj[q].M; e < Me; e++) {
+            if (e + kPF < Me && s.jInView[e + kPF]) __builtin_prefetch((const char*)&s.map.mps[s.localMPs[e + kPF]] + 64);   // the line of `visible`
+            if (s.jInView[e]) s.map.mps[s.localMPs[e]].visible++;
+        }
         for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.localMPs[s.jMatch[k]];
         fill_pose_job(c, s, ljw[q], s.jPose);
         s.hasPose2 = false;

@@ -126,6 +126,20 @@ struct MapPt {
     }
 };
 
+// The driver's per-frame loops gather MapPt records by index in keypoint / list order, i.e. at random over a table of several MB per sequence: each
+// loop requests the records of a later iteration early (a MapPt spans three cache lines; its observation list is a second, dependent access).
+constexpr int kPF = 12;
+inline void prefetch_mp(const MapPt* p) { __builtin_prefetch(p); __builtin_prefetch((const char*)p + 64); __builtin_prefetch((const char*)p + 128); }
+template <class Ids>
+inline void prefetch_ahead(const std::vector<MapPt>& mps, const Ids& ids, size_t i, size_t n) {
+    if (i + kPF < n) { const int q = ids[i + kPF]; if (q >= 0) prefetch_mp(&mps[q]); }
+}
+template <class Ids>
+inline void prefetch_obs_ahead(const std::vector<MapPt>& mps, const Ids& ids, size_t i, size_t n) {   // with prefetch_ahead: the list of a record requested kPF / 2 iterations ago
+    prefetch_ahead(mps, ids, i, n);
+    if (i + kPF / 2 < n) { const int q = ids[i + kPF / 2]; if (q >= 0) __builtin_prefetch(mps[q].obs.data()); }
+}
+
 struct KeyFrm {
     int id = 0, frameId = 0;
     double stamp = 0;
@@ -249,6 +263,7 @@ struct Map {
         KeyFrm& f = kfs[k];
         std::vector<int> touched;
         for (int i = 0; i < f.N; i++) {
+            prefetch_obs_ahead(mps, f.mp, i, f.N);
             const int p = f.mp[i];
             if (p < 0 || mps[p].bad) continue;
             for (auto& e : mps[p].obs) {
@@ -282,6 +297,7 @@ struct Map {
         const KeyFrm& f = kfs[k];
         int n = 0;
         for (int i = 0; i < f.N; i++) {
+            prefetch_ahead(mps, f.mp, i, f.N);
             const int p = f.mp[i];
             if (p < 0 || mps[p].bad) continue;
             if (minObs > 0) { if (mps[p].nObs >= minObs) n++; }
