@@ -617,6 +617,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         KeyFrm& kf = m.kfs[s.curKF];
         compute_bow(c, kf.N, kf.desc.data(), kf.bowNode);
         for (int i = 0; i < kf.N; i++) {
+            prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
             const int p = kf.mp[i];
             if (p < 0 || m.mps[p].bad) continue;
             if (m.mps[p].obs_index(s.curKF) < 0) { m.add_observation(p, s.curKF, i); s.updList.push_back(p); }
@@ -804,7 +805,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             const int cur = s.curKF;
             fs[w].pts.clear();
             for (int k : fs[w].targets)
-                for (int p : m.kfs[k].mp) {
+                for (size_t i = 0, n = m.kfs[k].mp.size(); i < n; i++) {
+                    prefetch_ahead(m.mps, m.kfs[k].mp, i, n);
+                    const int p = m.kfs[k].mp[i];
                     if (p < 0) continue;
                     MapPt& mp = m.mps[p];
                     if (mp.bad || mp.fuseCandidateForKF == cur) continue;
@@ -850,10 +853,17 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (!m.kfs[k].bad) W.kfs.push_back(k);
             }
             W.nLocal = (int)W.kfs.size();
-            for (int q = 0; q < W.nLocal; q++)
-                for (int p : m.kfs[W.kfs[q]].mp)
+            for (int q = 0; q < W.nLocal; q++) {
+                const std::vector<int>& kmp = m.kfs[W.kfs[q]].mp;
+                for (size_t i = 0; i < kmp.size(); i++) {
+                    prefetch_ahead(m.mps, kmp, i, kmp.size());
+                    const int p = kmp[i];
                     if (p >= 0 && !m.mps[p].bad && m.mps[p].baLocalForKF != cur) { W.pts.push_back(p); m.mps[p].baLocalForKF = cur; }
-            for (int p : W.pts)
+                }
+            }
+            for (size_t pi = 0; pi < W.pts.size(); pi++) {
+                if (pi + kPF / 2 < W.pts.size()) __builtin_prefetch(m.mps[W.pts[pi + kPF / 2]].obs.data());   // (the records were touched by the loop above)
+                const int p = W.pts[pi];
                 for (auto& e : m.mps[p].obs) {
                     KeyFrm& k = m.kfs[e.first];
                     if (k.baLocalForKF != cur && k.baFixedForKF != cur) {
@@ -863,6 +873,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                         if (!k.bad) { if ((int)W.kfs.size() < kMaxWindowKFs) W.kfs.push_back(e.first); else s.lbaFixedDropped++; }
                     }
                 }
+            }
             if (W.nLocal > kMaxWindowKFs) { W.kfs.resize(kMaxWindowKFs); W.nLocal = kMaxWindowKFs; }
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
@@ -946,6 +957,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 const KeyFrm& kf = m.kfs[k];
                 int nRed = 0, nMPs = 0;
                 for (int i = 0; i < kf.N; i++) {
+                    prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
                     const int p = kf.mp[i];
                     if (p < 0 || m.mps[p].bad) continue;
                     if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
