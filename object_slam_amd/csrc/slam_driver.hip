@@ -267,7 +267,7 @@ struct MpUpdate {
         }
         const size_t total = (size_t)start[P];
         const bool keyed = c.ops.mp_update_keyed != nullptr && do_desc;   // the table gathers the descriptors from its resident keyframes
-        if (!keyed) odesc.resize(std::max<size_t>(total, 1) * 32);
+        if (!keyed) odesc.resize(do_desc ? std::max<size_t>(total, 1) * 32 : 32);   // (UpdateNormalAndDepth alone reads no descriptors)
         else okey.resize(std::max<size_t>(total, 1) * 3);
         oOw.resize(std::max<size_t>(total, 1) * 3);
         pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
@@ -287,7 +287,7 @@ struct MpUpdate {
                     for (auto& e : p.obs) {
                         const KeyFrm& k = m.kfs[e.first];
                         if (keyed) { okey[at * 3] = items[i].seq; okey[at * 3 + 1] = e.first; okey[at * 3 + 2] = e.second; }
-                        else memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
+                        else if (do_desc) memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
                         oOw[at * 3] = k.pose.Ow[0]; oOw[at * 3 + 1] = k.pose.Ow[1]; oOw[at * 3 + 2] = k.pose.Ow[2];
                         at++;
                     }
