@@ -237,6 +237,25 @@ def test_local_search_capacity_grows_on_demand(oracle, monkeypatch):
     assert np.abs(ph - po).max() < 4e-4
 
 
+def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
+    """The HIP table keeps the packed SearchLocalPoints arrays of every slot and the keyframes' arrays resident in HBM (content ids / keyed operators);
+    with both switched off it uploads the host arrays of every job as the oracle table receives them.  The two runs must be bit-identical, and the
+    driver must actually have reused local maps in the first one (slow motion: most frames keep their local keyframe list)."""
+    from slam_common import make_scene_streams, run_scene
+    n = 24
+    seqs = make_scene_streams(2, n, speed=1.0)
+    a = slam.System(slam.make_config(W, H, 2))
+    pa, sa = run_scene(a, seqs, n)
+    reused, frames = a.local_map_reuse()
+    assert frames >= 2 * (n - 2) and reused >= frames // 3, (reused, frames)
+    monkeypatch.setenv("OSLAM_SLAM_NO_RESIDENT_LOCAL", "1")
+    monkeypatch.setenv("OSLAM_SLAM_NO_RESIDENT_KF", "1")
+    b = slam.System(slam.make_config(W, H, 2))
+    pb, sb = run_scene(b, seqs, n)
+    assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
+    assert a.stats(0) == b.stats(0) and a.stats(1) == b.stats(1)
+
+
 def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle):
     """Soak at the S1 specification: 200 frames at speed 1 (<= 2 cm, <= 0.5 deg per frame) with the three instance masks; the HIP and
     the oracle operator tables must lead the driver through the same 200 frames (states, map statistics, object bookkeeping), ATE below 2 cm."""
