@@ -116,6 +116,7 @@ struct Seq {
     long long mapVersion = 0, locVersion = -1, locContentId = 0;
     int locWalkFrame = -1;                // frame id of the cached walk: mpMark[p] == locWalkFrame <=> p was visited by it
     bool locReused = false;
+    int trkKF = -1, trkMinObs = 0, trkCount = 0; long long trkVersion = -1;   // cached KeyFrame::TrackedMapPoints of the reference keyframe (NeedNewKeyFrame)
     std::vector<int> locKFs, mpPos;       // cached keyframe list; position of a visited point in localMPs (-1: visited but bad)
     std::vector<int> seenList;            // points given mnLastFrameSeen = this frame outside SearchLocalPoints (outliers of the initial pose optimisation)
     std::vector<float> locPw, locPn, locMax, locMin;
@@ -1029,10 +1030,13 @@ static void fill_pose2_job(Ctx& c, Seq& s, int si) {
         if (o.obj3d < 0) continue;
         const Seq::Obj3D& ob = s.obj3ds[o.obj3d];
         s.jMaskPtrs.push_back(s.det->masks[o.det]);
-        for (int p : ob.mps) {
-            const float* x = s.map.mps[p].pos;
-            s.jObjXw.push_back(x[0]); s.jObjXw.push_back(x[1]); s.jObjXw.push_back(x[2]);
-            s.jObjOf.push_back(m);
+        const size_t n0 = s.jObjOf.size(), nob = ob.mps.size();
+        s.jObjXw.resize((n0 + nob) * 3); s.jObjOf.resize(n0 + nob, m);
+        for (size_t q = 0; q < nob; q++) {
+            if (q + kPF < nob) __builtin_prefetch(&s.map.mps[ob.mps[q + kPF]]);
+            const float* x = s.map.mps[ob.mps[q]].pos;
+            float* d = &s.jObjXw[(n0 + q) * 3];
+            d[0] = x[0]; d[1] = x[1]; d[2] = x[2];
         }
         for (int k = 0; k < f.N; k++) {
             const int p = f.mp[k];
@@ -1217,7 +1221,12 @@ static void stage_after_tracking(Ctx& c, int i) {
             const int nKFs = m.nKFsInMap;
             if (!(f.id < s.lastRelocFrameId + c.maxFrames && nKFs > c.maxFrames)) {
                 const int nMinObs = nKFs <= 2 ? 2 : 3;
-                const int nRefMatches = m.tracked_map_points(s.refKF, nMinObs);
+                // KeyFrame::TrackedMapPoints depends on the map alone: one count per (reference keyframe, nMinObs, map version)
+                if (!(s.trkKF == s.refKF && s.trkMinObs == nMinObs && s.trkVersion == s.mapVersion)) {
+                    s.trkCount = m.tracked_map_points(s.refKF, nMinObs);
+                    s.trkKF = s.refKF; s.trkMinObs = nMinObs; s.trkVersion = s.mapVersion;
+                }
+                const int nRefMatches = s.trkCount;
                 int nNonTrackedClose = 0, nTrackedClose = 0;
                 for (int k = 0; k < f.N; k++)
                     if (f.depth[k] > 0 && f.depth[k] < c.thDepth) {
