@@ -237,6 +237,40 @@ def test_local_search_capacity_grows_on_demand(oracle, monkeypatch):
     assert np.abs(ph - po).max() < 4e-4
 
 
+def test_lost_and_reset_on_one_slot_matches_oracle_driver(oracle):
+    """Sequence 0 starts on a textureless frame (NOT_INITIALIZED), tracks, loses the track on two blank frames with <= 5 keyframes (System::Reset,
+    reference src/Tracking.cc:553-561) and builds a new map whose keyframe ids restart at 0; sequence 1 runs undisturbed in the neighbouring slot.
+    The HIP table's per-slot resident state (keyframe records, local-map arrays) must follow the reset: same states, statistics and poses as the
+    oracle table."""
+    from slam_common import make_scene_streams
+    n = 16
+    seqs = make_scene_streams(2, n, speed=1.5)
+    blank = np.full((H, W), 90, np.uint8)
+    flat = np.full((H, W), 2.0, np.float32)
+    g0 = [blank] + list(seqs[0]["gray"][:6]) + [blank, blank] + list(seqs[0]["gray"][6:13])
+    d0 = [flat] + list(seqs[0]["depth"][:6]) + [flat, flat] + list(seqs[0]["depth"][6:13])
+
+    def run(system):
+        poses, states = [], []
+        for t in range(n):
+            T, st = system.TrackRGBD([g0[t], seqs[1]["gray"][t]], [d0[t], seqs[1]["depth"][t]], [t / 30.0] * 2)
+            poses.append(T.copy()); states.append(st.copy())
+        return np.array(poses), np.array(states)
+
+    hip = slam.System(slam.make_config(W, H, 2))
+    ph, sh = run(hip)
+    cfg_o = slam.make_config(W, H, 2)
+    ora = slam.System(cfg_o, oracle_ops(cfg_o))
+    po, so = run(ora)
+    assert np.array_equal(sh, so), (sh.T, so.T)
+    assert sh[0, 0] == slam.NOT_INITIALIZED and (sh[1:7, 0] == slam.OK).all() and sh[7, 0] == slam.LOST and sh[8, 0] == slam.NOT_INITIALIZED
+    assert (sh[9:, 0] == slam.OK).all() and (sh[:, 1] == slam.OK).all()
+    assert hip.stats(0) == ora.stats(0) and hip.stats(1) == ora.stats(1)
+    assert hip.stats(0)["lost_frames"] == 1 and hip.stats(0)["map_violations"] == 0
+    assert np.abs(ph - po).max() < 4e-4
+    assert len(hip.trajectory(0)[0]) == n - 9           # the trajectory of the new map only
+
+
 def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
     """The HIP table keeps the packed SearchLocalPoints arrays of every slot and the keyframes' arrays resident in HBM (content ids / keyed operators);
     with both switched off it uploads the host arrays of every job as the oracle table receives them.  The two runs must be bit-identical, and the
