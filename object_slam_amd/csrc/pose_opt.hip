@@ -27,6 +27,7 @@ struct SemCtx {
     int nObj;
     const short2* area;        // BOUNDARY pixels of the mask (== 255 with a 4-neighbour that is not, or on the image border) as (col,row), row-major scan order per object
     const int* area_start;     // [nObj+1]
+    const int* row_start;      // [nObj][H]: boundary pixels of the object in the rows before a row (k_mask_rowscan), relative to area_start[o]
     const uint8_t* masks; const uint8_t* const* mask_ptrs; int H, W, pitch;   // the masks themselves (mask o = mask_ptrs[o] or masks + o*H*pitch), for the pixels around a query
     int nObjMp; const float* objmp_Xw; const int* objmp_obj;          // object map points, object-major
     int nJoint; const int* joint_kp; const int* joint_obj;             // M_joint candidates (:721-726)
@@ -92,27 +93,54 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
     if (s1 <= s0) return false;   // no boundary pixel = empty mask
     float best = 0;
     int bx = -1, by = -1;
-    for (int i = s0; i < s1; i++) {   // list order = scan order: the first minimum wins
-        const short2 p = sm.area[i];
-        const float dx = (float)p.x - u, dy = (float)p.y - v;
+    // the candidate with the smallest (distance, row, col) wins: the first minimum in row-major scan order
+    auto consider = [&](int x, int y) {
+        const float dx = (float)x - u, dy = (float)y - v;
         float d = 0;
         d += dx * dx;
         d += dy * dy;
-        if (bx < 0 || d < best) { best = d; bx = p.x; by = p.y; }
-    }
+        if (bx < 0 || d < best || (d == best && (y < by || (y == by && x < bx)))) { best = d; bx = x; by = y; }
+    };
     const uint8_t* m = sm.mask_ptrs ? sm.mask_ptrs[o] : sm.masks + (long long)o * sm.H * sm.pitch;
     const float fu = floorf(u), fv = floorf(v);
-    if (fu >= -1.f && fu < (float)sm.W && fv >= -1.f && fv < (float)sm.H) {
+    if (fu >= -1.f && fu < (float)sm.W && fv >= -1.f && fv < (float)sm.H) {   // unit cell first: a query inside the mask starts with best <= 2
         const int x0 = (int)fu, y0 = (int)fv;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
             if (x < 0 || y < 0 || x >= sm.W || y >= sm.H || m[(long long)y * sm.pitch + x] != 255) continue;
-            const float dx = (float)x - u, dy = (float)y - v;
-            float d = 0;
-            d += dx * dx;
-            d += dy * dy;
-            if (d < best || (d == best && (y < by || (y == by && x < bx)))) { best = d; bx = x; by = y; }
+            consider(x, y);
+        }
+    }
+    if (!(fabsf(v) < 1.0e6f)) {   // no usable row order (never seen on this path): the whole list
+        for (int i = s0; i < s1; i++) { const short2 p = sm.area[i]; consider(p.x, p.y); }
+    } else {
+        // Boundary pixels row by row, outwards from the query's row in both directions: a row whose vertical distance alone exceeds the best distance so far
+        // cannot hold the minimum (d = fl(fl(dx^2) + fl(dy^2)) >= fl(dy^2) in float; equality still scans the row, for the tie rule), and the vertical
+        // distance grows monotonically in each direction.  For a query inside or next to the mask this visits two or three rows instead of the whole list.
+        const int* rs = sm.row_start + (long long)o * sm.H;
+        const int nb = s1 - s0;
+        int yu = min(sm.H - 1, (int)fv), yd = max(0, (int)fv + 1);
+        bool up = yu >= 0, dn = yd < sm.H;
+        while (up || dn) {
+            if (up) {
+                const float dy = (float)yu - v;
+                if (bx >= 0 && dy * dy > best) up = false;
+                else {
+                    const int a = rs[yu], e = yu + 1 < sm.H ? rs[yu + 1] : nb;
+                    for (int i = s0 + a; i < s0 + e; i++) consider(sm.area[i].x, yu);
+                    if (--yu < 0) up = false;
+                }
+            }
+            if (dn) {
+                const float dy = (float)yd - v;
+                if (bx >= 0 && dy * dy > best) dn = false;
+                else {
+                    const int a = rs[yd], e = yd + 1 < sm.H ? rs[yd + 1] : nb;
+                    for (int i = s0 + a; i < s0 + e; i++) consider(sm.area[i].x, yd);
+                    if (++yd >= sm.H) dn = false;
+                }
+            }
         }
     }
     px = bx | (by << 15);
@@ -236,7 +264,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     if (SEM && c.sem.frames) {
         const oslam_sem_frame_t f = c.sem.frames[b];
         const int e0 = f.objmp0 + f.joint0;
-        sm.nObj = f.nObj; sm.area_start += f.obj0; sm.mask_ptrs += f.obj0;
+        sm.nObj = f.nObj; sm.area_start += f.obj0; sm.mask_ptrs += f.obj0; sm.row_start += (long long)f.obj0 * sm.H;
         sm.nObjMp = f.nObjMp; sm.objmp_Xw += 3 * (long long)f.objmp0; sm.objmp_obj += f.objmp0;
         sm.nJoint = f.nJoint; sm.joint_kp += f.joint0; sm.joint_obj += f.joint0;
         sm.e_Xw += 3 * (long long)e0; sm.e_obs += 2 * (long long)e0; sm.e_level += e0; sm.e_chi2 += e0; sm.e_obj += e0; sm.e_out += e0; sm.e_tmp += e0;
@@ -918,7 +946,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     SemCtx& sm = c.sem;
-    sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p; sm.row_start = (int*)h->rowcnt.p;
     sm.masks = (const uint8_t*)h->masks.p; sm.mask_ptrs = nullptr; sm.H = sem->H; sm.W = sem->W; sm.pitch = sem->W;
     sm.nObjMp = sem->nObjMp; sm.objmp_Xw = (float*)h->objmp_Xw.p; sm.objmp_obj = (int*)h->objmp_obj.p;
     sm.nJoint = sem->nJoint; sm.joint_kp = (int*)h->joint_kp.p; sm.joint_obj = (int*)h->joint_obj.p; sm.kp_uv = (float*)h->kp_uv.p;
@@ -976,7 +1004,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     SemCtx& sm = c.sem;
     memset(&sm, 0, sizeof(sm));
-    sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p;
+    sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p; sm.row_start = (int*)h->rowcnt.p;
     sm.masks = nullptr; sm.mask_ptrs = d_mask_ptrs; sm.H = H; sm.W = W; sm.pitch = mask_pitch;
     sm.objmp_Xw = d_objmp_Xw; sm.objmp_obj = d_objmp_obj; sm.joint_kp = d_joint_kp; sm.joint_obj = d_joint_obj; sm.kp_uv = nullptr;
     sm.minX = bounds[0]; sm.minY = bounds[1]; sm.maxX = bounds[2]; sm.maxY = bounds[3]; sm.invSigma2_0 = invSigma2_0;
