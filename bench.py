@@ -323,7 +323,7 @@ def main():
             for sy in systems:
                 sy.kernel_times(True)
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
-                                                      host_threads=max(1, min(16, share) // G_), sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl")
+                                                      host_threads=int(os.environ.get("OSLAM_BENCH_HOST_THREADS", "0")) or max(1, min(16, share) // G_), sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl")
         tot = {}
         for sy in systems:
             for g, v in sy.kernel_times(False).items():

@@ -95,6 +95,7 @@ constexpr int kMaxWindowKFs = 128;   // keyframes (local + fixed) per local-BA w
 enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
 
 struct Ctx;
+struct MpUpdate;
 
 // Per-sequence Tracking + LocalMapping state (include/Tracking.h, include/LocalMapping.h members).
 struct Seq {
@@ -178,6 +179,14 @@ struct Ctx {
     double sec[16] = {0};
     double cpu[16] = {0};   // core-seconds of the same stages (host thread + workers)
     CpuAccount acct;
+    struct Win {   // one local-BA window (run_local_mapping)
+        int si = -1, nLocal = 0;
+        std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
+        std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref;
+        void reset() { kfs.clear(); pts.clear(); poses.clear(); points.clear(); eobs.clear(); einv.clear(); poses_out.clear(); points_out.clear(); fixed.clear(); erase.clear(); ekf.clear(); ept.clear(); eref.clear(); nLocal = 0; }
+    };
+    std::vector<Win> winPool;
+    std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
     std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
     long long next_content_id() { return contentCounter.fetch_add(1, std::memory_order_relaxed) + 1; }
     int mask_stride = 0, masks_on_device = 0;
@@ -345,8 +354,8 @@ static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
         for (int i = 0; i < f.N; i++) if (f.depth[i] > 0) make(i);
         return;
     }
-    std::vector<std::pair<float, int>> v;
-    v.reserve(f.N);
+    static thread_local std::vector<std::pair<float, int>> v;   // scratch
+    v.clear();
     for (int i = 0; i < f.N; i++) if (f.depth[i] > 0) v.push_back(std::make_pair(f.depth[i], i));
     if (v.empty()) return;
     std::sort(v.begin(), v.end());
@@ -367,7 +376,8 @@ static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
 static void update_local_map(Seq& s) {
     Map& m = s.map;
     Frame& f = *s.cur;
-    std::vector<int> touched;
+    static thread_local std::vector<int> touched;   // scratch: keeps its capacity from frame to frame
+    touched.clear();
     for (int i = 0; i < f.N; i++) {
         prefetch_obs_ahead(m.mps, f.mp, i, f.N);
         const int p = f.mp[i];
@@ -602,7 +612,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     if (who.empty()) return OSLAM_OK;
     Timer tm;
     int rc;
-    MpUpdate upd;
+    if (!c.updMap) c.updMap.reset(new MpUpdate);
+    MpUpdate& upd = *c.updMap;
+    upd.clear();
     const int flags = c.cfg.local_mapping;
     // --- ProcessNewKeyFrame (:129-169) ---
     Pool& pool = *c.pool;
@@ -643,7 +655,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         size_t maxn = 0;
         for (size_t w = 0; w < who.size(); w++) {
             Seq& s = *c.seq[who[w]];
-            neigh[w] = s.map.best_covisibles(s.curKF, 10);
+            const Map::IntSpan bc = s.map.best_covisibles(s.curKF, 10);
+            neigh[w].assign(bc.begin(), bc.end());
             maxn = std::max(maxn, neigh[w].size());
         }
         std::vector<std::vector<uint8_t>> flag1(who.size()), has2(who.size());
@@ -833,16 +846,15 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
 
     // --- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:453-778), all windows in one batch ---
     if (flags & 8) {
-        struct Win {
-            int si; std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
-            std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref; int nLocal;
-        };
-        std::vector<Win> wins(who.size());
+        typedef Ctx::Win Win;
+        std::vector<Win>& pool_w = c.winPool;   // the windows' arrays keep their capacity from step to step
+        if (pool_w.size() < who.size()) pool_w.resize(who.size());
         pool.parallel_for(nW, [&](int w) {
             const int si = who[w];
             Seq& s = *c.seq[si];
             Map& m = s.map;
-            Win& W = wins[w];
+            Win& W = pool_w[w];
+            W.reset();
             W.si = -1;
             if (m.nKFsInMap <= 2) return;   // src/LocalMapping.cc:81
             const int cur = s.curKF;
@@ -903,10 +915,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             W.poses_out.resize(W.poses.size()); W.points_out.resize(W.points.size() + 3); W.erase.assign(W.ekf.size() + 1, 0);
             s.st[5]++; s.st[14] += (int64_t)W.ekf.size();
         });
-        wins.erase(std::remove_if(wins.begin(), wins.end(), [](const Win& W) { return W.si < 0; }), wins.end());
+        std::vector<Win*> wins;
+        for (int w = 0; w < nW; w++) if (pool_w[w].si >= 0) wins.push_back(&pool_w[w]);
         std::vector<oslam_lba_problem_t> probs(wins.size());
         for (size_t i = 0; i < wins.size(); i++) {
-            Win& W = wins[i];
+            Win& W = *wins[i];
             oslam_lba_problem_t& p = probs[i];
             p.nKF = (int)W.kfs.size(); p.poses = W.poses.data(); p.fixed = W.fixed.data(); p.nP = (int)W.pts.size(); p.points = W.points.data();
             p.nE = (int)W.ekf.size(); p.edge_kf = W.ekf.data(); p.edge_pt = W.ept.data(); p.edge_obs = W.eobs.data(); p.edge_invSigma2 = W.einv.data();
@@ -916,7 +929,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
         { c.sec[6] += tm.lap(); c.cpu[6] += tm.cpu; }
         pool.parallel_for((int)wins.size(), [&](int wi) {
-            Win& W = wins[wi];
+            Win& W = *wins[wi];
             Seq& s = *c.seq[W.si];
             Map& m = s.map;
             // erase list: mono edges first, then stereo edges (:711-757)
@@ -1477,7 +1490,9 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
     // ---------------- after tracking (:470-566) ----------------
     pool.parallel_for(nT, [&](int q) { stage_after_tracking(c, tracking[q]); });
     std::vector<int> mapping;
-    MpUpdate upd;
+    if (!c.updTrack) c.updTrack.reset(new MpUpdate);
+    MpUpdate& upd = *c.updTrack;
+    upd.clear();
     for (int i = 0; i < S; i++) {
         Seq& s = *c.seq[i];
         if (!s.newKFs.empty()) mapping.push_back(i);

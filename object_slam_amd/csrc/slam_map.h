@@ -232,8 +232,8 @@ struct Map {
     // ---- KeyFrame covisibility graph (src/KeyFrame.cc:123-379) ----
     void update_best_covisibles(int k) {             // :138-157: descending (weight, id)
         KeyFrm& f = kfs[k];
-        std::vector<std::pair<int, int>> v;
-        v.reserve(f.connW.size());
+        static thread_local std::vector<std::pair<int, int>> v;   // scratch
+        v.clear();
         for (auto& e : f.connW) v.push_back(std::make_pair(e.second, e.first));
         std::sort(v.begin(), v.end());
         f.ordered.clear(); f.orderedW.clear();
@@ -250,10 +250,16 @@ struct Map {
     void erase_connection(int k, int other) {        // :553-567
         if (kfs[k].connW.erase(other)) update_best_covisibles(k);
     }
-    std::vector<int> best_covisibles(int k, int n) const {   // :174-182
+    struct IntSpan {   // view of the first entries of a keyframe's ordered list (valid until that list changes)
+        const int* b; const int* e;
+        const int* begin() const { return b; }
+        const int* end() const { return e; }
+        size_t size() const { return (size_t)(e - b); }
+    };
+    IntSpan best_covisibles(int k, int n) const {   // :174-182 (the reference returns a copy: per frame and local keyframe that is an allocation)
         const KeyFrm& f = kfs[k];
-        if ((int)f.ordered.size() < n) return f.ordered;
-        return std::vector<int>(f.ordered.begin(), f.ordered.begin() + n);
+        const size_t m = std::min<size_t>(f.ordered.size(), (size_t)std::max(n, 0));
+        return IntSpan{f.ordered.data(), f.ordered.data() + m};
     }
     int weight(int k, int other) const {
         auto it = kfs[k].connW.find(other);
@@ -261,7 +267,8 @@ struct Map {
     }
     void update_connections(int k, std::vector<int>& counter /* scratch, size >= kfs.size(), zeros */) {   // :289-379
         KeyFrm& f = kfs[k];
-        std::vector<int> touched;
+        static thread_local std::vector<int> touched;   // scratch
+        touched.clear();
         for (int i = 0; i < f.N; i++) {
             prefetch_obs_ahead(mps, f.mp, i, f.N);
             const int p = f.mp[i];
@@ -275,7 +282,9 @@ struct Map {
         std::sort(touched.begin(), touched.end());
         int nmax = 0, kmax = -1;
         const int th = 15;
-        std::vector<std::pair<int, int>> v;
+        static thread_local std::vector<std::pair<int, int>> v2;   // scratch (add_connection below uses update_best_covisibles' own)
+        std::vector<std::pair<int, int>>& v = v2;
+        v.clear();
         for (int o : touched) {
             const int c = counter[o];
             if (c > nmax) { nmax = c; kmax = o; }
