@@ -359,6 +359,14 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
                                       const int32_t* d_objmp_obj, int total_joint, const int32_t* d_joint_kp, const int32_t* d_joint_obj, const float bounds[4],
                                       float invSigma2_0, void* stream);
 int oslam_poseopt_semantic_results_device(const oslam_poseopt_t* h, const int32_t** d_n_semantic);
+/* One-bit-per-pixel form of n instance masks (device pointers, rows `pitch` bytes apart): d_bits [n][H][ceil(W / 64)] uint64, bit i of word w = pixel
+ * 64 w + i == 255 (the test of src/Frame.cc:266 and of the pcl cloud at src/ObjectOptimizer.cc:699-710).  One pass over the mask bytes; the keypoint test
+ * (oslam_frame_object_kp_test_bits_batch_device, same semantics as the byte form below) and the boundary lists of the next
+ * oslam_pose_optimize2_batch_device call (oslam_poseopt_use_mask_bits: pooled object o = bitmap d_bits_index[o]) then read words. */
+int oslam_mask_bits_device(const uint8_t* const* d_mask_ptrs, int n, int H, int W, int pitch, uint64_t* d_bits, void* stream);
+int oslam_poseopt_use_mask_bits(oslam_poseopt_t* h, const uint64_t* d_bits, const int32_t* d_bits_index);
+int oslam_frame_object_kp_test_bits_batch_device(const oslam_keypoint_t* d_keysUn, int kp_stride, const int32_t* d_n_kps, int batch, const uint64_t* d_bits,
+                                                 const int32_t* d_mask0, const int32_t* d_n_masks, int H, int W, uint8_t* d_out, void* stream);
 /* Frame::BuildObject2DsRGBD / BuildObject2DsStereo keypoint test (src/Frame.cc:262-272, :336-346): bit o of d_out[b][k] is set iff every pixel
  * (int)(kpUn.y + row), (int)(kpUn.x + col), row / col in [-10, 10), of mask d_mask_ptrs[d_mask0[b] + o] equals 255 (a pixel outside the image fails: the
  * reference reads out of bounds there); at most 8 masks per frame.  The depth gate and the sequential assignment (:273-301) stay with the caller. */

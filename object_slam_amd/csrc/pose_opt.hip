@@ -702,6 +702,110 @@ __global__ __launch_bounds__(256) void k_object_kp_test(const oslam_keypoint_t* 
     if (lane == 0) out[(long long)b * kp_stride + k] = bits;
 }
 
+// ---- one-bit-per-pixel form of the instance masks -------------------------------------------------------------------------------------------
+// bits[m][row][w] (uint64, WB = ceil(W / 64) words per row): bit i = pixel 64 w + i of mask m equals 255.  The keypoint test and the boundary lists read
+// this 1/8-size image instead of the masks: ONE pass over the mask bytes per step (k_mask_bits), everything after it works on words.
+__device__ __forceinline__ uint32_t ff_nibble(uint32_t x) {   // bit k = byte k of x == 0xFF
+    const uint32_t t = ((x & 0x7f7f7f7fu) + 0x01010101u) & x & 0x80808080u;   // bit 7 of every byte that is 0xFF (no carry leaves a byte)
+    return (((t >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+
+__global__ __launch_bounds__(256) void k_mask_bits(const uint8_t* const* ptrs, int H, int W, int pitch, int WB, unsigned long long* bits) {
+    const int m = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;   // (row, word)
+    if (i >= H * WB) return;
+    const int row = i / WB, w = i - row * WB;
+    const uint8_t* src = ptrs[m] + (long long)row * pitch + 64 * w;
+    const int n = min(64, W - 64 * w);
+    unsigned long long v = 0;
+    if (n == 64 && (((uintptr_t)src) & 15) == 0) {
+        const uint4* s4 = (const uint4*)src;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 x = s4[q];
+            const unsigned long long nib = (unsigned long long)(ff_nibble(x.x) | (ff_nibble(x.y) << 4) | (ff_nibble(x.z) << 8) | (ff_nibble(x.w) << 12));
+            v |= nib << (16 * q);
+        }
+    } else {
+        for (int k = 0; k < n; k++) v |= (unsigned long long)(src[k] == 255) << k;
+    }
+    bits[((long long)m * H + row) * WB + w] = v;
+}
+
+// 20 consecutive bits of a row starting at column x (0 <= x, x + 20 <= W)
+__device__ __forceinline__ bool row_ones20(const unsigned long long* r, int WB, int x) {
+    const int w = x >> 6, sh = x & 63;
+    unsigned long long v = r[w] >> sh;
+    if (sh > 44 && w + 1 < WB) v |= r[w + 1] << (64 - sh);
+    return (v & 0xFFFFFull) == 0xFFFFFull;
+}
+
+// Frame::BuildObject2DsRGBD keypoint test from the bitmaps: one thread per keypoint.  The reference evaluates (int)(kp.pt.y + row), (int)(kp.pt.x + col)
+// for every (row, col) in [-10, 10)^2; the float sums are monotone in row / col, so when the first and the last of the 20 differ by 19 the coordinates
+// are consecutive and a row of the window is 20 adjacent bits.  Anything else (a window that leaves the image, float sums that repeat an integer)
+// goes through the literal per-pixel form.
+__global__ __launch_bounds__(256) void k_object_kp_test_bits(const oslam_keypoint_t* keysUn, int kp_stride, const int* n_kps, const unsigned long long* bits,
+                                                             const int* mask0, const int* n_masks, int H, int W, int WB, uint8_t* out) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_kps[b]) return;
+    const oslam_keypoint_t kp = keysUn[(long long)b * kp_stride + k];
+    const int x_lo = (int)(kp.x + -10.0f), x_hi = (int)(kp.x + 9.0f), y_lo = (int)(kp.y + -10.0f), y_hi = (int)(kp.y + 9.0f);
+    const bool fast = x_hi - x_lo == 19 && y_hi - y_lo == 19 && x_lo >= 0 && x_hi < W && y_lo >= 0 && y_hi < H && kp.x + -10.0f >= 0.0f && kp.y + -10.0f >= 0.0f;
+    uint8_t res = 0;
+    for (int o = 0; o < n_masks[b]; o++) {
+        const unsigned long long* B = bits + (long long)(mask0[b] + o) * H * WB;
+        bool ok = true;
+        if (fast) {
+            for (int r = 0; r < 20 && ok; r++) ok = row_ones20(B + (long long)(y_lo + r) * WB, WB, x_lo);
+        } else {
+            for (int i = 0; i < 400 && ok; i++) {
+                const int row = i / 20 - 10, col = i % 20 - 10;
+                const int y = (int)(kp.y + (float)row), x = (int)(kp.x + (float)col);
+                ok = y >= 0 && y < H && x >= 0 && x < W && ((B[(long long)y * WB + (x >> 6)] >> (x & 63)) & 1ull);
+            }
+        }
+        if (ok) res |= (uint8_t)(1u << o);
+    }
+    out[(long long)b * kp_stride + k] = res;
+}
+
+// boundary word of (mask, row, w): inside and with a 4-neighbour that is not inside (pixels outside the image count as not inside, which makes the
+// image border a boundary exactly like mask_boundary)
+__device__ __forceinline__ unsigned long long boundary_word(const unsigned long long* B, int H, int WB, int row, int w) {
+    const unsigned long long* r = B + (long long)row * WB;
+    const unsigned long long I = r[w];
+    if (!I) return 0;
+    const unsigned long long L = (I << 1) | (w > 0 ? r[w - 1] >> 63 : 0ull), R = (I >> 1) | (w + 1 < WB ? r[w + 1] << 63 : 0ull);
+    const unsigned long long U = row > 0 ? r[w - WB] : 0ull, D = row + 1 < H ? r[w + WB] : 0ull;
+    return I & ~(L & R & U & D);
+}
+
+__global__ __launch_bounds__(256) void k_mask_rowcount_bits(const unsigned long long* bits, const int* bits_index, int H, int WB, int* rowcnt) {
+    const int o = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= H) return;
+    const unsigned long long* B = bits + (long long)bits_index[o] * H * WB;
+    int n = 0;
+    for (int w = 0; w < WB; w++) n += __popcll(boundary_word(B, H, WB, row, w));
+    rowcnt[o * H + row] = n;
+}
+
+__global__ __launch_bounds__(256) void k_mask_fill_bits(const unsigned long long* bits, const int* bits_index, int H, int WB, const int* rowstart, const int* area_start,
+                                                        short2* area) {
+    const int o = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= H) return;
+    const unsigned long long* B = bits + (long long)bits_index[o] * H * WB;
+    int at = area_start[o] + rowstart[o * H + row];
+    for (int w = 0; w < WB; w++) {
+        unsigned long long v = boundary_word(B, H, WB, row, w);
+        while (v) {
+            const int t = __ffsll((long long)v) - 1;
+            area[at++] = make_short2((short)(64 * w + t), (short)row);
+            v &= v - 1;
+        }
+    }
+}
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -721,6 +825,7 @@ struct oslam_poseopt {
     float* d_T = nullptr; float* d_Xw = nullptr; float* d_obs = nullptr; float* d_inv = nullptr; uint8_t* d_has = nullptr;
     uint8_t* h_pin = nullptr; size_t pin_cap = 0;   // pinned staging of the single-frame host API (inputs, then results)
     double* d_trace = nullptr; int trace_cap = 0;   // LM trace of frame 0 (oslam_poseopt_trace), off by default
+    const unsigned long long* bits = nullptr; const int* bits_index = nullptr;   // one-bit-per-pixel masks for the NEXT batch call (oslam_poseopt_use_mask_bits)
     // semantic variant: grow-only device buffers
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf masks, rowcnt, objcnt, area, area_start, objmp_Xw, objmp_obj, joint_kp, joint_obj, kp_uv, eXw, eobs, elevel, echi2, eobj, eout, etmp, nsem;
@@ -989,7 +1094,15 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
         (rc = ensure(h->elevel, nsemcap + 1)) || (rc = ensure(h->echi2, nsemcap * 8 + 8)) || (rc = ensure(h->eobj, nsemcap * 4 + 4)) || (rc = ensure(h->eout, nsemcap + 1)) ||
         (rc = ensure(h->etmp, nsemcap * 4 + 4)) || (rc = ensure(h->nsem, (size_t)h->max_batch * 4)))
         return rc;
-    if (total_obj > 0) {
+    if (total_obj > 0 && h->bits && h->bits_index) {   // boundary lists from the one-bit-per-pixel masks (oslam_poseopt_use_mask_bits)
+        const int WB = (W + 63) / 64;
+        hipLaunchKernelGGL(k_mask_rowcount_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, h->bits, h->bits_index, H, WB, (int*)h->rowcnt.p);
+        hipLaunchKernelGGL(k_mask_rowscan, dim3(total_obj), dim3(64), 0, st, H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
+        hipLaunchKernelGGL(k_mask_objscan, dim3(1), dim3(64), 0, st, total_obj, (int*)h->objcnt.p, (int*)h->area_start.p);
+        hipLaunchKernelGGL(k_mask_fill_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, h->bits, h->bits_index, H, WB, (int*)h->rowcnt.p, (int*)h->area_start.p,
+                           (short2*)h->area.p);
+        h->bits = nullptr; h->bits_index = nullptr;   // valid for this call only
+    } else if (total_obj > 0) {
         hipLaunchKernelGGL(k_mask_rowcount, dim3(H, total_obj), dim3(64), 0, st, nullptr, d_mask_ptrs, H, W, mask_pitch, (int*)h->rowcnt.p);
         hipLaunchKernelGGL(k_mask_rowscan, dim3(total_obj), dim3(64), 0, st, H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
         hipLaunchKernelGGL(k_mask_objscan, dim3(1), dim3(64), 0, st, total_obj, (int*)h->objcnt.p, (int*)h->area_start.p);
@@ -1019,6 +1132,33 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
 int oslam_poseopt_semantic_results_device(const oslam_poseopt_t* h, const int32_t** d_n_semantic) {
     if (!h || !d_n_semantic) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     *d_n_semantic = (const int32_t*)h->nsem.p;
+    return OSLAM_OK;
+}
+
+// One-bit-per-pixel form of n masks (device pointers, rows `pitch` bytes apart): d_bits [n][H][ceil(W / 64)] uint64, bit i of word w = pixel 64 w + i == 255.
+int oslam_mask_bits_device(const uint8_t* const* d_mask_ptrs, int n, int H, int W, int pitch, uint64_t* d_bits, void* stream) {
+    if (!d_mask_ptrs || !d_bits || n < 1 || H < 1 || W < 1 || pitch < W) { set_error("mask_bits: bad argument"); return OSLAM_E_INVALID; }
+    const int WB = (W + 63) / 64;
+    hipLaunchKernelGGL(k_mask_bits, dim3(div_up(H * WB, 256), n), dim3(256), 0, (hipStream_t)stream, d_mask_ptrs, H, W, pitch, WB, (unsigned long long*)d_bits);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+// The NEXT oslam_pose_optimize2_batch_device call of this handle builds its boundary lists from bitmaps made by oslam_mask_bits_device: object o of the call
+// (pooled index) is bitmap d_bits_index[o].  The mask pointers are still needed (unit-cell test of the nearest-pixel search).
+int oslam_poseopt_use_mask_bits(oslam_poseopt_t* h, const uint64_t* d_bits, const int32_t* d_bits_index) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    h->bits = (const unsigned long long*)d_bits; h->bits_index = d_bits_index;
+    return OSLAM_OK;
+}
+
+// The keypoint test from bitmaps: bit o of d_out[b][k] = the 20 x 20 window of keypoint k lies inside bitmap d_mask0[b] + o.
+int oslam_frame_object_kp_test_bits_batch_device(const oslam_keypoint_t* d_keysUn, int kp_stride, const int32_t* d_n_kps, int batch, const uint64_t* d_bits,
+                                                 const int32_t* d_mask0, const int32_t* d_n_masks, int H, int W, uint8_t* d_out, void* stream) {
+    if (!d_keysUn || !d_n_kps || !d_bits || !d_mask0 || !d_n_masks || !d_out || batch < 1 || kp_stride < 1 || H < 1 || W < 1) { set_error("object_kp_test_bits: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_object_kp_test_bits, dim3(div_up(kp_stride, 256), batch), dim3(256), 0, (hipStream_t)stream, d_keysUn, kp_stride, d_n_kps,
+                       (const unsigned long long*)d_bits, d_mask0, d_n_masks, H, W, (W + 63) / 64, d_out);
+    OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }
 

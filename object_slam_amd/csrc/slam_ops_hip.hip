@@ -3,6 +3,7 @@
 // translation units).  No CPU fallback: creation fails without a HIP device.  Never includes oracle/.
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/oslam_slam.h"
@@ -79,6 +80,20 @@ struct HipOps {
     const float* rec_ur(int r) const { return (const float*)(rec_desc(r) + oslam::align_up((size_t)cap * 32, 256)); }
     int rec_lookup(int slot, int kf) const { return (slot >= 0 && slot < (int)rec_of_kf.size() && kf >= 0 && kf < (int)rec_of_kf[slot].size()) ? rec_of_kf[slot][kf] : -1; }
     uint8_t* d_maskstage = nullptr; size_t mask_cap = 0;  // host masks of a stage, packed H x W
+    // One-bit-per-pixel form of the step's masks (oslam_mask_bits_device), built by object_kps and reused by pose_opt2 of the SAME step: keyed by the
+    // caller's mask pointer, valid while step_epoch (advanced by every Frame::Frame stage) equals bits_epoch
+    uint64_t* d_maskbits = nullptr; size_t maskbits_cap = 0;
+    std::unordered_map<const uint8_t*, int> bits_of_ptr;
+    long long step_epoch = 0, bits_epoch = -1;
+    int ensure_maskbits(size_t words) {
+        if (words <= maskbits_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+        if (d_maskbits) (void)hipFree(d_maskbits);
+        d_maskbits = nullptr; maskbits_cap = 0;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&d_maskbits, (words + words / 4) * 8));
+        maskbits_cap = words + words / 4;
+        return OSLAM_OK;
+    }
     int ensure_masks(size_t bytes) {
         if (bytes <= mask_cap) return OSLAM_OK;
         OSLAM_HIP_CHECK(hipDeviceSynchronize());
@@ -196,6 +211,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
 int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
              oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
+    o->step_epoch++;   // a new step: the mask bitmaps of the previous one are stale
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
@@ -242,6 +258,7 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
 int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                     oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
+    o->step_epoch++;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (!o->orbR || !o->stereo) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
     if (n > o->S) { oslam::set_error("frames_stereo: n > n_sequences"); return OSLAM_E_INVALID; }
@@ -544,6 +561,16 @@ int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
     memcpy(U + oPtr, ptrs.data(), 8 * (size_t)total); memcpy(U + oM0, mask0.data(), 4 * S); memcpy(U + oNm, nmask.data(), 4 * S);
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    if (!getenv("OSLAM_SLAM_NO_MASK_BITS")) {   // one pass over the mask bytes; the test (and pose_opt2's boundary lists later in this step) read bitmaps
+        const int H = o->cfg.height, W = o->cfg.width;
+        OPS_CHECK(o->ensure_maskbits((size_t)total * H * ((W + 63) / 64)));
+        OPS_CHECK(oslam_mask_bits_device((const uint8_t* const*)(Dv + oPtr), total, H, W, pitch, o->d_maskbits, o->strm));
+        OPS_CHECK(oslam_frame_object_kp_test_bits_batch_device(o->d_keysUn, (int)cap, o->d_cnt, (int)S, o->d_maskbits, (const int32_t*)(Dv + oM0), (const int32_t*)(Dv + oNm), H, W,
+                                                               o->d_objbits, o->strm));
+        o->bits_of_ptr.clear();
+        for (int m = 0; m < total; m++) o->bits_of_ptr[src[m]] = m;
+        o->bits_epoch = o->step_epoch;
+    } else
     OPS_CHECK(oslam_frame_object_kp_test_batch_device(o->d_keysUn, (int)cap, o->d_cnt, (int)S, (const uint8_t* const*)(Dv + oPtr), (const int32_t*)(Dv + oM0),
                                                       (const int32_t*)(Dv + oNm), o->cfg.height, o->cfg.width, pitch, o->d_objbits, o->strm));
     OPS_CHECK(o->ensure_dn(cap * S));
@@ -578,10 +605,16 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     Layout L;
     const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B),
                  oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
-                 oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ);
+                 oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ), oBi = L.take(4 * (size_t)tObj);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     memcpy(U + oFr, fr.data(), sizeof(oslam_sem_frame_t) * B);
+    bool use_bits = tObj > 0 && o->bits_epoch == o->step_epoch && o->d_maskbits;   // the bitmaps object_kps made of this step's masks
+    for (int m = 0; m < tObj && use_bits; m++) {
+        const auto it = o->bits_of_ptr.find(src[m]);
+        if (it == o->bits_of_ptr.end()) use_bits = false;
+        else ((int32_t*)(U + oBi))[m] = it->second;
+    }
     if (tObj) memcpy(U + oPtr, ptrs.data(), 8 * (size_t)tObj);
     o->pool->parallel_for(n, [&](int i) {
         const oslam_job_pose2_t& j2 = jobs[i];
@@ -597,6 +630,7 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
     o->t_begin();
+    if (use_bits) OPS_CHECK(oslam_poseopt_use_mask_bits(o->po, o->d_maskbits, (const int32_t*)(Dv + oBi)));
     OPS_CHECK(oslam_pose_optimize2_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), (const float*)(Dv + oT), (const float*)(Dv + oXw), (const float*)(Dv + oObs),
                                                 (const float*)(Dv + oInv), Dv + oHas, o->K5, (const oslam_sem_frame_t*)(Dv + oFr), tObj, (const uint8_t* const*)(Dv + oPtr),
                                                 o->cfg.height, o->cfg.width, pitch, tMp, (const float*)(Dv + oMx), (const int32_t*)(Dv + oMo), tJ, (const int32_t*)(Dv + oJk),
@@ -916,7 +950,7 @@ void h_destroy(void* p) {
     if (o->dn_h) (void)hipHostFree(o->dn_h);
     for (uint8_t* c : o->rec_chunks) (void)hipFree(c);
     if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
-    (void)hipFree(o->up_d); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
+    (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
     if (o->tev1) (void)hipEventDestroy(o->tev1);
