@@ -28,6 +28,7 @@ struct SemCtx {
     const short2* area;        // BOUNDARY pixels of the mask (== 255 with a 4-neighbour that is not, or on the image border) as (col,row), row-major scan order per object
     const int* area_start;     // [nObj+1]
     const int* row_start;      // [nObj][H]: boundary pixels of the object in the rows before a row (k_mask_rowscan), relative to area_start[o]
+    const unsigned long long* bits; const int* bits_index; int WB;   // optional one-bit-per-pixel masks (object o = bitmap bits_index[o]): then no mask byte is read
     const uint8_t* masks; const uint8_t* const* mask_ptrs; int H, W, pitch;   // the masks themselves (mask o = mask_ptrs[o] or masks + o*H*pitch), for the pixels around a query
     int nObjMp; const float* objmp_Xw; const int* objmp_obj;          // object map points, object-major
     int nJoint; const int* joint_kp; const int* joint_obj;             // M_joint candidates (:721-726)
@@ -101,14 +102,16 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
         d += dy * dy;
         if (bx < 0 || d < best || (d == best && (y < by || (y == by && x < bx)))) { best = d; bx = x; by = y; }
     };
-    const uint8_t* m = sm.mask_ptrs ? sm.mask_ptrs[o] : sm.masks + (long long)o * sm.H * sm.pitch;
+    const unsigned long long* Bm = sm.bits ? sm.bits + (long long)sm.bits_index[o] * sm.H * sm.WB : nullptr;
+    const uint8_t* m = Bm ? nullptr : (sm.mask_ptrs ? sm.mask_ptrs[o] : sm.masks + (long long)o * sm.H * sm.pitch);
     const float fu = floorf(u), fv = floorf(v);
     if (fu >= -1.f && fu < (float)sm.W && fv >= -1.f && fv < (float)sm.H) {   // unit cell first: a query inside the mask starts with best <= 2
         const int x0 = (int)fu, y0 = (int)fv;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int x = x0 + (k & 1), y = y0 + (k >> 1);
-            if (x < 0 || y < 0 || x >= sm.W || y >= sm.H || m[(long long)y * sm.pitch + x] != 255) continue;
+            if (x < 0 || y < 0 || x >= sm.W || y >= sm.H) continue;
+            if (Bm ? !((Bm[(long long)y * sm.WB + (x >> 6)] >> (x & 63)) & 1ull) : m[(long long)y * sm.pitch + x] != 255) continue;
             consider(x, y);
         }
     }
@@ -264,7 +267,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     if (SEM && c.sem.frames) {
         const oslam_sem_frame_t f = c.sem.frames[b];
         const int e0 = f.objmp0 + f.joint0;
-        sm.nObj = f.nObj; sm.area_start += f.obj0; sm.mask_ptrs += f.obj0; sm.row_start += (long long)f.obj0 * sm.H;
+        sm.nObj = f.nObj; sm.area_start += f.obj0; sm.row_start += (long long)f.obj0 * sm.H;
+        if (sm.bits) sm.bits_index += f.obj0; else sm.mask_ptrs += f.obj0;
         sm.nObjMp = f.nObjMp; sm.objmp_Xw += 3 * (long long)f.objmp0; sm.objmp_obj += f.objmp0;
         sm.nJoint = f.nJoint; sm.joint_kp += f.joint0; sm.joint_obj += f.joint0;
         sm.e_Xw += 3 * (long long)e0; sm.e_obs += 2 * (long long)e0; sm.e_level += e0; sm.e_chi2 += e0; sm.e_obj += e0; sm.e_out += e0; sm.e_tmp += e0;
@@ -1083,7 +1087,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
     if (!h || !d_n || !d_Tcw || !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp || !K5 || !d_frames || !bounds) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (batch < 1 || batch > h->max_batch) { set_error("batch %d outside [1,%d]", batch, h->max_batch); return OSLAM_E_INVALID; }
     if (stride < 1 || stride > h->max_points) { set_error("stride exceeds max_points %d", h->max_points); return OSLAM_E_CAPACITY; }
-    if (total_obj < 0 || total_objmp < 0 || total_joint < 0 || H < 1 || W < 1 || W >= 32768 || H >= 32768 || mask_pitch < W || (total_obj > 0 && !d_mask_ptrs) ||
+    if (total_obj < 0 || total_objmp < 0 || total_joint < 0 || H < 1 || W < 1 || W >= 32768 || H >= 32768 || mask_pitch < W || (total_obj > 0 && !d_mask_ptrs && !(h && h->bits && h->bits_index)) ||
         (total_objmp > 0 && (!d_objmp_Xw || !d_objmp_obj)) || (total_joint > 0 && (!d_joint_kp || !d_joint_obj))) { set_error("bad semantic sizes"); return OSLAM_E_INVALID; }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1094,6 +1098,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
         (rc = ensure(h->elevel, nsemcap + 1)) || (rc = ensure(h->echi2, nsemcap * 8 + 8)) || (rc = ensure(h->eobj, nsemcap * 4 + 4)) || (rc = ensure(h->eout, nsemcap + 1)) ||
         (rc = ensure(h->etmp, nsemcap * 4 + 4)) || (rc = ensure(h->nsem, (size_t)h->max_batch * 4)))
         return rc;
+    const unsigned long long* use_bits = h->bits; const int* use_index = h->bits_index;
     if (total_obj > 0 && h->bits && h->bits_index) {   // boundary lists from the one-bit-per-pixel masks (oslam_poseopt_use_mask_bits)
         const int WB = (W + 63) / 64;
         hipLaunchKernelGGL(k_mask_rowcount_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, h->bits, h->bits_index, H, WB, (int*)h->rowcnt.p);
@@ -1119,6 +1124,7 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
     memset(&sm, 0, sizeof(sm));
     sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p; sm.row_start = (int*)h->rowcnt.p;
     sm.masks = nullptr; sm.mask_ptrs = d_mask_ptrs; sm.H = H; sm.W = W; sm.pitch = mask_pitch;
+    if (total_obj > 0 && use_bits && use_index) { sm.bits = use_bits; sm.bits_index = use_index; sm.WB = (W + 63) / 64; }
     sm.objmp_Xw = d_objmp_Xw; sm.objmp_obj = d_objmp_obj; sm.joint_kp = d_joint_kp; sm.joint_obj = d_joint_obj; sm.kp_uv = nullptr;
     sm.minX = bounds[0]; sm.minY = bounds[1]; sm.maxX = bounds[2]; sm.maxY = bounds[3]; sm.invSigma2_0 = invSigma2_0;
     sm.e_Xw = (float*)h->eXw.p; sm.e_obs = (float*)h->eobs.p; sm.e_level = (uint8_t*)h->elevel.p; sm.e_chi2 = (double*)h->echi2.p; sm.e_obj = (int*)h->eobj.p;

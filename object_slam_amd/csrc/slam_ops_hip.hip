@@ -601,7 +601,15 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     }
     std::vector<const uint8_t*> ptrs;
     int pitch = o->cfg.width;
-    if (tObj) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
+    // with this step's bitmaps (object_kps) the kernel reads no mask byte: nothing to stage
+    bool use_bits = tObj > 0 && o->bits_epoch == o->step_epoch && o->d_maskbits;
+    std::vector<int32_t> bidx(tObj);
+    for (int m = 0; m < tObj && use_bits; m++) {
+        const auto it = o->bits_of_ptr.find(src[m]);
+        if (it == o->bits_of_ptr.end()) use_bits = false;
+        else bidx[m] = it->second;
+    }
+    if (tObj && !use_bits) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
     Layout L;
     const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B),
                  oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
@@ -609,13 +617,8 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     memcpy(U + oFr, fr.data(), sizeof(oslam_sem_frame_t) * B);
-    bool use_bits = tObj > 0 && o->bits_epoch == o->step_epoch && o->d_maskbits;   // the bitmaps object_kps made of this step's masks
-    for (int m = 0; m < tObj && use_bits; m++) {
-        const auto it = o->bits_of_ptr.find(src[m]);
-        if (it == o->bits_of_ptr.end()) use_bits = false;
-        else ((int32_t*)(U + oBi))[m] = it->second;
-    }
-    if (tObj) memcpy(U + oPtr, ptrs.data(), 8 * (size_t)tObj);
+    if (use_bits) memcpy(U + oBi, bidx.data(), 4 * (size_t)tObj);
+    if (tObj && !use_bits) memcpy(U + oPtr, ptrs.data(), 8 * (size_t)tObj);
     o->pool->parallel_for(n, [&](int i) {
         const oslam_job_pose2_t& j2 = jobs[i];
         const oslam_job_pose_t& j = j2.base;
@@ -632,7 +635,7 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     o->t_begin();
     if (use_bits) OPS_CHECK(oslam_poseopt_use_mask_bits(o->po, o->d_maskbits, (const int32_t*)(Dv + oBi)));
     OPS_CHECK(oslam_pose_optimize2_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), (const float*)(Dv + oT), (const float*)(Dv + oXw), (const float*)(Dv + oObs),
-                                                (const float*)(Dv + oInv), Dv + oHas, o->K5, (const oslam_sem_frame_t*)(Dv + oFr), tObj, (const uint8_t* const*)(Dv + oPtr),
+                                                (const float*)(Dv + oInv), Dv + oHas, o->K5, (const oslam_sem_frame_t*)(Dv + oFr), tObj, use_bits ? nullptr : (const uint8_t* const*)(Dv + oPtr),
                                                 o->cfg.height, o->cfg.width, pitch, tMp, (const float*)(Dv + oMx), (const int32_t*)(Dv + oMo), tJ, (const int32_t*)(Dv + oJk),
                                                 (const int32_t*)(Dv + oJo), o->bounds, o->invSigma2[0], o->strm));
     o->t_end();
