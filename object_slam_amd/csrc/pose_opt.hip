@@ -1055,6 +1055,7 @@ int oslam_pose_optimize2(oslam_poseopt_t* h, int N, const float Tcw_in[16], cons
     c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
     c.Tcw_out = h->d_Tout; c.outlier = h->d_outlier; c.n_inliers = h->d_ninl; c.stats = h->d_stats; c.trace = h->d_trace; c.trace_cap = h->trace_cap;
     SemCtx& sm = c.sem;
+    memset(&sm, 0, sizeof(sm));   // every optional pointer (bitmaps, frame table, pointer table) off unless set below
     sm.nObj = sem->nObj; sm.area = (short2*)h->area.p; sm.area_start = (int*)h->area_start.p; sm.row_start = (int*)h->rowcnt.p;
     sm.masks = (const uint8_t*)h->masks.p; sm.mask_ptrs = nullptr; sm.H = sem->H; sm.W = sem->W; sm.pitch = sem->W;
     sm.nObjMp = sem->nObjMp; sm.objmp_Xw = (float*)h->objmp_Xw.p; sm.objmp_obj = (int*)h->objmp_obj.p;
@@ -1084,10 +1085,13 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
                                       const uint8_t* const* d_mask_ptrs, int H, int W, int mask_pitch, int total_objmp, const float* d_objmp_Xw,
                                       const int32_t* d_objmp_obj, int total_joint, const int32_t* d_joint_kp, const int32_t* d_joint_obj, const float bounds[4],
                                       float invSigma2_0, void* stream) {
-    if (!h || !d_n || !d_Tcw || !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp || !K5 || !d_frames || !bounds) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    if (!h) { set_error("NULL argument"); return OSLAM_E_INVALID; }
+    const unsigned long long* use_bits = h->bits; const int* use_index = h->bits_index;
+    h->bits = nullptr; h->bits_index = nullptr;   // the bitmap hint (oslam_poseopt_use_mask_bits) holds for this call only, whatever its outcome
+    if (!d_n || !d_Tcw || !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp || !K5 || !d_frames || !bounds) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (batch < 1 || batch > h->max_batch) { set_error("batch %d outside [1,%d]", batch, h->max_batch); return OSLAM_E_INVALID; }
     if (stride < 1 || stride > h->max_points) { set_error("stride exceeds max_points %d", h->max_points); return OSLAM_E_CAPACITY; }
-    if (total_obj < 0 || total_objmp < 0 || total_joint < 0 || H < 1 || W < 1 || W >= 32768 || H >= 32768 || mask_pitch < W || (total_obj > 0 && !d_mask_ptrs && !(h && h->bits && h->bits_index)) ||
+    if (total_obj < 0 || total_objmp < 0 || total_joint < 0 || H < 1 || W < 1 || W >= 32768 || H >= 32768 || mask_pitch < W || (total_obj > 0 && !d_mask_ptrs && !(use_bits && use_index)) ||
         (total_objmp > 0 && (!d_objmp_Xw || !d_objmp_obj)) || (total_joint > 0 && (!d_joint_kp || !d_joint_obj))) { set_error("bad semantic sizes"); return OSLAM_E_INVALID; }
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1098,15 +1102,13 @@ int oslam_pose_optimize2_batch_device(oslam_poseopt_t* h, int batch, int stride,
         (rc = ensure(h->elevel, nsemcap + 1)) || (rc = ensure(h->echi2, nsemcap * 8 + 8)) || (rc = ensure(h->eobj, nsemcap * 4 + 4)) || (rc = ensure(h->eout, nsemcap + 1)) ||
         (rc = ensure(h->etmp, nsemcap * 4 + 4)) || (rc = ensure(h->nsem, (size_t)h->max_batch * 4)))
         return rc;
-    const unsigned long long* use_bits = h->bits; const int* use_index = h->bits_index;
-    if (total_obj > 0 && h->bits && h->bits_index) {   // boundary lists from the one-bit-per-pixel masks (oslam_poseopt_use_mask_bits)
+    if (total_obj > 0 && use_bits && use_index) {   // boundary lists from the one-bit-per-pixel masks (oslam_poseopt_use_mask_bits)
         const int WB = (W + 63) / 64;
-        hipLaunchKernelGGL(k_mask_rowcount_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, h->bits, h->bits_index, H, WB, (int*)h->rowcnt.p);
+        hipLaunchKernelGGL(k_mask_rowcount_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, use_bits, use_index, H, WB, (int*)h->rowcnt.p);
         hipLaunchKernelGGL(k_mask_rowscan, dim3(total_obj), dim3(64), 0, st, H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
         hipLaunchKernelGGL(k_mask_objscan, dim3(1), dim3(64), 0, st, total_obj, (int*)h->objcnt.p, (int*)h->area_start.p);
-        hipLaunchKernelGGL(k_mask_fill_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, h->bits, h->bits_index, H, WB, (int*)h->rowcnt.p, (int*)h->area_start.p,
+        hipLaunchKernelGGL(k_mask_fill_bits, dim3(div_up(H, 256), total_obj), dim3(256), 0, st, use_bits, use_index, H, WB, (int*)h->rowcnt.p, (int*)h->area_start.p,
                            (short2*)h->area.p);
-        h->bits = nullptr; h->bits_index = nullptr;   // valid for this call only
     } else if (total_obj > 0) {
         hipLaunchKernelGGL(k_mask_rowcount, dim3(H, total_obj), dim3(64), 0, st, nullptr, d_mask_ptrs, H, W, mask_pitch, (int*)h->rowcnt.p);
         hipLaunchKernelGGL(k_mask_rowscan, dim3(total_obj), dim3(64), 0, st, H, (int*)h->rowcnt.p, (int*)h->objcnt.p);
