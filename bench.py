@@ -263,7 +263,7 @@ def main():
     ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 4096 RGB-D / 512 stereo; measured 512 -> 9 k, 1024 -> 12 k, 2048 -> 15 k, 4096 -> 16 k, "
                                                         "8192 -> 17-20 k RGB-D frames/s: the per-stage fixed costs of the lockstep driver are amortised over more sequences)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8 / 4)")
-    ap.add_argument("--cpu-frames", type=int, default=150)
+    ap.add_argument("--cpu-frames", type=int, default=240, help="frames of one sequence through the CPU oracle table for cpu_baseline (~11 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
