@@ -547,6 +547,11 @@ int oslam_frame_stereo_from_rgbd_batch_ptrs_device(const oslam_keypoint_t* d_key
                                                    int stride, int batch, const float* const* d_depth_ptrs, int rows, int cols, int pitch, float mbf,
                                                    float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
 
+/* Two-level nearest-centre descent over 256-bit descriptors (the node assignment of a DBoW2-style vocabulary tree with branching 10, depth 2):
+ * d_out[i][k] = 11 + 10 b1 + b2 for descriptor k of array d_desc_ptrs[i] (d_counts[i] of them, at most `stride`), first minimum on ties. */
+int oslam_bow_nodes_device(const uint8_t* const* d_desc_ptrs, const int32_t* d_counts, int n, int stride, const uint64_t* d_top, const uint64_t* d_sub,
+                           uint32_t* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,12 @@ typedef struct oslam_slam_ops {
     int (*mp_update_keyed)(void* ctx, oslam_job_mp_update_t* job, const int32_t* obs_key);
     /* optional (NULL in tables without a device): see oslam_slam_kernel_times */
     int (*kernel_times)(void* ctx, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
+    /* optional, with register_keyframes: the FeatureVector node of every descriptor of registered keyframes (slot, kf_id), read from the resident copy.  The
+     * driver's substitute for the DBoW2 vocabulary that is not in the reference tree (KeyFrame::ComputeBoW, src/KeyFrame.cc:66-76) is a two-level tree of
+     * 10 x 10 256-bit centres: node = 11 + 10 b1 + b2 with b1 the nearest of top[10] and b2 the nearest of sub[b1][10] under the Hamming distance, first
+     * on ties.  counts[i] descriptors of keyframe i -> out[i][0 .. counts[i]). */
+    int (*bow_nodes_keyed)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids, const uint64_t* top /* [10][4] */, const uint64_t* sub /* [10][10][4] */,
+                           const int32_t* counts, uint32_t* const* out);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

@@ -116,6 +116,26 @@ __global__ __launch_bounds__(256) void k_gather_desc(const uint8_t* const* desc_
     ((uint32_t*)out)[(size_t)i * 8 + part] = ((const uint32_t*)(desc_base[r.x] + (size_t)r.y * 32))[part];
 }
 
+// node of every descriptor: nearest of the 10 top centres, then nearest of that centre's 10 children (Hamming, first minimum); the 110 centres sit in LDS
+__global__ __launch_bounds__(256) void k_bow_nodes(const uint8_t* const* desc_ptrs, const int* counts, int stride, const unsigned long long* top,
+                                                   const unsigned long long* sub, uint32_t* out) {
+    __shared__ unsigned long long s_c[110 * 4];
+    for (int i = threadIdx.x; i < 440; i += 256) s_c[i] = i < 40 ? top[i] : sub[i - 40];
+    __syncthreads();
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= counts[b]) return;
+    const uint4* d4 = (const uint4*)(desc_ptrs[b] + (size_t)k * 32);
+    const uint4 lo = d4[0], hi = d4[1];
+    const unsigned long long v[4] = {(unsigned long long)lo.x | ((unsigned long long)lo.y << 32), (unsigned long long)lo.z | ((unsigned long long)lo.w << 32),
+                                     (unsigned long long)hi.x | ((unsigned long long)hi.y << 32), (unsigned long long)hi.z | ((unsigned long long)hi.w << 32)};
+    auto dist = [&](const unsigned long long* c) { return __popcll(v[0] ^ c[0]) + __popcll(v[1] ^ c[1]) + __popcll(v[2] ^ c[2]) + __popcll(v[3] ^ c[3]); };
+    int b1 = 0, bd = 1 << 30;
+    for (int i = 0; i < 10; i++) { const int dd = dist(s_c + 4 * i); if (dd < bd) { bd = dd; b1 = i; } }
+    int b2 = 0; bd = 1 << 30;
+    for (int j = 0; j < 10; j++) { const int dd = dist(s_c + 40 + 4 * (b1 * 10 + j)); if (dd < bd) { bd = dd; b2 = j; } }
+    out[(size_t)b * stride + k] = 11u + (uint32_t)(b1 * 10 + b2);
+}
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -182,6 +202,15 @@ int oslam_frame_gather_images_device(const void* const* d_src_ptrs, int n, int s
 int oslam_copy_segments_device(const void* d_segs, int n, void* stream) {
     if (!d_segs || n < 1) { set_error("copy_segments: bad argument"); return OSLAM_E_INVALID; }
     hipLaunchKernelGGL(k_copy_segments, dim3(n), dim3(256), 0, (hipStream_t)stream, (const CopySeg*)d_segs);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_bow_nodes_device(const uint8_t* const* d_desc_ptrs, const int32_t* d_counts, int n, int stride, const uint64_t* d_top, const uint64_t* d_sub,
+                           uint32_t* d_out, void* stream) {
+    if (!d_desc_ptrs || !d_counts || !d_top || !d_sub || !d_out || n < 1 || stride < 1) { set_error("bow_nodes: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_bow_nodes, dim3(div_up(stride, 256), n), dim3(256), 0, (hipStream_t)stream, d_desc_ptrs, d_counts, stride, (const unsigned long long*)d_top,
+                       (const unsigned long long*)d_sub, d_out);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
 }

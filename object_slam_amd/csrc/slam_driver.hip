@@ -68,24 +68,41 @@ struct Timer {
 struct BowViews {
     std::vector<int32_t> q_idx; std::vector<uint32_t> q_node;
     std::vector<uint32_t> nodes; std::vector<int32_t> start, items;
+    // Both views order the keypoints by (node id, keypoint index).  Node ids are small integers (the vocabulary substitute has 100 leaves, DBoW2's level-4
+    // nodes of the reference vocabulary 10^4), so this is a stable counting sort by node, not a comparison sort of 1000-2000 pairs per keyframe.
+    static void by_node(const std::vector<uint32_t>& node, std::vector<int32_t>& order, std::vector<int32_t>& count /* [max node + 2], prefix sums on return */) {
+        const int N = (int)node.size();
+        uint32_t mx = 0;
+        for (int i = 0; i < N; i++) mx = std::max(mx, node[i]);
+        order.resize(N);
+        if (mx > (1u << 20)) {   // not a small-id vocabulary: comparison sort
+            std::vector<std::pair<uint32_t, int>> v(N);
+            for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
+            std::sort(v.begin(), v.end());
+            for (int i = 0; i < N; i++) order[i] = v[i].second;
+            count.clear();
+            return;
+        }
+        count.assign((size_t)mx + 2, 0);
+        for (int i = 0; i < N; i++) count[node[i] + 1]++;
+        for (size_t k = 1; k < count.size(); k++) count[k] += count[k - 1];
+        std::vector<int32_t> cur(count.begin(), count.end() - 1);
+        for (int i = 0; i < N; i++) order[cur[node[i]]++] = i;
+    }
     void side1(const std::vector<uint32_t>& node) {
         const int N = (int)node.size();
-        std::vector<std::pair<uint32_t, int>> v(N);
-        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
-        std::sort(v.begin(), v.end());
-        q_idx.resize(N); q_node.resize(N);
-        for (int i = 0; i < N; i++) { q_idx[i] = v[i].second; q_node[i] = v[i].first; }
+        std::vector<int32_t> cnt;
+        by_node(node, q_idx, cnt);
+        q_node.resize(N);
+        for (int i = 0; i < N; i++) q_node[i] = node[q_idx[i]];
     }
     void side2(const std::vector<uint32_t>& node) {
         const int N = (int)node.size();
-        std::vector<std::pair<uint32_t, int>> v(N);
-        for (int i = 0; i < N; i++) v[i] = std::make_pair(node[i], i);
-        std::sort(v.begin(), v.end());
-        nodes.clear(); start.clear(); items.resize(N);
-        for (int i = 0; i < N; i++) {
-            if (i == 0 || v[i].first != v[i - 1].first) { nodes.push_back(v[i].first); start.push_back(i); }
-            items[i] = v[i].second;
-        }
+        std::vector<int32_t> cnt;
+        by_node(node, items, cnt);
+        nodes.clear(); start.clear();
+        for (int i = 0; i < N; i++)
+            if (i == 0 || node[items[i]] != node[items[i - 1]]) { nodes.push_back(node[items[i]]); start.push_back(i); }
         start.push_back(N);
     }
 };
@@ -1506,6 +1523,16 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             c.seq[i]->pendingKF.clear();
         }
         if (!rs.empty() && (rc = c.ops.register_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
+        if (!rs.empty() && c.ops.bow_nodes_keyed) {   // KeyFrame::ComputeBoW of the new keyframes from their resident descriptors (ProcessNewKeyFrame finds it done)
+            std::vector<int32_t> cnt(rs.size());
+            std::vector<uint32_t*> outp(rs.size());
+            for (size_t q = 0; q < rs.size(); q++) {
+                KeyFrm& k = c.seq[rs[q]]->map.kfs[rk[q]];
+                k.bowNode.resize(k.N);
+                cnt[q] = k.N; outp[q] = k.bowNode.data();
+            }
+            if ((rc = c.ops.bow_nodes_keyed(c.ops.ctx, (int)rs.size(), rs.data(), rk.data(), &c.voc.top[0][0], &c.voc.sub[0][0][0], cnt.data(), outp.data()))) return rc;
+        }
     }
     if ((rc = upd.run(c, true, true))) return rc;   // descriptors / normals of the points created this step
     { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }

@@ -814,6 +814,36 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     return OSLAM_OK;
 }
 
+// KeyFrame::ComputeBoW node assignment of registered keyframes from their resident descriptors (see oslam_slam_ops_t::bow_nodes_keyed)
+int h_bow_nodes_keyed(void* p, int n, const int32_t* slots, const int32_t* kf_ids, const uint64_t* top, const uint64_t* sub, const int32_t* counts, uint32_t* const* out) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    const size_t cap = o->cap;
+    Layout L;
+    const size_t oPtr = L.take(8 * (size_t)n), oCnt = L.take(4 * (size_t)n), oTop = L.take(320), oSub = L.take(3200);
+    const size_t in_bytes = L.off;
+    const size_t oOut = L.take(4 * cap * (size_t)n);
+    OPS_CHECK(o->ensure_up(L.off));
+    OPS_CHECK(o->ensure_dn(4 * cap * (size_t)n));
+    uint8_t* U = o->up_h;
+    for (int i = 0; i < n; i++) {
+        const int r = o->rec_lookup(slots[i], kf_ids[i]);
+        if (r < 0 || counts[i] < 0 || counts[i] > (int)cap) { oslam::set_error("bow_nodes: keyframe not resident / bad count"); return OSLAM_E_INVALID; }
+        ((const uint8_t**)(U + oPtr))[i] = o->rec_desc(r);
+        ((int32_t*)(U + oCnt))[i] = counts[i];
+    }
+    memcpy(U + oTop, top, 320); memcpy(U + oSub, sub, 3200);
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    uint8_t* Dv = o->up_d;
+    OPS_CHECK(oslam_bow_nodes_device((const uint8_t* const*)(Dv + oPtr), (const int32_t*)(Dv + oCnt), n, (int)cap, (const uint64_t*)(Dv + oTop), (const uint64_t*)(Dv + oSub),
+                                     (uint32_t*)(Dv + oOut), o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, Dv + oOut, 4 * cap * (size_t)n, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->pool->parallel_for(n, [&](int i) { memcpy(out[i], o->dn_h + 4 * cap * (size_t)i, 4 * (size_t)counts[i]); });
+    return OSLAM_OK;
+}
+
 int h_bow_keyed(void* p, int n, oslam_job_bow_t* jobs, const oslam_kf_key_t* keys) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
@@ -1018,6 +1048,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; }
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
+        if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed; }
     return OSLAM_OK;
 }
