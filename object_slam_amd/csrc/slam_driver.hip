@@ -306,6 +306,11 @@ struct MpUpdate {
             for (int i = i0; i < i1; i++) {
                 if (i + kPF < i1) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
                 if (i + kPF / 2 < i1) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
+                if (do_normal && i + 2 < i1) {   // the reference keyframe's keypoint of item i + 2 (record and list were requested above): a third, dependent access
+                    const Map& m2 = c.seq[items[i + 2].seq]->map;
+                    const MapPt& p2 = m2.mps[items[i + 2].p];
+                    if (!p2.bad && p2.refKF >= 0) { const int i2 = p2.obs_index(p2.refKF); if (i2 >= 0) __builtin_prefetch(&m2.kfs[p2.refKF].keysUn[i2]); }
+                }
                 const Map& m = c.seq[items[i].seq]->map;
                 const MapPt& p = m.mps[items[i].p];
                 const int n = start[i + 1] - start[i];
@@ -915,6 +920,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             W.points.resize(W.pts.size() * 3);
             for (size_t j = 0; j < W.pts.size(); j++) {
                 prefetch_obs_ahead(m.mps, W.pts, j, W.pts.size());
+                if (j + 2 < W.pts.size())   // the keypoints its observations name: a third, dependent level (record and list of point j + 2 were requested above)
+                    for (auto& e : m.mps[W.pts[j + 2]].obs) { const KeyFrm& k2 = m.kfs[e.first]; __builtin_prefetch(&k2.keysUn[e.second]); __builtin_prefetch(&k2.uRight[e.second]); }
                 const MapPt& mp = m.mps[W.pts[j]];
                 for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
                 for (auto& e : mp.obs) {
@@ -1125,6 +1132,7 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     s.hasSL = false;
     // CheckReplacedInLastFrame (:820-835)
     for (int k = 0; k < l.N; k++) {
+        prefetch_ahead(s.map.mps, l.mp, k, l.N);
         const int p = l.mp[k];
         if (p >= 0 && s.map.mps[p].replaced >= 0) l.mp[k] = s.map.mps[p].replaced;
     }
