@@ -37,7 +37,10 @@
  *   - local map points searched per frame (Tracking::SearchLocalPoints): no fixed bound, the matcher's query buffers grow on demand;
  *   - local BA: points and edges per window grow on demand; at most 128 keyframes (local + fixed) per window: fixed cameras beyond that are left
  *     out of the window together with their observations (oslam_slam_object_stats [6] counts them) instead of failing the step;
- *   - detections per frame: OSLAM_SLAM_MAX_OBJECTS.
+ *   - detections per frame: OSLAM_SLAM_MAX_OBJECTS;
+ *   - resident keyframe records (keypoints, descriptors, stereo coordinates: ~64 B x capacity each): one per keyframe ever created in the current map of a
+ *     sequence (a culled keyframe keeps its record: map points may keep observations in it, src/KeyFrame.cc:382-462 erases only those of its own
+ *     mvpMapPoints); the records of a map that was reset are reused; the store itself only grows and is released with the handle.
  * A capacity error of an operator (OSLAM_E_CAPACITY) aborts the lockstep step of ALL sequences of the handle: the map bookkeeping of that step has
  * then partly run, so the handle must be discarded. */
 #ifndef OSLAM_SLAM_H

@@ -70,6 +70,7 @@ struct HipOps {
     static constexpr int kRecChunk = 256;
     std::vector<uint8_t*> rec_chunks;
     std::vector<std::vector<int>> rec_of_kf;              // [slot][kf id] -> record index or -1
+    std::vector<int> free_recs;                           // records of maps that were reset, reused before the store grows
     int n_rec = 0;
     uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
     std::vector<uint8_t*> h_rec_desc;
@@ -780,16 +781,23 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     for (int i = 0; i < n; i++) {
         const int slot = slots[i], kf = kf_ids[i];
         if (slot < 0 || slot >= o->S || kf < 0) { oslam::set_error("register_keyframes: bad slot / id"); return OSLAM_E_INVALID; }
-        if (kf == 0) o->rec_of_kf[slot].clear();   // the sequence was reset: its keyframe ids restart
+        if (kf == 0) {   // the sequence was reset: its keyframe ids restart, its records are free again
+            for (int r0 : o->rec_of_kf[slot]) if (r0 >= 0) o->free_recs.push_back(r0);
+            o->rec_of_kf[slot].clear();
+        }
         if ((int)o->rec_of_kf[slot].size() <= kf) o->rec_of_kf[slot].resize(kf + 1, -1);
-        const int r = o->n_rec++;
-        if (r / HipOps::kRecChunk >= (int)o->rec_chunks.size()) {
-            uint8_t* c = nullptr;
-            OSLAM_HIP_CHECK(hipMalloc((void**)&c, rb * HipOps::kRecChunk));
-            o->rec_chunks.push_back(c);
+        int r;
+        if (!o->free_recs.empty()) { r = o->free_recs.back(); o->free_recs.pop_back(); }   // a record of a map that was reset
+        else {
+            r = o->n_rec++;
+            if (r / HipOps::kRecChunk >= (int)o->rec_chunks.size()) {
+                uint8_t* c = nullptr;
+                OSLAM_HIP_CHECK(hipMalloc((void**)&c, rb * HipOps::kRecChunk));
+                o->rec_chunks.push_back(c);
+            }
+            o->h_rec_desc.push_back((uint8_t*)o->rec_desc(r));
         }
         o->rec_of_kf[slot][kf] = r;
-        o->h_rec_desc.push_back((uint8_t*)o->rec_desc(r));
         // the frame built for `slot` in this step is still in the batch arrays
         segs.push_back({(const uint8_t*)(o->d_keysUn + cap * slot), (uint8_t*)o->rec_keys(r), (uint32_t)(cap * sizeof(oslam_keypoint_t)), 0});
         segs.push_back({o->d_desc + 32 * cap * slot, (uint8_t*)o->rec_desc(r), (uint32_t)(cap * 32), 0});
