@@ -122,6 +122,10 @@ typedef struct oslam_job_mp_update {       /* MapPoint::ComputeDistinctiveDescri
     int32_t P; const int32_t* obs_start; const uint8_t* obs_desc; const float* obs_Ow;
     const float* Pos; const float* OwRef; const float* levelScaleFactor;
     int32_t do_desc, do_normal;
+    const int32_t* desc_start;             /* [P + 1] or NULL (= obs_start): CSR of the observations whose keyframe is NOT bad, the only ones
+                                            * ComputeDistinctiveDescriptors uses (src/MapPoint.cc:362-368; UpdateNormalAndDepth uses all of them, :441-453).
+                                            * obs_desc — and the keys of mp_update_keyed — follow THIS layout, obs_Ow follows obs_start.  A point whose
+                                            * list is empty keeps its descriptor (:370-371). */
     int32_t* best_idx; uint8_t* out_desc; float* out5;      /* out: see oslam_mp_distinctive_descriptors / oslam_mp_update_normal_depth */
 } oslam_job_mp_update_t;
 
@@ -257,6 +261,10 @@ int oslam_slam_stage_cpu_seconds(oslam_slam_t* h, double out[16]);
 /* out[0] = tracked frames whose local map (mvpLocalMapPoints and the packed SearchLocalPoints arrays) was reused from the previous frame because neither
  * the ordered local keyframe list nor the sequence's map had changed, out[1] = all tracked frames; summed over the sequences of the handle. */
 int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]);
+/* Observations in culled keyframes that ComputeDistinctiveDescriptors left out (src/MapPoint.cc:366: `if(!pKF->isBad())`), summed over the handle's
+ * sequences and calls: such observations exist when two new points triangulate against the same neighbour keypoint (the second AddMapPoint wins,
+ * src/LocalMapping.cc:440-446) and the neighbour is culled later (its SetBadFlag only erases the observations of its own mvpMapPoints). */
+int oslam_slam_bad_keyframe_observations(oslam_slam_t* h, int64_t* out);
 /* Device time of the kernel groups of the HIP operator table, measured with HIP events on the stream each group is launched on
  * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:
  * out[3g] = milliseconds, out[3g+1] = kernel launches, out[3g+2] = algorithmic work of those launches — bytes for group 0 (SURVEY.md

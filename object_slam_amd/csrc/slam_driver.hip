@@ -204,6 +204,7 @@ struct Ctx {
     };
     std::vector<Win> winPool;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
+    std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
     std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
     long long next_content_id() { return contentCounter.fetch_add(1, std::memory_order_relaxed) + 1; }
     int mask_stride = 0, masks_on_device = 0;
@@ -283,23 +284,32 @@ struct MpUpdate {
     std::vector<int> best;
     void clear() { items.clear(); }
     void add(int seq, int p) { items.push_back({seq, p}); }
+    std::vector<int> dstart;
     int run(Ctx& c, bool do_desc, bool do_normal) {
         const int P = (int)items.size();
         if (P == 0) return OSLAM_OK;
-        start.assign(P + 1, 0);
+        // Two observation lists per point: UpdateNormalAndDepth reads every observation (src/MapPoint.cc:441-453), ComputeDistinctiveDescriptors only those
+        // whose keyframe is not bad (:362-368).  They differ when a point still observes a culled keyframe: KeyFrame::SetBadFlag erases the observations of
+        // the keyframe's own mvpMapPoints only, and a keypoint's slot can have gone to another point (two new points triangulated against the same neighbour
+        // keypoint, src/LocalMapping.cc:440-446).
+        start.assign(P + 1, 0); dstart.assign(P + 1, 0);
         for (int i = 0; i < P; i++) {
             if (i + kPF < P) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
-            const MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
-            start[i + 1] = start[i] + (p.bad ? 0 : (int)p.obs.size());
+            if (i + kPF / 2 < P) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
+            const Map& m = c.seq[items[i].seq]->map;
+            const MapPt& p = m.mps[items[i].p];
+            int n = 0, nd = 0;
+            if (!p.bad) { n = (int)p.obs.size(); for (auto& e : p.obs) nd += !m.kfs[e.first].bad; }
+            start[i + 1] = start[i] + n; dstart[i + 1] = dstart[i] + nd;
         }
-        const size_t total = (size_t)start[P];
+        const size_t total = (size_t)start[P], dtotal = (size_t)dstart[P];
+        const bool split = dtotal != total;
+        if (do_desc) c.badKFObs.fetch_add((long long)(total - dtotal), std::memory_order_relaxed);
         const bool keyed = c.ops.mp_update_keyed != nullptr && do_desc;   // the table gathers the descriptors from its resident keyframes
-        if (!keyed) odesc.resize(do_desc ? std::max<size_t>(total, 1) * 32 : 32);   // (UpdateNormalAndDepth alone reads no descriptors)
-        else okey.resize(std::max<size_t>(total, 1) * 3);
+        if (!keyed) odesc.resize(do_desc ? std::max<size_t>(dtotal, 1) * 32 : 32);   // (UpdateNormalAndDepth alone reads no descriptors)
+        else okey.resize(std::max<size_t>(dtotal, 1) * 3);
         oOw.resize(std::max<size_t>(total, 1) * 3);
         pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
-        // ComputeDistinctiveDescriptors skips bad keyframes (src/MapPoint.cc:362-368), UpdateNormalAndDepth does not: a culled keyframe has
-        // already erased its observations (KeyFrame::SetBadFlag), so both see the same list.
         const int chunk = 256, nchunks = (P + chunk - 1) / chunk;
         c.pool->parallel_for(nchunks, [&](int ch) {
             const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
@@ -314,12 +324,15 @@ struct MpUpdate {
                 const Map& m = c.seq[items[i].seq]->map;
                 const MapPt& p = m.mps[items[i].p];
                 const int n = start[i + 1] - start[i];
-                size_t at = (size_t)start[i];
+                size_t at = (size_t)start[i], dat = (size_t)dstart[i];
                 if (n > 0)
                     for (auto& e : p.obs) {
                         const KeyFrm& k = m.kfs[e.first];
-                        if (keyed) { okey[at * 3] = items[i].seq; okey[at * 3 + 1] = e.first; okey[at * 3 + 2] = e.second; }
-                        else if (do_desc) memcpy(&odesc[at * 32], &k.desc[(size_t)e.second * 32], 32);
+                        if (do_desc && !k.bad) {
+                            if (keyed) { okey[dat * 3] = items[i].seq; okey[dat * 3 + 1] = e.first; okey[dat * 3 + 2] = e.second; }
+                            else memcpy(&odesc[dat * 32], &k.desc[(size_t)e.second * 32], 32);
+                            dat++;
+                        }
                         oOw[at * 3] = k.pose.Ow[0]; oOw[at * 3 + 1] = k.pose.Ow[1]; oOw[at * 3 + 2] = k.pose.Ow[2];
                         at++;
                     }
@@ -340,6 +353,7 @@ struct MpUpdate {
         oslam_job_mp_update_t j;
         j.P = P; j.obs_start = start.data(); j.obs_desc = keyed ? nullptr : odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
         j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
+        j.desc_start = split ? dstart.data() : nullptr;
         const int rc = keyed ? c.ops.mp_update_keyed(c.ops.ctx, &j, okey.data()) : c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
         // (an item can be listed twice after fusions; both copies carry the same result, so concurrent writers store the same bytes)
@@ -348,7 +362,7 @@ struct MpUpdate {
             for (int i = i0; i < i1; i++) {
                 if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
                 MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
-                if (do_desc) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);
+                if (do_desc && dstart[i + 1] > dstart[i]) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);   // every observing keyframe bad: the descriptor stays (:370-371)
                 if (do_normal) {
                     const float* o = &out5[(size_t)i * 5];
                     p.normal[0] = o[0]; p.normal[1] = o[1]; p.normal[2] = o[2]; p.maxD = o[3]; p.minD = o[4];
@@ -1750,6 +1764,12 @@ int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_K
     if (!h) { oslam::set_error("oslam_slam_kernel_times: bad argument"); return OSLAM_E_INVALID; }
     if (!h->c.ops.kernel_times) { oslam::set_error("oslam_slam_kernel_times: this operator table has no device timing"); return OSLAM_E_INVALID; }
     return h->c.ops.kernel_times(h->c.ops.ctx, enable, out);
+}
+
+int oslam_slam_bad_keyframe_observations(oslam_slam_t* h, int64_t* out) {
+    if (!h || !out) { oslam::set_error("oslam_slam_bad_keyframe_observations: bad argument"); return OSLAM_E_INVALID; }
+    *out = h->c.badKFObs.load();
+    return OSLAM_OK;
 }
 
 int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]) {

@@ -682,40 +682,44 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     const size_t P = j->P;
     if (P == 0) return OSLAM_OK;
     const size_t total = (size_t)j->obs_start[P];
+    // the descriptor selection has its own observation list when some observations sit in culled keyframes (oslam_job_mp_update_t::desc_start)
+    const int32_t* dstart = j->desc_start ? j->desc_start : j->obs_start;
+    const size_t dtotal = (size_t)dstart[P];
     Layout L;
     // with resident keyframes the observations' descriptors are gathered on the device from (record, keypoint) pairs: 8 bytes per observation travel
     // instead of 32, and the caller did not have to collect them
     std::vector<int32_t> rec;
-    bool keyed = obs_key && j->do_desc && total > 0;
+    bool keyed = obs_key && j->do_desc && dtotal > 0;
     if (keyed) {
-        rec.resize(2 * total);
-        for (size_t e = 0; e < total && keyed; e++) {
+        rec.resize(2 * dtotal);
+        for (size_t e = 0; e < dtotal && keyed; e++) {
             const int r = o->rec_lookup(obs_key[3 * e], obs_key[3 * e + 1]);
             if (r < 0 || obs_key[3 * e + 2] < 0 || obs_key[3 * e + 2] >= o->cap) keyed = false;
             rec[2 * e] = r; rec[2 * e + 1] = obs_key[3 * e + 2];
         }
         if (!keyed && !j->obs_desc) { oslam::set_error("mp_update: observation of a keyframe that is not resident"); return OSLAM_E_INVALID; }
     }
-    const size_t oStart = L.take(4 * (P + 1)), oRec = L.take(keyed ? 8 * total : 0), oOw = L.take(12 * total), oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P),
-                 oDescUp = L.take(keyed ? 0 : 32 * total);
+    const size_t oStart = L.take(4 * (P + 1)), oDStart = L.take(j->desc_start ? 4 * (P + 1) : 0), oRec = L.take(keyed ? 8 * dtotal : 0), oOw = L.take(12 * total),
+                 oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P), oDescUp = L.take(keyed ? 0 : 32 * dtotal);
     const size_t in_bytes = L.off;
-    const size_t oDesc = keyed ? L.take(32 * total) : oDescUp;
+    const size_t oDesc = keyed ? L.take(32 * dtotal) : oDescUp;
     const size_t oBest = L.take(4 * P), oOut = L.take(32 * P), oOut5 = L.take(20 * P);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     uint8_t* Dv = o->up_d;
     memcpy(U + oStart, j->obs_start, 4 * (P + 1));
-    if (keyed) memcpy(U + oRec, rec.data(), 8 * total);
-    else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * total);
+    if (j->desc_start) memcpy(U + oDStart, j->desc_start, 4 * (P + 1));
+    if (keyed) memcpy(U + oRec, rec.data(), 8 * dtotal);
+    else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * dtotal);
     if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
-    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)total, Dv + oDesc, o->strm));
+    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)dtotal, Dv + oDesc, o->strm));
     Layout R;
     const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
     OPS_CHECK(o->ensure_dn(R.off));
     if (j->do_desc) {
         OSLAM_HIP_CHECK(hipMemsetAsync(Dv + oOut, 0, 32 * P, o->strm));
-        OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(Dv + oStart), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
+        OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rBest, Dv + oBest, 4 * P, hipMemcpyDeviceToHost, o->strm));
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut, Dv + oOut, 32 * P, hipMemcpyDeviceToHost, o->strm));
     }

@@ -239,6 +239,12 @@ class System:
         check(self.L.oslam_slam_kernel_times(self.h, C.c_int(1 if enable else 0), ptr(out)))
         return {g: dict(ms=out[3 * i], launches=out[3 * i + 1], work=out[3 * i + 2]) for i, g in enumerate(self.KT_GROUPS)}
 
+    def bad_keyframe_observations(self):
+        """Observations in culled keyframes that ComputeDistinctiveDescriptors left out (include/oslam_slam.h)."""
+        out = C.c_int64(0)
+        check(self.L.oslam_slam_bad_keyframe_observations(self.h, C.byref(out)))
+        return int(out.value)
+
     def local_map_reuse(self):
         """(frames whose local map was reused from the previous frame, tracked frames) summed over the handle's sequences."""
         out = np.zeros(2, np.int64)

@@ -487,9 +487,12 @@ class Slam:
                 continue
             obs = pMP.obs_sorted()
             if do_desc:
-                d = np.stack([k.mDescriptors[i] for k, i in obs])
-                b = O.distinctive_descriptor(d)
-                pMP.mDescriptor = d[b].copy()
+                good = [(k, i) for k, i in obs if not k.mbBad]      # `if(!pKF->isBad())` (src/MapPoint.cc:366); none left: the descriptor stays (:370-371)
+                self.bad_kf_observations = getattr(self, "bad_kf_observations", 0) + len(obs) - len(good)
+                if good:
+                    d = np.stack([k.mDescriptors[i] for k, i in good])
+                    b = O.distinctive_descriptor(d)
+                    pMP.mDescriptor = d[b].copy()
             if do_normal:
                 Ow = np.stack([k.pose.Ow for k, _ in obs])
                 ref = pMP.mpRefKF

@@ -200,10 +200,12 @@ int o_mp_update(void* p, oslam_job_mp_update_t* j) {
     OCtx* o = (OCtx*)p;
     for (int i = 0; i < j->P; i++) {
         const int s = j->obs_start[i], n = j->obs_start[i + 1] - s;
-        if (j->do_desc) {
-            const int b = n > 0 ? oo_distinctive_descriptor(n, j->obs_desc + (size_t)s * 32) : -1;
+        if (j->do_desc) {   // over the observations in keyframes that are not bad (src/MapPoint.cc:362-368): their own CSR when the caller gives one
+            const int32_t* ds = j->desc_start ? j->desc_start : j->obs_start;
+            const int s2 = ds[i], n2 = ds[i + 1] - s2;
+            const int b = n2 > 0 ? oo_distinctive_descriptor(n2, j->obs_desc + (size_t)s2 * 32) : -1;
             j->best_idx[i] = b;
-            if (b >= 0) memcpy(j->out_desc + (size_t)i * 32, j->obs_desc + (size_t)(s + b) * 32, 32);
+            if (b >= 0) memcpy(j->out_desc + (size_t)i * 32, j->obs_desc + (size_t)(s2 + b) * 32, 32);
             else memset(j->out_desc + (size_t)i * 32, 0, 32);
         }
         if (j->do_normal && n > 0)

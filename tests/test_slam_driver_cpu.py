@@ -188,6 +188,9 @@ def test_keyframe_culling_against_independent_restatement(oracle):
     assert np.array_equal(Twc, np.stack([x[1] for x in tr]))
     sk, Tk = sysm.keyframe_trajectory(0)
     assert len(sk) == a["keyframes_in_map"]
+    # observations that survive in culled keyframes are left out of ComputeDistinctiveDescriptors (src/MapPoint.cc:366) by both drivers
+    assert sysm.bad_keyframe_observations() == getattr(ref, "bad_kf_observations", 0)
+    print("observations in culled keyframes skipped:", sysm.bad_keyframe_observations())
 
 
 def test_stereo_driver_against_independent_restatement(oracle):
@@ -236,3 +239,28 @@ def test_semantic_tracking_against_independent_restatement(oracle):
     assert a["object2ds"] == 3 * n
     assert diff > 1e-5, diff
     assert plain.stats(0)["semantic_edges"] == 0
+
+
+def test_observations_in_culled_keyframes_against_independent_restatement(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors skips observations whose keyframe is bad (reference src/MapPoint.cc:366) while UpdateNormalAndDepth reads
+    all of them (:441-453).  Such observations exist: two new points triangulated against the same neighbour keypoint both observe it, the keypoint's slot
+    belongs to the second (src/LocalMapping.cc:440-446), and KeyFrame::SetBadFlag later erases only the observations of the keyframe's own mvpMapPoints.
+    On this 3-D scene stream the case occurs from frame 103 on: the C++ driver and the independent restatement must count the same skipped observations
+    and stay bit-identical through it."""
+    from oracle import slam_driver_oracle as R
+    from object_slam_amd import scene
+    n = 108
+    q = scene.make_rgbd_sequence(2, n, speed=2.0, with_masks=False)
+    cfg = slam.make_config(W, H, 1)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    ref = R.Slam(_cfg_dict(cfg))
+    for t in range(n):
+        T, st = sysm.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0])
+        Tr, sr = ref.Track((q["gray"][t], q["depth"][t]), t / 30.0)
+        assert int(st[0]) == sr, t
+        assert np.array_equal(T[0], Tr), (t, np.abs(T[0] - Tr).max())
+    a, b = sysm.stats(0), ref.stats()
+    assert all(a[k] == b[k] for k in b), (a, b)
+    assert a["keyframes_culled"] >= 1 and a["map_violations"] == 0
+    nb = sysm.bad_keyframe_observations()
+    assert nb > 0 and nb == getattr(ref, "bad_kf_observations", 0), (nb, getattr(ref, "bad_kf_observations", 0))

@@ -308,3 +308,5 @@ def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle):
     assert np.abs(ph - po).max() < 4e-4, np.abs(ph - po).max()
     ah, _ = ate_scene(hip, [q], 0)
     assert ah < 0.02, ah
+    # the run reaches observations in culled keyframes (left out of ComputeDistinctiveDescriptors, reference src/MapPoint.cc:366): both tables saw the same
+    assert hip.bad_keyframe_observations() == ora.bad_keyframe_observations() > 0
