@@ -11,7 +11,10 @@ def run(S, G, steps):
     wl = seqbench.rgbd_workload(n_base=16, stagger=12)
     warm = 4
     seqs = seqbench.base_sequences(wl, 0, S, warm + steps, workers=16)            # forked workers, before the GPU is touched
-    pcs = ctypes.CDLL(os.path.join(ROOT, "tools", "pcsample", "libpcsample.so"))
+    so = os.path.join(ROOT, "tools", "pcsample", "libpcsample.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tools", "pcsample", "pcsample.c"), "-lrt"])
+    pcs = ctypes.CDLL(so)
     share = min(16, os.cpu_count() or 1)
     summ, rec, systems, _ = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), 0, 1, S, G, steps, warm, True, 0, host_threads=max(1, share // G),
                                               sequences=seqs, after_warmup=lambda systems: pcs.pcs_start(997))
