@@ -448,6 +448,12 @@ int oslam_mp_distinctive_descriptors(oslam_mappoint_t* h, int P, const int32_t* 
 int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*[P][3]*/, const int32_t* obs_start, const float* obs_Ow /*[total][3]*/,
                                  const float* OwRef /*[P][3]*/, const float* levelScaleFactor /*[P]*/, float lastScaleFactor, float* out /*[P][5]*/);
 
+/* Resident map-point table: d_tab[slot] = device array of 64-byte records indexed by map-point id — float pos[3], normal[3], minDistance, maxDistance, then the
+ * 32 descriptor bytes (mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance, mDescriptor of include/MapPoint.h:116-141).  After a MapPoint update of P points
+ * (the two functions below) this writes its results into the records d_items[i] = (slot, id): position (d_Pos) + normal / distances (d_out5) when do_normal,
+ * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; points without observations keep their record. */
+int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
+                                const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream);
 /* device-pointer forms (asynchronous on `stream`); d_out_desc rows of points without observations are left untouched (zero-fill them first) */
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream);
 int oslam_mp_update_normal_depth_device(int P, const float* d_Pos, const int32_t* d_obs_start, const float* d_obs_Ow, const float* d_OwRef,

@@ -122,6 +122,9 @@ typedef struct oslam_job_mp_update {       /* MapPoint::ComputeDistinctiveDescri
     int32_t P; const int32_t* obs_start; const uint8_t* obs_desc; const float* obs_Ow;
     const float* Pos; const float* OwRef; const float* levelScaleFactor;
     int32_t do_desc, do_normal;
+    const int32_t* items;                  /* [P][2] or NULL: (slot, map-point id) of every point — a table that keeps the map points resident (position,
+                                            * normal, distances, descriptor) writes the results into their records; every change of those fields goes
+                                            * through this job (new points, local BA, fusions), so the records always equal the host's */
     const int32_t* desc_start;             /* [P + 1] or NULL (= obs_start): CSR of the observations whose keyframe is NOT bad, the only ones
                                             * ComputeDistinctiveDescriptors uses (src/MapPoint.cc:362-368; UpdateNormalAndDepth uses all of them, :441-453).
                                             * obs_desc — and the keys of mp_update_keyed — follow THIS layout, obs_Ow follows obs_start.  A point whose
@@ -212,6 +215,8 @@ typedef struct oslam_slam_ops {
      * on ties.  counts[i] descriptors of keyframe i -> out[i][0 .. counts[i]). */
     int (*bow_nodes_keyed)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids, const uint64_t* top /* [10][4] */, const uint64_t* sub /* [10][10][4] */,
                            const int32_t* counts, uint32_t* const* out);
+    /* optional test hook of tables with resident map points: the 64-byte record of point `id` of `slot` (see oslam_job_mp_update_t::items) */
+    int (*point_record)(void* ctx, int slot, int id, uint8_t out[64]);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
@@ -265,6 +270,10 @@ int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]);
  * sequences and calls: such observations exist when two new points triangulate against the same neighbour keypoint (the second AddMapPoint wins,
  * src/LocalMapping.cc:440-446) and the neighbour is culled later (its SetBadFlag only erases the observations of its own mvpMapPoints). */
 int oslam_slam_bad_keyframe_observations(oslam_slam_t* h, int64_t* out);
+/* Test hook: host[64] = position, normal, minimum / maximum distance and descriptor of map point `id` of sequence `seq` as the driver holds them, resident[64] =
+ * the operator table's record of the same point (OSLAM_E_INVALID if the table keeps none); *bad = the point's mbBad.  The two must be equal for every
+ * point that is not bad and has observations. */
+int oslam_slam_debug_point(oslam_slam_t* h, int seq, int id, uint8_t host[64], uint8_t resident[64], int32_t* bad);
 /* Device time of the kernel groups of the HIP operator table, measured with HIP events on the stream each group is launched on
  * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:
  * out[3g] = milliseconds, out[3g+1] = kernel launches, out[3g+2] = algorithmic work of those launches — bytes for group 0 (SURVEY.md

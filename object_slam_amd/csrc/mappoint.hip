@@ -265,6 +265,31 @@ int oslam_mp_distinctive_descriptors(oslam_mappoint_t* h, int P, const int32_t* 
 
 // Device-pointer forms of the two MapPoint updates (everything in HBM, asynchronous on `stream`): the batch-of-sequences driver packs the touched
 // points of all sequences into one block.  d_out_desc must be zero-filled by the caller for points without observations (best_idx = -1).
+// Resident map-point table (see oslam_hip.h): the results of a MapPoint update are written into the 64-byte records of the points they belong to
+__global__ __launch_bounds__(256) void k_mp_table_write(int P, const int32_t* items, uint8_t* const* tab, const int32_t* obs_start, const int32_t* desc_start,
+                                                        const float* Pos, const float* out5, const uint8_t* out_desc, int do_desc, int do_normal) {
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (i >= P) return;
+    if (obs_start[i + 1] == obs_start[i]) return;   // no observations: both methods return early, the record stays
+    uint32_t* rec = (uint32_t*)(tab[items[2 * i]] + (size_t)items[2 * i + 1] * 64);
+    if (do_normal) {   // words 0-2 position, 3-5 normal, 6 minimum distance, 7 maximum distance
+        const uint32_t* ps = (const uint32_t*)(Pos + (size_t)i * 3);
+        const uint32_t* o5 = (const uint32_t*)(out5 + (size_t)i * 5);
+        rec[part] = part < 3 ? ps[part] : part < 6 ? o5[part - 3] : part == 6 ? o5[4] : o5[3];
+    }
+    if (do_desc && desc_start[i + 1] > desc_start[i]) rec[8 + part] = ((const uint32_t*)(out_desc + (size_t)i * 32))[part];   // (every observing keyframe bad: it stays)
+}
+
+int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
+                                const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream) {
+    if (P < 0 || (P > 0 && (!d_items || !d_tab || !d_obs_start || !d_desc_start || (do_normal && (!d_Pos || !d_out5)) || (do_desc && !d_out_desc)))) { set_error("mp_table_write: bad argument"); return OSLAM_E_INVALID; }
+    if (P == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_mp_table_write, dim3(div_up(P, 32)), dim3(256), 0, (hipStream_t)stream, P, d_items, d_tab, d_obs_start, d_desc_start, d_Pos, d_out5, d_out_desc,
+                       do_desc, do_normal);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream) {
     if (P < 0 || (P > 0 && (!d_obs_start || !d_obs_desc || !d_best_idx || !d_out_desc))) { set_error("bad argument"); return OSLAM_E_INVALID; }
     if (P == 0) return OSLAM_OK;

@@ -285,6 +285,7 @@ struct MpUpdate {
     void clear() { items.clear(); }
     void add(int seq, int p) { items.push_back({seq, p}); }
     std::vector<int> dstart;
+    std::vector<int32_t> ikey;
     int run(Ctx& c, bool do_desc, bool do_normal) {
         const int P = (int)items.size();
         if (P == 0) return OSLAM_OK;
@@ -354,6 +355,9 @@ struct MpUpdate {
         j.P = P; j.obs_start = start.data(); j.obs_desc = keyed ? nullptr : odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
         j.levelScaleFactor = lsf.data(); j.do_desc = do_desc; j.do_normal = do_normal; j.best_idx = best.data(); j.out_desc = outdesc.data(); j.out5 = out5.data();
         j.desc_start = split ? dstart.data() : nullptr;
+        ikey.resize((size_t)P * 2);
+        for (int i = 0; i < P; i++) { ikey[2 * (size_t)i] = items[i].seq; ikey[2 * (size_t)i + 1] = items[i].p; }
+        j.items = ikey.data();
         const int rc = keyed ? c.ops.mp_update_keyed(c.ops.ctx, &j, okey.data()) : c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
         // (an item can be listed twice after fusions; both copies carry the same result, so concurrent writers store the same bytes)
@@ -1764,6 +1768,18 @@ int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_K
     if (!h) { oslam::set_error("oslam_slam_kernel_times: bad argument"); return OSLAM_E_INVALID; }
     if (!h->c.ops.kernel_times) { oslam::set_error("oslam_slam_kernel_times: this operator table has no device timing"); return OSLAM_E_INVALID; }
     return h->c.ops.kernel_times(h->c.ops.ctx, enable, out);
+}
+
+int oslam_slam_debug_point(oslam_slam_t* h, int seq, int id, uint8_t host[64], uint8_t resident[64], int32_t* bad) {
+    if (!h || !host || !resident || !bad || seq < 0 || seq >= h->c.S) { oslam::set_error("oslam_slam_debug_point: bad argument"); return OSLAM_E_INVALID; }
+    const Map& m = h->c.seq[seq]->map;
+    if (id < 0 || id >= (int)m.mps.size()) { oslam::set_error("oslam_slam_debug_point: no such point"); return OSLAM_E_INVALID; }
+    const MapPt& p = m.mps[id];
+    static_assert(offsetof(MapPt, desc) == 32 && offsetof(MapPt, minD) == 24, "the first 64 bytes of MapPt are the resident record");
+    memcpy(host, &p, 64);
+    *bad = p.bad || p.obs.empty();
+    if (!h->c.ops.point_record) { oslam::set_error("oslam_slam_debug_point: the operator table keeps no resident map points"); return OSLAM_E_INVALID; }
+    return h->c.ops.point_record(h->c.ops.ctx, seq, id, resident);
 }
 
 int oslam_slam_bad_keyframe_observations(oslam_slam_t* h, int64_t* out) {

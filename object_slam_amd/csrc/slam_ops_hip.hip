@@ -80,6 +80,32 @@ struct HipOps {
     const uint8_t* rec_desc(int r) const { return rec_ptr(r) + oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256); }
     const float* rec_ur(int r) const { return (const float*)(rec_desc(r) + oslam::align_up((size_t)cap * 32, 256)); }
     int rec_lookup(int slot, int kf) const { return (slot >= 0 && slot < (int)rec_of_kf.size() && kf >= 0 && kf < (int)rec_of_kf[slot].size()) ? rec_of_kf[slot][kf] : -1; }
+    // Resident map points: one growing array of 64-byte records per slot (position, normal, distances, descriptor), written by every MapPoint update
+    std::vector<uint8_t*> mp_tab; std::vector<size_t> mp_cap;   // [S] device arrays and their capacity in records
+    uint8_t** d_mp_tab = nullptr;                               // [S] device copy of the pointers
+    bool mp_tab_on = true, mp_tab_dirty = true;
+    int ensure_mp_records(int slot, size_t need) {
+        if ((int)mp_tab.size() < S) { mp_tab.resize(S, nullptr); mp_cap.resize(S, 0); }
+        if (need <= mp_cap[slot]) return OSLAM_OK;
+        const size_t ncap = std::max<size_t>(need + need / 2, 4096);
+        uint8_t* nb = nullptr;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&nb, ncap * 64));
+        if (mp_tab[slot]) {
+            OSLAM_HIP_CHECK(hipMemcpyAsync(nb, mp_tab[slot], mp_cap[slot] * 64, hipMemcpyDeviceToDevice, strm));
+            OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+            (void)hipFree(mp_tab[slot]);
+        }
+        mp_tab[slot] = nb; mp_cap[slot] = ncap; mp_tab_dirty = true;
+        return OSLAM_OK;
+    }
+    int sync_mp_table() {   // the device pointer table follows the host's
+        if (!mp_tab_dirty) return OSLAM_OK;
+        if (!d_mp_tab) OSLAM_HIP_CHECK(hipMalloc((void**)&d_mp_tab, sizeof(uint8_t*) * (size_t)S));
+        OSLAM_HIP_CHECK(hipMemcpyAsync(d_mp_tab, mp_tab.data(), sizeof(uint8_t*) * (size_t)S, hipMemcpyHostToDevice, strm));
+        OSLAM_HIP_CHECK(hipStreamSynchronize(strm));   // (mp_tab is pageable host memory: the copy must have read it before it can change again)
+        mp_tab_dirty = false;
+        return OSLAM_OK;
+    }
     uint8_t* d_maskstage = nullptr; size_t mask_cap = 0;  // host masks of a stage, packed H x W
     // One-bit-per-pixel form of the step's masks (oslam_mask_bits_device), built by object_kps and reused by pose_opt2 of the SAME step: keyed by the
     // caller's mask pointer, valid while step_epoch (advanced by every Frame::Frame stage) equals bits_epoch
@@ -699,6 +725,18 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
         }
         if (!keyed && !j->obs_desc) { oslam::set_error("mp_update: observation of a keyframe that is not resident"); return OSLAM_E_INVALID; }
     }
+    const bool table = o->mp_tab_on && j->items != nullptr;
+    if (table) {   // room for the records of the points named (ids grow with the map)
+        std::vector<int> mx(o->S, -1);
+        for (size_t i = 0; i < P; i++) {
+            const int sl = j->items[2 * i], id = j->items[2 * i + 1];
+            if (sl < 0 || sl >= o->S || id < 0) { oslam::set_error("mp_update: bad item"); return OSLAM_E_INVALID; }
+            mx[sl] = std::max(mx[sl], id);
+        }
+        for (int sl = 0; sl < o->S; sl++) if (mx[sl] >= 0) OPS_CHECK(o->ensure_mp_records(sl, (size_t)mx[sl] + 1));
+        OPS_CHECK(o->sync_mp_table());
+    }
+    const size_t oItems = L.take(table ? 8 * P : 0);
     const size_t oStart = L.take(4 * (P + 1)), oDStart = L.take(j->desc_start ? 4 * (P + 1) : 0), oRec = L.take(keyed ? 8 * dtotal : 0), oOw = L.take(12 * total),
                  oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P), oDescUp = L.take(keyed ? 0 : 32 * dtotal);
     const size_t in_bytes = L.off;
@@ -708,6 +746,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     uint8_t* U = o->up_h;
     uint8_t* Dv = o->up_d;
     memcpy(U + oStart, j->obs_start, 4 * (P + 1));
+    if (table) memcpy(U + oItems, j->items, 8 * P);
     if (j->desc_start) memcpy(U + oDStart, j->desc_start, 4 * (P + 1));
     if (keyed) memcpy(U + oRec, rec.data(), 8 * dtotal);
     else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * dtotal);
@@ -728,6 +767,9 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
                                                       (const float*)(Dv + oLsf), o->scale[o->cfg.nLevels - 1], (float*)(Dv + oOut5), o->strm));
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut5, Dv + oOut5, 20 * P, hipMemcpyDeviceToHost, o->strm));
     }
+    if (table)
+        OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(Dv + oItems), o->d_mp_tab, (const int32_t*)(Dv + oStart), (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)),
+                                              (const float*)(Dv + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
     if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
     if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
@@ -823,6 +865,15 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
                                    hipMemcpyHostToDevice, o->strm));
     o->rec_desc_n = o->n_rec;
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
+    return OSLAM_OK;
+}
+
+int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (slot < 0 || slot >= (int)o->mp_tab.size() || id < 0 || (size_t)id >= o->mp_cap[slot]) { oslam::set_error("point_record: no such record"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(hipMemcpy(out, o->mp_tab[slot] + (size_t)id * 64, 64, hipMemcpyDeviceToHost));
     return OSLAM_OK;
 }
 
@@ -995,6 +1046,8 @@ void h_destroy(void* p) {
     if (o->dn_h) (void)hipHostFree(o->dn_h);
     for (uint8_t* c : o->rec_chunks) (void)hipFree(c);
     if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
+    for (uint8_t* q : o->mp_tab) if (q) (void)hipFree(q);
+    (void)hipFree(o->d_mp_tab);
     (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
@@ -1060,6 +1113,8 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
+    o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
+    if (o->mp_tab_on) ops->point_record = h_point_record;
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed; }
     return OSLAM_OK;

@@ -22,7 +22,7 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "point_record")]
 
 
 class SlamObjects(C.Structure):
@@ -238,6 +238,12 @@ class System:
         out = np.zeros(len(self.KT_GROUPS) * 3, np.float64)
         check(self.L.oslam_slam_kernel_times(self.h, C.c_int(1 if enable else 0), ptr(out)))
         return {g: dict(ms=out[3 * i], launches=out[3 * i + 1], work=out[3 * i + 2]) for i, g in enumerate(self.KT_GROUPS)}
+
+    def debug_point(self, seq, pid):
+        """Test hook: (host record[64], resident record[64], bad) of map point `pid` (include/oslam_slam.h)."""
+        a, b, bad = np.zeros(64, np.uint8), np.zeros(64, np.uint8), C.c_int32(0)
+        check(self.L.oslam_slam_debug_point(self.h, seq, pid, ptr(a), ptr(b), C.byref(bad)))
+        return a, b, bool(bad.value)
 
     def bad_keyframe_observations(self):
         """Observations in culled keyframes that ComputeDistinctiveDescriptors left out (include/oslam_slam.h)."""

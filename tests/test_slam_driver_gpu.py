@@ -271,6 +271,27 @@ def test_lost_and_reset_on_one_slot_matches_oracle_driver(oracle):
     assert len(hip.trajectory(0)[0]) == n - 9           # the trajectory of the new map only
 
 
+def test_resident_map_point_records_equal_the_host_map():
+    """The HIP table keeps a 64-byte record per map point (position, normal, distances, descriptor) that every MapPoint update writes.  After a run with
+    keyframe insertions, triangulation, fusions, local BA and cullings the record of EVERY point that is alive must equal the driver's host copy bit for bit."""
+    from slam_common import make_scene_streams, run_scene
+    n = 40
+    seqs = make_scene_streams(2, n, speed=2.0)
+    hip = slam.System(slam.make_config(W, H, 2))
+    run_scene(hip, seqs, n)
+    for s in range(2):
+        st = hip.stats(s)
+        assert st["local_bas"] >= 3 and st["points_fused"] > 0 and st["points_triangulated"] > 0
+        checked = 0
+        for pid in range(st["points_created"]):
+            host, res, bad = hip.debug_point(s, pid)
+            if bad:
+                continue
+            assert np.array_equal(host, res), (s, pid, host.view(np.float32)[:8], res.view(np.float32)[:8])
+            checked += 1
+        assert checked >= st["points_in_map"] > 500
+
+
 def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
     """The HIP table keeps the packed SearchLocalPoints arrays of every slot and the keyframes' arrays resident in HBM (content ids / keyed operators);
     with both switched off it uploads the host arrays of every job as the oracle table receives them.  The two runs must be bit-identical, and the
