@@ -454,6 +454,12 @@ int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*
  * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; points without observations keep their record. */
 int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
                                 const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream);
+/* Inputs of Optimizer::PoseOptimization (src/Optimizer.cc:258-340) for a batch of frames that are still on the device: frame b is frame d_slots[b] of the
+ * keypoint arrays d_keysUn / d_uRight ([.][kp_stride]) with d_n[b] keypoints; d_ids[b][i] = map point of keypoint i (record of d_tab[d_slots[b]]) or -1.
+ * Writes Xw, obs = (x, y, uRight), invSigma2 = invLevelSigma2[octave] and has_mp in the [batch][stride] layout of oslam_pose_optimize_batch_device. */
+int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slots, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab,
+                                    const oslam_keypoint_t* d_keysUn, const float* d_uRight, int kp_stride, const float* invLevelSigma2, int nLevels,
+                                    float* d_Xw, float* d_obs, float* d_invSigma2, uint8_t* d_has_mp, void* stream);
 /* device-pointer forms (asynchronous on `stream`); d_out_desc rows of points without observations are left untouched (zero-fill them first) */
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream);
 int oslam_mp_update_normal_depth_device(int P, const float* d_Pos, const int32_t* d_obs_start, const float* d_obs_Ow, const float* d_OwRef,

@@ -116,6 +116,9 @@ typedef struct oslam_job_pose {            /* Optimizer::PoseOptimization, src/O
     int32_t slot; int32_t N; float Tcw_in[16];
     const float* Xw; const float* obs; const float* invSigma2; const uint8_t* has_mp;
     float Tcw_out[16]; uint8_t* outlier; int32_t n_inliers;   /* out */
+    const int32_t* mp_ids;                 /* [N] map-point id of every keypoint of the slot's CURRENT frame or -1 (mvpMapPoints), or NULL.  A table that
+                                            * answers resident_points() reads the positions from its records and obs / invSigma2 from the frame it still
+                                            * holds; the four arrays above may then be NULL.  Other tables get the arrays and ignore this field. */
 } oslam_job_pose_t;
 
 typedef struct oslam_job_mp_update {       /* MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over P points (CSR observations) */
@@ -215,6 +218,8 @@ typedef struct oslam_slam_ops {
      * on ties.  counts[i] descriptors of keyframe i -> out[i][0 .. counts[i]). */
     int (*bow_nodes_keyed)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids, const uint64_t* top /* [10][4] */, const uint64_t* sub /* [10][10][4] */,
                            const int32_t* counts, uint32_t* const* out);
+    /* optional: != 0 if the table keeps the map points resident (oslam_job_mp_update_t::items) and serves pose jobs from mp_ids */
+    int (*resident_points)(void* ctx);
     /* optional test hook of tables with resident map points: the 64-byte record of point `id` of `slot` (see oslam_job_mp_update_t::items) */
     int (*point_record)(void* ctx, int slot, int id, uint8_t out[64]);
 } oslam_slam_ops_t;

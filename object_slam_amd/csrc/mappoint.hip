@@ -280,6 +280,36 @@ __global__ __launch_bounds__(256) void k_mp_table_write(int P, const int32_t* it
     if (do_desc && desc_start[i + 1] > desc_start[i]) rec[8 + part] = ((const uint32_t*)(out_desc + (size_t)i * 32))[part];   // (every observing keyframe bad: it stays)
 }
 
+struct InvSigma { float v[OSLAM_MAX_LEVELS]; };
+__global__ __launch_bounds__(256) void k_pose_inputs(int stride, const int32_t* slots, const int32_t* n, const int32_t* ids, uint8_t* const* tab, const oslam_keypoint_t* keysUn,
+                                                     const float* uRight, int kp_stride, InvSigma inv, float* Xw, float* obs, float* invS, uint8_t* has) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n[b]) return;
+    const int slot = slots[b];
+    const size_t at = (size_t)b * stride + i, src = (size_t)slot * kp_stride + i;
+    const oslam_keypoint_t kp = keysUn[src];
+    obs[at * 3] = kp.x; obs[at * 3 + 1] = kp.y; obs[at * 3 + 2] = uRight[src];
+    invS[at] = inv.v[kp.octave];
+    const int id = ids[at];
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (id >= 0) { const float* r = (const float*)(tab[slot] + (size_t)id * 64); x = r[0]; y = r[1]; z = r[2]; }
+    Xw[at * 3] = x; Xw[at * 3 + 1] = y; Xw[at * 3 + 2] = z;
+    has[at] = id >= 0;
+}
+
+int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slots, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab,
+                                    const oslam_keypoint_t* d_keysUn, const float* d_uRight, int kp_stride, const float* invLevelSigma2, int nLevels,
+                                    float* d_Xw, float* d_obs, float* d_invSigma2, uint8_t* d_has_mp, void* stream) {
+    if (batch < 1 || stride < 1 || kp_stride < 1 || !d_slots || !d_n || !d_ids || !d_tab || !d_keysUn || !d_uRight || !invLevelSigma2 || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS ||
+        !d_Xw || !d_obs || !d_invSigma2 || !d_has_mp) { set_error("pose_inputs_gather: bad argument"); return OSLAM_E_INVALID; }
+    InvSigma inv;
+    for (int l = 0; l < OSLAM_MAX_LEVELS; l++) inv.v[l] = l < nLevels ? invLevelSigma2[l] : 0.f;
+    hipLaunchKernelGGL(k_pose_inputs, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, stride, d_slots, d_n, d_ids, d_tab, d_keysUn, d_uRight, kp_stride, inv,
+                       d_Xw, d_obs, d_invSigma2, d_has_mp);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
                                 const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream) {
     if (P < 0 || (P > 0 && (!d_items || !d_tab || !d_obs_start || !d_desc_start || (do_normal && (!d_Pos || !d_out5)) || (do_desc && !d_out_desc)))) { set_error("mp_table_write: bad argument"); return OSLAM_E_INVALID; }

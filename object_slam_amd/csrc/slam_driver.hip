@@ -204,6 +204,7 @@ struct Ctx {
     };
     std::vector<Win> winPool;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
+    bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
     std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
     std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
     long long next_content_id() { return contentCounter.fetch_add(1, std::memory_order_relaxed) + 1; }
@@ -482,6 +483,15 @@ static void update_local_map(Seq& s) {
 static void fill_pose_job(Ctx& c, Seq& s, int si, oslam_job_pose_t& j) {
     Frame& f = *s.cur;
     const int N = f.N;
+    if (c.residentPts) {   // the table reads the map points' positions from its records and the keypoints from the frame it still holds: nothing to gather
+        s.jOutlier.assign(N, 0);
+        j.slot = si; j.N = N;
+        memcpy(j.Tcw_in, f.pose.Tcw.m, 64);
+        j.Xw = nullptr; j.obs = nullptr; j.invSigma2 = nullptr; j.has_mp = nullptr; j.mp_ids = f.mp.data();
+        j.outlier = s.jOutlier.data(); j.n_inliers = 0;
+        memcpy(j.Tcw_out, f.pose.Tcw.m, 64);
+        return;
+    }
     s.jXw.assign((size_t)N * 3, 0.f); s.jObs.resize((size_t)N * 3); s.jInv.resize(N); s.jHas.assign(N, 0); s.jOutlier.assign(N, 0);
     for (int i = 0; i < N; i++) {
         prefetch_ahead(s.map.mps, f.mp, i, N);
@@ -496,7 +506,7 @@ static void fill_pose_job(Ctx& c, Seq& s, int si, oslam_job_pose_t& j) {
     }
     j.slot = si; j.N = N;
     memcpy(j.Tcw_in, f.pose.Tcw.m, 64);
-    j.Xw = s.jXw.data(); j.obs = s.jObs.data(); j.invSigma2 = s.jInv.data(); j.has_mp = s.jHas.data();
+    j.Xw = s.jXw.data(); j.obs = s.jObs.data(); j.invSigma2 = s.jInv.data(); j.has_mp = s.jHas.data(); j.mp_ids = nullptr;
     j.outlier = s.jOutlier.data(); j.n_inliers = 0;
     memcpy(j.Tcw_out, f.pose.Tcw.m, 64);
 }
@@ -1637,6 +1647,7 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
     c.logScale = std::log(cfg->scaleFactor);
     c.maxFrames = (int)cfg->fps; c.minFrames = 0;
     c.stereo = cfg->sensor == 1;
+    c.residentPts = c.ops.resident_points && c.ops.resident_points(c.ops.ctx) != 0;
     c.pool.reset(new Pool(cfg->host_threads > 1 ? cfg->host_threads : 1));
     for (int i = 0; i < c.S; i++) {
         c.seq.emplace_back(new Seq);

@@ -99,6 +99,7 @@ struct HipOps {
         return OSLAM_OK;
     }
     int sync_mp_table() {   // the device pointer table follows the host's
+        if ((int)mp_tab.size() < S) { mp_tab.resize(S, nullptr); mp_cap.resize(S, 0); mp_tab_dirty = true; }
         if (!mp_tab_dirty) return OSLAM_OK;
         if (!d_mp_tab) OSLAM_HIP_CHECK(hipMalloc((void**)&d_mp_tab, sizeof(uint8_t*) * (size_t)S));
         OSLAM_HIP_CHECK(hipMemcpyAsync(d_mp_tab, mp_tab.data(), sizeof(uint8_t*) * (size_t)S, hipMemcpyHostToDevice, strm));
@@ -499,8 +500,15 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     if (n > o->S) { oslam::set_error("pose_opt: n > n_sequences"); return OSLAM_E_INVALID; }
     const size_t cap = o->cap, B = n;
     for (int i = 0; i < n; i++) if (jobs[i].N > (int)cap) { oslam::set_error("pose_opt: N > capacity"); return OSLAM_E_CAPACITY; }
+    // by id: the positions come from the resident map-point records, obs / invSigma2 from the frames of this step that are still on the device
+    bool by_id = o->mp_tab_on;
+    for (int i = 0; i < n && by_id; i++) by_id = jobs[i].mp_ids != nullptr && jobs[i].slot >= 0 && jobs[i].slot < o->S;
+    if (by_id) OPS_CHECK(o->sync_mp_table());
+    else for (int i = 0; i < n; i++) if (!jobs[i].Xw || !jobs[i].obs || !jobs[i].invSigma2 || !jobs[i].has_mp) { oslam::set_error("pose_opt: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
     Layout L;
-    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B);
+    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oSl = L.take(by_id ? 4 * B : 0), oIds = L.take(by_id ? 4 * cap * B : 0);
+    const size_t head = L.off;
+    const size_t oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     o->pool->parallel_for(n, [&](int i) {
@@ -508,11 +516,15 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
         const size_t N = j.N;
         ((int32_t*)(U + oN))[i] = j.N;
         memcpy(U + oT + 64 * i, j.Tcw_in, 64);
+        if (by_id) { ((int32_t*)(U + oSl))[i] = j.slot; memcpy(U + oIds + 4 * cap * i, j.mp_ids, 4 * N); return; }
         memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
         memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, by_id ? head : L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    if (by_id)
+        OPS_CHECK(oslam_pose_inputs_gather_device(n, (int)cap, (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oN), (const int32_t*)(Dv + oIds), o->d_mp_tab, o->d_keysUn,
+                                                  o->cur_uRight, (int)cap, o->invSigma2, o->cfg.nLevels, (float*)(Dv + oXw), (float*)(Dv + oObs), (float*)(Dv + oInv), Dv + oHas, o->strm));
     o->t_begin();
     OPS_CHECK(oslam_pose_optimize_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), 0, (const float*)(Dv + oT), (const float*)(Dv + oXw),
                                                (const float*)(Dv + oObs), (const float*)(Dv + oInv), Dv + oHas, o->K5, o->strm));
@@ -532,7 +544,7 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
         const int32_t* stt = (const int32_t*)(o->dn_h + rS);
         for (int i = 0; i < n; i++) {
             int ne = 0;
-            for (int k = 0; k < jobs[i].N; k++) ne += jobs[i].has_mp[k] != 0;
+            for (int k = 0; k < jobs[i].N; k++) ne += by_id ? jobs[i].mp_ids[k] >= 0 : jobs[i].has_mp[k] != 0;
             flop += (double)ne * (700.0 * stt[2 * i] + 90.0 * stt[2 * i + 1]);
         }
         o->t_collect(1, 1, flop);
@@ -637,10 +649,17 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
         else bidx[m] = it->second;
     }
     if (tObj && !use_bits) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
+    bool by_id = o->mp_tab_on;
+    for (int i = 0; i < n && by_id; i++) by_id = jobs[i].base.mp_ids != nullptr && jobs[i].base.slot >= 0 && jobs[i].base.slot < o->S;
+    if (by_id) OPS_CHECK(o->sync_mp_table());
+    else for (int i = 0; i < n; i++) if (!jobs[i].base.Xw || !jobs[i].base.obs || !jobs[i].base.invSigma2 || !jobs[i].base.has_mp) { oslam::set_error("pose_opt2: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
     Layout L;
-    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B),
+    // (the arrays the device builds itself when the frames are served by id sit behind everything that is uploaded)
+    const size_t oN = L.take(4 * B), oT = L.take(64 * B), oSl = L.take(by_id ? 4 * B : 0), oIds = L.take(by_id ? 4 * cap * B : 0),
                  oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
                  oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ), oBi = L.take(4 * (size_t)tObj);
+    const size_t head = L.off;
+    const size_t oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     memcpy(U + oFr, fr.data(), sizeof(oslam_sem_frame_t) * B);
@@ -652,13 +671,19 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
         const size_t N = j.N;
         ((int32_t*)(U + oN))[i] = j.N;
         memcpy(U + oT + 64 * i, j.Tcw_in, 64);
-        memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
-        memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
+        if (by_id) { ((int32_t*)(U + oSl))[i] = j.slot; memcpy(U + oIds + 4 * cap * i, j.mp_ids, 4 * N); }
+        else {
+            memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
+            memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
+        }
         if (j2.nObjMp) { memcpy(U + oMx + 12 * (size_t)fr[i].objmp0, j2.objmp_Xw, 12 * (size_t)j2.nObjMp); memcpy(U + oMo + 4 * (size_t)fr[i].objmp0, j2.objmp_obj, 4 * (size_t)j2.nObjMp); }
         if (j2.nJoint) { memcpy(U + oJk + 4 * (size_t)fr[i].joint0, j2.joint_kp, 4 * (size_t)j2.nJoint); memcpy(U + oJo + 4 * (size_t)fr[i].joint0, j2.joint_obj, 4 * (size_t)j2.nJoint); }
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, by_id ? head : L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    if (by_id)
+        OPS_CHECK(oslam_pose_inputs_gather_device(n, (int)cap, (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oN), (const int32_t*)(Dv + oIds), o->d_mp_tab, o->d_keysUn,
+                                                  o->cur_uRight, (int)cap, o->invSigma2, o->cfg.nLevels, (float*)(Dv + oXw), (float*)(Dv + oObs), (float*)(Dv + oInv), Dv + oHas, o->strm));
     o->t_begin();
     if (use_bits) OPS_CHECK(oslam_poseopt_use_mask_bits(o->po, o->d_maskbits, (const int32_t*)(Dv + oBi)));
     OPS_CHECK(oslam_pose_optimize2_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), (const float*)(Dv + oT), (const float*)(Dv + oXw), (const float*)(Dv + oObs),
@@ -683,7 +708,7 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
         const int32_t* stt = (const int32_t*)(o->dn_h + rS);
         for (int i = 0; i < n; i++) {
             int ne = jobs[i].nObjMp + jobs[i].nJoint;   // upper bound of the semantic edges
-            for (int k = 0; k < jobs[i].base.N; k++) ne += jobs[i].base.has_mp[k] != 0;
+            for (int k = 0; k < jobs[i].base.N; k++) ne += by_id ? jobs[i].base.mp_ids[k] >= 0 : jobs[i].base.has_mp[k] != 0;
             flop += (double)ne * (700.0 * stt[2 * i] + 90.0 * stt[2 * i + 1]);
         }
         o->t_collect(1, 5, flop);
@@ -867,6 +892,8 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
     return OSLAM_OK;
 }
+
+int h_resident_points(void* p) { return ((HipOps*)p)->mp_tab_on ? 1 : 0; }
 
 int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
     HipOps* o = (HipOps*)p;
@@ -1114,7 +1141,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
-    if (o->mp_tab_on) ops->point_record = h_point_record;
+    if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed; }
     return OSLAM_OK;
