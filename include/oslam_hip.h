@@ -460,6 +460,9 @@ int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d
 int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slots, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab,
                                     const oslam_keypoint_t* d_keysUn, const float* d_uRight, int kp_stride, const float* invLevelSigma2, int nLevels,
                                     float* d_Xw, float* d_obs, float* d_invSigma2, uint8_t* d_has_mp, void* stream);
+/* Position and descriptor of the map points d_ids[b][i] (records of d_tab[b]; -1 = none: zeros) into the [batch][stride] arrays that
+ * oslam_match_project_last_batch_device reads (the last frame's mvpMapPoints of ORBmatcher::SearchByProjection(Cur, Last), src/ORBmatcher.cc:1338-1366). */
+int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream);
 /* device-pointer forms (asynchronous on `stream`); d_out_desc rows of points without observations are left untouched (zero-fill them first) */
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream);
 int oslam_mp_update_normal_depth_device(int P, const float* d_Pos, const int32_t* d_obs_start, const float* d_obs_Ow, const float* d_OwRef,

@@ -97,6 +97,10 @@ typedef struct oslam_job_search_last {     /* ORBmatcher::SearchByProjection(Cur
     float Tcw[16], Tlw[16]; float th;
     int32_t* kp_match;                     /* out [cur->N]: last-frame keypoint whose map point is now in mvpMapPoints[k]; < 0 none */
     int32_t nmatches;                      /* out */
+    const int32_t* mp_ids;                 /* [Nlast] map-point id of the last frame's keypoints or -1, or NULL.  A table that answers resident_points()
+                                            * takes Xw and mp_desc from its records and last_keysUn from the previous step's frame of the slot, which it
+                                            * still holds (the last frame of a tracked sequence IS the previous step's frame); those three may then be
+                                            * NULL.  has_mp is always given (it carries Observations() > 0, which only the driver knows). */
 } oslam_job_search_last_t;
 
 typedef struct oslam_job_search_local {    /* Frame::isInFrustum(pMP, 0.5) over the local points + SearchByProjection(F, points, th), nnratio 0.8 */

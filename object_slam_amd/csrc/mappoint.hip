@@ -280,6 +280,24 @@ __global__ __launch_bounds__(256) void k_mp_table_write(int P, const int32_t* it
     if (do_desc && desc_start[i + 1] > desc_start[i]) rec[8 + part] = ((const uint32_t*)(out_desc + (size_t)i * 32))[part];   // (every observing keyframe bad: it stays)
 }
 
+// eight lanes per point: lane part copies word `part` of the descriptor, lanes 0-2 the position
+__global__ __launch_bounds__(256) void k_mp_table_gather(int stride, const int32_t* n, const int32_t* ids, uint8_t* const* tab, float* Xw, uint8_t* desc) {
+    const int b = blockIdx.y, i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (i >= n[b]) return;
+    const size_t at = (size_t)b * stride + i;
+    const int id = ids[at];
+    const uint32_t* rec = id >= 0 ? (const uint32_t*)(tab[b] + (size_t)id * 64) : nullptr;
+    ((uint32_t*)desc)[at * 8 + part] = rec ? rec[8 + part] : 0u;
+    if (part < 3) ((uint32_t*)Xw)[at * 3 + part] = rec ? rec[part] : 0u;
+}
+
+int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream) {
+    if (batch < 1 || stride < 1 || !d_n || !d_ids || !d_tab || !d_Xw || !d_desc) { set_error("mp_table_gather: bad argument"); return OSLAM_E_INVALID; }
+    hipLaunchKernelGGL(k_mp_table_gather, dim3(div_up(stride, 32), batch), dim3(256), 0, (hipStream_t)stream, stride, d_n, d_ids, d_tab, d_Xw, d_desc);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 struct InvSigma { float v[OSLAM_MAX_LEVELS]; };
 __global__ __launch_bounds__(256) void k_pose_inputs(int stride, const int32_t* slots, const int32_t* n, const int32_t* ids, uint8_t* const* tab, const oslam_keypoint_t* keysUn,
                                                      const float* uRight, int kp_stride, InvSigma inv, float* Xw, float* obs, float* invS, uint8_t* has) {

@@ -1170,19 +1170,24 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     l.pose.set_frame(mul4(s.rel.back().Tcr, s.map.kfs[l.refKF].pose.Tcw));
     f.pose.set_frame(mul4(s.velocity, l.pose.Tcw));
     const int NL = l.N;
-    s.jXw.assign((size_t)NL * 3, 0.f); s.jHas.assign(NL, 0); s.jDesc.assign((size_t)NL * 32, 0);
+    const bool by_id = c.residentPts;   // the table takes positions / descriptors from its records and the last frame's keypoints from the previous step
+    s.jHas.assign(NL, 0);
+    if (!by_id) { s.jXw.assign((size_t)NL * 3, 0.f); s.jDesc.assign((size_t)NL * 32, 0); }
     for (int k = 0; k < NL; k++) {
         prefetch_ahead(s.map.mps, l.mp, k, NL);
         const int p = l.mp[k];
         if (p < 0 || l.outlier[k]) continue;
         const MapPt& mp = s.map.mps[p];
         s.jHas[k] = 1 | (mp.nObs > 0 ? 2 : 0);
+        if (by_id) continue;
         for (int d = 0; d < 3; d++) s.jXw[(size_t)k * 3 + d] = mp.pos[d];
         memcpy(&s.jDesc[(size_t)k * 32], mp.desc, 32);
     }
     s.jMatch.assign(f.N + 1, -1);
     oslam_job_search_last_t& j = s.jSL;
-    j.slot = i; j.cur = &f.view; j.Nlast = NL; j.Xw = s.jXw.data(); j.has_mp = s.jHas.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data();
+    j.slot = i; j.cur = &f.view; j.Nlast = NL; j.has_mp = s.jHas.data();
+    if (by_id) { j.Xw = nullptr; j.last_keysUn = nullptr; j.mp_desc = nullptr; j.mp_ids = l.mp.data(); }
+    else { j.Xw = s.jXw.data(); j.last_keysUn = l.keysUn.data(); j.mp_desc = s.jDesc.data(); j.mp_ids = nullptr; }
     memcpy(j.Tcw, f.pose.Tcw.m, 64); memcpy(j.Tlw, l.pose.Tcw.m, 64);
     j.th = c.stereo ? 7.f : 15.f;   // :961-965
     j.kp_match = s.jMatch.data(); j.nmatches = 0;

@@ -35,6 +35,7 @@ struct HipOps {
     int max_local = 0;
     // device-resident batch state of the current step
     uint8_t* d_gray = nullptr; float* d_depth = nullptr; size_t gray_pitch = 0;
+    oslam_keypoint_t* d_keysUn_prev = nullptr;   // mvKeysUn of the PREVIOUS step's frames (the buffers swap at every Frame::Frame stage): the last frames of search_last
     oslam_keypoint_t* d_keysUn = nullptr; float* d_uRight = nullptr; float* d_mvDepth = nullptr; int32_t* d_status = nullptr;
     const oslam_keypoint_t* d_kp = nullptr; const uint8_t* d_desc = nullptr; const int32_t* d_cnt = nullptr;
     std::vector<oslam_proj_query_t> q;
@@ -240,6 +241,7 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
              oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
     o->step_epoch++;   // a new step: the mask bitmaps of the previous one are stale
+    std::swap(o->d_keysUn, o->d_keysUn_prev);   // what was the current frame of every slot is now its last frame
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
@@ -287,6 +289,7 @@ int h_frames_stereo(void* p, int n, const int32_t* slots, const uint8_t* const* 
                     oslam_slam_frame_t* const* out) {
     HipOps* o = (HipOps*)p;
     o->step_epoch++;
+    std::swap(o->d_keysUn, o->d_keysUn_prev);
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (!o->orbR || !o->stereo) { oslam::set_error("frames_stereo: the handle was not created for the STEREO sensor"); return OSLAM_E_INVALID; }
     if (n > o->S) { oslam::set_error("frames_stereo: n > n_sequences"); return OSLAM_E_INVALID; }
@@ -345,29 +348,38 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n == 0) return OSLAM_OK;
     const size_t S = o->S, cap = o->cap;
+    for (int i = 0; i < n; i++)
+        if (jobs[i].slot < 0 || jobs[i].slot >= (int)S || jobs[i].Nlast > (int)cap) { oslam::set_error("search_last: bad slot / size"); return OSLAM_E_INVALID; }
+    // by id: positions and descriptors of the last frame's map points come from the resident records, its keypoints from the previous step's buffer
+    bool by_id = o->mp_tab_on;
+    for (int i = 0; i < n && by_id; i++) by_id = jobs[i].mp_ids != nullptr;
+    if (by_id) OPS_CHECK(o->sync_mp_table());
+    else for (int i = 0; i < n; i++) if (!jobs[i].Xw || !jobs[i].last_keysUn || !jobs[i].mp_desc) { oslam::set_error("search_last: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
     Layout L;
-    const size_t oN = L.take(4 * S), oTc = L.take(64 * S), oTl = L.take(64 * S), oXw = L.take(12 * cap * S), oHas = L.take(cap * S),
-                 oKeys = L.take(sizeof(oslam_keypoint_t) * cap * S), oDesc = L.take(32 * cap * S);
+    const size_t oN = L.take(4 * S), oTc = L.take(64 * S), oTl = L.take(64 * S), oHas = L.take(cap * S), oIds = L.take(by_id ? 4 * cap * S : 0);
+    const size_t head = L.off;
+    const size_t oXw = L.take(12 * cap * S), oKeys = L.take(by_id ? 0 : sizeof(oslam_keypoint_t) * cap * S), oDesc = L.take(32 * cap * S);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
     memset(U + oN, 0, 4 * S);
-    for (int i = 0; i < n; i++)
-        if (jobs[i].slot < 0 || jobs[i].slot >= (int)S || jobs[i].Nlast > (int)cap) { oslam::set_error("search_last: bad slot / size"); return OSLAM_E_INVALID; }
     o->pool->parallel_for(n, [&](int i) {
         const oslam_job_search_last_t& j = jobs[i];
         const size_t b = j.slot, N = j.Nlast;
         ((int32_t*)(U + oN))[b] = j.Nlast;
         memcpy(U + oTc + 64 * b, j.Tcw, 64); memcpy(U + oTl + 64 * b, j.Tlw, 64);
-        memcpy(U + oXw + 12 * cap * b, j.Xw, 12 * N); memcpy(U + oHas + cap * b, j.has_mp, N);
+        memcpy(U + oHas + cap * b, j.has_mp, N);
+        if (by_id) { memcpy(U + oIds + 4 * cap * b, j.mp_ids, 4 * N); return; }
+        memcpy(U + oXw + 12 * cap * b, j.Xw, 12 * N);
         memcpy(U + oKeys + sizeof(oslam_keypoint_t) * cap * b, j.last_keysUn, sizeof(oslam_keypoint_t) * N);
         memcpy(U + oDesc + 32 * cap * b, j.mp_desc, 32 * N);
     });
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, by_id ? head : L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    if (by_id) OPS_CHECK(oslam_mp_table_gather_device((int)S, (int)cap, (const int32_t*)(Dv + oN), (const int32_t*)(Dv + oIds), o->d_mp_tab, (float*)(Dv + oXw), Dv + oDesc, o->strm));
     oslam_match_frames_t fr;
     frames_view(o, fr, nullptr);
     oslam_match_last_t la;
-    la.Xw = (const float*)(Dv + oXw); la.has_mp = Dv + oHas; la.keys = (const oslam_keypoint_t*)(Dv + oKeys); la.mp_desc = Dv + oDesc;
+    la.Xw = (const float*)(Dv + oXw); la.has_mp = Dv + oHas; la.keys = by_id ? o->d_keysUn_prev : (const oslam_keypoint_t*)(Dv + oKeys); la.mp_desc = Dv + oDesc;
     la.kp_stride = (int)cap; la.n_kps = (const int32_t*)(Dv + oN); la.n_kps_const = 0;
     o->t_begin();
     OPS_CHECK(oslam_match_project_last_batch_device(o->m_last, &la, (const float*)(Dv + oTc), (const float*)(Dv + oTl), &o->cam, &fr, o->scale, o->cfg.nLevels,
@@ -1080,7 +1092,7 @@ void h_destroy(void* p) {
     if (o->tev0) (void)hipEventDestroy(o->tev0);
     if (o->tev1) (void)hipEventDestroy(o->tev1);
     if (o->strm) (void)hipStreamDestroy(o->strm);
-    (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
+    (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_keysUn_prev); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
     delete o;
 }
 
@@ -1126,6 +1138,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
         if (e == hipSuccess && cfg->sensor == 1) e = hipMalloc((void**)&o->d_grayR, o->gray_pitch * cfg->height * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_depth, (size_t)cfg->width * cfg->height * 4 * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_keysUn, sizeof(oslam_keypoint_t) * o->cap * S);
+        if (e == hipSuccess) e = hipMalloc((void**)&o->d_keysUn_prev, sizeof(oslam_keypoint_t) * o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_uRight, 4 * (size_t)o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_mvDepth, 4 * (size_t)o->cap * S);
         if (e == hipSuccess) e = hipMalloc((void**)&o->d_objbits, (size_t)o->cap * S);
