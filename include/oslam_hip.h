@@ -451,7 +451,8 @@ int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*
 /* Resident map-point table: d_tab[slot] = device array of 64-byte records indexed by map-point id — float pos[3], normal[3], minDistance, maxDistance, then the
  * 32 descriptor bytes (mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance, mDescriptor of include/MapPoint.h:116-141).  After a MapPoint update of P points
  * (the two functions below) this writes its results into the records d_items[i] = (slot, id): position (d_Pos) + normal / distances (d_out5) when do_normal,
- * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; points without observations keep their record. */
+ * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; a point without observations (culled) keeps its record except
+ * for the position, which the caller may have changed before culling it (local BA). */
 int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
                                 const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream);
 /* Inputs of Optimizer::PoseOptimization (src/Optimizer.cc:258-340) for a batch of frames that are still on the device: frame b is frame d_slots[b] of the
@@ -462,6 +463,8 @@ int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slot
                                     float* d_Xw, float* d_obs, float* d_invSigma2, uint8_t* d_has_mp, void* stream);
 /* Position and descriptor of the map points d_ids[b][i] (records of d_tab[b]; -1 = none: zeros) into the [batch][stride] arrays that
  * oslam_match_project_last_batch_device reads (the last frame's mvpMapPoints of ORBmatcher::SearchByProjection(Cur, Last), src/ORBmatcher.cc:1338-1366). */
+/* Positions of n map points named by (d_slots[i], d_ids[i]) into d_Xw[n][3] (the object map points of ObjectOptimizer::PoseOptimization2). */
+int oslam_mp_table_positions_device(int n, const int32_t* d_slots, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, void* stream);
 int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream);
 /* device-pointer forms (asynchronous on `stream`); d_out_desc rows of points without observations are left untouched (zero-fill them first) */
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream);

@@ -166,6 +166,8 @@ typedef struct oslam_job_pose2 {           /* ObjectOptimizer::PoseOptimization2
     int32_t nObjMp; const float* objmp_Xw; const int32_t* objmp_obj;
     int32_t nJoint; const int32_t* joint_kp; const int32_t* joint_obj;
     int32_t n_semantic;                    /* out: nSemNum (:1232) */
+    const int32_t* objmp_ids;              /* [nObjMp] map-point ids of the objects' points or NULL: with resident_points() their positions come from the
+                                            * table's records and objmp_Xw may be NULL */
 } oslam_job_pose2_t;
 
 typedef oslam_bow_job_t oslam_job_bow_t;

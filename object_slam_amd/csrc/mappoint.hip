@@ -270,13 +270,15 @@ __global__ __launch_bounds__(256) void k_mp_table_write(int P, const int32_t* it
                                                         const float* Pos, const float* out5, const uint8_t* out_desc, int do_desc, int do_normal) {
     const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
     if (i >= P) return;
-    if (obs_start[i + 1] == obs_start[i]) return;   // no observations: both methods return early, the record stays
     uint32_t* rec = (uint32_t*)(tab[items[2 * i]] + (size_t)items[2 * i + 1] * 64);
+    const bool has_obs = obs_start[i + 1] > obs_start[i];   // none (a bad point): both methods return early, only the position the job carries is current
     if (do_normal) {   // words 0-2 position, 3-5 normal, 6 minimum distance, 7 maximum distance
         const uint32_t* ps = (const uint32_t*)(Pos + (size_t)i * 3);
         const uint32_t* o5 = (const uint32_t*)(out5 + (size_t)i * 5);
-        rec[part] = part < 3 ? ps[part] : part < 6 ? o5[part - 3] : part == 6 ? o5[4] : o5[3];
+        if (part < 3) rec[part] = ps[part];   // SetWorldPos happened before this job whatever became of the point (local BA moves a point, then may cull it)
+        else if (has_obs) rec[part] = part < 6 ? o5[part - 3] : part == 6 ? o5[4] : o5[3];
     }
+    if (!has_obs) return;
     if (do_desc && desc_start[i + 1] > desc_start[i]) rec[8 + part] = ((const uint32_t*)(out_desc + (size_t)i * 32))[part];   // (every observing keyframe bad: it stays)
 }
 
@@ -289,6 +291,21 @@ __global__ __launch_bounds__(256) void k_mp_table_gather(int stride, const int32
     const uint32_t* rec = id >= 0 ? (const uint32_t*)(tab[b] + (size_t)id * 64) : nullptr;
     ((uint32_t*)desc)[at * 8 + part] = rec ? rec[8 + part] : 0u;
     if (part < 3) ((uint32_t*)Xw)[at * 3 + part] = rec ? rec[part] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_mp_table_positions(int n, const int32_t* slots, const int32_t* ids, uint8_t* const* tab, float* Xw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* r = (const float*)(tab[slots[i]] + (size_t)ids[i] * 64);
+    Xw[(size_t)i * 3] = r[0]; Xw[(size_t)i * 3 + 1] = r[1]; Xw[(size_t)i * 3 + 2] = r[2];
+}
+
+int oslam_mp_table_positions_device(int n, const int32_t* d_slots, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, void* stream) {
+    if (n < 0 || (n > 0 && (!d_slots || !d_ids || !d_tab || !d_Xw))) { set_error("mp_table_positions: bad argument"); return OSLAM_E_INVALID; }
+    if (n == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_mp_table_positions, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, d_slots, d_ids, d_tab, d_Xw);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
 }
 
 int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream) {

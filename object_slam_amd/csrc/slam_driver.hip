@@ -162,7 +162,7 @@ struct Seq {
     int64_t lbaFixedDropped = 0;           // fixed keyframes left out of local-BA windows because of the per-window keyframe limit
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
-    std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj;
+    std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj, jObjIds;
     oslam_job_pose2_t jPose2; bool hasPose2 = false;
     const oslam_slam_objects_t* det = nullptr;           // this step's detections (NULL or n == 0: none)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
@@ -1088,7 +1088,7 @@ static void track_objects(Seq& s) {
 static void fill_pose2_job(Ctx& c, Seq& s, int si) {
     Frame& f = *s.cur;
     s.hasPose2 = false;
-    s.jMaskPtrs.clear(); s.jObjXw.clear(); s.jObjOf.clear(); s.jJointKp.clear(); s.jJointObj.clear();
+    s.jMaskPtrs.clear(); s.jObjXw.clear(); s.jObjOf.clear(); s.jJointKp.clear(); s.jJointObj.clear(); s.jObjIds.clear();
     int m = 0;
     for (size_t io = 0; io < f.objs.size(); io++) {
         const Frame::Obj2D& o = f.objs[io];
@@ -1096,8 +1096,10 @@ static void fill_pose2_job(Ctx& c, Seq& s, int si) {
         const Seq::Obj3D& ob = s.obj3ds[o.obj3d];
         s.jMaskPtrs.push_back(s.det->masks[o.det]);
         const size_t n0 = s.jObjOf.size(), nob = ob.mps.size();
-        s.jObjXw.resize((n0 + nob) * 3); s.jObjOf.resize(n0 + nob, m);
-        for (size_t q = 0; q < nob; q++) {
+        s.jObjOf.resize(n0 + nob, m);
+        if (c.residentPts) s.jObjIds.insert(s.jObjIds.end(), ob.mps.begin(), ob.mps.end());   // the table reads the positions from its records
+        else s.jObjXw.resize((n0 + nob) * 3);
+        for (size_t q = 0; q < nob && !c.residentPts; q++) {
             if (q + kPF < nob) __builtin_prefetch(&s.map.mps[ob.mps[q + kPF]]);
             const float* x = s.map.mps[ob.mps[q]].pos;
             float* d = &s.jObjXw[(n0 + q) * 3];
@@ -1114,7 +1116,8 @@ static void fill_pose2_job(Ctx& c, Seq& s, int si) {
     oslam_job_pose2_t& j = s.jPose2;
     j.base = s.jPose;
     j.nObj = m; j.masks = s.jMaskPtrs.data(); j.mask_stride = c.mask_stride; j.on_device = c.masks_on_device;
-    j.nObjMp = (int)s.jObjOf.size(); j.objmp_Xw = s.jObjXw.data(); j.objmp_obj = s.jObjOf.data();
+    j.nObjMp = (int)s.jObjOf.size(); j.objmp_Xw = c.residentPts ? nullptr : s.jObjXw.data(); j.objmp_obj = s.jObjOf.data();
+    j.objmp_ids = c.residentPts ? s.jObjIds.data() : nullptr;
     j.nJoint = (int)s.jJointKp.size(); j.joint_kp = s.jJointKp.data(); j.joint_obj = s.jJointObj.data();
     j.n_semantic = 0;
     s.hasPose2 = true;

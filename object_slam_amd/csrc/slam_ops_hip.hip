@@ -662,15 +662,17 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     }
     if (tObj && !use_bits) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
     bool by_id = o->mp_tab_on;
-    for (int i = 0; i < n && by_id; i++) by_id = jobs[i].base.mp_ids != nullptr && jobs[i].base.slot >= 0 && jobs[i].base.slot < o->S;
+    for (int i = 0; i < n && by_id; i++) by_id = jobs[i].base.mp_ids != nullptr && jobs[i].base.slot >= 0 && jobs[i].base.slot < o->S && (jobs[i].nObjMp == 0 || jobs[i].objmp_ids != nullptr);
     if (by_id) OPS_CHECK(o->sync_mp_table());
-    else for (int i = 0; i < n; i++) if (!jobs[i].base.Xw || !jobs[i].base.obs || !jobs[i].base.invSigma2 || !jobs[i].base.has_mp) { oslam::set_error("pose_opt2: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
+    else for (int i = 0; i < n; i++) if ((jobs[i].nObjMp > 0 && !jobs[i].objmp_Xw) || !jobs[i].base.Xw || !jobs[i].base.obs || !jobs[i].base.invSigma2 || !jobs[i].base.has_mp) { oslam::set_error("pose_opt2: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
     Layout L;
     // (the arrays the device builds itself when the frames are served by id sit behind everything that is uploaded)
     const size_t oN = L.take(4 * B), oT = L.take(64 * B), oSl = L.take(by_id ? 4 * B : 0), oIds = L.take(by_id ? 4 * cap * B : 0),
-                 oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
-                 oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ), oBi = L.take(4 * (size_t)tObj);
+                 oFr = L.take(sizeof(oslam_sem_frame_t) * B), oPtr = L.take(8 * (size_t)tObj), oMx = L.take(by_id ? 0 : 12 * (size_t)tMp), oMo = L.take(4 * (size_t)tMp),
+                 oJk = L.take(4 * (size_t)tJ), oJo = L.take(4 * (size_t)tJ), oBi = L.take(4 * (size_t)tObj), oMi = L.take(by_id ? 4 * (size_t)tMp : 0),
+                 oMs = L.take(by_id ? 4 * (size_t)tMp : 0);
     const size_t head = L.off;
+    const size_t oMxDev = by_id ? L.take(12 * (size_t)tMp) : oMx;   // object map-point positions: uploaded, or gathered from the records
     const size_t oXw = L.take(12 * cap * B), oObs = L.take(12 * cap * B), oInv = L.take(4 * cap * B), oHas = L.take(cap * B);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
@@ -688,19 +690,28 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
             memcpy(U + oXw + 12 * cap * i, j.Xw, 12 * N); memcpy(U + oObs + 12 * cap * i, j.obs, 12 * N);
             memcpy(U + oInv + 4 * cap * i, j.invSigma2, 4 * N); memcpy(U + oHas + cap * i, j.has_mp, N);
         }
-        if (j2.nObjMp) { memcpy(U + oMx + 12 * (size_t)fr[i].objmp0, j2.objmp_Xw, 12 * (size_t)j2.nObjMp); memcpy(U + oMo + 4 * (size_t)fr[i].objmp0, j2.objmp_obj, 4 * (size_t)j2.nObjMp); }
+        if (j2.nObjMp) {
+            memcpy(U + oMo + 4 * (size_t)fr[i].objmp0, j2.objmp_obj, 4 * (size_t)j2.nObjMp);
+            if (by_id) {
+                memcpy(U + oMi + 4 * (size_t)fr[i].objmp0, j2.objmp_ids, 4 * (size_t)j2.nObjMp);
+                int32_t* sl = (int32_t*)(U + oMs) + fr[i].objmp0;
+                for (int q = 0; q < j2.nObjMp; q++) sl[q] = j.slot;
+            } else memcpy(U + oMx + 12 * (size_t)fr[i].objmp0, j2.objmp_Xw, 12 * (size_t)j2.nObjMp);
+        }
         if (j2.nJoint) { memcpy(U + oJk + 4 * (size_t)fr[i].joint0, j2.joint_kp, 4 * (size_t)j2.nJoint); memcpy(U + oJo + 4 * (size_t)fr[i].joint0, j2.joint_obj, 4 * (size_t)j2.nJoint); }
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, by_id ? head : L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
-    if (by_id)
+    if (by_id) {
         OPS_CHECK(oslam_pose_inputs_gather_device(n, (int)cap, (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oN), (const int32_t*)(Dv + oIds), o->d_mp_tab, o->d_keysUn,
                                                   o->cur_uRight, (int)cap, o->invSigma2, o->cfg.nLevels, (float*)(Dv + oXw), (float*)(Dv + oObs), (float*)(Dv + oInv), Dv + oHas, o->strm));
+        OPS_CHECK(oslam_mp_table_positions_device(tMp, (const int32_t*)(Dv + oMs), (const int32_t*)(Dv + oMi), o->d_mp_tab, (float*)(Dv + oMxDev), o->strm));
+    }
     o->t_begin();
     if (use_bits) OPS_CHECK(oslam_poseopt_use_mask_bits(o->po, o->d_maskbits, (const int32_t*)(Dv + oBi)));
     OPS_CHECK(oslam_pose_optimize2_batch_device(o->po, n, (int)cap, (const int32_t*)(Dv + oN), (const float*)(Dv + oT), (const float*)(Dv + oXw), (const float*)(Dv + oObs),
                                                 (const float*)(Dv + oInv), Dv + oHas, o->K5, (const oslam_sem_frame_t*)(Dv + oFr), tObj, use_bits ? nullptr : (const uint8_t* const*)(Dv + oPtr),
-                                                o->cfg.height, o->cfg.width, pitch, tMp, (const float*)(Dv + oMx), (const int32_t*)(Dv + oMo), tJ, (const int32_t*)(Dv + oJk),
+                                                o->cfg.height, o->cfg.width, pitch, tMp, (const float*)(Dv + oMxDev), (const int32_t*)(Dv + oMo), tJ, (const int32_t*)(Dv + oJk),
                                                 (const int32_t*)(Dv + oJo), o->bounds, o->invSigma2[0], o->strm));
     o->t_end();
     const float* d_T; const uint8_t* d_out; const int32_t* d_ni; const int32_t* d_stats; const int32_t* d_ns;
