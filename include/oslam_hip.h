@@ -463,6 +463,12 @@ int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slot
                                     float* d_Xw, float* d_obs, float* d_invSigma2, uint8_t* d_has_mp, void* stream);
 /* Position and descriptor of the map points d_ids[b][i] (records of d_tab[b]; -1 = none: zeros) into the [batch][stride] arrays that
  * oslam_match_project_last_batch_device reads (the last frame's mvpMapPoints of ORBmatcher::SearchByProjection(Cur, Last), src/ORBmatcher.cc:1338-1366). */
+/* The projection gates of ORBmatcher::Fuse (src/ORBmatcher.cc:840-890) for n (keyframe, candidate list) jobs from the resident map-point records: job b has
+ * d_M[b] candidates d_ids[b][i] (records of d_tab[d_slots[b]]; excluded when d_ids < 0 or d_excl != 0), keyframe pose d_Tcw[b] / centre d_Ow[b]; writes the
+ * query of every candidate (inactive = flags 0) in candidate order into d_q[b][.] for oslam_match_fuse_batch_device. */
+int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl, uint8_t* const* d_tab,
+                              const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
+                              const float* scaleFactors, int nLevels, oslam_proj_query_t* d_q, void* stream);
 /* Positions of n map points named by (d_slots[i], d_ids[i]) into d_Xw[n][3] (the object map points of ObjectOptimizer::PoseOptimization2). */
 int oslam_mp_table_positions_device(int n, const int32_t* d_slots, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, void* stream);
 int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream);

@@ -145,6 +145,15 @@ typedef struct oslam_job_fuse {            /* search half of ORBmatcher::Fuse on
     int32_t* q_match;                      /* out [M] */
 } oslam_job_fuse_t;
 
+typedef struct oslam_job_fuse_pts {        /* ORBmatcher::Fuse on one resident keyframe with the candidates named by map-point id (tables with resident_points):
+                                            * the projection gates of src/ORBmatcher.cc:840-890 run on the device from the points' records */
+    int32_t slot, kf, N;                   /* the target keyframe (registered with register_keyframes) and its keypoint count */
+    int32_t M; const int32_t* ids;         /* candidates: map-point ids, -1 = none */
+    const uint8_t* excl;                   /* [M] != 0: the point is bad or already observed by the keyframe (:849) — only the driver knows */
+    float Tcw[16], Ow[3]; float th;        /* the keyframe's pose and camera centre, the radius factor (3.0) */
+    int32_t* q_match;                      /* out [M]: keypoint of the keyframe for candidate i or -1 */
+} oslam_job_fuse_pts_t;
+
 #define OSLAM_SLAM_MAX_OBJECTS 8           /* detections per frame (one bit each in the keypoint test) */
 
 typedef struct oslam_slam_objects {        /* the semantic detections of ONE frame (reference include/Semantic.h; src/Semantic.cc:14-96) */
@@ -226,6 +235,8 @@ typedef struct oslam_slam_ops {
                            const int32_t* counts, uint32_t* const* out);
     /* optional: != 0 if the table keeps the map points resident (oslam_job_mp_update_t::items) and serves pose jobs from mp_ids */
     int (*resident_points)(void* ctx);
+    /* optional, with resident_points and register_keyframes: the search half of ORBmatcher::Fuse with candidates by id (oslam_job_fuse_pts_t) */
+    int (*fuse_points_keyed)(void* ctx, int n, oslam_job_fuse_pts_t* jobs);
     /* optional test hook of tables with resident map points: the 64-byte record of point `id` of `slot` (see oslam_job_mp_update_t::items) */
     int (*point_record)(void* ctx, int slot, int id, uint8_t out[64]);
 } oslam_slam_ops_t;

@@ -293,6 +293,78 @@ __global__ __launch_bounds__(256) void k_mp_table_gather(int stride, const int32
     if (part < 3) ((uint32_t*)Xw)[at * 3 + part] = rec ? rec[part] : 0u;
 }
 
+struct FuseQCtx { float fx, fy, cx, cy, bf, minX, minY, maxX, maxY, th, logScale; float scale[OSLAM_MAX_LEVELS]; int nLevels; };
+// one thread per candidate; the arithmetic is the driver's fuse_queries (the host form the oracle table receives), operator by operator
+__global__ __launch_bounds__(256) void k_fuse_queries(FuseQCtx c, int stride, const int32_t* slots, const int32_t* Mn, const int32_t* ids, const uint8_t* excl,
+                                                      uint8_t* const* tab, const float* Tcw, const float* Ow, oslam_proj_query_t* qout) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mn[b]) return;
+    const size_t at = (size_t)b * stride + i;
+    oslam_proj_query_t q;
+    q.u = q.v = q.ur = q.radius = 0.f; q.minLevel = -1; q.maxLevel = -1; q.flags = 0; q.angle = 0.f;
+    uint32_t* qd = (uint32_t*)q.desc;
+#pragma unroll
+    for (int w = 0; w < 8; w++) qd[w] = 0u;
+    const int id = ids[at];
+    if (id >= 0 && !excl[at]) {
+        const float* r = (const float*)(tab[slots[b]] + (size_t)id * 64);   // pos[3], normal[3], minD, maxD, desc
+        const float* T = Tcw + (size_t)b * 16;
+        const float* O = Ow + (size_t)b * 3;
+        float pc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float s = T[k * 4] * r[0];
+            s += T[k * 4 + 1] * r[1];
+            s += T[k * 4 + 2] * r[2];
+            pc[k] = (float)((double)s + (double)T[k * 4 + 3]);
+        }
+        bool ok = !(pc[2] < 0.0f);
+        if (ok) {
+            const float invz = __fdiv_rn(1.0f, pc[2]);
+            const float x = pc[0] * invz, y = pc[1] * invz;
+            const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
+            ok = u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY;   // KeyFrame::IsInImage
+            if (ok) {
+                const float ur = u - c.bf * invz;
+                const float maxDistance = 1.2f * r[7], minDistance = 0.8f * r[6];
+                const float PO[3] = {r[0] - O[0], r[1] - O[1], r[2] - O[2]};
+                const float dist3D = (float)norm3d(PO[0], PO[1], PO[2]);
+                ok = !(dist3D < minDistance || dist3D > maxDistance);
+                if (ok) {
+                    const double dot = (double)PO[0] * r[3] + (double)PO[1] * r[4] + (double)PO[2] * r[5];
+                    ok = !(dot < 0.5 * dist3D);
+                }
+                if (ok) {
+                    const float ratio = __fdiv_rn(r[7], dist3D);
+                    int lvl = (int)ceilf(__fdiv_rn((float)log((double)ratio), c.logScale));   // std::log(float) / logScaleFactor, as Frame::isInFrustum's kernel does
+                    if (lvl < 0) lvl = 0;
+                    else if (lvl >= c.nLevels) lvl = c.nLevels - 1;
+                    q.u = u; q.v = v; q.ur = ur; q.radius = c.th * c.scale[lvl]; q.minLevel = lvl - 1; q.maxLevel = lvl; q.flags = 1;
+                    const uint32_t* rd = (const uint32_t*)r + 8;
+#pragma unroll
+                    for (int w = 0; w < 8; w++) qd[w] = rd[w];
+                }
+            }
+        }
+    }
+    qout[at] = q;
+}
+
+int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl, uint8_t* const* d_tab,
+                              const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
+                              const float* scaleFactors, int nLevels, oslam_proj_query_t* d_q, void* stream) {
+    if (n < 1 || stride < 1 || !d_slots || !d_M || !d_ids || !d_excl || !d_tab || !d_Tcw || !d_Ow || !K5 || !bounds || !scaleFactors || nLevels < 1 || nLevels > OSLAM_MAX_LEVELS || !d_q) {
+        set_error("fuse_queries: bad argument"); return OSLAM_E_INVALID;
+    }
+    FuseQCtx c;
+    c.fx = K5[0]; c.fy = K5[1]; c.cx = K5[2]; c.cy = K5[3]; c.bf = K5[4];
+    c.minX = bounds[0]; c.minY = bounds[1]; c.maxX = bounds[2]; c.maxY = bounds[3]; c.th = th; c.logScale = logScaleFactor; c.nLevels = nLevels;
+    for (int l = 0; l < OSLAM_MAX_LEVELS; l++) c.scale[l] = l < nLevels ? scaleFactors[l] : 1.f;
+    hipLaunchKernelGGL(k_fuse_queries, dim3(div_up(stride, 256), n), dim3(256), 0, (hipStream_t)stream, c, stride, d_slots, d_M, d_ids, d_excl, d_tab, d_Tcw, d_Ow, d_q);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 __global__ __launch_bounds__(256) void k_mp_table_positions(int n, const int32_t* slots, const int32_t* ids, uint8_t* const* tab, float* Xw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

@@ -803,7 +803,9 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     // The target keyframes of one sequence are fused one after the other like the reference's loop (a fusion changes descriptors and
     // observations the next target sees); round t handles target t of every sequence in one batch.
     if (flags & 4) {
-        struct FuseSeq { std::vector<int> targets; std::vector<int> pts; std::vector<oslam_proj_query_t> q; std::vector<int> qpt; std::vector<int32_t> qm; int kf; };
+        struct FuseSeq { std::vector<int> targets; std::vector<int> pts; std::vector<oslam_proj_query_t> q; std::vector<int> qpt; std::vector<int32_t> qm; std::vector<uint8_t> excl; int kf; };
+        const bool fuse_by_id = c.residentPts && c.ops.fuse_points_keyed != nullptr;   // the table runs the projection gates itself from its map-point records
+        std::vector<oslam_job_fuse_pts_t> pjobs;
         std::vector<FuseSeq> fs(who.size());
         std::vector<oslam_job_fuse_t> jobs;
         std::vector<int> jw;
@@ -825,7 +827,52 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             fs[w].pts.assign(m.kfs[cur].mp.begin(), m.kfs[cur].mp.end());   // vpMapPointMatches snapshot (:484)
         });
         for (size_t w = 0; w < who.size(); w++) maxt = std::max(maxt, fs[w].targets.size());
+        auto fuse_round_by_id = [&](bool into_current, size_t t) -> int {
+            jw.clear(); pjobs.clear();
+            pool.parallel_for(nW, [&](int w) {
+                Seq& s = *c.seq[who[w]];
+                fs[w].kf = -1;
+                if (!into_current && t >= fs[w].targets.size()) return;
+                if (into_current && fs[w].targets.empty()) return;
+                const int k = into_current ? s.curKF : fs[w].targets[t];
+                fs[w].kf = k;
+                const Map& m = s.map;
+                const std::vector<int>& pts = fs[w].pts;
+                fs[w].excl.assign(pts.size() + 1, 1);
+                bool any = false;
+                for (size_t pi = 0; pi < pts.size(); pi++) {   // what only the host knows of ORBmatcher::Fuse's gates (:849): bad, or already in the keyframe
+                    prefetch_obs_ahead(m.mps, pts, pi, pts.size());
+                    const int p = pts[pi];
+                    if (p < 0) continue;
+                    const MapPt& mp = m.mps[p];
+                    if (mp.bad || mp.obs_index(k) >= 0) continue;
+                    fs[w].excl[pi] = 0; any = true;
+                }
+                if (!any) fs[w].kf = -1;
+                fs[w].qm.assign(pts.size() + 1, -1);
+            });
+            for (size_t w = 0; w < who.size(); w++) {
+                if (fs[w].kf < 0) continue;
+                const KeyFrm& kf = c.seq[who[w]]->map.kfs[fs[w].kf];
+                oslam_job_fuse_pts_t j;
+                j.slot = who[w]; j.kf = fs[w].kf; j.N = kf.N; j.M = (int)fs[w].pts.size(); j.ids = fs[w].pts.data(); j.excl = fs[w].excl.data();
+                memcpy(j.Tcw, kf.pose.Tcw.m, 64); memcpy(j.Ow, kf.pose.Ow, 12); j.th = 3.0f; j.q_match = fs[w].qm.data();
+                pjobs.push_back(j); jw.push_back((int)w);
+            }
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            if (pjobs.empty()) return OSLAM_OK;
+            int rc2 = c.ops.fuse_points_keyed(c.ops.ctx, (int)pjobs.size(), pjobs.data());
+            if (rc2) return rc2;
+            { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
+            pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].pts, fs[w].qm.data()); });
+            merge_upd();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+            return rc2;
+        };
         auto fuse_round = [&](bool into_current, size_t t) -> int {
+            if (fuse_by_id) return fuse_round_by_id(into_current, t);
             jobs.clear(); jw.clear(); fkey.clear();
             pool.parallel_for(nW, [&](int w) {
                 Seq& s = *c.seq[who[w]];

@@ -1057,6 +1057,68 @@ static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_ke
     return OSLAM_OK;
 }
 
+// ORBmatcher::Fuse search half with the candidates named by map-point id: the projection gates run on the device from the resident records, the search reads the
+// resident keyframe; what travels is 5 bytes per candidate up and 4 back
+int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("fuse_points: n > n_sequences"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap, B = n;
+    int maxM = 1;
+    std::vector<int> rec(n);
+    for (int i = 0; i < n; i++) {
+        rec[i] = o->rec_lookup(jobs[i].slot, jobs[i].kf);
+        if (rec[i] < 0 || jobs[i].M < 0 || jobs[i].N < 0 || jobs[i].N > (int)cap) { oslam::set_error("fuse_points: keyframe not resident / bad size"); return OSLAM_E_INVALID; }
+        maxM = std::max(maxM, jobs[i].M);
+    }
+    if (maxM > o->max_local) {
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        oslam_matcher_destroy(o->m_map);
+        o->m_map = nullptr;
+        o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
+        OPS_CHECK(oslam_matcher_create(&o->m_map, o->S, o->cap, o->max_local, o->cfg.device));
+    }
+    OPS_CHECK(o->sync_mp_table());
+    const size_t st = oslam::align_up((size_t)maxM, 64);
+    Layout L;
+    const size_t oN = L.take(4 * B), oM = L.take(4 * B), oSl = L.take(4 * B), oT = L.take(64 * B), oOw = L.take(12 * B), oSeg = L.take(sizeof(CopySegH) * 3 * B),
+                 oIds = L.take(4 * st * B), oEx = L.take(st * B);
+    const size_t head = L.off;
+    const size_t oQ = L.take(sizeof(oslam_proj_query_t) * st * B), oKeys = L.take(sizeof(oslam_keypoint_t) * cap * B), oUr = L.take(4 * cap * B), oDesc = L.take(32 * cap * B);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    uint8_t* Dv = o->up_d;
+    CopySegH* segs = (CopySegH*)(U + oSeg);
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_fuse_pts_t& j = jobs[i];
+        const size_t N = j.N, M = j.M;
+        ((int32_t*)(U + oN))[i] = j.N; ((int32_t*)(U + oM))[i] = j.M; ((int32_t*)(U + oSl))[i] = j.slot;
+        memcpy(U + oT + 64 * i, j.Tcw, 64); memcpy(U + oOw + 12 * i, j.Ow, 12);
+        memcpy(U + oIds + 4 * st * i, j.ids, 4 * M); memcpy(U + oEx + st * i, j.excl, M);
+        segs[3 * i] = {(const uint8_t*)o->rec_keys(rec[i]), Dv + oKeys + sizeof(oslam_keypoint_t) * cap * i, (uint32_t)(sizeof(oslam_keypoint_t) * N), 0};
+        segs[3 * i + 1] = {(const uint8_t*)o->rec_ur(rec[i]), Dv + oUr + 4 * cap * i, (uint32_t)(4 * N), 0};
+        segs[3 * i + 2] = {o->rec_desc(rec[i]), Dv + oDesc + 32 * cap * i, (uint32_t)(32 * N), 0};
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, head, hipMemcpyHostToDevice, o->strm));
+    OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 3 * n, o->strm));
+    OPS_CHECK(oslam_fuse_queries_device(n, (int)st, (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oM), (const int32_t*)(Dv + oIds), Dv + oEx, o->d_mp_tab,
+                                        (const float*)(Dv + oT), (const float*)(Dv + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale, o->cfg.nLevels,
+                                        (oslam_proj_query_t*)(Dv + oQ), o->strm));
+    oslam_match_frames_t fr;
+    fr.keysUn = (const oslam_keypoint_t*)(Dv + oKeys); fr.kp_stride = (int)cap; fr.uRight = (const float*)(Dv + oUr); fr.desc = Dv + oDesc; fr.blocked = nullptr;
+    fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
+    fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
+    OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels, o->strm));
+    const int32_t* d_qm;
+    OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
+    OPS_CHECK(o->ensure_dn(4 * st * B));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
+    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
+    return OSLAM_OK;
+}
+
 int h_bow(void* p, int n, oslam_job_bow_t* jobs) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
@@ -1167,6 +1229,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
-        if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed; }
+        if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
+        if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
     return OSLAM_OK;
 }
