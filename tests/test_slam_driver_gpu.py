@@ -294,8 +294,8 @@ def test_resident_map_point_records_equal_the_host_map():
 
 
 def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
-    """The HIP table keeps the packed SearchLocalPoints arrays of every slot and the keyframes' arrays resident in HBM (content ids / keyed operators);
-    with both switched off it uploads the host arrays of every job as the oracle table receives them.  The two runs must be bit-identical, and the
+    """The HIP table keeps the packed SearchLocalPoints arrays of every slot, the keyframes' arrays and a record per map point resident in HBM (content ids /
+    keyed operators / jobs by map-point id); with all of it switched off it uploads the host arrays of every job as the oracle table receives them.  The two runs must be bit-identical, and the
     driver must actually have reused local maps in the first one (slow motion: most frames keep their local keyframe list)."""
     from slam_common import make_scene_streams, run_scene
     n = 24
@@ -306,6 +306,7 @@ def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
     assert frames >= 2 * (n - 2) and reused >= frames // 3, (reused, frames)
     monkeypatch.setenv("OSLAM_SLAM_NO_RESIDENT_LOCAL", "1")
     monkeypatch.setenv("OSLAM_SLAM_NO_RESIDENT_KF", "1")
+    monkeypatch.setenv("OSLAM_SLAM_NO_RESIDENT_POINTS", "1")   # pose / search_last / Fuse jobs carry their arrays again instead of map-point ids
     b = slam.System(slam.make_config(W, H, 2))
     pb, sb = run_scene(b, seqs, n)
     assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
