@@ -204,6 +204,7 @@ struct Ctx {
     };
     std::vector<Win> winPool;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
+    int mapStep = 0;            // local-mapping passes of this handle (MapPt::updStep)
     bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
     std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
     std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
@@ -372,6 +373,7 @@ struct MpUpdate {
                     const float* o = &out5[(size_t)i * 5];
                     p.normal[0] = o[0]; p.normal[1] = o[1]; p.normal[2] = o[2]; p.maxD = o[3]; p.minD = o[4];
                 }
+                if (do_desc && do_normal) { p.updVer = p.obsVer; p.updStep = c.mapStep; }   // (nothing touches the observation lists while a batch runs)
             }
         });
         return OSLAM_OK;
@@ -670,6 +672,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     Pool& pool = *c.pool;
     const int nW = (int)who.size();
     for (int si : who) c.seq[si]->mapVersion++;   // the map of these sequences changes below: their cached local maps are stale
+    c.mapStep++;
     auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
     pool.parallel_for(nW, [&](int w) {
         Seq& s = *c.seq[who[w]];
@@ -931,8 +934,15 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         upd.clear();
         for (int si : who) {
             Seq& s = *c.seq[si];
-            for (int p : s.map.kfs[s.curKF].mp)
-                if (p >= 0 && !s.map.mps[p].bad) upd.add(si, p);
+            // The reference recomputes descriptor and normal of every point of the keyframe here.  A point that went through a full update earlier in THIS
+            // pass (ProcessNewKeyFrame, triangulation) and whose observation list has not changed since would get the same result: its position, the poses and
+            // the bad flags of the observing keyframes only change later in the pass (local BA, culling).
+            for (int p : s.map.kfs[s.curKF].mp) {
+                if (p < 0) continue;
+                const MapPt& mp = s.map.mps[p];
+                if (mp.bad || (mp.updStep == c.mapStep && mp.updVer == mp.obsVer)) continue;
+                upd.add(si, p);
+            }
         }
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
         if ((rc = upd.run(c, true, true))) return rc;

@@ -120,6 +120,9 @@ struct MapPt {
     int replaced = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
     int lastFrameSeen = 0, trackRefForFrame = 0, baLocalForKF = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    // bookkeeping of the driver (not in the reference): obsVer counts the changes of the observation list; (updVer, updStep) = obsVer and the local-mapping
+    // step of the last full update (descriptor + normal / depth), so that an update whose inputs cannot have changed since is not repeated
+    int obsVer = 0, updVer = -1, updStep = -1;
     int obs_index(int kf) const {
         for (size_t i = 0; i < obs.size(); i++) if (obs[i].first == kf) return obs[i].second;
         return -1;
@@ -184,6 +187,7 @@ struct Map {
         if (at < m.obs.size() && m.obs[at].first == kf) return;
         m.obs.insert(m.obs.begin() + at, std::make_pair(kf, idx));
         m.nObs += kfs[kf].uRight[idx] >= 0 ? 2 : 1;
+        m.obsVer++;
     }
     void set_bad_point(int p) {                      // :253-270
         MapPt& m = mps[p];
@@ -200,6 +204,7 @@ struct Map {
             if (m.obs[i].first == kf) {
                 m.nObs -= kfs[kf].uRight[m.obs[i].second] >= 0 ? 2 : 1;
                 m.obs.erase(m.obs.begin() + i);
+                m.obsVer++;
                 if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
                 if (m.nObs <= 2) bad = true;
                 break;
