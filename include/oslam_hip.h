@@ -469,6 +469,12 @@ int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slot
 int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl, uint8_t* const* d_tab,
                               const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
                               const float* scaleFactors, int nLevels, oslam_proj_query_t* d_q, void* stream);
+/* The arrays of Tracking::SearchLocalPoints for n frames from the resident records: job i = {slot, M, byte offset of its ids (int32 [M]) and of its
+ * Observations() > 0 flags (uint8 [M]) inside d_stage}; writes position, normal, distances, flags and descriptor of every point into the [.][stride] arrays
+ * at row `slot` (the layout oslam_frame_is_in_frustum_batch_resident_device reads). */
+typedef struct oslam_local_gather { int32_t slot, M; uint32_t ids_off, obs_off; } oslam_local_gather_t;
+int oslam_mp_table_local_gather_device(int n, int maxM, const oslam_local_gather_t* d_jobs, const uint8_t* d_stage, uint8_t* const* d_tab, int stride, float* d_Pw,
+                                       float* d_Pn, float* d_maxDist, float* d_minDist, uint8_t* d_obs_gt0, uint8_t* d_mp_desc, void* stream);
 /* Positions of n map points named by (d_slots[i], d_ids[i]) into d_Xw[n][3] (the object map points of ObjectOptimizer::PoseOptimization2). */
 int oslam_mp_table_positions_device(int n, const int32_t* d_slots, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, void* stream);
 int oslam_mp_table_gather_device(int batch, int stride, const int32_t* d_n, const int32_t* d_ids, uint8_t* const* d_tab, float* d_Xw, uint8_t* d_desc, void* stream);

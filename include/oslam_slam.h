@@ -114,6 +114,8 @@ typedef struct oslam_job_search_local {    /* Frame::isInFrustum(pMP, 0.5) over 
     uint8_t* in_view;                      /* out [M]: mbTrackInView */
     int32_t* kp_match;                     /* out [N]: local point index now in mvpMapPoints[k]; < 0 none */
     int32_t nmatches;
+    const int32_t* local_ids;              /* [M] map-point ids of the local points or NULL: with resident_points() Pw, Pn, maxDist, minDist and mp_desc
+                                            * come from the table's records and may be NULL (obs_gt0 is always given: only the driver knows it) */
 } oslam_job_search_local_t;
 
 typedef struct oslam_job_pose {            /* Optimizer::PoseOptimization, src/Optimizer.cc:239 */

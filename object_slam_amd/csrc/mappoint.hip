@@ -365,6 +365,36 @@ int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const i
     return OSLAM_OK;
 }
 
+// eight lanes per local point: lane `part` moves word `part` of the record's first half (position, normal, distances) and of its descriptor
+__global__ __launch_bounds__(256) void k_local_gather(const oslam_local_gather_t* jobs, const uint8_t* stage, uint8_t* const* tab, int stride, float* Pw, float* Pn,
+                                                      float* maxD, float* minD, uint8_t* obs, uint8_t* desc) {
+    const oslam_local_gather_t j = jobs[blockIdx.y];
+    const int q = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (q >= j.M) return;
+    const int id = ((const int32_t*)(stage + j.ids_off))[q];
+    const uint32_t* rec = (const uint32_t*)(tab[j.slot] + (size_t)id * 64);
+    const size_t at = (size_t)j.slot * stride + q;
+    const uint32_t w = rec[part];
+    if (part < 3) ((uint32_t*)Pw)[at * 3 + part] = w;
+    else if (part < 6) ((uint32_t*)Pn)[at * 3 + part - 3] = w;
+    else if (part == 6) ((uint32_t*)minD)[at] = w;
+    else ((uint32_t*)maxD)[at] = w;
+    ((uint32_t*)desc)[at * 8 + part] = rec[8 + part];
+    if (part == 0) obs[at] = (stage + j.obs_off)[q];
+}
+
+int oslam_mp_table_local_gather_device(int n, int maxM, const oslam_local_gather_t* d_jobs, const uint8_t* d_stage, uint8_t* const* d_tab, int stride, float* d_Pw,
+                                       float* d_Pn, float* d_maxDist, float* d_minDist, uint8_t* d_obs_gt0, uint8_t* d_mp_desc, void* stream) {
+    if (n < 0 || maxM < 0 || (n > 0 && maxM > 0 && (!d_jobs || !d_stage || !d_tab || stride < maxM || !d_Pw || !d_Pn || !d_maxDist || !d_minDist || !d_obs_gt0 || !d_mp_desc))) {
+        set_error("mp_table_local_gather: bad argument"); return OSLAM_E_INVALID;
+    }
+    if (n == 0 || maxM == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_local_gather, dim3(div_up(maxM, 32), n), dim3(256), 0, (hipStream_t)stream, d_jobs, d_stage, d_tab, stride, d_Pw, d_Pn, d_maxDist, d_minDist,
+                       d_obs_gt0, d_mp_desc);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 __global__ __launch_bounds__(256) void k_mp_table_positions(int n, const int32_t* slots, const int32_t* ids, uint8_t* const* tab, float* Xw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;

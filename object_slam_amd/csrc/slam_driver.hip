@@ -1278,9 +1278,17 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     // (here and, by content id, in the operator table's resident copy) until the keyframe list or the map changes.
     const int M = (int)s.localMPs.size();
     if (!s.locReused) {
-        s.locPw.resize((size_t)M * 3 + 3); s.locPn.resize((size_t)M * 3 + 3); s.locMax.resize(M + 1); s.locMin.resize(M + 1); s.locObs.resize(M + 1);
-        s.locDesc.resize((size_t)M * 32 + 32);
-        for (int q = 0; q < M; q++) {
+        s.locObs.resize(M + 1);
+        if (c.residentPts) {   // the table gathers the points' arrays from its records: only Observations() > 0 is the driver's to tell
+            for (int q = 0; q < M; q++) {
+                if (q + kPF < M) __builtin_prefetch((const char*)&m.mps[s.localMPs[q + kPF]] + 64);
+                s.locObs[q] = m.mps[s.localMPs[q]].nObs > 0;
+            }
+        } else {
+            s.locPw.resize((size_t)M * 3 + 3); s.locPn.resize((size_t)M * 3 + 3); s.locMax.resize(M + 1); s.locMin.resize(M + 1);
+            s.locDesc.resize((size_t)M * 32 + 32);
+        }
+        for (int q = 0; q < M && !c.residentPts; q++) {
             prefetch_ahead(m.mps, s.localMPs, q, M);
             const MapPt& mp = m.mps[s.localMPs[q]];
             for (int d = 0; d < 3; d++) { s.locPw[(size_t)q * 3 + d] = mp.pos[d]; s.locPn[(size_t)q * 3 + d] = mp.normal[d]; }
@@ -1300,8 +1308,9 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     }
     s.jInView.assign(M + 1, 0); s.jMatch.assign(f.N + 1, -1);
     oslam_job_search_local_t& j = s.jLoc;
-    j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.Pw = s.locPw.data(); j.Pn = s.locPn.data(); j.maxDist = s.locMax.data();
-    j.minDist = s.locMin.data(); j.obs_gt0 = s.locObs.data(); j.mp_desc = s.locDesc.data(); j.skip = s.jSkip.data(); j.content_id = s.locContentId;
+    j.slot = i; j.cur = &f.view; j.blocked = s.jBlocked.data(); j.M = M; j.obs_gt0 = s.locObs.data(); j.skip = s.jSkip.data(); j.content_id = s.locContentId;
+    if (c.residentPts) { j.Pw = nullptr; j.Pn = nullptr; j.maxDist = nullptr; j.minDist = nullptr; j.mp_desc = nullptr; j.local_ids = s.localMPs.data(); }
+    else { j.Pw = s.locPw.data(); j.Pn = s.locPn.data(); j.maxDist = s.locMax.data(); j.minDist = s.locMin.data(); j.mp_desc = s.locDesc.data(); j.local_ids = nullptr; }
     memcpy(j.Tcw, f.pose.Tcw.m, 64);
     j.th = f.id < s.lastRelocFrameId + 2 ? 5.f : (c.stereo ? 1.f : 3.f);   // th = 1, RGB-D 3, after a relocalisation 5 (:1450-1455)
     j.in_view = s.jInView.data(); j.kp_match = s.jMatch.data(); j.nmatches = 0;

@@ -431,14 +431,25 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     std::vector<int> fresh;
     std::vector<size_t> foff;
     size_t fbytes = 0;
+    bool by_id = o->mp_tab_on;   // the fresh jobs name their points: the slot's arrays are gathered from the resident records (5 bytes per point travel, not 65)
     for (int i = 0; i < n; i++) {
         const oslam_job_search_local_t& j = jobs[i];
         if (resident && j.content_id != 0 && o->loc_id[j.slot] == j.content_id) continue;
-        fresh.push_back(i); foff.push_back(fbytes);
-        fbytes += oslam::align_up(65 * (size_t)j.M + 6 * 16, 64);   // six sub-arrays, each starting on a 16-byte boundary
+        fresh.push_back(i);
+        by_id = by_id && j.local_ids != nullptr;
+    }
+    if (by_id && !fresh.empty()) OPS_CHECK(o->sync_mp_table());
+    int freshMaxM = 0;
+    for (int i : fresh) {
+        const oslam_job_search_local_t& j = jobs[i];
+        if (!by_id && (!j.Pw || !j.Pn || !j.maxDist || !j.minDist || !j.mp_desc)) { oslam::set_error("search_local: job without arrays and without usable map-point ids"); return OSLAM_E_INVALID; }
+        foff.push_back(fbytes);
+        fbytes += by_id ? oslam::align_up(4 * (size_t)j.M, 16) + oslam::align_up((size_t)j.M, 64) : oslam::align_up(65 * (size_t)j.M + 6 * 16, 64);   // (six sub-arrays, each on a 16-byte boundary)
+        freshMaxM = std::max(freshMaxM, j.M);
     }
     Layout L;
-    const size_t oM = L.take(4 * S), oTc = L.take(64 * S), oTh = L.take(4 * S), oBl = L.take(cap * S), oSk = L.take(st * S), oSeg = L.take(sizeof(CopySegH) * 6 * fresh.size());
+    const size_t oM = L.take(4 * S), oTc = L.take(64 * S), oTh = L.take(4 * S), oBl = L.take(cap * S), oSk = L.take(st * S),
+                 oSeg = L.take(by_id ? sizeof(oslam_local_gather_t) * fresh.size() : sizeof(CopySegH) * 6 * fresh.size());
     const size_t small_bytes = L.off;
     const size_t oF = L.take(fbytes);
     OPS_CHECK(o->ensure_up(L.off));
@@ -461,6 +472,13 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         const oslam_job_search_local_t& j = jobs[fresh[q]];
         const size_t b = j.slot, M = j.M;
         uint8_t* at = U + oF + foff[q];
+        if (by_id) {
+            const size_t ooff = oslam::align_up(4 * M, 16);
+            memcpy(at, j.local_ids, 4 * M); memcpy(at + ooff, j.obs_gt0, M);
+            ((oslam_local_gather_t*)(U + oSeg))[q] = {(int32_t)b, (int32_t)M, (uint32_t)foff[q], (uint32_t)(foff[q] + ooff)};
+            o->loc_id[b] = j.content_id;
+            return;
+        }
         const uint8_t* dv = Dv + oF + foff[q];
         CopySegH* sg = (CopySegH*)(U + oSeg) + 6 * (size_t)q;
         const void* src[6] = {j.Pw, j.Pn, j.maxDist, j.minDist, j.obs_gt0, j.mp_desc};
@@ -476,7 +494,10 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         o->loc_id[b] = j.content_id;
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, fresh.empty() ? small_bytes : L.off, hipMemcpyHostToDevice, o->strm));
-    if (!fresh.empty()) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 6 * (int)fresh.size(), o->strm));   // (a zero-byte segment's workgroup returns at once)
+    if (!fresh.empty() && by_id)
+        OPS_CHECK(oslam_mp_table_local_gather_device((int)fresh.size(), freshMaxM, (const oslam_local_gather_t*)(Dv + oSeg), Dv + oF, o->d_mp_tab, (int)lst, o->loc_Pw(), o->loc_Pn(),
+                                                     o->loc_Max(), o->loc_Min(), o->loc_Obs(), o->loc_Desc(), o->strm));
+    else if (!fresh.empty()) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 6 * (int)fresh.size(), o->strm));   // (a zero-byte segment's workgroup returns at once)
     o->t_begin();
     OPS_CHECK(oslam_frame_is_in_frustum_batch_resident_device((int)S, (int)lst, (int)st, (const int32_t*)(Dv + oM), o->loc_Pw(), o->loc_Pn(), o->loc_Max(), o->loc_Min(),
                                                               o->loc_Obs(), o->loc_Desc(), Dv + oSk, (const float*)(Dv + oTc), (const float*)(Dv + oTh), o->K5,
