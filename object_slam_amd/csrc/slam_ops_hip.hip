@@ -3,6 +3,7 @@
 // translation units).  No CPU fallback: creation fails without a HIP device.  Never includes oracle/.
 #include <algorithm>
 #include <cmath>
+#include <atomic>
 #include <unordered_map>
 #include <vector>
 
@@ -785,13 +786,21 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     // instead of 32, and the caller did not have to collect them
     std::vector<int32_t> rec;
     bool keyed = obs_key && j->do_desc && dtotal > 0;
-    if (keyed) {
+    if (keyed) {   // (hundreds of thousands of observations per call: the lookup runs on the shared workers)
         rec.resize(2 * dtotal);
-        for (size_t e = 0; e < dtotal && keyed; e++) {
-            const int r = o->rec_lookup(obs_key[3 * e], obs_key[3 * e + 1]);
-            if (r < 0 || obs_key[3 * e + 2] < 0 || obs_key[3 * e + 2] >= o->cap) keyed = false;
-            rec[2 * e] = r; rec[2 * e + 1] = obs_key[3 * e + 2];
-        }
+        const size_t chunk = 16384, nch = (dtotal + chunk - 1) / chunk;
+        std::atomic<int> missing{0};
+        o->pool->parallel_for((int)nch, [&](int ch) {
+            const size_t e0 = (size_t)ch * chunk, e1 = std::min(dtotal, e0 + chunk);
+            bool ok = true;
+            for (size_t e = e0; e < e1; e++) {
+                const int r = o->rec_lookup(obs_key[3 * e], obs_key[3 * e + 1]);
+                if (r < 0 || obs_key[3 * e + 2] < 0 || obs_key[3 * e + 2] >= o->cap) ok = false;
+                rec[2 * e] = r; rec[2 * e + 1] = obs_key[3 * e + 2];
+            }
+            if (!ok) missing.fetch_add(1, std::memory_order_relaxed);
+        });
+        if (missing.load() > 0) keyed = false;
         if (!keyed && !j->obs_desc) { oslam::set_error("mp_update: observation of a keyframe that is not resident"); return OSLAM_E_INVALID; }
     }
     const bool table = o->mp_tab_on && j->items != nullptr;
