@@ -652,7 +652,10 @@ constexpr int kLinThreads = 4 * kWPt;   // 512
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w);
 __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
 
-__global__ __launch_bounds__(kLinThreads) void k_w_lin(const LbaProblem* probs, const LbaWide* ws) {
+#ifndef OSLAM_LIN_MIN_WAVES
+#define OSLAM_LIN_MIN_WAVES 4   // 128 VGPRs (96 B of scratch per lane) so that two 512-thread workgroups share a CU; 1 = the compiler's 166 VGPRs, one workgroup per CU
+#endif
+__global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(const LbaProblem* probs, const LbaWide* ws) {
     const LbaProblem& pr = probs[blockIdx.y];
     const LbaWide& w = ws[blockIdx.y];
     const LbaCtrl* ct = w.ct;
