@@ -93,6 +93,30 @@ def test_table_write_and_gathers():
             assert o[2][b, i].item() == inv[keys["octave"][s_, i]] and o[3][b, i].item() == int(pid2[b, i] >= 0)
             want_x = tab_np[s_][pid2[b, i]][:12].view(np.float32) if pid2[b, i] >= 0 else np.zeros(3, np.float32)
             assert np.array_equal(o[0][b, i].cpu().numpy().view(np.uint32), want_x.view(np.uint32))
+    # ---- oslam_mp_table_local_gather_device: two jobs fill the rows of their slots in the [S][stride] layout of SearchLocalPoints
+    lst, Ms, sl2 = 256, [200, 64], [2, 0]
+    stage = np.zeros(4096, np.uint8)
+    jobs = np.zeros(2, np.dtype([("slot", "i4"), ("M", "i4"), ("ids_off", "u4"), ("obs_off", "u4")]))
+    lid, lob, off = [], [], 0
+    for q in range(2):
+        a, b_ = rng.integers(0, R, Ms[q]).astype(np.int32), rng.integers(0, 2, Ms[q]).astype(np.uint8)
+        jobs[q] = (sl2[q], Ms[q], off, off + 1024)
+        stage[off:off + 4 * Ms[q]] = a.view(np.uint8); stage[off + 1024:off + 1024 + Ms[q]] = b_
+        lid.append(a); lob.append(b_); off += 2048
+    dPw, dPn = torch.zeros((S, lst, 3), dtype=torch.float32, device="cuda"), torch.zeros((S, lst, 3), dtype=torch.float32, device="cuda")
+    dMx, dMn = torch.zeros((S, lst), dtype=torch.float32, device="cuda"), torch.zeros((S, lst), dtype=torch.float32, device="cuda")
+    dOb, dDe = torch.zeros((S, lst), dtype=torch.uint8, device="cuda"), torch.zeros((S, lst, 32), dtype=torch.uint8, device="cuda")
+    k5 = [t(jobs.view(np.uint8)), t(stage)]
+    check(L.oslam_mp_table_local_gather_device(2, max(Ms), vp(k5[0]), vp(k5[1]), vp(ptrs), lst, vp(dPw), vp(dPn), vp(dMx), vp(dMn), vp(dOb), vp(dDe), None))
+    torch.cuda.synchronize()
+    for q in range(2):
+        s_ = sl2[q]
+        for i in range(Ms[q]):
+            r = tab_np[s_][lid[q][i]]
+            f = r[:32].view(np.float32)
+            assert np.array_equal(dPw[s_, i].cpu().numpy().view(np.uint32), f[0:3].view(np.uint32)) and np.array_equal(dPn[s_, i].cpu().numpy().view(np.uint32), f[3:6].view(np.uint32))
+            assert dMn[s_, i].cpu().numpy().view(np.uint32) == f[6:7].view(np.uint32) and dMx[s_, i].cpu().numpy().view(np.uint32) == f[7:8].view(np.uint32)
+            assert dOb[s_, i].item() == lob[q][i] and np.array_equal(dDe[s_, i].cpu().numpy(), r[32:])
 
 
 def test_bow_nodes_match_the_tree_descent():
