@@ -61,7 +61,9 @@ def launch_ranks(n):
 # --------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the same driver over the CPU oracle's operator table (test infrastructure; "port"), bounded sample
 # --------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, seq, n_frames):
+def cpu_baseline(wl, seq, first, n_timed):
+    """The same driver over the CPU oracle's operator table on one core: frames [0, first) of the sequence untimed (the map reaches the state the GPU leg's
+    sequences have when ITS timed region starts), then `n_timed` frames timed — the same frame range as the GPU leg's timed steps and the frames after them."""
     import ctypes as C
     from object_slam_amd import slam
     from object_slam_amd.e2e import horn_align_ate
@@ -72,28 +74,47 @@ def cpu_baseline(wl, seq, n_frames):
     assert O.lib().oo_slam_make_ops(C.byref(cfg), C.byref(ops)) == 0
     sysm = slam.System(cfg, ops)
     per = []
-    n = min(n_frames, len(seq["gray"]))
-    t0 = time.perf_counter()
-    for t in range(n):
-        t1 = time.perf_counter()
+    n = min(first + n_timed, len(seq["gray"]))
+    has_masks = seq.get("masks") is not None
+
+    def step(t):
         if wl.sensor == slam.STEREO:
             sysm.TrackStereo([seq["gray"][t]], [seq["right"][t]], [t / wl.fps])
         else:
-            sysm.TrackRGBD([seq["gray"][t]], [seq["depth"][t]], [t / wl.fps])
+            objs = [dict(masks=[seq["masks"][t, o] for o in range(seq["masks"].shape[1])], track_ids=seq["track_ids"], labels=seq.get("labels"))] if has_masks else None
+            if objs is not None and objs[0]["labels"] is None:
+                objs[0].pop("labels")
+            sysm.TrackRGBD([seq["gray"][t]], [seq["depth"][t]], [t / wl.fps], objects=objs)
+
+    tp = time.perf_counter()
+    for t in range(first):
+        step(t)
+    tp = time.perf_counter() - tp
+    w0 = sysm.lba_window_stats(0)
+    t0 = time.perf_counter()
+    for t in range(first, n):
+        t1 = time.perf_counter()
+        step(t)
         per.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
+    w1 = sysm.lba_window_stats(0)
     _, Twc = sysm.trajectory(0)
     T0inv = np.linalg.inv(seq["Twc"][0])
     gt = np.array([T0inv @ x for x in seq["Twc"][:len(Twc)]])
     st = sysm.stats(0)
     per = np.array(per)
+    nw = max(1, w1["windows"] - w0["windows"])
     # the reference prints median and mean tracking time per frame (Examples/RGB-D/rgbd_tum.cc:126-134)
-    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of one sequence of the same workload through the same driver over the CPU oracle's operator table, %.1f s; tracking AND local "
-                      "mapping run on ONE core one after the other (the reference overlaps LocalMapping on a second thread and, for stereo, extracts the two images "
-                      "on two threads: <= 3 busy cores, so its wall time per frame lies between the median and the mean below)" % (n, dt),
+    return {"value": round((n - first) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "frames %d..%d of one sequence of the same workload (the GPU leg's timed frame range and the frames after it) through the same driver over the CPU oracle's "
+                      "operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local mapping run on ONE core one after the other (the reference overlaps "
+                      "LocalMapping on a second thread and, for stereo, extracts the two images on two threads: <= 3 busy cores, so its wall time per frame lies between the "
+                      "median and the mean below)" % (first, n, dt, tp),
             "mean_ms_per_frame": round(float(per.mean()) * 1e3, 2), "median_ms_per_frame": round(float(np.median(per)) * 1e3, 2),
-            "ate_rmse_m": round(horn_align_ate(Twc[:, :, 3], gt[:, :3, 3]), 6), "keyframes": st["keyframes_created"], "local_bas": st["local_bas"]}
+            "ate_rmse_m": round(horn_align_ate(Twc[:, :, 3], gt[:, :3, 3]), 6), "keyframes": st["keyframes_created"], "local_bas": st["local_bas"],
+            "lba_windows_timed": {"windows": w1["windows"] - w0["windows"], "mean_local_kfs": round((w1["local_kfs"] - w0["local_kfs"]) / nw, 2),
+                                  "mean_fixed_kfs": round((w1["fixed_kfs"] - w0["fixed_kfs"]) / nw, 2), "mean_points": round((w1["points"] - w0["points"]) / nw, 1),
+                                  "mean_edges": round((w1["edges"] - w0["edges"]) / nw, 1)}}
 
 
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -254,16 +275,47 @@ def _pmc(kernel, field="bytes_per_launch"):
         return None
 
 
+def physical_cores():
+    """The CPUs this process may run on, grouped by physical core (SMT siblings together), cores in (package, core) order."""
+    allowed = sorted(os.sched_getaffinity(0))
+    groups = {}
+    for c in allowed:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            key = (int(open(base + "physical_package_id").read()), int(open(base + "core_id").read()))
+        except Exception:
+            key = (0, c)
+        groups.setdefault(key, []).append(c)
+    return [groups[k] for k in sorted(groups)]
+
+
+def pin_rank_cpus(local_rank, local_world, per_rank_cores):
+    """Gives every rank of a multi-rank run a disjoint, contiguous set of physical cores (both SMT threads of a core go to the same rank; contiguous cores
+    share a socket / NUMA node) — before the process touches the GPU or starts a thread, so the render pool, the driver's workers and torch inherit it.
+    A single rank is left where the launcher put it.  Returns the number of CPUs the rank may use."""
+    cores = physical_cores()
+    if local_world <= 1:
+        return sum(len(c) for c in cores)
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores[-per:]
+    if per_rank_cores:
+        mine = mine[:max(1, per_rank_cores)]
+    cpus = sorted(c for g in mine for c in g)
+    os.sched_setaffinity(0, cpus)
+    return len(cpus)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=("rgbd", "stereo"), default="rgbd")
-    ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 4096 RGB-D / 512 stereo; measured 512 -> 9 k, 1024 -> 12 k, 2048 -> 15 k, 4096 -> 16 k, "
-                                                        "8192 -> 17-20 k RGB-D frames/s: the per-stage fixed costs of the lockstep driver are amortised over more sequences)")
+    ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps before the warm-up that bring every sequence's map to its steady state (default: 200 for the "
+                                                             "RGB-D stream = SURVEY.md §8(d) frame >= 200, 40 for the stereo street); 0 = the cold-start regime of round 2")
+    ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 4096 RGB-D / 512 stereo)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8 / 4)")
-    ap.add_argument("--cpu-frames", type=int, default=240, help="frames of one sequence through the CPU oracle table for cpu_baseline (~11 s of CPU work)")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
@@ -274,25 +326,35 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    # a disjoint CPU set per rank, before anything forks, starts a thread or touches the GPU
+    ncpu = pin_rank_cpus(local_rank, local_world, int(os.environ.get("OSLAM_BENCH_CORES_PER_RANK", "0")))
+    share = min(16, ncpu)        # host threads of this rank: 16 = the box's CPU share per GPU
 
     from object_slam_amd import seqbench, slam
     cores = os.cpu_count() or 1
-    share = max(1, cores // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
-    wl_rgbd, wl_st = seqbench.rgbd_workload(n_base=16, stagger=12), seqbench.stereo_workload()
-    head, second = (wl_rgbd, wl_st) if args.workload == "rgbd" else (wl_st, wl_rgbd)
-    S = args.seqs or (4096 if head is wl_rgbd else 512)
-    G = args.handles or (8 if head is wl_rgbd else 4)
+    stereo_head = args.workload == "stereo"
+    preroll = args.preroll if args.preroll >= 0 else (40 if stereo_head else 200)
+    wl_rgbd = seqbench.rgbd_workload(speed=1.0, n_base=8, stagger=24)
+    wl_st = seqbench.stereo_workload()
+    head, second = (wl_st, wl_rgbd) if stereo_head else (wl_rgbd, wl_st)
+    S = args.seqs or (512 if stereo_head else 4096)
+    G = args.handles or (4 if stereo_head else 8)
     extras_on = rank == 0 and world == 1 and not args.no_extras
-    S2, G2 = (512, 4) if second is wl_st else (1024, 4)
-    n_frames = args.warmup + args.steps
+    host_phase = extras_on and not stereo_head            # the same warmed sequences continued with host-resident inputs
+    post_frames = (2 + args.steps) if host_phase else 0
+    n_frames = preroll + args.warmup + args.steps + post_frames
+    log = (lambda m: (sys.stderr.write("[bench] " + m + "\n"), sys.stderr.flush())) if rank == 0 else None
     # ---- render the input streams on the host cores BEFORE the process touches the GPU (worker processes are forked) ----
     t_gen = time.perf_counter()
-    seq_head = seqbench.base_sequences(head, rank, S, n_frames, workers=min(share, 16))
-    seq_second = None if args.no_extras else seqbench.base_sequences(second, rank, S2, n_frames, workers=min(share, 16))   # every rank runs the second figure too
-    cpu_seq = None
-    if extras_on and not args.no_cpu_baseline and args.cpu_frames > len(seq_head[0]["gray"]):
-        cpu_seq = head.make_sequence(0, args.cpu_frames)
+    seq_head = seqbench.base_sequences(head, rank, S, n_frames, workers=share)
+    seq_second = None
+    if extras_on:            # second figure: the other stream shape, cold start (rank 0 of a single-rank run only)
+        S2, G2 = (256, 4) if second is wl_st else (1024, 4)
+        seq_second = seqbench.base_sequences(second, rank, S2, args.warmup + args.steps, workers=share)
     t_gen = time.perf_counter() - t_gen
+    if log:
+        log("inputs rendered in %.1f s" % t_gen)
 
     import torch
     import torch.distributed as dist
@@ -315,112 +377,165 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    threads_per_handle = max(1, min(16, share) // G)
     kt = {}
 
-    def run(wl, seqs, S_, G_, tag):
+    def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None):
         def reset_timers(systems):
             for sy in systems:
                 sy.kernel_times(True)
+        threads = int(os.environ.get("OSLAM_BENCH_HOST_THREADS", "0")) or max(1, share // G_)
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
-                                                      host_threads=int(os.environ.get("OSLAM_BENCH_HOST_THREADS", "0")) or max(1, min(16, share) // G_), sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl")
-        tot = {}
-        for sy in systems:
-            for g, v in sy.kernel_times(False).items():
-                a = tot.setdefault(g, dict(ms=0.0, launches=0.0, work=0.0))
-                for k in v:
-                    a[k] += v[k]
+                                                      host_threads=threads, sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl",
+                                                      preroll=preroll_, post_frames=post_frames_, post=post_, progress=log)
+        tot = extra.get("post", {}).get("kernel_times_timed") if isinstance(extra.get("post"), dict) else None
+        if tot is None:
+            tot = {}
+            for sy in systems:
+                for g, v in sy.kernel_times(False).items():
+                    a = tot.setdefault(g, dict(ms=0.0, launches=0.0, work=0.0))
+                    for k in v:
+                        a[k] += v[k]
         kt[tag] = tot
-        stages = {}
+        stages, cores_s = {}, {}
         for sy in systems:
             for k, v in sy.stage_seconds().items():
                 stages[k] = stages.get(k, 0.0) + v
-        summ["stage_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in stages.items()}
-        cores_s = {}
-        for sy in systems:
             for k, v in sy.stage_seconds(cpu=True).items():
                 cores_s[k] = cores_s.get(k, 0.0) + v
+        summ["stage_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in stages.items()}
         summ["stage_core_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in cores_s.items()}
         reuse = [sy.local_map_reuse() for sy in systems]
         summ["local_map_reuse_frac"] = round(sum(r[0] for r in reuse) / max(1, sum(r[1] for r in reuse)), 4)
+        summ["host_threads_per_handle"] = threads
+        summ["post"] = extra.get("post")
         for sy in systems:
             sy.close()
         return summ, rec
 
-    summ, rec = run(head, seq_head, S, G, "head")
-    second_out = None
-    if seq_second is not None:
+    def host_inputs_phase(ctx):
+        """The warmed sequences continued for 2 + K more steps with the inputs in pinned HOST memory (gray u8, raw 16-bit depth, one-bit-per-pixel masks):
+        the upload is inside the timed region (the kernels read the pinned buffers over PCIe where they are)."""
+        systems = ctx["systems"]
+        ktm = {}
+        for sy in systems:                      # the headline's kernel groups end here
+            for g, v in sy.kernel_times(True).items():
+                a = ktm.setdefault(g, dict(ms=0.0, launches=0.0, work=0.0))
+                for k in v:
+                    a[k] += v[k]
+        out = {"kernel_times_timed": ktm}
+        try:
+            hc, nbytes = seqbench.host_input_calls(ctx, n_frames - post_frames, post_frames)
+            t0 = n_frames - post_frames
+            ctx["phase"](t0, t0 + 2, hc)
+            ctx["sync"]()
+            w0 = ctx["window_totals"]()
+            ts = time.perf_counter()
+            ctx["phase"](t0 + 2, t0 + post_frames, hc)
+            ctx["sync"]()
+            dt = time.perf_counter() - ts
+            fr = S * args.steps
+            out["host_inputs"] = {"frames_per_s": round(fr / dt, 1), "ms_per_step": round(dt / args.steps * 1e3, 3), "steps": args.steps,
+                                  "bytes_per_frame": int(nbytes), "pcie_GBs": round(nbytes * fr / dt / 1e9, 2),
+                                  "lba_windows_timed": seqbench.window_stats(ctx["window_totals"](), w0),
+                                  "inputs": "pinned host memory: 8-bit gray, raw 16-bit depth (DepthMapFactor 5000, src/Tracking.cc:262), 3 instance masks as one bit per "
+                                            "pixel; read by the Frame::Frame / object kernels over PCIe inside the timed region, the same warmed sequences as the headline"}
+        except Exception as ex:      # the extra leg must not break the headline line
+            out["host_inputs"] = {"error": repr(ex)}
+        return out
+
+    summ, rec = run(head, seq_head, S, G, "head", preroll, post_frames, host_inputs_phase if host_phase else None)
+    second_out = cold = None
+    if extras_on:
+        if log:
+            log("headline done: %.1f frames/s" % summ["frames_per_s"])
+        if preroll > 0:     # the cold-start regime of the earlier rounds on the same streams (maps at most warmup + steps frames old)
+            c, _ = run(head, seq_head, S, G, "cold")
+            cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
+                    "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
         s2, _ = run(second, seq_second, S2, G2, "second")
-        second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe" % (second.name, S2, G2, second.nFeatures),
+        second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe, cold start (steps %d..%d)"
+                                  % (second.name, S2, G2, second.nFeatures, args.warmup, args.warmup + args.steps),
                       "frames_per_s": round(s2["frames_per_s"], 1), "ms_per_step": round(s2["ms_per_step"], 3), "ate_rmse_m": round(s2["ate_rmse_m"], 6),
-                      "keyframes": s2["keyframes"], "local_bas": s2["local_bas"], "lost_frames": s2["lost_frames"],
+                      "keyframes": s2["keyframes"], "local_bas": s2["local_bas"], "lost_frames": s2["lost_frames"], "lba_windows_timed": s2["lba_windows_timed"],
                       "stage_seconds_sum_over_handles": s2["stage_seconds_sum_over_handles"]}
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel group of the timed region (HIP events on the launch streams, rank 0) ----
-        k = kt["head"]
-        names = {"frames": ("hbm", "Frame::Frame (k_resize_lds, k_fast_cells_wave, k_blur_strip, k_octree, k_orient_describe, undistort, depth lookup%s)"
-                            % (", stereo association" if head is wl_st else "")),
-                 "pose_opt": ("mfma", "k_pose_optimize"),
-                 "lba": ("mfma", "local BA, every LM trial of all windows as eight launches (k_w_lin, k_w_ctrlA, k_w_edgeW, k_w_schur, k_w_chol / k_w_chol_mfma, "
-                                 "k_w_update, k_w_eval, k_w_ctrlB)")}
-        dom = max(names, key=lambda g: k[g]["ms"])
-        bound, kname = names[dom]
-        ms, launches, work = k[dom]["ms"], max(k[dom]["launches"], 1.0), k[dom]["work"]
-        if bound == "hbm":
-            achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
-        group_tab = {}
-        for g in ("frames", "pose_opt", "lba", "search"):
-            v = k[g]
-            e = {"device_ms": round(v["ms"], 3), "launches": int(v["launches"])}
-            if g == "frames" and v["ms"] > 0:
-                e["GBs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1)
-            if g in ("pose_opt", "lba") and v["ms"] > 0:
-                e["fp64_TFLOPs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e12, 4)
-                e["flop"] = int(v["work"])
-            group_tab[g] = e
-        busy = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
-        roof = {"bound": bound, "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
-                "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else None, "launch_us": round(ms / launches * 1e3, 1),
-                "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
-                "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4),
-                "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "
-                        "iterations / trials the kernels report"}
+        roof = roofline_of(kt["head"], summ, head is wl_st)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(head, cpu_seq if cpu_seq is not None else seq_head[0], args.cpu_frames)
+            if log:
+                log("CPU baseline ...")
+            cpu = cpu_baseline(head, seq_head[0], preroll + args.warmup, args.cpu_frames or (len(seq_head[0]["gray"]) - preroll - args.warmup))
         front = None
         if extras_on and head is wl_rgbd:
             try:
                 q = seq_head[0]
-                front = frontend_stage(q["gray"], q["Twc"], q["depth"], local_rank, args.steps)
+                front = frontend_stage(q["gray"][:40], q["Twc"][:40], q["depth"][:40], local_rank, args.steps)
             except Exception as ex:      # the stage entry must not break the headline line
                 front = {"error": repr(ex)}
+        regime = ("steady state: every sequence is advanced %d untimed steps before the warm-up, so the timed steps are frames %d..%d of every sequence (SURVEY.md §8(d): "
+                  "frame >= 200 of the S1 stream at <= 2 cm / 0.5 deg per frame)" % (preroll, preroll + args.warmup, preroll + args.warmup + args.steps)) if preroll > 0 else \
+                 ("cold start: steps %d..%d of empty maps" % (args.warmup, args.warmup + args.steps))
         out = {"metric": "frames/sec tracking+localBA", "value": round(summ["frames_per_s"], 1), "unit": "frames/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(summ["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "%s stream through the oslam_slam driver (Tracking::Track + LocalMapping::Run incl. LocalBundleAdjustment on every keyframe): "
-                                      "%d sequences per GPU in %d handles (one host thread + %d workers each), %d ORB features, images resident in HBM; "
-                                      "BASELINE.json configs[%s]" % (head.name, S, G, threads_per_handle, head.nFeatures, "2" if head is wl_rgbd else "3]/[4"),
-                          "sequences_per_gpu": S, "frames_per_step": S * world, "host_cores": cores,
+                                      "%d sequences per GPU in %d handles (one host thread + %d workers each), %d ORB features, images resident in HBM; %s; "
+                                      "BASELINE.json configs[%s]" % (head.name, S, G, summ["host_threads_per_handle"] - 1, head.nFeatures, regime, "2" if head is wl_rgbd else "3]/[4"),
+                          "regime": "steady_state" if preroll > 0 else "cold_start", "preroll_steps": preroll, "preroll_s": round(summ["preroll_s"], 1),
+                          "sequences_per_gpu": S, "frames_per_step": S * world, "host_cores": cores, "host_cpus_of_rank": ncpu,
                           "arithmetic": "u8/int front-end, fp64 optimisers (dtype names the optimisers' type)",
                           "parallelism": "independent sequences sharded over ranks (sequence i -> rank i mod N); no data-path collective"},
+               "lba_windows_timed": summ["lba_windows_timed"],
                "ate_rmse_m": round(summ["ate_rmse_m"], 6), "keyframes": summ["keyframes"], "local_bas": summ["local_bas"], "lost_frames": summ["lost_frames"],
                "map_violations": summ["map_violations"], "semantic_edges": summ["semantic_edges"],
                "stage_seconds_sum_over_handles": summ["stage_seconds_sum_over_handles"],
                "stage_core_seconds_sum_over_handles": summ["stage_core_seconds_sum_over_handles"],
                "local_map_reuse_frac": summ["local_map_reuse_frac"],
                "per_rank": [{"rank": int(r[0]), "frames": int(r[2]), "elapsed_s": round(float(r[3]), 4), "local_bas": int(r[5]), "ate_rmse_m": round(float(r[7]), 6)} for r in rec],
-               "roofline": roof, "cpu_baseline": cpu, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
+               "roofline": roof, "cpu_baseline": cpu,
+               "host_inputs": (summ.get("post") or {}).get("host_inputs") if isinstance(summ.get("post"), dict) else None,
+               "cold_start": cold, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
                "input_render_s": round(t_gen, 1)}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_of(k, summ, stereo):
+    """Roofline of the dominant kernel group of the timed region (HIP events on the launch streams, rank 0)."""
+    names = {"frames": ("hbm", "Frame::Frame (k_resize_lds, k_fast_cells_wave, k_blur_strip, k_octree, k_orient_describe, undistort, depth lookup%s)"
+                        % (", stereo association" if stereo else "")),
+             "pose_opt": ("fp64-valu", "k_pose_optimize"),
+             "lba": ("fp64-valu", "local BA (lba.hip)")}
+    dom = max(names, key=lambda g: k[g]["ms"])
+    bound, kname = names[dom]
+    ms, launches, work = k[dom]["ms"], max(k[dom]["launches"], 1.0), k[dom]["work"]
+    if bound == "hbm":
+        achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+    else:
+        achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP64_PEAK_TFLOPS, "TFLOP/s"
+    group_tab = {}
+    for g, v in k.items():
+        e = {"device_ms": round(v["ms"], 3), "launches": int(v["launches"])}
+        if g == "frames" and v["ms"] > 0:
+            e["GBs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e9, 1)
+        if g in ("pose_opt", "lba") and v["ms"] > 0:
+            e["fp64_TFLOPs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e12, 4)
+            e["flop"] = int(v["work"])
+        group_tab[g] = e
+    busy = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
+    return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4; the kernels of this group issue "
+            "v_fma_f64 / v_mul_f64 / v_add_f64 — no MFMA instruction at these system sizes (the matrix-core Cholesky serves reduced systems beyond the LDS-resident size)",
+            "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
+            "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else None, "launch_us": round(ms / launches * 1e3, 1),
+            "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
+            "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4),
+            "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "
+                    "iterations / trials the kernels report"}
 
 
 if __name__ == "__main__":

@@ -577,6 +577,12 @@ int oslam_frame_stereo_from_rgbd_batch_ptrs_device(const oslam_keypoint_t* d_key
                                                    int stride, int batch, const float* const* d_depth_ptrs, int rows, int cols, int pitch, float mbf,
                                                    float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
 
+/* The same on RAW 16-bit depth images (what System::TrackRGBD receives, include/System.h:75): a value is scaled on lookup by depth_factor = mDepthMapFactor
+ * as imDepth.convertTo(CV_32F, mDepthMapFactor) scales the whole image (reference src/Tracking.cc:98-102,262): (float)d16 * depth_factor in float arithmetic. */
+int oslam_frame_stereo_from_rgbd_batch_ptrs_u16_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const,
+                                                       int stride, int batch, const uint16_t* const* d_depth16_ptrs, int rows, int cols, int pitch, float depth_factor,
+                                                       float mbf, float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream);
+
 /* Two-level nearest-centre descent over 256-bit descriptors (the node assignment of a DBoW2-style vocabulary tree with branching 10, depth 2):
  * d_out[i][k] = 11 + 10 b1 + b2 for descriptor k of array d_desc_ptrs[i] (d_counts[i] of them, at most `stride`), first minimum on ties. */
 int oslam_bow_nodes_device(const uint8_t* const* d_desc_ptrs, const int32_t* d_counts, int n, int stride, const uint64_t* d_top, const uint64_t* d_sub,

@@ -160,7 +160,8 @@ typedef struct oslam_job_fuse_pts {        /* ORBmatcher::Fuse on one resident k
 
 typedef struct oslam_slam_objects {        /* the semantic detections of ONE frame (reference include/Semantic.h; src/Semantic.cc:14-96) */
     int32_t n;                             /* <= OSLAM_SLAM_MAX_OBJECTS, in the order of the semantic file */
-    const uint8_t* const* masks;           /* n images of width x height, uint8 {0, 255}, rows mask_stride bytes apart (host or device like the frames) */
+    const uint8_t* const* masks;           /* n images of width x height, uint8 {0, 255}, rows mask_stride bytes apart (host or device like the frames);
+                                            * mask_stride = 0: one-bit-per-pixel images, see oslam_slam_track_rgbd_raw16 */
     const int32_t* track_id;               /* n: identity of the physical object (substitute for ObjectMatcher, see the head comment); < 0 = unknown */
     const int32_t* label;                  /* n: class label (recorded, not used on this path); may be NULL */
 } oslam_slam_objects_t;
@@ -241,6 +242,11 @@ typedef struct oslam_slam_ops {
     int (*fuse_points_keyed)(void* ctx, int n, oslam_job_fuse_pts_t* jobs);
     /* optional test hook of tables with resident map points: the 64-byte record of point `id` of `slot` (see oslam_job_mp_update_t::items) */
     int (*point_record)(void* ctx, int slot, int id, uint8_t out[64]);
+    /* optional: frames_rgbd on RAW 16-bit depth images (depth16[i]: width x height uint16, rows depth_pitch ELEMENTS apart), scaled by depth_factor =
+     * mDepthMapFactor on lookup exactly as imDepth.convertTo(CV_32F, mDepthMapFactor) scales the image (src/Tracking.cc:262).  NULL = oslam_slam_track_rgbd_raw16
+     * is refused on this table. */
+    int (*frames_rgbd_raw16)(void* ctx, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const uint16_t* const* depth16,
+                             int depth_pitch, float depth_factor, int on_device, oslam_slam_frame_t* const* out);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
@@ -264,10 +270,23 @@ int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, i
                                   const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
 int oslam_slam_track_stereo_objects(oslam_slam_t* h, const uint8_t* const* left, const uint8_t* const* right, int gray_stride, int on_device,
                                     const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
+/* System::TrackRGBD on the RAW inputs (include/System.h:75, src/Tracking.cc:241-275): gray as above, depth16[s] = the 16-bit depth image as read from the
+ * dataset (rows depth_pitch elements apart) with depth_factor = mDepthMapFactor = 1 / DepthMapFactor (1.0f / 5000 for TUM); objs may be NULL.  mask_stride = 0
+ * says that objs[s].masks are ONE-BIT-PER-PIXEL images in the layout of oslam_mask_bits_device ([height][ceil(width / 64)] uint64, bit i of word w = pixel
+ * 64 w + i == 255) packed by the caller.  With on_device != 0 every pointer only has to be DEVICE-ACCESSIBLE: pinned host memory (hipHostMalloc) qualifies —
+ * the Frame::Frame / object kernels then read the images over PCIe where they are (8-bit gray once, the depth values at the keypoints, the mask words),
+ * no staging copy.  Needs a table with frames_rgbd_raw16. */
+int oslam_slam_track_rgbd_raw16(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const uint16_t* const* depth16, int depth_pitch, float depth_factor,
+                                int on_device, const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
+
 /* Object layer counters of one sequence: [0] N_AllSemanticConstraintNum (src/ObjectOptimizer.cc:1233), [1] frames optimised with matched objects,
  * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] fixed keyframes left out of
  * local-BA windows (see "Limits" below). */
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
+
+/* Sizes of the local-BA windows of one sequence since creation (Optimizer::LocalBundleAdjustment's graph gather, src/Optimizer.cc:456-504):
+ * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] fixed keyframes left out (see "Limits"). */
+int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
  * Twc [n][12] = rows of [Rwc | twc]; lost frames are skipped like the reference.  Returns the count in *n_out (cap < n -> OSLAM_E_CAPACITY). */

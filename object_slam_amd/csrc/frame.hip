@@ -52,6 +52,8 @@ struct RgbdCtx {
     const float* depth; int pitch; long long image_stride; int rows, cols;
     float mbf; float* uRight; float* mvDepth; int* status;
     const float* const* depth_ptrs;   // batch of depth images given by a pointer table (image b = depth_ptrs[b]) instead of base + b * image_stride
+    const uint16_t* const* depth16_ptrs;   // the same with RAW 16-bit depth images, scaled on lookup by `factor` like imDepth.convertTo(CV_32F, mDepthMapFactor)
+    float factor;                          // (reference src/Tracking.cc:262; OpenCV 3.2 cvtScale_<ushort, float, float>: (float)d * scale in float arithmetic)
 };
 
 __global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdCtx c) {
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256) void k_stereo_from_rgbd(RgbdCtx c) {
         const int row = (int)kp.y, col = (int)kp.x;   // Mat::at<float>(v, u) with float arguments: truncation
         if (row < 0 || row >= c.rows || col < 0 || col >= c.cols) atomicOr(c.status, 1);   // the reference would read out of the image
         else {
-            const float d = c.depth_ptrs ? c.depth_ptrs[b][(long long)row * c.pitch + col] : c.depth[(long long)b * c.image_stride + (long long)row * c.pitch + col];
+            const float d = c.depth16_ptrs ? __fmul_rn((float)c.depth16_ptrs[b][(long long)row * c.pitch + col], c.factor)
+                          : c.depth_ptrs ? c.depth_ptrs[b][(long long)row * c.pitch + col] : c.depth[(long long)b * c.image_stride + (long long)row * c.pitch + col];
             if (d > 0) { dp = d; ur = c.keysUn[o].x - __fdiv_rn(c.mbf, d); }
         }
     }
@@ -233,7 +236,7 @@ int oslam_frame_stereo_from_rgbd_batch_device(const oslam_keypoint_t* d_keys, co
     RgbdCtx c;
     c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
     c.depth = d_depth; c.pitch = pitch; c.image_stride = (long long)image_stride; c.rows = rows; c.cols = cols;
-    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = nullptr;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = nullptr; c.depth16_ptrs = nullptr; c.factor = 1.f;
     hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;
@@ -249,7 +252,23 @@ int oslam_frame_stereo_from_rgbd_batch_ptrs_device(const oslam_keypoint_t* d_key
     RgbdCtx c;
     c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
     c.depth = nullptr; c.pitch = pitch; c.image_stride = 0; c.rows = rows; c.cols = cols;
-    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = d_depth_ptrs;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = d_depth_ptrs; c.depth16_ptrs = nullptr; c.factor = 1.f;
+    hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+// The same on RAW 16-bit depth images (the TUM PNGs as Tracking::GrabImageRGBD receives them): image b = d_depth16_ptrs[b], rows `pitch` elements apart;
+// a value is scaled on lookup by depth_factor = mDepthMapFactor exactly as imDepth.convertTo(CV_32F, mDepthMapFactor) would have scaled the whole image.
+int oslam_frame_stereo_from_rgbd_batch_ptrs_u16_device(const oslam_keypoint_t* d_keys, const oslam_keypoint_t* d_keysUn, const int32_t* d_counts, int n_const, int stride,
+                                                       int batch, const uint16_t* const* d_depth16_ptrs, int rows, int cols, int pitch, float depth_factor, float mbf,
+                                                       float* d_uRight, float* d_mvDepth, int32_t* d_status, void* stream) {
+    if (!d_keys || !d_keysUn || !d_depth16_ptrs || !d_uRight || !d_mvDepth || !d_status || batch < 1 || stride < 1 || rows < 1 || cols < 1 || pitch < cols ||
+        (!d_counts && (n_const < 0 || n_const > stride))) { set_error("stereo_from_rgbd (u16): bad argument"); return OSLAM_E_INVALID; }
+    RgbdCtx c;
+    c.keys = d_keys; c.keysUn = d_keysUn; c.counts = d_counts; c.n_const = n_const; c.stride = stride;
+    c.depth = nullptr; c.pitch = pitch; c.image_stride = 0; c.rows = rows; c.cols = cols;
+    c.mbf = mbf; c.uRight = d_uRight; c.mvDepth = d_mvDepth; c.status = d_status; c.depth_ptrs = nullptr; c.depth16_ptrs = d_depth16_ptrs; c.factor = depth_factor;
     hipLaunchKernelGGL(k_stereo_from_rgbd, dim3(div_up(stride, 256), batch), dim3(256), 0, (hipStream_t)stream, c);
     OSLAM_HIP_CHECK(hipGetLastError());
     return OSLAM_OK;

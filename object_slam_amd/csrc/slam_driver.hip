@@ -160,6 +160,7 @@ struct Seq {
     std::map<int, int> objOfTrack;
     int64_t sem[8] = {0};
     int64_t lbaFixedDropped = 0;           // fixed keyframes left out of local-BA windows because of the per-window keyframe limit
+    int64_t lbaWin[4] = {0, 0, 0, 0};      // local-BA window sizes summed over the sequence's windows: local keyframes, fixed keyframes, points, edges
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
     std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj, jObjIds;
@@ -1023,6 +1024,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = 0;
             W.poses_out.resize(W.poses.size()); W.points_out.resize(W.points.size() + 3); W.erase.assign(W.ekf.size() + 1, 0);
             s.st[5]++; s.st[14] += (int64_t)W.ekf.size();
+            s.lbaWin[0] += W.nLocal; s.lbaWin[1] += (int64_t)W.kfs.size() - W.nLocal; s.lbaWin[2] += (int64_t)W.pts.size(); s.lbaWin[3] += (int64_t)W.ekf.size();
         });
         std::vector<Win*> wins;
         for (int w = 0; w < nW; w++) if (pool_w[w].si >= 0) wins.push_back(&pool_w[w]);
@@ -1412,9 +1414,10 @@ static int run_pose_jobs(Ctx& c, const std::vector<int>& who) {
 // One lockstep step of Tracking::Track for all sequences
 // ------------------------------------------------------------------------------------------------------------------
 static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* right, int gray_stride, const float* const* depth, int depth_pitch,
-                      int on_device, const double* stamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
+                      int on_device, const double* stamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out,
+                      const uint16_t* const* depth16 = nullptr, float depth_factor = 1.f) {
     const int S = c.S;
-    thread_account() = &c.acct;   // the workers bill the tasks of this thread's batches (driver and operator table) to this handle
+    AccountScope acct_scope(&c.acct);   // the workers bill the tasks of this thread's batches (driver and operator table) to this handle; unbound again on every return
     c.acct.worker_ns.store(0, std::memory_order_relaxed);
     Timer tm;
     int rc;
@@ -1425,6 +1428,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         std::vector<oslam_slam_frame_t*> outs(S);
         for (int i = 0; i < S; i++) { slots[i] = i; outs[i] = &c.seq[i]->cur->view; }
         if (right) rc = c.ops.frames_stereo(c.ops.ctx, S, slots.data(), gray, right, gray_stride, on_device, outs.data());
+        else if (depth16) rc = c.ops.frames_rgbd_raw16(c.ops.ctx, S, slots.data(), gray, gray_stride, depth16, depth_pitch, depth_factor, on_device, outs.data());
         else rc = c.ops.frames_rgbd(c.ops.ctx, S, slots.data(), gray, gray_stride, depth, depth_pitch, on_device, outs.data());
         if (rc) return rc;
     }
@@ -1743,6 +1747,7 @@ int oslam_slam_create(oslam_slam_t** out, const oslam_slam_config_t* cfg) {
 
 void oslam_slam_destroy(oslam_slam_t* h) {
     if (!h) return;
+    if (thread_account() == &h->c.acct) thread_account() = nullptr;   // never leave a dangling account bound to the destroying thread
     if (h->c.ops.destroy) h->c.ops.destroy(h->c.ops.ctx);
     delete h;
 }
@@ -1760,6 +1765,24 @@ int oslam_slam_track_rgbd_objects(oslam_slam_t* h, const uint8_t* const* gray, i
     if (h->c.stereo) { oslam::set_error("oslam_slam_track_rgbd_objects on a STEREO handle"); return OSLAM_E_INVALID; }
     if (objs && mask_stride < h->c.cfg.width) { oslam::set_error("oslam_slam_track_rgbd_objects: mask_stride < width"); return OSLAM_E_INVALID; }
     return track_step(h->c, gray, nullptr, gray_stride, depth, depth_pitch, on_device, timestamps, objs, mask_stride, Tcw_out, state_out);
+}
+
+int oslam_slam_track_rgbd_raw16(oslam_slam_t* h, const uint8_t* const* gray, int gray_stride, const uint16_t* const* depth16, int depth_pitch, float depth_factor,
+                                int on_device, const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out) {
+    if (!h || !gray || !depth16) { oslam::set_error("oslam_slam_track_rgbd_raw16: bad argument"); return OSLAM_E_INVALID; }
+    if (h->c.stereo) { oslam::set_error("oslam_slam_track_rgbd_raw16 on a STEREO handle"); return OSLAM_E_INVALID; }
+    if (!h->c.ops.frames_rgbd_raw16) { oslam::set_error("oslam_slam_track_rgbd_raw16: the operator table has no frames_rgbd_raw16"); return OSLAM_E_INVALID; }
+    if (objs && mask_stride != 0 && mask_stride < h->c.cfg.width) { oslam::set_error("oslam_slam_track_rgbd_raw16: mask_stride must be 0 (bitmaps) or >= width"); return OSLAM_E_INVALID; }
+    if (objs && mask_stride == 0 && !on_device) { oslam::set_error("oslam_slam_track_rgbd_raw16: one-bit masks must be device-accessible (on_device != 0)"); return OSLAM_E_INVALID; }
+    return track_step(h->c, gray, nullptr, gray_stride, nullptr, depth_pitch, on_device, timestamps, objs, mask_stride, Tcw_out, state_out, depth16, depth_factor);
+}
+
+int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
+    if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_lba_window_stats: bad argument"); return OSLAM_E_INVALID; }
+    const auto& s = *h->c.seq[seq];
+    memset(out, 0, 8 * sizeof(int64_t));
+    out[0] = s.st[5]; out[1] = s.lbaWin[0]; out[2] = s.lbaWin[1]; out[3] = s.lbaWin[2]; out[4] = s.lbaWin[3]; out[5] = s.lbaFixedDropped;
+    return OSLAM_OK;
 }
 
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]) {

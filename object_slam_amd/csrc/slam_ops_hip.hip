@@ -238,31 +238,35 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
 
 // Frame::Frame (src/Frame.cc:117-172) for n frames: one batched extraction, one undistort launch, one depth lookup launch; the
 // keypoints / descriptors come back in one pass of copies after a single synchronisation.
-int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
-             oslam_slam_frame_t* const* out) {
-    HipOps* o = (HipOps*)p;
+static int frames_impl(HipOps* o, int n, const uint8_t* const* gray, int gray_stride, const float* const* depth, const uint16_t* const* depth16, int depth_pitch,
+                       float depth_factor, int on_device, oslam_slam_frame_t* const* out) {
     o->step_epoch++;   // a new step: the mask bitmaps of the previous one are stale
     std::swap(o->d_keysUn, o->d_keysUn_prev);   // what was the current frame of every slot is now its last frame
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     if (n > o->S) { oslam::set_error("frames_rgbd: n > n_sequences"); return OSLAM_E_INVALID; }
     const int W = o->cfg.width, H = o->cfg.height;
     const size_t gimg = o->gray_pitch * H, dimg = (size_t)W * H;
-    const float* const* depth_table = nullptr;
-    if (on_device) {   // two pointer tables up, ONE gather launch for the gray images (instead of 2n two-dimensional copies)
+    const void* const* depth_table = nullptr;
+    const void* const* dsrc = depth16 ? (const void* const*)depth16 : (const void* const*)depth;
+    if (on_device) {   // two pointer tables up, ONE gather launch for the gray images (instead of 2n two-dimensional copies).  "Device" pointers only have to be
+        // device-accessible: with pinned host images the gather and the depth lookup read them over PCIe where they are.
         OPS_CHECK(o->ensure_up(16 * (size_t)n + 512));
-        memcpy(o->up_h, gray, 8 * (size_t)n); memcpy(o->up_h + 8 * (size_t)n + 256 - (8 * (size_t)n) % 256, depth, 8 * (size_t)n);
+        memcpy(o->up_h, gray, 8 * (size_t)n); memcpy(o->up_h + 8 * (size_t)n + 256 - (8 * (size_t)n) % 256, dsrc, 8 * (size_t)n);
         const size_t oD = 8 * (size_t)n + 256 - (8 * (size_t)n) % 256;
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, oD + 8 * (size_t)n, hipMemcpyHostToDevice, o->strm));
         OPS_CHECK(oslam_frame_gather_images_device((const void* const*)o->up_d, n, gray_stride, W, H, o->d_gray, gimg, (int)o->gray_pitch, o->strm));
-        depth_table = (const float* const*)(o->up_d + oD);   // the depth images are read where they are: only the values at the keypoints are needed
+        depth_table = (const void* const*)(o->up_d + oD);   // the depth images are read where they are: only the values at the keypoints are needed
     } else {
-        // host images: rows packed into the pinned block in the device layout (parallel), then ONE copy per plane (a pageable 2-D copy is row-by-row)
+        // host images: rows packed into the pinned block in the device layout (parallel), then ONE copy per plane (a pageable 2-D copy is row-by-row);
+        // raw 16-bit depth is scaled here the way convertTo scales it (one float multiplication per pixel)
         OPS_CHECK(o->ensure_up((gimg + dimg * 4) * n));
         uint8_t* U = o->up_h;
         o->pool->parallel_for(n, [&](int i) {
             for (int r = 0; r < H; r++) {
                 memcpy(U + gimg * i + o->gray_pitch * r, gray[i] + (size_t)gray_stride * r, W);
-                memcpy(U + gimg * n + (dimg * i + (size_t)W * r) * 4, depth[i] + (size_t)depth_pitch * r, (size_t)W * 4);
+                float* drow = (float*)(U + gimg * n + (dimg * i + (size_t)W * r) * 4);
+                if (depth16) { const uint16_t* srow = depth16[i] + (size_t)depth_pitch * r; for (int x = 0; x < W; x++) drow[x] = (float)srow[x] * depth_factor; }
+                else memcpy(drow, depth[i] + (size_t)depth_pitch * r, (size_t)W * 4);
             }
         });
         OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_gray, U, gimg * n, hipMemcpyHostToDevice, o->strm));
@@ -273,15 +277,29 @@ int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, i
     const oslam_keypoint_t* d_kp; const uint8_t* d_desc; const int32_t* d_cnt; const int32_t* d_st;
     OPS_CHECK(oslam_orb_results_device(o->orb, &d_kp, &d_desc, &d_cnt, &d_st));
     OPS_CHECK(oslam_frame_undistort_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->K4, o->cfg.dist, o->cfg.ndist, o->strm));
-    if (depth_table) OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_ptrs_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, depth_table, H, W, depth_pitch, o->cfg.bf,
-                                                                              o->d_uRight, o->d_mvDepth, o->d_status, o->strm));
+    if (depth_table && depth16) OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_ptrs_u16_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, (const uint16_t* const*)depth_table, H, W, depth_pitch,
+                                                                                              depth_factor, o->cfg.bf, o->d_uRight, o->d_mvDepth, o->d_status, o->strm));
+    else if (depth_table) OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_ptrs_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, (const float* const*)depth_table, H, W, depth_pitch, o->cfg.bf,
+                                                                                   o->d_uRight, o->d_mvDepth, o->d_status, o->strm));
     else OPS_CHECK(oslam_frame_stereo_from_rgbd_batch_device(d_kp, o->d_keysUn, d_cnt, 0, o->cap, n, o->d_depth, H, W, W, dimg, o->cfg.bf, o->d_uRight,
                                                              o->d_mvDepth, o->d_status, o->strm));
     o->t_end();
-    (void)slots;
     OPS_CHECK(download_frames(o, n, d_kp, d_desc, d_cnt, d_st, o->d_uRight, o->d_mvDepth, out));
     if (o->timing) { double bytes = 0; for (int i = 0; i < n; i++) bytes += (double)oslam_orb_algorithmic_bytes(o->orb, out[i]->N); o->t_collect(0, 14, bytes); }
     return OSLAM_OK;
+}
+
+int h_frames(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const float* const* depth, int depth_pitch, int on_device,
+             oslam_slam_frame_t* const* out) {
+    (void)slots;
+    return frames_impl((HipOps*)p, n, gray, gray_stride, depth, nullptr, depth_pitch, 1.f, on_device, out);
+}
+
+// the same on raw 16-bit depth images (oslam_slam_track_rgbd_raw16)
+int h_frames_raw16(void* p, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const uint16_t* const* depth16, int depth_pitch, float depth_factor,
+                   int on_device, oslam_slam_frame_t* const* out) {
+    (void)slots;
+    return frames_impl((HipOps*)p, n, gray, gray_stride, nullptr, depth16, depth_pitch, depth_factor, on_device, out);
 }
 
 // Frame::Frame for n rectified stereo pairs (src/Frame.cc:61-115): both images extracted as two batches, UndistortKeyPoints, then ONE
@@ -626,18 +644,27 @@ int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
     if (total == 0) { for (int i = 0; i < n; i++) memset(jobs[i].in_mask, 0, (size_t)jobs[i].cur->N); return OSLAM_OK; }
     std::vector<const uint8_t*> ptrs;
     int pitch = 0;
-    OPS_CHECK(stage_masks(o, total, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
+    const bool caller_bits = jobs[0].mask_stride == 0;   // one-bit-per-pixel images packed by the caller (oslam_slam_track_rgbd_raw16), device-accessible
+    if (caller_bits && !jobs[0].on_device) { oslam::set_error("object_kps: one-bit masks must be device-accessible"); return OSLAM_E_INVALID; }
+    if (!caller_bits) OPS_CHECK(stage_masks(o, total, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
     Layout L;
-    const size_t oPtr = L.take(8 * (size_t)total), oM0 = L.take(4 * S), oNm = L.take(4 * S);
+    const size_t oPtr = L.take(8 * (size_t)total), oM0 = L.take(4 * S), oNm = L.take(4 * S), oSeg = L.take(caller_bits ? sizeof(CopySegH) * (size_t)total : 0);
     OPS_CHECK(o->ensure_up(L.off));
     uint8_t* U = o->up_h;
-    memcpy(U + oPtr, ptrs.data(), 8 * (size_t)total); memcpy(U + oM0, mask0.data(), 4 * S); memcpy(U + oNm, nmask.data(), 4 * S);
+    const size_t bits_bytes = (size_t)o->cfg.height * ((o->cfg.width + 63) / 64) * 8;
+    if (caller_bits) {
+        OPS_CHECK(o->ensure_maskbits((size_t)total * o->cfg.height * ((o->cfg.width + 63) / 64)));
+        CopySegH* sg = (CopySegH*)(U + oSeg);
+        for (int m = 0; m < total; m++) { sg[m].src = src[m]; sg[m].dst = (uint8_t*)o->d_maskbits + bits_bytes * m; sg[m].bytes = (uint32_t)bits_bytes; sg[m].pad = 0; }
+    } else memcpy(U + oPtr, ptrs.data(), 8 * (size_t)total);
+    memcpy(U + oM0, mask0.data(), 4 * S); memcpy(U + oNm, nmask.data(), 4 * S);
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
-    if (!getenv("OSLAM_SLAM_NO_MASK_BITS")) {   // one pass over the mask bytes; the test (and pose_opt2's boundary lists later in this step) read bitmaps
+    if (caller_bits || !getenv("OSLAM_SLAM_NO_MASK_BITS")) {   // one pass over the mask bytes; the test (and pose_opt2's boundary lists later in this step) read bitmaps
         const int H = o->cfg.height, W = o->cfg.width;
         OPS_CHECK(o->ensure_maskbits((size_t)total * H * ((W + 63) / 64)));
-        OPS_CHECK(oslam_mask_bits_device((const uint8_t* const*)(Dv + oPtr), total, H, W, pitch, o->d_maskbits, o->strm));
+        if (caller_bits) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, total, o->strm));   // the caller's bitmaps (pinned host memory: read over PCIe) into the step's bitmap array
+        else OPS_CHECK(oslam_mask_bits_device((const uint8_t* const*)(Dv + oPtr), total, H, W, pitch, o->d_maskbits, o->strm));
         OPS_CHECK(oslam_frame_object_kp_test_bits_batch_device(o->d_keysUn, (int)cap, o->d_cnt, (int)S, o->d_maskbits, (const int32_t*)(Dv + oM0), (const int32_t*)(Dv + oNm), H, W,
                                                                o->d_objbits, o->strm));
         o->bits_of_ptr.clear();
@@ -682,6 +709,7 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
         if (it == o->bits_of_ptr.end()) use_bits = false;
         else bidx[m] = it->second;
     }
+    if (tObj && !use_bits && jobs[0].mask_stride == 0) { oslam::set_error("pose_opt2: one-bit masks without the step's bitmaps (object_kps must run first)"); return OSLAM_E_INVALID; }
     if (tObj && !use_bits) OPS_CHECK(stage_masks(o, tObj, src, jobs[0].mask_stride, jobs[0].on_device, ptrs, pitch));
     bool by_id = o->mp_tab_on;
     for (int i = 0; i < n && by_id; i++) by_id = jobs[i].base.mp_ids != nullptr && jobs[i].base.slot >= 0 && jobs[i].base.slot < o->S && (jobs[i].nObjMp == 0 || jobs[i].objmp_ids != nullptr);
@@ -1252,7 +1280,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (!rc && hipDeviceSynchronize() != hipSuccess) { oslam::set_error("slam ops: device synchronisation failed"); rc = OSLAM_E_HIP; }   // creation-time fills ran on the null stream
     if (rc) { h_destroy(o); return rc; }
     ops->ctx = o;
-    ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames;
+    ops->max_keypoints = h_max_keypoints; ops->scale_tables = h_scale_tables; ops->image_bounds = h_image_bounds; ops->frames_rgbd = h_frames; ops->frames_rgbd_raw16 = h_frames_raw16;
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;

@@ -22,6 +22,15 @@ namespace oslam_drv {
 // set for its thread (the owner's own share is in its thread's CPU clock), so a stage's core-seconds can be told from its wall time.
 struct CpuAccount { std::atomic<long long> worker_ns{0}; };
 inline CpuAccount*& thread_account() { static thread_local CpuAccount* a = nullptr; return a; }
+// Binds an account to the calling thread for a scope and restores the previous binding on every exit path (a handle's account must not stay
+// bound to a thread after the handle's step returns: the handle may be destroyed while the thread goes on to use the shared workers).
+struct AccountScope {
+    CpuAccount* prev;
+    explicit AccountScope(CpuAccount* a) : prev(thread_account()) { thread_account() = a; }
+    ~AccountScope() { thread_account() = prev; }
+    AccountScope(const AccountScope&) = delete;
+    AccountScope& operator=(const AccountScope&) = delete;
+};
 inline long long thread_cpu_ns() {
     timespec ts;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);

@@ -269,18 +269,21 @@ def kitti_path(n, seed, speed=0.35):
     return T
 
 
-def make_stereo_sequence(seed, n, width=1241, height=376, speed=0.35, baseline=KITTI_BASELINE):
-    """S3: dict(gray = left [n,H,W] u8, right [n,H,W] u8, Twc [n,4,4] relative to the first left camera)."""
+def make_stereo_sequence(seed, n, width=1241, height=376, speed=0.35, baseline=KITTI_BASELINE, first=0, count=None):
+    """S3: dict(gray = left [n,H,W] u8, right [n,H,W] u8, Twc [n,4,4] relative to the first left camera).  first / count: only frames
+    [first, first + count) of the n-frame stream (see make_rgbd_sequence)."""
     planes = make_kitti_scene(seed, length=max(120.0, speed * n + 90.0))
     Twc = kitti_path(n, seed, speed)
-    left = np.empty((n, height, width), np.uint8)
-    right = np.empty((n, height, width), np.uint8)
-    for i in range(n):
+    m = n - first if count is None else count
+    left = np.empty((m, height, width), np.uint8)
+    right = np.empty((m, height, width), np.uint8)
+    for j in range(m):
+        i = first + j
         C = Twc[i, :3, 3]
         near = [p for p in planes if -15.0 < (p.P0[2] - C[2]) < 140.0 or p.density < 5.0]
-        left[i] = render(near, Twc[i], KITTI_K, width, height)[0]
+        left[j] = render(near, Twc[i], KITTI_K, width, height)[0]
         Tr = Twc[i].copy()
         Tr[:3, 3] = C + Twc[i, :3, 0] * baseline          # right camera: +baseline along the camera x axis
-        right[i] = render(near, Tr, KITTI_K, width, height)[0]
+        right[j] = render(near, Tr, KITTI_K, width, height)[0]
     T0inv = np.linalg.inv(Twc[0])
-    return dict(gray=left, right=right, Twc=np.array([T0inv @ T for T in Twc]))
+    return dict(gray=left, right=right, Twc=np.array([T0inv @ T for T in Twc[first:first + m]]))

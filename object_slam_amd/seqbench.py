@@ -49,12 +49,12 @@ class _Inputs:
                 for key in ("gray", "right"):
                     if key in q:
                         t = torch.zeros((self.length, wl.height, self.pitch), dtype=torch.uint8, device=device)
-                        t[:, :, :wl.width] = torch.from_numpy(q[key]).to(device)
+                        t[:, :, :wl.width] = torch.from_numpy(q[key][:self.length]).to(device)
                         d[key] = t
                 if "depth" in q:
-                    d["depth"] = torch.from_numpy(np.ascontiguousarray(q["depth"])).to(device)
+                    d["depth"] = torch.from_numpy(np.ascontiguousarray(q["depth"][:self.length])).to(device)
                 if q.get("masks") is not None:
-                    d["masks"] = torch.from_numpy(np.ascontiguousarray(q["masks"])).to(device)
+                    d["masks"] = torch.from_numpy(np.ascontiguousarray(q["masks"][:self.length])).to(device)
                 self.dev[b] = d
             torch.cuda.synchronize()
 
@@ -64,6 +64,28 @@ class _Inputs:
             x = self.dev[b][key][tt]
             return x.data_ptr()
         return self.seqs[b][key][tt]
+
+    def _base_addr(self, b, key, host=False):
+        """(address of frame 0, bytes per frame) of plane `key` of base sequence b."""
+        if self.on_device and not host:
+            t = self.dev[b][key]
+            return t.data_ptr(), t.stride(0) * t.element_size()
+        a = self.seqs[b][key]
+        assert a.flags["C_CONTIGUOUS"]
+        return a.__array_interface__["data"][0], a.strides[0]
+
+    def ptr_table(self, seq_ids, key, n_frames, sub=None, host=False):
+        """uint64 [n_frames, S] addresses of plane `key` (mask `sub` of the frame's masks when given) of every sequence's frame at every step."""
+        S = len(seq_ids)
+        base = np.zeros(S, np.uint64); stride = np.zeros(S, np.uint64); off = np.zeros(S, np.uint64)
+        for i, g in enumerate(seq_ids):
+            a, st = self._base_addr(self.base[g], key, host)
+            if sub is not None:
+                q = self.dev[self.base[g]][key] if (self.on_device and not host) else self.seqs[self.base[g]][key]
+                a += sub * ((q.stride(1) * q.element_size()) if (self.on_device and not host) else q.strides[1])
+            base[i], stride[i], off[i] = a, st, self.off[g]
+        t = np.arange(n_frames, dtype=np.uint64)[:, None]
+        return base[None, :] + (t + off[None, :]) * stride[None, :]
 
     @property
     def has_masks(self):
@@ -91,19 +113,22 @@ class _Inputs:
 
 
 def _prepare(system, wl, inp, seq_ids, n_frames):
-    """The call arguments of every step of one handle, marshalled once (the frame loop then only crosses the C boundary)."""
+    """The call arguments of every step of one handle, marshalled once and vectorised: the pointer tables of all steps are numpy arrays (a Python loop over
+    4096 sequences x 250 steps would take longer than the run), the frame loop then only crosses the C boundary."""
     S = len(seq_ids)
-    out = []
-    for t in range(n_frames):
-        stamps = [t / wl.fps] * S
-        if wl.sensor == slam.STEREO:
-            out.append(system.prepare_stereo([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "right") for g in seq_ids], stamps,
-                                             on_device=inp.on_device, stride=inp.pitch))
-        else:
-            objs = [inp.objects(g, t) for g in seq_ids] if inp.has_masks else None
-            out.append(system.prepare_rgbd([inp.frame(g, t, "gray") for g in seq_ids], [inp.frame(g, t, "depth") for g in seq_ids], stamps, objects=objs,
-                                           on_device=inp.on_device, gray_stride=inp.pitch, depth_pitch=wl.width, mask_stride=wl.width))
-    return out
+    dev = 1 if inp.on_device else 0
+    stamps = np.repeat((np.arange(n_frames, dtype=np.float64) / wl.fps)[:, None], S, 1)
+    if wl.sensor == slam.STEREO:
+        return system.prepare_stereo_bulk(inp.ptr_table(seq_ids, "gray", n_frames), inp.ptr_table(seq_ids, "right", n_frames), stamps, inp.pitch, on_device=dev)
+    masks = tids = labs = None
+    if inp.has_masks:
+        q0 = inp.seqs[inp.base[seq_ids[0]]]
+        nobj = q0["masks"].shape[1]
+        masks = np.stack([inp.ptr_table(seq_ids, "masks", n_frames, sub=o) for o in range(nobj)], 2)
+        tids = np.array([inp.seqs[inp.base[g]]["track_ids"] for g in seq_ids], np.int32)
+        labs = np.array([inp.seqs[inp.base[g]].get("labels", [0] * nobj) for g in seq_ids], np.int32)
+    return system.prepare_rgbd_bulk(inp.ptr_table(seq_ids, "gray", n_frames), inp.ptr_table(seq_ids, "depth", n_frames), stamps, inp.pitch, wl.width,
+                                    masks=masks, track_ids=tids, labels=labs, mask_stride=wl.width, on_device=dev)
 
 
 def _drive(system, wl, calls, t0, t1, poses_out=None):
@@ -113,23 +138,57 @@ def _drive(system, wl, calls, t0, t1, poses_out=None):
             poses_out.append(T.copy())
 
 
-def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1):
-    """The rank's base sequences {b: dict}, rendered by `workers` processes (call it before the process touches the GPU: fork)."""
+def _render_chunk(wl, seed, n, first, count):
+    return wl.make_sequence(seed, n, first=first, count=count)
+
+
+def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1, chunk=24):
+    """The rank's base sequences {b: dict}, rendered by `workers` processes in chunks of `chunk` frames (the images of a frame do not depend on the other
+    frames).  Call it before the process touches the GPU: the workers are forked."""
     nb = min(wl.n_base, seqs_per_rank)
-    jobs = [(wl.n_base * rank + b, n_frames + wl.stagger) for b in range(nb)]
-    if workers > 1 and nb > 1:
+    n = n_frames + wl.stagger
+    jobs = [(wl, wl.n_base * rank + b, n, f, min(chunk, n - f)) for b in range(nb) for f in range(0, n, chunk)]
+    if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(min(workers, nb)) as pool:
-            out = pool.starmap(wl.make_sequence, jobs)
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.starmap(_render_chunk, jobs)
     else:
-        out = [wl.make_sequence(*j) for j in jobs]
-    return dict(enumerate(out))
+        parts = [_render_chunk(*j) for j in jobs]
+    out = {}
+    per = len(jobs) // nb
+    for b in range(nb):
+        ps = parts[b * per:(b + 1) * per]
+        q = dict(ps[0])
+        for key in ("gray", "right", "depth", "masks", "Twc"):
+            if q.get(key) is not None:
+                q[key] = np.ascontiguousarray(np.concatenate([p[key] for p in ps], 0))
+        out[b] = q
+    return out
+
+
+def _window_totals(systems, per):
+    tot = np.zeros(6, np.int64)
+    for sy in systems:
+        for q in range(per):
+            w = sy.lba_window_stats(q)
+            tot += np.array([w["windows"], w["local_kfs"], w["fixed_kfs"], w["points"], w["edges"], w["fixed_dropped"]], np.int64)
+    return tot
+
+
+def window_stats(after, before):
+    """Mean local-BA window of the steps between two `_window_totals` snapshots."""
+    d = after - before
+    n = max(int(d[0]), 1)
+    return {"windows": int(d[0]), "mean_local_kfs": round(float(d[1]) / n, 2), "mean_fixed_kfs": round(float(d[2]) / n, 2), "mean_points": round(float(d[3]) / n, 1),
+            "mean_edges": round(float(d[4]) / n, 1), "fixed_kfs_left_out": int(d[5])}
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,
-             sequences=None, after_warmup=None, coll_on_device=True):
-    """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread), `warmup`
-    untimed lockstep steps, then exactly `steps` timed steps bracketed by a barrier + device synchronisation on both sides.
+             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None):
+    """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread); `preroll` untimed steps that
+    bring every sequence's map to its steady state (they are part of the set-up, like loading a map), `warmup` untimed lockstep steps, then exactly `steps`
+    timed steps bracketed by a barrier + device synchronisation on both sides.  `post(ctx)` (optional) may run further phases on the warmed sequences
+    (`post_frames` more frames are kept per sequence for it).
     Returns (summary dict on every rank, per-rank records [world, len(RECORD_FIELDS)], systems, extra)."""
     import torch
     import torch.distributed as dist
@@ -139,48 +198,59 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     assert len(mine) == seqs_per_rank and seqs_per_rank % handles == 0
     per = seqs_per_rank // handles
     groups = [mine[h * per:(h + 1) * per] for h in range(handles)]
-    n_frames = warmup + steps
-    inp = _Inputs(wl, mine, n_frames, on_device, device, base_seed=wl.n_base * rank, sequences=sequences)
+    n_timed0 = preroll + warmup
+    n_frames = n_timed0 + steps
+    inp = _Inputs(wl, mine, n_frames + post_frames, on_device, device, base_seed=wl.n_base * rank, sequences=sequences)
     systems = []
     for h in range(handles):
         cfg = slam.make_config(wl.width, wl.height, per, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor,
                                device=(device.index if hasattr(device, "index") and device.index is not None else 0) if on_device else 0, host_threads=host_threads)
         systems.append(make_system(cfg))
     poses = [[] for _ in range(handles)] if collect_poses else [None] * handles
-    calls = [_prepare(systems[h], wl, inp, groups[h], n_frames) for h in range(handles)]
+    calls = [_prepare(systems[h], wl, inp, groups[h], n_frames + post_frames) for h in range(handles)]
 
     def sync():
         if on_device:
             torch.cuda.synchronize()
 
-    def phase(t0, t1):
-        ths = [threading.Thread(target=_drive, args=(systems[h], wl, calls[h], t0, t1, poses[h])) for h in range(handles)]
+    def phase(t0, t1, calls_=None):
+        cl = calls_ if calls_ is not None else calls
+        ths = [threading.Thread(target=_drive, args=(systems[h], wl, cl[h], t0, t1, poses[h])) for h in range(handles)]
         for th in ths:
             th.start()
         for th in ths:
             th.join()
 
-    phase(0, warmup)
+    t_pre = time.perf_counter()
+    for t0 in range(0, preroll, 25):      # in chunks, so a long pre-roll reports progress
+        phase(t0, min(preroll, t0 + 25))
+        if progress is not None:
+            progress("pre-roll %d / %d steps, %.1f s" % (min(preroll, t0 + 25), preroll, time.perf_counter() - t_pre))
+    sync()
+    t_pre = time.perf_counter() - t_pre
+    phase(preroll, n_timed0)
     sync()
     if after_warmup is not None:
         after_warmup(systems)
+    win0 = _window_totals(systems, per)
     if multi:
         dist.barrier()
     sync()
     tstart = time.perf_counter()
-    phase(warmup, n_frames)
+    phase(n_timed0, n_frames)
     sync()
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - tstart
+    win1 = _window_totals(systems, per)
     frames = seqs_per_rank * steps
     total_frames, max_elapsed = aggregate_stats(elapsed, frames, device=device if (on_device and coll_on_device) else None)
 
     # per-rank record (fixed size, all-gathered once): counters summed over the rank's sequences, ATE of its first sequence
     kf = lba = lost = viol = sem = 0
     for h in range(handles):
-        for s in range(per):
-            st = systems[h].stats(s)
+        for q in range(per):
+            st = systems[h].stats(q)
             kf += st["keyframes_created"]; lba += st["local_bas"]; lost += st["lost_frames"]; viol += st["map_violations"]
             sem += st.get("semantic_edges", 0)
     _, Twc = systems[0].trajectory(0)
@@ -191,22 +261,77 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     summary = {"frames_per_s": total_frames / max_elapsed, "total_frames": total_frames, "elapsed_s": max_elapsed,
                "ms_per_step": max_elapsed / steps * 1e3, "n_ranks": int(records.shape[0]),
                "keyframes": int(records[:, 4].sum()), "local_bas": int(records[:, 5].sum()), "lost_frames": int(records[:, 6].sum()),
-               "ate_rmse_m": float(np.nanmean(records[:, 7])), "map_violations": int(records[:, 8].sum()), "semantic_edges": int(records[:, 9].sum())}
-    return summary, records, systems, {"inputs": inp, "groups": groups, "poses": poses}
+               "ate_rmse_m": float(np.nanmean(records[:, 7])), "map_violations": int(records[:, 8].sum()), "semantic_edges": int(records[:, 9].sum()),
+               "preroll_steps": preroll, "preroll_s": t_pre, "lba_windows_timed": window_stats(win1, win0), "lba_windows_all": window_stats(win1, np.zeros(6, np.int64))}
+    extra = {"inputs": inp, "groups": groups, "poses": poses, "calls": calls, "phase": phase, "sync": sync, "n_frames": n_frames, "per": per}
+    if post is not None:
+        extra["post"] = post(dict(extra, systems=systems, wl=wl, window_totals=lambda: _window_totals(systems, per)))
+    return summary, records, systems, extra
+
+
+def pack_mask_bits(masks):
+    """uint8 masks [..., H, W] ({0, 255}) -> one bit per pixel, uint64 [..., H, ceil(W / 64)] in the layout of oslam_mask_bits_device (bit i of word w = pixel 64 w + i == 255)."""
+    H, W = masks.shape[-2:]
+    WB = (W + 63) // 64
+    b = np.zeros(masks.shape[:-1] + (WB * 64,), np.uint8)
+    b[..., :W] = masks == 255
+    return np.ascontiguousarray(np.packbits(b, axis=-1, bitorder="little")).view("<u8")
+
+
+def host_input_calls(ctx, first, n):
+    """Call arguments of steps [first, first + n) of every handle with the inputs in PINNED HOST memory in the raw formats (8-bit gray, 16-bit depth with
+    DepthMapFactor 5000, instance masks as one bit per pixel): oslam_slam_track_rgbd_raw16 with device-accessible pointers — the kernels read the pinned
+    buffers over PCIe, nothing is staged.  Returns (per-handle call lists indexed by absolute step, input bytes per frame)."""
+    import torch
+    from .scene import DEPTH_FACTOR, depth_to_metres
+    inp, wl, systems, groups = ctx["inputs"], ctx["wl"], ctx["systems"], ctx["groups"]
+    last = first + n + wl.stagger
+    pinned = {}
+    for b, q in inp.seqs.items():
+        d16 = np.rint(q["depth"][first:last].astype(np.float64) * DEPTH_FACTOR).astype(np.uint16)
+        assert np.array_equal(depth_to_metres(d16), q["depth"][first:last])      # the float images of the HBM leg are exactly these raw images scaled
+        bits = pack_mask_bits(q["masks"][first:last])
+        pinned[b] = {"gray": torch.from_numpy(np.ascontiguousarray(q["gray"][first:last])).pin_memory(), "depth": torch.from_numpy(d16).pin_memory(),
+                     "masks": torch.from_numpy(bits.view(np.int64)).pin_memory()}
+    nobj = next(iter(inp.seqs.values()))["masks"].shape[1]
+
+    def table(seq_ids, key, sub=None):
+        S = len(seq_ids)
+        out = np.zeros((n, S), np.uint64)
+        for i, g in enumerate(seq_ids):
+            t = pinned[inp.base[g]][key]
+            a = t.data_ptr() + (sub * t.stride(1) * t.element_size() if sub is not None else 0)
+            out[:, i] = a + (np.arange(n, dtype=np.uint64) + np.uint64(inp.off[g])) * np.uint64(t.stride(0) * t.element_size())
+        return out
+
+    calls = []
+    for h, sy in enumerate(systems):
+        ids = groups[h]
+        S = len(ids)
+        stamps = np.repeat(((first + np.arange(n, dtype=np.float64)) / wl.fps)[:, None], S, 1)
+        masks = np.stack([table(ids, "masks", o) for o in range(nobj)], 2)
+        tids = np.array([inp.seqs[inp.base[g]]["track_ids"] for g in ids], np.int32)
+        labs = np.array([inp.seqs[inp.base[g]].get("labels", [0] * nobj) for g in ids], np.int32)
+        cl = sy.prepare_rgbd_bulk(table(ids, "gray"), table(ids, "depth"), stamps, wl.width, wl.width, masks=masks, track_ids=tids, labels=labs,
+                                  depth_u16_factor=float(np.float32(1.0) / np.float32(DEPTH_FACTOR)), mask_bits=True, on_device=1)
+        calls.append([None] * first + cl)
+    ctx["_pinned"] = pinned
+    WB = (wl.width + 63) // 64
+    return calls, wl.width * wl.height * 3 + nobj * wl.height * WB * 8
 
 
 # ---- the two stream shapes of SURVEY.md §8(d) ----
-def _make_rgbd(seed, n, speed=2.0, with_masks=True):
+def _make_rgbd(seed, n, speed=1.0, with_masks=True, first=0, count=None):
     from . import scene
-    return scene.make_rgbd_sequence(seed, n, speed=speed, with_masks=with_masks)
+    return scene.make_rgbd_sequence(seed, n, speed=speed, with_masks=with_masks, first=first, count=count)
 
 
-def _make_stereo(seed, n, speed=0.35):
+def _make_stereo(seed, n, speed=0.35, first=0, count=None):
     from . import scene
-    return scene.make_stereo_sequence(seed, n, speed=speed)
+    return scene.make_stereo_sequence(seed, n, speed=speed, first=first, count=count)
 
 
-def rgbd_workload(speed=2.0, with_masks=True, n_base=8, stagger=8):
+def rgbd_workload(speed=1.0, with_masks=True, n_base=8, stagger=8):
     """S1: TUM-shaped RGB-D room with three box objects (640x480, 1000 features, TUM2.yaml calibration)."""
     import functools
     return Workload("S1 TUM-shaped RGB-D", 640, 480, slam.RGBD, slam.TUM2, 1000, 30.0, functools.partial(_make_rgbd, speed=speed, with_masks=with_masks), n_base, stagger)

@@ -22,7 +22,7 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16")]
 
 
 class SlamObjects(C.Structure):
@@ -96,11 +96,50 @@ class System:
         if objects is not None:
             arr, ms, keep = self._objects(objects, on_device)
             ms = mask_stride if on_device else (ms or self.cfg.width)
-        return (gp, dp, ts, C.c_int(gs), C.c_int(dpp), C.c_int(1 if on_device else 0), arr, C.c_int(ms), keep, (gray, depth, objects))
+        return (gp, dp, ts, C.c_int(gs), C.c_int(dpp), C.c_int(1 if on_device else 0), arr, C.c_int(ms), (keep, gray, depth, objects), None)
+
+    def prepare_rgbd_bulk(self, gray, depth, stamps, gray_stride, depth_pitch, masks=None, track_ids=None, labels=None, mask_stride=0, depth_u16_factor=None, mask_bits=False,
+                          on_device=1):
+        """prepare_rgbd for T steps at once from address tables: gray / depth uint64 [T, S] (device-accessible addresses), stamps float64 [T, S], masks uint64
+        [T, S, n] with track_ids / labels int32 [S, n].  Returns a list of T tuples for `track_prepared`."""
+        T, S = gray.shape
+        assert S == self.S
+        gray, depth, stamps = np.ascontiguousarray(gray, np.uint64), np.ascontiguousarray(depth, np.uint64), np.ascontiguousarray(stamps, np.float64)
+        objs = None
+        if masks is not None:
+            n = masks.shape[2]
+            masks = np.ascontiguousarray(masks, np.uint64)
+            track_ids, labels = np.ascontiguousarray(track_ids, np.int32), np.ascontiguousarray(labels, np.int32)
+            odt = np.dtype([("n", np.int32), ("pad", np.int32), ("masks", np.uint64), ("track_id", np.uint64), ("label", np.uint64)])
+            assert odt.itemsize == C.sizeof(SlamObjects)
+            objs = np.zeros((T, S), odt)
+            objs["n"] = n
+            objs["masks"] = masks.ctypes.data + (np.arange(T * S, dtype=np.uint64).reshape(T, S)) * np.uint64(8 * n)
+            objs["track_id"] = (track_ids.ctypes.data + np.arange(S, dtype=np.uint64) * np.uint64(4 * n))[None, :]
+            objs["label"] = (labels.ctypes.data + np.arange(S, dtype=np.uint64) * np.uint64(4 * n))[None, :]
+        keep = (gray, depth, stamps, masks, track_ids, labels, objs)
+        out = []
+        for t in range(T):
+            gp = C.cast(gray[t].ctypes.data, C.POINTER(C.c_void_p)); dp = C.cast(depth[t].ctypes.data, C.POINTER(C.c_void_p))
+            arr = C.cast(objs[t].ctypes.data, C.POINTER(SlamObjects)) if objs is not None else None
+            ms = (0 if mask_bits else mask_stride) if objs is not None else 0
+            dpp = C.c_int(depth_pitch)
+            out.append((gp, dp, stamps[t], C.c_int(gray_stride), dpp, C.c_int(on_device), arr, C.c_int(ms), keep, depth_u16_factor))
+        return out
+
+    def prepare_stereo_bulk(self, left, right, stamps, stride, on_device=1):
+        T, S = left.shape
+        assert S == self.S
+        left, right, stamps = np.ascontiguousarray(left, np.uint64), np.ascontiguousarray(right, np.uint64), np.ascontiguousarray(stamps, np.float64)
+        keep = (left, right, stamps)
+        return [(C.cast(left[t].ctypes.data, C.POINTER(C.c_void_p)), C.cast(right[t].ctypes.data, C.POINTER(C.c_void_p)), stamps[t], C.c_int(stride), C.c_int(on_device), keep)
+                for t in range(T)]
 
     def track_prepared(self, prep):
-        gp, dp, ts, gs, dpp, dev, arr, ms, _, _ = prep
-        if arr is not None:
+        gp, dp, ts, gs, dpp, dev, arr, ms, _, u16 = prep
+        if u16 is not None:   # raw 16-bit depth images + DepthMapFactor (the reference's own input, src/Tracking.cc:262)
+            check(self.L.oslam_slam_track_rgbd_raw16(self.h, gp, gs, dp, dpp, C.c_float(u16), dev, ptr(ts) if ts is not None else None, arr, ms, ptr(self.Tcw), ptr(self.state)))
+        elif arr is not None:
             check(self.L.oslam_slam_track_rgbd_objects(self.h, gp, gs, dp, dpp, dev, ptr(ts) if ts is not None else None, arr, ms, ptr(self.Tcw), ptr(self.state)))
         else:
             check(self.L.oslam_slam_track_rgbd(self.h, gp, gs, dp, dpp, dev, ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
@@ -230,6 +269,12 @@ class System:
         check(self.L.oslam_slam_object_stats(self.h, C.c_int(seq), ptr(so)))
         d.update(zip(("semantic_edges", "semantic_frames", "semantic_frames_nonzero", "object3ds", "object_points", "object2ds"), so[:6].tolist()))
         return d
+
+    def lba_window_stats(self, seq):
+        """Local-BA window sizes of one sequence since creation: windows and the sums of local / fixed keyframes, points and edges over them."""
+        out = np.zeros(8, np.int64)
+        check(self.L.oslam_slam_lba_window_stats(self.h, C.c_int(seq), ptr(out)))
+        return dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "fixed_dropped"), out[:6].tolist()))
 
     KT_GROUPS = ("frames", "pose_opt", "lba", "search")
 

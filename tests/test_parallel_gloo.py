@@ -29,25 +29,29 @@ def _oracle_system(cfg):
     return slam.System(cfg, ops)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind="rgbd"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from object_slam_amd import seqbench
-    wl = seqbench.rgbd_workload(n_base=2, stagger=1)
-    summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=3, warmup=2, on_device=False, collect_poses=True)
+    if kind == "stereo":   # BASELINE.json configs[4]: KITTI-shaped stereo sequences dealt to the ranks
+        wl = seqbench.stereo_workload(n_base=2, stagger=1)
+        summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=2, warmup=1, on_device=False, collect_poses=True)
+    else:
+        wl = seqbench.rgbd_workload(n_base=2, stagger=1)
+        summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=3, warmup=2, on_device=False, collect_poses=True)
     poses = np.array(extra["poses"])          # [handles, frames, 1, 4, 4]
     q.put((rank, summ, rec.tolist(), poses, extra["groups"]))
     if world > 1:
         dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, kind="rgbd"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
@@ -73,6 +77,22 @@ def test_run_rank_world2_over_gloo(oracle):
     one = _run(1)
     assert one[0][4] == [[0], [1]]
     # sequence 0 is in both runs (same base sequence and offset): identical poses
+    assert np.array_equal(one[0][3][0], res[0][3][0])
+
+
+def test_run_rank_world2_over_gloo_stereo(oracle):
+    """configs[4] shape: the stereo workload (1241x376, 2000 features) through the same entry point at world_size 2."""
+    res = _run(2, "stereo")
+    s0, s1 = res[0][1], res[1][1]
+    assert s0["total_frames"] == s1["total_frames"] == 2 * 2 * 2 and s0["n_ranks"] == 2
+    assert s0["elapsed_s"] == s1["elapsed_s"] and s0["frames_per_s"] == s1["frames_per_s"]
+    rec = np.array(res[0][2])
+    assert np.array_equal(rec, np.array(res[1][2])) and rec.shape[0] == 2
+    assert list(rec[:, 0]) == [0, 1] and list(rec[:, 2]) == [4, 4]
+    assert res[0][4] == [[0], [2]] and res[1][4] == [[1], [3]]
+    assert s0["lost_frames"] == 0 and s0["map_violations"] == 0 and s0["keyframes"] >= 4      # every sequence initialises from its first stereo pair
+    # rank 0's sequence 0 alone (world 1) gives the same poses: the shard does not depend on the world size
+    one = _run(1, "stereo")
     assert np.array_equal(one[0][3][0], res[0][3][0])
 
 

@@ -221,6 +221,44 @@ def test_hip_semantic_tracking_matches_oracle_driver(oracle):
     assert np.abs(pp - ph).max() > 1e-5
 
 
+def test_raw16_depth_and_bit_masks_in_pinned_host_memory_equal_the_float_run():
+    """oslam_slam_track_rgbd_raw16: raw 16-bit depth images scaled on lookup (DepthMapFactor, reference src/Tracking.cc:262) and caller-packed one-bit masks,
+    all in PINNED HOST memory read by the kernels over PCIe, give bit-identical poses and statistics to the run on float depth images and byte masks;
+    raw16 depth in pageable host memory (scaled while staging) too."""
+    import torch
+    from object_slam_amd import seqbench
+    from object_slam_amd.scene import DEPTH_FACTOR, depth_to_metres
+    from slam_common import make_scene_streams
+    n = 16
+    q = make_scene_streams(1, n)[0]
+    ref = slam.System(slam.make_config(W, H, 1))
+    pr = _semantic_run(ref, q, n)
+    d16 = np.rint(q["depth"].astype(np.float64) * DEPTH_FACTOR).astype(np.uint16)
+    assert np.array_equal(depth_to_metres(d16), q["depth"])
+    bits = seqbench.pack_mask_bits(q["masks"])                       # [n, 3, H, 10] uint64
+    assert bits.shape == (n, 3, H, (W + 63) // 64)
+    g_p, d_p, b_p = torch.from_numpy(q["gray"]).pin_memory(), torch.from_numpy(d16).pin_memory(), torch.from_numpy(bits.view(np.int64)).pin_memory()
+    factor = float(np.float32(1.0) / np.float32(DEPTH_FACTOR))
+    raw = slam.System(slam.make_config(W, H, 1))
+
+    def tab(t_, per):
+        return (t_.data_ptr() + np.arange(n, dtype=np.uint64) * np.uint64(per)).reshape(n, 1)
+    masks = np.stack([tab(b_p, 3 * H * 10 * 8) + np.uint64(o * H * 10 * 8) for o in range(3)], 2)
+    calls = raw.prepare_rgbd_bulk(tab(g_p, W * H), tab(d_p, W * H * 2), np.arange(n, dtype=np.float64).reshape(n, 1) / 30.0, W, W, masks=masks,
+                                  track_ids=np.array([q["track_ids"]], np.int32), labels=np.zeros((1, 3), np.int32), depth_u16_factor=factor, mask_bits=True, on_device=1)
+    pw = np.array([raw.track_prepared(c)[0][0].copy() for c in calls])
+    assert np.array_equal(pw, pr) and raw.stats(0) == ref.stats(0)
+    # pageable host memory, byte masks, raw 16-bit depth
+    pag = slam.System(slam.make_config(W, H, 1))
+    masks_h = np.stack([(q["masks"].ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(3 * H * W) + np.uint64(o * H * W)).reshape(n, 1) for o in range(3)], 2)
+    calls = pag.prepare_rgbd_bulk((q["gray"].ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(W * H)).reshape(n, 1),
+                                  (d16.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(W * H * 2)).reshape(n, 1),
+                                  np.arange(n, dtype=np.float64).reshape(n, 1) / 30.0, W, W, masks=masks_h, track_ids=np.array([q["track_ids"]], np.int32),
+                                  labels=np.zeros((1, 3), np.int32), mask_stride=W, depth_u16_factor=factor, on_device=0)
+    pp = np.array([pag.track_prepared(c)[0][0].copy() for c in calls])
+    assert np.array_equal(pp, pr) and pag.stats(0) == ref.stats(0)
+
+
 def test_local_search_capacity_grows_on_demand(oracle, monkeypatch):
     """The reference's local map is unbounded.  With the first reservation of the local-point matcher forced below the size of the local map, the HIP
     table re-creates the matcher instead of failing the step; the run equals the oracle table's."""
