@@ -393,7 +393,9 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes /* <= 1
 void oslam_lba_destroy(oslam_lba_t* h);
 volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
 /* 1 (default): a single problem is spread over the whole GPU (multi-kernel LM, device-side control);
- * 0: one workgroup per problem in one launch (the batch-of-windows layout).  Same arithmetic. */
+ * 2: one workgroup per problem, the whole LM schedule in ONE launch with the reduced camera system resident in LDS (the batch-of-windows layout of the
+ *    driver; a window whose reduced system and poses exceed the CU's LDS — roughly 30 free keyframes — runs in mode 1 beside the others);
+ * 0: the round-1 one-workgroup-per-problem kernel (reduced system in global memory), kept as an A/B layout.  Same arithmetic in all three. */
 int oslam_lba_set_mode(oslam_lba_t* h, int wide);
 /* Kernel timing for bench.py's roofline: HIP events on the handle's stream around the solve kernels of every later call.
  * Returns and clears the accumulated milliseconds / kernel launches, then sets the switch to `enable`. */

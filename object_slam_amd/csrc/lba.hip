@@ -18,10 +18,12 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <array>
 #include <vector>
 
 #include "common.h"
 #include "se3_math.h"
+#include "slam_pool.h"
 
 namespace oslam {
 
@@ -588,6 +590,10 @@ struct LbaWide {
     const int2* pairs;        // (edge in pose a, edge in pose b) of every point both poses see, grouped by Schur block, point order
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
+    // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
+    const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* tb_start; const uint32_t* tpairs; const int* thr_own; const int* blk_thr;
+    double* parts;            // [nwg][ngroup * kWinThreads][42] per-workgroup, per-slot block sums
+    int ntile, ngroup, nwg, TE, TP, TQ, nblk;
 };
 
 constexpr int kWPt = 128;   // threads per block of the per-point kernels
@@ -1132,17 +1138,14 @@ constexpr int kMfmaMaxN = 6 * kLbaMaxKF;      // 768
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 constexpr int kMfmaThreads = 512;   // 8 wavefronts: 256 registers each (the four-tile trailing step needs ~150; 1024 threads would cap them at 128 and spill)
-__global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* probs, const LbaWide* ws) {
+// Body of the matrix-core solve for one workgroup of kMfmaThreads threads: A = augmented system [n][n + 1] in global memory (upper triangle + rhs column),
+// s_P = LDS row panel of 16 x pw doubles (pw = ((n + 1 + 15) / 16 + 1) * 16), s_x = LDS vector of n + 16 doubles; the solution goes to x (global or LDS).
+// Returns (to every thread) whether all pivots were positive.
+__device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, double* s_P, double* s_x) {
 #pragma clang fp contract(fast)
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
-    LbaCtrl* ct = w.ct;
-    if (ct->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = ct->n, ld = n + 1;
-    double* A = pr.Hs;
-    extern __shared__ __align__(16) double s_P[];          // [16][pw] row panel, pw = panel pitch (columns right of the block, incl. rhs, padded to 16)
-    __shared__ double s_D[kMB][kMB + 1], s_R[kMB], s_x[kMfmaMaxN + kMB];
+    const int ld = n + 1;
+    __shared__ double s_D[kMB][kMB + 1], s_R[kMB];
     __shared__ int s_ok;
     if (tid == 0) s_ok = 1;
     const int pw = ((n + 1 + kMB - 1) / kMB + 1) * kMB;   // pitch of the row panel in LDS
@@ -1277,11 +1280,23 @@ __global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* 
             }
             __syncthreads();
         }
-        for (int i = tid; i < n; i += kMfmaThreads) pr.xp[i] = s_x[i];
+        for (int i = tid; i < n; i += kMfmaThreads) x[i] = s_x[i];
     } else {
-        for (int i = tid; i < n; i += kMfmaThreads) pr.xp[i] = 0;
+        for (int i = tid; i < n; i += kMfmaThreads) x[i] = 0;
     }
-    if (tid == 0) ct->ok2 = ok2 ? 1 : 0;
+    __syncthreads();
+    return ok2;
+}
+
+__global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    extern __shared__ __align__(16) double s_P[];          // [16][pw] row panel, pw = panel pitch (columns right of the block, incl. rhs, padded to 16)
+    __shared__ double s_x[kMfmaMaxN + kMB];
+    const bool ok2 = chol_mfma_dev(pr.Hs, ct->n, pr.xp, s_P, s_x);
+    if (threadIdx.x == 0) ct->ok2 = ok2 ? 1 : 0;
 }
 
 // landmark back-substitution, trial state, computeScale partials
@@ -1507,6 +1522,8 @@ __global__ __launch_bounds__(256) void k_w_final(const LbaProblem* probs, const 
     if (gid == 0) { pr.stats[0] = ct->its[0]; pr.stats[1] = ct->trials[0]; pr.stats[2] = ct->its[1]; pr.stats[3] = ct->trials[1]; }
 }
 
+#include "lba_win.inc"
+
 }  // namespace oslam
 
 using namespace oslam;
@@ -1524,16 +1541,29 @@ struct oslam_lba {
     uint8_t* out_h = nullptr; size_t out_h_cap = 0;
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
-    int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch
+    int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
+                                  // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
+    size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
+    int schur_tiles = 1;          // wide layout: Schur complement by LDS tiles (k_w_schur_tiles, one coalesced read of Hpl per trial) instead of the pair gather (k_w_schur)
     int chol_mode = 0;            // reduced-system solver: 0 auto (LDS-resident scalar kernel while it fits, matrix cores beyond), 1 always MFMA, 2 never
-    struct Prep {                 // one prepared window: offsets into the `in` arena + host-side bookkeeping
+    struct Prep {                 // one prepared window: host-built arrays, then offsets into the `in` arena
         LbaProblem pr;            // scalar fields valid; pointers filled at launch
+        const float* p_poses = nullptr; const uint8_t* p_fixed = nullptr; const float* p_points = nullptr;   // the caller's arrays (copied into the arena by lba_place)
+        std::vector<int> ekf, ept, pt_start, pose_start, pose_edges, pstart, chunk_kf, chunk_e0, chunk_n, kf_chunk0, pt_edge, tile_p0, tile_s0, stg_edge, tb_start;
+        std::vector<uint32_t> tpairs;
+        std::vector<int> thr_own, blk_thr;
+        int TE = 0, TP = 0, TQ = 0, region_doubles = 0, ngroup = 1, hs_global = 0;
+        std::vector<float> eobs, einfo;
+        std::vector<int2> pairs;
         size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
+        size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_tb_start, o_tpairs, o_thr_own, o_blk_thr;
         size_t o_out_poses, o_out_points, o_out_erase, o_out_stats;   // offsets into the `out` arena
         int nfree = 0, nblk = 1; size_t npairs = 0;
-        std::vector<int> order;   // edge permutation (caller order -> point-major)
+        int layout = 0;           // 0 point-major edge numbering (compact / wide kernels), 1 keyframe-major (one workgroup per window, lba_win.inc)
+        std::vector<int> order;   // edge permutation (kernel numbering -> caller order)
     };
     std::vector<Prep> prep;
+    int n_prep = 0;               // windows of the current call (prep keeps its capacity)
     int* h_stop = nullptr;        // pinned, device-visible stop flag
     int* d_stop = nullptr;
     size_t lds = 0;
@@ -1665,13 +1695,18 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
+    if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e) ? 1 : 0;   // 0 = the round-2 pair-gather Schur kernels (k_w_edgeW + k_w_schur)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
     if (hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     h->lds = kRowBufBytes + 64;
+    h->win_lds_max = kWinLdsMax;
     if (hipFuncSetAttribute((const void*)k_lba, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_w_chol<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCholLdsN * (kCholLdsN + 1) * (int)sizeof(double)) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_w_chol_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, kMB * (kMfmaMaxN + 2 * kMB) * (int)sizeof(double)) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_w_chol_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, kMB * (kMfmaMaxN + 2 * kMB) * (int)sizeof(double)) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_lba_win, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_w_schur_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_w_chol_packed, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess) {
         set_error("hipFuncSetAttribute failed"); oslam_lba_destroy(h); return OSLAM_E_HIP;
     }
     *out = h;
@@ -1679,14 +1714,14 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
 }
 
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
-    if (!h || h->prep.empty() || !h->out_h) return OSLAM_E_INVALID;
+    if (!h || h->n_prep < 1 || !h->out_h) return OSLAM_E_INVALID;
     memcpy(out, h->out_h + h->prep[0].o_out_stats, 64);   // stats of window 0 of the last call
     return OSLAM_OK;
 }
 
 int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
-    if (!h) return OSLAM_E_INVALID;
-    h->wide = wide != 0;
+    if (!h || wide < 0 || wide > 2) { set_error("oslam_lba_set_mode: mode must be 0 (compact), 1 (wide) or 2 (one workgroup per window, LDS-resident)"); return OSLAM_E_INVALID; }
+    h->wide = wide;
     return OSLAM_OK;
 }
 
@@ -1700,98 +1735,239 @@ volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h) { return h ? (volatile int
 
 }  // extern "C"
 
-// Prepares window `slot` of the coming launch: validates, builds the point-major / keyframe-major edge orders and the Schur pair lists,
-// and writes the input arrays into the pinned mirror of the `in` arena.  Edge outputs come back in the caller's order.
-static int lba_prepare(oslam_lba_t* h, int slot, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
-                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2, const float K5[5],
-                       int use_stop_flag, const float* poses_out, const float* points_out, const uint8_t* erase, int iters0, int iters1, int nstages,
-                       int robust0, float delta_mono, float delta_stereo) {
-    if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase))) {
-        set_error("NULL argument");
-        return OSLAM_E_INVALID;
+// Schur tiles of a prepared window (lba_win.inc): points cut into tiles whose free-keyframe edges (<= TE) and pair list fit `region_bytes` of LDS, the
+// (tile, block) pair lists on tile-local edge indices and the thread slots of the blocks.  q.pt_edge lists every point's edges by ascending keyframe.
+static int lba_build_tiles(oslam_lba::Prep& q, const std::vector<int>& blk, int nfree, int nP, int nE, size_t region_bytes, char* err, size_t errn) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wformat-security"
+    auto fail = [&](int rc, const char* fmt, auto... a) { snprintf(err, errn, fmt, a...); return rc; };
+#pragma clang diagnostic pop
+    const std::vector<int>& pt_start = q.pt_start;
+    const std::vector<int>& ekf = q.ekf;
+    const int nblk = q.nblk;
+    auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
+    int TP = kWinTilePointsMax, TE = kWinTileEdgesMax, TQ = 0;
+    std::vector<int> stg_local(nE, -1), tile_of_pt(nP, 0);
+    for (;;) {   // the largest tile capacity whose buffers (incl. the largest tile's pair list) fit the region
+        q.tile_p0.clear(); q.tile_s0.clear(); q.stg_edge.clear();
+        int np = 0, ns = 0, nq = 0;
+        TQ = 0;
+        q.tile_p0.push_back(0); q.tile_s0.push_back(0);
+        for (int p = 0; p < nP; p++) {
+            int fe = 0;
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) fe += blk[ekf[q.pt_edge[i]]] >= 0 ? 1 : 0;
+            if (np > 0 && (np + 1 > TP || ns + fe > TE)) { q.tile_p0.push_back(p); q.tile_s0.push_back((int)q.stg_edge.size()); TQ = std::max(TQ, nq); np = 0; ns = 0; nq = 0; }
+            tile_of_pt[p] = (int)q.tile_p0.size() - 1;
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                const int e = q.pt_edge[i];
+                if (blk[ekf[e]] >= 0) { stg_local[e] = ns++; q.stg_edge.push_back(e); }
+            }
+            np++; nq += fe * (fe + 1) / 2;
+        }
+        TQ = std::max(TQ, nq);
+        q.tile_p0.push_back(nP); q.tile_s0.push_back((int)q.stg_edge.size());
+        if (win_tile_doubles(TE, TP, TQ, nblk) * 8 <= region_bytes || TE <= 128) break;
+        TE -= 32;
     }
-    if (nKF < 1 || nKF > h->max_kf || nP < 0 || nE < 0) {
-        set_error("problem (%d keyframes, %d points, %d edges) exceeds the handle capacity (%d keyframes per window)", nKF, nP, nE, h->max_kf);
-        return OSLAM_E_CAPACITY;
+    q.TE = TE; q.TP = TP; q.TQ = TQ;
+    const int ntile = (int)q.tile_p0.size() - 1;
+    std::vector<int>& tb = q.tb_start;
+    tb.assign((size_t)ntile * nblk + 1, 0);
+    for (int p = 0; p < nP; p++) {
+        const size_t base = (size_t)tile_of_pt[p] * nblk;
+        for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+            const int bi = blk[ekf[q.pt_edge[i]]];
+            if (bi < 0) continue;
+            for (int j = i; j < pt_start[p + 1]; j++) {   // ascending keyframe index inside a point: bj >= bi for every free partner at or after i
+                const int bj = blk[ekf[q.pt_edge[j]]];
+                if (bj >= 0) tb[base + tof(bi, bj) + 1]++;
+            }
+        }
     }
-    if (slot == 0) { h->in_off = 0; h->prep.clear(); }
-    // stable counting sort of the edges by point (O(E); the caller's order inside a point is kept)
-    std::vector<int> pt_start(nP + 1, 0), pose_start(nKF + 1, 0);
-    h->prep.emplace_back();
-    oslam_lba::Prep& q = h->prep.back();
+    for (size_t t2 = 0; t2 < (size_t)ntile * nblk; t2++) tb[t2 + 1] += tb[t2];
+    q.npairs = (size_t)tb[(size_t)ntile * nblk];
+    q.tpairs.resize(q.npairs);
+    {
+        std::vector<int> cur2(tb.begin(), tb.end() - 1);
+        for (int p = 0; p < nP; p++) {
+            const size_t base = (size_t)tile_of_pt[p] * nblk;
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                const int ei = q.pt_edge[i], bi = blk[ekf[ei]];
+                if (bi < 0) continue;
+                for (int j = i; j < pt_start[p + 1]; j++) {
+                    const int ej = q.pt_edge[j], bj = blk[ekf[ej]];
+                    if (bj >= 0) q.tpairs[cur2[base + tof(bi, bj)]++] = (uint32_t)stg_local[ei] | ((uint32_t)stg_local[ej] << 16);
+                }
+            }
+        }
+    }
+    {   // slots of the Schur phase: every block with pairs gets one thread of one pass; spare threads go where the pairs per thread are highest; ordered by load
+        std::vector<long long> load(nblk, 0);
+        for (int t2 = 0; t2 < ntile; t2++)
+            for (int b2 = 0; b2 < nblk; b2++) load[b2] += tb[(size_t)t2 * nblk + b2 + 1] - tb[(size_t)t2 * nblk + b2];
+        std::vector<int> cnt(nblk, 0);
+        int used = 0;
+        for (int b2 = 0; b2 < nblk; b2++) if (load[b2] > 0) { cnt[b2] = 1; used++; }
+        const int G = std::max(1, (used + kWinThreads - 1) / kWinThreads);
+        if (G > kWinGroupsMax) return fail(OSLAM_E_CAPACITY, "%d blocks with pairs > %d", used, kWinGroupsMax * kWinThreads);
+        q.ngroup = G;
+        if (G == 1 && used > 0) {
+            std::vector<std::pair<double, int>> heap;   // (pairs per thread, block)
+            for (int b2 = 0; b2 < nblk; b2++) if (cnt[b2]) heap.push_back(std::make_pair((double)load[b2], b2));
+            std::make_heap(heap.begin(), heap.end());
+            while (used < kWinThreads && !heap.empty()) {
+                std::pop_heap(heap.begin(), heap.end());
+                const int b2 = heap.back().second;
+                heap.pop_back();
+                if (cnt[b2] >= kWinSplitMax || load[b2] / cnt[b2] < 8) continue;   // (a thread with a handful of pairs gains nothing from help)
+                cnt[b2]++; used++;
+                heap.push_back(std::make_pair((double)load[b2] / cnt[b2], b2));
+                std::push_heap(heap.begin(), heap.end());
+            }
+        }
+        std::vector<std::pair<double, int>> ord;
+        for (int b2 = 0; b2 < nblk; b2++) if (cnt[b2]) ord.push_back(std::make_pair(-(double)load[b2] / cnt[b2], b2));
+        std::sort(ord.begin(), ord.end());
+        q.thr_own.assign((size_t)G * kWinThreads, -1); q.blk_thr.assign(nblk, 0);
+        if (G == 1) {
+            int t0 = 0;
+            for (auto& o2 : ord) {
+                const int b2 = o2.second;
+                q.blk_thr[b2] = t0 | (cnt[b2] << 16);
+                for (int s2 = 0; s2 < cnt[b2]; s2++) q.thr_own[t0 + s2] = b2 | (s2 << 16) | (cnt[b2] << 24);
+                t0 += cnt[b2];
+            }
+        } else {   // more blocks than threads: the load-sorted blocks are dealt to the passes in turn (every pass keeps the load order)
+            std::vector<int> fill(G, 0);
+            for (size_t i = 0; i < ord.size(); i++) {
+                const int b2 = ord[i].second, g = (int)(i % G), slot = g * kWinThreads + fill[g]++;
+                q.blk_thr[b2] = slot | (1 << 16);
+                q.thr_own[slot] = b2 | (1 << 24);
+            }
+        }
+    }
+    return OSLAM_OK;
+}
+
+// ---- preparation of one window (thread-safe: touches only its Prep): validation, the edge orders of the layout, Schur pair lists ----
+static int lba_build(const oslam_lba_t* h, oslam_lba::Prep& q, int layout, bool want_pairs, bool use_tiles, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points,
+                     int nE, const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2, const float K5[5], int use_stop_flag,
+                     const float* poses_out, const float* points_out, const uint8_t* erase, int iters0, int iters1, int nstages, int robust0, float delta_mono,
+                     float delta_stereo, char* err, size_t errn) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wformat-security"
+    auto fail = [&](int rc, const char* fmt, auto... a) { snprintf(err, errn, fmt, a...); return rc; };
+#pragma clang diagnostic pop
+    if (!h || !poses || !fixed || !points || !K5 || !poses_out || !points_out || (nE > 0 && (!edge_kf || !edge_pt || !edge_obs || !edge_invSigma2 || !erase)))
+        return fail(OSLAM_E_INVALID, "NULL argument");
+    if (nKF < 1 || nKF > h->max_kf || nP < 0 || nE < 0)
+        return fail(OSLAM_E_CAPACITY, "problem (%d keyframes, %d points, %d edges) exceeds the handle capacity (%d keyframes per window)", nKF, nP, nE, h->max_kf);
+    q.layout = layout;
+    q.p_poses = poses; q.p_fixed = fixed; q.p_points = points;
+    std::vector<int>& pt_start = q.pt_start; std::vector<int>& pose_start = q.pose_start;
+    pt_start.assign(nP + 1, 0); pose_start.assign(nKF + 1, 0);
     std::vector<int>& order = q.order;
     order.resize(nE);
     for (int i = 0; i < nE; i++) {
-        if (edge_kf[i] < 0 || edge_kf[i] >= nKF || edge_pt[i] < 0 || edge_pt[i] >= nP) { set_error("edge %d references vertex out of range", i); return OSLAM_E_INVALID; }
+        if (edge_kf[i] < 0 || edge_kf[i] >= nKF || edge_pt[i] < 0 || edge_pt[i] >= nP) return fail(OSLAM_E_INVALID, "edge %d references vertex out of range", i);
         pt_start[edge_pt[i] + 1]++;
         pose_start[edge_kf[i] + 1]++;
     }
     for (int p = 0; p < nP; p++) pt_start[p + 1] += pt_start[p];
     for (int k = 0; k < nKF; k++) pose_start[k + 1] += pose_start[k];
-    {
+    {   // stable counting sort of the edges by point (O(E); the caller's order inside a point is kept)
         std::vector<int> cur(pt_start.begin(), pt_start.end() - 1);
         for (int i = 0; i < nE; i++) order[cur[edge_pt[i]]++] = i;
     }
-    std::vector<int> ekf(nE), ept(nE), pose_edges(nE);
-    std::vector<float> eobs((size_t)nE * 3), einfo(nE);
+    if (layout == 1) {   // keyframe-major: a second stable counting sort, by keyframe -> (keyframe, point) order
+        std::vector<int> cur(pose_start.begin(), pose_start.end() - 1), o2(nE);
+        for (int i = 0; i < nE; i++) o2[cur[edge_kf[order[i]]]++] = order[i];
+        order.swap(o2);
+    }
+    std::vector<int>& ekf = q.ekf; std::vector<int>& ept = q.ept;
+    ekf.resize(nE); ept.resize(nE); q.eobs.resize((size_t)nE * 3); q.einfo.resize(nE);
     for (int i = 0; i < nE; i++) {
-        const int s = order[i];
-        ekf[i] = edge_kf[s]; ept[i] = edge_pt[s]; einfo[i] = edge_invSigma2[s];
-        for (int k = 0; k < 3; k++) eobs[(size_t)i * 3 + k] = edge_obs[(size_t)s * 3 + k];
-    }
-    {
-        std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
-        for (int i = 0; i < nE; i++) pose_edges[cur[ekf[i]]++] = i;
-    }
-    {   // the reference has one observation of a point per keyframe
-        std::vector<int> seen(nKF, -1);
-        for (int p = 0; p < nP; p++)
-            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                if (seen[ekf[i]] == p) { set_error("duplicate observation of point %d in keyframe %d", p, ekf[i]); return OSLAM_E_INVALID; }
-                seen[ekf[i]] = p;
-            }
+        const int sidx = order[i];
+        ekf[i] = edge_kf[sidx]; ept[i] = edge_pt[sidx]; q.einfo[i] = edge_invSigma2[sidx];
+        for (int k = 0; k < 3; k++) q.eobs[(size_t)i * 3 + k] = edge_obs[(size_t)sidx * 3 + k];
     }
     int nfree = 0;
     for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
-    if (nfree > kLbaMaxKF) { set_error("%d free keyframes > %d", nfree, kLbaMaxKF); return OSLAM_E_CAPACITY; }
+    if (nfree > kLbaMaxKF) return fail(OSLAM_E_CAPACITY, "%d free keyframes > %d", nfree, kLbaMaxKF);
     q.nfree = nfree; q.nblk = std::max(1, nfree * (nfree + 1) / 2);
-    int rc;
-    if ((rc = in_put(h, poses, (size_t)nKF * 64, &q.o_poses)) || (rc = in_put(h, fixed, (size_t)nKF, &q.o_fixed)) || (rc = in_put(h, points, (size_t)nP * 12, &q.o_points)) ||
-        (rc = in_put(h, ekf.data(), (size_t)nE * 4, &q.o_ekf)) || (rc = in_put(h, ept.data(), (size_t)nE * 4, &q.o_ept)) || (rc = in_put(h, eobs.data(), (size_t)nE * 12, &q.o_eobs)) ||
-        (rc = in_put(h, einfo.data(), (size_t)nE * 4, &q.o_einfo)) || (rc = in_put(h, pt_start.data(), (size_t)(nP + 1) * 4, &q.o_ptstart)) ||
-        (rc = in_put(h, pose_start.data(), (size_t)(nKF + 1) * 4, &q.o_posestart)) || (rc = in_put(h, pose_edges.data(), (size_t)nE * 4, &q.o_poseedges)))
-        return rc;
-    q.npairs = 0; q.o_pairs = q.o_pstart = 0;
-    if (h->wide) {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
+    std::vector<int> blk(nKF);
+    for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
+    auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
+    q.npairs = 0; q.pairs.clear(); q.pstart.clear();
+    if (layout == 0) {
+        q.pose_edges.resize(nE);
+        std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
+        for (int i = 0; i < nE; i++) q.pose_edges[cur[ekf[i]]++] = i;
+        std::vector<int> seen(nKF, -1);   // the reference has one observation of a point per keyframe
+        for (int p = 0; p < nP; p++)
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                if (seen[ekf[i]] == p) return fail(OSLAM_E_INVALID, "duplicate observation of point %d in keyframe %d", p, ekf[i]);
+                seen[ekf[i]] = p;
+            }
+        q.tile_p0.clear();
+        if (want_pairs && use_tiles) {
+            // Schur complement by tiles (k_w_schur_tiles): every point's edges by ascending keyframe, then the tile / pair / slot structures of lba_win.inc
+            q.pt_edge.resize(nE);
+            for (int i = 0; i < nE; i++) q.pt_edge[i] = i;
+            for (int p = 0; p < nP; p++) std::sort(q.pt_edge.begin() + pt_start[p], q.pt_edge.begin() + pt_start[p + 1], [&](int x, int y) { return ekf[x] < ekf[y]; });
+            const int rc = lba_build_tiles(q, blk, nfree, nP, nE, (size_t)kWinLdsMax, err, errn);
+            if (rc) return rc;
+        } else if (want_pairs) {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
+            const int nblk = q.nblk;
+            std::vector<int>& pstart = q.pstart;
+            pstart.assign(nblk + 1, 0);
+            for (int p = 0; p < nP; p++)
+                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                    const int bi = blk[ekf[i]];
+                    if (bi < 0) continue;
+                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                        const int bj = blk[ekf[j]];
+                        if (bj >= bi) pstart[tof(bi, bj) + 1]++;
+                    }
+                }
+            for (int t2 = 0; t2 < nblk; t2++) pstart[t2 + 1] += pstart[t2];
+            q.npairs = (size_t)pstart[nblk];
+            q.pairs.resize(q.npairs);
+            std::vector<int> cur2(pstart.begin(), pstart.end() - 1);
+            for (int p = 0; p < nP; p++)
+                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
+                    const int bi = blk[ekf[i]];
+                    if (bi < 0) continue;
+                    for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
+                        const int bj = blk[ekf[j]];
+                        if (bj >= bi) q.pairs[cur2[tof(bi, bj)]++] = make_int2(i, j);
+                    }
+                }
+        }
+    } else {
+        // a point's edges by ascending id (= ascending keyframe), the chunks of every keyframe, the pair lists on the keyframe-major ids
+        q.pt_edge.resize(nE);
+        {
+            std::vector<int> cur(pt_start.begin(), pt_start.end() - 1);
+            for (int i = 0; i < nE; i++) q.pt_edge[cur[ept[i]]++] = i;
+        }
+        for (int p = 0; p < nP; p++)
+            for (int i = pt_start[p] + 1; i < pt_start[p + 1]; i++)
+                if (ekf[q.pt_edge[i]] == ekf[q.pt_edge[i - 1]]) return fail(OSLAM_E_INVALID, "duplicate observation of point %d in keyframe %d", p, ekf[q.pt_edge[i]]);
+        q.chunk_kf.clear(); q.chunk_e0.clear(); q.chunk_n.clear(); q.kf_chunk0.assign(nKF + 1, 0);
+        for (int k = 0; k < nKF; k++) {
+            q.kf_chunk0[k] = (int)q.chunk_kf.size();
+            for (int e0 = pose_start[k]; e0 < pose_start[k + 1]; e0 += 64) { q.chunk_kf.push_back(k); q.chunk_e0.push_back(e0); q.chunk_n.push_back(std::min(64, pose_start[k + 1] - e0)); }
+        }
+        q.kf_chunk0[nKF] = (int)q.chunk_kf.size();
+        // Schur tiles (lba_win.inc): the reduced system and the tile buffers share one LDS region
         const int nblk = q.nblk;
-        std::vector<int> blk(nKF);
-        for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
-        auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
-        std::vector<int> pstart(nblk + 1, 0);
-        for (int p = 0; p < nP; p++)
-            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                const int bi = blk[ekf[i]];
-                if (bi < 0) continue;
-                for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
-                    const int bj = blk[ekf[j]];
-                    if (bj >= bi) pstart[tof(bi, bj) + 1]++;
-                }
-            }
-        for (int t2 = 0; t2 < nblk; t2++) pstart[t2 + 1] += pstart[t2];
-        q.npairs = (size_t)pstart[nblk];
-        if ((rc = in_take(h, q.npairs * sizeof(int2), &q.o_pairs))) return rc;
-        int2* pairs = (int2*)(h->in_h + q.o_pairs);
-        std::vector<int> cur(pstart.begin(), pstart.end() - 1);
-        for (int p = 0; p < nP; p++)
-            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                const int bi = blk[ekf[i]];
-                if (bi < 0) continue;
-                for (int j = pt_start[p]; j < pt_start[p + 1]; j++) {
-                    const int bj = blk[ekf[j]];
-                    if (bj >= bi) pairs[cur[tof(bi, bj)]++] = make_int2(i, j);
-                }
-            }
-        if ((rc = in_put(h, pstart.data(), (size_t)(nblk + 1) * 4, &q.o_pstart))) return rc;
+        const size_t region_bytes = h->win_lds_max - win_persist_bytes(nKF, nfree);
+        size_t hs_d = (size_t)win_hs_doubles(nfree);
+        q.hs_global = hs_d * 8 > region_bytes ? 1 : 0;
+        if (q.hs_global) { const size_t n6 = 6 * (size_t)nfree, pw = ((n6 + 1 + kMB - 1) / kMB + 1) * kMB; hs_d = (size_t)kMB * pw + n6 + 2 * kMB; }   // the matrix-core solver's row panel + vector
+        { const int rc = lba_build_tiles(q, blk, nfree, nP, nE, region_bytes, err, errn); if (rc) return rc; }
+        q.region_doubles = (int)std::max(hs_d, win_tile_doubles(q.TE, q.TP, q.TQ, nblk));
     }
     LbaProblem& pr = q.pr;
     memset(&pr, 0, sizeof(pr));
@@ -1802,42 +1978,149 @@ static int lba_prepare(oslam_lba_t* h, int slot, int nKF, const float* poses, co
     return OSLAM_OK;
 }
 
+// copies a prepared window's arrays into the pinned mirror of the `in` arena (serial: the arena is a bump allocator)
+static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
+    const size_t nKF = q.pr.K, nP = q.pr.P, nE = q.pr.E;
+    int rc;
+    if ((rc = in_put(h, q.p_poses, nKF * 64, &q.o_poses)) || (rc = in_put(h, q.p_fixed, nKF, &q.o_fixed)) || (rc = in_put(h, q.p_points, nP * 12, &q.o_points)) ||
+        (rc = in_put(h, q.ekf.data(), nE * 4, &q.o_ekf)) || (rc = in_put(h, q.ept.data(), nE * 4, &q.o_ept)) || (rc = in_put(h, q.eobs.data(), nE * 12, &q.o_eobs)) ||
+        (rc = in_put(h, q.einfo.data(), nE * 4, &q.o_einfo)) || (rc = in_put(h, q.pt_start.data(), (nP + 1) * 4, &q.o_ptstart)))
+        return rc;
+    q.o_posestart = q.o_poseedges = q.o_pairs = q.o_pstart = q.o_chunk_kf = q.o_chunk_e0 = q.o_chunk_n = q.o_kf_chunk0 = q.o_pt_edge = 0;
+    q.o_tile_p0 = q.o_tile_s0 = q.o_stg_edge = q.o_tb_start = q.o_tpairs = q.o_thr_own = q.o_blk_thr = 0;
+    if (q.layout == 0) {
+        if ((rc = in_put(h, q.pose_start.data(), (nKF + 1) * 4, &q.o_posestart)) || (rc = in_put(h, q.pose_edges.data(), nE * 4, &q.o_poseedges))) return rc;
+        if (!q.tile_p0.empty() &&
+            ((rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
+             (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.tb_start.data(), q.tb_start.size() * 4, &q.o_tb_start)) ||
+             (rc = in_put(h, q.tpairs.data(), q.tpairs.size() * 4, &q.o_tpairs)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
+             (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr))))
+            return rc;
+    } else {
+        const size_t nc = q.chunk_kf.size();
+        if ((rc = in_put(h, q.chunk_kf.data(), nc * 4, &q.o_chunk_kf)) || (rc = in_put(h, q.chunk_e0.data(), nc * 4, &q.o_chunk_e0)) || (rc = in_put(h, q.chunk_n.data(), nc * 4, &q.o_chunk_n)) ||
+            (rc = in_put(h, q.kf_chunk0.data(), (nKF + 1) * 4, &q.o_kf_chunk0)) || (rc = in_put(h, q.pt_edge.data(), nE * 4, &q.o_pt_edge)) ||
+            (rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
+            (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.tb_start.data(), q.tb_start.size() * 4, &q.o_tb_start)) ||
+            (rc = in_put(h, q.tpairs.data(), q.tpairs.size() * 4, &q.o_tpairs)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
+            (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr)))
+            return rc;
+    }
+    if (q.layout == 0 && !q.pstart.empty()) {
+        if ((rc = in_put(h, q.pairs.data(), q.npairs * sizeof(int2), &q.o_pairs)) || (rc = in_put(h, q.pstart.data(), q.pstart.size() * 4, &q.o_pstart))) return rc;
+    }
+    return OSLAM_OK;
+}
+
+struct LbaArgs {   // one window as the entry points receive it
+    int nKF; const float* poses; const uint8_t* fixed; int nP; const float* points; int nE; const int32_t* edge_kf; const int32_t* edge_pt; const float* edge_obs;
+    const float* edge_invSigma2; float* poses_out; float* points_out; uint8_t* erase;
+};
+
+// does window (K keyframes, nfree of them free) fit the one-workgroup-per-window kernel?
+static bool win_fits(const oslam_lba_t* h, int K, int nfree) {
+    if (nfree < 1 || nfree * (nfree + 1) / 2 > kWinGroupsMax * kWinThreads || nfree > kLbaMaxKF) return false;
+    const size_t persist = win_persist_bytes(K, nfree);
+    if (persist >= h->win_lds_max) return false;
+    const size_t n6 = 6 * (size_t)nfree, pw = ((n6 + 1 + kMB - 1) / kMB + 1) * kMB;
+    // a tile must hold every point's edges (<= nfree <= 128 <= TE) and, in the worst case, their pairs; a system that does not fit LDS needs the solver's panel
+    return persist + 8 * win_tile_doubles(128, kWinTilePointsMax, 128 * (nfree + 1) / 2, nfree * (nfree + 1) / 2) <= h->win_lds_max &&
+           persist + 8 * std::min((size_t)win_hs_doubles(nfree), (size_t)kMB * pw + n6 + 2 * kMB) <= h->win_lds_max;
+}
+
+// Prepares all windows of a call (in parallel on the shared workers when there are several) and places them in the `in` arena.
+static int lba_prepare_all(oslam_lba_t* h, int n, const LbaArgs* a, const float K5[5], int use_stop_flag, int iters0, int iters1, int nstages, int robust0, float delta_mono,
+                           float delta_stereo) {
+    h->in_off = 0;
+    if ((int)h->prep.size() < n) h->prep.resize(n);   // (the windows' vectors keep their capacity from call to call)
+    h->n_prep = n;
+    std::vector<int> rcs(n, 0);
+    std::vector<std::array<char, 192>> errs(n);
+    // wide layout: the Schur complement by tiles needs every window's blocks to fit the thread slots (<= 63 free keyframes); otherwise the whole call gathers pairs
+    bool use_tiles = h->schur_tiles != 0;
+    std::vector<int> nfrees(n, 0);
+    for (int i = 0; i < n; i++) {
+        const LbaArgs& q = a[i];
+        if (q.fixed && q.nKF > 0) for (int k = 0; k < q.nKF; k++) nfrees[i] += q.fixed[k] ? 0 : 1;
+        if (nfrees[i] * (nfrees[i] + 1) / 2 > kWinGroupsMax * kWinThreads) use_tiles = false;
+    }
+    auto one = [&](int i) {
+        const LbaArgs& q = a[i];
+        const int nfree = nfrees[i];
+        const int layout = (h->wide == 2 && win_fits(h, q.nKF, nfree)) ? 1 : 0;
+        errs[i][0] = 0;
+        rcs[i] = lba_build(h, h->prep[i], layout, layout == 1 || h->wide != 0, use_tiles, q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, K5,
+                           use_stop_flag, q.poses_out, q.points_out, q.erase, iters0, iters1, nstages, robust0, delta_mono, delta_stereo, errs[i].data(), errs[i].size());
+    };
+    if (n > 1) oslam_drv::shared_parallel_for(n, one);
+    else one(0);
+    for (int i = 0; i < n; i++) if (rcs[i]) { set_error("%s", errs[i].data()); return rcs[i]; }
+    for (int i = 0; i < n; i++) { const int rc = lba_place(h, h->prep[i]); if (rc) return rc; }
+    return OSLAM_OK;
+}
+
 // Runs the prepared windows and brings their outputs into the pinned `out` mirror (the stream is drained on return).
-// Compact mode: ONE launch of k_lba, one workgroup per window.  Wide mode: every LM trial is eight launches whose grids cover ALL
-// windows (blockIdx.y = window, blockIdx.x sized for the largest one); windows that have finished return at once.
+// Layout-1 windows: ONE launch of k_lba_win, one workgroup per window (largest first).  Layout-0 windows: compact mode = one launch of k_lba; wide mode =
+// every LM trial as eight launches whose grids cover all of them (blockIdx.y = window, blockIdx.x sized for the largest one; finished windows return at once).
 static int lba_launch(oslam_lba_t* h) {
-    const int n = (int)h->prep.size();
+    const int n = h->n_prep;
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = h->strm;
     int rc;
+    std::vector<int> idx0, idx1;   // windows by layout
+    for (int i = 0; i < n; i++) (h->prep[i].layout == 1 ? idx1 : idx0).push_back(i);
+    const int n0 = (int)idx0.size(), n1 = (int)idx1.size();
+    const bool wide = h->wide != 0;   // layout-0 windows of a wide / win handle run in wide mode
     // ---- carve the arenas ----
-    size_t o_probs, o_ws;
-    if ((rc = in_take(h, sizeof(LbaProblem) * n, &o_probs)) || (rc = in_take(h, sizeof(LbaWide) * n, &o_ws))) return rc;
+    size_t o_probs, o_ws, o_wins, o_order;
+    if ((rc = in_take(h, sizeof(LbaProblem) * n, &o_probs)) || (rc = in_take(h, sizeof(LbaWide) * std::max(n0, 1), &o_ws)) || (rc = in_take(h, sizeof(LbaWin) * std::max(n1, 1), &o_wins)) ||
+        (rc = in_take(h, sizeof(int) * std::max(n1, 1), &o_order)))
+        return rc;
     size_t work = 0, outb = 0;
     auto takeW = [&](size_t bytes) { const size_t at = work; work += (bytes + 255) & ~(size_t)255; return at; };
     auto takeO = [&](size_t bytes) { const size_t at = outb; outb += (bytes + 255) & ~(size_t)255; return at; };
-    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W; };
+    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, chunkC, pairPart, parts; };
+    bool tiles = wide && n0 > 0;     // wide layout: Schur complement by tiles when every layout-0 window carries the structures
+    for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
+    const int nwg_call = std::max(1, std::min(16, (2 * 256 + std::max(n0, 1) - 1) / std::max(n0, 1)));   // workgroups per window: ~2 per CU over the call
+    size_t tiles_lds = 0, packed_lds = 0;
+    int maxWg = 1, maxSum = 1;
     std::vector<WOff> wo(n);
     int maxNbPt = 1, maxK = 1, maxE = 1, maxBlk = 1, maxFin = 1, maxInit = 1, max_slots = 0, min_group = 4, max_n6 = 0;
     bool all_lds = true;
-    const size_t ctrl_base = takeW(sizeof(LbaCtrl) * n);   // contiguous: the host polls all of them with one copy
+    const size_t ctrl_base = takeW(sizeof(LbaCtrl) * std::max(n0, 1));   // contiguous: the host polls all of them with one copy
+    size_t win_lds = 0;
     for (int i = 0; i < n; i++) {
         oslam_lba::Prep& q = h->prep[i];
         const size_t K = q.pr.K, P = q.pr.P, E = q.pr.E, n6 = 6 * (size_t)q.nfree;
         const int nbpt = div_up(std::max((int)P, 1), kWPt);
         WOff& o = wo[i];
-        o.Xa = takeW(P * 24); o.Xb = takeW(P * 24); o.chi2 = takeW(E * 8); o.level = takeW(E); o.Hpl = takeW(E * 144); o.Hll = takeW(P * 72); o.Dinv = takeW(P * 72);
-        o.bl = takeW(P * 24); o.xl = takeW(P * 24); o.Hpp = takeW(K * 288); o.bp = takeW(K * 48); o.Hs = takeW(n6 * (n6 + 1) * 8); o.xp = takeW((n6 + 8) * 8);
-        if (h->wide) {
-            o.ctrl = ctrl_base + sizeof(LbaCtrl) * i; o.T = takeW(sizeof(SE3) * 2 * K); o.R = takeW(144 * K); o.blk = takeW(4 * K); o.free_pose = takeW(4 * K);
-            o.partF = takeW(8 * (nbpt + 2)); o.partS = takeW(8 * (nbpt + 2)); o.partM = takeW(8 * (nbpt + 2)); o.W = takeW(E * 144);
+        o.Xa = takeW(P * 24); o.Xb = takeW(P * 24); o.chi2 = takeW(E * 8); o.level = takeW(E); o.Hll = takeW(P * 72); o.bl = takeW(P * 24);
+        if (q.layout == 1) {
+            o.chunkC = takeW(q.chunk_kf.size() * 27 * 8); o.pairPart = takeW((size_t)q.ngroup * kWinThreads * 42 * 8);
+            o.Hs = q.hs_global ? takeW(n6 * (n6 + 1) * 8) : 0;
+            win_lds = std::max(win_lds, win_persist_bytes((int)K, q.nfree) + 8 * (size_t)q.region_doubles);
+        } else {
+            o.Hpl = takeW(E * 144); o.Dinv = takeW(P * 72); o.xl = takeW(P * 24); o.Hpp = takeW(K * 288); o.bp = takeW(K * 48); o.Hs = takeW(n6 * (n6 + 1) * 8); o.xp = takeW((n6 + 8) * 8);
+            if (wide) {
+                const int j = (int)(std::find(idx0.begin(), idx0.end(), i) - idx0.begin());
+                o.ctrl = ctrl_base + sizeof(LbaCtrl) * j; o.T = takeW(sizeof(SE3) * 2 * K); o.R = takeW(144 * K); o.blk = takeW(4 * K); o.free_pose = takeW(4 * K);
+                o.partF = takeW(8 * (nbpt + 2)); o.partS = takeW(8 * (nbpt + 2)); o.partM = takeW(8 * (nbpt + 2));
+                if (tiles) {
+                    const int ntile = (int)q.tile_p0.size() - 1, nwg = std::max(1, std::min(nwg_call, ntile));
+                    o.parts = takeW((size_t)nwg * q.ngroup * kWinThreads * 42 * 8);
+                    tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP, q.TQ, q.nblk));
+                    maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
+                } else o.W = takeW(E * 144);
+                packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
+            }
+            maxNbPt = std::max(maxNbPt, nbpt); maxK = std::max(maxK, (int)K); maxE = std::max(maxE, (int)E); maxBlk = std::max(maxBlk, q.nblk);
+            maxFin = std::max(maxFin, (int)std::max(std::max(E, K), P * 3)); maxInit = std::max(maxInit, (int)std::max(P * 3, E));
+            const int its = q.pr.iters0 + (q.pr.nstages > 1 ? q.pr.iters1 : 0);
+            max_slots = std::max(max_slots, its * 10 + 8); min_group = std::max(min_group, its);
+            all_lds = all_lds && (int)n6 <= kCholLdsN; max_n6 = std::max(max_n6, (int)n6);
         }
         q.o_out_poses = takeO(K * 64); q.o_out_points = takeO(P * 12); q.o_out_erase = takeO(E); q.o_out_stats = takeO(64);
-        maxNbPt = std::max(maxNbPt, nbpt); maxK = std::max(maxK, (int)K); maxE = std::max(maxE, (int)E); maxBlk = std::max(maxBlk, q.nblk);
-        maxFin = std::max(maxFin, (int)std::max(std::max(E, K), P * 3)); maxInit = std::max(maxInit, (int)std::max(P * 3, E));
-        const int its = q.pr.iters0 + (q.pr.nstages > 1 ? q.pr.iters1 : 0);
-        max_slots = std::max(max_slots, its * 10 + 8); min_group = std::max(min_group, its);
-        all_lds = all_lds && (int)n6 <= kCholLdsN; max_n6 = std::max(max_n6, (int)n6);
     }
     if ((rc = pool_ensure(h->in_d, h->in_off)) || (rc = pool_ensure(h->work_d, work)) || (rc = pool_ensure(h->out_d, outb))) return rc;
     if (outb > h->out_h_cap) {
@@ -1846,76 +2129,130 @@ static int lba_launch(oslam_lba_t* h) {
         OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->out_h, outb + outb / 2, 0));
         h->out_h_cap = outb + outb / 2;
     }
-    if (h->wide && sizeof(LbaCtrl) * n > h->h_ctrl_cap) {
+    if (wide && n0 > 0 && sizeof(LbaCtrl) * n0 > h->h_ctrl_cap) {
         if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
         h->h_ctrl = nullptr; h->h_ctrl_cap = 0;
-        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_ctrl, sizeof(LbaCtrl) * n * 2, 0));
-        h->h_ctrl_cap = sizeof(LbaCtrl) * n * 2;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&h->h_ctrl, sizeof(LbaCtrl) * n0 * 2, 0));
+        h->h_ctrl_cap = sizeof(LbaCtrl) * n0 * 2;
     }
     uint8_t* I = (uint8_t*)h->in_d.p; uint8_t* Wk = (uint8_t*)h->work_d.p; uint8_t* O = (uint8_t*)h->out_d.p;
+    // the problem records: layout-0 windows first (slots 0 .. n0-1 of probs / ws), then the layout-1 windows (slots n0 .. n-1 of probs, 0 .. n1-1 of wins)
     LbaProblem* hp = (LbaProblem*)(h->in_h + o_probs);
     LbaWide* hw = (LbaWide*)(h->in_h + o_ws);
-    for (int i = 0; i < n; i++) {
+    LbaWin* hwin = (LbaWin*)(h->in_h + o_wins);
+    int* horder = (int*)(h->in_h + o_order);
+    auto fill_problem = [&](int i) {
         const oslam_lba::Prep& q = h->prep[i];
         const WOff& o = wo[i];
         LbaProblem pr = q.pr;
         pr.poses = (const float*)(I + q.o_poses); pr.fixed = I + q.o_fixed; pr.points = (const float*)(I + q.o_points); pr.e_kf = (const int*)(I + q.o_ekf);
         pr.e_pt = (const int*)(I + q.o_ept); pr.e_obs = (const float*)(I + q.o_eobs); pr.e_info = (const float*)(I + q.o_einfo); pr.pt_start = (const int*)(I + q.o_ptstart);
         pr.pose_start = (const int*)(I + q.o_posestart); pr.pose_edges = (const int*)(I + q.o_poseedges);
-        pr.Xa = (double*)(Wk + o.Xa); pr.Xb = (double*)(Wk + o.Xb); pr.chi2 = (double*)(Wk + o.chi2); pr.level = Wk + o.level; pr.Hpl = (double*)(Wk + o.Hpl);
-        pr.Hll = (double*)(Wk + o.Hll); pr.Dinv = (double*)(Wk + o.Dinv); pr.bl = (double*)(Wk + o.bl); pr.xl = (double*)(Wk + o.xl); pr.Hpp = (double*)(Wk + o.Hpp);
-        pr.bp = (double*)(Wk + o.bp); pr.Hs = (double*)(Wk + o.Hs); pr.xp = (double*)(Wk + o.xp);
+        pr.Xa = (double*)(Wk + o.Xa); pr.Xb = (double*)(Wk + o.Xb); pr.chi2 = (double*)(Wk + o.chi2); pr.level = Wk + o.level;
+        pr.Hll = (double*)(Wk + o.Hll); pr.bl = (double*)(Wk + o.bl);
+        if (q.layout == 0) {
+            pr.Hpl = (double*)(Wk + o.Hpl);
+            pr.Dinv = (double*)(Wk + o.Dinv); pr.xl = (double*)(Wk + o.xl); pr.Hpp = (double*)(Wk + o.Hpp); pr.bp = (double*)(Wk + o.bp); pr.Hs = (double*)(Wk + o.Hs);
+            pr.xp = (double*)(Wk + o.xp);
+        }
         pr.poses_out = (float*)(O + q.o_out_poses); pr.points_out = (float*)(O + q.o_out_points); pr.erase = O + q.o_out_erase; pr.stats = (int*)(O + q.o_out_stats);
-        hp[i] = pr;
+        return pr;
+    };
+    for (int j = 0; j < n0; j++) {
+        const int i = idx0[j];
+        const oslam_lba::Prep& q = h->prep[i];
+        const WOff& o = wo[i];
+        hp[j] = fill_problem(i);
         LbaWide w;
         memset(&w, 0, sizeof(w));
-        if (h->wide) {
+        if (wide) {
             w.ct = (LbaCtrl*)(Wk + o.ctrl); w.T = (SE3*)(Wk + o.T); w.R = (double*)(Wk + o.R); w.blk = (int*)(Wk + o.blk); w.free_pose = (int*)(Wk + o.free_pose);
             w.partF = (double*)(Wk + o.partF); w.partS = (double*)(Wk + o.partS); w.partM = (double*)(Wk + o.partM); w.W = (double*)(Wk + o.W);
-            w.nblk_pt = div_up(std::max(pr.P, 1), kWPt);
+            w.nblk_pt = div_up(std::max(q.pr.P, 1), kWPt);
             w.pairs = (const int2*)(I + q.o_pairs); w.pair_start = (const int*)(I + q.o_pstart);
+            if (tiles) {
+                w.W = nullptr;
+                w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
+                w.tb_start = (const int*)(I + q.o_tb_start); w.tpairs = (const uint32_t*)(I + q.o_tpairs); w.thr_own = (const int*)(I + q.o_thr_own);
+                w.blk_thr = (const int*)(I + q.o_blk_thr); w.parts = (double*)(Wk + o.parts);
+                w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, w.ntile)); w.TE = q.TE; w.TP = q.TP; w.TQ = q.TQ; w.nblk = q.nblk;
+            }
         }
-        hw[i] = w;
+        hw[j] = w;
     }
+    std::vector<std::pair<long long, int>> cost(n1);
+    for (int j = 0; j < n1; j++) {
+        const int i = idx1[j];
+        const oslam_lba::Prep& q = h->prep[i];
+        const WOff& o = wo[i];
+        hp[n0 + j] = fill_problem(i);
+        LbaWin w;
+        memset(&w, 0, sizeof(w));
+        w.chunk_kf = (const int*)(I + q.o_chunk_kf); w.chunk_e0 = (const int*)(I + q.o_chunk_e0); w.chunk_n = (const int*)(I + q.o_chunk_n); w.kf_chunk0 = (const int*)(I + q.o_kf_chunk0);
+        w.pt_edge = (const int*)(I + q.o_pt_edge); w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
+        w.tb_start = (const int*)(I + q.o_tb_start); w.tpairs = (const uint32_t*)(I + q.o_tpairs); w.thr_own = (const int*)(I + q.o_thr_own); w.blk_thr = (const int*)(I + q.o_blk_thr);
+        w.chunkC = (double*)(Wk + o.chunkC); w.pairPart = (double*)(Wk + o.pairPart); w.HsG = q.hs_global ? (double*)(Wk + o.Hs) : nullptr;
+        w.ngroup = q.ngroup; w.hs_global = q.hs_global;
+        w.nchunk = (int)q.chunk_kf.size(); w.npairs = (int)q.npairs; w.nfree = q.nfree; w.nblk = q.nblk; w.ntile = (int)q.tile_p0.size() - 1;
+        w.TE = q.TE; w.TP = q.TP; w.TQ = q.TQ; w.hs_doubles = win_hs_doubles(q.nfree); w.region_doubles = q.region_doubles;
+        hwin[j] = w;
+        const long long n6 = 6LL * q.nfree;
+        cost[j] = std::make_pair(-(700LL * q.pr.E + 216LL * (long long)q.npairs + n6 * n6 * n6 / 3), j);
+    }
+    std::sort(cost.begin(), cost.end());   // the most expensive windows are dispatched first
+    for (int j = 0; j < n1; j++) horder[j] = cost[j].second;
     OSLAM_HIP_CHECK(hipMemcpyAsync(I, h->in_h, h->in_off, hipMemcpyHostToDevice, st));   // the ONE upload
     const LbaProblem* d_probs = (const LbaProblem*)(I + o_probs);
     const LbaWide* d_ws = (const LbaWide*)(I + o_ws);
-    long long launches = 1;
+    long long launches = 0;
     lba_time_begin(h);
-    if (!h->wide) {
-        hipLaunchKernelGGL(k_lba, dim3(n), dim3(kLbaThreads), h->lds, st, d_probs);
-    } else {
+    if (n1 > 0) {
+        hipLaunchKernelGGL(k_lba_win, dim3(n1), dim3(kWinThreads), win_lds, st, d_probs + n0, (const LbaWin*)(I + o_wins), (const int*)(I + o_order));
+        launches += 1;
+    }
+    if (n0 > 0 && !wide) {
+        hipLaunchKernelGGL(k_lba, dim3(n0), dim3(kLbaThreads), h->lds, st, d_probs);
+        launches += 1;
+    } else if (n0 > 0) {
         const size_t chol_lds = all_lds ? (size_t)max_n6 * (max_n6 + 1) * sizeof(double) : 0;
-        // systems beyond the LDS-resident kernel are factored by the matrix cores (k_w_chol_mfma); h->chol_mode 1 forces it, 2 forbids it
-        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds);
+        // systems beyond the LDS-resident kernels (full square up to 132 unknowns, packed upper triangle up to kCholPackedN) are factored by the matrix cores
+        // (k_w_chol_mfma); h->chol_mode 1 forces them, 2 forbids them
+        const bool chol_packed = h->chol_mode != 1 && !all_lds && max_n6 <= kCholPackedN;
+        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds && !chol_packed);
         const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
-        hipLaunchKernelGGL(k_w_init, dim3(1, n), dim3(256), 0, st, d_probs, d_ws);
-        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n), dim3(256), 0, st, d_probs);
+        hipLaunchKernelGGL(k_w_init, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
+        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
         // iteration), so the common case needs a single host round trip; rejected steps add groups of 4.
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
-                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, n), dim3(kLinThreads), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n), dim3(64), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n), dim3(256), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n), dim3(64), 0, st, d_probs, d_ws);
-                if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws);
-                else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n), dim3(1024), chol_lds, st, d_probs, d_ws);
-                else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n), dim3(1024), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n), dim3(kWPt), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n), dim3(kWPt), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n), dim3(256), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, n0), dim3(kLinThreads), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n0), dim3(64), 0, st, d_probs, d_ws);
+                if (tiles) {
+                    hipLaunchKernelGGL(k_w_schur_tiles, dim3(maxWg, n0), dim3(kWinThreads), tiles_lds, st, d_probs, d_ws);
+                    hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
+                } else {
+                    hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n0), dim3(256), 0, st, d_probs, d_ws);
+                    hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n0), dim3(64), 0, st, d_probs, d_ws);
+                }
+                if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);
+                else if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n0), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws);
+                else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
+                else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n0), dim3(kWPt), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n0), dim3(kWPt), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
-            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n, hipMemcpyDeviceToHost, st));
+            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, hipMemcpyDeviceToHost, st));
             OSLAM_HIP_CHECK(hipStreamSynchronize(st));
             bool all_done = true;
-            for (int i = 0; i < n; i++) all_done = all_done && h->h_ctrl[i].done != 0;
+            for (int i = 0; i < n0; i++) all_done = all_done && h->h_ctrl[i].done != 0;
             if (all_done) break;
             group = 4;
         }
-        hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n), dim3(256), 0, st, d_probs, d_ws);
-        launches = 3 + 8 * (long long)slots_done;
+        hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n0), dim3(256), 0, st, d_probs, d_ws);
+        launches += 3 + 8 * (long long)slots_done;
     }
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());
@@ -1941,8 +2278,9 @@ extern "C" {
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                        const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                        const float K5[5], int use_stop_flag, float* poses_out, float* points_out, uint8_t* erase, int32_t stats[4]) {
-    int rc = lba_prepare(h, 0, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out, erase,
-                         5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    const LbaArgs a = {nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, poses_out, points_out, erase};
+    int rc = lba_prepare_all(h, 1, &a, K5, use_stop_flag, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
     if (!rc) rc = lba_launch(h);
     if (!rc) lba_fetch(h, 0, poses_out, points_out, erase, stats);
     return rc;
@@ -1951,10 +2289,11 @@ int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_
 int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP, const float* points, int nE,
                       const int32_t* edge_kf, const int32_t* edge_pt, const float* edge_obs, const float* edge_invSigma2,
                       const float K5[5], int nIterations, int bRobust, int use_stop_flag, float* poses_out, float* points_out) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
     if (nIterations < 0) { set_error("nIterations < 0"); return OSLAM_E_INVALID; }
     std::vector<uint8_t> erase(nE > 0 ? nE : 1);
-    int rc = lba_prepare(h, 0, nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, K5, use_stop_flag, poses_out, points_out, erase.data(),
-                         nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
+    const LbaArgs a = {nKF, poses, fixed, nP, points, nE, edge_kf, edge_pt, edge_obs, edge_invSigma2, poses_out, points_out, erase.data()};
+    int rc = lba_prepare_all(h, 1, &a, K5, use_stop_flag, nIterations, 0, 1, bRobust ? 1 : 0, (float)sqrt(5.99), (float)sqrt(7.815));
     if (!rc) rc = lba_launch(h);
     if (!rc) lba_fetch(h, 0, poses_out, points_out, erase.data(), nullptr);
     return rc;
@@ -1964,13 +2303,14 @@ int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t
 int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* probs, const float K5[5]) {
     if (!h || !probs || !K5) { set_error("NULL argument"); return OSLAM_E_INVALID; }
     if (n < 1 || n > h->max_batch) { set_error("batch %d outside [1,%d]", n, h->max_batch); return OSLAM_E_INVALID; }
+    std::vector<LbaArgs> a(n);
     for (int i = 0; i < n; i++) {
         const oslam_lba_problem_t& q = probs[i];
-        const int rc = lba_prepare(h, i, q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, K5, 0, q.poses_out, q.points_out,
-                                   q.erase, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
-        if (rc) return rc;
+        a[i] = {q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, q.poses_out, q.points_out, q.erase};
     }
-    const int rc = lba_launch(h);
+    int rc = lba_prepare_all(h, n, a.data(), K5, 0, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
+    if (rc) return rc;
+    rc = lba_launch(h);
     if (rc) return rc;
     for (int i = 0; i < n; i++) lba_fetch(h, i, probs[i].poses_out, probs[i].points_out, probs[i].erase, probs[i].stats);
     return OSLAM_OK;

@@ -1252,7 +1252,11 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (!rc) rc = oslam_poseopt_create(&o->po, o->S, o->cap, dev);
     if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 4096, 32768, dev);    // points / edges per window grow on demand (include/oslam_hip.h); <= 128 keyframes per window
     if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 4096, 32768, dev);
-    if (!rc) rc = oslam_lba_set_mode(o->ba, getenv("OSLAM_LBA_BATCH_COMPACT") ? 0 : 1);   // default: every LM trial of ALL windows as six whole-GPU launches; compact = one workgroup per window (A/B knob)
+    // batches of windows: every LM trial of ALL windows as short whole-GPU launches (mode 1: the windows of a call spread over all CUs and the kernels of the other
+    // handles interleave; the Schur complement is formed on chip by tiles).  OSLAM_LBA_BATCH_MODE = 2 (one workgroup per window, the whole schedule in one launch:
+    // the most work per CU-second, but a call of ~40 windows then holds 40 CUs for tens of milliseconds and the other handles' short kernels queue behind the
+    // windows of all handles: measured 7.6 k against 16.8 k frames/s in bench.py's steady state) or 0 (the round-1 compact kernel) are A/B knobs
+    if (!rc) rc = oslam_lba_set_mode(o->ba, getenv("OSLAM_LBA_BATCH_MODE") ? atoi(getenv("OSLAM_LBA_BATCH_MODE")) : (getenv("OSLAM_LBA_BATCH_COMPACT") ? 0 : 1));
     if (!rc) rc = oslam_mappoint_create(&o->mp, dev);
     if (!rc) rc = oslam_frame_create(&o->fr, dev);
     if (!rc) rc = oslam_bow_create(&o->bow, o->cap, dev);
