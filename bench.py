@@ -528,6 +528,9 @@ def roofline_of(k, summ, stereo):
             e["flop"] = int(v["work"])
         group_tab[g] = e
     busy = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
+    total_ms = sum(v["ms"] for v in k.values())
+    for g in group_tab:
+        group_tab[g]["share"] = round(k[g]["ms"] / max(total_ms, 1e-9), 4)
     return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4; the kernels of this group issue "
             "v_fma_f64 / v_mul_f64 / v_add_f64 — no MFMA instruction at these system sizes (the matrix-core Cholesky serves reduced systems beyond the LDS-resident size)",
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),

@@ -388,7 +388,7 @@ int oslam_frame_object_kp_test_batch_device(const oslam_keypoint_t* d_keysUn, in
  * it is polled at the points g2o polls its force-stop flag when use_stop_flag != 0.
  * ---------------------------------------------------------------------------------------- */
 typedef struct oslam_lba oslam_lba_t;
-int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes /* <= 128 */, int max_points,
+int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes /* per window, fixed cameras included; at most 128 of them free */, int max_points,
                      int max_edges, int device);
 void oslam_lba_destroy(oslam_lba_t* h);
 volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
@@ -436,6 +436,10 @@ int oslam_ba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t
 typedef struct oslam_mappoint oslam_mappoint_t;
 int oslam_mappoint_create(oslam_mappoint_t** out, int device);
 void oslam_mappoint_destroy(oslam_mappoint_t* h);
+/* Device time of the batched SearchByBoW / SearchForTriangulation kernel (oslam_match_bow_batch) and of the batched triangulation kernel
+ * (oslam_mp_triangulate_pairs), HIP events on the handles' own streams: what accumulated since the last call, then the switch is set to `enable`. */
+int oslam_bow_kernel_time(oslam_bow_t* h, int enable, double* ms_out, long long* launches_out);
+int oslam_mappoint_kernel_time(oslam_mappoint_t* h, int enable, double* ms_out, long long* launches_out);
 
 /* MapPoint::ComputeDistinctiveDescriptors (reference src/MapPoint.cc:345-410): for each point the observation whose
  * median Hamming distance to the others (sorted row, element int(0.5*(N-1))) is the first strict minimum.

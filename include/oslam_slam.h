@@ -35,8 +35,8 @@
 /* Limits of the HIP operator table (the reference's containers are unbounded):
  *   - keypoints per frame: the extractor's capacity (sum of the level quotas + slack, oslam_orb_max_keypoints) — never exceeded by construction;
  *   - local map points searched per frame (Tracking::SearchLocalPoints): no fixed bound, the matcher's query buffers grow on demand;
- *   - local BA: points and edges per window grow on demand; at most 128 keyframes (local + fixed) per window: fixed cameras beyond that are left
- *     out of the window together with their observations (oslam_slam_object_stats [6] counts them) instead of failing the step;
+ *   - local BA: keyframes, points and edges per window grow on demand (every fixed keyframe enters the window, src/Optimizer.cc:489-504); at most 128 LOCAL
+ *     (free) keyframes per window, i.e. 768 unknowns of the reduced camera system — a window beyond that fails the step with OSLAM_E_CAPACITY;
  *   - detections per frame: OSLAM_SLAM_MAX_OBJECTS;
  *   - resident keyframe records (keypoints, descriptors, stereo coordinates: ~64 B x capacity each): one per keyframe ever created in the current map of a
  *     sequence (a culled keyframe keeps its record: map points may keep observations in it, src/KeyFrame.cc:382-462 erases only those of its own
@@ -190,7 +190,10 @@ typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (curr
     uint8_t* ok; float* x3D;
 } oslam_job_triangulate_t;
 
-#define OSLAM_SLAM_KT_GROUPS 4   /* kernel-time groups: 0 Frame::Frame (extraction .. stereo), 1 pose optimisation, 2 local BA, 3 window searches */
+#define OSLAM_SLAM_KT_GROUPS 8   /* kernel-time groups: 0 Frame::Frame (extraction .. stereo), 1 pose optimisation, 2 local BA, 3 window searches (SearchByProjection /
+                                  * SearchLocalPoints), 4 ORBmatcher::Fuse (projection gates + window search), 5 SearchByBoW / SearchForTriangulation + triangulation,
+                                  * 6 MapPoint updates (descriptor gather, ComputeDistinctiveDescriptors, UpdateNormalAndDepth, record writes), 7 other (keyframe
+                                  * registration copies, vocabulary nodes, object keypoint tests / mask bitmaps, local-map gathers) */
 
 typedef struct oslam_slam_ops {
     void* ctx;
@@ -280,12 +283,12 @@ int oslam_slam_track_rgbd_raw16(oslam_slam_t* h, const uint8_t* const* gray, int
                                 int on_device, const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
 
 /* Object layer counters of one sequence: [0] N_AllSemanticConstraintNum (src/ObjectOptimizer.cc:1233), [1] frames optimised with matched objects,
- * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] fixed keyframes left out of
- * local-BA windows (see "Limits" below). */
+ * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] 0 (was: fixed keyframes left out of
+ * local-BA windows; the windows are no longer capped). */
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* Sizes of the local-BA windows of one sequence since creation (Optimizer::LocalBundleAdjustment's graph gather, src/Optimizer.cc:456-504):
- * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] fixed keyframes left out (see "Limits"). */
+ * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] 0 (fixed keyframes are no longer left out). */
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
@@ -321,7 +324,7 @@ int oslam_slam_debug_point(oslam_slam_t* h, int seq, int id, uint8_t host[64], u
  * (bench.py's roofline).  Returns what accumulated since the last call, then sets the switch to `enable`.  Per group g:
  * out[3g] = milliseconds, out[3g+1] = kernel launches, out[3g+2] = algorithmic work of those launches — bytes for group 0 (SURVEY.md
  * §8(d) extraction model), fp64 flop for groups 1 and 2 (§8(d): 700 flop per edge and linearisation, 90 per edge and trial evaluation,
- * Schur 324 k_p^2 per point, Cholesky (6K)^3/3, back-substitution 2(6K)^2 + 45P per trial), descriptor pairs for group 3.
+ * Schur 324 k_p^2 per point, Cholesky (6K)^3/3, back-substitution 2(6K)^2 + 45P per trial), observations for group 6, 0 elsewhere.
  * OSLAM_E_INVALID on a table without device timing (the test seam). */
 int oslam_slam_kernel_times(oslam_slam_t* h, int enable, double out[OSLAM_SLAM_KT_GROUPS * 3]);
 

@@ -202,6 +202,8 @@ struct oslam_bow {
     Buf q_idx1, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm;
     uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;   // batch staging: pinned block mirrored on the device
     hipStream_t strm = nullptr;   // the batch form runs on the handle's own non-blocking stream (created on first use)
+    // device time of the batch kernel (bench.py's kernel-time groups): HIP events on `strm`
+    int timing = 0; hipEvent_t ev0 = nullptr, ev1 = nullptr; double kern_ms = 0; long long kern_n = 0;
 };
 
 static int bow_ensure(oslam_bow::Buf& b, size_t bytes) {
@@ -221,8 +223,20 @@ static int bow_up(oslam_bow::Buf& b, const void* src, size_t bytes) {
 
 extern "C" {
 
+int oslam_bow_kernel_time(oslam_bow_t* h, int enable, double* ms_out, long long* launches_out) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (enable && !h->ev0) { OSLAM_HIP_CHECK(hipEventCreate(&h->ev0)); OSLAM_HIP_CHECK(hipEventCreate(&h->ev1)); }
+    if (ms_out) *ms_out = h->kern_ms;
+    if (launches_out) *launches_out = h->kern_n;
+    h->kern_ms = 0; h->kern_n = 0; h->timing = enable;
+    return OSLAM_OK;
+}
+
 void oslam_bow_destroy(oslam_bow_t* h) {
     if (!h) return;
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     oslam_bow::Buf* bs[] = {&h->q_idx1, &h->q_node, &h->keys1, &h->desc1, &h->ur1, &h->flag1, &h->keys2, &h->desc2, &h->ur2, &h->mp2,
                             &h->nodes, &h->start, &h->items, &h->out, &h->qbest, &h->nm};
     for (auto* b : bs)
@@ -413,10 +427,13 @@ static int bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_b
     });
     if (!h->strm) OSLAM_HIP_CHECK(hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D, H, in_bytes, hipMemcpyHostToDevice, h->strm));
+    if (h->timing) (void)hipEventRecord(h->ev0, h->strm);
     hipLaunchKernelGGL(k_search_bow_batch, dim3(n), dim3(kBowThreads), h->lds, h->strm, (const BowCtx*)D, h->max_kps);
+    if (h->timing) (void)hipEventRecord(h->ev1, h->strm);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipMemcpyAsync(H + in_bytes, D + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, h->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    if (h->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_n += 1; } }
     for (int i = 0; i < n; i++) {
         jobs[i].nmatches = *(const int*)(H + off[i].nm);
         if (jobs[i].nmatches < 0) { set_error("BoW matcher kernel rejected pair %d (capacity)", i); return OSLAM_E_CAPACITY; }

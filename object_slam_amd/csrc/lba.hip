@@ -35,7 +35,8 @@ namespace oslam {
 
 constexpr int kLbaThreads = 512;
 constexpr int kLbaWaves = kLbaThreads / 64;
-constexpr int kLbaMaxKF = 128;
+constexpr int kLbaMaxKF = 128;           // FREE keyframes of a window (the reduced system's order is 6 x that); also every keyframe of the round-1 compact kernel
+constexpr int kLbaMaxWindowKF = 1 << 16; // keyframes of a window, fixed cameras included (wide / window layouts keep the poses in memory sized by the window)
 constexpr int kRowBufBytes = 8 * 1024;   // LDS scratch: back-substitution vector (n <= 768 doubles)
 
 struct LbaProblem {
@@ -591,9 +592,9 @@ struct LbaWide {
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
     // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
-    const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* tb_start; const uint32_t* tpairs; const int* thr_own; const int* blk_thr;
+    const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* thr_own; const int* blk_thr;
     double* parts;            // [nwg][ngroup * kWinThreads][42] per-workgroup, per-slot block sums
-    int ntile, ngroup, nwg, TE, TP, TQ, nblk;
+    int ntile, ngroup, nwg, TE, TP, nblk;
 };
 
 constexpr int kWPt = 128;   // threads per block of the per-point kernels
@@ -1549,14 +1550,13 @@ struct oslam_lba {
     struct Prep {                 // one prepared window: host-built arrays, then offsets into the `in` arena
         LbaProblem pr;            // scalar fields valid; pointers filled at launch
         const float* p_poses = nullptr; const uint8_t* p_fixed = nullptr; const float* p_points = nullptr;   // the caller's arrays (copied into the arena by lba_place)
-        std::vector<int> ekf, ept, pt_start, pose_start, pose_edges, pstart, chunk_kf, chunk_e0, chunk_n, kf_chunk0, pt_edge, tile_p0, tile_s0, stg_edge, tb_start;
-        std::vector<uint32_t> tpairs;
+        std::vector<int> ekf, ept, pt_start, pose_start, pose_edges, pstart, chunk_kf, chunk_e0, chunk_n, kf_chunk0, pt_edge, tile_p0, tile_s0, stg_edge;
         std::vector<int> thr_own, blk_thr;
-        int TE = 0, TP = 0, TQ = 0, region_doubles = 0, ngroup = 1, hs_global = 0;
+        int TE = 0, TP = 0, region_doubles = 0, ngroup = 1, hs_global = 0;
         std::vector<float> eobs, einfo;
         std::vector<int2> pairs;
         size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
-        size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_tb_start, o_tpairs, o_thr_own, o_blk_thr;
+        size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_thr_own, o_blk_thr;
         size_t o_out_poses, o_out_points, o_out_erase, o_out_stats;   // offsets into the `out` arena
         int nfree = 0, nblk = 1; size_t npairs = 0;
         int layout = 0;           // 0 point-major edge numbering (compact / wide kernels), 1 keyframe-major (one workgroup per window, lba_win.inc)
@@ -1683,8 +1683,8 @@ void oslam_lba_destroy(oslam_lba_t* h) {
 int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int max_points, int max_edges, int device) {
     if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }
     *out = nullptr;
-    if (max_batch < 1 || max_keyframes < 1 || max_keyframes > kLbaMaxKF || max_points < 1 || max_edges < 1) {
-        set_error("oslam_lba_create: invalid argument (max_keyframes <= %d)", kLbaMaxKF);
+    if (max_batch < 1 || max_keyframes < 1 || max_keyframes > kLbaMaxWindowKF || max_points < 1 || max_edges < 1) {
+        set_error("oslam_lba_create: invalid argument (max_keyframes <= %d)", kLbaMaxWindowKF);
         return OSLAM_E_INVALID;
     }
     int ndev = oslam_device_count();
@@ -1746,65 +1746,33 @@ static int lba_build_tiles(oslam_lba::Prep& q, const std::vector<int>& blk, int 
     const std::vector<int>& ekf = q.ekf;
     const int nblk = q.nblk;
     auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
-    int TP = kWinTilePointsMax, TE = kWinTileEdgesMax, TQ = 0;
-    std::vector<int> stg_local(nE, -1), tile_of_pt(nP, 0);
-    for (;;) {   // the largest tile capacity whose buffers (incl. the largest tile's pair list) fit the region
-        q.tile_p0.clear(); q.tile_s0.clear(); q.stg_edge.clear();
-        int np = 0, ns = 0, nq = 0;
-        TQ = 0;
+    int TP = kWinTilePointsMax, TE = kWinTileEdgesMax;
+    while (TE > 128 && win_tile_doubles(TE, TP) * 8 > region_bytes) TE -= 32;
+    q.TE = TE; q.TP = TP;
+    q.tile_p0.clear(); q.tile_s0.clear(); q.stg_edge.clear();
+    std::vector<long long> load(nblk, 0);   // pairs of every block (for the thread slots below)
+    {
+        int np = 0, ns = 0;
         q.tile_p0.push_back(0); q.tile_s0.push_back(0);
+        std::vector<int> fb;
         for (int p = 0; p < nP; p++) {
-            int fe = 0;
-            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) fe += blk[ekf[q.pt_edge[i]]] >= 0 ? 1 : 0;
-            if (np > 0 && (np + 1 > TP || ns + fe > TE)) { q.tile_p0.push_back(p); q.tile_s0.push_back((int)q.stg_edge.size()); TQ = std::max(TQ, nq); np = 0; ns = 0; nq = 0; }
-            tile_of_pt[p] = (int)q.tile_p0.size() - 1;
+            fb.clear();
+            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) { const int b2 = blk[ekf[q.pt_edge[i]]]; if (b2 >= 0) fb.push_back(b2); }
+            const int fe = (int)fb.size();
+            if (np > 0 && (np + 1 > TP || ns + fe > TE)) { q.tile_p0.push_back(p); q.tile_s0.push_back((int)q.stg_edge.size()); np = 0; ns = 0; }
             for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
                 const int e = q.pt_edge[i];
-                if (blk[ekf[e]] >= 0) { stg_local[e] = ns++; q.stg_edge.push_back(e); }
+                if (blk[ekf[e]] >= 0) { q.stg_edge.push_back(e); ns++; }
             }
-            np++; nq += fe * (fe + 1) / 2;
+            for (int i = 0; i < fe; i++)   // ascending keyframe index inside a point: fb is ascending
+                for (int j = i; j < fe; j++) load[tof(fb[i], fb[j])]++;
+            np++;
         }
-        TQ = std::max(TQ, nq);
         q.tile_p0.push_back(nP); q.tile_s0.push_back((int)q.stg_edge.size());
-        if (win_tile_doubles(TE, TP, TQ, nblk) * 8 <= region_bytes || TE <= 128) break;
-        TE -= 32;
     }
-    q.TE = TE; q.TP = TP; q.TQ = TQ;
-    const int ntile = (int)q.tile_p0.size() - 1;
-    std::vector<int>& tb = q.tb_start;
-    tb.assign((size_t)ntile * nblk + 1, 0);
-    for (int p = 0; p < nP; p++) {
-        const size_t base = (size_t)tile_of_pt[p] * nblk;
-        for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-            const int bi = blk[ekf[q.pt_edge[i]]];
-            if (bi < 0) continue;
-            for (int j = i; j < pt_start[p + 1]; j++) {   // ascending keyframe index inside a point: bj >= bi for every free partner at or after i
-                const int bj = blk[ekf[q.pt_edge[j]]];
-                if (bj >= 0) tb[base + tof(bi, bj) + 1]++;
-            }
-        }
-    }
-    for (size_t t2 = 0; t2 < (size_t)ntile * nblk; t2++) tb[t2 + 1] += tb[t2];
-    q.npairs = (size_t)tb[(size_t)ntile * nblk];
-    q.tpairs.resize(q.npairs);
-    {
-        std::vector<int> cur2(tb.begin(), tb.end() - 1);
-        for (int p = 0; p < nP; p++) {
-            const size_t base = (size_t)tile_of_pt[p] * nblk;
-            for (int i = pt_start[p]; i < pt_start[p + 1]; i++) {
-                const int ei = q.pt_edge[i], bi = blk[ekf[ei]];
-                if (bi < 0) continue;
-                for (int j = i; j < pt_start[p + 1]; j++) {
-                    const int ej = q.pt_edge[j], bj = blk[ekf[ej]];
-                    if (bj >= 0) q.tpairs[cur2[base + tof(bi, bj)]++] = (uint32_t)stg_local[ei] | ((uint32_t)stg_local[ej] << 16);
-                }
-            }
-        }
-    }
+    q.npairs = 0;
+    for (int b2 = 0; b2 < nblk; b2++) q.npairs += (size_t)load[b2];
     {   // slots of the Schur phase: every block with pairs gets one thread of one pass; spare threads go where the pairs per thread are highest; ordered by load
-        std::vector<long long> load(nblk, 0);
-        for (int t2 = 0; t2 < ntile; t2++)
-            for (int b2 = 0; b2 < nblk; b2++) load[b2] += tb[(size_t)t2 * nblk + b2 + 1] - tb[(size_t)t2 * nblk + b2];
         std::vector<int> cnt(nblk, 0);
         int used = 0;
         for (int b2 = 0; b2 < nblk; b2++) if (load[b2] > 0) { cnt[b2] = 1; used++; }
@@ -1894,6 +1862,7 @@ static int lba_build(const oslam_lba_t* h, oslam_lba::Prep& q, int layout, bool 
     int nfree = 0;
     for (int k = 0; k < nKF; k++) nfree += fixed[k] ? 0 : 1;
     if (nfree > kLbaMaxKF) return fail(OSLAM_E_CAPACITY, "%d free keyframes > %d", nfree, kLbaMaxKF);
+    if (h->wide == 0 && nKF > kLbaMaxKF) return fail(OSLAM_E_CAPACITY, "%d keyframes > %d (compact layout; use mode 1 or 2)", nKF, kLbaMaxKF);
     q.nfree = nfree; q.nblk = std::max(1, nfree * (nfree + 1) / 2);
     std::vector<int> blk(nKF);
     for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
@@ -1961,13 +1930,12 @@ static int lba_build(const oslam_lba_t* h, oslam_lba::Prep& q, int layout, bool 
         }
         q.kf_chunk0[nKF] = (int)q.chunk_kf.size();
         // Schur tiles (lba_win.inc): the reduced system and the tile buffers share one LDS region
-        const int nblk = q.nblk;
         const size_t region_bytes = h->win_lds_max - win_persist_bytes(nKF, nfree);
         size_t hs_d = (size_t)win_hs_doubles(nfree);
         q.hs_global = hs_d * 8 > region_bytes ? 1 : 0;
         if (q.hs_global) { const size_t n6 = 6 * (size_t)nfree, pw = ((n6 + 1 + kMB - 1) / kMB + 1) * kMB; hs_d = (size_t)kMB * pw + n6 + 2 * kMB; }   // the matrix-core solver's row panel + vector
         { const int rc = lba_build_tiles(q, blk, nfree, nP, nE, region_bytes, err, errn); if (rc) return rc; }
-        q.region_doubles = (int)std::max(hs_d, win_tile_doubles(q.TE, q.TP, q.TQ, nblk));
+        q.region_doubles = (int)std::max(hs_d, win_tile_doubles(q.TE, q.TP));
     }
     LbaProblem& pr = q.pr;
     memset(&pr, 0, sizeof(pr));
@@ -1987,13 +1955,12 @@ static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
         (rc = in_put(h, q.einfo.data(), nE * 4, &q.o_einfo)) || (rc = in_put(h, q.pt_start.data(), (nP + 1) * 4, &q.o_ptstart)))
         return rc;
     q.o_posestart = q.o_poseedges = q.o_pairs = q.o_pstart = q.o_chunk_kf = q.o_chunk_e0 = q.o_chunk_n = q.o_kf_chunk0 = q.o_pt_edge = 0;
-    q.o_tile_p0 = q.o_tile_s0 = q.o_stg_edge = q.o_tb_start = q.o_tpairs = q.o_thr_own = q.o_blk_thr = 0;
+    q.o_tile_p0 = q.o_tile_s0 = q.o_stg_edge = q.o_thr_own = q.o_blk_thr = 0;
     if (q.layout == 0) {
         if ((rc = in_put(h, q.pose_start.data(), (nKF + 1) * 4, &q.o_posestart)) || (rc = in_put(h, q.pose_edges.data(), nE * 4, &q.o_poseedges))) return rc;
         if (!q.tile_p0.empty() &&
             ((rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
-             (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.tb_start.data(), q.tb_start.size() * 4, &q.o_tb_start)) ||
-             (rc = in_put(h, q.tpairs.data(), q.tpairs.size() * 4, &q.o_tpairs)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
+             (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
              (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr))))
             return rc;
     } else {
@@ -2001,8 +1968,7 @@ static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
         if ((rc = in_put(h, q.chunk_kf.data(), nc * 4, &q.o_chunk_kf)) || (rc = in_put(h, q.chunk_e0.data(), nc * 4, &q.o_chunk_e0)) || (rc = in_put(h, q.chunk_n.data(), nc * 4, &q.o_chunk_n)) ||
             (rc = in_put(h, q.kf_chunk0.data(), (nKF + 1) * 4, &q.o_kf_chunk0)) || (rc = in_put(h, q.pt_edge.data(), nE * 4, &q.o_pt_edge)) ||
             (rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
-            (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.tb_start.data(), q.tb_start.size() * 4, &q.o_tb_start)) ||
-            (rc = in_put(h, q.tpairs.data(), q.tpairs.size() * 4, &q.o_tpairs)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
+            (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
             (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr)))
             return rc;
     }
@@ -2024,7 +1990,7 @@ static bool win_fits(const oslam_lba_t* h, int K, int nfree) {
     if (persist >= h->win_lds_max) return false;
     const size_t n6 = 6 * (size_t)nfree, pw = ((n6 + 1 + kMB - 1) / kMB + 1) * kMB;
     // a tile must hold every point's edges (<= nfree <= 128 <= TE) and, in the worst case, their pairs; a system that does not fit LDS needs the solver's panel
-    return persist + 8 * win_tile_doubles(128, kWinTilePointsMax, 128 * (nfree + 1) / 2, nfree * (nfree + 1) / 2) <= h->win_lds_max &&
+    return persist + 8 * win_tile_doubles(128, kWinTilePointsMax) <= h->win_lds_max &&
            persist + 8 * std::min((size_t)win_hs_doubles(nfree), (size_t)kMB * pw + n6 + 2 * kMB) <= h->win_lds_max;
 }
 
@@ -2109,7 +2075,7 @@ static int lba_launch(oslam_lba_t* h) {
                 if (tiles) {
                     const int ntile = (int)q.tile_p0.size() - 1, nwg = std::max(1, std::min(nwg_call, ntile));
                     o.parts = takeW((size_t)nwg * q.ngroup * kWinThreads * 42 * 8);
-                    tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP, q.TQ, q.nblk));
+                    tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP));
                     maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
                 } else o.W = takeW(E * 144);
                 packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
@@ -2173,9 +2139,9 @@ static int lba_launch(oslam_lba_t* h) {
             if (tiles) {
                 w.W = nullptr;
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
-                w.tb_start = (const int*)(I + q.o_tb_start); w.tpairs = (const uint32_t*)(I + q.o_tpairs); w.thr_own = (const int*)(I + q.o_thr_own);
+                w.thr_own = (const int*)(I + q.o_thr_own);
                 w.blk_thr = (const int*)(I + q.o_blk_thr); w.parts = (double*)(Wk + o.parts);
-                w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, w.ntile)); w.TE = q.TE; w.TP = q.TP; w.TQ = q.TQ; w.nblk = q.nblk;
+                w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, w.ntile)); w.TE = q.TE; w.TP = q.TP; w.nblk = q.nblk;
             }
         }
         hw[j] = w;
@@ -2190,11 +2156,11 @@ static int lba_launch(oslam_lba_t* h) {
         memset(&w, 0, sizeof(w));
         w.chunk_kf = (const int*)(I + q.o_chunk_kf); w.chunk_e0 = (const int*)(I + q.o_chunk_e0); w.chunk_n = (const int*)(I + q.o_chunk_n); w.kf_chunk0 = (const int*)(I + q.o_kf_chunk0);
         w.pt_edge = (const int*)(I + q.o_pt_edge); w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
-        w.tb_start = (const int*)(I + q.o_tb_start); w.tpairs = (const uint32_t*)(I + q.o_tpairs); w.thr_own = (const int*)(I + q.o_thr_own); w.blk_thr = (const int*)(I + q.o_blk_thr);
+        w.thr_own = (const int*)(I + q.o_thr_own); w.blk_thr = (const int*)(I + q.o_blk_thr);
         w.chunkC = (double*)(Wk + o.chunkC); w.pairPart = (double*)(Wk + o.pairPart); w.HsG = q.hs_global ? (double*)(Wk + o.Hs) : nullptr;
         w.ngroup = q.ngroup; w.hs_global = q.hs_global;
         w.nchunk = (int)q.chunk_kf.size(); w.npairs = (int)q.npairs; w.nfree = q.nfree; w.nblk = q.nblk; w.ntile = (int)q.tile_p0.size() - 1;
-        w.TE = q.TE; w.TP = q.TP; w.TQ = q.TQ; w.hs_doubles = win_hs_doubles(q.nfree); w.region_doubles = q.region_doubles;
+        w.TE = q.TE; w.TP = q.TP; w.hs_doubles = win_hs_doubles(q.nfree); w.region_doubles = q.region_doubles;
         hwin[j] = w;
         const long long n6 = 6LL * q.nfree;
         cost[j] = std::make_pair(-(700LL * q.pr.E + 216LL * (long long)q.npairs + n6 * n6 * n6 / 3), j);

@@ -201,6 +201,7 @@ struct oslam_mappoint {
     // batch form (oslam_mp_triangulate_pairs): one pinned block mirrored on the device, one stream — ONE upload, one launch, ONE download per call
     uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;
     hipStream_t strm = nullptr;
+    int timing = 0; hipEvent_t ev0 = nullptr, ev1 = nullptr; double kern_ms = 0; long long kern_n = 0;   // device time of the batched triangulation kernel
 };
 
 static int mp_ensure(oslam_mappoint::Buf& b, size_t bytes) {
@@ -220,8 +221,20 @@ static int mp_up(oslam_mappoint::Buf& b, const void* src, size_t bytes) {
 
 extern "C" {
 
+int oslam_mappoint_kernel_time(oslam_mappoint_t* h, int enable, double* ms_out, long long* launches_out) {
+    if (!h) { set_error("NULL handle"); return OSLAM_E_INVALID; }
+    OSLAM_HIP_CHECK(hipSetDevice(h->device));
+    if (enable && !h->ev0) { OSLAM_HIP_CHECK(hipEventCreate(&h->ev0)); OSLAM_HIP_CHECK(hipEventCreate(&h->ev1)); }
+    if (ms_out) *ms_out = h->kern_ms;
+    if (launches_out) *launches_out = h->kern_n;
+    h->kern_ms = 0; h->kern_n = 0; h->timing = enable;
+    return OSLAM_OK;
+}
+
 void oslam_mappoint_destroy(oslam_mappoint_t* h) {
     if (!h) return;
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     oslam_mappoint::Buf* bs[] = {&h->a, &h->b, &h->c, &h->d, &h->e, &h->e2, &h->f, &h->g, &h->g2, &h->o1, &h->o2};
     for (auto* b : bs)
         if (b->p) (void)hipFree(b->p);
@@ -927,10 +940,13 @@ extern "C" int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const
     for (int i = 0; i < OSLAM_MAX_LEVELS; i++) { c.scale[i] = i < nLevels ? scaleFactors[i] : 1.f; c.sigma2[i] = i < nLevels ? levelSigma2[i] : 1.f; }
     c.ratioFactor = ratioFactor;
     c.ok = D + o_ok; c.x3D = (float*)(D + o_x3);
+    if (h->timing) (void)hipEventRecord(h->ev0, h->strm);
     hipLaunchKernelGGL(k_triangulate, dim3(div_up(M, 128)), dim3(128), 0, h->strm, c);
+    if (h->timing) (void)hipEventRecord(h->ev1, h->strm);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipMemcpyAsync(H + o_ok, D + o_ok, at - in_bytes, hipMemcpyDeviceToHost, h->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    if (h->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_n += 1; } }
     memcpy(ok, H + o_ok, (size_t)M);
     memcpy(x3D, H + o_x3, (size_t)M * 12);
     return OSLAM_OK;

@@ -107,7 +107,7 @@ struct BowViews {
     }
 };
 
-constexpr int kMaxWindowKFs = 128;   // keyframes (local + fixed) per local-BA window: the limit of oslam_lba_create
+// (local-BA windows: the solver's reduced system holds 6 x 128 unknowns, i.e. at most 128 LOCAL keyframes; fixed keyframes are not limited)
 
 enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
 
@@ -159,7 +159,7 @@ struct Seq {
     std::vector<Obj3D> obj3ds;
     std::map<int, int> objOfTrack;
     int64_t sem[8] = {0};
-    int64_t lbaFixedDropped = 0;           // fixed keyframes left out of local-BA windows because of the per-window keyframe limit
+    int64_t lbaFixedDropped = 0;           // (always 0: local-BA windows are no longer capped; kept for the statistics layout)
     int64_t lbaWin[4] = {0, 0, 0, 0};      // local-BA window sizes summed over the sequence's windows: local keyframes, fixed keyframes, points, edges
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
@@ -989,13 +989,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     KeyFrm& k = m.kfs[e.first];
                     if (k.baLocalForKF != cur && k.baFixedForKF != cur) {
                         k.baFixedForKF = cur;
-                        // the solver takes at most kMaxWindowKFs keyframes per window (include/oslam_slam.h): fixed cameras beyond that are left
-                        // out together with their observations (they only anchor the gauge; the reference has no bound), counted in stats
-                        if (!k.bad) { if ((int)W.kfs.size() < kMaxWindowKFs) W.kfs.push_back(e.first); else s.lbaFixedDropped++; }
+                        if (!k.bad) W.kfs.push_back(e.first);   // every fixed keyframe enters the window (src/Optimizer.cc:489-504: no bound)
                     }
                 }
             }
-            if (W.nLocal > kMaxWindowKFs) { W.kfs.resize(kMaxWindowKFs); W.nLocal = kMaxWindowKFs; }
+            // (a window with more than 128 covisible LOCAL keyframes is refused by the operator with OSLAM_E_CAPACITY)
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
             W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());

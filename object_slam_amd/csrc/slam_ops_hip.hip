@@ -513,11 +513,11 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         o->loc_id[b] = j.content_id;
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, fresh.empty() ? small_bytes : L.off, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();   // (the gather of repacked local maps counts with the searches it feeds)
     if (!fresh.empty() && by_id)
         OPS_CHECK(oslam_mp_table_local_gather_device((int)fresh.size(), freshMaxM, (const oslam_local_gather_t*)(Dv + oSeg), Dv + oF, o->d_mp_tab, (int)lst, o->loc_Pw(), o->loc_Pn(),
                                                      o->loc_Max(), o->loc_Min(), o->loc_Obs(), o->loc_Desc(), o->strm));
     else if (!fresh.empty()) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 6 * (int)fresh.size(), o->strm));   // (a zero-byte segment's workgroup returns at once)
-    o->t_begin();
     OPS_CHECK(oslam_frame_is_in_frustum_batch_resident_device((int)S, (int)lst, (int)st, (const int32_t*)(Dv + oM), o->loc_Pw(), o->loc_Pn(), o->loc_Max(), o->loc_Min(),
                                                               o->loc_Obs(), o->loc_Desc(), Dv + oSk, (const float*)(Dv + oTc), (const float*)(Dv + oTh), o->K5,
                                                               o->bounds, 0.5f, o->logScale, o->scale, o->cfg.nLevels, o->d_lq, o->d_inview, o->strm));
@@ -660,6 +660,7 @@ int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
     memcpy(U + oM0, mask0.data(), 4 * S); memcpy(U + oNm, nmask.data(), 4 * S);
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, L.off, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    o->t_begin();
     if (caller_bits || !getenv("OSLAM_SLAM_NO_MASK_BITS")) {   // one pass over the mask bytes; the test (and pose_opt2's boundary lists later in this step) read bitmaps
         const int H = o->cfg.height, W = o->cfg.width;
         OPS_CHECK(o->ensure_maskbits((size_t)total * H * ((W + 63) / 64)));
@@ -673,9 +674,11 @@ int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
     } else
     OPS_CHECK(oslam_frame_object_kp_test_batch_device(o->d_keysUn, (int)cap, o->d_cnt, (int)S, (const uint8_t* const*)(Dv + oPtr), (const int32_t*)(Dv + oM0),
                                                       (const int32_t*)(Dv + oNm), o->cfg.height, o->cfg.width, pitch, o->d_objbits, o->strm));
+    o->t_end();
     OPS_CHECK(o->ensure_dn(cap * S));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, o->d_objbits, cap * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(7, 2, 0);
     for (int i = 0; i < n; i++) memcpy(jobs[i].in_mask, o->dn_h + cap * jobs[i].slot, (size_t)jobs[i].cur->N);
     return OSLAM_OK;
 }
@@ -858,6 +861,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * dtotal);
     if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
     if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)dtotal, Dv + oDesc, o->strm));
     Layout R;
     const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
@@ -876,7 +880,9 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     if (table)
         OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(Dv + oItems), o->d_mp_tab, (const int32_t*)(Dv + oStart), (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)),
                                               (const float*)(Dv + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
+    o->t_end();
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(6, (keyed ? 1 : 0) + (j->do_desc ? 2 : 0) + (j->do_normal ? 1 : 0) + (table ? 1 : 0), (double)dtotal);
     if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
     if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
     return OSLAM_OK;
@@ -958,7 +964,9 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     OPS_CHECK(o->ensure_up(segs.size() * sizeof(CopySegH)));
     memcpy(o->up_h, segs.data(), segs.size() * sizeof(CopySegH));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, segs.size() * sizeof(CopySegH), hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
     OPS_CHECK(oslam_copy_segments_device(o->up_d, (int)segs.size(), o->strm));
+    o->t_end();
     // descriptor-array table for the observation gathers
     if ((size_t)o->n_rec > o->rec_desc_cap) {
         OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
@@ -971,6 +979,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
                                    hipMemcpyHostToDevice, o->strm));
     o->rec_desc_n = o->n_rec;
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
+    o->t_collect(7, 1, 0);
     return OSLAM_OK;
 }
 
@@ -1007,10 +1016,13 @@ int h_bow_nodes_keyed(void* p, int n, const int32_t* slots, const int32_t* kf_id
     memcpy(U + oTop, top, 320); memcpy(U + oSub, sub, 3200);
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, U, in_bytes, hipMemcpyHostToDevice, o->strm));
     uint8_t* Dv = o->up_d;
+    o->t_begin();
     OPS_CHECK(oslam_bow_nodes_device((const uint8_t* const*)(Dv + oPtr), (const int32_t*)(Dv + oCnt), n, (int)cap, (const uint64_t*)(Dv + oTop), (const uint64_t*)(Dv + oSub),
                                      (uint32_t*)(Dv + oOut), o->strm));
+    o->t_end();
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, Dv + oOut, 4 * cap * (size_t)n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(7, 1, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(out[i], o->dn_h + 4 * cap * (size_t)i, 4 * (size_t)counts[i]); });
     return OSLAM_OK;
 }
@@ -1038,6 +1050,13 @@ int h_kernel_times(void* p, int enable, double* out) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
     if (enable && !o->tev0) { OSLAM_HIP_CHECK(hipEventCreate(&o->tev0)); OSLAM_HIP_CHECK(hipEventCreate(&o->tev1)); }
+    {   // the BoW matchers and the triangulation run on their handles' own streams
+        double ms = 0; long long ln = 0;
+        OPS_CHECK(oslam_bow_kernel_time(o->bow, enable, &ms, &ln));
+        o->kt[15] += ms; o->kt[16] += (double)ln;
+        OPS_CHECK(oslam_mappoint_kernel_time(o->mp, enable, &ms, &ln));
+        o->kt[15] += ms; o->kt[16] += (double)ln;
+    }
     if (out) memcpy(out, o->kt, sizeof(o->kt));
     memset(o->kt, 0, sizeof(o->kt));
     o->timing = enable;
@@ -1100,17 +1119,20 @@ static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_ke
         memcpy(U + oQ + sizeof(oslam_proj_query_t) * st * i, j.queries, sizeof(oslam_proj_query_t) * M);
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, nres == n ? small_bytes : L.off, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
     if (nres) OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 3 * nres, o->strm));
     oslam_match_frames_t fr;
     fr.keysUn = (const oslam_keypoint_t*)(Dv + oKeys); fr.kp_stride = (int)cap; fr.uRight = (const float*)(Dv + oUr); fr.desc = Dv + oDesc; fr.blocked = nullptr;
     fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
     fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
     OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels, o->strm));
+    o->t_end();
     const int32_t* d_qm;
     OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
     OPS_CHECK(o->ensure_dn(4 * st * B));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(4, 2, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
 }
@@ -1159,6 +1181,7 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         segs[3 * i + 2] = {o->rec_desc(rec[i]), Dv + oDesc + 32 * cap * i, (uint32_t)(32 * N), 0};
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, head, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
     OPS_CHECK(oslam_copy_segments_device(Dv + oSeg, 3 * n, o->strm));
     OPS_CHECK(oslam_fuse_queries_device(n, (int)st, (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oM), (const int32_t*)(Dv + oIds), Dv + oEx, o->d_mp_tab,
                                         (const float*)(Dv + oT), (const float*)(Dv + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale, o->cfg.nLevels,
@@ -1168,11 +1191,13 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
     fr.n_kps = (const int32_t*)(Dv + oN); fr.n_kps_const = 0;
     fr.minX = o->bounds[0]; fr.minY = o->bounds[1]; fr.maxX = o->bounds[2]; fr.maxY = o->bounds[3];
     OPS_CHECK(oslam_match_fuse_batch_device(o->m_map, &fr, (const oslam_proj_query_t*)(Dv + oQ), (int)st, (const int32_t*)(Dv + oM), 0, n, o->invSigma2, o->cfg.nLevels, o->strm));
+    o->t_end();
     const int32_t* d_qm;
     OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
     OPS_CHECK(o->ensure_dn(4 * st * B));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    o->t_collect(4, 3, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
 }
@@ -1250,8 +1275,8 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (!rc && cfg->sensor == 1) rc = oslam_orb_create(&o->orbR, cfg->nFeatures, cfg->scaleFactor, cfg->nLevels, cfg->iniThFAST, cfg->minThFAST, cfg->width, cfg->height, o->S, dev);
     if (!rc && cfg->sensor == 1) rc = oslam_stereo_create(&o->stereo, o->S, o->cap, dev);
     if (!rc) rc = oslam_poseopt_create(&o->po, o->S, o->cap, dev);
-    if (!rc) rc = oslam_lba_create(&o->ba, o->S, 128, 4096, 32768, dev);    // points / edges per window grow on demand (include/oslam_hip.h); <= 128 keyframes per window
-    if (!rc) rc = oslam_lba_create(&o->ba1, 1, 128, 4096, 32768, dev);
+    if (!rc) rc = oslam_lba_create(&o->ba, o->S, 1 << 16, 4096, 32768, dev);    // keyframes / points / edges per window grow on demand (include/oslam_hip.h); <= 128 FREE keyframes
+    if (!rc) rc = oslam_lba_create(&o->ba1, 1, 1 << 16, 4096, 32768, dev);
     // batches of windows: every LM trial of ALL windows as short whole-GPU launches (mode 1: the windows of a call spread over all CUs and the kernels of the other
     // handles interleave; the Schur complement is formed on chip by tiles).  OSLAM_LBA_BATCH_MODE = 2 (one workgroup per window, the whole schedule in one launch:
     // the most work per CU-second, but a call of ~40 windows then holds 40 CUs for tens of milliseconds and the other handles' short kernels queue behind the

@@ -276,7 +276,7 @@ class System:
         check(self.L.oslam_slam_lba_window_stats(self.h, C.c_int(seq), ptr(out)))
         return dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "fixed_dropped"), out[:6].tolist()))
 
-    KT_GROUPS = ("frames", "pose_opt", "lba", "search")
+    KT_GROUPS = ("frames", "pose_opt", "lba", "search", "fuse", "bow_triangulate", "mp_update", "other")
 
     def kernel_times(self, enable=True):
         """Device milliseconds / launches / algorithmic work (bytes, flop, flop, -) per kernel group since the last call (include/oslam_slam.h)."""

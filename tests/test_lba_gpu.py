@@ -76,7 +76,7 @@ def test_lba_stop_flag_and_errors(oracle, wide):
     with pytest.raises(OslamError):   # duplicate observation
         ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], np.r_[q["edge_kf"], q["edge_kf"][:1]], np.r_[q["edge_pt"], q["edge_pt"][:1]],
                                  np.r_[q["edge_obs"], q["edge_obs"][:1]], np.r_[q["edge_invSigma2"], q["edge_invSigma2"][:1]], q["K"])
-    with pytest.raises(OslamError):   # capacity
+    with pytest.raises(OslamError):   # capacity (the handle was created for 16 keyframes per window)
         big = synth.make_lba_problem(10, K_local=20, K_fixed=0, P=600)
         ba.LocalBundleAdjustment(big["poses"], big["fixed"], big["points"], big["edge_kf"], big["edge_pt"], big["edge_obs"], big["edge_invSigma2"], big["K"])
     ba.close()
@@ -148,6 +148,21 @@ def test_lba_window_layout_beyond_the_lds_resident_system(oracle, KL, KF, P, tra
     o = oracle.local_bundle_adjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
     _compare(outs[0], o)
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    ba.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lba_window_with_more_than_128_keyframes(oracle, mode):
+    """The reference gathers every covisible and every fixed keyframe (src/Optimizer.cc:456-504: no bound).  60 local + 120 fixed keyframes in one window: the
+    poses of the wide / window layouts are sized by the window, only the FREE keyframes are limited (128: the reduced system's order)."""
+    q = synth.make_lba_problem(321, K_local=60, K_fixed=120, P=6000, track=5)
+    assert len(q["poses"]) == 180
+    ba = LocalBundleAdjuster(max_batch=2, max_keyframes=256, max_points=8192, max_edges=65536)
+    ba.set_mode(mode)
+    a, o = _run(oracle, ba, q)
+    _compare(a, o)
+    outs = ba.LocalBundleAdjustmentBatch([q, synth.make_lba_problem(3, K_local=4, K_fixed=2, P=150)], q["K"])
+    assert np.array_equal(outs[0][0], a[0]) and np.array_equal(outs[0][1], a[1]) and np.array_equal(outs[0][2], a[2])
     ba.close()
 
 
