@@ -592,7 +592,7 @@ struct LbaWide {
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
     // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
-    const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* thr_own; const int* blk_thr;
+    const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* thr_own; const int* blk_thr; const int* blk_slots;
     double* parts;            // [nwg][ngroup * kWinThreads][42] per-workgroup, per-slot block sums
     int ntile, ngroup, nwg, TE, TP, nblk;
 };
@@ -1289,11 +1289,11 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
     return ok2;
 }
 
-__global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* probs, const LbaWide* ws) {
+__global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* probs, const LbaWide* ws, int min_n) {
     const LbaProblem& pr = probs[blockIdx.y];
     const LbaWide& w = ws[blockIdx.y];
     LbaCtrl* ct = w.ct;
-    if (ct->done) return;
+    if (ct->done || ct->n < min_n) return;   // (min_n: systems below it were factored by the LDS-resident kernel of the same trial)
     extern __shared__ __align__(16) double s_P[];          // [16][pw] row panel, pw = panel pitch (columns right of the block, incl. rhs, padded to 16)
     __shared__ double s_x[kMfmaMaxN + kMB];
     const bool ok2 = chol_mfma_dev(pr.Hs, ct->n, pr.xp, s_P, s_x);
@@ -1551,12 +1551,12 @@ struct oslam_lba {
         LbaProblem pr;            // scalar fields valid; pointers filled at launch
         const float* p_poses = nullptr; const uint8_t* p_fixed = nullptr; const float* p_points = nullptr;   // the caller's arrays (copied into the arena by lba_place)
         std::vector<int> ekf, ept, pt_start, pose_start, pose_edges, pstart, chunk_kf, chunk_e0, chunk_n, kf_chunk0, pt_edge, tile_p0, tile_s0, stg_edge;
-        std::vector<int> thr_own, blk_thr;
+        std::vector<int> thr_own, blk_thr, blk_slots;
         int TE = 0, TP = 0, region_doubles = 0, ngroup = 1, hs_global = 0;
         std::vector<float> eobs, einfo;
         std::vector<int2> pairs;
         size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
-        size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_thr_own, o_blk_thr;
+        size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_thr_own, o_blk_thr, o_blk_slots;
         size_t o_out_poses, o_out_points, o_out_erase, o_out_stats;   // offsets into the `out` arena
         int nfree = 0, nblk = 1; size_t npairs = 0;
         int layout = 0;           // 0 point-major edge numbering (compact / wide kernels), 1 keyframe-major (one workgroup per window, lba_win.inc)
@@ -1706,7 +1706,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
         hipFuncSetAttribute((const void*)k_w_chol_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, kMB * (kMfmaMaxN + 2 * kMB) * (int)sizeof(double)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lba_win, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_w_schur_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_w_chol_packed, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_w_chol_packed, hipFuncAttributeMaxDynamicSharedMemorySize, kCholPackedLds) != hipSuccess) {
         set_error("hipFuncSetAttribute failed"); oslam_lba_destroy(h); return OSLAM_E_HIP;
     }
     *out = h;
@@ -1779,11 +1779,12 @@ static int lba_build_tiles(oslam_lba::Prep& q, const std::vector<int>& blk, int 
         const int G = std::max(1, (used + kWinThreads - 1) / kWinThreads);
         if (G > kWinGroupsMax) return fail(OSLAM_E_CAPACITY, "%d blocks with pairs > %d", used, kWinGroupsMax * kWinThreads);
         q.ngroup = G;
-        if (G == 1 && used > 0) {
+        const int slots = G * kWinThreads;
+        if (used > 0) {   // spare slots (of any pass) go to the blocks with the most pairs per thread
             std::vector<std::pair<double, int>> heap;   // (pairs per thread, block)
             for (int b2 = 0; b2 < nblk; b2++) if (cnt[b2]) heap.push_back(std::make_pair((double)load[b2], b2));
             std::make_heap(heap.begin(), heap.end());
-            while (used < kWinThreads && !heap.empty()) {
+            while (used < slots && !heap.empty()) {
                 std::pop_heap(heap.begin(), heap.end());
                 const int b2 = heap.back().second;
                 heap.pop_back();
@@ -1793,26 +1794,25 @@ static int lba_build_tiles(oslam_lba::Prep& q, const std::vector<int>& blk, int 
                 std::push_heap(heap.begin(), heap.end());
             }
         }
-        std::vector<std::pair<double, int>> ord;
-        for (int b2 = 0; b2 < nblk; b2++) if (cnt[b2]) ord.push_back(std::make_pair(-(double)load[b2] / cnt[b2], b2));
+        // one entry per (block, sub), ordered by load; dealt to the passes in turn so that every pass keeps the load order and a similar total
+        std::vector<std::pair<double, int>> ord;   // (-pairs per thread, block * 64 + sub)
+        for (int b2 = 0; b2 < nblk; b2++) for (int s2 = 0; s2 < cnt[b2]; s2++) ord.push_back(std::make_pair(-(double)load[b2] / cnt[b2], b2 * 64 + s2));
         std::sort(ord.begin(), ord.end());
-        q.thr_own.assign((size_t)G * kWinThreads, -1); q.blk_thr.assign(nblk, 0);
-        if (G == 1) {
-            int t0 = 0;
-            for (auto& o2 : ord) {
-                const int b2 = o2.second;
-                q.blk_thr[b2] = t0 | (cnt[b2] << 16);
-                for (int s2 = 0; s2 < cnt[b2]; s2++) q.thr_own[t0 + s2] = b2 | (s2 << 16) | (cnt[b2] << 24);
-                t0 += cnt[b2];
-            }
-        } else {   // more blocks than threads: the load-sorted blocks are dealt to the passes in turn (every pass keeps the load order)
-            std::vector<int> fill(G, 0);
-            for (size_t i = 0; i < ord.size(); i++) {
-                const int b2 = ord[i].second, g = (int)(i % G), slot = g * kWinThreads + fill[g]++;
-                q.blk_thr[b2] = slot | (1 << 16);
-                q.thr_own[slot] = b2 | (1 << 24);
-            }
+        q.thr_own.assign((size_t)slots, -1); q.blk_thr.assign(nblk, 0); q.blk_slots.clear();
+        std::vector<int> fill(G, 0), slot_of(ord.size());
+        for (size_t i = 0; i < ord.size(); i++) {
+            const int b2 = ord[i].second / 64, s2 = ord[i].second % 64, g = (int)(i % G), slot = g * kWinThreads + fill[g]++;
+            q.thr_own[slot] = b2 | (s2 << 16) | (cnt[b2] << 24);
+            slot_of[i] = slot;
         }
+        // the slots of every block in sub order (the sums are added in this order)
+        std::vector<std::vector<int>> per(nblk);
+        for (size_t i = 0; i < ord.size(); i++) { const int b2 = ord[i].second / 64, s2 = ord[i].second % 64; if ((int)per[b2].size() < cnt[b2]) per[b2].resize(cnt[b2]); per[b2][s2] = slot_of[i]; }
+        for (int b2 = 0; b2 < nblk; b2++) {
+            q.blk_thr[b2] = (int)q.blk_slots.size() | (cnt[b2] << 16);
+            for (int s2 = 0; s2 < cnt[b2]; s2++) q.blk_slots.push_back(per[b2][s2]);
+        }
+        if (q.blk_slots.empty()) q.blk_slots.push_back(0);
     }
     return OSLAM_OK;
 }
@@ -1955,13 +1955,13 @@ static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
         (rc = in_put(h, q.einfo.data(), nE * 4, &q.o_einfo)) || (rc = in_put(h, q.pt_start.data(), (nP + 1) * 4, &q.o_ptstart)))
         return rc;
     q.o_posestart = q.o_poseedges = q.o_pairs = q.o_pstart = q.o_chunk_kf = q.o_chunk_e0 = q.o_chunk_n = q.o_kf_chunk0 = q.o_pt_edge = 0;
-    q.o_tile_p0 = q.o_tile_s0 = q.o_stg_edge = q.o_thr_own = q.o_blk_thr = 0;
+    q.o_tile_p0 = q.o_tile_s0 = q.o_stg_edge = q.o_thr_own = q.o_blk_thr = q.o_blk_slots = 0;
     if (q.layout == 0) {
         if ((rc = in_put(h, q.pose_start.data(), (nKF + 1) * 4, &q.o_posestart)) || (rc = in_put(h, q.pose_edges.data(), nE * 4, &q.o_poseedges))) return rc;
         if (!q.tile_p0.empty() &&
             ((rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
              (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
-             (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr))))
+             (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr)) || (rc = in_put(h, q.blk_slots.data(), q.blk_slots.size() * 4, &q.o_blk_slots))))
             return rc;
     } else {
         const size_t nc = q.chunk_kf.size();
@@ -1969,7 +1969,7 @@ static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
             (rc = in_put(h, q.kf_chunk0.data(), (nKF + 1) * 4, &q.o_kf_chunk0)) || (rc = in_put(h, q.pt_edge.data(), nE * 4, &q.o_pt_edge)) ||
             (rc = in_put(h, q.tile_p0.data(), q.tile_p0.size() * 4, &q.o_tile_p0)) || (rc = in_put(h, q.tile_s0.data(), q.tile_s0.size() * 4, &q.o_tile_s0)) ||
             (rc = in_put(h, q.stg_edge.data(), q.stg_edge.size() * 4, &q.o_stg_edge)) || (rc = in_put(h, q.thr_own.data(), q.thr_own.size() * 4, &q.o_thr_own)) ||
-            (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr)))
+            (rc = in_put(h, q.blk_thr.data(), q.blk_thr.size() * 4, &q.o_blk_thr)) || (rc = in_put(h, q.blk_slots.data(), q.blk_slots.size() * 4, &q.o_blk_slots)))
             return rc;
     }
     if (q.layout == 0 && !q.pstart.empty()) {
@@ -2050,7 +2050,7 @@ static int lba_launch(oslam_lba_t* h) {
     for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
     const int nwg_call = std::max(1, std::min(16, (2 * 256 + std::max(n0, 1) - 1) / std::max(n0, 1)));   // workgroups per window: ~2 per CU over the call
     size_t tiles_lds = 0, packed_lds = 0;
-    int maxWg = 1, maxSum = 1;
+    int maxWg = 1, maxSum = 1, min_n6_big = 1 << 30;   // (min_n6_big: the smallest reduced system of the call)
     std::vector<WOff> wo(n);
     int maxNbPt = 1, maxK = 1, maxE = 1, maxBlk = 1, maxFin = 1, maxInit = 1, max_slots = 0, min_group = 4, max_n6 = 0;
     bool all_lds = true;
@@ -2078,7 +2078,8 @@ static int lba_launch(oslam_lba_t* h) {
                     tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP));
                     maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
                 } else o.W = takeW(E * 144);
-                packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
+                if ((int)n6 <= kCholPackedN) packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
+                min_n6_big = std::min(min_n6_big, (int)n6);
             }
             maxNbPt = std::max(maxNbPt, nbpt); maxK = std::max(maxK, (int)K); maxE = std::max(maxE, (int)E); maxBlk = std::max(maxBlk, q.nblk);
             maxFin = std::max(maxFin, (int)std::max(std::max(E, K), P * 3)); maxInit = std::max(maxInit, (int)std::max(P * 3, E));
@@ -2140,7 +2141,7 @@ static int lba_launch(oslam_lba_t* h) {
                 w.W = nullptr;
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
                 w.thr_own = (const int*)(I + q.o_thr_own);
-                w.blk_thr = (const int*)(I + q.o_blk_thr); w.parts = (double*)(Wk + o.parts);
+                w.blk_thr = (const int*)(I + q.o_blk_thr); w.blk_slots = (const int*)(I + q.o_blk_slots); w.parts = (double*)(Wk + o.parts);
                 w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, w.ntile)); w.TE = q.TE; w.TP = q.TP; w.nblk = q.nblk;
             }
         }
@@ -2156,7 +2157,7 @@ static int lba_launch(oslam_lba_t* h) {
         memset(&w, 0, sizeof(w));
         w.chunk_kf = (const int*)(I + q.o_chunk_kf); w.chunk_e0 = (const int*)(I + q.o_chunk_e0); w.chunk_n = (const int*)(I + q.o_chunk_n); w.kf_chunk0 = (const int*)(I + q.o_kf_chunk0);
         w.pt_edge = (const int*)(I + q.o_pt_edge); w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
-        w.thr_own = (const int*)(I + q.o_thr_own); w.blk_thr = (const int*)(I + q.o_blk_thr);
+        w.thr_own = (const int*)(I + q.o_thr_own); w.blk_thr = (const int*)(I + q.o_blk_thr); w.blk_slots = (const int*)(I + q.o_blk_slots);
         w.chunkC = (double*)(Wk + o.chunkC); w.pairPart = (double*)(Wk + o.pairPart); w.HsG = q.hs_global ? (double*)(Wk + o.Hs) : nullptr;
         w.ngroup = q.ngroup; w.hs_global = q.hs_global;
         w.nchunk = (int)q.chunk_kf.size(); w.npairs = (int)q.npairs; w.nfree = q.nfree; w.nblk = q.nblk; w.ntile = (int)q.tile_p0.size() - 1;
@@ -2183,8 +2184,10 @@ static int lba_launch(oslam_lba_t* h) {
         const size_t chol_lds = all_lds ? (size_t)max_n6 * (max_n6 + 1) * sizeof(double) : 0;
         // systems beyond the LDS-resident kernels (full square up to 132 unknowns, packed upper triangle up to kCholPackedN) are factored by the matrix cores
         // (k_w_chol_mfma); h->chol_mode 1 forces them, 2 forbids them
-        const bool chol_packed = h->chol_mode != 1 && !all_lds && max_n6 <= kCholPackedN;
-        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds && !chol_packed);
+        // per window: the packed LDS kernel up to kCholPackedN unknowns, the matrix cores beyond (both kernels are launched when a call mixes the two)
+        const bool chol_packed = h->chol_mode != 1 && !all_lds && min_n6_big <= kCholPackedN && (h->chol_mode == 0 || max_n6 <= kCholPackedN);
+        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds && max_n6 > kCholPackedN);
+        const int mfma_min_n = chol_packed ? kCholPackedN + 1 : 0;
         const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
         hipLaunchKernelGGL(k_w_init, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
@@ -2203,7 +2206,8 @@ static int lba_launch(oslam_lba_t* h) {
                     hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n0), dim3(64), 0, st, d_probs, d_ws);
                 }
                 if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);
-                else if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n0), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws);
+                if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n0), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws, mfma_min_n);
+                if (chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n0), dim3(kWPt), 0, st, d_probs, d_ws);
