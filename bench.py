@@ -505,6 +505,23 @@ def main():
         dist.destroy_process_group()
 
 
+def _mfma_counters():
+    """MFMA counters of the matrix-core reduced-system solver from the committed rocprofv3 --pmc pass of tools/lba_mfma_pmc.py (S5-large, n = 240, and 40
+    driver-shaped windows of 34 free keyframes, n = 204; SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r03_pmc_lba_mfma.json)."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_lba_mfma.json")
+    try:
+        e = json.load(open(path))["k_w_chol_mfma"]
+        return {"kernel": "k_w_chol_mfma (v_mfma_f64_16x16x4_f64 trailing updates of the reduced camera system, n = 204 .. 240)",
+                "mfma_util": round(e["mfma_util_of_occupied_cus"], 4), "mfma_util_chip": round(e["mfma_util_chip"], 5),
+                "mfma_busy_cycles_per_launch": int(e["SQ_VALU_MFMA_BUSY_CYCLES"]), "mfma_mops_f64_per_launch": int(e["SQ_INSTS_VALU_MFMA_MOPS_F64"]),
+                "mean_launch_us": round(e["mean_us"], 1),
+                "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 4 SIMDs x CUs the launch occupies); counters, not pencil arithmetic: the solver "
+                              "is bound by the per-panel critical path (diagonal factor, row-panel solve, two global round trips per 16-wide panel), not by the matrix pipe",
+                "source": "profiles/r03_pmc_lba_mfma.json"}
+    except Exception:
+        return None
+
+
 def roofline_of(k, summ, stereo):
     """Roofline of the dominant kernel group of the timed region (HIP events on the launch streams, rank 0)."""
     names = {"frames": ("hbm", "Frame::Frame (k_resize_lds, k_fast_cells_wave, k_blur_strip, k_octree, k_orient_describe, undistort, depth lookup%s)"
@@ -536,7 +553,7 @@ def roofline_of(k, summ, stereo):
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
             "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else None, "launch_us": round(ms / launches * 1e3, 1),
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
-            "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4),
+            "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4), "mfma": _mfma_counters(),
             "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "
                     "iterations / trials the kernels report"}
 
