@@ -1545,7 +1545,11 @@ struct oslam_lba {
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
-    int schur_tiles = 1;          // wide layout: Schur complement by LDS tiles (k_w_schur_tiles, one coalesced read of Hpl per trial) instead of the pair gather (k_w_schur)
+    int schur_tiles = 0;          // wide layout, Schur complement (default 0: in the bench the gather is as fast or faster at every window size, see below): 1 = by LDS tiles (k_w_schur_tiles: one coalesced read of Hpl per trial), 0 = by the pair gather
+                                  // (k_w_edgeW + k_w_schur: 288 bytes per pair from memory), 2 = per call: tiles when the windows average >= kSchurTilesMinEdges edges.
+                                  // Measured (tools/lba_win_prof.py, kernels of one call): 50 windows of 10 keyframes / 4.4 k edges: gather 3.2 ms, tiles 5.7 ms; 40 windows
+                                  // of 27 keyframes / 13 k edges: gather 8.7 ms, tiles 9.2 ms alone, but in the bench (8 handles, ~330 such windows in flight: the W / B
+                                  // blocks no longer fit the 256 MB cache) the local-BA group takes 5.9 s with tiles against 6.9 s with the gather
     int chol_mode = 0;            // reduced-system solver: 0 auto (LDS-resident scalar kernel while it fits, matrix cores beyond), 1 always MFMA, 2 never
     struct Prep {                 // one prepared window: host-built arrays, then offsets into the `in` arena
         LbaProblem pr;            // scalar fields valid; pointers filled at launch
@@ -1695,7 +1699,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
-    if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e) ? 1 : 0;   // 0 = the round-2 pair-gather Schur kernels (k_w_edgeW + k_w_schur)
+    if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e);   // 0 = always the pair gather, 1 = always tiles, 2 = per call (default)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
     if (hipHostGetDevicePointer((void**)&h->d_stop, h->h_stop, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
@@ -1722,6 +1726,12 @@ int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]) {
 int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
     if (!h || wide < 0 || wide > 2) { set_error("oslam_lba_set_mode: mode must be 0 (compact), 1 (wide) or 2 (one workgroup per window, LDS-resident)"); return OSLAM_E_INVALID; }
     h->wide = wide;
+    return OSLAM_OK;
+}
+
+int oslam_lba_set_schur(oslam_lba_t* h, int mode) {
+    if (!h || mode < 0 || mode > 2) { set_error("oslam_lba_set_schur: mode must be 0 (pair gather), 1 (LDS tiles) or 2 (per call)"); return OSLAM_E_INVALID; }
+    h->schur_tiles = mode;
     return OSLAM_OK;
 }
 
@@ -1978,6 +1988,8 @@ static int lba_place(oslam_lba_t* h, oslam_lba::Prep& q) {
     return OSLAM_OK;
 }
 
+constexpr int kSchurTilesMinEdges = 8000;   // wide layout: mean edges per window from which a call forms the Schur complement by tiles (oslam_lba::schur_tiles)
+
 struct LbaArgs {   // one window as the entry points receive it
     int nKF; const float* poses; const uint8_t* fixed; int nP; const float* points; int nE; const int32_t* edge_kf; const int32_t* edge_pt; const float* edge_obs;
     const float* edge_invSigma2; float* poses_out; float* points_out; uint8_t* erase;
@@ -2003,7 +2015,9 @@ static int lba_prepare_all(oslam_lba_t* h, int n, const LbaArgs* a, const float 
     std::vector<int> rcs(n, 0);
     std::vector<std::array<char, 192>> errs(n);
     // wide layout: the Schur complement by tiles needs every window's blocks to fit the thread slots (<= 63 free keyframes); otherwise the whole call gathers pairs
-    bool use_tiles = h->schur_tiles != 0;
+    long long sumE = 0;
+    for (int i = 0; i < n; i++) sumE += a[i].nE;
+    bool use_tiles = h->schur_tiles == 1 || (h->schur_tiles == 2 && sumE >= (long long)kSchurTilesMinEdges * n);
     std::vector<int> nfrees(n, 0);
     for (int i = 0; i < n; i++) {
         const LbaArgs& q = a[i];
@@ -2073,7 +2087,7 @@ static int lba_launch(oslam_lba_t* h) {
                 o.ctrl = ctrl_base + sizeof(LbaCtrl) * j; o.T = takeW(sizeof(SE3) * 2 * K); o.R = takeW(144 * K); o.blk = takeW(4 * K); o.free_pose = takeW(4 * K);
                 o.partF = takeW(8 * (nbpt + 2)); o.partS = takeW(8 * (nbpt + 2)); o.partM = takeW(8 * (nbpt + 2));
                 if (tiles) {
-                    const int ntile = (int)q.tile_p0.size() - 1, nwg = std::max(1, std::min(nwg_call, ntile));
+                    const int ntile = (int)q.tile_p0.size() - 1, nwg = std::max(1, std::min(nwg_call, (ntile + 1) / 2));   // >= 2 tiles per workgroup (its block sums cost a pass over all slots)
                     o.parts = takeW((size_t)nwg * q.ngroup * kWinThreads * 42 * 8);
                     tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP));
                     maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
@@ -2142,7 +2156,7 @@ static int lba_launch(oslam_lba_t* h) {
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
                 w.thr_own = (const int*)(I + q.o_thr_own);
                 w.blk_thr = (const int*)(I + q.o_blk_thr); w.blk_slots = (const int*)(I + q.o_blk_slots); w.parts = (double*)(Wk + o.parts);
-                w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, w.ntile)); w.TE = q.TE; w.TP = q.TP; w.nblk = q.nblk;
+                w.ntile = (int)q.tile_p0.size() - 1; w.ngroup = q.ngroup; w.nwg = std::max(1, std::min(nwg_call, (w.ntile + 1) / 2)); w.TE = q.TE; w.TP = q.TP; w.nblk = q.nblk;
             }
         }
         hw[j] = w;

@@ -125,6 +125,10 @@ class LocalBundleAdjuster:
         """wide=True: one problem over the whole GPU (multi-kernel LM); False: one workgroup per problem."""
         check(self.L.oslam_lba_set_mode(self.h, int(wide)))
 
+    def set_schur(self, mode):
+        """Schur complement of the wide mode: 0 pair gather, 1 LDS tiles, 2 chosen per call (include/oslam_hip.h)."""
+        check(self.L.oslam_lba_set_schur(self.h, C.c_int(mode)))
+
     def set_solver(self, mode):
         """Reduced-camera-system solver of the wide mode: 0 auto, 1 matrix cores (MFMA f64) for every size, 2 never (include/oslam_hip.h)."""
         check(self.L.oslam_lba_set_solver(self.h, C.c_int(mode)))

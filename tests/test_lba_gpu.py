@@ -50,6 +50,12 @@ def test_lba_matches_oracle(oracle, seed, KL, KF, P, wide):
     ba.set_mode(wide)
     a, o = _run(oracle, ba, q)
     _compare(a, o)
+    if wide == 1:   # both Schur implementations of the wide layout (the default picks one per call from the window size)
+        for schur in (0, 1):
+            ba.set_schur(schur)
+            a2, _ = _run(oracle, ba, q)
+            _compare(a2, o)
+        ba.set_schur(2)
     # edges in a shuffled (non point-major) order give the same answer
     rng = np.random.default_rng(seed)
     perm = rng.permutation(len(q["edge_kf"]))

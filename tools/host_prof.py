@@ -6,18 +6,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(S, G, steps):
+def run(S, G, steps, preroll=200):
     from object_slam_amd import seqbench, slam
-    wl = seqbench.rgbd_workload(n_base=16, stagger=12)
+    wl = seqbench.rgbd_workload(speed=1.0, n_base=8, stagger=24)                  # bench.py's headline: steady state after `preroll` steps
     warm = 4
-    seqs = seqbench.base_sequences(wl, 0, S, warm + steps, workers=16)            # forked workers, before the GPU is touched
+    seqs = seqbench.base_sequences(wl, 0, S, preroll + warm + steps, workers=16)   # forked workers, before the GPU is touched
     so = os.path.join(ROOT, "tools", "pcsample", "libpcsample.so")
     if not os.path.exists(so):
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, os.path.join(ROOT, "tools", "pcsample", "pcsample.c"), "-lrt"])
     pcs = ctypes.CDLL(so)
     share = min(16, os.cpu_count() or 1)
     summ, rec, systems, _ = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), 0, 1, S, G, steps, warm, True, 0, host_threads=max(1, share // G),
-                                              sequences=seqs, after_warmup=lambda systems: pcs.pcs_start(997))
+                                              sequences=seqs, after_warmup=lambda systems: pcs.pcs_start(997), preroll=preroll,
+                                              progress=lambda m: print(m, flush=True))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     n = pcs.pcs_stop(os.path.join(ROOT, "gpurun_out", "host_prof.samples").encode())
     print("frames/s", round(summ["frames_per_s"], 1), "samples", n)
