@@ -432,7 +432,7 @@ static int bow_batch(oslam_bow_t* h, int n, oslam_bow_job_t* jobs, const oslam_b
     if (h->timing) (void)hipEventRecord(h->ev1, h->strm);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipMemcpyAsync(H + in_bytes, D + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, h->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    OSLAM_HIP_CHECK(stream_wait(h->strm));
     if (h->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_n += 1; } }
     for (int i = 0; i < n; i++) {
         jobs[i].nmatches = *(const int*)(H + off[i].nm);

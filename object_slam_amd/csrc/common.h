@@ -21,6 +21,12 @@ void set_error(const char* fmt, ...);
         }                                                                                  \
     } while (0)
 
+// Waits for everything enqueued on `s`: hipStreamSynchronize (the default), or — OSLAM_WAIT_SPIN_US >= 0 — a poll of that many microseconds followed by a
+// sleep on an event created with hipEventBlockingSync, which leaves the core to other threads.  Measured in bench.py's steady state (8 handles, 16 cores,
+// 150-step pre-roll): spinning 20.9 k frames/s, 60 us poll + sleep 18.7 k, and neither a third thread per handle (17.5 k) nor 12 handles (15.0 k) gains from
+// the freed cores: the wake-up latency of ~400 waits per step costs more than the spinning.  Kept as a knob.
+hipError_t stream_wait(hipStream_t s);
+
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

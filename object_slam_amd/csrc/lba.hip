@@ -2229,7 +2229,7 @@ static int lba_launch(oslam_lba_t* h) {
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
             OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, hipMemcpyDeviceToHost, st));
-            OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+            OSLAM_HIP_CHECK(stream_wait(st));
             bool all_done = true;
             for (int i = 0; i < n0; i++) all_done = all_done && h->h_ctrl[i].done != 0;
             if (all_done) break;
@@ -2241,7 +2241,7 @@ static int lba_launch(oslam_lba_t* h) {
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipMemcpyAsync(h->out_h, O, outb, hipMemcpyDeviceToHost, st));   // the ONE download
-    OSLAM_HIP_CHECK(hipStreamSynchronize(st));
+    OSLAM_HIP_CHECK(stream_wait(st));
     lba_time_collect(h, launches);
     return OSLAM_OK;
 }

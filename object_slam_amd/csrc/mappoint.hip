@@ -945,7 +945,7 @@ extern "C" int oslam_mp_triangulate_pairs(oslam_mappoint_t* h, int nPairs, const
     if (h->timing) (void)hipEventRecord(h->ev1, h->strm);
     OSLAM_HIP_CHECK(hipGetLastError());
     OSLAM_HIP_CHECK(hipMemcpyAsync(H + o_ok, D + o_ok, at - in_bytes, hipMemcpyDeviceToHost, h->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(h->strm));
+    OSLAM_HIP_CHECK(stream_wait(h->strm));
     if (h->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) { h->kern_ms += ms; h->kern_n += 1; } }
     memcpy(ok, H + o_ok, (size_t)M);
     memcpy(x3D, H + o_x3, (size_t)M * 12);

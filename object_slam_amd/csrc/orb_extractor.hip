@@ -9,6 +9,9 @@
 
 #include "common.h"
 
+#include <time.h>
+#include <stdlib.h>
+
 namespace oslam {
 
 static thread_local char g_err[512] = "";
@@ -17,6 +20,36 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// see common.h: poll briefly, then sleep on a blocking event (one event per host thread and device)
+hipError_t stream_wait(hipStream_t s) {
+    static const int spin_us = [] { const char* e = getenv("OSLAM_WAIT_SPIN_US"); return e ? atoi(e) : -1; }();
+    if (spin_us < 0) return hipStreamSynchronize(s);
+    struct Ev { hipEvent_t ev = nullptr; int dev = -1; };
+    static thread_local Ev t;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!t.ev || t.dev != dev) {
+        if (t.ev) (void)hipEventDestroy(t.ev);
+        t.ev = nullptr;
+        if ((e = hipEventCreateWithFlags(&t.ev, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
+        t.dev = dev;
+    }
+    if ((e = hipEventRecord(t.ev, s)) != hipSuccess) return e;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        e = hipEventQuery(t.ev);
+        if (e != hipErrorNotReady) return e;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000 > spin_us) break;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return hipEventSynchronize(t.ev);
 }
 
 static inline int cv_round(float v) { return (int)lrintf(v); }     // cvRound: half-to-even

@@ -218,7 +218,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, d_dp, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     const int32_t* st = (const int32_t*)(D + oSt);
     if (st[0]) { oslam::set_error("extractor arena overflow"); return OSLAM_E_CAPACITY; }
     if (st[1]) { oslam::set_error("keypoint outside the depth image / right extractor arena overflow"); return OSLAM_E_INVALID; }
@@ -412,7 +412,7 @@ int h_search_last(void* p, int n, oslam_job_search_last_t* jobs) {
     OPS_CHECK(o->ensure_dn(R.off));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(3, 2, 0);
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_last_t& j = jobs[i];
@@ -437,7 +437,7 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
         maxM = std::max(maxM, jobs[i].M);
     }
     if (maxM > o->max_local) {   // the reference's local map is unbounded: re-create the matcher with room to spare
-        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         oslam_matcher_destroy(o->m_map);
         o->m_map = nullptr;
         o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
@@ -533,7 +533,7 @@ int h_search_local(void* p, int n, oslam_job_search_local_t* jobs) {
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rKm, d_km, 4 * cap * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNm, d_nm, 4 * S, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rIn, o->d_inview, st * S, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(3, 2, 0);
     o->pool->parallel_for(n, [&](int i) {
         oslam_job_search_local_t& j = jobs[i];
@@ -590,7 +590,7 @@ int h_pose_opt(void* p, int n, oslam_job_pose_t* jobs) {
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rT, d_T, 64 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rO, d_out, cap * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     if (o->timing) {   // 700 flop per edge and linearisation, 90 per edge and trial evaluation
         double flop = 0;
         const int32_t* stt = (const int32_t*)(o->dn_h + rS);
@@ -677,7 +677,7 @@ int h_object_kps(void* p, int n, oslam_job_object_kps_t* jobs) {
     o->t_end();
     OPS_CHECK(o->ensure_dn(cap * S));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, o->d_objbits, cap * S, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(7, 2, 0);
     for (int i = 0; i < n; i++) memcpy(jobs[i].in_mask, o->dn_h + cap * jobs[i].slot, (size_t)jobs[i].cur->N);
     return OSLAM_OK;
@@ -778,7 +778,7 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rN, d_ni, 4 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rS, d_stats, 8 * B, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rNs, d_ns, 4 * B, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     if (o->timing) {
         double flop = 0;
         const int32_t* stt = (const int32_t*)(o->dn_h + rS);
@@ -881,7 +881,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
         OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(Dv + oItems), o->d_mp_tab, (const int32_t*)(Dv + oStart), (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)),
                                               (const float*)(Dv + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
     o->t_end();
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(6, (keyed ? 1 : 0) + (j->do_desc ? 2 : 0) + (j->do_normal ? 1 : 0) + (table ? 1 : 0), (double)dtotal);
     if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
     if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
@@ -969,7 +969,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     o->t_end();
     // descriptor-array table for the observation gathers
     if ((size_t)o->n_rec > o->rec_desc_cap) {
-        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
         o->rec_desc_cap = (size_t)o->n_rec * 2 + 1024;
         OSLAM_HIP_CHECK(hipMalloc((void**)&o->d_rec_desc, o->rec_desc_cap * sizeof(uint8_t*)));
@@ -978,7 +978,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_rec_desc + o->rec_desc_n, o->h_rec_desc.data() + o->rec_desc_n, (size_t)(o->n_rec - o->rec_desc_n) * sizeof(uint8_t*),
                                    hipMemcpyHostToDevice, o->strm));
     o->rec_desc_n = o->n_rec;
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
     o->t_collect(7, 1, 0);
     return OSLAM_OK;
 }
@@ -989,7 +989,7 @@ int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
     if (slot < 0 || slot >= (int)o->mp_tab.size() || id < 0 || (size_t)id >= o->mp_cap[slot]) { oslam::set_error("point_record: no such record"); return OSLAM_E_INVALID; }
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     OSLAM_HIP_CHECK(hipMemcpy(out, o->mp_tab[slot] + (size_t)id * 64, 64, hipMemcpyDeviceToHost));
     return OSLAM_OK;
 }
@@ -1021,7 +1021,7 @@ int h_bow_nodes_keyed(void* p, int n, const int32_t* slots, const int32_t* kf_id
                                      (uint32_t*)(Dv + oOut), o->strm));
     o->t_end();
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, Dv + oOut, 4 * cap * (size_t)n, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(7, 1, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(out[i], o->dn_h + 4 * cap * (size_t)i, 4 * (size_t)counts[i]); });
     return OSLAM_OK;
@@ -1081,7 +1081,7 @@ static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_ke
         maxM = std::max(maxM, jobs[i].M);
     }
     if (maxM > o->max_local) {
-        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         oslam_matcher_destroy(o->m_map);
         o->m_map = nullptr;
         o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
@@ -1131,7 +1131,7 @@ static int fuse_impl(HipOps* o, int n, oslam_job_fuse_t* jobs, const oslam_kf_ke
     OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
     OPS_CHECK(o->ensure_dn(4 * st * B));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(4, 2, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
@@ -1153,7 +1153,7 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         maxM = std::max(maxM, jobs[i].M);
     }
     if (maxM > o->max_local) {
-        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         oslam_matcher_destroy(o->m_map);
         o->m_map = nullptr;
         o->max_local = (int)oslam::align_up((size_t)maxM + maxM / 2, 64);
@@ -1196,7 +1196,7 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
     OPS_CHECK(oslam_match_results_device(o->m_map, &d_qm, nullptr, nullptr, nullptr, nullptr, nullptr));
     OPS_CHECK(o->ensure_dn(4 * st * B));
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h, d_qm, 4 * st * B, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     o->t_collect(4, 3, 0);
     o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
     return OSLAM_OK;
