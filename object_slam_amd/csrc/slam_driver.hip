@@ -703,8 +703,130 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     });
     { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[9] += d_; c.cpu[7] += tm.cpu; c.cpu[9] += tm.cpu; }
 
-    // --- CreateNewMapPoints (:208-453): neighbours in lockstep (the matches of neighbour i see the points created from neighbour i-1) ---
-    if (flags & 2) {
+    // --- CreateNewMapPoints (:208-453) ---
+    // The reference handles the neighbours one after the other, and neighbour i sees the points created from neighbours < i in exactly one way: a keypoint of the
+    // current keyframe that has received a point is skipped (`if(pMP1) continue`, src/ORBmatcher.cc:711-716).  Everything else a neighbour's search and
+    // triangulation read is fixed during the pass: the poses, the neighbour's own map points (a neighbour occurs once, and new points only touch the current
+    // keyframe and THEIR neighbour), and — SearchForTriangulation never sets vbMatched2 — every keypoint of the current keyframe picks its partner independently
+    // of the others.  So ALL neighbours of all sequences are searched and triangulated in ONE batch each from the state before the pass, and the results are
+    // applied in neighbour order with the skip test at application time: the same points in the same order as the reference's loop, with 3 operator calls instead
+    // of 3 per neighbour round.  OSLAM_SLAM_CNMP_ROUNDS=1 keeps the lockstep rounds (A/B: bit-identical runs, tests/test_slam_driver_gpu.py).
+    const bool cnmp_rounds = getenv("OSLAM_SLAM_CNMP_ROUNDS") != nullptr;
+    if ((flags & 2) && !cnmp_rounds) {
+        struct Pair { int w, ni, k2; };
+        std::vector<std::vector<int>> neigh(who.size());
+        std::vector<Pair> pairs;
+        for (size_t w = 0; w < who.size(); w++) {
+            Seq& s = *c.seq[who[w]];
+            const Map::IntSpan bc = s.map.best_covisibles(s.curKF, 10);
+            neigh[w].assign(bc.begin(), bc.end());
+            for (size_t ni = 0; ni < neigh[w].size(); ni++) pairs.push_back({(int)w, (int)ni, neigh[w][ni]});
+        }
+        const int nPairs = (int)pairs.size();
+        std::vector<std::vector<uint8_t>> flag1(who.size());
+        pool.parallel_for(nW, [&](int w) {
+            Seq& s = *c.seq[who[w]];
+            const KeyFrm& k1 = s.map.kfs[s.curKF];
+            flag1[w].resize(k1.N);
+            for (int i = 0; i < k1.N; i++) flag1[w][i] = k1.mp[i] >= 0;
+            (void)s.bow_views(c, s.curKF);   // (built once per keyframe: not from several pair jobs at a time)
+            for (int k2 : neigh[w]) (void)s.bow_views(c, k2);
+        });
+        std::vector<std::vector<uint8_t>> has2(nPairs);
+        std::vector<std::vector<int32_t>> match(nPairs);
+        std::vector<oslam_job_bow_t> cand(nPairs);
+        std::vector<uint8_t> have(nPairs, 0);
+        pool.parallel_for(nPairs, [&](int q) {
+            const Pair& pq = pairs[q];
+            Seq& s = *c.seq[who[pq.w]];
+            Map& m = s.map;
+            const KeyFrm& k1 = m.kfs[s.curKF];
+            KeyFrm& k2 = m.kfs[pq.k2];
+            const float vb[3] = {k2.pose.Ow[0] - k1.pose.Ow[0], k2.pose.Ow[1] - k1.pose.Ow[1], k2.pose.Ow[2] - k1.pose.Ow[2]};
+            if (norm3(vb) < c.mb) return;   // :251-254
+            oslam_job_bow_t& j = cand[q];
+            memset(&j, 0, sizeof(j));
+            compute_F12(c, k1, k2, j.F12);
+            // epipole of camera 1 in image 2 (src/ORBmatcher.cc:663-670)
+            float C2[3];
+            for (int r = 0; r < 3; r++) {
+                float sacc = k2.pose.Tcw.m[r * 4] * k1.pose.Ow[0];
+                sacc += k2.pose.Tcw.m[r * 4 + 1] * k1.pose.Ow[1];
+                sacc += k2.pose.Tcw.m[r * 4 + 2] * k1.pose.Ow[2];
+                C2[r] = (float)((double)sacc + (double)k2.pose.Tcw.m[r * 4 + 3]);
+            }
+            const float invz = 1.0f / C2[2];
+            j.ex = c.cfg.fx * C2[0] * invz + c.cfg.cx; j.ey = c.cfg.fy * C2[1] * invz + c.cfg.cy;
+            const BowViews& v1 = s.bow_views(c, s.curKF);
+            const BowViews& v2 = s.bow_views(c, pq.k2);
+            has2[q].resize(k2.N);
+            for (int i = 0; i < k2.N; i++) has2[q][i] = k2.mp[i] >= 0;
+            match[q].assign(k1.N, -1);
+            j.s1.N = k1.N; j.s1.keys = k1.keysUn.data(); j.s1.desc = k1.desc.data(); j.s1.uRight = k1.uRight.data(); j.s1.flag = flag1[pq.w].data();
+            j.s1.nq = k1.N; j.s1.q_idx = v1.q_idx.data(); j.s1.q_node = v1.q_node.data();
+            j.s2.N = k2.N; j.s2.keys = k2.keysUn.data(); j.s2.desc = k2.desc.data(); j.s2.uRight = k2.uRight.data(); j.s2.has_mp = has2[q].data();
+            j.s2.nNodes = (int)v2.nodes.size(); j.s2.nodes = v2.nodes.data(); j.s2.start = v2.start.data(); j.s2.items = v2.items.data();
+            j.triangulation = 1; j.nnratio = 0.6f; j.checkOri = 0; j.match = match[q].data();
+            have[q] = 1;
+        });
+        std::vector<oslam_job_bow_t> bj;
+        std::vector<int> bjq;
+        std::vector<oslam_kf_key_t> bkey;
+        for (int q = 0; q < nPairs; q++)
+            if (have[q]) { bj.push_back(cand[q]); bjq.push_back(q); bkey.push_back({who[pairs[q].w], c.seq[who[pairs[q].w]]->curKF, pairs[q].k2}); }
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; c.cpu[7] += tm.cpu; c.cpu[10] += tm.cpu; }
+        if (!bj.empty()) {
+            if ((rc = c.ops.bow_keyed ? c.ops.bow_keyed(c.ops.ctx, (int)bj.size(), bj.data(), bkey.data()) : c.ops.bow(c.ops.ctx, (int)bj.size(), bj.data()))) return rc;
+            const int nJ = (int)bj.size();
+            std::vector<oslam_job_triangulate_t> tj(nJ);
+            std::vector<std::vector<int32_t>> i1(nJ), i2(nJ);
+            std::vector<std::vector<uint8_t>> okv(nJ);
+            std::vector<std::vector<float>> x3(nJ);
+            pool.parallel_for(nJ, [&](int jq) {
+                const int q = bjq[jq];
+                Seq& s = *c.seq[who[pairs[q].w]];
+                const KeyFrm& k1 = s.map.kfs[s.curKF];
+                // vMatchedIndices order (:815-820): ascending index of keyframe 1
+                for (int i = 0; i < k1.N; i++) if (match[q][i] >= 0) { i1[jq].push_back(i); i2[jq].push_back(match[q][i]); }
+                oslam_job_triangulate_t& t = tj[jq];
+                fill_tri_kf(c, k1, t.kf1); fill_tri_kf(c, s.map.kfs[pairs[q].k2], t.kf2);
+                t.M = (int)i1[jq].size(); t.idx1 = i1[jq].data(); t.idx2 = i2[jq].data();
+                okv[jq].assign(t.M + 1, 0); x3[jq].assign((size_t)t.M * 3 + 3, 0.f);
+                t.ok = okv[jq].data(); t.x3D = x3[jq].data();
+            });
+            if ((rc = c.ops.triangulate(c.ops.ctx, nJ, tj.data()))) return rc;
+            { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
+            // application in neighbour order per sequence (the jobs of a sequence are consecutive and in neighbour order)
+            std::vector<int> first(who.size() + 1, 0);
+            for (int jq = 0; jq < nJ; jq++) first[pairs[bjq[jq]].w + 1]++;
+            for (size_t w = 0; w < who.size(); w++) first[w + 1] += first[w];
+            pool.parallel_for(nW, [&](int w) {
+                Seq& s = *c.seq[who[w]];
+                Map& m = s.map;
+                for (int jq = first[w]; jq < first[w + 1]; jq++) {
+                    const int k2 = pairs[bjq[jq]].k2;
+                    for (int e = 0; e < tj[jq].M; e++) {
+                        if (!okv[jq][e]) continue;
+                        if (m.kfs[s.curKF].mp[i1[jq][e]] >= 0) continue;   // the keypoint received a point from an earlier neighbour: the reference's search skipped it
+                        const int p = m.new_point(&x3[jq][(size_t)e * 3], s.curKF, m.kfs[s.curKF].frameId);   // :408-430
+                        m.add_observation(p, s.curKF, i1[jq][e]);
+                        m.add_observation(p, k2, i2[jq][e]);
+                        m.kfs[s.curKF].mp[i1[jq][e]] = p;
+                        m.kfs[k2].mp[i2[jq][e]] = p;
+                        m.nMPsInMap++; s.st[3]++; s.st[10]++;
+                        s.recentAdded.push_back(p);
+                        s.updList.push_back(p);
+                    }
+                }
+            });
+            merge_upd();
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[10] += d_; c.cpu[7] += tm.cpu; c.cpu[10] += tm.cpu; }
+            if ((rc = upd.run(c, true, true))) return rc;
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+        }
+    }
+    // the same in lockstep rounds (round i = neighbour i of every sequence; the matches of neighbour i see the points created from neighbour i-1): A/B form
+    if ((flags & 2) && cnmp_rounds) {
         std::vector<std::vector<int>> neigh(who.size());
         size_t maxn = 0;
         for (size_t w = 0; w < who.size(); w++) {

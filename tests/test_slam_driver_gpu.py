@@ -351,6 +351,24 @@ def test_resident_local_maps_and_keyframes_leave_the_run_unchanged(monkeypatch):
     assert a.stats(0) == b.stats(0) and a.stats(1) == b.stats(1)
 
 
+def test_create_new_map_points_in_one_batch_equals_the_neighbour_rounds(monkeypatch):
+    """LocalMapping::CreateNewMapPoints searches and triangulates ALL neighbours of a keyframe in one batch from the state before the pass and applies the results
+    in neighbour order with the reference's skip test (a keypoint that has received a point) at application time; OSLAM_SLAM_CNMP_ROUNDS=1 keeps one lockstep round
+    per neighbour.  Both give the same points in the same order: bit-identical poses and statistics over a run that triangulates."""
+    from slam_common import make_scene_streams, run_scene
+    n, S = 40, 2
+    seqs = make_scene_streams(S, n)
+    a = slam.System(slam.make_config(W, H, S))
+    pa, sa = run_scene(a, seqs, n)
+    monkeypatch.setenv("OSLAM_SLAM_CNMP_ROUNDS", "1")
+    b = slam.System(slam.make_config(W, H, S))
+    pb, sb = run_scene(b, seqs, n)
+    assert np.array_equal(sa, sb) and np.array_equal(pa, pb)
+    for q in range(S):
+        st = a.stats(q)
+        assert st == b.stats(q) and st["points_triangulated"] > 50, st
+
+
 def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle):
     """Soak at the S1 specification: 200 frames at speed 1 (<= 2 cm, <= 0.5 deg per frame) with the three instance masks; the HIP and
     the oracle operator tables must lead the driver through the same 200 frames (states, map statistics, object bookkeeping), ATE below 2 cm."""
