@@ -201,7 +201,8 @@ struct oslam_bow {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     Buf q_idx1, q_node, keys1, desc1, ur1, flag1, keys2, desc2, ur2, mp2, nodes, start, items, out, qbest, nm;
     uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;   // batch staging: pinned block mirrored on the device
-    hipStream_t strm = nullptr;   // the batch form runs on the handle's own non-blocking stream (created on first use)
+    hipStream_t strm = nullptr;   // the batch form runs on the handle's own non-blocking stream (created on first use) or on the stream given by bow_use_stream
+    bool owns_strm = true;
     // device time of the batch kernel (bench.py's kernel-time groups): HIP events on `strm`
     int timing = 0; hipEvent_t ev0 = nullptr, ev1 = nullptr; double kern_ms = 0; long long kern_n = 0;
 };
@@ -243,9 +244,19 @@ void oslam_bow_destroy(oslam_bow_t* h) {
         if (b->p) (void)hipFree(b->p);
     if (h->st_h) (void)hipHostFree(h->st_h);
     if (h->st_d) (void)hipFree(h->st_d);
-    if (h->strm) (void)hipStreamDestroy(h->strm);
+    if (h->strm && h->owns_strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
+
+extern "C++" {
+namespace oslam {
+void bow_use_stream(oslam_bow* h, hipStream_t s) {
+    if (!h || !s) return;
+    if (h->strm && h->owns_strm) (void)hipStreamDestroy(h->strm);
+    h->strm = s; h->owns_strm = false;
+}
+}  // namespace oslam
+}  // extern "C++"
 
 int oslam_bow_create(oslam_bow_t** out, int max_keypoints, int device) {
     if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }

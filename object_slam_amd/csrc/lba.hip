@@ -1542,6 +1542,7 @@ struct oslam_lba {
     uint8_t* out_h = nullptr; size_t out_h_cap = 0;
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
+    bool owns_strm = true;        // false: the stream of the driver handle this solver belongs to (lba_use_stream)
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
@@ -1678,9 +1679,19 @@ void oslam_lba_destroy(oslam_lba_t* h) {
     if (h->out_h) (void)hipHostFree(h->out_h);
     if (h->h_ctrl) (void)hipHostFree(h->h_ctrl);
     if (h->h_stop) (void)hipHostFree(h->h_stop);
-    if (h->strm) (void)hipStreamDestroy(h->strm);
+    if (h->strm && h->owns_strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
+
+extern "C++" {
+namespace oslam {
+void lba_use_stream(oslam_lba* h, hipStream_t s) {
+    if (!h || !s) return;
+    if (h->strm && h->owns_strm) { (void)hipStreamSynchronize(h->strm); (void)hipStreamDestroy(h->strm); }
+    h->strm = s; h->owns_strm = false;
+}
+}  // namespace oslam
+}  // extern "C++"
 
 // max_batch = windows per call; max_keyframes (<= 128) = keyframes per window; max_points / max_edges only size the first reservation: the
 // arenas grow with the problems (reference g2o has no such bounds).
@@ -2228,7 +2239,7 @@ static int lba_launch(oslam_lba_t* h) {
                 hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n0), dim3(kWPt), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
-            OSLAM_HIP_CHECK(hipMemcpyAsync(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, hipMemcpyDeviceToHost, st));
+            OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
             OSLAM_HIP_CHECK(stream_wait(st));
             bool all_done = true;
             for (int i = 0; i < n0; i++) all_done = all_done && h->h_ctrl[i].done != 0;
@@ -2240,7 +2251,7 @@ static int lba_launch(oslam_lba_t* h) {
     }
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(hipMemcpyAsync(h->out_h, O, outb, hipMemcpyDeviceToHost, st));   // the ONE download
+    OSLAM_HIP_CHECK(copy_to_host_async(h->out_h, O, outb, st));   // the ONE download
     OSLAM_HIP_CHECK(stream_wait(st));
     lba_time_collect(h, launches);
     return OSLAM_OK;

@@ -201,6 +201,7 @@ struct oslam_mappoint {
     // batch form (oslam_mp_triangulate_pairs): one pinned block mirrored on the device, one stream — ONE upload, one launch, ONE download per call
     uint8_t* st_h = nullptr; uint8_t* st_d = nullptr; size_t st_cap = 0;
     hipStream_t strm = nullptr;
+    bool owns_strm = true;
     int timing = 0; hipEvent_t ev0 = nullptr, ev1 = nullptr; double kern_ms = 0; long long kern_n = 0;   // device time of the batched triangulation kernel
 };
 
@@ -240,9 +241,19 @@ void oslam_mappoint_destroy(oslam_mappoint_t* h) {
         if (b->p) (void)hipFree(b->p);
     if (h->st_h) (void)hipHostFree(h->st_h);
     if (h->st_d) (void)hipFree(h->st_d);
-    if (h->strm) (void)hipStreamDestroy(h->strm);
+    if (h->strm && h->owns_strm) (void)hipStreamDestroy(h->strm);
     delete h;
 }
+
+extern "C++" {
+namespace oslam {
+void mappoint_use_stream(oslam_mappoint* h, hipStream_t s) {
+    if (!h || !s) return;
+    if (h->strm && h->owns_strm) (void)hipStreamDestroy(h->strm);
+    h->strm = s; h->owns_strm = false;
+}
+}  // namespace oslam
+}  // extern "C++"
 
 int oslam_mappoint_create(oslam_mappoint_t** out, int device) {
     if (!out) { set_error("out is NULL"); return OSLAM_E_INVALID; }

@@ -25,6 +25,15 @@ void set_error(const char* fmt, ...) {
 // see common.h: poll briefly, then sleep on a blocking event (one event per host thread and device)
 hipError_t stream_wait(hipStream_t s) {
     static const int spin_us = [] { const char* e = getenv("OSLAM_WAIT_SPIN_US"); return e ? atoi(e) : -1; }();
+    if (spin_us == -2) {   // pure poll of the stream (never sleeps on the interrupt path)
+        for (;;) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q != hipErrorNotReady) return q;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
     if (spin_us < 0) return hipStreamSynchronize(s);
     struct Ev { hipEvent_t ev = nullptr; int dev = -1; };
     static thread_local Ev t;

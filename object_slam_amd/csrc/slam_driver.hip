@@ -197,6 +197,7 @@ struct Ctx {
     double sec[16] = {0};
     double cpu[16] = {0};   // core-seconds of the same stages (host thread + workers)
     CpuAccount acct;
+    int shard = 0;   // worker set of this handle (slam_pool.h)
     struct Win {   // one local-BA window (run_local_mapping)
         int si = -1, nLocal = 0;
         std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
@@ -1537,6 +1538,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                       int on_device, const double* stamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out,
                       const uint16_t* const* depth16 = nullptr, float depth_factor = 1.f) {
     const int S = c.S;
+    oslam_drv::ShardScope shard_scope(c.shard);   // library code below the operator table (local-BA preparation, BoW views) uses this handle's worker set
     AccountScope acct_scope(&c.acct);   // the workers bill the tasks of this thread's batches (driver and operator table) to this handle; unbound again on every return
     c.acct.worker_ns.store(0, std::memory_order_relaxed);
     Timer tm;
@@ -1846,7 +1848,8 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
     c.maxFrames = (int)cfg->fps; c.minFrames = 0;
     c.stereo = cfg->sensor == 1;
     c.residentPts = c.ops.resident_points && c.ops.resident_points(c.ops.ctx) != 0;
-    c.pool.reset(new Pool(cfg->host_threads > 1 ? cfg->host_threads : 1));
+    c.shard = oslam_drv::next_pool_shard();
+    c.pool.reset(new Pool(cfg->host_threads > 1 ? cfg->host_threads : 1, true, c.shard));
     for (int i = 0; i < c.S; i++) {
         c.seq.emplace_back(new Seq);
         c.seq.back()->fa.alloc(c.cap);

@@ -1285,6 +1285,12 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (!rc) rc = oslam_mappoint_create(&o->mp, dev);
     if (!rc) rc = oslam_frame_create(&o->fr, dev);
     if (!rc) rc = oslam_bow_create(&o->bow, o->cap, dev);
+    // One stream per driver handle: the operators run one after the other on the handle's thread, so the solvers and batch matchers use o->strm instead of
+    // a stream each (OSLAM_SLAM_OWN_STREAMS=1 restores the separate streams: an A/B knob).
+    if (!rc && o->strm && !getenv("OSLAM_SLAM_OWN_STREAMS")) {
+        oslam::lba_use_stream(o->ba, o->strm); oslam::lba_use_stream(o->ba1, o->strm);
+        oslam::bow_use_stream(o->bow, o->strm); oslam::mappoint_use_stream(o->mp, o->strm);
+    }
     if (!rc) rc = oslam_orb_get_scale_tables(o->orb, o->scale, o->invScale, o->sigma2, o->invSigma2, nullptr);
     o->K4[0] = cfg->fx; o->K4[1] = cfg->fy; o->K4[2] = cfg->cx; o->K4[3] = cfg->cy;
     memcpy(o->K5, o->K4, 16); o->K5[4] = cfg->bf;

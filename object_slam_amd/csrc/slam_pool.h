@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <stdlib.h>
 #include <thread>
 #include <time.h>
 #include <vector>
@@ -46,9 +47,12 @@ public:
         CpuAccount* acct = nullptr;  // owner's account (may be null)
         std::atomic<int> users{0};   // workers inside work() for this batch (incremented under the pool mutex): the owner may not leave before they have
     };
-    static SharedWorkers& instance() {
-        static SharedWorkers* s = new SharedWorkers;   // never destroyed: the detached workers may outlive static destructors
-        return *s;
+    // The workers are kept in kMaxShards independent sets (own mutex, queue and threads): the handles of a process are dealt to the sets round robin
+    // (pool_shards() of them are in use), so that the ~100 short parallel_for calls per step of many handles do not all meet on one mutex.
+    static constexpr int kMaxShards = 16;
+    static SharedWorkers& instance(int shard = 0) {
+        static SharedWorkers* s = new SharedWorkers[kMaxShards];   // never destroyed: the detached workers may outlive static destructors
+        return s[shard < 0 ? 0 : shard % kMaxShards];
     }
     // A Pool asks for k workers while it lives: the set grows to the largest total ever asked for; workers beyond the CURRENT total park, so a later
     // run with fewer or smaller pools does not inherit the thread count of an earlier one.
@@ -150,26 +154,43 @@ private:
     int nthreads_ = 0, wanted_ = 0;
 };
 
+// number of worker sets in use (OSLAM_POOL_SHARDS, default 1 = one process-wide set) and the set of the handle the calling thread is stepping
+inline int pool_shards() {
+    static const int n = [] { const char* e = getenv("OSLAM_POOL_SHARDS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > SharedWorkers::kMaxShards ? SharedWorkers::kMaxShards : v); }();
+    return n;
+}
+inline int next_pool_shard() { static std::atomic<int> c{0}; return c.fetch_add(1) % pool_shards(); }
+inline int& thread_shard() { static thread_local int s = 0; return s; }
+struct ShardScope {
+    int prev;
+    explicit ShardScope(int s) : prev(thread_shard()) { thread_shard() = s; }
+    ~ShardScope() { thread_shard() = prev; }
+    ShardScope(const ShardScope&) = delete;
+    ShardScope& operator=(const ShardScope&) = delete;
+};
+
 // parallel_for on the shared workers for library code that has no Pool of its own (runs on the caller alone when no driver handle has added workers)
 template <class F>
 inline void shared_parallel_for(int n, F&& fn) {
     if (n <= 0) return;
-    if (n == 1 || SharedWorkers::instance().threads() == 0) { for (int i = 0; i < n; i++) fn(i); return; }
+    SharedWorkers& w = SharedWorkers::instance(thread_shard());
+    if (n == 1 || w.threads() == 0) { for (int i = 0; i < n; i++) fn(i); return; }
     std::function<void(int)> f = std::ref(fn);
     SharedWorkers::Batch b;
     b.fn = &f; b.n = n;
-    SharedWorkers::instance().run(b);
+    w.run(b);
 }
 
 class Pool {
 public:
     // own_workers = false: use the shared workers without asking for more (the operator table of a handle runs on the handle's thread, between the
     // driver's own parallel sections: the two never need workers at the same time)
-    explicit Pool(int threads, bool own_workers = true) : threads_(threads < 1 ? 1 : threads), own_(own_workers) {
-        if (threads_ > 1 && own_) SharedWorkers::instance().add_workers(threads_ - 1);
+    // shard >= 0: the worker set of this pool; -1: the set of whichever handle the calling thread is stepping (thread_shard())
+    explicit Pool(int threads, bool own_workers = true, int shard = -1) : threads_(threads < 1 ? 1 : threads), own_(own_workers), shard_(shard) {
+        if (threads_ > 1 && own_) SharedWorkers::instance(shard_).add_workers(threads_ - 1);
     }
     ~Pool() {
-        if (threads_ > 1 && own_) SharedWorkers::instance().remove_workers(threads_ - 1);
+        if (threads_ > 1 && own_) SharedWorkers::instance(shard_).remove_workers(threads_ - 1);
     }
     Pool(const Pool&) = delete;
     Pool& operator=(const Pool&) = delete;
@@ -182,12 +203,13 @@ public:
         std::function<void(int)> f = std::ref(fn);
         SharedWorkers::Batch b;
         b.fn = &f; b.n = n;
-        SharedWorkers::instance().run(b);
+        SharedWorkers::instance(shard_ >= 0 ? shard_ : thread_shard()).run(b);
     }
 
 private:
     int threads_;
     bool own_;
+    int shard_;
 };
 
 }  // namespace oslam_drv
