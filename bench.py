@@ -394,9 +394,21 @@ def main():
     kt = {}
 
     def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None):
+        snap = {}
+
+        def stage_totals(systems):
+            st, co = {}, {}
+            for sy in systems:
+                for k, v in sy.stage_seconds().items():
+                    st[k] = st.get(k, 0.0) + v
+                for k, v in sy.stage_seconds(cpu=True).items():
+                    co[k] = co.get(k, 0.0) + v
+            return st, co
+
         def reset_timers(systems):
             for sy in systems:
                 sy.kernel_times(True)
+            snap["t0"] = stage_totals(systems)
         threads = int(os.environ.get("OSLAM_BENCH_HOST_THREADS", "0")) or max(1, share // G_)
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
                                                       host_threads=threads, sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl",
@@ -410,14 +422,15 @@ def main():
                     for k in v:
                         a[k] += v[k]
         kt[tag] = tot
-        stages, cores_s = {}, {}
-        for sy in systems:
-            for k, v in sy.stage_seconds().items():
-                stages[k] = stages.get(k, 0.0) + v
-            for k, v in sy.stage_seconds(cpu=True).items():
-                cores_s[k] = cores_s.get(k, 0.0) + v
+        stages, cores_s = stage_totals(systems)
         summ["stage_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in stages.items()}
         summ["stage_core_seconds_sum_over_handles"] = {k: round(v, 4) for k, v in cores_s.items()}
+        # the same sums over the TIMED steps only (the totals above include the pre-roll, the warm-up and any later leg)
+        t1 = extra.get("post", {}).get("stages_timed_end") if isinstance(extra.get("post"), dict) else None
+        t1 = t1 or (stages, cores_s)
+        if "t0" in snap:
+            summ["stage_seconds_timed_sum_over_handles"] = {k: round(t1[0][k] - snap["t0"][0].get(k, 0.0), 4) for k in t1[0]}
+            summ["stage_core_seconds_timed_sum_over_handles"] = {k: round(t1[1][k] - snap["t0"][1].get(k, 0.0), 4) for k in t1[1]}
         reuse = [sy.local_map_reuse() for sy in systems]
         summ["local_map_reuse_frac"] = round(sum(r[0] for r in reuse) / max(1, sum(r[1] for r in reuse)), 4)
         summ["host_threads_per_handle"] = threads
@@ -436,7 +449,13 @@ def main():
                 a = ktm.setdefault(g, dict(ms=0.0, launches=0.0, work=0.0))
                 for k in v:
                     a[k] += v[k]
-        out = {"kernel_times_timed": ktm}
+        st_end, co_end = {}, {}
+        for sy in systems:
+            for k, v in sy.stage_seconds().items():
+                st_end[k] = st_end.get(k, 0.0) + v
+            for k, v in sy.stage_seconds(cpu=True).items():
+                co_end[k] = co_end.get(k, 0.0) + v
+        out = {"kernel_times_timed": ktm, "stages_timed_end": (st_end, co_end)}
         try:
             hc, nbytes = seqbench.host_input_calls(ctx, n_frames - post_frames, post_frames)
             t0 = n_frames - post_frames
@@ -506,6 +525,8 @@ def main():
                "map_violations": summ["map_violations"], "semantic_edges": summ["semantic_edges"],
                "stage_seconds_sum_over_handles": summ["stage_seconds_sum_over_handles"],
                "stage_core_seconds_sum_over_handles": summ["stage_core_seconds_sum_over_handles"],
+               "stage_seconds_timed_sum_over_handles": summ.get("stage_seconds_timed_sum_over_handles"),
+               "stage_core_seconds_timed_sum_over_handles": summ.get("stage_core_seconds_timed_sum_over_handles"),
                "local_map_reuse_frac": summ["local_map_reuse_frac"],
                "per_rank": [{"rank": int(r[0]), "frames": int(r[2]), "elapsed_s": round(float(r[3]), 4), "local_bas": int(r[5]), "ate_rmse_m": round(float(r[7]), 6)} for r in rec],
                "roofline": roof, "cpu_baseline": cpu,

@@ -478,6 +478,19 @@ int oslam_pose_inputs_gather_device(int batch, int stride, const int32_t* d_slot
 int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl, uint8_t* const* d_tab,
                               const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
                               const float* scaleFactors, int nLevels, oslam_proj_query_t* d_q, void* stream);
+/* Fuse against RESIDENT keyframes.  KeyFrame::mGrid is fixed at construction (src/KeyFrame.cc:44-52), so the grid of a registered keyframe is built ONCE:
+ * oslam_kf_grid_build_device sorts the keypoints of job i (the d_counts[slot] keypoints at `keys` / `uRight`) by cell — cells in the (x, y) nesting of
+ * Frame::mGrid, index order inside a cell (src/Frame.cc:455-470) — into cell_end[3072] (end of every cell in the sorted list) and cand[N][4] =
+ * (x, y, uRight, bit pattern of octave << 16 | keypoint index).  *d_status is set to 1 if a count exceeds max_keypoints (never truncated silently).
+ * oslam_fuse_search_device = oslam_fuse_queries_device + the window search of ORBmatcher::Fuse (src/ORBmatcher.cc:890-947: GetFeaturesInArea, level gate,
+ * chi2 gates, best Hamming distance <= TH_LOW) with one candidate per thread, straight from those arrays: d_q_match[b][i] = keypoint index or -1, the same
+ * values oslam_match_fuse_batch_device returns for the queries of oslam_fuse_queries_device (tests/test_mp_table_gpu.py). */
+typedef struct oslam_kf_grid_job { const oslam_keypoint_t* keys; const float* uRight; uint16_t* cell_end; float* cand; int32_t slot; int32_t pad_; } oslam_kf_grid_job_t;
+typedef struct oslam_kf_grid_ref { const uint16_t* cell_end; const float* cand; const uint8_t* desc; } oslam_kf_grid_ref_t;
+int oslam_kf_grid_build_device(int n, const oslam_kf_grid_job_t* d_jobs, const int32_t* d_counts, const float bounds[4], int max_keypoints, int32_t* d_status, void* stream);
+int oslam_fuse_search_device(int n, int stride, const oslam_kf_grid_ref_t* d_kfs, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl,
+                             uint8_t* const* d_tab, const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
+                             const float* scaleFactors, const float* invLevelSigma2, int nLevels, int32_t* d_q_match, void* stream);
 /* The arrays of Tracking::SearchLocalPoints for n frames from the resident records: job i = {slot, M, byte offset of its ids (int32 [M]) and of its
  * Observations() > 0 flags (uint8 [M]) inside d_stage}; writes position, normal, distances, flags and descriptor of every point into the [.][stride] arrays
  * at row `slot` (the layout oslam_frame_is_in_frustum_batch_resident_device reads). */

@@ -18,6 +18,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <array>
 #include <vector>
 
@@ -856,13 +860,30 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
 // Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
 // wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
 // rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
-__global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws) {
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
+// Workgroups are dispatched to the 8 XCDs round robin in linear block order, and every XCD has its own 4 MB L2.  The per-window kernels below map
+// (window, item) so that ALL workgroups of a window run on ONE XCD (window w -> XCD w mod 8; the windows of an XCD one after the other): the window's per-edge
+// blocks (B_e, W_e: 288 B per edge, read once per pair they take part in) then come out of that XCD's L2 instead of being pulled into all eight.
+// Launch grid: dim3(items per window, windows rounded up to a multiple of 8).
+// Calls with fewer than 8 windows keep the plain mapping (window = blockIdx.y: a window's workgroups spread over all XCDs), signalled by gridDim.y == nwin.
+__device__ __forceinline__ bool xcd_window_item(int nwin, int& win, int& item) {
+    if ((int)gridDim.y == nwin && (nwin & 7)) { win = blockIdx.y; item = blockIdx.x; return true; }
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, j = L >> 3;
+    const int grp = j / (int)gridDim.x;
+    item = j - grp * (int)gridDim.x;
+    win = grp * 8 + xcd;
+    return win < nwin;
+}
+
+__global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    int win, t;
+    if (!xcd_window_item(nwin, win, t)) return;
+    const LbaProblem& pr = probs[win];
+    const LbaWide& w = ws[win];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int nfree = ct->nfree, n = ct->n, ld = n + 1;
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     if (t >= nfree * (nfree + 1) / 2) return;
     const double lambda = ct->lambda;
     int ba = 0, rem = t;
@@ -894,27 +915,33 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
             for (int j = 0; j < 6; j++)
                 acc[i * 6 + j] += BD[i * 3] * B2[j * 3] + BD[i * 3 + 1] * B2[j * 3 + 1] + BD[i * 3 + 2] * B2[j * 3 + 2];
     }
+    // Sum of the 64 lanes' partial blocks through LDS: lane l stores its 36 (+6) partials as column l of a [42][65] array (rows skewed by one double: the
+    // row-wise reads below are bank-conflict free), then lane i < 42 adds row i in lane order with four running sums.  (36 butterfly reductions by
+    // ds_bpermute moved ~6x the bytes through the LDS crossbar.)
+    __shared__ double red[42 * 65];
 #pragma unroll
-    for (int i = 0; i < 36; i++) acc[i] = wsum(acc[i]);
+    for (int i = 0; i < 36; i++) red[i * 65 + lane] = acc[i];
     if (diag) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) bsv[i] = wsum(bsv[i]);
+        for (int i = 0; i < 6; i++) red[(36 + i) * 65 + lane] = bsv[i];
     }
-    // lanes 0..35 write one entry each (36 stores in parallel instead of a serial loop on lane 0)
+    __syncthreads();
     double mine = 0;
+    if (lane < (diag ? 42 : 36)) {
+        const double* row = red + lane * 65;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-    for (int i = 0; i < 36; i++) mine = lane == i ? acc[i] : mine;
-    if (lane < 36) {
+        for (int k = 0; k < 64; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
+        mine = (s0 + s1) + (s2 + s3);
+    }
+    if (lane < 36) {   // lanes 0..35 write one entry each
         const int i = lane / 6, j = lane - i * 6;
         double v = -mine;
         if (diag) v += pr.Hpp[a * 36 + lane] + (i == j ? lambda : 0.0);
         pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
-    }
-    if (diag) {
-        double bm = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) bm = lane == i ? bsv[i] : bm;
-        if (lane < 6) pr.Hs[(size_t)(6 * ba + lane) * ld + n] = pr.bp[a * 6 + lane] - bm;
+    } else if (diag && lane < 42) {
+        const int i = lane - 36;
+        pr.Hs[(size_t)(6 * ba + i) * ld + n] = pr.bp[a * 6 + i] - mine;
     }
 }
 
@@ -1543,6 +1570,7 @@ struct oslam_lba {
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
     bool owns_strm = true;        // false: the stream of the driver handle this solver belongs to (lba_use_stream)
+    long long prof_pre_upload_ns = 0;   // host time of the last lba_launch before its upload (OSLAM_LBA_HOSTPROF)
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
@@ -2054,6 +2082,7 @@ static int lba_prepare_all(oslam_lba_t* h, int n, const LbaArgs* a, const float 
 // Layout-1 windows: ONE launch of k_lba_win, one workgroup per window (largest first).  Layout-0 windows: compact mode = one launch of k_lba; wide mode =
 // every LM trial as eight launches whose grids cover all of them (blockIdx.y = window, blockIdx.x sized for the largest one; finished windows return at once).
 static int lba_launch(oslam_lba_t* h) {
+    const auto t_launch0 = std::chrono::steady_clock::now();
     const int n = h->n_prep;
     OSLAM_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = h->strm;
@@ -2193,6 +2222,17 @@ static int lba_launch(oslam_lba_t* h) {
     }
     std::sort(cost.begin(), cost.end());   // the most expensive windows are dispatched first
     for (int j = 0; j < n1; j++) horder[j] = cost[j].second;
+    // OSLAM_LBA_CONCURRENCY=k: at most k local-BA calls of this process have device work in flight at a time (A/B knob: two overlapping calls both take about
+    // twice as long, one after the other the first is back after half of that)
+    struct Gate {
+        std::mutex m; std::condition_variable cv; int free_slots;
+        explicit Gate(int k) : free_slots(k) {}
+        void enter() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return free_slots > 0; }); free_slots--; }
+        void leave() { { std::lock_guard<std::mutex> lk(m); free_slots++; } cv.notify_one(); }
+    };
+    static Gate* gate = [] { const char* e = getenv("OSLAM_LBA_CONCURRENCY"); const int k = e ? atoi(e) : 0; return k > 0 ? new Gate(k) : (Gate*)nullptr; }();
+    struct GateScope { Gate* g; explicit GateScope(Gate* g_) : g(g_) { if (g) g->enter(); } ~GateScope() { if (g) g->leave(); } } gate_scope(gate);
+    h->prof_pre_upload_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch0).count();
     OSLAM_HIP_CHECK(hipMemcpyAsync(I, h->in_h, h->in_off, hipMemcpyHostToDevice, st));   // the ONE upload
     const LbaProblem* d_probs = (const LbaProblem*)(I + o_probs);
     const LbaWide* d_ws = (const LbaWide*)(I + o_ws);
@@ -2218,6 +2258,7 @@ static int lba_launch(oslam_lba_t* h) {
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
         // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
         // iteration), so the common case needs a single host round trip; rejected steps add groups of 4.
+        const int ny_xcd = n0 >= 8 ? (n0 + 7) / 8 * 8 : n0;   // grid rows of the kernels that map a window to one XCD (xcd_window_item)
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
@@ -2228,7 +2269,7 @@ static int lba_launch(oslam_lba_t* h) {
                     hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
                 } else {
                     hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n0), dim3(256), 0, st, d_probs, d_ws);
-                    hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, n0), dim3(64), 0, st, d_probs, d_ws);
+                    hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
                 }
                 if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);
                 if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n0), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws, mfma_min_n);
@@ -2303,11 +2344,35 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
         const oslam_lba_problem_t& q = probs[i];
         a[i] = {q.nKF, q.poses, q.fixed, q.nP, q.points, q.nE, q.edge_kf, q.edge_pt, q.edge_obs, q.edge_invSigma2, q.poses_out, q.points_out, q.erase};
     }
+    // OSLAM_LBA_HOSTPROF=1: wall-clock split of the batch call (preparation / launch incl. the wait for the device / scatter of the results), printed at exit
+    struct HostProf {
+        std::atomic<long long> ns[4]; std::atomic<long long> calls{0}, windows{0};
+        HostProf() { for (auto& x : ns) x = 0; }
+        ~HostProf() {
+            if (calls.load()) fprintf(stderr, "[lba hostprof] %lld calls, %lld windows: prepare %.1f ms, launch+wait %.1f ms (of it before the upload %.1f ms), fetch %.1f ms\n", calls.load(),
+                                      windows.load(), ns[0] * 1e-6, ns[1] * 1e-6, ns[3] * 1e-6, ns[2] * 1e-6);
+        }
+    };
+    static HostProf* prof = getenv("OSLAM_LBA_HOSTPROF") ? new HostProf : nullptr;
+    static struct AtExit { ~AtExit() { delete prof; } } at_exit;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
     int rc = lba_prepare_all(h, n, a.data(), K5, 0, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
     if (rc) return rc;
+    auto t1 = now();
+    h->prof_pre_upload_ns = 0;
     rc = lba_launch(h);
     if (rc) return rc;
+    auto t2 = now();
     for (int i = 0; i < n; i++) lba_fetch(h, i, probs[i].poses_out, probs[i].points_out, probs[i].erase, probs[i].stats);
+    if (prof) {
+        auto t3 = now();
+        prof->ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+        prof->ns[1] += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+        prof->ns[2] += std::chrono::duration_cast<std::chrono::nanoseconds>(t3 - t2).count();
+        prof->ns[3] += h->prof_pre_upload_ns;
+        prof->calls++; prof->windows += n;
+    }
     return OSLAM_OK;
 }
 

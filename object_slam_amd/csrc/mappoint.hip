@@ -318,7 +318,37 @@ __global__ __launch_bounds__(256) void k_mp_table_gather(int stride, const int32
 }
 
 struct FuseQCtx { float fx, fy, cx, cy, bf, minX, minY, maxX, maxY, th, logScale; float scale[OSLAM_MAX_LEVELS]; int nLevels; };
-// one thread per candidate; the arithmetic is the driver's fuse_queries (the host form the oracle table receives), operator by operator
+// The projection gates of ORBmatcher::Fuse (src/ORBmatcher.cc:840-890) for one candidate record r = (pos[3], normal[3], minD, maxD, desc); the arithmetic is the
+// driver's fuse_queries (the host form the oracle table receives), operator by operator.  Returns false when a gate rejects the candidate.
+__device__ __forceinline__ bool fuse_gates(const FuseQCtx& c, const float* r, const float* T, const float* O, float& u, float& v, float& ur, int& lvl) {
+    float pc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float s = T[k * 4] * r[0];
+        s += T[k * 4 + 1] * r[1];
+        s += T[k * 4 + 2] * r[2];
+        pc[k] = (float)((double)s + (double)T[k * 4 + 3]);
+    }
+    if (pc[2] < 0.0f) return false;
+    const float invz = __fdiv_rn(1.0f, pc[2]);
+    const float x = pc[0] * invz, y = pc[1] * invz;
+    u = c.fx * x + c.cx; v = c.fy * y + c.cy;
+    if (!(u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY)) return false;   // KeyFrame::IsInImage
+    ur = u - c.bf * invz;
+    const float maxDistance = 1.2f * r[7], minDistance = 0.8f * r[6];
+    const float PO[3] = {r[0] - O[0], r[1] - O[1], r[2] - O[2]};
+    const float dist3D = (float)norm3d(PO[0], PO[1], PO[2]);
+    if (dist3D < minDistance || dist3D > maxDistance) return false;
+    const double dot = (double)PO[0] * r[3] + (double)PO[1] * r[4] + (double)PO[2] * r[5];
+    if (dot < 0.5 * dist3D) return false;
+    const float ratio = __fdiv_rn(r[7], dist3D);
+    lvl = (int)ceilf(__fdiv_rn((float)log((double)ratio), c.logScale));   // std::log(float) / logScaleFactor, as Frame::isInFrustum's kernel does
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= c.nLevels) lvl = c.nLevels - 1;
+    return true;
+}
+
+// one thread per candidate
 __global__ __launch_bounds__(256) void k_fuse_queries(FuseQCtx c, int stride, const int32_t* slots, const int32_t* Mn, const int32_t* ids, const uint8_t* excl,
                                                       uint8_t* const* tab, const float* Tcw, const float* Ow, oslam_proj_query_t* qout) {
     const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
@@ -332,46 +362,175 @@ __global__ __launch_bounds__(256) void k_fuse_queries(FuseQCtx c, int stride, co
     const int id = ids[at];
     if (id >= 0 && !excl[at]) {
         const float* r = (const float*)(tab[slots[b]] + (size_t)id * 64);   // pos[3], normal[3], minD, maxD, desc
-        const float* T = Tcw + (size_t)b * 16;
-        const float* O = Ow + (size_t)b * 3;
-        float pc[3];
+        float u, v, ur; int lvl;
+        if (fuse_gates(c, r, Tcw + (size_t)b * 16, Ow + (size_t)b * 3, u, v, ur, lvl)) {
+            q.u = u; q.v = v; q.ur = ur; q.radius = c.th * c.scale[lvl]; q.minLevel = lvl - 1; q.maxLevel = lvl; q.flags = 1;
+            const uint32_t* rd = (const uint32_t*)r + 8;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float s = T[k * 4] * r[0];
-            s += T[k * 4 + 1] * r[1];
-            s += T[k * 4 + 2] * r[2];
-            pc[k] = (float)((double)s + (double)T[k * 4 + 3]);
-        }
-        bool ok = !(pc[2] < 0.0f);
-        if (ok) {
-            const float invz = __fdiv_rn(1.0f, pc[2]);
-            const float x = pc[0] * invz, y = pc[1] * invz;
-            const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
-            ok = u >= c.minX && u < c.maxX && v >= c.minY && v < c.maxY;   // KeyFrame::IsInImage
-            if (ok) {
-                const float ur = u - c.bf * invz;
-                const float maxDistance = 1.2f * r[7], minDistance = 0.8f * r[6];
-                const float PO[3] = {r[0] - O[0], r[1] - O[1], r[2] - O[2]};
-                const float dist3D = (float)norm3d(PO[0], PO[1], PO[2]);
-                ok = !(dist3D < minDistance || dist3D > maxDistance);
-                if (ok) {
-                    const double dot = (double)PO[0] * r[3] + (double)PO[1] * r[4] + (double)PO[2] * r[5];
-                    ok = !(dot < 0.5 * dist3D);
-                }
-                if (ok) {
-                    const float ratio = __fdiv_rn(r[7], dist3D);
-                    int lvl = (int)ceilf(__fdiv_rn((float)log((double)ratio), c.logScale));   // std::log(float) / logScaleFactor, as Frame::isInFrustum's kernel does
-                    if (lvl < 0) lvl = 0;
-                    else if (lvl >= c.nLevels) lvl = c.nLevels - 1;
-                    q.u = u; q.v = v; q.ur = ur; q.radius = c.th * c.scale[lvl]; q.minLevel = lvl - 1; q.maxLevel = lvl; q.flags = 1;
-                    const uint32_t* rd = (const uint32_t*)r + 8;
-#pragma unroll
-                    for (int w = 0; w < 8; w++) qd[w] = rd[w];
-                }
-            }
+            for (int w = 0; w < 8; w++) qd[w] = rd[w];
         }
     }
     qout[at] = q;
+}
+
+// ---- Fuse against RESIDENT keyframes: the keyframe's feature grid is built once, when the keyframe is registered ----
+// KeyFrame::mGrid never changes after the constructor (src/KeyFrame.cc:44-52 copies Frame::mGrid), but the batched window search rebuilt it in LDS for every
+// Fuse job (staging of ~52 KB per keyframe + a counting sort: most of that kernel's 83 us).  k_kf_grid_build sorts a registered keyframe's keypoints by cell
+// (cells in the reference's (x, y) nesting, index order inside a cell = the push_back order of Frame::AssignFeaturesToGrid, src/Frame.cc:455-470) into
+//   cell_end[kGridCells]  (uint16: end of cell c in the sorted list; start = end of c - 1)
+//   cand[N]               (x, y, uRight, octave << 16 | keypoint index) in sorted order
+// and k_fuse_search does gates + window search of one candidate per THREAD straight from these arrays (no LDS, no per-job staging).
+constexpr int kFGridCols = 64, kFGridRows = 48, kFGridCells = kFGridCols * kFGridRows;   // include/Frame.h:43-44
+constexpr int kGridBuildThreads = 1024;
+
+__global__ __launch_bounds__(kGridBuildThreads) void k_kf_grid_build(const oslam_kf_grid_job_t* jobs, const int32_t* cnt, float minX, float minY, float invW, float invH, int ncap,
+                                                                      int32_t* status) {
+    const oslam_kf_grid_job_t j = jobs[blockIdx.x];
+    const int tid = threadIdx.x, N = cnt[j.slot];
+    extern __shared__ __align__(16) uint8_t smem[];
+    int* s_cell = (int*)smem;                                 // [kFGridCells + 1]
+    uint16_t* s_items = (uint16_t*)(s_cell + kFGridCells + 1);   // [ncap]
+    __shared__ int s_wtot[kGridBuildThreads / 64];
+    if (N < 0 || N > ncap) { if (tid == 0) atomicExch(status, 1); return; }   // host validates; never truncate silently
+    for (int i = tid; i <= kFGridCells; i += kGridBuildThreads) s_cell[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += kGridBuildThreads) {
+        const oslam_keypoint_t kp = j.keys[i];
+        const int px = (int)roundf((kp.x - minX) * invW);
+        const int py = (int)roundf((kp.y - minY) * invH);
+        if (px >= 0 && px < kFGridCols && py >= 0 && py < kFGridRows) atomicAdd(&s_cell[px * kFGridRows + py], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of the cell counts
+        constexpr int kCellsPer = kFGridCells / kGridBuildThreads;
+        static_assert(kCellsPer * kGridBuildThreads == kFGridCells, "the cell scan gives every thread the same number of cells");
+        const int lane = tid & 63, wv = tid >> 6, base = tid * kCellsPer;
+        int cc[kCellsPer], incl = 0;
+#pragma unroll
+        for (int k = 0; k < kCellsPer; k++) { cc[k] = s_cell[base + k]; incl += cc[k]; }
+        const int local = incl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int start = incl - local;
+        for (int i = 0; i < wv; i++) start += s_wtot[i];
+#pragma unroll
+        for (int k = 0; k < kCellsPer; k++) { s_cell[base + k] = start; start += cc[k]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += kGridBuildThreads) {   // scatter with the cell starts as cursors: afterwards s_cell[c] = end of cell c
+        const oslam_keypoint_t kp = j.keys[i];
+        const int px = (int)roundf((kp.x - minX) * invW);
+        const int py = (int)roundf((kp.y - minY) * invH);
+        if (px >= 0 && px < kFGridCols && py >= 0 && py < kFGridRows) s_items[atomicAdd(&s_cell[px * kFGridRows + py], 1)] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int cell = tid; cell < kFGridCells; cell += kGridBuildThreads) {   // index order inside every cell (insertion sort: cells hold a handful of points)
+        const int st = cell > 0 ? s_cell[cell - 1] : 0, en = s_cell[cell];
+        for (int a = st + 1; a < en; a++) {
+            const uint16_t v = s_items[a];
+            int q = a - 1;
+            while (q >= st && s_items[q] > v) { s_items[q + 1] = s_items[q]; q--; }
+            s_items[q + 1] = v;
+        }
+        j.cell_end[cell] = (uint16_t)en;
+    }
+    __syncthreads();
+    const int total = s_cell[kFGridCells - 1];
+    for (int t = tid; t < total; t += kGridBuildThreads) {
+        const int k = s_items[t];
+        const oslam_keypoint_t kp = j.keys[k];
+        ((float4*)j.cand)[t] = make_float4(kp.x, kp.y, j.uRight ? j.uRight[k] : -1.0f, __uint_as_float(((uint32_t)kp.octave << 16) | (uint32_t)k));
+    }
+}
+
+struct FuseSearchCtx { FuseQCtx q; float invW, invH; float invSigma2[OSLAM_MAX_LEVELS]; int th_high; };
+__global__ __launch_bounds__(256) void k_fuse_search(FuseSearchCtx c, int stride, const oslam_kf_grid_ref_t* kfs, const int32_t* slots, const int32_t* Mn, const int32_t* ids,
+                                                     const uint8_t* excl, uint8_t* const* tab, const float* Tcw, const float* Ow, int32_t* q_match) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mn[b]) return;
+    const size_t at = (size_t)b * stride + i;
+    int bestIdx = -1;
+    const int id = ids[at];
+    if (id >= 0 && !excl[at]) {
+        const float* r = (const float*)(tab[slots[b]] + (size_t)id * 64);
+        float x, y, qur; int lvl;
+        if (fuse_gates(c.q, r, Tcw + (size_t)b * 16, Ow + (size_t)b * 3, x, y, qur, lvl)) {
+            const float rad = c.q.th * c.q.scale[lvl];
+            const int minLevel = lvl - 1, maxLevel = lvl;
+            // KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:418-455; the window arithmetic of the batched search, matcher.hip)
+            const int nMinCellX = max(0, (int)floorf((x - c.q.minX - rad) * c.invW));
+            const int nMaxCellX = min(kFGridCols - 1, (int)ceilf((x - c.q.minX + rad) * c.invW));
+            const int nMinCellY = max(0, (int)floorf((y - c.q.minY - rad) * c.invH));
+            const int nMaxCellY = min(kFGridRows - 1, (int)ceilf((y - c.q.minY + rad) * c.invH));
+            if (nMinCellX < kFGridCols && nMaxCellX >= 0 && nMinCellY < kFGridRows && nMaxCellY >= 0) {
+                const oslam_kf_grid_ref_t kf = kfs[b];
+                const uint4 qd0 = ((const uint4*)r)[2], qd1 = ((const uint4*)r)[3];
+                int bestDist = 256;
+                for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                    const int c0 = ix * kFGridRows + nMinCellY;
+                    const int s = c0 > 0 ? kf.cell_end[c0 - 1] : 0, e = kf.cell_end[ix * kFGridRows + nMaxCellY];
+                    for (int t = s; t < e; t++) {   // cells iy = min..max are contiguous in this layout
+                        const float4 cd = ((const float4*)kf.cand)[t];
+                        if (!(fabsf(cd.x - x) < rad && fabsf(cd.y - y) < rad)) continue;
+                        const uint32_t ok = __float_as_uint(cd.w);
+                        const int oct = (int)(ok >> 16), k = (int)(ok & 0xFFFFu);
+                        if (oct < minLevel || oct > maxLevel) continue;   // :903-906
+                        const float ex = x - cd.x, ey = y - cd.y;
+                        if (cd.z >= 0) {   // chi2 gates :908-934
+                            const float er = qur - cd.z;
+                            const float e2 = ex * ex + ey * ey + er * er;
+                            if ((double)(e2 * c.invSigma2[oct]) > 7.8) continue;
+                        } else {
+                            const float e2 = ex * ex + ey * ey;
+                            if ((double)(e2 * c.invSigma2[oct]) > 5.99) continue;
+                        }
+                        const uint4* d = (const uint4*)(kf.desc + (size_t)k * 32);
+                        const uint4 d0 = d[0], d1 = d[1];
+                        const int dist = __popc(qd0.x ^ d0.x) + __popc(qd0.y ^ d0.y) + __popc(qd0.z ^ d0.z) + __popc(qd0.w ^ d0.w) + __popc(qd1.x ^ d1.x) + __popc(qd1.y ^ d1.y) +
+                                         __popc(qd1.z ^ d1.z) + __popc(qd1.w ^ d1.w);
+                        if (dist < bestDist) { bestDist = dist; bestIdx = k; }
+                    }
+                }
+                if (bestDist > c.th_high) bestIdx = -1;
+            }
+        }
+    }
+    q_match[at] = bestIdx;
+}
+
+int oslam_kf_grid_build_device(int n, const oslam_kf_grid_job_t* d_jobs, const int32_t* d_counts, const float bounds[4], int max_keypoints, int32_t* d_status, void* stream) {
+    if (n < 1 || !d_jobs || !d_counts || !bounds || max_keypoints < 1 || max_keypoints > 65535 || !d_status) { set_error("kf_grid_build: bad argument"); return OSLAM_E_INVALID; }
+    const size_t lds = (size_t)(kFGridCells + 1) * 4 + (size_t)max_keypoints * 2;
+    static bool attr_set = false;   // (the same value on every call of a process: the keypoint capacity of the extractor)
+    if (!attr_set) { OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_kf_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); attr_set = true; }
+    if (lds > 160 * 1024 - 2048) { set_error("kf_grid_build: max_keypoints too large"); return OSLAM_E_CAPACITY; }
+    const float invW = (float)kFGridCols / (float)(bounds[2] - bounds[0]), invH = (float)kFGridRows / (float)(bounds[3] - bounds[1]);   // src/Frame.cc:160-161
+    hipLaunchKernelGGL(k_kf_grid_build, dim3(n), dim3(kGridBuildThreads), lds, (hipStream_t)stream, d_jobs, d_counts, bounds[0], bounds[1], invW, invH, max_keypoints, d_status);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
+int oslam_fuse_search_device(int n, int stride, const oslam_kf_grid_ref_t* d_kfs, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl,
+                             uint8_t* const* d_tab, const float* d_Tcw, const float* d_Ow, const float K5[5], const float bounds[4], float th, float logScaleFactor,
+                             const float* scaleFactors, const float* invLevelSigma2, int nLevels, int32_t* d_q_match, void* stream) {
+    if (n < 1 || stride < 1 || !d_kfs || !d_slots || !d_M || !d_ids || !d_excl || !d_tab || !d_Tcw || !d_Ow || !K5 || !bounds || !scaleFactors || !invLevelSigma2 || nLevels < 1 ||
+        nLevels > OSLAM_MAX_LEVELS || !d_q_match) {
+        set_error("fuse_search: bad argument"); return OSLAM_E_INVALID;
+    }
+    FuseSearchCtx c;
+    c.q.fx = K5[0]; c.q.fy = K5[1]; c.q.cx = K5[2]; c.q.cy = K5[3]; c.q.bf = K5[4];
+    c.q.minX = bounds[0]; c.q.minY = bounds[1]; c.q.maxX = bounds[2]; c.q.maxY = bounds[3]; c.q.th = th; c.q.logScale = logScaleFactor; c.q.nLevels = nLevels;
+    for (int l = 0; l < OSLAM_MAX_LEVELS; l++) { c.q.scale[l] = l < nLevels ? scaleFactors[l] : 1.f; c.invSigma2[l] = l < nLevels ? invLevelSigma2[l] : 0.f; }
+    c.invW = (float)kFGridCols / (float)(bounds[2] - bounds[0]); c.invH = (float)kFGridRows / (float)(bounds[3] - bounds[1]);
+    c.th_high = 50;   // ORBmatcher::TH_LOW (src/ORBmatcher.cc:37, :936)
+    hipLaunchKernelGGL(k_fuse_search, dim3(div_up(stride, 256), n), dim3(256), 0, (hipStream_t)stream, c, stride, d_kfs, d_slots, d_M, d_ids, d_excl, d_tab, d_Tcw, d_Ow, d_q_match);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
 }
 
 int oslam_fuse_queries_device(int n, int stride, const int32_t* d_slots, const int32_t* d_M, const int32_t* d_ids, const uint8_t* d_excl, uint8_t* const* d_tab,

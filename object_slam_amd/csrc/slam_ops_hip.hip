@@ -76,11 +76,17 @@ struct HipOps {
     int n_rec = 0;
     uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
     std::vector<uint8_t*> h_rec_desc;
-    size_t rec_bytes() const { return oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256) + oslam::align_up((size_t)cap * 32, 256) + oslam::align_up((size_t)cap * 4, 256); }
+    // a record = mvKeysUn, descriptors, mvuRight and — built once at registration (oslam_kf_grid_build_device) — the feature grid: cell ends + candidates sorted by cell
+    size_t rec_bytes() const {
+        return oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256) + oslam::align_up((size_t)cap * 32, 256) + oslam::align_up((size_t)cap * 4, 256) +
+               oslam::align_up((size_t)3072 * 2, 256) + oslam::align_up((size_t)cap * 16, 256);
+    }
     uint8_t* rec_ptr(int r) const { return rec_chunks[r / kRecChunk] + (size_t)(r % kRecChunk) * rec_bytes(); }
     const oslam_keypoint_t* rec_keys(int r) const { return (const oslam_keypoint_t*)rec_ptr(r); }
     const uint8_t* rec_desc(int r) const { return rec_ptr(r) + oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256); }
     const float* rec_ur(int r) const { return (const float*)(rec_desc(r) + oslam::align_up((size_t)cap * 32, 256)); }
+    uint16_t* rec_cell_end(int r) const { return (uint16_t*)((const uint8_t*)rec_ur(r) + oslam::align_up((size_t)cap * 4, 256)); }
+    float* rec_cand(int r) const { return (float*)((uint8_t*)rec_cell_end(r) + oslam::align_up((size_t)3072 * 2, 256)); }
     int rec_lookup(int slot, int kf) const { return (slot >= 0 && slot < (int)rec_of_kf.size() && kf >= 0 && kf < (int)rec_of_kf[slot].size()) ? rec_of_kf[slot][kf] : -1; }
     // Resident map points: one growing array of 64-byte records per slot (position, normal, distances, descriptor), written by every MapPoint update
     std::vector<uint8_t*> mp_tab; std::vector<size_t> mp_cap;   // [S] device arrays and their capacity in records
@@ -961,11 +967,19 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         segs.push_back({o->d_desc + 32 * cap * slot, (uint8_t*)o->rec_desc(r), (uint32_t)(cap * 32), 0});
         segs.push_back({(const uint8_t*)(o->cur_uRight + cap * slot), (uint8_t*)o->rec_ur(r), (uint32_t)(cap * 4), 0});
     }
-    OPS_CHECK(o->ensure_up(segs.size() * sizeof(CopySegH)));
+    const size_t oJobs = oslam::align_up(segs.size() * sizeof(CopySegH), 256), up_bytes = oJobs + (size_t)n * sizeof(oslam_kf_grid_job_t);
+    OPS_CHECK(o->ensure_up(up_bytes));
     memcpy(o->up_h, segs.data(), segs.size() * sizeof(CopySegH));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, segs.size() * sizeof(CopySegH), hipMemcpyHostToDevice, o->strm));
+    oslam_kf_grid_job_t* gj = (oslam_kf_grid_job_t*)(o->up_h + oJobs);
+    for (int i = 0; i < n; i++) {
+        const int r = o->rec_of_kf[slots[i]][kf_ids[i]];
+        gj[i].keys = o->rec_keys(r); gj[i].uRight = o->rec_ur(r); gj[i].cell_end = o->rec_cell_end(r); gj[i].cand = o->rec_cand(r); gj[i].slot = slots[i]; gj[i].pad_ = 0;
+    }
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, up_bytes, hipMemcpyHostToDevice, o->strm));
     o->t_begin();
     OPS_CHECK(oslam_copy_segments_device(o->up_d, (int)segs.size(), o->strm));
+    // KeyFrame::mGrid of the new keyframes (fixed from here on): sorted once, read by every later Fuse against them
+    OPS_CHECK(oslam_kf_grid_build_device(n, (const oslam_kf_grid_job_t*)(o->up_d + oJobs), o->d_cnt, o->bounds, (int)cap, o->d_status + 8, o->strm));
     o->t_end();
     // descriptor-array table for the observation gathers
     if ((size_t)o->n_rec > o->rec_desc_cap) {
@@ -978,8 +992,11 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->d_rec_desc + o->rec_desc_n, o->h_rec_desc.data() + o->rec_desc_n, (size_t)(o->n_rec - o->rec_desc_n) * sizeof(uint8_t*),
                                    hipMemcpyHostToDevice, o->strm));
     o->rec_desc_n = o->n_rec;
-    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // the other operators run on their own streams: the copies are complete when this returns
-    o->t_collect(7, 1, 0);
+    OPS_CHECK(o->ensure_dn(4));
+    OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, o->d_status + 8, 4, o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // the records are complete when this returns
+    o->t_collect(7, 2, 0);
+    if (*(const int32_t*)o->dn_h != 0) { oslam::set_error("register_keyframes: a keyframe has more keypoints than the extractor's capacity"); return OSLAM_E_CAPACITY; }
     return OSLAM_OK;
 }
 
@@ -1151,6 +1168,41 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         rec[i] = o->rec_lookup(jobs[i].slot, jobs[i].kf);
         if (rec[i] < 0 || jobs[i].M < 0 || jobs[i].N < 0 || jobs[i].N > (int)cap) { oslam::set_error("fuse_points: keyframe not resident / bad size"); return OSLAM_E_INVALID; }
         maxM = std::max(maxM, jobs[i].M);
+    }
+    static const bool staged = getenv("OSLAM_SLAM_FUSE_STAGED") != nullptr;   // A/B knob: the round-2 path (copy the records into a batch, queries, LDS window search)
+    if (!staged) {
+        // gates + window search of every candidate in ONE launch, straight from the resident records and their grids (oslam_fuse_search_device)
+        OPS_CHECK(o->sync_mp_table());
+        const size_t st = oslam::align_up((size_t)maxM, 64);
+        Layout L;
+        const size_t oM = L.take(4 * B), oSl = L.take(4 * B), oT = L.take(64 * B), oOw = L.take(12 * B), oRef = L.take(sizeof(oslam_kf_grid_ref_t) * B), oIds = L.take(4 * st * B),
+                     oEx = L.take(st * B);
+        const size_t head = L.off;
+        const size_t oQm = L.take(4 * st * B);
+        OPS_CHECK(o->ensure_up(L.off));
+        OPS_CHECK(o->ensure_dn(4 * st * B));
+        uint8_t* U = o->up_h;
+        uint8_t* Dv = o->up_d;
+        o->pool->parallel_for(n, [&](int i) {
+            const oslam_job_fuse_pts_t& j = jobs[i];
+            const size_t M = j.M;
+            ((int32_t*)(U + oM))[i] = j.M; ((int32_t*)(U + oSl))[i] = j.slot;
+            memcpy(U + oT + 64 * i, j.Tcw, 64); memcpy(U + oOw + 12 * i, j.Ow, 12);
+            memcpy(U + oIds + 4 * st * i, j.ids, 4 * M); memcpy(U + oEx + st * i, j.excl, M);
+            oslam_kf_grid_ref_t& ref = ((oslam_kf_grid_ref_t*)(U + oRef))[i];
+            ref.cell_end = o->rec_cell_end(rec[i]); ref.cand = o->rec_cand(rec[i]); ref.desc = o->rec_desc(rec[i]);
+        });
+        OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, head, hipMemcpyHostToDevice, o->strm));
+        o->t_begin();
+        OPS_CHECK(oslam_fuse_search_device(n, (int)st, (const oslam_kf_grid_ref_t*)(Dv + oRef), (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oM), (const int32_t*)(Dv + oIds),
+                                           Dv + oEx, o->d_mp_tab, (const float*)(Dv + oT), (const float*)(Dv + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale,
+                                           o->invSigma2, o->cfg.nLevels, (int32_t*)(Dv + oQm), o->strm));
+        o->t_end();
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, Dv + oQm, 4 * st * B, o->strm));
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+        o->t_collect(4, 1, 0);
+        o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });
+        return OSLAM_OK;
     }
     if (maxM > o->max_local) {
         OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));

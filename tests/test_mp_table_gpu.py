@@ -217,3 +217,131 @@ def test_fuse_queries_match_the_host_form():
             assert (g["flags"] == 1) == want_active, (b, i)
             active += want_active
     assert active > 100 and near < 5
+
+
+def test_fuse_search_on_resident_grids_equals_queries_plus_window_search():
+    """oslam_kf_grid_build_device + oslam_fuse_search_device (one launch, one candidate per thread, the keyframe's grid built once) against (a) a numpy restatement
+    of Frame::AssignFeaturesToGrid's cell order (reference src/Frame.cc:455-470) for the grid arrays and (b) the staged path it replaces in the driver:
+    oslam_fuse_queries_device followed by the LDS window search of ORBmatcher::Fuse (oslam_match_fuse_search, itself oracle-checked in tests/test_matcher_gpu.py) —
+    index-exact."""
+    import torch
+    from object_slam_amd import ORBmatcher
+    from object_slam_amd._lib import KP_DTYPE
+    L = _lib.lib()
+    rng = np.random.default_rng(31)
+    f32 = np.float32
+    S, R, n, stride, cap = 3, 900, 3, 1024, 1200
+    K5 = np.array([535.4, 539.2, 320.1, 247.6, 40.0], f32)
+    bounds = np.array([0.0, 0.0, 640.0, 480.0], f32)
+    scale = (f32(1.2) ** np.arange(8)).astype(f32)
+    inv_sigma2 = (f32(1) / (scale * scale)).astype(f32)
+    logS = f32(np.log(f32(1.2)))
+    # keyframes: clustered keypoints (several per cell, some outside the grid's rounding range), mixed octaves, 30 % without depth
+    Ns = np.array([1100, 700, 0], np.int32)
+    slots_kf = np.array([2, 0, 1], np.int32)          # the frame of job i sits in slot slots_kf[i] of the batch arrays
+    keys = np.zeros((S, cap), KP_DTYPE); uR = np.full((S, cap), -1, f32); desc = rng.integers(0, 256, (S, cap, 32), dtype=np.uint8)
+    base_desc = rng.integers(0, 256, (R, 32), dtype=np.uint8)
+    for i in range(n):
+        sl, N = slots_kf[i], Ns[i]
+        keys["x"][sl, :N] = np.clip(rng.normal(320, 150, N), 0, 639.9).astype(f32); keys["y"][sl, :N] = np.clip(rng.normal(240, 110, N), 0, 479.9).astype(f32)
+        keys["x"][sl, :N][:8] = 639.9; keys["y"][sl, :N][:8] = 479.9       # rounds to cell (64, 48): outside the grid
+        keys["octave"][sl, :N] = rng.integers(0, 8, N); keys["angle"][sl, :N] = rng.uniform(0, 360, N)
+        has_d = rng.random(N) < 0.7
+        uR[sl, :N] = np.where(has_d, keys["x"][sl, :N] - rng.uniform(2, 30, N).astype(f32), -1).astype(f32)
+        pick = rng.integers(0, R, N)                                         # descriptors near those of the map points, so that matches exist
+        d = base_desc[pick].copy(); flip = rng.random((N, 32)) < 0.08; d[flip] ^= rng.integers(1, 256, (N, 32), dtype=np.uint8)[flip]
+        desc[sl, :N] = d
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_keys, d_uR, d_desc, d_cnt = t(keys.view(np.uint8).reshape(S, -1)), t(uR), t(desc), t(np.array([Ns[1], Ns[2], Ns[0]], np.int32))   # counts by slot
+    cell_end = torch.zeros((n, 3072), dtype=torch.int16, device="cuda"); cand = torch.zeros((n, cap, 4), dtype=torch.float32, device="cuda")
+    status = torch.zeros(4, dtype=torch.int32, device="cuda")
+    gj = np.zeros((n, 5), np.int64)                                          # oslam_kf_grid_job_t: four pointers, int32 slot, int32 pad = 40 bytes
+    for i in range(n):
+        sl = int(slots_kf[i])
+        gj[i] = (d_keys.data_ptr() + sl * cap * 28, d_uR.data_ptr() + sl * cap * 4, cell_end.data_ptr() + i * 3072 * 2, cand.data_ptr() + i * cap * 16, sl)
+    d_gj = t(gj)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    cp = lambda a: C.c_void_p(a.ctypes.data)
+    check(L.oslam_kf_grid_build_device(n, vp(d_gj), vp(d_cnt), cp(bounds), cap, vp(status), None))
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0
+    ce, cd = cell_end.cpu().numpy().view(np.uint16), cand.cpu().numpy()
+    for i in range(n):
+        sl, N = slots_kf[i], Ns[i]
+        px = np.rint((keys["x"][sl, :N] - bounds[0]) * f32(64.0 / 640.0)).astype(int); py = np.rint((keys["y"][sl, :N] - bounds[1]) * f32(48.0 / 480.0)).astype(int)
+        inside = (px >= 0) & (px < 64) & (py >= 0) & (py < 48)
+        order = [k for c in range(3072) for k in np.nonzero(inside & (px * 48 + py == c))[0]]     # cells in (x, y) nesting, index order inside a cell
+        counts = np.bincount((px * 48 + py)[inside], minlength=3072)
+        assert np.array_equal(ce[i], np.cumsum(counts).astype(np.uint16))
+        got = cd[i, :len(order)]
+        assert np.array_equal(got[:, 0], keys["x"][sl][order]) and np.array_equal(got[:, 1], keys["y"][sl][order]) and np.array_equal(got[:, 2], uR[sl][order])
+        assert np.array_equal(got[:, 3].view(np.uint32), (keys["octave"][sl][order].astype(np.uint32) << 16) | np.array(order, np.uint32))
+        if N: assert 0 < len(order) <= N - 8      # (points clipped to the right / bottom edge round to column 64 / row 48: outside, as in the reference)
+    # map-point records in front of the cameras, descriptors = base_desc
+    recs = np.zeros((S, R, 16), f32)
+    recs[:, :, 0:3] = rng.normal(0, 1.2, (S, R, 3)) + np.array([0, 0, 3.5])
+    recs[:, :, 3:6] = recs[:, :, 0:3] / np.linalg.norm(recs[:, :, 0:3], axis=-1, keepdims=True)
+    recs[:, :, 6] = rng.uniform(0.3, 2.0, (S, R)); recs[:, :, 7] = recs[:, :, 6] * rng.uniform(2.0, 8.0, (S, R))
+    raw = recs.astype(f32).view(np.uint8).reshape(S, R, 64).copy()
+    raw[:, :, 32:] = base_desc[None]
+    # put the keypoints of the first two keyframes where some of the points project, so that the window search has candidates
+    T = np.tile(np.eye(4, dtype=f32), (n, 1, 1)); T[0, :3, 3] = (0.1, -0.05, 0.2); T[1, 0, 3] = -0.3
+    Ow = np.stack([-(T[b, :3, :3].T @ T[b, :3, 3]) for b in range(n)]).astype(f32)
+    tabs = [torch.from_numpy(raw[s]).cuda() for s in range(S)]
+    ptrs = t(np.array([t_.data_ptr() for t_ in tabs], np.uint64).view(np.int64))
+    slots_mp, M = np.array([1, 0, 2], np.int32), np.array([900, 640, 333], np.int32)
+    # keypoints where the map points of the job's sequence project (position within ~1.5 px, predicted level or the one below, descriptor a few bits away), so
+    # that the window search has candidates that pass every gate; then the grids are built again
+    for b in range(2):
+        sl, N = slots_kf[b], Ns[b]
+        X = recs[slots_mp[b]].astype(np.float64)
+        pc = X[:, :3] @ T[b, :3, :3].T.astype(np.float64) + T[b, :3, 3]
+        u = K5[0] * pc[:, 0] / pc[:, 2] + K5[2]; v = K5[1] * pc[:, 1] / pc[:, 2] + K5[3]
+        dist = np.linalg.norm(X[:, :3] - Ow[b], axis=1)
+        lvl = np.clip(np.ceil(np.log(X[:, 7] / dist) / float(logS)), 0, 7).astype(int)
+        ok = np.nonzero((pc[:, 2] > 0) & (u > 5) & (u < 630) & (v > 5) & (v < 470))[0]
+        take = ok[:min(len(ok), N - 50)]
+        kk = np.arange(len(take)) + 20
+        keys["x"][sl, kk] = (u[take] + rng.uniform(-1.5, 1.5, len(take))).astype(f32); keys["y"][sl, kk] = (v[take] + rng.uniform(-1.5, 1.5, len(take))).astype(f32)
+        keys["octave"][sl, kk] = np.maximum(lvl[take] - rng.integers(0, 2, len(take)), 0)
+        uR[sl, kk] = np.where(rng.random(len(take)) < 0.7, u[take] - K5[4] / pc[take, 2] + rng.uniform(-1, 1, len(take)), -1).astype(f32)
+        d = base_desc[take].copy(); flip = rng.random(d.shape) < 0.05; d[flip] ^= (1 << rng.integers(0, 8, d.shape)).astype(np.uint8)[flip]
+        desc[sl, kk] = d
+    d_keys, d_uR, d_desc = t(keys.view(np.uint8).reshape(S, -1)), t(uR), t(desc)
+    for i in range(n):
+        sl = int(slots_kf[i])
+        gj[i, 0], gj[i, 1] = d_keys.data_ptr() + sl * cap * 28, d_uR.data_ptr() + sl * cap * 4
+    d_gj = t(gj)
+    check(L.oslam_kf_grid_build_device(n, vp(d_gj), vp(d_cnt), cp(bounds), cap, vp(status), None))
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0
+    ids = rng.integers(-1, R, (n, stride)).astype(np.int32)
+    excl = (rng.random((n, stride)) < 0.15).astype(np.uint8)
+    keep = [t(slots_mp), t(M), t(ids), t(excl), t(T.reshape(n, 16)), t(Ow)]
+    refs = np.zeros((n, 3), np.int64)
+    for i in range(n):
+        refs[i] = (cell_end.data_ptr() + i * 3072 * 2, cand.data_ptr() + i * cap * 16, d_desc.data_ptr() + int(slots_kf[i]) * cap * 32)
+    d_refs = t(refs)
+    qm = torch.full((n, stride), -7, dtype=torch.int32, device="cuda")
+    for th in (3.0, 6.0):
+        check(L.oslam_fuse_search_device(n, stride, vp(d_refs), vp(keep[0]), vp(keep[1]), vp(keep[2]), vp(keep[3]), vp(ptrs), vp(keep[4]), vp(keep[5]), cp(K5), cp(bounds),
+                                         C.c_float(th), C.c_float(float(logS)), cp(scale), cp(inv_sigma2), 8, vp(qm), None))
+        qbuf = torch.zeros((n, stride, 64), dtype=torch.uint8, device="cuda")
+        check(L.oslam_fuse_queries_device(n, stride, vp(keep[0]), vp(keep[1]), vp(keep[2]), vp(keep[3]), vp(ptrs), vp(keep[4]), vp(keep[5]), cp(K5), cp(bounds), C.c_float(th),
+                                          C.c_float(float(logS)), cp(scale), 8, vp(qbuf), None))
+        torch.cuda.synchronize()
+        got = qm.cpu().numpy()
+        from object_slam_amd.matcher import QUERY_DTYPE
+        queries = qbuf.cpu().numpy().view(QUERY_DTYPE).reshape(n, stride)
+        m = ORBmatcher(max_keypoints=cap, max_queries=stride)
+        fused = 0
+        for b in range(n):
+            sl, N = slots_kf[b], Ns[b]
+            if N == 0:
+                assert np.all(got[b, :M[b]] == -1)
+                continue
+            _, want, _ = m.fuse_search(keys[sl, :N], uR[sl, :N], desc[sl, :N], bounds, queries[b, :M[b]], inv_sigma2)
+            assert np.array_equal(got[b, :M[b]], want), (th, b, np.nonzero(got[b, :M[b]] != want)[0][:10])
+            fused += int((want >= 0).sum())
+        m.close()
+        assert fused > 60, fused
