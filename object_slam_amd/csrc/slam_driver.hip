@@ -641,7 +641,8 @@ static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<in
 }
 
 // surgery of ORBmatcher::Fuse (:950-970) in query order; points whose descriptor must be recomputed go to `upd`
-static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t* q_match) {
+// `touched` (optional): the points whose bad flag or observation list this call changed
+static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t* q_match, std::vector<int>* touched = nullptr) {
     Map& m = s.map;
     for (size_t i = 0; i < qpt.size(); i++) {
         const int best = q_match[i];
@@ -653,10 +654,12 @@ static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t
             if (!m.mps[inKF].bad) {
                 if (m.mps[inKF].nObs > m.mps[p].nObs) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
                 else { if (m.replace_point(inKF, p)) s.updList.push_back(p); }
+                if (touched) { touched->push_back(p); touched->push_back(inKF); }
             }
         } else {
             m.add_observation(p, k, best);
             m.kfs[k].mp[best] = p;
+            if (touched) touched->push_back(p);
         }
         s.st[9]++;
     }
@@ -930,7 +933,16 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
     // The target keyframes of one sequence are fused one after the other like the reference's loop (a fusion changes descriptors and
     // observations the next target sees); round t handles target t of every sequence in one batch.
     if (flags & 4) {
-        struct FuseSeq { std::vector<int> targets; std::vector<int> pts; std::vector<oslam_proj_query_t> q; std::vector<int> qpt; std::vector<int32_t> qm; std::vector<uint8_t> excl; int kf; };
+        // badf / mask / dup / slotOf / touched: what only the host knows of ORBmatcher::Fuse's gates (:849: the point is bad, or already observed in the target) for
+        // the points of the current keyframe against ALL targets, computed once before the rounds (bit t of mask[i] = point i is observed in the keyframe with
+        // slot t) and refreshed after every round for the points that round changed — instead of a pass over all ~1000 point records and their observation
+        // lists per round and sequence.
+        struct FuseSeq {
+            std::vector<int> targets; std::vector<int> pts; std::vector<oslam_proj_query_t> q; std::vector<int> qpt; std::vector<int32_t> qm; std::vector<uint8_t> excl; int kf;
+            std::vector<uint8_t> badf, slotOf; std::vector<uint64_t> mask; std::vector<int> dup, touched; bool cached = false;
+        };
+        static const bool excl_check = getenv("OSLAM_SLAM_FUSE_EXCL_CHECK") != nullptr;   // debugging: compare the cached flags with the full pass every round
+        static const bool excl_cache = !getenv("OSLAM_SLAM_FUSE_EXCL_FULL");               // A/B knob: the full pass every round
         const bool fuse_by_id = c.residentPts && c.ops.fuse_points_keyed != nullptr;   // the table runs the projection gates itself from its map-point records
         std::vector<oslam_job_fuse_pts_t> pjobs;
         std::vector<FuseSeq> fs(who.size());
@@ -952,7 +964,42 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
             }
             fs[w].pts.assign(m.kfs[cur].mp.begin(), m.kfs[cur].mp.end());   // vpMapPointMatches snapshot (:484)
+            FuseSeq& f = fs[w];
+            f.cached = false;
+            if (!fuse_by_id || !excl_cache) return;
+            f.slotOf.assign(m.kfs.size(), 255);
+            int nslot = 0;
+            for (int k : f.targets) if (f.slotOf[k] == 255) f.slotOf[k] = (uint8_t)nslot++;   // (the target list may name a keyframe twice, like the reference's)
+            if (nslot > 64) return;   // (cannot happen with 10 + 10 x 5 targets; the full pass serves it)
+            const size_t n = f.pts.size();
+            f.badf.assign(n, 1); f.mask.assign(n, 0); f.dup.assign(n, -1); f.touched.clear();
+            const int stamp = cur + 1;
+            for (size_t pi = 0; pi < n; pi++) {
+                prefetch_obs_ahead(m.mps, f.pts, pi, n);
+                const int p = f.pts[pi];
+                if (p < 0) continue;
+                MapPt& mp = m.mps[p];
+                if (mp.fuseListStamp == stamp) f.dup[pi] = mp.fuseListIdx;   // the same point at two keypoints of the keyframe: a chain through its positions
+                mp.fuseListStamp = stamp; mp.fuseListIdx = (int)pi;
+                f.badf[pi] = mp.bad ? 1 : 0;
+                uint64_t mk = 0;
+                for (auto& e : mp.obs) { const uint8_t sl = f.slotOf[e.first]; if (sl != 255) mk |= 1ull << sl; }
+                f.mask[pi] = mk;
+            }
+            f.cached = true;
         });
+        auto refresh_touched = [&](Seq& s, FuseSeq& f) {   // after a round: the points it changed, if they are in the list
+            const Map& m = s.map;
+            const int stamp = s.curKF + 1;
+            for (int x : f.touched) {
+                const MapPt& mp = m.mps[x];
+                if (mp.fuseListStamp != stamp) continue;
+                uint64_t mk = 0;
+                for (auto& e : mp.obs) { const uint8_t sl = (size_t)e.first < f.slotOf.size() ? f.slotOf[e.first] : 255; if (sl != 255) mk |= 1ull << sl; }
+                for (int pi = mp.fuseListIdx; pi >= 0; pi = f.dup[pi]) { f.badf[pi] = mp.bad ? 1 : 0; f.mask[pi] = mk; }
+            }
+            f.touched.clear();
+        };
         for (size_t w = 0; w < who.size(); w++) maxt = std::max(maxt, fs[w].targets.size());
         auto fuse_round_by_id = [&](bool into_current, size_t t) -> int {
             jw.clear(); pjobs.clear();
@@ -967,14 +1014,24 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 const std::vector<int>& pts = fs[w].pts;
                 fs[w].excl.assign(pts.size() + 1, 1);
                 bool any = false;
-                for (size_t pi = 0; pi < pts.size(); pi++) {   // what only the host knows of ORBmatcher::Fuse's gates (:849): bad, or already in the keyframe
-                    prefetch_obs_ahead(m.mps, pts, pi, pts.size());
-                    const int p = pts[pi];
-                    if (p < 0) continue;
-                    const MapPt& mp = m.mps[p];
-                    if (mp.bad || mp.obs_index(k) >= 0) continue;
-                    fs[w].excl[pi] = 0; any = true;
+                const bool cached = !into_current && fs[w].cached;
+                if (cached) {
+                    const FuseSeq& f = fs[w];
+                    const int sl = f.slotOf[k];
+                    for (size_t pi = 0; pi < pts.size(); pi++) {
+                        const uint8_t ex = f.badf[pi] | (uint8_t)((f.mask[pi] >> sl) & 1);
+                        fs[w].excl[pi] = ex; any = any || !ex;
+                    }
                 }
+                if (!cached || excl_check)
+                    for (size_t pi = 0; pi < pts.size(); pi++) {   // what only the host knows of ORBmatcher::Fuse's gates (:849): bad, or already in the keyframe
+                        prefetch_obs_ahead(m.mps, pts, pi, pts.size());
+                        const int p = pts[pi];
+                        uint8_t ex = 1;
+                        if (p >= 0) { const MapPt& mp = m.mps[p]; ex = (mp.bad || mp.obs_index(k) >= 0) ? 1 : 0; }
+                        if (cached) { if (ex != fs[w].excl[pi]) { fprintf(stderr, "[fuse excl check] mismatch: sequence %d keyframe %d point %d (list index %zu): cached %d, full %d\n", who[w], k, p, pi, fs[w].excl[pi], ex); abort(); } }
+                        else { fs[w].excl[pi] = ex; any = any || !ex; }
+                    }
                 if (!any) fs[w].kf = -1;
                 fs[w].qm.assign(pts.size() + 1, -1);
             });
@@ -991,7 +1048,12 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             int rc2 = c.ops.fuse_points_keyed(c.ops.ctx, (int)pjobs.size(), pjobs.data());
             if (rc2) return rc2;
             { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
-            pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].pts, fs[w].qm.data()); });
+            pool.parallel_for((int)jw.size(), [&](int q) {
+                const int w = jw[q];
+                const bool cached = !into_current && fs[w].cached;
+                fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].pts, fs[w].qm.data(), cached ? &fs[w].touched : nullptr);
+                if (cached) refresh_touched(*c.seq[who[w]], fs[w]);
+            });
             merge_upd();
             { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
             rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)

@@ -120,6 +120,8 @@ struct MapPt {
     int replaced = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
     int lastFrameSeen = 0, trackRefForFrame = 0, baLocalForKF = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    // driver scratch of SearchInNeighbors: position of the point in the current keyframe's point list (valid while fuseListStamp == current keyframe id + 1)
+    int fuseListIdx = 0, fuseListStamp = 0;
     // bookkeeping of the driver (not in the reference): obsVer counts the changes of the observation list; (updVer, updStep) = obsVer and the local-mapping
     // step of the last full update (descriptor + normal / depth), so that an update whose inputs cannot have changed since is not repeated
     int obsVer = 0, updVer = -1, updStep = -1;
