@@ -38,24 +38,11 @@ void mappoint_use_stream(struct ::oslam_mappoint* h, hipStream_t s);
 static inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 // Device -> pinned-host transfer as a KERNEL on the caller's stream (the pinned block of hipHostMalloc is mapped into the device's address space: the stores go
-// over PCIe).  Why not hipMemcpyAsync: the runtime executes device-to-host copies of ALL streams of a process on one SDMA ring, in submission order, each behind a
-// poll on the kernels it depends on — a download enqueued behind a long kernel sequence (a local-BA call: ~135 launches) stalls every other handle's small
-// downloads until that sequence has finished.  A copy kernel only occupies the stream it belongs to.  `dst` must be device-accessible host memory.
-__global__ static void k_copy_to_host(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n16, size_t bytes) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t i = t0; i < n16; i += stride) ((uint4*)dst)[i] = ((const uint4*)src)[i];
-    for (size_t i = n16 * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
-}
-static inline hipError_t copy_to_host_async(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s) {
-    if (!bytes) return hipSuccess;
-    static const bool sdma = getenv("OSLAM_D2H_SDMA") != nullptr;   // A/B knob: the runtime's copy path
-    if (sdma) return hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s);
-    const bool aligned = ((((uintptr_t)dst_pinned) | ((uintptr_t)src_dev)) & 15) == 0;
-    const size_t n16 = aligned ? bytes / 16 : 0, units = n16 + (bytes - n16 * 16);
-    const int blocks = (int)((units + 255) / 256 < 1024 ? (units + 255) / 256 : 1024);
-    hipLaunchKernelGGL(k_copy_to_host, dim3(blocks), dim3(256), 0, s, (uint8_t*)dst_pinned, (const uint8_t*)src_dev, n16, bytes);
-    return hipGetLastError();
-}
+// over PCIe), used for the small downloads that end an operator (local-BA results and control blocks, Fuse matches, status words): the copy stays in the stream's
+// own queue instead of going through the runtime's copy path, which all streams of the process share.  Same-box A/B in the steady-state bench: 17.3 k frames/s
+// against 17.0 k with hipMemcpyAsync (OSLAM_D2H_SDMA=1) — within the spread; kept because it removes a dependency on that shared path.  `dst` must be
+// device-accessible host memory.
+hipError_t copy_to_host_async(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);   // (defined once, in orb_extractor.hip, next to stream_wait)
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // Pinned host staging for the single-frame host-pointer entry points: uploads are memcpy'd into the pinned block and

@@ -666,9 +666,26 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
 #ifndef OSLAM_LIN_MIN_WAVES
 #define OSLAM_LIN_MIN_WAVES 4   // 128 VGPRs (96 B of scratch per lane) so that two 512-thread workgroups share a CU; 1 = the compiler's 166 VGPRs, one workgroup per CU
 #endif
-__global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(const LbaProblem* probs, const LbaWide* ws) {
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
+// Workgroups are dispatched to the 8 XCDs round robin in linear block order, and every XCD has its own 4 MB L2.  The per-window kernels below map
+// (window, item) so that ALL workgroups of a window run on ONE XCD (window w -> XCD w mod 8; the windows of an XCD one after the other): the window's per-edge
+// blocks (B_e, W_e: 288 B per edge, read once per pair they take part in) then come out of that XCD's L2 instead of being pulled into all eight.
+// Launch grid: dim3(items per window, windows rounded up to a multiple of 8).
+// Calls with fewer than 8 windows keep the plain mapping (window = blockIdx.y: a window's workgroups spread over all XCDs), signalled by gridDim.y == nwin.
+__device__ __forceinline__ bool xcd_window_item(int nwin, int& win, int& item) {
+    if ((int)gridDim.y == nwin && (nwin & 7)) { win = blockIdx.y; item = blockIdx.x; return true; }
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, j = L >> 3;
+    const int grp = j / (int)gridDim.x;
+    item = j - grp * (int)gridDim.x;
+    win = grp * 8 + xcd;
+    return win < nwin;
+}
+
+__global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    int win_, item_;
+    if (!xcd_window_item(nwin, win_, item_)) return;
+    const LbaProblem& pr = probs[win_];
+    const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done || !ct->need_lin) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
@@ -677,10 +694,10 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
     const double* X = w_X(pr, ct->cur);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ double sF[kLinThreads / 64], sM[kLinThreads / 64], sAcc[kLinThreads / 64][27];
-    if ((int)blockIdx.x < w.nblk_pt) {
+    if (item_ < w.nblk_pt) {
         const SE3* T = w.T + ct->cur * pr.K;
         const double* Rm = w.R + (size_t)ct->cur * pr.K * 9;
-        const int p = blockIdx.x * kWPt + (tid >> 2), sub = tid & 3;
+        const int p = item_ * kWPt + (tid >> 2), sub = tid & 3;
         double F0 = 0, dmax = 0;
         double hl[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         if (p < pr.P) {
@@ -746,12 +763,12 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         if (tid == 0) {
             double a = sF[0], bm = sM[0];
             for (int i = 1; i < kLinThreads / 64; i++) { a += sF[i]; bm = fmax(bm, sM[i]); }
-            w.partF[blockIdx.x] = a;
-            w.partM[blockIdx.x] = bm;
+            w.partF[item_] = a;
+            w.partM[item_] = bm;
         }
         return;
     }
-    const int a = (int)blockIdx.x - w.nblk_pt;
+    const int a = item_ - w.nblk_pt;
     if (a >= pr.K || w.blk[a] < 0) return;   // fixed keyframe, or a padding block of a batched launch
     const SE3 Ta = w.T[ct->cur * pr.K + a];
     const double* Ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
@@ -831,12 +848,14 @@ __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
 
 // W_e = B_e (Hll_p + lambda I)^-1 for every active edge of a free keyframe: one inversion per edge instead of one per
 // (block, edge) pair inside the Schur kernel
-__global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws) {
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
+__global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    int win_, item_;
+    if (!xcd_window_item(nwin, win_, item_)) return;
+    const LbaProblem& pr = probs[win_];
+    const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = item_ * 256 + threadIdx.x;
     if (e >= pr.E || pr.level[e] != 0 || w.blk[pr.e_kf[e]] < 0) return;
     const double lambda = ct->lambda;
     const int p = pr.e_pt[e];
@@ -860,21 +879,6 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
 // Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
 // wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
 // rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
-// Workgroups are dispatched to the 8 XCDs round robin in linear block order, and every XCD has its own 4 MB L2.  The per-window kernels below map
-// (window, item) so that ALL workgroups of a window run on ONE XCD (window w -> XCD w mod 8; the windows of an XCD one after the other): the window's per-edge
-// blocks (B_e, W_e: 288 B per edge, read once per pair they take part in) then come out of that XCD's L2 instead of being pulled into all eight.
-// Launch grid: dim3(items per window, windows rounded up to a multiple of 8).
-// Calls with fewer than 8 windows keep the plain mapping (window = blockIdx.y: a window's workgroups spread over all XCDs), signalled by gridDim.y == nwin.
-__device__ __forceinline__ bool xcd_window_item(int nwin, int& win, int& item) {
-    if ((int)gridDim.y == nwin && (nwin & 7)) { win = blockIdx.y; item = blockIdx.x; return true; }
-    const int L = blockIdx.x + gridDim.x * blockIdx.y;
-    const int xcd = L & 7, j = L >> 3;
-    const int grp = j / (int)gridDim.x;
-    item = j - grp * (int)gridDim.x;
-    win = grp * 8 + xcd;
-    return win < nwin;
-}
-
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win, t;
     if (!xcd_window_item(nwin, win, t)) return;
@@ -1328,9 +1332,11 @@ __global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* 
 }
 
 // landmark back-substitution, trial state, computeScale partials
-__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws) {
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
+__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    int win_, item_;
+    if (!xcd_window_item(nwin, win_, item_)) return;
+    const LbaProblem& pr = probs[win_];
+    const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const double lambda = ct->lambda;
@@ -1339,8 +1345,8 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     const double* X = w_X(pr, cur);
     double* Xn = w_X(pr, cur ^ 1);
     double sc = 0;
-    if ((int)blockIdx.x > w.nblk_pt) return;   // padding block of a batched launch (the grid is sized for the largest window)
-    if ((int)blockIdx.x == w.nblk_pt) {   // poses
+    if (item_ > w.nblk_pt) return;   // padding block of a batched launch (the grid is sized for the largest window)
+    if (item_ == w.nblk_pt) {   // poses
         for (int a = threadIdx.x; a < pr.K; a += kWPt) {
             const int ba = w.blk[a];
             SE3* Tn = w.T + (cur ^ 1) * pr.K + a;
@@ -1354,7 +1360,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
             se3_R(*Tn, w.R + ((size_t)(cur ^ 1) * pr.K + a) * 9);
         }
     } else {
-        const int p = blockIdx.x * kWPt + threadIdx.x;
+        const int p = item_ * kWPt + threadIdx.x;
         if (p < pr.P) {
             double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
             double xo[3] = {0, 0, 0};
@@ -1396,13 +1402,15 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     if (threadIdx.x == 0) {
         double a = sS[0];
         for (int i = 1; i < kWPt / 64; i++) a += sS[i];
-        w.partS[blockIdx.x] = a;
+        w.partS[item_] = a;
     }
 }
 
-__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const LbaWide* ws) {
-    const LbaProblem& pr = probs[blockIdx.y];
-    const LbaWide& w = ws[blockIdx.y];
+__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    int win_, item_;
+    if (!xcd_window_item(nwin, win_, item_)) return;
+    const LbaProblem& pr = probs[win_];
+    const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
@@ -1411,8 +1419,8 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const 
     const int tr = ct->cur ^ 1;
     const double* Xp = w_X(pr, tr);
     const SE3* Tp = w.T + tr * pr.K;
-    const int p = blockIdx.x * kWPt + threadIdx.x;
-    const bool padding = (int)blockIdx.x >= w.nblk_pt;   // batched launch: blocks past this window's points only report in
+    const int p = item_ * kWPt + threadIdx.x;
+    const bool padding = item_ >= w.nblk_pt;   // batched launch: blocks past this window's points only report in
     double F = 0;
     if (p < pr.P && !padding) {
         const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
@@ -1437,7 +1445,7 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const 
     if (threadIdx.x == 0 && !padding) {
         double a = sF[0];
         for (int i = 1; i < kWPt / 64; i++) a += sF[i];
-        w.partF[blockIdx.x] = a;
+        w.partF[item_] = a;
     }
 }
 
@@ -2262,13 +2270,13 @@ static int lba_launch(oslam_lba_t* h) {
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
-                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, n0), dim3(kLinThreads), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, ny_xcd), dim3(kLinThreads), 0, st, d_probs, d_ws, n0);
                 hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n0), dim3(64), 0, st, d_probs, d_ws);
                 if (tiles) {
                     hipLaunchKernelGGL(k_w_schur_tiles, dim3(maxWg, n0), dim3(kWinThreads), tiles_lds, st, d_probs, d_ws);
                     hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
                 } else {
-                    hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), n0), dim3(256), 0, st, d_probs, d_ws);
+                    hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
                     hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
                 }
                 if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);
@@ -2276,8 +2284,8 @@ static int lba_launch(oslam_lba_t* h) {
                 if (chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, n0), dim3(kWPt), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, n0), dim3(kWPt), 0, st, d_probs, d_ws);
+                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)

@@ -61,6 +61,22 @@ hipError_t stream_wait(hipStream_t s) {
     return hipEventSynchronize(t.ev);
 }
 
+__global__ void k_copy_to_host(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n16, size_t bytes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t0; i < n16; i += stride) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+    for (size_t i = n16 * 16 + t0; i < bytes; i += stride) dst[i] = src[i];
+}
+hipError_t copy_to_host_async(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    static const bool sdma = getenv("OSLAM_D2H_SDMA") != nullptr;   // A/B knob: the runtime's copy path
+    if (sdma) return hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s);
+    const bool aligned = ((((uintptr_t)dst_pinned) | ((uintptr_t)src_dev)) & 15) == 0;
+    const size_t n16 = aligned ? bytes / 16 : 0, units = n16 + (bytes - n16 * 16);
+    const int blocks = (int)((units + 255) / 256 < 1024 ? (units + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_copy_to_host, dim3(blocks), dim3(256), 0, s, (uint8_t*)dst_pinned, (const uint8_t*)src_dev, n16, bytes);
+    return hipGetLastError();
+}
+
 static inline int cv_round(float v) { return (int)lrintf(v); }     // cvRound: half-to-even
 static inline int cv_round(double v) { return (int)lrint(v); }
 static inline short sat_short(float v) {
