@@ -250,6 +250,10 @@ typedef struct oslam_slam_ops {
      * is refused on this table. */
     int (*frames_rgbd_raw16)(void* ctx, int n, const int32_t* slots, const uint8_t* const* gray, int gray_stride, const uint16_t* const* depth16,
                              int depth_pitch, float depth_factor, int on_device, oslam_slam_frame_t* const* out);
+    /* optional, with register_keyframes: the keyframes (slots[i], kf_ids[i]) were culled (KeyFrame::SetBadFlag, src/KeyFrame.cc:441-509) — no later job names
+     * them (the driver skips bad keyframes wherever the reference does, and ComputeDistinctiveDescriptors skips their observations, src/MapPoint.cc:366): a
+     * table may give their resident records to later keyframes.  Called once per local-mapping pass, after KeyFrameCulling. */
+    int (*release_keyframes)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

@@ -143,6 +143,7 @@ struct Seq {
     std::vector<int> recentAdded;          // mlpRecentAddedMapPoints
     std::vector<int> newKFs;               // mlNewKeyFrames (at most one per step)
     std::vector<int> pendingKF;            // keyframes created in this step, not yet announced to the operator table (register_keyframes)
+    std::vector<int> culledKFs;            // keyframes culled in this pass, not yet announced to the operator table (release_keyframes)
     std::vector<int> counter;              // scratch, indexed by keyframe id
     int64_t st[16] = {0};
     // per-step scratch
@@ -170,7 +171,7 @@ struct Seq {
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
         map = Map();
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
-        localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear();
+        localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear(); culledKFs.clear();
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
@@ -1280,9 +1281,15 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                         if (n >= 3) nRed++;
                     }
                 }
-                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; }
+                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
             }
         });
+    if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
+        std::vector<int32_t> rs, rk;
+        for (int si : who) { Seq& s = *c.seq[si]; for (int k : s.culledKFs) { rs.push_back(si); rk.push_back(k); } s.culledKFs.clear(); }
+        if (!rs.empty() && (rc = c.ops.release_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
+    } else
+        for (int si : who) c.seq[si]->culledKFs.clear();
     { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
     return OSLAM_OK;
 }

@@ -72,6 +72,7 @@ struct HipOps {
     static constexpr int kRecChunk = 256;
     std::vector<uint8_t*> rec_chunks;
     std::vector<std::vector<int>> rec_of_kf;              // [slot][kf id] -> record index or -1
+    long long n_released = 0;                             // records returned by release_keyframes (culled keyframes)
     std::vector<int> free_recs;                           // records of maps that were reset, reused before the store grows
     int n_rec = 0;
     uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
@@ -1000,6 +1001,21 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
     return OSLAM_OK;
 }
 
+// the records of culled keyframes go back to the free list (every operator synchronises before it returns: nothing in flight reads them)
+int h_release_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf_ids) {
+    HipOps* o = (HipOps*)p;
+    for (int i = 0; i < n; i++) {
+        const int slot = slots[i], kf = kf_ids[i];
+        if (slot < 0 || slot >= (int)o->rec_of_kf.size() || kf < 0 || kf >= (int)o->rec_of_kf[slot].size()) continue;
+        const int r = o->rec_of_kf[slot][kf];
+        if (r < 0) continue;
+        o->rec_of_kf[slot][kf] = -1;
+        o->free_recs.push_back(r);
+        o->n_released++;
+    }
+    return OSLAM_OK;
+}
+
 int h_resident_points(void* p) { return ((HipOps*)p)->mp_tab_on ? 1 : 0; }
 
 int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
@@ -1373,7 +1389,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
     return OSLAM_OK;
