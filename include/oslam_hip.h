@@ -398,7 +398,8 @@ volatile int32_t* oslam_lba_stop_flag(oslam_lba_t* h);
  * 0: the round-1 one-workgroup-per-problem kernel (reduced system in global memory), kept as an A/B layout.  Same arithmetic in all three. */
 int oslam_lba_set_mode(oslam_lba_t* h, int wide);
 /* Schur complement of mode 1: 0 = gather of the (W_a, B_b) pairs from memory (one wavefront per 6x6 block), 1 = on chip by tiles of points staged in LDS (one
- * coalesced read of the per-edge blocks per trial), 2 (default) = chosen per call from the mean window size.  Same results to rounding. */
+ * coalesced read of the per-edge blocks per trial), 2 = chosen per call from the mean window size.  Same results to rounding.  The pair lists of mode 0 (the
+ * default) are built on the device once per call (k_w_pair_*); 3 = mode 0 with the lists built by the host (the round-2 path): bit-identical results. */
 int oslam_lba_set_schur(oslam_lba_t* h, int mode);
 /* Kernel timing for bench.py's roofline: HIP events on the handle's stream around the solve kernels of every later call.
  * Returns and clears the accumulated milliseconds / kernel launches, then sets the switch to `enable`. */

@@ -594,6 +594,7 @@ struct LbaWide {
     int nblk_pt;
     const int2* pairs;        // (edge in pose a, edge in pose b) of every point both poses see, grouped by Schur block, point order
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
+    uint16_t* pairM; int2* pairs_w; int* pair_start_w;   // pair lists built on the device (k_w_pair_*): then pairs / pair_start point at pairs_w / pair_start_w
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
     // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
     const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* thr_own; const int* blk_thr; const int* blk_slots;
@@ -879,6 +880,64 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
 // Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
 // wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
 // rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
+// ---- Schur pair lists built on the device (once per call; the host used to spend ~430 us per steady-state window on them and upload 8 bytes per pair) ----
+// Block t = (a, b), a <= b, of the reduced system lists the points both free keyframes see, ascending, as (edge in a, edge in b): exactly the order of the host
+// builder in lba_build (a point has one observation per keyframe), so the sums of k_w_schur do not change by a bit.
+//   k_w_pair_matrix : M[p][a] = 1 + position of the edge of point p in free keyframe a inside the point's edge range (0 = not seen); M is zeroed by the caller
+//   k_w_pair_blocks : one wavefront per block walks the points 64 at a time — FILL = false counts, FILL = true writes the pairs at pair_start[t] + rank
+//   k_w_pair_scan   : one wavefront per window, exclusive scan of the counts into pair_start[0 .. nblk]
+__global__ __launch_bounds__(256) void k_w_pair_matrix(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= pr.E) return;
+    if (!w.pairM) return;
+    const int a = w.blk[pr.e_kf[e]];
+    if (a < 0) return;
+    const int p = pr.e_pt[e];
+    w.pairM[(size_t)p * w.ct->nfree + a] = (uint16_t)(e - pr.pt_start[p] + 1);
+}
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_w_pair_blocks(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaProblem& pr = probs[blockIdx.y];
+    const LbaWide& w = ws[blockIdx.y];
+    if (!w.pairM) return;
+    const int nfree = w.ct->nfree, t = blockIdx.x, lane = threadIdx.x;
+    if (t >= nfree * (nfree + 1) / 2) return;
+    int ba = 0, rem = t;
+    while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
+    const int bb = ba + rem;
+    int base = FILL ? w.pair_start_w[t] : 0;
+    for (int p0 = 0; p0 < pr.P; p0 += 64) {
+        const int p = p0 + lane;
+        int ma = 0, mb = 0;
+        if (p < pr.P) { ma = w.pairM[(size_t)p * nfree + ba]; mb = w.pairM[(size_t)p * nfree + bb]; }
+        const bool has = ma != 0 && mb != 0;
+        const unsigned long long bal = __ballot(has);
+        if (FILL && has) {
+            const int s = pr.pt_start[p];
+            w.pairs_w[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(s + ma - 1, s + mb - 1);
+        }
+        base += __popcll(bal);
+    }
+    if (!FILL && lane == 0) w.pair_start_w[t + 1] = base;   // counts, shifted by one: the scan below turns them into starts in place
+}
+__global__ __launch_bounds__(64) void k_w_pair_scan(const LbaProblem* probs, const LbaWide* ws) {
+    const LbaWide& w = ws[blockIdx.x];
+    if (!w.pairM) return;
+    const int nfree = w.ct->nfree, nblk = nfree * (nfree + 1) / 2, lane = threadIdx.x;
+    int carry = 0;
+    if (lane == 0) w.pair_start_w[0] = 0;
+    for (int t0 = 0; t0 < nblk; t0 += 64) {
+        const int t = t0 + lane;
+        int v = t < nblk ? w.pair_start_w[t + 1] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d, 64); if (lane >= d) v += u; }
+        if (t < nblk) w.pair_start_w[t + 1] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win, t;
     if (!xcd_window_item(nwin, win, t)) return;
@@ -1578,6 +1637,7 @@ struct oslam_lba {
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
     bool owns_strm = true;        // false: the stream of the driver handle this solver belongs to (lba_use_stream)
+    bool device_pairs = true;     // pair lists of the gather Schur built by k_w_pair_* (OSLAM_LBA_HOST_PAIRS=1: by lba_build on the host, the round-2 path)
     long long prof_pre_upload_ns = 0;   // host time of the last lba_launch before its upload (OSLAM_LBA_HOSTPROF)
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
@@ -1599,7 +1659,7 @@ struct oslam_lba {
         size_t o_poses, o_fixed, o_points, o_ekf, o_ept, o_eobs, o_einfo, o_ptstart, o_posestart, o_poseedges, o_pairs, o_pstart;
         size_t o_chunk_kf, o_chunk_e0, o_chunk_n, o_kf_chunk0, o_pt_edge, o_tile_p0, o_tile_s0, o_stg_edge, o_thr_own, o_blk_thr, o_blk_slots;
         size_t o_out_poses, o_out_points, o_out_erase, o_out_stats;   // offsets into the `out` arena
-        int nfree = 0, nblk = 1; size_t npairs = 0;
+        int nfree = 0, nblk = 1; size_t npairs = 0; bool dev_pairs = false;   // dev_pairs: the Schur pair lists are built on the device (npairs = their total)
         int layout = 0;           // 0 point-major edge numbering (compact / wide kernels), 1 keyframe-major (one workgroup per window, lba_win.inc)
         std::vector<int> order;   // edge permutation (kernel numbering -> caller order)
     };
@@ -1746,6 +1806,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
+    if (getenv("OSLAM_LBA_HOST_PAIRS")) h->device_pairs = false;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e);   // 0 = always the pair gather, 1 = always tiles, 2 = per call (default)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
@@ -1777,8 +1838,9 @@ int oslam_lba_set_mode(oslam_lba_t* h, int wide) {
 }
 
 int oslam_lba_set_schur(oslam_lba_t* h, int mode) {
-    if (!h || mode < 0 || mode > 2) { set_error("oslam_lba_set_schur: mode must be 0 (pair gather), 1 (LDS tiles) or 2 (per call)"); return OSLAM_E_INVALID; }
-    h->schur_tiles = mode;
+    if (!h || mode < 0 || mode > 3) { set_error("oslam_lba_set_schur: mode must be 0 (pair gather), 1 (LDS tiles), 2 (per call) or 3 (pair gather, host-built lists)"); return OSLAM_E_INVALID; }
+    h->schur_tiles = mode == 3 ? 0 : mode;
+    h->device_pairs = mode != 3 && !getenv("OSLAM_LBA_HOST_PAIRS");
     return OSLAM_OK;
 }
 
@@ -1924,7 +1986,7 @@ static int lba_build(const oslam_lba_t* h, oslam_lba::Prep& q, int layout, bool 
     std::vector<int> blk(nKF);
     for (int k = 0, nb = 0; k < nKF; k++) blk[k] = fixed[k] ? -1 : nb++;
     auto tof = [&](int x, int y) { return x * nfree - x * (x - 1) / 2 + (y - x); };
-    q.npairs = 0; q.pairs.clear(); q.pstart.clear();
+    q.npairs = 0; q.pairs.clear(); q.pstart.clear(); q.dev_pairs = false;
     if (layout == 0) {
         q.pose_edges.resize(nE);
         std::vector<int> cur(pose_start.begin(), pose_start.end() - 1);
@@ -1943,6 +2005,16 @@ static int lba_build(const oslam_lba_t* h, oslam_lba::Prep& q, int layout, bool 
             for (int p = 0; p < nP; p++) std::sort(q.pt_edge.begin() + pt_start[p], q.pt_edge.begin() + pt_start[p + 1], [&](int x, int y) { return ekf[x] < ekf[y]; });
             const int rc = lba_build_tiles(q, blk, nfree, nP, nE, (size_t)kWinLdsMax, err, errn);
             if (rc) return rc;
+        } else if (want_pairs && h->device_pairs && h->wide == 1) {
+            // the lists are built on the device (k_w_pair_*): the host only needs their total, sum over the points of k (k + 1) / 2 with k = edges in free keyframes
+            size_t tot = 0;
+            for (int p = 0; p < nP; p++) {
+                if (pt_start[p + 1] - pt_start[p] > 65534) return fail(OSLAM_E_CAPACITY, "point %d has more than 65534 observations", p);
+                size_t kf_ = 0;
+                for (int i = pt_start[p]; i < pt_start[p + 1]; i++) kf_ += blk[ekf[i]] >= 0;
+                tot += kf_ * (kf_ + 1) / 2;
+            }
+            q.npairs = tot; q.dev_pairs = true;
         } else if (want_pairs) {   // Schur pair lists: static over the LM iterations (edge levels are checked on the device)
             const int nblk = q.nblk;
             std::vector<int>& pstart = q.pstart;
@@ -2107,13 +2179,14 @@ static int lba_launch(oslam_lba_t* h) {
     size_t work = 0, outb = 0;
     auto takeW = [&](size_t bytes) { const size_t at = work; work += (bytes + 255) & ~(size_t)255; return at; };
     auto takeO = [&](size_t bytes) { const size_t at = outb; outb += (bytes + 255) & ~(size_t)255; return at; };
-    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, chunkC, pairPart, parts; };
+    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, chunkC, pairPart, parts, pairM, pairsW, pstartW; };
     bool tiles = wide && n0 > 0;     // wide layout: Schur complement by tiles when every layout-0 window carries the structures
     for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
     const int nwg_call = std::max(1, std::min(16, (2 * 256 + std::max(n0, 1) - 1) / std::max(n0, 1)));   // workgroups per window: ~2 per CU over the call
     size_t tiles_lds = 0, packed_lds = 0;
     int maxWg = 1, maxSum = 1, min_n6_big = 1 << 30;   // (min_n6_big: the smallest reduced system of the call)
     std::vector<WOff> wo(n);
+    bool any_dev_pairs = false;
     int maxNbPt = 1, maxK = 1, maxE = 1, maxBlk = 1, maxFin = 1, maxInit = 1, max_slots = 0, min_group = 4, max_n6 = 0;
     bool all_lds = true;
     const size_t ctrl_base = takeW(sizeof(LbaCtrl) * std::max(n0, 1));   // contiguous: the host polls all of them with one copy
@@ -2139,7 +2212,10 @@ static int lba_launch(oslam_lba_t* h) {
                     o.parts = takeW((size_t)nwg * q.ngroup * kWinThreads * 42 * 8);
                     tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP));
                     maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
-                } else o.W = takeW(E * 144);
+                } else {
+                    o.W = takeW(E * 144);
+                    if (q.dev_pairs) { o.pairsW = takeW(std::max<size_t>(q.npairs, 1) * 8); o.pstartW = takeW(((size_t)q.nblk + 1) * 4); any_dev_pairs = true; }   // (pairM: one block for the call, below)
+                }
                 if ((int)n6 <= kCholPackedN) packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
                 min_n6_big = std::min(min_n6_big, (int)n6);
             }
@@ -2151,6 +2227,14 @@ static int lba_launch(oslam_lba_t* h) {
         }
         q.o_out_poses = takeO(K * 64); q.o_out_points = takeO(P * 12); q.o_out_erase = takeO(E); q.o_out_stats = takeO(64);
     }
+    // the point x free-keyframe matrices of the device-built pair lists: one contiguous block (one memset per call)
+    const size_t pairM_base = work;
+    if (any_dev_pairs && !tiles)
+        for (int i = 0; i < n; i++) {
+            const oslam_lba::Prep& q = h->prep[i];
+            if (q.layout == 0 && q.dev_pairs) wo[i].pairM = takeW(std::max<size_t>((size_t)q.pr.P * q.nfree, 1) * 2);
+        }
+    const size_t pairM_bytes = work - pairM_base;
     if ((rc = pool_ensure(h->in_d, h->in_off)) || (rc = pool_ensure(h->work_d, work)) || (rc = pool_ensure(h->out_d, outb))) return rc;
     if (outb > h->out_h_cap) {
         if (h->out_h) (void)hipHostFree(h->out_h);
@@ -2199,6 +2283,10 @@ static int lba_launch(oslam_lba_t* h) {
             w.partF = (double*)(Wk + o.partF); w.partS = (double*)(Wk + o.partS); w.partM = (double*)(Wk + o.partM); w.W = (double*)(Wk + o.W);
             w.nblk_pt = div_up(std::max(q.pr.P, 1), kWPt);
             w.pairs = (const int2*)(I + q.o_pairs); w.pair_start = (const int*)(I + q.o_pstart);
+            if (q.dev_pairs && !tiles) {
+                w.pairM = (uint16_t*)(Wk + o.pairM); w.pairs_w = (int2*)(Wk + o.pairsW); w.pair_start_w = (int*)(Wk + o.pstartW);
+                w.pairs = w.pairs_w; w.pair_start = w.pair_start_w;
+            }
             if (tiles) {
                 w.W = nullptr;
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
@@ -2264,6 +2352,14 @@ static int lba_launch(oslam_lba_t* h) {
         const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
         hipLaunchKernelGGL(k_w_init, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
+        if (any_dev_pairs && !tiles) {   // the Schur pair lists of the call, once (k_w_init has numbered the free keyframes)
+            OSLAM_HIP_CHECK(hipMemsetAsync(Wk + pairM_base, 0, pairM_bytes, st));
+            hipLaunchKernelGGL(k_w_pair_matrix, dim3(div_up(maxE, 256), n0), dim3(256), 0, st, d_probs, d_ws);
+            hipLaunchKernelGGL(k_w_pair_blocks<false>, dim3(maxBlk, n0), dim3(64), 0, st, d_probs, d_ws);
+            hipLaunchKernelGGL(k_w_pair_scan, dim3(n0), dim3(64), 0, st, d_probs, d_ws);
+            hipLaunchKernelGGL(k_w_pair_blocks<true>, dim3(maxBlk, n0), dim3(64), 0, st, d_probs, d_ws);
+            launches += 4;
+        }
         // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
         // iteration), so the common case needs a single host round trip; rejected steps add groups of 4.
         const int ny_xcd = n0 >= 8 ? (n0 + 7) / 8 * 8 : n0;   // grid rows of the kernels that map a window to one XCD (xcd_window_item)

@@ -126,7 +126,7 @@ class LocalBundleAdjuster:
         check(self.L.oslam_lba_set_mode(self.h, int(wide)))
 
     def set_schur(self, mode):
-        """Schur complement of the wide mode: 0 pair gather, 1 LDS tiles, 2 chosen per call (include/oslam_hip.h)."""
+        """Schur complement of the wide mode: 0 pair gather (lists built on the device), 1 LDS tiles, 2 chosen per call, 3 pair gather with host-built lists (include/oslam_hip.h)."""
         check(self.L.oslam_lba_set_schur(self.h, C.c_int(mode)))
 
     def set_solver(self, mode):

@@ -204,3 +204,27 @@ def test_lba_s5_large_matches_oracle(oracle):
     so = oracle.local_bundle_adjustment(small["poses"], small["fixed"], small["points"], small["edge_kf"], small["edge_pt"], small["edge_obs"], small["edge_invSigma2"], small["K"])
     _compare(outs[1], so)
     ba.close()
+
+
+def test_device_built_pair_lists_equal_the_host_built_ones():
+    """The Schur pair lists of the gather layout built on the device (k_w_pair_matrix / k_w_pair_blocks / k_w_pair_scan, the default) against the lists built by
+    lba_build on the host (set_schur(3), the round-2 path): same lists in the same order, so every output is bit-identical — one window spread over the GPU, a
+    batch of unequal windows (>= 8: XCD-mapped launch), windows with fixed keyframes and with a point seen by a single free keyframe."""
+    probs = [synth.make_lba_problem(300 + i, K_local=[27, 12, 20, 9, 31, 6, 16, 24, 27, 14][i], K_fixed=[0, 3, 0, 6, 2, 0, 4, 0, 1, 0][i], P=[1500, 400, 900, 300, 1200, 150, 700, 1000, 1400, 500][i],
+                                     track=[13, 6, 9, 5, 11, 4, 8, 10, 12, 7][i], stereo_frac=0.9) for i in range(10)]
+    out = {}
+    for schur in (0, 3):
+        ba = LocalBundleAdjuster(max_batch=16, max_keyframes=64, max_points=8192, max_edges=65536)
+        ba.set_schur(schur)
+        q = probs[0]
+        single = ba.LocalBundleAdjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+        batch = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])
+        small = ba.LocalBundleAdjustmentBatch(probs[:3], probs[0]["K"])     # fewer than 8 windows: the plain launch mapping
+        out[schur] = (single, batch, small)
+        ba.close()
+    def same(a, b):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and tuple(a[3]) == tuple(b[3])
+    same(out[0][0], out[3][0])
+    for i in range(10): same(out[0][1][i], out[3][1][i])
+    for i in range(3): same(out[0][2][i], out[3][2][i])
+    for i in range(3): same(out[0][2][i], out[0][1][i])      # a window's result does not depend on the batch it is solved in
