@@ -291,23 +291,43 @@ struct MpUpdate {
     void add(int seq, int p) { items.push_back({seq, p}); }
     std::vector<int> dstart;
     std::vector<int32_t> ikey;
+    // OSLAM_MPU_PROF=1: wall-clock split of run() summed over all calls of the process (count / pack / operator / scatter), printed at exit
+    struct Prof {
+        std::atomic<long long> ns[4], calls{0}, pts{0}, obs{0};
+        Prof() { for (auto& x : ns) x = 0; }
+        ~Prof() {
+            if (calls.load()) fprintf(stderr, "[mp_update prof] %lld calls, %lld points, %lld observations: count %.1f ms, pack %.1f ms, operator %.1f ms, scatter %.1f ms\n", calls.load(), pts.load(),
+                                      obs.load(), ns[0] * 1e-6, ns[1] * 1e-6, ns[2] * 1e-6, ns[3] * 1e-6);
+        }
+    };
+    static Prof* prof() { static Prof* p = getenv("OSLAM_MPU_PROF") ? new Prof : nullptr; static struct D { ~D() { delete prof(); } } d; return p; }
     int run(Ctx& c, bool do_desc, bool do_normal) {
         const int P = (int)items.size();
         if (P == 0) return OSLAM_OK;
+        Prof* pf = prof();
+        auto t0_ = std::chrono::steady_clock::now();
+        auto lap_ = [&](int k) { if (pf) { auto t1_ = std::chrono::steady_clock::now(); pf->ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1_ - t0_).count(); t0_ = t1_; } };
         // Two observation lists per point: UpdateNormalAndDepth reads every observation (src/MapPoint.cc:441-453), ComputeDistinctiveDescriptors only those
         // whose keyframe is not bad (:362-368).  They differ when a point still observes a culled keyframe: KeyFrame::SetBadFlag erases the observations of
         // the keyframe's own mvpMapPoints only, and a keypoint's slot can have gone to another point (two new points triangulated against the same neighbour
         // keypoint, src/LocalMapping.cc:440-446).
+        // (the counts on the shared workers — after a local BA this pass walks ~10^5 point records and ~10^6 observations at random — then a serial prefix sum)
         start.assign(P + 1, 0); dstart.assign(P + 1, 0);
-        for (int i = 0; i < P; i++) {
-            if (i + kPF < P) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
-            if (i + kPF / 2 < P) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
-            const Map& m = c.seq[items[i].seq]->map;
-            const MapPt& p = m.mps[items[i].p];
-            int n = 0, nd = 0;
-            if (!p.bad) { n = (int)p.obs.size(); for (auto& e : p.obs) nd += !m.kfs[e.first].bad; }
-            start[i + 1] = start[i] + n; dstart[i + 1] = dstart[i] + nd;
-        }
+        const int chunk = 256, nchunks = (P + chunk - 1) / chunk;
+        c.pool->parallel_for(nchunks, [&](int ch) {
+            const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
+            for (int i = i0; i < i1; i++) {
+                if (i + kPF < i1) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
+                if (i + kPF / 2 < i1) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
+                const Map& m = c.seq[items[i].seq]->map;
+                const MapPt& p = m.mps[items[i].p];
+                int n = 0, nd = 0;
+                if (!p.bad) { n = (int)p.obs.size(); for (auto& e : p.obs) nd += !m.kfs[e.first].bad; }
+                start[i + 1] = n; dstart[i + 1] = nd;
+            }
+        });
+        for (int i = 0; i < P; i++) { start[i + 1] += start[i]; dstart[i + 1] += dstart[i]; }
+        lap_(0);
         const size_t total = (size_t)start[P], dtotal = (size_t)dstart[P];
         const bool split = dtotal != total;
         if (do_desc) c.badKFObs.fetch_add((long long)(total - dtotal), std::memory_order_relaxed);
@@ -316,7 +336,6 @@ struct MpUpdate {
         else okey.resize(std::max<size_t>(dtotal, 1) * 3);
         oOw.resize(std::max<size_t>(total, 1) * 3);
         pos.resize((size_t)P * 3); owref.resize((size_t)P * 3); lsf.resize(P);
-        const int chunk = 256, nchunks = (P + chunk - 1) / chunk;
         c.pool->parallel_for(nchunks, [&](int ch) {
             const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
             for (int i = i0; i < i1; i++) {
@@ -355,6 +374,7 @@ struct MpUpdate {
                 lsf[i] = lf;
             }
         });
+        lap_(1);
         best.resize(P); outdesc.resize((size_t)P * 32); out5.resize((size_t)P * 5);
         oslam_job_mp_update_t j;
         j.P = P; j.obs_start = start.data(); j.obs_desc = keyed ? nullptr : odesc.data(); j.obs_Ow = oOw.data(); j.Pos = pos.data(); j.OwRef = owref.data();
@@ -365,6 +385,7 @@ struct MpUpdate {
         j.items = ikey.data();
         const int rc = keyed ? c.ops.mp_update_keyed(c.ops.ctx, &j, okey.data()) : c.ops.mp_update(c.ops.ctx, &j);
         if (rc) return rc;
+        lap_(2);
         // (an item can be listed twice after fusions; both copies carry the same result, so concurrent writers store the same bytes)
         c.pool->parallel_for(nchunks, [&](int ch) {
             const int i0 = ch * chunk, i1 = std::min(P, i0 + chunk);
@@ -379,6 +400,8 @@ struct MpUpdate {
                 if (do_desc && do_normal) { p.updVer = p.obsVer; p.updStep = c.mapStep; }   // (nothing touches the observation lists while a batch runs)
             }
         });
+        lap_(3);
+        if (pf) { pf->calls++; pf->pts += P; pf->obs += (long long)total; }
         return OSLAM_OK;
     }
 };
@@ -1118,19 +1141,23 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         });
         if ((rc = fuse_round(true, 0))) return rc;
         // update points of the current keyframe (:517-531) and its connections
-        upd.clear();
-        for (int si : who) {
-            Seq& s = *c.seq[si];
+        pool.parallel_for(nW, [&](int w) {
+            Seq& s = *c.seq[who[w]];
             // The reference recomputes descriptor and normal of every point of the keyframe here.  A point that went through a full update earlier in THIS
             // pass (ProcessNewKeyFrame, triangulation) and whose observation list has not changed since would get the same result: its position, the poses and
             // the bad flags of the observing keyframes only change later in the pass (local BA, culling).
-            for (int p : s.map.kfs[s.curKF].mp) {
+            s.updList.clear();
+            const std::vector<int>& kmp = s.map.kfs[s.curKF].mp;
+            for (size_t i = 0; i < kmp.size(); i++) {
+                prefetch_ahead(s.map.mps, kmp, i, kmp.size());
+                const int p = kmp[i];
                 if (p < 0) continue;
                 const MapPt& mp = s.map.mps[p];
                 if (mp.bad || (mp.updStep == c.mapStep && mp.updVer == mp.obsVer)) continue;
-                upd.add(si, p);
+                s.updList.push_back(p);
             }
-        }
+        });
+        merge_upd();   // (sequence order, then keypoint order: the order of the serial loop this replaces)
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
         if ((rc = upd.run(c, true, true))) return rc;
         { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }

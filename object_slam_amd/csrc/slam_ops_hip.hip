@@ -73,6 +73,7 @@ struct HipOps {
     std::vector<uint8_t*> rec_chunks;
     std::vector<std::vector<int>> rec_of_kf;              // [slot][kf id] -> record index or -1
     long long n_released = 0;                             // records returned by release_keyframes (culled keyframes)
+    std::vector<int32_t> mpu_rec;                         // scratch of mp_update_impl: (record, keypoint) of every observation
     std::vector<int> free_recs;                           // records of maps that were reset, reused before the store grows
     int n_rec = 0;
     uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
@@ -822,7 +823,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     Layout L;
     // with resident keyframes the observations' descriptors are gathered on the device from (record, keypoint) pairs: 8 bytes per observation travel
     // instead of 32, and the caller did not have to collect them
-    std::vector<int32_t> rec;
+    std::vector<int32_t>& rec = o->mpu_rec;   // (keeps its capacity: 8 bytes per observation, up to ~10 MB per call after a local BA)
     bool keyed = obs_key && j->do_desc && dtotal > 0;
     if (keyed) {   // (hundreds of thousands of observations per call: the lookup runs on the shared workers)
         rec.resize(2 * dtotal);
