@@ -26,6 +26,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# One hardware queue per driver handle.  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES queues (default 4) and a queue executes its packets in
+# order whatever stream they came from: with 8 handles, two handles shared a queue and the short kernels of one waited behind the ~180 local-BA launches of the
+# other (the MapPoint-update operator spent 3.5x its kernels' time waiting).  Must be in the environment before the HIP runtime starts (the first import of
+# torch): measured 24.2 k against 22.7 k frames/s in the steady state (same box); 12 / 16 queues give 24.2 / 24.4 k.  INTEGRATION.md names it for host applications.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 matrix (= vector) peak, AMD datasheet: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk;
                            # MI355X_MICROARCH.md lists no fp64 row; tools/mfma_f64_rate.py measures the issue rate on the box)
@@ -534,7 +540,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu,
                "host_inputs": (summ.get("post") or {}).get("host_inputs") if isinstance(summ.get("post"), dict) else None,
                "cold_start": cold, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
-               "input_render_s": round(t_gen, 1), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
+               "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <atomic>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -97,7 +98,9 @@ struct HipOps {
     int ensure_mp_records(int slot, size_t need) {
         if ((int)mp_tab.size() < S) { mp_tab.resize(S, nullptr); mp_cap.resize(S, 0); }
         if (need <= mp_cap[slot]) return OSLAM_OK;
-        const size_t ncap = std::max<size_t>(need + need / 2, 4096);
+        // 16 K records (1 MB) per sequence to start with, doubling: a growth costs an allocation, a device copy, a stream synchronisation and a free (measured:
+        // 0.9 ms each, 22 s of the 64 s the MapPoint-update operator took in a 225-step run of 8 x 1024 sequences when the tables started at 4 K records x 1.5)
+        const size_t ncap = std::max<size_t>(need * 2, 16384);
         uint8_t* nb = nullptr;
         OSLAM_HIP_CHECK(hipMalloc((void**)&nb, ncap * 64));
         if (mp_tab[slot]) {
@@ -812,10 +815,24 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
 int h_mp_update(void* p, oslam_job_mp_update_t* j) { return mp_update_impl((HipOps*)p, j, nullptr); }
 int h_mp_update_keyed(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) { return mp_update_impl((HipOps*)p, j, obs_key); }
 
+// OSLAM_MPU_PROF=1: wall-clock split of the operator summed over all calls of the process, printed at exit
+struct MpuOpProf {
+    std::atomic<long long> ns[6];
+    MpuOpProf() { for (auto& x : ns) x = 0; }
+    ~MpuOpProf() {
+        fprintf(stderr, "[mp_update operator prof] record lookup %.1f ms, table growth / sync %.1f ms, staging %.1f ms, enqueue %.1f ms, wait %.1f ms, copy out %.1f ms\n", ns[0] * 1e-6, ns[1] * 1e-6,
+                ns[2] * 1e-6, ns[3] * 1e-6, ns[4] * 1e-6, ns[5] * 1e-6);
+    }
+};
+static MpuOpProf* mpu_op_prof() { static MpuOpProf* p = getenv("OSLAM_MPU_PROF") ? new MpuOpProf : nullptr; static struct D { ~D() { delete mpu_op_prof(); } } d; return p; }
+
 static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key) {
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     const size_t P = j->P;
     if (P == 0) return OSLAM_OK;
+    MpuOpProf* pf = mpu_op_prof();
+    auto t0_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](int k) { if (pf) { auto t1_ = std::chrono::steady_clock::now(); pf->ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1_ - t0_).count(); t0_ = t1_; } };
     const size_t total = (size_t)j->obs_start[P];
     // the descriptor selection has its own observation list when some observations sit in culled keyframes (oslam_job_mp_update_t::desc_start)
     const int32_t* dstart = j->desc_start ? j->desc_start : j->obs_start;
@@ -842,6 +859,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
         if (missing.load() > 0) keyed = false;
         if (!keyed && !j->obs_desc) { oslam::set_error("mp_update: observation of a keyframe that is not resident"); return OSLAM_E_INVALID; }
     }
+    lap_(0);
     const bool table = o->mp_tab_on && j->items != nullptr;
     if (table) {   // room for the records of the points named (ids grow with the map)
         std::vector<int> mx(o->S, -1);
@@ -853,6 +871,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
         for (int sl = 0; sl < o->S; sl++) if (mx[sl] >= 0) OPS_CHECK(o->ensure_mp_records(sl, (size_t)mx[sl] + 1));
         OPS_CHECK(o->sync_mp_table());
     }
+    lap_(1);
     const size_t oItems = L.take(table ? 8 * P : 0);
     const size_t oStart = L.take(4 * (P + 1)), oDStart = L.take(j->desc_start ? 4 * (P + 1) : 0), oRec = L.take(keyed ? 8 * dtotal : 0), oOw = L.take(12 * total),
                  oPos = L.take(12 * P), oRef = L.take(12 * P), oLsf = L.take(4 * P), oDescUp = L.take(keyed ? 0 : 32 * dtotal);
@@ -868,6 +887,7 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     if (keyed) memcpy(U + oRec, rec.data(), 8 * dtotal);
     else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * dtotal);
     if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
+    lap_(2);
     OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
     o->t_begin();
     if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)dtotal, Dv + oDesc, o->strm));
@@ -889,10 +909,13 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
         OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(Dv + oItems), o->d_mp_tab, (const int32_t*)(Dv + oStart), (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)),
                                               (const float*)(Dv + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
     o->t_end();
+    lap_(3);
     OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    lap_(4);
     o->t_collect(6, (keyed ? 1 : 0) + (j->do_desc ? 2 : 0) + (j->do_normal ? 1 : 0) + (table ? 1 : 0), (double)dtotal);
     if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
     if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
+    lap_(5);
     return OSLAM_OK;
 }
 
