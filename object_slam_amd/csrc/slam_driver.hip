@@ -160,7 +160,7 @@ struct Seq {
     std::vector<Obj3D> obj3ds;
     std::map<int, int> objOfTrack;
     int64_t sem[8] = {0};
-    int64_t lbaFixedDropped = 0;           // (always 0: local-BA windows are no longer capped; kept for the statistics layout)
+    int64_t lbaFixedDropped = 0;           // local-BA windows skipped because they had more than 128 free keyframes (the operator's bound)
     int64_t lbaWin[4] = {0, 0, 0, 0};      // local-BA window sizes summed over the sequence's windows: local keyframes, fixed keyframes, points, edges
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
@@ -1206,7 +1206,14 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     }
                 }
             }
-            // (a window with more than 128 covisible LOCAL keyframes is refused by the operator with OSLAM_E_CAPACITY)
+            // A window with more than 128 FREE keyframes (768 unknowns) is beyond the local-BA operator (OSLAM_E_CAPACITY).  The reference has no such bound; rather
+            // than failing the lockstep step of every sequence of the handle, THIS sequence skips this local BA (counted: oslam_slam_lba_window_stats, last
+            // field) — its map stays consistent, the next keyframe tries again.
+            {
+                int nFreeKF = 0;
+                for (int q = 0; q < W.nLocal; q++) nFreeKF += W.kfs[q] != 0;
+                if (nFreeKF > 128) { s.lbaFixedDropped++; W.si = -1; return; }
+            }
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
             W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());
