@@ -938,6 +938,15 @@ __global__ __launch_bounds__(64) void k_w_pair_scan(const LbaProblem* probs, con
     }
 }
 
+// x + the value of another lane of its quad (DPP quad_perm control CTRL), for fp64 as two 32-bit moves
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win, t;
     if (!xcd_window_item(nwin, win, t)) return;
@@ -957,6 +966,8 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
+    // (all 36 operand loads of a pair are issued together: the kernel is a latency-bound gather and lives on the loads in flight per wavefront — consuming B_b
+    // three doubles at a time to fit four wavefronts per SIMD was 25-60 % slower: 174 us at three, 220 us at four against 139 us at two)
     double bsv[6] = {0, 0, 0, 0, 0, 0};
     for (int q = w.pair_start[t] + lane; q < w.pair_start[t + 1]; q += 64) {
         const int2 pe = w.pairs[q];
@@ -978,23 +989,29 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
             for (int j = 0; j < 6; j++)
                 acc[i * 6 + j] += BD[i * 3] * B2[j * 3] + BD[i * 3 + 1] * B2[j * 3 + 1] + BD[i * 3 + 2] * B2[j * 3 + 2];
     }
-    // Sum of the 64 lanes' partial blocks through LDS: lane l stores its 36 (+6) partials as column l of a [42][65] array (rows skewed by one double: the
-    // row-wise reads below are bank-conflict free), then lane i < 42 adds row i in lane order with four running sums.  (36 butterfly reductions by
-    // ds_bpermute moved ~6x the bytes through the LDS crossbar.)
-    __shared__ double red[42 * 65];
+    // Sum of the 64 lanes' partial blocks: first inside every quad of lanes by two DPP quad-permute steps (full-rate cross-lane moves, no LDS), then the 16
+    // quad sums of each of the 36 (+6) entries through a [42][17] LDS array (rows skewed by one double: conflict-free row reads), added in lane order by
+    // lane i < 42: 5.7 KB of LDS per wavefront (the first version reduced by 36 ds_bpermute butterflies, the second through a [42][65] array that capped
+    // the CU at 7 wavefronts; the registers allow 8).
+    __shared__ double red[42 * 17];
+    auto quad_sum = [](double v) {
+        v += dpp_quad_f64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+        v += dpp_quad_f64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+        return v;
+    };
 #pragma unroll
-    for (int i = 0; i < 36; i++) red[i * 65 + lane] = acc[i];
+    for (int i = 0; i < 36; i++) { const double q4 = quad_sum(acc[i]); if ((lane & 3) == 0) red[i * 17 + (lane >> 2)] = q4; }
     if (diag) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) red[(36 + i) * 65 + lane] = bsv[i];
+        for (int i = 0; i < 6; i++) { const double q4 = quad_sum(bsv[i]); if ((lane & 3) == 0) red[(36 + i) * 17 + (lane >> 2)] = q4; }
     }
     __syncthreads();
     double mine = 0;
     if (lane < (diag ? 42 : 36)) {
-        const double* row = red + lane * 65;
+        const double* row = red + lane * 17;
         double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
+        for (int k = 0; k < 16; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
         mine = (s0 + s1) + (s2 + s3);
     }
     if (lane < 36) {   // lanes 0..35 write one entry each
