@@ -888,26 +888,34 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     else if (j->do_desc) memcpy(U + oDesc, j->obs_desc, 32 * dtotal);
     if (j->do_normal) { memcpy(U + oOw, j->obs_Ow, 12 * total); memcpy(U + oPos, j->Pos, 12 * P); memcpy(U + oRef, j->OwRef, 12 * P); memcpy(U + oLsf, j->levelScaleFactor, 4 * P); }
     lap_(2);
-    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    // The job block is read by the kernels where it is (pinned, mapped into the device's address space) unless it carries the observations' descriptors, which
+    // k_distinctive reads many times: every array of the keyed form is read once or twice, and the copy engine hop + its dependency cost more than the PCIe
+    // reads (Fuse: +4.4 % frames/s, same box).  Results come back through the copy kernel for the same reason.  OSLAM_SLAM_MPU_UPLOAD=1: the staged path.
+    static const bool force_upload = getenv("OSLAM_SLAM_MPU_UPLOAD") != nullptr;
+    // (only the SMALL jobs — the per-round descriptor updates of SearchInNeighbors: the large ones after a local BA read 12 bytes per observation, their kernels
+    // then hold the device 20 % longer and the whole bench loses 4 %)
+    const bool upload = force_upload || (j->do_desc && !keyed) || in_bytes > (size_t)(getenv("OSLAM_SLAM_MPU_ZC_BYTES") ? atol(getenv("OSLAM_SLAM_MPU_ZC_BYTES")) : 262144);
+    const uint8_t* In = upload ? Dv : U;
+    if (upload) OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
     o->t_begin();
-    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(Dv + oRec), (int)dtotal, Dv + oDesc, o->strm));
+    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(In + oRec), (int)dtotal, Dv + oDesc, o->strm));
     Layout R;
     const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
     OPS_CHECK(o->ensure_dn(R.off));
     if (j->do_desc) {
         OSLAM_HIP_CHECK(hipMemsetAsync(Dv + oOut, 0, 32 * P, o->strm));
-        OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rBest, Dv + oBest, 4 * P, hipMemcpyDeviceToHost, o->strm));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut, Dv + oOut, 32 * P, hipMemcpyDeviceToHost, o->strm));
+        OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(In + (j->desc_start ? oDStart : oStart)), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h + rBest, Dv + oBest, 4 * P, o->strm));
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h + rOut, Dv + oOut, 32 * P, o->strm));
     }
     if (j->do_normal) {
-        OPS_CHECK(oslam_mp_update_normal_depth_device((int)P, (const float*)(Dv + oPos), (const int32_t*)(Dv + oStart), (const float*)(Dv + oOw), (const float*)(Dv + oRef),
-                                                      (const float*)(Dv + oLsf), o->scale[o->cfg.nLevels - 1], (float*)(Dv + oOut5), o->strm));
-        OSLAM_HIP_CHECK(hipMemcpyAsync(o->dn_h + rOut5, Dv + oOut5, 20 * P, hipMemcpyDeviceToHost, o->strm));
+        OPS_CHECK(oslam_mp_update_normal_depth_device((int)P, (const float*)(In + oPos), (const int32_t*)(In + oStart), (const float*)(In + oOw), (const float*)(In + oRef),
+                                                      (const float*)(In + oLsf), o->scale[o->cfg.nLevels - 1], (float*)(Dv + oOut5), o->strm));
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h + rOut5, Dv + oOut5, 20 * P, o->strm));
     }
     if (table)
-        OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(Dv + oItems), o->d_mp_tab, (const int32_t*)(Dv + oStart), (const int32_t*)(Dv + (j->desc_start ? oDStart : oStart)),
-                                              (const float*)(Dv + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
+        OPS_CHECK(oslam_mp_table_write_device((int)P, (const int32_t*)(In + oItems), o->d_mp_tab, (const int32_t*)(In + oStart), (const int32_t*)(In + (j->desc_start ? oDStart : oStart)),
+                                              (const float*)(In + oPos), (const float*)(Dv + oOut5), Dv + oOut, j->do_desc, j->do_normal, o->strm));
     o->t_end();
     lap_(3);
     OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
@@ -1234,10 +1242,14 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
             oslam_kf_grid_ref_t& ref = ((oslam_kf_grid_ref_t*)(U + oRef))[i];
             ref.cell_end = o->rec_cell_end(rec[i]); ref.cand = o->rec_cand(rec[i]); ref.desc = o->rec_desc(rec[i]);
         });
-        OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, head, hipMemcpyHostToDevice, o->strm));
+        // The job block (~5 KB per job) is read by the kernel where it is — the pinned staging block is mapped into the device's address space — instead of
+        // being copied first: one dependent copy-engine hop less per SearchInNeighbors round (OSLAM_SLAM_FUSE_UPLOAD=1 restores the copy: A/B knob).
+        static const bool upload = getenv("OSLAM_SLAM_FUSE_UPLOAD") != nullptr;
+        const uint8_t* In = upload ? Dv : U;
+        if (upload) OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, head, hipMemcpyHostToDevice, o->strm));
         o->t_begin();
-        OPS_CHECK(oslam_fuse_search_device(n, (int)st, (const oslam_kf_grid_ref_t*)(Dv + oRef), (const int32_t*)(Dv + oSl), (const int32_t*)(Dv + oM), (const int32_t*)(Dv + oIds),
-                                           Dv + oEx, o->d_mp_tab, (const float*)(Dv + oT), (const float*)(Dv + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale,
+        OPS_CHECK(oslam_fuse_search_device(n, (int)st, (const oslam_kf_grid_ref_t*)(In + oRef), (const int32_t*)(In + oSl), (const int32_t*)(In + oM), (const int32_t*)(In + oIds),
+                                           In + oEx, o->d_mp_tab, (const float*)(In + oT), (const float*)(In + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale,
                                            o->invSigma2, o->cfg.nLevels, (int32_t*)(Dv + oQm), o->strm));
         o->t_end();
         OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, Dv + oQm, 4 * st * B, o->strm));

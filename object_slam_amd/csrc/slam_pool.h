@@ -82,7 +82,7 @@ public:
         if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
         work(b);
         auto finished = [&] { return b.finished.load(std::memory_order_acquire) == b.n && b.users.load(std::memory_order_acquire) == 0; };
-        for (int spin = 0; spin < kSpin && !finished(); spin++) relax();
+        for (int spin = 0, ns = spin_iters(); spin < ns && !finished(); spin++) relax();
         std::unique_lock<std::mutex> lk(m_);
         while (!finished()) done_.wait_for(lk, std::chrono::microseconds(100));
         for (size_t i = 0; i < active_.size(); i++)
@@ -90,7 +90,8 @@ public:
     }
 
 private:
-    static constexpr int kSpin = 4000;   // ~30-60 us of polling
+    // polling iterations before a worker (or an owner waiting for its batch) sleeps: ~30-60 us by default; OSLAM_POOL_SPIN overrides (A/B knob)
+    static int spin_iters() { static const int n = [] { const char* e = getenv("OSLAM_POOL_SPIN"); const int v = e ? atoi(e) : 4000; return v < 1 ? 1 : v; }(); return n; }
     static void relax() {
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -123,7 +124,7 @@ private:
                     const unsigned long seen = epoch_.load(std::memory_order_acquire);
                     lk.unlock();
                     bool changed = false;
-                    for (int spin = 0; spin < kSpin; spin++) {
+                    for (int spin = 0, ns = spin_iters(); spin < ns; spin++) {
                         if (epoch_.load(std::memory_order_acquire) != seen) { changed = true; break; }
                         relax();
                     }
