@@ -548,6 +548,14 @@ def main():
         dist.destroy_process_group()
 
 
+def _lba_traffic():
+    """Mean memory-side bytes per launch of an LM trial of the local-BA kernels (committed PMC summary; None when it is missing)."""
+    try:
+        return int(json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_lba_traffic.json")))["mean_bytes_per_launch_of_a_trial"])
+    except Exception:
+        return None
+
+
 def _mfma_counters():
     """MFMA counters of the matrix-core reduced-system solver from the committed rocprofv3 --pmc pass of tools/lba_mfma_pmc.py (S5-large, n = 240, and 40
     driver-shaped windows of 34 free keyframes, n = 204; SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r03_pmc_lba_mfma.json)."""
@@ -594,7 +602,10 @@ def roofline_of(k, summ, stereo):
     return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4; the kernels of this group issue "
             "v_fma_f64 / v_mul_f64 / v_add_f64 — no MFMA instruction at these system sizes (the matrix-core Cholesky serves reduced systems beyond the LDS-resident size)",
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
-            "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else None, "launch_us": round(ms / launches * 1e3, 1),
+            "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else _lba_traffic(), "launch_us": round(ms / launches * 1e3, 1),
+            "traffic_note": None if bound == "hbm" else "memory-side bytes per launch of the local-BA kernels (mean over the 8 launches of an LM trial) from the committed rocprofv3 "
+            "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r03_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
+            "calls of this run carry ~82 windows: scale by the windows per call",
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
             "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4), "mfma": _mfma_counters(),
             "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "

@@ -851,6 +851,10 @@ __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
 // (block, edge) pair inside the Schur kernel
 // (Writing W_e inside k_w_lin for the iterations whose lambda is known beforehand — the four lanes of a point hold its complete Hll — was measured: k_w_lin
 // 107 -> 160 us, this kernel 73 -> 14 us per trial of 40 steady-state windows, bit-identical results: no gain, not kept.)
+// The 144-byte block of an edge is computed by one lane, but a lane-per-block store (nine 16-byte pieces at a stride of 144 bytes across the lanes) reached
+// the memory side as 2.5x the bytes (rocprofv3 WRITE_SIZE 185 MB per launch of 40 windows against 75 MB of blocks: profiles/r03_pmc_lba_traffic.json): the blocks
+// of the workgroup's 256 consecutive edges are contiguous, so they go through LDS and out as 16 bytes per lane, consecutive lanes consecutive addresses.
+// (Inactive edges — outliers, fixed keyframes — get whatever the LDS held: nothing reads their W.)
 __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -858,30 +862,39 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
     const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
-    const int e = item_ * 256 + threadIdx.x;
-    if (e >= pr.E || pr.level[e] != 0 || w.blk[pr.e_kf[e]] < 0) return;
-    const double lambda = ct->lambda;
-    const int p = pr.e_pt[e];
-    double D[9], Di[9];
-    const double* H = pr.Hll + (long long)p * 9;
+    const int e0 = item_ * 256;
+    if (e0 >= pr.E) return;
+    __shared__ double sW[256 * 19];   // 19: one double of padding per block (18 would put the lanes of a wavefront on 16 of the 64 banks)
+    const int e = e0 + threadIdx.x;
+    if (e < pr.E && pr.level[e] == 0 && w.blk[pr.e_kf[e]] >= 0) {
+        const double lambda = ct->lambda;
+        const int p = pr.e_pt[e];
+        double D[9], Di[9];
+        const double* H = pr.Hll + (long long)p * 9;
 #pragma unroll
-    for (int i = 0; i < 9; i++) D[i] = H[i];
-    D[0] += lambda; D[4] += lambda; D[8] += lambda;
-    inv3(D, Di);
-    const double* Ba = pr.Hpl + (long long)e * 18;
-    double* We = w.W + (long long)e * 18;
+        for (int i = 0; i < 9; i++) D[i] = H[i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        inv3(D, Di);
+        const double* Ba = pr.Hpl + (long long)e * 18;
+        double* We = sW + threadIdx.x * 19;
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
-        We[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
-        We[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
-        We[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+        for (int i = 0; i < 6; i++) {
+            const double b0 = Ba[i * 3], b1 = Ba[i * 3 + 1], b2v = Ba[i * 3 + 2];
+            We[i * 3] = b0 * Di[0] + b1 * Di[3] + b2v * Di[6];
+            We[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
+            We[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
+        }
+    }
+    __syncthreads();
+    const int nE = min(256, pr.E - e0);
+    double2* out = (double2*)(w.W + (long long)e0 * 18);   // (e0 * 144 bytes: 16-byte aligned)
+    for (int k = threadIdx.x; k < nE * 9; k += 256) {
+        const int blk = k / 9, part = k - blk * 9;
+        const double* src = sW + blk * 19 + part * 2;
+        out[k] = make_double2(src[0], src[1]);
     }
 }
 
-// Reduced camera system: Hs(a,b) = [a==b](Hpp_a + lambda I) - sum_p W_ap B_bp^T over the points both keyframes see, one
-// wavefront per block a <= b walking the host-built pair list (two dependent loads per term instead of an edge-list scan);
-// rhs column: bp_a - sum_p W_ap bl_p.  Fixed summation order: lane-strided partial sums, then the shuffle tree.
 // ---- Schur pair lists built on the device (once per call; the host used to spend ~430 us per steady-state window on them and upload 8 bytes per pair) ----
 // Block t = (a, b), a <= b, of the reduced system lists the points both free keyframes see, ascending, as (edge in a, edge in b): exactly the order of the host
 // builder in lba_build (a point has one observation per keyframe), so the sums of k_w_schur do not change by a bit.
