@@ -401,6 +401,8 @@ def main():
 
     kt = {}
 
+    mem_gb = {}
+
     def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None):
         snap = {}
 
@@ -443,6 +445,11 @@ def main():
         summ["local_map_reuse_frac"] = round(sum(r[0] for r in reuse) / max(1, sum(r[1] for r in reuse)), 4)
         summ["host_threads_per_handle"] = threads
         summ["post"] = extra.get("post")
+        try:   # device memory in use while the leg's systems are alive (maps, resident records, extractor buffers, local-BA arenas, the input images)
+            free_b, total_b = torch.cuda.mem_get_info(device)
+            mem_gb[tag] = round((total_b - free_b) / 2**30, 1)
+        except Exception:
+            mem_gb[tag] = None
         for sy in systems:
             sy.close()
         return summ, rec
@@ -540,7 +547,7 @@ def main():
                "roofline": roof, "cpu_baseline": cpu,
                "host_inputs": (summ.get("post") or {}).get("host_inputs") if isinstance(summ.get("post"), dict) else None,
                "cold_start": cold, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
-               "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
+               "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "device_mem_used_gb_after_headline": mem_gb.get("head"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
