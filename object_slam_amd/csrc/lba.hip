@@ -984,14 +984,20 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
     // (all 36 operand loads of a pair are issued together: the kernel is a latency-bound gather and lives on the loads in flight per wavefront — consuming B_b
     // three doubles at a time to fit four wavefronts per SIMD was 25-60 % slower: 174 us at three, 220 us at four against 139 us at two)
     double bsv[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = w.pair_start[t] + lane; q < w.pair_start[t + 1]; q += 64) {
-        const int2 pe = w.pairs[q];
-        if (pr.level[pe.x] != 0 || pr.level[pe.y] != 0) continue;
+    const int q_end = w.pair_start[t + 1];
+    int2 pe_next = make_int2(0, 0);
+    if (w.pair_start[t] + lane < q_end) pe_next = w.pairs[w.pair_start[t] + lane];
+    for (int q = w.pair_start[t] + lane; q < q_end; q += 64) {
+        const int2 pe = pe_next;
+        if (q + 64 < q_end) pe_next = w.pairs[q + 64];   // the next round's list entry travels while this round's operands do
+        // (the operand loads do not wait for the two level bytes: all 38 loads of a pair are in flight together, the test only gates the sums)
+        const uint8_t la = pr.level[pe.x], lb = pr.level[pe.y];
         const double* Wa = w.W + (long long)pe.x * 18;
         const double* Bb = pr.Hpl + (long long)pe.y * 18;
         double BD[18], B2[18];
 #pragma unroll
         for (int i = 0; i < 18; i++) { BD[i] = Wa[i]; B2[i] = Bb[i]; }
+        if (la != 0 || lb != 0) continue;
         if (diag) {
             const double* bl = pr.bl + (long long)pr.e_pt[pe.x] * 3;
             const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
