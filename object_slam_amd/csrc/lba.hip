@@ -1521,15 +1521,21 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const 
     double F = 0;
     if (p < pr.P && !padding) {
         const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
-        for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
-            if (pr.level[e] != 0) continue;
-            const int a = pr.e_kf[e];
-            const float ur = pr.e_obs[e * 3 + 2];
+        // (an edge's inputs are loaded one round ahead and before its level byte is tested: the loop is a chain of dependent loads per edge otherwise)
+        const int e1 = pr.pt_start[p + 1];
+        int e = pr.pt_start[p];
+        uint8_t lv_n = 1; int a_n = 0; float o0_n = 0, o1_n = 0, o2_n = 0, inf_n = 0;
+        if (e < e1) { lv_n = pr.level[e]; a_n = pr.e_kf[e]; o0_n = pr.e_obs[e * 3]; o1_n = pr.e_obs[e * 3 + 1]; o2_n = pr.e_obs[e * 3 + 2]; inf_n = pr.e_info[e]; }
+        for (; e < e1; e++) {
+            const uint8_t lv = lv_n; const int a = a_n; const float o0 = o0_n, o1 = o1_n, ur = o2_n, inf = inf_n;
+            if (e + 1 < e1) { lv_n = pr.level[e + 1]; a_n = pr.e_kf[e + 1]; o0_n = pr.e_obs[e * 3 + 3]; o1_n = pr.e_obs[e * 3 + 4]; o2_n = pr.e_obs[e * 3 + 5]; inf_n = pr.e_info[e + 1]; }
+            const SE3 Ta = Tp[a];
+            if (lv != 0) continue;
             const bool stereo = !(ur < 0);
-            const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
+            const double ob[3] = {(double)o0, (double)o1, (double)ur};
             double pc[3], er[3];
-            se3_map(Tp[a], Xw, pc);
-            const double c2 = edge_error(cam, pc, ob, stereo, (double)pr.e_info[e], er);
+            se3_map(Ta, Xw, pc);
+            const double c2 = edge_error(cam, pc, ob, stereo, (double)inf, er);
             pr.chi2[e] = c2;
             if (robust) { double r0, r1; huber(c2, stereo ? dStereo : dMono, r0, r1); F += r0; }
             else F += c2;
