@@ -1463,10 +1463,14 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
             double xo[3] = {0, 0, 0};
             if (ok2) {
                 for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
-                    if (pr.level[e] != 0) continue;
+                    // (B_e is requested before the level byte and the keyframe's block index are known: its address depends on neither)
+                    const double* Bg = pr.Hpl + (long long)e * 18;
+                    double B[18];
+#pragma unroll
+                    for (int i = 0; i < 18; i++) B[i] = Bg[i];
+                    const uint8_t lv = pr.level[e];
                     const int ba = w.blk[pr.e_kf[e]];
-                    if (ba < 0) continue;
-                    const double* B = pr.Hpl + (long long)e * 18;
+                    if (lv != 0 || ba < 0) continue;
                     const double* xa = pr.xp + 6 * ba;
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
