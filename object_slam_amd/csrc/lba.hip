@@ -704,12 +704,14 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         if (p < pr.P) {
             const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
             for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
-                if (pr.level[e] != 0) continue;
+                // (the edge's inputs are requested together with its level byte, not after it)
+                const uint8_t lv = pr.level[e];
                 const int a = pr.e_kf[e];
-                const float ur = pr.e_obs[e * 3 + 2];
+                const float o0 = pr.e_obs[e * 3], o1 = pr.e_obs[e * 3 + 1], ur = pr.e_obs[e * 3 + 2], inf = pr.e_info[e];
+                if (lv != 0) continue;
                 const bool stereo = !(ur < 0);
-                const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
-                const double info = (double)pr.e_info[e];
+                const double ob[3] = {(double)o0, (double)o1, (double)ur};
+                const double info = (double)inf;
                 double pc[3], er[3], Jp[18], Jx[9];
                 se3_map(T[a], Xw, pc);
                 const double c2 = edge_error(cam, pc, ob, stereo, info, er);
@@ -778,13 +780,14 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
     for (int k = 0; k < 27; k++) acc[k] = 0;
     for (int q = pr.pose_start[a] + tid; q < pr.pose_start[a + 1]; q += kLinThreads) {
         const int e = pr.pose_edges[q];
-        if (pr.level[e] != 0) continue;
+        const uint8_t lv = pr.level[e];
         const int p = pr.e_pt[e];
+        const float o0 = pr.e_obs[e * 3], o1 = pr.e_obs[e * 3 + 1], ur = pr.e_obs[e * 3 + 2], inf = pr.e_info[e];
         const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
-        const float ur = pr.e_obs[e * 3 + 2];
+        if (lv != 0) continue;
         const bool stereo = !(ur < 0);
-        const double ob[3] = {(double)pr.e_obs[e * 3], (double)pr.e_obs[e * 3 + 1], (double)ur};
-        const double info = (double)pr.e_info[e];
+        const double ob[3] = {(double)o0, (double)o1, (double)ur};
+        const double info = (double)inf;
         double pc[3], er[3], Jp[18], Jx[9];
         se3_map(Ta, Xw, pc);
         const double c2 = edge_error(cam, pc, ob, stereo, info, er);
