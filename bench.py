@@ -126,6 +126,36 @@ def cpu_baseline(wl, seq, first, n_timed):
 # --------------------------------------------------------------------------------------------------------------------------------
 # S2 stage entry: ORBextractor + ORBmatcher only (BASELINE.json configs[1]), per-kernel HBM table
 # --------------------------------------------------------------------------------------------------------------------------------
+def lba_alone(device_index, windows=40, reps=3):
+    """The local-BA operator ALONE on the card: one call of `windows` steady-state-shaped windows (27 free keyframes, 1500 points, ~13 k edges: the shape of the
+    timed steps' windows, synthetic geometry of object_slam_amd/synth.py), multi-launch layout as the driver uses it; device time from the handle's HIP events,
+    fp64 work = the SURVEY.md §8(d) flop model x the LM trials the kernels report.  The headline's local-BA figure is the same kernels under the contention of 8
+    handles; this is what they reach by themselves."""
+    import ctypes as C
+    from object_slam_amd import LocalBundleAdjuster, synth
+    base = [synth.make_lba_problem(1234 + i, K_local=27, K_fixed=0, P=1500, track=13, stereo_frac=0.9) for i in range(8)]
+    probs = [base[i % len(base)] for i in range(windows)]
+    ba = LocalBundleAdjuster(max_batch=windows, max_keyframes=64, max_points=8192, max_edges=65536, device=device_index)
+    try:
+        ms, ln = C.c_double(0), C.c_longlong(0)
+        out = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])            # warm (allocations)
+        ba.L.oslam_lba_kernel_time(ba.h, 1, C.byref(ms), C.byref(ln))       # enable + reset
+        for _ in range(reps):
+            out = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])
+        ba.L.oslam_lba_kernel_time(ba.h, 1, C.byref(ms), C.byref(ln))
+        flop = 0.0
+        for q, o in zip(probs, out):
+            k = np.bincount(np.asarray(q["edge_pt"]), minlength=len(q["points"])).astype(np.float64)
+            n6 = 6.0 * int((np.asarray(q["fixed"]) == 0).sum())
+            flop += (o[3][1] + o[3][3]) * (700.0 * len(q["edge_kf"]) + 324.0 * float((k * k).sum()) + n6 ** 3 / 3.0 + 2.0 * n6 * n6 + 45.0 * len(q["points"]))
+        ms_call = ms.value / reps
+        tf = flop / (ms_call * 1e-3) / 1e12
+        return {"windows": windows, "edges_per_window": int(len(probs[0]["edge_kf"])), "ms_per_call": round(ms_call, 3), "launches_per_call": int(ln.value // reps),
+                "fp64_TFLOPs": round(tf, 3), "frac_of_fp64_peak": round(tf / FP64_PEAK_TFLOPS, 4)}
+    finally:
+        ba.close()
+
+
 def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
     """Batched extraction of B frames + SearchByProjection(Cur, Last) with the ground-truth pose, everything resident in HBM.
     The B frames of a step are cut into `parts` sub-batches, each with its own extractor / matcher handle and HIP stream: the quad-tree, descriptor
@@ -522,6 +552,11 @@ def main():
                 front = frontend_stage(q["gray"][:40], q["Twc"][:40], q["depth"][:40], local_rank, args.steps)
             except Exception as ex:      # the stage entry must not break the headline line
                 front = {"error": repr(ex)}
+        if extras_on:
+            try:
+                roof["lba_alone"] = lba_alone(local_rank)
+            except Exception as ex:      # (must not break the headline line)
+                roof["lba_alone"] = {"error": repr(ex)}
         regime = ("steady state: every sequence is advanced %d untimed steps before the warm-up, so the timed steps are frames %d..%d of every sequence (SURVEY.md §8(d): "
                   "frame >= 200 of the S1 stream at <= 2 cm / 0.5 deg per frame)" % (preroll, preroll + args.warmup, preroll + args.warmup + args.steps)) if preroll > 0 else \
                  ("cold start: steps %d..%d of empty maps" % (args.warmup, args.warmup + args.steps))
