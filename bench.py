@@ -364,6 +364,7 @@ def main():
     ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps before the warm-up that bring every sequence's map to its steady state (default: 200 for the "
                                                              "RGB-D stream = SURVEY.md §8(d) frame >= 200, 40 for the stereo street); 0 = the cold-start regime of round 2")
     ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 8192 RGB-D / 512 stereo)")
+    ap.add_argument("--bases", type=int, default=8, help="base renderings per GPU of the headline stream (distinct input streams = bases x 25 frame offsets)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8 / 4)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -385,7 +386,7 @@ def main():
     cores = os.cpu_count() or 1
     stereo_head = args.workload == "stereo"
     preroll = args.preroll if args.preroll >= 0 else (40 if stereo_head else 200)
-    wl_rgbd = seqbench.rgbd_workload(speed=1.0, n_base=8, stagger=24)
+    wl_rgbd = seqbench.rgbd_workload(speed=1.0, n_base=args.bases, stagger=24)
     wl_st = seqbench.stereo_workload()
     head, second = (wl_st, wl_rgbd) if stereo_head else (wl_rgbd, wl_st)
     # 8192 sequences per GPU: 21.7 k frames/s against 19.3 k with 4096 and 22.9 k with 16384 (same code; local-BA calls of ~82 windows instead of ~41; 55 GB of host
@@ -557,6 +558,12 @@ def main():
                 roof["lba_alone"] = lba_alone(local_rank)
             except Exception as ex:      # (must not break the headline line)
                 roof["lba_alone"] = {"error": repr(ex)}
+            try:                         # the card's measured fp64 issue rates beside the datasheet figure `peak` is taken from
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import mfma_f64_rate
+                roof["fp64_peak_measured"] = mfma_f64_rate.measure(local_rank)
+            except Exception as ex:
+                roof["fp64_peak_measured"] = {"error": repr(ex)}
         regime = ("steady state: every sequence is advanced %d untimed steps before the warm-up, so the timed steps are frames %d..%d of every sequence (SURVEY.md §8(d): "
                   "frame >= 200 of the S1 stream at <= 2 cm / 0.5 deg per frame)" % (preroll, preroll + args.warmup, preroll + args.warmup + args.steps)) if preroll > 0 else \
                  ("cold start: steps %d..%d of empty maps" % (args.warmup, args.warmup + args.steps))
@@ -567,7 +574,11 @@ def main():
                                       "%d sequences per GPU in %d handles (one host thread + %d workers each), %d ORB features, images resident in HBM; %s; "
                                       "BASELINE.json configs[%s]" % (head.name, S, G, summ["host_threads_per_handle"] - 1, head.nFeatures, regime, "2" if head is wl_rgbd else "3]/[4"),
                           "regime": "steady_state" if preroll > 0 else "cold_start", "preroll_steps": preroll, "preroll_s": round(summ["preroll_s"], 1),
-                          "sequences_per_gpu": S, "frames_per_step": S * world, "host_cores": cores, "host_cpus_of_rank": ncpu,
+                          "sequences_per_gpu": S, "frames_per_step": S * world,
+                          "distinct_streams_per_gpu": min(S, head.n_base * (head.stagger + 1)), "replicas_per_stream": round(S / min(S, head.n_base * (head.stagger + 1)), 1),
+                          "inputs_note": "the %d sequences of a GPU replay %d base renderings at %d frame offsets: every distinct input frame of a step is read by ~%.0f sequences "
+                                         "(maps, keyframes and local-BA windows are per sequence and not shared); --bases N renders more base streams for an A/B of the cache "
+                                         "effect on the Frame::Frame group" % (S, min(head.n_base, S), head.stagger + 1, S / min(S, head.n_base * (head.stagger + 1))), "host_cores": cores, "host_cpus_of_rank": ncpu,
                           "arithmetic": "u8/int front-end, fp64 optimisers (dtype names the optimisers' type)",
                           "parallelism": "independent sequences sharded over ranks (sequence i -> rank i mod N); no data-path collective"},
                "lba_windows_timed": summ["lba_windows_timed"],

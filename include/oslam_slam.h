@@ -36,8 +36,9 @@
  *   - keypoints per frame: the extractor's capacity (sum of the level quotas + slack, oslam_orb_max_keypoints) — never exceeded by construction;
  *   - local map points searched per frame (Tracking::SearchLocalPoints): no fixed bound, the matcher's query buffers grow on demand;
  *   - local BA: keyframes, points and edges per window grow on demand (every fixed keyframe enters the window, src/Optimizer.cc:489-504); at most 128 LOCAL
- *     (free) keyframes per window, i.e. 768 unknowns of the reduced camera system — the driver skips the local BA of a window beyond that for that sequence
- *     and counts it (oslam_slam_lba_window_stats);
+ *     (free) keyframes per window, i.e. 768 unknowns of the reduced camera system — a window beyond that is solved DEGRADED: the current keyframe and its
+ *     strongest covisible keyframes (KeyFrame::GetVectorCovisibleKeyFrames order, weight-descending) stay free up to the bound, the weaker local keyframes
+ *     enter as fixed cameras with all their points and edges; such windows are counted (oslam_slam_lba_window_stats [5]);
  *   - detections per frame: OSLAM_SLAM_MAX_OBJECTS;
  *   - resident keyframe records (keypoints, descriptors, stereo coordinates, feature grid: ~86 B x capacity + 6 KB each): one per keyframe in the current map
  *     of a sequence; the records of culled keyframes (release_keyframes, after KeyFrameCulling) and of a map that was reset are reused; the store itself only
@@ -288,13 +289,13 @@ int oslam_slam_track_rgbd_raw16(oslam_slam_t* h, const uint8_t* const* gray, int
                                 int on_device, const double* timestamps, const oslam_slam_objects_t* objs, int mask_stride, float* Tcw_out, int32_t* state_out);
 
 /* Object layer counters of one sequence: [0] N_AllSemanticConstraintNum (src/ObjectOptimizer.cc:1233), [1] frames optimised with matched objects,
- * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] local-BA windows skipped for capacity (see
+ * [2] frames whose nSemNum was > 0, [3] Object3Ds, [4] map points listed in Object3Ds, [5] Object2Ds built, [6] local-BA windows degraded for capacity (see
  * oslam_slam_lba_window_stats [5]). */
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* Sizes of the local-BA windows of one sequence since creation (Optimizer::LocalBundleAdjustment's graph gather, src/Optimizer.cc:456-504):
- * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] windows SKIPPED because they had more than 128 free
- * keyframes (the local-BA operator's bound; the reference has none). */
+ * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] windows DEGRADED because they had more than 128 free
+ * keyframes (the local-BA operator's bound; the reference has none): their weakest covisible keyframes were held fixed. */
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.

@@ -1,25 +1,35 @@
-"""Builds the in-tree gfx950 shared library (hipcc cross-compiles without a GPU)."""
+"""Builds the in-tree gfx950 shared library (hipcc cross-compiles without a GPU).
+
+Every source is compiled to its own object under object_slam_amd/_obj/ (only when it or a header changed, up to OSLAM_BUILD_JOBS at a time) and the
+objects are linked into liboslam_hip.so: an edit of one kernel file costs one compile, not ten."""
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "liboslam_hip.so")
 SOURCES = ["orb_extractor.hip", "matcher.hip", "pose_opt.hip", "lba.hip", "stereo.hip", "bow_matcher.hip", "mappoint.hip", "frame.hip", "slam_driver.hip", "slam_ops_hip.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = (os.environ["OSLAM_EXTRA_FLAGS"].split() if os.environ.get("OSLAM_EXTRA_FLAGS") else []) + (["-DOSLAM_LBA_PROFILE"] if os.environ.get("OSLAM_LBA_PROFILE") else []) + (["-DOSLAM_FAST_PROFILE"] if os.environ.get("OSLAM_FAST_PROFILE") else []) + (["-DOSLAM_MATCH_PROFILE"] if os.environ.get("OSLAM_MATCH_PROFILE") else []) + (["-DOSLAM_MATCH_ABLATE=" + os.environ["OSLAM_MATCH_ABLATE"]] if os.environ.get("OSLAM_MATCH_ABLATE") else []) + ["-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+FLAGS = (os.environ["OSLAM_EXTRA_FLAGS"].split() if os.environ.get("OSLAM_EXTRA_FLAGS") else []) + (["-DOSLAM_LBA_PROFILE"] if os.environ.get("OSLAM_LBA_PROFILE") else []) + (["-DOSLAM_FAST_PROFILE"] if os.environ.get("OSLAM_FAST_PROFILE") else []) + (["-DOSLAM_MATCH_PROFILE"] if os.environ.get("OSLAM_MATCH_PROFILE") else []) + (["-DOSLAM_MATCH_ABLATE=" + os.environ["OSLAM_MATCH_ABLATE"]] if os.environ.get("OSLAM_MATCH_ABLATE") else []) + ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
          "-ffp-contract=off",  # host AND device: reference float expressions round once per operator
          "-Wall", "-Wno-unused-function"]
 
 
-def _deps():
+def _headers():
     out = []
     for root, _, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files]
+        out += [os.path.join(root, f) for f in files if not f.endswith(".hip")]
     out.append(os.path.join(HERE, "..", "include", "oslam_hip.h"))
     out.append(os.path.join(HERE, "..", "include", "oslam_slam.h"))
     return out
+
+
+def _deps():
+    return _headers() + [os.path.join(CSRC, s) for s in SOURCES]
 
 
 def needs_build():
@@ -29,13 +39,47 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
+def _obj_path(src):
+    tag = hashlib.sha1(" ".join(FLAGS).encode()).hexdigest()[:10]   # objects of another flag set are not reused
+    return os.path.join(OBJ, "%s.%s.o" % (os.path.splitext(src)[0], tag))
+
+
+def _stale(src, obj):
+    """obj is older than src or than any file the compiler listed as included (-MD); system headers under /opt/rocm are skipped"""
+    if not os.path.exists(obj) or not os.path.exists(obj + ".d"):
+        return True
+    t = os.path.getmtime(obj)
+    deps = open(obj + ".d").read().replace("\\\n", " ").split()[1:]
+    for d in [src] + [d for d in deps if not d.startswith(("/opt/", "/usr/"))]:
+        if not os.path.exists(d) or os.path.getmtime(d) > t:
+            return True
+    return False
+
+
 def build_hip(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    todo = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), _obj_path(s)
+        if force or _stale(src, obj):
+            todo.append((src, obj))
+
+    def compile_one(job):
+        cmd = [HIPCC] + FLAGS + ["-MD", "-MF", job[1] + ".d", "-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    jobs = int(os.environ.get("OSLAM_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj_path(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
     return LIB
 
 

@@ -857,7 +857,7 @@ __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
 // The 144-byte block of an edge is computed by one lane, but a lane-per-block store (nine 16-byte pieces at a stride of 144 bytes across the lanes) reached
 // the memory side as 2.5x the bytes (rocprofv3 WRITE_SIZE 185 MB per launch of 40 windows against 75 MB of blocks: profiles/r03_pmc_lba_traffic.json): the blocks
 // of the workgroup's 256 consecutive edges are contiguous, so they go through LDS and out as 16 bytes per lane, consecutive lanes consecutive addresses.
-// (Inactive edges — outliers, fixed keyframes — get whatever the LDS held: nothing reads their W.)
+// (Inactive edges — outliers, fixed keyframes — get zeros: nothing reads their W.)
 __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -887,6 +887,10 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
             We[i * 3 + 1] = b0 * Di[1] + b1 * Di[4] + b2v * Di[7];
             We[i * 3 + 2] = b0 * Di[2] + b1 * Di[5] + b2v * Di[8];
         }
+    } else {   // inactive edge (outlier, fixed keyframe): nothing reads its W, but it is written below — zeros, not whatever the LDS held
+        double* We = sW + threadIdx.x * 19;
+#pragma unroll
+        for (int i = 0; i < 18; i++) We[i] = 0.0;
     }
     __syncthreads();
     const int nE = min(256, pr.E - e0);

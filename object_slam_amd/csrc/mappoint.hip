@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -506,8 +508,15 @@ __global__ __launch_bounds__(256) void k_fuse_search(FuseSearchCtx c, int stride
 int oslam_kf_grid_build_device(int n, const oslam_kf_grid_job_t* d_jobs, const int32_t* d_counts, const float bounds[4], int max_keypoints, int32_t* d_status, void* stream) {
     if (n < 1 || !d_jobs || !d_counts || !bounds || max_keypoints < 1 || max_keypoints > 65535 || !d_status) { set_error("kf_grid_build: bad argument"); return OSLAM_E_INVALID; }
     const size_t lds = (size_t)(kFGridCells + 1) * 4 + (size_t)max_keypoints * 2;
-    static bool attr_set = false;   // (the same value on every call of a process: the keypoint capacity of the extractor)
-    if (!attr_set) { OSLAM_HIP_CHECK(hipFuncSetAttribute((const void*)k_kf_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); attr_set = true; }
+    {   // once per DEVICE (the attribute belongs to the function on the current device) and safe against the handles' threads calling concurrently
+        static std::once_flag attr_once[64];
+        static std::atomic<int> attr_rc[64];
+        int dev = 0;
+        OSLAM_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64) { set_error("device index %d outside [0,64)", dev); return OSLAM_E_INVALID; }
+        std::call_once(attr_once[dev], [dev] { attr_rc[dev] = (int)hipFuncSetAttribute((const void*)k_kf_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048); });
+        if (attr_rc[dev] != (int)hipSuccess) { set_error("hipFuncSetAttribute(k_kf_grid_build): %s", hipGetErrorString((hipError_t)attr_rc[dev].load())); return OSLAM_E_HIP; }
+    }
     if (lds > 160 * 1024 - 2048) { set_error("kf_grid_build: max_keypoints too large"); return OSLAM_E_CAPACITY; }
     const float invW = (float)kFGridCols / (float)(bounds[2] - bounds[0]), invH = (float)kFGridRows / (float)(bounds[3] - bounds[1]);   // src/Frame.cc:160-161
     hipLaunchKernelGGL(k_kf_grid_build, dim3(n), dim3(kGridBuildThreads), lds, (hipStream_t)stream, d_jobs, d_counts, bounds[0], bounds[1], invW, invH, max_keypoints, d_status);

@@ -107,7 +107,9 @@ struct BowViews {
     }
 };
 
-// (local-BA windows: the solver's reduced system holds 6 x 128 unknowns, i.e. at most 128 LOCAL keyframes; fixed keyframes are not limited)
+// (local-BA windows: the solver's reduced system holds 6 x 128 unknowns, i.e. at most 128 FREE keyframes; fixed keyframes are not limited.  OSLAM_SLAM_LBA_MAX_FREE
+// lowers the bound — a test knob for the degraded-window path of run_local_mapping)
+static const int kLbaMaxFreeKFs = [] { const char* e = getenv("OSLAM_SLAM_LBA_MAX_FREE"); const int v = e ? atoi(e) : 0; return (v > 0 && v < 128) ? v : 128; }();
 
 enum { ST_NOT_INITIALIZED = OSLAM_SLAM_NOT_INITIALIZED, ST_OK = OSLAM_SLAM_OK, ST_LOST = OSLAM_SLAM_LOST };
 
@@ -160,7 +162,7 @@ struct Seq {
     std::vector<Obj3D> obj3ds;
     std::map<int, int> objOfTrack;
     int64_t sem[8] = {0};
-    int64_t lbaFixedDropped = 0;           // local-BA windows skipped because they had more than 128 free keyframes (the operator's bound)
+    int64_t lbaWindowsDegraded = 0;           // local-BA windows DEGRADED because they had more than 128 free keyframes (the operator's bound): the weakest covisible keyframes entered as fixed cameras
     int64_t lbaWin[4] = {0, 0, 0, 0};      // local-BA window sizes summed over the sequence's windows: local keyframes, fixed keyframes, points, edges
     std::vector<uint8_t> jInMask;                       // object_kps output
     std::vector<const uint8_t*> jMaskPtrs;              // masks of the matched objects (idx_obj order)
@@ -200,7 +202,7 @@ struct Ctx {
     CpuAccount acct;
     int shard = 0;   // worker set of this handle (slam_pool.h)
     struct Win {   // one local-BA window (run_local_mapping)
-        int si = -1, nLocal = 0;
+        int si = -1, nLocal = 0, nFree = 0;   // nFree: window indices below it are free poses (== nLocal unless the window was degraded)
         std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
         std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref;
         void reset() { kfs.clear(); pts.clear(); poses.clear(); points.clear(); eobs.clear(); einv.clear(); poses_out.clear(); points_out.clear(); fixed.clear(); erase.clear(); ekf.clear(); ept.clear(); eref.clear(); nLocal = 0; }
@@ -1206,20 +1208,26 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     }
                 }
             }
-            // A window with more than 128 FREE keyframes (768 unknowns) is beyond the local-BA operator (OSLAM_E_CAPACITY).  The reference has no such bound; rather
-            // than failing the lockstep step of every sequence of the handle, THIS sequence skips this local BA (counted: oslam_slam_lba_window_stats, last
-            // field) — its map stays consistent, the next keyframe tries again.
+            // A window with more than 128 FREE keyframes (768 unknowns) is beyond the local-BA operator (OSLAM_E_CAPACITY).  The reference has no such bound.  The
+            // window is kept, DEGRADED: m.kfs[cur].ordered is weight-descending, so the current keyframe and its strongest covisible keyframes stay free up to the
+            // bound and the remaining local keyframes enter as fixed cameras (fixed = 1): their points and edges are still in the window, points and the strongest
+            // poses are still refined and outlier observations still erased.  Counted (oslam_slam_lba_window_stats [5]: degraded windows).
+            int nFreeCap = W.nLocal;   // window indices >= nFreeCap are fixed cameras
             {
                 int nFreeKF = 0;
-                for (int q = 0; q < W.nLocal; q++) nFreeKF += W.kfs[q] != 0;
-                if (nFreeKF > 128) { s.lbaFixedDropped++; W.si = -1; return; }
+                for (int q = 0; q < W.nLocal; q++) {
+                    nFreeKF += W.kfs[q] != 0;
+                    if (nFreeKF > kLbaMaxFreeKFs) { nFreeCap = q; break; }
+                }
+                if (nFreeCap < W.nLocal) s.lbaWindowsDegraded++;
             }
+            W.nFree = nFreeCap;
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
             W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());
             for (size_t q = 0; q < W.kfs.size(); q++) {
                 memcpy(&W.poses[q * 16], m.kfs[W.kfs[q]].pose.Tcw.m, 64);
-                W.fixed[q] = (int)q >= W.nLocal ? 1 : (W.kfs[q] == 0 ? 2 : 0);
+                W.fixed[q] = (int)q >= nFreeCap ? 1 : (W.kfs[q] == 0 ? 2 : 0);
             }
             W.points.resize(W.pts.size() * 3);
             for (size_t j = 0; j < W.pts.size(); j++) {
@@ -1272,7 +1280,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     if (idx >= 0) m.kfs[k].mp[idx] = -1;
                     m.erase_observation(p, k);
                 }
-            for (int q = 0; q < W.nLocal; q++) {
+            for (int q = 0; q < W.nFree; q++) {   // (the local keyframes a degraded window held fixed keep their poses)
                 M4 T; memcpy(T.m, &W.poses_out[(size_t)q * 16], 64);
                 m.kfs[W.kfs[q]].pose.set_keyframe(T);
             }
@@ -2007,14 +2015,14 @@ int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
     if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_lba_window_stats: bad argument"); return OSLAM_E_INVALID; }
     const auto& s = *h->c.seq[seq];
     memset(out, 0, 8 * sizeof(int64_t));
-    out[0] = s.st[5]; out[1] = s.lbaWin[0]; out[2] = s.lbaWin[1]; out[3] = s.lbaWin[2]; out[4] = s.lbaWin[3]; out[5] = s.lbaFixedDropped;
+    out[0] = s.st[5]; out[1] = s.lbaWin[0]; out[2] = s.lbaWin[1]; out[3] = s.lbaWin[2]; out[4] = s.lbaWin[3]; out[5] = s.lbaWindowsDegraded;
     return OSLAM_OK;
 }
 
 int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
     if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_object_stats: bad argument"); return OSLAM_E_INVALID; }
     memcpy(out, h->c.seq[seq]->sem, sizeof(h->c.seq[seq]->sem));
-    out[6] = h->c.seq[seq]->lbaFixedDropped;
+    out[6] = h->c.seq[seq]->lbaWindowsDegraded;
     return OSLAM_OK;
 }
 

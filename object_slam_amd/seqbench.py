@@ -171,7 +171,7 @@ def _window_totals(systems, per):
     for sy in systems:
         for q in range(per):
             w = sy.lba_window_stats(q)
-            tot += np.array([w["windows"], w["local_kfs"], w["fixed_kfs"], w["points"], w["edges"], w["fixed_dropped"]], np.int64)
+            tot += np.array([w["windows"], w["local_kfs"], w["fixed_kfs"], w["points"], w["edges"], w["lba_windows_degraded"]], np.int64)
     return tot
 
 
@@ -180,7 +180,7 @@ def window_stats(after, before):
     d = after - before
     n = max(int(d[0]), 1)
     return {"windows": int(d[0]), "mean_local_kfs": round(float(d[1]) / n, 2), "mean_fixed_kfs": round(float(d[2]) / n, 2), "mean_points": round(float(d[3]) / n, 1),
-            "mean_edges": round(float(d[4]) / n, 1), "fixed_kfs_left_out": int(d[5])}
+            "mean_edges": round(float(d[4]) / n, 1), "lba_windows_degraded": int(d[5])}
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,

@@ -274,7 +274,7 @@ class System:
         """Local-BA window sizes of one sequence since creation: windows and the sums of local / fixed keyframes, points and edges over them."""
         out = np.zeros(8, np.int64)
         check(self.L.oslam_slam_lba_window_stats(self.h, C.c_int(seq), ptr(out)))
-        return dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "fixed_dropped"), out[:6].tolist()))
+        return dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "lba_windows_degraded"), out[:6].tolist()))
 
     KT_GROUPS = ("frames", "pose_opt", "lba", "search", "fuse", "bow_triangulate", "mp_update", "other")
 

@@ -228,3 +228,68 @@ def test_device_built_pair_lists_equal_the_host_built_ones():
     for i in range(10): same(out[0][1][i], out[3][1][i])
     for i in range(3): same(out[0][2][i], out[3][2][i])
     for i in range(3): same(out[0][2][i], out[0][1][i])      # a window's result does not depend on the batch it is solved in
+
+
+# ---- the wide (multi-launch) layout at the sizes the bench's steady state runs it at ----
+# Steady-state windows have 27-31 free keyframes: reduced systems of 133..192 unknowns, which the wide layout factors with the packed LDS solver
+# (k_w_chol_packed) and, from 8 windows per call, launches with every window on one XCD (xcd_window_item).
+HEADLINE_WINDOWS = [(77, 27, 0, 1500, 13), (121, 31, 3, 1800, 16)]
+
+
+@pytest.mark.parametrize("schur", [0, 1])
+@pytest.mark.parametrize("seed,KL,KF,P,track", HEADLINE_WINDOWS)
+def test_lba_wide_layout_at_headline_window_sizes_matches_oracle(oracle, seed, KL, KF, P, track, schur):
+    """Reference src/Optimizer.cc:453-778 (optimize(5) :660, optimize(10) :706-707) on windows of the bench's steady-state shape, DEFAULT layout (mode 1), both
+    Schur implementations: n = 156 / 186 unknowns -> k_w_chol_packed."""
+    q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, track=track, stereo_frac=0.9)
+    n = 6 * int((q["fixed"] == 0).sum())
+    assert 132 < n <= 192, n
+    ba = LocalBundleAdjuster(max_batch=2, max_keyframes=64, max_points=8192, max_edges=65536)
+    ba.set_mode(1)
+    ba.set_schur(schur)
+    a, o = _run(oracle, ba, q)
+    _compare(a, o)
+    ba.close()
+
+
+@pytest.mark.parametrize("seed,KL,KF,P,track", HEADLINE_WINDOWS)
+def test_lba_lm_schedule_at_headline_window_sizes_matches_oracle(oracle, seed, KL, KF, P, track):
+    """The LM trial sequence (accept / reject, rho, lambda, costs) of the default layout against the oracle's at n = 156 / 186."""
+    from lm_trace import compare_lm_traces
+    q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, track=track, stereo_frac=0.9)
+    args = (q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+    ba = LocalBundleAdjuster(max_keyframes=64, max_points=8192, max_edges=65536)
+    a, th = ba.lm_trace(lambda: ba.LocalBundleAdjustment(*args))
+    o, to = oracle.lm_trace(lambda: oracle.local_bundle_adjustment(*args))
+    assert len(th) == a[3][1] + a[3][3] and len(to) == o[3][1] + o[3][3]
+    compared, undecidable = compare_lm_traces(th, to)
+    assert compared >= 4, (compared, undecidable, len(th), len(to))
+    if undecidable == 0:
+        assert tuple(a[3]) == tuple(o[3]), (a[3], o[3])
+    ba.close()
+
+
+@pytest.mark.parametrize("schur", [0, 1])
+def test_lba_wide_batch_mixing_120_162_204_unknowns_matches_oracle(oracle, schur):
+    """One call of 9 windows (>= 8: the XCD-mapped launch) whose reduced systems have 120, 162 and 204 unknowns: the call launches BOTH k_w_chol_packed (n <= 192)
+    and the matrix-core solver (n = 204) and every window must equal the oracle; equal windows of the call must come out bit-identical."""
+    shapes = {120: (501, 21, 0, 1000, 10), 162: (502, 28, 0, 1500, 13), 204: (503, 35, 0, 2000, 17)}
+    qs = {n: synth.make_lba_problem(s, K_local=KL, K_fixed=KF, P=P, track=t, stereo_frac=0.9) for n, (s, KL, KF, P, t) in shapes.items()}
+    for n, q in qs.items():
+        assert 6 * int((q["fixed"] == 0).sum()) == n
+    order = [120, 162, 204, 162, 120, 162, 204, 162, 162]
+    ba = LocalBundleAdjuster(max_batch=16, max_keyframes=64, max_points=8192, max_edges=65536)
+    ba.set_mode(1)
+    ba.set_schur(schur)
+    outs = ba.LocalBundleAdjustmentBatch([qs[n] for n in order], qs[120]["K"])
+    first = {}
+    for n, r in zip(order, outs):
+        if n not in first:
+            q = qs[n]
+            o = oracle.local_bundle_adjustment(q["poses"], q["fixed"], q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"])
+            _compare(r, o)
+            first[n] = r
+        else:
+            f = first[n]
+            assert np.array_equal(r[0], f[0]) and np.array_equal(r[1], f[1]) and np.array_equal(r[2], f[2]) and tuple(r[3]) == tuple(f[3])
+    ba.close()

@@ -266,3 +266,34 @@ def test_observations_in_culled_keyframes_against_independent_restatement(oracle
     # the counts are per ComputeDistinctiveDescriptors call, so the driver's is the smaller one; the poses and statistics above are identical)
     nb, nr = sysm.bad_keyframe_observations(), getattr(ref, "bad_kf_observations", 0)
     assert 0 < nb <= nr, (nb, nr)
+
+
+def test_local_ba_window_beyond_the_operator_bound_is_degraded_not_skipped(oracle):
+    """The local-BA operator solves at most 128 FREE keyframes per window (the reference has no bound, src/Optimizer.cc:456-468).  A window beyond the bound is
+    kept: the current keyframe and its strongest covisible keyframes stay free, the weaker local keyframes enter as fixed cameras.  OSLAM_SLAM_LBA_MAX_FREE lowers
+    the bound to 3 (read when the library is loaded, hence the child process) so that the 36-frame stream reaches it: local BA still runs on every keyframe,
+    the map stays consistent and the trajectory accurate, and the degraded windows are counted."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from object_slam_amd import slam
+from slam_common import H, W, ate, make_streams, oracle_ops, run
+n = 36
+cfg = slam.make_config(W, H, 1)
+streams = make_streams(1, n)
+sysm = slam.System(cfg, oracle_ops(cfg))
+poses, states = run(sysm, streams, n)
+st, w = sysm.stats(0), sysm.lba_window_stats(0)
+a, _ = ate(sysm, cfg, streams, 0)
+assert (states == slam.OK).all() and st["lost_frames"] == 0 and st["map_violations"] == 0, st
+assert st["local_bas"] >= 2 and w["windows"] == st["local_bas"], (st, w)
+assert w["lba_windows_degraded"] >= 1, w
+assert a < 0.01, a
+print("degraded", w["lba_windows_degraded"], "of", w["windows"], "ate", a)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OSLAM_SLAM_LBA_MAX_FREE="3"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "degraded" in r.stdout
