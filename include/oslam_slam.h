@@ -12,8 +12,15 @@
  *   ProcessNewKeyFrame (src/LocalMapping.cc:129), MapPointCulling :171, CreateNewMapPoints :208, SearchInNeighbors :455,
  *   Optimizer::LocalBundleAdjustment's graph gather / write-back (src/Optimizer.cc:456-504, :746-777), KeyFrameCulling :633.
  * Normalisations (the reference is not deterministic there):
- *   - LocalMapping runs synchronously after the frame that inserted the keyframe (the reference runs it on a second
- *     thread; AcceptKeyFrames() is therefore always true and the BA is never interrupted);
+ *   - LocalMapping runs at fixed points of the step instead of on a second thread (src/System.cc:95): AcceptKeyFrames() is therefore always true and the BA
+ *     is never interrupted.  Two deterministic schedules (oslam_slam_config_t::local_mapping bit 5, OSLAM_SLAM_LM_DEFERRED):
+ *       synchronous — the whole pass (LocalMapping::Run, src/LocalMapping.cc:48-113) right after the frame that inserted the keyframe;
+ *       deferred    — ProcessNewKeyFrame .. SearchInNeighbors and the local-BA graph gather (src/Optimizer.cc:456-504) right after the frame that inserted
+ *                     the keyframe; Optimizer::LocalBundleAdjustment's solve runs while the NEXT frame is tracked (the reference's overlap of the two threads)
+ *                     and its write-back (:746-777), the MapPoint updates and KeyFrameCulling (:633) are applied after that frame's tracking, before the next
+ *                     local-mapping pass.  Tracking of frame t+1 thus reads the map as the reference's tracking thread does while the BA of keyframe t is
+ *                     still running.  oslam_slam_finish applies what is pending (System::Shutdown waits for the local mapper, src/System.cc:303-320);
+ *                     the trajectory getters call it.
  *   - containers ordered by pointer value (std::map<KeyFrame*,..>, std::set<KeyFrame*>, pair<int,KeyFrame*> sorts)
  *     are ordered by keyframe id;
  *   - DBoW2 and its vocabulary are not in the reference tree: ComputeBoW uses a substitute vocabulary (k = 10, two
@@ -69,10 +76,12 @@ typedef struct oslam_slam_config {
     int32_t device;
     int32_t host_threads;        /* worker threads for the per-sequence bookkeeping (0 = 1) */
     int32_t local_mapping;       /* bit0 MapPointCulling, bit1 CreateNewMapPoints, bit2 SearchInNeighbors, bit3 LocalBundleAdjustment,
-                                    bit4 KeyFrameCulling; 0x1F = the reference's LocalMapping::Run */
+                                    bit4 KeyFrameCulling; 0x1F = the reference's LocalMapping::Run; bit5 (OSLAM_SLAM_LM_DEFERRED): the deferred schedule of
+                                    the head comment (local BA solved during the next frame's tracking) */
     int32_t sensor;              /* System::eSensor (include/System.h:60-64): 1 STEREO, 2 RGBD; 0 = RGBD */
 } oslam_slam_config_t;
 
+#define OSLAM_SLAM_LM_DEFERRED 0x20
 #define OSLAM_SLAM_NOT_INITIALIZED 1   /* Tracking::eTrackingState, include/Tracking.h:91-97 */
 #define OSLAM_SLAM_OK 2
 #define OSLAM_SLAM_LOST 3
@@ -256,6 +265,12 @@ typedef struct oslam_slam_ops {
      * them (the driver skips bad keyframes wherever the reference does, and ComputeDistinctiveDescriptors skips their observations, src/MapPoint.cc:366): a
      * table may give their resident records to later keyframes.  Called once per local-mapping pass, after KeyFrameCulling. */
     int (*release_keyframes)(void* ctx, int n, const int32_t* slots, const int32_t* kf_ids);
+    /* optional pair, used by the deferred local-mapping schedule (OSLAM_SLAM_LM_DEFERRED): lba_submit starts the local BA of n windows and returns at once — the
+     * arrays `probs` names (inputs AND outputs) stay valid and untouched until lba_wait, which returns when their results are in place (same results as `lba` on
+     * the same windows: a window's result does not depend on what else is solved beside it).  At most one submission per table is in flight.  NULL: the driver
+     * calls `lba` where it would have waited. */
+    int (*lba_submit)(void* ctx, int n, const oslam_lba_problem_t* probs);
+    int (*lba_wait)(void* ctx);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */
@@ -297,6 +312,10 @@ int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
  * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] windows DEGRADED because they had more than 128 free
  * keyframes (the local-BA operator's bound; the reference has none): their weakest covisible keyframes were held fixed. */
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]);
+
+/* Deferred schedule: waits for the local BA in flight and applies its write-back, the MapPoint updates and KeyFrameCulling (what System::Shutdown's wait for the
+ * local mapper does, src/System.cc:303-320).  No effect when nothing is pending.  Called by oslam_slam_trajectory / oslam_slam_keyframe_trajectory. */
+int oslam_slam_finish(oslam_slam_t* h);
 
 /* System::SaveTrajectoryTUM (src/System.cc:378-440): per tracked frame the pose re-anchored on its reference keyframe's final pose.
  * Twc [n][12] = rows of [Rwc | twc]; lost frames are skipped like the reference.  Returns the count in *n_out (cap < n -> OSLAM_E_CAPACITY). */

@@ -208,6 +208,9 @@ struct Ctx {
         void reset() { kfs.clear(); pts.clear(); poses.clear(); points.clear(); eobs.clear(); einv.clear(); poses_out.clear(); points_out.clear(); fixed.clear(); erase.clear(); ekf.clear(); ept.clear(); eref.clear(); nLocal = 0; }
     };
     std::vector<Win> winPool;
+    // deferred schedule (OSLAM_SLAM_LM_DEFERRED): the second half of the local-mapping pass of the previous step — local-BA solve in flight or not yet started,
+    // write-back, MapPoint updates, KeyFrameCulling — applied by finish_local_mapping after the next step's tracking
+    struct PendingLM { bool active = false, submitted = false; std::vector<int> who; std::vector<Win*> wins; std::vector<oslam_lba_problem_t> probs; } pend;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
     int mapStep = 0;            // local-mapping passes of this handle (MapPt::updStep)
     bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
@@ -689,6 +692,110 @@ static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t
         }
         s.st[9]++;
     }
+}
+
+// Second half of a local-mapping pass: Optimizer::LocalBundleAdjustment's write-back (src/Optimizer.cc:711-777) from the solved windows, the MapPoint updates of
+// their points, KeyFrameCulling (src/LocalMapping.cc:633-697) for every sequence of the pass.  Synchronous schedule: called at the end of run_local_mapping;
+// deferred schedule: by finish_local_mapping after the next step's tracking.
+static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::vector<Ctx::Win*>& wins) {
+    typedef Ctx::Win Win;
+    Timer tm;
+    int rc;
+    if (!c.updMap) c.updMap.reset(new MpUpdate);
+    MpUpdate& upd = *c.updMap;
+    Pool& pool = *c.pool;
+    const int flags = c.cfg.local_mapping;
+    const int nW = (int)who.size();
+    auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
+    if (flags & 8) {
+        pool.parallel_for((int)wins.size(), [&](int wi) {
+            Win& W = *wins[wi];
+            Seq& s = *c.seq[W.si];
+            Map& m = s.map;
+            // erase list: mono edges first, then stereo edges (:711-757)
+            for (int pass = 0; pass < 2; pass++)
+                for (size_t e = 0; e < W.ekf.size(); e++) {
+                    if (!W.erase[e]) continue;
+                    const bool stereo = W.eobs[e * 3 + 2] >= 0;
+                    if ((pass == 1) != stereo) continue;
+                    const int k = W.eref[e].first, p = W.eref[e].second;
+                    const int idx = m.mps[p].obs_index(k);
+                    if (idx >= 0) m.kfs[k].mp[idx] = -1;
+                    m.erase_observation(p, k);
+                }
+            for (int q = 0; q < W.nFree; q++) {   // (the local keyframes a degraded window held fixed keep their poses)
+                M4 T; memcpy(T.m, &W.poses_out[(size_t)q * 16], 64);
+                m.kfs[W.kfs[q]].pose.set_keyframe(T);
+            }
+            for (size_t j = 0; j < W.pts.size(); j++) {
+                if (j + kPF < W.pts.size()) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
+                MapPt& mp = m.mps[W.pts[j]];
+                for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
+                s.updList.push_back(W.pts[j]);
+            }
+        });
+        merge_upd();
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
+        if ((rc = upd.run(c, false, true))) return rc;
+        { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+    }
+    // --- KeyFrameCulling (:633-697) ---
+    if (flags & 16)
+        pool.parallel_for(nW, [&](int w) {
+            Seq& s = *c.seq[who[w]];
+            Map& m = s.map;
+            const std::vector<int> local = m.kfs[s.curKF].ordered;
+            for (int k : local) {
+                if (k == 0) continue;
+                const KeyFrm& kf = m.kfs[k];
+                int nRed = 0, nMPs = 0;
+                for (int i = 0; i < kf.N; i++) {
+                    prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
+                    const int p = kf.mp[i];
+                    if (p < 0 || m.mps[p].bad) continue;
+                    if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
+                    nMPs++;
+                    if (m.mps[p].nObs > 3) {
+                        const int lvl = kf.keysUn[i].octave;
+                        int n = 0;
+                        for (auto& e : m.mps[p].obs) {
+                            if (e.first == k) continue;
+                            if (m.kfs[e.first].keysUn[e.second].octave <= lvl + 1) { n++; if (n >= 3) break; }
+                        }
+                        if (n >= 3) nRed++;
+                    }
+                }
+                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
+            }
+        });
+    if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
+        std::vector<int32_t> rs, rk;
+        for (int si : who) { Seq& s = *c.seq[si]; for (int k : s.culledKFs) { rs.push_back(si); rk.push_back(k); } s.culledKFs.clear(); }
+        if (!rs.empty() && (rc = c.ops.release_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
+    } else
+        for (int si : who) c.seq[si]->culledKFs.clear();
+    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
+    return OSLAM_OK;
+}
+
+
+// Deferred schedule: what is left of the previous step's local-mapping pass.  Waits for the local BA in flight (or runs it now when the table has no
+// asynchronous form), then write-back, MapPoint updates and KeyFrameCulling.
+static int finish_local_mapping(Ctx& c) {
+    Ctx::PendingLM& pd = c.pend;
+    if (!pd.active) return OSLAM_OK;
+    pd.active = false;
+    Timer tm;
+    int rc = OSLAM_OK;
+    if (!pd.probs.empty()) {
+        if (pd.submitted) rc = c.ops.lba_wait(c.ops.ctx);
+        else rc = c.ops.lba(c.ops.ctx, (int)pd.probs.size(), pd.probs.data());
+        pd.submitted = false;
+        if (rc) return rc;
+    }
+    { c.sec[6] += tm.lap(); c.cpu[6] += tm.cpu; }
+    for (int si : pd.who) c.seq[si]->mapVersion++;   // poses, positions and the keyframe set of these sequences change: their cached local maps are stale
+    return local_mapping_back(c, pd.who, pd.wins);
 }
 
 static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
@@ -1263,77 +1370,26 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data(); p.stats = nullptr;
         }
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
+        if (flags & OSLAM_SLAM_LM_DEFERRED) {
+            // deferred schedule: the solve runs while the next frame is tracked; write-back, MapPoint updates and KeyFrameCulling follow in finish_local_mapping
+            Ctx::PendingLM& pd = c.pend;
+            pd.active = true; pd.who = who; pd.wins = wins; pd.probs.swap(probs); pd.submitted = false;
+            if (!pd.probs.empty() && c.ops.lba_submit) {
+                if ((rc = c.ops.lba_submit(c.ops.ctx, (int)pd.probs.size(), pd.probs.data()))) return rc;
+                pd.submitted = true;
+            }
+            { c.sec[6] += tm.lap(); c.cpu[6] += tm.cpu; }
+            return OSLAM_OK;
+        }
         if (!probs.empty() && (rc = c.ops.lba(c.ops.ctx, (int)probs.size(), probs.data()))) return rc;
         { c.sec[6] += tm.lap(); c.cpu[6] += tm.cpu; }
-        pool.parallel_for((int)wins.size(), [&](int wi) {
-            Win& W = *wins[wi];
-            Seq& s = *c.seq[W.si];
-            Map& m = s.map;
-            // erase list: mono edges first, then stereo edges (:711-757)
-            for (int pass = 0; pass < 2; pass++)
-                for (size_t e = 0; e < W.ekf.size(); e++) {
-                    if (!W.erase[e]) continue;
-                    const bool stereo = W.eobs[e * 3 + 2] >= 0;
-                    if ((pass == 1) != stereo) continue;
-                    const int k = W.eref[e].first, p = W.eref[e].second;
-                    const int idx = m.mps[p].obs_index(k);
-                    if (idx >= 0) m.kfs[k].mp[idx] = -1;
-                    m.erase_observation(p, k);
-                }
-            for (int q = 0; q < W.nFree; q++) {   // (the local keyframes a degraded window held fixed keep their poses)
-                M4 T; memcpy(T.m, &W.poses_out[(size_t)q * 16], 64);
-                m.kfs[W.kfs[q]].pose.set_keyframe(T);
-            }
-            for (size_t j = 0; j < W.pts.size(); j++) {
-                if (j + kPF < W.pts.size()) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
-                MapPt& mp = m.mps[W.pts[j]];
-                for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
-                s.updList.push_back(W.pts[j]);
-            }
-        });
-        merge_upd();
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
-        if ((rc = upd.run(c, false, true))) return rc;
-        { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+        return local_mapping_back(c, who, wins);
     }
-
-    // --- KeyFrameCulling (:633-697) ---
-    if (flags & 16)
-        pool.parallel_for(nW, [&](int w) {
-            Seq& s = *c.seq[who[w]];
-            Map& m = s.map;
-            const std::vector<int> local = m.kfs[s.curKF].ordered;
-            for (int k : local) {
-                if (k == 0) continue;
-                const KeyFrm& kf = m.kfs[k];
-                int nRed = 0, nMPs = 0;
-                for (int i = 0; i < kf.N; i++) {
-                    prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
-                    const int p = kf.mp[i];
-                    if (p < 0 || m.mps[p].bad) continue;
-                    if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
-                    nMPs++;
-                    if (m.mps[p].nObs > 3) {
-                        const int lvl = kf.keysUn[i].octave;
-                        int n = 0;
-                        for (auto& e : m.mps[p].obs) {
-                            if (e.first == k) continue;
-                            if (m.kfs[e.first].keysUn[e.second].octave <= lvl + 1) { n++; if (n >= 3) break; }
-                        }
-                        if (n >= 3) nRed++;
-                    }
-                }
-                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
-            }
-        });
-    if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
-        std::vector<int32_t> rs, rk;
-        for (int si : who) { Seq& s = *c.seq[si]; for (int k : s.culledKFs) { rs.push_back(si); rk.push_back(k); } s.culledKFs.clear(); }
-        if (!rs.empty() && (rc = c.ops.release_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
-    } else
-        for (int si : who) c.seq[si]->culledKFs.clear();
-    { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
-    return OSLAM_OK;
+    if (flags & OSLAM_SLAM_LM_DEFERRED) {   // (no local BA in this configuration: only the culling is deferred)
+        c.pend.active = true; c.pend.who = who; c.pend.wins.clear(); c.pend.probs.clear(); c.pend.submitted = false;
+        return OSLAM_OK;
+    }
+    return local_mapping_back(c, who, std::vector<Ctx::Win*>());
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1907,6 +1963,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (s.state != ST_NOT_INITIALIZED) std::swap(s.cur, s.last);   // mLastFrame = Frame(mCurrentFrame)
     }
     { const double d_ = tm.lap(); c.sec[4] += d_; c.sec[14] += d_; c.cpu[4] += tm.cpu; c.cpu[14] += tm.cpu; }
+    if ((rc = finish_local_mapping(c))) return rc;   // (deferred schedule: the second half of the previous step's pass, before this step's pass)
     return run_local_mapping(c, mapping);
 }
 
@@ -2011,6 +2068,12 @@ int oslam_slam_track_rgbd_raw16(oslam_slam_t* h, const uint8_t* const* gray, int
     return track_step(h->c, gray, nullptr, gray_stride, nullptr, depth_pitch, on_device, timestamps, objs, mask_stride, Tcw_out, state_out, depth16, depth_factor);
 }
 
+int oslam_slam_finish(oslam_slam_t* h) {
+    if (!h) { oslam::set_error("oslam_slam_finish: NULL handle"); return OSLAM_E_INVALID; }
+    AccountScope acct_scope(&h->c.acct);
+    return finish_local_mapping(h->c);
+}
+
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
     if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_lba_window_stats: bad argument"); return OSLAM_E_INVALID; }
     const auto& s = *h->c.seq[seq];
@@ -2053,6 +2116,7 @@ static void twc_rows(const M4& Tcw, float* o) {   // Rwc = Rcw.t(), twc = -Rwc*t
 
 int oslam_slam_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out) {
     if (!h || seq < 0 || seq >= h->c.S || !n_out) { oslam::set_error("oslam_slam_trajectory: bad argument"); return OSLAM_E_INVALID; }
+    { const int rc_ = oslam_slam_finish(h); if (rc_) return rc_; }   // System::Shutdown waits for the local mapper before the trajectory is saved
     const Seq& s = *h->c.seq[seq];
     const Map& m = s.map;
     int n = 0;
@@ -2078,6 +2142,7 @@ int oslam_slam_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, flo
 
 int oslam_slam_keyframe_trajectory(oslam_slam_t* h, int seq, int cap, double* stamps, float* Twc, int32_t* n_out) {
     if (!h || seq < 0 || seq >= h->c.S || !n_out) { oslam::set_error("oslam_slam_keyframe_trajectory: bad argument"); return OSLAM_E_INVALID; }
+    { const int rc_ = oslam_slam_finish(h); if (rc_) return rc_; }   // System::Shutdown waits for the local mapper before the trajectory is saved
     const Map& m = h->c.seq[seq]->map;
     int n = 0;
     for (const KeyFrm& k : m.kfs) {

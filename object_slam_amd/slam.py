@@ -22,7 +22,7 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes", "lba_submit", "lba_wait")]
 
 
 class SlamObjects(C.Structure):
@@ -37,6 +37,7 @@ TUM2 = dict(fx=520.908620, fy=521.007327, cx=325.141442, cy=249.701764, bf=40.0,
 KITTI00 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, thDepth=35.0, fps=10.0)
 
 OK, LOST, NOT_INITIALIZED = 2, 3, 1
+LM_SYNC, LM_DEFERRED = 0x1F, 0x3F   # oslam_slam_config_t::local_mapping: the whole LocalMapping::Run pass; bit 5 = the deferred schedule (include/oslam_slam.h)
 STEREO, RGBD = 1, 2
 
 
@@ -250,6 +251,10 @@ class System:
         T = np.zeros((cap, 3, 4), np.float32)
         check(fn(self.h, C.c_int(seq), C.c_int(cap), ptr(st), ptr(T), C.byref(n)))
         return st[:n.value].copy(), T[:n.value].copy()
+
+    def finish(self):
+        """Deferred schedule: applies the pending half of the last local-mapping pass (System::Shutdown's wait for the local mapper)."""
+        check(self.L.oslam_slam_finish(self.h))
 
     def trajectory(self, seq):
         """(stamps, Twc[n,3,4]) as System::SaveTrajectoryTUM would write them (reference src/System.cc:378-440)."""

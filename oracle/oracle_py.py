@@ -17,8 +17,12 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO):
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    # make decides what is stale (the operator-table sources include the product's C ABI headers); where make or the sources are missing the prebuilt file is used
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(_SO):
+            raise
     return _SO
 
 

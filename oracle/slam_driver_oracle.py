@@ -365,6 +365,7 @@ class Slam:
         self.mlRelativeFramePoses = []     # (Tcr, refKF, stamp, lost)
         self.mlpRecentAddedMapPoints = []
         self.mlNewKeyFrames = []
+        self.pendingLM = None              # deferred schedule: (keyframe, gathered local-BA window) of the previous frame's pass
         self.mLastFrame = None
         self.mbReset = False
         self.keyframes = []
@@ -386,6 +387,7 @@ class Slam:
         self.keyframes = []
         self.nKFsInMap = self.nMPsInMap = 0
         self.mbReset = False
+        self.pendingLM = None
         self.mspObject3Ds, self.objOfTrack = [], {}          # Map::clear()
 
     # ------------------------------------------------------------------ object layer
@@ -824,6 +826,7 @@ class Slam:
                 F.mpReferenceKF = self.mpReferenceKF
         self._update_points(created, True, True)
         if self.mbReset:
+            self.FinishLocalMapping()
             return (None if F.pose.Tcw is None else F.pose.Tcw.copy()), self.mState
         if F.pose.Tcw is not None:
             self.mlRelativeFramePoses.append((mul4(F.pose.Tcw, F.mpReferenceKF.pose.Twc), self.mpReferenceKF, stamp, self.mState == LOST))
@@ -833,6 +836,7 @@ class Slam:
         if self.mState != NOT_INITIALIZED:
             self.mLastFrame = F
         Tcw = None if F.pose.Tcw is None else F.pose.Tcw.copy()
+        self.FinishLocalMapping()                                       # deferred schedule: the second half of the previous frame's pass
         if self.mlNewKeyFrames:
             self.LocalMapping()
         return Tcw, self.mState
@@ -1032,8 +1036,25 @@ class Slam:
                 self.Fuse(cur, cand)
             self._update_points([p for p in cur.mvpMapPoints if p is not None and not p.mbBad], True, True)
             cur.UpdateConnections()
-        if self.flags & 8 and self.nKFsInMap > 2:                      # LocalBundleAdjustment
-            self.LocalBundleAdjustment(cur)
+        # Second half of the pass (LocalBundleAdjustment's solve + write-back, KeyFrameCulling).  Synchronous schedule: right here.  Deferred schedule
+        # (flags bit 5, include/oslam_slam.h head comment): the graph gather happens here, the solve and everything after it once the NEXT frame has been
+        # tracked (FinishLocalMapping, called from Track before the next pass and from trajectory()).
+        gathered = self._lba_gather(cur) if (self.flags & 8 and self.nKFsInMap > 2) else None
+        if self.flags & 32:
+            self.pendingLM = (cur, gathered)
+            return
+        self._local_mapping_back(cur, gathered)
+
+    def FinishLocalMapping(self):
+        if self.pendingLM is None:
+            return
+        cur, gathered = self.pendingLM
+        self.pendingLM = None
+        self._local_mapping_back(cur, gathered)
+
+    def _local_mapping_back(self, cur, gathered):
+        if gathered is not None:
+            self._lba_solve_and_write_back(gathered)
         if self.flags & 16:                                            # KeyFrameCulling
             for k in list(cur.mvpOrderedConnectedKeyFrames):
                 if k.mnId == 0:
@@ -1060,7 +1081,8 @@ class Slam:
                 if nRed > 0.9 * nMPs:
                     k.SetBadFlag(self)
 
-    def LocalBundleAdjustment(self, cur):
+    def _lba_gather(self, cur):
+        """Optimizer::LocalBundleAdjustment's graph gather (src/Optimizer.cc:456-504, :522-651) into flat arrays."""
         kfs = [cur]
         cur.mnBALocalForKF = cur.mnId
         for k in cur.mvpOrderedConnectedKeyFrames:
@@ -1096,7 +1118,12 @@ class Slam:
                 eref.append((k, p))
         self.st["local_bas"] += 1
         self.st["lba_edges"] += len(ekf)
-        po, xo, erase, _ = O.local_bundle_adjustment(poses, fixed, points, ekf, ept, np.array(eobs, f32), np.array(einv, f32), self.K5)
+        return dict(kfs=kfs, nLocal=nLocal, pts=pts, poses=poses, fixed=fixed, points=points, ekf=ekf, ept=ept, eobs=eobs, einv=einv, eref=eref)
+
+    def _lba_solve_and_write_back(self, g):
+        """The two optimize() calls (:660, :706-707) on the gathered window, then the write-back under the map mutex (:711-777)."""
+        kfs, nLocal, pts, ekf, ept, eobs, einv, eref = g["kfs"], g["nLocal"], g["pts"], g["ekf"], g["ept"], g["eobs"], g["einv"], g["eref"]
+        po, xo, erase, _ = O.local_bundle_adjustment(g["poses"], g["fixed"], g["points"], ekf, ept, np.array(eobs, f32), np.array(einv, f32), self.K5)
         for stereo_pass in (False, True):
             for e in range(len(ekf)):
                 if not erase[e] or (eobs[e][2] >= 0) != stereo_pass:
@@ -1114,7 +1141,8 @@ class Slam:
 
     # ------------------------------------------------------------------ outputs
     def trajectory(self):
-        """System::SaveTrajectoryTUM: list of (stamp, Twc[3,4])."""
+        """System::SaveTrajectoryTUM: list of (stamp, Twc[3,4]).  (System::Shutdown has waited for the local mapper: src/System.cc:303-320.)"""
+        self.FinishLocalMapping()
         if not self.keyframes:
             return []
         Two = self.keyframes[0].pose.Twc

@@ -96,12 +96,13 @@ def test_map_bookkeeping_unit_checks(tmp_path):
     assert out.returncode == 0, out.stderr
 
 
-def test_not_initialised_lost_and_reset(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_not_initialised_lost_and_reset(oracle, lm):
     """A textureless first frame leaves the sequence NOT_INITIALIZED (StereoInitialization needs > 500 keypoints, reference
     src/Tracking.cc:592).  Losing the track with <= 5 keyframes resets the system (:553-561): the next textured frame initialises a new
     map whose ids restart at 0.  The independent restatement goes through the same states with the same poses."""
     from oracle import slam_driver_oracle as R
-    cfg = slam.make_config(W, H, 1)
+    cfg = slam.make_config(W, H, 1, local_mapping=lm)
     streams = make_streams(1, 12)
     blank = np.full((H, W), 90, np.uint8)
     seq = [blank] + list(streams[0][0][:6]) + [blank, blank] + list(streams[0][0][6:10])
@@ -136,12 +137,13 @@ def _cfg_dict(cfg):
                 sensor=cfg.sensor, local_mapping=cfg.local_mapping)
 
 
-def test_driver_against_independent_restatement(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_driver_against_independent_restatement(oracle, lm):
     """The product's driver (index-based, staged, C++) against oracle/slam_driver_oracle.py (object-style Python restatement of the
     reference's Tracking / LocalMapping flow), both over the CPU oracle operators: same states, same map statistics, same poses."""
     from oracle import slam_driver_oracle as R
     n = 26
-    cfg = slam.make_config(W, H, 1)
+    cfg = slam.make_config(W, H, 1, local_mapping=lm)
     streams = make_streams(1, n)
     depth = np.full((H, W), 2.0, np.float32)
     sysm = slam.System(cfg, oracle_ops(cfg))
@@ -161,14 +163,15 @@ def test_driver_against_independent_restatement(oracle):
     assert np.array_equal(Twc, np.stack([x[1] for x in tr]))
 
 
-def test_keyframe_culling_against_independent_restatement(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_keyframe_culling_against_independent_restatement(oracle, lm):
     """A stream with foreign texture over half of every second frame makes the tracker insert keyframes in mapped territory, so
     LocalMapping::KeyFrameCulling (reference src/LocalMapping.cc:638-713) removes redundant ones: both drivers must take the same
     decisions (the culled keyframes change covisibility, the spanning tree, the local map and the trajectory anchors)."""
     from oracle import slam_driver_oracle as R
     from object_slam_amd import synth
     n = 54
-    cfg = slam.make_config(W, H, 1)
+    cfg = slam.make_config(W, H, 1, local_mapping=lm)
     frames, _ = synth.make_occluded_stream(n, W, H, seed=11)
     depth = np.full((H, W), 2.0, np.float32)
     sysm = slam.System(cfg, oracle_ops(cfg))
@@ -297,3 +300,26 @@ print("degraded", w["lba_windows_degraded"], "of", w["windows"], "ate", a)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OSLAM_SLAM_LBA_MAX_FREE="3"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "degraded" in r.stdout
+
+
+def test_deferred_schedule_differs_from_the_synchronous_one_only_by_when_the_ba_lands(oracle):
+    """OSLAM_SLAM_LM_DEFERRED (include/oslam_slam.h head comment): local BA's write-back and KeyFrameCulling of keyframe t are applied after the tracking of
+    frame t+1.  The frame that follows a keyframe therefore tracks against the un-refined map — its pose differs from the synchronous run's by what the BA
+    would have moved — while the trajectory stays as accurate; the first pass (two keyframes: no BA, nothing to cull) is identical; oslam_slam_finish applies
+    the last pass, so both runs end with the same number of local BAs."""
+    n = 36
+    streams = make_streams(1, n)
+    out = {}
+    for lm in (slam.LM_SYNC, slam.LM_DEFERRED):
+        cfg = slam.make_config(W, H, 1, local_mapping=lm)
+        sysm = slam.System(cfg, oracle_ops(cfg))
+        poses, states = run(sysm, streams, n)
+        assert (states == slam.OK).all()
+        a, _ = ate(sysm, cfg, streams, 0)      # (trajectory() finishes the pending pass)
+        out[lm] = (poses, sysm.stats(0), a)
+        assert out[lm][1]["map_violations"] == 0 and a < 0.01, (lm, a)
+    ps, pd = out[slam.LM_SYNC][0], out[slam.LM_DEFERRED][0]
+    first_diff = next(t for t in range(n) if not np.array_equal(ps[t], pd[t]))
+    assert first_diff >= 2                      # frames 0-1 never differ: the first BA needs three keyframes in the map
+    assert np.abs(ps - pd).max() < 5e-3         # the same trajectory up to what one BA moves
+    assert out[slam.LM_SYNC][1]["local_bas"] >= 2 and out[slam.LM_DEFERRED][1]["local_bas"] >= 2
