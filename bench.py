@@ -67,7 +67,7 @@ def launch_ranks(n):
 # --------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the same driver over the CPU oracle's operator table (test infrastructure; "port"), bounded sample
 # --------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, seq, first, n_timed):
+def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F):
     """The same driver over the CPU oracle's operator table on one core: frames [0, first) of the sequence untimed (the map reaches the state the GPU leg's
     sequences have when ITS timed region starts), then `n_timed` frames timed — the same frame range as the GPU leg's timed steps and the frames after them."""
     import ctypes as C
@@ -75,7 +75,7 @@ def cpu_baseline(wl, seq, first, n_timed):
     from object_slam_amd.e2e import horn_align_ate
     from oracle import oracle_py as O
     O.build()
-    cfg = slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor)
+    cfg = slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor, local_mapping=local_mapping)   # (the GPU leg's schedule: one core runs the same passes either way)
     ops = slam.SlamOps()
     assert O.lib().oo_slam_make_ops(C.byref(cfg), C.byref(ops)) == 0
     sysm = slam.System(cfg, ops)
@@ -365,6 +365,9 @@ def main():
                                                              "RGB-D stream = SURVEY.md §8(d) frame >= 200, 40 for the stereo street); 0 = the cold-start regime of round 2")
     ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 8192 RGB-D / 512 stereo)")
     ap.add_argument("--bases", type=int, default=8, help="base renderings per GPU of the headline stream (distinct input streams = bases x 25 frame offsets)")
+    ap.add_argument("--lm", choices=("deferred", "sync"), default="deferred", help="local-mapping schedule (include/oslam_slam.h): deferred = the local BA of keyframe t is solved by the "
+                    "process-wide service while frame t+1 is tracked, its write-back and KeyFrameCulling land before frame t+2 (the reference's two-thread overlap, "
+                    "src/System.cc:95); sync = the whole pass right after the frame that inserted the keyframe (rounds 1-3)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8 / 4)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -453,7 +456,8 @@ def main():
         threads = int(os.environ.get("OSLAM_BENCH_HOST_THREADS", "0")) or max(1, share // G_)
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
                                                       host_threads=threads, sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl",
-                                                      preroll=preroll_, post_frames=post_frames_, post=post_, progress=log)
+                                                      preroll=preroll_, post_frames=post_frames_, post=post_, progress=log,
+                                                      local_mapping=slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC)
         tot = extra.get("post", {}).get("kernel_times_timed") if isinstance(extra.get("post"), dict) else None
         if tot is None:
             tot = {}
@@ -545,7 +549,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if log:
                 log("CPU baseline ...")
-            cpu = cpu_baseline(head, seq_head[0], preroll + args.warmup, args.cpu_frames or (len(seq_head[0]["gray"]) - preroll - args.warmup))
+            cpu = cpu_baseline(head, seq_head[0], preroll + args.warmup, args.cpu_frames or (len(seq_head[0]["gray"]) - preroll - args.warmup),
+                               slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC)
         front = None
         if extras_on and head is wl_rgbd:
             try:
@@ -574,7 +579,7 @@ def main():
                                       "%d sequences per GPU in %d handles (one host thread + %d workers each), %d ORB features, images resident in HBM; %s; "
                                       "BASELINE.json configs[%s]" % (head.name, S, G, summ["host_threads_per_handle"] - 1, head.nFeatures, regime, "2" if head is wl_rgbd else "3]/[4"),
                           "regime": "steady_state" if preroll > 0 else "cold_start", "preroll_steps": preroll, "preroll_s": round(summ["preroll_s"], 1),
-                          "sequences_per_gpu": S, "frames_per_step": S * world,
+                          "sequences_per_gpu": S, "frames_per_step": S * world, "local_mapping_schedule": args.lm,
                           "distinct_streams_per_gpu": min(S, head.n_base * (head.stagger + 1)), "replicas_per_stream": round(S / min(S, head.n_base * (head.stagger + 1)), 1),
                           "inputs_note": "the %d sequences of a GPU replay %d base renderings at %d frame offsets: every distinct input frame of a step is read by ~%.0f sequences "
                                          "(maps, keyframes and local-BA windows are per sequence and not shared); --bases N renders more base streams for an A/B of the cache "

@@ -5,6 +5,10 @@
 #include <cmath>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -14,7 +18,16 @@
 
 namespace {
 
+struct LbaService;
+struct LbaJob {   // one handle's submission to the local-BA service (below)
+    int n = 0; const oslam_lba_problem_t* probs = nullptr; float K5[5] = {0, 0, 0, 0, 0};
+    bool timing = false, done = false; int rc = 0; char err[256] = "";
+    double ms = 0, launches = 0, flop = 0;
+};
+
 struct HipOps {
+    LbaService* svc = nullptr;            // deferred schedule: the process-wide local-BA service of this device
+    LbaJob job; bool job_active = false;
     oslam_slam_config_t cfg;
     int S = 0, cap = 0;
     oslam_orb_t* orb = nullptr;
@@ -940,6 +953,149 @@ static double lba_flop(const oslam_lba_problem_t& q, const int32_t st[4]) {
     return (double)(st[1] + st[3]) * (700.0 * q.nE + schur + n6 * n6 * n6 / 3.0 + 2.0 * n6 * n6 + 45.0 * q.nP);
 }
 
+// ---- local-BA service (deferred schedule, include/oslam_slam.h: lba_submit / lba_wait) ----
+// The handles of a process step independently, each on its own host thread and stream.  In the synchronous schedule every handle runs its own local-BA call
+// (~40-80 windows) on its own stream: eight such calls interleave ~180 dependent launches each on one card and every launch runs several times longer than
+// alone.  In the deferred schedule a handle only SUBMITS its windows and tracks the next frame; ONE service thread per device takes whatever the handles have
+// submitted meanwhile (same camera), solves it as ONE batch on its own stream and wakes the submitters.  A window's result does not depend on the batch it is
+// solved in (tests/test_lba_gpu.py), so the schedule of the service does not enter the results.
+struct LbaService {
+    typedef LbaJob Job;
+    int device = 0;
+    oslam_lba_t* ba = nullptr;
+    hipStream_t strm = nullptr;
+    int max_batch = 0, mode_small = 1, mode_big = 1, big_from = 1 << 30;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Job*> queue;
+    bool stop = false;
+    int users = 0;
+    long long calls = 0, windows = 0, max_windows = 0;
+
+    static std::mutex& reg_mu() { static std::mutex m; return m; }
+    static LbaService*& slot(int device) { static LbaService* s[64] = {nullptr}; return s[device & 63]; }
+
+    static LbaService* acquire(int device) {
+        std::lock_guard<std::mutex> lk(reg_mu());
+        LbaService*& sv = slot(device);
+        if (!sv) {
+            LbaService* n = new LbaService;
+            n->device = device;
+            if (n->start()) { delete n; return nullptr; }
+            sv = n;
+        }
+        sv->users++;
+        return sv;
+    }
+    static void release(LbaService* sv) {
+        if (!sv) return;
+        std::lock_guard<std::mutex> lk(reg_mu());
+        if (--sv->users > 0) return;
+        { std::lock_guard<std::mutex> l2(sv->mu); sv->stop = true; }
+        sv->cv_work.notify_all();
+        if (sv->th.joinable()) sv->th.join();
+        if (getenv("OSLAM_LBA_SERVICE_STATS")) fprintf(stderr, "[lba service] %lld calls, %lld windows (%.1f per call, max %lld)\n", sv->calls, sv->windows, sv->calls ? (double)sv->windows / sv->calls : 0.0, sv->max_windows);
+        (void)hipSetDevice(sv->device);
+        oslam_lba_destroy(sv->ba);
+        if (sv->strm) (void)hipStreamDestroy(sv->strm);
+        slot(sv->device) = nullptr;
+        delete sv;
+    }
+    int start() {
+        OSLAM_HIP_CHECK(hipSetDevice(device));
+        max_batch = getenv("OSLAM_LBA_SERVICE_MAX_BATCH") ? atoi(getenv("OSLAM_LBA_SERVICE_MAX_BATCH")) : 4096;
+        int rc = oslam_lba_create(&ba, max_batch, 1 << 16, 4096, 32768, device);
+        if (rc) return rc;
+        // OSLAM_LBA_SERVICE_CUS=k: the service's stream may only use k of the card's CUs (the tracking kernels of the handles keep the others to themselves)
+        const int cus = getenv("OSLAM_LBA_SERVICE_CUS") ? atoi(getenv("OSLAM_LBA_SERVICE_CUS")) : 0;
+        if (cus > 0) {
+            hipDeviceProp_t pr;
+            OSLAM_HIP_CHECK(hipGetDeviceProperties(&pr, device));
+            const int total = pr.multiProcessorCount;
+            std::vector<uint32_t> mask((total + 31) / 32, 0u);
+            for (int i = 0; i < std::min(cus, total); i++) mask[i >> 5] |= 1u << (i & 31);
+            OSLAM_HIP_CHECK(hipExtStreamCreateWithCUMask(&strm, (uint32_t)mask.size(), mask.data()));
+            oslam::lba_use_stream(ba, strm);
+        }
+        // layout per call: batches of at least `big_from` windows go through the one-workgroup-per-window kernel (mode 2), smaller ones through the multi-launch layout
+        mode_small = getenv("OSLAM_LBA_SERVICE_MODE") ? atoi(getenv("OSLAM_LBA_SERVICE_MODE")) : 1;
+        mode_big = getenv("OSLAM_LBA_SERVICE_MODE_BIG") ? atoi(getenv("OSLAM_LBA_SERVICE_MODE_BIG")) : mode_small;
+        big_from = getenv("OSLAM_LBA_SERVICE_BIG_FROM") ? atoi(getenv("OSLAM_LBA_SERVICE_BIG_FROM")) : (1 << 30);
+        th = std::thread([this] { run(); });
+        return OSLAM_OK;
+    }
+    void submit(Job* j) {
+        { std::lock_guard<std::mutex> lk(mu); j->done = false; queue.push_back(j); }
+        cv_work.notify_one();
+    }
+    void wait(Job* j) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return j->done; });
+    }
+    void run() {
+        (void)hipSetDevice(device);
+        std::vector<Job*> take;
+        std::vector<oslam_lba_problem_t> probs;
+        std::vector<int32_t> st;
+        for (;;) {
+            take.clear();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !queue.empty(); });
+                if (queue.empty()) return;   // (stop with nothing left)
+                // everything submitted so far with the camera of the oldest job, up to the batch capacity
+                Job* first = queue.front();
+                int total = 0;
+                for (auto it = queue.begin(); it != queue.end();) {
+                    Job* j = *it;
+                    if (memcmp(j->K5, first->K5, sizeof(first->K5)) == 0 && (take.empty() || total + j->n <= max_batch)) { take.push_back(j); total += j->n; it = queue.erase(it); }
+                    else ++it;
+                }
+            }
+            probs.clear();
+            bool timing = false;
+            for (Job* j : take) { probs.insert(probs.end(), j->probs, j->probs + j->n); timing = timing || j->timing; }
+            const int n = (int)probs.size();
+            st.assign((size_t)4 * n, 0);
+            for (int i = 0; i < n; i++) probs[i].stats = &st[4 * (size_t)i];
+            int rc = OSLAM_OK;
+            double ms = 0; long long launches = 0;
+            if (n > 0) {
+                rc = oslam_lba_set_mode(ba, n >= big_from ? mode_big : mode_small);
+                if (!rc) rc = oslam_lba_kernel_time(ba, timing ? 1 : 0, nullptr, nullptr);
+                for (int at = 0; !rc && at < n; at += max_batch) rc = oslam_lba_optimize_batch(ba, std::min(max_batch, n - at), probs.data() + at, take[0]->K5);
+                if (!rc && timing) rc = oslam_lba_kernel_time(ba, 0, &ms, &launches);
+            }
+            calls++; windows += n; max_windows = std::max<long long>(max_windows, n);
+            // the call's kernel time and launches are shared out by the windows' flop / count (the sums over the handles are the call's)
+            std::vector<double> fl(take.size(), 0.0);
+            double fl_all = 0;
+            if (!rc && timing) {
+                size_t at = 0;
+                for (size_t q = 0; q < take.size(); q++) {
+                    for (int i = 0; i < take[q]->n; i++, at++) {
+                        const oslam_lba_problem_t& w = probs[at];
+                        fl[q] += lba_flop(w, w.stats);
+                    }
+                    fl_all += fl[q];
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                for (size_t q = 0; q < take.size(); q++) {
+                    Job* j = take[q];
+                    j->rc = rc;
+                    if (rc) snprintf(j->err, sizeof(j->err), "%s", oslam_last_error());
+                    j->flop = fl[q]; j->ms = fl_all > 0 ? ms * fl[q] / fl_all : 0; j->launches = n > 0 ? (double)launches * j->n / n : 0;
+                    j->done = true;
+                }
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
 int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
@@ -966,6 +1122,31 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
         o->kt[6] += ms; o->kt[7] += (double)launches; o->kt[8] += flop;
     }
     return rc;
+}
+
+static void lba_service_release(LbaService* s) { LbaService::release(s); }
+
+int h_lba_submit(void* p, int n, const oslam_lba_problem_t* pr) {
+    HipOps* o = (HipOps*)p;
+    if (!o->svc) { oslam::set_error("lba_submit: no local-BA service"); return OSLAM_E_INVALID; }
+    if (o->job_active) { oslam::set_error("lba_submit: a submission is already in flight"); return OSLAM_E_INVALID; }
+    LbaService::Job& j = o->job;
+    j = LbaService::Job();
+    j.n = n; j.probs = pr; memcpy(j.K5, o->K5, sizeof(j.K5)); j.timing = o->timing != 0;
+    o->job_active = true;
+    o->svc->submit(&j);
+    return OSLAM_OK;
+}
+
+int h_lba_wait(void* p) {
+    HipOps* o = (HipOps*)p;
+    if (!o->job_active) return OSLAM_OK;
+    o->svc->wait(&o->job);
+    o->job_active = false;
+    const LbaService::Job& j = o->job;
+    if (j.rc) { oslam::set_error("local-BA service: %s", j.err); return j.rc; }
+    if (o->timing) { o->kt[6] += j.ms; o->kt[7] += j.launches; o->kt[8] += j.flop; }
+    return OSLAM_OK;
 }
 
 // ---- resident keyframes ----
@@ -1341,6 +1522,8 @@ int h_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 void h_destroy(void* p) {
     HipOps* o = (HipOps*)p;
     (void)hipSetDevice(o->cfg.device);
+    if (o->job_active) (void)h_lba_wait(o);   // (the submitted windows' arrays belong to the driver handle being destroyed)
+    lba_service_release(o->svc);
     oslam_orb_destroy(o->orb); oslam_orb_destroy(o->orbR); oslam_stereo_destroy(o->stereo); (void)hipFree(o->d_grayR); oslam_matcher_destroy(o->m_last); oslam_matcher_destroy(o->m_map); oslam_poseopt_destroy(o->po);
     oslam_lba_destroy(o->ba); oslam_lba_destroy(o->ba1); oslam_mappoint_destroy(o->mp); oslam_frame_destroy(o->fr); oslam_bow_destroy(o->bow);
     if (o->up_h) (void)hipHostFree(o->up_h);
@@ -1425,6 +1608,11 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
+    if ((cfg->local_mapping & OSLAM_SLAM_LM_DEFERRED) && !getenv("OSLAM_LBA_NO_SERVICE")) {   // (OSLAM_LBA_NO_SERVICE=1: the deferred schedule with the handle's own solver at collection time)
+        o->svc = LbaService::acquire(dev);
+        if (!o->svc) { h_destroy(o); return OSLAM_E_HIP; }
+        ops->lba_submit = h_lba_submit; ops->lba_wait = h_lba_wait;
+    }
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;

@@ -184,7 +184,7 @@ def window_stats(after, before):
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,
-             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None):
+             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None, local_mapping=slam.LM_SYNC):
     """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread); `preroll` untimed steps that
     bring every sequence's map to its steady state (they are part of the set-up, like loading a map), `warmup` untimed lockstep steps, then exactly `steps`
     timed steps bracketed by a barrier + device synchronisation on both sides.  `post(ctx)` (optional) may run further phases on the warmed sequences
@@ -204,7 +204,8 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     systems = []
     for h in range(handles):
         cfg = slam.make_config(wl.width, wl.height, per, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor,
-                               device=(device.index if hasattr(device, "index") and device.index is not None else 0) if on_device else 0, host_threads=host_threads)
+                               device=(device.index if hasattr(device, "index") and device.index is not None else 0) if on_device else 0, host_threads=host_threads,
+                               local_mapping=local_mapping)
         systems.append(make_system(cfg))
     poses = [[] for _ in range(handles)] if collect_poses else [None] * handles
     calls = [_prepare(systems[h], wl, inp, groups[h], n_frames + post_frames) for h in range(handles)]

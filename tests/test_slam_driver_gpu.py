@@ -10,13 +10,16 @@ from slam_common import H, W, ate, make_streams, oracle_ops, run
 pytestmark = pytest.mark.gpu
 
 
-def test_hip_driver_matches_oracle_driver(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_hip_driver_matches_oracle_driver(oracle, lm):
+    """lm = deferred: the local BA of keyframe t is solved by the process-wide service while frame t+1 is tracked (include/oslam_slam.h head comment); the oracle
+    table has no asynchronous form and solves it at collection time — same windows, same results."""
     n, S = 30, 3
     streams = make_streams(S, n)
-    cfg = slam.make_config(W, H, S)
+    cfg = slam.make_config(W, H, S, local_mapping=lm)
     hip = slam.System(cfg)
     ph, sh = run(hip, streams, n)
-    cfg_o = slam.make_config(W, H, S)
+    cfg_o = slam.make_config(W, H, S, local_mapping=lm)
     ora = slam.System(cfg_o, oracle_ops(cfg_o))
     po, so = run(ora, streams, n)
     assert np.array_equal(sh, so) and (sh == slam.OK).all()
@@ -50,14 +53,15 @@ def test_hip_driver_device_resident_inputs():
     assert np.array_equal(np.array(pd), ph)
 
 
-def test_hip_stereo_driver_matches_oracle_driver(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_hip_stereo_driver_matches_oracle_driver(oracle, lm):
     from slam_common import ate_stereo, make_stereo_streams, run_stereo, stereo_config
     n, S = 16, 2
     streams = make_stereo_streams(S, n)
-    cfg = stereo_config(S)
+    cfg = stereo_config(S, local_mapping=lm)
     hip = slam.System(cfg)
     ph, sh = run_stereo(hip, streams, n)
-    cfg_o = stereo_config(S)
+    cfg_o = stereo_config(S, local_mapping=lm)
     ora = slam.System(cfg_o, oracle_ops(cfg_o))
     po, so = run_stereo(ora, streams, n)
     assert np.array_equal(sh, so) and (sh == slam.OK).all()
@@ -71,7 +75,8 @@ def test_hip_stereo_driver_matches_oracle_driver(oracle):
     assert np.abs(ph - po).max() < 2e-3, np.abs(ph - po).max()
 
 
-def test_two_handles_on_two_threads_match_sequential_runs():
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_two_handles_on_two_threads_match_sequential_runs(lm):
     """Several driver handles on one GPU, each advanced by its own host thread (the deployment bench.py measures): every handle owns its
     stream and buffers, so the concurrent runs must reproduce the sequential ones bit for bit."""
     import threading
@@ -79,10 +84,11 @@ def test_two_handles_on_two_threads_match_sequential_runs():
     streams = [make_streams(S, n, seed0=11), make_streams(S, n, seed0=31)]
     ref = []
     for g in range(2):
-        sysm = slam.System(slam.make_config(W, H, S))
+        sysm = slam.System(slam.make_config(W, H, S, local_mapping=lm))
         p, _ = run(sysm, streams[g], n)
         ref.append((p, [sysm.stats(s) for s in range(S)]))
-    systems = [slam.System(slam.make_config(W, H, S, host_threads=2)) for _ in range(2)]
+    # (deferred: both handles submit to ONE local-BA service, which solves whatever has been submitted as one batch — the results may not depend on that)
+    systems = [slam.System(slam.make_config(W, H, S, host_threads=2, local_mapping=lm)) for _ in range(2)]
     out = [None, None]
 
     def work(g):
@@ -114,16 +120,17 @@ def test_hip_driver_with_lens_distortion_matches_oracle_driver(oracle):
     assert np.abs(ph - po).max() < 2e-4
 
 
-def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle, lm):
     """Occluded stream (synth.make_occluded_stream): keyframes are inserted in mapped territory and LocalMapping::KeyFrameCulling removes
     redundant ones; the HIP operator table must lead the driver to the same culling decisions as the CPU oracle's table."""
     from object_slam_amd import synth
     n, S = 54, 2
     streams = [synth.make_occluded_stream(n, W, H, seed=sd) for sd in (11, 14)]
-    cfg = slam.make_config(W, H, S)
+    cfg = slam.make_config(W, H, S, local_mapping=lm)
     hip = slam.System(cfg)
     ph, sh = run(hip, streams, n)
-    cfg_o = slam.make_config(W, H, S)
+    cfg_o = slam.make_config(W, H, S, local_mapping=lm)
     ora = slam.System(cfg_o, oracle_ops(cfg_o))
     po, so = run(ora, streams, n)
     assert np.array_equal(sh, so) and (sh == slam.OK).all()
@@ -136,16 +143,17 @@ def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle):
     assert d < 2e-4, d
 
 
-def test_hip_driver_matches_oracle_driver_on_3d_scene(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_hip_driver_matches_oracle_driver_on_3d_scene(oracle, lm):
     """S1 as SURVEY.md §8(d) specifies it: SE3 path with rotation and forward / backward motion over walls and boxes at 1.3 - 4.6 m, so matches
     change pyramid level, triangulation fires and the local BA windows are not planar."""
     from slam_common import ate_scene, make_scene_streams, run_scene
     n, S = 36, 2
     seqs = make_scene_streams(S, n)
-    cfg = slam.make_config(W, H, S)
+    cfg = slam.make_config(W, H, S, local_mapping=lm)
     hip = slam.System(cfg)
     ph, sh = run_scene(hip, seqs, n)
-    cfg_o = slam.make_config(W, H, S)
+    cfg_o = slam.make_config(W, H, S, local_mapping=lm)
     ora = slam.System(cfg_o, oracle_ops(cfg_o))
     po, so = run_scene(ora, seqs, n)
     assert np.array_equal(sh, so) and (sh == slam.OK).all()
@@ -369,16 +377,17 @@ def test_create_new_map_points_in_one_batch_equals_the_neighbour_rounds(monkeypa
         assert st == b.stats(q) and st["points_triangulated"] > 50, st
 
 
-def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle):
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_hip_driver_200_frames_with_masks_matches_oracle_driver(oracle, lm):
     """Soak at the S1 specification: 200 frames at speed 1 (<= 2 cm, <= 0.5 deg per frame) with the three instance masks; the HIP and
     the oracle operator tables must lead the driver through the same 200 frames (states, map statistics, object bookkeeping), ATE below 2 cm."""
     from slam_common import ate_scene
     from object_slam_amd import scene
     n = 200
     q = scene.make_rgbd_sequence(5, n, speed=1.0)
-    hip = slam.System(slam.make_config(W, H, 1))
+    hip = slam.System(slam.make_config(W, H, 1, local_mapping=lm))
     ph = _semantic_run(hip, q, n)
-    cfg_o = slam.make_config(W, H, 1)
+    cfg_o = slam.make_config(W, H, 1, local_mapping=lm)
     ora = slam.System(cfg_o, oracle_ops(cfg_o))
     po = _semantic_run(ora, q, n)
     a, b = hip.stats(0), ora.stats(0)
