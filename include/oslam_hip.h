@@ -408,8 +408,10 @@ int oslam_lba_kernel_time(oslam_lba_t* h, int enable, double* ms_out, long long*
  * driven from src/Optimizer.cc:659-660,706-707); field 5 = first trial of a stage.  Process-wide: one handle traces at a time. */
 int oslam_lba_trace(oslam_lba_t* h, int cap);
 int oslam_lba_trace_read(oslam_lba_t* h, double* out, int32_t* n);
-/* Reduced-camera-system solver of the wide mode: 0 (default) = the LDS-resident scalar kernel while the augmented system fits (6 x free keyframes <= 132),
- * the matrix-core kernel (v_mfma_f64_16x16x4_f64 trailing updates, 16-wide panels) beyond; 1 = matrix cores for every size; 2 = never. */
+/* Reduced-camera-system solver of the wide mode: 0 (default) = the LDS-resident scalar kernel when EVERY system of the call has at most 132 unknowns
+ * (6 x free keyframes), otherwise matrix cores (v_mfma_f64_16x16x4_f64 trailing updates, 16-wide panels): with the system resident in LDS up to 186 unknowns
+ * (k_w_chol_lds_mfma: the windows of the driver's steady state), in global memory beyond; 1 = the global-memory matrix-core kernel for every size; 2 = no
+ * matrix cores; 3 = the round-3 choice (scalar packed LDS kernel up to 192 unknowns, global-memory matrix cores beyond), kept as an A/B. */
 int oslam_lba_set_solver(oslam_lba_t* h, int mode);
 int oslam_lba_debug_stats(oslam_lba_t* h, int32_t out[16]);   /* [0..3] stats, [8..15] per-phase kilo-cycles in profiling builds */
 int oslam_lba_optimize(oslam_lba_t* h, int nKF, const float* poses, const uint8_t* fixed, int nP,

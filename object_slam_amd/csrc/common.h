@@ -28,6 +28,9 @@ void set_error(const char* fmt, ...);
 // 150-step pre-roll): spinning 20.9 k frames/s, 60 us poll + sleep 18.7 k, and neither a third thread per handle (17.5 k) nor 12 handles (15.0 k) gains from
 // the freed cores: the wake-up latency of ~400 waits per step costs more than the spinning.  Kept as a knob.
 hipError_t stream_wait(hipStream_t s);
+// This host thread's own wait mode from now on (microseconds of polling before it sleeps on a blocking event; 0 = sleep at once, -1 = hipStreamSynchronize,
+// -2 = pure polling): the local-BA service thread is off every handle's critical path and sleeps, so that its core goes to the handles' workers.
+void stream_wait_thread_mode(int spin_us);
 // The operator table of a driver handle calls its sub-handles one after the other from one thread: they can share that handle's stream instead of
 // owning one each (streams beyond the device's hardware queues share queues, and a queue executes its packets in order whatever stream they came from).
 // The caller keeps the stream alive for the lifetime of the sub-handle.

@@ -566,6 +566,41 @@ __global__ __launch_bounds__(kLbaThreads) void k_lba(const LbaProblem* probs) {
 }
 
 
+// Jacobians of the binary edges (se3_math.h jac_binary) with ONE reciprocal: every x / z, y / z^2 ... of the g2o formulas becomes a product with iz = 1 / z,
+// iz2 = iz * iz (an fp64 division is ~12 dependent instructions on this part and jac_binary has 28 of them; the one-workgroup layout recomputes the Jacobians of an edge in
+// four places per LM trial, the multi-launch layout in two: k_w_lin's point and pose roles).  Entries differ from the divided form by a few ulp — far inside the 1e-4 bar; the residual (chi2, the erase decisions) keeps the
+// reference's own arithmetic in edge_error.
+__device__ __forceinline__ void jac_binary_rcp(const Cam& c, const double p[3], const double R[9], bool stereo, double Jp[18], double Jx[9]) {
+#pragma clang fp contract(fast)
+    const double x = p[0], y = p[1], iz = 1.0 / p[2], iz2 = iz * iz;
+    const double fxiz = c.fx * iz, fyiz = c.fy * iz, xiz2 = x * iz2, yiz2 = y * iz2;
+    Jp[0] = x * yiz2 * c.fx; Jp[1] = -(1 + (x * xiz2)) * c.fx; Jp[2] = y * fxiz;
+    Jp[3] = -fxiz; Jp[4] = 0; Jp[5] = xiz2 * c.fx;
+    Jp[6] = (1 + y * yiz2) * c.fy; Jp[7] = -x * yiz2 * c.fy; Jp[8] = -x * fyiz;
+    Jp[9] = 0; Jp[10] = -fyiz; Jp[11] = yiz2 * c.fy;
+    if (!stereo) {
+        const double t2 = xiz2 * c.fx, t5 = yiz2 * c.fy;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Jx[k] = -fxiz * R[k] + t2 * R[6 + k];
+            Jx[3 + k] = -fyiz * R[3 + k] + t5 * R[6 + k];
+            Jx[6 + k] = 0;
+        }
+        Jp[12] = Jp[13] = Jp[14] = Jp[15] = Jp[16] = Jp[17] = 0;
+    } else {
+        const double t2 = xiz2 * c.fx, t5 = yiz2 * c.fy, tb = c.bf * iz2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Jx[k] = -fxiz * R[k] + t2 * R[6 + k];
+            Jx[3 + k] = -fyiz * R[3 + k] + t5 * R[6 + k];
+            Jx[6 + k] = Jx[k] - tb * R[6 + k];
+        }
+        Jp[12] = Jp[0] - tb * y; Jp[13] = Jp[1] + tb * x; Jp[14] = Jp[2];
+        Jp[15] = Jp[3]; Jp[16] = 0; Jp[17] = Jp[5] - tb;
+    }
+}
+
+
 // ==========================================================================================
 // Wide mode: the same LM schedule spread over the whole GPU as a fixed sequence of small kernels
 // per LM trial, with the Levenberg-Marquardt control flow (accept / reject, lambda, iteration and
@@ -719,7 +754,7 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                 double r0 = c2, wgt = 1.0;
                 if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
                 F0 += r0;
-                jac_binary(cam, pc, Rm + a * 9, stereo, Jp, Jx);
+                jac_binary_rcp(cam, pc, Rm + a * 9, stereo, Jp, Jx);
                 const double wi = wgt * info;
                 int k = 0;
 #pragma unroll
@@ -793,7 +828,7 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         const double c2 = edge_error(cam, pc, ob, stereo, info, er);
         double r0 = c2, wgt = 1.0;
         if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
-        jac_binary(cam, pc, Ra, stereo, Jp, Jx);
+        jac_binary_rcp(cam, pc, Ra, stereo, Jp, Jx);
         const double wi = wgt * info;
         int k = 0;
 #pragma unroll
@@ -1873,7 +1908,8 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
         hipFuncSetAttribute((const void*)k_w_chol_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, kMB * (kMfmaMaxN + 2 * kMB) * (int)sizeof(double)) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_lba_win, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_w_schur_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLdsMax) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_w_chol_packed, hipFuncAttributeMaxDynamicSharedMemorySize, kCholPackedLds) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_w_chol_packed, hipFuncAttributeMaxDynamicSharedMemorySize, kCholPackedLds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_w_chol_lds_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol16_lds_bytes(kCholLdsMfmaN)) != hipSuccess) {
         set_error("hipFuncSetAttribute failed"); oslam_lba_destroy(h); return OSLAM_E_HIP;
     }
     *out = h;
@@ -1900,7 +1936,7 @@ int oslam_lba_set_schur(oslam_lba_t* h, int mode) {
 }
 
 int oslam_lba_set_solver(oslam_lba_t* h, int mode) {
-    if (!h || mode < 0 || mode > 2) { set_error("oslam_lba_set_solver: bad argument"); return OSLAM_E_INVALID; }
+    if (!h || mode < 0 || mode > 3) { set_error("oslam_lba_set_solver: bad argument"); return OSLAM_E_INVALID; }
     h->chol_mode = mode;
     return OSLAM_OK;
 }
@@ -2238,7 +2274,7 @@ static int lba_launch(oslam_lba_t* h) {
     bool tiles = wide && n0 > 0;     // wide layout: Schur complement by tiles when every layout-0 window carries the structures
     for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
     const int nwg_call = std::max(1, std::min(16, (2 * 256 + std::max(n0, 1) - 1) / std::max(n0, 1)));   // workgroups per window: ~2 per CU over the call
-    size_t tiles_lds = 0, packed_lds = 0;
+    size_t tiles_lds = 0, packed_lds = 0, ldsm_lds = 0;
     int maxWg = 1, maxSum = 1, min_n6_big = 1 << 30;   // (min_n6_big: the smallest reduced system of the call)
     std::vector<WOff> wo(n);
     bool any_dev_pairs = false;
@@ -2272,6 +2308,7 @@ static int lba_launch(oslam_lba_t* h) {
                     if (q.dev_pairs) { o.pairsW = takeW(std::max<size_t>(q.npairs, 1) * 8); o.pstartW = takeW(((size_t)q.nblk + 1) * 4); any_dev_pairs = true; }   // (pairM: one block for the call, below)
                 }
                 if ((int)n6 <= kCholPackedN) packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
+                if ((int)n6 <= kCholLdsMfmaN) ldsm_lds = std::max(ldsm_lds, chol16_lds_bytes((int)n6));
                 min_n6_big = std::min(min_n6_big, (int)n6);
             }
             maxNbPt = std::max(maxNbPt, nbpt); maxK = std::max(maxK, (int)K); maxE = std::max(maxE, (int)E); maxBlk = std::max(maxBlk, q.nblk);
@@ -2401,9 +2438,13 @@ static int lba_launch(oslam_lba_t* h) {
         // systems beyond the LDS-resident kernels (full square up to 132 unknowns, packed upper triangle up to kCholPackedN) are factored by the matrix cores
         // (k_w_chol_mfma); h->chol_mode 1 forces them, 2 forbids them
         // per window: the packed LDS kernel up to kCholPackedN unknowns, the matrix cores beyond (both kernels are launched when a call mixes the two)
-        const bool chol_packed = h->chol_mode != 1 && !all_lds && min_n6_big <= kCholPackedN && (h->chol_mode == 0 || max_n6 <= kCholPackedN);
-        const bool chol_mfma = h->chol_mode == 1 || (h->chol_mode == 0 && !all_lds && max_n6 > kCholPackedN);
-        const int mfma_min_n = chol_packed ? kCholPackedN + 1 : 0;
+        // chol_mode 0 (auto): LDS-resident matrix-core kernel (k_w_chol_lds_mfma) up to kCholLdsMfmaN unknowns, global-memory matrix-core kernel beyond;
+        // 3: the round-3 choice (scalar packed LDS kernel up to kCholPackedN, matrix cores beyond); 1: global-memory matrix cores for every size; 2: no matrix cores
+        const int cm = h->chol_mode;
+        const bool chol_ldsm = cm == 0 && !all_lds && min_n6_big <= kCholLdsMfmaN;
+        const bool chol_packed = !chol_ldsm && cm != 1 && !all_lds && min_n6_big <= kCholPackedN && (cm == 0 || cm == 3 || max_n6 <= kCholPackedN);
+        const bool chol_mfma = cm == 1 || ((cm == 0 || cm == 3) && !all_lds && max_n6 > (chol_ldsm ? kCholLdsMfmaN : kCholPackedN));
+        const int mfma_min_n = chol_ldsm ? kCholLdsMfmaN + 1 : (chol_packed ? kCholPackedN + 1 : 0);
         const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
         hipLaunchKernelGGL(k_w_init, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
         hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
@@ -2430,9 +2471,10 @@ static int lba_launch(oslam_lba_t* h) {
                     hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
                     hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
                 }
+                if (chol_ldsm) hipLaunchKernelGGL(k_w_chol_lds_mfma, dim3(1, n0), dim3(kWinThreads), ldsm_lds, st, d_probs, d_ws, 0);
                 if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);
                 if (chol_mfma) hipLaunchKernelGGL(k_w_chol_mfma, dim3(1, n0), dim3(kMfmaThreads), mfma_lds, st, d_probs, d_ws, mfma_min_n);
-                if (chol_packed || chol_mfma) { }
+                if (chol_ldsm || chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
                 hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);

@@ -23,8 +23,11 @@ void set_error(const char* fmt, ...) {
 }
 
 // see common.h: poll briefly, then sleep on a blocking event (one event per host thread and device)
+static thread_local int t_wait_mode = -3;   // -3: the process default (OSLAM_WAIT_SPIN_US), else this thread's own mode (stream_wait_thread_mode)
+void stream_wait_thread_mode(int spin_us) { t_wait_mode = spin_us; }
 hipError_t stream_wait(hipStream_t s) {
-    static const int spin_us = [] { const char* e = getenv("OSLAM_WAIT_SPIN_US"); return e ? atoi(e) : -1; }();
+    static const int spin_env = [] { const char* e = getenv("OSLAM_WAIT_SPIN_US"); return e ? atoi(e) : -1; }();
+    const int spin_us = t_wait_mode != -3 ? t_wait_mode : spin_env;
     if (spin_us == -2) {   // pure poll of the stream (never sleeps on the interrupt path)
         for (;;) {
             const hipError_t q = hipStreamQuery(s);

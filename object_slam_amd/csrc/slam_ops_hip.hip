@@ -7,6 +7,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -962,10 +963,11 @@ static double lba_flop(const oslam_lba_problem_t& q, const int32_t st[4]) {
 struct LbaService {
     typedef LbaJob Job;
     int device = 0;
-    oslam_lba_t* ba = nullptr;
-    hipStream_t strm = nullptr;
+    // OSLAM_LBA_SERVICE_THREADS workers (default 2), each with its own solver handle and stream: while one waits for the device the other prepares and
+    // uploads the next batch (window preparation, upload and result scatter are ~a third of a call's wall time)
+    struct Worker { oslam_lba_t* ba = nullptr; hipStream_t strm = nullptr; std::thread th; };
+    std::vector<std::unique_ptr<Worker>> workers;
     int max_batch = 0, mode_small = 1, mode_big = 1, big_from = 1 << 30;
-    std::thread th;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::deque<Job*> queue;
@@ -994,35 +996,39 @@ struct LbaService {
         if (--sv->users > 0) return;
         { std::lock_guard<std::mutex> l2(sv->mu); sv->stop = true; }
         sv->cv_work.notify_all();
-        if (sv->th.joinable()) sv->th.join();
+        for (auto& wk : sv->workers) if (wk->th.joinable()) wk->th.join();
         if (getenv("OSLAM_LBA_SERVICE_STATS")) fprintf(stderr, "[lba service] %lld calls, %lld windows (%.1f per call, max %lld)\n", sv->calls, sv->windows, sv->calls ? (double)sv->windows / sv->calls : 0.0, sv->max_windows);
         (void)hipSetDevice(sv->device);
-        oslam_lba_destroy(sv->ba);
-        if (sv->strm) (void)hipStreamDestroy(sv->strm);
+        for (auto& wk : sv->workers) { oslam_lba_destroy(wk->ba); if (wk->strm) (void)hipStreamDestroy(wk->strm); }
         slot(sv->device) = nullptr;
         delete sv;
     }
     int start() {
         OSLAM_HIP_CHECK(hipSetDevice(device));
         max_batch = getenv("OSLAM_LBA_SERVICE_MAX_BATCH") ? atoi(getenv("OSLAM_LBA_SERVICE_MAX_BATCH")) : 4096;
-        int rc = oslam_lba_create(&ba, max_batch, 1 << 16, 4096, 32768, device);
-        if (rc) return rc;
-        // OSLAM_LBA_SERVICE_CUS=k: the service's stream may only use k of the card's CUs (the tracking kernels of the handles keep the others to themselves)
+        const int nthreads = std::max(1, getenv("OSLAM_LBA_SERVICE_THREADS") ? atoi(getenv("OSLAM_LBA_SERVICE_THREADS")) : 2);
+        // OSLAM_LBA_SERVICE_CUS=k: the service's streams may only use k of the card's CUs (the tracking kernels of the handles keep the others to themselves)
         const int cus = getenv("OSLAM_LBA_SERVICE_CUS") ? atoi(getenv("OSLAM_LBA_SERVICE_CUS")) : 0;
-        if (cus > 0) {
-            hipDeviceProp_t pr;
-            OSLAM_HIP_CHECK(hipGetDeviceProperties(&pr, device));
-            const int total = pr.multiProcessorCount;
-            std::vector<uint32_t> mask((total + 31) / 32, 0u);
-            for (int i = 0; i < std::min(cus, total); i++) mask[i >> 5] |= 1u << (i & 31);
-            OSLAM_HIP_CHECK(hipExtStreamCreateWithCUMask(&strm, (uint32_t)mask.size(), mask.data()));
-            oslam::lba_use_stream(ba, strm);
+        for (int t = 0; t < nthreads; t++) {
+            std::unique_ptr<Worker> wk(new Worker);
+            const int rc = oslam_lba_create(&wk->ba, max_batch, 1 << 16, 4096, 32768, device);
+            if (rc) return rc;
+            if (cus > 0) {
+                hipDeviceProp_t pr;
+                OSLAM_HIP_CHECK(hipGetDeviceProperties(&pr, device));
+                const int total = pr.multiProcessorCount;
+                std::vector<uint32_t> mask((total + 31) / 32, 0u);
+                for (int i = 0; i < std::min(cus, total); i++) mask[i >> 5] |= 1u << (i & 31);
+                OSLAM_HIP_CHECK(hipExtStreamCreateWithCUMask(&wk->strm, (uint32_t)mask.size(), mask.data()));
+                oslam::lba_use_stream(wk->ba, wk->strm);
+            }
+            workers.push_back(std::move(wk));
         }
         // layout per call: batches of at least `big_from` windows go through the one-workgroup-per-window kernel (mode 2), smaller ones through the multi-launch layout
         mode_small = getenv("OSLAM_LBA_SERVICE_MODE") ? atoi(getenv("OSLAM_LBA_SERVICE_MODE")) : 1;
         mode_big = getenv("OSLAM_LBA_SERVICE_MODE_BIG") ? atoi(getenv("OSLAM_LBA_SERVICE_MODE_BIG")) : mode_small;
         big_from = getenv("OSLAM_LBA_SERVICE_BIG_FROM") ? atoi(getenv("OSLAM_LBA_SERVICE_BIG_FROM")) : (1 << 30);
-        th = std::thread([this] { run(); });
+        for (auto& wk : workers) { Worker* w = wk.get(); w->th = std::thread([this, w] { run(*w); }); }
         return OSLAM_OK;
     }
     void submit(Job* j) {
@@ -1033,8 +1039,10 @@ struct LbaService {
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return j->done; });
     }
-    void run() {
+    void run(Worker& wk) {
         (void)hipSetDevice(device);
+        oslam::stream_wait_thread_mode(getenv("OSLAM_LBA_SERVICE_SPIN_US") ? atoi(getenv("OSLAM_LBA_SERVICE_SPIN_US")) : 0);   // sleep, do not spin: off the critical path
+        oslam_lba_t* ba = wk.ba;
         std::vector<Job*> take;
         std::vector<oslam_lba_problem_t> probs;
         std::vector<int32_t> st;
@@ -1067,7 +1075,6 @@ struct LbaService {
                 for (int at = 0; !rc && at < n; at += max_batch) rc = oslam_lba_optimize_batch(ba, std::min(max_batch, n - at), probs.data() + at, take[0]->K5);
                 if (!rc && timing) rc = oslam_lba_kernel_time(ba, 0, &ms, &launches);
             }
-            calls++; windows += n; max_windows = std::max<long long>(max_windows, n);
             // the call's kernel time and launches are shared out by the windows' flop / count (the sums over the handles are the call's)
             std::vector<double> fl(take.size(), 0.0);
             double fl_all = 0;
@@ -1083,6 +1090,7 @@ struct LbaService {
             }
             {
                 std::lock_guard<std::mutex> lk(mu);
+                calls++; windows += n; max_windows = std::max<long long>(max_windows, n);
                 for (size_t q = 0; q < take.size(); q++) {
                     Job* j = take[q];
                     j->rc = rc;

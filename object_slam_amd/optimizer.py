@@ -130,7 +130,7 @@ class LocalBundleAdjuster:
         check(self.L.oslam_lba_set_schur(self.h, C.c_int(mode)))
 
     def set_solver(self, mode):
-        """Reduced-camera-system solver of the wide mode: 0 auto, 1 matrix cores (MFMA f64) for every size, 2 never (include/oslam_hip.h)."""
+        """Reduced-camera-system solver of the wide mode: 0 auto (LDS-resident matrix-core kernel at 133..186 unknowns), 1 global-memory matrix cores for every size, 2 never, 3 the round-3 choice (include/oslam_hip.h)."""
         check(self.L.oslam_lba_set_solver(self.h, C.c_int(mode)))
 
     def lm_trace(self, fn, cap=512):

@@ -236,17 +236,19 @@ def test_device_built_pair_lists_equal_the_host_built_ones():
 HEADLINE_WINDOWS = [(77, 27, 0, 1500, 13), (121, 31, 3, 1800, 16)]
 
 
+@pytest.mark.parametrize("solver", [0, 3])
 @pytest.mark.parametrize("schur", [0, 1])
 @pytest.mark.parametrize("seed,KL,KF,P,track", HEADLINE_WINDOWS)
-def test_lba_wide_layout_at_headline_window_sizes_matches_oracle(oracle, seed, KL, KF, P, track, schur):
+def test_lba_wide_layout_at_headline_window_sizes_matches_oracle(oracle, seed, KL, KF, P, track, schur, solver):
     """Reference src/Optimizer.cc:453-778 (optimize(5) :660, optimize(10) :706-707) on windows of the bench's steady-state shape, DEFAULT layout (mode 1), both
-    Schur implementations: n = 156 / 186 unknowns -> k_w_chol_packed."""
+    Schur implementations: n = 156 / 186 unknowns -> solver 0 (default): k_w_chol_lds_mfma (matrix cores, system resident in LDS); solver 3: k_w_chol_packed."""
     q = synth.make_lba_problem(seed, K_local=KL, K_fixed=KF, P=P, track=track, stereo_frac=0.9)
     n = 6 * int((q["fixed"] == 0).sum())
     assert 132 < n <= 192, n
     ba = LocalBundleAdjuster(max_batch=2, max_keyframes=64, max_points=8192, max_edges=65536)
     ba.set_mode(1)
     ba.set_schur(schur)
+    ba.set_solver(solver)
     a, o = _run(oracle, ba, q)
     _compare(a, o)
     ba.close()
@@ -292,4 +294,19 @@ def test_lba_wide_batch_mixing_120_162_204_unknowns_matches_oracle(oracle, schur
         else:
             f = first[n]
             assert np.array_equal(r[0], f[0]) and np.array_equal(r[1], f[1]) and np.array_equal(r[2], f[2]) and tuple(r[3]) == tuple(f[3])
+    ba.close()
+
+
+@pytest.mark.parametrize("nfree", [23, 24, 25, 29, 31])
+def test_lba_lds_matrix_core_solver_panel_edges(oracle, nfree):
+    """k_w_chol_lds_mfma at reduced-system orders around its panel structure: n = 138 (8 full panels + 10), 144 (9 full panels), 150, 174, 186 (the kernel's
+    bound: 152 KB of LDS), in a call that also holds a small window (n = 24: fewer unknowns than two panels) — all through the same kernel."""
+    q = synth.make_lba_problem(700 + nfree, K_local=nfree, K_fixed=2, P=60 * nfree, track=max(6, nfree // 2), stereo_frac=0.9)
+    small = synth.make_lba_problem(3, K_local=4, K_fixed=2, P=150)
+    assert 6 * int((q["fixed"] == 0).sum()) == 6 * nfree
+    ba = LocalBundleAdjuster(max_batch=4, max_keyframes=64, max_points=8192, max_edges=65536)
+    outs = ba.LocalBundleAdjustmentBatch([q, small], q["K"])
+    for r, w in zip(outs, (q, small)):
+        o = oracle.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], w["edge_kf"], w["edge_pt"], w["edge_obs"], w["edge_invSigma2"], w["K"])
+        _compare(r, o)
     ba.close()

@@ -137,8 +137,12 @@ def test_hip_driver_keyframe_culling_matches_oracle_driver(oracle, lm):
     for s in range(S):
         a, b = hip.stats(s), ora.stats(s)
         assert a == b, (s, a, b)
-        assert a["keyframes_culled"] >= 2 and a["map_violations"] == 0, a
+        assert a["map_violations"] == 0, a
+        if lm == slam.LM_SYNC:
+            assert a["keyframes_culled"] >= 2, a
         assert np.array_equal(hip.keyframe_trajectory(s)[0], ora.keyframe_trajectory(s)[0])
+    # (deferred: the culling of pass t sees the map after frame t+1 was tracked; on these streams it then removes fewer keyframes — both tables the same ones)
+    assert sum(hip.stats(s)["keyframes_culled"] for s in range(S)) >= 2
     d = np.abs(ph - po).max()
     assert d < 2e-4, d
 
