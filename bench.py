@@ -67,9 +67,36 @@ def launch_ranks(n):
 # --------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the same driver over the CPU oracle's operator table (test infrastructure; "port"), bounded sample
 # --------------------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F):
-    """The same driver over the CPU oracle's operator table on one core: frames [0, first) of the sequence untimed (the map reaches the state the GPU leg's
-    sequences have when ITS timed region starts), then `n_timed` frames timed — the same frame range as the GPU leg's timed steps and the frames after them."""
+def extend_sequence(wl, seed, seq, extra, workers=1, chunk=12):
+    """`seq` (frames [0, n) of stream `seed`) continued by `extra` frames of the SAME stream (the paths of object_slam_amd/scene.py are functions of the frame
+    index alone, so frames [n, n + extra) rendered later are the frames a longer rendering would have held).  A copy: the GPU legs keep their arrays."""
+    n = len(seq["gray"])
+    jobs = [(wl, seed, n + extra, f, min(chunk, n + extra - f)) for f in range(n, n + extra, chunk)]
+    if workers > 1 and len(jobs) > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
+            parts = pool.starmap(_render_piece, jobs)
+    else:
+        parts = [_render_piece(*j) for j in jobs]
+    out = dict(seq)
+    T0 = seq["Twc"][0]
+    for key in ("gray", "right", "depth", "masks"):
+        if seq.get(key) is not None:
+            out[key] = np.concatenate([seq[key]] + [p[key] for p in parts], 0)
+    out["Twc"] = np.concatenate([seq["Twc"]] + [p["Twc"] for p in parts], 0)   # (every piece is relative to frame 0 of the whole stream)
+    assert np.allclose(out["Twc"][0], T0)
+    return out
+
+
+def _render_piece(wl, seed, n, first, count):
+    return wl.make_sequence(seed, n, first=first, count=count)
+
+
+def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
+    """The same driver over the CPU oracle's operator table on one core, on frames [offset, ...) of the stream (offset = the mean frame offset of the GPU leg's
+    sequences in their base streams): `first` frames untimed (the map reaches the state the GPU leg's sequences have when ITS timed region starts), then `n_timed`
+    frames timed."""
+    seq = {k: (v[offset:] if k in ("gray", "right", "depth", "masks", "Twc") and v is not None else v) for k, v in seq.items()}
     import ctypes as C
     from object_slam_amd import slam
     from object_slam_amd.e2e import horn_align_ate
@@ -97,6 +124,7 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F):
         step(t)
     tp = time.perf_counter() - tp
     w0 = sysm.lba_window_stats(0)
+    stg0 = sysm.stage_seconds()
     t0 = time.perf_counter()
     for t in range(first, n):
         t1 = time.perf_counter()
@@ -104,6 +132,8 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F):
         per.append(time.perf_counter() - t1)
     dt = time.perf_counter() - t0
     w1 = sysm.lba_window_stats(0)
+    stg1 = sysm.stage_seconds()
+    map_s = sum(stg1.get(k, 0.0) - stg0.get(k, 0.0) for k in ("lba", "host_mapping", "fuse_bow_triangulate", "mp_update"))
     _, Twc = sysm.trajectory(0)
     T0inv = np.linalg.inv(seq["Twc"][0])
     gt = np.array([T0inv @ x for x in seq["Twc"][:len(Twc)]])
@@ -112,10 +142,13 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F):
     nw = max(1, w1["windows"] - w0["windows"])
     # the reference prints median and mean tracking time per frame (Examples/RGB-D/rgbd_tum.cc:126-134)
     return {"value": round((n - first) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "frames %d..%d of one sequence of the same workload (the GPU leg's timed frame range and the frames after it) through the same driver over the CPU oracle's "
-                      "operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local mapping run on ONE core one after the other (the reference overlaps "
-                      "LocalMapping on a second thread and, for stereo, extracts the two images on two threads: <= 3 busy cores, so its wall time per frame lies between the "
-                      "median and the mean below)" % (first, n, dt, tp),
+            "sample": "frames %d..%d (stream frames %d..%d: the mean offset of the GPU leg's sequences in their base streams, so the map is as old as theirs) of one sequence "
+                      "of the same workload through the same driver over the CPU oracle's operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local "
+                      "mapping run on ONE core one after the other" % (first, n, first + offset, n + offset, dt, tp),
+            # the reference's shape (<= 3 busy cores: LocalMapping on a second thread, src/System.cc:95; stereo extraction on two, src/Frame.cc:78-81): its frames/s lies between
+            # the one-core figure and the figure with every mapping stage hidden behind tracking
+            "three_core_bracket_frames_per_s": [round((n - first) / dt, 2), round((n - first) / max(dt - map_s, 1e-9), 2)],
+            "mapping_stage_seconds": round(map_s, 2), "timed_frames": n - first,
             "mean_ms_per_frame": round(float(per.mean()) * 1e3, 2), "median_ms_per_frame": round(float(np.median(per)) * 1e3, 2),
             "ate_rmse_m": round(horn_align_ate(Twc[:, :, 3], gt[:, :3, 3]), 6), "keyframes": st["keyframes_created"], "local_bas": st["local_bas"],
             "lba_windows_timed": {"windows": w1["windows"] - w0["windows"], "mean_local_kfs": round((w1["local_kfs"] - w0["local_kfs"]) / nw, 2),
@@ -372,6 +405,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--cold", action="store_true", help="also run the cold-start regime of rounds 1-2 (steps W..W+K of empty maps) on the headline streams")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -405,9 +439,21 @@ def main():
     t_gen = time.perf_counter()
     seq_head = seqbench.base_sequences(head, rank, S, n_frames, workers=share)
     seq_second = None
-    if extras_on:            # second figure: the other stream shape, cold start (rank 0 of a single-rank run only)
-        S2, G2 = (256, 4) if second is wl_st else (1024, 4)
-        seq_second = seqbench.base_sequences(second, rank, S2, args.warmup + args.steps, workers=share)
+    pre2 = 0
+    if extras_on:            # second figure: the other stream shape in ITS steady state (rank 0 of a single-rank run only)
+        S2, G2 = (512, 4) if second is wl_st else (1024, 4)
+        pre2 = 40 if second is wl_st else 200
+        seq_second = seqbench.base_sequences(second, rank, S2, pre2 + args.warmup + args.steps, workers=share)
+    # the CPU baselines run on frames [stagger / 2, ...) of base stream 0 and are timed over more frames than the GPU legs hold: base stream 0 continued (host only)
+    seq_cpu = seq_cpu2 = None
+    cpu_n = args.cpu_frames or (60 if stereo_head else 200)
+    cpu_n2 = 200 if stereo_head else 60
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        need = head.stagger // 2 + preroll + args.warmup + cpu_n - len(seq_head[0]["gray"])
+        seq_cpu = extend_sequence(head, head.n_base * rank, seq_head[0], need, workers=share) if need > 0 else seq_head[0]
+        if seq_second is not None:
+            need2 = second.stagger // 2 + pre2 + args.warmup + cpu_n2 - len(seq_second[0]["gray"])
+            seq_cpu2 = extend_sequence(second, second.n_base * rank, seq_second[0], need2, workers=share) if need2 > 0 else seq_second[0]
     t_gen = time.perf_counter() - t_gen
     if log:
         log("inputs rendered in %.1f s" % t_gen)
@@ -531,16 +577,27 @@ def main():
     if extras_on:
         if log:
             log("headline done: %.1f frames/s" % summ["frames_per_s"])
-        if preroll > 0:     # the cold-start regime of the earlier rounds on the same streams (maps at most warmup + steps frames old)
+        if preroll > 0 and args.cold:     # the cold-start regime of rounds 1-2 on the same streams (maps at most warmup + steps frames old)
             c, _ = run(head, seq_head, S, G, "cold")
             cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
                     "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
-        s2, _ = run(second, seq_second, S2, G2, "second")
-        second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe, cold start (steps %d..%d)"
-                                  % (second.name, S2, G2, second.nFeatures, args.warmup, args.warmup + args.steps),
+        s2, _ = run(second, seq_second, S2, G2, "second", pre2)
+        roof2 = roofline_of(kt["second"], s2, second is wl_st)
+        cpu2 = None
+        if not args.no_cpu_baseline:
+            if log:
+                log("CPU baseline of the second workload ...")
+            cpu2 = cpu_baseline(second, seq_cpu2 if seq_cpu2 is not None else seq_second[0], pre2 + args.warmup, cpu_n2, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
+                                offset=second.stagger // 2)
+        second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe; steady state: %d untimed steps, then steps %d..%d timed; "
+                                  "BASELINE.json configs[%s]" % (second.name, S2, G2, second.nFeatures, pre2, pre2 + args.warmup, pre2 + args.warmup + args.steps,
+                                                                 "3]/[4" if second is wl_st else "2"),
+                      "regime": "steady_state", "preroll_steps": pre2,
                       "frames_per_s": round(s2["frames_per_s"], 1), "ms_per_step": round(s2["ms_per_step"], 3), "ate_rmse_m": round(s2["ate_rmse_m"], 6),
                       "keyframes": s2["keyframes"], "local_bas": s2["local_bas"], "lost_frames": s2["lost_frames"], "lba_windows_timed": s2["lba_windows_timed"],
-                      "stage_seconds_sum_over_handles": s2["stage_seconds_sum_over_handles"]}
+                      "roofline": {k: roof2[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launch_us", "algorithmic_work_per_launch", "work_unit", "groups")},
+                      "cpu_baseline_stereo" if second is wl_st else "cpu_baseline_rgbd": cpu2,
+                      "stage_seconds_timed_sum_over_handles": s2.get("stage_seconds_timed_sum_over_handles")}
 
     out = None
     if rank == 0:
@@ -549,8 +606,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if log:
                 log("CPU baseline ...")
-            cpu = cpu_baseline(head, seq_head[0], preroll + args.warmup, args.cpu_frames or (len(seq_head[0]["gray"]) - preroll - args.warmup),
-                               slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC)
+            cpu = cpu_baseline(head, seq_cpu if seq_cpu is not None else seq_head[0], preroll + args.warmup, cpu_n, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
+                               offset=head.stagger // 2)
         front = None
         if extras_on and head is wl_rgbd:
             try:

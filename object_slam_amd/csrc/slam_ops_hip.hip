@@ -1021,6 +1021,13 @@ struct LbaService {
                 for (int i = 0; i < std::min(cus, total); i++) mask[i >> 5] |= 1u << (i & 31);
                 OSLAM_HIP_CHECK(hipExtStreamCreateWithCUMask(&wk->strm, (uint32_t)mask.size(), mask.data()));
                 oslam::lba_use_stream(wk->ba, wk->strm);
+            } else if (!getenv("OSLAM_LBA_SERVICE_NO_PRIORITY")) {
+                // the service is off every handle's critical path: its streams get the LOWEST priority, so that the handles' short tracking / mapping kernels are
+                // dispatched ahead of the queued local-BA launches
+                int lo = 0, hi = 0;
+                OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = numerically greatest = lowest priority)
+                OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, lo));
+                oslam::lba_use_stream(wk->ba, wk->strm);
             }
             workers.push_back(std::move(wk));
         }
