@@ -159,7 +159,7 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
 # --------------------------------------------------------------------------------------------------------------------------------
 # S2 stage entry: ORBextractor + ORBmatcher only (BASELINE.json configs[1]), per-kernel HBM table
 # --------------------------------------------------------------------------------------------------------------------------------
-def lba_alone(device_index, windows=40, reps=3):
+def lba_alone(device_index, windows=40, reps=3, mode=1):
     """The local-BA operator ALONE on the card: one call of `windows` steady-state-shaped windows (27 free keyframes, 1500 points, ~13 k edges: the shape of the
     timed steps' windows, synthetic geometry of object_slam_amd/synth.py), multi-launch layout as the driver uses it; device time from the handle's HIP events,
     fp64 work = the SURVEY.md §8(d) flop model x the LM trials the kernels report.  The headline's local-BA figure is the same kernels under the contention of 8
@@ -169,6 +169,7 @@ def lba_alone(device_index, windows=40, reps=3):
     base = [synth.make_lba_problem(1234 + i, K_local=27, K_fixed=0, P=1500, track=13, stereo_frac=0.9) for i in range(8)]
     probs = [base[i % len(base)] for i in range(windows)]
     ba = LocalBundleAdjuster(max_batch=windows, max_keyframes=64, max_points=8192, max_edges=65536, device=device_index)
+    ba.set_mode(mode)
     try:
         ms, ln = C.c_double(0), C.c_longlong(0)
         out = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])            # warm (allocations)
@@ -183,7 +184,8 @@ def lba_alone(device_index, windows=40, reps=3):
             flop += (o[3][1] + o[3][3]) * (700.0 * len(q["edge_kf"]) + 324.0 * float((k * k).sum()) + n6 ** 3 / 3.0 + 2.0 * n6 * n6 + 45.0 * len(q["points"]))
         ms_call = ms.value / reps
         tf = flop / (ms_call * 1e-3) / 1e12
-        return {"windows": windows, "edges_per_window": int(len(probs[0]["edge_kf"])), "ms_per_call": round(ms_call, 3), "launches_per_call": int(ln.value // reps),
+        return {"windows": windows, "layout": "multi-launch (mode 1)" if mode == 1 else "one workgroup per window (mode 2)",
+                "edges_per_window": int(len(probs[0]["edge_kf"])), "ms_per_call": round(ms_call, 3), "launches_per_call": int(ln.value // reps),
                 "fp64_TFLOPs": round(tf, 3), "frac_of_fp64_peak": round(tf / FP64_PEAK_TFLOPS, 4)}
     finally:
         ba.close()
@@ -618,8 +620,11 @@ def main():
         if extras_on:
             try:
                 roof["lba_alone"] = lba_alone(local_rank)
+                # the same operator at the batch sizes the deferred schedule's service runs it at (~120-160 windows per call) and at one window per CU
+                roof["lba_alone_by_batch"] = [lba_alone(local_rank, 160, 2, 1), lba_alone(local_rank, 256, 2, 1), lba_alone(local_rank, 256, 2, 2)]
             except Exception as ex:      # (must not break the headline line)
-                roof["lba_alone"] = {"error": repr(ex)}
+                roof["lba_alone"] = roof.get("lba_alone") or {"error": repr(ex)}
+                roof["lba_alone_by_batch"] = {"error": repr(ex)}
             try:                         # the card's measured fp64 issue rates beside the datasheet figure `peak` is taken from
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import mfma_f64_rate
@@ -666,24 +671,25 @@ def main():
 def _lba_traffic():
     """Mean memory-side bytes per launch of an LM trial of the local-BA kernels (committed PMC summary; None when it is missing)."""
     try:
-        return int(json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_lba_traffic.json")))["mean_bytes_per_launch_of_a_trial"])
+        return int(json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_lba_traffic.json")))["mean_bytes_per_launch_of_a_trial"])
     except Exception:
         return None
 
 
 def _mfma_counters():
-    """MFMA counters of the matrix-core reduced-system solver from the committed rocprofv3 --pmc pass of tools/lba_mfma_pmc.py (S5-large, n = 240, and 40
-    driver-shaped windows of 34 free keyframes, n = 204; SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r03_pmc_lba_mfma.json)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_lba_mfma.json")
+    """MFMA counters of the reduced-system solver the timed windows go through (k_w_chol_lds_mfma: LDS-resident system, v_mfma_f64_16x16x4_f64 row panels and
+    trailing updates) from the committed rocprofv3 --pmc pass over one call of 40 steady-state-shaped windows (tools/lba_win_prof.py MODES=1 NB=40: n = 156;
+    SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r04_pmc_lba_mfma.json, tools/gpu_r4_pmc.sh)."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_lba_mfma.json")
     try:
-        e = json.load(open(path))["k_w_chol_mfma"]
-        return {"kernel": "k_w_chol_mfma (v_mfma_f64_16x16x4_f64 trailing updates of the reduced camera system, n = 204 .. 240)",
+        e = json.load(open(path))["k_w_chol_lds_mfma"]
+        return {"kernel": "k_w_chol_lds_mfma (v_mfma_f64_16x16x4_f64 row panels + trailing updates of the LDS-resident reduced camera system, n = 156: the timed path's solver)",
                 "mfma_util": round(e["mfma_util_of_occupied_cus"], 4), "mfma_util_chip": round(e["mfma_util_chip"], 5),
                 "mfma_busy_cycles_per_launch": int(e["SQ_VALU_MFMA_BUSY_CYCLES"]), "mfma_mops_f64_per_launch": int(e["SQ_INSTS_VALU_MFMA_MOPS_F64"]),
                 "mean_launch_us": round(e["mean_us"], 1),
-                "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 4 SIMDs x CUs the launch occupies); counters, not pencil arithmetic: the solver "
-                              "is bound by the per-panel critical path (diagonal factor, row-panel solve, two global round trips per 16-wide panel), not by the matrix pipe",
-                "source": "profiles/r03_pmc_lba_mfma.json"}
+                "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 4 SIMDs x CUs the launch occupies); counters, not pencil arithmetic: one workgroup "
+                              "per window, bound by the per-panel critical path (16x16 diagonal factor + inverse on one wavefront), not by the matrix pipe",
+                "source": "profiles/r04_pmc_lba_mfma.json"}
     except Exception:
         return None
 
@@ -714,12 +720,15 @@ def roofline_of(k, summ, stereo):
     total_ms = sum(v["ms"] for v in k.values())
     for g in group_tab:
         group_tab[g]["share"] = round(k[g]["ms"] / max(total_ms, 1e-9), 4)
-    return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4; the kernels of this group issue "
-            "v_fma_f64 / v_mul_f64 / v_add_f64 — no MFMA instruction at these system sizes (the matrix-core Cholesky serves reduced systems beyond the LDS-resident size)",
+    if bound == "fp64-valu" and dom == "lba":
+        bound = "mfma"   # the contract's name for the flop-bound case; the group's flops are mostly plain fp64 FMAs (see peak_note)
+    return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4 (datasheet; `fp64_peak_measured` = what "
+            "tools/mfma_f64_rate.py reaches on this card); the linearisation / Schur / update kernels of this group issue v_fma_f64 / v_mul_f64 / v_add_f64, the reduced "
+            "camera solve (k_w_chol_lds_mfma at 133..186 unknowns) v_mfma_f64_16x16x4_f64",
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
             "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else _lba_traffic(), "launch_us": round(ms / launches * 1e3, 1),
             "traffic_note": None if bound == "hbm" else "memory-side bytes per launch of the local-BA kernels (mean over the 8 launches of an LM trial) from the committed rocprofv3 "
-            "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r03_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
+            "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r04_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
             "calls of this run carry ~82 windows: scale by the windows per call",
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
             "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4), "mfma": _mfma_counters(),

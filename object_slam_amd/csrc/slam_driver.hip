@@ -750,7 +750,7 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                 const KeyFrm& kf = m.kfs[k];
                 int nRed = 0, nMPs = 0;
                 for (int i = 0; i < kf.N; i++) {
-                    prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
+                    prefetch_okp_ahead(m.mps, kf.mp, i, kf.N);
                     const int p = kf.mp[i];
                     if (p < 0 || m.mps[p].bad) continue;
                     if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
@@ -758,9 +758,10 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                     if (m.mps[p].nObs > 3) {
                         const int lvl = kf.keysUn[i].octave;
                         int n = 0;
-                        for (auto& e : m.mps[p].obs) {
-                            if (e.first == k) continue;
-                            if (m.kfs[e.first].keysUn[e.second].octave <= lvl + 1) { n++; if (n >= 3) break; }
+                        const MapPt& mq = m.mps[p];
+                        for (size_t oi = 0; oi < mq.obs.size(); oi++) {
+                            if (mq.obs[oi].first == k) continue;
+                            if (mq.okp[oi].octave <= lvl + 1) { n++; if (n >= 3) break; }   // (the observing keypoint's octave, cached beside the observation: slam_map.h ObsKp)
                         }
                         if (n >= 3) nRed++;
                     }
@@ -1338,19 +1339,19 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
             W.points.resize(W.pts.size() * 3);
             for (size_t j = 0; j < W.pts.size(); j++) {
-                prefetch_obs_ahead(m.mps, W.pts, j, W.pts.size());
-                if (j + 2 < W.pts.size())   // the keypoints its observations name: a third, dependent level (record and list of point j + 2 were requested above)
-                    for (auto& e : m.mps[W.pts[j + 2]].obs) { const KeyFrm& k2 = m.kfs[e.first]; __builtin_prefetch(&k2.keysUn[e.second]); __builtin_prefetch(&k2.uRight[e.second]); }
+                prefetch_okp_ahead(m.mps, W.pts, j, W.pts.size());
                 const MapPt& mp = m.mps[W.pts[j]];
                 for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
-                for (auto& e : mp.obs) {
+                for (size_t oi = 0; oi < mp.obs.size(); oi++) {
+                    const std::pair<int, int>& e = mp.obs[oi];
                     const KeyFrm& k = m.kfs[e.first];
                     if (k.bad) continue;
                     const int q = slot[e.first] - 1;
                     if (q < 0) continue;
+                    const ObsKp& kp = mp.okp[oi];   // mvKeysUn[idx].pt, mvuRight[idx], octave of the observing keypoint (cached beside the observation)
                     W.ekf.push_back(q); W.ept.push_back((int)j);
-                    W.eobs.push_back(k.keysUn[e.second].x); W.eobs.push_back(k.keysUn[e.second].y); W.eobs.push_back(k.uRight[e.second]);
-                    W.einv.push_back(c.invSigma2[k.keysUn[e.second].octave]);
+                    W.eobs.push_back(kp.x); W.eobs.push_back(kp.y); W.eobs.push_back(kp.ur);
+                    W.einv.push_back(c.invSigma2[kp.octave]);
                     W.eref.push_back(std::make_pair(e.first, W.pts[j]));
                 }
             }

@@ -109,6 +109,12 @@ struct Frame {
     }
 };
 
+// The keypoint behind an observation: mvKeysUn.pt, mvuRight and octave of keypoint `second` of keyframe `first`, copied when the observation is added (a
+// keyframe's keypoints never change: include/KeyFrame.h:163-175 are const members).  Kept in a list PARALLEL to MapPt::obs: the loops that need the keypoint
+// (the local-BA graph gather, KeyFrameCulling, the observation counts) then stay inside the point's two lists instead of taking a dependent cache miss in the
+// keyframe's arrays per observation, and the loops that only need (keyframe, index) — UpdateLocalKeyFrames — keep walking 8 bytes per observation.
+struct ObsKp { float x, y, ur; int octave; };
+
 struct MapPt {
     float pos[3];
     float normal[3] = {0, 0, 0};
@@ -119,6 +125,7 @@ struct MapPt {
     bool bad = false;
     int replaced = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
+    std::vector<ObsKp> okp;                      // okp[i] = the keypoint of obs[i]
     int lastFrameSeen = 0, trackRefForFrame = 0, baLocalForKF = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
     // driver scratch of SearchInNeighbors: position of the point in the current keyframe's point list (valid while fuseListStamp == current keyframe id + 1)
     int fuseListIdx = 0, fuseListStamp = 0;
@@ -143,6 +150,12 @@ template <class Ids>
 inline void prefetch_obs_ahead(const std::vector<MapPt>& mps, const Ids& ids, size_t i, size_t n) {   // with prefetch_ahead: the list of a record requested kPF / 2 iterations ago
     prefetch_ahead(mps, ids, i, n);
     if (i + kPF / 2 < n) { const int q = ids[i + kPF / 2]; if (q >= 0) __builtin_prefetch(mps[q].obs.data()); }
+}
+
+template <class Ids>
+inline void prefetch_okp_ahead(const std::vector<MapPt>& mps, const Ids& ids, size_t i, size_t n) {   // prefetch_obs_ahead + the parallel keypoint list
+    prefetch_obs_ahead(mps, ids, i, n);
+    if (i + kPF / 2 < n) { const int q = ids[i + kPF / 2]; if (q >= 0) __builtin_prefetch(mps[q].okp.data()); }
 }
 
 struct KeyFrm {
@@ -187,8 +200,11 @@ struct Map {
         size_t at = 0;
         while (at < m.obs.size() && m.obs[at].first < kf) at++;
         if (at < m.obs.size() && m.obs[at].first == kf) return;
+        const KeyFrm& k = kfs[kf];
+        const ObsKp o = {k.keysUn[idx].x, k.keysUn[idx].y, k.uRight[idx], k.keysUn[idx].octave};
         m.obs.insert(m.obs.begin() + at, std::make_pair(kf, idx));
-        m.nObs += kfs[kf].uRight[idx] >= 0 ? 2 : 1;
+        m.okp.insert(m.okp.begin() + at, o);
+        m.nObs += o.ur >= 0 ? 2 : 1;
         m.obsVer++;
     }
     void set_bad_point(int p) {                      // :253-270
@@ -197,6 +213,7 @@ struct Map {
         m.bad = true;
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
+        m.okp.clear();
         for (auto& e : o) kfs[e.first].mp[e.second] = -1;
     }
     void erase_observation(int p, int kf) {          // :209-239
@@ -204,8 +221,9 @@ struct Map {
         bool bad = false;
         for (size_t i = 0; i < m.obs.size(); i++)
             if (m.obs[i].first == kf) {
-                m.nObs -= kfs[kf].uRight[m.obs[i].second] >= 0 ? 2 : 1;
+                m.nObs -= m.okp[i].ur >= 0 ? 2 : 1;
                 m.obs.erase(m.obs.begin() + i);
+                m.okp.erase(m.okp.begin() + i);
                 m.obsVer++;
                 if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
                 if (m.nObs <= 2) bad = true;
@@ -219,6 +237,7 @@ struct Map {
         MapPt& m = mps[p];
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
+        m.okp.clear();
         if (!m.bad) { nMPsInMap--; }
         m.bad = true;
         m.replaced = by;

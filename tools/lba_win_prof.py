@@ -10,6 +10,10 @@ cache = {}
 for mode in [int(x) for x in os.environ.get("MODES", "1,2").split(",")]:
     ba = LocalBundleAdjuster(max_batch=max(NB), max_keyframes=64, max_points=8192, max_edges=65536)
     ba.set_mode(mode)
+    if os.environ.get("SCHUR"):
+        ba.set_schur(int(os.environ["SCHUR"]))
+    if os.environ.get("SOLVER"):
+        ba.set_solver(int(os.environ["SOLVER"]))
     ms, ln = C.c_double(0), C.c_longlong(0)
     for nb in NB:
         if nb not in cache:
