@@ -99,7 +99,7 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
     seq = {k: (v[offset:] if k in ("gray", "right", "depth", "masks", "Twc") and v is not None else v) for k, v in seq.items()}
     import ctypes as C
     from object_slam_amd import slam
-    from object_slam_amd.e2e import horn_align_ate
+    from object_slam_amd.io import horn_align_ate
     from oracle import oracle_py as O
     O.build()
     cfg = slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor, local_mapping=local_mapping)   # (the GPU leg's schedule: one core runs the same passes either way)
@@ -381,13 +381,19 @@ def pin_rank_cpus(local_rank, local_world, per_rank_cores):
             os.sched_setaffinity(0, cpus)
             return len(cpus)
         return sum(len(c) for c in cores)
+    cpus = rank_cpu_set(cores, local_rank, local_world, per_rank_cores)
+    os.sched_setaffinity(0, cpus)
+    return len(cpus)
+
+
+def rank_cpu_set(cores, local_rank, local_world, per_rank_cores=0):
+    """The CPUs of rank `local_rank` of `local_world` ranks on a node whose physical cores are `cores` (lists of SMT siblings in (package, core) order): a
+    contiguous run of len(cores) // local_world cores (optionally only the first per_rank_cores of them), both SMT threads of a core to the same rank."""
     per = max(1, len(cores) // local_world)
     mine = cores[local_rank * per:(local_rank + 1) * per] or cores[-per:]
     if per_rank_cores:
         mine = mine[:max(1, per_rank_cores)]
-    cpus = sorted(c for g in mine for c in g)
-    os.sched_setaffinity(0, cpus)
-    return len(cpus)
+    return sorted(c for g in mine for c in g)
 
 
 def main():

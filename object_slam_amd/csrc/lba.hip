@@ -1896,6 +1896,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
+    if (const char* e = getenv("OSLAM_LBA_SOLVER")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->chol_mode = v; }   // A/B knob: oslam_lba_set_solver for every handle of the process
     if (getenv("OSLAM_LBA_HOST_PAIRS")) h->device_pairs = false;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e);   // 0 = always the pair gather, 1 = always tiles, 2 = per call (default)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }

@@ -216,6 +216,13 @@ def align_horn(model, data):
     return rot, trans, np.sqrt((err * err).sum(0))
 
 
+def horn_align_ate(est_xyz, gt_xyz):
+    """ATE RMSE of an estimate [n,3] against ground truth [n,3] after the rigid (no scale) Horn alignment of evaluate_ate.py:47-83,161 (model = estimate,
+    data = ground truth): the number bench.py and the driver tests report."""
+    _, _, e = align_horn(np.asarray(est_xyz, np.float64).T, np.asarray(gt_xyz, np.float64).T)
+    return float(np.sqrt((e * e).mean()))
+
+
 def evaluate_ate(gt_file, est_file, offset=0.0, scale=1.0, max_difference=0.02):
     """evaluate_ate.py main (:118-161): associate ground truth (first) with the estimate (second), align the estimate
     onto the ground truth, return the statistics it prints (rmse, mean, median, std, min, max) and the pair count."""

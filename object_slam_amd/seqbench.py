@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import slam
-from .e2e import horn_align_ate
+from .io import horn_align_ate
 from .parallel import aggregate_stats, gather_records, shard_sequences
 
 RECORD_FIELDS = ("rank", "sequences", "frames", "elapsed_s", "keyframes", "local_bas", "lost_frames", "ate_rmse_m", "map_violations", "semantic_edges")

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 
 from object_slam_amd import slam, synth
-from object_slam_amd.e2e import horn_align_ate
+from object_slam_amd.io import horn_align_ate
 
 W, H, Z0 = 640, 480, 2.0
 

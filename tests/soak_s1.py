@@ -33,7 +33,7 @@ def main():
     del parts
     print("rendered", S, "x", n, "frames in", round(time.time() - t0, 1), "s", flush=True)
     from object_slam_amd import slam
-    from object_slam_amd.e2e import horn_align_ate
+    from object_slam_amd.io import horn_align_ate
     from slam_common import H, W, oracle_ops
 
     def drive(system, ss, label):

@@ -32,3 +32,20 @@ def test_rank_cpu_sets_are_disjoint():
     assert all(sets)
     if world == 2 and len({tuple(g) for g in __import__("bench").physical_cores()}) >= 2:
         assert not (sets[0] & sets[1])
+
+
+def test_eight_ranks_on_a_two_socket_node_get_whole_cores_of_one_socket_each():
+    """configs[4] (8 GPUs, one rank each) on the topology of the MI355X hosts — 2 sockets x 64 cores x 2 SMT threads = 256 CPUs, siblings numbered c and c + 128:
+    every rank gets 16 physical cores = 32 CPUs (>= the 16 host threads a rank runs), disjoint from the others, SMT siblings together, all on one socket."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cores = [[c, c + 128] for c in range(128)]                  # (package, core) order: cores 0-63 on socket 0, 64-127 on socket 1
+    sets = [bench.rank_cpu_set(cores, r, 8) for r in range(8)]
+    assert all(len(s) == 32 for s in sets)
+    assert len(set().union(*map(set, sets))) == 256             # disjoint and complete
+    for r, s in enumerate(sets):
+        phys = sorted(c for c in s if c < 128)
+        assert sorted(c - 128 for c in s if c >= 128) == phys   # both threads of every core
+        assert phys == list(range(16 * r, 16 * r + 16))         # contiguous
+        assert len({c // 64 for c in phys}) == 1                # one socket
+    assert len(bench.rank_cpu_set(cores, 3, 8, per_rank_cores=8)) == 16

@@ -110,5 +110,5 @@ def test_associate_equals_brute_force_and_ate(tmp_path):
     fe.write_text("\n".join("%.6f %.9f %.9f %.9f 0 0 0 1" % (t + 0.003, *p) for t, p in zip(ts, est)))
     st = oio.evaluate_ate(str(fg), str(fe))
     assert st["pairs"] == n and 0.012 < st["rmse"] < 0.02 and st["min"] <= st["median"] <= st["max"]
-    from object_slam_amd.e2e import horn_align_ate
+    from object_slam_amd.io import horn_align_ate
     assert abs(horn_align_ate(est, gt) - st["rmse"]) < 1e-6
