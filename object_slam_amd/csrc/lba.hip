@@ -1004,6 +1004,12 @@ __device__ __forceinline__ double dpp_quad_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// One wavefront per 6x6 block (a, b) of the reduced system walks the block's pair list, 64 pairs per round, one pair per lane.
+// Operand fetch (round 4): a pair's operands are two 144-byte blocks, W_a of edge pe.x and B_b of edge pe.y.  Fetched by the lane that owns the pair (nine
+// 16-byte loads per block at a 144-byte stride ACROSS the lanes) every load instruction touched 64 different cache lines: rocprofv3 --pmc showed the texture
+// addresser busy 70-77 % of the launch (TA_BUSY_avr 176 k of 256 k cycles, 46 cache accesses per load instruction) with the vector ALU at 22 %.  Now the
+// wavefront fetches the 128 blocks of a round COOPERATIVELY — 16-byte piece g of the round's 18 KB goes to lane g mod 64, so nine consecutive lanes read one
+// block and a load instruction touches ~21 lines — and hands them to their owners through LDS (half a round at a time: 9.2 KB per wavefront).
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win, t;
     if (!xcd_window_item(nwin, win, t)) return;
@@ -1023,22 +1029,53 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) acc[i] = 0;
-    // (all 36 operand loads of a pair are issued together: the kernel is a latency-bound gather and lives on the loads in flight per wavefront — consuming B_b
-    // three doubles at a time to fit four wavefronts per SIMD was 25-60 % slower: 174 us at three, 220 us at four against 139 us at two)
     double bsv[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ __align__(16) double s_stage[64 * 18];   // 64 blocks of half a round; after the loop: the [42][17] reduction array
+    __shared__ int s_idx[128];                          // edge of block b of the round (b = 2 x pair lane + operand), -1 = none
     const int q_end = w.pair_start[t + 1];
     int2 pe_next = make_int2(0, 0);
     if (w.pair_start[t] + lane < q_end) pe_next = w.pairs[w.pair_start[t] + lane];
-    for (int q = w.pair_start[t] + lane; q < q_end; q += 64) {
+    const double2* Wg = (const double2*)w.W;
+    const double2* Bg = (const double2*)pr.Hpl;
+    for (int q = w.pair_start[t] + lane; q - lane < q_end; q += 64) {   // (wave-uniform trip count: every lane takes part in the cooperative fetch)
+        const bool mine = q < q_end;
         const int2 pe = pe_next;
         if (q + 64 < q_end) pe_next = w.pairs[q + 64];   // the next round's list entry travels while this round's operands do
-        // (the operand loads do not wait for the two level bytes: all 38 loads of a pair are in flight together, the test only gates the sums)
-        const uint8_t la = pr.level[pe.x], lb = pr.level[pe.y];
-        const double* Wa = w.W + (long long)pe.x * 18;
-        const double* Bb = pr.Hpl + (long long)pe.y * 18;
+        uint8_t la = 1, lb = 1;
+        if (mine) { la = pr.level[pe.x]; lb = pr.level[pe.y]; }
+        s_idx[2 * lane] = mine ? pe.x : -1;
+        s_idx[2 * lane + 1] = mine ? pe.y : -1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         double BD[18], B2[18];
 #pragma unroll
-        for (int i = 0; i < 18; i++) { BD[i] = Wa[i]; B2[i] = Bb[i]; }
+        for (int half = 0; half < 2; half++) {
+            double2 v[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int g = 64 * i + lane, b = g / 9, piece = g - 9 * b;   // piece `piece` of block b of this half
+                const int e = s_idx[64 * half + b];
+                const double2* src = (b & 1) ? Bg : Wg;
+                v[i] = e >= 0 ? src[(long long)e * 9 + piece] : make_double2(0.0, 0.0);
+            }
+            if (half == 1) {   // (the first half's blocks have been read by their owners)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) ((double2*)s_stage)[64 * i + lane] = v[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((lane >> 5) == half) {
+                const double2* mb = (const double2*)s_stage + (lane & 31) * 18;   // blocks 2 (lane & 31) and + 1: W_a then B_b
+#pragma unroll
+                for (int i = 0; i < 9; i++) { const double2 x = mb[i]; BD[2 * i] = x.x; BD[2 * i + 1] = x.y; }
+#pragma unroll
+                for (int i = 0; i < 9; i++) { const double2 x = mb[9 + i]; B2[2 * i] = x.x; B2[2 * i + 1] = x.y; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the next round's fetch overwrites the staging area and the index table)
         if (la != 0 || lb != 0) continue;
         if (diag) {
             const double* bl = pr.bl + (long long)pr.e_pt[pe.x] * 3;
@@ -1054,9 +1091,9 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
     }
     // Sum of the 64 lanes' partial blocks: first inside every quad of lanes by two DPP quad-permute steps (full-rate cross-lane moves, no LDS), then the 16
     // quad sums of each of the 36 (+6) entries through a [42][17] LDS array (rows skewed by one double: conflict-free row reads), added in lane order by
-    // lane i < 42: 5.7 KB of LDS per wavefront (the first version reduced by 36 ds_bpermute butterflies, the second through a [42][65] array that capped
-    // the CU at 7 wavefronts; the registers allow 8).
-    __shared__ double red[42 * 17];
+    // lane i < 42 (the array lives in the staging area: the fetch loop is over).
+    double* red = s_stage;
+    static_assert(42 * 17 <= 64 * 18, "reduction array fits the staging area");
     auto quad_sum = [](double v) {
         v += dpp_quad_f64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
         v += dpp_quad_f64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
