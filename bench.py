@@ -142,9 +142,9 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
     nw = max(1, w1["windows"] - w0["windows"])
     # the reference prints median and mean tracking time per frame (Examples/RGB-D/rgbd_tum.cc:126-134)
     return {"value": round((n - first) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "frames %d..%d (stream frames %d..%d: the mean offset of the GPU leg's sequences in their base streams, so the map is as old as theirs) of one sequence "
-                      "of the same workload through the same driver over the CPU oracle's operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local "
-                      "mapping run on ONE core one after the other" % (first, n, first + offset, n + offset, dt, tp),
+            "sample": "stream frames %d..%d of base stream 0 — the frames the GPU leg's sequences (offsets 0 .. stagger in their base streams) cover in its timed region, with a "
+                      "map of the same age — through the same driver over the CPU oracle's operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local "
+                      "mapping run on ONE core one after the other" % (first + offset, n + offset, dt, tp),
             # the reference's shape (<= 3 busy cores: LocalMapping on a second thread, src/System.cc:95; stereo extraction on two, src/Frame.cc:78-81): its frames/s lies between
             # the one-core figure and the figure with every mapping stage hidden behind tracking
             "three_core_bracket_frames_per_s": [round((n - first) / dt, 2), round((n - first) / max(dt - map_s, 1e-9), 2)],
@@ -454,13 +454,18 @@ def main():
         seq_second = seqbench.base_sequences(second, rank, S2, pre2 + args.warmup + args.steps, workers=share)
     # the CPU baselines run on frames [stagger / 2, ...) of base stream 0 and are timed over more frames than the GPU legs hold: base stream 0 continued (host only)
     seq_cpu = seq_cpu2 = None
-    cpu_n = args.cpu_frames or (60 if stereo_head else 200)
-    cpu_n2 = 200 if stereo_head else 60
+    # Timed range of a CPU baseline = the stream frames the GPU leg's sequences cover in ITS timed region: sequence offsets 0 .. stagger, steps preroll + warmup ..
+    # preroll + warmup + steps, i.e. stream frames [preroll + warmup, preroll + warmup + steps + stagger) — the same part of the path with a map of the same age
+    # (later frames of these periodic paths revisit mapped places and insert a third of the keyframes: timing 200 frames there measured 6 local BAs against the
+    # GPU leg's 18 per 200 frames).  --cpu-frames extends the range; the base stream is then continued on the host.
+    cpu_off = 0
+    cpu_n = args.cpu_frames or (args.steps + head.stagger)
+    cpu_n2 = args.steps + second.stagger
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        need = head.stagger // 2 + preroll + args.warmup + cpu_n - len(seq_head[0]["gray"])
+        need = cpu_off + preroll + args.warmup + cpu_n - len(seq_head[0]["gray"])
         seq_cpu = extend_sequence(head, head.n_base * rank, seq_head[0], need, workers=share) if need > 0 else seq_head[0]
         if seq_second is not None:
-            need2 = second.stagger // 2 + pre2 + args.warmup + cpu_n2 - len(seq_second[0]["gray"])
+            need2 = cpu_off + pre2 + args.warmup + cpu_n2 - len(seq_second[0]["gray"])
             seq_cpu2 = extend_sequence(second, second.n_base * rank, seq_second[0], need2, workers=share) if need2 > 0 else seq_second[0]
     t_gen = time.perf_counter() - t_gen
     if log:
@@ -596,7 +601,7 @@ def main():
             if log:
                 log("CPU baseline of the second workload ...")
             cpu2 = cpu_baseline(second, seq_cpu2 if seq_cpu2 is not None else seq_second[0], pre2 + args.warmup, cpu_n2, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
-                                offset=second.stagger // 2)
+                                offset=cpu_off)
         second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe; steady state: %d untimed steps, then steps %d..%d timed; "
                                   "BASELINE.json configs[%s]" % (second.name, S2, G2, second.nFeatures, pre2, pre2 + args.warmup, pre2 + args.warmup + args.steps,
                                                                  "3]/[4" if second is wl_st else "2"),
@@ -615,7 +620,7 @@ def main():
             if log:
                 log("CPU baseline ...")
             cpu = cpu_baseline(head, seq_cpu if seq_cpu is not None else seq_head[0], preroll + args.warmup, cpu_n, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
-                               offset=head.stagger // 2)
+                               offset=cpu_off)
         front = None
         if extras_on and head is wl_rgbd:
             try:
