@@ -1345,6 +1345,13 @@ constexpr int kMB = 16;                       // panel width = MFMA tile edge
 constexpr int kMfmaMaxN = 6 * kLbaMaxKF;      // 768
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// value of lane `src` (compile-time constant) of a double, as a wave-uniform scalar
+__device__ __forceinline__ double rl_f64(double v, int src) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 constexpr int kMfmaThreads = 512;   // 8 wavefronts: 256 registers each (the four-tile trailing step needs ~150; 1024 threads would cap them at 128 and spill)
 // Body of the matrix-core solve for one workgroup of kMfmaThreads threads: A = augmented system [n][n + 1] in global memory (upper triangle + rhs column),
 // s_P = LDS row panel of 16 x pw doubles (pw = ((n + 1 + 15) / 16 + 1) * 16), s_x = LDS vector of n + 16 doubles; the solution goes to x (global or LDS).
@@ -1353,55 +1360,73 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
 #pragma clang fp contract(fast)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ld = n + 1;
-    __shared__ double s_D[kMB][kMB + 1], s_R[kMB];
+    __shared__ double s_D[kMB][kMB + 1];
     __shared__ int s_ok;
     if (tid == 0) s_ok = 1;
     const int pw = ((n + 1 + kMB - 1) / kMB + 1) * kMB;   // pitch of the row panel in LDS
     __syncthreads();
     for (int j0 = 0; j0 < n; j0 += kMB) {
         const int nb = min(kMB, n - j0), c0 = j0 + nb, m = n - c0;   // trailing rows / columns m, plus the rhs column
-        // ---- 1. diagonal block -> LDS, factored by wavefront 0 ----
-        if (tid < kMB * kMB) {
-            const int i = tid >> 4, k = tid & 15;
-            s_D[i][k] = (i < nb && k < nb && k >= i) ? A[(size_t)(j0 + i) * ld + j0 + k] : (i == k ? 1.0 : 0.0);
-        }
-        __syncthreads();
+        // ---- 1. diagonal block, wavefront 0, in registers (round 4; the same scheme as k_w_chol_lds_mfma): lane k (mod 16) holds COLUMN k of the block padded
+        // to 16x16 with the identity; the pivot and the entries of row j reach the other lanes by readlane, no LDS round trip inside the 16 steps (the LDS form
+        // took ~8 us per block).  Then V = U11^-1 by back substitution on the identity, column k in lane k, into s_D for the row-panel product. ----
         if (wv == 0) {
+            const int kc = lane & 15;
+            double U[kMB], rinv[kMB];
+#pragma unroll
+            for (int i = 0; i < kMB; i++) U[i] = (i < nb && kc < nb && kc >= i) ? A[(size_t)(j0 + i) * ld + j0 + kc] : (i == kc ? 1.0 : 0.0);
             bool good = true;
-            for (int j = 0; j < nb; j++) {
-                const double d = s_D[j][j];
+#pragma unroll
+            for (int j = 0; j < kMB; j++) {
+                const double d = rl_f64(U[j], j);
                 good = good && (d > 0) && (d < 1.7e308);
                 const double r = rsqrt(d);
-                if (lane < kMB && lane > j) s_D[j][lane] *= r;
-                if (lane == 0) { s_D[j][j] = d * r; s_R[j] = r; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int e = lane; e < kMB * kMB; e += 64) {
-                    const int i = e >> 4, k = e & 15;
-                    if (i > j && k >= i) s_D[i][k] -= s_D[j][i] * s_D[j][k];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                rinv[j] = r;
+                U[j] = kc == j ? d * r : U[j] * r;
+#pragma unroll
+                for (int i = j + 1; i < kMB; i++) U[i] -= rl_f64(U[j], i) * U[j];
             }
             if (!good && lane == 0) s_ok = 0;
-            for (int e = lane; e < kMB * kMB; e += 64) {   // the factor back into the matrix (back substitution reads it)
-                const int i = e >> 4, k = e & 15;
-                if (i < nb && k < nb && k >= i) A[(size_t)(j0 + i) * ld + j0 + k] = s_D[i][k];
+            double V[kMB];
+#pragma unroll
+            for (int i = 0; i < kMB; i++) V[i] = i == kc ? rinv[i] : 0.0;
+#pragma unroll
+            for (int i = kMB - 2; i >= 0; i--) {
+                double sv = 0;
+#pragma unroll
+                for (int mm = i + 1; mm < kMB; mm++) sv += rl_f64(U[i], mm) * V[mm];
+                V[i] = i < kc ? -rinv[i] * sv : V[i];
+            }
+            if (lane < kMB) {
+#pragma unroll
+                for (int i = 0; i < kMB; i++) {
+                    s_D[i][kc] = V[i];
+                    if (i < nb && kc < nb && kc >= i) A[(size_t)(j0 + i) * ld + j0 + kc] = U[i];   // the factor back into the matrix (back substitution reads it)
+                }
             }
         }
         __syncthreads();
-        // ---- 2. row panel: U12 = U11^-T A12 (columns c0 .. n), one thread per column; rows >= nb and the padding columns are zero ----
-        for (int c = tid; c < pw; c += kMfmaThreads) {   // the column lives in LDS (a register array of 16 doubles per thread plus the factor spilled)
-            const int cg = c0 + c;
-            const bool live = c <= m;
-            for (int i = 0; i < kMB; i++) s_P[i * pw + c] = (live && i < nb) ? A[(size_t)(j0 + i) * ld + cg] : 0.0;
-            if (live) {
-                for (int j = 0; j < nb; j++) {
-                    double sv = s_P[j * pw + c];
-                    for (int i = 0; i < j; i++) sv -= s_D[i][j] * s_P[i * pw + c];
-                    sv *= s_R[j];
-                    s_P[j * pw + c] = sv;
-                    A[(size_t)(j0 + j) * ld + cg] = sv;
+        // ---- 2. row panel U12 = U11^-T A12 = V^T A12 by MFMA, one wavefront per 16-column tile: the result goes to the matrix AND to the LDS row panel the
+        // trailing update reads its operands from (rows >= nb and the padding columns of the panel are zero) ----
+        {
+            const int Tp = pw / kMB;
+            for (int tt = wv; tt < Tp; tt += kMfmaThreads / 64) {
+                const int c = kMB * tt + (lane & 15), cg = c0 + c;
+                const bool live = c <= m;
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sx = 0; sx < kMB / 4; sx++) {
+                    const int kk = 4 * sx + (lane >> 4);
+                    const double aop = s_D[kk][lane & 15];                                            // A[i][k] = V[k][i]
+                    const double bop = (live && kk < nb) ? A[(size_t)(j0 + kk) * ld + cg] : 0.0;   // B[k][j] = A12[k][c]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int r = (lane >> 4) + 4 * g;
+                    const bool rv = live && r < nb;
+                    s_P[r * pw + c] = rv ? acc[g] : 0.0;
+                    if (rv) A[(size_t)(j0 + r) * ld + cg] = acc[g];
                 }
             }
         }
