@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 # order whatever stream they came from: with 8 handles, two handles shared a queue and the short kernels of one waited behind the ~180 local-BA launches of the
 # other (the MapPoint-update operator spent 3.5x its kernels' time waiting).  Must be in the environment before the HIP runtime starts (the first import of
 # torch): measured 24.2 k against 22.7 k frames/s in the steady state (same box); 12 / 16 queues give 24.2 / 24.4 k.  INTEGRATION.md names it for host applications.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # (round 4: 8 handles + the 2 streams of the local-BA service; same-box A/B of the deferred schedule: 8 -> 26.4 k, 12 -> 27.3 k, 16 -> 26.6 k)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 matrix (= vector) peak, AMD datasheet: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 2048 flop / 64 clk;
