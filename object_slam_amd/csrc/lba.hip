@@ -1345,6 +1345,17 @@ constexpr int kMB = 16;                       // panel width = MFMA tile edge
 constexpr int kMfmaMaxN = 6 * kLbaMaxKF;      // 768
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// 1 / sqrt(d) for the pivots of the 16x16 diagonal blocks: v_rsq_f64 (the hardware's ~26-bit estimate) + two Newton steps, a dependent chain of ~9
+// instructions (16 of them sit on a panel's critical path).  Full double precision to an ulp or two; a non-positive or non-finite pivot is caught by the
+// caller's test of d itself.
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * (1.5 - h * r * r);
+    r = r * (1.5 - h * r * r);
+    return r;
+}
+
 // value of lane `src` (compile-time constant) of a double, as a wave-uniform scalar
 __device__ __forceinline__ double rl_f64(double v, int src) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -1380,7 +1391,7 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
             for (int j = 0; j < kMB; j++) {
                 const double d = rl_f64(U[j], j);
                 good = good && (d > 0) && (d < 1.7e308);
-                const double r = rsqrt(d);
+                const double r = rsqrt_nr(d);
                 rinv[j] = r;
                 U[j] = kc == j ? d * r : U[j] * r;
 #pragma unroll
