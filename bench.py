@@ -404,12 +404,12 @@ def main():
     ap.add_argument("--workload", choices=("rgbd", "stereo"), default="rgbd")
     ap.add_argument("--preroll", type=int, default=-1, help="untimed set-up steps before the warm-up that bring every sequence's map to its steady state (default: 200 for the "
                                                              "RGB-D stream = SURVEY.md §8(d) frame >= 200, 40 for the stereo street); 0 = the cold-start regime of round 2")
-    ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 8192 RGB-D / 512 stereo)")
+    ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 8192 RGB-D / 2048 stereo)")
     ap.add_argument("--bases", type=int, default=8, help="base renderings per GPU of the headline stream (distinct input streams = bases x 25 frame offsets)")
     ap.add_argument("--lm", choices=("deferred", "sync"), default="deferred", help="local-mapping schedule (include/oslam_slam.h): deferred = the local BA of keyframe t is solved by the "
                     "process-wide service while frame t+1 is tracked, its write-back and KeyFrameCulling land before frame t+2 (the reference's two-thread overlap, "
                     "src/System.cc:95); sync = the whole pass right after the frame that inserted the keyframe (rounds 1-3)")
-    ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8 / 4)")
+    ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
@@ -436,8 +436,8 @@ def main():
     head, second = (wl_st, wl_rgbd) if stereo_head else (wl_rgbd, wl_st)
     # 8192 sequences per GPU: 21.7 k frames/s against 19.3 k with 4096 and 22.9 k with 16384 (same code; local-BA calls of ~82 windows instead of ~41; 55 GB of host
     # memory for the maps, 53 s of pre-roll)
-    S = args.seqs or (512 if stereo_head else 8192)
-    G = args.handles or (4 if stereo_head else 8)
+    S = args.seqs or (2048 if stereo_head else 8192)
+    G = args.handles or 8
     extras_on = rank == 0 and world == 1 and not args.no_extras
     host_phase = extras_on and not stereo_head            # the same warmed sequences continued with host-resident inputs
     post_frames = (2 + args.steps) if host_phase else 0
@@ -449,7 +449,7 @@ def main():
     seq_second = None
     pre2 = 0
     if extras_on:            # second figure: the other stream shape in ITS steady state (rank 0 of a single-rank run only)
-        S2, G2 = (512, 4) if second is wl_st else (1024, 4)
+        S2, G2 = (2048, 8) if second is wl_st else (1024, 4)   # (stereo, same box: 512 / 4 -> 13.1 k frames/s, 1024 / 4 -> 16.2 k, 2048 / 4 -> 17.0 k, 2048 / 8 -> 19.8 k; 48 GB of HBM)
         pre2 = 40 if second is wl_st else 200
         seq_second = seqbench.base_sequences(second, rank, S2, pre2 + args.warmup + args.steps, workers=share)
     # the CPU baselines run on frames [stagger / 2, ...) of base stream 0 and are timed over more frames than the GPU legs hold: base stream 0 continued (host only)

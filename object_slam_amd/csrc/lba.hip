@@ -1383,7 +1383,7 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
         // took ~8 us per block).  Then V = U11^-1 by back substitution on the identity, column k in lane k, into s_D for the row-panel product. ----
         if (wv == 0) {
             const int kc = lane & 15;
-            double U[kMB], rinv[kMB];
+            double U[kMB], Y[kMB];
 #pragma unroll
             for (int i = 0; i < kMB; i++) U[i] = (i < nb && kc < nb && kc >= i) ? A[(size_t)(j0 + i) * ld + j0 + kc] : (i == kc ? 1.0 : 0.0);
             bool good = true;
@@ -1392,26 +1392,21 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
                 const double d = rl_f64(U[j], j);
                 good = good && (d > 0) && (d < 1.7e308);
                 const double r = rsqrt_nr(d);
-                rinv[j] = r;
+                // row j of Y = U^-T (forward substitution on the identity, column kc of Y in this lane): its inputs U(i, j), i < j, are final since step i, so this
+                // chain runs beside the factor's own dependent chain instead of after it (V = U^-1 = Y^T)
+                double sy = kc == j ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < j; i++) sy -= rl_f64(U[i], j) * Y[i];
+                Y[j] = sy * r;
                 U[j] = kc == j ? d * r : U[j] * r;
 #pragma unroll
-                for (int i = j + 1; i < kMB; i++) U[i] -= rl_f64(U[j], i) * U[j];
+                for (int i = j + 1; i < kMB; i++) U[i] -= rl_f64(U[j], i) * U[j];   // (lanes left of column i keep garbage below their diagonal: never read)
             }
             if (!good && lane == 0) s_ok = 0;
-            double V[kMB];
-#pragma unroll
-            for (int i = 0; i < kMB; i++) V[i] = i == kc ? rinv[i] : 0.0;
-#pragma unroll
-            for (int i = kMB - 2; i >= 0; i--) {
-                double sv = 0;
-#pragma unroll
-                for (int mm = i + 1; mm < kMB; mm++) sv += rl_f64(U[i], mm) * V[mm];
-                V[i] = i < kc ? -rinv[i] * sv : V[i];
-            }
             if (lane < kMB) {
 #pragma unroll
                 for (int i = 0; i < kMB; i++) {
-                    s_D[i][kc] = V[i];
+                    s_D[kc][i] = Y[i];
                     if (i < nb && kc < nb && kc >= i) A[(size_t)(j0 + i) * ld + j0 + kc] = U[i];   // the factor back into the matrix (back substitution reads it)
                 }
             }
