@@ -1,6 +1,7 @@
 // Shared host-side helpers for the gfx950 hot-path library (product code; never includes oracle/).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <cstdarg>
 #include <cstdint>
@@ -35,6 +36,8 @@ void stream_wait_thread_mode(int spin_us);
 // owning one each (streams beyond the device's hardware queues share queues, and a queue executes its packets in order whatever stream they came from).
 // The caller keeps the stream alive for the lifetime of the sub-handle.
 void lba_use_stream(struct ::oslam_lba* h, hipStream_t s);
+// Solver handles that share a gate run the device part of their calls (upload .. download) one at a time; the window preparation stays outside the gate.
+void lba_use_gate(struct ::oslam_lba* h, std::mutex* gate);
 void bow_use_stream(struct ::oslam_bow* h, hipStream_t s);
 void mappoint_use_stream(struct ::oslam_mappoint* h, hipStream_t s);
 

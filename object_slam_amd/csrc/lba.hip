@@ -1795,6 +1795,7 @@ struct oslam_lba {
     LbaCtrl* h_ctrl = nullptr; size_t h_ctrl_cap = 0;          // pinned copy of the control blocks (the host polls `done`)
     hipStream_t strm = nullptr;   // every copy and launch of this handle (non-blocking: handles driven by different host threads overlap on the GPU)
     bool owns_strm = true;        // false: the stream of the driver handle this solver belongs to (lba_use_stream)
+    std::mutex* launch_gate = nullptr;   // held from the upload to the download of a call when set (lba_use_gate): solvers sharing a gate take turns on the device
     bool device_pairs = true;     // pair lists of the gather Schur built by k_w_pair_* (OSLAM_LBA_HOST_PAIRS=1: by lba_build on the host, the round-2 path)
     long long prof_pre_upload_ns = 0;   // host time of the last lba_launch before its upload (OSLAM_LBA_HOSTPROF)
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
@@ -1939,6 +1940,7 @@ void oslam_lba_destroy(oslam_lba_t* h) {
 
 extern "C++" {
 namespace oslam {
+void lba_use_gate(oslam_lba* h, std::mutex* gate) { if (h) h->launch_gate = gate; }
 void lba_use_stream(oslam_lba* h, hipStream_t s) {
     if (!h || !s) return;
     if (h->strm && h->owns_strm) { (void)hipStreamSynchronize(h->strm); (void)hipStreamDestroy(h->strm); }
@@ -2489,6 +2491,8 @@ static int lba_launch(oslam_lba_t* h) {
     };
     static Gate* gate = [] { const char* e = getenv("OSLAM_LBA_CONCURRENCY"); const int k = e ? atoi(e) : 0; return k > 0 ? new Gate(k) : (Gate*)nullptr; }();
     struct GateScope { Gate* g; explicit GateScope(Gate* g_) : g(g_) { if (g) g->enter(); } ~GateScope() { if (g) g->leave(); } } gate_scope(gate);
+    std::unique_lock<std::mutex> handle_gate;   // (the window preparation above ran outside it: one solver prepares while the other has the device)
+    if (h->launch_gate) handle_gate = std::unique_lock<std::mutex>(*h->launch_gate);
     h->prof_pre_upload_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch0).count();
     OSLAM_HIP_CHECK(hipMemcpyAsync(I, h->in_h, h->in_off, hipMemcpyHostToDevice, st));   // the ONE upload
     const LbaProblem* d_probs = (const LbaProblem*)(I + o_probs);

@@ -963,11 +963,14 @@ static double lba_flop(const oslam_lba_problem_t& q, const int32_t st[4]) {
 struct LbaService {
     typedef LbaJob Job;
     int device = 0;
-    // OSLAM_LBA_SERVICE_THREADS workers (default 2), each with its own solver handle and stream: while one waits for the device the other prepares and
-    // uploads the next batch (window preparation, upload and result scatter are ~a third of a call's wall time)
+    // OSLAM_LBA_SERVICE_THREADS workers (default 2), each with its own solver handle and stream: while one has the device the other prepares the next batch
+    // and scatters the previous one's results (window preparation, upload and result scatter are ~a third of a call's wall time).  The device part of a call
+    // (upload .. download) is taken in turns (launch_mu): two overlapping calls ran 7.1 s of stream time per 20 bench steps against 5.3 s in turns, at the
+    // same frames/s (same-box A/B: 26.6 k overlapping, 26.3-27.1 k in turns)
     struct Worker { oslam_lba_t* ba = nullptr; hipStream_t strm = nullptr; std::thread th; };
     std::vector<std::unique_ptr<Worker>> workers;
     int max_batch = 0, mode_small = 1, mode_big = 1, big_from = 1 << 30;
+    std::mutex launch_mu;   // one call on the device at a time: the other worker prepares / scatters meanwhile (OSLAM_LBA_SERVICE_OVERLAP=1 lets the calls overlap)
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::deque<Job*> queue;
@@ -1029,6 +1032,7 @@ struct LbaService {
                 OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, lo));
                 oslam::lba_use_stream(wk->ba, wk->strm);
             }
+            if (!getenv("OSLAM_LBA_SERVICE_OVERLAP")) oslam::lba_use_gate(wk->ba, &launch_mu);
             workers.push_back(std::move(wk));
         }
         // layout per call: batches of at least `big_from` windows go through the one-workgroup-per-window kernel (mode 2), smaller ones through the multi-launch layout

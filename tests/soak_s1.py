@@ -2,7 +2,9 @@
 HIP operator table — S sequences in lockstep — and, for sequence 0, through the SAME driver over the CPU oracle's operator table; reports frames/s,
 ATE (Horn alignment, evaluate_ate.py semantics), lost frames, map statistics and the HIP-vs-oracle agreement.
 Lives under tests/ because its comparison leg loads the oracle (test infrastructure); not collected by pytest.
-usage: python tests/soak_s1.py [S=2] [n=1000] [oracle=1]"""
+The tables agree on every statistic for as long as no thresholded decision falls inside the optimisers' tolerance: `first_stat_difference`
+reports the first frame at which a counter of sequence 0 differs, what differed, and how far apart the poses were up to there.
+usage: python tests/soak_s1.py [S=2] [n=1000] [oracle=1] [sync|deferred]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +14,7 @@ import numpy as np
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 with_oracle = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+schedule = sys.argv[4] if len(sys.argv) > 4 else "sync"
 CH = 25
 
 
@@ -36,31 +39,41 @@ def main():
     from object_slam_amd.io import horn_align_ate
     from slam_common import H, W, oracle_ops
 
-    def drive(system, ss, label):
+    LM = slam.LM_DEFERRED if schedule == "deferred" else slam.LM_SYNC
+
+    def drive(system, ss, label, snaps=None):
         poses, t1 = [], time.time()
         for t in range(n):
             objs = [dict(masks=[q["masks"][t, o] for o in range(3)], track_ids=q["track_ids"]) for q in ss]
             T, st = system.TrackRGBD([q["gray"][t] for q in ss], [q["depth"][t] for q in ss], [t / 30.0] * len(ss), objects=objs)
             poses.append(T.copy())
+            if snaps is not None:
+                snaps.append(system.stats(0))
             if (t + 1) % 100 == 0:
                 print(label, "frame", t + 1, "states", st.tolist(), round(time.time() - t1, 1), "s", flush=True)
         return np.array(poses), time.time() - t1
 
-    hip = slam.System(slam.make_config(W, H, S, host_threads=8))
-    ph, dt = drive(hip, seqs, "hip")
-    out = {"sequences": S, "frames": n, "hip_frames_per_s": round(S * n / dt, 1), "per_sequence": []}
+    hip = slam.System(slam.make_config(W, H, S, host_threads=8, local_mapping=LM))
+    sh = []
+    ph, dt = drive(hip, seqs, "hip", sh)
+    out = {"sequences": S, "frames": n, "schedule": schedule, "hip_frames_per_s": round(S * n / dt, 1), "per_sequence": []}
     for s in range(S):
         stamps, Twc = hip.trajectory(s)
         a = horn_align_ate(Twc[:, :, 3], seqs[s]["Twc"][:len(stamps), :3, 3])
         out["per_sequence"].append(dict(ate_rmse_m=round(float(a), 5), **hip.stats(s)))
     if with_oracle:
-        cfg = slam.make_config(W, H, 1)
+        cfg = slam.make_config(W, H, 1, local_mapping=LM)
         ora = slam.System(cfg, oracle_ops(cfg))
-        po, dto = drive(ora, seqs[:1], "oracle")
+        so = []
+        po, dto = drive(ora, seqs[:1], "oracle", so)
         stamps, Twc = ora.trajectory(0)
         out["oracle_seq0"] = dict(frames_per_s=round(n / dto, 1), ate_rmse_m=round(float(horn_align_ate(Twc[:, :, 3], seqs[0]["Twc"][:len(stamps), :3, 3])), 5),
                                   **ora.stats(0))
         out["hip_vs_oracle_seq0"] = dict(stats_equal=hip.stats(0) == ora.stats(0), max_abs_pose_diff=float(np.abs(ph[:, 0] - po[:, 0]).max()))
+        first = next((t for t in range(n) if sh[t] != so[t]), None)
+        if first is not None:
+            out["first_stat_difference"] = dict(frame=first, counters={k: (sh[first][k], so[first][k]) for k in sh[first] if sh[first][k] != so[first][k]},
+                                                max_abs_pose_diff_before=float(np.abs(ph[:first + 1, 0] - po[:first + 1, 0]).max()))
     print(json.dumps(out))
 
 

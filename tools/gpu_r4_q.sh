@@ -12,7 +12,7 @@ print("$tag", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]
 print({k:d["stage_seconds_timed_sum_over_handles"][k] for k in ("lba","mp_update","host_mapping","host_tracking","frames","pose_opt","fuse_bow_triangulate")})
 PY
 }
+run t2c1 deferred OSLAM_LBA_SERVICE_THREADS=2 OSLAM_LBA_CONCURRENCY=1
+run t3c1 deferred OSLAM_LBA_SERVICE_THREADS=3 OSLAM_LBA_CONCURRENCY=1
 run t2 deferred OSLAM_LBA_SERVICE_THREADS=2
-run t1 deferred OSLAM_LBA_SERVICE_THREADS=1
-run t2b deferred OSLAM_LBA_SERVICE_THREADS=2
-run t1b deferred OSLAM_LBA_SERVICE_THREADS=1
+run t2c1b deferred OSLAM_LBA_SERVICE_THREADS=2 OSLAM_LBA_CONCURRENCY=1
