@@ -2491,10 +2491,15 @@ static int lba_launch(oslam_lba_t* h) {
     };
     static Gate* gate = [] { const char* e = getenv("OSLAM_LBA_CONCURRENCY"); const int k = e ? atoi(e) : 0; return k > 0 ? new Gate(k) : (Gate*)nullptr; }();
     struct GateScope { Gate* g; explicit GateScope(Gate* g_) : g(g_) { if (g) g->enter(); } ~GateScope() { if (g) g->leave(); } } gate_scope(gate);
-    std::unique_lock<std::mutex> handle_gate;   // (the window preparation above ran outside it: one solver prepares while the other has the device)
-    if (h->launch_gate) handle_gate = std::unique_lock<std::mutex>(*h->launch_gate);
     h->prof_pre_upload_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_launch0).count();
     OSLAM_HIP_CHECK(hipMemcpyAsync(I, h->in_h, h->in_off, hipMemcpyHostToDevice, st));   // the ONE upload
+    // Solvers that share a gate run their KERNELS in turns: the window preparation above and the upload (a DMA transfer on this solver's own stream: tens of
+    // MB per call) proceed while the other solver has the device.
+    std::unique_lock<std::mutex> handle_gate;
+    if (h->launch_gate) {
+        OSLAM_HIP_CHECK(stream_wait(st));   // (the upload has landed: what the gate then covers is kernel time only)
+        handle_gate = std::unique_lock<std::mutex>(*h->launch_gate);
+    }
     const LbaProblem* d_probs = (const LbaProblem*)(I + o_probs);
     const LbaWide* d_ws = (const LbaWide*)(I + o_ws);
     long long launches = 0;

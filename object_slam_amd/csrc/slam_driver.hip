@@ -346,11 +346,7 @@ struct MpUpdate {
             for (int i = i0; i < i1; i++) {
                 if (i + kPF < i1) prefetch_mp(&c.seq[items[i + kPF].seq]->map.mps[items[i + kPF].p]);
                 if (i + kPF / 2 < i1) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].obs.data());
-                if (do_normal && i + 2 < i1) {   // the reference keyframe's keypoint of item i + 2 (record and list were requested above): a third, dependent access
-                    const Map& m2 = c.seq[items[i + 2].seq]->map;
-                    const MapPt& p2 = m2.mps[items[i + 2].p];
-                    if (!p2.bad && p2.refKF >= 0) { const int i2 = p2.obs_index(p2.refKF); if (i2 >= 0) __builtin_prefetch(&m2.kfs[p2.refKF].keysUn[i2]); }
-                }
+                if (do_normal && i + kPF / 2 < i1) __builtin_prefetch(c.seq[items[i + kPF / 2].seq]->map.mps[items[i + kPF / 2].p].okp.data());   // (the reference keyframe's octave is read from the list beside obs)
                 const Map& m = c.seq[items[i].seq]->map;
                 const MapPt& p = m.mps[items[i].p];
                 const int n = start[i + 1] - start[i];
@@ -371,9 +367,9 @@ struct MpUpdate {
                 const float* ow = p.pos;
                 if (n > 0 && p.refKF >= 0) {
                     const KeyFrm& rk = m.kfs[p.refKF];
-                    const int idx = p.obs_index(p.refKF);
                     ow = rk.pose.Ow;
-                    if (idx >= 0) lf = c.scale[rk.keysUn[idx].octave];
+                    for (size_t oi = 0; oi < p.obs.size(); oi++)
+                        if (p.obs[oi].first == p.refKF) { lf = c.scale[p.okp[oi].octave]; break; }   // mvKeysUn[idx].octave of the reference keyframe's observation (src/MapPoint.cc:455-457), cached in ObsKp
                 }
                 for (int d = 0; d < 3; d++) owref[(size_t)i * 3 + d] = ow[d];
                 lsf[i] = lf;
