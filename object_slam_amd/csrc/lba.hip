@@ -615,6 +615,7 @@ struct LbaCtrl {
     int nfree, n;
     int ticket[2];   // blocks finished in k_w_lin / k_w_eval: the last one runs the LM control step
     double lambda, ni, currentChi, rho;
+    double lambdaA, FA;   // LM control after a linearisation, pair-gather path: written by block 0 of k_w_edgeW, committed by the next k_w_ctrlB (see w_ctrlA_values)
 };
 
 struct LbaWide {
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, const L
         ct->its[0] = ct->its[1] = ct->trials[0] = ct->trials[1] = 0;
         ct->ticket[0] = ct->ticket[1] = 0;
         ct->nfree = nb; ct->n = 6 * nb;
-        ct->lambda = 0; ct->ni = 2; ct->currentChi = 0; ct->rho = 0;
+        ct->lambda = 0; ct->ni = 2; ct->currentChi = 0; ct->rho = 0; ct->lambdaA = 0; ct->FA = 0;
         ct->early = pr.stop ? (*pr.stop != 0) : 0;   // reference :655-657
         if (ct->early) ct->done = 1;
     }
@@ -867,6 +868,12 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
 // LM control after the linearisation (k_w_ctrlA, one thread per window): chi2 of the current state, lambda init.
 // The control steps are their own tiny launches: a kernel boundary makes every block's partial sums visible, whereas a "last block to
 // finish" scheme needs an agent-scope release per block (an L2 write-back each): 185 us per k_w_lin launch of 28 windows x 20 blocks.
+// The damping of the trial in flight.  In the pair-gather path the control step after a linearisation (w_ctrlA) has no launch of its own: k_w_edgeW computes its
+// values — every workgroup for itself from the linearisation's partial sums, which no launch of the trial modifies — and workgroup 0 leaves them in
+// lambdaA / FA, which k_w_edgeW itself never reads; the kernels behind it take lambdaA while need_lin still says "first trial after a linearisation", and the
+// trial's k_w_ctrlB commits them (need_lin = 0, currentChi = FA, lambda = lambdaA on the first iteration of a stage) before it decides the trial.
+__device__ __forceinline__ double w_lambda_eff(const LbaCtrl* ct) { return (ct->need_lin && ct->iter == 0) ? ct->lambdaA : ct->lambda; }
+
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
     if (ct->gate) { ct->gate = 0; }
@@ -903,9 +910,32 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
     const int e0 = item_ * 256;
     if (e0 >= pr.E) return;
     __shared__ double sW[256 * 19];   // 19: one double of padding per block (18 would put the lanes of a wavefront on 16 of the 64 banks)
+    __shared__ double s_lambda;
+    // LM control after a linearisation (w_ctrlA's values, see w_lambda_eff): lambda of the first trial of a stage = 1e-5 x the largest diagonal entry of the
+    // linearised system (computeLambdaInit), from the landmark blocks' partial maxima and the free keyframes' Hpp — by wavefront 0 of every workgroup;
+    // workgroup 0 also sums the robust chi2 partials and publishes both for the later launches of the trial.
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        double lam = ct->lambda;
+        if (ct->need_lin) {
+            if (ct->iter == 0) {
+                double m = 0;
+                for (int i = lane; i < w.nblk_pt; i += 64) m = fmax(m, w.partM[i]);
+                for (int i = lane; i < ct->nfree * 6; i += 64) m = fmax(m, fabs(pr.Hpp[w.free_pose[i / 6] * 36 + (i % 6) * 7]));
+                lam = 1e-5 * wmax(m);
+            }
+            if (item_ == 0) {
+                double F = 0;
+                if (lane == 0) for (int i = 0; i < w.nblk_pt; i++) F += w.partF[i];   // (index order: the sum w_ctrlA forms)
+                if (lane == 0) { w.ct->lambdaA = lam; w.ct->FA = F; }
+            }
+        }
+        if (lane == 0) s_lambda = lam;
+    }
+    __syncthreads();
     const int e = e0 + threadIdx.x;
     if (e < pr.E && pr.level[e] == 0 && w.blk[pr.e_kf[e]] >= 0) {
-        const double lambda = ct->lambda;
+        const double lambda = s_lambda;
         const int p = pr.e_pt[e];
         double D[9], Di[9];
         const double* H = pr.Hll + (long long)p * 9;
@@ -1020,7 +1050,7 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
     const int nfree = ct->nfree, n = ct->n, ld = n + 1;
     const int lane = threadIdx.x;
     if (t >= nfree * (nfree + 1) / 2) return;
-    const double lambda = ct->lambda;
+    const double lambda = w_lambda_eff(ct);
     int ba = 0, rem = t;
     while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
     const int bb = ba + rem;
@@ -1538,7 +1568,10 @@ __global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* 
     if (threadIdx.x == 0) ct->ok2 = ok2 ? 1 : 0;
 }
 
-// landmark back-substitution, trial state, computeScale partials
+// Landmark back-substitution, trial state, computeScale partials AND the trial's chi2 (round 4: one launch instead of k_w_update + k_w_eval).
+// Blocks [0, nblk_pt): 128 landmarks each — x_l, the trial position, then the errors of the landmark's edges at the TRIAL state.  The trial poses of the free
+// keyframes are what the pose block (item == nblk_pt) writes to w.T / w.R for the later launches; a landmark block cannot wait for another block, so it
+// recomputes them itself into LDS (se3_exp + se3_mul per free keyframe: the same two calls on the same inputs, hence the same bits).
 __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -1546,13 +1579,15 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     const LbaWide& w = ws[win_];
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
-    const double lambda = ct->lambda;
+    const double lambda = w_lambda_eff(ct);
     const bool ok2 = ct->ok2 != 0;
     const int cur = ct->cur;
     const double* X = w_X(pr, cur);
     double* Xn = w_X(pr, cur ^ 1);
     double sc = 0;
     if (item_ > w.nblk_pt) return;   // padding block of a batched launch (the grid is sized for the largest window)
+    __shared__ double sS[kWPt / 64], sF[kWPt / 64];
+    __shared__ SE3 sTn[kLbaMaxKF];   // trial poses of the FREE keyframes (block index order)
     if (item_ == w.nblk_pt) {   // poses
         for (int a = threadIdx.x; a < pr.K; a += kWPt) {
             const int ba = w.blk[a];
@@ -1566,75 +1601,71 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
             }
             se3_R(*Tn, w.R + ((size_t)(cur ^ 1) * pr.K + a) * 9);
         }
-    } else {
-        const int p = item_ * kWPt + threadIdx.x;
-        if (p < pr.P) {
-            double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
-            double xo[3] = {0, 0, 0};
-            if (ok2) {
-                for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
-                    // (B_e is requested before the level byte and the keyframe's block index are known: its address depends on neither)
-                    const double* Bg = pr.Hpl + (long long)e * 18;
-                    double B[18];
-#pragma unroll
-                    for (int i = 0; i < 18; i++) B[i] = Bg[i];
-                    const uint8_t lv = pr.level[e];
-                    const int ba = w.blk[pr.e_kf[e]];
-                    if (lv != 0 || ba < 0) continue;
-                    const double* xa = pr.xp + 6 * ba;
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        double sv = 0;
-#pragma unroll
-                        for (int i = 0; i < 6; i++) sv += B[i * 3 + j] * xa[i];
-                        cl[j] -= sv;
-                    }
-                }
-                double D[9], Di[9];
-                const double* H = pr.Hll + (long long)p * 9;
-#pragma unroll
-                for (int i = 0; i < 9; i++) D[i] = H[i];
-                D[0] += lambda; D[4] += lambda; D[8] += lambda;
-                inv3(D, Di);
-#pragma unroll
-                for (int i = 0; i < 3; i++) xo[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                Xn[p * 3 + i] = X[p * 3 + i] + xo[i];
-                sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);
-            }
+        const double s1 = wsum(sc);
+        if ((threadIdx.x & 63) == 0) sS[threadIdx.x >> 6] = s1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = sS[0];
+            for (int i = 1; i < kWPt / 64; i++) a += sS[i];
+            w.partS[item_] = a;
         }
+        return;
     }
-    __shared__ double sS[kWPt / 64];
-    const double s1 = wsum(sc);
-    if ((threadIdx.x & 63) == 0) sS[threadIdx.x >> 6] = s1;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = sS[0];
-        for (int i = 1; i < kWPt / 64; i++) a += sS[i];
-        w.partS[item_] = a;
+    // ---- landmark block ----
+    const int nfree = ct->nfree;
+    for (int ba = threadIdx.x; ba < nfree; ba += kWPt) {
+        const int a = w.free_pose[ba];
+        double xa[6];
+        for (int i = 0; i < 6; i++) xa[i] = pr.xp[6 * ba + i];
+        sTn[ba] = se3_mul(se3_exp(xa), w.T[cur * pr.K + a]);
     }
-}
-
-__global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const LbaWide* ws, int nwin) {
-    int win_, item_;
-    if (!xcd_window_item(nwin, win_, item_)) return;
-    const LbaProblem& pr = probs[win_];
-    const LbaWide& w = ws[win_];
-    const LbaCtrl* ct = w.ct;
-    if (ct->done) return;
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
     const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
-    const int tr = ct->cur ^ 1;
-    const double* Xp = w_X(pr, tr);
-    const SE3* Tp = w.T + tr * pr.K;
+    const SE3* Tc = w.T + cur * pr.K;   // (a fixed keyframe's trial pose is its current pose)
     const int p = item_ * kWPt + threadIdx.x;
-    const bool padding = item_ >= w.nblk_pt;   // batched launch: blocks past this window's points only report in
     double F = 0;
-    if (p < pr.P && !padding) {
-        const double Xw[3] = {Xp[p * 3], Xp[p * 3 + 1], Xp[p * 3 + 2]};
+    double Xt[3] = {0, 0, 0};
+    if (p < pr.P) {
+        double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
+        double xo[3] = {0, 0, 0};
+        if (ok2) {
+            for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+                // (B_e is requested before the level byte and the keyframe's block index are known: its address depends on neither)
+                const double* Bg = pr.Hpl + (long long)e * 18;
+                double B[18];
+#pragma unroll
+                for (int i = 0; i < 18; i++) B[i] = Bg[i];
+                const uint8_t lv = pr.level[e];
+                const int ba = w.blk[pr.e_kf[e]];
+                if (lv != 0 || ba < 0) continue;
+                const double* xa = pr.xp + 6 * ba;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    double sv = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sv += B[i * 3 + j] * xa[i];
+                    cl[j] -= sv;
+                }
+            }
+            double D[9], Di[9];
+            const double* H = pr.Hll + (long long)p * 9;
+#pragma unroll
+            for (int i = 0; i < 9; i++) D[i] = H[i];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            inv3(D, Di);
+#pragma unroll
+            for (int i = 0; i < 3; i++) xo[i] = Di[i * 3] * cl[0] + Di[i * 3 + 1] * cl[1] + Di[i * 3 + 2] * cl[2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            Xt[i] = X[p * 3 + i] + xo[i];
+            Xn[p * 3 + i] = Xt[i];
+            sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);
+        }
+    }
+    __syncthreads();   // the trial poses are in LDS
+    if (p < pr.P) {
         // (an edge's inputs are loaded one round ahead and before its level byte is tested: the loop is a chain of dependent loads per edge otherwise)
         const int e1 = pr.pt_start[p + 1];
         int e = pr.pt_start[p];
@@ -1643,26 +1674,27 @@ __global__ __launch_bounds__(kWPt) void k_w_eval(const LbaProblem* probs, const 
         for (; e < e1; e++) {
             const uint8_t lv = lv_n; const int a = a_n; const float o0 = o0_n, o1 = o1_n, ur = o2_n, inf = inf_n;
             if (e + 1 < e1) { lv_n = pr.level[e + 1]; a_n = pr.e_kf[e + 1]; o0_n = pr.e_obs[e * 3 + 3]; o1_n = pr.e_obs[e * 3 + 4]; o2_n = pr.e_obs[e * 3 + 5]; inf_n = pr.e_info[e + 1]; }
-            const SE3 Ta = Tp[a];
+            const int ba = w.blk[a];
+            const SE3 Ta = ba >= 0 ? sTn[ba] : Tc[a];
             if (lv != 0) continue;
             const bool stereo = !(ur < 0);
             const double ob[3] = {(double)o0, (double)o1, (double)ur};
             double pc[3], er[3];
-            se3_map(Ta, Xw, pc);
+            se3_map(Ta, Xt, pc);
             const double c2 = edge_error(cam, pc, ob, stereo, (double)inf, er);
             pr.chi2[e] = c2;
             if (robust) { double r0, r1; huber(c2, stereo ? dStereo : dMono, r0, r1); F += r0; }
             else F += c2;
         }
     }
-    __shared__ double sF[kWPt / 64];
-    const double f = wsum(F);
-    if ((threadIdx.x & 63) == 0) sF[threadIdx.x >> 6] = f;
+    const double s1 = wsum(sc), f = wsum(F);
+    if ((threadIdx.x & 63) == 0) { sS[threadIdx.x >> 6] = s1; sF[threadIdx.x >> 6] = f; }
     __syncthreads();
-    if (threadIdx.x == 0 && !padding) {
-        double a = sF[0];
-        for (int i = 1; i < kWPt / 64; i++) a += sF[i];
-        w.partF[item_] = a;
+    if (threadIdx.x == 0) {
+        double a = sS[0], b = sF[0];
+        for (int i = 1; i < kWPt / 64; i++) { a += sS[i]; b += sF[i]; }
+        w.partS[item_] = a;
+        w.partF[item_] = b;
     }
 }
 
@@ -1677,6 +1709,12 @@ __device__ int g_lba_trace_cap = 0;
 
 __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     LbaCtrl* ct = w.ct;
+    if (ct->need_lin) {   // pair-gather path: w_ctrlA's step was left to k_w_edgeW (values) and to this commit (state); the tiles path ran k_w_ctrlA: need_lin is 0
+        ct->currentChi = ct->FA;
+        if (ct->iter == 0) { ct->lambda = ct->lambdaA; ct->ni = 2; }
+        ct->need_lin = 0;
+        ct->qmax = 0;
+    }
     double F1 = 0, sc = 0;
     for (int i = 0; i < w.nblk_pt; i++) { F1 += w.partF[i]; sc += w.partS[i]; }
     sc += w.partS[w.nblk_pt];
@@ -2541,8 +2579,8 @@ static int lba_launch(oslam_lba_t* h) {
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
                 hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, ny_xcd), dim3(kLinThreads), 0, st, d_probs, d_ws, n0);
-                hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n0), dim3(64), 0, st, d_probs, d_ws);
                 if (tiles) {
+                    hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n0), dim3(64), 0, st, d_probs, d_ws);   // (the pair-gather path folds this step into k_w_edgeW / k_w_ctrlB)
                     hipLaunchKernelGGL(k_w_schur_tiles, dim3(maxWg, n0), dim3(kWinThreads), tiles_lds, st, d_probs, d_ws);
                     hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
                 } else {
@@ -2555,8 +2593,7 @@ static int lba_launch(oslam_lba_t* h) {
                 if (chol_ldsm || chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                hipLaunchKernelGGL(k_w_eval, dim3(maxNbPt, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);   // (+ the trial's chi2: k_w_eval of rounds 1-3)
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
@@ -2567,7 +2604,7 @@ static int lba_launch(oslam_lba_t* h) {
             group = 4;
         }
         hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n0), dim3(256), 0, st, d_probs, d_ws);
-        launches += 3 + 8 * (long long)slots_done;
+        launches += 3 + (tiles ? 7 : 6) * (long long)slots_done;
     }
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());

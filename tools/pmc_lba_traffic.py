@@ -14,7 +14,7 @@ out = {}
 for k in sorted(f):
     fk = sum(f[k]) / len(f[k]); wk = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
     out[k] = {"launches": len(f[k]), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1), "bytes_per_launch": round((fk + wk) * 1024)}
-per_trial = ["k_w_lin", "k_w_ctrlA", "k_w_edgeW", "k_w_schur", "k_w_chol_lds_mfma", "k_w_chol_packed", "k_w_update", "k_w_eval", "k_w_ctrlB"]
+per_trial = ["k_w_lin", "k_w_ctrlA", "k_w_edgeW", "k_w_schur", "k_w_chol_lds_mfma", "k_w_chol_packed", "k_w_update", "k_w_ctrlB"]
 trial_bytes = sum(out[k]["bytes_per_launch"] for k in per_trial if k in out)
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/lba_win_prof.py MODES=1 NB=40: one call = 40 steady-state-shaped windows (27 keyframes, "
                    "1500 points, 13 075 edges each), multi-launch layout, pair gather with device-built lists; KB per launch, mean over the launches of the run.  FETCH_SIZE is "
