@@ -738,7 +738,7 @@ def roofline_of(k, summ, stereo):
             "camera solve (k_w_chol_lds_mfma at 133..186 unknowns) v_mfma_f64_16x16x4_f64",
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
             "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else _lba_traffic(), "launch_us": round(ms / launches * 1e3, 1),
-            "traffic_note": None if bound == "hbm" else "memory-side bytes per launch of the local-BA kernels (mean over the 8 launches of an LM trial) from the committed rocprofv3 "
+            "traffic_note": None if bound == "hbm" else "memory-side bytes per launch of the local-BA kernels (mean over the 6 launches of an LM trial) from the committed rocprofv3 "
             "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r04_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
             "calls of this run carry ~82 windows: scale by the windows per call",
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
