@@ -40,7 +40,9 @@ def _worker(rank, world, port, q, kind="rgbd"):
         summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=2, warmup=1, on_device=False, collect_poses=True)
     else:
         wl = seqbench.rgbd_workload(n_base=2, stagger=1)
-        summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=3, warmup=2, on_device=False, collect_poses=True)
+        from object_slam_amd import slam
+        summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 2, 2, steps=3, warmup=2, on_device=False, collect_poses=True,
+                                                      local_mapping=slam.LM_DEFERRED)   # bench.py's default schedule (the stereo test below runs the synchronous one)
     poses = np.array(extra["poses"])          # [handles, frames, 1, 4, 4]
     q.put((rank, summ, rec.tolist(), poses, extra["groups"]))
     if world > 1:
