@@ -130,6 +130,7 @@ struct Seq {
     int matchesInliers = 0;
     std::vector<int> localKFs, localMPs;
     std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
+    std::vector<int> baMark;              // mnBALocalForKF per map point id (dense, see the local-BA gather in run_local_mapping)
     // Local-map cache: mvpLocalMapPoints is a function of the ordered local keyframe list and of the map, and the map only changes when this sequence
     // creates a keyframe or its local mapping runs (mapVersion counts both).  A frame whose list and version equal the cached ones reuses the walk of
     // the keyframes' map points AND the packed SearchLocalPoints arrays (whose copy the operator table may keep resident: content id).
@@ -177,6 +178,7 @@ struct Seq {
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
+        std::fill(baMark.begin(), baMark.end(), 0);
         mapVersion++; locVersion = -1; locWalkFrame = -1; locKFs.clear();
         resetRequested = false;
     }
@@ -744,8 +746,14 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
             for (int k : local) {
                 if (k == 0) continue;
                 const KeyFrm& kf = m.kfs[k];
+                // The verdict is nRed > 0.9 * nMPs.  nMPs is at most the number of slots that hold a point at a usable depth (counted from the keyframe's own
+                // arrays, no map access), so once the points found NOT redundant reach a tenth of that bound (+ 2: away from the rounding of 0.9 * nMPs) the keyframe
+                // stays whatever the remaining slots hold, and the walk over their observation lists is skipped.  Most keyframes leave the loop this way.
+                int ub = 0;
+                for (int i = 0; i < kf.N; i++) ub += kf.mp[i] >= 0 && !(kf.depth[i] > c.thDepth || kf.depth[i] < 0);
+                const int keepAt = ub / 10 + 2;
                 int nRed = 0, nMPs = 0;
-                for (int i = 0; i < kf.N; i++) {
+                for (int i = 0; i < kf.N && nMPs - nRed < keepAt; i++) {
                     prefetch_okp_ahead(m.mps, kf.mp, i, kf.N);
                     const int p = kf.mp[i];
                     if (p < 0 || m.mps[p].bad) continue;
@@ -762,7 +770,7 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                         if (n >= 3) nRed++;
                     }
                 }
-                if (nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
+                if (nMPs - nRed < keepAt && nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
             }
         });
     if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
@@ -1287,31 +1295,55 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             const int cur = s.curKF;
             W.si = si;
             W.kfs.push_back(cur);
-            m.kfs[cur].baLocalForKF = cur;
-            for (int k : m.kfs[cur].ordered) {
-                m.kfs[k].baLocalForKF = cur;
+            for (int k : m.kfs[cur].ordered)
                 if (!m.kfs[k].bad) W.kfs.push_back(k);
-            }
             W.nLocal = (int)W.kfs.size();
+            // lLocalMapPoints (src/Optimizer.cc:470-487).  mnBALocalForKF of the points is a dense per-sequence array (as mpMark in update_local_map): the loop visits
+            // ~1000 slots per local keyframe and most of them hold a point that is already in the list, so it should touch 4 bytes per slot, not a MapPt record.
+            if (s.baMark.size() < m.mps.size()) s.baMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+            int* bam = s.baMark.data();
+            size_t edgeCap = 0;
             for (int q = 0; q < W.nLocal; q++) {
                 const std::vector<int>& kmp = m.kfs[W.kfs[q]].mp;
-                for (size_t i = 0; i < kmp.size(); i++) {
-                    prefetch_ahead(m.mps, kmp, i, kmp.size());
-                    const int p = kmp[i];
-                    if (p >= 0 && !m.mps[p].bad && m.mps[p].baLocalForKF != cur) { W.pts.push_back(p); m.mps[p].baLocalForKF = cur; }
+                const int* kp_ = kmp.data();
+                for (size_t i = 0, n = kmp.size(); i < n; i++) {
+                    if (i + kPF < n) { const int pq = kp_[i + kPF]; if (pq >= 0 && bam[pq] != cur) prefetch_mp(&m.mps[pq]); }
+                    const int p = kp_[i];
+                    if (p < 0 || bam[p] == cur) continue;
+                    bam[p] = cur;
+                    const MapPt& mp = m.mps[p];
+                    if (!mp.bad) { W.pts.push_back(p); edgeCap += mp.obs.size(); }
                 }
             }
-            for (size_t pi = 0; pi < W.pts.size(); pi++) {
-                if (pi + kPF / 2 < W.pts.size()) __builtin_prefetch(m.mps[W.pts[pi + kPF / 2]].obs.data());   // (the records were touched by the loop above)
-                const int p = W.pts[pi];
-                for (auto& e : m.mps[p].obs) {
-                    KeyFrm& k = m.kfs[e.first];
-                    if (k.baLocalForKF != cur && k.baFixedForKF != cur) {
-                        k.baFixedForKF = cur;
-                        if (!k.bad) W.kfs.push_back(e.first);   // every fixed keyframe enters the window (src/Optimizer.cc:489-504: no bound)
+            // Fixed keyframes (:489-504: every observer outside the local set, no bound) and the edges (:560-650) in ONE walk over the observation lists: a fixed
+            // keyframe takes the next window index the first time an observation names it, which is the order the reference's lFixedCameras list is built in.
+            std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
+            for (int q = 0; q < W.nLocal; q++) slot[W.kfs[q]] = q + 1;
+            W.points.resize(W.pts.size() * 3);
+            W.ekf.resize(edgeCap); W.ept.resize(edgeCap); W.eobs.resize(edgeCap * 3); W.einv.resize(edgeCap); W.eref.resize(edgeCap);
+            size_t ne = 0;
+            for (size_t j = 0; j < W.pts.size(); j++) {
+                prefetch_okp_ahead(m.mps, W.pts, j, W.pts.size());
+                const int p = W.pts[j];
+                const MapPt& mp = m.mps[p];
+                for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
+                for (size_t oi = 0; oi < mp.obs.size(); oi++) {
+                    const int kid = mp.obs[oi].first;
+                    int q = slot[kid];
+                    if (q == 0) {
+                        if (m.kfs[kid].bad) continue;
+                        W.kfs.push_back(kid);
+                        slot[kid] = q = (int)W.kfs.size();
                     }
+                    const ObsKp& kp = mp.okp[oi];   // mvKeysUn[idx].pt, mvuRight[idx], octave of the observing keypoint (cached beside the observation)
+                    W.ekf[ne] = q - 1; W.ept[ne] = (int)j;
+                    W.eobs[ne * 3] = kp.x; W.eobs[ne * 3 + 1] = kp.y; W.eobs[ne * 3 + 2] = kp.ur;
+                    W.einv[ne] = c.invSigma2[kp.octave];
+                    W.eref[ne] = std::make_pair(kid, p);
+                    ne++;
                 }
             }
+            W.ekf.resize(ne); W.ept.resize(ne); W.eobs.resize(ne * 3); W.einv.resize(ne); W.eref.resize(ne);
             // A window with more than 128 FREE keyframes (768 unknowns) is beyond the local-BA operator (OSLAM_E_CAPACITY).  The reference has no such bound.  The
             // window is kept, DEGRADED: m.kfs[cur].ordered is weight-descending, so the current keyframe and its strongest covisible keyframes stay free up to the
             // bound and the remaining local keyframes enter as fixed cameras (fixed = 1): their points and edges are still in the window, points and the strongest
@@ -1326,30 +1358,10 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (nFreeCap < W.nLocal) s.lbaWindowsDegraded++;
             }
             W.nFree = nFreeCap;
-            std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
-            for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = (int)q + 1;
             W.poses.resize(W.kfs.size() * 16); W.fixed.resize(W.kfs.size());
             for (size_t q = 0; q < W.kfs.size(); q++) {
                 memcpy(&W.poses[q * 16], m.kfs[W.kfs[q]].pose.Tcw.m, 64);
                 W.fixed[q] = (int)q >= nFreeCap ? 1 : (W.kfs[q] == 0 ? 2 : 0);
-            }
-            W.points.resize(W.pts.size() * 3);
-            for (size_t j = 0; j < W.pts.size(); j++) {
-                prefetch_okp_ahead(m.mps, W.pts, j, W.pts.size());
-                const MapPt& mp = m.mps[W.pts[j]];
-                for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
-                for (size_t oi = 0; oi < mp.obs.size(); oi++) {
-                    const std::pair<int, int>& e = mp.obs[oi];
-                    const KeyFrm& k = m.kfs[e.first];
-                    if (k.bad) continue;
-                    const int q = slot[e.first] - 1;
-                    if (q < 0) continue;
-                    const ObsKp& kp = mp.okp[oi];   // mvKeysUn[idx].pt, mvuRight[idx], octave of the observing keypoint (cached beside the observation)
-                    W.ekf.push_back(q); W.ept.push_back((int)j);
-                    W.eobs.push_back(kp.x); W.eobs.push_back(kp.y); W.eobs.push_back(kp.ur);
-                    W.einv.push_back(c.invSigma2[kp.octave]);
-                    W.eref.push_back(std::make_pair(e.first, W.pts[j]));
-                }
             }
             for (size_t q = 0; q < W.kfs.size(); q++) slot[W.kfs[q]] = 0;
             W.poses_out.resize(W.poses.size()); W.points_out.resize(W.points.size() + 3); W.erase.assign(W.ekf.size() + 1, 0);

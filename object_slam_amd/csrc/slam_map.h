@@ -126,7 +126,7 @@ struct MapPt {
     int replaced = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
     std::vector<ObsKp> okp;                      // okp[i] = the keypoint of obs[i]
-    int lastFrameSeen = 0, trackRefForFrame = 0, baLocalForKF = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    int lastFrameSeen = 0, trackRefForFrame = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
     // driver scratch of SearchInNeighbors: position of the point in the current keyframe's point list (valid while fuseListStamp == current keyframe id + 1)
     int fuseListIdx = 0, fuseListStamp = 0;
     // bookkeeping of the driver (not in the reference): obsVer counts the changes of the observation list; (updVer, updStep) = obsVer and the local-mapping
@@ -174,7 +174,7 @@ struct KeyFrm {
     int parent = -1;
     std::set<int> children;
     bool firstConnection = true, bad = false;
-    int trackRefForFrame = 0, fuseTargetForKF = 0, baLocalForKF = 0, baFixedForKF = 0;
+    int trackRefForFrame = 0, fuseTargetForKF = 0;
 };
 
 struct RelPose { M4 Tcr; int refKF; double stamp; bool lost; };

@@ -2,6 +2,7 @@
   on the GPU box : python tools/host_prof.py run [S=4096] [G=8] [steps=10]      -> gpurun_out/host_prof.samples
   afterwards     : python tools/host_prof.py report gpurun_out/host_prof.samples [top=60]"""
 import bisect, collections, ctypes, os, subprocess, sys
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")   # as bench.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -18,6 +19,7 @@ def run(S, G, steps, preroll=200):
     share = min(16, os.cpu_count() or 1)
     summ, rec, systems, _ = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), 0, 1, S, G, steps, warm, True, 0, host_threads=max(1, share // G),
                                               sequences=seqs, after_warmup=lambda systems: pcs.pcs_start(997), preroll=preroll,
+                                              local_mapping=slam.LM_SYNC if os.environ.get("HOST_PROF_SYNC") else slam.LM_DEFERRED,   # bench.py's default schedule
                                               progress=lambda m: print(m, flush=True))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     n = pcs.pcs_stop(os.path.join(ROOT, "gpurun_out", "host_prof.samples").encode())
