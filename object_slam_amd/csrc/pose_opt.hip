@@ -16,9 +16,10 @@
 namespace oslam {
 
 #ifndef OSLAM_POSE_THREADS
-#define OSLAM_POSE_THREADS 256
+#define OSLAM_POSE_THREADS 128
 #endif
-constexpr int kPoseThreads = OSLAM_POSE_THREADS;   // threads per frame (kernel experiments: -DOSLAM_POSE_THREADS=512)
+constexpr int kPoseThreads = OSLAM_POSE_THREADS;   // threads per frame.  Round 4: 128 (two wavefronts), four frames per CU — with the lean passes the card-filling rate is 0.72 us per frame
+                                                   // against 0.90 with 256 threads / two frames per CU and 0.78 with 64 / eight (tools/pose_prof.py, 4096 frames per launch)
 constexpr int kPoseWaves = kPoseThreads / 64;
 constexpr int kRedN = 29;   // 21 H (upper) + 6 b + chi + 1 spare
 
@@ -160,6 +161,88 @@ __device__ __forceinline__ void project_f32(const float* T, const float* P, floa
     }
 }
 
+// ---- per-edge arithmetic of the passes over the edges (round 4) -------------------------------------------------------------------------------------
+// The kernel is bound by fp64 instruction issue once the card is full (1.3 us per frame whether a frame has 64, 128 or 256 threads), so the passes are written
+// for instruction count: one reciprocal per edge by v_rcp_f64 + two Newton steps instead of IEEE divisions (~14 instructions each), the Huber square root and
+// its quotient from one v_rsq_f64 + two Newton steps, fused multiply-adds, and the normal equations accumulated over the NON-ZERO entries of the Jacobian rows
+// only (g2o's rows have J[4] = J[9] = J[16] = 0; the generic 3 x 6 x 6 triple product spent a third of its multiplications on exact zeros).  All of it is a few ulp
+// away from the divided / unfused form: far inside the 1e-4 bar the parity tests hold (the float `invz` of the fork's stereo projection is kept).
+__device__ __forceinline__ double rcp_nr(double z) {
+    double r = __builtin_amdgcn_rcp(z);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsq_nr(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    return r;
+}
+// camera-frame point, residual and chi2 of one edge; iz = 1 / z is returned for the Jacobian
+// (the pose as rotation matrix + translation, built once per pass: 9 fused multiply-adds per edge instead of the quaternion sandwich's ~24 instructions)
+struct PoseRt { double R[9], t[3]; };
+__device__ __forceinline__ PoseRt pose_rt(const SE3& P) { PoseRt o; se3_R(P, o.R); o.t[0] = P.t[0]; o.t[1] = P.t[1]; o.t[2] = P.t[2]; return o; }
+__device__ __forceinline__ double edge_residual_fast(const Cam& c, const PoseRt& P, const double X[3], const double ob[3], bool stereo, double info, double p[3], double e[3], double& iz) {
+#pragma clang fp contract(fast)
+#pragma unroll
+    for (int r = 0; r < 3; r++) p[r] = P.R[r * 3] * X[0] + P.R[r * 3 + 1] * X[1] + P.R[r * 3 + 2] * X[2] + P.t[r];
+    iz = rcp_nr(p[2]);
+    if (!stereo) {
+        e[0] = ob[0] - (p[0] * iz * c.fx + c.cx);
+        e[1] = ob[1] - (p[1] * iz * c.fy + c.cy);
+        e[2] = 0;
+        return info * (e[0] * e[0] + e[1] * e[1]);
+    }
+    const double izf = (double)(float)iz;   // the fork's `const float invz = 1.0f/trans_xyz[2];`
+    const double r0 = p[0] * izf * c.fx + c.cx;
+    const double r1 = p[1] * izf * c.fy + c.cy;
+    const double r2 = r0 - c.bf * izf;
+    e[0] = ob[0] - r0; e[1] = ob[1] - r1; e[2] = ob[2] - r2;
+    return info * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+}
+__device__ __forceinline__ void huber_fast(double e2, double delta, double& rho0, double& rho1) {
+#pragma clang fp contract(fast)
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
+    else {
+        const double rs = rsq_nr(e2), sq = e2 * rs;
+        rho0 = 2 * sq * delta - dsqr;
+        rho1 = delta * rs;
+    }
+}
+constexpr int h_idx(int a, int cc) { return a * 6 - a * (a - 1) / 2 + (cc - a); }   // position of H(a, cc), a <= cc, among the 21 accumulators
+// acc += (w info) Jr^T Jr and -= (w info) Jr^T e_r for Jacobian row R of one edge, over the row's non-zero columns
+template <int R>
+__device__ __forceinline__ void accumulate_row(const double (&Jr)[6], double er, double wi, double (&acc)[kRedN]) {
+#pragma clang fp contract(fast)
+    constexpr int zero = R == 1 ? 3 : 4;   // rows u and ur do not depend on v2 (column 4), row v not on v1 (column 3)
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        if (a == zero) continue;
+        const double wJ = wi * Jr[a];
+        acc[21 + a] -= wJ * er;
+#pragma unroll
+        for (int cc = a; cc < 6; cc++)
+            if (cc != zero) acc[h_idx(a, cc)] += wJ * Jr[cc];
+    }
+}
+// the OnlyPose Jacobian rows (se3_math.h jac_pose_onlypose) from iz = 1 / z, accumulated into the normal equations with weight wi = rho' * info
+__device__ __forceinline__ void accumulate_edge(const Cam& c, const double p[3], double iz, const double e[3], double wi, bool stereo, double (&acc)[kRedN]) {
+#pragma clang fp contract(fast)
+    const double x = p[0], y = p[1], iz2 = iz * iz, fxiz = c.fx * iz, fyiz = c.fy * iz, xiz2 = x * iz2, yiz2 = y * iz2;
+    const double Ju[6] = {x * yiz2 * c.fx, -(1 + x * xiz2) * c.fx, y * fxiz, -fxiz, 0, xiz2 * c.fx};
+    const double Jv[6] = {(1 + y * yiz2) * c.fy, -x * yiz2 * c.fy, -x * fyiz, 0, -fyiz, yiz2 * c.fy};
+    accumulate_row<0>(Ju, e[0], wi, acc);
+    accumulate_row<1>(Jv, e[1], wi, acc);
+    if (stereo) {
+        const double tb = c.bf * iz2;
+        const double Jr[6] = {Ju[0] - tb * y, Ju[1] + tb * x, Ju[2], Ju[3], 0, Ju[5] - tb};
+        accumulate_row<2>(Jr, e[2], wi, acc);
+    }
+}
+
 #ifdef OSLAM_POSE_PROFILE
 __device__ unsigned long long g_pose_prof[8];   // cycles of frame 0 per phase: build, sum28, solve+exp, eval, sum1, classify, prologue, total
 #define PSTAMP(i) do { if (b == 0 && tid == 0) { const long long t_ = clock64(); pacc[i] += (unsigned long long)(t_ - tp_); tp_ = t_; } } while (0)
@@ -174,7 +257,7 @@ __device__ unsigned long long g_pose_prof[8];   // cycles of frame 0 per phase: 
 // TWO frames fit into a CU's LDS beside their staged edges (the kernel's 214-235 registers allow two wavefronts per SIMD; one workgroup per CU left every
 // SIMD with a single wavefront of dependent fp64 chains).
 constexpr int kSumN = 28, kSumCols = kPoseThreads / 2, kSumPitch = kSumCols + 8;   // pitch = 8 mod 32 doubles: the value rows of a wavefront's reads fall on different banks
-constexpr int kSumLanes = kSumN * 8 <= kPoseThreads ? 8 : 4;   // summing threads per value
+constexpr int kSumLanes = kSumN * 8 <= kPoseThreads ? 8 : (kSumN * 4 <= kPoseThreads ? 4 : 2);   // summing threads per value
 static_assert(kSumN * kSumLanes <= kPoseThreads && kSumCols % kSumLanes == 0, "block_sum_wide: summing threads per value");
 __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_part /* [kSumN][kSumPitch] */, double* s_tot /* [kSumN] */) {
     const int tid = threadIdx.x;
@@ -200,8 +283,13 @@ __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_par
 
 // STAGE: the edge data (Xw, obs, invSigma2: 28 B per edge) are copied into LDS once; every pass of the ~100 over the edges then reads them at LDS
 // latency instead of paying a global-memory round trip per edge (one wavefront per SIMD: nothing else hides it).
+#ifdef OSLAM_POSE_WAVES_PER_EU
+#define POSE_OCC __attribute__((amdgpu_waves_per_eu(OSLAM_POSE_WAVES_PER_EU, OSLAM_POSE_WAVES_PER_EU)))
+#else
+#define POSE_OCC
+#endif
 template <bool SEM, bool STAGE>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
+__global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx c) {
     const int b = blockIdx.x, tid = threadIdx.x;
 #ifdef OSLAM_POSE_PROFILE
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -220,6 +308,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     double* s_chi2 = (double*)smem;                         // [stride] _error chi2 as last computed (may be stale)
     float* s_edge = (float*)(s_chi2 + c.stride);            // STAGE: [stride][3] Xw, [stride][3] obs, [stride] invSigma2
     uint8_t* s_level = (uint8_t*)(s_edge + (STAGE ? 7 * c.stride : 0));   // [stride] 0 active, 1 excluded, 255 no edge
+    uint16_t* s_act = (uint16_t*)(s_level + ((c.stride + 1) & ~1));         // [stride] the active edges of the current round, ascending (compact_active)
     const float* Xw = STAGE ? s_edge : gXw;
     const float* obsp = STAGE ? s_edge + 3 * c.stride : gobs;
     const float* inv = STAGE ? s_edge + 6 * c.stride : ginv;
@@ -230,8 +319,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     __shared__ double s_red[2 * kPoseWaves * kRedN];
     __shared__ double s_part[kSumN * kSumPitch], s_tot[kSumN];   // block_sum_wide (59 KB)
     constexpr int kCandN = 14;                                   // candidate pose (q, t), step x, solve ok
-    __shared__ double s_cand[kPoseWaves * kCandN];
-    const int wv = tid >> 6;
+    constexpr int kMaxTrials = 10;                               // g2o's maxTrialsAfterFailure
+    __shared__ double s_cand[kMaxTrials * kCandN];
+    constexpr int kMaxChunks = (11000 + 63) / 64;                // 64-edge chunks of the largest frame oslam_poseopt_create accepts
+    __shared__ int s_coff[kMaxChunks + 1];
+    const int wv = tid >> 6, lane = tid & 63;
     __shared__ int s_cnt[2];
     int phase = 0;
 
@@ -257,6 +349,41 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         if (tid == 0) { c.n_inliers[b] = 0; if (c.stats) { c.stats[b * 2] = 0; c.stats[b * 2 + 1] = 0; } if (SEM) c.sem.nSem[b] = 0; }
         return;
     }
+
+    // The passes of a round visit the ACTIVE edges only (level 0: 40-70 % of a frame's keypoint slots hold a map point, fewer after the outlier rounds), so they
+    // run over a compacted index list instead of masking idle lanes: chunk ballots, a scan of the chunk counts by wavefront 0, ordered scatter.  The list is
+    // ascending, so every thread's share — and with it the summation order — is a function of the levels alone.  Callers: s_level complete and visible.
+    auto compact_active = [&]() -> int {
+        const int nch = (N + 63) >> 6;
+        for (int ch = wv; ch < nch; ch += kPoseWaves) {
+            const int i = ch * 64 + lane;
+            const unsigned long long m = __ballot(i < N && s_level[i] == 0);
+            if (lane == 0) s_coff[ch] = __popcll(m);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            int carry = 0;
+            for (int base = 0; base < nch; base += 64) {
+                const int v = base + lane < nch ? s_coff[base + lane] : 0;
+                int incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                if (base + lane < nch) s_coff[base + lane] = carry + incl - v;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (lane == 0) s_coff[nch] = carry;
+        }
+        __syncthreads();
+        for (int ch = wv; ch < nch; ch += kPoseWaves) {
+            const int i = ch * 64 + lane;
+            const bool a = i < N && s_level[i] == 0;
+            const unsigned long long m = __ballot(a);
+            if (a) s_act[s_coff[ch] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        }
+        __syncthreads();
+        return s_coff[nch];
+    };
+    int nAct = 0;
 
     const SE3 T0 = se3_from_T(T0f);
     SE3 T = T0;
@@ -307,21 +434,21 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
     const double infoSem = (double)sm.invSigma2_0;
 
     // residual pass over the active edges at pose P: stores chi2 per edge, returns sum of robust chi2
-    auto eval = [&](const SE3& P, bool robust) -> double {
+    auto eval = [&](const SE3& Pq, bool robust) -> double {
         double F = 0;
-        for (int i = tid; i < N; i += kPoseThreads) {
-            if (s_level[i] != 0) continue;
+        const PoseRt P = pose_rt(Pq);
+        for (int j = tid; j < nAct; j += kPoseThreads) {
+            const int i = s_act[j];
             const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
             const float ur = obsp[i * 3 + 2];
             const bool stereo = !(ur < 0);
             const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
-            double p[3], e[3];
-            se3_map(P, X, p);
-            const double c2 = edge_error(cam, p, ob, stereo, (double)inv[i], e);
+            double p[3], e[3], iz;
+            const double c2 = edge_residual_fast(cam, P, X, ob, stereo, (double)inv[i], p, e, iz);
             s_chi2[i] = c2;
             if (robust) {
                 double r0, r1;
-                huber(c2, stereo ? deltaStereo : deltaMono, r0, r1);
+                huber_fast(c2, stereo ? deltaStereo : deltaMono, r0, r1);
                 F += r0;
             } else
                 F += c2;
@@ -331,12 +458,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 if (sm.e_level[i] != 0) continue;
                 const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
                 const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
-                double p[3], e[3];
-                se3_map(P, X, p);
-                const double c2 = edge_error(cam, p, ob, false, infoSem, e);
-                sm.e_chi2[i] = c2;
+                double p[3], e[3], iz;
+                const double c2 = edge_residual_fast(cam, P, X, ob, false, infoSem, p, e, iz);
                 double r0, r1;
-                huber(c2, deltaMono, r0, r1);
+                huber_fast(c2, deltaMono, r0, r1);
                 F += r0;
             }
         }
@@ -348,13 +473,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
         const bool robust = it < 3;   // setRobustKernel(0) after round index 2 (:407,:436)
         T = T0;                       // every round restarts from the input pose (:377)
         // initializeOptimization(0): any active edge?
-        int nact = 0;
-        for (int i = tid; i < N; i += kPoseThreads) nact += (s_level[i] == 0);
-        if (SEM) for (int i = tid; i < nsem; i += kPoseThreads) nact += (sm.e_level[i] == 0);
-        {
-            double v[1] = {(double)nact};
+        nAct = compact_active();   // (s_level: written before the barrier that ended the previous round / the prologue)
+        int nact = nAct;
+        if (SEM) {
+            int ns = 0;
+            for (int i = tid; i < nsem; i += kPoseThreads) ns += (sm.e_level[i] == 0);
+            double v[1] = {(double)ns};
             block_sum<1>(v, s_red, phase);
-            nact = (int)v[0];
+            nact += (int)v[0];
         }
         if (nact > 0) {
             double lambda = 0, ni = 2;
@@ -363,64 +489,33 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 double acc[kRedN];
 #pragma unroll
                 for (int k = 0; k < kRedN; k++) acc[k] = 0;
-                for (int i = tid; i < N; i += kPoseThreads) {
-                    if (s_level[i] != 0) continue;
+                const PoseRt Trt = pose_rt(T);
+                for (int j = tid; j < nAct; j += kPoseThreads) {
+                    const int i = s_act[j];
                     const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
                     const float ur = obsp[i * 3 + 2];
                     const bool stereo = !(ur < 0);
                     const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
                     const double info = (double)inv[i];
-                    double p[3], e[3], J[18];
-                    se3_map(T, X, p);
-                    const double c2 = edge_error(cam, p, ob, stereo, info, e);
+                    double p[3], e[3], iz;
+                    const double c2 = edge_residual_fast(cam, Trt, X, ob, stereo, info, p, e, iz);
                     s_chi2[i] = c2;
                     double r0 = c2, w = 1.0;
-                    if (robust) huber(c2, stereo ? deltaStereo : deltaMono, r0, w);
+                    if (robust) huber_fast(c2, stereo ? deltaStereo : deltaMono, r0, w);
                     acc[27] += r0;
-                    jac_pose_onlypose(cam, p, stereo, J);
-                    const double wi = w * info;
-                    // mono edges carry a zero third row (J, e): the 3-row loops add exact zeros
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        double sb = 0;
-                        _Pragma("unroll") for (int d = 0; d < 3; d++) sb += J[d * 6 + a] * (info * e[d]);
-                        acc[21 + a] -= w * sb;
-#pragma unroll
-                        for (int cc = a; cc < 6; cc++) {
-                            double sh = 0;
-                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
-                            acc[k++] += sh;
-                        }
-                    }
+                    accumulate_edge(cam, p, iz, e, w * info, stereo, acc);
                 }
                 if (SEM) {
                     for (int i = tid; i < nsem; i += kPoseThreads) {
                         if (sm.e_level[i] != 0) continue;
                         const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
                         const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
-                        double p[3], e[3], J[18];
-                        se3_map(T, X, p);
-                        const double c2 = edge_error(cam, p, ob, false, infoSem, e);
-                        sm.e_chi2[i] = c2;
+                        double p[3], e[3], iz;
+                        const double c2 = edge_residual_fast(cam, Trt, X, ob, false, infoSem, p, e, iz);
                         double r0, w;
-                        huber(c2, deltaMono, r0, w);
+                        huber_fast(c2, deltaMono, r0, w);
                         acc[27] += r0;
-                        jac_pose_onlypose(cam, p, false, J);
-                        const double wi = w * infoSem;
-                        int k = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; a++) {
-                            double sb = 0;
-                            _Pragma("unroll") for (int d = 0; d < 2; d++) sb += J[d * 6 + a] * (infoSem * e[d]);
-                            acc[21 + a] -= w * sb;
-#pragma unroll
-                            for (int cc = a; cc < 6; cc++) {
-                                double sh = 0;
-                                _Pragma("unroll") for (int d = 0; d < 2; d++) sh += J[d * 6 + a] * wi * J[d * 6 + cc];
-                                acc[k++] += sh;
-                            }
-                        }
+                        accumulate_edge(cam, p, iz, e, w * infoSem, false, acc);
                     }
                 }
                 PSTAMP(0);
@@ -443,24 +538,30 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                 double rho = 0;
                 int qmax = 0;
                 do {
-                    // A rejected trial multiplies lambda by ni and doubles ni, so the damping of the next trials is known in advance: wavefront w
-                    // solves for trial qmax + w (the 6x6 Cholesky and the exponential map are ~5 k cycles of dependent fp64 divisions,
-                    // square roots, sin / cos), the candidates wait in LDS and are evaluated one after the other exactly as before.
-                    if ((qmax % kPoseWaves) == 0) {
-                        double lw = lambda, nw = ni;
-                        for (int k = 0; k < wv; k++) { lw *= nw; nw *= 2; }
-                        double A[36], xw[6];
-                        for (int k = 0; k < 36; k++) A[k] = H[k];
-                        for (int a = 0; a < 6; a++) { A[a * 7] += lw; xw[a] = g[a]; }
-                        const bool okw = solve6(A, xw);
-                        if (!okw) for (int a = 0; a < 6; a++) xw[a] = 0;
-                        const SE3 Tw = se3_mul(se3_exp(xw), T);
-                        if ((tid & 63) == 0) {
-                            double* cd = s_cand + wv * kCandN;
-                            for (int k = 0; k < 4; k++) cd[k] = Tw.q[k];
-                            for (int k = 0; k < 3; k++) cd[4 + k] = Tw.t[k];
-                            for (int k = 0; k < 6; k++) cd[7 + k] = xw[k];
-                            cd[13] = okw ? 1.0 : 0.0;
+                    // A rejected trial multiplies lambda by ni and doubles ni, so the damping of every trial this iteration can make (at most 10) is known in
+                    // advance: LANE l of ONE wavefront solves for trial l (the 6x6 Cholesky and the exponential map are ~5 k cycles of dependent fp64 divisions,
+                    // square roots, sin / cos — the same instruction stream whatever the damping, so ten candidates cost what one does), the candidates wait in LDS and are
+                    // evaluated one after the other exactly as before.  (Rounds 1-3 had wavefront w solve for trial q + w: four instruction streams per group of
+                    // four trials, three of them wasted whenever the first trial was accepted — which is the usual case — and the kernel is bound by issue.)
+                    if (qmax == 0) {
+                        if (wv == (tot_its % kPoseWaves)) {   // the wavefronts take the solves in turns: each SIMD of the CU hosts one of them, and the chain is issue-bound
+                            const int tl = min(lane, kMaxTrials - 1);
+                            double lw = lambda, nw = ni;
+                            for (int k = 0; k < kMaxTrials - 1; k++)
+                                if (k < tl) { lw *= nw; nw *= 2; }
+                            double A[36], xw[6];
+                            for (int k = 0; k < 36; k++) A[k] = H[k];
+                            for (int a = 0; a < 6; a++) { A[a * 7] += lw; xw[a] = g[a]; }
+                            const bool okw = solve6(A, xw);
+                            if (!okw) for (int a = 0; a < 6; a++) xw[a] = 0;
+                            const SE3 Tw = se3_mul(se3_exp(xw), T);
+                            if (lane < kMaxTrials) {
+                                double* cd = s_cand + lane * kCandN;
+                                for (int k = 0; k < 4; k++) cd[k] = Tw.q[k];
+                                for (int k = 0; k < 3; k++) cd[4 + k] = Tw.t[k];
+                                for (int k = 0; k < 6; k++) cd[7 + k] = xw[k];
+                                cd[13] = okw ? 1.0 : 0.0;
+                            }
                         }
                         __syncthreads();
                     }
@@ -468,7 +569,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_optimize(PoseCtx c) {
                     SE3 Tn;
                     bool ok2;
                     {
-                        const double* cd = s_cand + (qmax % kPoseWaves) * kCandN;
+                        const double* cd = s_cand + qmax * kCandN;
                         for (int k = 0; k < 4; k++) Tn.q[k] = cd[k];
                         for (int k = 0; k < 3; k++) Tn.t[k] = cd[4 + k];
                         for (int k = 0; k < 6; k++) x[k] = cd[7 + k];
@@ -814,12 +915,13 @@ __global__ __launch_bounds__(256) void k_mask_fill_bits(const unsigned long long
 
 using namespace oslam;
 
-// dynamic LDS of k_pose_optimize: chi2 (8 B) + level (1 B) per edge slot, + the staged edge data (28 B) when STAGE
-static size_t pose_lds_bytes(size_t stride, bool stage) { return stride * (stage ? 37 : 9) + 64; }
+// dynamic LDS of k_pose_optimize: chi2 (8 B) + level (1 B) + active-list entry (2 B) per edge slot, + the staged edge data (28 B) when STAGE
+static size_t pose_lds_bytes(size_t stride, bool stage) { return stride * (stage ? 39 : 11) + 64; }
 #ifndef OSLAM_POSE_LDS_BUDGET
-#define OSLAM_POSE_LDS_BUDGET (48 * 1024)
+#define OSLAM_POSE_LDS_BUDGET (22 * 1024)
 #endif
-constexpr size_t kPoseLdsBudget = OSLAM_POSE_LDS_BUDGET;   // two workgroups per CU: 80 KB each minus the kernel's static arrays (30 KB of them block_sum_wide's)
+constexpr size_t kPoseLdsBudget = OSLAM_POSE_LDS_BUDGET;   // FOUR workgroups of 128 threads per CU (what the kernel's ~230 registers allow): 40 KB each minus the kernel's static arrays (18 KB, 16 of them block_sum_wide's).
+// Staging therefore only happens for frames of <= 570 edge slots; larger frames read their edges through the L2 in every pass, which measured faster than two staged frames per CU (0.85 against 1.37 ms per 1024 frames).
 
 struct oslam_poseopt {
     int device = 0, max_batch = 0, max_points = 0;
