@@ -250,7 +250,7 @@ __device__ unsigned long long g_pose_prof[8];   // cycles of frame 0 per phase: 
 #define PSTAMP(i) do { } while (0)
 #endif
 
-// Block-wide sums of the 28 accumulators of the build pass (21 H + 6 b + chi2), every thread returns the same totals (fixed order).
+// Block-wide sums of the 28 accumulators of the build pass (21 H + 6 b + chi2) into s_tot (fixed order).
 // Transposed through LDS: every thread parks its 28 partials, 8 threads per value add 32 partials each and combine with three
 // shuffle steps -- 28 writes + 32 reads per thread instead of the 168 double-precision shuffle steps of 28 wavefront butterflies.
 // Neighbouring lanes are added first (one DPP step per value), so only every second thread parks a partial: the buffer is 30 KB instead of 59 KB and
@@ -276,18 +276,16 @@ __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_par
         for (int d = 1; d < kSumLanes; d <<= 1) s += __shfl_xor(s, d, 64);
         if ((tid % kSumLanes) == 0) s_tot[tid / kSumLanes] = s;
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kSumN; i++) v[i] = s_tot[i];
+    __syncthreads();   // the totals are in s_tot: the callers read what they need (H is only needed by the wavefront that solves)
 }
 
 // STAGE: the edge data (Xw, obs, invSigma2: 28 B per edge) are copied into LDS once; every pass of the ~100 over the edges then reads them at LDS
 // latency instead of paying a global-memory round trip per edge (one wavefront per SIMD: nothing else hides it).
-#ifdef OSLAM_POSE_WAVES_PER_EU
-#define POSE_OCC __attribute__((amdgpu_waves_per_eu(OSLAM_POSE_WAVES_PER_EU, OSLAM_POSE_WAVES_PER_EU)))
-#else
-#define POSE_OCC
+// two wavefronts per SIMD (at most 256 registers): left to itself the compiler takes a 257th for the semantic variant, which halves the frames per CU
+#ifndef OSLAM_POSE_WAVES_PER_EU
+#define OSLAM_POSE_WAVES_PER_EU 2
 #endif
+#define POSE_OCC __attribute__((amdgpu_waves_per_eu(OSLAM_POSE_WAVES_PER_EU, OSLAM_POSE_WAVES_PER_EU)))
 template <bool SEM, bool STAGE>
 __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx c) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -320,7 +318,12 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
     __shared__ double s_part[kSumN * kSumPitch], s_tot[kSumN];   // block_sum_wide (59 KB)
     constexpr int kCandN = 14;                                   // candidate pose (q, t), step x, solve ok
     constexpr int kMaxTrials = 10;                               // g2o's maxTrialsAfterFailure
-    __shared__ double s_cand[kMaxTrials * kCandN];
+    // Poses live in LDS, not in registers (they are wave-uniform and read a few times per iteration; the kernel sits at the 256-register limit of two wavefronts
+    // per SIMD): the candidates of an iteration in s_cand[iteration parity], the input pose in s_T0, and `Tp` points at the current estimate — the input pose at
+    // a round's start, then the accepted candidate (an iteration without an accepted trial ends the round, so the slot Tp points into is never the one the next
+    // iteration's candidates are written to).
+    __shared__ double s_cand[2 * kMaxTrials * kCandN];
+    __shared__ double s_T0[8];
     constexpr int kMaxChunks = (11000 + 63) / 64;                // 64-edge chunks of the largest frame oslam_poseopt_create accepts
     __shared__ int s_coff[kMaxChunks + 1];
     const int wv = tid >> 6, lane = tid & 63;
@@ -350,43 +353,57 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
         return;
     }
 
-    // The passes of a round visit the ACTIVE edges only (level 0: 40-70 % of a frame's keypoint slots hold a map point, fewer after the outlier rounds), so they
-    // run over a compacted index list instead of masking idle lanes: chunk ballots, a scan of the chunk counts by wavefront 0, ordered scatter.  The list is
-    // ascending, so every thread's share — and with it the summation order — is a function of the levels alone.  Callers: s_level complete and visible.
-    auto compact_active = [&]() -> int {
-        const int nch = (N + 63) >> 6;
-        for (int ch = wv; ch < nch; ch += kPoseWaves) {
-            const int i = ch * 64 + lane;
-            const unsigned long long m = __ballot(i < N && s_level[i] == 0);
-            if (lane == 0) s_coff[ch] = __popcll(m);
-        }
-        __syncthreads();
-        if (wv == 0) {
-            int carry = 0;
-            for (int base = 0; base < nch; base += 64) {
-                const int v = base + lane < nch ? s_coff[base + lane] : 0;
-                int incl = v;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-                if (base + lane < nch) s_coff[base + lane] = carry + incl - v;
-                carry += __shfl(incl, 63, 64);
+    // Ordered compaction, the one pattern behind every list this kernel builds: emit(i, base + rank of i among the flagged indices below n), in index order, returns
+    // base + their number to every thread.  Chunk ballots, a scan of the chunk counts by wavefront 0, ordered scatter; ends with a barrier (the emitted data and
+    // s_coff are then free to use).  flag(i) is evaluated twice and must not change in between.
+    auto ordered_scatter = [&](int n, int base, auto flag, auto emit) -> int {
+        for (int i0 = 0; i0 < n; i0 += kMaxChunks * 64) {
+            const int nn = min(n - i0, kMaxChunks * 64), nch = (nn + 63) >> 6;
+            for (int ch = wv; ch < nch; ch += kPoseWaves) {
+                const int i = i0 + ch * 64 + lane;
+                const unsigned long long m = __ballot(i < i0 + nn && flag(i));
+                if (lane == 0) s_coff[ch] = __popcll(m);
             }
-            if (lane == 0) s_coff[nch] = carry;
+            __syncthreads();
+            if (wv == 0) {
+                int carry = 0;
+                for (int cb = 0; cb < nch; cb += 64) {
+                    const int v = cb + lane < nch ? s_coff[cb + lane] : 0;
+                    int incl = v;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+                    if (cb + lane < nch) s_coff[cb + lane] = carry + incl - v;
+                    carry += __shfl(incl, 63, 64);
+                }
+                if (lane == 0) s_coff[nch] = carry;
+            }
+            __syncthreads();
+            for (int ch = wv; ch < nch; ch += kPoseWaves) {
+                const int i = i0 + ch * 64 + lane;
+                const bool a = i < i0 + nn && flag(i);
+                const unsigned long long m = __ballot(a);
+                if (a) emit(i, base + s_coff[ch] + __popcll(m & ((1ull << lane) - 1ull)));
+            }
+            base += s_coff[nch];
+            __syncthreads();
         }
-        __syncthreads();
-        for (int ch = wv; ch < nch; ch += kPoseWaves) {
-            const int i = ch * 64 + lane;
-            const bool a = i < N && s_level[i] == 0;
-            const unsigned long long m = __ballot(a);
-            if (a) s_act[s_coff[ch] + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
-        }
-        __syncthreads();
-        return s_coff[nch];
+        return base;
+    };
+    // The passes of a round visit the ACTIVE edges only (level 0: 40-70 % of a frame's keypoint slots hold a map point, fewer after the outlier rounds), so they
+    // run over a compacted index list instead of masking idle lanes.  The list is ascending, so every thread's share — and with it the summation order — is a
+    // function of the levels alone.  Callers: s_level complete and visible.
+    auto compact_active = [&]() -> int {
+        return ordered_scatter(N, 0, [&](int i) { return s_level[i] == 0; }, [&](int i, int pos) { s_act[pos] = (uint16_t)i; });
     };
     int nAct = 0;
 
-    const SE3 T0 = se3_from_T(T0f);
-    SE3 T = T0;
+    if (tid == 0) {
+        const SE3 T0 = se3_from_T(T0f);
+        for (int k = 0; k < 4; k++) s_T0[k] = T0.q[k];
+        for (int k = 0; k < 3; k++) s_T0[4 + k] = T0.t[k];
+    }
+    const double* Tp = s_T0;   // (visible to the other threads after the barriers of the first compact_active)
+    auto load_pose = [&](const double* q) -> SE3 { SE3 o; for (int k = 0; k < 4; k++) o.q[k] = q[k]; for (int k = 0; k < 3; k++) o.t[k] = q[4 + k]; return o; };
     int nBad = 0, tot_its = 0, tot_trials = 0;
 
     // ---- semantic edges (PoseOptimization2) ----
@@ -414,37 +431,62 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
             sm.e_tmp[j] = ok;
         }
         __syncthreads();
-        if (tid == 0) {   // ordered compaction (creation order of the reference)
-            int n = 0;
-            for (int j = 0; j < sm.nJoint; j++) {
-                const int ok = sm.e_tmp[j];
-                if (!ok) continue;
-                const int kp = sm.joint_kp[j];
-                const int px = ok - 1;
-                sm.e_Xw[n * 3] = Xw[kp * 3]; sm.e_Xw[n * 3 + 1] = Xw[kp * 3 + 1]; sm.e_Xw[n * 3 + 2] = Xw[kp * 3 + 2];
-                sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
-                sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.joint_obj[j]; sm.e_out[n] = 0;
-                n++;
-            }
-            s_ninit = n; s_nsem = n; s_semnum = n;
-        }
+        // ordered compaction (creation order of the reference)
+        const int nj = ordered_scatter(sm.nJoint, 0, [&](int j) { return sm.e_tmp[j] != 0; }, [&](int j, int n) {
+            const int kp = sm.joint_kp[j];
+            const int px = sm.e_tmp[j] - 1;
+            sm.e_Xw[n * 3] = Xw[kp * 3]; sm.e_Xw[n * 3 + 1] = Xw[kp * 3 + 1]; sm.e_Xw[n * 3 + 2] = Xw[kp * 3 + 2];
+            sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
+            sm.e_level[n] = 0; sm.e_obj[n] = sm.joint_obj[j]; sm.e_out[n] = 0;
+        });
+        if (tid == 0) { s_ninit = nj; s_nsem = nj; s_semnum = nj; }
         __syncthreads();
         nsem = s_nsem; ninit = s_ninit;
     }
     const double infoSem = (double)sm.invSigma2_0;
 
     // residual pass over the active edges at pose P: stores chi2 per edge, returns sum of robust chi2
+    // Edge inputs of the passes.  Without staging they come through the L2 (and the semantic edges always do), and two wavefronts per SIMD do not hide that
+    // latency behind ~60-130 instructions of arithmetic per edge: every pass requests the inputs of its NEXT edge before it works on the current one.
+    struct EdgeIn { float x0, x1, x2, o0, o1, o2, iv; };
+    auto load_edge = [&](int i) -> EdgeIn { return EdgeIn{Xw[i * 3], Xw[i * 3 + 1], Xw[i * 3 + 2], obsp[i * 3], obsp[i * 3 + 1], obsp[i * 3 + 2], inv[i]}; };
+    struct SemIn { float x0, x1, x2, o0, o1; int lv; };
+    auto load_sem = [&](int i) -> SemIn { return SemIn{sm.e_Xw[i * 3], sm.e_Xw[i * 3 + 1], sm.e_Xw[i * 3 + 2], sm.e_obs[i * 2], sm.e_obs[i * 2 + 1], (int)sm.e_level[i]}; };
+    // for_edges(f): f(i, in) for the active edges of this thread; for_sem(f): f(i, in) for its active semantic edges
+    auto for_edges = [&](auto f) {
+        int j = tid, ic = 0;
+        EdgeIn cur = {};
+        if (j < nAct) { ic = s_act[j]; cur = load_edge(ic); }
+        while (j < nAct) {
+            const int jn = j + kPoseThreads;
+            int in_ = 0;
+            EdgeIn nxt = cur;
+            if (jn < nAct) { in_ = s_act[jn]; nxt = load_edge(in_); }
+            f(ic, cur);
+            cur = nxt; ic = in_; j = jn;
+        }
+    };
+    auto for_sem = [&](auto f) {
+        int i = tid;
+        SemIn cur = {};
+        if (i < nsem) cur = load_sem(i);
+        while (i < nsem) {
+            const int in_ = i + kPoseThreads;
+            SemIn nxt = cur;
+            if (in_ < nsem) nxt = load_sem(in_);
+            if (cur.lv == 0) f(i, cur);
+            cur = nxt; i = in_;
+        }
+    };
     auto eval = [&](const SE3& Pq, bool robust) -> double {
         double F = 0;
         const PoseRt P = pose_rt(Pq);
-        for (int j = tid; j < nAct; j += kPoseThreads) {
-            const int i = s_act[j];
-            const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
-            const float ur = obsp[i * 3 + 2];
-            const bool stereo = !(ur < 0);
-            const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
+        for_edges([&](int i, const EdgeIn& in) {
+            const double X[3] = {(double)in.x0, (double)in.x1, (double)in.x2};
+            const bool stereo = !(in.o2 < 0);
+            const double ob[3] = {(double)in.o0, (double)in.o1, (double)in.o2};
             double p[3], e[3], iz;
-            const double c2 = edge_residual_fast(cam, P, X, ob, stereo, (double)inv[i], p, e, iz);
+            const double c2 = edge_residual_fast(cam, P, X, ob, stereo, (double)in.iv, p, e, iz);
             s_chi2[i] = c2;
             if (robust) {
                 double r0, r1;
@@ -452,18 +494,17 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                 F += r0;
             } else
                 F += c2;
-        }
+        });
         if (SEM) {   // semantic edges keep their Huber kernel in every round
-            for (int i = tid; i < nsem; i += kPoseThreads) {
-                if (sm.e_level[i] != 0) continue;
-                const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
-                const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
+            for_sem([&](int, const SemIn& in) {
+                const double X[3] = {(double)in.x0, (double)in.x1, (double)in.x2};
+                const double ob[3] = {(double)in.o0, (double)in.o1, 0.0};
                 double p[3], e[3], iz;
                 const double c2 = edge_residual_fast(cam, P, X, ob, false, infoSem, p, e, iz);
                 double r0, r1;
                 huber_fast(c2, deltaMono, r0, r1);
                 F += r0;
-            }
+            });
         }
         return F;
     };
@@ -471,7 +512,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
     PSTAMP(6);
     for (int it = 0; it < 4; it++) {
         const bool robust = it < 3;   // setRobustKernel(0) after round index 2 (:407,:436)
-        T = T0;                       // every round restarts from the input pose (:377)
+        Tp = s_T0;                    // every round restarts from the input pose (:377)
         // initializeOptimization(0): any active edge?
         nAct = compact_active();   // (s_level: written before the barrier that ended the previous round / the prologue)
         int nact = nAct;
@@ -489,14 +530,12 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                 double acc[kRedN];
 #pragma unroll
                 for (int k = 0; k < kRedN; k++) acc[k] = 0;
-                const PoseRt Trt = pose_rt(T);
-                for (int j = tid; j < nAct; j += kPoseThreads) {
-                    const int i = s_act[j];
-                    const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
-                    const float ur = obsp[i * 3 + 2];
-                    const bool stereo = !(ur < 0);
-                    const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
-                    const double info = (double)inv[i];
+                const PoseRt Trt = pose_rt(load_pose(Tp));
+                for_edges([&](int i, const EdgeIn& in) {
+                    const double X[3] = {(double)in.x0, (double)in.x1, (double)in.x2};
+                    const bool stereo = !(in.o2 < 0);
+                    const double ob[3] = {(double)in.o0, (double)in.o1, (double)in.o2};
+                    const double info = (double)in.iv;
                     double p[3], e[3], iz;
                     const double c2 = edge_residual_fast(cam, Trt, X, ob, stereo, info, p, e, iz);
                     s_chi2[i] = c2;
@@ -504,34 +543,28 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                     if (robust) huber_fast(c2, stereo ? deltaStereo : deltaMono, r0, w);
                     acc[27] += r0;
                     accumulate_edge(cam, p, iz, e, w * info, stereo, acc);
-                }
+                });
                 if (SEM) {
-                    for (int i = tid; i < nsem; i += kPoseThreads) {
-                        if (sm.e_level[i] != 0) continue;
-                        const double X[3] = {(double)sm.e_Xw[i * 3], (double)sm.e_Xw[i * 3 + 1], (double)sm.e_Xw[i * 3 + 2]};
-                        const double ob[3] = {(double)sm.e_obs[i * 2], (double)sm.e_obs[i * 2 + 1], 0.0};
+                    for_sem([&](int, const SemIn& in) {
+                        const double X[3] = {(double)in.x0, (double)in.x1, (double)in.x2};
+                        const double ob[3] = {(double)in.o0, (double)in.o1, 0.0};
                         double p[3], e[3], iz;
                         const double c2 = edge_residual_fast(cam, Trt, X, ob, false, infoSem, p, e, iz);
                         double r0, w;
                         huber_fast(c2, deltaMono, r0, w);
                         acc[27] += r0;
                         accumulate_edge(cam, p, iz, e, w * infoSem, false, acc);
-                    }
+                    });
                 }
                 PSTAMP(0);
                 block_sum_wide(acc, s_part, s_tot);
                 PSTAMP(1);
-                double currentChi = acc[27];
-                double H[36], g[6];
-                {
-                    int k = 0;
-                    for (int a = 0; a < 6; a++)
-                        for (int cc = a; cc < 6; cc++) { H[a * 6 + cc] = acc[k]; H[cc * 6 + a] = acc[k]; k++; }
-                    for (int a = 0; a < 6; a++) g[a] = acc[21 + a];
-                }
+                double currentChi = s_tot[27];
+                double g[6];
+                for (int a = 0; a < 6; a++) g[a] = s_tot[21 + a];
                 if (iter == 0) {   // computeLambdaInit: 1e-5 * max |H_jj|
                     double md = 0;
-                    for (int a = 0; a < 6; a++) md = fmax(fabs(H[a * 7]), md);
+                    for (int a = 0; a < 6; a++) md = fmax(fabs(s_tot[h_idx(a, a)]), md);
                     lambda = 1e-5 * md;
                     ni = 2;
                 }
@@ -550,13 +583,14 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                             for (int k = 0; k < kMaxTrials - 1; k++)
                                 if (k < tl) { lw *= nw; nw *= 2; }
                             double A[36], xw[6];
-                            for (int k = 0; k < 36; k++) A[k] = H[k];
+                            for (int a = 0; a < 6; a++)
+                                for (int cc = a; cc < 6; cc++) { const double hv = s_tot[h_idx(a, cc)]; A[a * 6 + cc] = hv; A[cc * 6 + a] = hv; }
                             for (int a = 0; a < 6; a++) { A[a * 7] += lw; xw[a] = g[a]; }
                             const bool okw = solve6(A, xw);
                             if (!okw) for (int a = 0; a < 6; a++) xw[a] = 0;
-                            const SE3 Tw = se3_mul(se3_exp(xw), T);
+                            const SE3 Tw = se3_mul(se3_exp(xw), load_pose(Tp));
                             if (lane < kMaxTrials) {
-                                double* cd = s_cand + lane * kCandN;
+                                double* cd = s_cand + ((tot_its & 1) * kMaxTrials + lane) * kCandN;
                                 for (int k = 0; k < 4; k++) cd[k] = Tw.q[k];
                                 for (int k = 0; k < 3; k++) cd[4 + k] = Tw.t[k];
                                 for (int k = 0; k < 6; k++) cd[7 + k] = xw[k];
@@ -569,7 +603,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                     SE3 Tn;
                     bool ok2;
                     {
-                        const double* cd = s_cand + qmax * kCandN;
+                        const double* cd = s_cand + ((tot_its & 1) * kMaxTrials + qmax) * kCandN;
                         for (int k = 0; k < 4; k++) Tn.q[k] = cd[k];
                         for (int k = 0; k < 3; k++) Tn.t[k] = cd[4 + k];
                         for (int k = 0; k < 6; k++) x[k] = cd[7 + k];
@@ -602,7 +636,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                         lambda *= fmax(1. / 3., alpha);
                         ni = 2;
                         currentChi = tempChi;
-                        T = Tn;
+                        Tp = s_cand + ((tot_its & 1) * kMaxTrials + qmax) * kCandN;
                     } else {
                         lambda *= ni;
                         ni *= 2;
@@ -616,7 +650,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
         }
         if (SEM) {
             float Pose[16];
-            se3_to_T(T, Pose);   // Converter::toCvMat(vSE3->estimate())
+            se3_to_T(load_pose(Tp), Pose);   // Converter::toCvMat(vSE3->estimate())
             // re-gate the M_joint edges (:928-973 after round 0, :1042-1098 afterwards)
             int dsem = 0;
             for (int i = tid; i < ninit; i += kPoseThreads) {
@@ -654,20 +688,14 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                     sm.e_tmp[m] = (mask_nearest(sm, o, u, v, ni, d2) && d2 < 10) ? 1 + ni : 0;
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int n = s_nsem;
-                    for (int m = 0; m < sm.nObjMp; m++) {
-                        const int ok = sm.e_tmp[m];
-                        if (!ok) continue;
-                        const int px = ok - 1;
-                        sm.e_Xw[n * 3] = sm.objmp_Xw[m * 3]; sm.e_Xw[n * 3 + 1] = sm.objmp_Xw[m * 3 + 1]; sm.e_Xw[n * 3 + 2] = sm.objmp_Xw[m * 3 + 2];
-                        sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
-                        sm.e_level[n] = 0; sm.e_chi2[n] = 0; sm.e_obj[n] = sm.objmp_obj[m]; sm.e_out[n] = 0;
-                        n++;
-                    }
-                    s_semnum += n - s_nsem;
-                    s_nsem = n;
-                }
+                const int n0 = s_nsem;
+                const int n1 = ordered_scatter(sm.nObjMp, n0, [&](int m) { return sm.e_tmp[m] != 0; }, [&](int m, int n) {
+                    const int px = sm.e_tmp[m] - 1;
+                    sm.e_Xw[n * 3] = sm.objmp_Xw[m * 3]; sm.e_Xw[n * 3 + 1] = sm.objmp_Xw[m * 3 + 1]; sm.e_Xw[n * 3 + 2] = sm.objmp_Xw[m * 3 + 2];
+                    sm.e_obs[n * 2] = (float)(px & 0x7FFF); sm.e_obs[n * 2 + 1] = (float)(px >> 15);
+                    sm.e_level[n] = 0; sm.e_obj[n] = sm.objmp_obj[m]; sm.e_out[n] = 0;
+                });
+                if (tid == 0) { s_semnum += n1 - n0; s_nsem = n1; }
             }
             __syncthreads();
             nsem = s_nsem;
@@ -675,6 +703,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
         // inlier / outlier classification (:380-438): excluded edges get a fresh error at the final
         // pose, active edges keep the error of the last LM trial (g2o's _error buffer)
         int bad = 0;
+        const SE3 Tfin = load_pose(Tp);
         for (int i = tid; i < N; i += kPoseThreads) {
             const int lv = s_level[i];
             if (lv == 255) continue;
@@ -684,7 +713,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                 const double X[3] = {(double)Xw[i * 3], (double)Xw[i * 3 + 1], (double)Xw[i * 3 + 2]};
                 const double ob[3] = {(double)obsp[i * 3], (double)obsp[i * 3 + 1], (double)ur};
                 double p[3], e[3];
-                se3_map(T, X, p);
+                se3_map(Tfin, X, p);
                 s_chi2[i] = edge_error(cam, p, ob, stereo, (double)inv[i], e);
             }
             const float chi2 = (float)s_chi2[i];
@@ -702,7 +731,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
 
     if (tid == 0) {
         float To[16];
-        se3_to_T(T, To);
+        se3_to_T(load_pose(Tp), To);
         for (int k = 0; k < 16; k++) c.Tcw_out[b * 16 + k] = To[k];
         c.n_inliers[b] = nInitial - nBad;
         if (c.stats) { c.stats[b * 2] = tot_its; c.stats[b * 2 + 1] = tot_trials; }
