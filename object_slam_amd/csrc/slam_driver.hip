@@ -329,7 +329,7 @@ struct MpUpdate {
                 const Map& m = c.seq[items[i].seq]->map;
                 const MapPt& p = m.mps[items[i].p];
                 int n = 0, nd = 0;
-                if (!p.bad) { n = (int)p.obs.size(); for (auto& e : p.obs) nd += !m.kfs[e.first].bad; }
+                if (!m.pBad[items[i].p]) { n = (int)p.obs.size(); for (auto& e : p.obs) nd += !m.kfs[e.first].bad; }
                 start[i + 1] = n; dstart[i + 1] = nd;
             }
         });
@@ -437,7 +437,7 @@ static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
         bool create = false;
         const int p = f.mp[i];
         if (p < 0) create = true;
-        else if (m.mps[p].nObs < 1) { create = true; f.mp[i] = -1; }
+        else if (m.pNObs[p] < 1) { create = true; f.mp[i] = -1; }
         if (create) make(i);
         nPoints++;
         if (v[j].first > c.thDepth && nPoints > 100) break;
@@ -454,7 +454,7 @@ static void update_local_map(Seq& s) {
         prefetch_obs_ahead(m.mps, f.mp, i, f.N);
         const int p = f.mp[i];
         if (p < 0) continue;
-        if (m.mps[p].bad) { f.mp[i] = -1; continue; }
+        if (m.pBad[p]) { f.mp[i] = -1; continue; }
         for (auto& e : m.mps[p].obs)
             if (s.counter[e.first]++ == 0) touched.push_back(e.first);
     }
@@ -503,7 +503,7 @@ static void update_local_map(Seq& s) {
             const int p = kmp[i];
             if (p < 0 || mark[p] == f.id) continue;
             mark[p] = f.id;
-            if (!m.mps[p].bad) { pos[p] = (int)s.localMPs.size(); s.localMPs.push_back(p); }
+            if (!m.pBad[p]) { pos[p] = (int)s.localMPs.size(); s.localMPs.push_back(p); }
             else pos[p] = -1;
         }
     }
@@ -549,16 +549,15 @@ static bool finish_initial_pose(Seq& s, const oslam_job_pose_t& j) {
     f.pose.set_frame(T);
     int nmatchesMap = 0;
     for (int i = 0; i < f.N; i++) {
-        prefetch_ahead(s.map.mps, f.mp, i, f.N);
         const int p = f.mp[i];
         if (p < 0) continue;
         if (j.outlier[i]) {
             f.mp[i] = -1; f.outlier[i] = 0;
-            s.map.mps[p].lastFrameSeen = f.id;
+            s.map.pLastSeen[p] = f.id;
             s.seenList.push_back(p);
         } else {
             f.outlier[i] = 0;
-            if (s.map.mps[p].nObs > 0) nmatchesMap++;
+            if (s.map.pNObs[p] > 0) nmatchesMap++;
         }
     }
     return nmatchesMap >= 10;
@@ -573,9 +572,9 @@ static void map_point_culling(Seq& s) {   // :171-206
     std::vector<int> keep;
     for (int p : s.recentAdded) {
         MapPt& mp = m.mps[p];
-        if (mp.bad) continue;
-        if ((float)mp.found / mp.visible < 0.25f) { m.set_bad_point(p); s.st[12]++; continue; }
-        if (cur - mp.firstKF >= 2 && mp.nObs <= 3) { m.set_bad_point(p); s.st[12]++; continue; }
+        if (m.pBad[p]) continue;
+        if ((float)m.pFound[p] / m.pVisible[p] < 0.25f) { m.set_bad_point(p); s.st[12]++; continue; }
+        if (cur - mp.firstKF >= 2 && m.pNObs[p] <= 3) { m.set_bad_point(p); s.st[12]++; continue; }
         if (cur - mp.firstKF >= 3) continue;
         keep.push_back(p);
     }
@@ -638,7 +637,7 @@ static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<in
         const int p = pts[pi];
         if (p < 0) continue;
         const MapPt& mp = m.mps[p];
-        if (mp.bad || mp.obs_index(k) >= 0) continue;
+        if (m.pBad[p] || mp.obs_index(k) >= 0) continue;
         float pc[3];
         for (int r = 0; r < 3; r++) {
             float s = T[r * 4] * mp.pos[0];
@@ -675,11 +674,11 @@ static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t
         const int best = q_match[i];
         if (best < 0) continue;
         const int p = qpt[i];
-        if (m.mps[p].bad) continue;
+        if (m.pBad[p]) continue;
         const int inKF = m.kfs[k].mp[best];
         if (inKF >= 0) {
-            if (!m.mps[inKF].bad) {
-                if (m.mps[inKF].nObs > m.mps[p].nObs) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
+            if (!m.pBad[inKF]) {
+                if (m.pNObs[inKF] > m.pNObs[p]) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
                 else { if (m.replace_point(inKF, p)) s.updList.push_back(p); }
                 if (touched) { touched->push_back(p); touched->push_back(inKF); }
             }
@@ -756,10 +755,10 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                 for (int i = 0; i < kf.N && nMPs - nRed < keepAt; i++) {
                     prefetch_okp_ahead(m.mps, kf.mp, i, kf.N);
                     const int p = kf.mp[i];
-                    if (p < 0 || m.mps[p].bad) continue;
+                    if (p < 0 || m.pBad[p]) continue;
                     if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
                     nMPs++;
-                    if (m.mps[p].nObs > 3) {
+                    if (m.pNObs[p] > 3) {
                         const int lvl = kf.keysUn[i].octave;
                         int n = 0;
                         const MapPt& mq = m.mps[p];
@@ -828,7 +827,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         for (int i = 0; i < kf.N; i++) {
             prefetch_obs_ahead(m.mps, kf.mp, i, kf.N);
             const int p = kf.mp[i];
-            if (p < 0 || m.mps[p].bad) continue;
+            if (p < 0 || m.pBad[p]) continue;
             if (m.mps[p].obs_index(s.curKF) < 0) { m.add_observation(p, s.curKF, i); s.updList.push_back(p); }
             else s.recentAdded.push_back(p);
         }
@@ -1119,7 +1118,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 MapPt& mp = m.mps[p];
                 if (mp.fuseListStamp == stamp) f.dup[pi] = mp.fuseListIdx;   // the same point at two keypoints of the keyframe: a chain through its positions
                 mp.fuseListStamp = stamp; mp.fuseListIdx = (int)pi;
-                f.badf[pi] = mp.bad ? 1 : 0;
+                f.badf[pi] = m.pBad[p] ? 1 : 0;
                 uint64_t mk = 0;
                 for (auto& e : mp.obs) { const uint8_t sl = f.slotOf[e.first]; if (sl != 255) mk |= 1ull << sl; }
                 f.mask[pi] = mk;
@@ -1134,7 +1133,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (mp.fuseListStamp != stamp) continue;
                 uint64_t mk = 0;
                 for (auto& e : mp.obs) { const uint8_t sl = (size_t)e.first < f.slotOf.size() ? f.slotOf[e.first] : 255; if (sl != 255) mk |= 1ull << sl; }
-                for (int pi = mp.fuseListIdx; pi >= 0; pi = f.dup[pi]) { f.badf[pi] = mp.bad ? 1 : 0; f.mask[pi] = mk; }
+                for (int pi = mp.fuseListIdx; pi >= 0; pi = f.dup[pi]) { f.badf[pi] = m.pBad[x] ? 1 : 0; f.mask[pi] = mk; }
             }
             f.touched.clear();
         };
@@ -1166,7 +1165,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                         prefetch_obs_ahead(m.mps, pts, pi, pts.size());
                         const int p = pts[pi];
                         uint8_t ex = 1;
-                        if (p >= 0) { const MapPt& mp = m.mps[p]; ex = (mp.bad || mp.obs_index(k) >= 0) ? 1 : 0; }
+                        if (p >= 0) { const MapPt& mp = m.mps[p]; ex = (m.pBad[p] || mp.obs_index(k) >= 0) ? 1 : 0; }
                         if (cached) { if (ex != fs[w].excl[pi]) { fprintf(stderr, "[fuse excl check] mismatch: sequence %d keyframe %d point %d (list index %zu): cached %d, full %d\n", who[w], k, p, pi, fs[w].excl[pi], ex); abort(); } }
                         else { fs[w].excl[pi] = ex; any = any || !ex; }
                     }
@@ -1248,7 +1247,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     const int p = m.kfs[k].mp[i];
                     if (p < 0) continue;
                     MapPt& mp = m.mps[p];
-                    if (mp.bad || mp.fuseCandidateForKF == cur) continue;
+                    if (m.pBad[p] || mp.fuseCandidateForKF == cur) continue;
                     mp.fuseCandidateForKF = cur;
                     fs[w].pts.push_back(p);
                 }
@@ -1267,7 +1266,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 const int p = kmp[i];
                 if (p < 0) continue;
                 const MapPt& mp = s.map.mps[p];
-                if (mp.bad || (mp.updStep == c.mapStep && mp.updVer == mp.obsVer)) continue;
+                if (s.map.pBad[p] || (mp.updStep == c.mapStep && mp.updVer == mp.obsVer)) continue;
                 s.updList.push_back(p);
             }
         });
@@ -1307,12 +1306,12 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 const std::vector<int>& kmp = m.kfs[W.kfs[q]].mp;
                 const int* kp_ = kmp.data();
                 for (size_t i = 0, n = kmp.size(); i < n; i++) {
-                    if (i + kPF < n) { const int pq = kp_[i + kPF]; if (pq >= 0 && bam[pq] != cur) prefetch_mp(&m.mps[pq]); }
+                    if (i + kPF < n) { const int pq = kp_[i + kPF]; if (pq >= 0 && bam[pq] != cur) __builtin_prefetch(&m.mps[pq].obs); }
                     const int p = kp_[i];
                     if (p < 0 || bam[p] == cur) continue;
                     bam[p] = cur;
-                    const MapPt& mp = m.mps[p];
-                    if (!mp.bad) { W.pts.push_back(p); edgeCap += mp.obs.size(); }
+
+                    if (!m.pBad[p]) { W.pts.push_back(p); edgeCap += m.mps[p].obs.size(); }
                 }
             }
             // Fixed keyframes (:489-504: every observer outside the local set, no bound) and the edges (:560-650) in ONE walk over the observation lists: a fixed
@@ -1492,7 +1491,7 @@ static void update_current_objects(Seq& s) {
             std::vector<int> cand;
             for (int k : o.kps) {
                 const int p = f.mp[k];
-                if (p < 0 || m.mps[p].bad || f.outlier[k]) continue;
+                if (p < 0 || m.pBad[p] || f.outlier[k]) continue;
                 if (!(p < (int)ob.member.size() && ob.member[p])) cand.push_back(p);
             }
             for (int p : cand) { ob.mps.push_back(p); mark(ob, p); s.sem[4]++; }
@@ -1519,9 +1518,8 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     s.hasSL = false;
     // CheckReplacedInLastFrame (:820-835)
     for (int k = 0; k < l.N; k++) {
-        prefetch_ahead(s.map.mps, l.mp, k, l.N);
         const int p = l.mp[k];
-        if (p >= 0 && s.map.mps[p].replaced >= 0) l.mp[k] = s.map.mps[p].replaced;
+        if (p >= 0 && s.map.pReplaced[p] >= 0) l.mp[k] = s.map.pReplaced[p];
     }
     if (!s.hasVelocity || f.id < s.lastRelocFrameId + 2) { s.path = 2; return; }
     s.path = 1;
@@ -1533,11 +1531,11 @@ static void stage_motion_model_prepare(Ctx& c, int i) {
     s.jHas.assign(NL, 0);
     if (!by_id) { s.jXw.assign((size_t)NL * 3, 0.f); s.jDesc.assign((size_t)NL * 32, 0); }
     for (int k = 0; k < NL; k++) {
-        prefetch_ahead(s.map.mps, l.mp, k, NL);
+        if (!by_id) prefetch_ahead(s.map.mps, l.mp, k, NL);
         const int p = l.mp[k];
         if (p < 0 || l.outlier[k]) continue;
         const MapPt& mp = s.map.mps[p];
-        s.jHas[k] = 1 | (mp.nObs > 0 ? 2 : 0);
+        s.jHas[k] = 1 | (s.map.pNObs[p] > 0 ? 2 : 0);
         if (by_id) continue;
         for (int d = 0; d < 3; d++) s.jXw[(size_t)k * 3 + d] = mp.pos[d];
         memcpy(&s.jDesc[(size_t)k * 32], mp.desc, 32);
@@ -1564,13 +1562,12 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     Map& m = s.map;
     s.jBlocked.assign(f.N, 0);
     for (int k = 0; k < f.N; k++) {
-        prefetch_ahead(m.mps, f.mp, k, f.N);
         const int p = f.mp[k];
         if (p < 0) continue;
-        if (m.mps[p].bad) { f.mp[k] = -1; continue; }
-        m.mps[p].visible++;
-        m.mps[p].lastFrameSeen = f.id;
-        s.jBlocked[k] = m.mps[p].nObs > 0;
+        if (m.pBad[p]) { f.mp[k] = -1; continue; }
+        m.pVisible[p]++;
+        m.pLastSeen[p] = f.id;
+        s.jBlocked[k] = m.pNObs[p] > 0;
     }
     // The job lists ALL local points; those the reference leaves out of the projection (mnLastFrameSeen == this frame, :1413-1427: matched above or
     // discarded as outliers of the initial pose optimisation) are flagged in `skip`, so the packed arrays only depend on the local map and stay valid
@@ -1580,8 +1577,7 @@ static void stage_local_map_prepare(Ctx& c, int i) {
         s.locObs.resize(M + 1);
         if (c.residentPts) {   // the table gathers the points' arrays from its records: only Observations() > 0 is the driver's to tell
             for (int q = 0; q < M; q++) {
-                if (q + kPF < M) __builtin_prefetch((const char*)&m.mps[s.localMPs[q + kPF]] + 64);
-                s.locObs[q] = m.mps[s.localMPs[q]].nObs > 0;
+                s.locObs[q] = m.pNObs[s.localMPs[q]] > 0;
             }
         } else {
             s.locPw.resize((size_t)M * 3 + 3); s.locPn.resize((size_t)M * 3 + 3); s.locMax.resize(M + 1); s.locMin.resize(M + 1);
@@ -1591,7 +1587,7 @@ static void stage_local_map_prepare(Ctx& c, int i) {
             prefetch_ahead(m.mps, s.localMPs, q, M);
             const MapPt& mp = m.mps[s.localMPs[q]];
             for (int d = 0; d < 3; d++) { s.locPw[(size_t)q * 3 + d] = mp.pos[d]; s.locPn[(size_t)q * 3 + d] = mp.normal[d]; }
-            s.locMax[q] = mp.maxD; s.locMin[q] = mp.minD; s.locObs[q] = mp.nObs > 0;
+            s.locMax[q] = mp.maxD; s.locMin[q] = mp.minD; s.locObs[q] = m.pNObs[s.localMPs[q]] > 0;
             memcpy(&s.locDesc[(size_t)q * 32], mp.desc, 32);
         }
         s.locContentId = c.next_content_id();
@@ -1624,13 +1620,12 @@ static void stage_after_local_pose(Ctx& c, int i) {
     f.pose.set_frame(T);
     s.matchesInliers = 0;
     for (int k = 0; k < f.N; k++) {
-        prefetch_ahead(s.map.mps, f.mp, k, f.N);
         const int p = f.mp[k];
         if (p < 0) continue;
         f.outlier[k] = j.outlier[k];
         if (!f.outlier[k]) {
-            s.map.mps[p].found++;
-            if (s.map.mps[p].nObs > 0) s.matchesInliers++;
+            s.map.pFound[p]++;
+            if (s.map.pNObs[p] > 0) s.matchesInliers++;
         } else if (c.stereo) {
             f.mp[k] = -1;   // :1041-1042
         }
@@ -1650,9 +1645,8 @@ static void stage_after_tracking(Ctx& c, int i) {
         if (l.pose.valid) { s.velocity = mul4(f.pose.Tcw, l.pose.Twc); s.hasVelocity = true; }
         else s.hasVelocity = false;
         for (int k = 0; k < f.N; k++) {   // clean VO matches
-            prefetch_ahead(m.mps, f.mp, k, f.N);
             const int p = f.mp[k];
-            if (p >= 0 && m.mps[p].nObs < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
+            if (p >= 0 && m.pNObs[p] < 1) { f.outlier[k] = 0; f.mp[k] = -1; }
         }
         // NeedNewKeyFrame (:1242-1326) with an idle local mapper
         bool need = false;
@@ -1839,7 +1833,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 const BowViews& vk = s.bow_views(c, s.refKF);
                 bv[q].side2(f.bowNode);
                 flag[q].resize(kf.N);
-                for (int k = 0; k < kf.N; k++) flag[q][k] = kf.mp[k] >= 0 && !s.map.mps[kf.mp[k]].bad;
+                for (int k = 0; k < kf.N; k++) flag[q][k] = kf.mp[k] >= 0 && !s.map.pBad[kf.mp[k]];
                 match[q].assign(f.N + 1, -1);
                 oslam_job_bow_t& j = bj[q];
                 memset(&j, 0, sizeof(j));
@@ -1887,8 +1881,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         Seq& s = *c.seq[ljw[q]];
         Frame& f = *s.cur;
         for (int e = 0, Me = lj[q].M; e < Me; e++) {
-            if (e + kPF < Me && s.jInView[e + kPF]) __builtin_prefetch((const char*)&s.map.mps[s.localMPs[e + kPF]] + 64);   // the line of `visible`
-            if (s.jInView[e]) s.map.mps[s.localMPs[e]].visible++;
+            if (s.jInView[e]) s.map.pVisible[s.localMPs[e]]++;
         }
         for (int k = 0; k < f.N; k++) if (s.jMatch[k] >= 0) f.mp[k] = s.localMPs[s.jMatch[k]];
         fill_pose_job(c, s, ljw[q], s.jPose);
@@ -1983,7 +1976,7 @@ static int64_t map_violations(const Map& m) {
     int64_t bad = 0;
     for (size_t p = 0; p < m.mps.size(); p++) {
         const MapPt& mp = m.mps[p];
-        if (mp.bad) { bad += !mp.obs.empty(); continue; }
+        if (m.pBad[p]) { bad += !mp.obs.empty(); continue; }
         int n = 0;
         for (auto& e : mp.obs) {
             const KeyFrm& k = m.kfs[e.first];
@@ -1992,7 +1985,7 @@ static int64_t map_violations(const Map& m) {
             if (e.second < 0 || e.second >= k.N) { bad++; continue; }
             n += k.uRight[e.second] >= 0 ? 2 : 1;
         }
-        if (n != mp.nObs) { bad++; if (getenv("OSLAM_SLAM_DEBUG")) fprintf(stderr, "violation: point %d nObs %d != %d\n", (int)p, mp.nObs, n); }
+        if (n != m.pNObs[p]) { bad++; if (getenv("OSLAM_SLAM_DEBUG")) fprintf(stderr, "violation: point %d nObs %d != %d\n", (int)p, m.pNObs[p], n); }
     }
     for (size_t k = 0; k < m.kfs.size(); k++) {
         const KeyFrm& kf = m.kfs[k];
@@ -2193,7 +2186,7 @@ int oslam_slam_debug_point(oslam_slam_t* h, int seq, int id, uint8_t host[64], u
     const MapPt& p = m.mps[id];
     static_assert(offsetof(MapPt, desc) == 32 && offsetof(MapPt, minD) == 24, "the first 64 bytes of MapPt are the resident record");
     memcpy(host, &p, 64);
-    *bad = p.bad || p.obs.empty();
+    *bad = m.pBad[id] || p.obs.empty();
     if (!h->c.ops.point_record) { oslam::set_error("oslam_slam_debug_point: the operator table keeps no resident map points"); return OSLAM_E_INVALID; }
     return h->c.ops.point_record(h->c.ops.ctx, seq, id, resident);
 }

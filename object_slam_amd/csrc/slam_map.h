@@ -120,13 +120,11 @@ struct MapPt {
     float normal[3] = {0, 0, 0};
     float minD = 0, maxD = 0;
     uint8_t desc[32];
-    int nObs = 0, visible = 1, found = 1;        // src/MapPoint.cc:33-46
+    // (nObs, mnVisible, mnFound, mbBad, mpReplaced and mnLastFrameSeen live in Map's dense per-point arrays: Map::pNObs ...)
     int firstKF = 0, firstFrame = 0, refKF = -1;
-    bool bad = false;
-    int replaced = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
     std::vector<ObsKp> okp;                      // okp[i] = the keypoint of obs[i]
-    int lastFrameSeen = 0, trackRefForFrame = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    int trackRefForFrame = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
     // driver scratch of SearchInNeighbors: position of the point in the current keyframe's point list (valid while fuseListStamp == current keyframe id + 1)
     int fuseListIdx = 0, fuseListStamp = 0;
     // bookkeeping of the driver (not in the reference): obsVer counts the changes of the observation list; (updVer, updStep) = obsVer and the local-mapping
@@ -187,12 +185,20 @@ struct Map {
     int64_t nCulledKF = 0, nCulledMP = 0;
 
     // ---- MapPoint (src/MapPoint.cc) ----
+    // The scalars the per-frame loops of tracking read or bump for every matched / visible point, dense by point id: nObs (Observations()), mnVisible, mnFound,
+    // mnLastFrameSeen, mpReplaced (-1: none) and mbBad.  A loop over a frame's points then touches 4 bytes at neighbouring ids (the points a keyframe created have
+    // consecutive ids) instead of one or two cache lines of a 170-byte MapPt record per point, whose maps (several MB per sequence, thousands of sequences per
+    // rank) never stay in a cache from one frame to the next.
+    std::vector<int> pNObs, pVisible, pFound, pLastSeen, pReplaced;
+    std::vector<uint8_t> pBad;
     int new_point(const float x[3], int refKF, int refFrame) {
         MapPt p;
         p.pos[0] = x[0]; p.pos[1] = x[1]; p.pos[2] = x[2];
         memset(p.desc, 0, 32);
         p.firstKF = refKF; p.firstFrame = refFrame; p.refKF = refKF;
         mps.push_back(p);
+        pNObs.push_back(0); pVisible.push_back(1); pFound.push_back(1);   // src/MapPoint.cc:33-46
+        pLastSeen.push_back(0); pReplaced.push_back(-1); pBad.push_back(0);
         return (int)mps.size() - 1;
     }
     void add_observation(int p, int kf, int idx) {   // :196-207
@@ -204,13 +210,13 @@ struct Map {
         const ObsKp o = {k.keysUn[idx].x, k.keysUn[idx].y, k.uRight[idx], k.keysUn[idx].octave};
         m.obs.insert(m.obs.begin() + at, std::make_pair(kf, idx));
         m.okp.insert(m.okp.begin() + at, o);
-        m.nObs += o.ur >= 0 ? 2 : 1;
+        pNObs[p] += o.ur >= 0 ? 2 : 1;
         m.obsVer++;
     }
     void set_bad_point(int p) {                      // :253-270
         MapPt& m = mps[p];
-        if (!m.bad) { nMPsInMap--; nCulledMP++; }
-        m.bad = true;
+        if (!pBad[p]) { nMPsInMap--; nCulledMP++; }
+        pBad[p] = 1;
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
         m.okp.clear();
@@ -221,12 +227,12 @@ struct Map {
         bool bad = false;
         for (size_t i = 0; i < m.obs.size(); i++)
             if (m.obs[i].first == kf) {
-                m.nObs -= m.okp[i].ur >= 0 ? 2 : 1;
+                pNObs[p] -= m.okp[i].ur >= 0 ? 2 : 1;
                 m.obs.erase(m.obs.begin() + i);
                 m.okp.erase(m.okp.begin() + i);
                 m.obsVer++;
                 if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
-                if (m.nObs <= 2) bad = true;
+                if (pNObs[p] <= 2) bad = true;
                 break;
             }
         if (bad) set_bad_point(p);
@@ -238,10 +244,10 @@ struct Map {
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
         m.okp.clear();
-        if (!m.bad) { nMPsInMap--; }
-        m.bad = true;
-        m.replaced = by;
-        const int nvisible = m.visible, nfound = m.found;
+        if (!pBad[p]) { nMPsInMap--; }
+        pBad[p] = 1;
+        pReplaced[p] = by;
+        const int nvisible = pVisible[p], nfound = pFound[p];
         for (auto& e : o) {
             if (mps[by].obs_index(e.first) < 0) {
                 kfs[e.first].mp[e.second] = by;
@@ -250,8 +256,8 @@ struct Map {
                 kfs[e.first].mp[e.second] = -1;
             }
         }
-        mps[by].found += nfound;
-        mps[by].visible += nvisible;
+        pFound[by] += nfound;
+        pVisible[by] += nvisible;
         return true;
     }
 
@@ -298,7 +304,7 @@ struct Map {
         for (int i = 0; i < f.N; i++) {
             prefetch_obs_ahead(mps, f.mp, i, f.N);
             const int p = f.mp[i];
-            if (p < 0 || mps[p].bad) continue;
+            if (p < 0 || pBad[p]) continue;
             for (auto& e : mps[p].obs) {
                 if (e.first == k) continue;
                 if (counter[e.first]++ == 0) touched.push_back(e.first);
@@ -332,10 +338,9 @@ struct Map {
         const KeyFrm& f = kfs[k];
         int n = 0;
         for (int i = 0; i < f.N; i++) {
-            prefetch_ahead(mps, f.mp, i, f.N);
             const int p = f.mp[i];
-            if (p < 0 || mps[p].bad) continue;
-            if (minObs > 0) { if (mps[p].nObs >= minObs) n++; }
+            if (p < 0 || pBad[p]) continue;
+            if (minObs > 0) { if (pNObs[p] >= minObs) n++; }
             else n++;
         }
         return n;

@@ -34,8 +34,8 @@ int main() {
     for (int p = 0; p < 41; p++) { m.new_point(x, 0, 0); m.nMPsInMap++; }
     for (int p = 0; p < 20; p++) for (int k = 0; k <= 2; k++) observe(m, p, k, p);
     for (int p = 20; p < 40; p++) for (int k = 1; k <= 4; k++) observe(m, p, k, p);
-    CHECK(m.mps[0].nObs == 6);     // stereo observations count twice (src/MapPoint.cc:203-206)
-    CHECK(m.mps[20].nObs == 8);
+    CHECK(m.pNObs[0] == 6);     // stereo observations count twice (src/MapPoint.cc:203-206)
+    CHECK(m.pNObs[20] == 8);
     for (int k = 0; k < 5; k++) m.update_connections(k, counter);
     for (int v : counter) CHECK(v == 0);
     // weights: (0,1)=20 (0,2)=20 (1,2)=40 (1,3)=20 (1,4)=20 (2,3)=20 (2,4)=20 (3,4)=20
@@ -55,24 +55,24 @@ int main() {
     // erase_observation: refKF moves to the first remaining observer; <= 2 observations left -> point culled (src/MapPoint.cc:209-239)
     // (free slot 38 of keyframes 3 and 4 first: point 38 loses two stereo observations)
     m.erase_observation(38, 3); m.erase_observation(38, 4);
-    CHECK(m.mps[38].nObs == 4 && !m.mps[38].bad && m.kfs[3].mp[38] == 38);   // EraseObservation does not touch the keyframe slot; the caller does (src/Optimizer.cc:752-753)
+    CHECK(m.pNObs[38] == 4 && !m.pBad[38] && m.kfs[3].mp[38] == 38);   // EraseObservation does not touch the keyframe slot; the caller does (src/Optimizer.cc:752-753)
     m.kfs[3].mp[38] = -1; m.kfs[4].mp[38] = -1;
     m.kfs[3].uRight[38] = -1.f; m.kfs[4].uRight[38] = -1.f;   // two monocular observations: nObs = 2
     observe(m, 40, 3, 38); observe(m, 40, 4, 38);
     m.mps[40].refKF = 3;
-    CHECK(m.mps[40].nObs == 2);
+    CHECK(m.pNObs[40] == 2);
     m.erase_observation(40, 3);
-    CHECK(m.mps[40].bad && m.mps[40].obs.empty() && m.kfs[4].mp[38] == -1);   // nObs <= 2 -> SetBadFlag clears the remaining slot
+    CHECK(m.pBad[40] && m.mps[40].obs.empty() && m.kfs[4].mp[38] == -1);   // nObs <= 2 -> SetBadFlag clears the remaining slot
     // Replace (src/MapPoint.cc:279-318): observations move unless the target is already in that keyframe
     const int pa = m.new_point(x, 0, 0), pb = m.new_point(x, 0, 0);
     m.nMPsInMap += 2;
     observe(m, pa, 0, 45); observe(m, pa, 1, 46); observe(m, pb, 1, 47); observe(m, pb, 2, 48);
-    m.mps[pa].found = 3; m.mps[pa].visible = 7;
-    const int f0 = m.mps[pb].found, v0 = m.mps[pb].visible;
+    m.pFound[pa] = 3; m.pVisible[pa] = 7;
+    const int f0 = m.pFound[pb], v0 = m.pVisible[pb];
     CHECK(m.replace_point(pa, pb));
-    CHECK(m.mps[pa].bad && m.mps[pa].replaced == pb && m.mps[pa].obs.empty());
+    CHECK(m.pBad[pa] && m.pReplaced[pa] == pb && m.mps[pa].obs.empty());
     CHECK(m.kfs[0].mp[45] == pb && m.kfs[1].mp[46] == -1 && m.kfs[1].mp[47] == pb);   // keyframe 1 already observed pb: pa's slot is erased
-    CHECK(m.mps[pb].obs.size() == 3 && m.mps[pb].found == f0 + 3 && m.mps[pb].visible == v0 + 7);
+    CHECK(m.mps[pb].obs.size() == 3 && m.pFound[pb] == f0 + 3 && m.pVisible[pb] == v0 + 7);
     // SetBadFlag of keyframe 2 (src/KeyFrame.cc:453-545): links and observations removed, children re-attached, mTcp stored, id 0 is immune
     const int nk = m.nKFsInMap;
     m.set_bad_keyframe(0);
@@ -94,7 +94,7 @@ int main() {
     if (par2 >= 0) CHECK(m.kfs[par2].children.count(2) == 0);
     for (int p = 0; p < 40; p++) CHECK(m.mps[p].obs_index(2) < 0);
     // points 0..19 had observers 0,1,2 (+5 for the first five): after losing keyframe 2 they keep nObs = 4 (or 6)
-    CHECK(m.mps[10].nObs == 4 && !m.mps[10].bad && m.mps[0].nObs == 6);
+    CHECK(m.pNObs[10] == 4 && !m.pBad[10] && m.pNObs[0] == 6);
     // Tcp = Tcw * parent.Twc
     const M4 Tcp = mul4(m.kfs[2].pose.Tcw, m.kfs[par2].pose.Twc);
     for (int i = 0; i < 16; i++) CHECK(m.kfs[2].Tcp.m[i] == Tcp.m[i]);
