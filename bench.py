@@ -321,7 +321,7 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
            "GBs": {k: round(alg[k] / (us[k] * 1e-6) / 1e9, 1) for k in us if us[k] > 0},
            "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * steps / dt / 1e9, 1),
            "hamming_pairs_per_frame": round(pairs.value / Bp, 1),
-           # committed PMC passes of this stage (profiles/r02_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
+           # committed PMC passes of this stage (profiles/r04_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
            "pmc_hbm_KB_per_frame": {k: round(_pmc(k) / 512 / 1e3, 1) for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_blur_strip<true>", "k_octree",
                                                                                "k_orient_describe", "k_search_window") if _pmc(k) is not None},
            "pmc_valu_issue_frac": {k: _pmc(k, "valu_issue_frac_at_4_cycles") for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_octree", "k_orient_describe",
@@ -334,10 +334,10 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
 
 
 def _pmc(kernel, field="bytes_per_launch"):
-    """Per-launch PMC figure of `kernel` from the committed summary of this round (profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc passes of
+    """Per-launch PMC figure of `kernel` from the committed summary of this round (profiles/r04_pmc_traffic.json: separate rocprofv3 --pmc passes of
     the S2 stage at 512 frames per launch — FETCH_SIZE, WRITE_SIZE, SQ_* — corrected as MI355X_MICROARCH.md §HBM prescribes); None when the summary has
     no row for it.  HBM bytes for the fp64 solver kernels were not collected (their bound is not HBM)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # (re-taken in round 4 on the unchanged front-end kernels: within 0.3 % of the round-2 file)
     if not os.path.exists(path):
         return None
     try:

@@ -748,38 +748,47 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                 const bool stereo = !(ur < 0);
                 const double ob[3] = {(double)o0, (double)o1, (double)ur};
                 const double info = (double)inf;
-                double pc[3], er[3], Jp[18], Jx[9];
-                se3_map(T[a], Xw, pc);
-                const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+                // (se3_math.h fast forms: rotation-matrix map, one Newton reciprocal, fused multiply-adds, products over the non-zero Jacobian entries only)
+                double pc[3], er[3], iz, Jx[9];
+                const double* Ra_ = Rm + a * 9;
+                map_rt(Ra_, T[a].t, Xw, pc);
+                const double c2 = residual_fast(cam, pc, ob, stereo, info, er, iz);
                 pr.chi2[e] = c2;
                 double r0 = c2, wgt = 1.0;
-                if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
+                if (robust) huber_fast(c2, stereo ? dStereo : dMono, r0, wgt);
                 F0 += r0;
-                jac_binary_rcp(cam, pc, Rm + a * 9, stereo, Jp, Jx);
+                point_jac_rows(cam, pc, iz, Ra_, stereo, Jx);
                 const double wi = wgt * info;
-                int k = 0;
+                {
+#pragma clang fp contract(fast)
+                    double wJx[9];
 #pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    double sb = 0;
-                    _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jx[d * 3 + i] * (info * er[d]);
-                    bl[i] -= wgt * sb;
+                    for (int q = 0; q < 9; q++) wJx[q] = wi * Jx[q];   // (row ur of a monocular edge is zero)
 #pragma unroll
-                    for (int j = i; j < 3; j++) {
-                        double sh = 0;
-                        _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jx[d * 3 + i] * wi * Jx[d * 3 + j];
-                        hl[k++] += sh;
-                    }
-                }
-                if (w.blk[a] >= 0) {
-                    double* B = pr.Hpl + (long long)e * 18;
+                    for (int d = 0; d < 3; d++) {
+                        int k = 0;
 #pragma unroll
-                    for (int i = 0; i < 6; i++)
+                        for (int i = 0; i < 3; i++) {
+                            bl[i] -= wJx[d * 3 + i] * er[d];
 #pragma unroll
-                        for (int j = 0; j < 3; j++) {
-                            double sh = 0;
-                            _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jx[d * 3 + j];
-                            B[i * 3 + j] = sh;
+                            for (int j = i; j < 3; j++) hl[k++] += wJx[d * 3 + i] * Jx[d * 3 + j];
                         }
+                    }
+                    if (w.blk[a] >= 0) {
+                        double Ju[6], Jv[6], Jr[6];
+                        pose_jac_rows(cam, pc, iz, stereo, Ju, Jv, Jr);
+                        double* B = pr.Hpl + (long long)e * 18;
+#pragma unroll
+                        for (int i = 0; i < 6; i++)
+#pragma unroll
+                            for (int j = 0; j < 3; j++) {
+                                double sh = 0;   // Ju[4] = Jv[3] = Jr[4] = 0
+                                if (i != 4) sh += Ju[i] * wJx[j];
+                                if (i != 3) sh += Jv[i] * wJx[3 + j];
+                                if (i != 4) sh += Jr[i] * wJx[6 + j];
+                                B[i * 3 + j] = sh;
+                            }
+                    }
                 }
             }
         }
@@ -824,26 +833,17 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         const bool stereo = !(ur < 0);
         const double ob[3] = {(double)o0, (double)o1, (double)ur};
         const double info = (double)inf;
-        double pc[3], er[3], Jp[18], Jx[9];
-        se3_map(Ta, Xw, pc);
-        const double c2 = edge_error(cam, pc, ob, stereo, info, er);
+        double pc[3], er[3], iz;
+        map_rt(Ra, Ta.t, Xw, pc);
+        const double c2 = residual_fast(cam, pc, ob, stereo, info, er, iz);
         double r0 = c2, wgt = 1.0;
-        if (robust) huber(c2, stereo ? dStereo : dMono, r0, wgt);
-        jac_binary_rcp(cam, pc, Ra, stereo, Jp, Jx);
+        if (robust) huber_fast(c2, stereo ? dStereo : dMono, r0, wgt);
         const double wi = wgt * info;
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            double sb = 0;
-            _Pragma("unroll") for (int d = 0; d < 3; d++) sb += Jp[d * 6 + i] * (info * er[d]);
-            acc[21 + i] -= wgt * sb;
-#pragma unroll
-            for (int j = i; j < 6; j++) {
-                double sh = 0;
-                _Pragma("unroll") for (int d = 0; d < 3; d++) sh += Jp[d * 6 + i] * wi * Jp[d * 6 + j];
-                acc[k++] += sh;
-            }
-        }
+        double Ju[6], Jv[6], Jr[6];
+        pose_jac_rows(cam, pc, iz, stereo, Ju, Jv, Jr);
+        accumulate_row<0>(Ju, er[0], wi, acc);
+        accumulate_row<1>(Jv, er[1], wi, acc);
+        if (stereo) accumulate_row<2>(Jr, er[2], wi, acc);
     }
 #pragma unroll
     for (int k = 0; k < 27; k++) {

@@ -167,80 +167,15 @@ __device__ __forceinline__ void project_f32(const float* T, const float* P, floa
 // its quotient from one v_rsq_f64 + two Newton steps, fused multiply-adds, and the normal equations accumulated over the NON-ZERO entries of the Jacobian rows
 // only (g2o's rows have J[4] = J[9] = J[16] = 0; the generic 3 x 6 x 6 triple product spent a third of its multiplications on exact zeros).  All of it is a few ulp
 // away from the divided / unfused form: far inside the 1e-4 bar the parity tests hold (the float `invz` of the fork's stereo projection is kept).
-__device__ __forceinline__ double rcp_nr(double z) {
-    double r = __builtin_amdgcn_rcp(z);
-    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ double rsq_nr(double d) {
-    double r = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    r = r * __builtin_fma(-h * r, r, 1.5);
-    r = r * __builtin_fma(-h * r, r, 1.5);
-    return r;
-}
-// camera-frame point, residual and chi2 of one edge; iz = 1 / z is returned for the Jacobian
-// (the pose as rotation matrix + translation, built once per pass: 9 fused multiply-adds per edge instead of the quaternion sandwich's ~24 instructions)
-struct PoseRt { double R[9], t[3]; };
-__device__ __forceinline__ PoseRt pose_rt(const SE3& P) { PoseRt o; se3_R(P, o.R); o.t[0] = P.t[0]; o.t[1] = P.t[1]; o.t[2] = P.t[2]; return o; }
-__device__ __forceinline__ double edge_residual_fast(const Cam& c, const PoseRt& P, const double X[3], const double ob[3], bool stereo, double info, double p[3], double e[3], double& iz) {
-#pragma clang fp contract(fast)
-#pragma unroll
-    for (int r = 0; r < 3; r++) p[r] = P.R[r * 3] * X[0] + P.R[r * 3 + 1] * X[1] + P.R[r * 3 + 2] * X[2] + P.t[r];
-    iz = rcp_nr(p[2]);
-    if (!stereo) {
-        e[0] = ob[0] - (p[0] * iz * c.fx + c.cx);
-        e[1] = ob[1] - (p[1] * iz * c.fy + c.cy);
-        e[2] = 0;
-        return info * (e[0] * e[0] + e[1] * e[1]);
-    }
-    const double izf = (double)(float)iz;   // the fork's `const float invz = 1.0f/trans_xyz[2];`
-    const double r0 = p[0] * izf * c.fx + c.cx;
-    const double r1 = p[1] * izf * c.fy + c.cy;
-    const double r2 = r0 - c.bf * izf;
-    e[0] = ob[0] - r0; e[1] = ob[1] - r1; e[2] = ob[2] - r2;
-    return info * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-}
-__device__ __forceinline__ void huber_fast(double e2, double delta, double& rho0, double& rho1) {
-#pragma clang fp contract(fast)
-    const double dsqr = delta * delta;
-    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
-    else {
-        const double rs = rsq_nr(e2), sq = e2 * rs;
-        rho0 = 2 * sq * delta - dsqr;
-        rho1 = delta * rs;
-    }
-}
-constexpr int h_idx(int a, int cc) { return a * 6 - a * (a - 1) / 2 + (cc - a); }   // position of H(a, cc), a <= cc, among the 21 accumulators
-// acc += (w info) Jr^T Jr and -= (w info) Jr^T e_r for Jacobian row R of one edge, over the row's non-zero columns
-template <int R>
-__device__ __forceinline__ void accumulate_row(const double (&Jr)[6], double er, double wi, double (&acc)[kRedN]) {
-#pragma clang fp contract(fast)
-    constexpr int zero = R == 1 ? 3 : 4;   // rows u and ur do not depend on v2 (column 4), row v not on v1 (column 3)
-#pragma unroll
-    for (int a = 0; a < 6; a++) {
-        if (a == zero) continue;
-        const double wJ = wi * Jr[a];
-        acc[21 + a] -= wJ * er;
-#pragma unroll
-        for (int cc = a; cc < 6; cc++)
-            if (cc != zero) acc[h_idx(a, cc)] += wJ * Jr[cc];
-    }
-}
+// (rcp_nr, rsq_nr, PoseRt, edge_residual_fast, huber_fast, accumulate_row: se3_math.h, shared with the local-BA linearisation)
 // the OnlyPose Jacobian rows (se3_math.h jac_pose_onlypose) from iz = 1 / z, accumulated into the normal equations with weight wi = rho' * info
 __device__ __forceinline__ void accumulate_edge(const Cam& c, const double p[3], double iz, const double e[3], double wi, bool stereo, double (&acc)[kRedN]) {
 #pragma clang fp contract(fast)
-    const double x = p[0], y = p[1], iz2 = iz * iz, fxiz = c.fx * iz, fyiz = c.fy * iz, xiz2 = x * iz2, yiz2 = y * iz2;
-    const double Ju[6] = {x * yiz2 * c.fx, -(1 + x * xiz2) * c.fx, y * fxiz, -fxiz, 0, xiz2 * c.fx};
-    const double Jv[6] = {(1 + y * yiz2) * c.fy, -x * yiz2 * c.fy, -x * fyiz, 0, -fyiz, yiz2 * c.fy};
+    double Ju[6], Jv[6], Jr[6];
+    pose_jac_rows(c, p, iz, stereo, Ju, Jv, Jr);
     accumulate_row<0>(Ju, e[0], wi, acc);
     accumulate_row<1>(Jv, e[1], wi, acc);
-    if (stereo) {
-        const double tb = c.bf * iz2;
-        const double Jr[6] = {Ju[0] - tb * y, Ju[1] + tb * x, Ju[2], Ju[3], 0, Ju[5] - tb};
-        accumulate_row<2>(Jr, e[2], wi, acc);
-    }
+    if (stereo) accumulate_row<2>(Jr, e[2], wi, acc);
 }
 
 #ifdef OSLAM_POSE_PROFILE
