@@ -742,6 +742,7 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
             Seq& s = *c.seq[who[w]];
             Map& m = s.map;
             const std::vector<int> local = m.kfs[s.curKF].ordered;
+            const bool useHist = !m.lvlOverflow;
             for (int k : local) {
                 if (k == 0) continue;
                 const KeyFrm& kf = m.kfs[k];
@@ -753,13 +754,17 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                 const int keepAt = ub / 10 + 2;
                 int nRed = 0, nMPs = 0;
                 for (int i = 0; i < kf.N && nMPs - nRed < keepAt; i++) {
-                    prefetch_okp_ahead(m.mps, kf.mp, i, kf.N);
+                    if (!useHist) prefetch_okp_ahead(m.mps, kf.mp, i, kf.N);
                     const int p = kf.mp[i];
                     if (p < 0 || m.pBad[p]) continue;
                     if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
                     nMPs++;
                     if (m.pNObs[p] > 3) {
                         const int lvl = kf.keysUn[i].octave;
+                        // "three OTHER observations at octave <= lvl + 1": the point's octave histogram counts ALL its observations there; with four or more the
+                        // answer is yes and with two or fewer no, whether or not this keyframe's own observation is among them (Map::pLvl).  Exactly three: the lists.
+                        const int all_le = useHist ? m.lvl_count_le(p, lvl + 1) : 3;
+                        if (all_le != 3) { nRed += all_le >= 4; continue; }
                         int n = 0;
                         const MapPt& mq = m.mps[p];
                         for (size_t oi = 0; oi < mq.obs.size(); oi++) {
@@ -1984,6 +1989,11 @@ static int64_t map_violations(const Map& m) {
             // keypoints of the current keyframe can triangulate against the same neighbour keypoint and the second AddMapPoint wins)
             if (e.second < 0 || e.second >= k.N) { bad++; continue; }
             n += k.uRight[e.second] >= 0 ? 2 : 1;
+        }
+        if (!m.lvlOverflow) {   // the octave histogram KeyFrameCulling trusts equals the lists
+            uint64_t h = 0;
+            for (auto& o : mp.okp) h += 1ull << (8 * (o.octave & 7));
+            if (h != m.pLvl[p]) bad++;
         }
         if (n != m.pNObs[p]) { bad++; if (getenv("OSLAM_SLAM_DEBUG")) fprintf(stderr, "violation: point %d nObs %d != %d\n", (int)p, m.pNObs[p], n); }
     }

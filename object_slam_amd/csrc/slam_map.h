@@ -191,6 +191,26 @@ struct Map {
     // rank) never stay in a cache from one frame to the next.
     std::vector<int> pNObs, pVisible, pFound, pLastSeen, pReplaced;
     std::vector<uint8_t> pBad;
+    // Octave histogram of a point's observations, byte o of pLvl[p] = observations whose keypoint has octave o (kept beside obs / okp by the four functions that
+    // change the lists).  KeyFrameCulling asks "at least three OTHER observations at octave <= l + 1": the histogram answers it without walking the lists unless
+    // exactly three observations qualify (then it matters whether the keyframe's own observation is one of them).  lvlOverflow: a count reached 255 or an octave
+    // was >= 8 — the histogram is then not trusted for this map and the lists are walked as before.
+    std::vector<uint64_t> pLvl;
+    bool lvlOverflow = false;
+    void lvl_add(int p, int oct) {
+        if ((unsigned)oct >= 8u || ((pLvl[p] >> (8 * oct)) & 0xFFull) == 0xFFull) { lvlOverflow = true; return; }
+        pLvl[p] += 1ull << (8 * oct);
+    }
+    void lvl_sub(int p, int oct) {
+        if ((unsigned)oct >= 8u || ((pLvl[p] >> (8 * oct)) & 0xFFull) == 0ull) { lvlOverflow = true; return; }
+        pLvl[p] -= 1ull << (8 * oct);
+    }
+    int lvl_count_le(int p, int oct) const {   // observations of p at octave <= oct (valid while !lvlOverflow)
+        const uint64_t h = oct >= 7 ? pLvl[p] : (pLvl[p] & ((1ull << (8 * (oct + 1))) - 1ull));
+        uint64_t s2 = (h & 0x00FF00FF00FF00FFull) + ((h >> 8) & 0x00FF00FF00FF00FFull);   // four 16-bit partial sums
+        s2 = (s2 & 0x0000FFFF0000FFFFull) + ((s2 >> 16) & 0x0000FFFF0000FFFFull);
+        return (int)((s2 & 0xFFFFFFFFull) + (s2 >> 32));
+    }
     int new_point(const float x[3], int refKF, int refFrame) {
         MapPt p;
         p.pos[0] = x[0]; p.pos[1] = x[1]; p.pos[2] = x[2];
@@ -198,7 +218,7 @@ struct Map {
         p.firstKF = refKF; p.firstFrame = refFrame; p.refKF = refKF;
         mps.push_back(p);
         pNObs.push_back(0); pVisible.push_back(1); pFound.push_back(1);   // src/MapPoint.cc:33-46
-        pLastSeen.push_back(0); pReplaced.push_back(-1); pBad.push_back(0);
+        pLastSeen.push_back(0); pReplaced.push_back(-1); pBad.push_back(0); pLvl.push_back(0);
         return (int)mps.size() - 1;
     }
     void add_observation(int p, int kf, int idx) {   // :196-207
@@ -210,6 +230,7 @@ struct Map {
         const ObsKp o = {k.keysUn[idx].x, k.keysUn[idx].y, k.uRight[idx], k.keysUn[idx].octave};
         m.obs.insert(m.obs.begin() + at, std::make_pair(kf, idx));
         m.okp.insert(m.okp.begin() + at, o);
+        lvl_add(p, o.octave);
         pNObs[p] += o.ur >= 0 ? 2 : 1;
         m.obsVer++;
     }
@@ -220,6 +241,7 @@ struct Map {
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
         m.okp.clear();
+        pLvl[p] = 0;
         for (auto& e : o) kfs[e.first].mp[e.second] = -1;
     }
     void erase_observation(int p, int kf) {          // :209-239
@@ -229,6 +251,7 @@ struct Map {
             if (m.obs[i].first == kf) {
                 pNObs[p] -= m.okp[i].ur >= 0 ? 2 : 1;
                 m.obs.erase(m.obs.begin() + i);
+                lvl_sub(p, m.okp[i].octave);
                 m.okp.erase(m.okp.begin() + i);
                 m.obsVer++;
                 if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
@@ -244,6 +267,7 @@ struct Map {
         std::vector<std::pair<int, int>> o;
         o.swap(m.obs);
         m.okp.clear();
+        pLvl[p] = 0;
         if (!pBad[p]) { nMPsInMap--; }
         pBad[p] = 1;
         pReplaced[p] = by;
