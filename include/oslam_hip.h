@@ -465,6 +465,14 @@ int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*
  * (the two functions below) this writes its results into the records d_items[i] = (slot, id): position (d_Pos) + normal / distances (d_out5) when do_normal,
  * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; a point without observations (culled) keeps its record except
  * for the position, which the caller may have changed before culling it (local BA). */
+/* MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:432-474) for P points of solved local-BA windows, as Optimizer::LocalBundleAdjustment's write-back calls it
+ * per point (src/Optimizer.cc:769-776), from the windows' own arrays (include/oslam_slam.h oslam_job_mp_window_t, flattened over the windows of a call): point j
+ * has the edges d_e0[j] .. d_e0[j] + d_ne[j] of d_edge_kf / d_erase (window keyframe index, erased flag), its window's camera centres start at row d_kbase[j] of
+ * d_Ow, d_ref[j] = window index of its reference keyframe, d_lsf[j] = that observation's level scale factor, d_skip[j] != 0 = position only.  Results as
+ * oslam_mp_update_normal_depth in d_out5; with d_tab the resident records (d_items[2 j], d_items[2 j + 1]) are updated in the same pass. */
+int oslam_mp_update_windows_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_e0, const int32_t* d_ne, const int32_t* d_kbase, const int32_t* d_ref,
+                                   const float* d_lsf, const uint8_t* d_skip, const float* d_Pos, const int32_t* d_edge_kf, const uint8_t* d_erase, const float* d_Ow, float lastScale,
+                                   float* d_out5, void* stream);
 int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_obs_start, const int32_t* d_desc_start, const float* d_Pos,
                                 const float* d_out5, const uint8_t* d_out_desc, int do_desc, int do_normal, void* stream);
 /* Inputs of Optimizer::PoseOptimization (src/Optimizer.cc:258-340) for a batch of frames that are still on the device: frame b is frame d_slots[b] of the

@@ -152,6 +152,25 @@ typedef struct oslam_job_mp_update {       /* MapPoint::ComputeDistinctiveDescri
     int32_t* best_idx; uint8_t* out_desc; float* out5;      /* out: see oslam_mp_distinctive_descriptors / oslam_mp_update_normal_depth */
 } oslam_job_mp_update_t;
 
+typedef struct oslam_job_mp_window {       /* MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:432-474) for the points of ONE solved local-BA window, straight from the
+                                            * window's own arrays — what Optimizer::LocalBundleAdjustment's write-back does per point (src/Optimizer.cc:769-776:
+                                            * SetWorldPos, UpdateNormalAndDepth) after the outlier observations were erased (:752-757).  The observations of a point
+                                            * are the window's edges of that point that were not erased: the driver lists a point here only when that holds (every
+                                            * observing keyframe is in the window and alive); the others go through mp_update as before. */
+    int32_t slot;                          /* sequence slot: the resident records (slot, pt_ids[j]) are updated like oslam_job_mp_update_t::items */
+    int32_t nP, nE, nK;
+    const int32_t* pt_ids;                 /* [nP] map point ids */
+    const int32_t* pt_start;               /* [nP + 1] the edges of point j are pt_start[j] .. pt_start[j + 1], in the order of its observation list */
+    const int32_t* edge_kf;                /* [nE] window index of the observing keyframe */
+    const uint8_t* erase;                  /* [nE] != 0: the observation was erased by the write-back */
+    const uint8_t* skip;                   /* [nP] != 0: position only (the point went bad in the write-back, or is updated through mp_update) */
+    const int32_t* ref_kf;                 /* [nP] window index of the point's reference keyframe (after the write-back) */
+    const float* lsf;                      /* [nP] mvScaleFactors[octave of the reference keyframe's observation] */
+    const float* Ow;                       /* [nK][3] camera centres after the write-back */
+    const float* pos;                      /* [nP][3] positions after the write-back */
+    float* out5;                           /* out [nP][5]: normal, mfMaxDistance, mfMinDistance (oslam_mp_update_normal_depth); untouched rows for skipped points */
+} oslam_job_mp_window_t;
+
 typedef struct oslam_job_fuse {            /* search half of ORBmatcher::Fuse on one keyframe, src/ORBmatcher.cc:888-947 */
     int32_t N; const oslam_keypoint_t* keysUn; const float* uRight; const uint8_t* desc;
     int32_t M; const oslam_proj_query_t* queries;
@@ -271,6 +290,9 @@ typedef struct oslam_slam_ops {
      * calls `lba` where it would have waited. */
     int (*lba_submit)(void* ctx, int n, const oslam_lba_problem_t* probs);
     int (*lba_wait)(void* ctx);
+    /* optional: the MapPoint updates after a local BA from the solved windows themselves (oslam_job_mp_window_t).  NULL: the driver packs every point's
+     * observations into an oslam_job_mp_update_t as for any other update. */
+    int (*mp_update_windows)(void* ctx, int n, oslam_job_mp_window_t* wins);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

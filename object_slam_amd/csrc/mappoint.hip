@@ -649,6 +649,56 @@ int oslam_mp_table_write_device(int P, const int32_t* d_items, uint8_t* const* d
     return OSLAM_OK;
 }
 
+// MapPoint::UpdateNormalAndDepth for the points of solved local-BA windows (include/oslam_slam.h oslam_job_mp_window_t), one thread per point: the observations
+// are the point's window edges that the write-back did not erase, the camera centres come from the windows' own keyframe tables.  Same float arithmetic, in
+// the same order, as k_update_normal_depth over the packed observation list; the resident record (position always, normal / distances unless skipped) is written
+// in the same pass (k_mp_table_write's layout).
+__global__ __launch_bounds__(256) void k_mp_windows(int P, const int32_t* items, uint8_t* const* tab, const int32_t* e0, const int32_t* ne, const int32_t* kbase, const int32_t* ref,
+                                                    const float* lsf, const uint8_t* skip, const float* Pos, const int32_t* edge_kf, const uint8_t* erase, const float* Ow,
+                                                    float lastScale, float* out5) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const float px = Pos[p * 3], py = Pos[p * 3 + 1], pz = Pos[p * 3 + 2];
+    float* rec = tab ? (float*)(tab[items[2 * p]] + (size_t)items[2 * p + 1] * 64) : nullptr;
+    if (rec) { rec[0] = px; rec[1] = py; rec[2] = pz; }   // SetWorldPos happened whatever became of the point
+    float* o = out5 + (size_t)p * 5;
+    if (skip[p]) { for (int k = 0; k < 5; k++) o[k] = 0.f; return; }
+    const int s = e0[p], n = ne[p], kb = kbase[p];
+    float nx = 0, ny = 0, nz = 0;
+    int cnt = 0;
+    for (int i = 0; i < n; i++) {
+        if (erase[s + i]) continue;
+        const float* c = Ow + (size_t)(kb + edge_kf[s + i]) * 3;
+        const float ax = px - c[0], ay = py - c[1], az = pz - c[2];
+        const float inv = (float)(1.0 / norm3d(ax, ay, az));   // cv::scaleAdd with float alpha
+        nx = ax * inv + nx;
+        ny = ay * inv + ny;
+        nz = az * inv + nz;
+        cnt++;
+    }
+    if (cnt == 0) { for (int k = 0; k < 5; k++) o[k] = 0.f; return; }
+    const float* cr = Ow + (size_t)(kb + ref[p]) * 3;
+    const float dist = (float)norm3d(px - cr[0], py - cr[1], pz - cr[2]);
+    const float maxD = dist * lsf[p];
+    const float invn = (float)(1.0 / (double)cnt);   // convertTo(alpha = 1/n): float scale
+    const float r0 = nx * invn + 0.0f, r1 = ny * invn + 0.0f, r2 = nz * invn + 0.0f, minD = __fdiv_rn(maxD, lastScale);
+    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = maxD; o[4] = minD;
+    if (rec) { rec[3] = r0; rec[4] = r1; rec[5] = r2; rec[6] = minD; rec[7] = maxD; }
+}
+
+int oslam_mp_update_windows_device(int P, const int32_t* d_items, uint8_t* const* d_tab, const int32_t* d_e0, const int32_t* d_ne, const int32_t* d_kbase, const int32_t* d_ref,
+                                   const float* d_lsf, const uint8_t* d_skip, const float* d_Pos, const int32_t* d_edge_kf, const uint8_t* d_erase, const float* d_Ow, float lastScale,
+                                   float* d_out5, void* stream) {
+    if (P < 0 || (P > 0 && (!d_e0 || !d_ne || !d_kbase || !d_ref || !d_lsf || !d_skip || !d_Pos || !d_edge_kf || !d_erase || !d_Ow || !d_out5 || (d_tab && !d_items)))) {
+        set_error("mp_update_windows: bad argument"); return OSLAM_E_INVALID;
+    }
+    if (P == 0) return OSLAM_OK;
+    hipLaunchKernelGGL(k_mp_windows, dim3(div_up(P, 256)), dim3(256), 0, (hipStream_t)stream, P, d_items, d_tab, d_e0, d_ne, d_kbase, d_ref, d_lsf, d_skip, d_Pos, d_edge_kf, d_erase,
+                       d_Ow, lastScale, d_out5);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream) {
     if (P < 0 || (P > 0 && (!d_obs_start || !d_obs_desc || !d_best_idx || !d_out_desc))) { set_error("bad argument"); return OSLAM_E_INVALID; }
     if (P == 0) return OSLAM_OK;

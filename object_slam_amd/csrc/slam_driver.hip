@@ -207,6 +207,9 @@ struct Ctx {
         int si = -1, nLocal = 0, nFree = 0;   // nFree: window indices below it are free poses (== nLocal unless the window was degraded)
         std::vector<int> kfs, pts; std::vector<float> poses, points, eobs, einv, poses_out, points_out; std::vector<uint8_t> fixed, erase;
         std::vector<int32_t> ekf, ept; std::vector<std::pair<int, int>> eref;
+        // for the MapPoint updates after the solve (oslam_job_mp_window_t): first edge of every point, octave of every edge's keypoint, points with an observation
+        // outside the window (in a culled keyframe), and the job's own arrays
+        std::vector<int32_t> pstart, uref; std::vector<uint8_t> eoct, pquirk, uskip; std::vector<float> ulsf, uOw, uout5;
         void reset() { kfs.clear(); pts.clear(); poses.clear(); points.clear(); eobs.clear(); einv.clear(); poses_out.clear(); points_out.clear(); fixed.clear(); erase.clear(); ekf.clear(); ept.clear(); eref.clear(); nLocal = 0; }
     };
     std::vector<Win> winPool;
@@ -704,6 +707,7 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
     const int flags = c.cfg.local_mapping;
     const int nW = (int)who.size();
     auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
+    const bool useWin = c.ops.mp_update_windows != nullptr;
     if (flags & 8) {
         pool.parallel_for((int)wins.size(), [&](int wi) {
             Win& W = *wins[wi];
@@ -724,13 +728,73 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                 M4 T; memcpy(T.m, &W.poses_out[(size_t)q * 16], 64);
                 m.kfs[W.kfs[q]].pose.set_keyframe(T);
             }
-            for (size_t j = 0; j < W.pts.size(); j++) {
-                if (j + kPF < W.pts.size()) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
-                MapPt& mp = m.mps[W.pts[j]];
-                for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
-                s.updList.push_back(W.pts[j]);
+            if (!useWin) {
+                for (size_t j = 0; j < W.pts.size(); j++) {
+                    if (j + kPF < W.pts.size()) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
+                    MapPt& mp = m.mps[W.pts[j]];
+                    for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
+                    s.updList.push_back(W.pts[j]);
+                }
+                return;
             }
+            // UpdateNormalAndDepth from the window itself (oslam_job_mp_window_t): per point only the reference keyframe's window index and level scale factor
+            // are looked up here; the positions are written together with the results below.  A point with an observation the window does not carry, or
+            // whose reference keyframe's observation is not among its surviving edges, takes the general path (position now, update through mp_update).
+            const size_t nP = W.pts.size(), nK = W.kfs.size();
+            std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
+            for (size_t q = 0; q < nK; q++) slot[W.kfs[q]] = (int)q + 1;
+            W.uOw.resize(nK * 3);
+            for (size_t q = 0; q < nK; q++) memcpy(&W.uOw[q * 3], m.kfs[W.kfs[q]].pose.Ow, 12);
+            W.uskip.assign(nP, 0); W.uref.assign(nP, 0); W.ulsf.assign(nP, 1.f); W.uout5.resize(nP * 5 + 5);
+            for (size_t j = 0; j < nP; j++) {
+                const int p = W.pts[j];
+                if (j + kPF < nP && !m.pBad[W.pts[j + kPF]]) __builtin_prefetch(&m.mps[W.pts[j + kPF]].refKF);
+                if (m.pBad[p]) { W.uskip[j] = 1; continue; }
+                int q = -1, eRef = -1;
+                if (!W.pquirk[j]) {
+                    const int rk = m.mps[p].refKF;
+                    q = rk >= 0 ? slot[rk] - 1 : -1;
+                    if (q >= 0)
+                        for (int e = W.pstart[j]; e < W.pstart[j + 1]; e++)
+                            if (W.ekf[e] == q && !W.erase[e]) { eRef = e; break; }
+                }
+                if (eRef < 0) {   // general path
+                    W.uskip[j] = 2;
+                    MapPt& mp = m.mps[p];
+                    for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
+                    s.updList.push_back(p);
+                    continue;
+                }
+                W.uref[j] = q; W.ulsf[j] = c.scale[W.eoct[eRef]];
+            }
+            for (size_t q = 0; q < nK; q++) slot[W.kfs[q]] = 0;
         });
+        if (useWin && !wins.empty()) {
+            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
+            std::vector<oslam_job_mp_window_t> wj(wins.size());
+            for (size_t wi = 0; wi < wins.size(); wi++) {
+                Win& W = *wins[wi];
+                oslam_job_mp_window_t& j = wj[wi];
+                j.slot = W.si; j.nP = (int32_t)W.pts.size(); j.nE = (int32_t)W.ekf.size(); j.nK = (int32_t)W.kfs.size();
+                j.pt_ids = W.pts.data(); j.pt_start = W.pstart.data(); j.edge_kf = W.ekf.data(); j.erase = W.erase.data(); j.skip = W.uskip.data(); j.ref_kf = W.uref.data();
+                j.lsf = W.ulsf.data(); j.Ow = W.uOw.data(); j.pos = W.points_out.data(); j.out5 = W.uout5.data();
+            }
+            if ((rc = c.ops.mp_update_windows(c.ops.ctx, (int)wj.size(), wj.data()))) return rc;
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+            pool.parallel_for((int)wins.size(), [&](int wi) {
+                Win& W = *wins[wi];
+                Map& m = c.seq[W.si]->map;
+                for (size_t j = 0; j < W.pts.size(); j++) {
+                    if (j + kPF < W.pts.size() && W.uskip[j + kPF] != 2) __builtin_prefetch(&m.mps[W.pts[j + kPF]]);
+                    if (W.uskip[j] == 2) continue;   // (took the general path: position already written)
+                    MapPt& mp = m.mps[W.pts[j]];
+                    for (int d = 0; d < 3; d++) mp.pos[d] = W.points_out[j * 3 + d];
+                    if (W.uskip[j]) continue;
+                    const float* o = &W.uout5[j * 5];
+                    mp.normal[0] = o[0]; mp.normal[1] = o[1]; mp.normal[2] = o[2]; mp.maxD = o[3]; mp.minD = o[4];
+                }
+            });
+        }
         merge_upd();
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
         if ((rc = upd.run(c, false, true))) return rc;
@@ -1324,18 +1388,20 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             std::vector<int>& slot = s.counter;   // keyframe id -> window index + 1 (restored to 0 below)
             for (int q = 0; q < W.nLocal; q++) slot[W.kfs[q]] = q + 1;
             W.points.resize(W.pts.size() * 3);
-            W.ekf.resize(edgeCap); W.ept.resize(edgeCap); W.eobs.resize(edgeCap * 3); W.einv.resize(edgeCap); W.eref.resize(edgeCap);
+            W.ekf.resize(edgeCap); W.ept.resize(edgeCap); W.eobs.resize(edgeCap * 3); W.einv.resize(edgeCap); W.eref.resize(edgeCap); W.eoct.resize(edgeCap);
+            W.pstart.resize(W.pts.size() + 1); W.pquirk.assign(W.pts.size(), 0);
             size_t ne = 0;
             for (size_t j = 0; j < W.pts.size(); j++) {
                 prefetch_okp_ahead(m.mps, W.pts, j, W.pts.size());
                 const int p = W.pts[j];
                 const MapPt& mp = m.mps[p];
+                W.pstart[j] = (int32_t)ne;
                 for (int d = 0; d < 3; d++) W.points[j * 3 + d] = mp.pos[d];
                 for (size_t oi = 0; oi < mp.obs.size(); oi++) {
                     const int kid = mp.obs[oi].first;
                     int q = slot[kid];
                     if (q == 0) {
-                        if (m.kfs[kid].bad) continue;
+                        if (m.kfs[kid].bad) { W.pquirk[j] = 1; continue; }   // (an observation the window does not carry: this point's update takes the general path)
                         W.kfs.push_back(kid);
                         slot[kid] = q = (int)W.kfs.size();
                     }
@@ -1343,11 +1409,13 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     W.ekf[ne] = q - 1; W.ept[ne] = (int)j;
                     W.eobs[ne * 3] = kp.x; W.eobs[ne * 3 + 1] = kp.y; W.eobs[ne * 3 + 2] = kp.ur;
                     W.einv[ne] = c.invSigma2[kp.octave];
+                    W.eoct[ne] = (uint8_t)kp.octave;
                     W.eref[ne] = std::make_pair(kid, p);
                     ne++;
                 }
             }
-            W.ekf.resize(ne); W.ept.resize(ne); W.eobs.resize(ne * 3); W.einv.resize(ne); W.eref.resize(ne);
+            W.pstart[W.pts.size()] = (int32_t)ne;
+            W.ekf.resize(ne); W.ept.resize(ne); W.eobs.resize(ne * 3); W.einv.resize(ne); W.eref.resize(ne); W.eoct.resize(ne);
             // A window with more than 128 FREE keyframes (768 unknowns) is beyond the local-BA operator (OSLAM_E_CAPACITY).  The reference has no such bound.  The
             // window is kept, DEGRADED: m.kfs[cur].ordered is weight-descending, so the current keyframe and its strongest covisible keyframes stay free up to the
             // bound and the remaining local keyframes enter as fixed cameras (fixed = 1): their points and edges are still in the window, points and the strongest

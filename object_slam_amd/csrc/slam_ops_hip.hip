@@ -941,6 +941,71 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     return OSLAM_OK;
 }
 
+// MapPoint::UpdateNormalAndDepth after a local BA, from the solved windows themselves (oslam_job_mp_window_t): the windows' arrays go up as they are (5 bytes per
+// edge, ~40 per point — no walk over the map), one launch over all points of all windows, the 20-byte results come back; the resident records are updated in
+// the same kernel.
+int h_mp_update_windows(void* p, int n, oslam_job_mp_window_t* wins) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    size_t P = 0, E = 0, K = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_mp_window_t& w = wins[i];
+        if (w.nP < 0 || w.nE < 0 || w.nK < 1 || w.slot < 0 || w.slot >= o->S || (w.nP > 0 && (!w.pt_ids || !w.pt_start || !w.skip || !w.ref_kf || !w.lsf || !w.pos || !w.out5)) ||
+            (w.nE > 0 && (!w.edge_kf || !w.erase)) || !w.Ow) { oslam::set_error("mp_update_windows: bad window"); return OSLAM_E_INVALID; }
+        P += w.nP; E += w.nE; K += w.nK;
+    }
+    if (P == 0) return OSLAM_OK;
+    const bool table = o->mp_tab_on;
+    if (table) {
+        for (int i = 0; i < n; i++) {
+            int mx = -1;
+            for (int j = 0; j < wins[i].nP; j++) mx = std::max(mx, wins[i].pt_ids[j]);
+            if (mx >= 0) OPS_CHECK(o->ensure_mp_records(wins[i].slot, (size_t)mx + 1));
+        }
+        OPS_CHECK(o->sync_mp_table());
+    }
+    Layout L;
+    const size_t oItems = L.take(8 * P), oE0 = L.take(4 * P), oNe = L.take(4 * P), oKb = L.take(4 * P), oRef = L.take(4 * P), oLsf = L.take(4 * P), oSkip = L.take(P), oPos = L.take(12 * P),
+                 oEkf = L.take(4 * E), oEr = L.take(E), oOw = L.take(12 * K);
+    const size_t in_bytes = L.off;
+    const size_t oOut = L.take(20 * P);
+    OPS_CHECK(o->ensure_up(L.off));
+    uint8_t* U = o->up_h;
+    uint8_t* Dv = o->up_d;
+    std::vector<size_t> pb(n + 1, 0), eb(n + 1, 0), kb(n + 1, 0);
+    for (int i = 0; i < n; i++) { pb[i + 1] = pb[i] + wins[i].nP; eb[i + 1] = eb[i] + wins[i].nE; kb[i + 1] = kb[i] + wins[i].nK; }
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_job_mp_window_t& w = wins[i];
+        int32_t* it = (int32_t*)(U + oItems) + 2 * pb[i];
+        int32_t* e0 = (int32_t*)(U + oE0) + pb[i];
+        int32_t* ne = (int32_t*)(U + oNe) + pb[i];
+        int32_t* kq = (int32_t*)(U + oKb) + pb[i];
+        for (int j = 0; j < w.nP; j++) {
+            it[2 * j] = w.slot; it[2 * j + 1] = w.pt_ids[j];
+            e0[j] = (int32_t)eb[i] + w.pt_start[j]; ne[j] = w.pt_start[j + 1] - w.pt_start[j]; kq[j] = (int32_t)kb[i];
+        }
+        memcpy((int32_t*)(U + oRef) + pb[i], w.ref_kf, 4 * (size_t)w.nP);
+        memcpy((float*)(U + oLsf) + pb[i], w.lsf, 4 * (size_t)w.nP);
+        memcpy(U + oSkip + pb[i], w.skip, (size_t)w.nP);
+        memcpy((float*)(U + oPos) + 3 * pb[i], w.pos, 12 * (size_t)w.nP);
+        memcpy((int32_t*)(U + oEkf) + eb[i], w.edge_kf, 4 * (size_t)w.nE);
+        memcpy(U + oEr + eb[i], w.erase, (size_t)w.nE);
+        memcpy((float*)(U + oOw) + 3 * kb[i], w.Ow, 12 * (size_t)w.nK);
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
+    OPS_CHECK(oslam_mp_update_windows_device((int)P, (const int32_t*)(Dv + oItems), table ? o->d_mp_tab : nullptr, (const int32_t*)(Dv + oE0), (const int32_t*)(Dv + oNe),
+                                             (const int32_t*)(Dv + oKb), (const int32_t*)(Dv + oRef), (const float*)(Dv + oLsf), Dv + oSkip, (const float*)(Dv + oPos),
+                                             (const int32_t*)(Dv + oEkf), Dv + oEr, (const float*)(Dv + oOw), o->scale[o->cfg.nLevels - 1], (float*)(Dv + oOut), o->strm));
+    o->t_end();
+    OPS_CHECK(o->ensure_dn(20 * P));
+    OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, Dv + oOut, 20 * P, o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    o->t_collect(6, 1, (double)E);
+    o->pool->parallel_for(n, [&](int i) { memcpy(wins[i].out5, o->dn_h + 20 * pb[i], 20 * (size_t)wins[i].nP); });
+    return OSLAM_OK;
+}
+
 // fp64 work of one local BA: per LM trial 700 flop per edge (linearise + accumulate), Schur 324 k_p^2 per point, Cholesky (6K)^3/3,
 // back-substitution 2(6K)^2 + 45P; trials = stats[1] + stats[3]
 static double lba_flop(const oslam_lba_problem_t& q, const int32_t st[4]) {
@@ -1634,6 +1699,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     }
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
+    if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }

@@ -22,7 +22,7 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes", "lba_submit", "lba_wait")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes", "lba_submit", "lba_wait", "mp_update_windows")]
 
 
 class SlamObjects(C.Structure):
