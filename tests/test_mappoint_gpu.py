@@ -57,6 +57,64 @@ def test_update_normal_and_depth():
         assert np.array_equal(out[p].view(np.uint32), ref.view(np.uint32)), p
 
 
+def test_update_normal_and_depth_from_local_ba_windows():
+    """oslam_mp_update_windows_device (the MapPoint updates after a local BA, from the solved windows' own arrays: include/oslam_slam.h oslam_job_mp_window_t)
+    against the oracle's UpdateNormalAndDepth over the surviving observations of every point — bit for bit — incl. erased edges, skipped points, several windows
+    per call and the resident records."""
+    import ctypes as C
+    import torch
+    from object_slam_amd._lib import lib, check
+    from oracle import oracle_py as O
+    L = lib()
+    rng = np.random.default_rng(11)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    wins, P, E, Kt = [], 0, 0, 0
+    for w in range(3):
+        K, nP = int(rng.integers(3, 30)), int(rng.integers(50, 400))
+        Ow = rng.normal(0, 3, (K, 3)).astype(np.float32)
+        pos = rng.normal(0, 5, (nP, 3)).astype(np.float32)
+        pstart, ekf, erase, ref, lsf, skip = [0], [], [], [], [], []
+        for j in range(nP):
+            kfs = np.sort(rng.choice(K, int(rng.integers(2, min(K, 12) + 1)), replace=False))
+            er = (rng.random(len(kfs)) < 0.15).astype(np.uint8)
+            if er.all():
+                er[0] = 0
+            live = kfs[er == 0]
+            ekf += kfs.tolist(); erase += er.tolist(); pstart.append(len(ekf))
+            ref.append(int(live[rng.integers(0, len(live))])); lsf.append(float(sf[rng.integers(0, 8)])); skip.append(int(rng.random() < 0.05))
+        wins.append(dict(K=K, nP=nP, Ow=Ow, pos=pos, pstart=np.array(pstart, np.int32), ekf=np.array(ekf, np.int32), erase=np.array(erase, np.uint8), ref=np.array(ref, np.int32),
+                         lsf=np.array(lsf, np.float32), skip=np.array(skip, np.uint8), p0=P, e0=E, k0=Kt))
+        P += nP; E += len(ekf); Kt += K
+    cat = lambda f: np.concatenate([f(w) for w in wins])
+    e0 = cat(lambda w: w["e0"] + w["pstart"][:-1]).astype(np.int32)
+    ne = cat(lambda w: np.diff(w["pstart"])).astype(np.int32)
+    kbase = cat(lambda w: np.full(w["nP"], w["k0"])).astype(np.int32)
+    items = np.stack([np.zeros(P, np.int32), np.arange(P, dtype=np.int32)], 1)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tab = torch.full((P, 16), 7.0, dtype=torch.float32, device="cuda")
+    tabp = torch.tensor([tab.data_ptr()], dtype=torch.int64, device="cuda")
+    d = dict(items=dev(items), e0=dev(e0), ne=dev(ne), kb=dev(kbase), ref=dev(cat(lambda w: w["ref"])), lsf=dev(cat(lambda w: w["lsf"])), skip=dev(cat(lambda w: w["skip"])),
+             pos=dev(cat(lambda w: w["pos"])), ekf=dev(cat(lambda w: w["ekf"])), er=dev(cat(lambda w: w["erase"])), Ow=dev(cat(lambda w: w["Ow"])))
+    out = torch.zeros((P, 5), dtype=torch.float32, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    check(L.oslam_mp_update_windows_device(P, vp(d["items"]), vp(tabp), vp(d["e0"]), vp(d["ne"]), vp(d["kb"]), vp(d["ref"]), vp(d["lsf"]), vp(d["skip"]), vp(d["pos"]), vp(d["ekf"]),
+                                           vp(d["er"]), vp(d["Ow"]), C.c_float(float(sf[-1])), vp(out), None))
+    torch.cuda.synchronize()
+    out, rec = out.cpu().numpy(), tab.cpu().numpy()
+    for w in wins:
+        for j in range(w["nP"]):
+            g = w["p0"] + j
+            assert np.array_equal(rec[g, :3], w["pos"][j])
+            if w["skip"][j]:
+                assert not out[g].any() and (rec[g, 3:8] == 7.0).all()
+                continue
+            sl = slice(w["pstart"][j], w["pstart"][j + 1])
+            live = w["ekf"][sl][w["erase"][sl] == 0]
+            ref = O.update_normal_depth(w["pos"][j], w["Ow"][live], w["Ow"][w["ref"][j]], w["lsf"][j], sf[-1])
+            assert np.array_equal(out[g].view(np.uint32), ref.view(np.uint32)), (g, out[g], ref)
+            assert np.array_equal(rec[g, 3:6], ref[:3]) and rec[g, 6] == ref[4] and rec[g, 7] == ref[3] and (rec[g, 8:] == 7.0).all()
+
+
 @pytest.mark.parametrize("th", [1.0, 3.0])
 def test_is_in_frustum(th):
     from object_slam_amd import MapPointBatch, ORBmatcher, QUERY_DTYPE

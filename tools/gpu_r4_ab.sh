@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OSLAM_LIB_PATH=$PWD/tools/_build/liboslam_hip_FP.so timeout -k 10 200 python tools/fast_phase_prof.py 2>&1 | tail -8
+timeout -k 10 300 python -m pytest tests/test_mappoint_gpu.py tests/test_capi_cpu.py -x -q 2>&1 | tail -15
