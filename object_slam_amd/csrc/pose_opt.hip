@@ -90,7 +90,9 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [2][
 // query can be that pixel: an interior pixel more than half a pixel away in x or y has a 4-neighbour inside the mask that is strictly nearer, and a
 // pixel within one pixel in both x and y is one of the floor / ceil combinations.  (Pixel minus query is exact in float for |difference| <= 1.)
 // px = col | row << 15.
-__device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, float v, int& px, float& d2) {
+// cutoff: the caller only distinguishes distances up to it (d2 < 10 / d2 > 10 gates of the M_semantic creation and the re-gating): rows whose vertical distance
+// alone exceeds it are not visited, and a non-empty mask without a pixel that near reports d2 = +inf (px = 0) — exact whenever the true minimum is <= cutoff.
+__device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, float v, int& px, float& d2, const float cutoff = __builtin_inff()) {
     const int s0 = sm.area_start[o], s1 = sm.area_start[o + 1];
     if (s1 <= s0) return false;   // no boundary pixel = empty mask
     float best = 0;
@@ -129,7 +131,7 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
         while (up || dn) {
             if (up) {
                 const float dy = (float)yu - v;
-                if (bx >= 0 && dy * dy > best) up = false;
+                if ((bx >= 0 && dy * dy > best) || dy * dy > cutoff) up = false;
                 else {
                     const int a = rs[yu], e = yu + 1 < sm.H ? rs[yu + 1] : nb;
                     for (int i = s0 + a; i < s0 + e; i++) consider(sm.area[i].x, yu);
@@ -138,7 +140,7 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
             }
             if (dn) {
                 const float dy = (float)yd - v;
-                if (bx >= 0 && dy * dy > best) dn = false;
+                if ((bx >= 0 && dy * dy > best) || dy * dy > cutoff) dn = false;
                 else {
                     const int a = rs[yd], e = yd + 1 < sm.H ? rs[yd + 1] : nb;
                     for (int i = s0 + a; i < s0 + e; i++) consider(sm.area[i].x, yd);
@@ -147,6 +149,7 @@ __device__ __forceinline__ bool mask_nearest(const SemCtx& sm, int o, float u, f
             }
         }
     }
+    if (bx < 0) { px = 0; d2 = __builtin_inff(); return true; }   // (only with a cutoff: nothing that near)
     px = bx | (by << 15);
     d2 = best;
     return true;
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                 if (u < sm.minX || v < sm.minY || u > sm.maxX || v > sm.maxY) out = true;
                 else {
                     int ni; float d2;
-                    if (!mask_nearest(sm, sm.e_obj[i], u, v, ni, d2)) continue;
+                    if (!mask_nearest(sm, sm.e_obj[i], u, v, ni, d2, 10.f)) continue;
                     out = d2 > 10;
                     if (!out) { sm.e_obs[i * 2] = u; sm.e_obs[i * 2 + 1] = v; }   // measurement := projection (:969-971)
                 }
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(kPoseThreads) POSE_OCC void k_pose_optimize(PoseCtx
                     const float x = __fdiv_rn(Pc[0], Pc[2]), y = __fdiv_rn(Pc[1], Pc[2]);
                     const float u = c.fx * x + c.cx, v = c.fy * y + c.cy;
                     int ni; float d2;
-                    sm.e_tmp[m] = (mask_nearest(sm, o, u, v, ni, d2) && d2 < 10) ? 1 + ni : 0;
+                    sm.e_tmp[m] = (mask_nearest(sm, o, u, v, ni, d2, 10.f) && d2 < 10) ? 1 + ni : 0;
                 }
                 __syncthreads();
                 const int n0 = s_nsem;
