@@ -131,6 +131,11 @@ struct Seq {
     std::vector<int> localKFs, localMPs;
     std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
     std::vector<int> baMark;              // mnBALocalForKF per map point id (dense, see the local-BA gather in run_local_mapping)
+    // UpdateLocalKeyFrames' keyframeCounter kept from frame to frame (update_local_map): vote[k] = matched points of the last voted frame that keyframe k observes,
+    // votePts = those points (one entry per keypoint), valid while voteVersion == mapVersion (observation lists only change under a version bump)
+    std::vector<int> vote, votePts, votePrev;
+    std::vector<int8_t> voteDelta;        // dense by map point id, all zero between calls
+    long long voteVersion = -1;
     // Local-map cache: mvpLocalMapPoints is a function of the ordered local keyframe list and of the map, and the map only changes when this sequence
     // creates a keyframe or its local mapping runs (mapVersion counts both).  A frame whose list and version equal the cached ones reuses the walk of
     // the keyframes' map points AND the packed SearchLocalPoints arrays (whose copy the operator table may keep resident: content id).
@@ -179,6 +184,7 @@ struct Seq {
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
         std::fill(baMark.begin(), baMark.end(), 0);
+        voteVersion = -1; votePts.clear();
         mapVersion++; locVersion = -1; locWalkFrame = -1; locKFs.clear();
         resetRequested = false;
     }
@@ -451,23 +457,60 @@ static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
 static void update_local_map(Seq& s) {
     Map& m = s.map;
     Frame& f = *s.cur;
-    static thread_local std::vector<int> touched;   // scratch: keeps its capacity from frame to frame
-    touched.clear();
+    // keyframeCounter (:1499-1517): for every keypoint with a map point, +1 for every keyframe that observes the point.  The matched set of consecutive frames
+    // differs by 10-20 % and the observation lists only change under a map-version bump, so the counts are kept and only the points that entered or left the
+    // set since the last voted frame walk their observation lists (a full recount after a version change).  OSLAM_SLAM_VOTE_CHECK=1 compares with the recount.
+    s.votePrev.swap(s.votePts);
+    s.votePts.clear();
     for (int i = 0; i < f.N; i++) {
-        prefetch_obs_ahead(m.mps, f.mp, i, f.N);
         const int p = f.mp[i];
         if (p < 0) continue;
         if (m.pBad[p]) { f.mp[i] = -1; continue; }
-        for (auto& e : m.mps[p].obs)
-            if (s.counter[e.first]++ == 0) touched.push_back(e.first);
+        s.votePts.push_back(p);
     }
-    if (!touched.empty()) {
-        std::sort(touched.begin(), touched.end());
+    if (s.vote.size() < m.kfs.size()) s.vote.resize(m.kfs.size() + 16, 0);
+    const std::vector<int>& cur = s.votePts;
+    if (s.voteVersion != s.mapVersion) {   // recount
+        std::fill(s.vote.begin(), s.vote.end(), 0);
+        for (size_t i = 0; i < cur.size(); i++) {
+            prefetch_obs_ahead(m.mps, cur, i, cur.size());
+            for (auto& e : m.mps[cur[i]].obs) s.vote[e.first]++;
+        }
+        s.voteVersion = s.mapVersion;
+    } else {
+        if (s.voteDelta.size() < m.mps.size()) s.voteDelta.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+        int8_t* dl = s.voteDelta.data();
+        for (int p : s.votePrev) dl[p]--;
+        for (int p : cur) dl[p]++;
+        static thread_local std::vector<std::pair<int, int>> chg;   // (point, change of its multiplicity) for the points that entered or left the matched set
+        chg.clear();
+        auto collect = [&](const std::vector<int>& pts) {
+            for (int p : pts) { const int d = dl[p]; if (d != 0) { dl[p] = 0; chg.push_back(std::make_pair(p, d)); } }
+        };
+        collect(s.votePrev);
+        collect(cur);
+        const size_t nc = chg.size();
+        for (size_t i = 0; i < nc; i++) {   // (records and lists of later entries requested ahead: every one of them is a cache miss)
+            if (i + kPF < nc) __builtin_prefetch(&m.mps[chg[i + kPF].first].obs);
+            if (i + kPF / 2 < nc) __builtin_prefetch(m.mps[chg[i + kPF / 2].first].obs.data());
+            const int d = chg[i].second;
+            for (auto& e : m.mps[chg[i].first].obs) s.vote[e.first] += d;
+        }
+    }
+    static const bool vote_check = getenv("OSLAM_SLAM_VOTE_CHECK") != nullptr;
+    if (vote_check) {
+        std::vector<int> ref(s.vote.size(), 0);
+        for (int p : cur) for (auto& e : m.mps[p].obs) ref[e.first]++;
+        if (ref != s.vote) { fprintf(stderr, "OSLAM_SLAM_VOTE_CHECK: the kept keyframe counter differs from the recount (frame %d)\n", f.id); abort(); }
+    }
+    bool any = false;
+    for (size_t k = 0; k < m.kfs.size() && !any; k++) any = s.vote[k] > 0;
+    if (any) {
         int mx = 0, kmax = -1;
         s.localKFs.clear();
-        for (int k : touched) {
-            const int cnt = s.counter[k];
-            s.counter[k] = 0;
+        for (int k = 0; k < (int)m.kfs.size(); k++) {   // (ascending keyframe id: the order of the reference's map, see slam_map.h)
+            const int cnt = s.vote[k];
+            if (cnt == 0) continue;
             if (m.kfs[k].bad) continue;
             if (cnt > mx) { mx = cnt; kmax = k; }
             s.localKFs.push_back(k);

@@ -2,9 +2,9 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r4z
 mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_slam_driver_gpu.py -x -q > $O/pytest_drv.log 2>&1 || { tail -30 $O/pytest_drv.log; exit 1; }
+OSLAM_SLAM_VOTE_CHECK=1 timeout -k 10 600 python -m pytest tests/test_slam_driver_gpu.py -x -q > $O/pytest_drv.log 2>&1 || { tail -30 $O/pytest_drv.log; exit 1; }
 tail -2 $O/pytest_drv.log
-for m in a; do
+for m in a b; do
   timeout -k 10 400 python bench.py --no-extras --no-cpu-baseline > $O/b_$m.json 2> $O/b_$m.err || exit 1
   python - <<PY
 import json
