@@ -131,6 +131,7 @@ struct Seq {
     std::vector<int> localKFs, localMPs;
     std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
     std::vector<int> baMark;              // mnBALocalForKF per map point id (dense, see the local-BA gather in run_local_mapping)
+    std::vector<int> fuseMark;            // mnFuseCandidateForKF per map point id (dense, SearchInNeighbors' second direction)
     // UpdateLocalKeyFrames' keyframeCounter kept from frame to frame (update_local_map): vote[k] = matched points of the last voted frame that keyframe k observes,
     // votePts = those points (one entry per keypoint), valid while voteVersion == mapVersion (observation lists only change under a version bump)
     std::vector<int> vote, votePts, votePrev;
@@ -184,6 +185,7 @@ struct Seq {
         std::fill(counter.begin(), counter.end(), 0);
         std::fill(mpMark.begin(), mpMark.end(), 0);
         std::fill(baMark.begin(), baMark.end(), 0);
+        std::fill(fuseMark.begin(), fuseMark.end(), 0);
         voteVersion = -1; votePts.clear();
         mapVersion++; locVersion = -1; locWalkFrame = -1; locKFs.clear();
         resetRequested = false;
@@ -281,6 +283,8 @@ static int new_keyframe(Seq& s, const Frame& f) {
     k.frameId = f.id; k.stamp = f.stamp; k.N = f.N;
     k.keys.assign(f.keys.begin(), f.keys.begin() + f.N);
     k.keysUn.assign(f.keysUn.begin(), f.keysUn.begin() + f.N);
+    k.oct.resize(f.N);
+    for (int i = 0; i < f.N; i++) k.oct[i] = (uint8_t)f.keysUn[i].octave;   // (KeyFrameCulling reads the octaves alone: 1 byte per keypoint instead of a pass over the 28-byte records)
     k.desc.assign(f.desc.begin(), f.desc.begin() + (size_t)f.N * 32);
     k.uRight.assign(f.uRight.begin(), f.uRight.begin() + f.N);
     k.depth.assign(f.depth.begin(), f.depth.begin() + f.N);
@@ -867,7 +871,7 @@ static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::ve
                     if (kf.depth[i] > c.thDepth || kf.depth[i] < 0) continue;
                     nMPs++;
                     if (m.pNObs[p] > 3) {
-                        const int lvl = kf.keysUn[i].octave;
+                        const int lvl = kf.oct[i];
                         // "three OTHER observations at octave <= lvl + 1": the point's octave histogram counts ALL its observations there; with four or more the
                         // answer is yes and with two or fewer no, whether or not this keyframe's own observation is among them (Map::pLvl).  Exactly three: the lists.
                         const int all_le = useHist ? m.lvl_count_le(p, lvl + 1) : 3;
@@ -1353,16 +1357,18 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             Map& m = s.map;
             const int cur = s.curKF;
             fs[w].pts.clear();
-            for (int k : fs[w].targets)
+            // (mnFuseCandidateForKF as a dense per-sequence array, like baMark: up to 60 targets x 1000 slots per keyframe, most of them already marked)
+            if (s.fuseMark.size() < m.mps.size()) s.fuseMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+            int* fm = s.fuseMark.data();
+            for (int k : fs[w].targets) {
+                const int* kmp = m.kfs[k].mp.data();
                 for (size_t i = 0, n = m.kfs[k].mp.size(); i < n; i++) {
-                    prefetch_ahead(m.mps, m.kfs[k].mp, i, n);
-                    const int p = m.kfs[k].mp[i];
-                    if (p < 0) continue;
-                    MapPt& mp = m.mps[p];
-                    if (m.pBad[p] || mp.fuseCandidateForKF == cur) continue;
-                    mp.fuseCandidateForKF = cur;
+                    const int p = kmp[i];
+                    if (p < 0 || m.pBad[p] || fm[p] == cur) continue;
+                    fm[p] = cur;
                     fs[w].pts.push_back(p);
                 }
+            }
         });
         if ((rc = fuse_round(true, 0))) return rc;
         // update points of the current keyframe (:517-531) and its connections

@@ -124,7 +124,7 @@ struct MapPt {
     int firstKF = 0, firstFrame = 0, refKF = -1;
     std::vector<std::pair<int, int>> obs;        // (keyframe id, keypoint index), ascending keyframe id
     std::vector<ObsKp> okp;                      // okp[i] = the keypoint of obs[i]
-    int trackRefForFrame = 0, fuseCandidateForKF = 0;   // zero-initialised like the reference
+    int trackRefForFrame = 0;   // zero-initialised like the reference
     // driver scratch of SearchInNeighbors: position of the point in the current keyframe's point list (valid while fuseListStamp == current keyframe id + 1)
     int fuseListIdx = 0, fuseListStamp = 0;
     // bookkeeping of the driver (not in the reference): obsVer counts the changes of the observation list; (updVer, updStep) = obsVer and the local-mapping
@@ -161,7 +161,7 @@ struct KeyFrm {
     double stamp = 0;
     int N = 0;
     std::vector<KP> keys, keysUn;
-    std::vector<uint8_t> desc;
+    std::vector<uint8_t> desc, oct;               // oct[i] = keysUn[i].octave
     std::vector<float> uRight, depth;
     std::vector<int> mp;
     std::vector<uint32_t> bowNode;
