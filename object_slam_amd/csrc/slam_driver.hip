@@ -129,7 +129,7 @@ struct Seq {
     int refKF = -1, lastKFFrameId = 0, lastRelocFrameId = 0;
     int matchesInliers = 0;
     std::vector<int> localKFs, localMPs;
-    std::vector<int> mpMark;              // mnTrackReferenceForFrame per map point id (dense, see update_local_map)
+    std::vector<uint64_t> mpMark;         // mnTrackReferenceForFrame of the map points as ONE BIT per point id: set <=> the point was visited by the cached walk (update_local_map)
     std::vector<int> baMark;              // mnBALocalForKF per map point id (dense, see the local-BA gather in run_local_mapping)
     std::vector<int> fuseMark;            // mnFuseCandidateForKF per map point id (dense, SearchInNeighbors' second direction)
     // UpdateLocalKeyFrames' keyframeCounter kept from frame to frame (update_local_map): vote[k] = matched points of the last voted frame that keyframe k observes,
@@ -141,7 +141,7 @@ struct Seq {
     // creates a keyframe or its local mapping runs (mapVersion counts both).  A frame whose list and version equal the cached ones reuses the walk of
     // the keyframes' map points AND the packed SearchLocalPoints arrays (whose copy the operator table may keep resident: content id).
     long long mapVersion = 0, locVersion = -1, locContentId = 0;
-    int locWalkFrame = -1;                // frame id of the cached walk: mpMark[p] == locWalkFrame <=> p was visited by it
+    int locWalkFrame = -1;                // frame id of the cached walk (-1: none)
     bool locReused = false;
     int trkKF = -1, trkMinObs = 0, trkCount = 0; long long trkVersion = -1;   // cached KeyFrame::TrackedMapPoints of the reference keyframe (NeedNewKeyFrame)
     std::vector<int> locKFs, mpPos;       // cached keyframe list; position of a visited point in localMPs (-1: visited but bad)
@@ -183,7 +183,7 @@ struct Seq {
         localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear(); culledKFs.clear();
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
         std::fill(counter.begin(), counter.end(), 0);
-        std::fill(mpMark.begin(), mpMark.end(), 0);
+        std::fill(mpMark.begin(), mpMark.end(), 0ull);
         std::fill(baMark.begin(), baMark.end(), 0);
         std::fill(fuseMark.begin(), fuseMark.end(), 0);
         voteVersion = -1; votePts.clear();
@@ -539,11 +539,16 @@ static void update_local_map(Seq& s) {
     }
     s.locReused = s.locVersion == s.mapVersion && s.locWalkFrame >= 0 && s.localKFs == s.locKFs;
     if (s.locReused) return;   // same ordered keyframe list over an unchanged map: the walk below would rebuild the same list
-    // mnTrackReferenceForFrame of the map points as a dense per-sequence array: the loop below visits 10-20 k keyframe slots per frame and
-    // most of them hit an already marked point, so it should touch 4 bytes per slot, not a 136-byte MapPt.  A bad point is marked too (it
-    // is never pushed either way), which leaves the list unchanged.
-    if (s.mpMark.size() < m.mps.size()) { const size_t n = m.mps.size() + m.mps.size() / 2 + 64; s.mpMark.resize(n, 0); s.mpPos.resize(n, -1); }
-    int* mark = s.mpMark.data();
+    // mnTrackReferenceForFrame of the map points as a per-sequence BITMAP, cleared per walk: the loop below visits 20-80 k keyframe slots and most of them hit
+    // an already marked point; one bit per point id keeps the marks of a whole map (~20 k points) in 2.5 KB — first-level cache — where a stamped int per point
+    // was an 80 KB array that every other sequence's walk had evicted.  A bad point is marked too (it is never pushed either way), which leaves the list unchanged.
+    {
+        const size_t nw = (m.mps.size() + 63) / 64;
+        if (s.mpMark.size() < nw) s.mpMark.resize(nw + nw / 2 + 4, 0ull);
+        if (s.mpPos.size() < m.mps.size()) s.mpPos.resize(m.mps.size() + m.mps.size() / 2 + 64, -1);
+        std::fill(s.mpMark.begin(), s.mpMark.end(), 0ull);
+    }
+    uint64_t* mark = s.mpMark.data();
     int* pos = s.mpPos.data();
     s.localMPs.clear();
     for (int k : s.localKFs) {
@@ -551,8 +556,11 @@ static void update_local_map(Seq& s) {
         const int* kmp = kf.mp.data();
         for (int i = 0; i < kf.N; i++) {
             const int p = kmp[i];
-            if (p < 0 || mark[p] == f.id) continue;
-            mark[p] = f.id;
+            if (p < 0) continue;
+            const uint64_t bit = 1ull << (p & 63);
+            uint64_t& wd = mark[p >> 6];
+            if (wd & bit) continue;
+            wd |= bit;
             if (!m.pBad[p]) { pos[p] = (int)s.localMPs.size(); s.localMPs.push_back(p); }
             else pos[p] = -1;
         }
@@ -1717,9 +1725,10 @@ static void stage_local_map_prepare(Ctx& c, int i) {
     c.locFrames.fetch_add(1, std::memory_order_relaxed);
     s.jSkip.assign(M + 1, 0);
     {
-        const int* mark = s.mpMark.data();
+        const uint64_t* mark = s.mpMark.data();
+        const size_t markBits = s.mpMark.size() * 64;
         const int* pos = s.mpPos.data();
-        auto flag = [&](int p) { if ((size_t)p < s.mpMark.size() && mark[p] == s.locWalkFrame && pos[p] >= 0) s.jSkip[pos[p]] = 1; };
+        auto flag = [&](int p) { if (s.locWalkFrame >= 0 && (size_t)p < markBits && ((mark[p >> 6] >> (p & 63)) & 1ull) && pos[p] >= 0) s.jSkip[pos[p]] = 1; };
         for (int k = 0; k < f.N; k++) if (f.mp[k] >= 0) flag(f.mp[k]);
         for (int p : s.seenList) flag(p);
     }
