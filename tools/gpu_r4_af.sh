@@ -13,5 +13,6 @@ print("$tag", "frames/s", d["value"], "frac", d["roofline"]["frac"], "lba ms", r
 PY
   grep "lba service" $O/b_$tag.err | tail -1
 }
-run noprio OSLAM_LBA_SERVICE_NO_PRIORITY=1
+run tiles OSLAM_LBA_SCHUR_TILES=1
 run base A=1
+run tiles2 OSLAM_LBA_SCHUR_TILES=1
