@@ -900,6 +900,11 @@ __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w) {
 // the memory side as 2.5x the bytes (rocprofv3 WRITE_SIZE 185 MB per launch of 40 windows against 75 MB of blocks: profiles/r03_pmc_lba_traffic.json): the blocks
 // of the workgroup's 256 consecutive edges are contiguous, so they go through LDS and out as 16 bytes per lane, consecutive lanes consecutive addresses.
 // (Inactive edges — outliers, fixed keyframes — get zeros: nothing reads their W.)
+// VINV (round 4, default): the kernel only inverts — (Hll_p + lambda I)^-1 of every landmark as 6 doubles (the cofactor inverse of a symmetric matrix is
+// symmetric bit for bit) at w.W + 6 p — and k_w_schur forms W_e = B_e V^-1 for the operand it needs from the B block it fetched: the 144-byte W blocks (1.9 MB
+// per steady-state window and trial written here, re-read ~8.5 times by the pair gather) no longer exist, both operands of a pair come from ONE array, and
+// this launch shrinks from 145 to ~10 us per 128 windows.  Same products in the same order: the reduced system does not change by a bit.
+template <bool VINV>
 __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -908,8 +913,8 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
     const LbaCtrl* ct = w.ct;
     if (ct->done) return;
     const int e0 = item_ * 256;
-    if (e0 >= pr.E) return;
-    __shared__ double sW[256 * 19];   // 19: one double of padding per block (18 would put the lanes of a wavefront on 16 of the 64 banks)
+    if (e0 >= (VINV ? max(pr.P, 1) : pr.E)) return;   // (VINV: 256 landmarks per workgroup; workgroup 0 always runs — it publishes the control values)
+    __shared__ double sW[VINV ? 1 : 256 * 19];   // 19: one double of padding per block (18 would put the lanes of a wavefront on 16 of the 64 banks)
     __shared__ double s_lambda;
     // LM control after a linearisation (w_ctrlA's values, see w_lambda_eff): lambda of the first trial of a stage = 1e-5 x the largest diagonal entry of the
     // linearised system (computeLambdaInit), from the landmark blocks' partial maxima and the free keyframes' Hpp — by wavefront 0 of every workgroup;
@@ -933,6 +938,20 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
         if (lane == 0) s_lambda = lam;
     }
     __syncthreads();
+    if (VINV) {
+        const int p = e0 + threadIdx.x;
+        if (p >= pr.P) return;
+        const double lambda = s_lambda;
+        double D[9], Di[9];
+        const double* H = pr.Hll + (long long)p * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) D[i] = H[i];
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        inv3(D, Di);
+        double2* out = (double2*)(w.W + (long long)p * 6);
+        out[0] = make_double2(Di[0], Di[1]); out[1] = make_double2(Di[2], Di[4]); out[2] = make_double2(Di[5], Di[8]);
+        return;
+    }
     const int e = e0 + threadIdx.x;
     if (e < pr.E && pr.level[e] == 0 && w.blk[pr.e_kf[e]] >= 0) {
         const double lambda = s_lambda;
@@ -1040,6 +1059,7 @@ __device__ __forceinline__ double dpp_quad_f64(double v) {
 // addresser busy 70-77 % of the launch (TA_BUSY_avr 176 k of 256 k cycles, 46 cache accesses per load instruction) with the vector ALU at 22 %.  Now the
 // wavefront fetches the 128 blocks of a round COOPERATIVELY — 16-byte piece g of the round's 18 KB goes to lane g mod 64, so nine consecutive lanes read one
 // block and a load instruction touches ~21 lines — and hands them to their owners through LDS (half a round at a time: 9.2 KB per wavefront).
+template <bool VINV>
 __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win, t;
     if (!xcd_window_item(nwin, win, t)) return;
@@ -1072,7 +1092,10 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
         const int2 pe = pe_next;
         if (q + 64 < q_end) pe_next = w.pairs[q + 64];   // the next round's list entry travels while this round's operands do
         uint8_t la = 1, lb = 1;
-        if (mine) { la = pr.level[pe.x]; lb = pr.level[pe.y]; }
+        int pt = 0;
+        if (mine) { la = pr.level[pe.x]; lb = pr.level[pe.y]; if (VINV) pt = pr.e_pt[pe.x]; }
+        double2 vi0 = make_double2(0.0, 0.0), vi1 = vi0, vi2 = vi0;
+        if (VINV && mine) { const double2* vp = (const double2*)(w.W + (long long)pt * 6); vi0 = vp[0]; vi1 = vp[1]; vi2 = vp[2]; }   // V^-1 of the pair's landmark (k_w_edgeW<true>)
         s_idx[2 * lane] = mine ? pe.x : -1;
         s_idx[2 * lane + 1] = mine ? pe.y : -1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1085,7 +1108,7 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
             for (int i = 0; i < 9; i++) {
                 const int g = 64 * i + lane, b = g / 9, piece = g - 9 * b;   // piece `piece` of block b of this half
                 const int e = s_idx[64 * half + b];
-                const double2* src = (b & 1) ? Bg : Wg;
+                const double2* src = (VINV || (b & 1)) ? Bg : Wg;
                 v[i] = e >= 0 ? src[(long long)e * 9 + piece] : make_double2(0.0, 0.0);
             }
             if (half == 1) {   // (the first half's blocks have been read by their owners)
@@ -1107,8 +1130,18 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the next round's fetch overwrites the staging area and the index table)
         if (la != 0 || lb != 0) continue;
+        if (VINV) {   // W_a = B_a V^-1: k_w_edgeW's products, in its order
+            const double d0 = vi0.x, d1 = vi0.y, d2 = vi1.x, d4 = vi1.y, d5 = vi2.x, d8 = vi2.y;   // Di[0], [1] = [3], [2] = [6], [4], [5] = [7], [8]
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double b0 = BD[i * 3], b1 = BD[i * 3 + 1], b2v = BD[i * 3 + 2];
+                BD[i * 3] = b0 * d0 + b1 * d1 + b2v * d2;
+                BD[i * 3 + 1] = b0 * d1 + b1 * d4 + b2v * d5;
+                BD[i * 3 + 2] = b0 * d2 + b1 * d5 + b2v * d8;
+            }
+        }
         if (diag) {
-            const double* bl = pr.bl + (long long)pr.e_pt[pe.x] * 3;
+            const double* bl = pr.bl + (long long)(VINV ? pt : pr.e_pt[pe.x]) * 3;
             const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
 #pragma unroll
             for (int i = 0; i < 6; i++) bsv[i] += BD[i * 3] * l0 + BD[i * 3 + 1] * l1 + BD[i * 3 + 2] * l2;
@@ -1839,6 +1872,7 @@ struct oslam_lba {
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
+    int schur_vinv = 1;           // pair gather: W_e = B_e V^-1 formed inside k_w_schur from per-landmark inverses (1, default) or materialised per edge by k_w_edgeW (0: rounds 1-3)
     int schur_tiles = 0;          // wide layout, Schur complement (default 0: in the bench the gather is as fast or faster at every window size, see below): 1 = by LDS tiles (k_w_schur_tiles: one coalesced read of Hpl per trial), 0 = by the pair gather
                                   // (k_w_edgeW + k_w_schur: 288 bytes per pair from memory), 2 = per call: tiles when the windows average >= kSchurTilesMinEdges edges.
                                   // Measured (tools/lba_win_prof.py, kernels of one call): 50 windows of 10 keyframes / 4.4 k edges: gather 3.2 ms, tiles 5.7 ms; 40 windows
@@ -2006,6 +2040,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
     if (const char* e = getenv("OSLAM_LBA_SOLVER")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->chol_mode = v; }   // A/B knob: oslam_lba_set_solver for every handle of the process
     if (getenv("OSLAM_LBA_HOST_PAIRS")) h->device_pairs = false;
+    if (const char* e = getenv("OSLAM_LBA_SCHUR_VINV")) h->schur_vinv = atoi(e) != 0;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e);   // 0 = always the pair gather, 1 = always tiles, 2 = per call (default)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
@@ -2584,8 +2619,13 @@ static int lba_launch(oslam_lba_t* h) {
                     hipLaunchKernelGGL(k_w_schur_tiles, dim3(maxWg, n0), dim3(kWinThreads), tiles_lds, st, d_probs, d_ws);
                     hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
                 } else {
-                    hipLaunchKernelGGL(k_w_edgeW, dim3(div_up(maxE, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
-                    hipLaunchKernelGGL(k_w_schur, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
+                    if (h->schur_vinv) {
+                        hipLaunchKernelGGL(k_w_edgeW<true>, dim3(div_up(maxNbPt * kWPt, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
+                        hipLaunchKernelGGL(k_w_schur<true>, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
+                    } else {
+                        hipLaunchKernelGGL(k_w_edgeW<false>, dim3(div_up(maxE, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
+                        hipLaunchKernelGGL(k_w_schur<false>, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
+                    }
                 }
                 if (chol_ldsm) hipLaunchKernelGGL(k_w_chol_lds_mfma, dim3(1, n0), dim3(kWinThreads), ldsm_lds, st, d_probs, d_ws, 0);
                 if (chol_packed) hipLaunchKernelGGL(k_w_chol_packed, dim3(1, n0), dim3(kWinThreads), packed_lds, st, d_probs, d_ws);

@@ -13,6 +13,6 @@ print("$tag", "frames/s", d["value"], "frac", d["roofline"]["frac"], "lba ms", r
 PY
   grep "lba service" $O/b_$tag.err | tail -1
 }
-run tiles OSLAM_LBA_SCHUR_TILES=1
-run base A=1
-run tiles2 OSLAM_LBA_SCHUR_TILES=1
+run vinv1 OSLAM_LBA_SCHUR_VINV=1
+run vinv0 OSLAM_LBA_SCHUR_VINV=0
+run vinv1b OSLAM_LBA_SCHUR_VINV=1
