@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 O=gpurun_out/r4soak
 mkdir -p $O
 for sch in sync deferred; do
-  timeout -k 10 500 python tests/soak_s1.py 2 1000 1 $sch > $O/soak_$sch.log 2>&1 || { tail -5 $O/soak_$sch.log; exit 1; }
+  OSLAM_SLAM_VOTE_CHECK=1 timeout -k 10 500 python tests/soak_s1.py 2 1000 1 $sch > $O/soak_$sch.log 2>&1 || { tail -5 $O/soak_$sch.log; exit 1; }
   tail -1 $O/soak_$sch.log > $O/soak_$sch.json
   python - <<PY
 import json
