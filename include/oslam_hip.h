@@ -465,6 +465,13 @@ int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*
  * (the two functions below) this writes its results into the records d_items[i] = (slot, id): position (d_Pos) + normal / distances (d_out5) when do_normal,
  * the descriptor when do_desc and the point's descriptor list (d_desc_start) is not empty; a point without observations (culled) keeps its record except
  * for the position, which the caller may have changed before culling it (local BA). */
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:345-430) and / or UpdateNormalAndDepth (:432-474) for P points in ONE launch, for the driver's small
+ * updates: the descriptors of the observations are read from resident keyframe records (d_rec = (record, keypoint) per entry of the descriptor list d_desc_start,
+ * d_rec_desc[record] = that keyframe's descriptor array), the results go to o_best / o_desc / o_out5 — any device-accessible memory, e.g. pinned host memory — and,
+ * with d_tab, into the points' resident records like oslam_mp_table_write_device.  Same results as the separate functions.  At most 128 observations per point. */
+int oslam_mp_update_fused_device(int P, int do_desc, int do_normal, const int32_t* d_obs_start, const int32_t* d_desc_start, const int32_t* d_rec, const uint8_t* const* d_rec_desc,
+                                 const float* d_obs_Ow, const float* d_Pos, const float* d_OwRef, const float* d_lsf, float lastScale, const int32_t* d_items, uint8_t* const* d_tab,
+                                 int32_t* o_best, uint8_t* o_desc, float* o_out5, void* stream);
 /* MapPoint::UpdateNormalAndDepth (src/MapPoint.cc:432-474) for P points of solved local-BA windows, as Optimizer::LocalBundleAdjustment's write-back calls it
  * per point (src/Optimizer.cc:769-776), from the windows' own arrays (include/oslam_slam.h oslam_job_mp_window_t, flattened over the windows of a call): point j
  * has the edges d_e0[j] .. d_e0[j] + d_ne[j] of d_edge_kf / d_erase (window keyframe index, erased flag), its window's camera centres start at row d_kbase[j] of

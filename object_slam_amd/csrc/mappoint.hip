@@ -699,6 +699,113 @@ int oslam_mp_update_windows_device(int P, const int32_t* d_items, uint8_t* const
     return OSLAM_OK;
 }
 
+// The driver's small MapPoint updates (new points, the descriptor updates after every Fuse round: tens to hundreds of points per call, dozens of calls per
+// keyframe) in ONE launch instead of up to eight (descriptor gather, memset, k_distinctive, k_update_normal_depth, k_mp_table_write, three copy kernels): one
+// wavefront per point reads its observations' descriptors straight from the resident keyframe records (rec = (record, keypoint) per observation of the
+// descriptor list), runs k_distinctive's selection and k_update_normal_depth's sums (lane 0), and writes the results to the caller's device-accessible host
+// block AND into the point's resident record.  Same arithmetic, same order as the separate kernels.  Points with more than kDdMaxObs observations: not here
+// (the caller checks).
+struct MpFused {
+    int P, do_desc, do_normal;
+    const int32_t* obs_start; const int32_t* desc_start; const int32_t* rec; const uint8_t* const* rec_desc;
+    const float* obs_Ow; const float* Pos; const float* OwRef; const float* lsf; float lastScale;
+    const int32_t* items; uint8_t* const* tab;
+    int32_t* o_best; uint8_t* o_desc; float* o_out5;
+};
+__global__ __launch_bounds__(256) void k_mp_update_fused(MpFused c) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    __shared__ uint32_t s_d[4][kDdMaxObs * 8];
+    if (p >= c.P) return;
+    const bool has_obs = c.obs_start[p + 1] > c.obs_start[p];
+    uint32_t* recw = c.tab ? (uint32_t*)(c.tab[c.items[2 * p]] + (size_t)c.items[2 * p + 1] * 64) : nullptr;
+    if (c.do_desc) {
+        const int s = c.desc_start[p], N = c.desc_start[p + 1] - s;
+        uint32_t* od = (uint32_t*)(c.o_desc + (size_t)p * 32);
+        if (N <= 0) {
+            if (lane == 0) c.o_best[p] = -1;
+            if (lane < 8) od[lane] = 0u;
+        } else {
+            uint32_t* D = s_d[wv];
+            for (int i = lane; i < N * 8; i += 64) {
+                const int o = i >> 3, w = i & 7;
+                D[i] = ((const uint32_t*)(c.rec_desc[c.rec[2 * (s + o)]] + (size_t)c.rec[2 * (s + o) + 1] * 32))[w];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int k = (int)(0.5 * (N - 1));   // vDists[0.5*(N-1)]
+            int bestMedian = 0x7fffffff, bestI = 0;
+            for (int i = lane; i < N; i += 64) {
+                uint32_t qi[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) qi[w] = D[i * 8 + w];
+                int lo = 0, hi = 256;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    int cnt = 0;
+                    for (int j = 0; j < N; j++) {
+                        int dist = 0;
+#pragma unroll
+                        for (int w = 0; w < 8; w++) dist += __popc(qi[w] ^ D[j * 8 + w]);
+                        cnt += dist <= mid;
+                    }
+                    if (cnt >= k + 1) hi = mid; else lo = mid + 1;
+                }
+                if (lo < bestMedian) { bestMedian = lo; bestI = i; }
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const int om = __shfl_xor(bestMedian, sft, 64), oi = __shfl_xor(bestI, sft, 64);
+                if (om < bestMedian || (om == bestMedian && oi < bestI)) { bestMedian = om; bestI = oi; }
+            }
+            if (lane == 0) c.o_best[p] = bestI;
+            if (lane < 8) {
+                const uint32_t v = D[bestI * 8 + lane];
+                od[lane] = v;
+                if (recw && has_obs) recw[8 + lane] = v;   // (every observing keyframe bad: the record's descriptor stays, k_mp_table_write)
+            }
+        }
+    }
+    if (c.do_normal && lane == 0) {
+        const float px = c.Pos[p * 3], py = c.Pos[p * 3 + 1], pz = c.Pos[p * 3 + 2];
+        float* o = c.o_out5 + (size_t)p * 5;
+        float* rf = (float*)recw;
+        if (rf) { rf[0] = px; rf[1] = py; rf[2] = pz; }
+        const int s = c.obs_start[p], n = c.obs_start[p + 1] - s;
+        if (n <= 0) { for (int k = 0; k < 5; k++) o[k] = 0.f; }
+        else {
+            float nx = 0, ny = 0, nz = 0;
+            for (int i = 0; i < n; i++) {
+                const float ax = px - c.obs_Ow[(s + i) * 3], ay = py - c.obs_Ow[(s + i) * 3 + 1], az = pz - c.obs_Ow[(s + i) * 3 + 2];
+                const float inv = (float)(1.0 / norm3d(ax, ay, az));   // cv::scaleAdd with float alpha
+                nx = ax * inv + nx;
+                ny = ay * inv + ny;
+                nz = az * inv + nz;
+            }
+            const float dist = (float)norm3d(px - c.OwRef[p * 3], py - c.OwRef[p * 3 + 1], pz - c.OwRef[p * 3 + 2]);
+            const float maxD = dist * c.lsf[p];
+            const float invn = (float)(1.0 / (double)n);   // convertTo(alpha = 1/n): float scale
+            const float r0 = nx * invn + 0.0f, r1 = ny * invn + 0.0f, r2 = nz * invn + 0.0f, minD = __fdiv_rn(maxD, c.lastScale);
+            o[0] = r0; o[1] = r1; o[2] = r2; o[3] = maxD; o[4] = minD;
+            if (rf) { rf[3] = r0; rf[4] = r1; rf[5] = r2; rf[6] = minD; rf[7] = maxD; }
+        }
+    }
+}
+
+int oslam_mp_update_fused_device(int P, int do_desc, int do_normal, const int32_t* d_obs_start, const int32_t* d_desc_start, const int32_t* d_rec, const uint8_t* const* d_rec_desc,
+                                 const float* d_obs_Ow, const float* d_Pos, const float* d_OwRef, const float* d_lsf, float lastScale, const int32_t* d_items, uint8_t* const* d_tab,
+                                 int32_t* o_best, uint8_t* o_desc, float* o_out5, void* stream) {
+    if (P < 0 || (P > 0 && (!d_obs_start || !d_desc_start || (do_desc && (!d_rec || !d_rec_desc || !o_best || !o_desc)) ||
+                            (do_normal && (!d_obs_Ow || !d_Pos || !d_OwRef || !d_lsf || !o_out5)) || (d_tab && !d_items)))) { set_error("mp_update_fused: bad argument"); return OSLAM_E_INVALID; }
+    if (P == 0) return OSLAM_OK;
+    MpFused c;
+    c.P = P; c.do_desc = do_desc; c.do_normal = do_normal; c.obs_start = d_obs_start; c.desc_start = d_desc_start; c.rec = d_rec; c.rec_desc = d_rec_desc;
+    c.obs_Ow = d_obs_Ow; c.Pos = d_Pos; c.OwRef = d_OwRef; c.lsf = d_lsf; c.lastScale = lastScale; c.items = d_items; c.tab = d_tab;
+    c.o_best = o_best; c.o_desc = o_desc; c.o_out5 = o_out5;
+    hipLaunchKernelGGL(k_mp_update_fused, dim3(div_up(P, 4)), dim3(256), 0, (hipStream_t)stream, c);
+    OSLAM_HIP_CHECK(hipGetLastError());
+    return OSLAM_OK;
+}
+
 int oslam_mp_distinctive_descriptors_device(int P, const int32_t* d_obs_start, const uint8_t* d_obs_desc, int32_t* d_best_idx, uint8_t* d_out_desc, void* stream) {
     if (P < 0 || (P > 0 && (!d_obs_start || !d_obs_desc || !d_best_idx || !d_out_desc))) { set_error("bad argument"); return OSLAM_E_INVALID; }
     if (P == 0) return OSLAM_OK;

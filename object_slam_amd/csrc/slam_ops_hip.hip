@@ -911,11 +911,33 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     const bool upload = force_upload || (j->do_desc && !keyed) || in_bytes > (size_t)(getenv("OSLAM_SLAM_MPU_ZC_BYTES") ? atol(getenv("OSLAM_SLAM_MPU_ZC_BYTES")) : 262144);
     const uint8_t* In = upload ? Dv : U;
     if (upload) OSLAM_HIP_CHECK(hipMemcpyAsync(Dv, U, in_bytes, hipMemcpyHostToDevice, o->strm));
-    o->t_begin();
-    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(In + oRec), (int)dtotal, Dv + oDesc, o->strm));
     Layout R;
     const size_t rBest = R.take(4 * P), rOut = R.take(32 * P), rOut5 = R.take(20 * P);
     OPS_CHECK(o->ensure_dn(R.off));
+    // The small keyed jobs (every Fuse round's descriptor updates, the new keyframe's and the new points' updates) in ONE launch: k_mp_update_fused reads the
+    // observations' descriptors from the resident keyframes, writes the results straight into the (device-accessible) result block and into the resident records.
+    // OSLAM_SLAM_MPU_FUSED=0: the separate kernels.
+    static const bool fused_on = !(getenv("OSLAM_SLAM_MPU_FUSED") && atoi(getenv("OSLAM_SLAM_MPU_FUSED")) == 0);
+    bool fused = fused_on && (!j->do_desc || keyed);
+    if (fused && j->do_desc) for (size_t i = 0; i < P && fused; i++) fused = dstart[i + 1] - dstart[i] <= 128;   // (kDdMaxObs of csrc/mappoint.hip: beyond it k_distinctive reads from memory)
+    if (fused) {
+        o->t_begin();
+        OPS_CHECK(oslam_mp_update_fused_device((int)P, j->do_desc, j->do_normal, (const int32_t*)(In + oStart), (const int32_t*)(In + (j->desc_start ? oDStart : oStart)),
+                                               keyed ? (const int32_t*)(In + oRec) : nullptr, (const uint8_t* const*)o->d_rec_desc, (const float*)(In + oOw), (const float*)(In + oPos),
+                                               (const float*)(In + oRef), (const float*)(In + oLsf), o->scale[o->cfg.nLevels - 1], table ? (const int32_t*)(In + oItems) : nullptr,
+                                               table ? o->d_mp_tab : nullptr, (int32_t*)(o->dn_h + rBest), o->dn_h + rOut, (float*)(o->dn_h + rOut5), o->strm));
+        o->t_end();
+        lap_(3);
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+        lap_(4);
+        o->t_collect(6, 1, (double)dtotal);
+        if (j->do_desc) { memcpy(j->best_idx, o->dn_h + rBest, 4 * P); memcpy(j->out_desc, o->dn_h + rOut, 32 * P); }
+        if (j->do_normal) memcpy(j->out5, o->dn_h + rOut5, 20 * P);
+        lap_(5);
+        return OSLAM_OK;
+    }
+    o->t_begin();
+    if (keyed) OPS_CHECK(oslam_gather_descriptors_device((const uint8_t* const*)o->d_rec_desc, (const int32_t*)(In + oRec), (int)dtotal, Dv + oDesc, o->strm));
     if (j->do_desc) {
         OSLAM_HIP_CHECK(hipMemsetAsync(Dv + oOut, 0, 32 * P, o->strm));
         OPS_CHECK(oslam_mp_distinctive_descriptors_device((int)P, (const int32_t*)(In + (j->desc_start ? oDStart : oStart)), Dv + oDesc, (int32_t*)(Dv + oBest), Dv + oOut, o->strm));
