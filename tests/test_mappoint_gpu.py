@@ -57,6 +57,66 @@ def test_update_normal_and_depth():
         assert np.array_equal(out[p].view(np.uint32), ref.view(np.uint32)), p
 
 
+@pytest.mark.parametrize("nmax", [1, 9, 40, 128])
+def test_fused_small_update_matches_oracle(nmax):
+    """oslam_mp_update_fused_device (the driver's small MapPoint updates in one launch: descriptors read from resident keyframe records through (record, keypoint)
+    pairs) against the oracle's ComputeDistinctiveDescriptors and UpdateNormalAndDepth, bit for bit, incl. points without observations, a descriptor list shorter
+    than the observation list, and the resident records."""
+    import ctypes as C
+    import torch
+    from object_slam_amd._lib import lib, check
+    from oracle import oracle_py as O
+    L = lib()
+    rng = np.random.default_rng(100 + nmax)
+    P, nkf, nkp = 257, 12, 500
+    kf_desc = [torch.from_numpy(rng.integers(0, 256, (nkp, 32), dtype=np.uint8)).cuda() for _ in range(nkf)]
+    kf_host = [k.cpu().numpy() for k in kf_desc]
+    recp = torch.tensor([k.data_ptr() for k in kf_desc], dtype=torch.int64, device="cuda")
+    obs_start, desc_start, rec, lists, ow_lists = [0], [0], [], [], []
+    for p in range(P):
+        n = int(rng.integers(0, nmax + 1)) if p % 7 else (0 if p % 14 == 0 else nmax)
+        nd = n if p % 5 else max(0, n - 2)          # some observations sit in culled keyframes: not in the descriptor list
+        pairs = [(int(rng.integers(0, nkf)), int(rng.integers(0, nkp))) for _ in range(nd)]
+        if nd >= 3 and p % 3 == 0:                   # near-duplicate views: ties in the medians
+            pairs = [pairs[0]] * nd
+        rec += pairs
+        lists.append(np.stack([kf_host[r][k] for r, k in pairs]) if nd else np.zeros((0, 32), np.uint8))
+        ow_lists.append(rng.normal(0, 3, (n, 3)).astype(np.float32))
+        obs_start.append(obs_start[-1] + n); desc_start.append(desc_start[-1] + nd)
+    Pos = rng.normal(0, 5, (P, 3)).astype(np.float32)
+    OwRef = rng.normal(0, 3, (P, 3)).astype(np.float32)
+    sf = (1.2 ** np.arange(8)).astype(np.float32)
+    lsf = sf[rng.integers(0, 8, P)]
+    dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dt))).cuda()
+    d = dict(os=dev(obs_start, np.int32), ds=dev(desc_start, np.int32), rec=dev(np.array(rec, np.int32).reshape(-1, 2) if rec else np.zeros((1, 2), np.int32), np.int32),
+             ow=dev(np.concatenate(ow_lists) if obs_start[-1] else np.zeros((1, 3), np.float32), np.float32), pos=dev(Pos, np.float32), ref=dev(OwRef, np.float32), lsf=dev(lsf, np.float32),
+             items=dev(np.stack([np.zeros(P, np.int32), np.arange(P, dtype=np.int32)], 1), np.int32))
+    tab = torch.full((P, 16), 7.0, dtype=torch.float32, device="cuda")
+    tabp = torch.tensor([tab.data_ptr()], dtype=torch.int64, device="cuda")
+    best = torch.full((P,), 99, dtype=torch.int32, device="cuda"); od = torch.full((P, 32), 9, dtype=torch.uint8, device="cuda"); o5 = torch.full((P, 5), 3.0, dtype=torch.float32, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    check(L.oslam_mp_update_fused_device(P, 1, 1, vp(d["os"]), vp(d["ds"]), vp(d["rec"]), vp(recp), vp(d["ow"]), vp(d["pos"]), vp(d["ref"]), vp(d["lsf"]), C.c_float(float(sf[-1])),
+                                         vp(d["items"]), vp(tabp), vp(best), vp(od), vp(o5), None))
+    torch.cuda.synchronize()
+    best, od, o5, recs = best.cpu().numpy(), od.cpu().numpy(), o5.cpu().numpy(), tab.cpu().numpy()
+    for p in range(P):
+        ref = O.distinctive_descriptor(lists[p])
+        assert best[p] == ref, (p, len(lists[p]), best[p], ref)
+        assert np.array_equal(od[p], lists[p][ref]) if ref >= 0 else not od[p].any()
+        n = obs_start[p + 1] - obs_start[p]
+        assert np.array_equal(recs[p, :3], Pos[p])
+        if n == 0:
+            assert not o5[p].any() and (recs[p, 3:] == 7.0).all()
+            continue
+        r5 = O.update_normal_depth(Pos[p], ow_lists[p], OwRef[p], lsf[p], sf[-1])
+        assert np.array_equal(o5[p].view(np.uint32), r5.view(np.uint32)), p
+        assert np.array_equal(recs[p, 3:6], r5[:3]) and recs[p, 6] == r5[4] and recs[p, 7] == r5[3]
+        if ref >= 0:
+            assert np.array_equal(recs[p, 8:].view(np.uint8), lists[p][ref])
+        else:
+            assert (recs[p, 8:] == 7.0).all()
+
+
 def test_update_normal_and_depth_from_local_ba_windows():
     """oslam_mp_update_windows_device (the MapPoint updates after a local BA, from the solved windows' own arrays: include/oslam_slam.h oslam_job_mp_window_t)
     against the oracle's UpdateNormalAndDepth over the surviving observations of every point — bit for bit — incl. erased edges, skipped points, several windows
