@@ -1515,9 +1515,8 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         const size_t oM = L.take(4 * B), oSl = L.take(4 * B), oT = L.take(64 * B), oOw = L.take(12 * B), oRef = L.take(sizeof(oslam_kf_grid_ref_t) * B), oIds = L.take(4 * st * B),
                      oEx = L.take(st * B);
         const size_t head = L.off;
-        const size_t oQm = L.take(4 * st * B);
         OPS_CHECK(o->ensure_up(L.off));
-        OPS_CHECK(o->ensure_dn(4 * st * B));
+        OPS_CHECK(o->ensure_dn(4 * st * B));   // the match table: written by the kernel itself
         uint8_t* U = o->up_h;
         uint8_t* Dv = o->up_d;
         o->pool->parallel_for(n, [&](int i) {
@@ -1537,9 +1536,8 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         o->t_begin();
         OPS_CHECK(oslam_fuse_search_device(n, (int)st, (const oslam_kf_grid_ref_t*)(In + oRef), (const int32_t*)(In + oSl), (const int32_t*)(In + oM), (const int32_t*)(In + oIds),
                                            In + oEx, o->d_mp_tab, (const float*)(In + oT), (const float*)(In + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale,
-                                           o->invSigma2, o->cfg.nLevels, (int32_t*)(Dv + oQm), o->strm));
+                                           o->invSigma2, o->cfg.nLevels, (int32_t*)o->dn_h, o->strm));   // (every query writes its one result: straight into the pinned result block, no copy kernel behind it)
         o->t_end();
-        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, Dv + oQm, 4 * st * B, o->strm));
         OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         o->t_collect(4, 1, 0);
         o->pool->parallel_for(n, [&](int i) { memcpy(jobs[i].q_match, o->dn_h + 4 * st * i, 4 * (size_t)jobs[i].M); });

@@ -4,7 +4,7 @@ O=gpurun_out/r4z
 mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_slam_driver_gpu.py tests/test_mp_table_gpu.py -x -q > $O/pytest_drv.log 2>&1 || { tail -30 $O/pytest_drv.log; exit 1; }
 tail -2 $O/pytest_drv.log
-for m in 1 0 1; do
+for m in 1 1; do
   OSLAM_SLAM_MPU_FUSED=$m timeout -k 10 400 python bench.py --no-extras --no-cpu-baseline > $O/b_$m.json 2> $O/b_$m.err || exit 1
   python - <<PY
 import json
