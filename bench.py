@@ -406,9 +406,10 @@ def main():
                                                              "RGB-D stream = SURVEY.md §8(d) frame >= 200, 40 for the stereo street); 0 = the cold-start regime of round 2")
     ap.add_argument("--seqs", type=int, default=0, help="sequences per GPU (default: 8192 RGB-D / 2048 stereo)")
     ap.add_argument("--bases", type=int, default=8, help="base renderings per GPU of the headline stream (distinct input streams = bases x 25 frame offsets)")
-    ap.add_argument("--lm", choices=("deferred", "sync"), default="deferred", help="local-mapping schedule (include/oslam_slam.h): deferred = the local BA of keyframe t is solved by the "
-                    "process-wide service while frame t+1 is tracked, its write-back and KeyFrameCulling land before frame t+2 (the reference's two-thread overlap, "
-                    "src/System.cc:95); sync = the whole pass right after the frame that inserted the keyframe (rounds 1-3)")
+    ap.add_argument("--lm", choices=("deferred", "sync"), default="sync", help="local-mapping schedule (include/oslam_slam.h): sync (default) = the whole pass right after the frame "
+                    "that inserted the keyframe, its local BA solved by the process-wide service in batches shared with the other handles; deferred = the local BA of keyframe "
+                    "t is solved while frame t+1 is tracked, its write-back and KeyFrameCulling land before frame t+2 (the reference's two-thread overlap, src/System.cc:95).  "
+                    "On the final code of round 4 sync is the faster one on the headline stream (12 % fewer keyframes, DESIGN.md section 5)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1202,9 +1202,18 @@ struct LbaService {
     }
 };
 
+int h_lba_submit(void* p, int n, const oslam_lba_problem_t* pr);
+int h_lba_wait(void* p);
 int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
+    if (o->svc && n > 1) {   // Also the synchronous schedule solves through the process-wide service: the windows of the handles that are at this point together
+                             // form shared batches, one call on the device at a time, and this handle SLEEPS meanwhile.  On its own stream a handle's call ran
+                             // against the other handles' calls (6.2 s of device time per 20 steps of the headline against 4.3 s) and its thread spun through
+                             // the wait (73 against 58 busy core-seconds): 31.8 k -> 35.4-36.3 k frames/s, same box.  OSLAM_LBA_SYNC_OWN_STREAM=1: as before.
+        const int rc = h_lba_submit(p, n, pr);
+        return rc ? rc : h_lba_wait(p);
+    }
     std::vector<oslam_lba_problem_t> tp;
     std::vector<int32_t> st;
     if (o->timing) {
@@ -1712,10 +1721,11 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     ops->search_last = h_search_last; ops->search_local = h_search_local; ops->pose_opt = h_pose_opt; ops->mp_update = h_mp_update; ops->lba = h_lba;
     ops->fuse = h_fuse; ops->bow = h_bow; ops->triangulate = h_triangulate; ops->destroy = h_destroy; ops->frames_stereo = cfg->sensor == 1 ? h_frames_stereo : nullptr;
     ops->kernel_times = h_kernel_times; ops->object_kps = h_object_kps; ops->pose_opt2 = h_pose_opt2;
-    if ((cfg->local_mapping & OSLAM_SLAM_LM_DEFERRED) && !getenv("OSLAM_LBA_NO_SERVICE")) {   // (OSLAM_LBA_NO_SERVICE=1: the deferred schedule with the handle's own solver at collection time)
+    const bool deferred_cfg = (cfg->local_mapping & OSLAM_SLAM_LM_DEFERRED) != 0;
+    if (deferred_cfg ? !getenv("OSLAM_LBA_NO_SERVICE") : !getenv("OSLAM_LBA_SYNC_OWN_STREAM")) {   // (OSLAM_LBA_NO_SERVICE=1: the deferred schedule with the handle's own solver at collection time)
         o->svc = LbaService::acquire(dev);
         if (!o->svc) { h_destroy(o); return OSLAM_E_HIP; }
-        ops->lba_submit = h_lba_submit; ops->lba_wait = h_lba_wait;
+        if (deferred_cfg) { ops->lba_submit = h_lba_submit; ops->lba_wait = h_lba_wait; }
     }
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
