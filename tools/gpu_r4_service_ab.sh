@@ -13,6 +13,5 @@ print("$tag", "frames/s", d["value"], "frac", d["roofline"]["frac"], "lba ms", r
 PY
   grep "lba service" $O/b_$tag.err | tail -1
 }
-run overlap OSLAM_LBA_SERVICE_OVERLAP=1
+run noprio OSLAM_LBA_SERVICE_NO_PRIORITY=1
 run base A=1
-run thr3 OSLAM_LBA_SERVICE_THREADS=3
