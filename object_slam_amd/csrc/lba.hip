@@ -632,6 +632,8 @@ struct LbaWide {
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
     uint16_t* pairM; int2* pairs_w; int* pair_start_w;   // pair lists built on the device (k_w_pair_*): then pairs / pair_start point at pairs_w / pair_start_w
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
+    double* rec;              // [E][4] compact edge records of the current linearisation (x, y, 1/z of the point in the camera frame, weight x information with the
+                              // sign bit = monocular), or null: the per-edge blocks B_e are then materialised in pr.Hpl (see k_w_schur_rec)
     // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
     const int* tile_p0; const int* tile_s0; const int* stg_edge; const int* thr_own; const int* blk_thr; const int* blk_slots;
     double* parts;            // [nwg][ngroup * kWinThreads][42] per-workgroup, per-slot block sums
@@ -718,6 +720,7 @@ __device__ __forceinline__ bool xcd_window_item(int nwin, int& win, int& item) {
     return win < nwin;
 }
 
+template <bool REC>
 __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -744,7 +747,13 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                 const uint8_t lv = pr.level[e];
                 const int a = pr.e_kf[e];
                 const float o0 = pr.e_obs[e * 3], o1 = pr.e_obs[e * 3 + 1], ur = pr.e_obs[e * 3 + 2], inf = pr.e_info[e];
-                if (lv != 0) continue;
+                if (lv != 0) {
+                    if (REC) {   // weight 0: the edge adds exact zeros wherever its record is read
+                        double2* rc = (double2*)(w.rec + (long long)e * 4);
+                        rc[0] = make_double2(0.0, 0.0); rc[1] = make_double2(1.0, 0.0);
+                    }
+                    continue;
+                }
                 const bool stereo = !(ur < 0);
                 const double ob[3] = {(double)o0, (double)o1, (double)ur};
                 const double info = (double)inf;
@@ -774,7 +783,10 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                             for (int j = i; j < 3; j++) hl[k++] += wJx[d * 3 + i] * Jx[d * 3 + j];
                         }
                     }
-                    if (w.blk[a] >= 0) {
+                    if (REC) {
+                        double2* rc = (double2*)(w.rec + (long long)e * 4);
+                        rc[0] = make_double2(pc[0], pc[1]); rc[1] = make_double2(iz, stereo ? wi : -wi);
+                    } else if (w.blk[a] >= 0) {
                         double Ju[6], Jv[6], Jr[6];
                         pose_jac_rows(cam, pc, iz, stereo, Ju, Jv, Jr);
                         double* B = pr.Hpl + (long long)e * 18;
@@ -1178,6 +1190,170 @@ __global__ __launch_bounds__(64) void k_w_schur(const LbaProblem* probs, const L
         mine = (s0 + s1) + (s2 + s3);
     }
     if (lane < 36) {   // lanes 0..35 write one entry each
+        const int i = lane / 6, j = lane - i * 6;
+        double v = -mine;
+        if (diag) v += pr.Hpp[a * 36 + lane] + (i == j ? lambda : 0.0);
+        pr.Hs[(size_t)(6 * ba + i) * ld + 6 * bb + j] = v;
+    } else if (diag && lane < 42) {
+        const int i = lane - 36;
+        pr.Hs[(size_t)(6 * ba + i) * ld + n] = pr.bp[a * 6 + i] - mine;
+    }
+}
+
+// The Schur complement from COMPACT EDGE RECORDS (round 5, the default of the pair-gather path).  The 144-byte block of an edge, B_e = Jp^T (w info) Jx, is a
+// function of four doubles — the point in the edge's camera frame as (x, y, 1/z) and the edge's weight — and of the keyframe's rotation, which is the same
+// for every pair of a 6x6 block (a, b).  So k_w_lin<true> stores 32 bytes per edge instead of 144, and the product of a pair is formed from the records:
+//     W_a B_b^T = Jp_a^T [ (w_a Jx_a) V^-1 (w_b Jx_b)^T ] Jp_b = Jp_a^T M Jp_b,       M 3x3,
+// (Jx = -d proj / d p_c * R: point_jac_rows; Jp: pose_jac_rows — the formulas k_w_lin used for B_e).  Per pair a lane fetches 64 + 48 bytes (two records and
+// the landmark's V^-1) instead of two 144-byte blocks, straight into registers: the cooperative fetch through LDS of k_w_schur (two dependent hand-overs per
+// round, the kernel's bound after round 4: profiles/r04_pmc_lba_wait_ta.json) is gone, and so are k_w_lin's 144-byte-per-lane stores (128 MB written per launch
+// of 40 windows for 75 MB of blocks).  ~300 fused multiply-adds per pair instead of ~180: the vector ALU was at 16-22 % of the wave cycles.  An edge that has
+// left the problem (level 1) carries weight 0 and adds exact zeros.  Same summation order over the pairs as k_w_schur (lane l takes pairs l, l + 64, ...; quad
+// sums, then 16 partial sums in lane order), so a window's result does not depend on the batch it is solved in.
+#ifndef OSLAM_SCHUR_REC_WAVES
+#define OSLAM_SCHUR_REC_WAVES 2
+#endif
+__device__ __forceinline__ double uniform_f64(double v) {   // a wave-uniform value into scalar registers
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_REC_WAVES, OSLAM_SCHUR_REC_WAVES))) void k_w_schur_rec(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+#pragma clang fp contract(fast)
+    int win, t;
+    if (!xcd_window_item(nwin, win, t)) return;
+    const LbaProblem& pr = probs[win];
+    const LbaWide& w = ws[win];
+    const LbaCtrl* ct = w.ct;
+    if (ct->done) return;
+    const int nfree = ct->nfree, n = ct->n, ld = n + 1;
+    const int lane = threadIdx.x;
+    if (t >= nfree * (nfree + 1) / 2) return;
+    const double lambda = w_lambda_eff(ct);
+    int ba = 0, rem = t;
+    while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
+    const int bb = ba + rem;
+    const int a = w.free_pose[ba], b = w.free_pose[bb];
+    const bool diag = ba == bb;
+    const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
+    double Ra[9], Rb[9];   // (wave-uniform: scalar loads)
+    {
+        const double* ra = w.R + ((size_t)ct->cur * pr.K + a) * 9;
+        const double* rb = w.R + ((size_t)ct->cur * pr.K + b) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { Ra[i] = uniform_f64(ra[i]); Rb[i] = uniform_f64(rb[i]); }
+    }
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) acc[i] = 0;
+    double bsv[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ __align__(16) double red[42 * 17];
+    const int q0 = w.pair_start[t], q_end = w.pair_start[t + 1];
+    const double2* rec = (const double2*)w.rec;
+    const double2* Vg = (const double2*)w.W;
+    // operands of a round are requested one round ahead of the arithmetic
+    int2 pe = make_int2(0, 0);
+    double2 a0 = make_double2(0.0, 0.0), a1 = make_double2(1.0, 0.0), b0 = a0, b1 = a1, v0 = a0, v1 = a0, v2 = a0;
+    int pt = 0;
+    if (q0 + lane < q_end) {
+        pe = w.pairs[q0 + lane];
+        a0 = rec[(long long)pe.x * 2]; a1 = rec[(long long)pe.x * 2 + 1];
+        if (!diag) { b0 = rec[(long long)pe.y * 2]; b1 = rec[(long long)pe.y * 2 + 1]; }
+        pt = pr.e_pt[pe.x];
+        v0 = Vg[(long long)pt * 3]; v1 = Vg[(long long)pt * 3 + 1]; v2 = Vg[(long long)pt * 3 + 2];
+    }
+    for (int q = q0 + lane; q < q_end; q += 64) {
+        const double2 ca0 = a0, ca1 = a1, cb0 = diag ? a0 : b0, cb1 = diag ? a1 : b1, cv0 = v0, cv1 = v1, cv2 = v2;
+        const int cpt = pt;
+        if (q + 64 < q_end) {
+            pe = w.pairs[q + 64];
+            a0 = rec[(long long)pe.x * 2]; a1 = rec[(long long)pe.x * 2 + 1];
+            if (!diag) { b0 = rec[(long long)pe.y * 2]; b1 = rec[(long long)pe.y * 2 + 1]; }
+            pt = pr.e_pt[pe.x];
+            v0 = Vg[(long long)pt * 3]; v1 = Vg[(long long)pt * 3 + 1]; v2 = Vg[(long long)pt * 3 + 2];
+        }
+        const double wa = fabs(ca1.y), wb = fabs(cb1.y);
+        if (wa == 0.0 || wb == 0.0) continue;
+        const bool sa = !__builtin_signbit(ca1.y), sb = !__builtin_signbit(cb1.y);
+        const double pa[3] = {ca0.x, ca0.y, 0.0}, pb[3] = {cb0.x, cb0.y, 0.0};
+        // N = (w_a Jx_a) V^-1
+        double Jxa[9], N[9];
+        point_jac_rows(cam, pa, ca1.x, Ra, sa, Jxa);
+        {
+            const double d0 = cv0.x, d1 = cv0.y, d2 = cv1.x, d4 = cv1.y, d5 = cv2.x, d8 = cv2.y;   // V^-1: [0], [1] = [3], [2] = [6], [4], [5] = [7], [8]
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const double g0 = wa * Jxa[d * 3], g1 = wa * Jxa[d * 3 + 1], g2 = wa * Jxa[d * 3 + 2];
+                N[d * 3] = g0 * d0 + g1 * d1 + g2 * d2;
+                N[d * 3 + 1] = g0 * d1 + g1 * d4 + g2 * d5;
+                N[d * 3 + 2] = g0 * d2 + g1 * d5 + g2 * d8;
+            }
+        }
+        double Jua[6], Jva[6], Jra[6];
+        pose_jac_rows(cam, pa, ca1.x, sa, Jua, Jva, Jra);
+        if (diag) {   // rhs: W_a b_l = Jp_a^T (N b_l)
+            const double* bl = pr.bl + (long long)cpt * 3;
+            const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
+            const double n0 = N[0] * l0 + N[1] * l1 + N[2] * l2, n1 = N[3] * l0 + N[4] * l1 + N[5] * l2, n2 = N[6] * l0 + N[7] * l1 + N[8] * l2;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                double sv = 0;   // (Ju[4] = Jv[3] = Jr[4] = 0)
+                if (i != 4) sv += Jua[i] * n0;
+                if (i != 3) sv += Jva[i] * n1;
+                if (i != 4) sv += Jra[i] * n2;
+                bsv[i] += sv;
+            }
+        }
+        // M = N (w_b Jx_b)^T
+        double Jxb[9], M[9];
+        point_jac_rows(cam, pb, cb1.x, Rb, sb, Jxb);
+#pragma unroll
+        for (int db = 0; db < 3; db++) {
+            const double g0 = wb * Jxb[db * 3], g1 = wb * Jxb[db * 3 + 1], g2 = wb * Jxb[db * 3 + 2];
+#pragma unroll
+            for (int da = 0; da < 3; da++) M[da * 3 + db] = N[da * 3] * g0 + N[da * 3 + 1] * g1 + N[da * 3 + 2] * g2;
+        }
+        double Jub[6], Jvb[6], Jrb[6];
+        pose_jac_rows(cam, pb, cb1.x, sb, Jub, Jvb, Jrb);
+        // acc += Jp_a^T M Jp_b over the non-zero Jacobian entries
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double T0 = 0, T1 = 0, T2 = 0;   // row i of Jp_a^T M
+            if (i != 4) { T0 += Jua[i] * M[0]; T1 += Jua[i] * M[1]; T2 += Jua[i] * M[2]; }
+            if (i != 3) { T0 += Jva[i] * M[3]; T1 += Jva[i] * M[4]; T2 += Jva[i] * M[5]; }
+            if (i != 4) { T0 += Jra[i] * M[6]; T1 += Jra[i] * M[7]; T2 += Jra[i] * M[8]; }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                double sv = 0;
+                if (j != 4) sv += T0 * Jub[j];
+                if (j != 3) sv += T1 * Jvb[j];
+                if (j != 4) sv += T2 * Jrb[j];
+                acc[i * 6 + j] += sv;
+            }
+        }
+    }
+    // reduction: as k_w_schur (quad sums by DPP, then the 16 quad sums of every entry in lane order through LDS)
+    auto quad_sum = [](double v) {
+        v += dpp_quad_f64<0xB1>(v);
+        v += dpp_quad_f64<0x4E>(v);
+        return v;
+    };
+#pragma unroll
+    for (int i = 0; i < 36; i++) { const double q4 = quad_sum(acc[i]); if ((lane & 3) == 0) red[i * 17 + (lane >> 2)] = q4; }
+    if (diag) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { const double q4 = quad_sum(bsv[i]); if ((lane & 3) == 0) red[(36 + i) * 17 + (lane >> 2)] = q4; }
+    }
+    __syncthreads();
+    double mine = 0;
+    if (lane < (diag ? 42 : 36)) {
+        const double* row = red + lane * 17;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { s0 += row[k]; s1 += row[k + 1]; s2 += row[k + 2]; s3 += row[k + 3]; }
+        mine = (s0 + s1) + (s2 + s3);
+    }
+    if (lane < 36) {
         const int i = lane / 6, j = lane - i * 6;
         double v = -mine;
         if (diag) v += pr.Hpp[a * 36 + lane] + (i == j ? lambda : 0.0);
@@ -1605,6 +1781,7 @@ __global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* 
 // Blocks [0, nblk_pt): 128 landmarks each — x_l, the trial position, then the errors of the landmark's edges at the TRIAL state.  The trial poses of the free
 // keyframes are what the pose block (item == nblk_pt) writes to w.T / w.R for the later launches; a landmark block cannot wait for another block, so it
 // recomputes them itself into LDS (se3_exp + se3_mul per free keyframe: the same two calls on the same inputs, hence the same bits).
+template <bool REC>
 __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -1645,6 +1822,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
         return;
     }
     // ---- landmark block ----
+    const Cam cam_ = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
     const int nfree = ct->nfree;
     for (int ba = threadIdx.x; ba < nfree; ba += kWPt) {
         const int a = w.free_pose[ba];
@@ -1662,7 +1840,39 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     if (p < pr.P) {
         double cl[3] = {pr.bl[p * 3], pr.bl[p * 3 + 1], pr.bl[p * 3 + 2]};
         double xo[3] = {0, 0, 0};
-        if (ok2) {
+        if (ok2 && REC) {
+            // B_e^T x_a from the edge's compact record (k_w_schur_rec): (w Jx)^T (Jp x_a)
+#pragma clang fp contract(fast)
+            const double* Rc = w.R + (size_t)cur * pr.K * 9;
+            const int e1 = pr.pt_start[p + 1];
+            int e = pr.pt_start[p];
+            double2 r0n = make_double2(0.0, 0.0), r1n = r0n; int a_n = 0;
+            if (e < e1) { const double2* rc = (const double2*)(w.rec + (long long)e * 4); r0n = rc[0]; r1n = rc[1]; a_n = pr.e_kf[e]; }
+            for (; e < e1; e++) {
+                const double2 r0 = r0n, r1 = r1n; const int a = a_n;
+                if (e + 1 < e1) { const double2* rc = (const double2*)(w.rec + (long long)(e + 1) * 4); r0n = rc[0]; r1n = rc[1]; a_n = pr.e_kf[e + 1]; }
+                const int ba = w.blk[a];
+                const double wi = fabs(r1.y);
+                if (wi == 0.0 || ba < 0) continue;
+                const bool stereo = !__builtin_signbit(r1.y);
+                const double pcv[3] = {r0.x, r0.y, 0.0};
+                const double* xa = pr.xp + 6 * ba;
+                double Ju[6], Jv[6], Jr[6], Jx[9];
+                pose_jac_rows(cam_, pcv, r1.x, stereo, Ju, Jv, Jr);
+                point_jac_rows(cam_, pcv, r1.x, Rc + a * 9, stereo, Jx);
+                double v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const double x = xa[i];
+                    if (i != 4) v0 += Ju[i] * x;
+                    if (i != 3) v1 += Jv[i] * x;
+                    if (i != 4) v2 += Jr[i] * x;
+                }
+                v0 *= wi; v1 *= wi; v2 *= wi;
+#pragma unroll
+                for (int j = 0; j < 3; j++) cl[j] -= Jx[j] * v0 + Jx[3 + j] * v1 + Jx[6 + j] * v2;
+            }
+        } else if (ok2) {
             for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
                 // (B_e is requested before the level byte and the keyframe's block index are known: its address depends on neither)
                 const double* Bg = pr.Hpl + (long long)e * 18;
@@ -1681,6 +1891,14 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
                     cl[j] -= sv;
                 }
             }
+        }
+        if (ok2 && REC) {   // (Hll_p + lambda I)^-1 as k_w_edgeW<true> left it for this trial
+            const double2* vp = (const double2*)(w.W + (long long)p * 6);
+            const double2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+            xo[0] = v0.x * cl[0] + v0.y * cl[1] + v1.x * cl[2];
+            xo[1] = v0.y * cl[0] + v1.y * cl[1] + v2.x * cl[2];
+            xo[2] = v1.x * cl[0] + v2.x * cl[1] + v2.y * cl[2];
+        } else if (ok2) {
             double D[9], Di[9];
             const double* H = pr.Hll + (long long)p * 9;
 #pragma unroll
@@ -1872,6 +2090,7 @@ struct oslam_lba {
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
+    int edge_rec = 1;             // pair gather with per-landmark inverses: compact 32-byte edge records instead of the 144-byte B_e blocks (k_w_schur_rec; round 5 default), 0 = materialised B_e
     int schur_vinv = 1;           // pair gather: W_e = B_e V^-1 formed inside k_w_schur from per-landmark inverses (1, default) or materialised per edge by k_w_edgeW (0: rounds 1-3)
     int schur_tiles = 0;          // wide layout, Schur complement (default 0: in the bench the gather is as fast or faster at every window size, see below): 1 = by LDS tiles (k_w_schur_tiles: one coalesced read of Hpl per trial), 0 = by the pair gather
                                   // (k_w_edgeW + k_w_schur: 288 bytes per pair from memory), 2 = per call: tiles when the windows average >= kSchurTilesMinEdges edges.
@@ -2041,6 +2260,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (const char* e = getenv("OSLAM_LBA_SOLVER")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->chol_mode = v; }   // A/B knob: oslam_lba_set_solver for every handle of the process
     if (getenv("OSLAM_LBA_HOST_PAIRS")) h->device_pairs = false;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_VINV")) h->schur_vinv = atoi(e) != 0;
+    if (const char* e = getenv("OSLAM_LBA_REC")) h->edge_rec = atoi(e) != 0;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_TILES")) h->schur_tiles = atoi(e);   // 0 = always the pair gather, 1 = always tiles, 2 = per call (default)
     if (hipHostMalloc((void**)&h->h_stop, sizeof(int), hipHostMallocMapped) != hipSuccess) { set_error("LBA stop flag allocation failed"); oslam_lba_destroy(h); return OSLAM_E_HIP; }
     *h->h_stop = 0;
@@ -2414,9 +2634,10 @@ static int lba_launch(oslam_lba_t* h) {
     size_t work = 0, outb = 0;
     auto takeW = [&](size_t bytes) { const size_t at = work; work += (bytes + 255) & ~(size_t)255; return at; };
     auto takeO = [&](size_t bytes) { const size_t at = outb; outb += (bytes + 255) & ~(size_t)255; return at; };
-    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, chunkC, pairPart, parts, pairM, pairsW, pstartW; };
+    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, rec, chunkC, pairPart, parts, pairM, pairsW, pstartW; };
     bool tiles = wide && n0 > 0;     // wide layout: Schur complement by tiles when every layout-0 window carries the structures
     for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
+    const bool use_rec = wide && !tiles && h->schur_vinv && h->edge_rec;   // compact edge records (k_w_schur_rec): no B_e blocks at all
     const int nwg_call = std::max(1, std::min(16, (2 * 256 + std::max(n0, 1) - 1) / std::max(n0, 1)));   // workgroups per window: ~2 per CU over the call
     size_t tiles_lds = 0, packed_lds = 0, ldsm_lds = 0;
     int maxWg = 1, maxSum = 1, min_n6_big = 1 << 30;   // (min_n6_big: the smallest reduced system of the call)
@@ -2437,7 +2658,7 @@ static int lba_launch(oslam_lba_t* h) {
             o.Hs = q.hs_global ? takeW(n6 * (n6 + 1) * 8) : 0;
             win_lds = std::max(win_lds, win_persist_bytes((int)K, q.nfree) + 8 * (size_t)q.region_doubles);
         } else {
-            o.Hpl = takeW(E * 144); o.Dinv = takeW(P * 72); o.xl = takeW(P * 24); o.Hpp = takeW(K * 288); o.bp = takeW(K * 48); o.Hs = takeW(n6 * (n6 + 1) * 8); o.xp = takeW((n6 + 8) * 8);
+            o.Hpl = use_rec ? 0 : takeW(E * 144); o.Dinv = takeW(P * 72); o.xl = takeW(P * 24); o.Hpp = takeW(K * 288); o.bp = takeW(K * 48); o.Hs = takeW(n6 * (n6 + 1) * 8); o.xp = takeW((n6 + 8) * 8);
             if (wide) {
                 const int j = (int)(std::find(idx0.begin(), idx0.end(), i) - idx0.begin());
                 o.ctrl = ctrl_base + sizeof(LbaCtrl) * j; o.T = takeW(sizeof(SE3) * 2 * K); o.R = takeW(144 * K); o.blk = takeW(4 * K); o.free_pose = takeW(4 * K);
@@ -2448,7 +2669,9 @@ static int lba_launch(oslam_lba_t* h) {
                     tiles_lds = std::max(tiles_lds, 8 * win_tile_doubles(q.TE, q.TP));
                     maxWg = std::max(maxWg, nwg); maxSum = std::max(maxSum, div_up(q.nblk * 42, 256));
                 } else {
-                    o.W = takeW(E * 144);
+                    // (per-landmark inverses: 48 bytes per point, whatever the edge count — a window may hold points without edges)
+                    o.W = takeW(use_rec ? P * 48 : std::max(E * 144, h->schur_vinv ? P * 48 : (size_t)0));
+                    o.rec = use_rec ? takeW(E * 32) : 0;
                     if (q.dev_pairs) { o.pairsW = takeW(std::max<size_t>(q.npairs, 1) * 8); o.pstartW = takeW(((size_t)q.nblk + 1) * 4); any_dev_pairs = true; }   // (pairM: one block for the call, below)
                 }
                 if ((int)n6 <= kCholPackedN) packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
@@ -2500,7 +2723,7 @@ static int lba_launch(oslam_lba_t* h) {
         pr.Xa = (double*)(Wk + o.Xa); pr.Xb = (double*)(Wk + o.Xb); pr.chi2 = (double*)(Wk + o.chi2); pr.level = Wk + o.level;
         pr.Hll = (double*)(Wk + o.Hll); pr.bl = (double*)(Wk + o.bl);
         if (q.layout == 0) {
-            pr.Hpl = (double*)(Wk + o.Hpl);
+            pr.Hpl = use_rec ? nullptr : (double*)(Wk + o.Hpl);
             pr.Dinv = (double*)(Wk + o.Dinv); pr.xl = (double*)(Wk + o.xl); pr.Hpp = (double*)(Wk + o.Hpp); pr.bp = (double*)(Wk + o.bp); pr.Hs = (double*)(Wk + o.Hs);
             pr.xp = (double*)(Wk + o.xp);
         }
@@ -2517,6 +2740,7 @@ static int lba_launch(oslam_lba_t* h) {
         if (wide) {
             w.ct = (LbaCtrl*)(Wk + o.ctrl); w.T = (SE3*)(Wk + o.T); w.R = (double*)(Wk + o.R); w.blk = (int*)(Wk + o.blk); w.free_pose = (int*)(Wk + o.free_pose);
             w.partF = (double*)(Wk + o.partF); w.partS = (double*)(Wk + o.partS); w.partM = (double*)(Wk + o.partM); w.W = (double*)(Wk + o.W);
+            w.rec = use_rec ? (double*)(Wk + o.rec) : nullptr;
             w.nblk_pt = div_up(std::max(q.pr.P, 1), kWPt);
             w.pairs = (const int2*)(I + q.o_pairs); w.pair_start = (const int*)(I + q.o_pstart);
             if (q.dev_pairs && !tiles) {
@@ -2524,7 +2748,7 @@ static int lba_launch(oslam_lba_t* h) {
                 w.pairs = w.pairs_w; w.pair_start = w.pair_start_w;
             }
             if (tiles) {
-                w.W = nullptr;
+                w.W = nullptr; w.rec = nullptr;
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
                 w.thr_own = (const int*)(I + q.o_thr_own);
                 w.blk_thr = (const int*)(I + q.o_blk_thr); w.blk_slots = (const int*)(I + q.o_blk_slots); w.parts = (double*)(Wk + o.parts);
@@ -2613,13 +2837,17 @@ static int lba_launch(oslam_lba_t* h) {
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
-                hipLaunchKernelGGL(k_w_lin, dim3(maxNbPt + maxK, ny_xcd), dim3(kLinThreads), 0, st, d_probs, d_ws, n0);
+                if (use_rec) hipLaunchKernelGGL(k_w_lin<true>, dim3(maxNbPt + maxK, ny_xcd), dim3(kLinThreads), 0, st, d_probs, d_ws, n0);
+                else hipLaunchKernelGGL(k_w_lin<false>, dim3(maxNbPt + maxK, ny_xcd), dim3(kLinThreads), 0, st, d_probs, d_ws, n0);
                 if (tiles) {
                     hipLaunchKernelGGL(k_w_ctrlA, dim3(1, n0), dim3(64), 0, st, d_probs, d_ws);   // (the pair-gather path folds this step into k_w_edgeW / k_w_ctrlB)
                     hipLaunchKernelGGL(k_w_schur_tiles, dim3(maxWg, n0), dim3(kWinThreads), tiles_lds, st, d_probs, d_ws);
                     hipLaunchKernelGGL(k_w_schur_sum, dim3(maxSum, n0), dim3(256), 0, st, d_probs, d_ws);
                 } else {
-                    if (h->schur_vinv) {
+                    if (use_rec) {
+                        hipLaunchKernelGGL(k_w_edgeW<true>, dim3(div_up(maxNbPt * kWPt, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
+                        hipLaunchKernelGGL(k_w_schur_rec, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
+                    } else if (h->schur_vinv) {
                         hipLaunchKernelGGL(k_w_edgeW<true>, dim3(div_up(maxNbPt * kWPt, 256), ny_xcd), dim3(256), 0, st, d_probs, d_ws, n0);
                         hipLaunchKernelGGL(k_w_schur<true>, dim3(maxBlk, ny_xcd), dim3(64), 0, st, d_probs, d_ws, n0);
                     } else {
@@ -2633,7 +2861,8 @@ static int lba_launch(oslam_lba_t* h) {
                 if (chol_ldsm || chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
-                hipLaunchKernelGGL(k_w_update, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);   // (+ the trial's chi2: k_w_eval of rounds 1-3)
+                if (use_rec) hipLaunchKernelGGL(k_w_update<true>, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                else hipLaunchKernelGGL(k_w_update<false>, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);   // (+ the trial's chi2: k_w_eval of rounds 1-3)
                 hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
             }
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
