@@ -468,7 +468,8 @@ int oslam_mp_update_normal_depth(oslam_mappoint_t* h, int P, const float* Pos /*
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:345-430) and / or UpdateNormalAndDepth (:432-474) for P points in ONE launch, for the driver's small
  * updates: the descriptors of the observations are read from resident keyframe records (d_rec = (record, keypoint) per entry of the descriptor list d_desc_start,
  * d_rec_desc[record] = that keyframe's descriptor array), the results go to o_best / o_desc / o_out5 — any device-accessible memory, e.g. pinned host memory — and,
- * with d_tab, into the points' resident records like oslam_mp_table_write_device.  Same results as the separate functions.  At most 128 observations per point. */
+ * with d_tab, into the points' resident records like oslam_mp_table_write_device.  Same results as the separate functions.  At most 128 observations per point:
+ * a point with a longer descriptor list gets o_best = -2 and no descriptor (neither in o_desc nor in its record) — use oslam_mp_distinctive_descriptors for it. */
 int oslam_mp_update_fused_device(int P, int do_desc, int do_normal, const int32_t* d_obs_start, const int32_t* d_desc_start, const int32_t* d_rec, const uint8_t* const* d_rec_desc,
                                  const float* d_obs_Ow, const float* d_Pos, const float* d_OwRef, const float* d_lsf, float lastScale, const int32_t* d_items, uint8_t* const* d_tab,
                                  int32_t* o_best, uint8_t* o_desc, float* o_out5, void* stream);

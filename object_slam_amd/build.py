@@ -67,19 +67,25 @@ def build_hip(force=False, verbose=False):
             todo.append((src, obj))
 
     def compile_one(job):
-        cmd = [HIPCC] + FLAGS + ["-MD", "-MF", job[1] + ".d", "-c", job[0], "-o", job[1]]
+        # objects and dependency files appear under their final names only when complete (os.replace): several ranks / test workers may build the same
+        # stale library at once, and none of them may link or date-check another one's half-written file
+        tmp = "%s.%d.tmp" % (job[1], os.getpid())
+        cmd = [HIPCC] + FLAGS + ["-MD", "-MF", tmp + ".d", "-MT", job[1], "-c", job[0], "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(tmp + ".d", job[1] + ".d")
+        os.replace(tmp, job[1])
 
     jobs = int(os.environ.get("OSLAM_BUILD_JOBS", "0")) or min(6, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj_path(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    lib_tmp = "%s.%d.tmp" % (LIB, os.getpid())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj_path(s) for s in SOURCES] + ["-o", lib_tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(lib_tmp, LIB)
     return LIB
 
 

@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_w_edgeW(const LbaProblem* probs, const 
 // ---- Schur pair lists built on the device (once per call; the host used to spend ~430 us per steady-state window on them and upload 8 bytes per pair) ----
 // Block t = (a, b), a <= b, of the reduced system lists the points both free keyframes see, ascending, as (edge in a, edge in b): exactly the order of the host
 // builder in lba_build (a point has one observation per keyframe), so the sums of k_w_schur do not change by a bit.
-//   k_w_pair_matrix : M[p][a] = 1 + position of the edge of point p in free keyframe a inside the point's edge range (0 = not seen); M is zeroed by the caller
+//   k_w_pair_matrix : M[a][p] = 1 + position of the edge of point p in free keyframe a inside the point's edge range (0 = not seen); M is zeroed by the caller
 //   k_w_pair_blocks : one wavefront per block walks the points 64 at a time — FILL = false counts, FILL = true writes the pairs at pair_start[t] + rank
 //   k_w_pair_scan   : one wavefront per window, exclusive scan of the counts into pair_start[0 .. nblk]
 __global__ __launch_bounds__(256) void k_w_pair_matrix(const LbaProblem* probs, const LbaWide* ws) {
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_w_pair_matrix(const LbaProblem* probs, 
     const int a = w.blk[pr.e_kf[e]];
     if (a < 0) return;
     const int p = pr.e_pt[e];
-    w.pairM[(size_t)p * w.ct->nfree + a] = (uint16_t)(e - pr.pt_start[p] + 1);
+    w.pairM[(size_t)a * pr.P + p] = (uint16_t)(e - pr.pt_start[p] + 1);   // keyframe-major: k_w_pair_blocks reads a keyframe's row 64 consecutive points at a time
 }
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_w_pair_blocks(const LbaProblem* probs, const LbaWide* ws) {
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_w_pair_blocks(const LbaProblem* probs, c
     for (int p0 = 0; p0 < pr.P; p0 += 64) {
         const int p = p0 + lane;
         int ma = 0, mb = 0;
-        if (p < pr.P) { ma = w.pairM[(size_t)p * nfree + ba]; mb = w.pairM[(size_t)p * nfree + bb]; }
+        if (p < pr.P) { ma = w.pairM[(size_t)ba * pr.P + p]; mb = w.pairM[(size_t)bb * pr.P + p]; }
         const bool has = ma != 0 && mb != 0;
         const unsigned long long bal = __ballot(has);
         if (FILL && has) {
@@ -1251,98 +1251,116 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_
     const int q0 = w.pair_start[t], q_end = w.pair_start[t + 1];
     const double2* rec = (const double2*)w.rec;
     const double2* Vg = (const double2*)w.W;
-    // operands of a round are requested one round ahead of the arithmetic
-    int2 pe = make_int2(0, 0);
-    double2 a0 = make_double2(0.0, 0.0), a1 = make_double2(1.0, 0.0), b0 = a0, b1 = a1, v0 = a0, v1 = a0, v2 = a0;
-    int pt = 0;
-    if (q0 + lane < q_end) {
-        pe = w.pairs[q0 + lane];
-        a0 = rec[(long long)pe.x * 2]; a1 = rec[(long long)pe.x * 2 + 1];
-        if (!diag) { b0 = rec[(long long)pe.y * 2]; b1 = rec[(long long)pe.y * 2 + 1]; }
-        pt = pr.e_pt[pe.x];
-        v0 = Vg[(long long)pt * 3]; v1 = Vg[(long long)pt * 3 + 1]; v2 = Vg[(long long)pt * 3 + 2];
-    }
-    for (int q = q0 + lane; q < q_end; q += 64) {
-        const double2 ca0 = a0, ca1 = a1, cb0 = diag ? a0 : b0, cb1 = diag ? a1 : b1, cv0 = v0, cv1 = v1, cv2 = v2;
-        const int cpt = pt;
-        if (q + 64 < q_end) {
-            pe = w.pairs[q + 64];
-            a0 = rec[(long long)pe.x * 2]; a1 = rec[(long long)pe.x * 2 + 1];
-            if (!diag) { b0 = rec[(long long)pe.y * 2]; b1 = rec[(long long)pe.y * 2 + 1]; }
-            pt = pr.e_pt[pe.x];
-            v0 = Vg[(long long)pt * 3]; v1 = Vg[(long long)pt * 3 + 1]; v2 = Vg[(long long)pt * 3 + 2];
-        }
-        const double wa = fabs(ca1.y), wb = fabs(cb1.y);
-        if (wa == 0.0 || wb == 0.0) continue;
-        const bool sa = !__builtin_signbit(ca1.y), sb = !__builtin_signbit(cb1.y);
-        const double pa[3] = {ca0.x, ca0.y, 0.0}, pb[3] = {cb0.x, cb0.y, 0.0};
+    // Operands of a round are requested one round ahead of the arithmetic, in two register sets used in turn (the loop below is unrolled by two: no copies).
+    struct Ops { double2 a0, a1, b0, b1, v0, v1, v2; int pt; };
+    auto fetch = [&](Ops& o, int q) {
+        const int2 pe = w.pairs[(unsigned)q];   // (32-bit offsets from wave-uniform bases)
+        o.a0 = rec[(unsigned)pe.x * 2u]; o.a1 = rec[(unsigned)pe.x * 2u + 1u];
+        if (!diag) { o.b0 = rec[(unsigned)pe.y * 2u]; o.b1 = rec[(unsigned)pe.y * 2u + 1u]; }
+        o.pt = pr.e_pt[(unsigned)pe.x];
+        o.v0 = Vg[(unsigned)o.pt * 3u]; o.v1 = Vg[(unsigned)o.pt * 3u + 1u]; o.v2 = Vg[(unsigned)o.pt * 3u + 2u];
+    };
+    auto compute = [&](const Ops& o) {
+        const double2 cb0 = diag ? o.a0 : o.b0, cb1 = diag ? o.a1 : o.b1;
+        const double wa = fabs(o.a1.y), wb = fabs(cb1.y);
+        if (wa == 0.0 || wb == 0.0) return;
+        // A monocular edge has no u_R row: its weight for that row is 0, so row r of (w Jx) — and with it row / column r of M — is zero and whatever the
+        // stereo formulas put into Jx's and Jp's third rows is multiplied by zeros.
+        const double wra = __builtin_signbit(o.a1.y) ? 0.0 : wa, wrb = __builtin_signbit(cb1.y) ? 0.0 : wb;
+        const double pa[3] = {o.a0.x, o.a0.y, 0.0}, pb[3] = {cb0.x, cb0.y, 0.0};
         // N = (w_a Jx_a) V^-1
         double Jxa[9], N[9];
-        point_jac_rows(cam, pa, ca1.x, Ra, sa, Jxa);
+        point_jac_rows(cam, pa, o.a1.x, Ra, true, Jxa);
         {
-            const double d0 = cv0.x, d1 = cv0.y, d2 = cv1.x, d4 = cv1.y, d5 = cv2.x, d8 = cv2.y;   // V^-1: [0], [1] = [3], [2] = [6], [4], [5] = [7], [8]
+            const double d0 = o.v0.x, d1 = o.v0.y, d2 = o.v1.x, d4 = o.v1.y, d5 = o.v2.x, d8 = o.v2.y;   // V^-1: [0], [1] = [3], [2] = [6], [4], [5] = [7], [8]
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                const double g0 = wa * Jxa[d * 3], g1 = wa * Jxa[d * 3 + 1], g2 = wa * Jxa[d * 3 + 2];
+                const double wd = d == 2 ? wra : wa;
+                const double g0 = wd * Jxa[d * 3], g1 = wd * Jxa[d * 3 + 1], g2 = wd * Jxa[d * 3 + 2];
                 N[d * 3] = g0 * d0 + g1 * d1 + g2 * d2;
                 N[d * 3 + 1] = g0 * d1 + g1 * d4 + g2 * d5;
                 N[d * 3 + 2] = g0 * d2 + g1 * d5 + g2 * d8;
             }
         }
         double Jua[6], Jva[6], Jra[6];
-        pose_jac_rows(cam, pa, ca1.x, sa, Jua, Jva, Jra);
+        pose_jac_rows(cam, pa, o.a1.x, true, Jua, Jva, Jra);
         if (diag) {   // rhs: W_a b_l = Jp_a^T (N b_l)
-            const double* bl = pr.bl + (long long)cpt * 3;
+            const double* bl = pr.bl + (unsigned)o.pt * 3u;
             const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
             const double n0 = N[0] * l0 + N[1] * l1 + N[2] * l2, n1 = N[3] * l0 + N[4] * l1 + N[5] * l2, n2 = N[6] * l0 + N[7] * l1 + N[8] * l2;
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                double sv = 0;   // (Ju[4] = Jv[3] = Jr[4] = 0)
-                if (i != 4) sv += Jua[i] * n0;
-                if (i != 3) sv += Jva[i] * n1;
-                if (i != 4) sv += Jra[i] * n2;
-                bsv[i] += sv;
+            for (int i = 0; i < 6; i++) {   // (Ju[4] = Jv[3] = Jr[4] = 0; every term is accumulated by its own fused multiply-add)
+                if (i != 4) bsv[i] = __builtin_fma(Jua[i], n0, bsv[i]);
+                if (i != 3) bsv[i] = __builtin_fma(Jva[i], n1, bsv[i]);
+                if (i != 4) bsv[i] = __builtin_fma(Jra[i], n2, bsv[i]);
             }
         }
         // M = N (w_b Jx_b)^T
         double Jxb[9], M[9];
-        point_jac_rows(cam, pb, cb1.x, Rb, sb, Jxb);
+        point_jac_rows(cam, pb, cb1.x, Rb, true, Jxb);
 #pragma unroll
         for (int db = 0; db < 3; db++) {
-            const double g0 = wb * Jxb[db * 3], g1 = wb * Jxb[db * 3 + 1], g2 = wb * Jxb[db * 3 + 2];
+            const double wd = db == 2 ? wrb : wb;
+            const double g0 = wd * Jxb[db * 3], g1 = wd * Jxb[db * 3 + 1], g2 = wd * Jxb[db * 3 + 2];
 #pragma unroll
             for (int da = 0; da < 3; da++) M[da * 3 + db] = N[da * 3] * g0 + N[da * 3 + 1] * g1 + N[da * 3 + 2] * g2;
         }
         double Jub[6], Jvb[6], Jrb[6];
-        pose_jac_rows(cam, pb, cb1.x, sb, Jub, Jvb, Jrb);
+        pose_jac_rows(cam, pb, cb1.x, true, Jub, Jvb, Jrb);
         // acc += Jp_a^T M Jp_b over the non-zero Jacobian entries
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            double T0 = 0, T1 = 0, T2 = 0;   // row i of Jp_a^T M
-            if (i != 4) { T0 += Jua[i] * M[0]; T1 += Jua[i] * M[1]; T2 += Jua[i] * M[2]; }
-            if (i != 3) { T0 += Jva[i] * M[3]; T1 += Jva[i] * M[4]; T2 += Jva[i] * M[5]; }
-            if (i != 4) { T0 += Jra[i] * M[6]; T1 += Jra[i] * M[7]; T2 += Jra[i] * M[8]; }
+            double T0, T1, T2;   // row i of Jp_a^T M
+            if (i == 4) { T0 = Jva[i] * M[3]; T1 = Jva[i] * M[4]; T2 = Jva[i] * M[5]; }
+            else {
+                T0 = Jua[i] * M[0]; T1 = Jua[i] * M[1]; T2 = Jua[i] * M[2];
+                if (i != 3) { T0 = __builtin_fma(Jva[i], M[3], T0); T1 = __builtin_fma(Jva[i], M[4], T1); T2 = __builtin_fma(Jva[i], M[5], T2); }
+                T0 = __builtin_fma(Jra[i], M[6], T0); T1 = __builtin_fma(Jra[i], M[7], T1); T2 = __builtin_fma(Jra[i], M[8], T2);
+            }
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                double sv = 0;
-                if (j != 4) sv += T0 * Jub[j];
-                if (j != 3) sv += T1 * Jvb[j];
-                if (j != 4) sv += T2 * Jrb[j];
-                acc[i * 6 + j] += sv;
+                if (j != 4) acc[i * 6 + j] = __builtin_fma(T0, Jub[j], acc[i * 6 + j]);
+                if (j != 3) acc[i * 6 + j] = __builtin_fma(T1, Jvb[j], acc[i * 6 + j]);
+                if (j != 4) acc[i * 6 + j] = __builtin_fma(T2, Jrb[j], acc[i * 6 + j]);
             }
         }
+    };
+    {
+        Ops oa, ob;
+        oa.a0 = ob.a0 = oa.b0 = ob.b0 = make_double2(0.0, 0.0); oa.a1 = ob.a1 = oa.b1 = ob.b1 = make_double2(1.0, 0.0);
+        oa.v0 = oa.v1 = oa.v2 = ob.v0 = ob.v1 = ob.v2 = make_double2(0.0, 0.0); oa.pt = ob.pt = 0;
+        int q = q0 + lane;
+        if (q < q_end) fetch(oa, q);
+        while (q < q_end) {
+            if (q + 64 < q_end) fetch(ob, q + 64);
+            compute(oa);
+            q += 64;
+            if (q >= q_end) break;
+            if (q + 64 < q_end) fetch(oa, q + 64);
+            compute(ob);
+            q += 64;
+        }
     }
-    // reduction: as k_w_schur (quad sums by DPP, then the 16 quad sums of every entry in lane order through LDS)
+    // reduction: quad sums by DPP, then the 16 quad sums of every entry in lane order through LDS
     auto quad_sum = [](double v) {
         v += dpp_quad_f64<0xB1>(v);
         v += dpp_quad_f64<0x4E>(v);
         return v;
     };
 #pragma unroll
-    for (int i = 0; i < 36; i++) { const double q4 = quad_sum(acc[i]); if ((lane & 3) == 0) red[i * 17 + (lane >> 2)] = q4; }
+    for (int i = 0; i < 36; i++) acc[i] = quad_sum(acc[i]);
     if (diag) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) { const double q4 = quad_sum(bsv[i]); if ((lane & 3) == 0) red[(36 + i) * 17 + (lane >> 2)] = q4; }
+        for (int i = 0; i < 6; i++) bsv[i] = quad_sum(bsv[i]);
+    }
+    if ((lane & 3) == 0) {
+        double* rq = red + (lane >> 2);
+#pragma unroll
+        for (int i = 0; i < 36; i++) rq[i * 17] = acc[i];
+        if (diag) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) rq[(36 + i) * 17] = bsv[i];
+        }
     }
     __syncthreads();
     double mine = 0;
@@ -2090,7 +2108,7 @@ struct oslam_lba {
     int wide = 1;                 // 1: every LM trial of all windows as whole-GPU launches, 0: one workgroup per window in one launch (k_lba, the round-1 kernel),
                                   // 2: one workgroup per window, LDS-resident reduced system (k_lba_win); windows that do not fit its LDS go through layout 1
     size_t win_lds_max = 0;       // dynamic LDS a k_lba_win workgroup may use
-    int edge_rec = 1;             // pair gather with per-landmark inverses: compact 32-byte edge records instead of the 144-byte B_e blocks (k_w_schur_rec; round 5 default), 0 = materialised B_e
+    int edge_rec = 1;             // pair gather with per-landmark inverses: compact 32-byte edge records instead of the 144-byte B_e blocks (k_w_schur_rec; round 5 default), 0 = materialised B_e (OSLAM_LBA_REC)
     int schur_vinv = 1;           // pair gather: W_e = B_e V^-1 formed inside k_w_schur from per-landmark inverses (1, default) or materialised per edge by k_w_edgeW (0: rounds 1-3)
     int schur_tiles = 0;          // wide layout, Schur complement (default 0: in the bench the gather is as fast or faster at every window size, see below): 1 = by LDS tiles (k_w_schur_tiles: one coalesced read of Hpl per trial), 0 = by the pair gather
                                   // (k_w_edgeW + k_w_schur: 288 bytes per pair from memory), 2 = per call: tiles when the windows average >= kSchurTilesMinEdges edges.
@@ -2873,7 +2891,9 @@ static int lba_launch(oslam_lba_t* h) {
             group = 4;
         }
         hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n0), dim3(256), 0, st, d_probs, d_ws);
-        launches += 3 + (tiles ? 7 : 6) * (long long)slots_done;
+        // launches per trial slot: linearisation, (control step +) Schur complement, the solver kernels this call mixes, update, control
+        const int n_chol = (chol_ldsm ? 1 : 0) + (chol_packed ? 1 : 0) + (chol_mfma ? 1 : 0);
+        launches += 3 + (1 + (tiles ? 3 : 2) + std::max(n_chol, 1) + 2) * (long long)slots_done;
     }
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());

@@ -722,8 +722,8 @@ __global__ __launch_bounds__(256) void k_mp_update_fused(MpFused c) {
     if (c.do_desc) {
         const int s = c.desc_start[p], N = c.desc_start[p + 1] - s;
         uint32_t* od = (uint32_t*)(c.o_desc + (size_t)p * 32);
-        if (N <= 0) {
-            if (lane == 0) c.o_best[p] = -1;
+        if (N <= 0 || N > kDdMaxObs) {   // (more observations than the staging slice holds: reported as best = -2, the point's descriptor is left to the caller)
+            if (lane == 0) c.o_best[p] = N <= 0 ? -1 : -2;
             if (lane < 8) od[lane] = 0u;
         } else {
             uint32_t* D = s_d[wv];
