@@ -1620,6 +1620,53 @@ __device__ __forceinline__ double rl_f64(double v, int src) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
+// Cholesky factor AND inverse of a 16x16 diagonal block in ONE pass of one wavefront (round 5).  The wavefront holds the 16 x 32 matrix [A | I]: lane
+// 32 h + c keeps column c (c < 16: A, c >= 16: the identity) of the rows of parity h, row 2 s + h in R[s].  The right-looking factorisation A = U^T U applies
+// to every column the row operations that turn A into U, so the identity half ends as U^-T: after the 16 steps R holds [U | U^-T] and V = U^-1 = (U^-T)^T —
+// no second substitution pass.  Step j: the pivot comes from one lane (readlane: a scalar); row j reaches the other parity's lanes and the entries
+// U(j, i) reach the lanes of the rows i below by ds_bpermute — all of a step's permutes read the one register that holds row j and are issued together, so a
+// step costs one crossbar round trip plus 8 multiply / multiply-add pairs, with every lane busy.  The round-4 form (lane k = column k in 16 lanes, 120 + 120
+// readlane pairs in two dependent chains) took 5.2 us per block and was the critical path of a panel.
+// Rows and columns >= nb are padded with the identity by the caller.  Returns (wave-uniform) whether every pivot was positive and finite.
+__device__ __forceinline__ double bperm_f64(int byte_addr, double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b & 0xffffffffll)), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double rcp_nr2(double z) {
+    double r = __builtin_amdgcn_rcp(z);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-z, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ bool chol16_aug(double (&R)[8], int lane) {
+#pragma clang fp contract(fast)
+    const int h = lane >> 5, c = lane & 31;
+    bool good = true;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int sj = j >> 1, hj = j & 1;
+        // requests of this step: row j at my column; U(j, i) for my rows i = 2 s + h > j
+        const double rowj = bperm_f64((hj * 32 + c) * 4, R[sj]);
+        double u[8];
+#pragma unroll
+        for (int sI = 0; sI < 8; sI++)
+            if (2 * sI + 1 > j) u[sI] = bperm_f64((hj * 32 + 2 * sI + h) * 4, R[sj]);
+        const double d = rl_f64(R[sj], hj * 32 + j);
+        good = good && (d > 0) && (d < 1.7e308);
+        const double rd = rcp_nr2(d), r = rsqrt_nr(d);
+#pragma unroll
+        for (int sI = 0; sI < 8; sI++) {
+            if (2 * sI + 1 < j + 1) continue;           // rows 2 s, 2 s + 1 <= j
+            if (2 * sI > j) R[sI] = __builtin_fma(-(u[sI] * rd), rowj, R[sI]);                 // both parities below row j
+            else if (h == 1) R[sI] = __builtin_fma(-(u[sI] * rd), rowj, R[sI]);                // 2 s == j: only row 2 s + 1
+        }
+        if (h == hj) R[sj] = rowj * r;   // row j is final: U(j, .) | U^-T(j, .)
+    }
+    return good;
+}
+
 constexpr int kMfmaThreads = 512;   // 8 wavefronts: 256 registers each (the four-tile trailing step needs ~150; 1024 threads would cap them at 128 and spill)
 // Body of the matrix-core solve for one workgroup of kMfmaThreads threads: A = augmented system [n][n + 1] in global memory (upper triangle + rhs column),
 // s_P = LDS row panel of 16 x pw doubles (pw = ((n + 1 + 15) / 16 + 1) * 16), s_x = LDS vector of n + 16 doubles; the solution goes to x (global or LDS).
@@ -1639,33 +1686,21 @@ __device__ __forceinline__ bool chol_mfma_dev(double* A, int n, double* x, doubl
         // to 16x16 with the identity; the pivot and the entries of row j reach the other lanes by readlane, no LDS round trip inside the 16 steps (the LDS form
         // took ~8 us per block).  Then V = U11^-1 by back substitution on the identity, column k in lane k, into s_D for the row-panel product. ----
         if (wv == 0) {
-            const int kc = lane & 15;
-            double U[kMB], Y[kMB];
+            const int hh = lane >> 5, cc = lane & 31;
+            double R[8];
 #pragma unroll
-            for (int i = 0; i < kMB; i++) U[i] = (i < nb && kc < nb && kc >= i) ? A[(size_t)(j0 + i) * ld + j0 + kc] : (i == kc ? 1.0 : 0.0);
-            bool good = true;
-#pragma unroll
-            for (int j = 0; j < kMB; j++) {
-                const double d = rl_f64(U[j], j);
-                good = good && (d > 0) && (d < 1.7e308);
-                const double r = rsqrt_nr(d);
-                // row j of Y = U^-T (forward substitution on the identity, column kc of Y in this lane): its inputs U(i, j), i < j, are final since step i, so this
-                // chain runs beside the factor's own dependent chain instead of after it (V = U^-1 = Y^T)
-                double sy = kc == j ? 1.0 : 0.0;
-#pragma unroll
-                for (int i = 0; i < j; i++) sy -= rl_f64(U[i], j) * Y[i];
-                Y[j] = sy * r;
-                U[j] = kc == j ? d * r : U[j] * r;
-#pragma unroll
-                for (int i = j + 1; i < kMB; i++) U[i] -= rl_f64(U[j], i) * U[j];   // (lanes left of column i keep garbage below their diagonal: never read)
+            for (int sI = 0; sI < 8; sI++) {
+                const int i = 2 * sI + hh;
+                if (cc < kMB) R[sI] = (i < nb && cc < nb && cc >= i) ? A[(size_t)(j0 + i) * ld + j0 + cc] : (i == cc ? 1.0 : 0.0);
+                else R[sI] = (cc - kMB == i) ? 1.0 : 0.0;
             }
+            const bool good = chol16_aug(R, lane);
             if (!good && lane == 0) s_ok = 0;
-            if (lane < kMB) {
 #pragma unroll
-                for (int i = 0; i < kMB; i++) {
-                    s_D[kc][i] = Y[i];
-                    if (i < nb && kc < nb && kc >= i) A[(size_t)(j0 + i) * ld + j0 + kc] = U[i];   // the factor back into the matrix (back substitution reads it)
-                }
+            for (int sI = 0; sI < 8; sI++) {
+                const int i = 2 * sI + hh;
+                if (cc < kMB) { if (i < nb && cc < nb && cc >= i) A[(size_t)(j0 + i) * ld + j0 + cc] = R[sI]; }   // the factor back into the matrix (back substitution reads it)
+                else s_D[cc - kMB][i] = R[sI];                                                                      // V = U11^-1: V[k][i] = U^-T[i][k]
             }
         }
         __syncthreads();
