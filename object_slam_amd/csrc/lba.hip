@@ -2887,6 +2887,8 @@ static int lba_launch(oslam_lba_t* h) {
         // worst case 15 iterations x 10 trials; slots past `done` return at once.  First group = the minimum number of LM trials (one per
         // iteration), so the common case needs a single host round trip; rejected steps add groups of 4.
         const int ny_xcd = n0 >= 8 ? (n0 + 7) / 8 * 8 : n0;   // grid rows of the kernels that map a window to one XCD (xcd_window_item)
+        static const double gate_release_frac = [] { const char* e = getenv("OSLAM_LBA_GATE_RELEASE"); return e ? atof(e) : 0.0; }();
+        static const bool call_stats = getenv("OSLAM_LBA_CALL_STATS") != nullptr;   // per host poll: windows of the call, trial slots enqueued so far, windows not done
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
@@ -2921,8 +2923,16 @@ static int lba_launch(oslam_lba_t* h) {
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
             OSLAM_HIP_CHECK(stream_wait(st));
             bool all_done = true;
-            for (int i = 0; i < n0; i++) all_done = all_done && h->h_ctrl[i].done != 0;
+            int n_active = 0;
+            for (int i = 0; i < n0; i++) { all_done = all_done && h->h_ctrl[i].done != 0; n_active += h->h_ctrl[i].done == 0; }
+            if (call_stats) fprintf(stderr, "[lba call] %d windows, %d slots done, %d active\n", n0, slots_done, n_active);
             if (all_done) break;
+            // The tail of a call — the few windows whose LM rejects steps (after the first 15 slots ~16 % of the windows of a steady-state call are still active,
+            // after 19 slots ~6 %) — is a chain of latency-bound launches that leaves the card almost idle: the solver that shares the gate may start its call
+            // beside it when OSLAM_LBA_GATE_RELEASE=f is set (release once <= f x windows are active).  Default off: same-box A/B of the headline with f = 0.25,
+            // alternating runs: 35.2 / 38.7 k frames/s against 37.7 / 38.5 k without — the overlapping call stretches this call's kernels (local-BA device time
+            // 3.6 -> 3.9-4.4 s per 20 steps) by what the tail used to idle.
+            if (handle_gate.owns_lock() && gate_release_frac > 0 && (double)n_active <= gate_release_frac * n0) handle_gate.unlock();
             group = 4;
         }
         hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n0), dim3(256), 0, st, d_probs, d_ws);

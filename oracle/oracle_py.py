@@ -26,6 +26,16 @@ def build(force=False):
     return _SO
 
 
+def native_lib():
+    """bench.py's CPU baseline: the oracle built -march=native ON THE HOST IT IS TIMED ON (make native); falls back to the portable build.  Returns (CDLL, march)."""
+    so = os.path.join(_HERE, "_build", "liboslam_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"])
+        return C.CDLL(so), "native"
+    except (OSError, subprocess.CalledProcessError):
+        return lib(), "x86-64-v3 (the native build failed on this host)"
+
+
 _lib = None
 
 

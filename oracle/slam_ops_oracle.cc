@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../include/oslam_slam.h"
@@ -55,6 +56,7 @@ struct OCtx {
     int cap;
     float scale[16], invScale[16], sigma2[16], invSigma2[16];
     float bounds[4], K4[4], K5[5], K6[6];
+    std::thread lba_thread;   // oo_slam_make_ops_threaded: the local BA in flight (the reference's LocalMapping thread, src/System.cc:95)
 };
 
 int o_max_keypoints(void* p) { return ((OCtx*)p)->cap; }
@@ -225,6 +227,19 @@ int o_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     return 0;
 }
 
+// The deferred schedule's operator pair on a second thread: the solve of keyframe t runs while the caller tracks frame t + 1 (bench.py's two-thread CPU baseline).
+int o_lba_submit(void* p, int n, const oslam_lba_problem_t* pr) {
+    OCtx* o = (OCtx*)p;
+    if (o->lba_thread.joinable()) o->lba_thread.join();
+    o->lba_thread = std::thread([o, n, pr] { o_lba(o, n, pr); });
+    return 0;
+}
+int o_lba_wait(void* p) {
+    OCtx* o = (OCtx*)p;
+    if (o->lba_thread.joinable()) o->lba_thread.join();
+    return 0;
+}
+
 int o_fuse(void* p, int n, oslam_job_fuse_t* jobs) {
     OCtx* o = (OCtx*)p;
     std::vector<int> qd;
@@ -270,6 +285,7 @@ int o_triangulate(void* p, int n, oslam_job_triangulate_t* jobs) {
 
 void o_destroy(void* p) {
     OCtx* o = (OCtx*)p;
+    if (o->lba_thread.joinable()) o->lba_thread.join();
     oo_orb_destroy(o->orb);
     oo_orb_destroy(o->orbR);
     delete o;
@@ -297,5 +313,13 @@ extern "C" int oo_slam_make_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t
     ops->search_last = o_search_last; ops->search_local = o_search_local; ops->pose_opt = o_pose_opt; ops->mp_update = o_mp_update; ops->lba = o_lba;
     ops->fuse = o_fuse; ops->bow = o_bow; ops->triangulate = o_triangulate; ops->destroy = o_destroy; ops->frames_stereo = o_frames_stereo;
     ops->object_kps = o_object_kps; ops->pose_opt2 = o_pose_opt2;
+    return 0;
+}
+
+// The same table with the local BA of the deferred schedule on its own thread (lba_submit / lba_wait): same results, two busy cores.
+extern "C" int oo_slam_make_ops_threaded(const oslam_slam_config_t* cfg, oslam_slam_ops_t* ops) {
+    const int rc = oo_slam_make_ops(cfg, ops);
+    if (rc) return rc;
+    ops->lba_submit = o_lba_submit; ops->lba_wait = o_lba_wait;
     return 0;
 }
