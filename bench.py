@@ -92,21 +92,15 @@ def _render_piece(wl, seed, n, first, count):
     return wl.make_sequence(seed, n, first=first, count=count)
 
 
-def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
-    """The same driver over the CPU oracle's operator table on one core, on frames [offset, ...) of the stream (offset = the mean frame offset of the GPU leg's
-    sequences in their base streams): `first` frames untimed (the map reaches the state the GPU leg's sequences have when ITS timed region starts), then `n_timed`
-    frames timed."""
-    seq = {k: (v[offset:] if k in ("gray", "right", "depth", "masks", "Twc") and v is not None else v) for k, v in seq.items()}
+def _cpu_stream(L, make_ops, wl, seq, first, n_timed, local_mapping):
+    """One base stream through the product's driver over the CPU oracle's operator table `make_ops` of library L: `first` frames untimed, then `n_timed` timed."""
     import ctypes as C
     from object_slam_amd import slam
     from object_slam_amd.io import horn_align_ate
-    from oracle import oracle_py as O
-    O.build()
-    cfg = slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor, local_mapping=local_mapping)   # (the GPU leg's schedule: one core runs the same passes either way)
+    cfg = slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor, local_mapping=local_mapping)
     ops = slam.SlamOps()
-    assert O.lib().oo_slam_make_ops(C.byref(cfg), C.byref(ops)) == 0
+    assert getattr(L, make_ops)(C.byref(cfg), C.byref(ops)) == 0
     sysm = slam.System(cfg, ops)
-    per = []
     n = min(first + n_timed, len(seq["gray"]))
     has_masks = seq.get("masks") is not None
 
@@ -122,14 +116,19 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
     tp = time.perf_counter()
     for t in range(first):
         step(t)
+    if hasattr(sysm, "finish"):
+        sysm.finish()
     tp = time.perf_counter() - tp
     w0 = sysm.lba_window_stats(0)
     stg0 = sysm.stage_seconds()
+    per = []
     t0 = time.perf_counter()
     for t in range(first, n):
         t1 = time.perf_counter()
         step(t)
         per.append(time.perf_counter() - t1)
+    if hasattr(sysm, "finish"):
+        sysm.finish()          # (deferred schedule: the local BA in flight belongs to the timed frames)
     dt = time.perf_counter() - t0
     w1 = sysm.lba_window_stats(0)
     stg1 = sysm.stage_seconds()
@@ -138,22 +137,96 @@ def cpu_baseline(wl, seq, first, n_timed, local_mapping=0x1F, offset=0):
     T0inv = np.linalg.inv(seq["Twc"][0])
     gt = np.array([T0inv @ x for x in seq["Twc"][:len(Twc)]])
     st = sysm.stats(0)
-    per = np.array(per)
-    nw = max(1, w1["windows"] - w0["windows"])
+    out = {"frames": n - first, "dt": dt, "preroll_s": tp, "map_s": map_s, "per": per, "ate": horn_align_ate(Twc[:, :, 3], gt[:, :3, 3]),
+           "keyframes": st["keyframes_created"], "local_bas": st["local_bas"],
+           "win": np.array([w1[k] - w0[k] for k in ("windows", "local_kfs", "fixed_kfs", "points", "edges")], np.float64)}
+    sysm.close()
+    return out
+
+
+def cpu_baseline(wl, seqs, first, n_timed, local_mapping=0x1F, two_thread_streams=4):
+    """The same driver over the CPU oracle's operator table (kind "port"; built -march=native on this host as BASELINE.md section 3 asks), on EVERY base stream in
+    `seqs` over the stream frames the GPU leg's sequences cover in its timed region (`first` frames untimed so that the map has the same age, then `n_timed` frames
+    timed).  The streams run side by side, one core each (`value` = timed frames / core-seconds: the one-core rate); then the reference's threading shape is
+    MEASURED on `two_thread_streams` of them: the deferred schedule with the local BA on a second thread (src/System.cc:95), two cores per stream."""
+    import threading
+    from object_slam_amd import slam
+    from oracle import oracle_py as O
+    O.build()
+    L, march = O.native_lib()
+
+    def run_all(make_ops, lm, which):
+        res = [None] * len(which)
+
+        def work(i):
+            res[i] = _cpu_stream(L, make_ops, wl, seqs[which[i]], first, n_timed, lm)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(which))]   # (the operators release the GIL: ctypes calls)
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return res, time.perf_counter() - t0
+
+    which = sorted(seqs)[:8]
+    res, wall = run_all("oo_slam_make_ops", local_mapping, which)
+    frames = sum(r["frames"] for r in res)
+    core_s = sum(r["dt"] for r in res)
+    per = np.concatenate([np.array(r["per"]) for r in res])
+    win = sum(r["win"] for r in res)
+    nw = max(1.0, win[0])
+    hidden = sum(r["frames"] for r in res) / max(sum(r["dt"] - r["map_s"] for r in res), 1e-9)
+    two = None
+    if two_thread_streams > 0 and hasattr(L, "oo_slam_make_ops_threaded"):
+        w2 = which[:two_thread_streams]
+        r2, wall2 = run_all("oo_slam_make_ops_threaded", slam.LM_DEFERRED, w2)
+        per2 = np.concatenate([np.array(r["per"]) for r in r2])
+        two = {"value": round(sum(r["frames"] for r in r2) / sum(r["dt"] for r in r2), 2), "unit": "frames/s per stream", "cores": 2, "streams": len(w2),
+               "timed_frames": int(sum(r["frames"] for r in r2)), "mean_ms_per_frame": round(float(per2.mean()) * 1e3, 2), "median_ms_per_frame": round(float(np.median(per2)) * 1e3, 2),
+               "local_bas": int(sum(r["local_bas"] for r in r2)), "ate_rmse_m": round(float(np.mean([r["ate"] for r in r2])), 6),
+               "shape": "tracking (with the rest of the local-mapping pass) on one thread, Optimizer::LocalBundleAdjustment of keyframe t on a second thread while frame t + 1 is "
+                        "tracked (deferred schedule, oo_slam_make_ops_threaded): the reference's LocalMapping thread, src/System.cc:95"}
     # the reference prints median and mean tracking time per frame (Examples/RGB-D/rgbd_tum.cc:126-134)
-    return {"value": round((n - first) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "stream frames %d..%d of base stream 0 — the frames the GPU leg's sequences (offsets 0 .. stagger in their base streams) cover in its timed region, with a "
-                      "map of the same age — through the same driver over the CPU oracle's operator table, %.1f s timed after %.1f s of untimed pre-roll; tracking AND local "
-                      "mapping run on ONE core one after the other" % (first + offset, n + offset, dt, tp),
+    return {"value": round(frames / core_s, 2), "unit": "frames/s", "cores": 1, "kind": "port", "march": march,
+            "sample": "stream frames %d..%d of the %d base streams — the frames the GPU leg's sequences (offsets 0 .. stagger in their base streams) cover in its timed region, each "
+                      "with a map of the same age (%d untimed frames first) — through the same driver over the CPU oracle's operator table; the streams run side by side on "
+                      "%d CPUs, tracking AND local mapping of a stream on ONE core one after the other; %.1f core-seconds timed (%.1f s wall incl. %.1f s of untimed pre-roll per stream)"
+                      % (first, first + n_timed, len(which), first, len(which), core_s, wall, float(np.mean([r["preroll_s"] for r in res]))),
+            "streams": len(which), "frames_per_s_by_stream": [round(r["frames"] / r["dt"], 2) for r in res],
             # the reference's shape (<= 3 busy cores: LocalMapping on a second thread, src/System.cc:95; stereo extraction on two, src/Frame.cc:78-81): its frames/s lies between
-            # the one-core figure and the figure with every mapping stage hidden behind tracking
-            "three_core_bracket_frames_per_s": [round((n - first) / dt, 2), round((n - first) / max(dt - map_s, 1e-9), 2)],
-            "mapping_stage_seconds": round(map_s, 2), "timed_frames": n - first,
+            # the one-core figure and the figure with every mapping stage hidden behind tracking; `two_thread` is the measured run of that shape
+            "three_core_bracket_frames_per_s": [round(frames / core_s, 2), round(hidden, 2)], "two_thread": two,
+            "mapping_stage_seconds": round(sum(r["map_s"] for r in res), 2), "timed_frames": int(frames),
             "mean_ms_per_frame": round(float(per.mean()) * 1e3, 2), "median_ms_per_frame": round(float(np.median(per)) * 1e3, 2),
-            "ate_rmse_m": round(horn_align_ate(Twc[:, :, 3], gt[:, :3, 3]), 6), "keyframes": st["keyframes_created"], "local_bas": st["local_bas"],
-            "lba_windows_timed": {"windows": w1["windows"] - w0["windows"], "mean_local_kfs": round((w1["local_kfs"] - w0["local_kfs"]) / nw, 2),
-                                  "mean_fixed_kfs": round((w1["fixed_kfs"] - w0["fixed_kfs"]) / nw, 2), "mean_points": round((w1["points"] - w0["points"]) / nw, 1),
-                                  "mean_edges": round((w1["edges"] - w0["edges"]) / nw, 1)}}
+            "ate_rmse_m": round(float(np.mean([r["ate"] for r in res])), 6), "keyframes": int(sum(r["keyframes"] for r in res)), "local_bas": int(sum(r["local_bas"] for r in res)),
+            "lba_windows_timed": {"windows": int(win[0]), "mean_local_kfs": round(win[1] / nw, 2), "mean_fixed_kfs": round(win[2] / nw, 2), "mean_points": round(win[3] / nw, 1),
+                                  "mean_edges": round(win[4] / nw, 1)}}
+
+
+def single_sequence(wl, seq, first, n_timed, device_index):
+    """The HIP path as ONE caller sees it (the reference's only timing: median / mean tracking time per frame of one sequence, Examples/RGB-D/rgbd_tum.cc:93-134):
+    one sequence, host images handed over per frame, the same stream frames the CPU port is timed on, `first` frames untimed."""
+    from object_slam_amd import slam
+    sysm = slam.System(slam.make_config(wl.width, wl.height, 1, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor, host_threads=1, device=device_index))
+    has_masks = seq.get("masks") is not None
+    n = min(first + n_timed, len(seq["gray"]))
+    per = []
+    for t in range(n):
+        t1 = time.perf_counter()
+        if wl.sensor == slam.STEREO:
+            sysm.TrackStereo([seq["gray"][t]], [seq["right"][t]], [t / wl.fps])
+        else:
+            objs = [dict(masks=[seq["masks"][t, o] for o in range(seq["masks"].shape[1])], track_ids=seq["track_ids"])] if has_masks else None
+            sysm.TrackRGBD([seq["gray"][t]], [seq["depth"][t]], [t / wl.fps], objects=objs)
+        if t >= first:
+            per.append(time.perf_counter() - t1)
+    st = sysm.stats(0)
+    sysm.close()
+    per = np.array(per) * 1e3
+    return {"sequences": 1, "timed_frames": int(len(per)), "mean_ms_per_frame": round(float(per.mean()), 3), "median_ms_per_frame": round(float(np.median(per)), 3),
+            "p95_ms_per_frame": round(float(np.percentile(per, 95)), 3), "frames_per_s": round(1e3 / float(per.mean()), 1), "local_bas": st["local_bas"], "lost_frames": st["lost_frames"],
+            "note": "one sequence through the oslam_slam driver over the HIP operator table, host images uploaded per frame (PCIe inside the figure), local mapping incl. local BA "
+                    "inside the frame call that inserted the keyframe: latency, not throughput — the card is idle most of each frame"}
 
 
 # --------------------------------------------------------------------------------------------------------------------------------
@@ -414,6 +487,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--strict", action="store_true", help="exit non-zero when one of the extra legs (front end, local BA alone, host inputs, second workload ...) failed, instead of "
+                    "only recording its error in the line")
+    ap.add_argument("--no-bases32", action="store_true", help="skip the second headline figure with 32 base renderings (800 distinct input streams)")
     ap.add_argument("--cold", action="store_true", help="also run the cold-start regime of rounds 1-2 (steps W..W+K of empty maps) on the headline streams")
     args = ap.parse_args()
 
@@ -453,21 +529,17 @@ def main():
         S2, G2 = (2048, 8) if second is wl_st else (1024, 4)   # (stereo, same box: 512 / 4 -> 13.1 k frames/s, 1024 / 4 -> 16.2 k, 2048 / 4 -> 17.0 k, 2048 / 8 -> 19.8 k; 48 GB of HBM)
         pre2 = 40 if second is wl_st else 200
         seq_second = seqbench.base_sequences(second, rank, S2, pre2 + args.warmup + args.steps, workers=share)
-    # the CPU baselines run on frames [stagger / 2, ...) of base stream 0 and are timed over more frames than the GPU legs hold: base stream 0 continued (host only)
-    seq_cpu = seq_cpu2 = None
     # Timed range of a CPU baseline = the stream frames the GPU leg's sequences cover in ITS timed region: sequence offsets 0 .. stagger, steps preroll + warmup ..
     # preroll + warmup + steps, i.e. stream frames [preroll + warmup, preroll + warmup + steps + stagger) — the same part of the path with a map of the same age
-    # (later frames of these periodic paths revisit mapped places and insert a third of the keyframes: timing 200 frames there measured 6 local BAs against the
-    # GPU leg's 18 per 200 frames).  --cpu-frames extends the range; the base stream is then continued on the host.
-    cpu_off = 0
+    # (later frames of these periodic paths revisit mapped places and insert a third of the keyframes).  Every base stream holds n_frames + stagger frames.
     cpu_n = args.cpu_frames or (args.steps + head.stagger)
     cpu_n2 = args.steps + second.stagger
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        need = cpu_off + preroll + args.warmup + cpu_n - len(seq_head[0]["gray"])
-        seq_cpu = extend_sequence(head, head.n_base * rank, seq_head[0], need, workers=share) if need > 0 else seq_head[0]
-        if seq_second is not None:
-            need2 = cpu_off + pre2 + args.warmup + cpu_n2 - len(seq_second[0]["gray"])
-            seq_cpu2 = extend_sequence(second, second.n_base * rank, seq_second[0], need2, workers=share) if need2 > 0 else seq_second[0]
+    # second headline figure: 32 base renderings (800 distinct input streams): the first 8 are the headline's, 24 more are rendered
+    seq_b32 = wl_b32 = None
+    if extras_on and not stereo_head and not args.no_bases32 and args.bases < 32 and S >= 32:
+        wl_b32 = seqbench.rgbd_workload(speed=1.0, n_base=32, stagger=24)
+        seq_b32 = seqbench.base_sequences(wl_b32, rank, S, preroll + args.warmup + args.steps + post_frames, workers=share,
+                                          have=seq_head if (rank == 0 and head.stagger == wl_b32.stagger) else None)
     t_gen = time.perf_counter() - t_gen
     if log:
         log("inputs rendered in %.1f s" % t_gen)
@@ -494,6 +566,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     kt = {}
+    extras_failed = []   # names of extra legs that raised (the line records their errors; --strict turns them into a non-zero exit)
 
     mem_gb = {}
 
@@ -583,11 +656,11 @@ def main():
                                   "inputs": "pinned host memory: 8-bit gray, raw 16-bit depth (DepthMapFactor 5000, src/Tracking.cc:262), 3 instance masks as one bit per "
                                             "pixel; read by the Frame::Frame / object kernels over PCIe inside the timed region, the same warmed sequences as the headline"}
         except Exception as ex:      # the extra leg must not break the headline line
-            out["host_inputs"] = {"error": repr(ex)}
+            out["host_inputs"] = {"error": repr(ex)}; extras_failed.append("host_inputs")
         return out
 
     summ, rec = run(head, seq_head, S, G, "head", preroll, post_frames, host_inputs_phase if host_phase else None)
-    second_out = cold = None
+    second_out = cold = bases32 = None
     if extras_on:
         if log:
             log("headline done: %.1f frames/s" % summ["frames_per_s"])
@@ -595,14 +668,26 @@ def main():
             c, _ = run(head, seq_head, S, G, "cold")
             cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
                     "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
+        if seq_b32 is not None:
+            try:
+                sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll)
+                kb = kt["bases32"]
+                bases32 = {"frames_per_s": round(sb["frames_per_s"], 1), "ms_per_step": round(sb["ms_per_step"], 3), "distinct_streams_per_gpu": min(S, wl_b32.n_base * (wl_b32.stagger + 1)),
+                           "replicas_per_stream": round(S / min(S, wl_b32.n_base * (wl_b32.stagger + 1)), 1), "lba_windows_timed": sb["lba_windows_timed"],
+                           "keyframes": sb["keyframes"], "local_bas": sb["local_bas"], "lost_frames": sb["lost_frames"], "ate_rmse_m": round(sb["ate_rmse_m"], 6),
+                           "device_ms_by_group": {g: round(v["ms"], 1) for g, v in kb.items()},
+                           "note": "the headline configuration with 32 base renderings instead of 8: ~10 sequences per distinct input frame instead of ~41 (less cache sharing of the "
+                                   "input images in Frame::Frame); the 24 other scenes insert fewer keyframes, so compare `lba_windows_timed` before comparing frames/s"}
+            except Exception as ex:
+                bases32 = {"error": repr(ex)}; extras_failed.append("bases32")
+            seq_b32 = None
         s2, _ = run(second, seq_second, S2, G2, "second", pre2)
         roof2 = roofline_of(kt["second"], s2, second is wl_st)
         cpu2 = None
         if not args.no_cpu_baseline:
             if log:
                 log("CPU baseline of the second workload ...")
-            cpu2 = cpu_baseline(second, seq_cpu2 if seq_cpu2 is not None else seq_second[0], pre2 + args.warmup, cpu_n2, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
-                                offset=cpu_off)
+            cpu2 = cpu_baseline(second, seq_second, pre2 + args.warmup, cpu_n2, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC, two_thread_streams=2)
         second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe; steady state: %d untimed steps, then steps %d..%d timed; "
                                   "BASELINE.json configs[%s]" % (second.name, S2, G2, second.nFeatures, pre2, pre2 + args.warmup, pre2 + args.warmup + args.steps,
                                                                  "3]/[4" if second is wl_st else "2"),
@@ -620,15 +705,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if log:
                 log("CPU baseline ...")
-            cpu = cpu_baseline(head, seq_cpu if seq_cpu is not None else seq_head[0], preroll + args.warmup, cpu_n, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC,
-                               offset=cpu_off)
+            cpu = cpu_baseline(head, seq_head, preroll + args.warmup, cpu_n, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC)
+            if extras_on:
+                try:
+                    cpu["single_sequence_hip"] = single_sequence(head, seq_head[0], preroll + args.warmup, cpu_n, local_rank)
+                except Exception as ex:
+                    cpu["single_sequence_hip"] = {"error": repr(ex)}; extras_failed.append("single_sequence_hip")
         front = None
         if extras_on and head is wl_rgbd:
             try:
                 q = seq_head[0]
                 front = frontend_stage(q["gray"][:40], q["Twc"][:40], q["depth"][:40], local_rank, args.steps)
             except Exception as ex:      # the stage entry must not break the headline line
-                front = {"error": repr(ex)}
+                front = {"error": repr(ex)}; extras_failed.append("frontend")
         if extras_on:
             try:
                 roof["lba_alone"] = lba_alone(local_rank)
@@ -636,13 +725,13 @@ def main():
                 roof["lba_alone_by_batch"] = [lba_alone(local_rank, 160, 2, 1), lba_alone(local_rank, 256, 2, 1), lba_alone(local_rank, 256, 2, 2)]
             except Exception as ex:      # (must not break the headline line)
                 roof["lba_alone"] = roof.get("lba_alone") or {"error": repr(ex)}
-                roof["lba_alone_by_batch"] = {"error": repr(ex)}
+                roof["lba_alone_by_batch"] = {"error": repr(ex)}; extras_failed.append("lba_alone")
             try:                         # the card's measured fp64 issue rates beside the datasheet figure `peak` is taken from
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import mfma_f64_rate
                 roof["fp64_peak_measured"] = mfma_f64_rate.measure(local_rank)
             except Exception as ex:
-                roof["fp64_peak_measured"] = {"error": repr(ex)}
+                roof["fp64_peak_measured"] = {"error": repr(ex)}; extras_failed.append("fp64_peak_measured")
         regime = ("steady state: every sequence is advanced %d untimed steps before the warm-up, so the timed steps are frames %d..%d of every sequence (SURVEY.md §8(d): "
                   "frame >= 200 of the S1 stream at <= 2 cm / 0.5 deg per frame)" % (preroll, preroll + args.warmup, preroll + args.warmup + args.steps)) if preroll > 0 else \
                  ("cold start: steps %d..%d of empty maps" % (args.warmup, args.warmup + args.steps))
@@ -671,13 +760,15 @@ def main():
                "per_rank": [{"rank": int(r[0]), "frames": int(r[2]), "elapsed_s": round(float(r[3]), 4), "local_bas": int(r[5]), "ate_rmse_m": round(float(r[7]), 6)} for r in rec],
                "roofline": roof, "cpu_baseline": cpu,
                "host_inputs": (summ.get("post") or {}).get("host_inputs") if isinstance(summ.get("post"), dict) else None,
-               "cold_start": cold, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front,
+               "cold_start": cold, "bases32": bases32, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front, "extras_failed": extras_failed,
                "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "device_mem_used_gb_after_headline": mem_gb.get("head"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if args.strict and extras_failed:
+        raise SystemExit("extra legs failed: " + ", ".join(extras_failed))
 
 
 def _lba_traffic():
@@ -728,13 +819,14 @@ def roofline_of(k, summ, stereo):
             e["fp64_TFLOPs"] = round(v["work"] / (v["ms"] * 1e-3) / 1e12, 4)
             e["flop"] = int(v["work"])
         group_tab[g] = e
-    busy = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
+    stream_ratio = sum(v["ms"] for v in k.values()) / (summ["elapsed_s"] * 1e3)
     total_ms = sum(v["ms"] for v in k.values())
     for g in group_tab:
         group_tab[g]["share"] = round(k[g]["ms"] / max(total_ms, 1e-9), 4)
-    if bound == "fp64-valu" and dom == "lba":
-        bound = "mfma"   # the contract's name for the flop-bound case; the group's flops are mostly plain fp64 FMAs (see peak_note)
-    return {"bound": bound, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4 (datasheet; `fp64_peak_measured` = what "
+    pipe = {"hbm": "hbm", "fp64-valu": "fp64 vector ALU (v_fma_f64 / v_mul_f64 / v_add_f64)"}[bound]
+    if bound == "fp64-valu":
+        bound = "mfma"   # the contract's two names are "hbm" | "mfma": `mfma` stands for the flop-bound case, `pipe` says which pipe executes the flops
+    return {"bound": bound, "pipe": pipe, "peak_note": "HBM3E 8 TB/s" if bound == "hbm" else "fp64 vector ALU peak = fp64 matrix (MFMA) peak = 78.6 TFLOP/s on CDNA4 (datasheet; `fp64_peak_measured` = what "
             "tools/mfma_f64_rate.py reaches on this card); the linearisation / Schur / update kernels of this group issue v_fma_f64 / v_mul_f64 / v_add_f64, the reduced "
             "camera solve (k_w_chol_lds_mfma at 133..186 unknowns) v_mfma_f64_16x16x4_f64",
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
@@ -743,7 +835,10 @@ def roofline_of(k, summ, stereo):
             "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r04_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
             "calls of this run carry ~82 windows: scale by the windows per call",
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
-            "groups": group_tab, "device_busy_frac_of_timed_region": round(busy, 4), "mfma": _mfma_counters(),
+            "groups": group_tab,
+            # kernel time summed over the rank's streams (8 handles + the local-BA service run side by side) divided by the wall time of the timed region: how many
+            # streams the card serves at once on average, NOT a busy fraction (it exceeds 1)
+            "stream_time_over_wall_time": round(stream_ratio, 4), "mfma": _mfma_counters(),
             "note": "device ms summed over the rank's handles (their streams overlap); `lba` and `pose_opt` work = SURVEY.md §8(d) flop model x the LM "
                     "iterations / trials the kernels report"}
 

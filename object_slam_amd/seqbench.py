@@ -142,26 +142,32 @@ def _render_chunk(wl, seed, n, first, count):
     return wl.make_sequence(seed, n, first=first, count=count)
 
 
-def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1, chunk=24):
+def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1, chunk=24, have=None):
     """The rank's base sequences {b: dict}, rendered by `workers` processes in chunks of `chunk` frames (the images of a frame do not depend on the other
-    frames).  Call it before the process touches the GPU: the workers are forked."""
+    frames).  Call it before the process touches the GPU: the workers are forked.  `have` = base sequences already rendered for the same stream seeds and
+    length (a run of the same workload with fewer bases on rank 0): taken over instead of rendered again."""
     nb = min(wl.n_base, seqs_per_rank)
     n = n_frames + wl.stagger
-    jobs = [(wl, wl.n_base * rank + b, n, f, min(chunk, n - f)) for b in range(nb) for f in range(0, n, chunk)]
+    have = {b: q for b, q in (have or {}).items() if b < nb and len(q["gray"]) == n and wl.n_base * rank + b == q.get("stream_seed", -1)}
+    todo = [b for b in range(nb) if b not in have]
+    if not todo:
+        return dict(have)
+    jobs = [(wl, wl.n_base * rank + b, n, f, min(chunk, n - f)) for b in todo for f in range(0, n, chunk)]
     if workers > 1 and len(jobs) > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(min(workers, len(jobs))) as pool:
             parts = pool.starmap(_render_chunk, jobs)
     else:
         parts = [_render_chunk(*j) for j in jobs]
-    out = {}
-    per = len(jobs) // nb
-    for b in range(nb):
-        ps = parts[b * per:(b + 1) * per]
+    out = dict(have)
+    per = len(jobs) // len(todo)
+    for i, b in enumerate(todo):
+        ps = parts[i * per:(i + 1) * per]
         q = dict(ps[0])
         for key in ("gray", "right", "depth", "masks", "Twc"):
             if q.get(key) is not None:
                 q[key] = np.ascontiguousarray(np.concatenate([p[key] for p in ps], 0))
+        q["stream_seed"] = wl.n_base * rank + b
         out[b] = q
     return out
 

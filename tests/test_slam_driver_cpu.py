@@ -323,3 +323,23 @@ def test_deferred_schedule_differs_from_the_synchronous_one_only_by_when_the_ba_
     assert first_diff >= 2                      # frames 0-1 never differ: the first BA needs three keyframes in the map
     assert np.abs(ps - pd).max() < 5e-3         # the same trajectory up to what one BA moves
     assert out[slam.LM_SYNC][1]["local_bas"] >= 2 and out[slam.LM_DEFERRED][1]["local_bas"] >= 2
+
+
+def test_threaded_oracle_table_equals_the_plain_one_under_the_deferred_schedule(oracle):
+    """bench.py's two-thread CPU baseline (oracle/slam_ops_oracle.cc oo_slam_make_ops_threaded: the local BA of keyframe t on a second thread while frame t + 1
+    is tracked, the reference's LocalMapping thread, src/System.cc:95) produces the poses and statistics of the plain table under the same schedule."""
+    from oracle import oracle_py as O
+    n = 26
+    streams = make_streams(1, n)
+    out = []
+    for maker in ("oo_slam_make_ops", "oo_slam_make_ops_threaded"):
+        cfg = slam.make_config(W, H, 1, local_mapping=slam.LM_DEFERRED)
+        ops = slam.SlamOps()
+        assert getattr(O.lib(), maker)(C.byref(cfg), C.byref(ops)) == 0
+        sysm = slam.System(cfg, ops)
+        poses, states = run(sysm, streams, n)
+        sysm.finish()
+        out.append((poses, states, sysm.stats(0)))
+        sysm.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    assert out[0][2]["local_bas"] >= 2
