@@ -620,6 +620,11 @@ def main():
             mem_gb[tag] = None
         for sy in systems:
             sy.close()
+        try:   # the maps of the leg (tens of GB of small blocks) go back to the system before the next leg builds its own
+            import ctypes
+            ctypes.CDLL("libc.so.6").malloc_trim(0)
+        except Exception:
+            pass
         return summ, rec
 
     def host_inputs_phase(ctx):

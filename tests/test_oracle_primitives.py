@@ -187,3 +187,146 @@ def test_grid_area_query(oracle):
         # (a keypoint whose rounded cell lies just outside the scanned cell range can be missed:
         # that is the reference's behaviour, src/Frame.cc:572-584 vs :624-625)
         assert len(want - got) <= 2
+
+
+# ---- exact known answers from the PUBLISHED definitions of the OpenCV 3.2 fixed-point paths: each expectation below is computed here, in
+# integer / float32 arithmetic written from the library's documented algorithm, independently of oracle/*.cc; the oracle must reproduce it bit for bit ----
+def _resize_linear_8u_by_definition(src, dw, dh):
+    """cv::resize INTER_LINEAR, CV_8UC1 (imgproc/src/imgwarp.cpp, OpenCV 3.2): 11-bit coefficients (INTER_RESIZE_COEF_SCALE = 2048) computed in float and
+    rounded to short; horizontal pass in int; vertical pass ((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2."""
+    sh, sw = src.shape
+
+    def coeffs(dn, sn):
+        scale = np.float64(sn) / np.float64(dn)
+        idx, ab = [], []
+        for d in range(dn):
+            f = np.float32((d + 0.5) * scale - 0.5)
+            s = int(np.floor(f))
+            f = np.float32(f - s)
+            if s < 0:
+                s, f = 0, np.float32(0)
+            if s >= sn - 1:
+                s, f = sn - 1, np.float32(0)
+            a0 = int(np.rint(np.float32((np.float32(1) - f) * np.float32(2048))))
+            a1 = int(np.rint(np.float32(f * np.float32(2048))))
+            idx.append(s); ab.append((a0, a1))
+        return idx, ab
+    xi, xa = coeffs(dw, sw)
+    yi, ya = coeffs(dh, sh)
+    rows = np.zeros((sh, dw), np.int64)
+    for y in range(sh):
+        for x in range(dw):
+            s = xi[x]
+            rows[y, x] = int(src[y, s]) * xa[x][0] + int(src[y, min(s + 1, sw - 1)]) * xa[x][1]
+    out = np.zeros((dh, dw), np.uint8)
+    for y in range(dh):
+        s = yi[y]
+        r0, r1 = rows[s], rows[min(s + 1, sh - 1)]
+        b0, b1 = ya[y]
+        for x in range(dw):
+            out[y, x] = (((b0 * (int(r0[x]) >> 4)) >> 16) + ((b1 * (int(r1[x]) >> 4)) >> 16) + 2) >> 2
+    return out
+
+
+def test_resize_fixed_point_known_answers(oracle):
+    # the hand-computable case: 4x4 -> 3x3 (scale 4/3: source positions 1/6, 1.5, 2 5/6 -> coefficients (1707, 341), (1024, 1024), (341, 1707))
+    src = np.array([[0, 40, 80, 120], [10, 50, 90, 130], [200, 160, 120, 80], [255, 0, 255, 0]], np.uint8)
+    want = _resize_linear_8u_by_definition(src, 3, 3)
+    # first row by hand: y coefficients (1707, 341) over rows 0 / 1
+    r0 = [0 * 1707 + 40 * 341, 40 * 1024 + 80 * 1024, 80 * 341 + 120 * 1707]
+    r1 = [10 * 1707 + 50 * 341, 50 * 1024 + 90 * 1024, 90 * 341 + 130 * 1707]
+    hand = [((((1707 * (a >> 4)) >> 16) + ((341 * (b >> 4)) >> 16) + 2) >> 2) for a, b in zip(r0, r1)]
+    assert list(want[0]) == hand == [8, 62, 115]
+    np.testing.assert_array_equal(oracle.resize_linear_u8(src, 3, 3), want)
+    # the pyramid's own ratios (x 1/1.2 cascades) and an odd size, random content
+    rng = np.random.default_rng(11)
+    for (sw, sh, dw, dh) in [(64, 48, 53, 40), (53, 40, 44, 33), (37, 29, 31, 24), (1241 // 8, 47, 129, 39)]:
+        s = rng.integers(0, 256, (sh, sw)).astype(np.uint8)
+        np.testing.assert_array_equal(oracle.resize_linear_u8(s, dw, dh), _resize_linear_8u_by_definition(s, dw, dh))
+
+
+GAUSS7_S2_TAPS = [18, 34, 49, 55, 49, 34, 18]   # cvRound(256 * getGaussianKernel(7, 2)): 8-bit fixed point, sum 257
+
+
+def test_gaussian_7x7_sigma2_integer_weights_and_rounding(oracle):
+    k = np.exp(-(np.arange(7) - 3.0) ** 2 / (2 * 2.0 ** 2))
+    k = (k / k.sum()).astype(np.float32)   # getGaussianKernel(7, 2, CV_32F)
+    assert [int(np.rint(float(v) * 256)) for v in k] == GAUSS7_S2_TAPS and sum(GAUSS7_S2_TAPS) == 257
+    t = np.array(GAUSS7_S2_TAPS, np.int64)
+    # impulse: the response IS the outer product of the taps, rounded once at the end ((v + 2^15) >> 16: FixedPtCastEx of the column filter)
+    src = np.zeros((15, 15), np.uint8)
+    src[7, 7] = 255
+    want = np.zeros((15, 15), np.int64)
+    want[4:11, 4:11] = (255 * np.outer(t, t) + 32768) >> 16
+    for sse2 in (True, False):
+        np.testing.assert_array_equal(oracle.gaussian_blur(src, sse2), want.astype(np.uint8))
+    assert want[7, 7] == (255 * 55 * 55 + 32768) >> 16 == 12
+    # vertical step 0 | 200 with BORDER_REFLECT_101: every row the same, columns = partial sums of the taps
+    src = np.zeros((12, 16), np.uint8)
+    src[:, 8:] = 200
+    row = []
+    for x in range(16):
+        acc = 0
+        for j in range(7):
+            xx = x + j - 3
+            xx = -xx if xx < 0 else (2 * 15 - xx if xx > 15 else xx)   # reflect 101
+            acc += int(t[j]) * int(src[0, xx])
+        row.append((257 * acc + 32768) >> 16)   # the row pass of a constant column profile: x 257 (sum of the taps)
+    for sse2 in (True, False):
+        out = oracle.gaussian_blur(src, sse2)
+        assert all(list(out[y]) == row for y in range(12)), (list(out[0]), row)
+    assert row[:5] == [0] * 5 and row[-5:] == [(257 * 257 * 200 + 32768) >> 16] * 5 == [202] * 5
+
+
+def _fast_atan2_by_definition(y, x):
+    """cv::fastAtan2 (core/src/mathfuncs_core.cpp, OpenCV 3.2 scalar path): 7th-order odd polynomial on [0, 1] in float32, then the octant reflections."""
+    f = np.float32
+    s = f(180.0 / np.pi)
+    p1, p3, p5, p7 = f(0.9997878412794807) * s, f(-0.3258083974640975) * s, f(0.1555786518463281) * s, f(-0.04432655554792128) * s
+    x, y = f(x), f(y)
+    ax, ay = abs(x), abs(y)
+    eps = f(2.220446049250313e-16)
+    if ax >= ay:
+        c = ay / (ax + eps)
+        c2 = c * c
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    else:
+        c = ax / (ay + eps)
+        c2 = c * c
+        a = f(90.0) - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c
+    if x < 0:
+        a = f(180.0) - a
+    if y < 0:
+        a = f(360.0) - a
+    return f(a)
+
+
+def test_fast_atan2_polynomial_at_the_octant_boundaries(oracle):
+    pts = [(0, 7), (7, 7), (7, 0), (7, -7), (0, -7), (-7, -7), (-7, 0), (-7, 7)]   # (y, x): 0, 45, 90, ... 315 degrees
+    pts += [(1, 1000), (1000, 1), (999, 1000), (1000, 999), (-1, 1000), (-1000, -999), (3, -4), (-12345, 67890)]
+    for (y, x) in pts:
+        got = np.float32(oracle.fast_atan2(y, x))
+        want = _fast_atan2_by_definition(y, x)
+        assert got == want, (y, x, got, want)
+    # the polynomial is not exact at 45 degrees: OpenCV 3.2 returns 44.99.. / 45.00.. there, the same in every octant by symmetry
+    d45 = _fast_atan2_by_definition(7, 7)
+    assert abs(float(d45) - 45.0) < 0.01
+    assert np.float32(oracle.fast_atan2(7, -7)) == np.float32(180.0) - d45 and np.float32(oracle.fast_atan2(-7, 7)) == np.float32(360.0) - d45
+
+
+def test_fast9_on_the_16_rotations_of_a_minimal_arc(oracle):
+    """cv::FAST (TYPE_9_16): a pixel is a corner iff 9 CONTIGUOUS pixels of the 16-pixel Bresenham circle are all brighter than v + t or all darker than v - t —
+    every start position of the arc, both polarities, and the 8-pixel arc that must NOT fire."""
+    t = 20
+    for start in range(16):
+        for length, want in ((9, True), (8, False)):
+            for bright in (True, False):
+                img = np.full((9, 9), 100, np.uint8)
+                for k in range(length):
+                    dx, dy = CIRCLE[(start + k) % 16]
+                    img[4 + dy, 4 + dx] = 100 + t + 1 if bright else 100 - t - 1
+                got = {(int(q["x"]), int(q["y"])) for q in oracle.fast_9_16(img, t, nms=False)}
+                assert ((4, 4) in got) == want, (start, length, bright, got)
+                if want:   # the score of the centre = the largest threshold that still passes = t (the arc is exactly t + 1 away)
+                    kn = [q for q in oracle.fast_9_16(img, t, nms=True) if (int(q["x"]), int(q["y"])) == (4, 4)]
+                    assert len(kn) == 1 and int(kn[0]["response"]) == t
