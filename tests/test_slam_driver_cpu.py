@@ -343,3 +343,25 @@ def test_threaded_oracle_table_equals_the_plain_one_under_the_deferred_schedule(
         sysm.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
     assert out[0][2]["local_bas"] >= 2
+
+
+@pytest.mark.parametrize("tag,lm", [("sync", slam.LM_SYNC), ("deferred", slam.LM_DEFERRED)])
+def test_golden_driver_fixture_equals_the_cpp_driver_over_the_oracle_table(oracle, tag, lm):
+    """tests/golden/driver_rgbd_*.npz (oracle/slam_driver_oracle.py, the Python restatement: tests/golden/gen_driver_golden.py) is what the GPU suite compares the
+    HIP path with; here the product's C++ driver over the CPU oracle's operators must reproduce it bit for bit — the fixture is current and the two drivers agree."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "driver_rgbd_%s.npz" % tag))
+    n = int(g["n"])
+    streams = make_streams(1, n)
+    depth = np.full((H, W), 2.0, np.float32)
+    cfg = slam.make_config(W, H, 1, local_mapping=lm)
+    sysm = slam.System(cfg, oracle_ops(cfg))
+    keys = [str(k) for k in g["stat_keys"]]
+    for t in range(n):
+        T, st = sysm.TrackRGBD([streams[0][0][t]], [depth], [t / 30.0])
+        assert int(st[0]) == int(g["states"][t]) and np.array_equal(T[0], g["poses"][t]), t
+        s = sysm.stats(0)
+        assert [int(s[k]) for k in keys] == [int(v) for v in g["stats"][t]], t
+    sysm.finish()
+    _, Twc = sysm.trajectory(0)
+    assert np.array_equal(Twc, g["trajectory"])

@@ -438,3 +438,53 @@ def test_hip_driver_200_frames_with_masks_deferred_schedule_tracks_the_oracle_dr
     ah, _ = ate_scene(hip, [q], 0)
     ao, _ = ate_scene(ora, [q], 0)
     assert ah < 0.02 and ao < 0.02, (ah, ao)
+
+
+# ---- the C++ driver over the HIP operators against the INDEPENDENT Python restatement of the driver ----
+# tests/golden/driver_*.npz: per-frame states, poses and map statistics of oracle/slam_driver_oracle.py over the CPU oracle's operators, generated in the build
+# container by tests/golden/gen_driver_golden.py (the Python driver takes minutes; the fixtures travel as data).  Every discrete statistic must agree on every
+# frame; poses within the optimisers' 1e-4 relative tolerance (2e-4 absolute on these ~2 m scenes).
+def _golden(name):
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+@pytest.mark.parametrize("tag,lm", [("sync", slam.LM_SYNC), ("deferred", slam.LM_DEFERRED)])
+def test_hip_driver_matches_python_restatement_fixture(tag, lm):
+    g = _golden("driver_rgbd_%s.npz" % tag)
+    n = int(g["n"])
+    assert int(g["local_mapping"]) == lm
+    streams = make_streams(1, n)
+    depth = np.full((H, W), 2.0, np.float32)
+    sysm = slam.System(slam.make_config(W, H, 1, local_mapping=lm))
+    keys = [str(k) for k in g["stat_keys"]]
+    for t in range(n):
+        T, st = sysm.TrackRGBD([streams[0][0][t]], [depth], [t / 30.0])
+        assert int(st[0]) == int(g["states"][t]), t
+        assert np.abs(T[0] - g["poses"][t]).max() < 2e-4, (t, np.abs(T[0] - g["poses"][t]).max())
+        s = sysm.stats(0)
+        got = [int(s[k]) for k in keys]
+        assert got == [int(v) for v in g["stats"][t]], (t, dict(zip(keys, got)), dict(zip(keys, g["stats"][t])))
+    sysm.finish()
+    _, Twc = sysm.trajectory(0)
+    assert Twc.shape == g["trajectory"].shape and np.abs(Twc - g["trajectory"]).max() < 2e-4
+    assert sysm.stats(0)["map_violations"] == 0 and sysm.stats(0)["local_bas"] >= 3
+
+
+def test_hip_semantic_driver_matches_python_restatement_fixture():
+    """BASELINE.json configs[2] shape (three box objects with instance masks, ObjectOptimizer::PoseOptimization2 in TrackLocalMap) against the Python restatement."""
+    from slam_common import make_scene_streams
+    g = _golden("driver_semantic_sync.npz")
+    n = int(g["n"])
+    q = make_scene_streams(1, n)[0]
+    sysm = slam.System(slam.make_config(W, H, 1))
+    keys = [str(k) for k in g["stat_keys"]]
+    for t in range(n):
+        objs = dict(masks=[q["masks"][t, o] for o in range(3)], track_ids=q["track_ids"])
+        T, st = sysm.TrackRGBD([q["gray"][t]], [q["depth"][t]], [t / 30.0], objects=[objs])
+        assert int(st[0]) == int(g["states"][t]), t
+        assert np.abs(T[0] - g["poses"][t]).max() < 2e-4, (t, np.abs(T[0] - g["poses"][t]).max())
+        s = sysm.stats(0)
+        got = [int(s[k]) for k in keys]
+        assert got == [int(v) for v in g["stats"][t]], (t, dict(zip(keys, got)), dict(zip(keys, g["stats"][t])))
+    assert sysm.stats(0)["semantic_edges"] > 1000 and sysm.stats(0)["object3ds"] == 3
