@@ -88,12 +88,27 @@ def test_lba_stop_flag_and_errors(oracle, wide):
     ba.close()
 
 
-@pytest.mark.parametrize("wide,robust,its", [(1, True, 5), (0, False, 20), (1, False, 10), (2, True, 5), (2, False, 20)])
+def _ba_cost(poses, points, q):
+    """Sum over the edges of invSigma2 * |obs - projection|^2 (Optimizer::BundleAdjustment's objective without the robust kernel), float64."""
+    K = np.asarray(q["K"], np.float64)
+    T = np.asarray(poses, np.float64).reshape(-1, 4, 4)[np.asarray(q["edge_kf"])]
+    X = np.asarray(points, np.float64)[np.asarray(q["edge_pt"])]
+    pc = np.einsum("eij,ej->ei", T[:, :3, :3], X) + T[:, :3, 3]
+    u = K[0] * pc[:, 0] / pc[:, 2] + K[2]
+    v = K[1] * pc[:, 1] / pc[:, 2] + K[3]
+    ob = np.asarray(q["edge_obs"], np.float64)
+    e2 = (ob[:, 0] - u) ** 2 + (ob[:, 1] - v) ** 2
+    st = ob[:, 2] >= 0
+    e2 = e2 + np.where(st, (ob[:, 2] - (u - K[4] / pc[:, 2])) ** 2, 0.0)
+    return float((np.asarray(q["edge_invSigma2"], np.float64) * e2).sum())
+
+
+@pytest.mark.parametrize("wide,robust,its", [(1, True, 5), (0, False, 20), (1, False, 10), (2, True, 5), (2, False, 20), (1, False, 20)])
 def test_bundle_adjustment_matches_oracle(oracle, wide, robust, its):
-    """Optimizer::BundleAdjustment (one optimize(n), optional Huber sqrt(5.99)/sqrt(7.815))."""
-    # without the Huber kernel gross outliers make the problem chaotic (both implementations diverge
-    # on the affected points), so the non-robust runs use inlier-only data
-    q = synth.make_lba_problem(21, K_local=8, K_fixed=0, P=400, outlier_frac=0.02 if robust else 0.0)
+    """Optimizer::BundleAdjustment (one optimize(n), optional Huber sqrt(5.99)/sqrt(7.815)): every pose and EVERY point within 1e-4 relative, every layout."""
+    # without the Huber kernel gross outliers make the problem chaotic (both implementations diverge on the affected points), so the non-robust runs use
+    # inlier-only data; seed 24: every point of the problem is well conditioned (seed 21, the case of rounds 1-4, has one point in a flat valley: next test)
+    q = synth.make_lba_problem(24, K_local=8, K_fixed=0, P=400, outlier_frac=0.02 if robust else 0.0)
     fixed = np.zeros(8, np.uint8); fixed[0] = 1
     ba = LocalBundleAdjuster(max_keyframes=16, max_points=1024, max_edges=8192)
     ba.set_mode(wide)
@@ -101,13 +116,31 @@ def test_bundle_adjustment_matches_oracle(oracle, wide, robust, its):
     opo, oxo = oracle.bundle_adjustment(q["poses"], fixed, q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], its, robust)
     assert np.abs(po - opo).max() / max(1.0, np.abs(opo).max()) <= RTOL
     err = np.abs(xo - oxo).max(axis=1) / max(1.0, np.abs(oxo).max())
-    if wide == 2 and not robust:
-        # 20 non-robust iterations leave one low-parallax point of this problem (seen by two neighbouring keyframes at 40 m) with a valley of cost along its
-        # viewing ray: the fused multiply-adds of the one-workgroup layout move it 3.6e-3 along that ray at equal cost.  Every other point and all poses
-        # agree to the tolerance, and the cost of the result is the oracle's.
-        assert (err > RTOL).sum() <= 1 and err.max() < 5e-3, (np.sort(err)[-3:],)
-    else:
-        assert err.max() <= RTOL
+    assert err.max() <= RTOL, np.sort(err)[-3:]
+    ba.close()
+
+
+@pytest.mark.parametrize("wide", [0, 1, 2])
+def test_bundle_adjustment_flat_valley_reaches_the_oracles_cost(oracle, wide):
+    """Seed 21 of the same generator holds one low-parallax point (seen by two neighbouring keyframes at 40 m) whose cost is flat along its viewing ray: 20
+    non-robust iterations leave it wherever the last ulps of the arithmetic put it on that ray (3-4e-3 of the scene size between the implementations, in the
+    layouts that fuse multiply-adds).  What IS determined there is the objective: the HIP result must reach the oracle's cost, agree on all poses, and agree
+    on every OTHER point — no tolerance is widened."""
+    q = synth.make_lba_problem(21, K_local=8, K_fixed=0, P=400, outlier_frac=0.0)
+    fixed = np.zeros(8, np.uint8); fixed[0] = 1
+    ba = LocalBundleAdjuster(max_keyframes=16, max_points=1024, max_edges=8192)
+    ba.set_mode(wide)
+    args = (q["poses"], fixed, q["points"], q["edge_kf"], q["edge_pt"], q["edge_obs"], q["edge_invSigma2"], q["K"], 20, False)
+    po, xo = ba.BundleAdjustment(*args)
+    opo, oxo = oracle.bundle_adjustment(*args)
+    assert np.abs(po - opo).max() / max(1.0, np.abs(opo).max()) <= RTOL
+    c_hip, c_ora, c_init = _ba_cost(po, xo, q), _ba_cost(opo, oxo, q), _ba_cost(q["poses"], q["points"], q)
+    assert c_ora < 0.1 * c_init                                   # (the optimisation did its work: what is left is the pixel noise)
+    assert abs(c_hip - c_ora) <= 1e-6 * c_ora, (c_hip, c_ora)     # the same minimum of the objective
+    err = np.abs(xo - oxo).max(axis=1) / max(1.0, np.abs(oxo).max())
+    k = np.bincount(np.asarray(q["edge_pt"]), minlength=len(q["points"]))
+    off = np.nonzero(err > RTOL)[0]
+    assert len(off) <= 1 and all(k[p] <= 2 for p in off), (off, err[off], k[off])   # at most THE two-observation point, nothing else
     ba.close()
 
 
