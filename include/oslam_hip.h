@@ -427,6 +427,9 @@ typedef struct oslam_lba_problem {
     int32_t nE; const int32_t* edge_kf; const int32_t* edge_pt; const float* edge_obs; const float* edge_invSigma2;
     float* poses_out; float* points_out; uint8_t* erase; int32_t* stats;   /* stats may be NULL */
 } oslam_lba_problem_t;
+/* A window of the batch that the solver refuses (an index out of range, a duplicate observation, more free keyframes than the bound ...) fails ALONE when it has
+ * a stats array: stats = {-1, OSLAM_E_* code, 0, 0}, poses_out / points_out = the inputs, erase = 0, and the other windows are solved (return value OSLAM_OK).
+ * Without a stats array such a window fails the call, as in rounds 1-4. */
 int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* probs, const float K5[5]);
 
 /* Optimizer::BundleAdjustment (include/Optimizer.h:38, src/Optimizer.cc:49-237) on the same flattened graph:

@@ -50,8 +50,11 @@
  *   - resident keyframe records (keypoints, descriptors, stereo coordinates, feature grid: ~86 B x capacity + 6 KB each): one per keyframe in the current map
  *     of a sequence; the records of culled keyframes (release_keyframes, after KeyFrameCulling) and of a map that was reset are reused; the store itself only
  *     grows and is released with the handle.
- * Any other error of an operator aborts the lockstep step of ALL sequences of the handle: the map bookkeeping of that step has then partly run, so the
- * handle must be discarded. */
+ * Per-sequence failure isolation: a local-BA window the operator refuses (malformed or beyond its bounds; oslam_lba_problem_t::stats[0] < 0, include/oslam_hip.h)
+ * fails ITS sequence only — the sequence is counted (oslam_slam_lba_window_stats [7]), reports LOST for that frame and starts a new map with its next frame, the
+ * way one System of the reference resets itself (src/Tracking.cc:553-560) — while the other sequences of the handle, and the other handles that shared the
+ * local-BA batch, continue with unchanged results.  Device / runtime errors (OSLAM_E_HIP: no device, out of memory, a failed launch) are not per-sequence: they
+ * abort the lockstep step of ALL sequences of the handle; the map bookkeeping of that step has then partly run, so the handle must be discarded. */
 #ifndef OSLAM_SLAM_H
 #define OSLAM_SLAM_H
 
@@ -334,6 +337,10 @@ int oslam_slam_object_stats(oslam_slam_t* h, int seq, int64_t out[8]);
  * [0] windows, then sums over them: [1] local keyframes, [2] fixed keyframes, [3] map points, [4] edges; [5] windows DEGRADED because they had more than 128 free
  * keyframes (the local-BA operator's bound; the reference has none): their weakest covisible keyframes were held fixed. */
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]);
+/* Test hook of the per-sequence failure isolation: the next local-BA window of sequence `seq` is handed to the operator with an edge that names a keyframe outside
+ * the window, which an operator table that validates its windows (the HIP table does) refuses with OSLAM_E_INVALID for that window alone.  out[7] of
+ * oslam_slam_lba_window_stats counts the operator failures of a sequence. */
+int oslam_slam_inject_failure(oslam_slam_t* h, int seq);
 
 /* Deferred schedule: waits for the local BA in flight and applies its write-back, the MapPoint updates and KeyFrameCulling (what System::Shutdown's wait for the
  * local mapper does, src/System.cc:303-320).  No effect when nothing is pending.  Called by oslam_slam_trajectory / oslam_slam_keyframe_trajectory. */

@@ -2635,7 +2635,7 @@ static bool win_fits(const oslam_lba_t* h, int K, int nfree) {
 
 // Prepares all windows of a call (in parallel on the shared workers when there are several) and places them in the `in` arena.
 static int lba_prepare_all(oslam_lba_t* h, int n, const LbaArgs* a, const float K5[5], int use_stop_flag, int iters0, int iters1, int nstages, int robust0, float delta_mono,
-                           float delta_stereo) {
+                           float delta_stereo, std::vector<int>* window_rc = nullptr) {
     h->in_off = 0;
     if ((int)h->prep.size() < n) h->prep.resize(n);   // (the windows' vectors keep their capacity from call to call)
     h->n_prep = n;
@@ -2661,7 +2661,9 @@ static int lba_prepare_all(oslam_lba_t* h, int n, const LbaArgs* a, const float 
     };
     if (n > 1) oslam_drv::shared_parallel_for(n, one);
     else one(0);
+    if (window_rc) *window_rc = rcs;   // (which windows were refused: oslam_lba_optimize_batch solves the others)
     for (int i = 0; i < n; i++) if (rcs[i]) { set_error("%s", errs[i].data()); return rcs[i]; }
+    if (window_rc) window_rc->assign(n, 0);
     for (int i = 0; i < n; i++) { const int rc = lba_place(h, h->prep[i]); if (rc) return rc; }
     return OSLAM_OK;
 }
@@ -3007,14 +3009,39 @@ int oslam_lba_optimize_batch(oslam_lba_t* h, int n, const oslam_lba_problem_t* p
     static struct AtExit { ~AtExit() { delete prof; } } at_exit;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t0 = now();
-    int rc = lba_prepare_all(h, n, a.data(), K5, 0, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815));
-    if (rc) return rc;
+    std::vector<int> wrc;
+    int rc = lba_prepare_all(h, n, a.data(), K5, 0, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815), &wrc);
+    std::vector<int> good;   // indices of the windows that are solved (empty: all of them)
+    if (rc) {
+        // A window the solver refuses (more free keyframes than its bound, an index out of range, a duplicate observation ...) fails ALONE when the caller
+        // gave it a stats array: stats = {-1, error code, 0, 0}, outputs = inputs, nothing erased — and the other windows of the call are solved.  The batch
+        // may carry the windows of a thousand independent sequences (and, through the local-BA service, of several driver handles).
+        bool soft = (int)wrc.size() == n;
+        for (int i = 0; soft && i < n; i++) if (wrc[i] && !probs[i].stats) soft = false;
+        if (!soft) return rc;
+        for (int i = 0; i < n; i++) {
+            if (!wrc[i]) { good.push_back(i); continue; }
+            const oslam_lba_problem_t& q = probs[i];
+            if (q.poses_out && q.poses && q.nKF > 0) memcpy(q.poses_out, q.poses, (size_t)q.nKF * 64);
+            if (q.points_out && q.points && q.nP > 0) memcpy(q.points_out, q.points, (size_t)q.nP * 12);
+            if (q.erase && q.nE > 0) memset(q.erase, 0, (size_t)q.nE);
+            q.stats[0] = -1; q.stats[1] = wrc[i]; q.stats[2] = q.stats[3] = 0;
+        }
+        if (good.empty()) return OSLAM_OK;
+        std::vector<LbaArgs> a2(good.size());
+        for (size_t j = 0; j < good.size(); j++) a2[j] = a[good[j]];
+        a.swap(a2);
+        if ((rc = lba_prepare_all(h, (int)a.size(), a.data(), K5, 0, 5, 10, 2, 1, (float)sqrt(5.991), (float)sqrt(7.815)))) return rc;
+    }
     auto t1 = now();
     h->prof_pre_upload_ns = 0;
     rc = lba_launch(h);
     if (rc) return rc;
     auto t2 = now();
-    for (int i = 0; i < n; i++) lba_fetch(h, i, probs[i].poses_out, probs[i].points_out, probs[i].erase, probs[i].stats);
+    for (int j = 0; j < (int)a.size(); j++) {
+        const oslam_lba_problem_t& q = probs[good.empty() ? j : good[j]];
+        lba_fetch(h, j, q.poses_out, q.points_out, q.erase, q.stats);
+    }
     if (prof) {
         auto t3 = now();
         prof->ns[0] += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();

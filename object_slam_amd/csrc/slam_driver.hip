@@ -176,6 +176,7 @@ struct Seq {
     std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj, jObjIds;
     oslam_job_pose2_t jPose2; bool hasPose2 = false;
     const oslam_slam_objects_t* det = nullptr;           // this step's detections (NULL or n == 0: none)
+    int64_t opFailures = 0;               // operator errors confined to this sequence (its map was reset: local_mapping_back)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
         map = Map();
@@ -218,6 +219,7 @@ struct Ctx {
         // for the MapPoint updates after the solve (oslam_job_mp_window_t): first edge of every point, octave of every edge's keypoint, points with an observation
         // outside the window (in a culled keyframe), and the job's own arrays
         std::vector<int32_t> pstart, uref; std::vector<uint8_t> eoct, pquirk, uskip; std::vector<float> ulsf, uOw, uout5;
+        int32_t st[4] = {0, 0, 0, 0};   // the solver's statistics of the window; st[0] < 0: the operator refused THIS window (st[1] = its error code), see local_mapping_back
         void reset() { kfs.clear(); pts.clear(); poses.clear(); points.clear(); eobs.clear(); einv.clear(); poses_out.clear(); points_out.clear(); fixed.clear(); erase.clear(); ekf.clear(); ept.clear(); eref.clear(); nLocal = 0; }
     };
     std::vector<Win> winPool;
@@ -226,6 +228,7 @@ struct Ctx {
     struct PendingLM { bool active = false, submitted = false; std::vector<int> who; std::vector<Win*> wins; std::vector<oslam_lba_problem_t> probs; } pend;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
     int mapStep = 0;            // local-mapping passes of this handle (MapPt::updStep)
+    int injectLbaFailure = -1;  // oslam_slam_inject_failure: sequence whose next local-BA window is made invalid (tests of the per-sequence failure isolation)
     bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
     std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
     std::atomic<long long> contentCounter{0}, locReuse{0}, locFrames{0};   // content ids of the packed local maps; frames that reused theirs / all tracked frames
@@ -752,7 +755,33 @@ static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t
 // Second half of a local-mapping pass: Optimizer::LocalBundleAdjustment's write-back (src/Optimizer.cc:711-777) from the solved windows, the MapPoint updates of
 // their points, KeyFrameCulling (src/LocalMapping.cc:633-697) for every sequence of the pass.  Synchronous schedule: called at the end of run_local_mapping;
 // deferred schedule: by finish_local_mapping after the next step's tracking.
+static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std::vector<Ctx::Win*>& wins);
+// Per-sequence failure isolation (the reference: one System that loses track resets ITSELF, src/Tracking.cc:553-560).  A local-BA window the operator refused
+// (Win::st[0] < 0: beyond its bounds, malformed) fails its own sequence only: that sequence leaves the pass here — no write-back, no culling —, is counted
+// (oslam_slam_lba_window_stats [7]) and resets before its next frame like a system that lost track right after initialisation; the other sequences of the handle
+// go on, with the results they would have had without it (tests/test_slam_driver_gpu.py).  Device / runtime errors (OSLAM_E_HIP) are not per-sequence and still
+// fail the step.
 static int local_mapping_back(Ctx& c, const std::vector<int>& who, const std::vector<Ctx::Win*>& wins) {
+    bool any = false;
+    for (const Ctx::Win* W : wins) any = any || W->st[0] < 0;
+    if (!any) return local_mapping_back_ok(c, who, wins);
+    std::vector<char> failed(c.S, 0);
+    std::vector<Ctx::Win*> wins2;
+    for (Ctx::Win* W : wins) {
+        if (W->st[0] < 0) {
+            Seq& s = *c.seq[W->si];
+            failed[W->si] = 1;
+            s.opFailures++;
+            s.resetRequested = true;
+            s.state = ST_LOST;
+        } else wins2.push_back(W);
+    }
+    std::vector<int> who2;
+    for (int si : who) if (!failed[si]) who2.push_back(si);
+    return local_mapping_back_ok(c, who2, wins2);
+}
+
+static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std::vector<Ctx::Win*>& wins) {
     typedef Ctx::Win Win;
     Timer tm;
     int rc;
@@ -1505,7 +1534,10 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             oslam_lba_problem_t& p = probs[i];
             p.nKF = (int)W.kfs.size(); p.poses = W.poses.data(); p.fixed = W.fixed.data(); p.nP = (int)W.pts.size(); p.points = W.points.data();
             p.nE = (int)W.ekf.size(); p.edge_kf = W.ekf.data(); p.edge_pt = W.ept.data(); p.edge_obs = W.eobs.data(); p.edge_invSigma2 = W.einv.data();
-            p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data(); p.stats = nullptr;
+            p.poses_out = W.poses_out.data(); p.points_out = W.points_out.data(); p.erase = W.erase.data();
+            W.st[0] = W.st[1] = W.st[2] = W.st[3] = 0;
+            p.stats = W.st;
+            if (c.injectLbaFailure >= 0 && W.si == c.injectLbaFailure && !W.ekf.empty()) { W.ekf[0] = (int32_t)W.kfs.size(); c.injectLbaFailure = -1; }   // test hook (oslam_slam_inject_failure): an edge that names a keyframe outside the window — the operator refuses the window (OSLAM_E_INVALID)
         }
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
         if (flags & OSLAM_SLAM_LM_DEFERRED) {
@@ -2212,11 +2244,17 @@ int oslam_slam_finish(oslam_slam_t* h) {
     return finish_local_mapping(h->c);
 }
 
+int oslam_slam_inject_failure(oslam_slam_t* h, int seq) {
+    if (!h || seq < 0 || seq >= h->c.S) { oslam::set_error("oslam_slam_inject_failure: bad argument"); return OSLAM_E_INVALID; }
+    h->c.injectLbaFailure = seq;
+    return OSLAM_OK;
+}
+
 int oslam_slam_lba_window_stats(oslam_slam_t* h, int seq, int64_t out[8]) {
     if (!h || seq < 0 || seq >= h->c.S || !out) { oslam::set_error("oslam_slam_lba_window_stats: bad argument"); return OSLAM_E_INVALID; }
     const auto& s = *h->c.seq[seq];
     memset(out, 0, 8 * sizeof(int64_t));
-    out[0] = s.st[5]; out[1] = s.lbaWin[0]; out[2] = s.lbaWin[1]; out[3] = s.lbaWin[2]; out[4] = s.lbaWin[3]; out[5] = s.lbaWindowsDegraded;
+    out[0] = s.st[5]; out[1] = s.lbaWin[0]; out[2] = s.lbaWin[1]; out[3] = s.lbaWin[2]; out[4] = s.lbaWin[3]; out[5] = s.lbaWindowsDegraded; out[7] = s.opFailures;
     return OSLAM_OK;
 }
 

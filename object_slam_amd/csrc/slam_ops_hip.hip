@@ -1164,7 +1164,8 @@ struct LbaService {
             for (Job* j : take) { probs.insert(probs.end(), j->probs, j->probs + j->n); timing = timing || j->timing; }
             const int n = (int)probs.size();
             st.assign((size_t)4 * n, 0);
-            for (int i = 0; i < n; i++) probs[i].stats = &st[4 * (size_t)i];
+            std::vector<int32_t*> caller_stats(n);
+            for (int i = 0; i < n; i++) { caller_stats[i] = probs[i].stats; probs[i].stats = &st[4 * (size_t)i]; }
             int rc = OSLAM_OK;
             double ms = 0; long long launches = 0;
             if (n > 0) {
@@ -1172,6 +1173,17 @@ struct LbaService {
                 if (!rc) rc = oslam_lba_kernel_time(ba, timing ? 1 : 0, nullptr, nullptr);
                 for (int at = 0; !rc && at < n; at += max_batch) rc = oslam_lba_optimize_batch(ba, std::min(max_batch, n - at), probs.data() + at, take[0]->K5);
                 if (!rc && timing) rc = oslam_lba_kernel_time(ba, 0, &ms, &launches);
+            }
+            // A window the solver refused (stats[0] < 0, oslam_lba_optimize_batch) fails alone: its submitter sees it in the stats array it passed, or — when it
+            // passed none — as the error of ITS job; the other jobs of the batch are complete.
+            std::vector<int> job_rc(take.size(), 0);
+            if (!rc) {
+                size_t at = 0;
+                for (size_t q = 0; q < take.size(); q++)
+                    for (int i = 0; i < take[q]->n; i++, at++) {
+                        if (caller_stats[at]) memcpy(caller_stats[at], probs[at].stats, 16);
+                        else if (probs[at].stats[0] < 0 && !job_rc[q]) job_rc[q] = probs[at].stats[1];
+                    }
             }
             // the call's kernel time and launches are shared out by the windows' flop / count (the sums over the handles are the call's)
             std::vector<double> fl(take.size(), 0.0);
@@ -1181,7 +1193,7 @@ struct LbaService {
                 for (size_t q = 0; q < take.size(); q++) {
                     for (int i = 0; i < take[q]->n; i++, at++) {
                         const oslam_lba_problem_t& w = probs[at];
-                        fl[q] += lba_flop(w, w.stats);
+                        if (w.stats[0] >= 0) fl[q] += lba_flop(w, w.stats);
                     }
                     fl_all += fl[q];
                 }
@@ -1191,8 +1203,9 @@ struct LbaService {
                 calls++; windows += n; max_windows = std::max<long long>(max_windows, n);
                 for (size_t q = 0; q < take.size(); q++) {
                     Job* j = take[q];
-                    j->rc = rc;
+                    j->rc = rc ? rc : job_rc[q];
                     if (rc) snprintf(j->err, sizeof(j->err), "%s", oslam_last_error());
+                    else if (job_rc[q]) snprintf(j->err, sizeof(j->err), "a window of the submission was refused by the solver (pass stats to learn which)");
                     j->flop = fl[q]; j->ms = fl_all > 0 ? ms * fl[q] / fl_all : 0; j->launches = n > 0 ? (double)launches * j->n / n : 0;
                     j->done = true;
                 }
@@ -1216,6 +1229,7 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     }
     std::vector<oslam_lba_problem_t> tp;
     std::vector<int32_t> st;
+    const oslam_lba_problem_t* caller = pr;
     if (o->timing) {
         tp.assign(pr, pr + n); st.assign((size_t)4 * n, 0);
         for (int i = 0; i < n; i++) tp[i].stats = &st[4 * (size_t)i];
@@ -1223,15 +1237,25 @@ int h_lba(void* p, int n, const oslam_lba_problem_t* pr) {
     }
     oslam_lba_t* ba = n == 1 ? o->ba1 : o->ba;
     int rc;
-    if (n == 1)   // one window: spread over the whole GPU
+    if (n == 1) {   // one window: spread over the whole GPU
         rc = oslam_lba_optimize(o->ba1, pr[0].nKF, pr[0].poses, pr[0].fixed, pr[0].nP, pr[0].points, pr[0].nE, pr[0].edge_kf, pr[0].edge_pt, pr[0].edge_obs,
                                 pr[0].edge_invSigma2, o->K5, 0, pr[0].poses_out, pr[0].points_out, pr[0].erase, pr[0].stats);
-    else rc = oslam_lba_optimize_batch(o->ba, n, pr, o->K5);   // one workgroup per window, one launch
+        if ((rc == OSLAM_E_CAPACITY || rc == OSLAM_E_INVALID) && caller[0].stats) {   // the window was refused: it fails alone, like a window of a batch (oslam_lba_optimize_batch)
+            const oslam_lba_problem_t& q = pr[0];
+            if (q.poses_out && q.poses && q.nKF > 0) memcpy(q.poses_out, q.poses, (size_t)q.nKF * 64);
+            if (q.points_out && q.points && q.nP > 0) memcpy(q.points_out, q.points, (size_t)q.nP * 12);
+            if (q.erase && q.nE > 0) memset(q.erase, 0, (size_t)q.nE);
+            q.stats[0] = -1; q.stats[1] = rc; q.stats[2] = q.stats[3] = 0;
+            rc = OSLAM_OK;
+        }
+    } else rc = oslam_lba_optimize_batch(o->ba, n, pr, o->K5);   // one workgroup per window, one launch
+    if (!rc && pr != caller)
+        for (int i = 0; i < n; i++) if (caller[i].stats) memcpy(caller[i].stats, pr[i].stats, 16);
     if (!rc && o->timing) {
         double ms = 0; long long launches = 0;
         OPS_CHECK(oslam_lba_kernel_time(ba, 1, &ms, &launches));
         std::vector<double> fl(n, 0.0);   // (instrumentation inside the timed region of bench.py: on the shared workers, not serially on the stepping thread)
-        o->pool->parallel_for(n, [&](int i) { fl[i] = lba_flop(pr[i], pr[i].stats); });
+        o->pool->parallel_for(n, [&](int i) { fl[i] = pr[i].stats[0] >= 0 ? lba_flop(pr[i], pr[i].stats) : 0.0; });
         double flop = 0;
         for (int i = 0; i < n; i++) flop += fl[i];
         o->kt[6] += ms; o->kt[7] += (double)launches; o->kt[8] += flop;

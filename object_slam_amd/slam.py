@@ -279,7 +279,13 @@ class System:
         """Local-BA window sizes of one sequence since creation: windows and the sums of local / fixed keyframes, points and edges over them."""
         out = np.zeros(8, np.int64)
         check(self.L.oslam_slam_lba_window_stats(self.h, C.c_int(seq), ptr(out)))
-        return dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "lba_windows_degraded"), out[:6].tolist()))
+        d = dict(zip(("windows", "local_kfs", "fixed_kfs", "points", "edges", "lba_windows_degraded"), out[:6].tolist()))
+        d["operator_failures"] = int(out[7])
+        return d
+
+    def inject_failure(self, seq):
+        """Test hook (include/oslam_slam.h oslam_slam_inject_failure): the next local-BA window of `seq` is refused by the operator."""
+        check(self.L.oslam_slam_inject_failure(self.h, C.c_int(seq)))
 
     KT_GROUPS = ("frames", "pose_opt", "lba", "search", "fuse", "bow_triangulate", "mp_update", "other")
 

@@ -343,3 +343,31 @@ def test_lba_lds_matrix_core_solver_panel_edges(oracle, nfree):
         o = oracle.local_bundle_adjustment(w["poses"], w["fixed"], w["points"], w["edge_kf"], w["edge_pt"], w["edge_obs"], w["edge_invSigma2"], w["K"])
         _compare(r, o)
     ba.close()
+
+
+def test_lba_batch_refuses_one_window_and_solves_the_others(oracle):
+    """A window the solver refuses (an edge that names a keyframe outside the window) fails ALONE when it carries a stats array (include/oslam_hip.h,
+    oslam_lba_problem_t): stats = (-1, OSLAM_E_INVALID, 0, 0), outputs = inputs, and the other windows of the call come out bit-identical to a call without it.
+    Also ADVICE r4: a window with points that no edge observes, batched next to a normal window (the per-landmark inverses are sized by the points)."""
+    probs = [synth.make_lba_problem(60 + i, K_local=4 + i, K_fixed=i % 2, P=150 + 30 * i) for i in range(4)]
+    ba = LocalBundleAdjuster(max_keyframes=16, max_points=1024, max_edges=8192, max_batch=8)
+    clean = ba.LocalBundleAdjustmentBatch(probs, probs[0]["K"])
+    bad = dict(probs[1])
+    bad["edge_kf"] = probs[1]["edge_kf"].copy()
+    bad["edge_kf"][0] = len(probs[1]["poses"])      # out of range
+    res = ba.LocalBundleAdjustmentBatch([probs[0], bad, probs[2], probs[3]], probs[0]["K"])
+    assert tuple(res[1][3])[:2] == (-1, -1), res[1][3]                    # refused: OSLAM_E_INVALID = -1
+    assert np.array_equal(res[1][0].reshape(-1, 16), probs[1]["poses"].reshape(-1, 16)) and np.array_equal(res[1][1], probs[1]["points"]) and res[1][2].sum() == 0
+    for i in (0, 2, 3):
+        assert np.array_equal(res[i][0], clean[i][0]) and np.array_equal(res[i][1], clean[i][1]) and np.array_equal(res[i][2], clean[i][2]) and tuple(res[i][3]) == tuple(clean[i][3])
+    # points without any edge: 3 x as many points as edges in one window of the batch
+    q = synth.make_lba_problem(70, K_local=4, K_fixed=1, P=60)
+    lonely = dict(q)
+    extra = np.random.default_rng(5).uniform(-1, 1, (3 * len(q["edge_kf"]), 3)).astype(np.float32) + np.array([0, 0, 4], np.float32)
+    lonely["points"] = np.concatenate([q["points"], extra]).astype(np.float32)
+    res2 = ba.LocalBundleAdjustmentBatch([lonely, probs[2]], probs[0]["K"])
+    alone = ba.LocalBundleAdjustmentBatch([q, probs[2]], probs[0]["K"])
+    assert np.array_equal(res2[0][0], alone[0][0]) and np.array_equal(res2[0][1][:len(q["points"])], alone[0][1])
+    assert np.array_equal(res2[0][1][len(q["points"]):], extra)          # unobserved points do not move
+    assert np.array_equal(res2[1][0], clean[2][0]) and np.array_equal(res2[1][1], clean[2][1])
+    ba.close()

@@ -488,3 +488,40 @@ def test_hip_semantic_driver_matches_python_restatement_fixture():
         got = [int(s[k]) for k in keys]
         assert got == [int(v) for v in g["stats"][t]], (t, dict(zip(keys, got)), dict(zip(keys, g["stats"][t])))
     assert sysm.stats(0)["semantic_edges"] > 1000 and sysm.stats(0)["object3ds"] == 3
+
+
+@pytest.mark.parametrize("lm", [slam.LM_SYNC, slam.LM_DEFERRED], ids=["sync", "deferred"])
+def test_operator_failure_is_confined_to_its_sequence(lm):
+    """Per-sequence failure isolation (include/oslam_slam.h; reference: one System resets itself, src/Tracking.cc:553-560): the local-BA window of ONE sequence of a
+    4-sequence handle is made invalid (oslam_slam_inject_failure) — that sequence reports LOST, starts a new map and is counted; the other three sequences come
+    out bit-identical to a run without the failure."""
+    n, S, victim = 30, 4, 2
+    streams = make_streams(S, n)
+    clean = slam.System(slam.make_config(W, H, S, local_mapping=lm))
+    pc, sc = run(clean, streams, n)
+    hit = slam.System(slam.make_config(W, H, S, local_mapping=lm))
+    depth = np.full((H, W), 2.0, np.float32)
+    poses, states = [], []
+    injected_at = None
+    for t in range(n):
+        if injected_at is None and hit.stats(victim)["local_bas"] >= 1:     # after its first local BA: the next window of the victim is refused
+            hit.inject_failure(victim)
+            injected_at = t
+        T, st = hit.TrackRGBD([streams[s][0][t] for s in range(S)], [depth] * S, [t / 30.0] * S)
+        poses.append(T.copy()); states.append(st.copy())
+    hit.finish(); clean.finish()
+    poses, states = np.array(poses), np.array(states)
+    assert injected_at is not None
+    others = [s for s in range(S) if s != victim]
+    assert np.array_equal(poses[:, others], pc[:, others]) and np.array_equal(states[:, others], sc[:, others])
+    for s in others:
+        assert hit.stats(s) == clean.stats(s) and hit.lba_window_stats(s)["operator_failures"] == 0
+    w = hit.lba_window_stats(victim)
+    assert w["operator_failures"] == 1
+    # the failure is visible to the caller: the sequence re-initialises on the frame after the refused window (StereoInitialization: the identity pose of a new map) ...
+    eye = np.eye(4, dtype=np.float32)
+    restarts = [t for t in range(injected_at, n) if np.array_equal(poses[t, victim], eye)]
+    assert len(restarts) == 1, restarts
+    # ... and tracks again on that map
+    assert states[-1, victim] == slam.OK and hit.stats(victim)["map_violations"] == 0 and hit.stats(victim)["lost_frames"] == 0
+    assert np.array_equal(poses[:injected_at, victim], pc[:injected_at, victim])
