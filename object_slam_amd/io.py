@@ -235,3 +235,121 @@ def evaluate_ate(gt_file, est_file, offset=0.0, scale=1.0, max_difference=0.02):
     _, _, e = align_horn(second_xyz, first_xyz)
     return {"pairs": len(e), "rmse": float(np.sqrt(np.dot(e, e) / len(e))), "mean": float(e.mean()), "median": float(np.median(e)),
             "std": float(e.std()), "min": float(e.min()), "max": float(e.max())}
+
+
+# ---- dataset side of the runners in examples/ (reference Examples/RGB-D/rgbd_tum.cc, Examples/Stereo/stereo_kitti.cc, src/Tracking.cc:60-170, :195-275) ----
+def load_settings(path):
+    """The settings file the reference reads with cv::FileStorage (`%YAML:1.0`, `Key.sub: value` rows, Examples/RGB-D/TUM2.yaml): {key: float | str}."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            line = line.split("#", 1)[0].strip()
+            if not line or line.startswith("%") or line.startswith("---") or ":" not in line:
+                continue
+            k, v = line.split(":", 1)
+            v = v.strip().strip('"')
+            try:
+                out[k.strip()] = float(v)
+            except ValueError:
+                out[k.strip()] = v
+    return out
+
+
+def config_from_settings(st, n_sequences=1, sensor=None, **kw):
+    """oslam_slam_config_t from the reference's settings keys (src/Tracking.cc:60-170): Camera.fx .. Camera.k3, Camera.bf, ThDepth, Camera.fps, ORBextractor.*."""
+    from . import slam
+    cam = dict(fx=st["Camera.fx"], fy=st["Camera.fy"], cx=st["Camera.cx"], cy=st["Camera.cy"], bf=st["Camera.bf"], thDepth=st.get("ThDepth", 40.0), fps=st.get("Camera.fps", 30.0) or 30.0)
+    dist = [st.get("Camera.k1", 0.0), st.get("Camera.k2", 0.0), st.get("Camera.p1", 0.0), st.get("Camera.p2", 0.0)]
+    if st.get("Camera.k3", 0.0) != 0.0:     # src/Tracking.cc:96-101: k3 only when non-zero
+        dist.append(st["Camera.k3"])
+    if not any(dist):
+        dist = None
+    return slam.make_config(int(st["Camera.width"]), int(st["Camera.height"]), n_sequences, cam=cam, dist=dist, nFeatures=int(st["ORBextractor.nFeatures"]),
+                            scaleFactor=float(st["ORBextractor.scaleFactor"]), nLevels=int(st["ORBextractor.nLevels"]), iniThFAST=int(st["ORBextractor.iniThFAST"]),
+                            minThFAST=int(st["ORBextractor.minThFAST"]), sensor=slam.RGBD if sensor is None else sensor, **kw)
+
+
+def read_image(path):
+    """cv::imread(path, CV_LOAD_IMAGE_UNCHANGED): uint8 [H,W] / [H,W,3|4] or uint16 [H,W] (TUM depth); an unreadable file -> an empty array."""
+    from PIL import Image
+    if not os.path.exists(path):
+        return np.zeros((0, 0), np.uint8)
+    im = Image.open(path)
+    a = np.asarray(im)
+    if a.dtype == np.int32:      # PIL mode "I" for 16-bit PNGs
+        a = a.astype(np.uint16)
+    return a
+
+
+def write_png(path, a):
+    """uint8 gray / RGB or uint16 gray PNG (for writing synthetic sequences in the datasets' layouts)."""
+    from PIL import Image
+    a = np.asarray(a)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    if a.dtype == np.uint16:
+        Image.fromarray(a.astype(np.uint16)).save(path)     # mode I;16
+    else:
+        Image.fromarray(a.astype(np.uint8)).save(path)
+
+
+def to_gray(img, rgb_order=True):
+    """cv::cvtColor(.., CV_RGB2GRAY / CV_BGR2GRAY) on 8-bit images as Tracking::GrabImageRGBD applies it by Camera.RGB (src/Tracking.cc:248-262): OpenCV's 14-bit
+    fixed point, Y = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14.  Gray images pass through."""
+    a = np.asarray(img)
+    if a.ndim == 2:
+        return np.ascontiguousarray(a.astype(np.uint8))
+    c = a[..., :3].astype(np.int64)
+    r, g, b = (c[..., 0], c[..., 1], c[..., 2]) if rgb_order else (c[..., 2], c[..., 1], c[..., 0])
+    return np.ascontiguousarray(((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8))
+
+
+def depth_to_float(imD, depth_map_factor):
+    """imDepth.convertTo(CV_32F, mDepthMapFactor) with mDepthMapFactor = 1 / DepthMapFactor (src/Tracking.cc:163-167, :264-265): float32 product, saturate-free."""
+    a = np.asarray(imD)
+    if a.dtype == np.float32 and abs(depth_map_factor - 1.0) <= 1e-5:
+        return np.ascontiguousarray(a)
+    f = np.float32(1.0) / np.float32(depth_map_factor) if abs(depth_map_factor) >= 1e-5 else np.float32(1.0)
+    return np.ascontiguousarray((a.astype(np.float64) * np.float64(f)).astype(np.float32))
+
+
+def load_kitti_sequence(path):
+    """stereo_kitti.cc LoadImages (Examples/Stereo/stereo_kitti.cc:127-158): times.txt, image_0/%06d.png, image_1/%06d.png."""
+    ts = [float(s) for s in open(os.path.join(path, "times.txt")).read().split()]
+    left = [os.path.join(path, "image_0", "%06d.png" % i) for i in range(len(ts))]
+    right = [os.path.join(path, "image_1", "%06d.png" % i) for i in range(len(ts))]
+    return left, right, np.asarray(ts, np.float64)
+
+
+def save_trajectory_tum_twc(path, stamps, Twc, prec=9):
+    """System::SaveTrajectoryTUM (prec 9, src/System.cc:429) / SaveKeyFrameTrajectoryTUM (prec 7, :466) rows from [R_wc | t_wc] (oslam_slam_trajectory's output)."""
+    with open(path, "w") as f:
+        for t, T in zip(stamps, np.asarray(Twc, np.float32)):
+            q = _quat_xyzw(T[:3, :3])
+            f.write(_fx(t, 6) + " " + " ".join(_fx(v, prec) for v in (T[0, 3], T[1, 3], T[2, 3], q[0], q[1], q[2], q[3])) + "\n")
+
+
+def save_trajectory_kitti_twc(path, Twc):
+    """System::SaveTrajectoryKITTI (src/System.cc:521-523) rows from [R_wc | t_wc]."""
+    with open(path, "w") as f:
+        for T in np.asarray(Twc, np.float32):
+            f.write(" ".join(_fx(v, 9) for v in T[:3, :4].reshape(-1)) + "\n")
+
+
+def detections_for_driver(sem, height, width):
+    """The driver's detection input (include/oslam_slam.h: masks + the CALLER's track id per detection) from one frame's semantic entries (read_semantic_*).
+    Association across frames is the out-of-scope object layer of the reference (ObjectMatcher); the substitute used by the runners: the k-th detection of a label,
+    ordered by its box's x, keeps track id label * 100 + k."""
+    per = {}
+    out = dict(masks=[], track_ids=[], labels=[])
+    for e in sorted(sem, key=lambda e: (e["label"], e["x"])):
+        m = np.asarray(e["mask"])
+        if m.ndim == 3:
+            m = m[..., 0]
+        if m.shape != (height, width):
+            continue
+        k = per.get(e["label"], 0)
+        per[e["label"]] = k + 1
+        out["masks"].append(np.ascontiguousarray(np.where(m > 0, 255, 0).astype(np.uint8)))
+        out["track_ids"].append(e["label"] * 100 + k)
+        out["labels"].append(e["label"])
+    return out if out["masks"] else None

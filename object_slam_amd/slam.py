@@ -215,8 +215,9 @@ class System:
                                            ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
         return self.Tcw, self.state
 
-    def TrackStereo(self, left, right, timestamps=None, on_device=False, stride=None):
-        """left / right: S uint8 arrays [H, W] (or device addresses with on_device=True and the row stride in bytes)."""
+    def TrackStereo(self, left, right, timestamps=None, on_device=False, stride=None, objects=None, mask_stride=None):
+        """left / right: S uint8 arrays [H, W] (or device addresses with on_device=True and the row stride in bytes); objects: the frames' semantic detections
+        (see _objects; Tracking::GrabImageStereo reads them per frame, src/Tracking.cc:229-232)."""
         if not hasattr(self, "_rp"):
             self._rp = (C.c_void_p * self.S)()
         for i in range(self.S):
@@ -228,6 +229,12 @@ class System:
                 self._rp[i] = right[i].__array_interface__["data"][0]
         ts = None if timestamps is None else np.ascontiguousarray(timestamps, np.float64)
         st = stride if on_device else left[0].strides[0]
+        if objects is not None:
+            arr, ms, keep = self._objects(objects, on_device)
+            ms = mask_stride if on_device else (ms or self.cfg.width)
+            check(self.L.oslam_slam_track_stereo_objects(self.h, self._gp, self._rp, C.c_int(st), C.c_int(1 if on_device else 0),
+                                                         ptr(ts) if ts is not None else None, arr, C.c_int(ms), ptr(self.Tcw), ptr(self.state)))
+            return self.Tcw, self.state
         check(self.L.oslam_slam_track_stereo(self.h, self._gp, self._rp, C.c_int(st), C.c_int(1 if on_device else 0),
                                              ptr(ts) if ts is not None else None, ptr(self.Tcw), ptr(self.state)))
         return self.Tcw, self.state

@@ -112,3 +112,42 @@ def test_associate_equals_brute_force_and_ate(tmp_path):
     assert st["pairs"] == n and 0.012 < st["rmse"] < 0.02 and st["min"] <= st["median"] <= st["max"]
     from object_slam_amd.io import horn_align_ate
     assert abs(horn_align_ate(est, gt) - st["rmse"]) < 1e-6
+
+
+# ---- the dataset side of the runners in examples/ (VERDICT r4 item 8): a synthetic sequence written to disk in the TUM layout + semantic/<ts>/, read back ----
+def test_tum_layout_round_trip_and_settings(tmp_path):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import numpy as np
+    from object_slam_amd import io, scene, slam
+    from dataset_layout import TUM_FACTOR, write_tum_sequence
+    n = 3
+    q = scene.make_rgbd_sequence(0, n, speed=2.0)
+    sp, ap, stamps = write_tum_sequence(str(tmp_path), q, slam.TUM2, n)
+    rgb, dep, ts = io.load_associations(ap)
+    assert len(rgb) == len(dep) == n and np.allclose(ts, stamps, atol=1e-6)
+    st = io.load_settings(sp)
+    assert st["Camera.fx"] == slam.TUM2["fx"] and st["ORBextractor.nFeatures"] == 1000 and st["DepthMapFactor"] == TUM_FACTOR and st["DataSetPath"] == str(tmp_path)
+    cfg = io.config_from_settings(st, 1, slam.RGBD)
+    assert (cfg.width, cfg.height, cfg.nFeatures, cfg.nLevels, cfg.ndist) == (640, 480, 1000, 8, 0) and abs(cfg.bf - slam.TUM2["bf"]) < 1e-6
+    for i in range(n):
+        im = io.read_image(os.path.join(str(tmp_path), rgb[i]))
+        assert im.shape == (480, 640, 3)
+        assert np.array_equal(io.to_gray(im, True), q["gray"][i])             # R = G = B: (4899 + 9617 + 1868) v + 8192 >> 14 = v
+        d = io.depth_to_float(io.read_image(os.path.join(str(tmp_path), dep[i])), st["DepthMapFactor"])
+        assert d.dtype == np.float32 and np.abs(d - q["depth"][i]).max() <= 0.5 / TUM_FACTOR + 1e-6
+        sem = io.read_semantic_tum(str(tmp_path) + "/semantic/", ts[i], 0.5)
+        det = io.detections_for_driver(sem, 480, 640)
+        assert det is not None and len(det["masks"]) == 3 and sorted(det["labels"]) == [41, 56, 62]      # the low-confidence and the invalid-label rows are dropped
+        for m in det["masks"]:
+            assert any(np.array_equal(m, q["masks"][i, k]) for k in range(3))
+    # cv::cvtColor RGB2GRAY fixed point on a colour pixel: (200 * 4899 + 100 * 9617 + 50 * 1868 + 8192) >> 14 = 124; BGR order swaps the outer weights
+    px = np.array([[[200, 100, 50]]], np.uint8)
+    assert io.to_gray(px, True)[0, 0] == (200 * 4899 + 100 * 9617 + 50 * 1868 + 8192) >> 14 == 124
+    assert io.to_gray(px, False)[0, 0] == (50 * 4899 + 100 * 9617 + 200 * 1868 + 8192) >> 14 == 96
+    # the reference's own settings file parses (it is data of the reference tree, read in place when present)
+    ref = "/root/reference/Examples/RGB-D/TUM2.yaml"
+    if os.path.exists(ref):
+        r = io.load_settings(ref)
+        assert r["Camera.fx"] == 520.908620 and r["Camera.k3"] == 0.917205 and r["ORBextractor.nFeatures"] == 1000 and r["DepthMapFactor"] == 5208.0
+        assert io.config_from_settings(r).ndist == 5
