@@ -175,7 +175,7 @@ def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1, chunk=24, have=
 def _window_totals(systems, per):
     tot = np.zeros(6, np.int64)
     for sy in systems:
-        for q in range(per):
+        for q in range(sy.S if per is None else per):
             w = sy.lba_window_stats(q)
             tot += np.array([w["windows"], w["local_kfs"], w["fixed_kfs"], w["points"], w["edges"], w["lba_windows_degraded"]], np.int64)
     return tot
@@ -190,7 +190,7 @@ def window_stats(after, before):
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,
-             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None, local_mapping=slam.LM_SYNC):
+             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None, local_mapping=slam.LM_SYNC, total_sequences=None):
     """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread); `preroll` untimed steps that
     bring every sequence's map to its steady state (they are part of the set-up, like loading a map), `warmup` untimed lockstep steps, then exactly `steps`
     timed steps bracketed by a barrier + device synchronisation on both sides.  `post(ctx)` (optional) may run further phases on the warmed sequences
@@ -199,17 +199,23 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     import torch
     import torch.distributed as dist
     multi = world > 1 and dist.is_available() and dist.is_initialized()
-    total = seqs_per_rank * world
+    # total_sequences (optional): a job whose sequence count is NOT a multiple of the world size (configs[4]: "8 sequences"; any number of sequences on any number
+    # of GPUs): rank r still takes sequences r, r + world, ...; the ranks' shards then differ by one sequence and a rank's handles by one as well
+    total = seqs_per_rank * world if total_sequences is None else int(total_sequences)
     mine = shard_sequences(total, world, rank)                 # global sequence ids of this rank
-    assert len(mine) == seqs_per_rank and seqs_per_rank % handles == 0
-    per = seqs_per_rank // handles
-    groups = [mine[h * per:(h + 1) * per] for h in range(handles)]
+    assert len(mine) >= 1, "rank %d of %d has no sequence (total %d)" % (rank, world, total)
+    if total_sequences is None:
+        assert len(mine) == seqs_per_rank and seqs_per_rank % handles == 0
+    seqs_per_rank = len(mine)
+    handles = min(handles, seqs_per_rank)
+    groups = [[int(x) for x in g] for g in np.array_split(np.asarray(mine), handles)]
+    per = None if len({len(g) for g in groups}) > 1 else len(groups[0])
     n_timed0 = preroll + warmup
     n_frames = n_timed0 + steps
     inp = _Inputs(wl, mine, n_frames + post_frames, on_device, device, base_seed=wl.n_base * rank, sequences=sequences)
     systems = []
     for h in range(handles):
-        cfg = slam.make_config(wl.width, wl.height, per, cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor,
+        cfg = slam.make_config(wl.width, wl.height, len(groups[h]), cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor,
                                device=(device.index if hasattr(device, "index") and device.index is not None else 0) if on_device else 0, host_threads=host_threads,
                                local_mapping=local_mapping)
         systems.append(make_system(cfg))
@@ -256,7 +262,7 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     # per-rank record (fixed size, all-gathered once): counters summed over the rank's sequences, ATE of its first sequence
     kf = lba = lost = viol = sem = 0
     for h in range(handles):
-        for q in range(per):
+        for q in range(len(groups[h])):
             st = systems[h].stats(q)
             kf += st["keyframes_created"]; lba += st["local_bas"]; lost += st["lost_frames"]; viol += st["map_violations"]
             sem += st.get("semantic_edges", 0)

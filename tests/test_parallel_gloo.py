@@ -103,3 +103,42 @@ def test_shard_and_aggregate_passthrough():
     assert shard_sequences(8, 2, 1) == [1, 3, 5, 7]
     assert aggregate_stats(2.0, 10) == (10, 2.0)
     assert gather_records([1.0, 2.0]).tolist() == [[1.0, 2.0]]
+
+
+def _worker_unequal(rank, world, port, q, total):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_slam_amd import seqbench
+    wl = seqbench.rgbd_workload(n_base=2, stagger=1, with_masks=False)
+    summ, rec, systems, extra = seqbench.run_rank(wl, _oracle_system, rank, world, 0, 2, steps=2, warmup=1, on_device=False, collect_poses=True, total_sequences=total)
+    q.put((rank, summ, rec.tolist(), extra["groups"], [np.array(p) for p in extra["poses"]]))
+    dist.destroy_process_group()
+
+
+def test_run_rank_world4_with_unequal_shards(oracle):
+    """6 sequences on 4 ranks (the sequence count is not a multiple of the world size: configs[4] names 8 sequences on 1 / 2 / 4 / 8 GPUs, a deployment any count):
+    sequence i -> rank i mod 4, so ranks 0 and 1 run two sequences (one per handle) and ranks 2 and 3 one; frames are summed over the ranks, the time is the
+    slowest rank's, and a sequence's poses do not depend on the rank or the handle it ran in."""
+    world, total = 4, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_unequal, args=(r, world, port, q, total)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r[0])
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[3] for r in res] == [[[0], [4]], [[1], [5]], [[2]], [[3]]]
+    rec = np.array(res[0][2])
+    assert all(np.array_equal(rec, np.array(r[2])) for r in res) and rec.shape[0] == 4
+    assert list(rec[:, 1]) == [2, 2, 1, 1] and list(rec[:, 2]) == [4, 4, 2, 2]          # sequences and timed frames per rank
+    s = res[0][1]
+    assert s["total_frames"] == total * 2 and s["n_ranks"] == 4 and s["elapsed_s"] == max(rec[:, 3])
+    assert all(r[1]["frames_per_s"] == s["frames_per_s"] for r in res) and s["lost_frames"] == 0 and s["map_violations"] == 0
+    # every handle of every rank advanced its sequences through warm-up + timed steps from the identity pose of a new map
+    for r in res:
+        for p in r[4]:
+            assert p.shape[0] == 3 and p.shape[-2:] == (4, 4) and np.array_equal(p[0, 0], np.eye(4, dtype=np.float32))
