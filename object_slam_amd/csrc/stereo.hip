@@ -191,21 +191,49 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoCtx c, int ncap) {
         const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
         // guard the window reads (the reference does not check the left window / the right -10 side)
         if (cy - w < 0 || cy + w >= c.L.h[oct] || cxL - w < 0 || cxL + w >= c.L.w[oct] || cxR0 - L - w < 0 || cxR0 + L + w >= c.R.w[oct]) return;
-        // lanes hold the 121 left-patch values (2 per lane); every byte of the left patch and of the 11 x 21 right strip is requested
-        // before the first one is used
+        // lanes hold the 121 left-patch values (2 per lane).  The 11 x 11 left patch and the 11 x 21 right strip are fetched ONCE per wavefront as aligned
+        // words (44 + 66 words: three load instructions) into LDS and the lanes pick their bytes there.  Round 4 had every lane load its 35 bytes from global
+        // memory itself: 35 byte-gather instructions per keypoint, and the kernel — the largest of the stereo workload, 1.98 ms per 256 frames — ran at the
+        // texture addresser's rate (rocprofv3: profiles/r05_stereo_bench_kernel_stats_before.csv).  A keypoint lies >= 19 pixels inside its level and the
+        // guard above keeps the strip inside the row, so the words that hold the first / last bytes are inside the image buffer.
+        __shared__ uint32_t s_pat[4][112];
+        uint32_t* sp = s_pat[threadIdx.x >> 6];
+        const uint8_t* spb = (const uint8_t*)sp;
+        {
+            if (lane < 44) {
+                const uint8_t* a = imL + (long long)(cy + (lane >> 2) - w) * pL + cxL - w;
+                sp[lane] = *(const uint32_t*)((const uint8_t*)((unsigned long long)a & ~3ull) + 4 * (lane & 3));
+            }
+            const int r = lane / 6, wd = lane - 6 * r;   // right strip rows 0 .. 10 (lanes 0 .. 63 cover words 0 .. 63; lanes 0, 1 add words 64, 65)
+            const uint8_t* a = imR + (long long)(cy + r - w) * pR + cxR0 - L - w;
+            sp[44 + lane] = *(const uint32_t*)((const uint8_t*)((unsigned long long)a & ~3ull) + 4 * wd);
+            if (lane < 2) {
+                const uint8_t* a2 = imR + (long long)(cy + 10 - w) * pR + cxR0 - L - w;
+                sp[44 + 64 + lane] = *(const uint32_t*)((const uint8_t*)((unsigned long long)a2 & ~3ull) + 4 * (4 + lane));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto left_px = [&](int dy, int dx) -> int {    // imL[(cy + dy) * pL + cxL + dx]
+            const unsigned sh = (unsigned)((unsigned long long)(imL + (long long)(cy + dy) * pL + cxL - w) & 3ull);
+            return (int)spb[(dy + w) * 16 + sh + dx + w];
+        };
+        auto right_px = [&](int dy, int x) -> int {    // imR[(cy + dy) * pR + cxR0 - 10 + x], x = 0 .. 20
+            const unsigned sh = (unsigned)((unsigned long long)(imR + (long long)(cy + dy) * pR + cxR0 - L - w) & 3ull);
+            return (int)spb[176 + (dy + w) * 24 + sh + x];
+        };
         const bool has1 = lane + 64 < 121;
         const int dy0 = lane / 11 - w, dx0 = lane % 11 - w;
         const int dy1 = has1 ? (lane + 64) / 11 - w : 0, dx1 = has1 ? (lane + 64) % 11 - w : 0;
-        const int centerL = imL[(long long)cy * pL + cxL];
-        const int l0 = imL[(long long)(cy + dy0) * pL + cxL + dx0];
-        const int l1 = imL[(long long)(cy + dy1) * pL + cxL + dx1];
+        const int centerL = left_px(0, 0);
+        const int l0 = left_px(dy0, dx0);
+        const int l1 = left_px(dy1, dx1);
         int r0[11], r1[11], rc[11];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const int cxR = cxR0 + k - 5;
-            rc[k] = imR[(long long)cy * pR + cxR];
-            r0[k] = imR[(long long)(cy + dy0) * pR + cxR + dx0];
-            r1[k] = imR[(long long)(cy + dy1) * pR + cxR + dx1];
+        for (int k = 0; k < 11; k++) {   // cxR = cxR0 + k - 5: strip column k + 5 (+ dx)
+            rc[k] = right_px(0, k + 5);
+            r0[k] = right_px(dy0, k + 5 + dx0);
+            r1[k] = right_px(dy1, k + 5 + dx1);
         }
         const int lv0 = l0 - centerL, lv1 = l1 - centerL;
         int bestDist = 0x7fffffff, bestinc = 0;
