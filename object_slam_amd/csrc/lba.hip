@@ -632,6 +632,7 @@ struct LbaWide {
     const int* pair_start;    // [nfree*(nfree+1)/2 + 1]
     uint16_t* pairM; int2* pairs_w; int* pair_start_w;   // pair lists built on the device (k_w_pair_*): then pairs / pair_start point at pairs_w / pair_start_w
     double* W;                // [E][18]: Hpl_e * (Hll_p + lambda I)^-1, written by k_w_edgeW for the current trial
+    float4* eoi;              // [E] (u, v, u_R, invSigma2) of every edge in one 16-byte record (k_w_init_arrays packs e_obs / e_info once per call), or null
     double* rec;              // [E][4] compact edge records of the current linearisation (x, y, 1/z of the point in the camera frame, weight x information with the
                               // sign bit = monocular), or null: the per-edge blocks B_e are then materialised in pr.Hpl (see k_w_schur_rec)
     // Schur complement by tiles (k_w_schur_tiles / k_w_schur_sum, lba_win.inc): the structures of LbaWin on the point-major edge numbering
@@ -670,11 +671,14 @@ __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, const L
 }
 
 // state arrays of a fresh problem (grid-wide; k_w_init's single block only sets the control block and the poses)
-__global__ __launch_bounds__(256) void k_w_init_arrays(const LbaProblem* probs) {
+__global__ __launch_bounds__(256) void k_w_init_arrays(const LbaProblem* probs, const LbaWide* ws) {
     const LbaProblem& pr = probs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < pr.P * 3) pr.Xa[i] = (double)pr.points[i];
-    if (i < pr.E) { pr.level[i] = 0; pr.chi2[i] = 0; pr.erase[i] = 0; }
+    if (i < pr.E) {
+        pr.level[i] = 0; pr.chi2[i] = 0; pr.erase[i] = 0;
+        if (ws && ws[blockIdx.y].eoi) ws[blockIdx.y].eoi[i] = make_float4(pr.e_obs[i * 3], pr.e_obs[i * 3 + 1], pr.e_obs[i * 3 + 2], pr.e_info[i]);
+    }
 }
 
 // Between the two optimisation stages (reference src/Optimizer.cc:668-689): edges with chi2 above the gate or behind the
@@ -698,6 +702,7 @@ __device__ void w_gate_block(const LbaProblem& pr, const LbaWide& w) {
 // [nblk_pt, nblk_pt + K) own one keyframe each (8 wavefronts split its edge list: Hpp, bp).  Both roles are independent,
 // so they overlap instead of running back to back.
 constexpr int kLinThreads = 4 * kWPt;   // 512
+constexpr int kLinKfLds = 128;          // keyframes of a window whose rotation + translation k_w_lin's landmark blocks stage in LDS (12 KB)
 
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w);
 __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
@@ -734,33 +739,40 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
     const double* X = w_X(pr, ct->cur);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ double sF[kLinThreads / 64], sM[kLinThreads / 64], sAcc[kLinThreads / 64][27];
+    // Point role: rotation matrix + translation of the window's keyframes staged in LDS (12 doubles each) when the window has at most kLinKfLds of them: a
+    // landmark's edges name different keyframes, and the 12 doubles of an edge's keyframe came as twelve 8-byte gathers per edge from global memory (the
+    // kernel's largest group of vector-memory instructions); larger windows (fixed cameras are unbounded, src/Optimizer.cc:489-504) read them where they are.
+    __shared__ double sRt[REC ? kLinKfLds * 12 : 1];
     if (item_ < w.nblk_pt) {
         const SE3* T = w.T + ct->cur * pr.K;
         const double* Rm = w.R + (size_t)ct->cur * pr.K * 9;
+        const bool staged = REC && pr.K <= kLinKfLds;
+        if (staged) {
+            for (int i = tid; i < pr.K * 12; i += kLinThreads) {
+                const int a = i / 12, j = i - a * 12;
+                sRt[i] = j < 9 ? Rm[a * 9 + j] : T[a].t[j - 9];
+            }
+            __syncthreads();
+        }
         const int p = item_ * kWPt + (tid >> 2), sub = tid & 3;
         double F0 = 0, dmax = 0;
         double hl[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         if (p < pr.P) {
             const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
-            for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
-                // (the edge's inputs are requested together with its level byte, not after it)
-                const uint8_t lv = pr.level[e];
-                const int a = pr.e_kf[e];
-                const float o0 = pr.e_obs[e * 3], o1 = pr.e_obs[e * 3 + 1], ur = pr.e_obs[e * 3 + 2], inf = pr.e_info[e];
+            auto edge = [&](int e, uint8_t lv, int a, float o0, float o1, float ur, float inf, const double* Ra_, const double* ta_) {
                 if (lv != 0) {
                     if (REC) {   // weight 0: the edge adds exact zeros wherever its record is read
                         double2* rc = (double2*)(w.rec + (long long)e * 4);
                         rc[0] = make_double2(0.0, 0.0); rc[1] = make_double2(1.0, 0.0);
                     }
-                    continue;
+                    return;
                 }
                 const bool stereo = !(ur < 0);
                 const double ob[3] = {(double)o0, (double)o1, (double)ur};
                 const double info = (double)inf;
                 // (se3_math.h fast forms: rotation-matrix map, one Newton reciprocal, fused multiply-adds, products over the non-zero Jacobian entries only)
                 double pc[3], er[3], iz, Jx[9];
-                const double* Ra_ = Rm + a * 9;
-                map_rt(Ra_, T[a].t, Xw, pc);
+                map_rt(Ra_, ta_, Xw, pc);
                 const double c2 = residual_fast(cam, pc, ob, stereo, info, er, iz);
                 pr.chi2[e] = c2;
                 double r0 = c2, wgt = 1.0;
@@ -802,6 +814,16 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                             }
                     }
                 }
+            };
+            for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
+                // (the edge's inputs are requested together with its level byte, not after it)
+                const uint8_t lv = pr.level[e];
+                const int a = pr.e_kf[e];
+                float o0, o1, ur, inf;
+                if (REC && w.eoi) { const float4 oi = w.eoi[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }
+                else { o0 = pr.e_obs[e * 3]; o1 = pr.e_obs[e * 3 + 1]; ur = pr.e_obs[e * 3 + 2]; inf = pr.e_info[e]; }
+                if (staged) edge(e, lv, a, o0, o1, ur, inf, sRt + a * 12, sRt + a * 12 + 9);
+                else edge(e, lv, a, o0, o1, ur, inf, Rm + a * 9, T[a].t);
             }
         }
         // the 4 lanes of a landmark: (s0 + s1) + (s2 + s3)
@@ -1026,17 +1048,27 @@ __global__ __launch_bounds__(64) void k_w_pair_blocks(const LbaProblem* probs, c
     while (rem >= nfree - ba) { rem -= nfree - ba; ba++; }
     const int bb = ba + rem;
     int base = FILL ? w.pair_start_w[t] : 0;
-    for (int p0 = 0; p0 < pr.P; p0 += 64) {
-        const int p = p0 + lane;
-        int ma = 0, mb = 0;
-        if (p < pr.P) { ma = w.pairM[(size_t)ba * pr.P + p]; mb = w.pairM[(size_t)bb * pr.P + p]; }
-        const bool has = ma != 0 && mb != 0;
-        const unsigned long long bal = __ballot(has);
-        if (FILL && has) {
-            const int s = pr.pt_start[p];
-            w.pairs_w[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(s + ma - 1, s + mb - 1);
+    const uint16_t* rowa = w.pairM + (size_t)ba * pr.P;
+    const uint16_t* rowb = w.pairM + (size_t)bb * pr.P;
+    for (int p0 = 0; p0 < pr.P; p0 += 256) {   // four chunks of 64 points per round: their eight loads travel together (the walk is a chain of load -> ballot -> count otherwise)
+        int ma[4], mb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = p0 + 64 * u + lane;
+            ma[u] = 0; mb[u] = 0;
+            if (p < pr.P) { ma[u] = rowa[p]; mb[u] = rowb[p]; }
         }
-        base += __popcll(bal);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int p = p0 + 64 * u + lane;
+            const bool has = ma[u] != 0 && mb[u] != 0;
+            const unsigned long long bal = __ballot(has);
+            if (FILL && has) {
+                const int s = pr.pt_start[p];
+                w.pairs_w[base + __popcll(bal & ((1ull << lane) - 1ull))] = make_int2(s + ma[u] - 1, s + mb[u] - 1);
+            }
+            base += __popcll(bal);
+        }
     }
     if (!FILL && lane == 0) w.pair_start_w[t + 1] = base;   // counts, shifted by one: the scan below turns them into starts in place
 }
@@ -2310,7 +2342,7 @@ int oslam_lba_create(oslam_lba_t** out, int max_batch, int max_keyframes, int ma
     if (hipStreamCreateWithFlags(&h->strm, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete h; return OSLAM_E_HIP; }
     h->device = device; h->max_batch = max_batch; h->max_kf = max_keyframes;
     if (const char* e = getenv("OSLAM_LBA_CHOL_MFMA")) h->chol_mode = atoi(e) ? 1 : 2;   // kernel experiments: 1 = matrix cores for every size, 0 = never
-    if (const char* e = getenv("OSLAM_LBA_SOLVER")) { const int v = atoi(e); if (v >= 0 && v <= 3) h->chol_mode = v; }   // A/B knob: oslam_lba_set_solver for every handle of the process
+    if (const char* e = getenv("OSLAM_LBA_SOLVER")) { const int v = atoi(e); if (v >= 0 && v <= 4) h->chol_mode = v; }   // A/B knob: oslam_lba_set_solver for every handle of the process
     if (getenv("OSLAM_LBA_HOST_PAIRS")) h->device_pairs = false;
     if (const char* e = getenv("OSLAM_LBA_SCHUR_VINV")) h->schur_vinv = atoi(e) != 0;
     if (const char* e = getenv("OSLAM_LBA_REC")) h->edge_rec = atoi(e) != 0;
@@ -2353,7 +2385,7 @@ int oslam_lba_set_schur(oslam_lba_t* h, int mode) {
 }
 
 int oslam_lba_set_solver(oslam_lba_t* h, int mode) {
-    if (!h || mode < 0 || mode > 3) { set_error("oslam_lba_set_solver: bad argument"); return OSLAM_E_INVALID; }
+    if (!h || mode < 0 || mode > 4) { set_error("oslam_lba_set_solver: bad argument"); return OSLAM_E_INVALID; }
     h->chol_mode = mode;
     return OSLAM_OK;
 }
@@ -2689,7 +2721,7 @@ static int lba_launch(oslam_lba_t* h) {
     size_t work = 0, outb = 0;
     auto takeW = [&](size_t bytes) { const size_t at = work; work += (bytes + 255) & ~(size_t)255; return at; };
     auto takeO = [&](size_t bytes) { const size_t at = outb; outb += (bytes + 255) & ~(size_t)255; return at; };
-    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, rec, chunkC, pairPart, parts, pairM, pairsW, pstartW; };
+    struct WOff { size_t Xa, Xb, chi2, level, Hpl, Hll, Dinv, bl, xl, Hpp, bp, Hs, xp, ctrl, T, R, blk, free_pose, partF, partS, partM, W, rec, eoi, chunkC, pairPart, parts, pairM, pairsW, pstartW; };
     bool tiles = wide && n0 > 0;     // wide layout: Schur complement by tiles when every layout-0 window carries the structures
     for (int i : idx0) tiles = tiles && !h->prep[i].tile_p0.empty();
     const bool use_rec = wide && !tiles && h->schur_vinv && h->edge_rec;   // compact edge records (k_w_schur_rec): no B_e blocks at all
@@ -2727,6 +2759,7 @@ static int lba_launch(oslam_lba_t* h) {
                     // (per-landmark inverses: 48 bytes per point, whatever the edge count — a window may hold points without edges)
                     o.W = takeW(use_rec ? P * 48 : std::max(E * 144, h->schur_vinv ? P * 48 : (size_t)0));
                     o.rec = use_rec ? takeW(E * 32) : 0;
+                    o.eoi = use_rec ? takeW(E * 16) : 0;
                     if (q.dev_pairs) { o.pairsW = takeW(std::max<size_t>(q.npairs, 1) * 8); o.pstartW = takeW(((size_t)q.nblk + 1) * 4); any_dev_pairs = true; }   // (pairM: one block for the call, below)
                 }
                 if ((int)n6 <= kCholPackedN) packed_lds = std::max(packed_lds, ((size_t)win_hs_doubles(q.nfree) + n6 / 2 + 4 + n6 + 8) * 8);
@@ -2796,6 +2829,7 @@ static int lba_launch(oslam_lba_t* h) {
             w.ct = (LbaCtrl*)(Wk + o.ctrl); w.T = (SE3*)(Wk + o.T); w.R = (double*)(Wk + o.R); w.blk = (int*)(Wk + o.blk); w.free_pose = (int*)(Wk + o.free_pose);
             w.partF = (double*)(Wk + o.partF); w.partS = (double*)(Wk + o.partS); w.partM = (double*)(Wk + o.partM); w.W = (double*)(Wk + o.W);
             w.rec = use_rec ? (double*)(Wk + o.rec) : nullptr;
+            w.eoi = use_rec ? (float4*)(Wk + o.eoi) : nullptr;
             w.nblk_pt = div_up(std::max(q.pr.P, 1), kWPt);
             w.pairs = (const int2*)(I + q.o_pairs); w.pair_start = (const int*)(I + q.o_pstart);
             if (q.dev_pairs && !tiles) {
@@ -2803,7 +2837,7 @@ static int lba_launch(oslam_lba_t* h) {
                 w.pairs = w.pairs_w; w.pair_start = w.pair_start_w;
             }
             if (tiles) {
-                w.W = nullptr; w.rec = nullptr;
+                w.W = nullptr; w.rec = nullptr; w.eoi = nullptr;
                 w.tile_p0 = (const int*)(I + q.o_tile_p0); w.tile_s0 = (const int*)(I + q.o_tile_s0); w.stg_edge = (const int*)(I + q.o_stg_edge);
                 w.thr_own = (const int*)(I + q.o_thr_own);
                 w.blk_thr = (const int*)(I + q.o_blk_thr); w.blk_slots = (const int*)(I + q.o_blk_slots); w.parts = (double*)(Wk + o.parts);
@@ -2871,13 +2905,15 @@ static int lba_launch(oslam_lba_t* h) {
         // chol_mode 0 (auto): LDS-resident matrix-core kernel (k_w_chol_lds_mfma) up to kCholLdsMfmaN unknowns, global-memory matrix-core kernel beyond;
         // 3: the round-3 choice (scalar packed LDS kernel up to kCholPackedN, matrix cores beyond); 1: global-memory matrix cores for every size; 2: no matrix cores
         const int cm = h->chol_mode;
-        const bool chol_ldsm = cm == 0 && !all_lds && min_n6_big <= kCholLdsMfmaN;
+        // (4: the LDS-resident matrix-core kernel also for calls whose systems would all fit the scalar LDS kernel — A/B of the small-window regime)
+        const bool chol_ldsm = (cm == 0 && !all_lds && min_n6_big <= kCholLdsMfmaN) || (cm == 4 && min_n6_big <= kCholLdsMfmaN);
+        if (cm == 4) all_lds = false;
         const bool chol_packed = !chol_ldsm && cm != 1 && !all_lds && min_n6_big <= kCholPackedN && (cm == 0 || cm == 3 || max_n6 <= kCholPackedN);
-        const bool chol_mfma = cm == 1 || ((cm == 0 || cm == 3) && !all_lds && max_n6 > (chol_ldsm ? kCholLdsMfmaN : kCholPackedN));
+        const bool chol_mfma = cm == 1 || ((cm == 0 || cm == 3 || cm == 4) && !all_lds && max_n6 > (chol_ldsm ? kCholLdsMfmaN : kCholPackedN));
         const int mfma_min_n = chol_ldsm ? kCholLdsMfmaN + 1 : (chol_packed ? kCholPackedN + 1 : 0);
         const size_t mfma_lds = (size_t)kMB * (((max_n6 + 1 + kMB - 1) / kMB + 1) * kMB) * sizeof(double);
         hipLaunchKernelGGL(k_w_init, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
-        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs);
+        hipLaunchKernelGGL(k_w_init_arrays, dim3(div_up(maxInit, 256), n0), dim3(256), 0, st, d_probs, d_ws);
         if (any_dev_pairs && !tiles) {   // the Schur pair lists of the call, once (k_w_init has numbered the free keyframes)
             OSLAM_HIP_CHECK(hipMemsetAsync(Wk + pairM_base, 0, pairM_bytes, st));
             hipLaunchKernelGGL(k_w_pair_matrix, dim3(div_up(maxE, 256), n0), dim3(256), 0, st, d_probs, d_ws);
