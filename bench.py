@@ -394,7 +394,7 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
            "GBs": {k: round(alg[k] / (us[k] * 1e-6) / 1e9, 1) for k in us if us[k] > 0},
            "whole_path_GBs": round(ex.algorithmic_bytes(int(n_kp)) * B * steps / dt / 1e9, 1),
            "hamming_pairs_per_frame": round(pairs.value / Bp, 1),
-           # committed PMC passes of this stage (profiles/r04_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
+           # committed PMC passes of this stage (profiles/r05_pmc_traffic.json): HBM bytes per frame and the VALU issue share of the kernels' own duration
            "pmc_hbm_KB_per_frame": {k: round(_pmc(k) / 512 / 1e3, 1) for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_blur_strip<true>", "k_octree",
                                                                                "k_orient_describe", "k_search_window") if _pmc(k) is not None},
            "pmc_valu_issue_frac": {k: _pmc(k, "valu_issue_frac_at_4_cycles") for k in ("k_resize_lds", "k_fast_cells_wave", "k_blur_strip<false>", "k_octree", "k_orient_describe",
@@ -407,10 +407,10 @@ def frontend_stage(frames, Twc, depth, local_rank, steps, B=512, parts=None):
 
 
 def _pmc(kernel, field="bytes_per_launch"):
-    """Per-launch PMC figure of `kernel` from the committed summary of this round (profiles/r04_pmc_traffic.json: separate rocprofv3 --pmc passes of
+    """Per-launch PMC figure of `kernel` from the committed summary of this round (profiles/r05_pmc_traffic.json: separate rocprofv3 --pmc passes of
     the S2 stage at 512 frames per launch — FETCH_SIZE, WRITE_SIZE, SQ_* — corrected as MI355X_MICROARCH.md §HBM prescribes); None when the summary has
     no row for it.  HBM bytes for the fp64 solver kernels were not collected (their bound is not HBM)."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # (re-taken in round 4 on the unchanged front-end kernels: within 0.3 % of the round-2 file)
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")   # (re-taken in round 5: tools/gpu/prof_stereo.sh; the front-end kernels are those of round 2)
     if not os.path.exists(path):
         return None
     try:
@@ -779,7 +779,7 @@ def main():
 def _lba_traffic():
     """Mean memory-side bytes per launch of an LM trial of the local-BA kernels (committed PMC summary; None when it is missing)."""
     try:
-        return int(json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_lba_traffic.json")))["mean_bytes_per_launch_of_a_trial"])
+        return int(json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_lba_traffic.json")))["mean_bytes_per_launch_of_a_trial"])
     except Exception:
         return None
 
@@ -787,8 +787,8 @@ def _lba_traffic():
 def _mfma_counters():
     """MFMA counters of the reduced-system solver the timed windows go through (k_w_chol_lds_mfma: LDS-resident system, v_mfma_f64_16x16x4_f64 row panels and
     trailing updates) from the committed rocprofv3 --pmc pass over one call of 40 steady-state-shaped windows (tools/lba_win_prof.py MODES=1 NB=40: n = 156;
-    SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r04_pmc_lba_mfma.json, tools/gpu_r4_pmc.sh)."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_lba_mfma.json")
+    SQ_INSTS_VALU_MFMA_MOPS_F64, SQ_VALU_MFMA_BUSY_CYCLES; profiles/r05_pmc_lba_mfma.json, tools/gpu/final_prof.sh)."""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_lba_mfma.json")
     try:
         e = json.load(open(path))["k_w_chol_lds_mfma"]
         return {"kernel": "k_w_chol_lds_mfma (v_mfma_f64_16x16x4_f64 row panels + trailing updates of the LDS-resident reduced camera system, n = 156: the timed path's solver)",
@@ -796,8 +796,8 @@ def _mfma_counters():
                 "mfma_busy_cycles_per_launch": int(e["SQ_VALU_MFMA_BUSY_CYCLES"]), "mfma_mops_f64_per_launch": int(e["SQ_INSTS_VALU_MFMA_MOPS_F64"]),
                 "mean_launch_us": round(e["mean_us"], 1),
                 "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 4 SIMDs x CUs the launch occupies); counters, not pencil arithmetic: one workgroup "
-                              "per window, bound by the per-panel critical path (16x16 diagonal factor + inverse on one wavefront), not by the matrix pipe",
-                "source": "profiles/r04_pmc_lba_mfma.json"}
+                              "per window, bound by the per-panel critical path (16x16 diagonal factor + inverse on one wavefront: chol16_aug), not by the matrix pipe",
+                "source": "profiles/r05_pmc_lba_mfma.json"}
     except Exception:
         return None
 
@@ -837,7 +837,7 @@ def roofline_of(k, summ, stereo):
             "kernel": kname, "achieved": round(achieved, 4), "peak": peak, "unit": unit, "frac": round(achieved / peak, 5),
             "traffic": _pmc(kname.split(" ")[0].split(",")[0]) if bound == "hbm" else _lba_traffic(), "launch_us": round(ms / launches * 1e3, 1),
             "traffic_note": None if bound == "hbm" else "memory-side bytes per launch of the local-BA kernels (mean over the 6 launches of an LM trial) from the committed rocprofv3 "
-            "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r04_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
+            "--pmc FETCH_SIZE / WRITE_SIZE passes of ONE call of 40 steady-state-shaped windows (profiles/r05_pmc_lba_traffic.json, tools/pmc_lba_traffic.py); the "
             "calls of this run carry ~82 windows: scale by the windows per call",
             "algorithmic_work_per_launch": int(work / launches), "work_unit": "bytes" if bound == "hbm" else "fp64 flop",
             "groups": group_tab,
