@@ -228,6 +228,9 @@ typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (curr
                                   * 6 MapPoint updates (descriptor gather, ComputeDistinctiveDescriptors, UpdateNormalAndDepth, record writes), 7 other (keyframe
                                   * registration copies, vocabulary nodes, object keypoint tests / mask bitmaps, local-map gathers) */
 
+/* KeyFrameCulling candidates of one sequence (oslam_slam_ops_t::kf_culling_counts): n keyframe ids in the reference's order, out [n][4]. */
+typedef struct oslam_job_cull { int32_t slot, n; const int32_t* kf_ids; int32_t* out; } oslam_job_cull_t;
+
 typedef struct oslam_slam_ops {
     void* ctx;
     /* capacity of the per-frame arrays the driver must allocate */
@@ -296,6 +299,23 @@ typedef struct oslam_slam_ops {
     /* optional: the MapPoint updates after a local BA from the solved windows themselves (oslam_job_mp_window_t).  NULL: the driver packs every point's
      * observations into an oslam_job_mp_update_t as for any other update. */
     int (*mp_update_windows)(void* ctx, int n, oslam_job_mp_window_t* wins);
+    /* optional pair, with register_keyframes (round 5): a DEVICE MIRROR of the observation graph and its first consumer.
+     * map_journal: the changes the driver made to the maps of `slots` since its last call, in program order — per sequence a run of variable-length records of
+     * 32-bit words, first word = op | (record length in words << 8):
+     *   1 KFMP      kf idx p            KeyFrame::mvpMapPoints[idx] = p (-1: none)                      (src/KeyFrame.cc:201-230)
+     *   2 KFMP_BULK kf N p[0..N) g[ceil(N/32)]   the point list of a NEW keyframe and, bit i of g, !(mvDepth[i] > mThDepth || mvDepth[i] < 0)   (src/KeyFrame.cc:30-58)
+     *   3 OKF_SET   kf idx p            MapPoint p now has the observation (kf, idx)                    (MapPoint::AddObservation, src/MapPoint.cc:196-207)
+     *   4 OKF_CLR   kf idx p            ... no longer has it                                           (EraseObservation / SetBadFlag / Replace, :209-318)
+     *   5 PT        p nObs bad lvl[2]   Observations(), isBad() and the octave histogram of p's observations (byte o of the 64-bit lvl = observations at octave o)
+     *   6 RESET                         the sequence starts a new map (Tracking::Reset): ids restart at 0
+     * The table applies them to device copies kept beside the resident keyframe / map-point records.
+     * kf_culling_counts: LocalMapping::KeyFrameCulling's counting loop (src/LocalMapping.cc:649-690) for the candidate keyframes of every job from those copies:
+     * out[4 q] = slots of keyframe q with a point at a usable depth, [4 q + 1] = nMPs, [4 q + 2] = nRedundantObservations, [4 q + 3] != 0: a point with exactly
+     * three observations at a fine enough scale whose own observation the mirror cannot vouch for — the driver recounts that keyframe from its lists.  The driver
+     * takes the verdicts in the reference's order and recounts on the host from the first culled keyframe of a pass on (SetBadFlag changes the counts of the
+     * candidates behind it).  NULL: the driver counts on the host. */
+    int (*map_journal)(void* ctx, int n, const int32_t* slots, const uint32_t* const* words, const int32_t* nwords);
+    int (*kf_culling_counts)(void* ctx, int n, const oslam_job_cull_t* jobs, float thDepth);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

@@ -179,7 +179,10 @@ struct Seq {
     int64_t opFailures = 0;               // operator errors confined to this sequence (its map was reset: local_mapping_back)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
+        const bool jr_on = map.jrOn;
         map = Map();
+        map.jrOn = jr_on;
+        if (jr_on) map.jr.push_back((uint32_t)Map::JR_RESET | (1u << 8));   // (device mirror of the observation graph: oslam_slam_ops_t::map_journal)
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
         localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear(); culledKFs.clear();
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
@@ -278,7 +281,7 @@ static bool unproject_frame(const Ctx& c, const Frame& f, int i, float out[3]) {
 }
 
 // KeyFrame::KeyFrame(Frame&, ...) (src/KeyFrame.cc:30-58)
-static int new_keyframe(Seq& s, const Frame& f) {
+static int new_keyframe(Seq& s, const Frame& f, float thDepth) {
     s.mapVersion++;
     s.map.kfs.emplace_back();
     KeyFrm& k = s.map.kfs.back();
@@ -298,6 +301,7 @@ static int new_keyframe(Seq& s, const Frame& f) {
     s.counter.resize(s.map.kfs.size() + 8, 0);
     s.st[1]++;
     s.pendingKF.push_back(k.id);
+    s.map.jr_kfmp_bulk(k.id, k.mp, k.depth, thDepth);
     return k.id;
 }
 
@@ -433,7 +437,7 @@ static void create_stereo_points(Ctx& c, Seq& s, Frame& f, int kf, bool all) {
         if (!unproject_frame(c, f, i, x)) return;
         const int p = m.new_point(x, kf, m.kfs[kf].frameId);
         m.add_observation(p, kf, i);
-        m.kfs[kf].mp[i] = p;
+        m.set_kf_mp(kf, i, p);
         m.nMPsInMap++; s.st[3]++;
         f.mp[i] = p;
         s.updList.push_back(p);
@@ -745,7 +749,7 @@ static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t
             }
         } else {
             m.add_observation(p, k, best);
-            m.kfs[k].mp[best] = p;
+            m.set_kf_mp(k, best, p);
             if (touched) touched->push_back(p);
         }
         s.st[9]++;
@@ -805,7 +809,7 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
                     if ((pass == 1) != stereo) continue;
                     const int k = W.eref[e].first, p = W.eref[e].second;
                     const int idx = m.mps[p].obs_index(k);
-                    if (idx >= 0) m.kfs[k].mp[idx] = -1;
+                    if (idx >= 0) m.set_kf_mp(k, idx, -1);
                     m.erase_observation(p, k);
                 }
             for (int q = 0; q < W.nFree; q++) {   // (the local keyframes a degraded window held fixed keep their poses)
@@ -885,14 +889,70 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
         { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
     }
     // --- KeyFrameCulling (:633-697) ---
+    // Round 5: the counting loop of the candidates runs on the device from the table's mirror of the observation graph (oslam_slam_ops_t::map_journal /
+    // kf_culling_counts); the host takes the verdicts in the reference's order.  SetBadFlag changes the counts of the candidates behind a culled keyframe, so from
+    // the first cull of a pass on — and for a keyframe the mirror flags as ambiguous, and for a map whose octave histogram overflowed — the host counts itself.
+    std::vector<std::vector<int32_t>> cullOut;   // [w][4 per candidate] device counts (empty: host path)
+    std::vector<std::vector<int32_t>> cullIds;
+    static const bool cull_dev = !getenv("OSLAM_SLAM_CULL_HOST");
+    static const bool cull_check = getenv("OSLAM_SLAM_CULL_CHECK") != nullptr;   // debugging: every device verdict is compared with the host count
+    if ((flags & 16) && cull_dev && c.ops.map_journal && c.ops.kf_culling_counts) {
+        cullOut.resize(nW); cullIds.resize(nW);
+        std::vector<int32_t> js; std::vector<const uint32_t*> jw; std::vector<int32_t> jn;
+        std::vector<oslam_job_cull_t> jobs;
+        for (int w = 0; w < nW; w++) {
+            Seq& s = *c.seq[who[w]];
+            Map& m = s.map;
+            if (!m.jr.empty()) { js.push_back(who[w]); jw.push_back(m.jr.data()); jn.push_back((int32_t)m.jr.size()); }
+            if (m.lvlOverflow) continue;
+            for (int k : m.kfs[s.curKF].ordered) if (k != 0) cullIds[w].push_back(k);
+            if (cullIds[w].empty()) continue;
+            cullOut[w].assign(cullIds[w].size() * 4, 0);
+            oslam_job_cull_t j; j.slot = who[w]; j.n = (int32_t)cullIds[w].size(); j.kf_ids = cullIds[w].data(); j.out = cullOut[w].data();
+            jobs.push_back(j);
+        }
+        if (!js.empty() && (rc = c.ops.map_journal(c.ops.ctx, (int)js.size(), js.data(), jw.data(), jn.data()))) return rc;
+        for (int si : js) c.seq[si]->map.jr.clear();
+        if (!jobs.empty() && (rc = c.ops.kf_culling_counts(c.ops.ctx, (int)jobs.size(), jobs.data(), c.thDepth))) return rc;
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
+    }
     if (flags & 16)
         pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];
             Map& m = s.map;
             const std::vector<int> local = m.kfs[s.curKF].ordered;
             const bool useHist = !m.lvlOverflow;
+            const int32_t* dev = (!cullOut.empty() && !cullOut[w].empty()) ? cullOut[w].data() : nullptr;
+            bool culled_any = false;
+            int qi = 0;   // index of the candidate among the non-zero ids (cullIds order)
             for (int k : local) {
                 if (k == 0) continue;
+                const int q = qi++;
+                if (dev && !culled_any && dev[4 * q + 3] == 0) {
+                    const int ub = dev[4 * q], nMPs = dev[4 * q + 1], nRed = dev[4 * q + 2];
+                    const int keepAt = ub / 10 + 2;
+                    const bool cull = (nMPs - nRed < keepAt) && (nRed > 0.9 * nMPs);
+                    if (cull_check) {
+                        const KeyFrm& kfc = m.kfs[k];
+                        int ub2 = 0, r2 = 0, n2 = 0;
+                        for (int i = 0; i < kfc.N; i++) {
+                            const int p = kfc.mp[i];
+                            const bool good = !(kfc.depth[i] > c.thDepth || kfc.depth[i] < 0);
+                            ub2 += p >= 0 && good;
+                            if (p < 0 || m.pBad[p] || !good) continue;
+                            n2++;
+                            if (m.pNObs[p] > 3) {
+                                int nn = 0;
+                                const MapPt& mq = m.mps[p];
+                                for (size_t oi = 0; oi < mq.obs.size(); oi++) if (mq.obs[oi].first != k && mq.okp[oi].octave <= kfc.oct[i] + 1) nn++;
+                                r2 += nn >= 3;
+                            }
+                        }
+                        if (ub2 != ub || n2 != nMPs || r2 != nRed) { fprintf(stderr, "OSLAM_SLAM_CULL_CHECK: sequence %d keyframe %d: device (%d, %d, %d), host (%d, %d, %d)\n", who[w], k, ub, nMPs, nRed, ub2, n2, r2); abort(); }
+                    }
+                    if (cull) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); culled_any = true; }
+                    continue;
+                }
                 const KeyFrm& kf = m.kfs[k];
                 // The verdict is nRed > 0.9 * nMPs.  nMPs is at most the number of slots that hold a point at a usable depth (counted from the keyframe's own
                 // arrays, no map access), so once the points found NOT redundant reach a tenth of that bound (+ 2: away from the rounding of 0.9 * nMPs) the keyframe
@@ -922,7 +982,7 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
                         if (n >= 3) nRed++;
                     }
                 }
-                if (nMPs - nRed < keepAt && nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); }
+                if (nMPs - nRed < keepAt && nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); culled_any = true; }
             }
         });
     if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
@@ -1105,8 +1165,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                         const int p = m.new_point(&x3[jq][(size_t)e * 3], s.curKF, m.kfs[s.curKF].frameId);   // :408-430
                         m.add_observation(p, s.curKF, i1[jq][e]);
                         m.add_observation(p, k2, i2[jq][e]);
-                        m.kfs[s.curKF].mp[i1[jq][e]] = p;
-                        m.kfs[k2].mp[i2[jq][e]] = p;
+                        m.set_kf_mp(s.curKF, i1[jq][e], p);
+                        m.set_kf_mp(k2, i2[jq][e], p);
                         m.nMPsInMap++; s.st[3]++; s.st[10]++;
                         s.recentAdded.push_back(p);
                         s.updList.push_back(p);
@@ -1205,8 +1265,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                     const int p = m.new_point(&x3[q][(size_t)e * 3], s.curKF, m.kfs[s.curKF].frameId);   // :408-430
                     m.add_observation(p, s.curKF, i1[q][e]);
                     m.add_observation(p, k2, i2[q][e]);
-                    m.kfs[s.curKF].mp[i1[q][e]] = p;
-                    m.kfs[k2].mp[i2[q][e]] = p;
+                    m.set_kf_mp(s.curKF, i1[q][e], p);
+                    m.set_kf_mp(k2, i2[q][e], p);
                     m.nMPsInMap++; s.st[3]++; s.st[10]++;
                     s.recentAdded.push_back(p);
                     s.updList.push_back(p);
@@ -1839,7 +1899,7 @@ static void stage_after_tracking(Ctx& c, int i) {
             }
         }
         if (need) {   // CreateNewKeyFrame (:1328-1406)
-            const int kf = new_keyframe(s, f);
+            const int kf = new_keyframe(s, f, c.thDepth);
             s.refKF = kf; f.refKF = kf;
             create_stereo_points(c, s, f, kf, false);
             s.newKFs.push_back(kf);
@@ -1902,7 +1962,7 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
         if (s.state == ST_NOT_INITIALIZED && f.N > 500) {
             // StereoInitialization (:590-642)
             f.pose.set_frame(eye4());
-            const int kf = new_keyframe(s, f);
+            const int kf = new_keyframe(s, f, c.thDepth);
             // mpMap->AddKeyFrame (:601): counted when ProcessNewKeyFrame inserts it (same std::set entry in the reference)
             create_stereo_points(c, s, f, kf, true);
             s.newKFs.push_back(kf);
@@ -2193,6 +2253,8 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
         c.seq.back()->fa.alloc(c.cap);
         c.seq.back()->fb.alloc(c.cap);
         c.seq.back()->counter.assign(64, 0);
+        // the table keeps a device mirror of the observation graph: the maps journal their changes (slam_map.h)
+        c.seq.back()->map.jrOn = c.ops.map_journal && c.ops.kf_culling_counts && (cfg->local_mapping & 16) && !getenv("OSLAM_SLAM_CULL_HOST");
     }
     *out = h;
     return OSLAM_OK;

@@ -211,6 +211,36 @@ struct Map {
         s2 = (s2 & 0x0000FFFF0000FFFFull) + ((s2 >> 16) & 0x0000FFFF0000FFFFull);
         return (int)((s2 & 0xFFFFFFFFull) + (s2 >> 32));
     }
+    // ---- mutation journal for a DEVICE MIRROR of the observation graph (round 5; include/oslam_slam.h oslam_slam_ops_t::map_journal) ----
+    // When an operator table keeps device copies of the keyframes' point lists, of "which point observes keypoint (kf, idx)" and of the per-point scalars
+    // (Observations(), bad flag, octave histogram), every change of those is appended here in program order — variable-length records, first word = op | words << 8 —
+    // and handed to the table before a device-side consumer runs (KeyFrameCulling's redundancy counts).  Off (jrOn = false) the map behaves as before.
+    enum { JR_KFMP = 1, JR_KFMP_BULK = 2, JR_OKF_SET = 3, JR_OKF_CLR = 4, JR_PT = 5, JR_RESET = 6 };
+    bool jrOn = false;
+    std::vector<uint32_t> jr;
+    void jr_kfmp(int kf, int idx, int p) { if (jrOn) { jr.push_back(JR_KFMP | (4u << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)idx); jr.push_back((uint32_t)p); } }
+    void jr_okf(int op, int kf, int idx, int p) { if (jrOn) { jr.push_back((uint32_t)op | (4u << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)idx); jr.push_back((uint32_t)p); } }
+    void jr_pt(int p) {
+        if (!jrOn) return;
+        jr.push_back(JR_PT | (6u << 8)); jr.push_back((uint32_t)p); jr.push_back((uint32_t)pNObs[p]); jr.push_back((uint32_t)pBad[p]);
+        jr.push_back((uint32_t)(pLvl[p] & 0xFFFFFFFFull)); jr.push_back((uint32_t)(pLvl[p] >> 32));
+    }
+    // (a new keyframe: its point list and, one bit per keypoint, whether the keypoint's depth is usable for KeyFrameCulling — !(depth > thDepth || depth < 0),
+    // src/LocalMapping.cc:663-667; keypoints, depths and thDepth never change)
+    void jr_kfmp_bulk(int kf, const std::vector<int>& mp, const std::vector<float>& depth, float thDepth) {
+        if (!jrOn) return;
+        const size_t N = mp.size(), nw = (N + 31) / 32;
+        jr.push_back(JR_KFMP_BULK | ((uint32_t)(3 + N + nw) << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)N);
+        for (int v : mp) jr.push_back((uint32_t)v);
+        for (size_t wI = 0; wI < nw; wI++) {
+            uint32_t bits = 0;
+            for (size_t i = wI * 32; i < std::min(N, wI * 32 + 32); i++) bits |= (uint32_t)(!(depth[i] > thDepth || depth[i] < 0)) << (i & 31);
+            jr.push_back(bits);
+        }
+    }
+    // kfs[kf].mp[idx] = p, journalled (every write to a keyframe's point list outside this file goes through here)
+    void set_kf_mp(int kf, int idx, int p) { kfs[kf].mp[idx] = p; jr_kfmp(kf, idx, p); }
+
     int new_point(const float x[3], int refKF, int refFrame) {
         MapPt p;
         p.pos[0] = x[0]; p.pos[1] = x[1]; p.pos[2] = x[2];
@@ -233,6 +263,7 @@ struct Map {
         lvl_add(p, o.octave);
         pNObs[p] += o.ur >= 0 ? 2 : 1;
         m.obsVer++;
+        jr_okf(JR_OKF_SET, kf, idx, p); jr_pt(p);
     }
     void set_bad_point(int p) {                      // :253-270
         MapPt& m = mps[p];
@@ -242,7 +273,8 @@ struct Map {
         o.swap(m.obs);
         std::vector<ObsKp>().swap(m.okp);   // (a bad point never gets an observation again: its lists' memory goes back, 40 % of the points a sequence creates end here)
         pLvl[p] = 0;
-        for (auto& e : o) kfs[e.first].mp[e.second] = -1;
+        for (auto& e : o) { set_kf_mp(e.first, e.second, -1); jr_okf(JR_OKF_CLR, e.first, e.second, p); }
+        jr_pt(p);
     }
     void erase_observation(int p, int kf) {          // :209-239
         MapPt& m = mps[p];
@@ -250,12 +282,14 @@ struct Map {
         for (size_t i = 0; i < m.obs.size(); i++)
             if (m.obs[i].first == kf) {
                 pNObs[p] -= m.okp[i].ur >= 0 ? 2 : 1;
+                jr_okf(JR_OKF_CLR, kf, m.obs[i].second, p);
                 m.obs.erase(m.obs.begin() + i);
                 lvl_sub(p, m.okp[i].octave);
                 m.okp.erase(m.okp.begin() + i);
                 m.obsVer++;
                 if (m.refKF == kf && !m.obs.empty()) m.refKF = m.obs.front().first;
                 if (pNObs[p] <= 2) bad = true;
+                jr_pt(p);
                 break;
             }
         if (bad) set_bad_point(p);
@@ -273,13 +307,15 @@ struct Map {
         pReplaced[p] = by;
         const int nvisible = pVisible[p], nfound = pFound[p];
         for (auto& e : o) {
+            jr_okf(JR_OKF_CLR, e.first, e.second, p);
             if (mps[by].obs_index(e.first) < 0) {
-                kfs[e.first].mp[e.second] = by;
+                set_kf_mp(e.first, e.second, by);
                 add_observation(by, e.first, e.second);
             } else {
-                kfs[e.first].mp[e.second] = -1;
+                set_kf_mp(e.first, e.second, -1);
             }
         }
+        jr_pt(p);
         pFound[by] += nfound;
         pVisible[by] += nvisible;
         return true;

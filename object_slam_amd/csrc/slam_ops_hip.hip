@@ -94,9 +94,48 @@ struct HipOps {
     uint8_t** d_rec_desc = nullptr; size_t rec_desc_cap = 0; int rec_desc_n = 0;   // device table: descriptor array of every record (for k_gather_desc)
     std::vector<uint8_t*> h_rec_desc;
     // a record = mvKeysUn, descriptors, mvuRight and — built once at registration (oslam_kf_grid_build_device) — the feature grid: cell ends + candidates sorted by cell
-    size_t rec_bytes() const {
+    // (+ the mirror of the observation graph, round 5: the keyframe's point list, "which point observes keypoint i" and the usable-depth bits: oslam_slam_ops_t::map_journal)
+    size_t rec_core_bytes() const {
         return oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256) + oslam::align_up((size_t)cap * 32, 256) + oslam::align_up((size_t)cap * 4, 256) +
                oslam::align_up((size_t)3072 * 2, 256) + oslam::align_up((size_t)cap * 16, 256);
+    }
+    size_t rec_bytes() const { return rec_core_bytes() + 2 * oslam::align_up((size_t)cap * 4, 256) + oslam::align_up(((size_t)cap + 31) / 32 * 4, 256); }
+    int32_t* rec_mp(int r) const { return (int32_t*)(rec_ptr(r) + rec_core_bytes()); }
+    // per-point scalars of the mirror: 16-byte records (Observations(), isBad(), octave histogram) per slot, grown like the map-point table
+    std::vector<uint8_t*> pt_aux; std::vector<size_t> pt_aux_cap;
+    uint8_t** d_pt_aux = nullptr; uint8_t** d_rec_chunk = nullptr; size_t rec_chunk_cap = 0, rec_chunk_n = 0;
+    bool pt_aux_dirty = true;
+    int ensure_pt_aux(int slot, size_t need) {
+        if ((int)pt_aux.size() < S) { pt_aux.resize(S, nullptr); pt_aux_cap.resize(S, 0); }
+        if (need <= pt_aux_cap[slot]) return OSLAM_OK;
+        const size_t ncap = std::max<size_t>(need * 2, 16384);
+        uint8_t* nb = nullptr;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&nb, ncap * 16));
+        OSLAM_HIP_CHECK(hipMemsetAsync(nb, 0, ncap * 16, strm));
+        if (pt_aux[slot]) {
+            OSLAM_HIP_CHECK(hipMemcpyAsync(nb, pt_aux[slot], pt_aux_cap[slot] * 16, hipMemcpyDeviceToDevice, strm));
+            OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+            (void)hipFree(pt_aux[slot]);
+        }
+        pt_aux[slot] = nb; pt_aux_cap[slot] = ncap; pt_aux_dirty = true;
+        return OSLAM_OK;
+    }
+    int sync_mirror_tables() {   // device copies of the per-slot aux pointers and of the record chunk pointers
+        if ((int)pt_aux.size() < S) { pt_aux.resize(S, nullptr); pt_aux_cap.resize(S, 0); pt_aux_dirty = true; }
+        if (!d_pt_aux) { OSLAM_HIP_CHECK(hipMalloc((void**)&d_pt_aux, sizeof(uint8_t*) * S)); pt_aux_dirty = true; }
+        if (pt_aux_dirty) { OSLAM_HIP_CHECK(hipMemcpyAsync(d_pt_aux, pt_aux.data(), sizeof(uint8_t*) * S, hipMemcpyHostToDevice, strm)); OSLAM_HIP_CHECK(hipStreamSynchronize(strm)); pt_aux_dirty = false; }
+        if (rec_chunks.size() > rec_chunk_cap) {
+            OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+            if (d_rec_chunk) (void)hipFree(d_rec_chunk);
+            rec_chunk_cap = rec_chunks.size() * 2 + 64; rec_chunk_n = 0;
+            OSLAM_HIP_CHECK(hipMalloc((void**)&d_rec_chunk, sizeof(uint8_t*) * rec_chunk_cap));
+        }
+        if (rec_chunk_n < rec_chunks.size()) {
+            OSLAM_HIP_CHECK(hipMemcpyAsync(d_rec_chunk + rec_chunk_n, rec_chunks.data() + rec_chunk_n, sizeof(uint8_t*) * (rec_chunks.size() - rec_chunk_n), hipMemcpyHostToDevice, strm));
+            OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+            rec_chunk_n = rec_chunks.size();
+        }
+        return OSLAM_OK;
     }
     uint8_t* rec_ptr(int r) const { return rec_chunks[r / kRecChunk] + (size_t)(r % kRecChunk) * rec_bytes(); }
     const oslam_keypoint_t* rec_keys(int r) const { return (const oslam_keypoint_t*)rec_ptr(r); }
@@ -1370,6 +1409,178 @@ int h_release_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf_
     return OSLAM_OK;
 }
 
+// ---- device mirror of the observation graph (round 5, include/oslam_slam.h oslam_slam_ops_t::map_journal / kf_culling_counts) ----
+// Per keyframe record: mp[cap] (KeyFrame::mvpMapPoints), okf[cap] (the point that holds the observation (kf, i): MapPoint::mObservations seen from the keyframe's
+// side; the LAST AddObservation wins when two points claim one keypoint) and good[(cap + 31) / 32] (usable-depth bits).  Per slot: 16 bytes per point id
+// (Observations(), isBad(), octave histogram).  The host translates keyframe ids to record indices while it copies a journal into the upload block; one wavefront
+// per sequence applies its records in program order (lane 0; the bulk record of a new keyframe by all lanes).
+struct MirrorSeq { uint32_t first, nwords; int32_t slot, pad; };
+struct MirrorGeom { uint64_t rec_bytes, core_bytes, okf_off, good_off; int32_t cap, chunk; };
+__device__ __forceinline__ int32_t* mirror_mp(uint8_t* const* chunks, const MirrorGeom& g, int r) { return (int32_t*)(chunks[r / g.chunk] + (size_t)(r % g.chunk) * g.rec_bytes + g.core_bytes); }
+__global__ __launch_bounds__(64) void k_mirror_apply(const uint32_t* words, const MirrorSeq* seqs, uint8_t* const* chunks, uint8_t* const* pt_aux, MirrorGeom g) {
+    const MirrorSeq sq = seqs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint32_t* w = words + sq.first;
+    uint32_t at = 0;
+    while (at < sq.nwords) {
+        const uint32_t head = w[at], op = head & 0xFFu, len = head >> 8;
+        if (len == 0) break;   // (malformed: never produced)
+        if (op == 2) {         // KFMP_BULK r N p[N] good[ceil(N/32)]: a new keyframe — its lists start from scratch
+            const int r = (int)w[at + 1], N = (int)w[at + 2];
+            if (r >= 0) {
+                int32_t* mp = mirror_mp(chunks, g, r);
+                int32_t* okf = (int32_t*)((uint8_t*)mp + g.okf_off);
+                uint32_t* good = (uint32_t*)((uint8_t*)mp + g.good_off);
+                for (int i = lane; i < g.cap; i += 64) { mp[i] = i < N ? (int32_t)w[at + 3 + i] : -1; okf[i] = -1; }
+                for (int i = lane; i < (g.cap + 31) / 32; i += 64) good[i] = i < (N + 31) / 32 ? w[at + 3 + N + i] : 0u;
+            }
+        } else if (lane == 0) {
+            if (op == 1 || op == 3 || op == 4) {
+                const int r = (int)w[at + 1], idx = (int)w[at + 2], p = (int)w[at + 3];
+                if (r >= 0 && idx >= 0 && idx < g.cap) {
+                    int32_t* mp = mirror_mp(chunks, g, r);
+                    int32_t* okf = (int32_t*)((uint8_t*)mp + g.okf_off);
+                    if (op == 1) mp[idx] = p;
+                    else if (op == 3) okf[idx] = p;
+                    else if (okf[idx] == p) okf[idx] = -1;
+                }
+            } else if (op == 5) {
+                uint4* a = (uint4*)pt_aux[sq.slot] + w[at + 1];
+                *a = make_uint4(w[at + 2], w[at + 3], w[at + 4], w[at + 5]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (records are applied in program order: a later single-lane record may touch what the bulk record wrote)
+        __builtin_amdgcn_wave_barrier();
+        at += len;
+    }
+}
+
+// LocalMapping::KeyFrameCulling's counting loop (src/LocalMapping.cc:649-690) for one candidate keyframe per wavefront, from the mirror: out = (slots with a point
+// at a usable depth, nMPs, nRedundantObservations, ambiguous).  "At least three OTHER observations at octave <= level + 1" from the point's octave histogram: four or
+// more qualifying observations -> yes, two or fewer -> no; exactly three -> yes iff this keyframe's own observation is not one of them — it is when okf[i] == p
+// (its octave IS the level); otherwise the mirror cannot tell (a displaced claim) and the host recounts the keyframe.
+struct CullCand { int32_t rec, slot; };
+__global__ __launch_bounds__(64) void k_cull_counts(const CullCand* cands, uint8_t* const* chunks, uint8_t* const* pt_aux, MirrorGeom g, int32_t* out) {
+    const CullCand cd = cands[blockIdx.x];
+    const int lane = threadIdx.x;
+    int ub = 0, nMPs = 0, nRed = 0, amb = 0;
+    if (cd.rec >= 0) {
+        const uint8_t* rec = chunks[cd.rec / g.chunk] + (size_t)(cd.rec % g.chunk) * g.rec_bytes;
+        const oslam_keypoint_t* keys = (const oslam_keypoint_t*)rec;
+        const int32_t* mp = (const int32_t*)(rec + g.core_bytes);
+        const int32_t* okf = (const int32_t*)((const uint8_t*)mp + g.okf_off);
+        const uint32_t* good = (const uint32_t*)((const uint8_t*)mp + g.good_off);
+        const uint4* aux = (const uint4*)pt_aux[cd.slot];
+        for (int i = lane; i < g.cap; i += 64) {
+            const int p = mp[i];
+            if (p < 0) continue;
+            if (!((good[i >> 5] >> (i & 31)) & 1u)) continue;
+            ub++;
+            const uint4 a = aux[p];   // (nObs, bad, lvl lo, lvl hi)
+            if (a.y != 0u) continue;
+            nMPs++;
+            if ((int)a.x > 3) {
+                const int lvl = keys[i].octave + 1;
+                const unsigned long long hgram = ((unsigned long long)a.w << 32) | a.z;
+                const unsigned long long hh = lvl >= 7 ? hgram : (hgram & ((1ull << (8 * (lvl + 1))) - 1ull));
+                unsigned long long s2 = (hh & 0x00FF00FF00FF00FFull) + ((hh >> 8) & 0x00FF00FF00FF00FFull);
+                s2 = (s2 & 0x0000FFFF0000FFFFull) + ((s2 >> 16) & 0x0000FFFF0000FFFFull);
+                const int all_le = (int)((s2 & 0xFFFFFFFFull) + (s2 >> 32));
+                if (all_le >= 4) nRed++;
+                else if (all_le == 3 && okf[i] != p) amb++;
+            }
+        }
+    } else amb = 1;   // (the keyframe has no resident record: the host counts)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { ub += __shfl_xor(ub, d, 64); nMPs += __shfl_xor(nMPs, d, 64); nRed += __shfl_xor(nRed, d, 64); amb += __shfl_xor(amb, d, 64); }
+    if (lane == 0) { out[4 * blockIdx.x] = ub; out[4 * blockIdx.x + 1] = nMPs; out[4 * blockIdx.x + 2] = nRed; out[4 * blockIdx.x + 3] = amb; }
+}
+
+static MirrorGeom mirror_geom(const HipOps* o) {
+    MirrorGeom g;
+    g.rec_bytes = o->rec_bytes(); g.core_bytes = o->rec_core_bytes(); g.okf_off = oslam::align_up((size_t)o->cap * 4, 256); g.good_off = 2 * oslam::align_up((size_t)o->cap * 4, 256);
+    g.cap = o->cap; g.chunk = HipOps::kRecChunk;
+    return g;
+}
+
+int h_map_journal(void* p, int n, const int32_t* slots, const uint32_t* const* words, const int32_t* nwords) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n <= 0) return OSLAM_OK;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= o->S || nwords[i] < 0) { oslam::set_error("map_journal: bad slot / size"); return OSLAM_E_INVALID; } total += (size_t)nwords[i]; }
+    Layout L;
+    const size_t oSeq = L.take(sizeof(MirrorSeq) * (size_t)n), oW = L.take(4 * total);
+    OPS_CHECK(o->ensure_up(L.off));
+    MirrorSeq* sq = (MirrorSeq*)(o->up_h + oSeq);
+    uint32_t* W = (uint32_t*)(o->up_h + oW);
+    size_t at = 0;
+    if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
+    for (int i = 0; i < n; i++) {
+        const int slot = slots[i];
+        sq[i].first = (uint32_t)at; sq[i].nwords = (uint32_t)nwords[i]; sq[i].slot = slot; sq[i].pad = 0;
+        memcpy(W + at, words[i], 4 * (size_t)nwords[i]);
+        // keyframe id -> record index (a keyframe whose record was released — culled — or never registered: -1, its records are skipped); the largest point id
+        uint32_t* w = W + at;
+        long long maxp = -1;
+        for (uint32_t q = 0; q < (uint32_t)nwords[i];) {
+            const uint32_t op = w[q] & 0xFFu, len = w[q] >> 8;
+            if (len == 0 || q + len > (uint32_t)nwords[i]) { oslam::set_error("map_journal: malformed record"); return OSLAM_E_INVALID; }
+            if (op == 2) { const uint32_t N = w[q + 2]; for (uint32_t k = 0; k < N && q + 3 + k < q + len; k++) maxp = std::max<long long>(maxp, (long long)(int32_t)w[q + 3 + k]); }
+            if (op == 1) maxp = std::max<long long>(maxp, (long long)(int32_t)w[q + 3]);
+            if (op >= 1 && op <= 4) w[q + 1] = (uint32_t)o->rec_lookup(slot, (int)w[q + 1]);
+            else if (op == 5) maxp = std::max<long long>(maxp, (long long)w[q + 1]);
+            q += len;
+        }
+        if (maxp >= 0) OPS_CHECK(o->ensure_pt_aux(slot, (size_t)maxp + 1));
+        at += (size_t)nwords[i];
+    }
+    OPS_CHECK(o->sync_mirror_tables());
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, L.off, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
+    hipLaunchKernelGGL(k_mirror_apply, dim3(n), dim3(64), 0, o->strm, (const uint32_t*)(o->up_d + oW), (const MirrorSeq*)(o->up_d + oSeq), (uint8_t* const*)o->d_rec_chunk,
+                       (uint8_t* const*)o->d_pt_aux, mirror_geom(o));
+    o->t_end();
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // (the upload block is reused by the next operator)
+    o->t_collect(7, 1, 0);
+    return OSLAM_OK;
+}
+
+int h_kf_culling_counts(void* p, int n, const oslam_job_cull_t* jobs, float thDepth) {
+    HipOps* o = (HipOps*)p;
+    (void)thDepth;   // (the usable-depth bits came with the keyframes' bulk records)
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    size_t total = 0;
+    for (int i = 0; i < n; i++) { if (jobs[i].slot < 0 || jobs[i].slot >= o->S || jobs[i].n < 0 || !jobs[i].out) { oslam::set_error("kf_culling_counts: bad job"); return OSLAM_E_INVALID; } total += (size_t)jobs[i].n; }
+    if (total == 0) return OSLAM_OK;
+    Layout L;
+    const size_t oC = L.take(sizeof(CullCand) * total);
+    const size_t in_bytes = L.off;
+    const size_t oOut = L.take(16 * total);
+    OPS_CHECK(o->ensure_up(L.off));
+    OPS_CHECK(o->ensure_dn(16 * total));
+    CullCand* cc = (CullCand*)(o->up_h + oC);
+    size_t at = 0;
+    for (int i = 0; i < n; i++)
+        for (int q = 0; q < jobs[i].n; q++, at++) { cc[at].rec = o->rec_lookup(jobs[i].slot, jobs[i].kf_ids[q]); cc[at].slot = jobs[i].slot; }
+    if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
+    for (int i = 0; i < n; i++) if (!o->pt_aux[jobs[i].slot]) OPS_CHECK(o->ensure_pt_aux(jobs[i].slot, 1));
+    OPS_CHECK(o->sync_mirror_tables());
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, in_bytes, hipMemcpyHostToDevice, o->strm));
+    o->t_begin();
+    hipLaunchKernelGGL(k_cull_counts, dim3((unsigned)total), dim3(64), 0, o->strm, (const CullCand*)(o->up_d + oC), (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux,
+                       mirror_geom(o), (int32_t*)(o->up_d + oOut));
+    o->t_end();
+    OSLAM_HIP_CHECK(hipGetLastError());
+    OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, o->up_d + oOut, 16 * total, o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    o->t_collect(7, 1, 0);
+    at = 0;
+    for (int i = 0; i < n; i++) { memcpy(jobs[i].out, o->dn_h + 16 * at, 16 * (size_t)jobs[i].n); at += (size_t)jobs[i].n; }
+    return OSLAM_OK;
+}
+
 int h_resident_points(void* p) { return ((HipOps*)p)->mp_tab_on ? 1 : 0; }
 
 int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
@@ -1669,6 +1880,9 @@ void h_destroy(void* p) {
     if (o->d_rec_desc) (void)hipFree(o->d_rec_desc);
     for (uint8_t* q : o->mp_tab) if (q) (void)hipFree(q);
     (void)hipFree(o->d_mp_tab);
+    for (uint8_t* q : o->pt_aux) if (q) (void)hipFree(q);
+    if (o->d_pt_aux) (void)hipFree(o->d_pt_aux);
+    if (o->d_rec_chunk) (void)hipFree(o->d_rec_chunk);
     (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
@@ -1754,6 +1968,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
