@@ -300,8 +300,9 @@ typedef struct oslam_slam_ops {
      * observations into an oslam_job_mp_update_t as for any other update. */
     int (*mp_update_windows)(void* ctx, int n, oslam_job_mp_window_t* wins);
     /* optional pair, with register_keyframes (round 5): a DEVICE MIRROR of the observation graph and its first consumer.
-     * map_journal: the changes the driver made to the maps of `slots` since its last call, in program order — per sequence a run of variable-length records of
-     * 32-bit words, first word = op | (record length in words << 8):
+     * map_journal: what changed in the maps of `slots` since the driver's last call — per sequence a run of variable-length records of 32-bit words, first word =
+     * op | (record length in words << 8).  Records 1, 2 and 5 carry CURRENT values (order-free; a bulk record precedes every other record of its keyframe); records
+     * 3 / 4 are events in program order: for one (kf, idx) the LAST one decides (an erase clears the cell whoever held it):
      *   1 KFMP      kf idx p            KeyFrame::mvpMapPoints[idx] = p (-1: none)                      (src/KeyFrame.cc:201-230)
      *   2 KFMP_BULK kf N p[0..N) g[ceil(N/32)]   the point list of a NEW keyframe and, bit i of g, !(mvDepth[i] > mThDepth || mvDepth[i] < 0)   (src/KeyFrame.cc:30-58)
      *   3 OKF_SET   kf idx p            MapPoint p now has the observation (kf, idx)                    (MapPoint::AddObservation, src/MapPoint.cc:196-207)

@@ -181,8 +181,7 @@ struct Seq {
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
         const bool jr_on = map.jrOn;
         map = Map();
-        map.jrOn = jr_on;
-        if (jr_on) map.jr.push_back((uint32_t)Map::JR_RESET | (1u << 8));   // (device mirror of the observation graph: oslam_slam_ops_t::map_journal)
+        map.jrOn = jr_on; map.jrReset = jr_on;   // (device mirror of the observation graph: oslam_slam_ops_t::map_journal)
         state = ST_NOT_INITIALIZED; nextFrameId = 0; refKF = -1;
         localKFs.clear(); localMPs.clear(); rel.clear(); recentAdded.clear(); newKFs.clear(); kfBow.clear(); pendingKF.clear(); culledKFs.clear();
         obj3ds.clear(); objOfTrack.clear();   // Map::clear() drops the Object3Ds too; the counters in sem[] run on like N_AllSemanticConstraintNum
@@ -231,6 +230,7 @@ struct Ctx {
     struct PendingLM { bool active = false, submitted = false; std::vector<int> who; std::vector<Win*> wins; std::vector<oslam_lba_problem_t> probs; } pend;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
     int mapStep = 0;            // local-mapping passes of this handle (MapPt::updStep)
+    std::vector<std::vector<uint32_t>> jrWords;   // per sequence: the record stream handed to oslam_slam_ops_t::map_journal in this pass (kept for its capacity)
     int injectLbaFailure = -1;  // oslam_slam_inject_failure: sequence whose next local-BA window is made invalid (tests of the per-sequence failure isolation)
     bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
     std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
@@ -301,7 +301,8 @@ static int new_keyframe(Seq& s, const Frame& f, float thDepth) {
     s.counter.resize(s.map.kfs.size() + 8, 0);
     s.st[1]++;
     s.pendingKF.push_back(k.id);
-    s.map.jr_kfmp_bulk(k.id, k.mp, k.depth, thDepth);
+    (void)thDepth;
+    s.map.jr_new_kf(k.id);
     return k.id;
 }
 
@@ -900,10 +901,12 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
         cullOut.resize(nW); cullIds.resize(nW);
         std::vector<int32_t> js; std::vector<const uint32_t*> jw; std::vector<int32_t> jn;
         std::vector<oslam_job_cull_t> jobs;
+        if (c.jrWords.size() < (size_t)c.S) c.jrWords.resize(c.S);
+        pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; if (s.map.jr_pending()) s.map.journal_words(c.thDepth, c.jrWords[who[w]]); else c.jrWords[who[w]].clear(); });
         for (int w = 0; w < nW; w++) {
             Seq& s = *c.seq[who[w]];
             Map& m = s.map;
-            if (!m.jr.empty()) { js.push_back(who[w]); jw.push_back(m.jr.data()); jn.push_back((int32_t)m.jr.size()); }
+            if (!c.jrWords[who[w]].empty()) { js.push_back(who[w]); jw.push_back(c.jrWords[who[w]].data()); jn.push_back((int32_t)c.jrWords[who[w]].size()); }
             if (m.lvlOverflow) continue;
             for (int k : m.kfs[s.curKF].ordered) if (k != 0) cullIds[w].push_back(k);
             if (cullIds[w].empty()) continue;
@@ -912,7 +915,6 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
             jobs.push_back(j);
         }
         if (!js.empty() && (rc = c.ops.map_journal(c.ops.ctx, (int)js.size(), js.data(), jw.data(), jn.data()))) return rc;
-        for (int si : js) c.seq[si]->map.jr.clear();
         if (!jobs.empty() && (rc = c.ops.kf_culling_counts(c.ops.ctx, (int)jobs.size(), jobs.data(), c.thDepth))) return rc;
         { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
     }

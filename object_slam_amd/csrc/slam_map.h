@@ -211,34 +211,56 @@ struct Map {
         s2 = (s2 & 0x0000FFFF0000FFFFull) + ((s2 >> 16) & 0x0000FFFF0000FFFFull);
         return (int)((s2 & 0xFFFFFFFFull) + (s2 >> 32));
     }
-    // ---- mutation journal for a DEVICE MIRROR of the observation graph (round 5; include/oslam_slam.h oslam_slam_ops_t::map_journal) ----
-    // When an operator table keeps device copies of the keyframes' point lists, of "which point observes keypoint (kf, idx)" and of the per-point scalars
-    // (Observations(), bad flag, octave histogram), every change of those is appended here in program order — variable-length records, first word = op | words << 8 —
-    // and handed to the table before a device-side consumer runs (KeyFrameCulling's redundancy counts).  Off (jrOn = false) the map behaves as before.
+    // ---- change log for a DEVICE MIRROR of the observation graph (round 5; include/oslam_slam.h oslam_slam_ops_t::map_journal) ----
+    // When an operator table keeps device copies of the keyframes' point lists, of "which point holds the observation (kf, idx)" and of the per-point scalars
+    // (Observations(), bad flag, octave histogram), the map notes what changed — dirty cells of the point lists, the ordered AddObservation / EraseObservation
+    // events, dirty points, new keyframes — and journal_words() turns the notes into the table's record stream with the CURRENT values of everything that only
+    // needs its final state.  Off (jrOn = false) the map behaves as before.
     enum { JR_KFMP = 1, JR_KFMP_BULK = 2, JR_OKF_SET = 3, JR_OKF_CLR = 4, JR_PT = 5, JR_RESET = 6 };
-    bool jrOn = false;
-    std::vector<uint32_t> jr;
-    void jr_kfmp(int kf, int idx, int p) { if (jrOn) { jr.push_back(JR_KFMP | (4u << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)idx); jr.push_back((uint32_t)p); } }
-    void jr_okf(int op, int kf, int idx, int p) { if (jrOn) { jr.push_back((uint32_t)op | (4u << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)idx); jr.push_back((uint32_t)p); } }
+    bool jrOn = false, jrReset = false;
+    std::vector<std::pair<int, int>> jrCells;   // (kf, idx) whose mp entry changed
+    std::vector<uint32_t> jrOkf;                // (kf, idx | set << 31, p) triples in program order
+    std::vector<int> jrPts, jrNewKFs;           // dirty points (deduped through jrPtMark), keyframes created since the last flush
+    std::vector<uint8_t> jrPtMark;
+    bool jr_pending() const { return jrReset || !jrCells.empty() || !jrOkf.empty() || !jrPts.empty() || !jrNewKFs.empty(); }
+    void jr_kfmp(int kf, int idx, int) { if (jrOn) jrCells.push_back(std::make_pair(kf, idx)); }
+    void jr_okf(int op, int kf, int idx, int p) { if (jrOn) { jrOkf.push_back((uint32_t)kf); jrOkf.push_back((uint32_t)idx | (op == JR_OKF_SET ? 0x80000000u : 0u)); jrOkf.push_back((uint32_t)p); } }
     void jr_pt(int p) {
         if (!jrOn) return;
-        jr.push_back(JR_PT | (6u << 8)); jr.push_back((uint32_t)p); jr.push_back((uint32_t)pNObs[p]); jr.push_back((uint32_t)pBad[p]);
-        jr.push_back((uint32_t)(pLvl[p] & 0xFFFFFFFFull)); jr.push_back((uint32_t)(pLvl[p] >> 32));
+        if (jrPtMark.size() <= (size_t)p) jrPtMark.resize((size_t)p + 1 + jrPtMark.size() / 2, 0);
+        if (!jrPtMark[p]) { jrPtMark[p] = 1; jrPts.push_back(p); }
     }
-    // (a new keyframe: its point list and, one bit per keypoint, whether the keypoint's depth is usable for KeyFrameCulling — !(depth > thDepth || depth < 0),
-    // src/LocalMapping.cc:663-667; keypoints, depths and thDepth never change)
-    void jr_kfmp_bulk(int kf, const std::vector<int>& mp, const std::vector<float>& depth, float thDepth) {
-        if (!jrOn) return;
-        const size_t N = mp.size(), nw = (N + 31) / 32;
-        jr.push_back(JR_KFMP_BULK | ((uint32_t)(3 + N + nw) << 8)); jr.push_back((uint32_t)kf); jr.push_back((uint32_t)N);
-        for (int v : mp) jr.push_back((uint32_t)v);
-        for (size_t wI = 0; wI < nw; wI++) {
-            uint32_t bits = 0;
-            for (size_t i = wI * 32; i < std::min(N, wI * 32 + 32); i++) bits |= (uint32_t)(!(depth[i] > thDepth || depth[i] < 0)) << (i & 31);
-            jr.push_back(bits);
+    void jr_new_kf(int kf) { if (jrOn) jrNewKFs.push_back(kf); }
+    // The record stream of oslam_slam_ops_t::map_journal for everything noted since the last call (cleared here): RESET first, then the new keyframes' bulk records
+    // (their point lists as they are NOW and the usable-depth bits, src/LocalMapping.cc:663-667: !(depth > thDepth || depth < 0)), the dirty cells with their
+    // current values, the observation events in program order, the dirty points' current scalars.
+    void journal_words(float thDepth, std::vector<uint32_t>& out) {
+        out.clear();
+        if (jrReset) { out.push_back(JR_RESET | (1u << 8)); jrReset = false; }
+        for (int kf : jrNewKFs) {
+            const KeyFrm& k = kfs[kf];
+            const size_t N = k.mp.size(), nw = (N + 31) / 32;
+            out.push_back(JR_KFMP_BULK | ((uint32_t)(3 + N + nw) << 8)); out.push_back((uint32_t)kf); out.push_back((uint32_t)N);
+            for (int v : k.mp) out.push_back((uint32_t)v);
+            for (size_t wI = 0; wI < nw; wI++) {
+                uint32_t bits = 0;
+                for (size_t i = wI * 32; i < std::min(N, wI * 32 + 32); i++) bits |= (uint32_t)(!(k.depth[i] > thDepth || k.depth[i] < 0)) << (i & 31);
+                out.push_back(bits);
+            }
         }
+        for (auto& c : jrCells) { out.push_back(JR_KFMP | (4u << 8)); out.push_back((uint32_t)c.first); out.push_back((uint32_t)c.second); out.push_back((uint32_t)kfs[c.first].mp[c.second]); }
+        for (size_t i = 0; i + 2 < jrOkf.size(); i += 3) {
+            const bool set = (jrOkf[i + 1] & 0x80000000u) != 0;
+            out.push_back((uint32_t)(set ? JR_OKF_SET : JR_OKF_CLR) | (4u << 8)); out.push_back(jrOkf[i]); out.push_back(jrOkf[i + 1] & 0x7FFFFFFFu); out.push_back(jrOkf[i + 2]);
+        }
+        for (int p : jrPts) {
+            jrPtMark[p] = 0;
+            out.push_back(JR_PT | (6u << 8)); out.push_back((uint32_t)p); out.push_back((uint32_t)pNObs[p]); out.push_back((uint32_t)pBad[p]);
+            out.push_back((uint32_t)(pLvl[p] & 0xFFFFFFFFull)); out.push_back((uint32_t)(pLvl[p] >> 32));
+        }
+        jrNewKFs.clear(); jrCells.clear(); jrOkf.clear(); jrPts.clear();
     }
-    // kfs[kf].mp[idx] = p, journalled (every write to a keyframe's point list outside this file goes through here)
+    // kfs[kf].mp[idx] = p, noted (every write to a keyframe's point list outside this file goes through here)
     void set_kf_mp(int kf, int idx, int p) { kfs[kf].mp[idx] = p; jr_kfmp(kf, idx, p); }
 
     int new_point(const float x[3], int refKF, int refFrame) {

@@ -99,7 +99,21 @@ struct HipOps {
         return oslam::align_up((size_t)cap * sizeof(oslam_keypoint_t), 256) + oslam::align_up((size_t)cap * 32, 256) + oslam::align_up((size_t)cap * 4, 256) +
                oslam::align_up((size_t)3072 * 2, 256) + oslam::align_up((size_t)cap * 16, 256);
     }
-    size_t rec_bytes() const { return rec_core_bytes() + 2 * oslam::align_up((size_t)cap * 4, 256) + oslam::align_up(((size_t)cap + 31) / 32 * 4, 256); }
+    size_t rec_bytes() const { return rec_core_bytes() + oslam::align_up((size_t)cap * 4, 256) + oslam::align_up((size_t)cap * 8, 256) + oslam::align_up(((size_t)cap + 31) / 32 * 4, 256); }
+    std::vector<uint32_t> okf_seq;                        // [S] event counter of the mirror's okf cells (a cell keeps the event with the largest number)
+    uint8_t* mir_h = nullptr; uint8_t* mir_d = nullptr; size_t mir_cap = 0;   // the mirror's own upload block (map_journal returns without waiting: the consumer that follows on the stream does)
+    int ensure_mir(size_t bytes) {
+        if (bytes <= mir_cap) return OSLAM_OK;
+        OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
+        if (mir_h) (void)hipHostFree(mir_h);
+        if (mir_d) (void)hipFree(mir_d);
+        mir_h = nullptr; mir_d = nullptr; mir_cap = 0;
+        const size_t want = bytes + bytes / 2 + (1 << 20);
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&mir_h, want, 0));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&mir_d, want));
+        mir_cap = want;
+        return OSLAM_OK;
+    }
     int32_t* rec_mp(int r) const { return (int32_t*)(rec_ptr(r) + rec_core_bytes()); }
     // per-point scalars of the mirror: 16-byte records (Observations(), isBad(), octave histogram) per slot, grown like the map-point table
     std::vector<uint8_t*> pt_aux; std::vector<size_t> pt_aux_cap;
@@ -1414,44 +1428,38 @@ int h_release_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf_
 // side; the LAST AddObservation wins when two points claim one keypoint) and good[(cap + 31) / 32] (usable-depth bits).  Per slot: 16 bytes per point id
 // (Observations(), isBad(), octave histogram).  The host translates keyframe ids to record indices while it copies a journal into the upload block; one wavefront
 // per sequence applies its records in program order (lane 0; the bulk record of a new keyframe by all lanes).
-struct MirrorSeq { uint32_t first, nwords; int32_t slot, pad; };
 struct MirrorGeom { uint64_t rec_bytes, core_bytes, okf_off, good_off; int32_t cap, chunk; };
+struct MirrorBulk { int32_t r, N; uint32_t word_off, seq; };   // a new keyframe: p[N] then good[ceil(N/32)] at word_off of the bulk payload
 __device__ __forceinline__ int32_t* mirror_mp(uint8_t* const* chunks, const MirrorGeom& g, int r) { return (int32_t*)(chunks[r / g.chunk] + (size_t)(r % g.chunk) * g.rec_bytes + g.core_bytes); }
-__global__ __launch_bounds__(64) void k_mirror_apply(const uint32_t* words, const MirrorSeq* seqs, uint8_t* const* chunks, uint8_t* const* pt_aux, MirrorGeom g) {
-    const MirrorSeq sq = seqs[blockIdx.x];
-    const int lane = threadIdx.x;
-    const uint32_t* w = words + sq.first;
-    uint32_t at = 0;
-    while (at < sq.nwords) {
-        const uint32_t head = w[at], op = head & 0xFFu, len = head >> 8;
-        if (len == 0) break;   // (malformed: never produced)
-        if (op == 2) {         // KFMP_BULK r N p[N] good[ceil(N/32)]: a new keyframe — its lists start from scratch
-            const int r = (int)w[at + 1], N = (int)w[at + 2];
-            if (r >= 0) {
-                int32_t* mp = mirror_mp(chunks, g, r);
-                int32_t* okf = (int32_t*)((uint8_t*)mp + g.okf_off);
-                uint32_t* good = (uint32_t*)((uint8_t*)mp + g.good_off);
-                for (int i = lane; i < g.cap; i += 64) { mp[i] = i < N ? (int32_t)w[at + 3 + i] : -1; okf[i] = -1; }
-                for (int i = lane; i < (g.cap + 31) / 32; i += 64) good[i] = i < (N + 31) / 32 ? w[at + 3 + N + i] : 0u;
-            }
-        } else if (lane == 0) {
-            if (op == 1 || op == 3 || op == 4) {
-                const int r = (int)w[at + 1], idx = (int)w[at + 2], p = (int)w[at + 3];
-                if (r >= 0 && idx >= 0 && idx < g.cap) {
-                    int32_t* mp = mirror_mp(chunks, g, r);
-                    int32_t* okf = (int32_t*)((uint8_t*)mp + g.okf_off);
-                    if (op == 1) mp[idx] = p;
-                    else if (op == 3) okf[idx] = p;
-                    else if (okf[idx] == p) okf[idx] = -1;
-                }
-            } else if (op == 5) {
-                uint4* a = (uint4*)pt_aux[sq.slot] + w[at + 1];
-                *a = make_uint4(w[at + 2], w[at + 3], w[at + 4], w[at + 5]);
-            }
+// one workgroup per new keyframe: its point list, its usable-depth bits, and every okf cell back to "nobody" at the bulk's event number
+__global__ __launch_bounds__(256) void k_mirror_bulk(const MirrorBulk* bulks, const uint32_t* payload, uint8_t* const* chunks, MirrorGeom g) {
+    const MirrorBulk b = bulks[blockIdx.x];
+    if (b.r < 0) return;
+    int32_t* mp = mirror_mp(chunks, g, b.r);
+    unsigned long long* okf = (unsigned long long*)((uint8_t*)mp + g.okf_off);
+    uint32_t* good = (uint32_t*)((uint8_t*)mp + g.good_off);
+    const uint32_t* w = payload + b.word_off;
+    for (int i = threadIdx.x; i < g.cap; i += 256) { mp[i] = i < b.N ? (int32_t)w[i] : -1; okf[i] = ((unsigned long long)b.seq << 32) | 0xFFFFFFFFull; }
+    for (int i = threadIdx.x; i < (g.cap + 31) / 32; i += 256) good[i] = i < (b.N + 31) / 32 ? w[b.N + i] : 0u;
+}
+// one thread per record: dirty cells of the point lists (current values), observation events (the event with the largest number stays in a cell: 64-bit
+// max of number << 32 | point), dirty points (current scalars)
+__global__ __launch_bounds__(256) void k_mirror_ops(const int4* cells, int ncell, const uint4* okfs, int nokf, const uint4* pts, int npt, uint8_t* const* chunks, uint8_t* const* pt_aux,
+                                                    MirrorGeom g) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ncell) {
+        const int4 c = cells[i];
+        if (c.x >= 0 && c.y >= 0 && c.y < g.cap) mirror_mp(chunks, g, c.x)[c.y] = c.z;
+    } else if (i < ncell + nokf) {
+        const uint4 e = okfs[i - ncell];   // (record, idx, point, event number)
+        const int r = (int)e.x, idx = (int)e.y;
+        if (r >= 0 && idx >= 0 && idx < g.cap) {
+            unsigned long long* okf = (unsigned long long*)((uint8_t*)mirror_mp(chunks, g, r) + g.okf_off);
+            atomicMax(okf + idx, ((unsigned long long)e.w << 32) | (unsigned long long)e.z);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (records are applied in program order: a later single-lane record may touch what the bulk record wrote)
-        __builtin_amdgcn_wave_barrier();
-        at += len;
+    } else if (i < ncell + nokf + npt) {
+        const uint4 a = pts[2 * (i - ncell - nokf)], b = pts[2 * (i - ncell - nokf) + 1];   // (slot, p, nObs, bad), (lvl lo, lvl hi, -, -)
+        ((uint4*)pt_aux[a.x])[a.y] = make_uint4(a.z, a.w, b.x, b.y);
     }
 }
 
@@ -1468,7 +1476,7 @@ __global__ __launch_bounds__(64) void k_cull_counts(const CullCand* cands, uint8
         const uint8_t* rec = chunks[cd.rec / g.chunk] + (size_t)(cd.rec % g.chunk) * g.rec_bytes;
         const oslam_keypoint_t* keys = (const oslam_keypoint_t*)rec;
         const int32_t* mp = (const int32_t*)(rec + g.core_bytes);
-        const int32_t* okf = (const int32_t*)((const uint8_t*)mp + g.okf_off);
+        const unsigned long long* okf = (const unsigned long long*)((const uint8_t*)mp + g.okf_off);
         const uint32_t* good = (const uint32_t*)((const uint8_t*)mp + g.good_off);
         const uint4* aux = (const uint4*)pt_aux[cd.slot];
         for (int i = lane; i < g.cap; i += 64) {
@@ -1487,7 +1495,7 @@ __global__ __launch_bounds__(64) void k_cull_counts(const CullCand* cands, uint8
                 s2 = (s2 & 0x0000FFFF0000FFFFull) + ((s2 >> 16) & 0x0000FFFF0000FFFFull);
                 const int all_le = (int)((s2 & 0xFFFFFFFFull) + (s2 >> 32));
                 if (all_le >= 4) nRed++;
-                else if (all_le == 3 && okf[i] != p) amb++;
+                else if (all_le == 3 && (int)(uint32_t)(okf[i] & 0xFFFFFFFFull) != p) amb++;
             }
         }
     } else amb = 1;   // (the keyframe has no resident record: the host counts)
@@ -1498,7 +1506,7 @@ __global__ __launch_bounds__(64) void k_cull_counts(const CullCand* cands, uint8
 
 static MirrorGeom mirror_geom(const HipOps* o) {
     MirrorGeom g;
-    g.rec_bytes = o->rec_bytes(); g.core_bytes = o->rec_core_bytes(); g.okf_off = oslam::align_up((size_t)o->cap * 4, 256); g.good_off = 2 * oslam::align_up((size_t)o->cap * 4, 256);
+    g.rec_bytes = o->rec_bytes(); g.core_bytes = o->rec_core_bytes(); g.okf_off = oslam::align_up((size_t)o->cap * 4, 256); g.good_off = g.okf_off + oslam::align_up((size_t)o->cap * 8, 256);
     g.cap = o->cap; g.chunk = HipOps::kRecChunk;
     return g;
 }
@@ -1507,43 +1515,79 @@ int h_map_journal(void* p, int n, const int32_t* slots, const uint32_t* const* w
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
     if (n <= 0) return OSLAM_OK;
-    size_t total = 0;
-    for (int i = 0; i < n; i++) { if (slots[i] < 0 || slots[i] >= o->S || nwords[i] < 0) { oslam::set_error("map_journal: bad slot / size"); return OSLAM_E_INVALID; } total += (size_t)nwords[i]; }
-    Layout L;
-    const size_t oSeq = L.take(sizeof(MirrorSeq) * (size_t)n), oW = L.take(4 * total);
-    OPS_CHECK(o->ensure_up(L.off));
-    MirrorSeq* sq = (MirrorSeq*)(o->up_h + oSeq);
-    uint32_t* W = (uint32_t*)(o->up_h + oW);
-    size_t at = 0;
+    for (int i = 0; i < n; i++) if (slots[i] < 0 || slots[i] >= o->S || nwords[i] < 0) { oslam::set_error("map_journal: bad slot / size"); return OSLAM_E_INVALID; }
     if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
-    for (int i = 0; i < n; i++) {
-        const int slot = slots[i];
-        sq[i].first = (uint32_t)at; sq[i].nwords = (uint32_t)nwords[i]; sq[i].slot = slot; sq[i].pad = 0;
-        memcpy(W + at, words[i], 4 * (size_t)nwords[i]);
-        // keyframe id -> record index (a keyframe whose record was released — culled — or never registered: -1, its records are skipped); the largest point id
-        uint32_t* w = W + at;
-        long long maxp = -1;
+    if ((int)o->okf_seq.size() < o->S) o->okf_seq.resize(o->S, 0u);
+    // pass 1 (parallel over the sequences): record counts by class, the bulk payload size, the largest point id, malformed streams
+    struct Cnt { int nbulk = 0, ncell = 0, nokf = 0, npt = 0, bad = 0; size_t bulk_words = 0; long long maxp = -1; };
+    std::vector<Cnt> cn(n);
+    o->pool->parallel_for(n, [&](int i) {
+        const uint32_t* w = words[i];
+        Cnt c;
         for (uint32_t q = 0; q < (uint32_t)nwords[i];) {
             const uint32_t op = w[q] & 0xFFu, len = w[q] >> 8;
-            if (len == 0 || q + len > (uint32_t)nwords[i]) { oslam::set_error("map_journal: malformed record"); return OSLAM_E_INVALID; }
-            if (op == 2) { const uint32_t N = w[q + 2]; for (uint32_t k = 0; k < N && q + 3 + k < q + len; k++) maxp = std::max<long long>(maxp, (long long)(int32_t)w[q + 3 + k]); }
-            if (op == 1) maxp = std::max<long long>(maxp, (long long)(int32_t)w[q + 3]);
-            if (op >= 1 && op <= 4) w[q + 1] = (uint32_t)o->rec_lookup(slot, (int)w[q + 1]);
-            else if (op == 5) maxp = std::max<long long>(maxp, (long long)w[q + 1]);
+            if (len == 0 || q + len > (uint32_t)nwords[i]) { c.bad = 1; break; }
+            if (op == 1) { c.ncell++; c.maxp = std::max<long long>(c.maxp, (long long)(int32_t)w[q + 3]); }
+            else if (op == 2) {
+                const uint32_t N = w[q + 2];
+                if (3 + N + (N + 31) / 32 != len) { c.bad = 1; break; }
+                c.nbulk++; c.bulk_words += N + (N + 31) / 32;
+                for (uint32_t k = 0; k < N; k++) c.maxp = std::max<long long>(c.maxp, (long long)(int32_t)w[q + 3 + k]);
+            } else if (op == 3 || op == 4) c.nokf++;
+            else if (op == 5) { c.npt++; c.maxp = std::max<long long>(c.maxp, (long long)w[q + 1]); }
             q += len;
         }
-        if (maxp >= 0) OPS_CHECK(o->ensure_pt_aux(slot, (size_t)maxp + 1));
-        at += (size_t)nwords[i];
+        cn[i] = c;
+    });
+    size_t nbulk = 0, ncell = 0, nokf = 0, npt = 0, bw = 0;
+    std::vector<size_t> oB(n), oC(n), oO(n), oP(n), oW(n);
+    for (int i = 0; i < n; i++) {
+        if (cn[i].bad) { oslam::set_error("map_journal: malformed record"); return OSLAM_E_INVALID; }
+        oB[i] = nbulk; oC[i] = ncell; oO[i] = nokf; oP[i] = npt; oW[i] = bw;
+        nbulk += cn[i].nbulk; ncell += cn[i].ncell; nokf += cn[i].nokf; npt += cn[i].npt; bw += cn[i].bulk_words;
+        if (cn[i].maxp >= 0) OPS_CHECK(o->ensure_pt_aux(slots[i], (size_t)cn[i].maxp + 1));
     }
+    Layout L;
+    const size_t aB = L.take(sizeof(MirrorBulk) * nbulk), aW = L.take(4 * bw), aC = L.take(16 * ncell), aO = L.take(16 * nokf), aP = L.take(32 * npt);
+    OPS_CHECK(o->ensure_mir(L.off));
     OPS_CHECK(o->sync_mirror_tables());
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, L.off, hipMemcpyHostToDevice, o->strm));
-    o->t_begin();
-    hipLaunchKernelGGL(k_mirror_apply, dim3(n), dim3(64), 0, o->strm, (const uint32_t*)(o->up_d + oW), (const MirrorSeq*)(o->up_d + oSeq), (uint8_t* const*)o->d_rec_chunk,
-                       (uint8_t* const*)o->d_pt_aux, mirror_geom(o));
-    o->t_end();
+    // event numbers: the bulk records of a flush take the slot's counter, its observation events counter + 1 + position
+    std::vector<uint32_t> seq0(n);
+    for (int i = 0; i < n; i++) { seq0[i] = o->okf_seq[slots[i]]; o->okf_seq[slots[i]] += 1u + (uint32_t)cn[i].nokf; }
+    uint8_t* U = o->mir_h;
+    // pass 2 (parallel): the translated arrays (keyframe id -> record index; a keyframe whose record was released or never registered: -1, skipped on the device)
+    o->pool->parallel_for(n, [&](int i) {
+        const uint32_t* w = words[i];
+        const int slot = slots[i];
+        MirrorBulk* B = (MirrorBulk*)(U + aB) + oB[i];
+        uint32_t* PW = (uint32_t*)(U + aW);
+        int4* Cc = (int4*)(U + aC) + oC[i];
+        uint4* Oo = (uint4*)(U + aO) + oO[i];
+        uint4* Pp = (uint4*)(U + aP) + 2 * oP[i];
+        size_t wo = oW[i];
+        uint32_t ev = seq0[i] + 1u;
+        for (uint32_t q = 0; q < (uint32_t)nwords[i];) {
+            const uint32_t op = w[q] & 0xFFu, len = w[q] >> 8;
+            if (op == 1) { *Cc++ = make_int4(o->rec_lookup(slot, (int)w[q + 1]), (int)w[q + 2], (int)w[q + 3], 0); }
+            else if (op == 2) {
+                const uint32_t N = w[q + 2], pw = N + (N + 31) / 32;
+                B->r = o->rec_lookup(slot, (int)w[q + 1]); B->N = (int)N; B->word_off = (uint32_t)wo; B->seq = seq0[i]; B++;
+                memcpy(PW + wo, w + q + 3, 4 * (size_t)pw);
+                wo += pw;
+            } else if (op == 3 || op == 4) { *Oo++ = make_uint4((uint32_t)o->rec_lookup(slot, (int)w[q + 1]), w[q + 2], op == 3 ? w[q + 3] : 0xFFFFFFFFu, ev++); }
+            else if (op == 5) { Pp[0] = make_uint4((uint32_t)slot, w[q + 1], w[q + 2], w[q + 3]); Pp[1] = make_uint4(w[q + 4], w[q + 5], 0u, 0u); Pp += 2; }
+            q += len;
+        }
+    });
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->mir_d, o->mir_h, L.off, hipMemcpyHostToDevice, o->strm));
+    const MirrorGeom g = mirror_geom(o);
+    if (nbulk) hipLaunchKernelGGL(k_mirror_bulk, dim3((unsigned)nbulk), dim3(256), 0, o->strm, (const MirrorBulk*)(o->mir_d + aB), (const uint32_t*)(o->mir_d + aW), (uint8_t* const*)o->d_rec_chunk, g);
+    const size_t nops = ncell + nokf + npt;
+    if (nops) hipLaunchKernelGGL(k_mirror_ops, dim3((unsigned)((nops + 255) / 256)), dim3(256), 0, o->strm, (const int4*)(o->mir_d + aC), (int)ncell, (const uint4*)(o->mir_d + aO), (int)nokf,
+                                 (const uint4*)(o->mir_d + aP), (int)npt, (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux, g);
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // (the upload block is reused by the next operator)
-    o->t_collect(7, 1, 0);
+    // (no wait: the consumer that follows on this stream — kf_culling_counts — synchronises; the mirror's upload block is not touched before the next flush, and
+    // every operator of the step after this one waits for the stream before it returns)
     return OSLAM_OK;
 }
 
@@ -1883,6 +1927,8 @@ void h_destroy(void* p) {
     for (uint8_t* q : o->pt_aux) if (q) (void)hipFree(q);
     if (o->d_pt_aux) (void)hipFree(o->d_pt_aux);
     if (o->d_rec_chunk) (void)hipFree(o->d_rec_chunk);
+    if (o->mir_h) (void)hipHostFree(o->mir_h);
+    if (o->mir_d) (void)hipFree(o->mir_d);
     (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);

@@ -1,0 +1,13 @@
+set -e
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+for V in 0 1 0 1; do
+if [ $V = 1 ]; then export OSLAM_SLAM_CULL_HOST=1; else unset OSLAM_SLAM_CULL_HOST; fi
+python bench.py --no-extras --no-cpu-baseline > gpurun_out/r05_ab_cull$V.json 2> gpurun_out/r05_ab_cull.err || { tail -20 gpurun_out/r05_ab_cull.err; exit 1; }
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r05_ab_cull$V.json").read().strip().splitlines()[-1])
+co=d["stage_core_seconds_timed_sum_over_handles"]; st=d["stage_seconds_timed_sum_over_handles"]
+print("cull_host=$V", d["value"], "hm_kf_culling core-s", co["hm_kf_culling"], "wall", st["hm_kf_culling"], "host_mapping", co["host_mapping"], "keyframes", d["keyframes"], "local_bas", d["local_bas"])
+PY
+done
