@@ -228,6 +228,22 @@ typedef struct oslam_job_triangulate {     /* oslam_mp_triangulate for one (curr
                                   * 6 MapPoint updates (descriptor gather, ComputeDistinctiveDescriptors, UpdateNormalAndDepth, record writes), 7 other (keyframe
                                   * registration copies, vocabulary nodes, object keypoint tests / mask bitmaps, local-map gathers) */
 
+/* Changes of one sequence's map for the table's device mirror (oslam_slam_ops_t::map_journal).  Everything that only needs its final state carries CURRENT values;
+ * the observation events are in program order and for one (kf, idx) the LAST one decides (an erase clears the cell whoever held it).
+ *   reset        != 0: the sequence started a new map before these changes (Tracking::Reset): ids restart at 0
+ *   new_kfs      n_new keyframes created since the last call: id, keypoint count, KeyFrame::mvpMapPoints as it is now, and one bit per keypoint
+ *                !(mvDepth[i] > mThDepth || mvDepth[i] < 0) (src/LocalMapping.cc:663-667; keypoints, depths and mThDepth never change)
+ *   cells        n_cells x (kf, idx, p): KeyFrame::mvpMapPoints[idx] is now p (-1: none)                        (src/KeyFrame.cc:201-230)
+ *   events       n_events x (kf, idx | set << 31, p): MapPoint p gained (set) / lost the observation (kf, idx)  (src/MapPoint.cc:196-318)
+ *   points       n_points x (p, Observations(), isBad(), histogram lo, histogram hi): byte o of the 64-bit histogram = observations of p at octave o */
+typedef struct oslam_map_new_kf { int32_t kf, N; const int32_t* mp; const uint32_t* good; } oslam_map_new_kf_t;
+typedef struct oslam_map_changes {
+    int32_t slot, reset;
+    int32_t n_new; const oslam_map_new_kf_t* new_kfs;
+    int32_t n_cells; const int32_t* cells;
+    int32_t n_events; const uint32_t* events;
+    int32_t n_points; const uint32_t* points;
+} oslam_map_changes_t;
 /* KeyFrameCulling candidates of one sequence (oslam_slam_ops_t::kf_culling_counts): n keyframe ids in the reference's order, out [n][4]. */
 typedef struct oslam_job_cull { int32_t slot, n; const int32_t* kf_ids; int32_t* out; } oslam_job_cull_t;
 
@@ -300,23 +316,20 @@ typedef struct oslam_slam_ops {
      * observations into an oslam_job_mp_update_t as for any other update. */
     int (*mp_update_windows)(void* ctx, int n, oslam_job_mp_window_t* wins);
     /* optional pair, with register_keyframes (round 5): a DEVICE MIRROR of the observation graph and its first consumer.
-     * map_journal: what changed in the maps of `slots` since the driver's last call — per sequence a run of variable-length records of 32-bit words, first word =
-     * op | (record length in words << 8).  Records 1, 2 and 5 carry CURRENT values (order-free; a bulk record precedes every other record of its keyframe); records
-     * 3 / 4 are events in program order: for one (kf, idx) the LAST one decides (an erase clears the cell whoever held it):
-     *   1 KFMP      kf idx p            KeyFrame::mvpMapPoints[idx] = p (-1: none)                      (src/KeyFrame.cc:201-230)
-     *   2 KFMP_BULK kf N p[0..N) g[ceil(N/32)]   the point list of a NEW keyframe and, bit i of g, !(mvDepth[i] > mThDepth || mvDepth[i] < 0)   (src/KeyFrame.cc:30-58)
-     *   3 OKF_SET   kf idx p            MapPoint p now has the observation (kf, idx)                    (MapPoint::AddObservation, src/MapPoint.cc:196-207)
-     *   4 OKF_CLR   kf idx p            ... no longer has it                                           (EraseObservation / SetBadFlag / Replace, :209-318)
-     *   5 PT        p nObs bad lvl[2]   Observations(), isBad() and the octave histogram of p's observations (byte o of the 64-bit lvl = observations at octave o)
-     *   6 RESET                         the sequence starts a new map (Tracking::Reset): ids restart at 0
-     * The table applies them to device copies kept beside the resident keyframe / map-point records.
+     * map_journal: what changed in the maps of n sequences since the driver's last call for them (oslam_map_changes_t).  The table applies the changes to device
+     * copies kept beside the resident keyframe / map-point records: per keyframe KeyFrame::mvpMapPoints, "which point holds the observation (kf, idx)" and the
+     * usable-depth bits; per point Observations(), isBad() and the octave histogram of its observations.
      * kf_culling_counts: LocalMapping::KeyFrameCulling's counting loop (src/LocalMapping.cc:649-690) for the candidate keyframes of every job from those copies:
      * out[4 q] = slots of keyframe q with a point at a usable depth, [4 q + 1] = nMPs, [4 q + 2] = nRedundantObservations, [4 q + 3] != 0: a point with exactly
      * three observations at a fine enough scale whose own observation the mirror cannot vouch for — the driver recounts that keyframe from its lists.  The driver
      * takes the verdicts in the reference's order and recounts on the host from the first culled keyframe of a pass on (SetBadFlag changes the counts of the
      * candidates behind it).  NULL: the driver counts on the host. */
-    int (*map_journal)(void* ctx, int n, const int32_t* slots, const uint32_t* const* words, const int32_t* nwords);
+    int (*map_journal)(void* ctx, int n, const oslam_map_changes_t* changes);
     int (*kf_culling_counts)(void* ctx, int n, const oslam_job_cull_t* jobs, float thDepth);
+    /* optional, with kf_culling_counts: when set, kf_culling_counts may return before the counts are in the jobs' `out` arrays (which must stay valid); this call
+     * returns when they are.  The driver asks for the counts right after the local-BA write-back — the last step of a pass that changes observations — and
+     * collects them after the MapPoint updates, so the round trip to the device hides behind that stage. */
+    int (*kf_culling_collect)(void* ctx);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

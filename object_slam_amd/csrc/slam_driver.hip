@@ -230,7 +230,7 @@ struct Ctx {
     struct PendingLM { bool active = false, submitted = false; std::vector<int> who; std::vector<Win*> wins; std::vector<oslam_lba_problem_t> probs; } pend;
     std::unique_ptr<MpUpdate> updTrack, updMap;   // batched MapPoint updates of the two halves of a step (arrays keep their capacity)
     int mapStep = 0;            // local-mapping passes of this handle (MapPt::updStep)
-    std::vector<std::vector<uint32_t>> jrWords;   // per sequence: the record stream handed to oslam_slam_ops_t::map_journal in this pass (kept for its capacity)
+    std::vector<Map::JrScratch> jrScratch;   // per sequence: the arrays of the change set handed to oslam_slam_ops_t::map_journal in this pass (kept for their capacity)
     int injectLbaFailure = -1;  // oslam_slam_inject_failure: sequence whose next local-BA window is made invalid (tests of the per-sequence failure isolation)
     bool residentPts = false;   // the operator table serves pose jobs from map-point ids (oslam_slam_ops_t::resident_points)
     std::atomic<long long> badKFObs{0};   // observations in culled keyframes left out by ComputeDistinctiveDescriptors (oslam_slam_bad_keyframe_observations)
@@ -797,6 +797,43 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
     const int nW = (int)who.size();
     auto merge_upd = [&]() { upd.clear(); for (int si : who) { Seq& s = *c.seq[si]; for (int p : s.updList) upd.add(si, p); s.updList.clear(); } };
     const bool useWin = c.ops.mp_update_windows != nullptr;
+    std::vector<std::vector<int32_t>> cullOut;   // [w][4 per candidate] device counts (empty: host path)
+    std::vector<std::vector<int32_t>> cullIds;
+    std::vector<oslam_job_cull_t> cullJobs;
+    static const bool cull_dev = !getenv("OSLAM_SLAM_CULL_HOST");
+    static const bool cull_check = getenv("OSLAM_SLAM_CULL_CHECK") != nullptr;   // debugging: every device verdict is compared with the host count
+    struct CullStats { std::atomic<long long> dev{0}, amb{0}, after{0}; ~CullStats() { fprintf(stderr, "[cull stats] candidates decided from device counts %lld, ambiguous (host recount) %lld, after a cull of the pass (host) %lld\n", dev.load(), amb.load(), after.load()); } };
+    static CullStats* cull_stats = getenv("OSLAM_SLAM_CULL_STATS") ? new CullStats : nullptr;
+    static struct CullStatsAtExit { ~CullStatsAtExit() { delete cull_stats; } } cull_stats_at_exit;
+    bool cull_requested = false, cull_collected = false;
+    auto request_cull = [&]() -> int {
+        cull_requested = true;
+        if (!((flags & 16) && cull_dev && c.ops.map_journal && c.ops.kf_culling_counts)) { cull_collected = true; return OSLAM_OK; }
+        cullOut.resize(nW); cullIds.resize(nW);
+        std::vector<oslam_map_changes_t> chg(nW), chs;
+        std::vector<uint8_t> has(nW, 0);
+        std::vector<oslam_job_cull_t> jobs;
+        if (c.jrScratch.size() < (size_t)c.S) c.jrScratch.resize(c.S);
+        pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; if (s.map.jr_pending()) { s.map.journal_changes(who[w], c.thDepth, c.jrScratch[who[w]], chg[w]); has[w] = 1; } });
+        for (int w = 0; w < nW; w++) {
+            Seq& s = *c.seq[who[w]];
+            Map& m = s.map;
+            if (has[w]) chs.push_back(chg[w]);
+            if (m.lvlOverflow) continue;
+            for (int k : m.kfs[s.curKF].ordered) if (k != 0) cullIds[w].push_back(k);
+            if (cullIds[w].empty()) continue;
+            cullOut[w].assign(cullIds[w].size() * 4, 0);
+            oslam_job_cull_t j; j.slot = who[w]; j.n = (int32_t)cullIds[w].size(); j.kf_ids = cullIds[w].data(); j.out = cullOut[w].data();
+            jobs.push_back(j);
+        }
+        int rc2;
+        if (!chs.empty() && (rc2 = c.ops.map_journal(c.ops.ctx, (int)chs.size(), chs.data()))) return rc2;
+        cullJobs.swap(jobs);   // (the jobs name arrays of cullIds / cullOut: all stay alive until the collection)
+        if (!cullJobs.empty() && (rc2 = c.ops.kf_culling_counts(c.ops.ctx, (int)cullJobs.size(), cullJobs.data(), c.thDepth))) return rc2;
+        if (!c.ops.kf_culling_collect) cull_collected = true;
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
+        return OSLAM_OK;
+    };
     if (flags & 8) {
         pool.parallel_for((int)wins.size(), [&](int wi) {
             Win& W = *wins[wi];
@@ -858,6 +895,9 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
             }
             for (size_t q = 0; q < nK; q++) slot[W.kfs[q]] = 0;
         });
+        // the observation lists are final for this pass (the MapPoint updates below do not touch them): the culling counts are requested now and collected after them
+        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
+        if ((rc = request_cull())) return rc;
         if (useWin && !wins.empty()) {
             { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[12] += d_; c.cpu[7] += tm.cpu; c.cpu[12] += tm.cpu; }
             std::vector<oslam_job_mp_window_t> wj(wins.size());
@@ -893,31 +933,8 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
     // Round 5: the counting loop of the candidates runs on the device from the table's mirror of the observation graph (oslam_slam_ops_t::map_journal /
     // kf_culling_counts); the host takes the verdicts in the reference's order.  SetBadFlag changes the counts of the candidates behind a culled keyframe, so from
     // the first cull of a pass on — and for a keyframe the mirror flags as ambiguous, and for a map whose octave histogram overflowed — the host counts itself.
-    std::vector<std::vector<int32_t>> cullOut;   // [w][4 per candidate] device counts (empty: host path)
-    std::vector<std::vector<int32_t>> cullIds;
-    static const bool cull_dev = !getenv("OSLAM_SLAM_CULL_HOST");
-    static const bool cull_check = getenv("OSLAM_SLAM_CULL_CHECK") != nullptr;   // debugging: every device verdict is compared with the host count
-    if ((flags & 16) && cull_dev && c.ops.map_journal && c.ops.kf_culling_counts) {
-        cullOut.resize(nW); cullIds.resize(nW);
-        std::vector<int32_t> js; std::vector<const uint32_t*> jw; std::vector<int32_t> jn;
-        std::vector<oslam_job_cull_t> jobs;
-        if (c.jrWords.size() < (size_t)c.S) c.jrWords.resize(c.S);
-        pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; if (s.map.jr_pending()) s.map.journal_words(c.thDepth, c.jrWords[who[w]]); else c.jrWords[who[w]].clear(); });
-        for (int w = 0; w < nW; w++) {
-            Seq& s = *c.seq[who[w]];
-            Map& m = s.map;
-            if (!c.jrWords[who[w]].empty()) { js.push_back(who[w]); jw.push_back(c.jrWords[who[w]].data()); jn.push_back((int32_t)c.jrWords[who[w]].size()); }
-            if (m.lvlOverflow) continue;
-            for (int k : m.kfs[s.curKF].ordered) if (k != 0) cullIds[w].push_back(k);
-            if (cullIds[w].empty()) continue;
-            cullOut[w].assign(cullIds[w].size() * 4, 0);
-            oslam_job_cull_t j; j.slot = who[w]; j.n = (int32_t)cullIds[w].size(); j.kf_ids = cullIds[w].data(); j.out = cullOut[w].data();
-            jobs.push_back(j);
-        }
-        if (!js.empty() && (rc = c.ops.map_journal(c.ops.ctx, (int)js.size(), js.data(), jw.data(), jn.data()))) return rc;
-        if (!jobs.empty() && (rc = c.ops.kf_culling_counts(c.ops.ctx, (int)jobs.size(), jobs.data(), c.thDepth))) return rc;
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[13] += d_; c.cpu[7] += tm.cpu; c.cpu[13] += tm.cpu; }
-    }
+    if (!cull_requested && (rc = request_cull())) return rc;   // (a pass without local BA)
+    if (!cull_collected) { if ((rc = c.ops.kf_culling_collect(c.ops.ctx))) return rc; cull_collected = true; }
     if (flags & 16)
         pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];
@@ -926,10 +943,12 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
             const bool useHist = !m.lvlOverflow;
             const int32_t* dev = (!cullOut.empty() && !cullOut[w].empty()) ? cullOut[w].data() : nullptr;
             bool culled_any = false;
+            long long n_dev = 0, n_amb = 0, n_after = 0;
             int qi = 0;   // index of the candidate among the non-zero ids (cullIds order)
             for (int k : local) {
                 if (k == 0) continue;
                 const int q = qi++;
+                if (dev) { if (culled_any) n_after++; else if (dev[4 * q + 3] != 0) n_amb++; else n_dev++; }
                 if (dev && !culled_any && dev[4 * q + 3] == 0) {
                     const int ub = dev[4 * q], nMPs = dev[4 * q + 1], nRed = dev[4 * q + 2];
                     const int keepAt = ub / 10 + 2;
@@ -986,6 +1005,7 @@ static int local_mapping_back_ok(Ctx& c, const std::vector<int>& who, const std:
                 }
                 if (nMPs - nRed < keepAt && nRed > 0.9 * nMPs) { m.set_bad_keyframe(k); s.st[11]++; s.culledKFs.push_back(k); culled_any = true; }
             }
+            if (cull_stats) { cull_stats->dev += n_dev; cull_stats->amb += n_amb; cull_stats->after += n_after; }
         });
     if (c.ops.release_keyframes) {   // the table may recycle the resident records of the keyframes culled above
         std::vector<int32_t> rs, rk;

@@ -231,33 +231,44 @@ struct Map {
         if (!jrPtMark[p]) { jrPtMark[p] = 1; jrPts.push_back(p); }
     }
     void jr_new_kf(int kf) { if (jrOn) jrNewKFs.push_back(kf); }
-    // The record stream of oslam_slam_ops_t::map_journal for everything noted since the last call (cleared here): RESET first, then the new keyframes' bulk records
-    // (their point lists as they are NOW and the usable-depth bits, src/LocalMapping.cc:663-667: !(depth > thDepth || depth < 0)), the dirty cells with their
-    // current values, the observation events in program order, the dirty points' current scalars.
-    void journal_words(float thDepth, std::vector<uint32_t>& out) {
-        out.clear();
-        if (jrReset) { out.push_back(JR_RESET | (1u << 8)); jrReset = false; }
+    // The change set of oslam_slam_ops_t::map_journal for everything noted since the last call (the notes are cleared; the arrays the change set points into
+    // live in `sc` and in the map's keyframes until the next call).
+    struct JrScratch { std::vector<oslam_map_new_kf_t> kfs; std::vector<uint32_t> good, pts; std::vector<int32_t> cells; std::vector<uint32_t> events; };
+    void journal_changes(int slot, float thDepth, JrScratch& sc, oslam_map_changes_t& ch) {
+        ch.slot = slot; ch.reset = jrReset ? 1 : 0; jrReset = false;
+        sc.kfs.clear(); sc.good.clear();
+        size_t gw = 0;
+        for (int kf : jrNewKFs) gw += (kfs[kf].mp.size() + 31) / 32;
+        sc.good.resize(gw);
+        gw = 0;
         for (int kf : jrNewKFs) {
             const KeyFrm& k = kfs[kf];
             const size_t N = k.mp.size(), nw = (N + 31) / 32;
-            out.push_back(JR_KFMP_BULK | ((uint32_t)(3 + N + nw) << 8)); out.push_back((uint32_t)kf); out.push_back((uint32_t)N);
-            for (int v : k.mp) out.push_back((uint32_t)v);
             for (size_t wI = 0; wI < nw; wI++) {
                 uint32_t bits = 0;
                 for (size_t i = wI * 32; i < std::min(N, wI * 32 + 32); i++) bits |= (uint32_t)(!(k.depth[i] > thDepth || k.depth[i] < 0)) << (i & 31);
-                out.push_back(bits);
+                sc.good[gw + wI] = bits;
             }
+            oslam_map_new_kf_t e; e.kf = kf; e.N = (int32_t)N; e.mp = k.mp.data(); e.good = nullptr;
+            sc.kfs.push_back(e);
+            gw += nw;
         }
-        for (auto& c : jrCells) { out.push_back(JR_KFMP | (4u << 8)); out.push_back((uint32_t)c.first); out.push_back((uint32_t)c.second); out.push_back((uint32_t)kfs[c.first].mp[c.second]); }
-        for (size_t i = 0; i + 2 < jrOkf.size(); i += 3) {
-            const bool set = (jrOkf[i + 1] & 0x80000000u) != 0;
-            out.push_back((uint32_t)(set ? JR_OKF_SET : JR_OKF_CLR) | (4u << 8)); out.push_back(jrOkf[i]); out.push_back(jrOkf[i + 1] & 0x7FFFFFFFu); out.push_back(jrOkf[i + 2]);
-        }
-        for (int p : jrPts) {
+        gw = 0;
+        for (auto& e : sc.kfs) { e.good = sc.good.data() + gw; gw += ((size_t)e.N + 31) / 32; }
+        sc.cells.resize(jrCells.size() * 3);
+        for (size_t i = 0; i < jrCells.size(); i++) { sc.cells[3 * i] = jrCells[i].first; sc.cells[3 * i + 1] = jrCells[i].second; sc.cells[3 * i + 2] = kfs[jrCells[i].first].mp[jrCells[i].second]; }
+        sc.events.swap(jrOkf);
+        sc.pts.resize(jrPts.size() * 5);
+        for (size_t i = 0; i < jrPts.size(); i++) {
+            const int p = jrPts[i];
             jrPtMark[p] = 0;
-            out.push_back(JR_PT | (6u << 8)); out.push_back((uint32_t)p); out.push_back((uint32_t)pNObs[p]); out.push_back((uint32_t)pBad[p]);
-            out.push_back((uint32_t)(pLvl[p] & 0xFFFFFFFFull)); out.push_back((uint32_t)(pLvl[p] >> 32));
+            sc.pts[5 * i] = (uint32_t)p; sc.pts[5 * i + 1] = (uint32_t)pNObs[p]; sc.pts[5 * i + 2] = (uint32_t)pBad[p];
+            sc.pts[5 * i + 3] = (uint32_t)(pLvl[p] & 0xFFFFFFFFull); sc.pts[5 * i + 4] = (uint32_t)(pLvl[p] >> 32);
         }
+        ch.n_new = (int32_t)sc.kfs.size(); ch.new_kfs = sc.kfs.data();
+        ch.n_cells = (int32_t)jrCells.size(); ch.cells = sc.cells.data();
+        ch.n_events = (int32_t)(sc.events.size() / 3); ch.events = sc.events.data();
+        ch.n_points = (int32_t)jrPts.size(); ch.points = sc.pts.data();
         jrNewKFs.clear(); jrCells.clear(); jrOkf.clear(); jrPts.clear();
     }
     // kfs[kf].mp[idx] = p, noted (every write to a keyframe's point list outside this file goes through here)

@@ -101,6 +101,10 @@ struct HipOps {
     }
     size_t rec_bytes() const { return rec_core_bytes() + oslam::align_up((size_t)cap * 4, 256) + oslam::align_up((size_t)cap * 8, 256) + oslam::align_up(((size_t)cap + 31) / 32 * 4, 256); }
     std::vector<uint32_t> okf_seq;                        // [S] event counter of the mirror's okf cells (a cell keeps the event with the largest number)
+    size_t mir_used = 0;                                  // bytes of the mirror's upload block in use by the flush / count request in flight
+    uint8_t* cull_h = nullptr; size_t cull_cap = 0;       // pinned result block of kf_culling_counts
+    struct CullPending { int32_t* out; int n; };
+    std::vector<CullPending> cull_pending;
     uint8_t* mir_h = nullptr; uint8_t* mir_d = nullptr; size_t mir_cap = 0;   // the mirror's own upload block (map_journal returns without waiting: the consumer that follows on the stream does)
     int ensure_mir(size_t bytes) {
         if (bytes <= mir_cap) return OSLAM_OK;
@@ -1511,75 +1515,71 @@ static MirrorGeom mirror_geom(const HipOps* o) {
     return g;
 }
 
-int h_map_journal(void* p, int n, const int32_t* slots, const uint32_t* const* words, const int32_t* nwords) {
+int h_map_journal(void* p, int n, const oslam_map_changes_t* ch) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
     if (n <= 0) return OSLAM_OK;
-    for (int i = 0; i < n; i++) if (slots[i] < 0 || slots[i] >= o->S || nwords[i] < 0) { oslam::set_error("map_journal: bad slot / size"); return OSLAM_E_INVALID; }
     if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
     if ((int)o->okf_seq.size() < o->S) o->okf_seq.resize(o->S, 0u);
-    // pass 1 (parallel over the sequences): record counts by class, the bulk payload size, the largest point id, malformed streams
-    struct Cnt { int nbulk = 0, ncell = 0, nokf = 0, npt = 0, bad = 0; size_t bulk_words = 0; long long maxp = -1; };
-    std::vector<Cnt> cn(n);
-    o->pool->parallel_for(n, [&](int i) {
-        const uint32_t* w = words[i];
-        Cnt c;
-        for (uint32_t q = 0; q < (uint32_t)nwords[i];) {
-            const uint32_t op = w[q] & 0xFFu, len = w[q] >> 8;
-            if (len == 0 || q + len > (uint32_t)nwords[i]) { c.bad = 1; break; }
-            if (op == 1) { c.ncell++; c.maxp = std::max<long long>(c.maxp, (long long)(int32_t)w[q + 3]); }
-            else if (op == 2) {
-                const uint32_t N = w[q + 2];
-                if (3 + N + (N + 31) / 32 != len) { c.bad = 1; break; }
-                c.nbulk++; c.bulk_words += N + (N + 31) / 32;
-                for (uint32_t k = 0; k < N; k++) c.maxp = std::max<long long>(c.maxp, (long long)(int32_t)w[q + 3 + k]);
-            } else if (op == 3 || op == 4) c.nokf++;
-            else if (op == 5) { c.npt++; c.maxp = std::max<long long>(c.maxp, (long long)w[q + 1]); }
-            q += len;
-        }
-        cn[i] = c;
-    });
+    if (o->mir_used) { OSLAM_HIP_CHECK(oslam::stream_wait(o->strm)); o->mir_used = 0; }   // (a flush without a collected count request before it: its block must have landed)
     size_t nbulk = 0, ncell = 0, nokf = 0, npt = 0, bw = 0;
     std::vector<size_t> oB(n), oC(n), oO(n), oP(n), oW(n);
+    std::vector<long long> maxp(n, -1);
     for (int i = 0; i < n; i++) {
-        if (cn[i].bad) { oslam::set_error("map_journal: malformed record"); return OSLAM_E_INVALID; }
+        const oslam_map_changes_t& c = ch[i];
+        if (c.slot < 0 || c.slot >= o->S || c.n_new < 0 || c.n_cells < 0 || c.n_events < 0 || c.n_points < 0) { oslam::set_error("map_journal: bad change set"); return OSLAM_E_INVALID; }
         oB[i] = nbulk; oC[i] = ncell; oO[i] = nokf; oP[i] = npt; oW[i] = bw;
-        nbulk += cn[i].nbulk; ncell += cn[i].ncell; nokf += cn[i].nokf; npt += cn[i].npt; bw += cn[i].bulk_words;
-        if (cn[i].maxp >= 0) OPS_CHECK(o->ensure_pt_aux(slots[i], (size_t)cn[i].maxp + 1));
+        nbulk += c.n_new; ncell += c.n_cells; nokf += c.n_events; npt += c.n_points;
+        for (int k = 0; k < c.n_new; k++) { if (c.new_kfs[k].N < 0 || c.new_kfs[k].N > o->cap) { oslam::set_error("map_journal: keyframe with more keypoints than the capacity"); return OSLAM_E_CAPACITY; } bw += (size_t)c.new_kfs[k].N + ((size_t)c.new_kfs[k].N + 31) / 32; }
     }
+    // the largest point id named anywhere: the per-point records of a slot cover it before anything on the device indexes them
+    o->pool->parallel_for(n, [&](int i) {
+        const oslam_map_changes_t& c = ch[i];
+        long long m = -1;
+        for (int k = 0; k < c.n_new; k++) for (int q = 0; q < c.new_kfs[k].N; q++) m = std::max<long long>(m, c.new_kfs[k].mp[q]);
+        for (int q = 0; q < c.n_cells; q++) m = std::max<long long>(m, c.cells[3 * q + 2]);
+        for (int q = 0; q < c.n_points; q++) m = std::max<long long>(m, (long long)c.points[5 * q]);
+        maxp[i] = m;
+    });
+    for (int i = 0; i < n; i++) if (maxp[i] >= 0) OPS_CHECK(o->ensure_pt_aux(ch[i].slot, (size_t)maxp[i] + 1));
     Layout L;
     const size_t aB = L.take(sizeof(MirrorBulk) * nbulk), aW = L.take(4 * bw), aC = L.take(16 * ncell), aO = L.take(16 * nokf), aP = L.take(32 * npt);
-    OPS_CHECK(o->ensure_mir(L.off));
+    OPS_CHECK(o->ensure_mir(L.off + (1 << 20)));   // (+ room for the count request that usually follows)
     OPS_CHECK(o->sync_mirror_tables());
-    // event numbers: the bulk records of a flush take the slot's counter, its observation events counter + 1 + position
+    // event numbers: the new keyframes of a flush take the slot's counter, its observation events counter + 1 + position
     std::vector<uint32_t> seq0(n);
-    for (int i = 0; i < n; i++) { seq0[i] = o->okf_seq[slots[i]]; o->okf_seq[slots[i]] += 1u + (uint32_t)cn[i].nokf; }
+    for (int i = 0; i < n; i++) { seq0[i] = o->okf_seq[ch[i].slot]; o->okf_seq[ch[i].slot] += 1u + (uint32_t)ch[i].n_events; }
     uint8_t* U = o->mir_h;
-    // pass 2 (parallel): the translated arrays (keyframe id -> record index; a keyframe whose record was released or never registered: -1, skipped on the device)
+    // keyframe id -> record index (a keyframe whose record was released — culled — or never registered: -1, skipped on the device)
     o->pool->parallel_for(n, [&](int i) {
-        const uint32_t* w = words[i];
-        const int slot = slots[i];
+        const oslam_map_changes_t& c = ch[i];
+        const int slot = c.slot;
         MirrorBulk* B = (MirrorBulk*)(U + aB) + oB[i];
         uint32_t* PW = (uint32_t*)(U + aW);
         int4* Cc = (int4*)(U + aC) + oC[i];
         uint4* Oo = (uint4*)(U + aO) + oO[i];
         uint4* Pp = (uint4*)(U + aP) + 2 * oP[i];
         size_t wo = oW[i];
+        for (int k = 0; k < c.n_new; k++) {
+            const oslam_map_new_kf_t& e = c.new_kfs[k];
+            B[k].r = o->rec_lookup(slot, e.kf); B[k].N = e.N; B[k].word_off = (uint32_t)wo; B[k].seq = seq0[i];
+            memcpy(PW + wo, e.mp, 4 * (size_t)e.N);
+            memcpy(PW + wo + e.N, e.good, 4 * (((size_t)e.N + 31) / 32));
+            wo += (size_t)e.N + ((size_t)e.N + 31) / 32;
+        }
+        for (int q = 0; q < c.n_cells; q++) Cc[q] = make_int4(o->rec_lookup(slot, c.cells[3 * q]), c.cells[3 * q + 1], c.cells[3 * q + 2], 0);
         uint32_t ev = seq0[i] + 1u;
-        for (uint32_t q = 0; q < (uint32_t)nwords[i];) {
-            const uint32_t op = w[q] & 0xFFu, len = w[q] >> 8;
-            if (op == 1) { *Cc++ = make_int4(o->rec_lookup(slot, (int)w[q + 1]), (int)w[q + 2], (int)w[q + 3], 0); }
-            else if (op == 2) {
-                const uint32_t N = w[q + 2], pw = N + (N + 31) / 32;
-                B->r = o->rec_lookup(slot, (int)w[q + 1]); B->N = (int)N; B->word_off = (uint32_t)wo; B->seq = seq0[i]; B++;
-                memcpy(PW + wo, w + q + 3, 4 * (size_t)pw);
-                wo += pw;
-            } else if (op == 3 || op == 4) { *Oo++ = make_uint4((uint32_t)o->rec_lookup(slot, (int)w[q + 1]), w[q + 2], op == 3 ? w[q + 3] : 0xFFFFFFFFu, ev++); }
-            else if (op == 5) { Pp[0] = make_uint4((uint32_t)slot, w[q + 1], w[q + 2], w[q + 3]); Pp[1] = make_uint4(w[q + 4], w[q + 5], 0u, 0u); Pp += 2; }
-            q += len;
+        for (int q = 0; q < c.n_events; q++) {
+            const uint32_t w1 = c.events[3 * q + 1];
+            Oo[q] = make_uint4((uint32_t)o->rec_lookup(slot, (int)c.events[3 * q]), w1 & 0x7FFFFFFFu, (w1 & 0x80000000u) ? c.events[3 * q + 2] : 0xFFFFFFFFu, ev++);
+        }
+        for (int q = 0; q < c.n_points; q++) {
+            Pp[2 * q] = make_uint4((uint32_t)slot, c.points[5 * q], c.points[5 * q + 1], c.points[5 * q + 2]);
+            Pp[2 * q + 1] = make_uint4(c.points[5 * q + 3], c.points[5 * q + 4], 0u, 0u);
         }
     });
     OSLAM_HIP_CHECK(hipMemcpyAsync(o->mir_d, o->mir_h, L.off, hipMemcpyHostToDevice, o->strm));
+    o->mir_used = L.off;
     const MirrorGeom g = mirror_geom(o);
     if (nbulk) hipLaunchKernelGGL(k_mirror_bulk, dim3((unsigned)nbulk), dim3(256), 0, o->strm, (const MirrorBulk*)(o->mir_d + aB), (const uint32_t*)(o->mir_d + aW), (uint8_t* const*)o->d_rec_chunk, g);
     const size_t nops = ncell + nokf + npt;
@@ -1593,35 +1593,54 @@ int h_map_journal(void* p, int n, const int32_t* slots, const uint32_t* const* w
 
 int h_kf_culling_counts(void* p, int n, const oslam_job_cull_t* jobs, float thDepth) {
     HipOps* o = (HipOps*)p;
-    (void)thDepth;   // (the usable-depth bits came with the keyframes' bulk records)
+    (void)thDepth;   // (the usable-depth bits came with the keyframes' change sets)
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    o->cull_pending.clear();
     size_t total = 0;
     for (int i = 0; i < n; i++) { if (jobs[i].slot < 0 || jobs[i].slot >= o->S || jobs[i].n < 0 || !jobs[i].out) { oslam::set_error("kf_culling_counts: bad job"); return OSLAM_E_INVALID; } total += (size_t)jobs[i].n; }
     if (total == 0) return OSLAM_OK;
-    Layout L;
-    const size_t oC = L.take(sizeof(CullCand) * total);
-    const size_t in_bytes = L.off;
-    const size_t oOut = L.take(16 * total);
-    OPS_CHECK(o->ensure_up(L.off));
-    OPS_CHECK(o->ensure_dn(16 * total));
-    CullCand* cc = (CullCand*)(o->up_h + oC);
+    // the request goes behind the flush in the mirror's upload block (both may be in flight together)
+    const size_t base = oslam::align_up(o->mir_used, 256), oC = base, oOut = oslam::align_up(oC + sizeof(CullCand) * total, 256), end = oOut + 16 * total;
+    if (end > o->mir_cap) {   // (rare: the block is grown with nothing in flight; the flush, if any, has completed by then)
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        o->mir_used = 0;
+        OPS_CHECK(o->ensure_mir(sizeof(CullCand) * total + 16 * total + 1024));
+        return h_kf_culling_counts(p, n, jobs, thDepth);
+    }
+    if (16 * total > o->cull_cap) {
+        OSLAM_HIP_CHECK(hipStreamSynchronize(o->strm));
+        if (o->cull_h) (void)hipHostFree(o->cull_h);
+        o->cull_h = nullptr; o->cull_cap = 0;
+        OSLAM_HIP_CHECK(hipHostMalloc((void**)&o->cull_h, 32 * total + 4096, 0));
+        o->cull_cap = 32 * total + 4096;
+    }
+    CullCand* cc = (CullCand*)(o->mir_h + oC);
     size_t at = 0;
-    for (int i = 0; i < n; i++)
-        for (int q = 0; q < jobs[i].n; q++, at++) { cc[at].rec = o->rec_lookup(jobs[i].slot, jobs[i].kf_ids[q]); cc[at].slot = jobs[i].slot; }
     if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
-    for (int i = 0; i < n; i++) if (!o->pt_aux[jobs[i].slot]) OPS_CHECK(o->ensure_pt_aux(jobs[i].slot, 1));
+    for (int i = 0; i < n; i++) {
+        if (!o->pt_aux[jobs[i].slot]) OPS_CHECK(o->ensure_pt_aux(jobs[i].slot, 1));
+        for (int q = 0; q < jobs[i].n; q++, at++) { cc[at].rec = o->rec_lookup(jobs[i].slot, jobs[i].kf_ids[q]); cc[at].slot = jobs[i].slot; }
+        o->cull_pending.push_back({jobs[i].out, jobs[i].n});
+    }
     OPS_CHECK(o->sync_mirror_tables());
-    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, in_bytes, hipMemcpyHostToDevice, o->strm));
-    o->t_begin();
-    hipLaunchKernelGGL(k_cull_counts, dim3((unsigned)total), dim3(64), 0, o->strm, (const CullCand*)(o->up_d + oC), (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux,
-                       mirror_geom(o), (int32_t*)(o->up_d + oOut));
-    o->t_end();
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->mir_d + oC, o->mir_h + oC, sizeof(CullCand) * total, hipMemcpyHostToDevice, o->strm));
+    hipLaunchKernelGGL(k_cull_counts, dim3((unsigned)total), dim3(64), 0, o->strm, (const CullCand*)(o->mir_d + oC), (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux,
+                       mirror_geom(o), (int32_t*)(o->mir_d + oOut));
     OSLAM_HIP_CHECK(hipGetLastError());
-    OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h, o->up_d + oOut, 16 * total, o->strm));
-    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
-    o->t_collect(7, 1, 0);
-    at = 0;
-    for (int i = 0; i < n; i++) { memcpy(jobs[i].out, o->dn_h + 16 * at, 16 * (size_t)jobs[i].n); at += (size_t)jobs[i].n; }
+    OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->cull_h, o->mir_d + oOut, 16 * total, o->strm));
+    o->mir_used = end;
+    return OSLAM_OK;   // (results: h_kf_culling_collect)
+}
+
+int h_kf_culling_collect(void* p) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (o->cull_pending.empty()) { o->mir_used = 0; return OSLAM_OK; }
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));   // (usually already drained: the MapPoint-update operator between request and collection synchronises the same stream)
+    size_t at = 0;
+    for (const HipOps::CullPending& c : o->cull_pending) { memcpy(c.out, o->cull_h + 16 * at, 16 * (size_t)c.n); at += (size_t)c.n; }
+    o->cull_pending.clear();
+    o->mir_used = 0;
     return OSLAM_OK;
 }
 
@@ -1927,6 +1946,7 @@ void h_destroy(void* p) {
     for (uint8_t* q : o->pt_aux) if (q) (void)hipFree(q);
     if (o->d_pt_aux) (void)hipFree(o->d_pt_aux);
     if (o->d_rec_chunk) (void)hipFree(o->d_rec_chunk);
+    if (o->cull_h) (void)hipHostFree(o->cull_h);
     if (o->mir_h) (void)hipHostFree(o->mir_h);
     if (o->mir_d) (void)hipFree(o->mir_d);
     (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
@@ -2014,7 +2034,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; }
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
