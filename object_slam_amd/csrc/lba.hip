@@ -705,7 +705,7 @@ constexpr int kLinThreads = 4 * kWPt;   // 512
 constexpr int kLinKfLds = 128;          // keyframes of a window whose rotation + translation k_w_lin's landmark blocks stage in LDS (12 KB)
 
 __device__ void w_ctrlA(const LbaProblem& pr, const LbaWide& w);
-__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w);
+__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win);
 
 #ifndef OSLAM_LIN_MIN_WAVES
 #define OSLAM_LIN_MIN_WAVES 4   // 128 VGPRs (96 B of scratch per lane) so that two 512-thread workgroups share a CU; 1 = the compiler's 166 VGPRs, one workgroup per CU
@@ -1866,7 +1866,36 @@ __global__ __launch_bounds__(kMfmaThreads) void k_w_chol_mfma(const LbaProblem* 
 // Blocks [0, nblk_pt): 128 landmarks each — x_l, the trial position, then the errors of the landmark's edges at the TRIAL state.  The trial poses of the free
 // keyframes are what the pose block (item == nblk_pt) writes to w.T / w.R for the later launches; a landmark block cannot wait for another block, so it
 // recomputes them itself into LDS (se3_exp + se3_mul per free keyframe: the same two calls on the same inputs, hence the same bits).
-template <bool REC>
+__device__ void w_gate_block(const LbaProblem& pr, const LbaWide& w);
+// FOLD: the LM control step of the trial (k_w_ctrlB of rounds 1-4) runs in the LAST workgroup of the window to finish — every workgroup publishes its partial sums,
+// then takes a ticket; the one that draws the last ticket sees all of them (release / acquire fences at device scope around the ticket) — one launch less per trial,
+// and slower than the launch it replaces (see fold_ctrl at the launch site): an A/B knob, off by default.
+__device__ __forceinline__ void w_update_tail(const LbaProblem& pr, const LbaWide& w, int win) {
+    __shared__ int s_last, s_gate;
+    __threadfence();        // every lane's chi2 / trial-state stores are out before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LbaCtrl* ct = w.ct;
+        const int t = atomicAdd(&ct->ticket[1], 1);
+        s_last = t == w.nblk_pt;
+        s_gate = 0;
+        if (s_last) {
+            ct->ticket[1] = 0;
+            __threadfence();
+            w_ctrlB(pr, w, win);
+            s_gate = ct->gate && !ct->done;
+        }
+    }
+    __syncthreads();
+    if (s_last && s_gate) {
+        __threadfence();
+        w_gate_block(pr, w);
+        __syncthreads();
+        if (threadIdx.x == 0) w.ct->gate = 0;
+    }
+}
+
+template <bool REC, bool FOLD>
 __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
@@ -1904,6 +1933,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
             for (int i = 1; i < kWPt / 64; i++) a += sS[i];
             w.partS[item_] = a;
         }
+        if (FOLD) w_update_tail(pr, w, win_);
         return;
     }
     // ---- landmark block ----
@@ -2032,6 +2062,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
         w.partS[item_] = a;
         w.partF[item_] = b;
     }
+    if (FOLD) w_update_tail(pr, w, win_);
 }
 
 // Levenberg-Marquardt decision + schedule transitions (g2o OptimizationAlgorithmLevenberg::solve tail,
@@ -2043,7 +2074,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
 __device__ double* g_lba_trace = nullptr;
 __device__ int g_lba_trace_cap = 0;
 
-__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
+__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) {
     LbaCtrl* ct = w.ct;
     if (ct->need_lin) {   // pair-gather path: w_ctrlA's step was left to k_w_edgeW (values) and to this commit (state); the tiles path ran k_w_ctrlA: need_lin is 0
         ct->currentChi = ct->FA;
@@ -2058,7 +2089,7 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w) {
     if (!ct->ok2) tempChi = 1.7976931348623157e308;
     const double rho = (ct->currentChi - tempChi) / (sc + 1e-3);
     const bool finite = (tempChi - tempChi) == 0;
-    if (g_lba_trace && blockIdx.y == 0) {
+    if (g_lba_trace && win == 0) {
         const int r = (int)g_lba_trace[0];
         if (r < g_lba_trace_cap) {
             double* t = g_lba_trace + 1 + 6 * r;
@@ -2113,7 +2144,7 @@ __global__ __launch_bounds__(256) void k_w_ctrlB(const LbaProblem* probs, const 
     if (w.ct->done) return;
     __shared__ int s_gate;
     if (threadIdx.x == 0) {
-        w_ctrlB(pr, w);
+        w_ctrlB(pr, w, blockIdx.y);
         s_gate = w.ct->gate && !w.ct->done;
     }
     __syncthreads();
@@ -2927,6 +2958,10 @@ static int lba_launch(oslam_lba_t* h) {
         const int ny_xcd = n0 >= 8 ? (n0 + 7) / 8 * 8 : n0;   // grid rows of the kernels that map a window to one XCD (xcd_window_item)
         static const double gate_release_frac = [] { const char* e = getenv("OSLAM_LBA_GATE_RELEASE"); return e ? atof(e) : 0.0; }();
         static const bool call_stats = getenv("OSLAM_LBA_CALL_STATS") != nullptr;   // per host poll: windows of the call, trial slots enqueued so far, windows not done
+        // LM control step in the last workgroup of k_w_update instead of its own launch (5 launches per trial instead of 6).  Default OFF, measured: the device-scope release
+        // fence every workgroup needs before it takes its ticket (an L2 write-back on gfx950: the window's workgroups may sit on different XCDs) costs more than the
+        // launch it saves — 314 against 294 us per trial at 40 windows, 750 against 640 us at 128 (same box, alternating runs; tests/test_lba_gpu.py green both ways).
+        static const bool fold_ctrl = [] { const char* e = getenv("OSLAM_LBA_FOLD_CTRL"); return e && atoi(e) != 0; }();
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
@@ -2954,9 +2989,15 @@ static int lba_launch(oslam_lba_t* h) {
                 if (chol_ldsm || chol_packed || chol_mfma) { }
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
-                if (use_rec) hipLaunchKernelGGL(k_w_update<true>, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                else hipLaunchKernelGGL(k_w_update<false>, dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);   // (+ the trial's chi2: k_w_eval of rounds 1-3)
-                hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
+                // (+ the trial's chi2: k_w_eval of rounds 1-3; OSLAM_LBA_FOLD_CTRL=1: + the LM control step in the window's last workgroup)
+                if (fold_ctrl) {
+                    if (use_rec) hipLaunchKernelGGL((k_w_update<true, true>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                    else hipLaunchKernelGGL((k_w_update<false, true>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                } else {
+                    if (use_rec) hipLaunchKernelGGL((k_w_update<true, false>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                    else hipLaunchKernelGGL((k_w_update<false, false>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
+                    hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
+                }
             }
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
             OSLAM_HIP_CHECK(stream_wait(st));
@@ -2976,7 +3017,7 @@ static int lba_launch(oslam_lba_t* h) {
         hipLaunchKernelGGL(k_w_final, dim3(div_up(maxFin, 256), n0), dim3(256), 0, st, d_probs, d_ws);
         // launches per trial slot: linearisation, (control step +) Schur complement, the solver kernels this call mixes, update, control
         const int n_chol = (chol_ldsm ? 1 : 0) + (chol_packed ? 1 : 0) + (chol_mfma ? 1 : 0);
-        launches += 3 + (1 + (tiles ? 3 : 2) + std::max(n_chol, 1) + 2) * (long long)slots_done;
+        launches += 3 + (1 + (tiles ? 3 : 2) + std::max(n_chol, 1) + (fold_ctrl ? 1 : 2)) * (long long)slots_done;
     }
     lba_time_end(h);
     OSLAM_HIP_CHECK(hipGetLastError());
