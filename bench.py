@@ -569,6 +569,7 @@ def main():
     extras_failed = []   # names of extra legs that raised (the line records their errors; --strict turns them into a non-zero exit)
 
     mem_gb = {}
+    rss_gb = {}
 
     def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None):
         snap = {}
@@ -618,6 +619,12 @@ def main():
             mem_gb[tag] = round((total_b - free_b) / 2**30, 1)
         except Exception:
             mem_gb[tag] = None
+        try:   # host memory of the process while the leg's systems are alive (their maps, the pinned staging blocks, every leg's rendered inputs)
+            with open("/proc/self/status") as fh:
+                vm = {ln.split(":")[0]: int(ln.split()[1]) for ln in fh if ln.startswith(("VmRSS", "VmHWM"))}
+            rss_gb[tag] = {"rss": round(vm["VmRSS"] / 1048576.0, 2), "peak_so_far": round(vm["VmHWM"] / 1048576.0, 2)}
+        except Exception:
+            rss_gb[tag] = None
         for sy in systems:
             sy.close()
         # (malloc_trim(0) here — handing the closed leg's tens of GB of small blocks back to the system — was measured: it lowers the peak RSS of the whole run from 96 to
@@ -763,7 +770,10 @@ def main():
                "roofline": roof, "cpu_baseline": cpu,
                "host_inputs": (summ.get("post") or {}).get("host_inputs") if isinstance(summ.get("post"), dict) else None,
                "cold_start": cold, "bases32": bases32, "stereo" if second is wl_st else "rgbd": second_out, "frontend": front, "extras_failed": extras_failed,
-               "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "device_mem_used_gb_after_headline": mem_gb.get("head"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2)}
+               "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "device_mem_used_gb_after_headline": mem_gb.get("head"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
+               # (the line above is the peak over ALL legs of this process — each leg's maps are freed into the allocator's arenas, not back to the system — ; the headline
+               # job's own footprint, inputs of the other legs included, is the figure below, taken while its 8192 maps are alive)
+               "host_rss_gb_headline_leg": rss_gb.get("head")}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -525,3 +525,26 @@ def test_operator_failure_is_confined_to_its_sequence(lm):
     # ... and tracks again on that map
     assert states[-1, victim] == slam.OK and hit.stats(victim)["map_violations"] == 0 and hit.stats(victim)["lost_frames"] == 0
     assert np.array_equal(poses[:injected_at, victim], pc[:injected_at, victim])
+
+
+def test_device_culling_counts_equal_the_host_walk():
+    """KeyFrameCulling's redundancy counts come from the device's mirror of the observation graph (include/oslam_slam.h: map_journal / kf_culling_counts).
+    OSLAM_SLAM_CULL_CHECK=1 makes the driver recount every candidate on the host and abort on a difference; OSLAM_SLAM_CULL_HOST=1 is the host walk alone.
+    Both runs (occluded streams: keyframes ARE culled) must end with the same statistics and bit-identical poses."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        p = subprocess.run([sys.executable, os.path.join(here, "cull_check_run.py")], env=e, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, (tag, p.stdout[-2000:], p.stderr[-2000:])
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        res[tag] = json.loads(line[7:])
+    assert res["check"] == res["host"]
+    for name in ("sync", "deferred"):
+        assert res["check"][name]["status_ok"]
+    assert sum(s["keyframes_culled"] for s in res["check"]["sync"]["stats"]) >= 2
