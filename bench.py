@@ -544,6 +544,16 @@ def main():
     if log:
         log("inputs rendered in %.1f s" % t_gen)
 
+    def _input_gb(seqs, seen):   # host bytes of a leg's rendered base streams (arrays shared with an earlier leg counted once)
+        n = 0
+        for q in (seqs or {}).values():
+            for v in q.values():
+                if hasattr(v, "nbytes") and id(v) not in seen:
+                    seen.add(id(v)); n += v.nbytes
+        return round(n / 2**30, 2)
+    _seen = set()
+    inputs_host_gb = {"headline": _input_gb(seq_head, _seen), "bases32_extra": _input_gb(seq_b32, _seen), "second_workload": _input_gb(seq_second, _seen)}
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -773,7 +783,9 @@ def main():
                "input_render_s": round(t_gen, 1), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "device_mem_used_gb_after_headline": mem_gb.get("head"), "host_max_rss_gb": round(__import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1048576.0, 2),
                # (the line above is the peak over ALL legs of this process — each leg's maps are freed into the allocator's arenas, not back to the system — ; the headline
                # job's own footprint, inputs of the other legs included, is the figure below, taken while its 8192 maps are alive)
-               "host_rss_gb_headline_leg": rss_gb.get("head")}
+               "host_rss_gb_headline_leg": rss_gb.get("head"),
+               # every leg's inputs are rendered (forked workers) BEFORE the process touches the GPU, so the figure above contains the other legs' inputs too:
+               "host_input_arrays_gb": inputs_host_gb}
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

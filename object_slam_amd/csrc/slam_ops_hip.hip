@@ -1173,7 +1173,8 @@ struct LbaService {
                 // dispatched ahead of the queued local-BA launches
                 int lo = 0, hi = 0;
                 OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = numerically greatest = lowest priority)
-                OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, lo));
+                const char* pe = getenv("OSLAM_LBA_SERVICE_PRIORITY");   // A/B knob: "high" = the greatest priority (measured: DESIGN.md section 7.2)
+                OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, pe && !strcmp(pe, "high") ? hi : lo));
                 oslam::lba_use_stream(wk->ba, wk->strm);
             }
             if (!getenv("OSLAM_LBA_SERVICE_OVERLAP")) oslam::lba_use_gate(wk->ba, &launch_mu);
