@@ -330,6 +330,13 @@ typedef struct oslam_slam_ops {
      * returns when they are.  The driver asks for the counts right after the local-BA write-back — the last step of a pass that changes observations — and
      * collects them after the MapPoint updates, so the round trip to the device hides behind that stage. */
     int (*kf_culling_collect)(void* ctx);
+    /* optional pair (round 5): mp_update_keyed whose results may arrive later.  mp_update_keyed_async enqueues the job and may return before best_idx / out_desc /
+     * out5 are written (the job and every array it names must stay valid and untouched); mp_update_collect returns when they are.  At most one job is in flight per
+     * table; operators called in between see the job's effects on the resident records (same stream order).  The driver uses it for the descriptor updates that
+     * follow every ORBmatcher::Fuse round of SearchInNeighbors (MapPoint::Replace -> ComputeDistinctiveDescriptors, src/MapPoint.cc:314): the next round's host
+     * bookkeeping and search are issued behind the update instead of waiting for it. */
+    int (*mp_update_keyed_async)(void* ctx, oslam_job_mp_update_t* job, const int32_t* obs_key);
+    int (*mp_update_collect)(void* ctx);
 } oslam_slam_ops_t;
 
 /* System::System for S sequences of one camera model (src/System.cc:33-120, minus vocabulary / viewer / loop closer). */

@@ -60,6 +60,13 @@ struct HipOps {
     // fill (parallel memcpy) -> ONE host-to-device copy -> batch kernels -> result copies -> ONE synchronisation -> scatter
     uint8_t* up_h = nullptr; uint8_t* up_d = nullptr; size_t up_cap = 0;
     uint8_t* dn_h = nullptr; size_t dn_cap = 0;
+    // second staging set + event pair for the ONE deferred MapPoint update (mp_update_keyed_async): its job block is read in place by the kernel and its results
+    // land in the pinned block while the next operator already uses the first set
+    uint8_t* upB_h = nullptr; uint8_t* upB_d = nullptr; size_t upB_cap = 0;
+    uint8_t* dnB_h = nullptr; size_t dnB_cap = 0;
+    hipEvent_t tevB0 = nullptr, tevB1 = nullptr;
+    struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; } mpu_pend;
+    void swap_staging() { std::swap(up_h, upB_h); std::swap(up_d, upB_d); std::swap(up_cap, upB_cap); std::swap(dn_h, dnB_h); std::swap(dn_cap, dnB_cap); std::swap(tev0, tevB0); std::swap(tev1, tevB1); }
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     uint8_t* d_objbits = nullptr;                        // [S][cap] keypoint test bits (object_kps)
     // Resident local maps: the packed SearchLocalPoints arrays of every slot stay on the device ([S][loc_st] each); a job whose content id equals the
@@ -882,9 +889,35 @@ int h_pose_opt2(void* p, int n, oslam_job_pose2_t* jobs) {
 }
 
 // MapPoint::ComputeDistinctiveDescriptors + UpdateNormalAndDepth over the touched points of all sequences: one block up, two launches, one block down
-static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key);
-int h_mp_update(void* p, oslam_job_mp_update_t* j) { return mp_update_impl((HipOps*)p, j, nullptr); }
-int h_mp_update_keyed(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) { return mp_update_impl((HipOps*)p, j, obs_key); }
+static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key, bool defer = false);
+int h_mp_update_collect(void* p);
+int h_mp_update(void* p, oslam_job_mp_update_t* j) { int rc = h_mp_update_collect(p); return rc ? rc : mp_update_impl((HipOps*)p, j, nullptr); }
+int h_mp_update_keyed(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) { int rc = h_mp_update_collect(p); return rc ? rc : mp_update_impl((HipOps*)p, j, obs_key); }
+// The deferred form: only the one-launch path (k_mp_update_fused) is deferred — it needs no staging beyond the job block and writes its results into a pinned
+// block by itself; any other job is run to completion here (mp_update_collect then has nothing to wait for).
+int h_mp_update_keyed_async(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) {
+    HipOps* o = (HipOps*)p;
+    int rc = h_mp_update_collect(p);
+    if (rc) return rc;
+    o->swap_staging();
+    rc = mp_update_impl(o, j, obs_key, true);
+    o->swap_staging();
+    return rc;
+}
+int h_mp_update_collect(void* p) {
+    HipOps* o = (HipOps*)p;
+    if (!o->mpu_pend.on) return OSLAM_OK;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    HipOps::MpuPending& q = o->mpu_pend;
+    q.on = false;
+    o->swap_staging();   // (the deferred job's event pair and result block)
+    o->t_collect(6, 1, q.dtotal);
+    if (q.j->do_desc) { memcpy(q.j->best_idx, o->dn_h + q.rBest, 4 * q.P); memcpy(q.j->out_desc, o->dn_h + q.rOut, 32 * q.P); }
+    if (q.j->do_normal) memcpy(q.j->out5, o->dn_h + q.rOut5, 20 * q.P);
+    o->swap_staging();
+    return OSLAM_OK;
+}
 
 // OSLAM_MPU_PROF=1: wall-clock split of the operator summed over all calls of the process, printed at exit
 struct MpuOpProf {
@@ -897,7 +930,7 @@ struct MpuOpProf {
 };
 static MpuOpProf* mpu_op_prof() { static MpuOpProf* p = getenv("OSLAM_MPU_PROF") ? new MpuOpProf : nullptr; static struct D { ~D() { delete mpu_op_prof(); } } d; return p; }
 
-static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key) {
+static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* obs_key, bool defer) {
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));   // the HIP current device is per host thread: a handle may be stepped from any thread
     const size_t P = j->P;
     if (P == 0) return OSLAM_OK;
@@ -985,6 +1018,10 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
                                                table ? o->d_mp_tab : nullptr, (int32_t*)(o->dn_h + rBest), o->dn_h + rOut, (float*)(o->dn_h + rOut5), o->strm));
         o->t_end();
         lap_(3);
+        if (defer) {   // (h_mp_update_collect finishes it)
+            o->mpu_pend.on = true; o->mpu_pend.j = j; o->mpu_pend.P = P; o->mpu_pend.rBest = rBest; o->mpu_pend.rOut = rOut; o->mpu_pend.rOut5 = rOut5; o->mpu_pend.dtotal = (double)dtotal;
+            return OSLAM_OK;
+        }
         OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         lap_(4);
         o->t_collect(6, 1, (double)dtotal);
@@ -1711,7 +1748,7 @@ int h_bow_keyed(void* p, int n, oslam_job_bow_t* jobs, const oslam_kf_key_t* key
 int h_kernel_times(void* p, int enable, double* out) {
     HipOps* o = (HipOps*)p;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
-    if (enable && !o->tev0) { OSLAM_HIP_CHECK(hipEventCreate(&o->tev0)); OSLAM_HIP_CHECK(hipEventCreate(&o->tev1)); }
+    if (enable && !o->tev0) { OSLAM_HIP_CHECK(hipEventCreate(&o->tev0)); OSLAM_HIP_CHECK(hipEventCreate(&o->tev1)); OSLAM_HIP_CHECK(hipEventCreate(&o->tevB0)); OSLAM_HIP_CHECK(hipEventCreate(&o->tevB1)); }
     {   // the BoW matchers and the triangulation run on their handles' own streams
         double ms = 0; long long ln = 0;
         OPS_CHECK(oslam_bow_kernel_time(o->bow, enable, &ms, &ln));
@@ -1953,6 +1990,11 @@ void h_destroy(void* p) {
     (void)hipFree(o->up_d); (void)hipFree(o->d_maskbits); (void)hipFree(o->d_loc); (void)hipFree(o->d_lq); (void)hipFree(o->d_inview); (void)hipFree(o->d_objbits); (void)hipFree(o->d_maskstage);
     delete o->pool;
     if (o->tev0) (void)hipEventDestroy(o->tev0);
+    if (o->tevB0) (void)hipEventDestroy(o->tevB0);
+    if (o->tevB1) (void)hipEventDestroy(o->tevB1);
+    if (o->upB_h) (void)hipHostFree(o->upB_h);
+    if (o->upB_d) (void)hipFree(o->upB_d);
+    if (o->dnB_h) (void)hipHostFree(o->dnB_h);
     if (o->tev1) (void)hipEventDestroy(o->tev1);
     if (o->strm) (void)hipStreamDestroy(o->strm);
     (void)hipFree(o->d_gray); (void)hipFree(o->d_depth); (void)hipFree(o->d_keysUn); (void)hipFree(o->d_keysUn_prev); (void)hipFree(o->d_uRight); (void)hipFree(o->d_mvDepth); (void)hipFree(o->d_status);
@@ -2036,7 +2078,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; }
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed;
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
     return OSLAM_OK;

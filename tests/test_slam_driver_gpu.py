@@ -537,14 +537,15 @@ def test_device_culling_counts_equal_the_host_walk():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1"})):
+    # (third run: the deferred form of the per-round descriptor updates of SearchInNeighbors, oslam_slam_ops_t::mp_update_keyed_async — an A/B knob, off by default)
+    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1"}), ("mpu_async", {"OSLAM_SLAM_MPU_ASYNC": "1"})):
         e = dict(os.environ)
         e.update(env)
         p = subprocess.run([sys.executable, os.path.join(here, "cull_check_run.py")], env=e, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, (tag, p.stdout[-2000:], p.stderr[-2000:])
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         res[tag] = json.loads(line[7:])
-    assert res["check"] == res["host"]
+    assert res["check"] == res["host"] == res["mpu_async"]
     for name in ("sync", "deferred"):
         assert res["check"][name]["status_ok"]
     assert sum(s["keyframes_culled"] for s in res["check"]["sync"]["stats"]) >= 2
