@@ -643,6 +643,7 @@ struct LbaWide {
 
 constexpr int kWPt = 128;   // threads per block of the per-point kernels
 
+
 __device__ __forceinline__ double* w_X(const LbaProblem& pr, int which) { return which ? pr.Xb : pr.Xa; }
 
 __global__ __launch_bounds__(256) void k_w_init(const LbaProblem* probs, const LbaWide* ws) {
@@ -1895,8 +1896,11 @@ __device__ __forceinline__ void w_update_tail(const LbaProblem& pr, const LbaWid
     }
 }
 
-template <bool REC, bool FOLD>
-__global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+// (round 5: kUpdLanes = 1, 2 or 4 lanes per landmark split its edge list — stride kUpdLanes, partial sums combined by a fixed xor-shuffle tree — like k_w_lin's landmark
+// role: the one-lane form walked ~8 edges twice in one dependent chain and the kernel spent its time waiting)
+template <bool REC, bool FOLD, int kUpdLanes>
+__global__ __launch_bounds__(kWPt * kUpdLanes) void k_w_update(const LbaProblem* probs, const LbaWide* ws, int nwin) {
+    constexpr int kUpdThreads = kWPt * kUpdLanes;   // the workgroup still owns kWPt landmarks
     int win_, item_;
     if (!xcd_window_item(nwin, win_, item_)) return;
     const LbaProblem& pr = probs[win_];
@@ -1910,10 +1914,10 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     double* Xn = w_X(pr, cur ^ 1);
     double sc = 0;
     if (item_ > w.nblk_pt) return;   // padding block of a batched launch (the grid is sized for the largest window)
-    __shared__ double sS[kWPt / 64], sF[kWPt / 64];
+    __shared__ double sS[kUpdThreads / 64], sF[kUpdThreads / 64];
     __shared__ SE3 sTn[kLbaMaxKF];   // trial poses of the FREE keyframes (block index order)
     if (item_ == w.nblk_pt) {   // poses
-        for (int a = threadIdx.x; a < pr.K; a += kWPt) {
+        for (int a = threadIdx.x; a < pr.K; a += kUpdThreads) {
             const int ba = w.blk[a];
             SE3* Tn = w.T + (cur ^ 1) * pr.K + a;
             const SE3 Tc = w.T[cur * pr.K + a];
@@ -1930,7 +1934,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
         __syncthreads();
         if (threadIdx.x == 0) {
             double a = sS[0];
-            for (int i = 1; i < kWPt / 64; i++) a += sS[i];
+            for (int i = 1; i < kUpdThreads / 64; i++) a += sS[i];
             w.partS[item_] = a;
         }
         if (FOLD) w_update_tail(pr, w, win_);
@@ -1939,7 +1943,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     // ---- landmark block ----
     const Cam cam_ = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
     const int nfree = ct->nfree;
-    for (int ba = threadIdx.x; ba < nfree; ba += kWPt) {
+    for (int ba = threadIdx.x; ba < nfree; ba += kUpdThreads) {
         const int a = w.free_pose[ba];
         double xa[6];
         for (int i = 0; i < 6; i++) xa[i] = pr.xp[6 * ba + i];
@@ -1949,7 +1953,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
     const SE3* Tc = w.T + cur * pr.K;   // (a fixed keyframe's trial pose is its current pose)
-    const int p = item_ * kWPt + threadIdx.x;
+    const int p = item_ * kWPt + (int)(threadIdx.x / kUpdLanes), sub = (int)(threadIdx.x % kUpdLanes);
     double F = 0;
     double Xt[3] = {0, 0, 0};
     if (p < pr.P) {
@@ -1960,12 +1964,13 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
 #pragma clang fp contract(fast)
             const double* Rc = w.R + (size_t)cur * pr.K * 9;
             const int e1 = pr.pt_start[p + 1];
-            int e = pr.pt_start[p];
+            int e = pr.pt_start[p] + sub;
             double2 r0n = make_double2(0.0, 0.0), r1n = r0n; int a_n = 0;
             if (e < e1) { const double2* rc = (const double2*)(w.rec + (long long)e * 4); r0n = rc[0]; r1n = rc[1]; a_n = pr.e_kf[e]; }
-            for (; e < e1; e++) {
+            double dl[3] = {0, 0, 0};
+            for (; e < e1; e += kUpdLanes) {
                 const double2 r0 = r0n, r1 = r1n; const int a = a_n;
-                if (e + 1 < e1) { const double2* rc = (const double2*)(w.rec + (long long)(e + 1) * 4); r0n = rc[0]; r1n = rc[1]; a_n = pr.e_kf[e + 1]; }
+                if (e + kUpdLanes < e1) { const double2* rc = (const double2*)(w.rec + (long long)(e + kUpdLanes) * 4); r0n = rc[0]; r1n = rc[1]; a_n = pr.e_kf[e + kUpdLanes]; }
                 const int ba = w.blk[a];
                 const double wi = fabs(r1.y);
                 if (wi == 0.0 || ba < 0) continue;
@@ -1985,10 +1990,17 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
                 }
                 v0 *= wi; v1 *= wi; v2 *= wi;
 #pragma unroll
-                for (int j = 0; j < 3; j++) cl[j] -= Jx[j] * v0 + Jx[3 + j] * v1 + Jx[6 + j] * v2;
+                for (int j = 0; j < 3; j++) dl[j] += Jx[j] * v0 + Jx[3 + j] * v1 + Jx[6 + j] * v2;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+#pragma unroll
+                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += __shfl_xor(dl[j], d, 64);
+                cl[j] -= dl[j];
             }
         } else if (ok2) {
-            for (int e = pr.pt_start[p]; e < pr.pt_start[p + 1]; e++) {
+            double dl[3] = {0, 0, 0};
+            for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += kUpdLanes) {
                 // (B_e is requested before the level byte and the keyframe's block index are known: its address depends on neither)
                 const double* Bg = pr.Hpl + (long long)e * 18;
                 double B[18];
@@ -2003,8 +2015,14 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
                     double sv = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++) sv += B[i * 3 + j] * xa[i];
-                    cl[j] -= sv;
+                    dl[j] += sv;
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+#pragma unroll
+                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += __shfl_xor(dl[j], d, 64);
+                cl[j] -= dl[j];
             }
         }
         if (ok2 && REC) {   // (Hll_p + lambda I)^-1 as k_w_edgeW<true> left it for this trial
@@ -2026,20 +2044,22 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             Xt[i] = X[p * 3 + i] + xo[i];
-            Xn[p * 3 + i] = Xt[i];
-            sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);
+            if (sub == 0) {   // (the lanes of a landmark hold the same step)
+                Xn[p * 3 + i] = Xt[i];
+                sc += xo[i] * (lambda * xo[i] + pr.bl[p * 3 + i]);
+            }
         }
     }
     __syncthreads();   // the trial poses are in LDS
     if (p < pr.P) {
         // (an edge's inputs are loaded one round ahead and before its level byte is tested: the loop is a chain of dependent loads per edge otherwise)
         const int e1 = pr.pt_start[p + 1];
-        int e = pr.pt_start[p];
+        int e = pr.pt_start[p] + sub;
         uint8_t lv_n = 1; int a_n = 0; float o0_n = 0, o1_n = 0, o2_n = 0, inf_n = 0;
         if (e < e1) { lv_n = pr.level[e]; a_n = pr.e_kf[e]; o0_n = pr.e_obs[e * 3]; o1_n = pr.e_obs[e * 3 + 1]; o2_n = pr.e_obs[e * 3 + 2]; inf_n = pr.e_info[e]; }
-        for (; e < e1; e++) {
+        for (; e < e1; e += kUpdLanes) {
             const uint8_t lv = lv_n; const int a = a_n; const float o0 = o0_n, o1 = o1_n, ur = o2_n, inf = inf_n;
-            if (e + 1 < e1) { lv_n = pr.level[e + 1]; a_n = pr.e_kf[e + 1]; o0_n = pr.e_obs[e * 3 + 3]; o1_n = pr.e_obs[e * 3 + 4]; o2_n = pr.e_obs[e * 3 + 5]; inf_n = pr.e_info[e + 1]; }
+            if (e + kUpdLanes < e1) { const int en = e + kUpdLanes; lv_n = pr.level[en]; a_n = pr.e_kf[en]; o0_n = pr.e_obs[en * 3]; o1_n = pr.e_obs[en * 3 + 1]; o2_n = pr.e_obs[en * 3 + 2]; inf_n = pr.e_info[en]; }
             const int ba = w.blk[a];
             const SE3 Ta = ba >= 0 ? sTn[ba] : Tc[a];
             if (lv != 0) continue;
@@ -2058,7 +2078,7 @@ __global__ __launch_bounds__(kWPt) void k_w_update(const LbaProblem* probs, cons
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = sS[0], b = sF[0];
-        for (int i = 1; i < kWPt / 64; i++) { a += sS[i]; b += sF[i]; }
+        for (int i = 1; i < kUpdThreads / 64; i++) { a += sS[i]; b += sF[i]; }
         w.partS[item_] = a;
         w.partF[item_] = b;
     }
@@ -2962,6 +2982,11 @@ static int lba_launch(oslam_lba_t* h) {
         // fence every workgroup needs before it takes its ticket (an L2 write-back on gfx950: the window's workgroups may sit on different XCDs) costs more than the
         // launch it saves — 314 against 294 us per trial at 40 windows, 750 against 640 us at 128 (same box, alternating runs; tests/test_lba_gpu.py green both ways).
         static const bool fold_ctrl = [] { const char* e = getenv("OSLAM_LBA_FOLD_CTRL"); return e && atoi(e) != 0; }();
+        // lanes per landmark in k_w_update (OSLAM_LBA_UPD_LANES = 1 / 2 / 4 overrides).  us per LM trial of a call, 1 / 2 / 4 lanes, same box, two sweeps: 40 windows
+        // 293 / 279 / 283, 96 windows 494 / 485 / 498, 128 windows 639 / 616 / 641, 256 windows 1223 / 1180 / 1232: the one-lane form waits (~8 edges walked twice in one
+        // dependent chain), four lanes repeat the per-landmark part (inverse, step, stores) four times
+        static const int upd_lanes_env = getenv("OSLAM_LBA_UPD_LANES") ? atoi(getenv("OSLAM_LBA_UPD_LANES")) : 0;
+        const int upd_lanes = upd_lanes_env ? upd_lanes_env : 2;
         int slots_done = 0, group = min_group;
         while (slots_done < max_slots) {
             for (int sl = 0; sl < group; sl++, slots_done++) {
@@ -2990,13 +3015,15 @@ static int lba_launch(oslam_lba_t* h) {
                 else if (chol_lds) hipLaunchKernelGGL(k_w_chol<true>, dim3(1, n0), dim3(1024), chol_lds, st, d_probs, d_ws);
                 else hipLaunchKernelGGL(k_w_chol<false>, dim3(1, n0), dim3(1024), 0, st, d_probs, d_ws);
                 // (+ the trial's chi2: k_w_eval of rounds 1-3; OSLAM_LBA_FOLD_CTRL=1: + the LM control step in the window's last workgroup)
-                if (fold_ctrl) {
-                    if (use_rec) hipLaunchKernelGGL((k_w_update<true, true>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                    else hipLaunchKernelGGL((k_w_update<false, true>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                } else {
-                    if (use_rec) hipLaunchKernelGGL((k_w_update<true, false>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                    else hipLaunchKernelGGL((k_w_update<false, false>), dim3(maxNbPt + 1, ny_xcd), dim3(kWPt), 0, st, d_probs, d_ws, n0);
-                    hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
+                {
+                    const dim3 ug(maxNbPt + 1, ny_xcd);
+#define OSLAM_UPD_LAUNCH(R, F, L) hipLaunchKernelGGL((k_w_update<R, F, L>), ug, dim3(kWPt * L), 0, st, d_probs, d_ws, n0)
+#define OSLAM_UPD_LANES(R, F) do { if (upd_lanes == 4) OSLAM_UPD_LAUNCH(R, F, 4); else if (upd_lanes == 2) OSLAM_UPD_LAUNCH(R, F, 2); else OSLAM_UPD_LAUNCH(R, F, 1); } while (0)
+                    if (fold_ctrl) { if (use_rec) OSLAM_UPD_LANES(true, true); else OSLAM_UPD_LANES(false, true); }
+                    else { if (use_rec) OSLAM_UPD_LANES(true, false); else OSLAM_UPD_LANES(false, false); }
+#undef OSLAM_UPD_LANES
+#undef OSLAM_UPD_LAUNCH
+                    if (!fold_ctrl) hipLaunchKernelGGL(k_w_ctrlB, dim3(1, n0), dim3(256), 0, st, d_probs, d_ws);
                 }
             }
             OSLAM_HIP_CHECK(copy_to_host_async(h->h_ctrl, Wk + ctrl_base, sizeof(LbaCtrl) * n0, st));   // (a copy kernel, not the SDMA ring: common.h)
