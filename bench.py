@@ -522,7 +522,17 @@ def main():
     log = (lambda m: (sys.stderr.write("[bench] " + m + "\n"), sys.stderr.flush())) if rank == 0 else None
     # ---- render the input streams on the host cores BEFORE the process touches the GPU (worker processes are forked) ----
     t_gen = time.perf_counter()
-    seq_head = seqbench.base_sequences(head, rank, S, n_frames, workers=share)
+    # OSLAM_BENCH_SHARED_BASES=1 (multi-rank runs): the node's ranks replay ONE set of rendered base streams mapped from a shared-memory segment instead of
+    # rendering a set each (seqbench.shared_base_sequences; every rank then runs rank 0's streams: identical work per rank).  Any failure falls back to private sets.
+    seq_head = None
+    if world > 1 and os.environ.get("OSLAM_BENCH_SHARED_BASES"):
+        try:
+            seq_head = seqbench.shared_base_sequences(head, local_rank, local_world, S, n_frames, tag=os.environ.get("MASTER_PORT", "0"), workers=share, log=log)
+        except Exception as ex:     # (no segment within the time limit, no room in /dev/shm, ...)
+            sys.stderr.write("[bench] rank %d: shared base streams unavailable (%r): rendering a private set\n" % (rank, ex))
+            seq_head = None
+    if seq_head is None:
+        seq_head = seqbench.base_sequences(head, rank, S, n_frames, workers=share)
     seq_second = None
     pre2 = 0
     if extras_on:            # second figure: the other stream shape in ITS steady state (rank 0 of a single-rank run only)

@@ -6,6 +6,7 @@ barriers around the timed region, the max-over-ranks wall time and ONE all-gathe
 bench.py and tests/test_parallel_gloo.py call the same entry point, `run_rank`; the operator table comes from `make_system`
 (the product binds the HIP table; the gloo test passes a factory that binds the CPU oracle's table — nothing here imports oracle/).
 """
+import os
 import threading
 import time
 
@@ -169,6 +170,85 @@ def base_sequences(wl, rank, seqs_per_rank, n_frames, workers=1, chunk=24, have=
                 q[key] = np.ascontiguousarray(np.concatenate([p[key] for p in ps], 0))
         q["stream_seed"] = wl.n_base * rank + b
         out[b] = q
+    return out
+
+
+_SHARED_KEYS = ("gray", "right", "depth", "masks", "Twc")
+
+
+def shared_base_sequences(wl, local_rank, local_world, seqs_per_rank, n_frames, tag, workers=1, shm_dir="/dev/shm", timeout_s=900.0, log=None):
+    """The base streams of ONE node rendered once and mapped by all of its ranks: local rank 0 renders rank 0's base streams
+    (`base_sequences(wl, 0, ...)`) straight into files under `shm_dir` (tmpfs: one copy in memory for the node, page-shared by the ranks' read-only mappings),
+    the other local ranks wait for its `ready` marker and map the same files.  Every rank then replays the SAME base streams (weak scaling: identical work per
+    rank); without sharing, rank r renders its own seeds `n_base * r + b`.  `tag` must be the same on the node's ranks and unique per job (bench.py:
+    MASTER_PORT).  The files are unlinked as soon as every local rank has mapped them (the mappings stay valid), so nothing is left behind if a rank dies later;
+    a rank that cannot get the segment within `timeout_s` raises TimeoutError (bench.py then renders privately)."""
+    import json
+    import time
+    base = os.path.join(shm_dir, "oslam_bases_%s_%s" % (tag, wl.name.replace(" ", "_")))
+    ready, meta_path = base + ".ready", base + ".meta.json"
+
+    def mapped_marker(r):
+        return base + ".mapped%d" % r
+
+    if local_rank == 0:
+        for stale in [ready, meta_path] + [mapped_marker(r) for r in range(local_world)]:
+            if os.path.exists(stale):
+                os.unlink(stale)
+        seqs = base_sequences(wl, 0, seqs_per_rank, n_frames, workers=workers)
+        meta = {}
+        out = {}
+        for b, q in seqs.items():
+            mb, qb = {}, {}
+            for k, v in q.items():
+                if isinstance(v, np.ndarray):
+                    path = "%s.b%d.%s.npy" % (base, b, k)
+                    mm = np.lib.format.open_memmap(path, mode="w+", dtype=v.dtype, shape=v.shape)
+                    mm[...] = v
+                    mm.flush()
+                    del mm
+                    big = k in _SHARED_KEYS
+                    qb[k] = np.load(path, mmap_mode="r") if big else v      # rank 0 reads the shared copy of the images too and drops its private one
+                    mb[k] = {"npy": path, "mmap": big}
+                else:
+                    qb[k] = v
+                    mb[k] = v
+            meta[str(b)] = mb
+            out[b] = qb
+        with open(meta_path + ".tmp", "w") as fh:
+            json.dump(meta, fh)
+        os.replace(meta_path + ".tmp", meta_path)
+        open(ready, "w").close()
+        open(mapped_marker(0), "w").close()
+        t0 = time.time()
+        while not all(os.path.exists(mapped_marker(r)) for r in range(local_world)):   # then the names can go: the mappings keep the pages
+            if time.time() - t0 > timeout_s:
+                break
+            time.sleep(0.05)
+        for b, mb in meta.items():
+            for k, v in mb.items():
+                if isinstance(v, dict) and "npy" in v and os.path.exists(v["npy"]):
+                    os.unlink(v["npy"])
+        for f in [ready, meta_path] + [mapped_marker(r) for r in range(local_world)]:
+            if os.path.exists(f):
+                os.unlink(f)
+        if log:
+            log("base streams shared through %s (%d local ranks)" % (shm_dir, local_world))
+        return out
+    t0 = time.time()
+    while not os.path.exists(ready):
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError("shared base streams: local rank 0 did not publish %s within %.0f s" % (ready, timeout_s))
+        time.sleep(0.05)
+    with open(meta_path) as fh:
+        meta = json.load(fh)
+    out = {}
+    for b, mb in meta.items():
+        q = {}
+        for k, v in mb.items():
+            q[k] = (np.load(v["npy"], mmap_mode="r") if v["mmap"] else np.load(v["npy"])) if (isinstance(v, dict) and "npy" in v) else v
+        out[int(b)] = q
+    open(mapped_marker(local_rank), "w").close()
     return out
 
 

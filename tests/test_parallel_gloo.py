@@ -142,3 +142,36 @@ def test_run_rank_world4_with_unequal_shards(oracle):
     for r in res:
         for p in r[4]:
             assert p.shape[0] == 3 and p.shape[-2:] == (4, 4) and np.array_equal(p[0, 0], np.eye(4, dtype=np.float32))
+
+
+def _shared_worker(local_rank, local_world, tag, shm_dir, q):
+    from object_slam_amd import seqbench
+    wl = seqbench.rgbd_workload(n_base=2, stagger=1, with_masks=True)
+    seqs = seqbench.shared_base_sequences(wl, local_rank, local_world, 2, 3, tag, workers=1, shm_dir=shm_dir, timeout_s=120.0)
+    import hashlib
+    dig = {b: {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in s.items() if isinstance(v, np.ndarray)} for b, s in seqs.items()}
+    mapped = {b: isinstance(s["gray"], np.memmap) for b, s in seqs.items()}
+    q.put((local_rank, dig, mapped, {b: int(s["stream_seed"]) for b, s in seqs.items()}))
+
+
+def test_base_streams_shared_between_the_ranks_of_a_node(tmp_path):
+    """One segment for the node's rendered base streams (seqbench.shared_base_sequences, bench.py OSLAM_BENCH_SHARED_BASES=1): local rank 0 renders, the others
+    map; every rank sees rank 0's streams bit for bit, the images are file mappings (one copy for the node) and no file is left behind."""
+    from object_slam_amd import seqbench
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    ps = [ctx.Process(target=_shared_worker, args=(r, world, "t%d" % os.getpid(), str(tmp_path), q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    wl = seqbench.rgbd_workload(n_base=2, stagger=1, with_masks=True)
+    import hashlib
+    ref = seqbench.base_sequences(wl, 0, 2, 3)
+    ref_dig = {b: {k: hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() for k, v in s.items() if isinstance(v, np.ndarray)} for b, s in ref.items()}
+    for r in res:
+        assert r[1] == ref_dig and all(r[2].values()) and r[3] == {0: 0, 1: 1}
+    assert os.listdir(str(tmp_path)) == []
