@@ -817,7 +817,8 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                 }
             };
             for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
-                // (the edge's inputs are requested together with its level byte, not after it)
+                // (the edge's inputs are requested together with its level byte, not after it; requesting them one edge AHEAD of the arithmetic as well was measured:
+                // 55 -> 61 us per launch of 40 windows — the kernel already spills at its 128-register cap)
                 const uint8_t lv = pr.level[e];
                 const int a = pr.e_kf[e];
                 float o0, o1, ur, inf;
@@ -862,7 +863,9 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         const int e = pr.pose_edges[q];
         const uint8_t lv = pr.level[e];
         const int p = pr.e_pt[e];
-        const float o0 = pr.e_obs[e * 3], o1 = pr.e_obs[e * 3 + 1], ur = pr.e_obs[e * 3 + 2], inf = pr.e_info[e];
+        float o0, o1, ur, inf;
+        if (REC && w.eoi) { const float4 oi = w.eoi[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }   // (one 16-byte gather instead of four 4-byte ones)
+        else { o0 = pr.e_obs[e * 3]; o1 = pr.e_obs[e * 3 + 1]; ur = pr.e_obs[e * 3 + 2]; inf = pr.e_info[e]; }
         const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
         if (lv != 0) continue;
         const bool stereo = !(ur < 0);
