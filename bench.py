@@ -697,6 +697,10 @@ def main():
             c, _ = run(head, seq_head, S, G, "cold")
             cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
                     "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
+        # (the second workload runs right behind the headline, before the 32-base leg: after TWO 8192-sequence legs have come and gone in the process its device-side
+        # stages ran 1.5-2x slower — 12.5 / 16.1 k against 22.8 k frames/s for the same workload in a fresh process: gpurun_out of round 5)
+        s2, _ = run(second, seq_second, S2, G2, "second", pre2)
+        roof2 = roofline_of(kt["second"], s2, second is wl_st)
         if seq_b32 is not None:
             try:
                 sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll)
@@ -710,8 +714,6 @@ def main():
             except Exception as ex:
                 bases32 = {"error": repr(ex)}; extras_failed.append("bases32")
             seq_b32 = None
-        s2, _ = run(second, seq_second, S2, G2, "second", pre2)
-        roof2 = roofline_of(kt["second"], s2, second is wl_st)
         cpu2 = None
         if not args.no_cpu_baseline:
             if log:
