@@ -97,7 +97,7 @@ typedef struct oslam_slam_config {
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct oslam_slam_frame {          /* what Frame::Frame leaves behind (src/Frame.cc:117-172) */
     int32_t N;
-    oslam_keypoint_t* keys;                /* mvKeys   [cap] */
+    oslam_keypoint_t* keys;                /* mvKeys   [cap] (a table with oslam_slam_ops_t::keyframe_raw_keys may leave them untouched) */
     oslam_keypoint_t* keysUn;              /* mvKeysUn [cap] */
     uint8_t* desc;                         /* mDescriptors [cap][32] */
     float* uRight;                         /* mvuRight [cap] */
@@ -335,6 +335,11 @@ typedef struct oslam_slam_ops {
      * table; operators called in between see the job's effects on the resident records (same stream order).  The driver uses it for the descriptor updates that
      * follow every ORBmatcher::Fuse round of SearchInNeighbors (MapPoint::Replace -> ComputeDistinctiveDescriptors, src/MapPoint.cc:314): the next round's host
      * bookkeeping and search are issued behind the update instead of waiting for it. */
+    /* optional, with register_keyframes (round 5): mvKeys on demand.  A table that offers it may leave oslam_slam_frame_t::keys of every frame untouched; the driver
+     * then asks for the raw keypoints of the frames that BECAME keyframes — right after register_keyframes, for the same slots: out[q] receives counts[q] keypoints —
+     * because only KeyFrame::UnprojectStereo reads them (src/KeyFrame.cc:620-621, called by CreateNewMapPoints).  One frame in ~15 becomes a keyframe: 28 of the 96
+     * bytes per keypoint a frame sends back to the host stay on the device. */
+    int (*keyframe_raw_keys)(void* ctx, int n, const int32_t* slots, const int32_t* counts, oslam_keypoint_t* const* out);
     int (*mp_update_keyed_async)(void* ctx, oslam_job_mp_update_t* job, const int32_t* obs_key);
     int (*mp_update_collect)(void* ctx);
 } oslam_slam_ops_t;

@@ -176,6 +176,7 @@ struct Seq {
     std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj, jObjIds;
     oslam_job_pose2_t jPose2; bool hasPose2 = false;
     const oslam_slam_objects_t* det = nullptr;           // this step's detections (NULL or n == 0: none)
+    bool lazyKeys = false;                // the table hands mvKeys out for keyframes only (oslam_slam_ops_t::keyframe_raw_keys)
     int64_t opFailures = 0;               // operator errors confined to this sequence (its map was reset: local_mapping_back)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
     void reset() {                        // Tracking::Reset (:1769-1815) + LocalMapping::ResetIfRequested + Map::clear; id counters restart at 0
@@ -287,7 +288,7 @@ static int new_keyframe(Seq& s, const Frame& f, float thDepth) {
     KeyFrm& k = s.map.kfs.back();
     k.id = (int)s.map.kfs.size() - 1;
     k.frameId = f.id; k.stamp = f.stamp; k.N = f.N;
-    k.keys.assign(f.keys.begin(), f.keys.begin() + f.N);
+    if (!s.lazyKeys) k.keys.assign(f.keys.begin(), f.keys.begin() + f.N);   // (else: fetched for the new keyframes only, after register_keyframes)
     k.keysUn.assign(f.keysUn.begin(), f.keysUn.begin() + f.N);
     k.oct.resize(f.N);
     for (int i = 0; i < f.N; i++) k.oct[i] = (uint8_t)f.keysUn[i].octave;   // (KeyFrameCulling reads the octaves alone: 1 byte per keypoint instead of a pass over the 28-byte records)
@@ -2214,6 +2215,16 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             c.seq[i]->pendingKF.clear();
         }
         if (!rs.empty() && (rc = c.ops.register_keyframes(c.ops.ctx, (int)rs.size(), rs.data(), rk.data()))) return rc;
+        if (!rs.empty() && c.ops.keyframe_raw_keys) {   // mvKeys of the new keyframes (KeyFrame::UnprojectStereo in CreateNewMapPoints reads them; no frame does)
+            std::vector<int32_t> cnt(rs.size());
+            std::vector<oslam_keypoint_t*> outp(rs.size());
+            for (size_t q = 0; q < rs.size(); q++) {
+                KeyFrm& k = c.seq[rs[q]]->map.kfs[rk[q]];
+                k.keys.resize(k.N);
+                cnt[q] = k.N; outp[q] = (oslam_keypoint_t*)k.keys.data();
+            }
+            if ((rc = c.ops.keyframe_raw_keys(c.ops.ctx, (int)rs.size(), rs.data(), cnt.data(), outp.data()))) return rc;
+        }
         if (!rs.empty() && c.ops.bow_nodes_keyed) {   // KeyFrame::ComputeBoW of the new keyframes from their resident descriptors (ProcessNewKeyFrame finds it done)
             std::vector<int32_t> cnt(rs.size());
             std::vector<uint32_t*> outp(rs.size());
@@ -2317,6 +2328,7 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
         c.seq.back()->fb.alloc(c.cap);
         c.seq.back()->counter.assign(64, 0);
         // the table keeps a device mirror of the observation graph: the maps journal their changes (slam_map.h)
+        c.seq.back()->lazyKeys = c.ops.keyframe_raw_keys != nullptr && c.ops.register_keyframes != nullptr;
         c.seq.back()->map.jrOn = c.ops.map_journal && c.ops.kf_culling_counts && (cfg->local_mapping & 16) && !getenv("OSLAM_SLAM_CULL_HOST");
     }
     *out = h;

@@ -65,6 +65,8 @@ struct HipOps {
     uint8_t* upB_h = nullptr; uint8_t* upB_d = nullptr; size_t upB_cap = 0;
     uint8_t* dnB_h = nullptr; size_t dnB_cap = 0;
     hipEvent_t tevB0 = nullptr, tevB1 = nullptr;
+    bool lazy_keys = false;                          // frames do not send mvKeys back; register_keyframes stages the new keyframes' rows for keyframe_raw_keys
+    uint8_t* kfk_h = nullptr; size_t kfk_cap = 0; std::vector<int32_t> kfk_slots;
     struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; } mpu_pend;
     void swap_staging() { std::swap(up_h, upB_h); std::swap(up_d, upB_d); std::swap(up_cap, upB_cap); std::swap(dn_h, dnB_h); std::swap(dn_cap, dnB_cap); std::swap(tev0, tevB0); std::swap(tev1, tevB1); }
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
@@ -302,7 +304,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oCnt, d_cnt, 4 * (size_t)n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt, d_st, 4, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
+    if (!o->lazy_keys) OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
@@ -316,7 +318,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
         oslam_slam_frame_t* f = out[i];
         const size_t N = cnt[i], at = (size_t)i * cap;
         f->N = (int)N;
-        memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
+        if (!o->lazy_keys) memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
         memcpy(f->keysUn, D + oKeysUn + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
         memcpy(f->desc, D + oDesc + at * 32, N * 32);
         memcpy(f->uRight, D + oUr + at * 4, N * 4);
@@ -893,6 +895,18 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
 int h_mp_update_collect(void* p);
 int h_mp_update(void* p, oslam_job_mp_update_t* j) { int rc = h_mp_update_collect(p); return rc ? rc : mp_update_impl((HipOps*)p, j, nullptr); }
 int h_mp_update_keyed(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) { int rc = h_mp_update_collect(p); return rc ? rc : mp_update_impl((HipOps*)p, j, obs_key); }
+// mvKeys of the keyframes registered by the LAST register_keyframes call (include/oslam_slam.h): staged by that call's copy launch, handed out here
+int h_keyframe_raw_keys(void* p, int n, const int32_t* slots, const int32_t* counts, oslam_keypoint_t* const* out) {
+    HipOps* o = (HipOps*)p;
+    if (!o->lazy_keys) { oslam::set_error("keyframe_raw_keys: the table sends mvKeys with every frame"); return OSLAM_E_INVALID; }
+    if (n != (int)o->kfk_slots.size()) { oslam::set_error("keyframe_raw_keys: not the keyframes of the last register_keyframes call"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap;
+    for (int i = 0; i < n; i++) {
+        if (slots[i] != o->kfk_slots[i] || counts[i] < 0 || (size_t)counts[i] > cap) { oslam::set_error("keyframe_raw_keys: not the keyframes of the last register_keyframes call"); return OSLAM_E_INVALID; }
+        memcpy(out[i], o->kfk_h + (size_t)i * cap * sizeof(oslam_keypoint_t), (size_t)counts[i] * sizeof(oslam_keypoint_t));
+    }
+    return OSLAM_OK;
+}
 // The deferred form: only the one-launch path (k_mp_update_fused) is deferred — it needs no staging beyond the job block and writes its results into a pinned
 // block by itself; any other job is run to completion here (mp_update_collect then has nothing to wait for).
 int h_mp_update_keyed_async(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) {
@@ -1416,6 +1430,19 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         segs.push_back({(const uint8_t*)(o->d_keysUn + cap * slot), (uint8_t*)o->rec_keys(r), (uint32_t)(cap * sizeof(oslam_keypoint_t)), 0});
         segs.push_back({o->d_desc + 32 * cap * slot, (uint8_t*)o->rec_desc(r), (uint32_t)(cap * 32), 0});
         segs.push_back({(const uint8_t*)(o->cur_uRight + cap * slot), (uint8_t*)o->rec_ur(r), (uint32_t)(cap * 4), 0});
+    }
+    if (o->lazy_keys) {   // mvKeys of the new keyframes: written by the same launch into a pinned block the device can address (keyframe_raw_keys hands them out)
+        const size_t need = (size_t)n * cap * sizeof(oslam_keypoint_t);
+        if (need > o->kfk_cap) {
+            OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+            if (o->kfk_h) (void)hipHostFree(o->kfk_h);
+            o->kfk_h = nullptr; o->kfk_cap = 0;
+            OSLAM_HIP_CHECK(hipHostMalloc((void**)&o->kfk_h, need + need / 2 + 4096, 0));
+            o->kfk_cap = need + need / 2 + 4096;
+        }
+        o->kfk_slots.assign(slots, slots + n);
+        for (int i = 0; i < n; i++)
+            segs.push_back({(const uint8_t*)(o->d_kp + cap * slots[i]), o->kfk_h + (size_t)i * cap * sizeof(oslam_keypoint_t), (uint32_t)(cap * sizeof(oslam_keypoint_t)), 0});
     }
     const size_t oJobs = oslam::align_up(segs.size() * sizeof(CopySegH), 256), up_bytes = oJobs + (size_t)n * sizeof(oslam_kf_grid_job_t);
     OPS_CHECK(o->ensure_up(up_bytes));
@@ -1993,6 +2020,7 @@ void h_destroy(void* p) {
     if (o->tevB0) (void)hipEventDestroy(o->tevB0);
     if (o->tevB1) (void)hipEventDestroy(o->tevB1);
     if (o->upB_h) (void)hipHostFree(o->upB_h);
+    if (o->kfk_h) (void)hipHostFree(o->kfk_h);
     if (o->upB_d) (void)hipFree(o->upB_d);
     if (o->dnB_h) (void)hipHostFree(o->dnB_h);
     if (o->tev1) (void)hipEventDestroy(o->tev1);
@@ -2078,7 +2106,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; }
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; if (!getenv("OSLAM_SLAM_EAGER_KEYS")) { o->lazy_keys = true; ops->keyframe_raw_keys = h_keyframe_raw_keys; } ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
     return OSLAM_OK;
