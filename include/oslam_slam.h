@@ -99,7 +99,7 @@ typedef struct oslam_slam_frame {          /* what Frame::Frame leaves behind (s
     int32_t N;
     oslam_keypoint_t* keys;                /* mvKeys   [cap] (a table with oslam_slam_ops_t::keyframe_raw_keys may leave them untouched) */
     oslam_keypoint_t* keysUn;              /* mvKeysUn [cap] */
-    uint8_t* desc;                         /* mDescriptors [cap][32] */
+    uint8_t* desc;                         /* mDescriptors [cap][32] (a table with oslam_slam_ops_t::frame_descriptors may leave them untouched) */
     float* uRight;                         /* mvuRight [cap] */
     float* depth;                          /* mvDepth  [cap] */
 } oslam_slam_frame_t;
@@ -340,6 +340,12 @@ typedef struct oslam_slam_ops {
      * because only KeyFrame::UnprojectStereo reads them (src/KeyFrame.cc:620-621, called by CreateNewMapPoints).  One frame in ~15 becomes a keyframe: 28 of the 96
      * bytes per keypoint a frame sends back to the host stay on the device. */
     int (*keyframe_raw_keys)(void* ctx, int n, const int32_t* slots, const int32_t* counts, oslam_keypoint_t* const* out);
+    /* optional pair, with keyframe_raw_keys (round 5): mDescriptors on demand.  A table that offers both may leave oslam_slam_frame_t::desc of every frame untouched.
+     * keyframe_descriptors: like keyframe_raw_keys, for the descriptors of the frames that became keyframes (the host copy KeyFrame::mDescriptors).
+     * frame_descriptors: the descriptors of the CURRENT frames of `slots` (valid until the next frames_* call) — the driver asks for them when a frame takes the
+     * TrackReferenceKeyFrame path, whose Frame::ComputeBoW runs on the host (src/Tracking.cc:841); every other reader of a frame's descriptors is an operator. */
+    int (*keyframe_descriptors)(void* ctx, int n, const int32_t* slots, const int32_t* counts, uint8_t* const* out);
+    int (*frame_descriptors)(void* ctx, int n, const int32_t* slots, const int32_t* counts, uint8_t* const* out);
     int (*mp_update_keyed_async)(void* ctx, oslam_job_mp_update_t* job, const int32_t* obs_key);
     int (*mp_update_collect)(void* ctx);
 } oslam_slam_ops_t;

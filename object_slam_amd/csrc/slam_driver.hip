@@ -176,6 +176,7 @@ struct Seq {
     std::vector<float> jObjXw; std::vector<int32_t> jObjOf, jJointKp, jJointObj, jObjIds;
     oslam_job_pose2_t jPose2; bool hasPose2 = false;
     const oslam_slam_objects_t* det = nullptr;           // this step's detections (NULL or n == 0: none)
+    bool lazyDesc = false;                // the same for mDescriptors (keyframe_descriptors / frame_descriptors)
     bool lazyKeys = false;                // the table hands mvKeys out for keyframes only (oslam_slam_ops_t::keyframe_raw_keys)
     int64_t opFailures = 0;               // operator errors confined to this sequence (its map was reset: local_mapping_back)
     bool resetRequested = false;          // System::Reset() asked by Track() (lost with <= 5 keyframes, reference src/Tracking.cc:553-561)
@@ -292,7 +293,7 @@ static int new_keyframe(Seq& s, const Frame& f, float thDepth) {
     k.keysUn.assign(f.keysUn.begin(), f.keysUn.begin() + f.N);
     k.oct.resize(f.N);
     for (int i = 0; i < f.N; i++) k.oct[i] = (uint8_t)f.keysUn[i].octave;   // (KeyFrameCulling reads the octaves alone: 1 byte per keypoint instead of a pass over the 28-byte records)
-    k.desc.assign(f.desc.begin(), f.desc.begin() + (size_t)f.N * 32);
+    if (!s.lazyDesc) k.desc.assign(f.desc.begin(), f.desc.begin() + (size_t)f.N * 32);   // (else: after register_keyframes, like mvKeys)
     k.uRight.assign(f.uRight.begin(), f.uRight.begin() + f.N);
     k.depth.assign(f.depth.begin(), f.depth.begin() + f.N);
     k.mp.assign(f.mp.begin(), f.mp.begin() + f.N);
@@ -2112,6 +2113,12 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
             std::vector<BowViews> bv(rk.size());
             std::vector<std::vector<uint8_t>> flag(rk.size());
             std::vector<std::vector<int32_t>> match(rk.size());
+            if (c.seq[rk[0]]->lazyDesc) {   // Frame::ComputeBoW below runs on the host: these frames' descriptors are fetched now
+                std::vector<int32_t> cnt(rk.size());
+                std::vector<uint8_t*> outd(rk.size());
+                for (size_t q = 0; q < rk.size(); q++) { Frame& f = *c.seq[rk[q]]->cur; cnt[q] = f.N; outd[q] = f.desc.data(); }
+                if ((rc = c.ops.frame_descriptors(c.ops.ctx, (int)rk.size(), rk.data(), cnt.data(), outd.data()))) return rc;
+            }
             pool.parallel_for((int)rk.size(), [&](int q) {
                 Seq& s = *c.seq[rk[q]];
                 Frame& f = *s.cur;
@@ -2224,6 +2231,15 @@ static int track_step(Ctx& c, const uint8_t* const* gray, const uint8_t* const* 
                 cnt[q] = k.N; outp[q] = (oslam_keypoint_t*)k.keys.data();
             }
             if ((rc = c.ops.keyframe_raw_keys(c.ops.ctx, (int)rs.size(), rs.data(), cnt.data(), outp.data()))) return rc;
+            if (c.seq[rs[0]]->lazyDesc) {   // KeyFrame::mDescriptors of the new keyframes (the frames' own descriptors stay on the device)
+                std::vector<uint8_t*> outd(rs.size());
+                for (size_t q = 0; q < rs.size(); q++) {
+                    KeyFrm& k = c.seq[rs[q]]->map.kfs[rk[q]];
+                    k.desc.resize((size_t)k.N * 32);
+                    outd[q] = k.desc.data();
+                }
+                if ((rc = c.ops.keyframe_descriptors(c.ops.ctx, (int)rs.size(), rs.data(), cnt.data(), outd.data()))) return rc;
+            }
         }
         if (!rs.empty() && c.ops.bow_nodes_keyed) {   // KeyFrame::ComputeBoW of the new keyframes from their resident descriptors (ProcessNewKeyFrame finds it done)
             std::vector<int32_t> cnt(rs.size());
@@ -2329,6 +2345,7 @@ int oslam_slam_create_with_ops(oslam_slam_t** out, const oslam_slam_config_t* cf
         c.seq.back()->counter.assign(64, 0);
         // the table keeps a device mirror of the observation graph: the maps journal their changes (slam_map.h)
         c.seq.back()->lazyKeys = c.ops.keyframe_raw_keys != nullptr && c.ops.register_keyframes != nullptr;
+        c.seq.back()->lazyDesc = c.seq.back()->lazyKeys && c.ops.keyframe_descriptors != nullptr && c.ops.frame_descriptors != nullptr && c.ops.bow_keyed != nullptr;
         c.seq.back()->map.jrOn = c.ops.map_journal && c.ops.kf_culling_counts && (cfg->local_mapping & 16) && !getenv("OSLAM_SLAM_CULL_HOST");
     }
     *out = h;

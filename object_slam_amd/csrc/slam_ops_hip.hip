@@ -65,6 +65,7 @@ struct HipOps {
     uint8_t* upB_h = nullptr; uint8_t* upB_d = nullptr; size_t upB_cap = 0;
     uint8_t* dnB_h = nullptr; size_t dnB_cap = 0;
     hipEvent_t tevB0 = nullptr, tevB1 = nullptr;
+    bool lazy_desc = false;                          // the same for mDescriptors (keyframe_descriptors / frame_descriptors)
     bool lazy_keys = false;                          // frames do not send mvKeys back; register_keyframes stages the new keyframes' rows for keyframe_raw_keys
     uint8_t* kfk_h = nullptr; size_t kfk_cap = 0; std::vector<int32_t> kfk_slots;
     struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; } mpu_pend;
@@ -306,7 +307,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oSt + 4, o->d_status, 4, hipMemcpyDeviceToHost, o->strm));
     if (!o->lazy_keys) OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeys, d_kp, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oKeysUn, o->d_keysUn, sizeof(oslam_keypoint_t) * cap * n, hipMemcpyDeviceToHost, o->strm));
-    OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, o->strm));
+    if (!o->lazy_desc) OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDesc, d_desc, 32 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oUr, d_uR, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(hipMemcpyAsync(D + oDp, d_dp, 4 * cap * n, hipMemcpyDeviceToHost, o->strm));
     OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
@@ -320,7 +321,7 @@ static int download_frames(HipOps* o, int n, const oslam_keypoint_t* d_kp, const
         f->N = (int)N;
         if (!o->lazy_keys) memcpy(f->keys, D + oKeys + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
         memcpy(f->keysUn, D + oKeysUn + at * sizeof(oslam_keypoint_t), N * sizeof(oslam_keypoint_t));
-        memcpy(f->desc, D + oDesc + at * 32, N * 32);
+        if (!o->lazy_desc) memcpy(f->desc, D + oDesc + at * 32, N * 32);
         memcpy(f->uRight, D + oUr + at * 4, N * 4);
         memcpy(f->depth, D + oDp + at * 4, N * 4);
     });
@@ -907,6 +908,38 @@ int h_keyframe_raw_keys(void* p, int n, const int32_t* slots, const int32_t* cou
     }
     return OSLAM_OK;
 }
+int h_keyframe_descriptors(void* p, int n, const int32_t* slots, const int32_t* counts, uint8_t* const* out) {
+    HipOps* o = (HipOps*)p;
+    if (!o->lazy_desc || n != (int)o->kfk_slots.size()) { oslam::set_error("keyframe_descriptors: not the keyframes of the last register_keyframes call"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap;
+    const uint8_t* base = o->kfk_h + (size_t)n * cap * sizeof(oslam_keypoint_t);
+    for (int i = 0; i < n; i++) {
+        if (slots[i] != o->kfk_slots[i] || counts[i] < 0 || (size_t)counts[i] > cap) { oslam::set_error("keyframe_descriptors: not the keyframes of the last register_keyframes call"); return OSLAM_E_INVALID; }
+        memcpy(out[i], base + (size_t)i * cap * 32, (size_t)counts[i] * 32);
+    }
+    return OSLAM_OK;
+}
+// mDescriptors of the current frames of `slots`, from the extractor's batch arrays (still on the device until the next Frame::Frame stage)
+int h_frame_descriptors(void* p, int n, const int32_t* slots, const int32_t* counts, uint8_t* const* out) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if (!o->d_desc) { oslam::set_error("frame_descriptors: no frame has been built yet"); return OSLAM_E_INVALID; }
+    const size_t cap = o->cap;
+    OPS_CHECK(o->ensure_dn((size_t)n * cap * 32));
+    std::vector<CopySegH> segs(n);
+    for (int i = 0; i < n; i++) {
+        if (slots[i] < 0 || slots[i] >= o->S || counts[i] < 0 || (size_t)counts[i] > cap) { oslam::set_error("frame_descriptors: bad slot / count"); return OSLAM_E_INVALID; }
+        segs[i] = {o->d_desc + 32 * cap * slots[i], o->dn_h + (size_t)i * cap * 32, (uint32_t)(cap * 32), 0};
+    }
+    OPS_CHECK(o->ensure_up(segs.size() * sizeof(CopySegH)));
+    memcpy(o->up_h, segs.data(), segs.size() * sizeof(CopySegH));
+    OSLAM_HIP_CHECK(hipMemcpyAsync(o->up_d, o->up_h, segs.size() * sizeof(CopySegH), hipMemcpyHostToDevice, o->strm));
+    OPS_CHECK(oslam_copy_segments_device(o->up_d, (int)segs.size(), o->strm));
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    for (int i = 0; i < n; i++) memcpy(out[i], o->dn_h + (size_t)i * cap * 32, (size_t)counts[i] * 32);
+    return OSLAM_OK;
+}
 // The deferred form: only the one-launch path (k_mp_update_fused) is deferred — it needs no staging beyond the job block and writes its results into a pinned
 // block by itself; any other job is run to completion here (mp_update_collect then has nothing to wait for).
 int h_mp_update_keyed_async(void* p, oslam_job_mp_update_t* j, const int32_t* obs_key) {
@@ -1432,7 +1465,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         segs.push_back({(const uint8_t*)(o->cur_uRight + cap * slot), (uint8_t*)o->rec_ur(r), (uint32_t)(cap * 4), 0});
     }
     if (o->lazy_keys) {   // mvKeys of the new keyframes: written by the same launch into a pinned block the device can address (keyframe_raw_keys hands them out)
-        const size_t need = (size_t)n * cap * sizeof(oslam_keypoint_t);
+        const size_t need = (size_t)n * cap * (sizeof(oslam_keypoint_t) + (o->lazy_desc ? 32 : 0));
         if (need > o->kfk_cap) {
             OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
             if (o->kfk_h) (void)hipHostFree(o->kfk_h);
@@ -1443,6 +1476,9 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         o->kfk_slots.assign(slots, slots + n);
         for (int i = 0; i < n; i++)
             segs.push_back({(const uint8_t*)(o->d_kp + cap * slots[i]), o->kfk_h + (size_t)i * cap * sizeof(oslam_keypoint_t), (uint32_t)(cap * sizeof(oslam_keypoint_t)), 0});
+        if (o->lazy_desc)
+            for (int i = 0; i < n; i++)
+                segs.push_back({o->d_desc + 32 * cap * slots[i], o->kfk_h + (size_t)n * cap * sizeof(oslam_keypoint_t) + (size_t)i * cap * 32, (uint32_t)(cap * 32), 0});
     }
     const size_t oJobs = oslam::align_up(segs.size() * sizeof(CopySegH), 256), up_bytes = oJobs + (size_t)n * sizeof(oslam_kf_grid_job_t);
     OPS_CHECK(o->ensure_up(up_bytes));
@@ -2106,7 +2142,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; }
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; if (!getenv("OSLAM_SLAM_EAGER_KEYS")) { o->lazy_keys = true; ops->keyframe_raw_keys = h_keyframe_raw_keys; } ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; if (!getenv("OSLAM_SLAM_EAGER_KEYS")) { o->lazy_keys = true; ops->keyframe_raw_keys = h_keyframe_raw_keys; if (!getenv("OSLAM_SLAM_EAGER_DESC")) { o->lazy_desc = true; ops->keyframe_descriptors = h_keyframe_descriptors; ops->frame_descriptors = h_frame_descriptors; } } ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }
     return OSLAM_OK;

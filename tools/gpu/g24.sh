@@ -9,10 +9,10 @@ python - <<PY
 import json
 d=json.loads(open("gpurun_out/r05_ab_k.json").read().strip().splitlines()[-1])
 st=d["stage_seconds_timed_sum_over_handles"]; co=d["stage_core_seconds_timed_sum_over_handles"]
-print("eager=$OSLAM_SLAM_EAGER_KEYS", d["value"], "kf", d["keyframes"], "frames wall", st["frames"], "core", co["frames"], "dev", d["roofline"]["groups"]["frames"]["device_ms"])
+print("eager=$OSLAM_SLAM_EAGER_DESC", d["value"], "kf", d["keyframes"], "frames wall", st["frames"], "core", co["frames"], "dev", d["roofline"]["groups"]["frames"]["device_ms"])
 PY
 }
-OSLAM_SLAM_EAGER_KEYS=1 run
-unset OSLAM_SLAM_EAGER_KEYS; run
-OSLAM_SLAM_EAGER_KEYS=1 run
-unset OSLAM_SLAM_EAGER_KEYS; run
+OSLAM_SLAM_EAGER_DESC=1 run
+unset OSLAM_SLAM_EAGER_DESC; run
+OSLAM_SLAM_EAGER_DESC=1 run
+unset OSLAM_SLAM_EAGER_DESC; run
