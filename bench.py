@@ -482,7 +482,7 @@ def main():
     ap.add_argument("--lm", choices=("deferred", "sync"), default="sync", help="local-mapping schedule (include/oslam_slam.h): sync (default) = the whole pass right after the frame "
                     "that inserted the keyframe, its local BA solved by the process-wide service in batches shared with the other handles; deferred = the local BA of keyframe "
                     "t is solved while frame t+1 is tracked, its write-back and KeyFrameCulling land before frame t+2 (the reference's two-thread overlap, src/System.cc:95).  "
-                    "On the final code of round 4 sync is the faster one on the headline stream (12 % fewer keyframes, DESIGN.md section 5)")
+                    "On the final code of round 4 sync is the faster one on the headline stream (12 %% fewer keyframes, DESIGN.md section 7.2)")
     ap.add_argument("--handles", type=int, default=0, help="driver handles per GPU, one host thread each (default 8)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline's timed range (default: the timed steps and what the base sequence holds after them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -490,6 +490,8 @@ def main():
     ap.add_argument("--strict", action="store_true", help="exit non-zero when one of the extra legs (front end, local BA alone, host inputs, second workload ...) failed, instead of "
                     "only recording its error in the line")
     ap.add_argument("--no-bases32", action="store_true", help="skip the second headline figure with 32 base renderings (800 distinct input streams)")
+    ap.add_argument("--extras-child-processes", action="store_true", help="run the second workload and the 32-base leg each in a child process of this program instead of "
+                    "inside this process behind the headline (measured in round 5: much slower while the parent process is alive on the card - 4.5 k against 18-22 k stereo frames/s)")
     ap.add_argument("--cold", action="store_true", help="also run the cold-start regime of rounds 1-2 (steps W..W+K of empty maps) on the headline streams")
     args = ap.parse_args()
 
@@ -546,8 +548,11 @@ def main():
     cpu_n2 = args.steps + second.stagger
     # second headline figure: 32 base renderings (800 distinct input streams): the first 8 are the headline's, 24 more are rendered
     seq_b32 = wl_b32 = None
-    if extras_on and not stereo_head and not args.no_bases32 and args.bases < 32 and S >= 32:
+    child_legs = extras_on and args.extras_child_processes
+    want_b32 = extras_on and not stereo_head and not args.no_bases32 and args.bases < 32 and S >= 32
+    if want_b32:
         wl_b32 = seqbench.rgbd_workload(speed=1.0, n_base=32, stagger=24)
+    if want_b32 and not child_legs:
         seq_b32 = seqbench.base_sequences(wl_b32, rank, S, preroll + args.warmup + args.steps + post_frames, workers=share,
                                           have=seq_head if (rank == 0 and head.stagger == wl_b32.stagger) else None)
     t_gen = time.perf_counter() - t_gen
@@ -697,29 +702,74 @@ def main():
             c, _ = run(head, seq_head, S, G, "cold")
             cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
                     "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
-        # (the second workload runs right behind the headline, before the 32-base leg: after TWO 8192-sequence legs have come and gone in the process its device-side
-        # stages ran 1.5-2x slower — 12.5 / 16.1 k against 22.8 k frames/s for the same workload in a fresh process: gpurun_out of round 5)
-        s2, _ = run(second, seq_second, S2, G2, "second", pre2)
-        roof2 = roofline_of(kt["second"], s2, second is wl_st)
-        if seq_b32 is not None:
+        # --extras-child-processes: the second workload and the 32-base leg each in a CHILD PROCESS (this program again, headline only).  Built because the third
+        # 8192-sequence leg of one process runs its device-side stages 1.2-2x slower than the same leg in a fresh process (stereo 12.5 / 16.1 k in-process behind two
+        # legs against 22.8 k alone; whichever leg comes third pays); measured worse still: with the parent process alive on the card the stereo child ran at 4.5 k
+        # and the 32-base child at 33.8 k frames/s.  Default: in-process, the second workload right behind the headline (18.6-22.5 k), the 32-base leg last.
+        def child_leg(tag, extra):
+            import subprocess
             try:
-                sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll)
-                kb = kt["bases32"]
-                bases32 = {"frames_per_s": round(sb["frames_per_s"], 1), "ms_per_step": round(sb["ms_per_step"], 3), "distinct_streams_per_gpu": min(S, wl_b32.n_base * (wl_b32.stagger + 1)),
-                           "replicas_per_stream": round(S / min(S, wl_b32.n_base * (wl_b32.stagger + 1)), 1), "lba_windows_timed": sb["lba_windows_timed"],
-                           "keyframes": sb["keyframes"], "local_bas": sb["local_bas"], "lost_frames": sb["lost_frames"], "ate_rmse_m": round(sb["ate_rmse_m"], 6),
-                           "device_ms_by_group": {g: round(v["ms"], 1) for g, v in kb.items()},
-                           "note": "the headline configuration with 32 base renderings instead of 8: ~10 sequences per distinct input frame instead of ~41 (less cache sharing of the "
-                                   "input images in Frame::Frame); the 24 other scenes insert fewer keyframes, so compare `lba_windows_timed` before comparing frames/s"}
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-extras", "--no-cpu-baseline", "--steps", str(args.steps), "--warmup", str(args.warmup), "--lm", args.lm] + extra
+            if log:
+                log("%s leg in a child process ..." % tag)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError("child leg %s failed (rc %d): %s" % (tag, r.returncode, r.stderr[-1500:]))
+            return json.loads(lines[-1])
+
+        s2 = roof2 = None
+        second_err = None
+        if child_legs:
+            try:
+                c2 = child_leg("second workload", ["--workload", "stereo" if second is wl_st else "rgbd", "--seqs", str(S2), "--handles", str(G2)])
+                s2 = {"frames_per_s": c2["value"], "ms_per_step": c2["ms_per_step"], "ate_rmse_m": c2["ate_rmse_m"], "keyframes": c2["keyframes"], "local_bas": c2["local_bas"],
+                      "lost_frames": c2["lost_frames"], "lba_windows_timed": c2["lba_windows_timed"], "stage_seconds_timed_sum_over_handles": c2.get("stage_seconds_timed_sum_over_handles")}
+                roof2 = c2["roofline"]
             except Exception as ex:
-                bases32 = {"error": repr(ex)}; extras_failed.append("bases32")
-            seq_b32 = None
+                extras_failed.append("second_workload"); s2 = None
+                second_err = repr(ex)
+            if want_b32:
+                try:
+                    cb = child_leg("32-base", ["--bases", "32", "--seqs", str(S), "--handles", str(G)])
+                    bases32 = {"frames_per_s": cb["value"], "ms_per_step": cb["ms_per_step"], "distinct_streams_per_gpu": min(S, wl_b32.n_base * (wl_b32.stagger + 1)),
+                               "replicas_per_stream": round(S / min(S, wl_b32.n_base * (wl_b32.stagger + 1)), 1), "lba_windows_timed": cb["lba_windows_timed"],
+                               "keyframes": cb["keyframes"], "local_bas": cb["local_bas"], "lost_frames": cb["lost_frames"], "ate_rmse_m": cb["ate_rmse_m"],
+                               "device_ms_by_group": {g: round(v["device_ms"], 1) for g, v in cb["roofline"]["groups"].items()}, "process": "child",
+                               "note": "the headline configuration with 32 base renderings instead of 8 (its own process): ~10 sequences per distinct input frame instead of ~41 (less "
+                                       "cache sharing of the input images in Frame::Frame); the 24 other scenes insert fewer keyframes, so compare `lba_windows_timed` before comparing frames/s"}
+                except Exception as ex:
+                    bases32 = {"error": repr(ex)}; extras_failed.append("bases32")
+        else:
+            # (the second workload runs right behind the headline, before the 32-base leg: after TWO 8192-sequence legs have come and gone in the process its device-side
+            # stages ran 1.5-2x slower — 12.5 / 16.1 k against 22.8 k frames/s for the same workload in a fresh process: gpurun_out of round 5)
+            s2, _ = run(second, seq_second, S2, G2, "second", pre2)
+            roof2 = roofline_of(kt["second"], s2, second is wl_st)
+            if seq_b32 is not None:
+                try:
+                    sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll)
+                    kb = kt["bases32"]
+                    bases32 = {"frames_per_s": round(sb["frames_per_s"], 1), "ms_per_step": round(sb["ms_per_step"], 3), "distinct_streams_per_gpu": min(S, wl_b32.n_base * (wl_b32.stagger + 1)),
+                               "replicas_per_stream": round(S / min(S, wl_b32.n_base * (wl_b32.stagger + 1)), 1), "lba_windows_timed": sb["lba_windows_timed"],
+                               "keyframes": sb["keyframes"], "local_bas": sb["local_bas"], "lost_frames": sb["lost_frames"], "ate_rmse_m": round(sb["ate_rmse_m"], 6),
+                               "device_ms_by_group": {g: round(v["ms"], 1) for g, v in kb.items()},
+                               "note": "the headline configuration with 32 base renderings instead of 8: ~10 sequences per distinct input frame instead of ~41 (less cache sharing of the "
+                                       "input images in Frame::Frame); the 24 other scenes insert fewer keyframes, so compare `lba_windows_timed` before comparing frames/s"}
+                except Exception as ex:
+                    bases32 = {"error": repr(ex)}; extras_failed.append("bases32")
+                seq_b32 = None
         cpu2 = None
         if not args.no_cpu_baseline:
             if log:
                 log("CPU baseline of the second workload ...")
             cpu2 = cpu_baseline(second, seq_second, pre2 + args.warmup, cpu_n2, slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC, two_thread_streams=2)
-        second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe; steady state: %d untimed steps, then steps %d..%d timed; "
+        if s2 is None:
+            second_out = {"error": second_err}
+        else:
+          second_out = {"workload": "%s, %d sequences per GPU in %d handles, %d features, local BA on every keyframe; steady state: %d untimed steps, then steps %d..%d timed; "
                                   "BASELINE.json configs[%s]" % (second.name, S2, G2, second.nFeatures, pre2, pre2 + args.warmup, pre2 + args.warmup + args.steps,
                                                                  "3]/[4" if second is wl_st else "2"),
                       "regime": "steady_state", "preroll_steps": pre2,
