@@ -652,6 +652,10 @@ def main():
             rss_gb[tag] = None
         for sy in systems:
             sy.close()
+        del systems, extra
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()   # (the leg's input tensors go back to the driver before the next leg allocates)
         # (malloc_trim(0) here — handing the closed leg's tens of GB of small blocks back to the system — was measured: it lowers the peak RSS of the whole run from 96 to
         # 84 GB and costs the NEXT legs their speed: stereo 22.8 -> 16.3 k frames/s, 32-base leg 46.6 -> 43.8 k, same box, alternating runs; not done)
         return summ, rec
