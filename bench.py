@@ -655,7 +655,7 @@ def main():
         del systems, extra
         import gc
         gc.collect()
-        torch.cuda.empty_cache()   # (the leg's input tensors go back to the driver before the next leg allocates)
+        torch.cuda.empty_cache()   # (the leg's systems and input tensors are gone before the next leg allocates: left referenced, they made every later leg 1.2-2x slower)
         # (malloc_trim(0) here — handing the closed leg's tens of GB of small blocks back to the system — was measured: it lowers the peak RSS of the whole run from 96 to
         # 84 GB and costs the NEXT legs their speed: stereo 22.8 -> 16.3 k frames/s, 32-base leg 46.6 -> 43.8 k, same box, alternating runs; not done)
         return summ, rec
@@ -706,10 +706,9 @@ def main():
             c, _ = run(head, seq_head, S, G, "cold")
             cold = {"frames_per_s": round(c["frames_per_s"], 1), "ms_per_step": round(c["ms_per_step"], 3), "lba_windows_timed": c["lba_windows_timed"],
                     "note": "steps %d..%d of empty maps (no pre-roll): the regime bench.py timed in rounds 1-2 (there at twice the motion per frame)" % (args.warmup, args.warmup + args.steps)}
-        # --extras-child-processes: the second workload and the 32-base leg each in a CHILD PROCESS (this program again, headline only).  Built because the third
-        # 8192-sequence leg of one process runs its device-side stages 1.2-2x slower than the same leg in a fresh process (stereo 12.5 / 16.1 k in-process behind two
-        # legs against 22.8 k alone; whichever leg comes third pays); measured worse still: with the parent process alive on the card the stereo child ran at 4.5 k
-        # and the 32-base child at 33.8 k frames/s.  Default: in-process, the second workload right behind the headline (18.6-22.5 k), the 32-base leg last.
+        # --extras-child-processes: the second workload and the 32-base leg each in a CHILD PROCESS (this program again, headline only).  Built while the third
+        # 8192-sequence leg of one process ran 1.2-2x slower than alone (cause: the previous legs' device memory was still referenced, see run()); measured worse: with
+        # the parent process alive on the card the stereo child ran at 4.5 k and the 32-base child at 33.8 k frames/s.  Default: in-process.
         def child_leg(tag, extra):
             import subprocess
             try:
