@@ -1464,6 +1464,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         segs.push_back({o->d_desc + 32 * cap * slot, (uint8_t*)o->rec_desc(r), (uint32_t)(cap * 32), 0});
         segs.push_back({(const uint8_t*)(o->cur_uRight + cap * slot), (uint8_t*)o->rec_ur(r), (uint32_t)(cap * 4), 0});
     }
+    if (o->lazy_keys && (!o->d_kp || !o->d_desc)) { oslam::set_error("register_keyframes: no frame has been built yet"); return OSLAM_E_INVALID; }
     if (o->lazy_keys) {   // mvKeys of the new keyframes: written by the same launch into a pinned block the device can address (keyframe_raw_keys hands them out)
         const size_t need = (size_t)n * cap * (sizeof(oslam_keypoint_t) + (o->lazy_desc ? 32 : 0));
         if (need > o->kfk_cap) {
