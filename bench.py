@@ -516,6 +516,19 @@ def main():
     # 8192 sequences per GPU: 21.7 k frames/s against 19.3 k with 4096 and 22.9 k with 16384 (same code; local-BA calls of ~82 windows instead of ~41; 55 GB of host
     # memory for the maps, 53 s of pre-roll)
     S = args.seqs or (2048 if stereo_head else 8192)
+    # A rank of the default RGB-D job holds ~70 GB of host memory (8192 per-sequence maps of ~6.3 MB + the inputs: DESIGN.md section 9).  On a node whose memory
+    # does not hold that for every local rank the job would be killed, not slowed down: the per-rank sequence count is halved until it fits (reported in `config`).
+    seqs_reduced_from = None
+    if not args.seqs and not stereo_head and world > 1:
+        try:
+            with open("/proc/meminfo") as fh:
+                host_mem_gb = next(int(ln.split()[1]) for ln in fh if ln.startswith("MemTotal")) / 1048576.0
+            per_rank = 0.85 * host_mem_gb / max(1, local_world)
+            while S > 1024 and 8.5e-3 * S + 8.0 > per_rank:     # (8.5 MB per sequence incl. allocator overhead and scratch, 8 GB of inputs / runtime)
+                seqs_reduced_from = seqs_reduced_from or S
+                S //= 2
+        except Exception:
+            pass
     G = args.handles or 8
     extras_on = rank == 0 and world == 1 and not args.no_extras
     host_phase = extras_on and not stereo_head            # the same warmed sequences continued with host-resident inputs
@@ -826,7 +839,7 @@ def main():
                                       "%d sequences per GPU in %d handles (one host thread + %d workers each), %d ORB features, images resident in HBM; %s; "
                                       "BASELINE.json configs[%s]" % (head.name, S, G, summ["host_threads_per_handle"] - 1, head.nFeatures, regime, "2" if head is wl_rgbd else "3]/[4"),
                           "regime": "steady_state" if preroll > 0 else "cold_start", "preroll_steps": preroll, "preroll_s": round(summ["preroll_s"], 1),
-                          "sequences_per_gpu": S, "frames_per_step": S * world, "local_mapping_schedule": args.lm,
+                          "sequences_per_gpu": S, "sequences_per_gpu_reduced_from_for_host_memory": seqs_reduced_from, "frames_per_step": S * world, "local_mapping_schedule": args.lm,
                           "distinct_streams_per_gpu": min(S, head.n_base * (head.stagger + 1)), "replicas_per_stream": round(S / min(S, head.n_base * (head.stagger + 1)), 1),
                           "inputs_note": "the %d sequences of a GPU replay %d base renderings at %d frame offsets: every distinct input frame of a step is read by ~%.0f sequences "
                                          "(maps, keyframes and local-BA windows are per sequence and not shared); --bases N renders more base streams for an A/B of the cache "

@@ -214,6 +214,7 @@ struct Ctx {
     std::unique_ptr<Pool> pool;
     double sec[16] = {0};
     double cpu[16] = {0};   // core-seconds of the same stages (host thread + workers)
+    double fine[8] = {0};   // OSLAM_SLAM_SN_STATS: core-seconds inside SearchInNeighbors (target lists + masks, first-direction rounds, second-direction list, its round, updates + connections)
     CpuAccount acct;
     int shard = 0;   // worker set of this handle (slam_pool.h)
     struct Win {   // one local-BA window (run_local_mapping)
@@ -1390,6 +1391,8 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
             f.cached = true;
         });
+        auto fine = [&](int i) { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; c.fine[i] += tm.cpu; };
+        fine(0);
         auto refresh_touched = [&](Seq& s, FuseSeq& f) {   // after a round: the points it changed, if they are in the list
             const Map& m = s.map;
             const int stamp = s.curKF + 1;
@@ -1445,7 +1448,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 memcpy(j.Tcw, kf.pose.Tcw.m, 64); memcpy(j.Ow, kf.pose.Ow, 12); j.th = 3.0f; j.q_match = fs[w].qm.data();
                 pjobs.push_back(j); jw.push_back((int)w);
             }
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            fine(into_current ? 3 : 1);
             int rc2 = OSLAM_OK;
             if (pjobs.empty()) {
                 if ((rc2 = upd.finish(c))) return rc2;
@@ -1466,7 +1469,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 if (cached) refresh_touched(*c.seq[who[w]], fs[w]);
             });
             merge_upd();
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            fine(into_current ? 3 : 1);
             rc2 = upd.submit(c, true, false, mpu_async);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314); collected behind the next round's search
             { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
             return rc2;
@@ -1495,14 +1498,14 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 j.M = (int)fs[w].q.size(); j.queries = fs[w].q.data(); j.q_match = fs[w].qm.data();
                 jobs.push_back(j); jw.push_back((int)w); fkey.push_back({who[w], k, -1});
             }
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            fine(into_current ? 3 : 1);
             if (jobs.empty()) return OSLAM_OK;
             int rc2 = c.ops.fuse_keyed ? c.ops.fuse_keyed(c.ops.ctx, (int)jobs.size(), jobs.data(), fkey.data()) : c.ops.fuse(c.ops.ctx, (int)jobs.size(), jobs.data());
             if (rc2) return rc2;
             { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
             pool.parallel_for((int)jw.size(), [&](int q) { const int w = jw[q]; fuse_apply(*c.seq[who[w]], fs[w].kf, fs[w].qpt, fs[w].qm.data()); });
             merge_upd();
-            { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+            fine(into_current ? 3 : 1);
             rc2 = upd.run(c, true, false);   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
             { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
             return rc2;
@@ -1530,6 +1533,7 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
                 }
             }
         });
+        fine(2);
         if ((rc = fuse_round(true, 0))) return rc;
         if ((rc = upd.finish(c))) return rc;
         { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
@@ -1551,11 +1555,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
             }
         });
         merge_upd();   // (sequence order, then keypoint order: the order of the serial loop this replaces)
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+        fine(4);
         if ((rc = upd.run(c, true, true))) return rc;
         { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
         pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; s.map.update_connections(s.curKF, s.counter); });
-        { const double d_ = tm.lap(); c.sec[7] += d_; c.sec[11] += d_; c.cpu[7] += tm.cpu; c.cpu[11] += tm.cpu; }
+        fine(4);
     }
 
     // --- Optimizer::LocalBundleAdjustment (src/Optimizer.cc:453-778), all windows in one batch ---
@@ -2361,6 +2365,7 @@ int oslam_slam_create(oslam_slam_t** out, const oslam_slam_config_t* cfg) {
 }
 
 void oslam_slam_destroy(oslam_slam_t* h) {
+    if (h && getenv("OSLAM_SLAM_SN_STATS")) { const double* f = h->c.fine; fprintf(stderr, "[search-neighbors core-s] targets+masks %.3f rounds %.3f second-direction list %.3f its round %.3f updates+connections %.3f\n", f[0], f[1], f[2], f[3], f[4]); }
     if (!h) return;
     if (thread_account() == &h->c.acct) thread_account() = nullptr;   // never leave a dangling account bound to the destroying thread
     if (h->c.ops.destroy) h->c.ops.destroy(h->c.ops.ctx);
