@@ -247,6 +247,21 @@ typedef struct oslam_map_changes {
 /* KeyFrameCulling candidates of one sequence (oslam_slam_ops_t::kf_culling_counts): n keyframe ids in the reference's order, out [n][4]. */
 typedef struct oslam_job_cull { int32_t slot, n; const int32_t* kf_ids; int32_t* out; } oslam_job_cull_t;
 
+/* LocalMapping::SearchInNeighbors, second direction (src/LocalMapping.cc:492-515), for one sequence: the map points of the target keyframes are fused into the
+ * current keyframe.  The table builds vpFuseCandidates itself — the targets' point lists in the given order, bad points skipped, every point once
+ * (mnFuseCandidateForKF) — from its mirror of the observation graph (map_journal), runs ORBmatcher::Fuse's gates and search for them and returns the matches:
+ * pairs[2 q] = map point, pairs[2 q + 1] = keypoint of the current keyframe, in candidate order; the driver applies them (Replace / AddObservation) as it applies the
+ * match table of fuse_points_keyed.  overflow != 0: more candidates or matches than the table's bounds — the driver then takes its own path for the whole call.
+ * dbg_ids / dbg_excl (optional, tests): the candidate list and its "bad or already observed by the keyframe" flags, at most dbg_cap entries. */
+typedef struct oslam_job_fuse_cur {
+    int32_t slot, kf;
+    int32_t n_targets; const int32_t* targets;
+    float Tcw[16], Ow[3], th;
+    int32_t max_pairs; int32_t* pairs;
+    int32_t n_pairs, n_candidates, overflow;      /* out */
+    int32_t dbg_cap; int32_t* dbg_ids; uint8_t* dbg_excl;
+} oslam_job_fuse_cur_t;
+
 typedef struct oslam_slam_ops {
     void* ctx;
     /* capacity of the per-frame arrays the driver must allocate */
@@ -330,6 +345,8 @@ typedef struct oslam_slam_ops {
      * returns when they are.  The driver asks for the counts right after the local-BA write-back — the last step of a pass that changes observations — and
      * collects them after the MapPoint updates, so the round trip to the device hides behind that stage. */
     int (*kf_culling_collect)(void* ctx);
+    /* optional, with map_journal and fuse_points_keyed (round 5): oslam_job_fuse_cur_t above.  The driver flushes its change sets (map_journal) right before. */
+    int (*fuse_into_current)(void* ctx, int n, oslam_job_fuse_cur_t* jobs);
     /* optional pair (round 5): mp_update_keyed whose results may arrive later.  mp_update_keyed_async enqueues the job and may return before best_idx / out_desc /
      * out5 are written (the job and every array it names must stay valid and untouched); mp_update_collect returns when they are.  At most one job is in flight per
      * table; operators called in between see the job's effects on the resident records (same stream order).  The driver uses it for the descriptor updates that

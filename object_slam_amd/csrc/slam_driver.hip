@@ -761,27 +761,30 @@ static void fuse_queries(const Ctx& c, const Map& m, int k, const std::vector<in
 
 // surgery of ORBmatcher::Fuse (:950-970) in query order; points whose descriptor must be recomputed go to `upd`
 // `touched` (optional): the points whose bad flag or observation list this call changed
-static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t* q_match, std::vector<int>* touched = nullptr) {
+static inline void fuse_apply_one(Seq& s, int k, int p, int best, std::vector<int>* touched) {
     Map& m = s.map;
-    for (size_t i = 0; i < qpt.size(); i++) {
-        const int best = q_match[i];
-        if (best < 0) continue;
-        const int p = qpt[i];
-        if (m.pBad[p]) continue;
-        const int inKF = m.kfs[k].mp[best];
-        if (inKF >= 0) {
-            if (!m.pBad[inKF]) {
-                if (m.pNObs[inKF] > m.pNObs[p]) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
-                else { if (m.replace_point(inKF, p)) s.updList.push_back(p); }
-                if (touched) { touched->push_back(p); touched->push_back(inKF); }
-            }
-        } else {
-            m.add_observation(p, k, best);
-            m.set_kf_mp(k, best, p);
-            if (touched) touched->push_back(p);
+    if (m.pBad[p]) return;
+    const int inKF = m.kfs[k].mp[best];
+    if (inKF >= 0) {
+        if (!m.pBad[inKF]) {
+            if (m.pNObs[inKF] > m.pNObs[p]) { if (m.replace_point(p, inKF)) s.updList.push_back(inKF); }
+            else { if (m.replace_point(inKF, p)) s.updList.push_back(p); }
+            if (touched) { touched->push_back(p); touched->push_back(inKF); }
         }
-        s.st[9]++;
+    } else {
+        m.add_observation(p, k, best);
+        m.set_kf_mp(k, best, p);
+        if (touched) touched->push_back(p);
     }
+    s.st[9]++;
+}
+static void fuse_apply(Seq& s, int k, const std::vector<int>& qpt, const int32_t* q_match, std::vector<int>* touched = nullptr) {
+    for (size_t i = 0; i < qpt.size(); i++)
+        if (q_match[i] >= 0) fuse_apply_one(s, k, qpt[i], q_match[i], touched);
+}
+// the same from the (point, keypoint) pairs of oslam_slam_ops_t::fuse_into_current (candidate order)
+static void fuse_apply_pairs(Seq& s, int k, const int32_t* pairs, int n) {
+    for (int q = 0; q < n; q++) fuse_apply_one(s, k, pairs[2 * q], pairs[2 * q + 1], nullptr);
 }
 
 // Second half of a local-mapping pass: Optimizer::LocalBundleAdjustment's write-back (src/Optimizer.cc:711-777) from the solved windows, the MapPoint updates of
@@ -1515,28 +1518,96 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         if ((rc = upd.finish(c))) return rc;
         { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
         // the targets' points into the current keyframe (:492-515)
-        pool.parallel_for(nW, [&](int w) {
-            Seq& s = *c.seq[who[w]];
-            Map& m = s.map;
-            const int cur = s.curKF;
-            fs[w].pts.clear();
-            // (mnFuseCandidateForKF as a dense per-sequence array, like baMark: up to 60 targets x 1000 slots per keyframe, most of them already marked)
-            if (s.fuseMark.size() < m.mps.size()) s.fuseMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
-            int* fm = s.fuseMark.data();
-            for (int k : fs[w].targets) {
-                const int* kmp = m.kfs[k].mp.data();
-                for (size_t i = 0, n = m.kfs[k].mp.size(); i < n; i++) {
-                    const int p = kmp[i];
-                    if (p < 0 || m.pBad[p] || fm[p] == cur) continue;
-                    fm[p] = cur;
-                    fs[w].pts.push_back(p);
+        auto build_lists = [&]() {
+            pool.parallel_for(nW, [&](int w) {
+                Seq& s = *c.seq[who[w]];
+                Map& m = s.map;
+                const int cur = s.curKF;
+                fs[w].pts.clear();
+                // (mnFuseCandidateForKF as a dense per-sequence array, like baMark: up to 60 targets x 1000 slots per keyframe, most of them already marked)
+                if (s.fuseMark.size() < m.mps.size()) s.fuseMark.resize(m.mps.size() + m.mps.size() / 2 + 64, 0);
+                int* fm = s.fuseMark.data();
+                for (int k : fs[w].targets) {
+                    const int* kmp = m.kfs[k].mp.data();
+                    for (size_t i = 0, n = m.kfs[k].mp.size(); i < n; i++) {
+                        const int p = kmp[i];
+                        if (p < 0 || m.pBad[p] || fm[p] == cur) continue;
+                        fm[p] = cur;
+                        fs[w].pts.push_back(p);
+                    }
+                }
+            });
+        };
+        // With a table that mirrors the observation graph the candidate list is the TABLE's: it walks the targets' point lists where they are resident, runs Fuse's gates
+        // and search and returns the matches (oslam_slam_ops_t::fuse_into_current) — no 60 x 1000-slot walk, no observation-list lookups, no candidate upload.  The change
+        // sets of this pass so far (new keyframe, triangulated points, the first direction's fusions) go to the table first.  OSLAM_SLAM_FUSECUR_CHECK=1: the list and
+        // its flags are also built here and compared entry by entry.
+        static const bool fusecur_check = getenv("OSLAM_SLAM_FUSECUR_CHECK") != nullptr;
+        bool cur_done = false;
+        if (fuse_by_id && c.ops.fuse_into_current && c.ops.map_journal) {
+            bool all_on = true;
+            for (int w = 0; w < nW; w++) all_on = all_on && c.seq[who[w]]->map.jrOn;
+            if (all_on) {
+                std::vector<oslam_map_changes_t> chg(nW), chs;
+                std::vector<uint8_t> has(nW, 0);
+                if (c.jrScratch.size() < (size_t)c.S) c.jrScratch.resize(c.S);
+                pool.parallel_for(nW, [&](int w) { Seq& s = *c.seq[who[w]]; if (s.map.jr_pending()) { s.map.journal_changes(who[w], c.thDepth, c.jrScratch[who[w]], chg[w]); has[w] = 1; } });
+                for (int w = 0; w < nW; w++) if (has[w]) chs.push_back(chg[w]);
+                if (!chs.empty() && (rc = c.ops.map_journal(c.ops.ctx, (int)chs.size(), chs.data()))) return rc;
+                std::vector<oslam_job_fuse_cur_t> cj;
+                std::vector<int> cw;
+                std::vector<std::vector<int32_t>> cpairs(nW), dIds(nW);
+                std::vector<std::vector<uint8_t>> dEx(nW);
+                for (int w = 0; w < nW; w++) {
+                    if (fs[w].targets.empty()) continue;
+                    Seq& s = *c.seq[who[w]];
+                    const KeyFrm& kf = s.map.kfs[s.curKF];
+                    oslam_job_fuse_cur_t j;
+                    memset(&j, 0, sizeof(j));
+                    j.slot = who[w]; j.kf = s.curKF; j.n_targets = (int32_t)fs[w].targets.size(); j.targets = fs[w].targets.data();
+                    memcpy(j.Tcw, kf.pose.Tcw.m, 64); memcpy(j.Ow, kf.pose.Ow, 12); j.th = 3.0f;
+                    cpairs[w].resize(2 * 2048); j.max_pairs = 2048; j.pairs = cpairs[w].data();
+                    if (fusecur_check) { dIds[w].resize(16384); dEx[w].resize(16384); j.dbg_cap = 16384; j.dbg_ids = dIds[w].data(); j.dbg_excl = dEx[w].data(); }
+                    cj.push_back(j); cw.push_back(w);
+                }
+                fine(2);
+                if (!cj.empty() && (rc = c.ops.fuse_into_current(c.ops.ctx, (int)cj.size(), cj.data()))) return rc;
+                { c.sec[8] += tm.lap(); c.cpu[8] += tm.cpu; }
+                bool overflow = false;
+                for (auto& j : cj) overflow = overflow || j.overflow != 0;
+                if (!overflow) {
+                    if (fusecur_check) {
+                        build_lists();
+                        for (size_t q = 0; q < cj.size(); q++) {
+                            const int w = cw[q];
+                            const Seq& s = *c.seq[who[w]];
+                            const std::vector<int>& pts = fs[w].pts;
+                            bool same = (size_t)cj[q].n_candidates == pts.size();
+                            for (size_t pi = 0; same && pi < pts.size(); pi++) {
+                                const int pp = pts[pi];
+                                const uint8_t ex = (s.map.pBad[pp] || s.map.mps[pp].obs_index(s.curKF) >= 0) ? 1 : 0;
+                                same = dIds[w][pi] == pp && dEx[w][pi] == ex;
+                                if (!same) fprintf(stderr, "OSLAM_SLAM_FUSECUR_CHECK: sequence %d keyframe %d candidate %zu: table (%d, %d), driver (%d, %d)\n", who[w], s.curKF, pi, dIds[w][pi], dEx[w][pi], pp, ex);
+                            }
+                            if (!same) { fprintf(stderr, "OSLAM_SLAM_FUSECUR_CHECK: the table's candidate list differs from the driver's (sequence %d keyframe %d: %d against %zu candidates)\n", who[w], s.curKF, cj[q].n_candidates, pts.size()); abort(); }
+                        }
+                    }
+                    pool.parallel_for((int)cj.size(), [&](int q) { Seq& s = *c.seq[who[cw[q]]]; fuse_apply_pairs(s, s.curKF, cj[q].pairs, cj[q].n_pairs); });
+                    merge_upd();
+                    fine(3);
+                    if ((rc = upd.run(c, true, false))) return rc;   // Replace -> ComputeDistinctiveDescriptors (src/MapPoint.cc:314)
+                    { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+                    cur_done = true;
                 }
             }
-        });
-        fine(2);
-        if ((rc = fuse_round(true, 0))) return rc;
-        if ((rc = upd.finish(c))) return rc;
-        { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+        }
+        if (!cur_done) {
+            build_lists();
+            fine(2);
+            if ((rc = fuse_round(true, 0))) return rc;
+            if ((rc = upd.finish(c))) return rc;
+            { c.sec[5] += tm.lap(); c.cpu[5] += tm.cpu; }
+        }
         // update points of the current keyframe (:517-531) and its connections
         pool.parallel_for(nW, [&](int w) {
             Seq& s = *c.seq[who[w]];

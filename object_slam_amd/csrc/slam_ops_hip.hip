@@ -68,6 +68,8 @@ struct HipOps {
     bool lazy_desc = false;                          // the same for mDescriptors (keyframe_descriptors / frame_descriptors)
     bool lazy_keys = false;                          // frames do not send mvKeys back; register_keyframes stages the new keyframes' rows for keyframe_raw_keys
     uint8_t* kfk_h = nullptr; size_t kfk_cap = 0; std::vector<int32_t> kfk_slots;
+    static constexpr int kFuseCurStride = 16384, kFuseCurPairs = 2048;   // candidates / matches per job of fuse_into_current (beyond: overflow, the driver's own path)
+    uint8_t* fc_d = nullptr; size_t fc_cap = 0; uint32_t fc_stamp = 0;
     struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; } mpu_pend;
     void swap_staging() { std::swap(up_h, upB_h); std::swap(up_d, upB_d); std::swap(up_cap, upB_cap); std::swap(dn_h, dnB_h); std::swap(dn_cap, dnB_cap); std::swap(tev0, tevB0); std::swap(tev1, tevB1); }
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
@@ -129,7 +131,9 @@ struct HipOps {
         return OSLAM_OK;
     }
     int32_t* rec_mp(int r) const { return (int32_t*)(rec_ptr(r) + rec_core_bytes()); }
-    // per-point scalars of the mirror: 16-byte records (Observations(), isBad(), octave histogram) per slot, grown like the map-point table
+    // per-point scalars of the mirror: 32-byte records per slot, grown like the map-point table: (Observations(), isBad(), octave histogram) in the first 16 bytes,
+    // then the transient marks of SearchInNeighbors' second direction (k_fusecur_*: 64-bit first-occurrence key, stamp of the current keyframe's points)
+    static constexpr size_t kPtAuxBytes = 32;
     std::vector<uint8_t*> pt_aux; std::vector<size_t> pt_aux_cap;
     uint8_t** d_pt_aux = nullptr; uint8_t** d_rec_chunk = nullptr; size_t rec_chunk_cap = 0, rec_chunk_n = 0;
     bool pt_aux_dirty = true;
@@ -138,10 +142,10 @@ struct HipOps {
         if (need <= pt_aux_cap[slot]) return OSLAM_OK;
         const size_t ncap = std::max<size_t>(need * 2, 16384);
         uint8_t* nb = nullptr;
-        OSLAM_HIP_CHECK(hipMalloc((void**)&nb, ncap * 16));
-        OSLAM_HIP_CHECK(hipMemsetAsync(nb, 0, ncap * 16, strm));
+        OSLAM_HIP_CHECK(hipMalloc((void**)&nb, ncap * kPtAuxBytes));
+        OSLAM_HIP_CHECK(hipMemsetAsync(nb, 0, ncap * kPtAuxBytes, strm));
         if (pt_aux[slot]) {
-            OSLAM_HIP_CHECK(hipMemcpyAsync(nb, pt_aux[slot], pt_aux_cap[slot] * 16, hipMemcpyDeviceToDevice, strm));
+            OSLAM_HIP_CHECK(hipMemcpyAsync(nb, pt_aux[slot], pt_aux_cap[slot] * kPtAuxBytes, hipMemcpyDeviceToDevice, strm));
             OSLAM_HIP_CHECK(hipStreamSynchronize(strm));
             (void)hipFree(pt_aux[slot]);
         }
@@ -1470,6 +1474,7 @@ int h_register_keyframes(void* p, int n, const int32_t* slots, const int32_t* kf
         if (need > o->kfk_cap) {
             OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
             if (o->kfk_h) (void)hipHostFree(o->kfk_h);
+    if (o->fc_d) (void)hipFree(o->fc_d);
             o->kfk_h = nullptr; o->kfk_cap = 0;
             OSLAM_HIP_CHECK(hipHostMalloc((void**)&o->kfk_h, need + need / 2 + 4096, 0));
             o->kfk_cap = need + need / 2 + 4096;
@@ -1565,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_mirror_ops(const int4* cells, int ncell
         }
     } else if (i < ncell + nokf + npt) {
         const uint4 a = pts[2 * (i - ncell - nokf)], b = pts[2 * (i - ncell - nokf) + 1];   // (slot, p, nObs, bad), (lvl lo, lvl hi, -, -)
-        ((uint4*)pt_aux[a.x])[a.y] = make_uint4(a.z, a.w, b.x, b.y);
+        ((uint4*)pt_aux[a.x])[2 * (size_t)a.y] = make_uint4(a.z, a.w, b.x, b.y);   // (32-byte records: the marks in the second half are not touched)
     }
 }
 
@@ -1590,7 +1595,7 @@ __global__ __launch_bounds__(64) void k_cull_counts(const CullCand* cands, uint8
             if (p < 0) continue;
             if (!((good[i >> 5] >> (i & 31)) & 1u)) continue;
             ub++;
-            const uint4 a = aux[p];   // (nObs, bad, lvl lo, lvl hi)
+            const uint4 a = aux[2 * (size_t)p];   // (nObs, bad, lvl lo, lvl hi)
             if (a.y != 0u) continue;
             nMPs++;
             if ((int)a.x > 3) {
@@ -1743,6 +1748,190 @@ int h_kf_culling_collect(void* p) {
     for (const HipOps::CullPending& c : o->cull_pending) { memcpy(c.out, o->cull_h + 16 * at, 16 * (size_t)c.n); at += (size_t)c.n; }
     o->cull_pending.clear();
     o->mir_used = 0;
+    return OSLAM_OK;
+}
+
+// ---- SearchInNeighbors, second direction, from the mirror (oslam_job_fuse_cur_t) ----
+// vpFuseCandidates of one sequence = the targets' point lists in order, bad points skipped, every point once.  "Once, at its FIRST occurrence in (target, slot)
+// order" in parallel: every (target t, slot i) proposes the key stamp << 32 | (0xFFFF - t) << 16 | (0xFFFF - i) for its point with a 64-bit atomicMax (a newer stamp
+// beats an old one; within a stamp the smallest (t, i) is the largest key); the slot whose key stays is the point's first occurrence.  The current keyframe's own
+// points get the stamp in a second word: a candidate already observed by the keyframe is excluded (MapPoint::IsInKeyFrame, src/ORBmatcher.cc:849).
+struct FuseCurJob { int32_t slot, cur_rec, nT, t_off; };
+__device__ __forceinline__ unsigned long long fusecur_key(uint32_t stamp, int t, int i) { return ((unsigned long long)stamp << 32) | ((unsigned long long)(0xFFFF - t) << 16) | (unsigned long long)(0xFFFF - i); }
+__global__ __launch_bounds__(256) void k_fusecur_mark(const FuseCurJob* jobs, const int32_t* recs, uint8_t* const* chunks, uint8_t* const* pt_aux, MirrorGeom g, uint32_t stamp) {
+    const FuseCurJob j = jobs[blockIdx.z];
+    const int t = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (t > j.nT || i >= g.cap) return;
+    const int rec = t == j.nT ? j.cur_rec : recs[j.t_off + t];
+    if (rec < 0) return;
+    const int p = mirror_mp(chunks, g, rec)[i];
+    if (p < 0) return;
+    uint4* aux = (uint4*)pt_aux[j.slot] + 2 * (size_t)p;
+    if (t == j.nT) { ((uint32_t*)(aux + 1))[2] = stamp; return; }
+    if (aux[0].y != 0u) return;
+    atomicMax((unsigned long long*)(aux + 1), fusecur_key(stamp, t, i));
+}
+__global__ __launch_bounds__(1024) void k_fusecur_list(const FuseCurJob* jobs, const int32_t* recs, uint8_t* const* chunks, uint8_t* const* pt_aux, MirrorGeom g, uint32_t stamp, int stride,
+                                                        int32_t* ids, uint8_t* excl, int32_t* Mout) {
+    const FuseCurJob j = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const uint4* aux = (const uint4*)pt_aux[j.slot];
+    for (int t = 0; t < j.nT; t++) {
+        const int rec = recs[j.t_off + t];
+        if (rec < 0) continue;   // (uniform)
+        const int32_t* mp = mirror_mp(chunks, g, rec);
+        for (int i0 = 0; i0 < g.cap; i0 += 1024) {
+            const int i = i0 + tid;
+            int p = -1;
+            bool first = false;
+            if (i < g.cap) {
+                p = mp[i];
+                if (p >= 0) {
+                    const uint4 a0 = aux[2 * (size_t)p];
+                    first = a0.y == 0u && *(const unsigned long long*)(aux + 2 * (size_t)p + 1) == fusecur_key(stamp, t, i);
+                }
+            }
+            const unsigned long long bal = __ballot(first);
+            if (lane == 0) s_cnt[wv] = __popcll(bal);
+            __syncthreads();
+            int off = s_base, tot = 0;
+            for (int w2 = 0; w2 < 16; w2++) { if (w2 < wv) off += s_cnt[w2]; tot += s_cnt[w2]; }
+            if (first) {
+                const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < stride) {
+                    ids[(size_t)blockIdx.x * stride + pos] = p;
+                    excl[(size_t)blockIdx.x * stride + pos] = ((const uint32_t*)(aux + 2 * (size_t)p + 1))[2] == stamp ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_base += tot;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { const int b = s_base; Mout[2 * blockIdx.x] = b < stride ? b : stride; Mout[2 * blockIdx.x + 1] = b > stride ? 1 : 0; }
+}
+// the matches of one job in candidate order: (point, keypoint) pairs straight into the pinned result block
+__global__ __launch_bounds__(1024) void k_fusecur_pairs(const int32_t* Mn, const int32_t* ids, const int32_t* q_match, int stride, int max_pairs, int32_t* pairs, int32_t* counts) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int M = Mn[2 * blockIdx.x];
+    __shared__ int s_cnt[16];
+    __shared__ int s_base;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += 1024) {
+        const int i = i0 + tid;
+        const int best = i < M ? q_match[(size_t)blockIdx.x * stride + i] : -1;
+        const bool hit = best >= 0;
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = s_base, tot = 0;
+        for (int w2 = 0; w2 < 16; w2++) { if (w2 < wv) off += s_cnt[w2]; tot += s_cnt[w2]; }
+        if (hit) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < max_pairs) { pairs[((size_t)blockIdx.x * max_pairs + pos) * 2] = ids[(size_t)blockIdx.x * stride + i]; pairs[((size_t)blockIdx.x * max_pairs + pos) * 2 + 1] = best; }
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) { counts[3 * blockIdx.x] = s_base; counts[3 * blockIdx.x + 1] = M; counts[3 * blockIdx.x + 2] = Mn[2 * blockIdx.x + 1]; }
+}
+
+__global__ void k_fusecur_counts(const int32_t* Mn, int n, int32_t* M) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < n) M[i] = Mn[2 * i]; }
+
+int h_fuse_into_current(void* p, int n, oslam_job_fuse_cur_t* jobs) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("fuse_into_current: n > n_sequences"); return OSLAM_E_INVALID; }
+    const int stride = HipOps::kFuseCurStride, maxPairs = HipOps::kFuseCurPairs;
+    size_t nrec = 0;
+    int maxT = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_fuse_cur_t& j = jobs[i];
+        if (j.slot < 0 || j.slot >= o->S || j.n_targets < 0 || j.n_targets > 0xFFFF || !j.pairs || j.max_pairs < 0 || (j.n_targets > 0 && !j.targets)) { oslam::set_error("fuse_into_current: bad job"); return OSLAM_E_INVALID; }
+        nrec += (size_t)j.n_targets; maxT = std::max(maxT, j.n_targets);
+    }
+    if (o->cap > 0xFFFF) { oslam::set_error("fuse_into_current: more than 65535 keypoints per keyframe"); return OSLAM_E_CAPACITY; }
+    OPS_CHECK(o->sync_mp_table());
+    if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
+    for (int i = 0; i < n; i++) if (!o->pt_aux[jobs[i].slot]) OPS_CHECK(o->ensure_pt_aux(jobs[i].slot, 1));
+    OPS_CHECK(o->sync_mirror_tables());
+    // job block (pinned, read in place) | device scratch: candidate ids, flags, match table, counts
+    const size_t B = n;
+    Layout L;
+    const size_t oJ = L.take(sizeof(FuseCurJob) * B), oR = L.take(4 * std::max<size_t>(nrec, 1)), oSl = L.take(4 * B), oT = L.take(64 * B), oOw = L.take(12 * B), oRef = L.take(sizeof(oslam_kf_grid_ref_t) * B);
+    OPS_CHECK(o->ensure_up(L.off));
+    const size_t sIds = 0, sEx = oslam::align_up(sIds + 4 * (size_t)stride * B, 256), sQm = oslam::align_up(sEx + (size_t)stride * B, 256), sM = oslam::align_up(sQm + 4 * (size_t)stride * B, 256),
+                 sM1 = oslam::align_up(sM + 8 * B, 256), sEnd = sM1 + 4 * B;
+    if (sEnd > o->fc_cap) {
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+        if (o->fc_d) (void)hipFree(o->fc_d);
+        o->fc_d = nullptr; o->fc_cap = 0;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&o->fc_d, sEnd + sEnd / 2));
+        o->fc_cap = sEnd + sEnd / 2;
+    }
+    Layout R;
+    const size_t rCnt = R.take(12 * B), rPairs = R.take(8 * (size_t)maxPairs * B);
+    bool dbg = false;
+    for (int i = 0; i < n; i++) dbg = dbg || (jobs[i].dbg_cap > 0 && jobs[i].dbg_ids && jobs[i].dbg_excl);
+    const size_t rIds = R.take(dbg ? 4 * (size_t)stride * B : 0), rEx = R.take(dbg ? (size_t)stride * B : 0);
+    OPS_CHECK(o->ensure_dn(R.off));
+    uint8_t* U = o->up_h;
+    FuseCurJob* fj = (FuseCurJob*)(U + oJ);
+    int32_t* recs = (int32_t*)(U + oR);
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_fuse_cur_t& j = jobs[i];
+        const int cr = o->rec_lookup(j.slot, j.kf);
+        if (cr < 0) { oslam::set_error("fuse_into_current: the current keyframe is not resident"); return OSLAM_E_INVALID; }
+        fj[i].slot = j.slot; fj[i].cur_rec = cr; fj[i].nT = j.n_targets; fj[i].t_off = (int32_t)at;
+        for (int t = 0; t < j.n_targets; t++) recs[at++] = o->rec_lookup(j.slot, j.targets[t]);   // (-1: not resident — cannot happen for a keyframe of the map; skipped)
+        ((int32_t*)(U + oSl))[i] = j.slot;
+        memcpy(U + oT + 64 * i, j.Tcw, 64); memcpy(U + oOw + 12 * i, j.Ow, 12);
+        oslam_kf_grid_ref_t& ref = ((oslam_kf_grid_ref_t*)(U + oRef))[i];
+        ref.cell_end = o->rec_cell_end(cr); ref.cand = o->rec_cand(cr); ref.desc = o->rec_desc(cr);
+    }
+    const uint32_t stamp = ++o->fc_stamp;
+    const MirrorGeom g = mirror_geom(o);
+    uint8_t* D = o->fc_d;
+    o->t_begin();
+    hipLaunchKernelGGL(k_fusecur_mark, dim3((unsigned)((g.cap + 255) / 256), (unsigned)(maxT + 1), (unsigned)n), dim3(256), 0, o->strm, (const FuseCurJob*)(U + oJ), (const int32_t*)(U + oR),
+                       (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux, g, stamp);
+    hipLaunchKernelGGL(k_fusecur_list, dim3((unsigned)n), dim3(1024), 0, o->strm, (const FuseCurJob*)(U + oJ), (const int32_t*)(U + oR), (uint8_t* const*)o->d_rec_chunk,
+                       (uint8_t* const*)o->d_pt_aux, g, stamp, stride, (int32_t*)(D + sIds), D + sEx, (int32_t*)(D + sM));
+    OSLAM_HIP_CHECK(hipGetLastError());
+    // (k_fuse_search reads M at d_M[b]; the list kernel's table holds [M, overflow] pairs: the search gets a compacted copy)
+    hipLaunchKernelGGL(k_fusecur_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, o->strm, (const int32_t*)(D + sM), n, (int32_t*)(D + sM1));
+    OPS_CHECK(oslam_fuse_search_device(n, stride, (const oslam_kf_grid_ref_t*)(U + oRef), (const int32_t*)(U + oSl), (const int32_t*)(D + sM1), (const int32_t*)(D + sIds), D + sEx,
+                                       o->d_mp_tab, (const float*)(U + oT), (const float*)(U + oOw), o->K5, o->bounds, jobs[0].th, o->logScale, o->scale, o->invSigma2, o->cfg.nLevels,
+                                       (int32_t*)(D + sQm), o->strm));
+    hipLaunchKernelGGL(k_fusecur_pairs, dim3((unsigned)n), dim3(1024), 0, o->strm, (const int32_t*)(D + sM), (const int32_t*)(D + sIds), (const int32_t*)(D + sQm), stride, maxPairs,
+                       (int32_t*)(o->dn_h + rPairs), (int32_t*)(o->dn_h + rCnt));
+    OSLAM_HIP_CHECK(hipGetLastError());
+    if (dbg) {
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h + rIds, D + sIds, 4 * (size_t)stride * B, o->strm));
+        OSLAM_HIP_CHECK(oslam::copy_to_host_async(o->dn_h + rEx, D + sEx, (size_t)stride * B, o->strm));
+    }
+    o->t_end();
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    o->t_collect(4, 4, 0);
+    const int32_t* cnt = (const int32_t*)(o->dn_h + rCnt);
+    for (int i = 0; i < n; i++) {
+        oslam_job_fuse_cur_t& j = jobs[i];
+        j.n_pairs = cnt[3 * i]; j.n_candidates = cnt[3 * i + 1]; j.overflow = (cnt[3 * i + 2] != 0 || j.n_pairs > maxPairs || j.n_pairs > j.max_pairs) ? 1 : 0;
+        if (!j.overflow) memcpy(j.pairs, o->dn_h + rPairs + 8 * (size_t)maxPairs * i, 8 * (size_t)j.n_pairs);
+        if (j.dbg_cap > 0 && j.dbg_ids && j.dbg_excl) {
+            const int m = std::min(j.n_candidates, j.dbg_cap);
+            memcpy(j.dbg_ids, o->dn_h + rIds + 4 * (size_t)stride * i, 4 * (size_t)m);
+            memcpy(j.dbg_excl, o->dn_h + rEx + (size_t)stride * i, (size_t)m);
+        }
+    }
     return OSLAM_OK;
 }
 
@@ -2142,7 +2331,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; }
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; if (o->mp_tab_on && !getenv("OSLAM_SLAM_FUSECUR_HOST")) ops->fuse_into_current = h_fuse_into_current; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; if (!getenv("OSLAM_SLAM_EAGER_KEYS")) { o->lazy_keys = true; ops->keyframe_raw_keys = h_keyframe_raw_keys; if (!getenv("OSLAM_SLAM_EAGER_DESC")) { o->lazy_desc = true; ops->keyframe_descriptors = h_keyframe_descriptors; ops->frame_descriptors = h_frame_descriptors; } } ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }

@@ -538,7 +538,10 @@ def test_device_culling_counts_equal_the_host_walk():
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
     # (third run: the deferred form of the per-round descriptor updates of SearchInNeighbors, oslam_slam_ops_t::mp_update_keyed_async — an A/B knob, off by default)
-    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1"}), ("mpu_async", {"OSLAM_SLAM_MPU_ASYNC": "1"})):
+    # (the same two processes cover SearchInNeighbors' second direction from the mirror — oslam_slam_ops_t::fuse_into_current: OSLAM_SLAM_FUSECUR_CHECK=1 compares the
+    # table's candidate list and flags with the driver's entry by entry, OSLAM_SLAM_FUSECUR_HOST=1 is the driver's own walk)
+    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1", "OSLAM_SLAM_FUSECUR_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1", "OSLAM_SLAM_FUSECUR_HOST": "1"}),
+                     ("mpu_async", {"OSLAM_SLAM_MPU_ASYNC": "1"})):
         e = dict(os.environ)
         e.update(env)
         p = subprocess.run([sys.executable, os.path.join(here, "cull_check_run.py")], env=e, capture_output=True, text=True, timeout=900)
