@@ -262,6 +262,8 @@ typedef struct oslam_job_fuse_cur {
     int32_t dbg_cap; int32_t* dbg_ids; uint8_t* dbg_excl;
 } oslam_job_fuse_cur_t;
 
+typedef struct oslam_job_local_list { int32_t slot, n_kfs; const int32_t* kfs; int32_t cap; int32_t* ids; int32_t n_ids, overflow; } oslam_job_local_list_t;
+
 typedef struct oslam_slam_ops {
     void* ctx;
     /* capacity of the per-frame arrays the driver must allocate */
@@ -347,6 +349,10 @@ typedef struct oslam_slam_ops {
     int (*kf_culling_collect)(void* ctx);
     /* optional, with map_journal and fuse_points_keyed (round 5): oslam_job_fuse_cur_t above.  The driver flushes its change sets (map_journal) right before. */
     int (*fuse_into_current)(void* ctx, int n, oslam_job_fuse_cur_t* jobs);
+    /* optional, with map_journal (round 5): Tracking::UpdateLocalPoints (src/Tracking.cc:1470-1493) from the mirror — mvpLocalMapPoints of a sequence = the point
+     * lists of its local keyframes in the given order, every point once, bad points left out.  ids receives at most `cap` point ids; overflow != 0: more than the
+     * table's bound or `cap` (the driver then walks the lists itself).  The driver flushes its change sets (map_journal) right before. */
+    int (*local_points_list)(void* ctx, int n, oslam_job_local_list_t* jobs);
     /* optional pair (round 5): mp_update_keyed whose results may arrive later.  mp_update_keyed_async enqueues the job and may return before best_idx / out_desc /
      * out5 are written (the job and every array it names must stay valid and untouched); mp_update_collect returns when they are.  At most one job is in flight per
      * table; operators called in between see the job's effects on the resident records (same stream order).  The driver uses it for the descriptor updates that

@@ -1935,6 +1935,69 @@ int h_fuse_into_current(void* p, int n, oslam_job_fuse_cur_t* jobs) {
     return OSLAM_OK;
 }
 
+// Tracking::UpdateLocalPoints from the mirror (oslam_job_local_list_t): the same first-occurrence compaction as the Fuse candidates, over the local keyframes' lists;
+// the ids go straight into the pinned result block.
+int h_local_points_list(void* p, int n, oslam_job_local_list_t* jobs) {
+    HipOps* o = (HipOps*)p;
+    OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    if (n == 0) return OSLAM_OK;
+    if (n > o->S) { oslam::set_error("local_points_list: n > n_sequences"); return OSLAM_E_INVALID; }
+    const int stride = HipOps::kFuseCurStride;
+    size_t nrec = 0;
+    int maxT = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_local_list_t& j = jobs[i];
+        if (j.slot < 0 || j.slot >= o->S || j.n_kfs < 0 || j.n_kfs > 0xFFFF || !j.ids || j.cap < 0 || (j.n_kfs > 0 && !j.kfs)) { oslam::set_error("local_points_list: bad job"); return OSLAM_E_INVALID; }
+        nrec += (size_t)j.n_kfs; maxT = std::max(maxT, j.n_kfs);
+    }
+    if (o->cap > 0xFFFF) { oslam::set_error("local_points_list: more than 65535 keypoints per keyframe"); return OSLAM_E_CAPACITY; }
+    if ((int)o->pt_aux.size() < o->S) { o->pt_aux.resize(o->S, nullptr); o->pt_aux_cap.resize(o->S, 0); }
+    for (int i = 0; i < n; i++) if (!o->pt_aux[jobs[i].slot]) OPS_CHECK(o->ensure_pt_aux(jobs[i].slot, 1));
+    OPS_CHECK(o->sync_mirror_tables());
+    const size_t B = n;
+    Layout L;
+    const size_t oJ = L.take(sizeof(FuseCurJob) * B), oR = L.take(4 * std::max<size_t>(nrec, 1));
+    OPS_CHECK(o->ensure_up(L.off));
+    const size_t sEx = 0, sEnd = (size_t)stride * B;
+    if (sEnd > o->fc_cap) {
+        OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+        if (o->fc_d) (void)hipFree(o->fc_d);
+        o->fc_d = nullptr; o->fc_cap = 0;
+        OSLAM_HIP_CHECK(hipMalloc((void**)&o->fc_d, sEnd + sEnd / 2));
+        o->fc_cap = sEnd + sEnd / 2;
+    }
+    Layout R;
+    const size_t rM = R.take(8 * B), rIds = R.take(4 * (size_t)stride * B);
+    OPS_CHECK(o->ensure_dn(R.off));
+    uint8_t* U = o->up_h;
+    FuseCurJob* fj = (FuseCurJob*)(U + oJ);
+    int32_t* recs = (int32_t*)(U + oR);
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {
+        const oslam_job_local_list_t& j = jobs[i];
+        fj[i].slot = j.slot; fj[i].cur_rec = -1; fj[i].nT = j.n_kfs; fj[i].t_off = (int32_t)at;
+        for (int t = 0; t < j.n_kfs; t++) recs[at++] = o->rec_lookup(j.slot, j.kfs[t]);
+    }
+    const uint32_t stamp = ++o->fc_stamp;
+    const MirrorGeom g = mirror_geom(o);
+    o->t_begin();
+    hipLaunchKernelGGL(k_fusecur_mark, dim3((unsigned)((g.cap + 255) / 256), (unsigned)(maxT + 1), (unsigned)n), dim3(256), 0, o->strm, (const FuseCurJob*)(U + oJ), (const int32_t*)(U + oR),
+                       (uint8_t* const*)o->d_rec_chunk, (uint8_t* const*)o->d_pt_aux, g, stamp);
+    hipLaunchKernelGGL(k_fusecur_list, dim3((unsigned)n), dim3(1024), 0, o->strm, (const FuseCurJob*)(U + oJ), (const int32_t*)(U + oR), (uint8_t* const*)o->d_rec_chunk,
+                       (uint8_t* const*)o->d_pt_aux, g, stamp, stride, (int32_t*)(o->dn_h + rIds), o->fc_d + sEx, (int32_t*)(o->dn_h + rM));
+    OSLAM_HIP_CHECK(hipGetLastError());
+    o->t_end();
+    OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
+    o->t_collect(3, 2, 0);
+    const int32_t* Mn = (const int32_t*)(o->dn_h + rM);
+    for (int i = 0; i < n; i++) {
+        oslam_job_local_list_t& j = jobs[i];
+        j.n_ids = Mn[2 * i]; j.overflow = (Mn[2 * i + 1] != 0 || j.n_ids > j.cap) ? 1 : 0;
+        if (!j.overflow) memcpy(j.ids, o->dn_h + rIds + 4 * (size_t)stride * i, 4 * (size_t)j.n_ids);
+    }
+    return OSLAM_OK;
+}
+
 int h_resident_points(void* p) { return ((HipOps*)p)->mp_tab_on ? 1 : 0; }
 
 int h_point_record(void* p, int slot, int id, uint8_t out[64]) {
@@ -2331,7 +2394,7 @@ int oslam_slam_make_hip_ops(const oslam_slam_config_t* cfg, oslam_slam_ops_t* op
     o->mp_tab_on = getenv("OSLAM_SLAM_NO_RESIDENT_POINTS") == nullptr;
     if (o->mp_tab_on) { ops->point_record = h_point_record; ops->resident_points = h_resident_points; }
     if (!getenv("OSLAM_SLAM_NO_WINDOW_UPDATES")) ops->mp_update_windows = h_mp_update_windows;   // (A/B: the MapPoint updates after a local BA through mp_update as before)
-    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; if (o->mp_tab_on && !getenv("OSLAM_SLAM_FUSECUR_HOST")) ops->fuse_into_current = h_fuse_into_current; }
+    if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF") && !getenv("OSLAM_SLAM_NO_MIRROR")) { ops->map_journal = h_map_journal; ops->kf_culling_counts = h_kf_culling_counts; ops->kf_culling_collect = h_kf_culling_collect; if (o->mp_tab_on && !getenv("OSLAM_SLAM_FUSECUR_HOST")) ops->fuse_into_current = h_fuse_into_current; ops->local_points_list = h_local_points_list; }
     if (!getenv("OSLAM_SLAM_NO_RESIDENT_KF")) { ops->register_keyframes = h_register_keyframes; if (!getenv("OSLAM_SLAM_KEEP_CULLED_RECORDS")) ops->release_keyframes = h_release_keyframes; ops->bow_keyed = h_bow_keyed; ops->fuse_keyed = h_fuse_keyed; ops->mp_update_keyed = h_mp_update_keyed; if (!getenv("OSLAM_SLAM_EAGER_KEYS")) { o->lazy_keys = true; ops->keyframe_raw_keys = h_keyframe_raw_keys; if (!getenv("OSLAM_SLAM_EAGER_DESC")) { o->lazy_desc = true; ops->keyframe_descriptors = h_keyframe_descriptors; ops->frame_descriptors = h_frame_descriptors; } } ops->mp_update_keyed_async = h_mp_update_keyed_async; ops->mp_update_collect = h_mp_update_collect;
         if (!getenv("OSLAM_SLAM_HOST_BOW_NODES")) ops->bow_nodes_keyed = h_bow_nodes_keyed;
         if (o->mp_tab_on && !getenv("OSLAM_SLAM_HOST_FUSE_QUERIES")) ops->fuse_points_keyed = h_fuse_points_keyed; }

@@ -539,8 +539,9 @@ def test_device_culling_counts_equal_the_host_walk():
     res = {}
     # (third run: the deferred form of the per-round descriptor updates of SearchInNeighbors, oslam_slam_ops_t::mp_update_keyed_async — an A/B knob, off by default)
     # (the same two processes cover SearchInNeighbors' second direction from the mirror — oslam_slam_ops_t::fuse_into_current: OSLAM_SLAM_FUSECUR_CHECK=1 compares the
-    # table's candidate list and flags with the driver's entry by entry, OSLAM_SLAM_FUSECUR_HOST=1 is the driver's own walk)
-    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1", "OSLAM_SLAM_FUSECUR_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1", "OSLAM_SLAM_FUSECUR_HOST": "1"}),
+    # table's candidate list and flags with the driver's entry by entry, OSLAM_SLAM_FUSECUR_HOST=1 is the driver's own walk — and, in the check process, the opt-in
+    # Tracking::UpdateLocalPoints from the mirror: oslam_slam_ops_t::local_points_list, OSLAM_SLAM_LOCLIST_DEV=1, compared list by list)
+    for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1", "OSLAM_SLAM_FUSECUR_CHECK": "1", "OSLAM_SLAM_LOCLIST_DEV": "1", "OSLAM_SLAM_LOCLIST_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1", "OSLAM_SLAM_FUSECUR_HOST": "1"}),
                      ("mpu_async", {"OSLAM_SLAM_MPU_ASYNC": "1"})):
         e = dict(os.environ)
         e.update(env)
