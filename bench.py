@@ -609,7 +609,7 @@ def main():
     mem_gb = {}
     rss_gb = {}
 
-    def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None):
+    def run(wl, seqs, S_, G_, tag, preroll_=0, post_frames_=0, post_=None, drop_host_inputs=(), trim=False):
         snap = {}
 
         def stage_totals(systems):
@@ -629,7 +629,7 @@ def main():
         summ, rec, systems, extra = seqbench.run_rank(wl, lambda cfg: slam.System(cfg), rank, world, S_, G_, args.steps, args.warmup, True, device,
                                                       host_threads=threads, sequences=seqs, after_warmup=reset_timers, coll_on_device=backend == "nccl",
                                                       preroll=preroll_, post_frames=post_frames_, post=post_, progress=log,
-                                                      local_mapping=slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC)
+                                                      local_mapping=slam.LM_DEFERRED if args.lm == "deferred" else slam.LM_SYNC, drop_host_inputs=drop_host_inputs)
         tot = extra.get("post", {}).get("kernel_times_timed") if isinstance(extra.get("post"), dict) else None
         if tot is None:
             tot = {}
@@ -669,8 +669,15 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()   # (the leg's systems and input tensors are gone before the next leg allocates: left referenced, they made every later leg 1.2-2x slower)
-        # (malloc_trim(0) here — handing the closed leg's tens of GB of small blocks back to the system — was measured: it lowers the peak RSS of the whole run from 96 to
-        # 84 GB and costs the NEXT legs their speed: stereo 22.8 -> 16.3 k frames/s, 32-base leg 46.6 -> 43.8 k, same box, alternating runs; not done)
+        # malloc_trim(0) — handing the closed leg's tens of GB of small blocks back to the system — only where the caller asks for it (`trim`): it costs the NEXT leg some
+        # speed (page faults while its maps grow: measured 46.6 -> 43.8 k for the 32-base leg) and is what keeps the peak of the whole run away from the box's memory
+        # limit: without it the 32-base leg's maps come on top of the arenas the headline's maps left behind (105-107 GB; one run of the round was killed there).
+        if trim:
+            try:
+                import ctypes
+                ctypes.CDLL("libc.so.6").malloc_trim(0)
+            except Exception:
+                pass
         return summ, rec
 
     def host_inputs_phase(ctx):
@@ -762,11 +769,11 @@ def main():
         else:
             # (the second workload runs right behind the headline, before the 32-base leg: after TWO 8192-sequence legs have come and gone in the process its device-side
             # stages ran 1.5-2x slower — 12.5 / 16.1 k against 22.8 k frames/s for the same workload in a fresh process: gpurun_out of round 5)
-            s2, _ = run(second, seq_second, S2, G2, "second", pre2)
+            s2, _ = run(second, seq_second, S2, G2, "second", pre2, trim=seq_b32 is not None)
             roof2 = roofline_of(kt["second"], s2, second is wl_st)
             if seq_b32 is not None:
                 try:
-                    sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll)
+                    sb, _ = run(wl_b32, seq_b32, S, G, "bases32", preroll, drop_host_inputs=[b for b in seq_b32 if b not in seq_head], trim=True)
                     kb = kt["bases32"]
                     bases32 = {"frames_per_s": round(sb["frames_per_s"], 1), "ms_per_step": round(sb["ms_per_step"], 3), "distinct_streams_per_gpu": min(S, wl_b32.n_base * (wl_b32.stagger + 1)),
                                "replicas_per_stream": round(S / min(S, wl_b32.n_base * (wl_b32.stagger + 1)), 1), "lba_windows_timed": sb["lba_windows_timed"],

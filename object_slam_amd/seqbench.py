@@ -270,7 +270,8 @@ def window_stats(after, before):
 
 
 def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup, on_device, device=None, host_threads=0, collect_poses=False,
-             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None, local_mapping=slam.LM_SYNC, total_sequences=None):
+             sequences=None, after_warmup=None, coll_on_device=True, preroll=0, post_frames=0, post=None, progress=None, local_mapping=slam.LM_SYNC, total_sequences=None,
+             drop_host_inputs=()):
     """Runs this rank's shard: `seqs_per_rank` sequences in `handles` driver handles (each advanced by its own host thread); `preroll` untimed steps that
     bring every sequence's map to its steady state (they are part of the set-up, like loading a map), `warmup` untimed lockstep steps, then exactly `steps`
     timed steps bracketed by a barrier + device synchronisation on both sides.  `post(ctx)` (optional) may run further phases on the warmed sequences
@@ -293,6 +294,12 @@ def run_rank(wl, make_system, rank, world, seqs_per_rank, handles, steps, warmup
     n_timed0 = preroll + warmup
     n_frames = n_timed0 + steps
     inp = _Inputs(wl, mine, n_frames + post_frames, on_device, device, base_seed=wl.n_base * rank, sequences=sequences)
+    if on_device:   # (the images of these base streams are in HBM now; the caller does not need their host copies again: they go back before the maps grow)
+        for b in drop_host_inputs:
+            for key in ("gray", "right", "depth", "masks"):
+                if b in inp.seqs and isinstance(inp.seqs[b].get(key), np.ndarray):   # (a zero-stride stand-in keeps shape and dtype for the code that asks for them)
+                    a = inp.seqs[b][key]
+                    inp.seqs[b][key] = np.broadcast_to(np.zeros((1,) * a.ndim, a.dtype), a.shape)
     systems = []
     for h in range(handles):
         cfg = slam.make_config(wl.width, wl.height, len(groups[h]), cam=wl.cam, nFeatures=wl.nFeatures, sensor=wl.sensor,
