@@ -1394,10 +1394,11 @@ static int run_local_mapping(Ctx& c, const std::vector<int>& who) {
         static const bool excl_check = getenv("OSLAM_SLAM_FUSE_EXCL_CHECK") != nullptr;   // debugging: compare the cached flags with the full pass every round
         static const bool excl_cache = !getenv("OSLAM_SLAM_FUSE_EXCL_FULL");               // A/B knob: the full pass every round
         const bool fuse_by_id = c.residentPts && c.ops.fuse_points_keyed != nullptr;   // the table runs the projection gates itself from its map-point records
-        // A/B knob (OSLAM_SLAM_MPU_ASYNC=1): a round's descriptor updates are enqueued and collected behind the NEXT round's search instead of waited for.  Default
-        // off, measured (same box, alternating runs, identical results): 33.4 / 35.4 k frames/s deferred against 36.1 / 37.8 k waiting — the wait moves into the
-        // search (Fuse stage +0.65 handle-seconds, MapPoint-update stage -0.8) and the round's host bookkeeping slows down beside the running kernel (+0.5-0.9).
-        static const bool mpu_async = getenv("OSLAM_SLAM_MPU_ASYNC") != nullptr;
+        // A round's descriptor updates (MapPoint::Replace -> ComputeDistinctiveDescriptors) are handed to the table WITHOUT a wait (mp_update_keyed_async): the table launches
+        // them right in front of the NEXT round's search, so one wait covers both — one device round trip per round instead of two.  Same-box A/B, alternating,
+        // identical results: 39.7 / 40.9 k against 38.6 / 40.6 k frames/s.  (The first form enqueued the update kernel at once and let it run beside the round's host
+        // bookkeeping: 33.4 / 35.4 k against 36.1 / 37.8 k — slower; OSLAM_SLAM_MPU_SYNC=1 restores the wait per update.)
+        static const bool mpu_async = getenv("OSLAM_SLAM_MPU_SYNC") == nullptr;
         std::vector<oslam_job_fuse_pts_t> pjobs;
         std::vector<FuseSeq> fs(who.size());
         std::vector<oslam_job_fuse_t> jobs;

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <thread>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "../../include/oslam_slam.h"
@@ -70,7 +71,8 @@ struct HipOps {
     uint8_t* kfk_h = nullptr; size_t kfk_cap = 0; std::vector<int32_t> kfk_slots;
     static constexpr int kFuseCurStride = 16384, kFuseCurPairs = 2048;   // candidates / matches per job of fuse_into_current (beyond: overflow, the driver's own path)
     uint8_t* fc_d = nullptr; size_t fc_cap = 0; uint32_t fc_stamp = 0;
-    struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; } mpu_pend;
+    struct MpuPending { bool on = false; oslam_job_mp_update_t* j = nullptr; size_t P = 0, rBest = 0, rOut = 0, rOut5 = 0; double dtotal = 0; std::function<int()> launch; } mpu_pend;
+    int mpu_launch_pending() { if (mpu_pend.on && mpu_pend.launch) { std::function<int()> f; f.swap(mpu_pend.launch); return f(); } return OSLAM_OK; }
     void swap_staging() { std::swap(up_h, upB_h); std::swap(up_d, upB_d); std::swap(up_cap, upB_cap); std::swap(dn_h, dnB_h); std::swap(dn_cap, dnB_cap); std::swap(tev0, tevB0); std::swap(tev1, tevB1); }
     oslam_proj_query_t* d_lq = nullptr; uint8_t* d_inview = nullptr; size_t lq_cap = 0;
     uint8_t* d_objbits = nullptr;                        // [S][cap] keypoint test bits (object_kps)
@@ -959,6 +961,7 @@ int h_mp_update_collect(void* p) {
     HipOps* o = (HipOps*)p;
     if (!o->mpu_pend.on) return OSLAM_OK;
     OSLAM_HIP_CHECK(hipSetDevice(o->cfg.device));
+    OPS_CHECK(o->mpu_launch_pending());
     OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
     HipOps::MpuPending& q = o->mpu_pend;
     q.on = false;
@@ -1062,17 +1065,27 @@ static int mp_update_impl(HipOps* o, oslam_job_mp_update_t* j, const int32_t* ob
     bool fused = fused_on && (!j->do_desc || keyed);
     if (fused && j->do_desc) for (size_t i = 0; i < P && fused; i++) fused = dstart[i + 1] - dstart[i] <= 128;   // (kDdMaxObs of csrc/mappoint.hip: beyond it k_distinctive reads from memory)
     if (fused) {
-        o->t_begin();
-        OPS_CHECK(oslam_mp_update_fused_device((int)P, j->do_desc, j->do_normal, (const int32_t*)(In + oStart), (const int32_t*)(In + (j->desc_start ? oDStart : oStart)),
-                                               keyed ? (const int32_t*)(In + oRec) : nullptr, (const uint8_t* const*)o->d_rec_desc, (const float*)(In + oOw), (const float*)(In + oPos),
-                                               (const float*)(In + oRef), (const float*)(In + oLsf), o->scale[o->cfg.nLevels - 1], table ? (const int32_t*)(In + oItems) : nullptr,
-                                               table ? o->d_mp_tab : nullptr, (int32_t*)(o->dn_h + rBest), o->dn_h + rOut, (float*)(o->dn_h + rOut5), o->strm));
-        o->t_end();
-        lap_(3);
+        // (the deferred form does not even enqueue the kernel here: it is launched right in front of the next operator's own kernel — the next Fuse round's search —
+        // or by mp_update_collect, so that ONE wait covers both and nothing runs on the card while the driver does the round's bookkeeping)
+        const bool do_desc = j->do_desc != 0, do_normal = j->do_normal != 0, has_ds = j->desc_start != nullptr;
+        uint8_t* const dn = o->dn_h;
+        hipEvent_t e0 = o->tev0, e1 = o->tev1;
+        std::function<int()> launch = [=]() -> int {
+            if (o->timing) (void)hipEventRecord(e0, o->strm);
+            const int rcl = oslam_mp_update_fused_device((int)P, do_desc, do_normal, (const int32_t*)(In + oStart), (const int32_t*)(In + (has_ds ? oDStart : oStart)),
+                                                         keyed ? (const int32_t*)(In + oRec) : nullptr, (const uint8_t* const*)o->d_rec_desc, (const float*)(In + oOw), (const float*)(In + oPos),
+                                                         (const float*)(In + oRef), (const float*)(In + oLsf), o->scale[o->cfg.nLevels - 1], table ? (const int32_t*)(In + oItems) : nullptr,
+                                                         table ? o->d_mp_tab : nullptr, (int32_t*)(dn + rBest), dn + rOut, (float*)(dn + rOut5), o->strm);
+            if (o->timing) (void)hipEventRecord(e1, o->strm);
+            return rcl;
+        };
         if (defer) {   // (h_mp_update_collect finishes it)
             o->mpu_pend.on = true; o->mpu_pend.j = j; o->mpu_pend.P = P; o->mpu_pend.rBest = rBest; o->mpu_pend.rOut = rOut; o->mpu_pend.rOut5 = rOut5; o->mpu_pend.dtotal = (double)dtotal;
+            o->mpu_pend.launch = launch;
             return OSLAM_OK;
         }
+        OPS_CHECK(launch());
+        lap_(3);
         OSLAM_HIP_CHECK(oslam::stream_wait(o->strm));
         lap_(4);
         o->t_collect(6, 1, (double)dtotal);
@@ -2167,6 +2180,7 @@ int h_fuse_points_keyed(void* p, int n, oslam_job_fuse_pts_t* jobs) {
         if (rec[i] < 0 || jobs[i].M < 0 || jobs[i].N < 0 || jobs[i].N > (int)cap) { oslam::set_error("fuse_points: keyframe not resident / bad size"); return OSLAM_E_INVALID; }
         maxM = std::max(maxM, jobs[i].M);
     }
+    OPS_CHECK(o->mpu_launch_pending());   // (the previous round's descriptor updates, if they were deferred: in front of this search, behind one wait)
     static const bool staged = getenv("OSLAM_SLAM_FUSE_STAGED") != nullptr;   // A/B knob: the round-2 path (copy the records into a batch, queries, LDS window search)
     if (!staged) {
         // gates + window search of every candidate in ONE launch, straight from the resident records and their grids (oslam_fuse_search_device)

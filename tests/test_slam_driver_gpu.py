@@ -537,19 +537,19 @@ def test_device_culling_counts_equal_the_host_walk():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    # (third run: the deferred form of the per-round descriptor updates of SearchInNeighbors, oslam_slam_ops_t::mp_update_keyed_async — an A/B knob, off by default)
+    # (third run: WITHOUT the deferred form of the per-round descriptor updates of SearchInNeighbors, oslam_slam_ops_t::mp_update_keyed_async — the default since round 5)
     # (the same two processes cover SearchInNeighbors' second direction from the mirror — oslam_slam_ops_t::fuse_into_current: OSLAM_SLAM_FUSECUR_CHECK=1 compares the
     # table's candidate list and flags with the driver's entry by entry, OSLAM_SLAM_FUSECUR_HOST=1 is the driver's own walk — and, in the check process, the opt-in
     # Tracking::UpdateLocalPoints from the mirror: oslam_slam_ops_t::local_points_list, OSLAM_SLAM_LOCLIST_DEV=1, compared list by list)
     for tag, env in (("check", {"OSLAM_SLAM_CULL_CHECK": "1", "OSLAM_SLAM_FUSECUR_CHECK": "1", "OSLAM_SLAM_LOCLIST_DEV": "1", "OSLAM_SLAM_LOCLIST_CHECK": "1"}), ("host", {"OSLAM_SLAM_CULL_HOST": "1", "OSLAM_SLAM_FUSECUR_HOST": "1"}),
-                     ("mpu_async", {"OSLAM_SLAM_MPU_ASYNC": "1"})):
+                     ("mpu_sync", {"OSLAM_SLAM_MPU_SYNC": "1"})):
         e = dict(os.environ)
         e.update(env)
         p = subprocess.run([sys.executable, os.path.join(here, "cull_check_run.py")], env=e, capture_output=True, text=True, timeout=900)
         assert p.returncode == 0, (tag, p.stdout[-2000:], p.stderr[-2000:])
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         res[tag] = json.loads(line[7:])
-    assert res["check"] == res["host"] == res["mpu_async"]
+    assert res["check"] == res["host"] == res["mpu_sync"]
     for name in ("sync", "deferred"):
         assert res["check"][name]["status_ok"]
     assert sum(s["keyframes_culled"] for s in res["check"]["sync"]["stats"]) >= 2
