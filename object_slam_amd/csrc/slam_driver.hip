@@ -429,7 +429,10 @@ struct MpUpdate {
         return OSLAM_OK;
     }
     bool pAsync = false;
+    struct SpecStats { std::atomic<long long> upd{0}, changed{0}, changed_in_list{0}; ~SpecStats() { fprintf(stderr, "[fuse spec stats] per-round descriptor updates %lld, changed %lld, changed and in the current keyframe's candidate list %lld\n", upd.load(), changed.load(), changed_in_list.load()); } };
     int finish(Ctx& c) {
+        static SpecStats* spec_stats = getenv("OSLAM_SLAM_SPEC_STATS") ? new SpecStats : nullptr;
+        static struct SpecAtExit { ~SpecAtExit() { delete spec_stats; } } spec_at_exit;
         if (!pending) return OSLAM_OK;
         pending = false;
         if (pAsync) { const int rc = c.ops.mp_update_collect(c.ops.ctx); if (rc) return rc; }
@@ -445,6 +448,11 @@ struct MpUpdate {
             for (int i = i0; i < i1; i++) {
                 if (start[i + 1] == start[i]) continue;   // no observations: both methods return early
                 MapPt& p = c.seq[items[i].seq]->map.mps[items[i].p];
+                if (spec_stats && do_desc && !do_normal && dstart[i + 1] > dstart[i]) {   // (how often a Fuse round changes the descriptor of a point that later rounds still search)
+                    spec_stats->upd++;
+                    const Seq& sq = *c.seq[items[i].seq];
+                    if (memcmp(p.desc, &outdesc[(size_t)i * 32], 32) != 0) { spec_stats->changed++; if (p.fuseListStamp == sq.curKF + 1) spec_stats->changed_in_list++; }
+                }
                 if (do_desc && dstart[i + 1] > dstart[i]) memcpy(p.desc, &outdesc[(size_t)i * 32], 32);   // every observing keyframe bad: the descriptor stays (:370-371)
                 if (do_normal) {
                     const float* o = &out5[(size_t)i * 5];
