@@ -21,8 +21,8 @@ FLAGS = (os.environ["OSLAM_EXTRA_FLAGS"].split() if os.environ.get("OSLAM_EXTRA_
 
 def _headers():
     out = []
-    for root, _, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files if not f.endswith(".hip")]
+    for root, _, files in os.walk(CSRC):   # (every file under csrc/ that is not a translation unit: headers, .inc — and .hip files that are #included, e.g. orb_kernels.hip)
+        out += [os.path.join(root, f) for f in files if f not in SOURCES]
     out.append(os.path.join(HERE, "..", "include", "oslam_hip.h"))
     out.append(os.path.join(HERE, "..", "include", "oslam_slam.h"))
     return out

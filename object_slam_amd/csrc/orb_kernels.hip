@@ -1247,7 +1247,13 @@ __device__ __forceinline__ void octree_block(const OrbCtx& c) {
 
 // Three kernels instead of one with three copies of the body: with the spill copy inside, the common variant ran 13 % slower, with the HBM
 // copy as well 30 % slower (registers 91 -> 107, code size).
-__global__ __launch_bounds__(kOctThreads) void k_octree(OrbCtx c) { octree_block<0>(c); }
+// (dbg[8 + level] += the workgroup's duration in 100 MHz ticks, one atomic per workgroup: tools/octree_levels_prof.py reads how the launch's slot time splits over
+// the pyramid levels — VERDICT r4 asked whether levels 4-7 should share a workgroup)
+__global__ __launch_bounds__(kOctThreads) void k_octree(OrbCtx c) {
+    const long long t0 = wall_clock64();
+    octree_block<0>(c);
+    if (threadIdx.x == 0 && c.dbg && blockIdx.x < 8) atomicAdd(&c.dbg[8 + blockIdx.x], (unsigned long long)(wall_clock64() - t0));
+}
 // levels that k_octree flagged (more than kCandCap candidates: noise images); every other block returns after one load
 __global__ __launch_bounds__(kOctThreads) void k_octree_spill(OrbCtx c) { octree_block<1>(c); }
 // quotas so large that the node tables exceed the LDS (e.g. 2000+ features on one or two levels): tables and candidates in HBM
