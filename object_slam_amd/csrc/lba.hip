@@ -737,8 +737,18 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
     const Cam cam = {(double)pr.K5[0], (double)pr.K5[1], (double)pr.K5[2], (double)pr.K5[3], (double)pr.K5[4]};
     const double dMono = (double)pr.delta_mono, dStereo = (double)pr.delta_stereo;
     const bool robust = ct->robust != 0;
-    const double* X = w_X(pr, ct->cur);
+    const double* __restrict__ X = w_X(pr, ct->cur);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (bases of the arrays the edge loops walk, read once: the loops store through pr.chi2 / w.rec, so the compiler reloaded every base it took from pr / w with a
+    // scalar load + wait per edge: ISA)
+    const uint8_t* __restrict__ level_g = pr.level;
+    const int* __restrict__ e_kf_g = pr.e_kf;
+    const int* __restrict__ e_pt_g = pr.e_pt;
+    const float* __restrict__ e_obs_g = pr.e_obs;
+    const float* __restrict__ e_info_g = pr.e_info;
+    const float4* __restrict__ eoi_g = REC ? w.eoi : nullptr;
+    double* __restrict__ chi2_g = pr.chi2;
+    double* __restrict__ rec_g = REC ? w.rec : nullptr;
     __shared__ double sF[kLinThreads / 64], sM[kLinThreads / 64], sAcc[kLinThreads / 64][27];
     // Point role: rotation matrix + translation of the window's keyframes staged in LDS (12 doubles each) when the window has at most kLinKfLds of them: a
     // landmark's edges name different keyframes, and the 12 doubles of an edge's keyframe came as twelve 8-byte gathers per edge from global memory (the
@@ -763,7 +773,7 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
             auto edge = [&](int e, uint8_t lv, int a, float o0, float o1, float ur, float inf, const double* Ra_, const double* ta_) {
                 if (lv != 0) {
                     if (REC) {   // weight 0: the edge adds exact zeros wherever its record is read
-                        double2* rc = (double2*)(w.rec + (long long)e * 4);
+                        double2* rc = (double2*)(rec_g + (long long)e * 4);
                         rc[0] = make_double2(0.0, 0.0); rc[1] = make_double2(1.0, 0.0);
                     }
                     return;
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                 double pc[3], er[3], iz, Jx[9];
                 map_rt(Ra_, ta_, Xw, pc);
                 const double c2 = residual_fast(cam, pc, ob, stereo, info, er, iz);
-                pr.chi2[e] = c2;
+                chi2_g[e] = c2;
                 double r0 = c2, wgt = 1.0;
                 if (robust) huber_fast(c2, stereo ? dStereo : dMono, r0, wgt);
                 F0 += r0;
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                         }
                     }
                     if (REC) {
-                        double2* rc = (double2*)(w.rec + (long long)e * 4);
+                        double2* rc = (double2*)(rec_g + (long long)e * 4);
                         rc[0] = make_double2(pc[0], pc[1]); rc[1] = make_double2(iz, stereo ? wi : -wi);
                     } else if (w.blk[a] >= 0) {
                         double Ju[6], Jv[6], Jr[6];
@@ -816,14 +826,15 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
                     }
                 }
             };
-            for (int e = pr.pt_start[p] + sub; e < pr.pt_start[p + 1]; e += 4) {
+            const int e_end = pr.pt_start[p + 1];
+            for (int e = pr.pt_start[p] + sub; e < e_end; e += 4) {
                 // (the edge's inputs are requested together with its level byte, not after it; requesting them one edge AHEAD of the arithmetic as well was measured:
                 // 55 -> 61 us per launch of 40 windows — the kernel already spills at its 128-register cap)
-                const uint8_t lv = pr.level[e];
-                const int a = pr.e_kf[e];
+                const uint8_t lv = level_g[e];
+                const int a = e_kf_g[e];
                 float o0, o1, ur, inf;
-                if (REC && w.eoi) { const float4 oi = w.eoi[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }
-                else { o0 = pr.e_obs[e * 3]; o1 = pr.e_obs[e * 3 + 1]; ur = pr.e_obs[e * 3 + 2]; inf = pr.e_info[e]; }
+                if (REC && eoi_g) { const float4 oi = eoi_g[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }
+                else { o0 = e_obs_g[e * 3]; o1 = e_obs_g[e * 3 + 1]; ur = e_obs_g[e * 3 + 2]; inf = e_info_g[e]; }
                 if (staged) edge(e, lv, a, o0, o1, ur, inf, sRt + a * 12, sRt + a * 12 + 9);
                 else edge(e, lv, a, o0, o1, ur, inf, Rm + a * 9, T[a].t);
             }
@@ -859,13 +870,15 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; k++) acc[k] = 0;
-    for (int q = pr.pose_start[a] + tid; q < pr.pose_start[a + 1]; q += kLinThreads) {
-        const int e = pr.pose_edges[q];
-        const uint8_t lv = pr.level[e];
-        const int p = pr.e_pt[e];
+    const int* __restrict__ pose_edges_g = pr.pose_edges;
+    const int q_end = pr.pose_start[a + 1];
+    for (int q = pr.pose_start[a] + tid; q < q_end; q += kLinThreads) {
+        const int e = pose_edges_g[q];
+        const uint8_t lv = level_g[e];
+        const int p = e_pt_g[e];
         float o0, o1, ur, inf;
-        if (REC && w.eoi) { const float4 oi = w.eoi[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }   // (one 16-byte gather instead of four 4-byte ones)
-        else { o0 = pr.e_obs[e * 3]; o1 = pr.e_obs[e * 3 + 1]; ur = pr.e_obs[e * 3 + 2]; inf = pr.e_info[e]; }
+        if (REC && eoi_g) { const float4 oi = eoi_g[e]; o0 = oi.x; o1 = oi.y; ur = oi.z; inf = oi.w; }   // (one 16-byte gather instead of four 4-byte ones)
+        else { o0 = e_obs_g[e * 3]; o1 = e_obs_g[e * 3 + 1]; ur = e_obs_g[e * 3 + 2]; inf = e_info_g[e]; }
         const double Xw[3] = {X[p * 3], X[p * 3 + 1], X[p * 3 + 2]};
         if (lv != 0) continue;
         const bool stereo = !(ur < 0);
@@ -1254,6 +1267,9 @@ __device__ __forceinline__ double uniform_f64(double v) {   // a wave-uniform va
     const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+#ifndef OSLAM_SCHUR_PRE
+#define OSLAM_SCHUR_PRE 2   // rounds of a Schur block whose pair entries and point indices are requested together
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_REC_WAVES, OSLAM_SCHUR_REC_WAVES))) void k_w_schur_rec(const LbaProblem* probs, const LbaWide* ws, int nwin) {
 #pragma clang fp contract(fast)
     int win, t;
@@ -1285,16 +1301,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_
     double bsv[6] = {0, 0, 0, 0, 0, 0};
     __shared__ __align__(16) double red[42 * 17];
     const int q0 = w.pair_start[t], q_end = w.pair_start[t + 1];
-    const double2* rec = (const double2*)w.rec;
-    const double2* Vg = (const double2*)w.W;
-    // Operands of a round are requested one round ahead of the arithmetic, in two register sets used in turn (the loop below is unrolled by two: no copies).
+    const double2* __restrict__ rec = (const double2*)w.rec;
+    const double2* __restrict__ Vg = (const double2*)w.W;
+    // (the bases the loop gathers from, read ONCE: through pr / w the compiler reloaded w.pairs, pr.e_pt and pr.bl with a scalar load + wait in every round: ISA)
+    const int2* __restrict__ pairs_g = w.pairs;
+    const int* __restrict__ e_pt_g = pr.e_pt;
+    const double* __restrict__ bl_g = pr.bl;
+    // Operands of a round are requested one round ahead of the arithmetic, in two register sets used in turn.  A pair's operands sit behind TWO dependent index
+    // loads (pair entry -> edge records and the edge's point -> V_p): the index loads of kSchurPre rounds are issued up front, all pair entries first, then all
+    // point indices (round 5, second pass: inside the one-round-ahead fetch each round still waited three dependent memory latencies — ISA — and a block has
+    // only 2-3 rounds).
     struct Ops { double2 a0, a1, b0, b1, v0, v1, v2; int pt; };
-    auto fetch = [&](Ops& o, int q) {
-        const int2 pe = w.pairs[(unsigned)q];   // (32-bit offsets from wave-uniform bases)
+    auto fetch = [&](Ops& o, int2 pe, int pt) {   // (32-bit offsets from wave-uniform bases)
         o.a0 = rec[(unsigned)pe.x * 2u]; o.a1 = rec[(unsigned)pe.x * 2u + 1u];
         if (!diag) { o.b0 = rec[(unsigned)pe.y * 2u]; o.b1 = rec[(unsigned)pe.y * 2u + 1u]; }
-        o.pt = pr.e_pt[(unsigned)pe.x];
-        o.v0 = Vg[(unsigned)o.pt * 3u]; o.v1 = Vg[(unsigned)o.pt * 3u + 1u]; o.v2 = Vg[(unsigned)o.pt * 3u + 2u];
+        o.pt = pt;
+        o.v0 = Vg[(unsigned)pt * 3u]; o.v1 = Vg[(unsigned)pt * 3u + 1u]; o.v2 = Vg[(unsigned)pt * 3u + 2u];
     };
     auto compute = [&](const Ops& o) {
         const double2 cb0 = diag ? o.a0 : o.b0, cb1 = diag ? o.a1 : o.b1;
@@ -1321,7 +1343,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_
         double Jua[6], Jva[6], Jra[6];
         pose_jac_rows(cam, pa, o.a1.x, true, Jua, Jva, Jra);
         if (diag) {   // rhs: W_a b_l = Jp_a^T (N b_l)
-            const double* bl = pr.bl + (unsigned)o.pt * 3u;
+            const double* bl = bl_g + (unsigned)o.pt * 3u;
             const double l0 = bl[0], l1 = bl[1], l2 = bl[2];
             const double n0 = N[0] * l0 + N[1] * l1 + N[2] * l2, n1 = N[3] * l0 + N[4] * l1 + N[5] * l2, n2 = N[6] * l0 + N[7] * l1 + N[8] * l2;
 #pragma unroll
@@ -1365,16 +1387,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OSLAM_SCHUR_
         Ops oa, ob;
         oa.a0 = ob.a0 = oa.b0 = ob.b0 = make_double2(0.0, 0.0); oa.a1 = ob.a1 = oa.b1 = ob.b1 = make_double2(1.0, 0.0);
         oa.v0 = oa.v1 = oa.v2 = ob.v0 = ob.v1 = ob.v2 = make_double2(0.0, 0.0); oa.pt = ob.pt = 0;
-        int q = q0 + lane;
-        if (q < q_end) fetch(oa, q);
-        while (q < q_end) {
-            if (q + 64 < q_end) fetch(ob, q + 64);
-            compute(oa);
-            q += 64;
-            if (q >= q_end) break;
-            if (q + 64 < q_end) fetch(oa, q + 64);
-            compute(ob);
-            q += 64;
+        constexpr int kSchurPre = OSLAM_SCHUR_PRE;
+        for (int q = q0 + lane; q < q_end; q += 64 * kSchurPre) {   // (per lane; a lane past its last pair idles)
+            int2 pe[kSchurPre]; int pt[kSchurPre];
+#pragma unroll
+            for (int r = 0; r < kSchurPre; r++) pe[r] = pairs_g[(unsigned)min(q + 64 * r, q_end - 1)];
+#pragma unroll
+            for (int r = 0; r < kSchurPre; r++) pt[r] = e_pt_g[(unsigned)pe[r].x];
+            fetch(oa, pe[0], pt[0]);
+#pragma unroll
+            for (int r = 0; r < kSchurPre; r++) {
+                if (q + 64 * r >= q_end) break;
+                Ops& cur = (r & 1) ? ob : oa;
+                Ops& nxt = (r & 1) ? oa : ob;
+                if (r + 1 < kSchurPre && q + 64 * (r + 1) < q_end) fetch(nxt, pe[r + 1], pt[r + 1]);
+                compute(cur);
+            }
         }
     }
     // reduction: quad sums by DPP, then the 16 quad sums of every entry in lane order through LDS
@@ -1677,28 +1705,51 @@ __device__ __forceinline__ double rcp_nr2(double z) {
 }
 __device__ __forceinline__ bool chol16_aug(double (&R)[8], int lane) {
 #pragma clang fp contract(fast)
+    // Software-pipelined over the 16 steps (round 5, second pass; the ISA of the straight form showed a step's eight row updates, its reciprocal chain AND the
+    // reciprocal-square-root chain of the final row scaling all in front of the next step's permutes: 460 cycles per step, tools/chol_lds_phase_prof.py).  Step j
+    // needs row j only, and row j is final as soon as step j - 1 has updated the ONE register that holds it: that update goes first, the next step's permutes and
+    // pivot read are issued right behind it, and the other seven updates and the scaling of row j - 1 run while they are in flight.
     const int h = lane >> 5, c = lane & 31;
     bool good = true;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        constexpr int dummy = 0; (void)dummy;
+    double rowc = 0, dc = 0, uc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto request = [&](int j, double& row, double (&u)[8], double& d) __attribute__((always_inline)) {
         const int sj = j >> 1, hj = j & 1;
-        // requests of this step: row j at my column; U(j, i) for my rows i = 2 s + h > j
-        const double rowj = bperm_f64((hj * 32 + c) * 4, R[sj]);
-        double u[8];
+        row = bperm_f64((hj * 32 + c) * 4, R[sj]);                                 // row j at my column
 #pragma unroll
         for (int sI = 0; sI < 8; sI++)
-            if (2 * sI + 1 > j) u[sI] = bperm_f64((hj * 32 + 2 * sI + h) * 4, R[sj]);
-        const double d = rl_f64(R[sj], hj * 32 + j);
-        good = good && (d > 0) && (d < 1.7e308);
-        const double rd = rcp_nr2(d), r = rsqrt_nr(d);
+            if (2 * sI + 1 > j) u[sI] = bperm_f64((hj * 32 + 2 * sI + h) * 4, R[sj]);   // U(j, i) for my rows i = 2 s + h > j
+        d = rl_f64(R[sj], hj * 32 + j);
+    };
+    auto update = [&](int j, int sI, double rd) __attribute__((always_inline)) {
+        if (2 * sI > j) R[sI] = __builtin_fma(-(uc[sI] * rd), rowc, R[sI]);                 // both parities below row j
+        else if (h == 1) R[sI] = __builtin_fma(-(uc[sI] * rd), rowc, R[sI]);                // 2 s == j: only row 2 s + 1
+    };
+    request(0, rowc, uc, dc);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int sj = j >> 1, hj = j & 1;
+        good = good && (dc > 0) && (dc < 1.7e308);
+        const double rd = rcp_nr2(dc);
+        const int sn = (j + 1) >> 1;   // the register of row j + 1
+        double rown = 0, dn = 0, un[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (j + 1 < 16) {
+            update(j, sn, rd);
+            __builtin_amdgcn_sched_barrier(0);
+            request(j + 1, rown, un, dn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int sI = 0; sI < 8; sI++) {
-            if (2 * sI + 1 < j + 1) continue;           // rows 2 s, 2 s + 1 <= j
-            if (2 * sI > j) R[sI] = __builtin_fma(-(u[sI] * rd), rowj, R[sI]);                 // both parities below row j
-            else if (h == 1) R[sI] = __builtin_fma(-(u[sI] * rd), rowj, R[sI]);                // 2 s == j: only row 2 s + 1
+            if (2 * sI + 1 < j + 1 || (j + 1 < 16 && sI == sn)) continue;   // rows <= j; the register done above
+            update(j, sI, rd);
         }
-        if (h == hj) R[sj] = rowj * r;   // row j is final: U(j, .) | U^-T(j, .)
+        const double r = rsqrt_nr(dc);
+        if (h == hj) R[sj] = rowc * r;   // row j is final: U(j, .) | U^-T(j, .)
+        if (j + 1 < 16) {
+            rowc = rown; dc = dn;
+#pragma unroll
+            for (int sI = 0; sI < 8; sI++) uc[sI] = un[sI];
+        }
     }
     return good;
 }

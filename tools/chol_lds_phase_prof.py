@@ -15,3 +15,5 @@ d = (b - a)[8:13].astype(np.float64) * 10.0 / 1e3   # 100 MHz ticks -> us
 launches = r[3][1] + r[3][3]
 print("n =", 6 * int((q["fixed"] == 0).sum()), "chol launches (trials):", launches)
 for n, v in zip(["load to LDS", "diagonal factors", "row panels", "trailing (MFMA)", "back-substitution"], d): print("%-18s %8.1f us total  %6.2f us/launch" % (n, v, v / max(launches, 1)))
+sub = (b - a)[13:16].astype(np.float64) * 10.0 / 1e3
+for n, v in zip(["  wave 0: tile (0, 0)", "  wave 0: factor", "  wave 1: its strips"], sub): print("%-22s %8.1f us total  %6.2f us/launch" % (n, v, v / max(launches, 1)))
