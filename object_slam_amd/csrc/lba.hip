@@ -85,15 +85,78 @@ struct LbaShared {
     int stopflag;
 };
 
+// ---- wavefront reductions without the LDS crossbar (round 5, second pass) ----
+// __shfl_xor of a double is two ds_bpermute_b32: the 27 sums of a keyframe block of k_w_lin were 324 of them per wavefront, sixteen wavefronts of a CU queueing
+// at one LDS pipe.  gfx950 can exchange lanes in the vector ALU: v_permlane32_swap / v_permlane16_swap (halves / odd-even rows of 16 between two registers),
+// DPP row_ror:8 and quad_perm; only lane ^ 4 still goes through ds_swizzle.  Every function below forms the sums of the xor butterfly d = 32, 16, 8, 4, 2, 1
+// with the same operand pairs (a + b against b + a at most): bit-identical results.
+typedef unsigned int oslam_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double f64_from(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+__device__ __forceinline__ unsigned f64_lo(double v) { return (unsigned)(unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned f64_hi(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
+// a's upper 32 lanes <-> b's lower 32 lanes
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+    const oslam_u2 l = __builtin_amdgcn_permlane32_swap(f64_lo(a), f64_lo(b), false, false);
+    const oslam_u2 h = __builtin_amdgcn_permlane32_swap(f64_hi(a), f64_hi(b), false, false);
+    a = f64_from(l[0], h[0]); b = f64_from(l[1], h[1]);
+}
+// a's rows 1, 3 (of 16 lanes) <-> b's rows 0, 2
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {
+    const oslam_u2 l = __builtin_amdgcn_permlane16_swap(f64_lo(a), f64_lo(b), false, false);
+    const oslam_u2 h = __builtin_amdgcn_permlane16_swap(f64_hi(a), f64_hi(b), false, false);
+    a = f64_from(l[0], h[0]); b = f64_from(l[1], h[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {   // (all lanes valid for the controls used here: quad_perm, row_ror)
+    return f64_from((unsigned)__builtin_amdgcn_mov_dpp((int)f64_lo(v), CTRL, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)f64_hi(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_f64<0x128>(v); }   // row_ror:8
+__device__ __forceinline__ double lane_xor4(double v) {                                     // swizzle(SWAP, 4)
+    return f64_from((unsigned)__builtin_amdgcn_ds_swizzle((int)f64_lo(v), 0x101F), (unsigned)__builtin_amdgcn_ds_swizzle((int)f64_hi(v), 0x101F));
+}
+__device__ __forceinline__ double lane_xor2(double v) { return dpp_mov_f64<0x4E>(v); }    // quad_perm [2,3,0,1]
+__device__ __forceinline__ double lane_xor1(double v) { return dpp_mov_f64<0xB1>(v); }    // quad_perm [1,0,3,2]
+// the last four butterfly steps (inside a row of 16 lanes)
+__device__ __forceinline__ double row16_sum(double v) { v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v); return v; }
+
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    double a = v, b = v;
+    swap32_f64(a, b);   // a = [lower half | lower half], b = [upper half | upper half]
+    v = a + b;
+    a = v; b = v;
+    swap16_f64(a, b);   // a = [row 0, row 0, row 2, row 2], b = [row 1, row 1, row 3, row 3]
+    v = a + b;
+    return row16_sum(v);
 }
 __device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    double a = v, b = v;
+    swap32_f64(a, b);
+    v = fmax(a, b);
+    a = v; b = v;
+    swap16_f64(a, b);
+    v = fmax(a, b);
+    v = fmax(v, lane_xor8(v)); v = fmax(v, lane_xor4(v)); v = fmax(v, lane_xor2(v)); v = fmax(v, lane_xor1(v));
     return v;
+}
+// Sums over the wavefront of N values at once: the first two butterfly steps pair the values, so that after them every row of 16 lanes carries ONE value's
+// partial sums (a quarter of the registers); out[q] holds, in every lane of row (b5, b4) of the wavefront (b5 = lane >> 5, b4 = (lane >> 4) & 1), the sum of
+// value 4 q + 2 b4 + b5.  Same operand pairs as wsum per value.
+template <int N>
+__device__ __forceinline__ void wsum_rows(const double (&in)[N], double (&out)[(N + 3) / 4]) {
+    constexpr int N2 = (N + 1) / 2, N4 = (N + 3) / 4;
+    double r1[2 * N4];
+#pragma unroll
+    for (int q = 0; q < 2 * N4; q++) {
+        double a = 2 * q < N ? in[2 * q] : 0.0, b = 2 * q + 1 < N ? in[2 * q + 1] : 0.0;
+        if (q < N2) { swap32_f64(a, b); r1[q] = a + b; }   // lanes < 32: value 2 q, lanes >= 32: value 2 q + 1
+        else r1[q] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < N4; q++) {
+        double a = r1[2 * q], b = r1[2 * q + 1];
+        swap16_f64(a, b);                                  // rows 0, 2: register 2 q; rows 1, 3: register 2 q + 1
+        out[q] = row16_sum(a + b);
+    }
 }
 
 // block-wide sum / max of up to 2 values; all threads get identical results
@@ -841,10 +904,10 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         }
         // the 4 lanes of a landmark: (s0 + s1) + (s2 + s3)
 #pragma unroll
-        for (int k = 0; k < 6; k++) { hl[k] += __shfl_xor(hl[k], 1, 64); hl[k] += __shfl_xor(hl[k], 2, 64); }
+        for (int k = 0; k < 6; k++) { hl[k] += lane_xor1(hl[k]); hl[k] += lane_xor2(hl[k]); }
 #pragma unroll
-        for (int k = 0; k < 3; k++) { bl[k] += __shfl_xor(bl[k], 1, 64); bl[k] += __shfl_xor(bl[k], 2, 64); }
-        F0 += __shfl_xor(F0, 1, 64); F0 += __shfl_xor(F0, 2, 64);
+        for (int k = 0; k < 3; k++) { bl[k] += lane_xor1(bl[k]); bl[k] += lane_xor2(bl[k]); }
+        F0 += lane_xor1(F0); F0 += lane_xor2(F0);
         if (p < pr.P && sub == 0) {
             double* H = pr.Hll + (long long)p * 9;
             H[0] = hl[0]; H[1] = hl[1]; H[2] = hl[2]; H[3] = hl[1]; H[4] = hl[3]; H[5] = hl[4]; H[6] = hl[2]; H[7] = hl[4]; H[8] = hl[5];
@@ -896,10 +959,13 @@ __global__ __launch_bounds__(kLinThreads, OSLAM_LIN_MIN_WAVES) void k_w_lin(cons
         accumulate_row<1>(Jv, er[1], wi, acc);
         if (stereo) accumulate_row<2>(Jr, er[2], wi, acc);
     }
+    {
+        double rs[7];
+        wsum_rows<27>(acc, rs);   // (the 27 wavefront sums in 7 registers: row (b5, b4) of register q holds value 4 q + 2 b4 + b5)
+        const int kq = 2 * ((lane >> 4) & 1) + (lane >> 5);
 #pragma unroll
-    for (int k = 0; k < 27; k++) {
-        const double sv = wsum(acc[k]);
-        if (lane == 0) sAcc[wv][k] = sv;
+        for (int q = 0; q < 7; q++)
+            if ((lane & 15) == 0 && 4 * q + kq < 27) sAcc[wv][4 * q + kq] = rs[q];
     }
     __syncthreads();
     if (tid < 27) {
@@ -2049,7 +2115,7 @@ __global__ __launch_bounds__(kWPt * kUpdLanes) void k_w_update(const LbaProblem*
 #pragma unroll
             for (int j = 0; j < 3; j++) {
 #pragma unroll
-                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += __shfl_xor(dl[j], d, 64);
+                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += d == 1 ? lane_xor1(dl[j]) : (d == 2 ? lane_xor2(dl[j]) : __shfl_xor(dl[j], d, 64));
                 cl[j] -= dl[j];
             }
         } else if (ok2) {
@@ -2075,7 +2141,7 @@ __global__ __launch_bounds__(kWPt * kUpdLanes) void k_w_update(const LbaProblem*
 #pragma unroll
             for (int j = 0; j < 3; j++) {
 #pragma unroll
-                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += __shfl_xor(dl[j], d, 64);
+                for (int d = 1; d < kUpdLanes; d <<= 1) dl[j] += d == 1 ? lane_xor1(dl[j]) : (d == 2 ? lane_xor2(dl[j]) : __shfl_xor(dl[j], d, 64));
                 cl[j] -= dl[j];
             }
         }
