@@ -1778,6 +1778,9 @@ __device__ __forceinline__ bool chol16_aug(double (&R)[8], int lane) {
     const int h = lane >> 5, c = lane & 31;
     bool good = true;
     double rowc = 0, dc = 0, uc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // (The lane exchanges stay on ds_bpermute.  A form that keeps them in the vector ALU — v_permlane32_swap for the row, v_permlane16_swap + DPP row_newbcast for the
+    // U(j, i) — was built and measured: 25.4 -> 27.9 us of factor time per launch.  One wavefront issues an fp64 instruction every ~10 cycles (tools/mfma_f64_rate.py:
+    // 31.6 of 78.6 TFLOP/s at one wavefront per SIMD), the factor is bound by exactly that, and the LDS crossbar works beside the vector ALU, not instead of it.)
     auto request = [&](int j, double& row, double (&u)[8], double& d) __attribute__((always_inline)) {
         const int sj = j >> 1, hj = j & 1;
         row = bperm_f64((hj * 32 + c) * 4, R[sj]);                                 // row j at my column
@@ -1786,16 +1789,20 @@ __device__ __forceinline__ bool chol16_aug(double (&R)[8], int lane) {
             if (2 * sI + 1 > j) u[sI] = bperm_f64((hj * 32 + 2 * sI + h) * 4, R[sj]);   // U(j, i) for my rows i = 2 s + h > j
         d = rl_f64(R[sj], hj * 32 + j);
     };
-    auto update = [&](int j, int sI, double rd) __attribute__((always_inline)) {
-        if (2 * sI > j) R[sI] = __builtin_fma(-(uc[sI] * rd), rowc, R[sI]);                 // both parities below row j
-        else if (h == 1) R[sI] = __builtin_fma(-(uc[sI] * rd), rowc, R[sI]);                // 2 s == j: only row 2 s + 1
+    // (rows is the pivot row times -1 / d: one multiply per step instead of one per updated row)
+    auto update = [&](int j, int sI, double rows) __attribute__((always_inline)) {
+        if (2 * sI > j) R[sI] = __builtin_fma(uc[sI], rows, R[sI]);                 // both parities below row j
+        else if (h == 1) R[sI] = __builtin_fma(uc[sI], rows, R[sI]);                // 2 s == j: only row 2 s + 1
     };
     request(0, rowc, uc, dc);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int sj = j >> 1, hj = j & 1;
-        good = good && (dc > 0) && (dc < 1.7e308);
-        const double rd = rcp_nr2(dc);
+        good = good && __builtin_amdgcn_class(dc, 0x180);   // positive and finite (normal or subnormal): one compare
+        // the step's fp64 instructions are what bounds the factor (one wavefront): 1 / sqrt(d) by rsq + two Newton steps, 1 / d as its square (no second chain),
+        // the pivot row scaled once
+        const double r = rsqrt_nr(dc);
+        const double rd = -(r * r) * rowc;
         const int sn = (j + 1) >> 1;   // the register of row j + 1
         double rown = 0, dn = 0, un[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (j + 1 < 16) {
@@ -1809,7 +1816,6 @@ __device__ __forceinline__ bool chol16_aug(double (&R)[8], int lane) {
             if (2 * sI + 1 < j + 1 || (j + 1 < 16 && sI == sn)) continue;   // rows <= j; the register done above
             update(j, sI, rd);
         }
-        const double r = rsqrt_nr(dc);
         if (h == hj) R[sj] = rowc * r;   // row j is final: U(j, .) | U^-T(j, .)
         if (j + 1 < 16) {
             rowc = rown; dc = dn;
