@@ -27,6 +27,7 @@
 
 #include "common.h"
 #include "se3_math.h"
+#include "lane_ops.h"
 #include "slam_pool.h"
 
 namespace oslam {
@@ -85,49 +86,7 @@ struct LbaShared {
     int stopflag;
 };
 
-// ---- wavefront reductions without the LDS crossbar (round 5, second pass) ----
-// __shfl_xor of a double is two ds_bpermute_b32: the 27 sums of a keyframe block of k_w_lin were 324 of them per wavefront, sixteen wavefronts of a CU queueing
-// at one LDS pipe.  gfx950 can exchange lanes in the vector ALU: v_permlane32_swap / v_permlane16_swap (halves / odd-even rows of 16 between two registers),
-// DPP row_ror:8 and quad_perm; only lane ^ 4 still goes through ds_swizzle.  Every function below forms the sums of the xor butterfly d = 32, 16, 8, 4, 2, 1
-// with the same operand pairs (a + b against b + a at most): bit-identical results.
-typedef unsigned int oslam_u2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double f64_from(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
-__device__ __forceinline__ unsigned f64_lo(double v) { return (unsigned)(unsigned long long)__double_as_longlong(v); }
-__device__ __forceinline__ unsigned f64_hi(double v) { return (unsigned)((unsigned long long)__double_as_longlong(v) >> 32); }
-// a's upper 32 lanes <-> b's lower 32 lanes
-__device__ __forceinline__ void swap32_f64(double& a, double& b) {
-    const oslam_u2 l = __builtin_amdgcn_permlane32_swap(f64_lo(a), f64_lo(b), false, false);
-    const oslam_u2 h = __builtin_amdgcn_permlane32_swap(f64_hi(a), f64_hi(b), false, false);
-    a = f64_from(l[0], h[0]); b = f64_from(l[1], h[1]);
-}
-// a's rows 1, 3 (of 16 lanes) <-> b's rows 0, 2
-__device__ __forceinline__ void swap16_f64(double& a, double& b) {
-    const oslam_u2 l = __builtin_amdgcn_permlane16_swap(f64_lo(a), f64_lo(b), false, false);
-    const oslam_u2 h = __builtin_amdgcn_permlane16_swap(f64_hi(a), f64_hi(b), false, false);
-    a = f64_from(l[0], h[0]); b = f64_from(l[1], h[1]);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v) {   // (all lanes valid for the controls used here: quad_perm, row_ror)
-    return f64_from((unsigned)__builtin_amdgcn_mov_dpp((int)f64_lo(v), CTRL, 0xf, 0xf, true), (unsigned)__builtin_amdgcn_mov_dpp((int)f64_hi(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ double lane_xor8(double v) { return dpp_mov_f64<0x128>(v); }   // row_ror:8
-__device__ __forceinline__ double lane_xor4(double v) {                                     // swizzle(SWAP, 4)
-    return f64_from((unsigned)__builtin_amdgcn_ds_swizzle((int)f64_lo(v), 0x101F), (unsigned)__builtin_amdgcn_ds_swizzle((int)f64_hi(v), 0x101F));
-}
-__device__ __forceinline__ double lane_xor2(double v) { return dpp_mov_f64<0x4E>(v); }    // quad_perm [2,3,0,1]
-__device__ __forceinline__ double lane_xor1(double v) { return dpp_mov_f64<0xB1>(v); }    // quad_perm [1,0,3,2]
-// the last four butterfly steps (inside a row of 16 lanes)
-__device__ __forceinline__ double row16_sum(double v) { v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v); return v; }
-
-__device__ __forceinline__ double wsum(double v) {
-    double a = v, b = v;
-    swap32_f64(a, b);   // a = [lower half | lower half], b = [upper half | upper half]
-    v = a + b;
-    a = v; b = v;
-    swap16_f64(a, b);   // a = [row 0, row 0, row 2, row 2], b = [row 1, row 1, row 3, row 3]
-    v = a + b;
-    return row16_sum(v);
-}
+__device__ __forceinline__ double wsum(double v) { return wave_sum_xor(v); }   // (lane_ops.h: the xor butterfly without the LDS crossbar)
 __device__ __forceinline__ double wmax(double v) {
     double a = v, b = v;
     swap32_f64(a, b);
@@ -2220,8 +2179,8 @@ __global__ __launch_bounds__(kWPt * kUpdLanes) void k_w_update(const LbaProblem*
 __device__ double* g_lba_trace = nullptr;
 __device__ int g_lba_trace_cap = 0;
 
-__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) {
-    LbaCtrl* ct = w.ct;
+// (ct: the window's control block or a register copy of it; pF / pS: the trial's partial sums, in global memory or staged)
+__device__ __forceinline__ void w_ctrlB_impl(const LbaProblem& pr, const LbaWide& w, int win, LbaCtrl* ct, const double* pF, const double* pS) {
     if (ct->need_lin) {   // pair-gather path: w_ctrlA's step was left to k_w_edgeW (values) and to this commit (state); the tiles path ran k_w_ctrlA: need_lin is 0
         ct->currentChi = ct->FA;
         if (ct->iter == 0) { ct->lambda = ct->lambdaA; ct->ni = 2; }
@@ -2229,8 +2188,8 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) {
         ct->qmax = 0;
     }
     double F1 = 0, sc = 0;
-    for (int i = 0; i < w.nblk_pt; i++) { F1 += w.partF[i]; sc += w.partS[i]; }
-    sc += w.partS[w.nblk_pt];
+    for (int i = 0; i < w.nblk_pt; i++) { F1 += pF[i]; sc += pS[i]; }
+    sc += pS[w.nblk_pt];
     double tempChi = F1;
     if (!ct->ok2) tempChi = 1.7976931348623157e308;
     const double rho = (ct->currentChi - tempChi) / (sc + 1e-3);
@@ -2256,11 +2215,11 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) {
     }
     ct->rho = rho;
     ct->qmax++;
-    ct->trials[ct->stage]++;
+    if (ct->stage == 0) ct->trials[0]++; else ct->trials[1]++;   // (constant indices: a register copy of the block stays in registers)
     const bool stop = pr.stop ? (*pr.stop != 0) : false;
     if (rho < 0 && ct->qmax < 10 && !stop) return;   // another trial with the new lambda
     // iteration finished
-    ct->its[ct->stage]++;
+    if (ct->stage == 0) ct->its[0]++; else ct->its[1]++;
     if (ct->qmax == 10 || rho == 0) ct->ok = 0;
     ct->iter++;
     const int iters = ct->stage == 0 ? pr.iters0 : pr.iters1;
@@ -2276,6 +2235,8 @@ __device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) {
     }
 }
 
+__device__ void w_ctrlB(const LbaProblem& pr, const LbaWide& w, int win) { w_ctrlB_impl(pr, w, win, w.ct, w.partF, w.partS); }
+
 __global__ __launch_bounds__(64) void k_w_ctrlA(const LbaProblem* probs, const LbaWide* ws) {
     const LbaProblem& pr = probs[blockIdx.y];
     const LbaWide& w = ws[blockIdx.y];
@@ -2289,6 +2250,8 @@ __global__ __launch_bounds__(256) void k_w_ctrlB(const LbaProblem* probs, const 
     const LbaWide& w = ws[blockIdx.y];
     if (w.ct->done) return;
     __shared__ int s_gate;
+    // (Measured and not kept: the trial's partial sums staged through LDS by the whole workgroup and the control block worked on in registers — 9.6 -> 12.3 us per
+    // launch of 40 windows, 10.5 -> 18.5 us at 128: the step is short next to two more barriers and 256 busy threads per window.)
     if (threadIdx.x == 0) {
         w_ctrlB(pr, w, blockIdx.y);
         s_gate = w.ct->gate && !w.ct->done;

@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "se3_math.h"
+#include "lane_ops.h"
 
 namespace oslam {
 
@@ -58,11 +59,7 @@ struct PoseCtx {
     SemCtx sem;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_xor(v); }   // (lane_ops.h: same operand pairs as the __shfl_xor butterfly, no LDS crossbar)
 
 // Block-wide sums of NV doubles; every thread returns the same totals (fixed summation order).
 template <int NV>
@@ -201,7 +198,7 @@ __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_par
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < kSumN; i++) {
-        const double s = v[i] + __shfl_xor(v[i], 1, 64);
+        const double s = v[i] + lane_xor1(v[i]);   // (DPP quad_perm instead of two ds_bpermute per value)
         if (!(tid & 1)) s_part[i * kSumPitch + (tid >> 1)] = s;
     }
     __syncthreads();
@@ -211,7 +208,7 @@ __device__ __forceinline__ void block_sum_wide(double (&v)[kRedN], double* s_par
 #pragma unroll
         for (int k = 1; k < kSumCols / kSumLanes; k++) s += row[kSumLanes * k];
 #pragma unroll
-        for (int d = 1; d < kSumLanes; d <<= 1) s += __shfl_xor(s, d, 64);
+        for (int d = 1; d < kSumLanes; d <<= 1) s += d == 1 ? lane_xor1(s) : (d == 2 ? lane_xor2(s) : __shfl_xor(s, d, 64));
         if ((tid % kSumLanes) == 0) s_tot[tid / kSumLanes] = s;
     }
     __syncthreads();   // the totals are in s_tot: the callers read what they need (H is only needed by the wavefront that solves)
