@@ -38,6 +38,45 @@ __device__ __forceinline__ double lane_xor1(double v) { return dpp_mov_f64<0xB1>
 // the last four butterfly steps (inside a row of 16 lanes)
 __device__ __forceinline__ double row16_sum(double v) { v += lane_xor8(v); v += lane_xor4(v); v += lane_xor2(v); v += lane_xor1(v); return v; }
 
+// ---- 32-bit integers (sums are exact: any order) ----
+__device__ __forceinline__ void swap32_i32(int& a, int& b) {
+    const oslam_u2 r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    a = (int)r[0]; b = (int)r[1];
+}
+__device__ __forceinline__ void swap16_i32(int& a, int& b) {
+    const oslam_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    a = (int)r[0]; b = (int)r[1];
+}
+__device__ __forceinline__ int row16_sum_i32(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0x128, 0xf, 0xf, true);    // row_ror:8
+    v += __builtin_amdgcn_ds_swizzle(v, 0x101F);                // lane ^ 4
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);     // lane ^ 2
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);     // lane ^ 1
+    return v;
+}
+// Sums over the wavefront of N ints at once (the paired first steps of wsum_rows): out[q], in every lane of row (b5, b4), = the sum of value 4 q + 2 b4 + b5;
+// wave_sums_get(out, k) hands value k to every lane.
+template <int N>
+__device__ __forceinline__ void wave_sums_i32(const int (&in)[N], int (&out)[(N + 3) / 4]) {
+    constexpr int N2 = (N + 1) / 2, N4 = (N + 3) / 4;
+    int r1[2 * N4];
+#pragma unroll
+    for (int q = 0; q < 2 * N4; q++) {
+        int a = 2 * q < N ? in[2 * q] : 0, b = 2 * q + 1 < N ? in[2 * q + 1] : 0;
+        if (q < N2) { swap32_i32(a, b); r1[q] = a + b; } else r1[q] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < N4; q++) {
+        int a = r1[2 * q], b = r1[2 * q + 1];
+        swap16_i32(a, b);
+        out[q] = row16_sum_i32(a + b);
+    }
+}
+template <int N4>
+__device__ __forceinline__ int wave_sums_get(const int (&out)[N4], int k) {   // k: compile-time constant after unrolling
+    return __builtin_amdgcn_readlane(out[k >> 2], 32 * (k & 1) + 16 * ((k >> 1) & 1));
+}
+
 // sum over the wavefront, every lane gets it: the xor butterfly d = 32, 16, 8, 4, 2, 1 (same operand pairs as the __shfl_xor loop it replaces)
 __device__ __forceinline__ double wave_sum_xor(double v) {
     double a = v, b = v;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "lane_ops.h"
 
 namespace oslam {
 
@@ -239,14 +240,21 @@ __global__ __launch_bounds__(256) void k_stereo_sad(StereoCtx c, int ncap) {
         int bestDist = 0x7fffffff, bestinc = 0;
         float d_m1 = 0, d_0 = 0, d_p1 = 0;
         float vd[11];
+        {   // the 11 SADs: lane partials, then all 11 wavefront sums at once in the vector ALU (lane_ops.h; 66 ds_bpermute before)
+            int part[11], sums[3];
 #pragma unroll
-        for (int inc = -5; inc <= 5; inc++) {
-            int s = abs(lv0 - (r0[inc + 5] - rc[inc + 5]));
-            if (has1) s += abs(lv1 - (r1[inc + 5] - rc[inc + 5]));
+            for (int inc = -5; inc <= 5; inc++) {
+                int s = abs(lv0 - (r0[inc + 5] - rc[inc + 5]));
+                if (has1) s += abs(lv1 - (r1[inc + 5] - rc[inc + 5]));
+                part[inc + 5] = s;
+            }
+            wave_sums_i32<11>(part, sums);
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            vd[inc + 5] = (float)s;
-            if ((float)s < (float)bestDist) { bestDist = s; bestinc = inc; }
+            for (int inc = -5; inc <= 5; inc++) {
+                const int s = wave_sums_get<3>(sums, inc + 5);
+                vd[inc + 5] = (float)s;
+                if ((float)s < (float)bestDist) { bestDist = s; bestinc = inc; }
+            }
         }
         if (bestinc == -L || bestinc == L) return;
 #pragma unroll
