@@ -505,10 +505,17 @@ int oslam_orb_create(oslam_orb_t** out, int nfeatures, float scaleFactor_, int n
     ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
     ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree_spill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
     ORB_CREATE_CHECK(hipFuncSetAttribute((const void*)k_octree_hbm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->oct_lds));
-    {   // the blur stream runs at the lowest priority: FAST, the overflow cells and the quad-tree on the caller's stream are dispatched first
+    {   // The blur runs on a side stream of ORDINARY priority.  Rounds 2-5 created it with the lowest priority (FAST, the overflow cells and the quad-tree on the
+        // caller's stream dispatched first).  In the batch-of-sequences driver that starves it: with eight handles on the card there is almost always ordinary-priority
+        // work of another handle to dispatch, the blur — and with it the frame's descriptor kernel and the whole Frame::Frame stage — waits for gaps, and the stereo
+        // workload (two extractions per frame) fell into phases of 10-30x its Frame::Frame time in 6 of 9 runs on fresh boxes (2.3-4.0 k instead of 22-24 k frames/s;
+        // tools/gpu/r5b_stereo_queues.sh).  Ordinary priority: 3 of 3 stereo runs at 22.4-23.3 k, the RGB-D headline 41.2-41.9 k against 41.0 k (same box).
+        // OSLAM_ORB_SIDE_PRIORITY=low restores the lowest priority (A/B knob).
         int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least) != hipSuccess) {
-            (void)hipGetLastError();   // no stream priorities here: an ordinary side stream still overlaps the blur
+        const char* spe = getenv("OSLAM_ORB_SIDE_PRIORITY");
+        const bool low = spe && !strcmp(spe, "low");
+        if (!low || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
             h->side_stream = nullptr;
             ORB_CREATE_CHECK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         }
