@@ -1269,14 +1269,17 @@ struct LbaService {
                 for (int i = 0; i < std::min(cus, total); i++) mask[i >> 5] |= 1u << (i & 31);
                 OSLAM_HIP_CHECK(hipExtStreamCreateWithCUMask(&wk->strm, (uint32_t)mask.size(), mask.data()));
                 oslam::lba_use_stream(wk->ba, wk->strm);
-            } else if (!getenv("OSLAM_LBA_SERVICE_NO_PRIORITY")) {
-                // the service is off every handle's critical path: its streams get the LOWEST priority, so that the handles' short tracking / mapping kernels are
-                // dispatched ahead of the queued local-BA launches
-                int lo = 0, hi = 0;
-                OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = numerically greatest = lowest priority)
-                const char* pe = getenv("OSLAM_LBA_SERVICE_PRIORITY");   // A/B knob: "high" = the greatest priority (measured: DESIGN.md section 7.2)
-                OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, pe && !strcmp(pe, "high") ? hi : lo));
-                oslam::lba_use_stream(wk->ba, wk->strm);
+            } else if (const char* pe = getenv("OSLAM_LBA_SERVICE_PRIORITY")) {
+                // Rounds 4-5 gave the service's streams the LOWEST priority (the handles' short tracking / mapping kernels dispatched ahead of the queued local-BA
+                // launches).  Since the end of round 5 they are ordinary streams (the solver handle's own): same frames/s (41.10 / 41.17 k against 41.13 k, same box,
+                // alternating), 6.5 % less local-BA device time (roofline.frac 0.056 against 0.052), and no stream of the rank left that the other streams' work can
+                // starve ("A starved side stream").  OSLAM_LBA_SERVICE_PRIORITY=low / high are the A/B knobs (section 7.2).
+                if (!strcmp(pe, "low") || !strcmp(pe, "high")) {
+                    int lo = 0, hi = 0;
+                    OSLAM_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // (lo = numerically greatest = lowest priority)
+                    OSLAM_HIP_CHECK(hipStreamCreateWithPriority(&wk->strm, hipStreamNonBlocking, !strcmp(pe, "high") ? hi : lo));
+                    oslam::lba_use_stream(wk->ba, wk->strm);
+                }
             }
             if (!getenv("OSLAM_LBA_SERVICE_OVERLAP")) oslam::lba_use_gate(wk->ba, &launch_mu);
             workers.push_back(std::move(wk));

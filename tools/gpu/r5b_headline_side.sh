@@ -13,6 +13,6 @@ try:
 except Exception as e: print("$tag no line", e, flush=True)
 PY
 }
-run normal_a OSLAM_ORB_SIDE_PRIORITY=normal
-run low_a OSLAM_X=0
-run normal_b OSLAM_ORB_SIDE_PRIORITY=normal
+run svc_normal_a OSLAM_LBA_SERVICE_NO_PRIORITY=1
+run svc_low_a OSLAM_X=0
+run svc_normal_b OSLAM_LBA_SERVICE_NO_PRIORITY=1
