@@ -14,7 +14,7 @@ try:
 except Exception as e: print("$tag no line", e, flush=True)
 PY
 }
-run sn_a OSLAM_ORB_SIDE_PRIORITY=normal
-run sn_b OSLAM_ORB_SIDE_PRIORITY=normal
-run sn_c OSLAM_ORB_SIDE_PRIORITY=normal
-run q12_c OSLAM_X=0
+run svcdef_a OSLAM_X=0
+run svclow_a OSLAM_LBA_SERVICE_PRIORITY=low
+run svcdef_b OSLAM_X=0
+run svclow_b OSLAM_LBA_SERVICE_PRIORITY=low
