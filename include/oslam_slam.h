@@ -439,6 +439,10 @@ int oslam_slam_stage_seconds(oslam_slam_t* h, double out[16]);
 /* Core-seconds of the same stages: CPU time of the stepping thread plus the time the shared workers spent on its parallel sections (for the device
  * stages [0]-[3], [5], [6], [8] this is the host side of the operator: packing, launches, polling). */
 int oslam_slam_stage_cpu_seconds(oslam_slam_t* h, double out[16]);
+/* sizeof of the structs that cross this boundary, as THIS library was compiled: [0] oslam_slam_config_t, [1] oslam_slam_ops_t, [2] oslam_slam_objects_t,
+ * [3] oslam_map_changes_t.  A binding in another language mirrors these structs by hand (object_slam_amd/slam.py does): it compares its own sizes with these before
+ * the first call — a mirror of oslam_slam_ops_t that misses the members added later is a buffer overflow on both sides of the table. */
+int oslam_slam_struct_sizes(int32_t out[4]);
 /* out[0] = tracked frames whose local map (mvpLocalMapPoints and the packed SearchLocalPoints arrays) was reused from the previous frame because neither
  * the ordered local keyframe list nor the sequence's map had changed, out[1] = all tracked frames; summed over the sequences of the handle. */
 int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]);

@@ -2714,6 +2714,12 @@ int oslam_slam_local_map_reuse(oslam_slam_t* h, int64_t out[2]) {
     return OSLAM_OK;
 }
 
+int oslam_slam_struct_sizes(int32_t out[4]) {
+    if (!out) return OSLAM_E_INVALID;
+    out[0] = (int32_t)sizeof(oslam_slam_config_t); out[1] = (int32_t)sizeof(oslam_slam_ops_t); out[2] = (int32_t)sizeof(oslam_slam_objects_t); out[3] = (int32_t)sizeof(oslam_map_changes_t);
+    return OSLAM_OK;
+}
+
 int oslam_slam_stage_cpu_seconds(oslam_slam_t* h, double out[16]) {
     if (!h || !out) { oslam::set_error("oslam_slam_stage_cpu_seconds: bad argument"); return OSLAM_E_INVALID; }
     memcpy(out, h->c.cpu, sizeof(h->c.cpu));

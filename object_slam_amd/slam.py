@@ -22,7 +22,24 @@ class SlamConfig(C.Structure):
 class SlamOps(C.Structure):
     _fields_ = [("ctx", C.c_void_p)] + [(n, C.c_void_p) for n in (
         "max_keypoints", "scale_tables", "image_bounds", "frames_rgbd", "search_last", "search_local", "pose_opt", "mp_update", "lba", "fuse", "bow",
-        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes", "lba_submit", "lba_wait", "mp_update_windows")]
+        "triangulate", "destroy", "frames_stereo", "object_kps", "pose_opt2", "register_keyframes", "bow_keyed", "fuse_keyed", "mp_update_keyed", "kernel_times", "bow_nodes_keyed", "resident_points", "fuse_points_keyed", "point_record", "frames_rgbd_raw16", "release_keyframes", "lba_submit", "lba_wait", "mp_update_windows",
+        # round 5 (include/oslam_slam.h): the mirror of the observation graph, arrays on demand, deferred descriptor updates
+        "map_journal", "kf_culling_counts", "kf_culling_collect", "fuse_into_current", "local_points_list", "keyframe_raw_keys", "keyframe_descriptors", "frame_descriptors",
+        "mp_update_keyed_async", "mp_update_collect")]
+
+
+def _check_struct_sizes(L):
+    """The structs above are hand-written mirrors of include/oslam_slam.h: compare their sizes with the library's own before the first call (a short SlamOps was a
+    silent 80-byte overflow of every operator table handed to oslam_slam_create_with_ops until the end of round 5)."""
+    if getattr(L, "_oslam_slam_sizes_ok", False):
+        return
+    out = (C.c_int32 * 4)()
+    check(L.oslam_slam_struct_sizes(out))
+    mine = (C.sizeof(SlamConfig), C.sizeof(SlamOps), C.sizeof(SlamObjects))
+    if tuple(out[:3]) != mine:
+        raise RuntimeError("object_slam_amd/slam.py mirrors include/oslam_slam.h with other struct sizes than the library was built with: config / ops / objects %s here, %s there"
+                           % (mine, tuple(out[:3])))
+    L._oslam_slam_sizes_ok = True
 
 
 class SlamObjects(C.Structure):
@@ -58,6 +75,7 @@ def make_config(width, height, n_sequences, cam=TUM2, dist=None, nFeatures=1000,
 class System:
     def __init__(self, cfg, ops=None):
         self.L = lib()
+        _check_struct_sizes(self.L)
         self.cfg = cfg
         self.S = cfg.n_sequences
         self.h = C.c_void_p()
